@@ -1,0 +1,209 @@
+/* pgo.h — C ABI of the MI355X-native pose-graph nonlinear-least-squares core (libpgo_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of TurtleZhong/PoseGraph-Ceres: the solve that
+ * src/POSE_GRAPH_CERES_PLUS/test/pose_graph_ceres_plus_finial.cpp hands to Ceres.  The reference
+ * reaches that path through the Ceres C++ API (9 imported symbols); the header-only
+ * facade in include/ceres/ maps those C++ calls 1:1 onto the entry points below, and any other host
+ * language binds them directly (plain pointers and sizes, no C++ or torch types).  Each entry point
+ * cites the reference interface it replaces (REF = src/POSE_GRAPH_CERES_PLUS).
+ *
+ * Conventions
+ *   - every function returns PGO_OK (0) or a negative pgo_status; pgo_last_error() has the text.
+ *     Nothing aborts or throws across this boundary (Ceres itself CHECK-aborts on API misuse).
+ *   - quaternions are Hamilton, stored x,y,z,w (Eigen coeffs() order, REF/include/types.h:15-20).
+ *   - the compute path is HIP on gfx950 only.  There is no CPU fallback: without a usable GPU
+ *     pgo_solve / pgo_evaluate return PGO_ERR_NO_DEVICE.
+ */
+#ifndef PGO_H_
+#define PGO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGO_VERSION 100
+
+typedef struct pgo_problem pgo_problem;
+
+typedef enum pgo_status {
+  PGO_OK = 0,
+  PGO_ERR_INVALID_ARGUMENT = -1,
+  PGO_ERR_NO_DEVICE = -2,
+  PGO_ERR_HIP = -3,
+  PGO_ERR_UNSUPPORTED = -4,
+  PGO_ERR_NUMERICAL = -5
+} pgo_status;
+
+/* ceres::LossFunction kinds (REF/test/pose_graph_ceres_plus_finial.cpp:495 uses HuberLoss(1.0)). */
+typedef enum pgo_loss_kind { PGO_LOSS_TRIVIAL = 0, PGO_LOSS_HUBER = 1 } pgo_loss_kind;
+
+/* ceres::LinearSolverType values the path understands (finial.cpp:536 sets SPARSE_NORMAL_CHOLESKY). */
+typedef enum pgo_linear_solver {
+  PGO_SPARSE_NORMAL_CHOLESKY = 0, /* exact solve of the LM system */
+  PGO_BLOCK_JACOBI_PCG = 1        /* Ceres CGNR + JACOBI analogue: truncated PCG, Q-tolerance eta */
+} pgo_linear_solver;
+
+/* ceres::TerminationType */
+typedef enum pgo_termination { PGO_CONVERGENCE = 0, PGO_NO_CONVERGENCE = 1, PGO_FAILURE = 2 } pgo_termination;
+
+/* ceres::Solver::Options — the fields the path reads; defaults are the Ceres 1.13.0 defaults
+ * recovered from the reference binary. */
+typedef struct pgo_solver_options {
+  int max_num_iterations;                 /* 50   (finial.cpp:535 sets 1000) */
+  int linear_solver_type;                 /* pgo_linear_solver, default PGO_SPARSE_NORMAL_CHOLESKY */
+  int jacobi_scaling;                     /* 1 */
+  int max_linear_solver_iterations;       /* 500 */
+  int min_linear_solver_iterations;       /* 0 */
+  int max_num_consecutive_invalid_steps;  /* 5 */
+  int cg_batch;                           /* CG iterations enqueued per host check (0 = auto) */
+  int reserved0;
+  double function_tolerance;              /* 1e-6 */
+  double gradient_tolerance;              /* 1e-10 */
+  double parameter_tolerance;             /* 1e-8 */
+  double initial_trust_region_radius;     /* 1e4 */
+  double max_trust_region_radius;         /* 1e16 */
+  double min_trust_region_radius;         /* 1e-32 */
+  double min_relative_decrease;           /* 1e-3 */
+  double min_lm_diagonal;                 /* 1e-6 */
+  double max_lm_diagonal;                 /* 1e32 */
+  double eta;                             /* 0.1 */
+  double exact_r_tolerance;               /* relative residual of the exact path when it is iterative, 1e-13 */
+} pgo_solver_options;
+
+/* ceres::Solver::Summary — the fields the path fills (finial.cpp:538-543). */
+typedef struct pgo_solver_summary {
+  int termination_type;         /* pgo_termination */
+  int num_successful_steps;
+  int num_unsuccessful_steps;
+  int num_iterations;           /* iteration records, iteration 0 included */
+  int num_linear_solver_iterations;
+  int num_poses;
+  int num_edges;
+  int reason;                   /* 1 function tol, 2 parameter tol, 3 gradient tol, 4 min radius, 5 max iterations,
+                                   6 invalid steps, 7 linear solver failure */
+  double initial_cost;
+  double final_cost;
+  double total_time_in_seconds;
+  double setup_time_in_seconds;          /* topology build + upload */
+  double linear_solver_time_in_seconds;
+  double jacobian_evaluation_time_in_seconds;
+  double residual_evaluation_time_in_seconds;
+  double final_gradient_max_norm;
+  double final_trust_region_radius;
+  char message[256];
+} pgo_solver_summary;
+
+/* One row per iteration, the numbers Summary::FullReport() tabulates with
+ * minimizer_progress_to_stdout. */
+typedef struct pgo_iteration_record {
+  int iteration;
+  int step_is_successful;
+  int linear_solver_iterations;
+  int reserved;
+  double cost;
+  double cost_change;
+  double gradient_max_norm;
+  double step_norm;
+  double relative_decrease;
+  double trust_region_radius;
+} pgo_iteration_record;
+
+/* ---- library ---- */
+int pgo_version(void);
+const char* pgo_last_error(void);
+/* number of HIP devices visible (0 on a CPU-only host; never an error) */
+int pgo_device_count(void);
+/* binds the calling process to a device (one process per GPU); default device 0 */
+int pgo_set_device(int device);
+
+/* ---- problem construction: ceres::Problem (finial.cpp:58, 491-528) ---- */
+pgo_problem* pgo_problem_create(void);                  /* ceres::Problem::Problem()  */
+void pgo_problem_destroy(pgo_problem* problem);         /* ceres::Problem::~Problem() */
+
+/* Declares a pose whose translation lives at p[3] and quaternion at q[4] in CALLER memory; both are
+ * updated in place by pgo_solve, exactly like the parameter blocks handed to
+ * Problem::AddResidualBlock (finial.cpp:513-517).  Identity is the pointer value: re-adding the same
+ * (p,q) pair returns the existing index.  Returns the pose index (>= 0) or a negative status. */
+int pgo_problem_add_pose(pgo_problem* problem, double* p, double* q);
+/* n poses laid out at base + i*stride_doubles: p = 3 doubles, q = the 4 doubles after them.
+ * Returns the index of the first pose. */
+int pgo_problem_add_poses(pgo_problem* problem, int n, double* base, int stride_doubles);
+
+/* PoseGraph3dErrorTerm::Create(t_be, sqrt_information) + Problem::AddResidualBlock(cost, loss,
+ * p_begin, q_begin, p_end, q_end) + SetParameterization(q, EigenQuaternionParameterization)
+ * (REF/include/PoseGraph3dError.h:56-61, finial.cpp:508-522).  sqrt_information is the 6x6 row-major
+ * matrix applied on the LEFT of the residual (the lower Cholesky factor of the information matrix);
+ * NULL means identity. Returns the edge index (>= 0) or a negative status. */
+int pgo_problem_add_se3_between(pgo_problem* problem, int pose_begin, int pose_end, const double* t_be_p,
+                                const double* t_be_q, const double* sqrt_information);
+/* batch form: begin/end [n], t_be [n][7] (p then q), sqrt_information [n][36] or NULL */
+int pgo_problem_add_se3_between_batch(pgo_problem* problem, int n, const int* pose_begin, const int* pose_end,
+                                      const double* t_be, const double* sqrt_information);
+
+/* the single LossFunction instance shared by every residual block (finial.cpp:495,513) */
+int pgo_problem_set_loss(pgo_problem* problem, int loss_kind, double loss_parameter);
+
+/* Problem::SetParameterBlockConstant (finial.cpp:525-527). which: 1 = translation, 2 = rotation, 3 = both */
+int pgo_problem_set_pose_constant(pgo_problem* problem, int pose, int which);
+/* same, addressed by the parameter-block pointer as Ceres does */
+int pgo_problem_set_parameter_block_constant(pgo_problem* problem, const double* block);
+
+int pgo_problem_num_poses(const pgo_problem* problem);
+int pgo_problem_num_edges(const pgo_problem* problem);
+
+/* ---- solve: ceres::Solve(options, problem, &summary) (finial.cpp:534-539) ---- */
+void pgo_solver_options_init(pgo_solver_options* options);
+/* Runs the Levenberg-Marquardt trust-region loop on the GPU and writes the result into the caller's
+ * p/q memory (also on NO_CONVERGENCE).  records (may be NULL) receives up to records_capacity rows. */
+int pgo_solve(pgo_problem* problem, const pgo_solver_options* options, pgo_solver_summary* summary,
+              pgo_iteration_record* records, int records_capacity);
+/* Summary::IsSolutionUsable (finial.cpp:543) */
+int pgo_summary_is_solution_usable(const pgo_solver_summary* summary);
+/* Summary::FullReport (finial.cpp:541): writes a NUL-terminated report, returns the length needed */
+size_t pgo_summary_full_report(const pgo_solver_summary* summary, const pgo_iteration_record* records,
+                               int num_records, char* buffer, size_t capacity);
+
+/* ---- evaluation at the current caller-side parameter values (ceres::Problem::Evaluate analogue;
+ * what ResidualBlock::Evaluate produces per block: loss-corrected residuals and local-tangent
+ * Jacobians, columns [dp(3) | dtheta(3)], constant blocks zeroed).  Any output may be NULL.
+ *   residuals [E][6], jacobian_begin/end [E][36] row-major, gradient [N][6] ---- */
+int pgo_evaluate(pgo_problem* problem, double* cost, double* residuals, double* jacobian_begin,
+                 double* jacobian_end, double* gradient);
+/* Gauss-Newton blocks of J'J at the current values, without Jacobi scaling or damping:
+ *   diag [N][36], offdiag [E][36] = J_begin' J_end per edge.  Any output may be NULL. */
+int pgo_normal_equations(pgo_problem* problem, double* diag, double* offdiag, double* gradient);
+/* Solves (J'J + diag(d2)) x = b on the GPU with the selected linear solver at the current values
+ * (solver-level parity tests).  d2, b, x are [N][6]; returns CG iterations through *iterations. */
+int pgo_linear_solve(pgo_problem* problem, const pgo_solver_options* options, const double* d2,
+                     const double* b, double* x, int* iterations);
+/* Plus: x_plus = x [+] delta for every pose (EigenQuaternionParameterization::Plus on q, p += dp),
+ * written back into the caller's p/q memory.  delta [N][6]. */
+int pgo_plus(pgo_problem* problem, const double* delta);
+
+/* ---- device-resident stepping for benchmarks: poses stay in HBM between calls ---- */
+int pgo_solver_begin(pgo_problem* problem, const pgo_solver_options* options);
+/* runs up to n LM iterations (successful or not); *done becomes 1 when a termination test fired */
+int pgo_solver_step(pgo_problem* problem, int n, int* done);
+/* restores the device state to the poses given at pgo_solver_begin (no host traffic) */
+int pgo_solver_reset(pgo_problem* problem);
+int pgo_solver_end(pgo_problem* problem, pgo_solver_summary* summary, pgo_iteration_record* records,
+                   int records_capacity);
+/* repeats one kernel of the path `repeats` times on the solver stream between two HIP events and
+ * returns the average milliseconds per launch.  kernel: "linearize", "spmv", "cost", "evaluate",
+ * "pcg_update". */
+int pgo_time_kernel(pgo_problem* problem, const char* kernel, int repeats, double* avg_ms);
+
+/* ---- one process per GPU: edge/row sharding over RCCL ---- */
+/* contiguous share [begin,end) of n units for `rank` of `world` (host-only helper, no GPU needed) */
+int pgo_shard_range(long long n, int rank, int world, long long* begin, long long* end);
+/* 128-byte RCCL unique id created on rank 0 and handed to every rank by the launcher */
+int pgo_comm_get_unique_id(unsigned char id[128]);
+int pgo_comm_init(pgo_problem* problem, const unsigned char id[128], int rank, int world);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGO_H_ */

@@ -1,0 +1,1147 @@
+// =============================================================================================
+// oracle/pgo_oracle.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement (plain C++17, no third-party code) of the pose-graph NLLS hot path of
+// TurtleZhong/PoseGraph-Ceres.  It is the *checker* for the HIP path: only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product library
+// (posegraph-ceres_amd/csrc) never includes, links or calls anything in this directory.
+//
+// PARITY UNPINNED: the reference holds no golden vector / known-answer test for this path and its
+// own implementation (Ceres 1.13.0 + Eigen + CHOLMOD, un-vendored) cannot be built in this image
+// (SURVEY.md §8c).  This oracle is therefore pinned only by (a) an independent numpy/scipy
+// restatement with finite differences (tests/test_oracle_numpy.py) and (b) the committed fixtures
+// under tests/golden/ that this file generated.
+//
+// What each part follows (REF = /root/reference/src/POSE_GRAPH_CERES_PLUS):
+//   * residual functor ............ REF/include/PoseGraph3dError.h:21-54 (templated operator())
+//   * AutoDiff<6,3,4,3,4> ......... REF/include/PoseGraph3dError.h:56-61 ; Jet<double,14>  [Ceres 1.13]
+//   * quaternion Plus + 4x3 Jac ... src/other_projects/bundle_adjustment/ceres_extensions.h:25-50
+//   * quaternion product .......... ceres_extensions.h:144-150 (== Eigen quat_product)
+//   * problem construction ........ REF/test/pose_graph_ceres_plus_finial.cpp:491-528
+//                                   (HuberLoss(1.0), L = information.llt().matrixL(), pose 0 const)
+//   * solver options .............. REF/test/pose_graph_ceres_plus_finial.cpp:531-544 + the Ceres
+//                                   1.13 defaults recovered from the binary
+//   * LM loop / Huber corrector / Jacobi scaling / termination: SURVEY.md Appendix A.4-A.6
+//     [Ceres 1.13 TrustRegionMinimizer + LevenbergMarquardtStrategy + ConjugateGradientsSolver]
+// =============================================================================================
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <queue>
+#include <set>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Forward-mode dual number, the role Jet<double,14> plays in Ceres' AutoDiffCostFunction.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct Jet {
+  double a;
+  double v[N];
+  Jet() : a(0) { for (int i = 0; i < N; ++i) v[i] = 0; }
+  Jet(double s) : a(s) { for (int i = 0; i < N; ++i) v[i] = 0; }  // NOLINT
+  Jet(double s, int k) : a(s) { for (int i = 0; i < N; ++i) v[i] = 0; v[k] = 1.0; }
+};
+template <int N> Jet<N> operator+(const Jet<N>& f, const Jet<N>& g) { Jet<N> h; h.a = f.a + g.a; for (int i = 0; i < N; ++i) h.v[i] = f.v[i] + g.v[i]; return h; }
+template <int N> Jet<N> operator-(const Jet<N>& f, const Jet<N>& g) { Jet<N> h; h.a = f.a - g.a; for (int i = 0; i < N; ++i) h.v[i] = f.v[i] - g.v[i]; return h; }
+template <int N> Jet<N> operator-(const Jet<N>& f) { Jet<N> h; h.a = -f.a; for (int i = 0; i < N; ++i) h.v[i] = -f.v[i]; return h; }
+template <int N> Jet<N> operator*(const Jet<N>& f, const Jet<N>& g) { Jet<N> h; h.a = f.a * g.a; for (int i = 0; i < N; ++i) h.v[i] = f.a * g.v[i] + f.v[i] * g.a; return h; }
+template <int N> Jet<N> operator*(double s, const Jet<N>& g) { Jet<N> h; h.a = s * g.a; for (int i = 0; i < N; ++i) h.v[i] = s * g.v[i]; return h; }
+template <int N> Jet<N> operator*(const Jet<N>& g, double s) { return s * g; }
+template <int N> Jet<N>& operator+=(Jet<N>& f, const Jet<N>& g) { f = f + g; return f; }
+
+// ---------------------------------------------------------------------------------------------
+// Eigen-equivalent quaternion helpers, coefficient order x,y,z,w (Eigen coeffs()).
+// ---------------------------------------------------------------------------------------------
+template <class T> struct Q4 { T x, y, z, w; };
+template <class T> struct V3 { T x, y, z; };
+
+template <class T> Q4<T> qconj(const Q4<T>& q) { return Q4<T>{-q.x, -q.y, -q.z, q.w}; }
+// Hamilton product a*b (Eigen quat_product / ceres_extensions.h:144-150).
+template <class T> Q4<T> qmul(const Q4<T>& a, const Q4<T>& b) {
+  Q4<T> r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  return r;
+}
+template <class T> V3<T> cross(const V3<T>& a, const V3<T>& b) {
+  return V3<T>{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// Eigen QuaternionBase::_transformVector: v + 2w(u x v) + 2 u x (u x v)   (no normalisation)
+template <class T> V3<T> qrot(const Q4<T>& q, const V3<T>& v) {
+  V3<T> u{q.x, q.y, q.z};
+  V3<T> uv = cross(u, v);
+  uv = V3<T>{uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
+  V3<T> c = cross(u, uv);
+  return V3<T>{v.x + q.w * uv.x + c.x, v.y + q.w * uv.y + c.y, v.z + q.w * uv.z + c.z};
+}
+
+// ---------------------------------------------------------------------------------------------
+// The residual functor.  REF/include/PoseGraph3dError.h:21-54, statement by statement.
+//   L is the 6x6 "sqrt_information" (row-major), applied on the left: r = L * e   (:51)
+// ---------------------------------------------------------------------------------------------
+template <class T>
+void functor(const double* mp, const double* mq, const double* L, const T* p_a, const T* q_a,
+             const T* p_b, const T* q_b, T* res) {
+  Q4<T> qa{q_a[0], q_a[1], q_a[2], q_a[3]};
+  Q4<T> qb{q_b[0], q_b[1], q_b[2], q_b[3]};
+  Q4<T> qa_inv = qconj(qa);                                       // :32
+  Q4<T> q_ab = qmul(qa_inv, qb);                                  // :33
+  V3<T> d{p_b[0] - p_a[0], p_b[1] - p_a[1], p_b[2] - p_a[2]};
+  V3<T> p_ab = qrot(qa_inv, d);                                   // :36
+  Q4<T> qm{T(mq[0]), T(mq[1]), T(mq[2]), T(mq[3])};
+  Q4<T> dq = qmul(qm, qconj(q_ab));                               // :39-40
+  T e[6] = {p_ab.x - T(mp[0]), p_ab.y - T(mp[1]), p_ab.z - T(mp[2]),   // :45-46
+            T(2.0) * dq.x, T(2.0) * dq.y, T(2.0) * dq.z};              // :47-48
+  for (int i = 0; i < 6; ++i) {                                   // :51 applyOnTheLeft(L)
+    T s = T(0.0);
+    for (int j = 0; j < 6; ++j) s = s + T(L[6 * i + j]) * e[j];
+    res[i] = s;
+  }
+}
+
+// EigenQuaternionParameterization::ComputeJacobian, ceres_extensions.h:44-50 (4x3 row-major).
+void quat_plus_jacobian(const double* x, double* J) {
+  J[0] = x[3];  J[1] = x[2];   J[2] = -x[1];
+  J[3] = -x[2]; J[4] = x[3];   J[5] = x[0];
+  J[6] = x[1];  J[7] = -x[0];  J[8] = x[3];
+  J[9] = -x[0]; J[10] = -x[1]; J[11] = -x[2];
+}
+// EigenQuaternionParameterization::Plus, ceres_extensions.h:25-42.
+void quat_plus(const double* x, const double* delta, double* out) {
+  const double n = std::sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
+  if (n > 0.0) {
+    const double s = std::sin(n) / n;
+    Q4<double> t{s * delta[0], s * delta[1], s * delta[2], std::cos(n)};
+    Q4<double> q{x[0], x[1], x[2], x[3]};
+    Q4<double> r = qmul(t, q);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+  } else {
+    out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3];
+  }
+}
+
+const double kIdentity6[36] = {1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0,
+                               0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1};
+
+// AutoDiffCostFunction<..,6,3,4,3,4>::Evaluate followed by the local-parameterization chain rule
+// Ceres applies in ResidualBlock::Evaluate: J_local = J_global(6x4) * PlusJacobian(4x3).
+// Outputs r[6], Ja[36], Jb[36] (row-major 6x6, columns = [dp(3) | dtheta(3)]), no loss applied.
+void edge_eval_autodiff(const double* pa, const double* qa, const double* pb, const double* qb,
+                        const double* mp, const double* mq, const double* L, double* r, double* Ja,
+                        double* Jb) {
+  typedef Jet<14> J14;
+  J14 jpa[3], jqa[4], jpb[3], jqb[4], res[6];
+  for (int i = 0; i < 3; ++i) jpa[i] = J14(pa[i], i);
+  for (int i = 0; i < 4; ++i) jqa[i] = J14(qa[i], 3 + i);
+  for (int i = 0; i < 3; ++i) jpb[i] = J14(pb[i], 7 + i);
+  for (int i = 0; i < 4; ++i) jqb[i] = J14(qb[i], 10 + i);
+  functor<J14>(mp, mq, L, jpa, jqa, jpb, jqb, res);
+  double PJa[12], PJb[12];
+  quat_plus_jacobian(qa, PJa);
+  quat_plus_jacobian(qb, PJb);
+  for (int i = 0; i < 6; ++i) {
+    r[i] = res[i].a;
+    for (int j = 0; j < 3; ++j) {
+      Ja[6 * i + j] = res[i].v[j];
+      Jb[6 * i + j] = res[i].v[7 + j];
+      double sa = 0, sb = 0;
+      for (int k = 0; k < 4; ++k) {
+        sa += res[i].v[3 + k] * PJa[3 * k + j];
+        sb += res[i].v[10 + k] * PJb[3 * k + j];
+      }
+      Ja[6 * i + 3 + j] = sa;
+      Jb[6 * i + 3 + j] = sb;
+    }
+  }
+}
+
+// Closed-form local Jacobians (generalised so that it equals the autodiff
+// chain for quaternions that are not exactly unit: the translation rows differentiate Eigen's
+// v + 2w(u x v) + 2u x (u x v) formula itself instead of assuming R(q) is orthonormal).
+void edge_eval_analytic(const double* pa, const double* qa, const double* pb, const double* qb,
+                        const double* mp, const double* mq, const double* L, double* r, double* Ja,
+                        double* Jb) {
+  // c = conj(q_a): vector part u, scalar w
+  const V3<double> u{-qa[0], -qa[1], -qa[2]};
+  const double w = qa[3];
+  const V3<double> d{pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+  // Rt = I + 2w[u]x + 2[u]x[u]x  (matrix of v -> qrot(conj(q_a), v))
+  double Rt[9];
+  {
+    const double ux[9] = {0, -u.z, u.y, u.z, 0, -u.x, -u.y, u.x, 0};
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double uu = 0;
+        for (int k = 0; k < 3; ++k) uu += ux[3 * i + k] * ux[3 * k + j];
+        Rt[3 * i + j] = (i == j ? 1.0 : 0.0) + 2.0 * w * ux[3 * i + j] + 2.0 * uu;
+      }
+  }
+  const V3<double> ud = cross(u, d);
+  double e[6];
+  {
+    const V3<double> uud = cross(u, ud);
+    e[0] = d.x + 2.0 * w * ud.x + 2.0 * uud.x - mp[0];
+    e[1] = d.y + 2.0 * w * ud.y + 2.0 * uud.y - mp[1];
+    e[2] = d.z + 2.0 * w * ud.z + 2.0 * uud.z - mp[2];
+  }
+  // G = d e_p / d theta_a.  Under q_a <- [dth;1] (x) q_a, conj(q_a) changes by
+  //   du = -(w_a dth + dth x u_a) ,  dw = -dth . u_a      (u_a = vec(q_a) = -u)
+  double G[9];
+  for (int k = 0; k < 3; ++k) {
+    double eh[3] = {0, 0, 0};
+    eh[k] = 1.0;
+    const V3<double> ek{eh[0], eh[1], eh[2]};
+    const V3<double> ua{qa[0], qa[1], qa[2]};
+    const V3<double> exu = cross(ek, ua);
+    const V3<double> du{-(w * ek.x + exu.x), -(w * ek.y + exu.y), -(w * ek.z + exu.z)};
+    const double dw = -(ek.x * ua.x + ek.y * ua.y + ek.z * ua.z);
+    const V3<double> dud = cross(du, d);
+    const V3<double> t1 = cross(du, ud);
+    const V3<double> t2 = cross(u, dud);
+    G[0 + k] = 2.0 * dw * ud.x + 2.0 * w * dud.x + 2.0 * t1.x + 2.0 * t2.x;
+    G[3 + k] = 2.0 * dw * ud.y + 2.0 * w * dud.y + 2.0 * t1.y + 2.0 * t2.y;
+    G[6 + k] = 2.0 * dw * ud.z + 2.0 * w * dud.z + 2.0 * t1.z + 2.0 * t2.z;
+  }
+  // rotation part: e_q = 2 vec(qm (x) conj(q_b) (x) q_a); A = qm (x) conj(q_b)
+  const Q4<double> qm{mq[0], mq[1], mq[2], mq[3]};
+  const Q4<double> qbq{qb[0], qb[1], qb[2], qb[3]};
+  const Q4<double> qaq{qa[0], qa[1], qa[2], qa[3]};
+  const Q4<double> A = qmul(qm, qconj(qbq));
+  const Q4<double> dq = qmul(A, qaq);
+  e[3] = 2.0 * dq.x; e[4] = 2.0 * dq.y; e[5] = 2.0 * dq.z;
+  // M = d vec(A (x) [dth;0] (x) q_a) / d dth  (3x3)
+  double M[9];
+  for (int k = 0; k < 3; ++k) {
+    Q4<double> dth{k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0, 0.0};
+    Q4<double> t = qmul(qmul(A, dth), qaq);
+    M[0 + k] = t.x; M[3 + k] = t.y; M[6 + k] = t.z;
+  }
+  double Ea[36], Eb[36];
+  for (int i = 0; i < 36; ++i) Ea[i] = Eb[i] = 0.0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      Ea[6 * i + j] = -Rt[3 * i + j];
+      Ea[6 * i + 3 + j] = G[3 * i + j];
+      Ea[6 * (3 + i) + 3 + j] = 2.0 * M[3 * i + j];
+      Eb[6 * i + j] = Rt[3 * i + j];
+      Eb[6 * (3 + i) + 3 + j] = -2.0 * M[3 * i + j];
+    }
+  for (int i = 0; i < 6; ++i) {
+    double s = 0;
+    for (int j = 0; j < 6; ++j) s += L[6 * i + j] * e[j];
+    r[i] = s;
+    for (int c = 0; c < 6; ++c) {
+      double sa = 0, sb = 0;
+      for (int j = 0; j < 6; ++j) { sa += L[6 * i + j] * Ea[6 * j + c]; sb += L[6 * i + j] * Eb[6 * j + c]; }
+      Ja[6 * i + c] = sa;
+      Jb[6 * i + c] = sb;
+    }
+  }
+}
+
+// ceres::HuberLoss::Evaluate [Ceres 1.13; SURVEY.md App. E @0xbccc0].  a<=0 means "no loss".
+void loss_eval(int kind, double a, double s, double rho[3]) {
+  if (kind == 1 && a > 0) {
+    const double b = a * a;
+    if (s > b) {
+      const double r = std::sqrt(s);
+      rho[0] = 2.0 * a * r - b;
+      rho[1] = std::max(std::numeric_limits<double>::min(), a / r);
+      rho[2] = -rho[1] / (2.0 * s);
+      return;
+    }
+  }
+  rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Problem view (arrays owned by the caller).
+//   poses : N x 7 (px py pz qx qy qz qw)       cmask : N bytes, bit0 = p constant, bit1 = q constant
+//   ia/ib : id_begin / id_end pose indices      meas  : E x 7      sqrt_info : E x 36 row-major or NULL
+// ---------------------------------------------------------------------------------------------
+struct Prob {
+  int N, E;
+  const uint8_t* cmask;
+  const int *ia, *ib;
+  const double* meas;
+  const double* sqrt_info;
+  int loss_kind;
+  double loss_a;
+};
+
+// One residual block with Ceres' Corrector applied: returns 0.5*rho(s).
+double edge_linearize(const Prob& P, const double* poses, int e, double* r, double* Ja, double* Jb,
+                      bool want_jac) {
+  const int a = P.ia[e], b = P.ib[e];
+  const double* L = P.sqrt_info ? P.sqrt_info + 36 * (size_t)e : kIdentity6;
+  const double* pa = poses + 7 * (size_t)a;
+  const double* pb = poses + 7 * (size_t)b;
+  double JaL[36], JbL[36];
+  if (want_jac) {
+    edge_eval_analytic(pa, pa + 3, pb, pb + 3, P.meas + 7 * (size_t)e, P.meas + 7 * (size_t)e + 3, L, r, JaL, JbL);
+  } else {
+    functor<double>(P.meas + 7 * (size_t)e, P.meas + 7 * (size_t)e + 3, L, pa, pa + 3, pb, pb + 3, r);
+  }
+  double s = 0;
+  for (int i = 0; i < 6; ++i) s += r[i] * r[i];
+  double rho[3];
+  loss_eval(P.loss_kind, P.loss_a, s, rho);
+  const double sc = std::sqrt(rho[1]);  // Corrector with alpha = 0 (rho'' <= 0)
+  if (want_jac) {
+    for (int i = 0; i < 6; ++i) r[i] *= sc;
+    for (int i = 0; i < 36; ++i) { Ja[i] = JaL[i] * sc; Jb[i] = JbL[i] * sc; }
+    // constant parameter blocks: their Jacobian columns are removed from the program
+    const uint8_t ma = P.cmask[a], mb = P.cmask[b];
+    for (int i = 0; i < 6; ++i) {
+      if (ma & 1) Ja[6 * i] = Ja[6 * i + 1] = Ja[6 * i + 2] = 0.0;
+      if (ma & 2) Ja[6 * i + 3] = Ja[6 * i + 4] = Ja[6 * i + 5] = 0.0;
+      if (mb & 1) Jb[6 * i] = Jb[6 * i + 1] = Jb[6 * i + 2] = 0.0;
+      if (mb & 2) Jb[6 * i + 3] = Jb[6 * i + 4] = Jb[6 * i + 5] = 0.0;
+    }
+  }
+  return 0.5 * rho[0];
+}
+
+double total_cost(const Prob& P, const double* poses) {
+  double c = 0, r[6];
+  for (int e = 0; e < P.E; ++e) c += edge_linearize(P, poses, e, r, nullptr, nullptr, false);
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block-sparse normal equations, 6x6 pose blocks.  Lower triangle by block column:
+// col j holds the diagonal block first, then off-diagonal blocks (i > j) sorted by row.
+// ---------------------------------------------------------------------------------------------
+typedef std::array<double, 36> Blk;
+
+struct BlockSym {
+  int n = 0;
+  std::vector<int> colptr, rowidx;  // block CSC of the lower triangle (diag included, first)
+  std::vector<Blk> val;
+  std::vector<int> edge_slot;       // for each edge: slot of its off-diagonal block
+  std::vector<uint8_t> edge_transposed;  // 1 if the stored block is (b,a) i.e. J_b^T J_a
+};
+
+void build_structure(const Prob& P, BlockSym& H) {
+  const int n = P.N;
+  H.n = n;
+  std::vector<std::vector<int>> cols(n);
+  for (int e = 0; e < P.E; ++e) {
+    int a = P.ia[e], b = P.ib[e];
+    if (a == b) continue;
+    int j = std::min(a, b), i = std::max(a, b);
+    cols[j].push_back(i);
+  }
+  H.colptr.assign(n + 1, 0);
+  for (int j = 0; j < n; ++j) {
+    std::sort(cols[j].begin(), cols[j].end());
+    cols[j].erase(std::unique(cols[j].begin(), cols[j].end()), cols[j].end());
+    H.colptr[j + 1] = H.colptr[j] + 1 + (int)cols[j].size();
+  }
+  H.rowidx.resize(H.colptr[n]);
+  H.val.resize(H.colptr[n]);
+  for (int j = 0; j < n; ++j) {
+    int p = H.colptr[j];
+    H.rowidx[p++] = j;
+    for (int i : cols[j]) H.rowidx[p++] = i;
+  }
+  H.edge_slot.resize(P.E);
+  H.edge_transposed.resize(P.E);
+  for (int e = 0; e < P.E; ++e) {
+    int a = P.ia[e], b = P.ib[e];
+    int j = std::min(a, b), i = std::max(a, b);
+    const int* lo = &H.rowidx[H.colptr[j] + 1];
+    const int* hi = &H.rowidx[0] + H.colptr[j + 1];
+    H.edge_slot[e] = (int)(std::lower_bound(lo, hi, i) - &H.rowidx[0]);
+    // block (i,j) = J_i^T J_j.  If a is the larger index, block = J_a^T J_b, else J_b^T J_a.
+    H.edge_transposed[e] = (a > b) ? 0 : 1;
+  }
+}
+
+// C(6x6) += A^T B
+inline void atb_add(const double* A, const double* B, double* C) {
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      double s = 0;
+      for (int k = 0; k < 6; ++k) s += A[6 * k + i] * B[6 * k + j];
+      C[6 * i + j] += s;
+    }
+}
+
+// H = J^T J (blocks), g = J^T r.  Constant dims: zero row/col + unit diagonal, g = 0.
+double linearize(const Prob& P, const double* poses, BlockSym& H, std::vector<double>& g) {
+  for (auto& b : H.val) b.fill(0.0);
+  g.assign((size_t)6 * P.N, 0.0);
+  double cost = 0;
+  double r[6], Ja[36], Jb[36];
+  for (int e = 0; e < P.E; ++e) {
+    cost += edge_linearize(P, poses, e, r, Ja, Jb, true);
+    const int a = P.ia[e], b = P.ib[e];
+    atb_add(Ja, Ja, H.val[H.colptr[a]].data());
+    atb_add(Jb, Jb, H.val[H.colptr[b]].data());
+    if (a != b) {
+      if (H.edge_transposed[e]) atb_add(Jb, Ja, H.val[H.edge_slot[e]].data());
+      else atb_add(Ja, Jb, H.val[H.edge_slot[e]].data());
+    }
+    for (int i = 0; i < 6; ++i)
+      for (int k = 0; k < 6; ++k) {
+        g[6 * (size_t)a + i] += Ja[6 * k + i] * r[k];
+        g[6 * (size_t)b + i] += Jb[6 * k + i] * r[k];
+      }
+  }
+  for (int v = 0; v < P.N; ++v) {
+    double* D = H.val[H.colptr[v]].data();
+    for (int i = 0; i < 6; ++i) {
+      const bool c = (i < 3) ? (P.cmask[v] & 1) : (P.cmask[v] & 2);
+      if (c) D[7 * i] = 1.0;
+    }
+  }
+  return cost;
+}
+
+// y = (H + diag(d2)) x  using the symmetric lower storage
+void sym_matvec(const BlockSym& H, const double* d2, const double* x, double* y) {
+  const int n = H.n;
+  for (size_t i = 0; i < (size_t)6 * n; ++i) y[i] = d2 ? d2[i] * x[i] : 0.0;
+  for (int j = 0; j < n; ++j) {
+    for (int p = H.colptr[j]; p < H.colptr[j + 1]; ++p) {
+      const int i = H.rowidx[p];
+      const double* B = H.val[p].data();
+      const double* xj = x + 6 * (size_t)j;
+      double* yi = y + 6 * (size_t)i;
+      for (int r = 0; r < 6; ++r) {
+        double s = 0;
+        for (int c = 0; c < 6; ++c) s += B[6 * r + c] * xj[c];
+        yi[r] += s;
+      }
+      if (i != j) {
+        const double* xi = x + 6 * (size_t)i;
+        double* yj = y + 6 * (size_t)j;
+        for (int c = 0; c < 6; ++c) {
+          double s = 0;
+          for (int r = 0; r < 6; ++r) s += B[6 * r + c] * xi[r];
+          yj[c] += s;
+        }
+      }
+    }
+  }
+}
+
+// dense 6x6 Cholesky (lower), in place; returns false if not positive definite
+bool chol6(double* A) {
+  for (int j = 0; j < 6; ++j) {
+    double d = A[7 * j];
+    for (int k = 0; k < j; ++k) d -= A[6 * j + k] * A[6 * j + k];
+    if (!(d > 0.0)) return false;
+    d = std::sqrt(d);
+    A[7 * j] = d;
+    for (int i = j + 1; i < 6; ++i) {
+      double s = A[6 * i + j];
+      for (int k = 0; k < j; ++k) s -= A[6 * i + k] * A[6 * j + k];
+      A[6 * i + j] = s / d;
+    }
+    for (int i = 0; i < j; ++i) A[6 * i + j] = 0.0;
+  }
+  return true;
+}
+// solve L L^T x = b for 6-vector, L lower from chol6
+void chol6_solve(const double* L, const double* b, double* x) {
+  double y[6];
+  for (int i = 0; i < 6; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
+    y[i] = s / L[7 * i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double s = y[i];
+    for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
+    x[i] = s / L[7 * i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact linear solver: block-sparse Cholesky  P (H + D^2) P^T = L L^T  with a minimum-degree
+// ordering on the pose graph, block up-looking numeric phase.  Plays the role of
+// SparseNormalCholeskySolver + CHOLMOD in the reference.
+// ---------------------------------------------------------------------------------------------
+struct SparseChol {
+  int n = 0;
+  std::vector<int> perm, iperm, parent;
+  // permuted upper pattern per column k: rows i<k with A(i,k) != 0, with source slot + transpose flag
+  struct Src { int row; int slot; uint8_t transpose; };
+  std::vector<std::vector<Src>> upper;
+  std::vector<int> diag_slot;
+  // factor: per column, rows ascending (diag first) and blocks
+  std::vector<std::vector<int>> Lrow;
+  std::vector<std::vector<Blk>> Lval;
+  long long nnz_blocks = 0;
+  double flops = 0;
+
+  static void min_degree(int n, const std::vector<std::vector<int>>& adj0, std::vector<int>& perm) {
+    std::vector<std::vector<int>> adj = adj0;
+    std::vector<char> dead(n, 0);
+    typedef std::pair<int, int> DI;
+    std::priority_queue<DI, std::vector<DI>, std::greater<DI>> pq;
+    std::vector<int> deg(n);
+    for (int v = 0; v < n; ++v) { deg[v] = (int)adj[v].size(); pq.push(DI(deg[v], v)); }
+    perm.clear();
+    perm.reserve(n);
+    std::vector<int> merged;
+    while (!pq.empty()) {
+      DI top = pq.top(); pq.pop();
+      const int v = top.second;
+      if (dead[v] || top.first != deg[v]) continue;
+      dead[v] = 1;
+      perm.push_back(v);
+      std::vector<int> nb;
+      for (int u : adj[v]) if (!dead[u]) nb.push_back(u);
+      for (int u : nb) {
+        merged.clear();
+        std::set_union(adj[u].begin(), adj[u].end(), nb.begin(), nb.end(), std::back_inserter(merged));
+        std::vector<int> out;
+        out.reserve(merged.size());
+        for (int w : merged) if (w != u && !dead[w]) out.push_back(w);
+        adj[u].swap(out);
+        deg[u] = (int)adj[u].size();
+        pq.push(DI(deg[u], u));
+      }
+      std::vector<int>().swap(adj[v]);
+    }
+  }
+
+  void analyze(const BlockSym& H) {
+    n = H.n;
+    std::vector<std::vector<int>> adj(n);
+    for (int j = 0; j < n; ++j)
+      for (int p = H.colptr[j] + 1; p < H.colptr[j + 1]; ++p) {
+        adj[j].push_back(H.rowidx[p]);
+        adj[H.rowidx[p]].push_back(j);
+      }
+    for (auto& a : adj) std::sort(a.begin(), a.end());
+    min_degree(n, adj, perm);
+    iperm.assign(n, 0);
+    for (int k = 0; k < n; ++k) iperm[perm[k]] = k;
+    upper.assign(n, {});
+    diag_slot.assign(n, 0);
+    for (int j = 0; j < n; ++j) {
+      diag_slot[iperm[j]] = H.colptr[j];
+      for (int p = H.colptr[j] + 1; p < H.colptr[j + 1]; ++p) {
+        const int i = H.rowidx[p];  // stored block = (i,j), i>j in original numbering
+        const int pi = iperm[i], pj = iperm[j];
+        // we need the block at (row=min, col=max) of the permuted upper triangle
+        if (pi < pj) upper[pj].push_back(Src{pi, p, 0});  // (pi,pj) = stored (i,j) as is
+        else upper[pi].push_back(Src{pj, p, 1});          // (pj,pi) = stored^T
+      }
+    }
+    // elimination tree (Liu), with path compression
+    parent.assign(n, -1);
+    std::vector<int> anc(n, -1);
+    for (int k = 0; k < n; ++k)
+      for (const Src& s : upper[k]) {
+        int i = s.row;
+        while (i != -1 && i < k) {
+          int nx = anc[i];
+          anc[i] = k;
+          if (nx == -1) parent[i] = k;
+          i = nx;
+        }
+      }
+    Lrow.assign(n, {});
+    Lval.assign(n, {});
+  }
+
+  // numeric factorisation of H + diag(d2); returns false on a non-positive pivot
+  bool factor(const BlockSym& H, const double* d2) {
+    for (int j = 0; j < n; ++j) { Lrow[j].clear(); Lval[j].clear(); }
+    nnz_blocks = 0;
+    flops = 0;
+    std::vector<Blk> x(n);
+    std::vector<int> mark(n, -1), stack(n), reach(n);
+    for (int k = 0; k < n; ++k) {
+      // scatter column k of the permuted upper triangle into x, compute reach
+      int top = n;
+      mark[k] = k;
+      for (const Src& s : upper[k]) {
+        const double* B = H.val[s.slot].data();
+        Blk& xb = x[s.row];
+        if (s.transpose) { for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) xb[6 * r + c] = B[6 * c + r]; }
+        else { for (int q = 0; q < 36; ++q) xb[q] = B[q]; }
+        int len = 0;
+        for (int i = s.row; mark[i] != k; i = parent[i]) { stack[len++] = i; mark[i] = k; }
+        while (len > 0) reach[--top] = stack[--len];
+      }
+      // NOTE: entries reached through the etree but not present in A start at zero
+      Blk d;
+      {
+        const int orig = perm[k];
+        const double* B = H.val[diag_slot[k]].data();
+        for (int q = 0; q < 36; ++q) d[q] = B[q];
+        if (d2) for (int i = 0; i < 6; ++i) d[7 * i] += d2[6 * (size_t)orig + i];
+      }
+      for (int t = top; t < n; ++t) {
+        const int j = reach[t];
+        // L_kj = x_j^T L_jj^{-T}   <=>  solve L_jj * Lkj^T = x_j   (column by column)
+        const double* Ljj = Lval[j][0].data();
+        Blk lkjT;  // holds Lkj^T (6x6): column c solves L_jj y = x_j[:,c]
+        for (int c = 0; c < 6; ++c) {
+          double y[6];
+          for (int i = 0; i < 6; ++i) {
+            double s = x[j][6 * i + c];
+            for (int q = 0; q < i; ++q) s -= Ljj[6 * i + q] * y[q];
+            y[i] = s / Ljj[7 * i];
+          }
+          for (int i = 0; i < 6; ++i) lkjT[6 * i + c] = y[i];
+        }
+        Blk lkj;
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) lkj[6 * r + c] = lkjT[6 * c + r];
+        x[j].fill(0.0);
+        // x_i -= L_ij * L_kj^T  for stored rows i of column j (j < i < k)
+        const size_t cnt = Lrow[j].size();
+        for (size_t p = 1; p < cnt; ++p) {
+          const int i = Lrow[j][p];
+          const double* Lij = Lval[j][p].data();
+          Blk& xi = x[i];
+          for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) {
+              double s = 0;
+              for (int q = 0; q < 6; ++q) s += Lij[6 * r + q] * lkj[6 * c + q];
+              xi[6 * r + c] -= s;
+            }
+        }
+        flops += 432.0 * (double)(cnt - 1) + 432.0 + 216.0;
+        // d -= L_kj L_kj^T
+        for (int r = 0; r < 6; ++r)
+          for (int c = 0; c < 6; ++c) {
+            double s = 0;
+            for (int q = 0; q < 6; ++q) s += lkj[6 * r + q] * lkj[6 * c + q];
+            d[6 * r + c] -= s;
+          }
+        Lrow[j].push_back(k);
+        Lval[j].push_back(lkj);
+      }
+      // the x entries for rows in reach were initialised lazily: rows never scattered must be zero.
+      if (!chol6(d.data())) return false;
+      Lrow[k].push_back(k);
+      Lval[k].push_back(d);
+    }
+    for (int j = 0; j < n; ++j) nnz_blocks += (long long)Lrow[j].size();
+    return true;
+  }
+
+  void solve(const double* b, double* out) const {
+    std::vector<double> y((size_t)6 * n);
+    for (int k = 0; k < n; ++k) for (int i = 0; i < 6; ++i) y[6 * (size_t)k + i] = b[6 * (size_t)perm[k] + i];
+    // forward: L y = b
+    for (int j = 0; j < n; ++j) {
+      double* yj = &y[6 * (size_t)j];
+      const double* Ljj = Lval[j][0].data();
+      for (int i = 0; i < 6; ++i) {
+        double s = yj[i];
+        for (int q = 0; q < i; ++q) s -= Ljj[6 * i + q] * yj[q];
+        yj[i] = s / Ljj[7 * i];
+      }
+      for (size_t p = 1; p < Lrow[j].size(); ++p) {
+        double* yi = &y[6 * (size_t)Lrow[j][p]];
+        const double* B = Lval[j][p].data();
+        for (int r = 0; r < 6; ++r) {
+          double s = 0;
+          for (int c = 0; c < 6; ++c) s += B[6 * r + c] * yj[c];
+          yi[r] -= s;
+        }
+      }
+    }
+    // backward: L^T x = y
+    for (int j = n - 1; j >= 0; --j) {
+      double* yj = &y[6 * (size_t)j];
+      for (size_t p = 1; p < Lrow[j].size(); ++p) {
+        const double* yi = &y[6 * (size_t)Lrow[j][p]];
+        const double* B = Lval[j][p].data();
+        for (int c = 0; c < 6; ++c) {
+          double s = 0;
+          for (int r = 0; r < 6; ++r) s += B[6 * r + c] * yi[r];
+          yj[c] -= s;
+        }
+      }
+      const double* Ljj = Lval[j][0].data();
+      for (int i = 5; i >= 0; --i) {
+        double s = yj[i];
+        for (int q = i + 1; q < 6; ++q) s -= Ljj[6 * q + i] * yj[q];
+        yj[i] = s / Ljj[7 * i];
+      }
+    }
+    for (int k = 0; k < n; ++k) for (int i = 0; i < 6; ++i) out[6 * (size_t)perm[k] + i] = y[6 * (size_t)k + i];
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Ceres 1.13 ConjugateGradientsSolver restated (Q-tolerance termination, residual reset every 10
+// iterations) with a block-Jacobi preconditioner on the 6x6 pose blocks of H + D^2.
+// Solves (H + D^2) x = b, x0 = 0.  Returns iterations used; *ok=false on breakdown.
+// ---------------------------------------------------------------------------------------------
+int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, double q_tol,
+              int max_it, int min_it, int residual_reset_period, bool* ok, double* final_rnorm) {
+  const int n = H.n;
+  const size_t m = (size_t)6 * n;
+  std::vector<Blk> Minv(n);
+  for (int v = 0; v < n; ++v) {
+    Blk A = H.val[H.colptr[v]];
+    for (int i = 0; i < 6; ++i) A[7 * i] += d2[6 * (size_t)v + i];
+    // symmetrise from the stored full block, factor
+    if (!chol6(A.data())) { *ok = false; return 0; }
+    Minv[v] = A;  // keep the Cholesky factor; apply by solves
+  }
+  std::vector<double> r(b, b + m), z(m), p(m, 0.0), q(m), tmp(m);
+  std::fill(x, x + m, 0.0);
+  double rho = 1.0;
+  auto dot = [&](const double* a_, const double* b_) { double s = 0; for (size_t i = 0; i < m; ++i) s += a_[i] * b_[i]; return s; };
+  double Q0;
+  { double s = 0; for (size_t i = 0; i < m; ++i) s += x[i] * (b[i] + r[i]); Q0 = -1.0 * s; }
+  *ok = true;
+  int it = 1;
+  for (;; ++it) {
+    for (int v = 0; v < n; ++v) chol6_solve(Minv[v].data(), &r[6 * (size_t)v], &z[6 * (size_t)v]);
+    const double last_rho = rho;
+    rho = dot(r.data(), z.data());
+    if (rho == 0.0 || !std::isfinite(rho)) { *ok = (rho == 0.0); break; }
+    if (it == 1) p = z;
+    else {
+      const double beta = rho / last_rho;
+      if (beta == 0.0 || !std::isfinite(beta)) { *ok = false; break; }
+      for (size_t i = 0; i < m; ++i) p[i] = z[i] + beta * p[i];
+    }
+    sym_matvec(H, d2, p.data(), q.data());
+    const double pq = dot(p.data(), q.data());
+    if (pq <= 0.0 || !std::isfinite(pq)) break;  // NO_CONVERGENCE: keep current x
+    const double alpha = rho / pq;
+    if (!std::isfinite(alpha)) { *ok = false; break; }
+    for (size_t i = 0; i < m; ++i) x[i] += alpha * p[i];
+    if (residual_reset_period > 0 && it % residual_reset_period == 0) {
+      sym_matvec(H, d2, x, tmp.data());
+      for (size_t i = 0; i < m; ++i) r[i] = b[i] - tmp[i];
+    } else {
+      for (size_t i = 0; i < m; ++i) r[i] -= alpha * q[i];
+    }
+    double s = 0;
+    for (size_t i = 0; i < m; ++i) s += x[i] * (b[i] + r[i]);
+    const double Q1 = -1.0 * s;
+    const double zeta = it * (Q1 - Q0) / Q1;
+    if (zeta < q_tol && it >= min_it) break;
+    Q0 = Q1;
+    if (it >= max_it) break;
+  }
+  if (final_rnorm) *final_rnorm = std::sqrt(dot(r.data(), r.data()));
+  return it;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C interface (ctypes)
+// =============================================================================================
+extern "C" {
+
+struct oracle_options {
+  int max_num_iterations;        // 50 (Ceres default); the reference sets 1000 (finial.cpp:535)
+  int linear_solver;             // 0 = exact sparse Cholesky (SPARSE_NORMAL_CHOLESKY), 1 = block-Jacobi PCG (CGNR/JACOBI)
+  int jacobi_scaling;            // 1
+  int max_linear_solver_iterations;  // 500
+  int min_linear_solver_iterations;  // 0
+  int residual_reset_period;     // 10
+  int max_num_consecutive_invalid_steps;  // 5
+  int loss_kind;                 // 0 trivial, 1 Huber
+  double loss_a;                 // 1.0
+  double function_tolerance;     // 1e-6
+  double gradient_tolerance;     // 1e-10
+  double parameter_tolerance;    // 1e-8
+  double initial_trust_region_radius;  // 1e4
+  double max_trust_region_radius;      // 1e16
+  double min_trust_region_radius;      // 1e-32
+  double min_relative_decrease;        // 1e-3
+  double min_lm_diagonal;              // 1e-6
+  double max_lm_diagonal;              // 1e32
+  double eta;                          // 0.1
+};
+
+struct oracle_summary {
+  int termination_type;  // 0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE
+  int num_successful_steps;
+  int num_unsuccessful_steps;
+  int num_iterations;            // entries in the trace (iteration 0 included)
+  int num_linear_iterations;     // CG iterations summed over the solve
+  int reason;                    // 1 function tol, 2 parameter tol, 3 gradient tol, 4 min radius, 5 max iterations, 6 invalid steps, 7 linear solver failure
+  double initial_cost;
+  double final_cost;
+  double total_seconds;
+  double linear_solver_seconds;
+  double jacobian_seconds;
+  double cost_eval_seconds;
+  long long factor_nnz_blocks;
+  double factor_flops;
+};
+
+// trace row: [iteration, cost, cost_change, gradient_max_norm, step_norm, relative_decrease,
+//             trust_region_radius, linear_iterations, step_is_successful]
+enum { ORACLE_TRACE_COLS = 9 };
+
+void oracle_default_options(oracle_options* o) {
+  o->max_num_iterations = 50;
+  o->linear_solver = 0;
+  o->jacobi_scaling = 1;
+  o->max_linear_solver_iterations = 500;
+  o->min_linear_solver_iterations = 0;
+  o->residual_reset_period = 10;
+  o->max_num_consecutive_invalid_steps = 5;
+  o->loss_kind = 1;
+  o->loss_a = 1.0;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->eta = 0.1;
+}
+
+void oracle_edge_eval_autodiff(const double* pa, const double* qa, const double* pb, const double* qb,
+                               const double* mp, const double* mq, const double* L, double* r,
+                               double* Ja, double* Jb) {
+  edge_eval_autodiff(pa, qa, pb, qb, mp, mq, L ? L : kIdentity6, r, Ja, Jb);
+}
+void oracle_edge_eval_analytic(const double* pa, const double* qa, const double* pb, const double* qb,
+                               const double* mp, const double* mq, const double* L, double* r,
+                               double* Ja, double* Jb) {
+  edge_eval_analytic(pa, qa, pb, qb, mp, mq, L ? L : kIdentity6, r, Ja, Jb);
+}
+void oracle_quat_plus(const double* q, const double* delta, double* out) { quat_plus(q, delta, out); }
+void oracle_loss(int kind, double a, double s, double* rho3) { loss_eval(kind, a, s, rho3); }
+
+// lower Cholesky factor of a 6x6 information matrix (finial.cpp:508 information.llt().matrixL())
+int oracle_chol6(const double* info, double* L) {
+  for (int i = 0; i < 36; ++i) L[i] = info[i];
+  return chol6(L) ? 0 : -1;
+}
+
+// Per-edge evaluation with loss correction and constant-block masking, as the evaluator sees it.
+// residuals E x 6, Ja/Jb E x 36 (may be NULL), rho E x 3 (may be NULL). Returns total cost.
+double oracle_evaluate(int N, int E, const double* poses, const uint8_t* cmask, const int* ia,
+                       const int* ib, const double* meas, const double* sqrt_info, int loss_kind,
+                       double loss_a, double* residuals, double* Ja, double* Jb) {
+  Prob P{N, E, cmask, ia, ib, meas, sqrt_info, loss_kind, loss_a};
+  double cost = 0, r[6], A[36], B[36];
+  for (int e = 0; e < E; ++e) {
+    const bool wj = (Ja != nullptr) || (residuals != nullptr);
+    cost += edge_linearize(P, poses, e, r, A, B, wj);
+    if (residuals) std::memcpy(residuals + 6 * (size_t)e, r, sizeof r);
+    if (Ja) std::memcpy(Ja + 36 * (size_t)e, A, sizeof A);
+    if (Jb) std::memcpy(Jb + 36 * (size_t)e, B, sizeof B);
+  }
+  return cost;
+}
+
+double oracle_cost(int N, int E, const double* poses, const uint8_t* cmask, const int* ia, const int* ib,
+                   const double* meas, const double* sqrt_info, int loss_kind, double loss_a) {
+  Prob P{N, E, cmask, ia, ib, meas, sqrt_info, loss_kind, loss_a};
+  return total_cost(P, poses);
+}
+
+// Dense normal equations for small problems: Hdense (6N x 6N, row-major, full symmetric), g (6N).
+double oracle_normal_equations_dense(int N, int E, const double* poses, const uint8_t* cmask,
+                                     const int* ia, const int* ib, const double* meas,
+                                     const double* sqrt_info, int loss_kind, double loss_a,
+                                     double* Hdense, double* g_out) {
+  Prob P{N, E, cmask, ia, ib, meas, sqrt_info, loss_kind, loss_a};
+  BlockSym H;
+  build_structure(P, H);
+  std::vector<double> g;
+  const double cost = linearize(P, poses, H, g);
+  const size_t m = (size_t)6 * N;
+  std::fill(Hdense, Hdense + m * m, 0.0);
+  for (int j = 0; j < N; ++j)
+    for (int p = H.colptr[j]; p < H.colptr[j + 1]; ++p) {
+      const int i = H.rowidx[p];
+      for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) {
+          Hdense[(6 * (size_t)i + r) * m + 6 * (size_t)j + c] = H.val[p][6 * r + c];
+          Hdense[(6 * (size_t)j + c) * m + 6 * (size_t)i + r] = H.val[p][6 * r + c];
+        }
+    }
+  std::memcpy(g_out, g.data(), m * sizeof(double));
+  return cost;
+}
+
+// Solve (H + diag(d2)) x = b on the current linearisation with the exact factorisation or PCG
+// (for solver-level tests).  Returns CG iterations (0 for the direct solver), <0 on failure.
+int oracle_linear_solve(int N, int E, const double* poses, const uint8_t* cmask, const int* ia,
+                        const int* ib, const double* meas, const double* sqrt_info, int loss_kind,
+                        double loss_a, const double* d2, const double* b, int linear_solver,
+                        double q_tol, int max_it, double* x) {
+  Prob P{N, E, cmask, ia, ib, meas, sqrt_info, loss_kind, loss_a};
+  BlockSym H;
+  build_structure(P, H);
+  std::vector<double> g;
+  linearize(P, poses, H, g);
+  if (linear_solver == 0) {
+    SparseChol C;
+    C.analyze(H);
+    if (!C.factor(H, d2)) return -1;
+    C.solve(b, x);
+    return 0;
+  }
+  bool ok;
+  int it = pcg_solve(H, d2, b, x, q_tol, max_it, 0, 10, &ok, nullptr);
+  return ok ? it : -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ceres::Solve restated: TrustRegionMinimizer::Minimize + LevenbergMarquardtStrategy [Ceres 1.13],
+// SURVEY.md Appendix A.6 step by step.  poses (N x 7) are updated in place, like the parameter
+// blocks the reference hands to Problem (finial.cpp:513-517).
+// ---------------------------------------------------------------------------------------------
+int oracle_solve(int N, int E, double* poses, const uint8_t* cmask, const int* ia, const int* ib,
+                 const double* meas, const double* sqrt_info, const oracle_options* opt,
+                 oracle_summary* sum, double* trace, int trace_capacity) {
+  typedef std::chrono::steady_clock Clock;
+  auto secs = [](Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  const auto t_start = Clock::now();
+  Prob P{N, E, cmask, ia, ib, meas, sqrt_info, opt->loss_kind, opt->loss_a};
+  const size_t m = (size_t)6 * N;
+  std::memset(sum, 0, sizeof *sum);
+
+  BlockSym H;
+  build_structure(P, H);
+  SparseChol chol;
+  if (opt->linear_solver == 0) chol.analyze(H);
+
+  std::vector<double> x(poses, poses + 7 * (size_t)N), cand(7 * (size_t)N);
+  std::vector<double> g, scale(m, 1.0), diag(m), d2(m), gs(m), step(m), delta(m), tmp(m);
+  double x_cost = 0, radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
+  bool reuse_diagonal = false;
+  int n_trace = 0;
+
+  auto is_const = [&](int v, int i) { return (i < 3) ? (cmask[v] & 1) != 0 : (cmask[v] & 2) != 0; };
+  auto x_norm_of = [&](const std::vector<double>& xx) {
+    double s = 0;
+    for (int v = 0; v < N; ++v) {
+      if (!(cmask[v] & 1)) for (int i = 0; i < 3; ++i) s += xx[7 * (size_t)v + i] * xx[7 * (size_t)v + i];
+      if (!(cmask[v] & 2)) for (int i = 3; i < 7; ++i) s += xx[7 * (size_t)v + i] * xx[7 * (size_t)v + i];
+    }
+    return std::sqrt(s);
+  };
+  auto plus = [&](const std::vector<double>& xx, const double* dl, std::vector<double>& out) {
+    for (int v = 0; v < N; ++v) {
+      const double* xv = &xx[7 * (size_t)v];
+      double* ov = &out[7 * (size_t)v];
+      if (cmask[v] & 1) { ov[0] = xv[0]; ov[1] = xv[1]; ov[2] = xv[2]; }
+      else for (int i = 0; i < 3; ++i) ov[i] = xv[i] + dl[6 * (size_t)v + i];
+      if (cmask[v] & 2) { ov[3] = xv[3]; ov[4] = xv[4]; ov[5] = xv[5]; ov[6] = xv[6]; }
+      else quat_plus(xv + 3, dl + 6 * (size_t)v + 3, ov + 3);
+    }
+  };
+  double gradient_max_norm = 0;
+  bool scaled_once = false;
+  // EvaluateGradientAndJacobian: H~ = S H S, g (unscaled) kept for the gradient test, gs = S g
+  auto evaluate_gradient_and_jacobian = [&]() {
+    const auto t0 = Clock::now();
+    x_cost = linearize(P, x.data(), H, g);
+    if (opt->jacobi_scaling) {
+      if (!scaled_once) {
+        for (int v = 0; v < N; ++v)
+          for (int i = 0; i < 6; ++i) {
+            const double cn = is_const(v, i) ? 0.0 : H.val[H.colptr[v]][7 * i];
+            scale[6 * (size_t)v + i] = 1.0 / (1.0 + std::sqrt(cn));
+          }
+        scaled_once = true;
+      }
+      for (int j = 0; j < N; ++j)
+        for (int p = H.colptr[j]; p < H.colptr[j + 1]; ++p) {
+          const int i = H.rowidx[p];
+          for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c)
+              H.val[p][6 * r + c] *= scale[6 * (size_t)i + r] * scale[6 * (size_t)j + c];
+        }
+      // keep the unit diagonal of constant dims exactly 1
+      for (int v = 0; v < N; ++v)
+        for (int i = 0; i < 6; ++i) if (is_const(v, i)) H.val[H.colptr[v]][7 * i] = 1.0;
+    }
+    for (size_t i = 0; i < m; ++i) gs[i] = g[i] * scale[i];
+    // gradient_max_norm = || x - Plus(x, -g) ||_inf over the non-constant blocks
+    for (size_t i = 0; i < m; ++i) tmp[i] = -g[i];
+    plus(x, tmp.data(), cand);
+    double gm = 0;
+    for (int v = 0; v < N; ++v) {
+      if (!(cmask[v] & 1)) for (int i = 0; i < 3; ++i) gm = std::max(gm, std::fabs(x[7 * (size_t)v + i] - cand[7 * (size_t)v + i]));
+      if (!(cmask[v] & 2)) for (int i = 3; i < 7; ++i) gm = std::max(gm, std::fabs(x[7 * (size_t)v + i] - cand[7 * (size_t)v + i]));
+    }
+    gradient_max_norm = gm;
+    sum->jacobian_seconds += secs(t0, Clock::now());
+  };
+
+  struct Iter { int iteration; double cost, cost_change, gmax, step_norm, rel_dec, radius; int lin_it; bool ok, valid; } it{};
+  auto push_trace = [&]() {
+    if (trace && n_trace < trace_capacity) {
+      double* t = trace + (size_t)ORACLE_TRACE_COLS * n_trace;
+      t[0] = it.iteration; t[1] = it.cost; t[2] = it.cost_change; t[3] = it.gmax; t[4] = it.step_norm;
+      t[5] = it.rel_dec; t[6] = it.radius; t[7] = it.lin_it; t[8] = it.ok ? 1.0 : 0.0;
+    }
+    ++n_trace;
+  };
+
+  // ---- Init + IterationZero ----
+  double x_norm = x_norm_of(x);
+  evaluate_gradient_and_jacobian();
+  sum->initial_cost = x_cost;
+  it = Iter{0, x_cost, 0, gradient_max_norm, 0, 0, radius, 0, true, true};
+  int num_consecutive_invalid = 0;
+  int term = 1, reason = 5;
+
+  for (;;) {
+    // ---- FinalizeIterationAndCheckIfMinimizerCanContinue ----
+    if (it.ok) ++sum->num_successful_steps; else ++sum->num_unsuccessful_steps;
+    it.radius = radius;
+    push_trace();
+    if (it.iteration >= opt->max_num_iterations) { term = 1; reason = 5; break; }
+    if (it.ok && it.gmax <= opt->gradient_tolerance) { term = 0; reason = 3; break; }
+    if (it.radius <= opt->min_trust_region_radius) { term = 0; reason = 4; break; }
+
+    Iter nx{};
+    nx.iteration = it.iteration + 1;
+    nx.gmax = it.gmax;
+
+    // ---- ComputeTrustRegionStep (LevenbergMarquardtStrategy::ComputeStep) ----
+    const auto t_lin = Clock::now();
+    if (!reuse_diagonal) {
+      for (int v = 0; v < N; ++v)
+        for (int i = 0; i < 6; ++i) {
+          double dv = H.val[H.colptr[v]][7 * i];
+          diag[6 * (size_t)v + i] = std::min(std::max(dv, opt->min_lm_diagonal), opt->max_lm_diagonal);
+        }
+    }
+    for (size_t i = 0; i < m; ++i) d2[i] = diag[i] / radius;  // lm_diagonal^2
+    bool lin_ok = true;
+    int lin_it = 0;
+    if (opt->linear_solver == 0) {
+      lin_ok = chol.factor(H, d2.data());
+      if (lin_ok) chol.solve(gs.data(), step.data());
+      sum->factor_nnz_blocks = chol.nnz_blocks;
+      sum->factor_flops = chol.flops;
+    } else {
+      lin_it = pcg_solve(H, d2.data(), gs.data(), step.data(), opt->eta, opt->max_linear_solver_iterations,
+                         opt->min_linear_solver_iterations, opt->residual_reset_period, &lin_ok, nullptr);
+      sum->num_linear_iterations += lin_it;
+    }
+    if (lin_ok) for (size_t i = 0; i < m; ++i) { if (!std::isfinite(step[i])) { lin_ok = false; break; } }
+    for (size_t i = 0; i < m; ++i) step[i] = -step[i];
+    reuse_diagonal = true;
+    sum->linear_solver_seconds += secs(t_lin, Clock::now());
+    nx.lin_it = lin_it;
+
+    double model_cost_change = 0;
+    bool step_valid = false;
+    if (lin_ok) {
+      // model_cost_change = -(J~ step)'(r + J~ step / 2) = -step' g~ - step' H~ step / 2
+      sym_matvec(H, nullptr, step.data(), tmp.data());
+      double a = 0, b = 0;
+      for (int v = 0; v < N; ++v)
+        for (int i = 0; i < 6; ++i) {
+          const size_t k = 6 * (size_t)v + i;
+          if (is_const(v, i)) continue;
+          a += step[k] * gs[k];
+          b += step[k] * tmp[k];
+        }
+      model_cost_change = -a - 0.5 * b;
+      step_valid = model_cost_change > 0.0;
+    }
+    if (!step_valid) {
+      // ---- HandleInvalidStep ----
+      ++num_consecutive_invalid;
+      if (num_consecutive_invalid >= opt->max_num_consecutive_invalid_steps) { term = 2; reason = 6; it = nx; break; }
+      radius *= 0.5;  // LevenbergMarquardtStrategy::StepIsInvalid
+      reuse_diagonal = true;
+      nx.cost = x_cost; nx.cost_change = 0; nx.step_norm = 0; nx.rel_dec = 0; nx.ok = false; nx.valid = false;
+      it = nx;
+      continue;
+    }
+    num_consecutive_invalid = 0;
+    for (size_t i = 0; i < m; ++i) delta[i] = step[i] * scale[i];
+
+    // ---- ComputeCandidatePointAndEvaluateCost ----
+    const auto t_c = Clock::now();
+    plus(x, delta.data(), cand);
+    const double cand_cost = total_cost(P, cand.data());
+    sum->cost_eval_seconds += secs(t_c, Clock::now());
+
+    // ---- ParameterToleranceReached ----
+    {
+      double s = 0;
+      for (int v = 0; v < N; ++v) {
+        if (!(cmask[v] & 1)) for (int i = 0; i < 3; ++i) { const double d = x[7 * (size_t)v + i] - cand[7 * (size_t)v + i]; s += d * d; }
+        if (!(cmask[v] & 2)) for (int i = 3; i < 7; ++i) { const double d = x[7 * (size_t)v + i] - cand[7 * (size_t)v + i]; s += d * d; }
+      }
+      nx.step_norm = std::sqrt(s);
+    }
+    if (nx.step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) { term = 0; reason = 2; it = nx; it.cost = x_cost; break; }
+    // ---- FunctionToleranceReached ----
+    nx.cost_change = x_cost - cand_cost;
+    if (std::fabs(nx.cost_change) <= opt->function_tolerance * x_cost) { term = 0; reason = 1; it = nx; it.cost = x_cost; break; }
+    // ---- IsStepSuccessful ----
+    nx.rel_dec = nx.cost_change / model_cost_change;
+    if (nx.rel_dec > opt->min_relative_decrease) {
+      // ---- HandleSuccessfulStep ----
+      x.swap(cand);
+      x_norm = x_norm_of(x);
+      evaluate_gradient_and_jacobian();
+      nx.ok = true; nx.valid = true; nx.cost = x_cost; nx.gmax = gradient_max_norm;
+      // LevenbergMarquardtStrategy::StepAccepted
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * nx.rel_dec - 1.0, 3));
+      radius = std::min(opt->max_trust_region_radius, radius);
+      decrease_factor = 2.0;
+      reuse_diagonal = false;
+    } else {
+      // ---- HandleUnsuccessfulStep / StepRejected ----
+      nx.ok = false; nx.valid = true; nx.cost = cand_cost;
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+      reuse_diagonal = true;
+    }
+    it = nx;
+  }
+
+  std::memcpy(poses, x.data(), sizeof(double) * 7 * (size_t)N);
+  sum->termination_type = term;
+  sum->reason = reason;
+  sum->final_cost = x_cost;
+  sum->num_iterations = n_trace;
+  sum->total_seconds = secs(t_start, Clock::now());
+  return term == 2 ? -1 : 0;
+}
+
+// Timed pieces for bench.py's cpu_baseline: one Jacobian evaluation sweep (residual + analytic
+// Jacobians + corrector for every edge), returns seconds for `repeats` sweeps.
+double oracle_time_jacobian_eval(int N, int E, const double* poses, const uint8_t* cmask, const int* ia,
+                                 const int* ib, const double* meas, const double* sqrt_info, int loss_kind,
+                                 double loss_a, int repeats, double* checksum) {
+  Prob P{N, E, cmask, ia, ib, meas, sqrt_info, loss_kind, loss_a};
+  double r[6], A[36], B[36], acc = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < repeats; ++k)
+    for (int e = 0; e < E; ++e) { acc += edge_linearize(P, poses, e, r, A, B, true); acc += A[7] + B[14]; }
+  const auto t1 = std::chrono::steady_clock::now();
+  if (checksum) *checksum = acc;
+  return std::chrono::duration<double>(t1 - t0).count();
+}
+
+}  // extern "C"

@@ -1,0 +1,322 @@
+"""posegraph-ceres_amd — Python host-side mirror of the C ABI in include/pgo.h (libpgo_hip.so).
+
+The compute path is hand-written HIP for gfx950 (csrc/); this module only marshals arrays through
+ctypes.  It mirrors the reference's use of Ceres (REF = src/POSE_GRAPH_CERES_PLUS):
+
+    problem = Problem()                                   # ceres::Problem            finial.cpp:58
+    problem.add_poses(poses)                              # parameter blocks p(3), q(4 xyzw)
+    problem.add_se3_between(ia, ib, t_be, sqrt_info)      # PoseGraph3dErrorTerm::Create + AddResidualBlock
+    problem.set_loss(HUBER, 1.0)                          # new HuberLoss(1.0)        finial.cpp:495
+    problem.set_pose_constant(0)                          # SetParameterBlockConstant finial.cpp:525-527
+    summary = solve(SolverOptions(max_num_iterations=1000,
+                                  linear_solver_type=SPARSE_NORMAL_CHOLESKY), problem)   # finial.cpp:534-539
+    print(summary.full_report()); summary.is_solution_usable()
+
+The directory name contains a hyphen, so import it through `pgo_loader.load()` (repo root).
+There is no CPU fallback: without the built library or without a GPU every compute call raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgo_hip.so")
+
+TRIVIAL, HUBER = 0, 1
+SPARSE_NORMAL_CHOLESKY, BLOCK_JACOBI_PCG = 0, 1
+CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
+TERMINATION_NAMES = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE"}
+
+OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NUMERICAL = 0, -1, -2, -3, -4, -5
+
+# every symbol include/pgo.h declares (tests check the built library exports all of them)
+C_ABI_SYMBOLS = [
+    "pgo_version", "pgo_last_error", "pgo_device_count", "pgo_set_device", "pgo_problem_create",
+    "pgo_problem_destroy", "pgo_problem_add_pose", "pgo_problem_add_poses", "pgo_problem_add_se3_between",
+    "pgo_problem_add_se3_between_batch", "pgo_problem_set_loss", "pgo_problem_set_pose_constant",
+    "pgo_problem_set_parameter_block_constant", "pgo_problem_num_poses", "pgo_problem_num_edges",
+    "pgo_solver_options_init", "pgo_solve", "pgo_summary_is_solution_usable", "pgo_summary_full_report",
+    "pgo_evaluate", "pgo_normal_equations", "pgo_linear_solve", "pgo_plus", "pgo_solver_begin",
+    "pgo_solver_step", "pgo_solver_reset", "pgo_solver_end", "pgo_time_kernel", "pgo_shard_range",
+    "pgo_comm_get_unique_id", "pgo_comm_init",
+]
+
+
+class PgoError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("pgo error %d: %s" % (code, message))
+        self.code = code
+
+
+class _COptions(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int), ("linear_solver_type", C.c_int), ("jacobi_scaling", C.c_int),
+        ("max_linear_solver_iterations", C.c_int), ("min_linear_solver_iterations", C.c_int),
+        ("max_num_consecutive_invalid_steps", C.c_int), ("cg_batch", C.c_int), ("reserved0", C.c_int),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+        ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double), ("eta", C.c_double),
+        ("exact_r_tolerance", C.c_double),
+    ]
+
+
+class _CSummary(C.Structure):
+    _fields_ = [
+        ("termination_type", C.c_int), ("num_successful_steps", C.c_int), ("num_unsuccessful_steps", C.c_int),
+        ("num_iterations", C.c_int), ("num_linear_solver_iterations", C.c_int), ("num_poses", C.c_int),
+        ("num_edges", C.c_int), ("reason", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+        ("total_time_in_seconds", C.c_double), ("setup_time_in_seconds", C.c_double),
+        ("linear_solver_time_in_seconds", C.c_double), ("jacobian_evaluation_time_in_seconds", C.c_double),
+        ("residual_evaluation_time_in_seconds", C.c_double), ("final_gradient_max_norm", C.c_double),
+        ("final_trust_region_radius", C.c_double), ("message", C.c_char * 256),
+    ]
+
+
+class _CRecord(C.Structure):
+    _fields_ = [
+        ("iteration", C.c_int), ("step_is_successful", C.c_int), ("linear_solver_iterations", C.c_int),
+        ("reserved", C.c_int), ("cost", C.c_double), ("cost_change", C.c_double), ("gradient_max_norm", C.c_double),
+        ("step_norm", C.c_double), ("relative_decrease", C.c_double), ("trust_region_radius", C.c_double),
+    ]
+
+
+RECORD_DTYPE = np.dtype([
+    ("iteration", np.int32), ("step_is_successful", np.int32), ("linear_solver_iterations", np.int32),
+    ("reserved", np.int32), ("cost", np.float64), ("cost_change", np.float64), ("gradient_max_norm", np.float64),
+    ("step_norm", np.float64), ("relative_decrease", np.float64), ("trust_region_radius", np.float64)])
+
+_lib = None
+
+
+def build(force=False):
+    """Compiles csrc/ into libpgo_hip.so with hipcc --offload-arch=gfx950 (works without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    deps = [os.path.join(src, f) for f in os.listdir(src)] + [os.path.join(_HERE, "..", "include", "pgo.h")]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps)
+    if force or stale:
+        subprocess.check_call(["make", "-C", src] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def lib():
+    """Loads libpgo_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PgoError(ERR_NO_DEVICE, "%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                                          "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.pgo_last_error.restype = C.c_char_p
+        L.pgo_problem_create.restype = C.c_void_p
+        L.pgo_problem_destroy.argtypes = [C.c_void_p]
+        L.pgo_summary_full_report.restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise PgoError(rc, lib().pgo_last_error().decode())
+    return rc
+
+
+def device_count():
+    return lib().pgo_device_count()
+
+
+def set_device(i):
+    _check(lib().pgo_set_device(C.c_int(i)))
+
+
+def shard_range(n, rank, world):
+    b, e = C.c_longlong(0), C.c_longlong(0)
+    _check(lib().pgo_shard_range(C.c_longlong(n), C.c_int(rank), C.c_int(world), C.byref(b), C.byref(e)))
+    return b.value, e.value
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class SolverOptions:
+    """ceres::Solver::Options (fields the path reads)."""
+
+    def __init__(self, **kw):
+        self.c = _COptions()
+        lib().pgo_solver_options_init(C.byref(self.c))
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def __getattr__(self, k):
+        if k != "c" and hasattr(_COptions, k):
+            return getattr(self.c, k)
+        raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        if k == "c":
+            object.__setattr__(self, k, v)
+        elif hasattr(_COptions, k):
+            setattr(self.c, k, v)
+        else:
+            raise AttributeError("unknown solver option %r" % k)
+
+
+class Summary:
+    """ceres::Solver::Summary."""
+
+    def __init__(self, c, records):
+        self.c = c
+        self.iterations = records
+
+    def __getattr__(self, k):
+        if k not in ("c", "iterations") and hasattr(_CSummary, k):
+            v = getattr(self.c, k)
+            return v.decode() if isinstance(v, bytes) else v
+        raise AttributeError(k)
+
+    def is_solution_usable(self):
+        return bool(lib().pgo_summary_is_solution_usable(C.byref(self.c)))
+
+    def full_report(self):
+        n = len(self.iterations)
+        rec = (_CRecord * max(n, 1)).from_buffer_copy(self.iterations.tobytes() if n else bytes(C.sizeof(_CRecord)))
+        need = lib().pgo_summary_full_report(C.byref(self.c), rec, C.c_int(n), None, C.c_size_t(0))
+        buf = C.create_string_buffer(need)
+        lib().pgo_summary_full_report(C.byref(self.c), rec, C.c_int(n), buf, C.c_size_t(need))
+        return buf.value.decode()
+
+
+class Problem:
+    """ceres::Problem restricted to the reference's use: SE(3) poses + between-factor residual blocks."""
+
+    def __init__(self):
+        self._h = C.c_void_p(lib().pgo_problem_create())
+        if not self._h:
+            raise MemoryError("pgo_problem_create failed")
+        self._keep = []       # parameter memory must outlive the problem (Ceres: user owns parameters)
+        self.poses = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().pgo_problem_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def add_poses(self, poses):
+        """poses: (N,7) float64 C-contiguous array px py pz qx qy qz qw; updated IN PLACE by solve()."""
+        if not (isinstance(poses, np.ndarray) and poses.dtype == np.float64 and poses.ndim == 2 and poses.shape[1] == 7
+                and poses.flags["C_CONTIGUOUS"]):
+            raise ValueError("poses must be a C-contiguous float64 (N,7) array")
+        self._keep.append(poses)
+        if self.poses is None:
+            self.poses = poses
+        return _check(lib().pgo_problem_add_poses(self._h, C.c_int(poses.shape[0]), _dp(poses), C.c_int(7)))
+
+    def add_se3_between(self, id_begin, id_end, t_be, sqrt_information=None):
+        ia = np.ascontiguousarray(id_begin, dtype=np.int32).reshape(-1)
+        ib = np.ascontiguousarray(id_end, dtype=np.int32).reshape(-1)
+        t = np.ascontiguousarray(t_be, dtype=np.float64).reshape(-1, 7)
+        si = None if sqrt_information is None else np.ascontiguousarray(sqrt_information, dtype=np.float64).reshape(-1, 36)
+        if not (len(ia) == len(ib) == len(t)) or (si is not None and len(si) != len(ia)):
+            raise ValueError("edge arrays disagree in length")
+        return _check(lib().pgo_problem_add_se3_between_batch(self._h, C.c_int(len(ia)), _ip(ia), _ip(ib), _dp(t), _dp(si)))
+
+    def set_loss(self, kind, a=1.0):
+        _check(lib().pgo_problem_set_loss(self._h, C.c_int(kind), C.c_double(a)))
+
+    def set_pose_constant(self, pose, which=3):
+        _check(lib().pgo_problem_set_pose_constant(self._h, C.c_int(pose), C.c_int(which)))
+
+    @property
+    def num_poses(self):
+        return lib().pgo_problem_num_poses(self._h)
+
+    @property
+    def num_edges(self):
+        return lib().pgo_problem_num_edges(self._h)
+
+    # ---- evaluation (Problem::Evaluate analogue) ----
+    def evaluate(self, residuals=True, jacobians=True, gradient=True):
+        N, E = self.num_poses, self.num_edges
+        cost = C.c_double(0)
+        r = np.zeros((E, 6)) if residuals else None
+        ja = np.zeros((E, 6, 6)) if jacobians else None
+        jb = np.zeros((E, 6, 6)) if jacobians else None
+        g = np.zeros((N, 6)) if gradient else None
+        _check(lib().pgo_evaluate(self._h, C.byref(cost), _dp(r), _dp(ja), _dp(jb), _dp(g)))
+        return cost.value, r, ja, jb, g
+
+    def normal_equations(self):
+        N, E = self.num_poses, self.num_edges
+        diag, off, g = np.zeros((N, 6, 6)), np.zeros((E, 6, 6)), np.zeros((N, 6))
+        _check(lib().pgo_normal_equations(self._h, _dp(diag), _dp(off), _dp(g)))
+        return diag, off, g
+
+    def linear_solve(self, d2, b, options=None):
+        options = options or SolverOptions()
+        N = self.num_poses
+        d2 = np.ascontiguousarray(d2, dtype=np.float64).reshape(N * 6)
+        b = np.ascontiguousarray(b, dtype=np.float64).reshape(N * 6)
+        x = np.zeros(N * 6)
+        it = C.c_int(0)
+        _check(lib().pgo_linear_solve(self._h, C.byref(options.c), _dp(d2), _dp(b), _dp(x), C.byref(it)))
+        return x, it.value
+
+    def plus(self, delta):
+        delta = np.ascontiguousarray(delta, dtype=np.float64).reshape(self.num_poses * 6)
+        _check(lib().pgo_plus(self._h, _dp(delta)))
+
+    # ---- device-resident stepping (benchmarks) ----
+    def solver_begin(self, options):
+        _check(lib().pgo_solver_begin(self._h, C.byref(options.c)))
+
+    def solver_step(self, n):
+        done = C.c_int(0)
+        _check(lib().pgo_solver_step(self._h, C.c_int(n), C.byref(done)))
+        return bool(done.value)
+
+    def solver_reset(self):
+        _check(lib().pgo_solver_reset(self._h))
+
+    def solver_end(self, records_capacity=4096):
+        s = _CSummary()
+        rec = (_CRecord * records_capacity)()
+        _check(lib().pgo_solver_end(self._h, C.byref(s), rec, C.c_int(records_capacity)))
+        n = min(s.num_iterations, records_capacity)
+        return Summary(s, np.frombuffer(bytes(rec), dtype=RECORD_DTYPE)[:n].copy())
+
+    def time_kernel(self, name, repeats=100):
+        ms = C.c_double(0)
+        _check(lib().pgo_time_kernel(self._h, name.encode(), C.c_int(repeats), C.byref(ms)))
+        return ms.value
+
+
+def solve(options, problem, records_capacity=4096):
+    """ceres::Solve(options, &problem, &summary): runs LM on the GPU, updates the pose arrays in place."""
+    s = _CSummary()
+    rec = (_CRecord * records_capacity)()
+    _check(lib().pgo_solve(problem._h, C.byref(options.c), C.byref(s), rec, C.c_int(records_capacity)))
+    n = min(s.num_iterations, records_capacity)
+    return Summary(s, np.frombuffer(bytes(rec), dtype=RECORD_DTYPE)[:n].copy())
+
+
+def problem_from_graph(g, loss=HUBER, loss_a=1.0, constant_first=True):
+    """Mirror of BuildOptimizationProblem (finial.cpp:491-528) for array inputs; g has poses/ia/ib/meas/sqrt_info.
+    Returns (problem, poses_array_updated_in_place)."""
+    poses = np.array(g.poses, dtype=np.float64, order="C", copy=True)
+    p = Problem()
+    p.add_poses(poses)
+    p.add_se3_between(g.ia, g.ib, g.meas, g.sqrt_info)
+    p.set_loss(loss, loss_a)
+    if constant_first:
+        p.set_pose_constant(0, 3)
+    return p, poses

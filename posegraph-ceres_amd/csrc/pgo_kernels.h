@@ -1,0 +1,131 @@
+// pgo_kernels.h — launch interface between the host LM driver (pgo_solver.cpp) and the gfx950
+// kernels (pgo_kernels.hip).  Plain structs of device pointers; no torch types.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pgo {
+
+// Pose storage: 8 doubles per pose (px py pz qx qy qz qw pad) = one 64-byte line per gather.
+enum { POSE_STRIDE = 8 };
+// bsr_val tile layout: 64 slots per tile, 36 doubles per slot, element k of slot t at
+//   (t>>6)*2304 + (k>>1)*128 + (t&63)*2 + (k&1)          (16 B per lane per access, 1 KiB per wave)
+enum { TILE_DOUBLES = 36 * 64 };
+__host__ __device__ inline size_t bsr_index(int slot, int k) {
+  return (size_t)(slot >> 6) * TILE_DOUBLES + (size_t)(k >> 1) * 128 + (size_t)(slot & 63) * 2 + (k & 1);
+}
+
+enum SlotSide : uint8_t { SIDE_BEGIN = 0, SIDE_END = 1, SIDE_DIAG = 2, SIDE_PAD = 3 };
+
+// Scalars the host reads once per LM iteration (pinned, device-visible).
+struct LmScalars {
+  double cand_cost;        // 0.5 * sum rho(s) at the candidate point
+  double model_change;     // -(J~ step)'(r + J~ step / 2)
+  double step_norm_sq;     // |x - x_cand|^2 in the ambient space, non-constant blocks
+  double x_norm_sq;        // |x|^2 ambient, non-constant blocks
+  double gradient_max;     // |x - Plus(x, -g)|_inf
+  double cg_residual_sq;   // |b - A x|^2 from the CG recurrence
+  int cg_iterations;
+  int cg_status;           // 0 ok, 1 p'q <= 0 (no further progress), 2 non-finite
+  int linearize_bad;       // non-finite values seen while linearising
+  int pad;
+};
+
+struct CgState {
+  int done;        // set by the first kernel that decides to stop; later kernels exit at once
+  int iters;       // CG iterations completed when `done` was set
+  int status;      // as LmScalars::cg_status
+  int cnt_a;       // iteration index published by the SpMV kernel for the update kernel
+  int cnt_b;       // iterations completed, published by the update kernel for the next SpMV
+  int pad[3];
+};
+
+struct DeviceGraph {
+  int N, E;
+  int n_wg;          // workgroups of the row partition
+  int n_slots;       // padded (multiple of block)
+  int block;         // threads per workgroup of the row-partitioned kernels = slots per chunk
+  int info_mode;     // 0 identity information, 1 general W = L^T L
+  int loss_kind;
+  double loss_a;
+
+  // static topology
+  const int* slot_col;        // [n_slots] pose index of the block column (self for the diagonal slot), -1 pad
+  const int* slot_row;        // [n_slots] pose index of the row
+  const uint8_t* slot_side;   // [n_slots] SlotSide
+  const int* wg_slot_begin;   // [n_wg+1]
+  const int* wg_row_begin;    // [n_wg+1]
+  const int* row_slot_begin;  // [N]
+  const int* row_slot_cnt;    // [N]
+  const uint8_t* cmask;       // [N] bit0: p constant, bit1: q constant
+  // measurements, slot order (component major: [c][n_slots]) and edge order ([c][E])
+  const double* smeas;        // 7 x n_slots
+  const double* sW;           // 21 x n_slots (upper triangle of L^T L, row-major order) or null
+  const int* edge_a;          // [E]
+  const int* edge_b;          // [E]
+  const double* emeas;        // 7 x E
+  const double* eW;           // 21 x E or null
+  const double* eL;           // 36 x E (sqrt information, row-major element major) or null
+
+  // state
+  double* pose_x;     // [N][8] current iterate
+  double* pose_c;     // [N][8] candidate
+  double* bsr_val;    // tile layout, n_slots slots
+  double* Hdiag;      // [N][36] scaled Gauss-Newton diagonal blocks (no damping)
+  double* Minv;       // [N][36] (Hdiag + D^2)^-1
+  double* grad;       // [6N] unscaled gradient J'r
+  double* scale;      // [6N] Jacobi column scaling
+  double* d2;         // [6N] LM diagonal squared
+  double* diag_clamped;  // [6N] clamp(diag(H~), min, max) kept while the diagonal is reused
+  double* cg_b;       // [6N] rhs = S g
+  double* cg_x;       // [6N]
+  double* cg_r;       // [6N]
+  double* cg_z;       // [6N]
+  double* cg_q;       // [6N]
+  double* cg_p0;      // [6N] p ping
+  double* cg_p1;      // [6N] p pong
+  double* delta;      // [6N] tangent step actually applied (S * step)
+  // partial sums
+  double* part_rz;    // [2][n_part]
+  double* part_q;     // [2][n_part]
+  double* part_pq;    // [n_part]
+  double* part_rr;    // [2][n_part]  |r|^2
+  double* part_bb;    // [n_part]     |b|^2 (written by pcg_init)
+  double* part_misc;  // [8][n_part] scratch partials for LM scalars
+  int n_part;         // capacity of one partial row (>= max grid of any reducing kernel)
+  int n_vec_wg;       // grid of the element-wise kernels (6N lanes)
+  int n_edge_wg;      // grid of edge-parallel kernels
+  int n_pose_wg;      // grid of pose-parallel kernels
+  CgState* cg;        // device
+  LmScalars* scal;    // device-visible pinned host memory
+  int* flags;         // [4] device flags: [0] linearize saw non-finite
+};
+
+struct CgParams {
+  double q_tolerance;   // eta
+  double r_tolerance;   // |r| <= r_tolerance * |b| stop; negative disables (Ceres LM passes -1)
+  int max_iterations;
+  int min_iterations;
+};
+
+// launches (all asynchronous on `s`)
+void launch_linearize(const DeviceGraph& g, hipStream_t s);
+void launch_scale_from_diag(const DeviceGraph& g, hipStream_t s);
+void launch_damping(const DeviceGraph& g, double radius, double min_diag, double max_diag, int mode, hipStream_t s);
+void launch_cost(const DeviceGraph& g, const double* poses, int part_row, hipStream_t s);
+void launch_evaluate_edges(const DeviceGraph& g, const double* poses, double* res, double* ja, double* jb, hipStream_t s);
+void launch_pcg_init(const DeviceGraph& g, hipStream_t s);
+void launch_pcg_iteration(const DeviceGraph& g, const CgParams& p, hipStream_t s);   // SpMV + update kernels
+void launch_pcg_finish(const DeviceGraph& g, const CgParams& p, hipStream_t s);      // final termination bookkeeping
+void launch_model_and_retract(const DeviceGraph& g, hipStream_t s);                  // A x, model change, delta, candidate
+void launch_gradient_norm(const DeviceGraph& g, hipStream_t s);
+void launch_finalize_scalars(const DeviceGraph& g, int n_cost_part, hipStream_t s);
+void launch_apply_step(const DeviceGraph& g, const double* step, hipStream_t s);     // for tests: delta -> candidate
+void launch_spmv_plain(const DeviceGraph& g, hipStream_t s);
+void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, hipStream_t s);
+void launch_pcg_update_only(const DeviceGraph& g, hipStream_t s);
+int vec_block();
+int pose_block();
+int edge_block();
+
+}  // namespace pgo

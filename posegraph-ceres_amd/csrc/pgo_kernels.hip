@@ -1,0 +1,841 @@
+// pgo_kernels.hip — gfx950 (MI355X / CDNA4) kernels of the pose-graph NLLS hot path.
+//
+// Reference behaviour implemented (never its code): PLUS/include/PoseGraph3dError.h:21-54 residual,
+// finial.cpp:491-544 problem/solver set-up, Ceres 1.13 semantics restated in SURVEY.md Appendix A.
+//
+// Design: the normal equations are kept as a block-sparse row matrix whose block
+// slots ARE the pose-graph incidences.  Row v owns one diagonal slot plus one slot per incident edge;
+// rows are packed into workgroups of `block` slots.  One lane owns one slot:
+//   * k_linearize   : lane recomputes the edge geometry from the two 64-byte pose records, forms its
+//                     off-diagonal 6x6 block (written as 18 x 16 B, 1 KiB per wave instruction) and
+//                     its 21+6 contribution to the row's diagonal block / gradient, which are summed
+//                     per row through LDS in a fixed order (deterministic, no FP64 atomics).
+//   * k_pcg_spmv    : lane multiplies its block with the gathered 6-vector, LDS segmented row sums.
+// Everything is FP64 and HBM/L2 bound; MFMA is deliberately not used for 6x6 blocks.
+#include "pgo_kernels.h"
+#include "pgo_math.h"
+
+namespace pgo {
+
+namespace {
+
+constexpr int VEC_BLOCK = 192;  // 32 poses x 6 tangent dims: a pose never straddles a workgroup
+constexpr int POSE_BLOCK = 256;
+constexpr int EDGE_BLOCK = 256;
+constexpr int NV_LIN = 27;      // 21 (symmetric diagonal block) + 6 (gradient)
+constexpr int SPMV_LDS_STRIDE = 7;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+
+// Sum NV values over the workgroup in a fixed order; every thread gets the totals.
+// scratch: >= NV * (blockDim/64) doubles of LDS.  Ends with a barrier so scratch can be reused.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const double s = wave_sum(v[k]);
+    if (lane == 0) scratch[wave * NV + k] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double s = 0.0;
+    for (int w = 0; w < nw; ++w) s += scratch[w * NV + k];
+    v[k] = s;
+  }
+  __syncthreads();
+}
+
+// Strided sum of an array of partials by the whole workgroup (fixed order -> deterministic).
+__device__ __forceinline__ double partial_sum(const double* p, int n) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += p[i];
+  return s;
+}
+
+struct PoseRec { V3 p; Q4 q; };
+__device__ __forceinline__ PoseRec load_pose(const double* poses, int v) {
+  const double2* s = reinterpret_cast<const double2*>(poses + (size_t)POSE_STRIDE * v);
+  const double2 a = s[0], b = s[1], c = s[2], d = s[3];
+  return PoseRec{V3{a.x, a.y, b.x}, Q4{b.y, c.x, c.y, d.x}};
+}
+
+__device__ __forceinline__ int upper_index(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+
+struct WBlocks { M3 pp, pr, rr; };
+__device__ __forceinline__ WBlocks load_W(const double* W, size_t stride, size_t idx) {
+  double u[21];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) u[k] = W[(size_t)k * stride + idx];
+  WBlocks w;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      w.pp.m[3 * i + j] = (i <= j) ? u[upper_index(i, j)] : u[upper_index(j, i)];
+      w.pr.m[3 * i + j] = u[upper_index(i, 3 + j)];
+      w.rr.m[3 * i + j] = (i <= j) ? u[upper_index(3 + i, 3 + j)] : u[upper_index(3 + j, 3 + i)];
+    }
+  return w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_linearize: residual + closed-form Jacobians + Huber corrector + J^T J / J^T r, fused.
+// ------------------------------------------------------------------------------------------------
+template <int INFO>
+__global__ __launch_bounds__(256) void k_linearize(DeviceGraph g) {
+  extern __shared__ double lds[];  // NV_LIN * block
+  const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
+  const int s_begin = g.wg_slot_begin[wg], s_end = g.wg_slot_begin[wg + 1];
+  const int r0 = g.wg_row_begin[wg], nrows = g.wg_row_begin[wg + 1] - r0;
+  const bool single = (s_end - s_begin) == B;
+  double acc = 0.0;
+
+  for (int cb = s_begin; cb < s_end; cb += B) {
+    const int t = cb + tid;
+    const uint8_t side = g.slot_side[t];
+    double v[NV_LIN];
+#pragma unroll
+    for (int k = 0; k < NV_LIN; ++k) v[k] = 0.0;
+
+    if (side <= SIDE_END) {
+      const int row = g.slot_row[t], col = g.slot_col[t];
+      const int a = (side == SIDE_BEGIN) ? row : col;
+      const int b = (side == SIDE_BEGIN) ? col : row;
+      const PoseRec A = load_pose(g.pose_x, a), Bp = load_pose(g.pose_x, b);
+      const size_t ns = (size_t)g.n_slots;
+      const V3 mp{g.smeas[t], g.smeas[ns + t], g.smeas[2 * ns + t]};
+      const Q4 mq{g.smeas[3 * ns + t], g.smeas[4 * ns + t], g.smeas[5 * ns + t], g.smeas[6 * ns + t]};
+      const EdgeGeom eg = edge_geometry(A.p, A.q, Bp.p, Bp.q, mp, mq);
+      const V3 ep{eg.e[0], eg.e[1], eg.e[2]}, er{eg.e[3], eg.e[4], eg.e[5]};
+
+      V3 wep, wer;
+      M3 C1, C2, RU, GP, MQ, GU;
+      if (INFO) {
+        const WBlocks W = load_W(g.sW, ns, (size_t)t);
+        const V3 a1 = mulv(W.pp, ep), a2 = mulv(W.pr, er), b1 = mulTv(W.pr, ep), b2 = mulv(W.rr, er);
+        wep = V3{a1.x + a2.x, a1.y + a2.y, a1.z + a2.z};
+        wer = V3{b1.x + b2.x, b1.y + b2.y, b1.z + b2.z};
+        const M3 X = mul(W.pp, eg.Rt), P = mul(W.pr, eg.M), Qm = mul(W.rr, eg.M), U = mul(W.pp, eg.G);
+        C1 = mulT(eg.Rt, X); C2 = mulT(eg.Rt, P); RU = mulT(eg.Rt, U);
+        GP = mulT(eg.G, P); MQ = mulT(eg.M, Qm); GU = mulT(eg.G, U);
+      } else {
+        wep = ep; wer = er;
+        C1 = mulT(eg.Rt, eg.Rt); RU = mulT(eg.Rt, eg.G); MQ = mulT(eg.M, eg.M); GU = mulT(eg.G, eg.G);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { C2.m[k] = 0.0; GP.m[k] = 0.0; }
+      }
+      const double s = dot(ep, wep) + dot(er, wer);
+      double rho0, rho1;
+      loss_eval(g.loss_kind, g.loss_a, s, &rho0, &rho1);
+
+      // 6x6 results for this row: off-diagonal block, own diagonal contribution, own gradient
+      double off[36], dg[36], gv[6];
+      const M3 RU2C2 = axpby(1.0, RU, 2.0, C2);          // Rt^T (U + 2P)
+      const M3 GP4MQ = axpby(2.0, GP, 4.0, MQ);          // 2 G^T P + 4 M^T Qm
+      const V3 rtw = mulTv(eg.Rt, wep), gtw = mulTv(eg.G, wep), mtw = mulTv(eg.M, wer);
+      if (side == SIDE_BEGIN) {
+        // H_ab = [ -C1 , 2C2 ; (RU+2C2)^T , -(2GP+4MQ) ]    H_aa = [ C1 , -(RU+2C2) ; sym , GU + 2(GP+GP^T) + 4MQ ]
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            off[6 * i + j] = -C1.m[3 * i + j];
+            off[6 * i + 3 + j] = 2.0 * C2.m[3 * i + j];
+            off[6 * (3 + i) + j] = RU2C2.m[3 * j + i];
+            off[6 * (3 + i) + 3 + j] = -GP4MQ.m[3 * i + j];
+            dg[6 * i + j] = C1.m[3 * i + j];
+            dg[6 * i + 3 + j] = -RU2C2.m[3 * i + j];
+            dg[6 * (3 + i) + j] = -RU2C2.m[3 * j + i];
+            dg[6 * (3 + i) + 3 + j] = GU.m[3 * i + j] + 2.0 * (GP.m[3 * i + j] + GP.m[3 * j + i]) + 4.0 * MQ.m[3 * i + j];
+          }
+        gv[0] = -rtw.x; gv[1] = -rtw.y; gv[2] = -rtw.z;
+        gv[3] = gtw.x + 2.0 * mtw.x; gv[4] = gtw.y + 2.0 * mtw.y; gv[5] = gtw.z + 2.0 * mtw.z;
+      } else {
+        // H_ba = H_ab^T                                      H_bb = [ C1 , -2C2 ; -2C2^T , 4MQ ]
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            off[6 * i + j] = -C1.m[3 * j + i];
+            off[6 * i + 3 + j] = RU2C2.m[3 * i + j];
+            off[6 * (3 + i) + j] = 2.0 * C2.m[3 * j + i];
+            off[6 * (3 + i) + 3 + j] = -GP4MQ.m[3 * j + i];
+            dg[6 * i + j] = C1.m[3 * i + j];
+            dg[6 * i + 3 + j] = -2.0 * C2.m[3 * i + j];
+            dg[6 * (3 + i) + j] = -2.0 * C2.m[3 * j + i];
+            dg[6 * (3 + i) + 3 + j] = 4.0 * MQ.m[3 * i + j];
+          }
+        gv[0] = rtw.x; gv[1] = rtw.y; gv[2] = rtw.z;
+        gv[3] = -2.0 * mtw.x; gv[4] = -2.0 * mtw.y; gv[5] = -2.0 * mtw.z;
+      }
+      // constant parameter blocks drop out of the program; Jacobi column scaling S
+      const uint8_t m_own = g.cmask[row], m_oth = g.cmask[col];
+      double so[6], st[6], mo[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const bool co = (i < 3) ? (m_own & 1) : (m_own & 2);
+        const bool ct = (i < 3) ? (m_oth & 1) : (m_oth & 2);
+        mo[i] = co ? 0.0 : 1.0;
+        so[i] = co ? 0.0 : g.scale[6 * (size_t)row + i];
+        st[i] = ct ? 0.0 : g.scale[6 * (size_t)col + i];
+      }
+      double2* out = reinterpret_cast<double2*>(g.bsr_val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+#pragma unroll
+      for (int kk = 0; kk < 18; ++kk) {
+        const int k0 = 2 * kk, k1 = 2 * kk + 1;
+        double2 w;
+        w.x = rho1 * so[k0 / 6] * st[k0 % 6] * off[k0];
+        w.y = rho1 * so[k1 / 6] * st[k1 % 6] * off[k1];
+        out[(size_t)kk * 64] = w;
+      }
+      int k = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) v[k++] = rho1 * so[i] * so[j] * dg[6 * i + j];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v[21 + i] = rho1 * mo[i] * gv[i];
+    }
+
+#pragma unroll
+    for (int k = 0; k < NV_LIN; ++k) lds[tid * NV_LIN + k] = v[k];
+    __syncthreads();
+    for (int idx = tid; idx < nrows * NV_LIN; idx += B) {
+      const int rl = idx / NV_LIN, k = idx - rl * NV_LIN;
+      const int row = r0 + rl;
+      const int rb = g.row_slot_begin[row];
+      const int sb = max(rb, cb) - cb, se = min(rb + g.row_slot_cnt[row], cb + B) - cb;
+      double s = 0.0;
+      for (int j = sb; j < se; ++j) s += lds[j * NV_LIN + k];
+      if (single) {
+        if (k < 21) {
+          // k -> (i,j) of the upper triangle
+          int i = 0, base = 0;
+          while (k >= base + (6 - i)) { base += 6 - i; ++i; }
+          const int j = i + (k - base);
+          if (i == j) {
+            const bool c = (i < 3) ? (g.cmask[row] & 1) : (g.cmask[row] & 2);
+            if (c) s = 1.0;  // unit diagonal keeps the constant dims decoupled and the block SPD
+          }
+          g.Hdiag[36 * (size_t)row + 6 * i + j] = s;
+          g.Hdiag[36 * (size_t)row + 6 * j + i] = s;
+        } else {
+          g.grad[6 * (size_t)row + (k - 21)] = s;
+        }
+      } else {
+        acc += s;
+      }
+    }
+    __syncthreads();
+  }
+  if (!single && tid < NV_LIN) {
+    const int row = r0, k = tid;
+    double s = acc;
+    if (k < 21) {
+      int i = 0, base = 0;
+      while (k >= base + (6 - i)) { base += 6 - i; ++i; }
+      const int j = i + (k - base);
+      if (i == j) {
+        const bool c = (i < 3) ? (g.cmask[row] & 1) : (g.cmask[row] & 2);
+        if (c) s = 1.0;
+      }
+      g.Hdiag[36 * (size_t)row + 6 * i + j] = s;
+      g.Hdiag[36 * (size_t)row + 6 * j + i] = s;
+    } else {
+      g.grad[6 * (size_t)row + (k - 21)] = s;
+    }
+  }
+}
+
+// Jacobi scaling, computed once at iteration 0 from the unscaled diag(J^T J):  S = 1 / (1 + sqrt(d)).
+__global__ void k_scale_from_diag(DeviceGraph g) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 6 * g.N) return;
+  const int v = idx / 6, i = idx - 6 * v;
+  const bool c = (i < 3) ? (g.cmask[v] & 1) : (g.cmask[v] & 2);
+  const double d = c ? 0.0 : g.Hdiag[36 * (size_t)v + 7 * i];
+  g.scale[idx] = 1.0 / (1.0 + sqrt(d));
+}
+
+// LM damping (LevenbergMarquardtStrategy::ComputeStep) per pose:
+//   D^2 = clamp(diag(H~)) / radius, A_vv = H~_vv + D^2 -> diagonal BSR slot, M_v = A_vv^-1.
+// mode 0: clamp fresh, 1: reuse the clamped diagonal (rejected step), 2: take g.d2 as given (tests)
+__global__ void k_damping(DeviceGraph g, double radius, double min_diag, double max_diag, int mode) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= g.N) return;
+  double A[36];
+  const double2* src = reinterpret_cast<const double2*>(g.Hdiag + 36 * (size_t)v);
+#pragma unroll
+  for (int k = 0; k < 18; ++k) { const double2 t = src[k]; A[2 * k] = t.x; A[2 * k + 1] = t.y; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double d2;
+    if (mode == 2) {
+      d2 = g.d2[6 * (size_t)v + i];
+    } else {
+      double dc;
+      if (mode == 1) dc = g.diag_clamped[6 * (size_t)v + i];
+      else { dc = fmin(fmax(A[7 * i], min_diag), max_diag); g.diag_clamped[6 * (size_t)v + i] = dc; }
+      d2 = dc / radius;
+      g.d2[6 * (size_t)v + i] = d2;
+    }
+    A[7 * i] += d2;
+  }
+  const int slot = g.row_slot_begin[v];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) g.bsr_val[bsr_index(slot, k)] = A[k];
+  double Ai[36];
+  if (!spd6_inverse(A, Ai)) atomicOr(&g.flags[1], 1);
+  double2* dst = reinterpret_cast<double2*>(g.Minv + 36 * (size_t)v);
+#pragma unroll
+  for (int k = 0; k < 18; ++k) dst[k] = double2{Ai[2 * k], Ai[2 * k + 1]};
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cost only: 0.5 * sum rho(|L e|^2) over edges at `poses` (ComputeCandidatePointAndEvaluateCost).
+// ------------------------------------------------------------------------------------------------
+template <int INFO>
+__global__ void k_cost(DeviceGraph g, const double* poses, double* part) {
+  __shared__ double scratch[8];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  double c[1] = {0.0};
+  if (e < g.E) {
+    const PoseRec A = load_pose(poses, g.edge_a[e]), B = load_pose(poses, g.edge_b[e]);
+    const size_t E = (size_t)g.E;
+    const V3 mp{g.emeas[e], g.emeas[E + e], g.emeas[2 * E + e]};
+    const Q4 mq{g.emeas[3 * E + e], g.emeas[4 * E + e], g.emeas[5 * E + e], g.emeas[6 * E + e]};
+    double er[6];
+    edge_error(A.p, A.q, B.p, B.q, mp, mq, er);
+    double s;
+    if (INFO) {
+      const WBlocks W = load_W(g.eW, E, (size_t)e);
+      const V3 ep{er[0], er[1], er[2]}, eq{er[3], er[4], er[5]};
+      const V3 a1 = mulv(W.pp, ep), a2 = mulv(W.pr, eq), b1 = mulTv(W.pr, ep), b2 = mulv(W.rr, eq);
+      s = dot(ep, V3{a1.x + a2.x, a1.y + a2.y, a1.z + a2.z}) + dot(eq, V3{b1.x + b2.x, b1.y + b2.y, b1.z + b2.z});
+    } else {
+      s = er[0] * er[0] + er[1] * er[1] + er[2] * er[2] + er[3] * er[3] + er[4] * er[4] + er[5] * er[5];
+    }
+    double rho0, rho1;
+    loss_eval(g.loss_kind, g.loss_a, s, &rho0, &rho1);
+    c[0] = 0.5 * rho0;
+  }
+  block_sum<1>(c, scratch);
+  if (threadIdx.x == 0) part[blockIdx.x] = c[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Materialising evaluation (the Problem::Evaluate analogue): per edge r (6), J_begin, J_end (6x6
+// row-major, local tangent columns [dp|dtheta]) with the loss corrector and constant masks applied.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_evaluate_edges(DeviceGraph g, const double* poses, double* res, double* ja, double* jb) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= g.E) return;
+  const int a = g.edge_a[e], b = g.edge_b[e];
+  const PoseRec A = load_pose(poses, a), B = load_pose(poses, b);
+  const size_t E = (size_t)g.E;
+  const V3 mp{g.emeas[e], g.emeas[E + e], g.emeas[2 * E + e]};
+  const Q4 mq{g.emeas[3 * E + e], g.emeas[4 * E + e], g.emeas[5 * E + e], g.emeas[6 * E + e]};
+  const EdgeGeom eg = edge_geometry(A.p, A.q, B.p, B.q, mp, mq);
+  double Aa[36], Ab[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) { Aa[k] = 0.0; Ab[k] = 0.0; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Aa[6 * i + j] = -eg.Rt.m[3 * i + j];
+      Aa[6 * i + 3 + j] = eg.G.m[3 * i + j];
+      Aa[6 * (3 + i) + 3 + j] = 2.0 * eg.M.m[3 * i + j];
+      Ab[6 * i + j] = eg.Rt.m[3 * i + j];
+      Ab[6 * (3 + i) + 3 + j] = -2.0 * eg.M.m[3 * i + j];
+    }
+  double L[36];
+  if (g.eL) {
+#pragma unroll
+    for (int k = 0; k < 36; ++k) L[k] = g.eL[(size_t)k * E + e];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 36; ++k) L[k] = (k % 7 == 0) ? 1.0 : 0.0;
+  }
+  double r[6], s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) t += L[6 * i + j] * eg.e[j];
+    r[i] = t;
+    s += t * t;
+  }
+  double rho0, rho1;
+  loss_eval(g.loss_kind, g.loss_a, s, &rho0, &rho1);
+  const double sc = sqrt(rho1);
+  const uint8_t ma = g.cmask[a], mb = g.cmask[b];
+  if (res) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) res[6 * (size_t)e + i] = sc * r[i];
+  }
+  if (ja || jb) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double ta = 0.0, tb = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { ta += L[6 * i + j] * Aa[6 * j + c]; tb += L[6 * i + j] * Ab[6 * j + c]; }
+        const bool ca = (c < 3) ? (ma & 1) : (ma & 2);
+        const bool cb = (c < 3) ? (mb & 1) : (mb & 2);
+        if (ja) ja[36 * (size_t)e + 6 * i + c] = ca ? 0.0 : sc * ta;
+        if (jb) jb[36 * (size_t)e + 6 * i + c] = cb ? 0.0 : sc * tb;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block-Jacobi preconditioned CG on (H~ + D^2) x = S g   [Ceres 1.13 ConjugateGradientsSolver with
+// the Nash-Sofer Q-tolerance stop, SURVEY §7.2 #1].  Two kernels per iteration; all scalars are
+// re-derived by every workgroup from per-workgroup partial sums (fixed order), so there is no host
+// round trip, no atomics and no grid barrier inside the iteration.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pcg_init(DeviceGraph g) {
+  __shared__ double rl[VEC_BLOCK];
+  __shared__ double scratch[16];
+  const int tid = threadIdx.x;
+  double acc[2] = {0.0, 0.0};
+  for (int base = blockIdx.x * VEC_BLOCK; base < 6 * g.N; base += gridDim.x * VEC_BLOCK) {
+    const int idx = base + tid;
+    const bool live = idx < 6 * g.N;
+    double b = 0.0;
+    if (live) {
+      b = g.scale[idx] * g.grad[idx];
+      g.cg_b[idx] = b;
+      g.cg_x[idx] = 0.0;
+      g.cg_r[idx] = b;
+      g.cg_p0[idx] = 0.0;
+      g.cg_p1[idx] = 0.0;
+    }
+    rl[tid] = b;
+    __syncthreads();
+    if (live) {
+      const int v = idx / 6, c = idx - 6 * v, lv = tid / 6;
+      const double* Mi = g.Minv + 36 * (size_t)v + 6 * c;
+      double z = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) z += Mi[k] * rl[6 * lv + k];
+      g.cg_z[idx] = z;
+      acc[0] += b * z;
+      acc[1] += b * b;
+    }
+    __syncthreads();
+  }
+  block_sum<2>(acc, scratch);
+  if (tid == 0) {
+    g.part_rz[blockIdx.x] = acc[0];
+    g.part_rz[g.n_part + blockIdx.x] = 0.0;
+    g.part_bb[blockIdx.x] = acc[1];
+    g.part_rr[blockIdx.x] = acc[1];
+    g.part_rr[g.n_part + blockIdx.x] = acc[1];
+    g.part_q[blockIdx.x] = 0.0;
+    g.part_q[g.n_part + blockIdx.x] = 0.0;
+    if (blockIdx.x == 0) {
+      g.cg->done = 0; g.cg->iters = 0; g.cg->status = 0; g.cg->cnt_a = 0; g.cg->cnt_b = 0;
+    }
+  }
+}
+
+// Row-partitioned block SpMV: dst_row = sum_slots B_slot * src[col].  MODE 0: PCG step
+// (src = z + beta p_old, also writes p_new, partial p'q).  MODE 1: plain q = A x for the model change.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm) {
+  extern __shared__ double lds[];  // SPMV_LDS_STRIDE * block
+  __shared__ double scratch[32];  // >= 6 sums x 4 waves
+  const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
+  double beta = 0.0;
+  const double* p_old = nullptr;
+  double* p_new = nullptr;
+  const double* src = g.cg_x;
+  int it = 0;
+  if (MODE == 0) {
+    if (g.cg->done) return;
+    it = g.cg->cnt_b + 1;
+    const int cur = (it - 1) & 1, prev = it & 1;
+    double sums[6];
+    sums[0] = partial_sum(g.part_rz + (size_t)cur * g.n_part, g.n_vec_wg);   // rho_it
+    sums[1] = partial_sum(g.part_rz + (size_t)prev * g.n_part, g.n_vec_wg);  // rho_{it-1}
+    sums[2] = partial_sum(g.part_q + (size_t)cur * g.n_part, g.n_vec_wg);    // Q(x_{it-1})
+    sums[3] = partial_sum(g.part_q + (size_t)prev * g.n_part, g.n_vec_wg);   // Q(x_{it-2})
+    sums[4] = partial_sum(g.part_rr + (size_t)cur * g.n_part, g.n_vec_wg);   // |r_{it-1}|^2
+    sums[5] = partial_sum(g.part_bb, g.n_vec_wg);                             // |b|^2
+    block_sum<6>(sums, scratch);
+    const double rho = sums[0], rho_prev = sums[1], Q1 = -sums[2], Q0 = -sums[3];
+    int stop = 0, status = 0;
+    if (it > 1) {
+      const int done_it = it - 1;
+      const double zeta = done_it * (Q1 - Q0) / Q1;
+      if (zeta < prm.q_tolerance && done_it >= prm.min_iterations) stop = 1;
+      if (prm.r_tolerance >= 0.0 && sqrt(sums[4]) <= prm.r_tolerance * sqrt(sums[5]) && done_it >= prm.min_iterations) stop = 1;
+      if (done_it >= prm.max_iterations) stop = 1;
+    }
+    if (!stop && (rho == 0.0 || !isfinite(rho))) { stop = 1; status = (rho == 0.0) ? 0 : 2; }
+    if (!stop && it > 1) {
+      beta = rho / rho_prev;
+      if (beta == 0.0 || !isfinite(beta)) { stop = 1; status = 2; }
+    }
+    if (stop) {
+      if (wg == 0 && tid == 0) { g.cg->iters = it - 1; g.cg->status = status; g.cg->done = 1; }
+      return;
+    }
+    p_old = (it & 1) ? g.cg_p0 : g.cg_p1;
+    p_new = (it & 1) ? g.cg_p1 : g.cg_p0;
+  }
+
+  const int s_begin = g.wg_slot_begin[wg], s_end = g.wg_slot_begin[wg + 1];
+  const int r0 = g.wg_row_begin[wg], nrows = g.wg_row_begin[wg + 1] - r0;
+  const bool single = (s_end - s_begin) == B;
+  double acc = 0.0;
+  double pq[1] = {0.0};
+
+  for (int cb = s_begin; cb < s_end; cb += B) {
+    const int t = cb + tid;
+    const int col = g.slot_col[t];
+    double y[6] = {0, 0, 0, 0, 0, 0};
+    if (col >= 0) {
+      double x[6];
+      if (MODE == 0) {
+        const double2* zs = reinterpret_cast<const double2*>(g.cg_z + 6 * (size_t)col);
+        const double2* ps = reinterpret_cast<const double2*>(p_old + 6 * (size_t)col);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double2 z2 = zs[k], p2 = ps[k];
+          x[2 * k] = z2.x + beta * p2.x;
+          x[2 * k + 1] = z2.y + beta * p2.y;
+        }
+        if (g.slot_side[t] == SIDE_DIAG) {
+          double2* pn = reinterpret_cast<double2*>(p_new + 6 * (size_t)col);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pn[k] = double2{x[2 * k], x[2 * k + 1]};
+        }
+      } else {
+        const double2* xs = reinterpret_cast<const double2*>(src + 6 * (size_t)col);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double2 t2 = xs[k]; x[2 * k] = t2.x; x[2 * k + 1] = t2.y; }
+      }
+      const double2* blk = reinterpret_cast<const double2*>(g.bsr_val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double2 b0 = blk[(size_t)(3 * i) * 64], b1 = blk[(size_t)(3 * i + 1) * 64], b2 = blk[(size_t)(3 * i + 2) * 64];
+        y[i] = b0.x * x[0] + b0.y * x[1] + b1.x * x[2] + b1.y * x[3] + b2.x * x[4] + b2.y * x[5];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) lds[tid * SPMV_LDS_STRIDE + k] = y[k];
+    __syncthreads();
+    for (int idx = tid; idx < nrows * 6; idx += B) {
+      const int rl = idx / 6, k = idx - rl * 6;
+      const int row = r0 + rl;
+      const int rb = g.row_slot_begin[row];
+      const int sb = max(rb, cb) - cb, se = min(rb + g.row_slot_cnt[row], cb + B) - cb;
+      double s = 0.0;
+      for (int j = sb; j < se; ++j) s += lds[j * SPMV_LDS_STRIDE + k];
+      if (single) {
+        g.cg_q[6 * (size_t)row + k] = s;
+        if (MODE == 0) pq[0] += s * (g.cg_z[6 * (size_t)row + k] + beta * p_old[6 * (size_t)row + k]);
+      } else {
+        acc += s;
+      }
+    }
+    __syncthreads();
+  }
+  if (!single && tid < 6) {
+    g.cg_q[6 * (size_t)r0 + tid] = acc;
+    if (MODE == 0) pq[0] += acc * (g.cg_z[6 * (size_t)r0 + tid] + beta * p_old[6 * (size_t)r0 + tid]);
+  }
+  if (MODE == 0) {
+    block_sum<1>(pq, scratch);
+    if (tid == 0) {
+      g.part_pq[wg] = pq[0];
+      if (wg == 0) g.cg->cnt_a = it;
+    }
+  }
+}
+
+__global__ void k_pcg_update(DeviceGraph g) {
+  __shared__ double rl[VEC_BLOCK];
+  __shared__ double scratch[16];
+  if (g.cg->done) return;
+  const int tid = threadIdx.x;
+  const int it = g.cg->cnt_a;
+  double sums[2];
+  sums[0] = partial_sum(g.part_rz + (size_t)((it - 1) & 1) * g.n_part, g.n_vec_wg);
+  sums[1] = partial_sum(g.part_pq, g.n_wg);
+  block_sum<2>(sums, scratch);
+  const double rho = sums[0], pq = sums[1];
+  if (!(pq > 0.0) || !isfinite(pq)) {
+    // "Matrix is indefinite, no more progress can be made": keep x of the previous iteration
+    if (blockIdx.x == 0 && tid == 0) { g.cg->iters = it - 1; g.cg->status = 1; g.cg->done = 1; }
+    return;
+  }
+  const double alpha = rho / pq;
+  const double* p = (it & 1) ? g.cg_p1 : g.cg_p0;
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int base = blockIdx.x * VEC_BLOCK; base < 6 * g.N; base += gridDim.x * VEC_BLOCK) {
+    const int idx = base + tid;
+    const bool live = idx < 6 * g.N;
+    double x = 0.0, r = 0.0, b = 0.0;
+    if (live) {
+      x = g.cg_x[idx] + alpha * p[idx];
+      r = g.cg_r[idx] - alpha * g.cg_q[idx];
+      b = g.cg_b[idx];
+      g.cg_x[idx] = x;
+      g.cg_r[idx] = r;
+    }
+    rl[tid] = r;
+    __syncthreads();
+    if (live) {
+      const int v = idx / 6, c = idx - 6 * v, lv = tid / 6;
+      const double* Mi = g.Minv + 36 * (size_t)v + 6 * c;
+      double z = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) z += Mi[k] * rl[6 * lv + k];
+      g.cg_z[idx] = z;
+      acc[0] += r * z;
+      acc[1] += x * (b + r);
+      acc[2] += r * r;
+    }
+    __syncthreads();
+  }
+  block_sum<3>(acc, scratch);
+  if (tid == 0) {
+    g.part_rz[(size_t)(it & 1) * g.n_part + blockIdx.x] = acc[0];
+    g.part_q[(size_t)(it & 1) * g.n_part + blockIdx.x] = acc[1];
+    g.part_rr[(size_t)(it & 1) * g.n_part + blockIdx.x] = acc[2];
+    if (blockIdx.x == 0) g.cg->cnt_b = it;
+  }
+}
+
+// Runs after a batch of iterations: applies the termination test to the last completed iteration
+// (the SpMV kernel of the next iteration would do it) and publishes the CG state for the host.
+__global__ void k_pcg_finish(DeviceGraph g, CgParams prm) {
+  __shared__ double scratch[16];
+  const int tid = threadIdx.x;
+  int done = g.cg->done, iters = g.cg->iters, status = g.cg->status;
+  if (!done) {
+    const int it = g.cg->cnt_b;  // completed
+    double sums[4];
+    sums[0] = partial_sum(g.part_q + (size_t)(it & 1) * g.n_part, g.n_vec_wg);
+    sums[1] = partial_sum(g.part_q + (size_t)((it + 1) & 1) * g.n_part, g.n_vec_wg);
+    sums[2] = partial_sum(g.part_rr + (size_t)(it & 1) * g.n_part, g.n_vec_wg);
+    sums[3] = partial_sum(g.part_bb, g.n_vec_wg);
+    block_sum<4>(sums, scratch);
+    iters = it;
+    if (it >= 1) {
+      const double Q1 = -sums[0], Q0 = -sums[1];
+      const double zeta = it * (Q1 - Q0) / Q1;
+      if ((zeta < prm.q_tolerance && it >= prm.min_iterations) || it >= prm.max_iterations) done = 1;
+      if (prm.r_tolerance >= 0.0 && sqrt(sums[2]) <= prm.r_tolerance * sqrt(sums[3]) && it >= prm.min_iterations) done = 1;
+    }
+  }
+  double rr[1] = {0.0};
+  for (int i = tid; i < 6 * g.N; i += blockDim.x) rr[0] += g.cg_r[i] * g.cg_r[i];
+  block_sum<1>(rr, scratch);
+  if (tid == 0) {
+    if (done && !g.cg->done) { g.cg->done = 1; g.cg->iters = iters; }
+    g.scal->cg_iterations = iters;
+    g.scal->cg_status = done ? status : -1;  // -1: not finished, host launches another batch
+    g.scal->cg_residual_sq = rr[0];
+  }
+}
+
+// model_cost_change = -(J~ step)'(r + J~ step/2) with step = -x:  x'b - x'(q - D^2 x)/2, q = A x;
+// delta = S * step.
+__global__ void k_model_delta(DeviceGraph g) {
+  __shared__ double scratch[8];
+  double acc[1] = {0.0};
+  for (int idx = blockIdx.x * VEC_BLOCK + threadIdx.x; idx < 6 * g.N; idx += gridDim.x * VEC_BLOCK) {
+    const double x = g.cg_x[idx];
+    const double hx = g.cg_q[idx] - g.d2[idx] * x;
+    const int v = idx / 6, i = idx - 6 * v;
+    const bool c = (i < 3) ? (g.cmask[v] & 1) : (g.cmask[v] & 2);
+    acc[0] += c ? 0.0 : (x * g.cg_b[idx] - 0.5 * x * hx);
+    g.delta[idx] = c ? 0.0 : -g.scale[idx] * x;
+  }
+  block_sum<1>(acc, scratch);
+  if (threadIdx.x == 0) g.part_misc[1 * (size_t)g.n_part + blockIdx.x] = acc[0];
+}
+
+// x_cand = Plus(x, delta) per pose (p += dp ; q <- exp(dtheta) (x) q); ambient step / state norms.
+__global__ void k_retract(DeviceGraph g) {
+  __shared__ double scratch[16];
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  double acc[2] = {0.0, 0.0};
+  if (v < g.N) {
+    const PoseRec P = load_pose(g.pose_x, v);
+    const uint8_t m = g.cmask[v];
+    const double* d = g.delta + 6 * (size_t)v;
+    V3 p = P.p;
+    Q4 q = P.q;
+    if (!(m & 1)) {
+      p = V3{P.p.x + d[0], P.p.y + d[1], P.p.z + d[2]};
+      const double dx = P.p.x - p.x, dy = P.p.y - p.y, dz = P.p.z - p.z;
+      acc[0] += dx * dx + dy * dy + dz * dz;
+      acc[1] += P.p.x * P.p.x + P.p.y * P.p.y + P.p.z * P.p.z;
+    }
+    if (!(m & 2)) {
+      q = quat_plus(P.q, V3{d[3], d[4], d[5]});
+      const double dx = P.q.x - q.x, dy = P.q.y - q.y, dz = P.q.z - q.z, dw = P.q.w - q.w;
+      acc[0] += dx * dx + dy * dy + dz * dz + dw * dw;
+      acc[1] += P.q.x * P.q.x + P.q.y * P.q.y + P.q.z * P.q.z + P.q.w * P.q.w;
+    }
+    double2* o = reinterpret_cast<double2*>(g.pose_c + (size_t)POSE_STRIDE * v);
+    o[0] = double2{p.x, p.y};
+    o[1] = double2{p.z, q.x};
+    o[2] = double2{q.y, q.z};
+    o[3] = double2{q.w, 0.0};
+  }
+  block_sum<2>(acc, scratch);
+  if (threadIdx.x == 0) {
+    g.part_misc[2 * (size_t)g.n_part + blockIdx.x] = acc[0];
+    g.part_misc[3 * (size_t)g.n_part + blockIdx.x] = acc[1];
+  }
+}
+
+// gradient_max_norm = | x - Plus(x, -g) |_inf over the non-constant blocks.
+__global__ void k_gradient_norm(DeviceGraph g) {
+  __shared__ double scratch[8];
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  double m = 0.0;
+  if (v < g.N) {
+    const PoseRec P = load_pose(g.pose_x, v);
+    const uint8_t cm = g.cmask[v];
+    const double* gr = g.grad + 6 * (size_t)v;
+    if (!(cm & 1)) m = fmax(m, fmax(fabs(gr[0]), fmax(fabs(gr[1]), fabs(gr[2]))));
+    if (!(cm & 2)) {
+      const Q4 q = quat_plus(P.q, V3{-gr[3], -gr[4], -gr[5]});
+      m = fmax(m, fmax(fmax(fabs(P.q.x - q.x), fabs(P.q.y - q.y)), fmax(fabs(P.q.z - q.z), fabs(P.q.w - q.w))));
+    }
+  }
+  m = wave_max(m);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) scratch[wave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) t = fmax(t, scratch[w]);
+    g.part_misc[4 * (size_t)g.n_part + blockIdx.x] = t;
+  }
+}
+
+// One workgroup folds the partial rows into the pinned scalar block the host reads.
+__global__ void k_finalize_scalars(DeviceGraph g, int n_cost_part) {
+  __shared__ double scratch[32];
+  double s[4];
+  s[0] = partial_sum(g.part_misc, n_cost_part);
+  s[1] = partial_sum(g.part_misc + 1 * (size_t)g.n_part, g.n_vec_wg);
+  s[2] = partial_sum(g.part_misc + 2 * (size_t)g.n_part, g.n_pose_wg);
+  s[3] = partial_sum(g.part_misc + 3 * (size_t)g.n_part, g.n_pose_wg);
+  block_sum<4>(s, scratch);
+  double m = 0.0;
+  for (int i = threadIdx.x; i < g.n_pose_wg; i += blockDim.x) m = fmax(m, g.part_misc[4 * (size_t)g.n_part + i]);
+  m = wave_max(m);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) scratch[wave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) t = fmax(t, scratch[w]);
+    g.scal->cand_cost = s[0];
+    g.scal->model_change = s[1];
+    g.scal->step_norm_sq = s[2];
+    g.scal->x_norm_sq = s[3];
+    g.scal->gradient_max = t;
+    g.scal->linearize_bad = g.flags[1];
+  }
+}
+
+__global__ void k_copy_delta(DeviceGraph g, const double* step) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < 6 * g.N) g.delta[idx] = step[idx];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+void launch_linearize(const DeviceGraph& g, hipStream_t s) {
+  const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);
+  if (g.info_mode) hipLaunchKernelGGL(k_linearize<1>, dim3(g.n_wg), dim3(g.block), lds, s, g);
+  else hipLaunchKernelGGL(k_linearize<0>, dim3(g.n_wg), dim3(g.block), lds, s, g);
+}
+void launch_scale_from_diag(const DeviceGraph& g, hipStream_t s) {
+  hipLaunchKernelGGL(k_scale_from_diag, dim3(cdiv(6 * g.N, 256)), dim3(256), 0, s, g);
+}
+void launch_damping(const DeviceGraph& g, double radius, double min_diag, double max_diag, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(k_damping, dim3(cdiv(g.N, 64)), dim3(64), 0, s, g, radius, min_diag, max_diag, mode);
+}
+void launch_cost(const DeviceGraph& g, const double* poses, int part_row, hipStream_t s) {
+  double* part = g.part_misc + (size_t)part_row * g.n_part;
+  if (g.info_mode) hipLaunchKernelGGL(k_cost<1>, dim3(g.n_edge_wg), dim3(EDGE_BLOCK), 0, s, g, poses, part);
+  else hipLaunchKernelGGL(k_cost<0>, dim3(g.n_edge_wg), dim3(EDGE_BLOCK), 0, s, g, poses, part);
+}
+void launch_evaluate_edges(const DeviceGraph& g, const double* poses, double* res, double* ja, double* jb, hipStream_t s) {
+  hipLaunchKernelGGL(k_evaluate_edges, dim3(cdiv(g.E, 128)), dim3(128), 0, s, g, poses, res, ja, jb);
+}
+void launch_pcg_init(const DeviceGraph& g, hipStream_t s) {
+  hipLaunchKernelGGL(k_pcg_init, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
+}
+void launch_pcg_iteration(const DeviceGraph& g, const CgParams& p, hipStream_t s) {
+  const size_t lds = (size_t)SPMV_LDS_STRIDE * g.block * sizeof(double);
+  hipLaunchKernelGGL(k_spmv<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, p);
+  hipLaunchKernelGGL(k_pcg_update, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
+}
+void launch_pcg_finish(const DeviceGraph& g, const CgParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(k_pcg_finish, dim3(1), dim3(256), 0, s, g, p);
+}
+void launch_model_and_retract(const DeviceGraph& g, hipStream_t s) {
+  const size_t lds = (size_t)SPMV_LDS_STRIDE * g.block * sizeof(double);
+  CgParams dummy{0.0, -1.0, 0, 0};
+  hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy);
+  hipLaunchKernelGGL(k_model_delta, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
+  hipLaunchKernelGGL(k_retract, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g);
+}
+void launch_spmv_plain(const DeviceGraph& g, hipStream_t s) {
+  const size_t lds = (size_t)SPMV_LDS_STRIDE * g.block * sizeof(double);
+  CgParams dummy{0.0, -1.0, 0, 0};
+  hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy);
+}
+void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, hipStream_t s) {
+  const size_t lds = (size_t)SPMV_LDS_STRIDE * g.block * sizeof(double);
+  hipLaunchKernelGGL(k_spmv<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, p);
+}
+void launch_pcg_update_only(const DeviceGraph& g, hipStream_t s) {
+  hipLaunchKernelGGL(k_pcg_update, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
+}
+void launch_gradient_norm(const DeviceGraph& g, hipStream_t s) {
+  hipLaunchKernelGGL(k_gradient_norm, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g);
+}
+void launch_finalize_scalars(const DeviceGraph& g, int n_cost_part, hipStream_t s) {
+  hipLaunchKernelGGL(k_finalize_scalars, dim3(1), dim3(256), 0, s, g, n_cost_part);
+}
+void launch_apply_step(const DeviceGraph& g, const double* step, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy_delta, dim3(cdiv(6 * g.N, 256)), dim3(256), 0, s, g, step);
+  hipLaunchKernelGGL(k_retract, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g);
+}
+
+int vec_block() { return VEC_BLOCK; }
+int pose_block() { return POSE_BLOCK; }
+int edge_block() { return EDGE_BLOCK; }
+
+}  // namespace pgo

@@ -1,0 +1,1126 @@
+// pgo_solver.cpp — host side of libpgo_hip.so: ceres::Problem-style bookkeeping, topology build,
+// the Levenberg-Marquardt trust-region driver and the C ABI of include/pgo.h.
+//
+// Reference behaviour mirrored (REF = src/POSE_GRAPH_CERES_PLUS):
+//   BuildOptimizationProblem  REF/test/pose_graph_ceres_plus_finial.cpp:491-528
+//   SolveOptimizationProblem  REF/test/pose_graph_ceres_plus_finial.cpp:531-544
+//   ceres::Solve control flow SURVEY.md Appendix A.6 (Ceres 1.13 TrustRegionMinimizer order,
+//                             LevenbergMarquardtStrategy radius rules, Options defaults of row a9)
+// All arithmetic of the path runs in the HIP kernels of pgo_kernels.hip; this file only sequences
+// them and takes the accept/reject decisions from scalars the device reduces.
+#include "../../include/pgo.h"
+#include "pgo_kernels.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_error;
+
+int set_error(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t err__ = (expr);                                                                \
+    if (err__ != hipSuccess)                                                                  \
+      return set_error(PGO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(err__), \
+                       __FILE__, __LINE__);                                                   \
+  } while (0)
+
+typedef std::chrono::steady_clock Clock;
+inline double seconds_since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+  }
+  hipError_t upload(const std::vector<T>& h, hipStream_t s) {
+    hipError_t e = alloc(h.size());
+    if (e != hipSuccess || h.empty()) return e;
+    e = hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(s);  // h may be a temporary
+  }
+  hipError_t zero(hipStream_t s) { return n ? hipMemsetAsync(p, 0, n * sizeof(T), s) : hipSuccess; }
+};
+
+struct LmState {
+  bool active = false;
+  bool terminated = false;
+  bool pending_record = false;
+  int termination = PGO_NO_CONVERGENCE;
+  int reason = 5;
+  double radius = 1e4, decrease_factor = 2.0;
+  bool reuse_diagonal = false;
+  double x_cost = 0, x_norm = 0, gmax = 0, initial_cost = 0;
+  int num_successful = 0, num_unsuccessful = 0, num_consecutive_invalid = 0, num_linear_iterations = 0;
+  pgo_iteration_record cur{};
+  std::vector<pgo_iteration_record> records;
+  double t_total = 0, t_linear = 0, t_jacobian = 0, t_residual = 0, t_setup = 0;
+  std::string message;
+};
+
+}  // namespace
+
+struct pgo_problem {
+  // ---- host-side problem (ceres::Problem bookkeeping) ----
+  std::vector<double*> pp, qq;
+  std::unordered_map<const double*, int> block_of_ptr;  // pose*2 + (0: p block, 1: q block)
+  std::vector<uint8_t> cmask;
+  std::vector<int> ia, ib;
+  std::vector<double> meas;       // 7 per edge
+  std::vector<double> sqrt_info;  // 36 per edge once any edge carries a non-identity matrix
+  bool has_info = false;
+  int loss_kind = PGO_LOSS_TRIVIAL;
+  double loss_a = 1.0;
+  bool topo_dirty = true;
+
+  // ---- device ----
+  int device = 0;
+  bool stream_ready = false;
+  hipStream_t stream = nullptr;
+  pgo::DeviceGraph g{};
+  std::vector<int> edge_begin_slot;  // host: slot of the begin-side incidence of every edge
+  DevBuf<int> d_slot_col, d_slot_row, d_wg_slot_begin, d_wg_row_begin, d_row_slot_begin, d_row_slot_cnt, d_edge_a, d_edge_b, d_flags;
+  DevBuf<uint8_t> d_slot_side, d_cmask;
+  DevBuf<double> d_smeas, d_sW, d_emeas, d_eW, d_eL, d_pose_x, d_pose_c, d_pose_0, d_bsr, d_Hdiag, d_Minv, d_grad,
+      d_scale, d_d2, d_diagc, d_cg_b, d_cg_x, d_cg_r, d_cg_z, d_cg_q, d_cg_p0, d_cg_p1, d_delta, d_part_rz, d_part_q,
+      d_part_pq, d_part_rr, d_part_bb, d_part_misc, d_tmp_a, d_tmp_b, d_tmp_c;
+  DevBuf<pgo::CgState> d_cg;
+  pgo::LmScalars* scal = nullptr;  // pinned, device visible
+  // captured CG batch
+  hipGraphExec_t cg_exec = nullptr;
+  hipGraph_t cg_graph = nullptr;
+  pgo::CgParams cg_graph_params{};
+  int cg_graph_batch = 0;
+  bool use_graph = true;
+
+  pgo_solver_options opt{};
+  LmState lm;
+
+  ~pgo_problem() {
+    drop_graph();
+    if (scal) (void)hipHostFree(scal);
+    if (stream_ready) (void)hipStreamDestroy(stream);
+  }
+  void drop_graph() {
+    if (cg_exec) { (void)hipGraphExecDestroy(cg_exec); cg_exec = nullptr; }
+    if (cg_graph) { (void)hipGraphDestroy(cg_graph); cg_graph = nullptr; }
+    cg_graph_batch = 0;
+  }
+};
+
+namespace {
+
+int ensure_device(pgo_problem* P) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return set_error(PGO_ERR_NO_DEVICE,
+                     "no HIP device available: the pose-graph path runs on gfx950 only and has no CPU fallback");
+  }
+  HIP_TRY(hipSetDevice(P->device));
+  if (!P->stream_ready) {
+    HIP_TRY(hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking));
+    P->stream_ready = true;
+    const char* ng = getenv("PGO_NO_GRAPH");
+    P->use_graph = !(ng && ng[0] == '1');
+  }
+  if (!P->scal) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&P->scal), sizeof(pgo::LmScalars), hipHostMallocMapped));
+    memset(P->scal, 0, sizeof(pgo::LmScalars));
+  }
+  return PGO_OK;
+}
+
+int choose_block(long long total_slots) {
+  if (total_slots >= 256LL * 512) return 256;
+  if (total_slots >= 128LL * 384) return 128;
+  return 64;
+}
+
+// Builds the incidence-slot topology and uploads every static array.
+int prepare(pgo_problem* P) {
+  int rc = ensure_device(P);
+  if (rc) return rc;
+  if (!P->topo_dirty) return PGO_OK;
+  const auto t0 = Clock::now();
+  const int N = (int)P->pp.size(), E = (int)P->ia.size();
+  if (N == 0) return set_error(PGO_ERR_INVALID_ARGUMENT, "problem has no poses");
+  hipStream_t s = P->stream;
+  P->drop_graph();
+
+  std::vector<int> deg(N, 0);
+  for (int e = 0; e < E; ++e) { ++deg[P->ia[e]]; ++deg[P->ib[e]]; }
+  long long total = 0;
+  for (int v = 0; v < N; ++v) total += 1 + deg[v];
+  const int B = choose_block(total);
+
+  // rows -> workgroups
+  std::vector<int> wg_row_begin, wg_slot_begin, row_slot_begin(N), row_slot_cnt(N);
+  long long slot = 0;
+  int cur = 0;
+  wg_row_begin.push_back(0);
+  wg_slot_begin.push_back(0);
+  auto close_wg = [&](int next_row) {
+    slot = (slot + B - 1) / B * B;
+    wg_row_begin.push_back(next_row);
+    wg_slot_begin.push_back((int)slot);
+    cur = 0;
+  };
+  for (int v = 0; v < N; ++v) {
+    const int c = 1 + deg[v];
+    if (c > B) {
+      if (cur > 0) close_wg(v);
+      row_slot_begin[v] = (int)slot;
+      row_slot_cnt[v] = c;
+      slot += c;
+      close_wg(v + 1);
+      continue;
+    }
+    if (cur + c > B) close_wg(v);
+    row_slot_begin[v] = (int)slot;
+    row_slot_cnt[v] = c;
+    slot += c;
+    cur += c;
+  }
+  if (cur > 0) close_wg(N);
+  if (slot > 0x7fffffffLL - 1024) return set_error(PGO_ERR_UNSUPPORTED, "graph too large for 32-bit slot indices");
+  const int n_wg = (int)wg_row_begin.size() - 1;
+  const int n_slots = (int)slot;
+
+  // slots: diagonal first, then the row's incidences in edge order
+  std::vector<int> slot_col(n_slots, -1), slot_row(n_slots, 0), slot_edge(n_slots, -1), fill(N);
+  std::vector<uint8_t> slot_side(n_slots, pgo::SIDE_PAD);
+  for (int v = 0; v < N; ++v) {
+    const int sb = row_slot_begin[v];
+    slot_col[sb] = v; slot_row[sb] = v; slot_side[sb] = pgo::SIDE_DIAG;
+    fill[v] = sb + 1;
+  }
+  P->edge_begin_slot.assign(E, -1);
+  for (int e = 0; e < E; ++e) {
+    const int a = P->ia[e], b = P->ib[e];
+    int t = fill[a]++;
+    slot_col[t] = b; slot_row[t] = a; slot_side[t] = pgo::SIDE_BEGIN; slot_edge[t] = e;
+    P->edge_begin_slot[e] = t;
+    t = fill[b]++;
+    slot_col[t] = a; slot_row[t] = b; slot_side[t] = pgo::SIDE_END; slot_edge[t] = e;
+  }
+  // pad slots keep a valid row index so that loads stay in range
+  for (int w = 0; w < n_wg; ++w) {
+    const int r = std::min(wg_row_begin[w], N - 1);
+    for (int t = wg_slot_begin[w]; t < wg_slot_begin[w + 1]; ++t) if (slot_side[t] == pgo::SIDE_PAD) slot_row[t] = r;
+  }
+
+  // measurements: edge order and slot order, component major
+  std::vector<double> emeas((size_t)7 * E), smeas((size_t)7 * n_slots, 0.0);
+  for (int e = 0; e < E; ++e) for (int c = 0; c < 7; ++c) emeas[(size_t)c * E + e] = P->meas[(size_t)7 * e + c];
+  for (int t = 0; t < n_slots; ++t) {
+    const int e = slot_edge[t];
+    if (e < 0) { smeas[(size_t)6 * n_slots + t] = 1.0; continue; }
+    for (int c = 0; c < 7; ++c) smeas[(size_t)c * n_slots + t] = P->meas[(size_t)7 * e + c];
+  }
+  std::vector<double> eW, sW, eL;
+  if (P->has_info) {
+    eW.resize((size_t)21 * E); eL.resize((size_t)36 * E); sW.assign((size_t)21 * n_slots, 0.0);
+    for (int e = 0; e < E; ++e) {
+      const double* L = &P->sqrt_info[(size_t)36 * e];
+      int k = 0;
+      for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) {
+          double w = 0;
+          for (int r = 0; r < 6; ++r) w += L[6 * r + i] * L[6 * r + j];  // W = L^T L
+          eW[(size_t)k * E + e] = w;
+          ++k;
+        }
+      for (int q = 0; q < 36; ++q) eL[(size_t)q * E + e] = L[q];
+    }
+    for (int t = 0; t < n_slots; ++t) {
+      const int e = slot_edge[t];
+      if (e < 0) continue;
+      for (int k = 0; k < 21; ++k) sW[(size_t)k * n_slots + t] = eW[(size_t)k * E + e];
+    }
+  }
+
+  HIP_TRY(P->d_slot_col.upload(slot_col, s));
+  HIP_TRY(P->d_slot_row.upload(slot_row, s));
+  HIP_TRY(P->d_slot_side.upload(slot_side, s));
+  HIP_TRY(P->d_wg_slot_begin.upload(wg_slot_begin, s));
+  HIP_TRY(P->d_wg_row_begin.upload(wg_row_begin, s));
+  HIP_TRY(P->d_row_slot_begin.upload(row_slot_begin, s));
+  HIP_TRY(P->d_row_slot_cnt.upload(row_slot_cnt, s));
+  HIP_TRY(P->d_cmask.upload(P->cmask, s));
+  HIP_TRY(P->d_edge_a.upload(P->ia, s));
+  HIP_TRY(P->d_edge_b.upload(P->ib, s));
+  HIP_TRY(P->d_smeas.upload(smeas, s));
+  HIP_TRY(P->d_emeas.upload(emeas, s));
+  HIP_TRY(P->d_sW.upload(sW, s));
+  HIP_TRY(P->d_eW.upload(eW, s));
+  HIP_TRY(P->d_eL.upload(eL, s));
+
+  const size_t m = (size_t)6 * N;
+  HIP_TRY(P->d_pose_x.alloc((size_t)pgo::POSE_STRIDE * N));
+  HIP_TRY(P->d_pose_c.alloc((size_t)pgo::POSE_STRIDE * N));
+  HIP_TRY(P->d_pose_0.alloc((size_t)pgo::POSE_STRIDE * N));
+  HIP_TRY(P->d_bsr.alloc((size_t)n_slots * 36));
+  HIP_TRY(P->d_bsr.zero(s));
+  HIP_TRY(P->d_Hdiag.alloc((size_t)36 * N));
+  HIP_TRY(P->d_Minv.alloc((size_t)36 * N));
+  DevBuf<double>* vecs[] = {&P->d_grad, &P->d_scale, &P->d_d2, &P->d_diagc, &P->d_cg_b, &P->d_cg_x, &P->d_cg_r,
+                            &P->d_cg_z, &P->d_cg_q, &P->d_cg_p0, &P->d_cg_p1, &P->d_delta};
+  for (DevBuf<double>* b : vecs) { HIP_TRY(b->alloc(m)); HIP_TRY(b->zero(s)); }
+  const int n_vec_wg = std::max(1, std::min((int)((m + pgo::vec_block() - 1) / pgo::vec_block()), 128));
+  const int n_edge_wg = std::max(1, (E + pgo::edge_block() - 1) / pgo::edge_block());
+  const int n_pose_wg = (N + pgo::pose_block() - 1) / pgo::pose_block();
+  const int n_part = std::max(std::max(n_wg, n_vec_wg), std::max(n_edge_wg, n_pose_wg));
+  HIP_TRY(P->d_part_rz.alloc((size_t)2 * n_part));
+  HIP_TRY(P->d_part_q.alloc((size_t)2 * n_part));
+  HIP_TRY(P->d_part_rr.alloc((size_t)2 * n_part));
+  HIP_TRY(P->d_part_pq.alloc((size_t)n_part));
+  HIP_TRY(P->d_part_bb.alloc((size_t)n_part));
+  HIP_TRY(P->d_part_misc.alloc((size_t)8 * n_part));
+  HIP_TRY(P->d_part_misc.zero(s));
+  HIP_TRY(P->d_cg.alloc(1));
+  HIP_TRY(P->d_cg.zero(s));
+  HIP_TRY(P->d_flags.alloc(4));
+  HIP_TRY(P->d_flags.zero(s));
+
+  pgo::DeviceGraph& g = P->g;
+  g.N = N; g.E = E; g.n_wg = n_wg; g.n_slots = n_slots; g.block = B;
+  g.info_mode = P->has_info ? 1 : 0;
+  g.loss_kind = P->loss_kind; g.loss_a = P->loss_a;
+  g.slot_col = P->d_slot_col.p; g.slot_row = P->d_slot_row.p; g.slot_side = P->d_slot_side.p;
+  g.wg_slot_begin = P->d_wg_slot_begin.p; g.wg_row_begin = P->d_wg_row_begin.p;
+  g.row_slot_begin = P->d_row_slot_begin.p; g.row_slot_cnt = P->d_row_slot_cnt.p; g.cmask = P->d_cmask.p;
+  g.smeas = P->d_smeas.p; g.sW = P->d_sW.p; g.edge_a = P->d_edge_a.p; g.edge_b = P->d_edge_b.p;
+  g.emeas = P->d_emeas.p; g.eW = P->d_eW.p; g.eL = P->d_eL.p;
+  g.pose_x = P->d_pose_x.p; g.pose_c = P->d_pose_c.p; g.bsr_val = P->d_bsr.p; g.Hdiag = P->d_Hdiag.p;
+  g.Minv = P->d_Minv.p; g.grad = P->d_grad.p; g.scale = P->d_scale.p; g.d2 = P->d_d2.p;
+  g.diag_clamped = P->d_diagc.p; g.cg_b = P->d_cg_b.p; g.cg_x = P->d_cg_x.p; g.cg_r = P->d_cg_r.p;
+  g.cg_z = P->d_cg_z.p; g.cg_q = P->d_cg_q.p; g.cg_p0 = P->d_cg_p0.p; g.cg_p1 = P->d_cg_p1.p;
+  g.delta = P->d_delta.p; g.part_rz = P->d_part_rz.p; g.part_q = P->d_part_q.p; g.part_pq = P->d_part_pq.p;
+  g.part_rr = P->d_part_rr.p; g.part_bb = P->d_part_bb.p; g.part_misc = P->d_part_misc.p;
+  g.n_part = n_part; g.n_vec_wg = n_vec_wg; g.n_edge_wg = n_edge_wg; g.n_pose_wg = n_pose_wg;
+  g.cg = P->d_cg.p; g.flags = P->d_flags.p;
+  void* dscal = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&dscal, P->scal, 0));
+  g.scal = reinterpret_cast<pgo::LmScalars*>(dscal);
+  HIP_TRY(hipStreamSynchronize(s));
+  P->topo_dirty = false;
+  P->lm.t_setup = seconds_since(t0);
+  return PGO_OK;
+}
+
+int upload_poses(pgo_problem* P, double* dst) {
+  const int N = (int)P->pp.size();
+  std::vector<double> h((size_t)pgo::POSE_STRIDE * N, 0.0);
+  for (int v = 0; v < N; ++v) {
+    double* o = &h[(size_t)pgo::POSE_STRIDE * v];
+    o[0] = P->pp[v][0]; o[1] = P->pp[v][1]; o[2] = P->pp[v][2];
+    o[3] = P->qq[v][0]; o[4] = P->qq[v][1]; o[5] = P->qq[v][2]; o[6] = P->qq[v][3];
+  }
+  HIP_TRY(hipMemcpyAsync(dst, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, P->stream));
+  HIP_TRY(hipStreamSynchronize(P->stream));
+  return PGO_OK;
+}
+
+int download_poses(pgo_problem* P, const double* src) {
+  const int N = (int)P->pp.size();
+  std::vector<double> h((size_t)pgo::POSE_STRIDE * N);
+  HIP_TRY(hipMemcpyAsync(h.data(), src, h.size() * sizeof(double), hipMemcpyDeviceToHost, P->stream));
+  HIP_TRY(hipStreamSynchronize(P->stream));
+  for (int v = 0; v < N; ++v) {
+    const double* o = &h[(size_t)pgo::POSE_STRIDE * v];
+    // constant blocks are never written (row 0 of the reference's before/after files is identical)
+    if (!(P->cmask[v] & 1)) { P->pp[v][0] = o[0]; P->pp[v][1] = o[1]; P->pp[v][2] = o[2]; }
+    if (!(P->cmask[v] & 2)) { P->qq[v][0] = o[3]; P->qq[v][1] = o[4]; P->qq[v][2] = o[5]; P->qq[v][3] = o[6]; }
+  }
+  return PGO_OK;
+}
+
+int fill_scale_one(pgo_problem* P) {
+  std::vector<double> one((size_t)6 * P->g.N, 1.0);
+  HIP_TRY(hipMemcpyAsync(P->g.scale, one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice, P->stream));
+  HIP_TRY(hipStreamSynchronize(P->stream));
+  return PGO_OK;
+}
+
+// ---- CG driver: batches of iterations, one host check per batch ----
+int run_pcg(pgo_problem* P, const pgo::CgParams& prm, int batch, int* iterations, int* status) {
+  hipStream_t s = P->stream;
+  pgo::launch_pcg_init(P->g, s);
+  if (batch <= 0) batch = 16;
+  batch = std::min(batch, std::max(1, prm.max_iterations));
+  for (;;) {
+    bool launched = false;
+    if (P->use_graph) {
+      const bool same = P->cg_exec && P->cg_graph_batch == batch && memcmp(&P->cg_graph_params, &prm, sizeof prm) == 0;
+      if (!same) {
+        P->drop_graph();
+        hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+          for (int i = 0; i < batch; ++i) pgo::launch_pcg_iteration(P->g, prm, s);
+          pgo::launch_pcg_finish(P->g, prm, s);
+          e = hipStreamEndCapture(s, &P->cg_graph);
+          if (e == hipSuccess) e = hipGraphInstantiate(&P->cg_exec, P->cg_graph, nullptr, nullptr, 0);
+        }
+        if (e != hipSuccess) {
+          (void)hipGetLastError();
+          P->drop_graph();
+          P->use_graph = false;  // fall back to plain stream launches (same kernels)
+        } else {
+          P->cg_graph_batch = batch;
+          P->cg_graph_params = prm;
+        }
+      }
+      if (P->cg_exec) {
+        HIP_TRY(hipGraphLaunch(P->cg_exec, s));
+        launched = true;
+      }
+    }
+    if (!launched) {
+      for (int i = 0; i < batch; ++i) pgo::launch_pcg_iteration(P->g, prm, s);
+      pgo::launch_pcg_finish(P->g, prm, s);
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (P->scal->cg_status != -1) break;
+  }
+  HIP_TRY(hipGetLastError());
+  *iterations = P->scal->cg_iterations;
+  *status = P->scal->cg_status;
+  return PGO_OK;
+}
+
+pgo::CgParams cg_params_for(const pgo_solver_options& o) {
+  pgo::CgParams prm;
+  if (o.linear_solver_type == PGO_BLOCK_JACOBI_PCG) {
+    prm.q_tolerance = o.eta;
+    prm.r_tolerance = -1.0;  // LevenbergMarquardtStrategy disables the residual test
+    prm.max_iterations = o.max_linear_solver_iterations;
+    prm.min_iterations = o.min_linear_solver_iterations;
+  } else {
+    // SPARSE_NORMAL_CHOLESKY is an exact solve.  Until the direct factorisation path is wired in it is
+    // served by the same PCG run to a tight relative residual.
+    prm.q_tolerance = -1.0;
+    prm.r_tolerance = o.exact_r_tolerance;
+    prm.max_iterations = 200000;
+    prm.min_iterations = 0;
+  }
+  return prm;
+}
+
+// ---- LM driver ------------------------------------------------------------------------------
+
+int evaluate_gradient_and_jacobian(pgo_problem* P, bool first) {
+  const auto t0 = Clock::now();
+  hipStream_t s = P->stream;
+  if (first) {
+    int rc = fill_scale_one(P);
+    if (rc) return rc;
+    pgo::launch_linearize(P->g, s);
+    if (P->opt.jacobi_scaling) {
+      pgo::launch_scale_from_diag(P->g, s);
+      pgo::launch_linearize(P->g, s);
+    }
+  } else {
+    pgo::launch_linearize(P->g, s);
+  }
+  pgo::launch_gradient_norm(P->g, s);
+  P->lm.t_jacobian += seconds_since(t0);
+  return PGO_OK;
+}
+
+int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
+  int rc = prepare(P);
+  if (rc) return rc;
+  P->opt = *options;
+  LmState& L = P->lm;
+  const double t_setup = L.t_setup;
+  L = LmState();
+  L.t_setup = t_setup;
+  const auto t0 = Clock::now();
+  P->g.loss_kind = P->loss_kind;
+  P->g.loss_a = P->loss_a;
+  P->g.pose_x = P->d_pose_x.p;
+  P->g.pose_c = P->d_pose_c.p;
+  rc = upload_poses(P, P->g.pose_x);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(P->d_pose_0.p, P->g.pose_x, P->d_pose_0.n * sizeof(double), hipMemcpyDeviceToDevice, P->stream));
+  HIP_TRY(P->d_flags.zero(P->stream));
+  // Init + IterationZero
+  rc = evaluate_gradient_and_jacobian(P, true);
+  if (rc) return rc;
+  pgo::launch_cost(P->g, P->g.pose_x, 0, P->stream);
+  // x_norm: run the retraction with a zero step (delta is zero after prepare/reset)
+  HIP_TRY(P->d_delta.zero(P->stream));
+  pgo::launch_apply_step(P->g, P->g.delta, P->stream);
+  pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, P->stream);
+  HIP_TRY(hipStreamSynchronize(P->stream));
+  HIP_TRY(hipGetLastError());
+  L.x_cost = P->scal->cand_cost;
+  L.initial_cost = L.x_cost;
+  L.x_norm = std::sqrt(P->scal->x_norm_sq);
+  L.gmax = P->scal->gradient_max;
+  L.radius = P->opt.initial_trust_region_radius;
+  L.decrease_factor = 2.0;
+  L.reuse_diagonal = false;
+  L.cur = pgo_iteration_record{};
+  L.cur.iteration = 0;
+  L.cur.step_is_successful = 1;
+  L.cur.cost = L.x_cost;
+  L.cur.gradient_max_norm = L.gmax;
+  L.pending_record = true;
+  L.active = true;
+  L.t_total += seconds_since(t0);
+  if (!std::isfinite(L.x_cost)) {
+    L.terminated = true; L.termination = PGO_FAILURE; L.reason = 7;
+    L.message = "Initial cost is not finite.";
+  }
+  return PGO_OK;
+}
+
+void terminate(LmState& L, int termination, int reason, const char* fmt, ...) {
+  char buf[240];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  L.terminated = true;
+  L.termination = termination;
+  L.reason = reason;
+  L.message = buf;
+}
+
+// One pass of the TrustRegionMinimizer loop body (SURVEY.md A.6 step 7 order).
+int lm_advance(pgo_problem* P) {
+  LmState& L = P->lm;
+  const pgo_solver_options& o = P->opt;
+  hipStream_t s = P->stream;
+  if (L.terminated) return PGO_OK;
+  const auto t_it = Clock::now();
+
+  // FinalizeIterationAndCheckIfMinimizerCanContinue
+  if (L.pending_record) {
+    if (L.cur.step_is_successful) ++L.num_successful; else ++L.num_unsuccessful;
+    L.cur.trust_region_radius = L.radius;
+    L.records.push_back(L.cur);
+    L.pending_record = false;
+  }
+  if (L.cur.iteration >= o.max_num_iterations) {
+    terminate(L, PGO_NO_CONVERGENCE, 5, "Maximum number of iterations reached. Number of iterations: %d.", L.cur.iteration);
+    return PGO_OK;
+  }
+  if (L.cur.step_is_successful && L.cur.gradient_max_norm <= o.gradient_tolerance) {
+    terminate(L, PGO_CONVERGENCE, 3, "Gradient tolerance reached. Gradient max norm: %e <= %e", L.cur.gradient_max_norm, o.gradient_tolerance);
+    return PGO_OK;
+  }
+  if (L.radius <= o.min_trust_region_radius) {
+    terminate(L, PGO_CONVERGENCE, 4, "Minimum trust region radius reached. Trust region radius: %e <= %e", L.radius, o.min_trust_region_radius);
+    return PGO_OK;
+  }
+
+  pgo_iteration_record nx{};
+  nx.iteration = L.cur.iteration + 1;
+  nx.gradient_max_norm = L.cur.gradient_max_norm;
+
+  // ComputeTrustRegionStep
+  const auto t_lin = Clock::now();
+  pgo::launch_damping(P->g, L.radius, o.min_lm_diagonal, o.max_lm_diagonal, L.reuse_diagonal ? 1 : 0, s);
+  int cg_it = 0, cg_status = 0;
+  int rc = run_pcg(P, cg_params_for(o), o.cg_batch, &cg_it, &cg_status);
+  if (rc) return rc;
+  L.reuse_diagonal = true;
+  L.num_linear_iterations += cg_it;
+  nx.linear_solver_iterations = cg_it;
+  // model cost change, delta, candidate, candidate cost — one more sync
+  pgo::launch_model_and_retract(P->g, s);
+  L.t_linear += seconds_since(t_lin);
+  const auto t_res = Clock::now();
+  pgo::launch_cost(P->g, P->g.pose_c, 0, s);
+  pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s);
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  L.t_residual += seconds_since(t_res);
+  const pgo::LmScalars sc = *P->scal;
+  const bool lin_ok = (cg_status != 2) && std::isfinite(sc.model_change) && !sc.linearize_bad;
+  const double model_cost_change = sc.model_change;
+  const bool step_valid = lin_ok && model_cost_change > 0.0;
+
+  if (!step_valid) {
+    // HandleInvalidStep
+    ++L.num_consecutive_invalid;
+    if (L.num_consecutive_invalid >= o.max_num_consecutive_invalid_steps) {
+      terminate(L, PGO_FAILURE, 6, "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d",
+                o.max_num_consecutive_invalid_steps);
+      L.cur = nx;
+      return PGO_OK;
+    }
+    L.radius *= 0.5;
+    L.reuse_diagonal = true;
+    nx.cost = L.x_cost;
+    nx.step_is_successful = 0;
+    L.cur = nx;
+    L.pending_record = true;
+    L.t_total += seconds_since(t_it);
+    return PGO_OK;
+  }
+  L.num_consecutive_invalid = 0;
+
+  // ParameterToleranceReached
+  nx.step_norm = std::sqrt(sc.step_norm_sq);
+  L.x_norm = std::sqrt(sc.x_norm_sq);
+  const double step_size_tolerance = o.parameter_tolerance * (L.x_norm + o.parameter_tolerance);
+  if (nx.step_norm <= step_size_tolerance) {
+    terminate(L, PGO_CONVERGENCE, 2, "Parameter tolerance reached. Relative step_norm: %e <= %e.",
+              nx.step_norm / (L.x_norm + o.parameter_tolerance), o.parameter_tolerance);
+    L.t_total += seconds_since(t_it);
+    return PGO_OK;
+  }
+  // FunctionToleranceReached
+  const double cand_cost = sc.cand_cost;
+  nx.cost_change = L.x_cost - cand_cost;
+  if (std::fabs(nx.cost_change) <= o.function_tolerance * L.x_cost) {
+    terminate(L, PGO_CONVERGENCE, 1, "Function tolerance reached. |cost_change|/cost: %e <= %e",
+              std::fabs(nx.cost_change) / L.x_cost, o.function_tolerance);
+    L.t_total += seconds_since(t_it);
+    return PGO_OK;
+  }
+  // IsStepSuccessful
+  nx.relative_decrease = nx.cost_change / model_cost_change;
+  if (nx.relative_decrease > o.min_relative_decrease) {
+    // HandleSuccessfulStep: x <- candidate, re-linearise, LevenbergMarquardtStrategy::StepAccepted
+    std::swap(P->g.pose_x, P->g.pose_c);
+    L.x_cost = cand_cost;
+    rc = evaluate_gradient_and_jacobian(P, false);
+    if (rc) return rc;
+    pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s);
+    HIP_TRY(hipStreamSynchronize(s));
+    L.gmax = P->scal->gradient_max;
+    nx.step_is_successful = 1;
+    nx.cost = L.x_cost;
+    nx.gradient_max_norm = L.gmax;
+    L.radius = L.radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * nx.relative_decrease - 1.0, 3));
+    L.radius = std::min(o.max_trust_region_radius, L.radius);
+    L.decrease_factor = 2.0;
+    L.reuse_diagonal = false;
+  } else {
+    // HandleUnsuccessfulStep / StepRejected
+    nx.step_is_successful = 0;
+    nx.cost = cand_cost;
+    L.radius = L.radius / L.decrease_factor;
+    L.decrease_factor *= 2.0;
+    L.reuse_diagonal = true;
+  }
+  L.cur = nx;
+  L.pending_record = true;
+  L.t_total += seconds_since(t_it);
+  return PGO_OK;
+}
+
+int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* records, int capacity) {
+  LmState& L = P->lm;
+  if (!L.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_end without pgo_solver_begin");
+  if (L.pending_record) {
+    if (L.cur.step_is_successful) ++L.num_successful; else ++L.num_unsuccessful;
+    L.cur.trust_region_radius = L.radius;
+    L.records.push_back(L.cur);
+    L.pending_record = false;
+  }
+  if (!L.terminated) terminate(L, PGO_NO_CONVERGENCE, 5, "Stepping stopped by the caller after %d iterations.", L.cur.iteration);
+  int rc = download_poses(P, P->g.pose_x);
+  if (rc) return rc;
+  if (summary) {
+    memset(summary, 0, sizeof *summary);
+    summary->termination_type = L.termination;
+    summary->reason = L.reason;
+    summary->num_successful_steps = L.num_successful;
+    summary->num_unsuccessful_steps = L.num_unsuccessful;
+    summary->num_iterations = (int)L.records.size();
+    summary->num_linear_solver_iterations = L.num_linear_iterations;
+    summary->num_poses = P->g.N;
+    summary->num_edges = P->g.E;
+    summary->initial_cost = L.initial_cost;
+    summary->final_cost = L.x_cost;
+    summary->total_time_in_seconds = L.t_total;
+    summary->setup_time_in_seconds = L.t_setup;
+    summary->linear_solver_time_in_seconds = L.t_linear;
+    summary->jacobian_evaluation_time_in_seconds = L.t_jacobian;
+    summary->residual_evaluation_time_in_seconds = L.t_residual;
+    summary->final_gradient_max_norm = L.gmax;
+    summary->final_trust_region_radius = L.radius;
+    snprintf(summary->message, sizeof summary->message, "%s", L.message.c_str());
+  }
+  if (records) {
+    const int n = std::min(capacity, (int)L.records.size());
+    for (int i = 0; i < n; ++i) records[i] = L.records[i];
+  }
+  L.active = false;
+  return PGO_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int pgo_version(void) { return PGO_VERSION; }
+const char* pgo_last_error(void) { return g_error.c_str(); }
+
+int pgo_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return count;
+}
+
+static int g_default_device = 0;
+int pgo_set_device(int device) {
+  if (device < 0) return set_error(PGO_ERR_INVALID_ARGUMENT, "negative device index");
+  g_default_device = device;
+  return PGO_OK;
+}
+
+pgo_problem* pgo_problem_create(void) {
+  pgo_problem* p = new (std::nothrow) pgo_problem();
+  if (p) p->device = g_default_device;
+  return p;
+}
+void pgo_problem_destroy(pgo_problem* problem) { delete problem; }
+
+int pgo_problem_add_pose(pgo_problem* P, double* p, double* q) {
+  if (!P || !p || !q) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_problem_add_pose");
+  auto ip = P->block_of_ptr.find(p), iq = P->block_of_ptr.find(q);
+  if (ip != P->block_of_ptr.end() || iq != P->block_of_ptr.end()) {
+    if (ip != P->block_of_ptr.end() && iq != P->block_of_ptr.end() && (ip->second >> 1) == (iq->second >> 1) &&
+        (ip->second & 1) == 0 && (iq->second & 1) == 1)
+      return ip->second >> 1;
+    return set_error(PGO_ERR_UNSUPPORTED, "a parameter block is already paired with a different translation/rotation block");
+  }
+  const int idx = (int)P->pp.size();
+  P->pp.push_back(p);
+  P->qq.push_back(q);
+  P->cmask.push_back(0);
+  P->block_of_ptr[p] = 2 * idx;
+  P->block_of_ptr[q] = 2 * idx + 1;
+  P->topo_dirty = true;
+  return idx;
+}
+
+int pgo_problem_add_poses(pgo_problem* P, int n, double* base, int stride) {
+  if (!P || !base || n < 0 || stride < 7) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_problem_add_poses");
+  const int first = (int)P->pp.size();
+  P->pp.reserve(first + n); P->qq.reserve(first + n); P->cmask.reserve(first + n);
+  P->block_of_ptr.reserve((size_t)2 * (first + n));
+  for (int i = 0; i < n; ++i) {
+    const int r = pgo_problem_add_pose(P, base + (size_t)i * stride, base + (size_t)i * stride + 3);
+    if (r < 0) return r;
+  }
+  return first;
+}
+
+int pgo_problem_add_se3_between_batch(pgo_problem* P, int n, const int* begin, const int* end, const double* t_be,
+                                      const double* sqrt_information) {
+  if (!P || n < 0 || (n > 0 && (!begin || !end || !t_be))) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_problem_add_se3_between_batch");
+  const int N = (int)P->pp.size();
+  for (int i = 0; i < n; ++i) {
+    if (begin[i] < 0 || begin[i] >= N || end[i] < 0 || end[i] >= N)
+      return set_error(PGO_ERR_INVALID_ARGUMENT, "edge %d references a pose that was never added", i);
+    if (begin[i] == end[i]) return set_error(PGO_ERR_INVALID_ARGUMENT, "edge %d connects a pose to itself", i);
+  }
+  const int first = (int)P->ia.size();
+  if (sqrt_information && !P->has_info) {
+    // earlier edges used the identity
+    P->sqrt_info.assign((size_t)36 * first, 0.0);
+    for (int e = 0; e < first; ++e) for (int d = 0; d < 6; ++d) P->sqrt_info[(size_t)36 * e + 7 * d] = 1.0;
+    P->has_info = true;
+  }
+  P->ia.insert(P->ia.end(), begin, begin + n);
+  P->ib.insert(P->ib.end(), end, end + n);
+  P->meas.insert(P->meas.end(), t_be, t_be + (size_t)7 * n);
+  if (P->has_info) {
+    if (sqrt_information) {
+      P->sqrt_info.insert(P->sqrt_info.end(), sqrt_information, sqrt_information + (size_t)36 * n);
+    } else {
+      const size_t old = P->sqrt_info.size();
+      P->sqrt_info.resize(old + (size_t)36 * n, 0.0);
+      for (int e = 0; e < n; ++e) for (int d = 0; d < 6; ++d) P->sqrt_info[old + (size_t)36 * e + 7 * d] = 1.0;
+    }
+  }
+  P->topo_dirty = true;
+  return first;
+}
+
+int pgo_problem_add_se3_between(pgo_problem* P, int pose_begin, int pose_end, const double* t_be_p, const double* t_be_q,
+                                const double* sqrt_information) {
+  if (!P || !t_be_p || !t_be_q) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_problem_add_se3_between");
+  double t[7] = {t_be_p[0], t_be_p[1], t_be_p[2], t_be_q[0], t_be_q[1], t_be_q[2], t_be_q[3]};
+  return pgo_problem_add_se3_between_batch(P, 1, &pose_begin, &pose_end, t, sqrt_information);
+}
+
+int pgo_problem_set_loss(pgo_problem* P, int kind, double a) {
+  if (!P) return set_error(PGO_ERR_INVALID_ARGUMENT, "null problem");
+  if (kind != PGO_LOSS_TRIVIAL && kind != PGO_LOSS_HUBER) return set_error(PGO_ERR_UNSUPPORTED, "unknown loss kind %d", kind);
+  if (kind == PGO_LOSS_HUBER && !(a > 0.0)) return set_error(PGO_ERR_INVALID_ARGUMENT, "Huber scale must be positive");
+  P->loss_kind = kind;
+  P->loss_a = a;
+  return PGO_OK;
+}
+
+int pgo_problem_set_pose_constant(pgo_problem* P, int pose, int which) {
+  if (!P || pose < 0 || pose >= (int)P->pp.size() || (which & ~3) || which == 0)
+    return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_problem_set_pose_constant");
+  P->cmask[pose] |= (uint8_t)which;
+  P->topo_dirty = true;
+  return PGO_OK;
+}
+
+int pgo_problem_set_parameter_block_constant(pgo_problem* P, const double* block) {
+  if (!P || !block) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument");
+  auto it = P->block_of_ptr.find(block);
+  if (it == P->block_of_ptr.end()) return set_error(PGO_ERR_INVALID_ARGUMENT, "parameter block not found in the problem");
+  return pgo_problem_set_pose_constant(P, it->second >> 1, (it->second & 1) ? 2 : 1);
+}
+
+int pgo_problem_num_poses(const pgo_problem* P) { return P ? (int)P->pp.size() : 0; }
+int pgo_problem_num_edges(const pgo_problem* P) { return P ? (int)P->ia.size() : 0; }
+
+void pgo_solver_options_init(pgo_solver_options* o) {
+  memset(o, 0, sizeof *o);
+  o->max_num_iterations = 50;
+  o->linear_solver_type = PGO_SPARSE_NORMAL_CHOLESKY;
+  o->jacobi_scaling = 1;
+  o->max_linear_solver_iterations = 500;
+  o->min_linear_solver_iterations = 0;
+  o->max_num_consecutive_invalid_steps = 5;
+  o->cg_batch = 0;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->eta = 1e-1;
+  o->exact_r_tolerance = 1e-13;
+}
+
+int pgo_solver_begin(pgo_problem* P, const pgo_solver_options* options) {
+  if (!P || !options) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_solver_begin");
+  return lm_begin(P, options);
+}
+
+int pgo_solver_step(pgo_problem* P, int n, int* done) {
+  if (!P || !P->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_step without pgo_solver_begin");
+  for (int i = 0; i < n && !P->lm.terminated; ++i) {
+    int rc = lm_advance(P);
+    if (rc) return rc;
+  }
+  if (done) *done = P->lm.terminated ? 1 : 0;
+  return PGO_OK;
+}
+
+int pgo_solver_reset(pgo_problem* P) {
+  if (!P || !P->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_reset without pgo_solver_begin");
+  LmState& L = P->lm;
+  HIP_TRY(hipMemcpyAsync(P->g.pose_x, P->d_pose_0.p, P->d_pose_0.n * sizeof(double), hipMemcpyDeviceToDevice, P->stream));
+  int rc = evaluate_gradient_and_jacobian(P, true);
+  if (rc) return rc;
+  pgo::launch_cost(P->g, P->g.pose_x, 0, P->stream);
+  pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, P->stream);
+  HIP_TRY(hipStreamSynchronize(P->stream));
+  L.x_cost = P->scal->cand_cost;
+  L.gmax = P->scal->gradient_max;
+  L.radius = P->opt.initial_trust_region_radius;
+  L.decrease_factor = 2.0;
+  L.reuse_diagonal = false;
+  L.terminated = false;
+  L.num_consecutive_invalid = 0;
+  pgo_iteration_record r{};
+  r.iteration = 0;  // the iteration budget restarts with the state
+  r.step_is_successful = 1;
+  r.cost = L.x_cost;
+  r.gradient_max_norm = L.gmax;
+  L.cur = r;
+  L.pending_record = false;
+  return PGO_OK;
+}
+
+int pgo_solver_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* records, int capacity) {
+  if (!P) return set_error(PGO_ERR_INVALID_ARGUMENT, "null problem");
+  return lm_end(P, summary, records, capacity);
+}
+
+int pgo_solve(pgo_problem* P, const pgo_solver_options* options, pgo_solver_summary* summary,
+              pgo_iteration_record* records, int capacity) {
+  if (!P || !options) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_solve");
+  int rc = lm_begin(P, options);
+  if (rc) return rc;
+  while (!P->lm.terminated) {
+    rc = lm_advance(P);
+    if (rc) return rc;
+  }
+  return lm_end(P, summary, records, capacity);
+}
+
+int pgo_summary_is_solution_usable(const pgo_solver_summary* s) {
+  return s && (s->termination_type == PGO_CONVERGENCE || s->termination_type == PGO_NO_CONVERGENCE) ? 1 : 0;
+}
+
+size_t pgo_summary_full_report(const pgo_solver_summary* s, const pgo_iteration_record* rec, int n_rec, char* buffer, size_t capacity) {
+  std::string r;
+  char line[512];
+  auto add = [&](const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(line, sizeof line, fmt, ap);
+    va_end(ap);
+    r += line;
+  };
+  static const char* term[] = {"CONVERGENCE", "NO_CONVERGENCE", "FAILURE"};
+  add("\nSolver Summary (v %d.%d.%d-hip-gfx950)\n\n", PGO_VERSION / 100, (PGO_VERSION / 10) % 10, PGO_VERSION % 10);
+  add("%-28s %12s\n", "", "Original");
+  add("%-28s %12d\n", "Parameter blocks", 2 * s->num_poses);
+  add("%-28s %12d\n", "Parameters", 7 * s->num_poses);
+  add("%-28s %12d\n", "Effective parameters", 6 * s->num_poses);
+  add("%-28s %12d\n", "Residual blocks", s->num_edges);
+  add("%-28s %12d\n\n", "Residual", 6 * s->num_edges);
+  add("Minimizer                        TRUST_REGION\n");
+  add("Trust region strategy     LEVENBERG_MARQUARDT\n");
+  add("Compute device              HIP gfx950 (FP64)\n\n");
+  add("Cost:\n");
+  add("%-28s %e\n", "Initial", s->initial_cost);
+  add("%-28s %e\n", "Final", s->final_cost);
+  add("%-28s %e\n\n", "Change", s->initial_cost - s->final_cost);
+  add("Minimizer iterations         %12d\n", s->num_iterations);
+  add("Successful steps             %12d\n", s->num_successful_steps);
+  add("Unsuccessful steps           %12d\n", s->num_unsuccessful_steps);
+  add("Linear solver iterations     %12d\n\n", s->num_linear_solver_iterations);
+  add("Time (in seconds):\n");
+  add("Preprocessor (topology+upload) %10.6f\n\n", s->setup_time_in_seconds);
+  add("  Residual evaluation          %10.6f\n", s->residual_evaluation_time_in_seconds);
+  add("  Jacobian evaluation          %10.6f\n", s->jacobian_evaluation_time_in_seconds);
+  add("  Linear solver                %10.6f\n", s->linear_solver_time_in_seconds);
+  add("Minimizer                      %10.6f\n\n", s->total_time_in_seconds);
+  if (rec && n_rec > 0) {
+    add("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  ls_iter\n");
+    for (int i = 0; i < n_rec; ++i)
+      add("%4d %.6e %10.2e %10.2e %9.2e %10.2e %9.2e %8d\n", rec[i].iteration, rec[i].cost, rec[i].cost_change,
+          rec[i].gradient_max_norm, rec[i].step_norm, rec[i].relative_decrease, rec[i].trust_region_radius,
+          rec[i].linear_solver_iterations);
+    add("\n");
+  }
+  const int t = (s->termination_type >= 0 && s->termination_type <= 2) ? s->termination_type : 2;
+  add("Termination: %24s (%s)\n", term[t], s->message);
+  if (buffer && capacity) {
+    const size_t n = std::min(capacity - 1, r.size());
+    memcpy(buffer, r.data(), n);
+    buffer[n] = 0;
+  }
+  return r.size() + 1;
+}
+
+// ---- evaluation entry points -------------------------------------------------------------------
+int pgo_evaluate(pgo_problem* P, double* cost, double* residuals, double* jac_begin, double* jac_end, double* gradient) {
+  if (!P) return set_error(PGO_ERR_INVALID_ARGUMENT, "null problem");
+  int rc = prepare(P);
+  if (rc) return rc;
+  hipStream_t s = P->stream;
+  P->g.loss_kind = P->loss_kind; P->g.loss_a = P->loss_a;
+  P->g.pose_x = P->d_pose_x.p; P->g.pose_c = P->d_pose_c.p;
+  rc = upload_poses(P, P->g.pose_x);
+  if (rc) return rc;
+  const int E = P->g.E, N = P->g.N;
+  if (residuals || jac_begin || jac_end) {
+    if (residuals) HIP_TRY(P->d_tmp_a.alloc((size_t)6 * E));
+    if (jac_begin) HIP_TRY(P->d_tmp_b.alloc((size_t)36 * E));
+    if (jac_end) HIP_TRY(P->d_tmp_c.alloc((size_t)36 * E));
+    if (E > 0) pgo::launch_evaluate_edges(P->g, P->g.pose_x, residuals ? P->d_tmp_a.p : nullptr, jac_begin ? P->d_tmp_b.p : nullptr,
+                               jac_end ? P->d_tmp_c.p : nullptr, s);
+    if (residuals && E) HIP_TRY(hipMemcpyAsync(residuals, P->d_tmp_a.p, sizeof(double) * 6 * E, hipMemcpyDeviceToHost, s));
+    if (jac_begin && E) HIP_TRY(hipMemcpyAsync(jac_begin, P->d_tmp_b.p, sizeof(double) * 36 * E, hipMemcpyDeviceToHost, s));
+    if (jac_end && E) HIP_TRY(hipMemcpyAsync(jac_end, P->d_tmp_c.p, sizeof(double) * 36 * E, hipMemcpyDeviceToHost, s));
+  }
+  if (cost) {
+    pgo::launch_cost(P->g, P->g.pose_x, 0, s);
+    pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s);
+  }
+  if (gradient) {
+    rc = fill_scale_one(P);
+    if (rc) return rc;
+    pgo::launch_linearize(P->g, s);
+    HIP_TRY(hipMemcpyAsync(gradient, P->g.grad, sizeof(double) * 6 * N, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  if (cost) *cost = P->scal->cand_cost;
+  return PGO_OK;
+}
+
+int pgo_normal_equations(pgo_problem* P, double* diag, double* offdiag, double* gradient) {
+  if (!P) return set_error(PGO_ERR_INVALID_ARGUMENT, "null problem");
+  int rc = prepare(P);
+  if (rc) return rc;
+  hipStream_t s = P->stream;
+  P->g.loss_kind = P->loss_kind; P->g.loss_a = P->loss_a;
+  P->g.pose_x = P->d_pose_x.p; P->g.pose_c = P->d_pose_c.p;
+  rc = upload_poses(P, P->g.pose_x);
+  if (rc) return rc;
+  rc = fill_scale_one(P);
+  if (rc) return rc;
+  pgo::launch_linearize(P->g, s);
+  const int N = P->g.N, E = P->g.E;
+  if (diag) HIP_TRY(hipMemcpyAsync(diag, P->g.Hdiag, sizeof(double) * 36 * N, hipMemcpyDeviceToHost, s));
+  if (gradient) HIP_TRY(hipMemcpyAsync(gradient, P->g.grad, sizeof(double) * 6 * N, hipMemcpyDeviceToHost, s));
+  std::vector<double> bsr;
+  if (offdiag) {
+    bsr.resize((size_t)P->g.n_slots * 36);
+    HIP_TRY(hipMemcpyAsync(bsr.data(), P->g.bsr_val, bsr.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  if (offdiag)
+    for (int e = 0; e < E; ++e) {
+      const int t = P->edge_begin_slot[e];
+      for (int k = 0; k < 36; ++k) offdiag[(size_t)36 * e + k] = bsr[pgo::bsr_index(t, k)];
+    }
+  return PGO_OK;
+}
+
+int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const double* d2, const double* b, double* x, int* iterations) {
+  if (!P || !options || !d2 || !b || !x) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_linear_solve");
+  int rc = prepare(P);
+  if (rc) return rc;
+  hipStream_t s = P->stream;
+  P->g.loss_kind = P->loss_kind; P->g.loss_a = P->loss_a;
+  P->g.pose_x = P->d_pose_x.p; P->g.pose_c = P->d_pose_c.p;
+  rc = upload_poses(P, P->g.pose_x);
+  if (rc) return rc;
+  rc = fill_scale_one(P);
+  if (rc) return rc;
+  const size_t m = (size_t)6 * P->g.N;
+  pgo::launch_linearize(P->g, s);
+  HIP_TRY(hipMemcpyAsync(P->g.d2, d2, m * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(P->g.grad, b, m * sizeof(double), hipMemcpyHostToDevice, s));  // rhs = scale(=1) * grad
+  HIP_TRY(hipStreamSynchronize(s));
+  pgo::launch_damping(P->g, 1.0, 0.0, 0.0, 2, s);
+  int it = 0, status = 0;
+  rc = run_pcg(P, cg_params_for(*options), options->cg_batch, &it, &status);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(x, P->g.cg_x, m * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (iterations) *iterations = it;
+  if (status == 2) return set_error(PGO_ERR_NUMERICAL, "PCG broke down with non-finite values");
+  return PGO_OK;
+}
+
+int pgo_plus(pgo_problem* P, const double* delta) {
+  if (!P || !delta) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_plus");
+  int rc = prepare(P);
+  if (rc) return rc;
+  hipStream_t s = P->stream;
+  P->g.pose_x = P->d_pose_x.p; P->g.pose_c = P->d_pose_c.p;
+  rc = upload_poses(P, P->g.pose_x);
+  if (rc) return rc;
+  const size_t m = (size_t)6 * P->g.N;
+  HIP_TRY(P->d_tmp_a.alloc(m));
+  HIP_TRY(hipMemcpyAsync(P->d_tmp_a.p, delta, m * sizeof(double), hipMemcpyHostToDevice, s));
+  pgo::launch_apply_step(P->g, P->d_tmp_a.p, s);
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  return download_poses(P, P->g.pose_c);
+}
+
+int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg_ms) {
+  if (!P || !kernel || repeats <= 0 || !avg_ms) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_time_kernel");
+  if (P->topo_dirty || !P->stream_ready) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel needs a prepared problem (call pgo_solver_begin first)");
+  hipStream_t s = P->stream;
+  const std::string k = kernel;
+  pgo::CgParams prm = cg_params_for(P->opt);
+  if (k == "evaluate") {
+    HIP_TRY(P->d_tmp_a.alloc((size_t)6 * P->g.E));
+    HIP_TRY(P->d_tmp_b.alloc((size_t)36 * P->g.E));
+    HIP_TRY(P->d_tmp_c.alloc((size_t)36 * P->g.E));
+  }
+  // "pcg_spmv" repeats the SpMV kernel of CG iteration 1 (the update kernel never runs, so the
+  // iteration counter stays put); "pcg_update" likewise repeats the update of iteration 1.
+  if (k == "pcg_spmv" || k == "pcg_update" || k == "pcg_iteration") {
+    pgo::launch_damping(P->g, P->lm.radius, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, 0, s);
+    pgo::launch_pcg_init(P->g, s);
+  }
+  if (k == "pcg_update") pgo::launch_pcg_spmv_only(P->g, prm, s);
+  auto once = [&]() -> int {
+    if (k == "linearize") pgo::launch_linearize(P->g, s);
+    else if (k == "cost") pgo::launch_cost(P->g, P->g.pose_x, 5, s);
+    else if (k == "evaluate") pgo::launch_evaluate_edges(P->g, P->g.pose_x, P->d_tmp_a.p, P->d_tmp_b.p, P->d_tmp_c.p, s);
+    else if (k == "spmv") pgo::launch_spmv_plain(P->g, s);
+    else if (k == "pcg_spmv") pgo::launch_pcg_spmv_only(P->g, prm, s);
+    else if (k == "pcg_update") pgo::launch_pcg_update_only(P->g, s);
+    else if (k == "pcg_iteration") pgo::launch_pcg_iteration(P->g, prm, s);
+    else return -1;
+    return 0;
+  };
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  if (once() != 0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return set_error(PGO_ERR_INVALID_ARGUMENT, "unknown kernel '%s'", kernel); }
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipEventRecord(e0, s));
+  for (int i = 0; i < repeats; ++i) once();
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = (double)ms / repeats;
+  return PGO_OK;
+}
+
+// ---- sharding helpers ------------------------------------------------------------------------------
+int pgo_shard_range(long long n, int rank, int world, long long* begin, long long* end) {
+  if (n < 0 || world <= 0 || rank < 0 || rank >= world || !begin || !end) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_shard_range");
+  const long long base = n / world, rem = n % world;
+  *begin = base * rank + std::min<long long>(rank, rem);
+  *end = *begin + base + (rank < rem ? 1 : 0);
+  return PGO_OK;
+}
+
+int pgo_comm_get_unique_id(unsigned char id[128]) {
+  (void)id;
+  return set_error(PGO_ERR_UNSUPPORTED, "RCCL sharding is not wired in this build");
+}
+int pgo_comm_init(pgo_problem* problem, const unsigned char id[128], int rank, int world) {
+  (void)problem; (void)id; (void)rank; (void)world;
+  return set_error(PGO_ERR_UNSUPPORTED, "RCCL sharding is not wired in this build");
+}
+
+}  // extern "C"

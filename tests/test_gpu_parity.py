@@ -1,0 +1,201 @@
+"""-m gpu parity tests: the HIP path (through the C ABI of include/pgo.h) against the CPU oracle on the
+same seeded inputs.  Tolerances are stated per test; everything is FP64."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_graph(ds, n, e, seed, info="full", unit=True):
+    """Random poses / measurements (large residuals, random 6x6 sqrt information)."""
+    rng = np.random.default_rng(seed)
+    poses = np.zeros((n, 7))
+    poses[:, :3] = rng.normal(0, 2.0, size=(n, 3))
+    q = rng.normal(size=(n, 4))
+    poses[:, 3:] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    if not unit:
+        poses[:, 3:] *= (1.0 + 1e-4 * rng.normal(size=(n, 1)))
+    ia = rng.integers(0, n, size=e).astype(np.int32)
+    ib = (ia + 1 + rng.integers(0, n - 1, size=e)).astype(np.int32) % n
+    meas = np.zeros((e, 7))
+    meas[:, :3] = rng.normal(0, 1.0, size=(e, 3))
+    mq = rng.normal(size=(e, 4))
+    meas[:, 3:] = mq / np.linalg.norm(mq, axis=1, keepdims=True)
+    sqrt_info = None
+    if info == "full":
+        A = rng.normal(size=(e, 6, 6))
+        M = A @ np.transpose(A, (0, 2, 1)) + 6 * np.eye(6)
+        sqrt_info = np.linalg.cholesky(M).reshape(e, 36) * 0.3
+    elif info == "diag":
+        sqrt_info = np.repeat(np.diag(rng.uniform(0.5, 3.0, size=6)).reshape(1, 36), e, axis=0)
+    return ds.PoseGraphData(poses, ia, ib, meas, sqrt_info)
+
+
+def _pair(gpu, O, g, cmask=None, loss=1, loss_a=1.0):
+    og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info, cmask)
+    prob, poses = gpu.problem_from_graph(g, loss=loss, loss_a=loss_a, constant_first=False)
+    cm = og.cmask
+    for v in np.nonzero(cm)[0]:
+        prob.set_pose_constant(int(v), int(cm[v]))
+    return prob, poses, og
+
+
+@pytest.mark.parametrize("info", ["full", "diag", None])
+@pytest.mark.parametrize("loss", [0, 1])
+def test_evaluate_matches_oracle(gpu, O, ds, info, loss):
+    g = _random_graph(ds, 200, 900, seed=11, info=info, unit=(info != "diag"))
+    cmask = np.zeros(200, dtype=np.uint8)
+    cmask[0] = 3
+    cmask[5] = 1
+    cmask[9] = 2
+    prob, poses, og = _pair(gpu, O, g, cmask, loss=loss, loss_a=1.5)
+    cost, r, ja, jb, grad = prob.evaluate()
+    ocost, orr, oja, ojb = O.evaluate(og, loss_kind=loss, loss_a=1.5)
+    assert cost == pytest.approx(ocost, rel=1e-12)
+    scale = max(1.0, np.abs(oja).max())
+    assert np.abs(r - orr).max() <= 1e-11 * max(1.0, np.abs(orr).max())
+    assert np.abs(ja - oja).max() <= 1e-11 * scale
+    assert np.abs(jb - ojb).max() <= 1e-11 * scale
+    # gradient = sum J^T r
+    og_grad = np.zeros((g.N, 6))
+    np.add.at(og_grad, g.ia, np.einsum("eki,ek->ei", oja, orr))
+    np.add.at(og_grad, g.ib, np.einsum("eki,ek->ei", ojb, orr))
+    assert np.abs(grad - og_grad).max() <= 1e-10 * max(1.0, np.abs(og_grad).max())
+
+
+@pytest.mark.parametrize("info", ["full", None])
+def test_normal_equations_match_oracle(gpu, O, ds, info):
+    g = _random_graph(ds, 60, 400, seed=5, info=info)
+    cmask = np.zeros(60, dtype=np.uint8)
+    cmask[0] = 3
+    cmask[7] = 2
+    prob, poses, og = _pair(gpu, O, g, cmask)
+    diag, off, grad = prob.normal_equations()
+    ocost, H, ograd = O.normal_equations_dense(og)
+    tol = 1e-10 * np.abs(H).max()
+    for v in range(g.N):
+        assert np.abs(diag[v] - H[6 * v:6 * v + 6, 6 * v:6 * v + 6]).max() <= tol
+    # off-diagonal: oracle accumulates duplicates of a pair; compare sums per (a,b)
+    acc = {}
+    for e in range(g.E):
+        key = (int(g.ia[e]), int(g.ib[e]))
+        acc[key] = acc.get(key, 0) + off[e]
+    merged = {}
+    for (a, b), blk in acc.items():
+        k2 = (a, b) if a < b else (b, a)
+        merged[k2] = merged.get(k2, 0) + (blk if a < b else blk.T)
+    for (a, b), blk in merged.items():
+        assert np.abs(blk - H[6 * a:6 * a + 6, 6 * b:6 * b + 6]).max() <= tol
+    assert np.abs(grad.reshape(-1) - ograd).max() <= 1e-10 * max(1.0, np.abs(ograd).max())
+
+
+def test_plus_matches_oracle(gpu, O, ds):
+    g = _random_graph(ds, 300, 400, seed=3)
+    prob, poses, og = _pair(gpu, O, g, np.zeros(300, dtype=np.uint8))
+    rng = np.random.default_rng(0)
+    delta = rng.normal(0, 0.3, size=(300, 6))
+    delta[10, 3:] = 0.0  # zero rotation step keeps q bitwise
+    before = poses.copy()
+    prob.plus(delta)
+    for v in range(300):
+        assert np.allclose(poses[v, :3], before[v, :3] + delta[v, :3], rtol=0, atol=1e-15)
+        assert np.allclose(poses[v, 3:], O.quat_plus(before[v, 3:], delta[v, 3:]), rtol=0, atol=1e-15)
+    assert np.array_equal(poses[10, 3:], before[10, 3:])
+
+
+def test_linear_solve_matches_exact_oracle(gpu, O, ds):
+    g = ds.manhattan_se3(150, 500, seed=2)
+    prob, poses, og = _pair(gpu, O, g)
+    rng = np.random.default_rng(1)
+    d2 = rng.uniform(0.1, 1.0, size=g.N * 6)
+    b = rng.normal(size=g.N * 6)
+    b[:6] = 0.0  # constant pose
+    x, it = prob.linear_solve(d2, b, gpu.SolverOptions(linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY))
+    xo, _ = O.linear_solve(og, d2, b, linear_solver=0)
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    # truncated PCG with the Ceres Q-tolerance: same iteration count and iterate as the oracle's PCG
+    x2, it2 = prob.linear_solve(d2, b, gpu.SolverOptions(linear_solver_type=gpu.BLOCK_JACOBI_PCG, eta=0.1))
+    xo2, ito2 = O.linear_solve(og, d2, b, linear_solver=1, q_tol=0.1, max_it=500)
+    assert it2 == ito2
+    assert np.abs(x2 - xo2).max() <= 1e-9 * np.abs(xo2).max()
+
+
+@pytest.mark.parametrize("solver", ["pcg", "exact"])
+def test_lm_trace_matches_oracle(gpu, O, ds, solver):
+    g = ds.manhattan_se3(300, 1000, seed=4)
+    prob, poses, og = _pair(gpu, O, g)
+    ls = gpu.BLOCK_JACOBI_PCG if solver == "pcg" else gpu.SPARSE_NORMAL_CHOLESKY
+    opt = gpu.SolverOptions(max_num_iterations=40, linear_solver_type=ls)
+    s = gpu.solve(opt, prob)
+    oposes, osum, otrace = O.solve(og, O.default_options(max_num_iterations=40, linear_solver=1 if solver == "pcg" else 0))
+    assert s.initial_cost == pytest.approx(osum.initial_cost, rel=1e-12)
+    n = min(len(s.iterations), len(otrace), 12)
+    # same accept/reject decisions and costs over the first iterations (later ones amplify rounding)
+    assert list(s.iterations["step_is_successful"][:n]) == [int(v) for v in otrace[:n, 8]]
+    assert np.allclose(s.iterations["cost"][:n], otrace[:n, 1], rtol=1e-7)
+    assert s.final_cost == pytest.approx(osum.final_cost, rel=1e-5)
+    assert s.is_solution_usable()
+    # constant pose untouched, result written in place
+    assert np.array_equal(poses[0], g.poses[0])
+    assert not np.array_equal(poses[1:], g.poses[1:])
+
+
+def test_tight_convergence_pose_parity(gpu, O, ds):
+    """Both sides run to tight convergence (function_tolerance -> 0): poses must agree."""
+    g = ds.manhattan_se3(200, 800, seed=9, sigma_t=0.02, sigma_r=0.004)
+    prob, poses, og = _pair(gpu, O, g, loss=0)
+    opt = gpu.SolverOptions(max_num_iterations=200, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY,
+                            function_tolerance=1e-14, parameter_tolerance=1e-12)
+    s = gpu.solve(opt, prob)
+    oposes, osum, _ = O.solve(og, O.default_options(max_num_iterations=200, linear_solver=0, loss_kind=0,
+                                                   function_tolerance=1e-14, parameter_tolerance=1e-12))
+    assert s.final_cost == pytest.approx(osum.final_cost, rel=1e-9)
+    assert np.abs(poses[:, :3] - oposes[:, :3]).max() <= 1e-6          # metres
+    dq = np.minimum(np.abs(poses[:, 3:] - oposes[:, 3:]).max(axis=1), np.abs(poses[:, 3:] + oposes[:, 3:]).max(axis=1))
+    assert dq.max() <= 1e-7
+
+
+def test_edge_cases(gpu, O, ds):
+    # empty edge set: cost 0, converges immediately, poses untouched
+    poses = np.zeros((3, 7))
+    poses[:, 6] = 1.0
+    p = gpu.Problem()
+    p.add_poses(poses)
+    p.set_pose_constant(0)
+    s = gpu.solve(gpu.SolverOptions(), p)
+    assert s.final_cost == 0.0 and s.is_solution_usable()
+    # a star: one hub with > block incidences (fat row spanning several chunks)
+    rng = np.random.default_rng(2)
+    n = 700
+    truth = np.zeros((n, 7))
+    truth[:, :3] = rng.normal(0, 3, size=(n, 3))
+    q = rng.normal(size=(n, 4))
+    truth[:, 3:] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    ia = np.arange(1, n, dtype=np.int32)
+    ib = np.zeros(n - 1, dtype=np.int32)
+    meas = ds.relative_pose(truth[ia], truth[ib])
+    meas[:, :3] += rng.normal(0, 0.01, size=(n - 1, 3))
+    init = truth.copy()
+    init[1:, :3] += rng.normal(0, 0.1, size=(n - 1, 3))
+    g = ds.PoseGraphData(init, ia, ib, meas, None)
+    prob, poses2, og = _pair(gpu, O, g)
+    diag, off, grad = prob.normal_equations()
+    ocost, H, ograd = O.normal_equations_dense(og)
+    assert np.abs(diag[0] - H[:6, :6]).max() <= 1e-9 * np.abs(H[:6, :6]).max()
+    assert np.abs(grad.reshape(-1) - ograd).max() <= 1e-9 * max(1.0, np.abs(ograd).max())
+    s2 = gpu.solve(gpu.SolverOptions(max_num_iterations=20, linear_solver_type=gpu.BLOCK_JACOBI_PCG), prob)
+    _, osum, _ = O.solve(og, O.default_options(max_num_iterations=20, linear_solver=1))
+    assert s2.final_cost == pytest.approx(osum.final_cost, rel=1e-6)
+
+
+def test_api_misuse_reports_errors(gpu):
+    p = gpu.Problem()
+    poses = np.zeros((2, 7))
+    poses[:, 6] = 1
+    p.add_poses(poses)
+    with pytest.raises(gpu.PgoError):
+        p.add_se3_between([0], [5], np.zeros((1, 7)))       # unknown pose
+    with pytest.raises(gpu.PgoError):
+        p.add_se3_between([1], [1], np.zeros((1, 7)))       # self edge
+    with pytest.raises(gpu.PgoError):
+        p.set_loss(gpu.HUBER, -1.0)
