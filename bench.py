@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py — the hot path of TurtleZhong/PoseGraph-Ceres on MI355X: Levenberg-Marquardt iterations of the
+SE(3) pose-graph solve (residual + analytic Jacobians + J'J assembly + block-Jacobi PCG + step control).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic Manhattan SE(3) graph, 10 000 poses /
+40 000 odometry+loop edges per GPU, diagonal information, Huber(1.0), dead-reckoning initial guess,
+block-Jacobi PCG with Ceres' iterative-solver policy (eta = 0.1 Q-tolerance, <= 500 iterations).
+A "step" is one LM iteration (trial step solve + candidate cost + accept/reject + re-linearisation on
+acceptance).  The timed region starts from the dead-reckoning state with all inputs resident in HBM and
+runs exactly K LM iterations; `value` = edges x LM-iterations per second over all ranks.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_POSES = 10000
+N_EDGES = 40000
+SEED = 20260928
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=25)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--poses", type=int, default=N_POSES)
+    ap.add_argument("--edges", type=int, default=N_EDGES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=12)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    use_dist = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import pgo_loader
+    pkg = pgo_loader.load()
+    ds = pgo_loader.datasets()
+    pkg.build()
+    pkg.set_device(local_rank)
+
+    # every rank owns one graph of the same size (weak scaling; see DESIGN.md §8 for the sharded variant)
+    g = ds.manhattan_se3(args.poses, args.edges, seed=SEED + rank)
+    N, E = g.N, g.E
+    prob, poses = pkg.problem_from_graph(g)
+    opt = pkg.SolverOptions(max_num_iterations=2 ** 30, linear_solver_type=pkg.BLOCK_JACOBI_PCG, eta=0.1,
+                            max_linear_solver_iterations=500, function_tolerance=0.0, parameter_tolerance=0.0,
+                            gradient_tolerance=0.0)
+    prob.solver_begin(opt)
+
+    def run_steps(k):
+        left = k
+        resets = 0
+        while left > 0:
+            ran, done = prob.solver_step(left)
+            left -= ran
+            if done and left > 0:
+                prob.solver_reset()
+                resets += 1
+                if ran == 0 and resets > 4:
+                    raise RuntimeError("LM terminates without making steps")
+        return resets
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(args.warmup)
+    prob.solver_reset()
+    barrier()
+    t0 = time.perf_counter()
+    resets = run_steps(args.steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    # ---- per-kernel durations, HIP events on the solver stream (rank 0) ----
+    roofline = None
+    extra = {}
+    if rank == 0:
+        reps = 400
+        t_spmv = prob.time_kernel("pcg_spmv", reps)
+        t_upd = prob.time_kernel("pcg_update", reps)
+        t_lin = prob.time_kernel("linearize", reps)
+        t_cost = prob.time_kernel("cost", reps)
+        t_eval = prob.time_kernel("evaluate", 100)
+        # algorithmic bytes, SURVEY.md §8d: block SpMV (symmetric BSR accounting) and fused Jacobian+J'J
+        b_spmv = (N + E) * 288 + 2 * N * 48
+        b_lin = 640 * E + 392 * N
+        b_eval = 976 * E + 56 * N
+        ach = b_spmv / (t_spmv * 1e-3) / 1e9
+        roofline = {"kernel": "k_spmv<0> (PCG block SpMV, FP64 6x6 BSR)", "bound": "hbm", "achieved": round(ach, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": b_spmv, "avg_launch_us": round(t_spmv * 1e3, 3)}
+        ach_lin = b_lin / (t_lin * 1e-3) / 1e9
+        ach_eval = b_eval / (t_eval * 1e-3) / 1e9
+        extra["roofline_jacobian_kernel"] = {
+            "kernel": "k_linearize (residual + analytic Jacobians + Huber + J'J/J'r, fused)", "bound": "hbm",
+            "achieved": round(ach_lin, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_lin / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_launch": b_lin, "avg_launch_us": round(t_lin * 1e3, 3),
+            "edge_jacobians_per_sec": round(E / (t_lin * 1e-3), 1)}
+        extra["roofline_materialising_jacobian_kernel"] = {
+            "kernel": "k_evaluate_edges (r, J_begin, J_end written to HBM)", "bound": "hbm", "achieved": round(ach_eval, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_eval / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_launch": b_eval, "avg_launch_us": round(t_eval * 1e3, 3),
+            "edge_jacobians_per_sec": round(E / (t_eval * 1e-3), 1)}
+        extra["kernel_avg_us"] = {"pcg_spmv": round(t_spmv * 1e3, 3), "pcg_update": round(t_upd * 1e3, 3),
+                                  "linearize": round(t_lin * 1e3, 3), "cost": round(t_cost * 1e3, 3),
+                                  "evaluate_edges": round(t_eval * 1e3, 3)}
+    summary = prob.solver_end()
+
+    # ---- CPU baseline on this box's host cores, rank 0, bounded sample ----
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        from oracle import oracle as O
+        og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
+        k = max(1, args.cpu_iters)
+        t1 = time.perf_counter()
+        _, osum, _ = O.solve(og, O.default_options(max_num_iterations=k, linear_solver=0, function_tolerance=0.0,
+                                                   parameter_tolerance=0.0, gradient_tolerance=0.0))
+        dt = time.perf_counter() - t1
+        iters = max(1, osum.num_iterations - 1)
+        cpu = {"value": round(E * iters / dt, 1), "unit": "edge-LM-iterations/s", "cores": 1, "kind": "port",
+               "sample": "%d LM iterations of the same graph from the same start with exact block-sparse Cholesky steps "
+                         "(the reference's SPARSE_NORMAL_CHOLESKY setting, num_threads=1); Ceres itself is not "
+                         "available, this is the in-repo Ceres-equivalent restatement" % iters,
+               "lm_iters_per_sec": round(iters / dt, 4), "seconds": round(dt, 3), "host_cores_available": os.cpu_count()}
+        t2 = time.perf_counter()
+        _, osum2, _ = O.solve(og, O.default_options(max_num_iterations=args.steps, linear_solver=1, function_tolerance=0.0,
+                                                    parameter_tolerance=0.0, gradient_tolerance=0.0))
+        dt2 = time.perf_counter() - t2
+        it2 = max(1, osum2.num_iterations - 1)
+        extra["cpu_same_policy"] = {"value": round(E * it2 / dt2, 1), "unit": "edge-LM-iterations/s", "cores": 1,
+                                    "sample": "%d LM iterations, block-Jacobi PCG eta=0.1 (same policy as the GPU run)" % it2,
+                                    "final_cost": osum2.final_cost, "cg_iterations": osum2.num_linear_iterations}
+        extra["cpu_jacobian_eval_edges_per_sec"] = round(E / (O.time_jacobian_eval(og, 10) / 10), 1)
+
+    if rank == 0:
+        total_edges = E * world
+        value = total_edges * args.steps / elapsed
+        out = {
+            "metric": "lm_edge_iterations_per_sec", "value": round(value, 1), "unit": "edge-LM-iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Synthetic Manhattan SE3 graph, %d poses / %d odom+loop edges per GPU, block-Jacobi PCG "
+                                   "(eta=0.1, <=500 it), Huber(1.0), LM from dead reckoning" % (N, E),
+                       "poses_per_gpu": N, "edges_per_gpu": E, "seed": SEED,
+                       "parallelism": "1 graph per GPU" if world > 1 else "single GPU"},
+            "lm_iters_per_sec": round(args.steps * world / elapsed, 2),
+            "cg_iterations_in_solver_state": summary.num_linear_solver_iterations,
+            "final_cost": summary.final_cost, "resets": resets,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        out.update(extra)
+        print(json.dumps(out))
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

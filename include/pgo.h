@@ -185,8 +185,9 @@ int pgo_plus(pgo_problem* problem, const double* delta);
 
 /* ---- device-resident stepping for benchmarks: poses stay in HBM between calls ---- */
 int pgo_solver_begin(pgo_problem* problem, const pgo_solver_options* options);
-/* runs up to n LM iterations (successful or not); *done becomes 1 when a termination test fired */
-int pgo_solver_step(pgo_problem* problem, int n, int* done);
+/* runs up to n LM iterations (successful or not); *executed = iterations actually run, *done becomes 1
+ * when a termination test fired (either may be NULL) */
+int pgo_solver_step(pgo_problem* problem, int n, int* executed, int* done);
 /* restores the device state to the poses given at pgo_solver_begin (no host traffic) */
 int pgo_solver_reset(pgo_problem* problem);
 int pgo_solver_end(pgo_problem* problem, pgo_solver_summary* summary, pgo_iteration_record* records,

@@ -280,9 +280,10 @@ class Problem:
         _check(lib().pgo_solver_begin(self._h, C.byref(options.c)))
 
     def solver_step(self, n):
-        done = C.c_int(0)
-        _check(lib().pgo_solver_step(self._h, C.c_int(n), C.byref(done)))
-        return bool(done.value)
+        """Runs up to n LM iterations on the device-resident state. Returns (executed, done)."""
+        done, ran = C.c_int(0), C.c_int(0)
+        _check(lib().pgo_solver_step(self._h, C.c_int(n), C.byref(ran), C.byref(done)))
+        return ran.value, bool(done.value)
 
     def solver_reset(self):
         _check(lib().pgo_solver_reset(self._h))

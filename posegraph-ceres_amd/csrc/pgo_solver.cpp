@@ -838,12 +838,17 @@ int pgo_solver_begin(pgo_problem* P, const pgo_solver_options* options) {
   return lm_begin(P, options);
 }
 
-int pgo_solver_step(pgo_problem* P, int n, int* done) {
+int pgo_solver_step(pgo_problem* P, int n, int* executed, int* done) {
   if (!P || !P->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_step without pgo_solver_begin");
+  int ran = 0;
   for (int i = 0; i < n && !P->lm.terminated; ++i) {
+    const int before = P->lm.cur.iteration;
     int rc = lm_advance(P);
     if (rc) return rc;
+    // an iteration counts when a trial step was computed (a pure termination check does not)
+    if (P->lm.cur.iteration != before || !P->lm.terminated) ++ran;
   }
+  if (executed) *executed = ran;
   if (done) *done = P->lm.terminated ? 1 : 0;
   return PGO_OK;
 }

@@ -13,8 +13,8 @@ t = time.time(); g = ds.manhattan_se3(n, e); print("gen", time.time() - t)
 prob, poses = pkg.problem_from_graph(g)
 opt = pkg.SolverOptions(max_num_iterations=1000, linear_solver_type=pkg.BLOCK_JACOBI_PCG, function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
 t = time.time(); prob.solver_begin(opt); print("begin", time.time() - t)
-t = time.time(); done = prob.solver_step(5); print("5 steps", time.time() - t)
-t = time.time(); done = prob.solver_step(20); dt = time.time() - t; print("20 steps", dt, "per step ms", dt / 20 * 1e3)
+t = time.time(); ran, done = prob.solver_step(5); print("5 steps", time.time() - t)
+t = time.time(); ran, done = prob.solver_step(20); dt = time.time() - t; print("20 steps", dt, "per step ms", dt / 20 * 1e3)
 for k in ["linearize", "spmv", "pcg_spmv", "pcg_update", "pcg_iteration", "cost", "evaluate"]:
     print(k, "avg ms", prob.time_kernel(k, 200))
 s = prob.solver_end()
