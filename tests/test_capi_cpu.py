@@ -1,0 +1,107 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/pgo.h declares; host-side
+bookkeeping works without a GPU; compute entry points fail loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "pgo.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pgo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.lib()
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(pkg.C_ABI_SYMBOLS) == names
+    assert L.pgo_version() == 100
+
+
+def test_options_defaults(pkg):
+    o = pkg.SolverOptions()
+    assert (o.max_num_iterations, o.linear_solver_type, o.jacobi_scaling) == (50, pkg.SPARSE_NORMAL_CHOLESKY, 1)
+    assert (o.max_linear_solver_iterations, o.min_linear_solver_iterations, o.max_num_consecutive_invalid_steps) == (500, 0, 5)
+    assert (o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (1e-6, 1e-10, 1e-8)
+    assert (o.initial_trust_region_radius, o.max_trust_region_radius, o.min_trust_region_radius) == (1e4, 1e16, 1e-32)
+    assert (o.min_relative_decrease, o.min_lm_diagonal, o.max_lm_diagonal, o.eta) == (1e-3, 1e-6, 1e32, 0.1)
+    with pytest.raises(AttributeError):
+        pkg.SolverOptions(no_such_option=1)
+
+
+def test_problem_bookkeeping_without_gpu(pkg):
+    L = pkg.lib()
+    poses = np.zeros((4, 7))
+    poses[:, 6] = 1
+    p = pkg.Problem()
+    assert p.add_poses(poses) == 0
+    assert p.num_poses == 4
+    # parameter identity is the pointer value: re-adding the same blocks returns the same index
+    base = poses.ctypes.data_as(C.POINTER(C.c_double))
+    dbl = C.sizeof(C.c_double)
+    addr = poses.ctypes.data
+    pp = C.cast(addr + 7 * dbl * 2, C.POINTER(C.c_double))
+    qq = C.cast(addr + 7 * dbl * 2 + 3 * dbl, C.POINTER(C.c_double))
+    assert L.pgo_problem_add_pose(p._h, pp, qq) == 2
+    # pairing a translation block with another pose's rotation block is refused
+    q_other = C.cast(addr + 7 * dbl * 3 + 3 * dbl, C.POINTER(C.c_double))
+    assert L.pgo_problem_add_pose(p._h, pp, q_other) == pkg.ERR_UNSUPPORTED
+    assert p.add_se3_between([1, 2], [0, 1], np.tile([0, 0, 0, 0, 0, 0, 1.0], (2, 1))) == 0
+    assert p.add_se3_between([3], [2], [[1, 0, 0, 0, 0, 0, 1.0]], np.eye(6).reshape(1, 36)) == 2
+    assert p.num_edges == 3
+    assert L.pgo_problem_set_parameter_block_constant(p._h, base) == 0          # p block of pose 0
+    assert L.pgo_problem_set_parameter_block_constant(p._h, C.cast(addr + 3 * dbl, C.POINTER(C.c_double))) == 0
+    assert L.pgo_problem_set_parameter_block_constant(p._h, C.cast(addr + dbl, C.POINTER(C.c_double))) == pkg.ERR_INVALID_ARGUMENT
+    with pytest.raises(pkg.PgoError):
+        p.add_se3_between([9], [0], np.zeros((1, 7)))
+    with pytest.raises(pkg.PgoError):
+        p.set_pose_constant(17)
+    with pytest.raises(ValueError):
+        pkg.Problem().add_poses(np.zeros((3, 6)))
+
+
+def test_shard_range_partitions_exactly(pkg):
+    for n in (0, 1, 7, 40000, 1000003):
+        for world in (1, 2, 3, 8):
+            parts = [pkg.shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in parts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(pkg.PgoError):
+        pkg.shard_range(10, 2, 2)
+
+
+def test_compute_calls_fail_loudly_without_a_gpu(pkg):
+    if pkg.device_count() > 0:
+        pytest.skip("GPU present")
+    poses = np.zeros((2, 7))
+    poses[:, 6] = 1
+    p = pkg.Problem()
+    p.add_poses(poses)
+    p.add_se3_between([1], [0], [[1, 0, 0, 0, 0, 0, 1.0]])
+    for call in (lambda: pkg.solve(pkg.SolverOptions(), p), lambda: p.evaluate(), lambda: p.normal_equations(),
+                 lambda: p.plus(np.zeros((2, 6)))):
+        with pytest.raises(pkg.PgoError) as ei:
+            call()
+        assert ei.value.code == pkg.ERR_NO_DEVICE and "no CPU fallback" in str(ei.value)
+
+
+def test_full_report_renders(pkg):
+    from posegraph_ceres_amd import _CSummary, RECORD_DTYPE, Summary
+    s = _CSummary()
+    s.num_poses, s.num_edges, s.initial_cost, s.final_cost = 10, 20, 5.0, 1.0
+    s.message = b"Function tolerance reached."
+    rec = np.zeros(2, dtype=RECORD_DTYPE)
+    rec["iteration"] = [0, 1]
+    text = Summary(s, rec).full_report()
+    assert "Solver Summary" in text and "Residual blocks" in text and "CONVERGENCE" in text
+    assert Summary(s, rec).is_solution_usable()
