@@ -99,6 +99,7 @@ struct DeviceGraph {
   CgState* cg;        // device
   LmScalars* scal;    // device-visible pinned host memory
   int* flags;         // [4] device flags: [0] linearize saw non-finite
+  int debug;          // development ablation switches (0 in production)
 };
 
 struct CgParams {
@@ -115,7 +116,7 @@ void launch_damping(const DeviceGraph& g, double radius, double min_diag, double
 void launch_cost(const DeviceGraph& g, const double* poses, int part_row, hipStream_t s);
 void launch_evaluate_edges(const DeviceGraph& g, const double* poses, double* res, double* ja, double* jb, hipStream_t s);
 void launch_pcg_init(const DeviceGraph& g, hipStream_t s);
-void launch_pcg_iteration(const DeviceGraph& g, const CgParams& p, hipStream_t s);   // SpMV + update kernels
+void launch_pcg_iteration(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s);   // SpMV + update kernels of an odd/even iteration
 void launch_pcg_finish(const DeviceGraph& g, const CgParams& p, hipStream_t s);      // final termination bookkeeping
 void launch_model_and_retract(const DeviceGraph& g, hipStream_t s);                  // A x, model change, delta, candidate
 void launch_gradient_norm(const DeviceGraph& g, hipStream_t s);
@@ -124,6 +125,7 @@ void launch_apply_step(const DeviceGraph& g, const double* step, hipStream_t s);
 void launch_spmv_plain(const DeviceGraph& g, hipStream_t s);
 void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, hipStream_t s);
 void launch_pcg_update_only(const DeviceGraph& g, hipStream_t s);
+void launch_debug(const DeviceGraph& g, int which, hipStream_t s);
 int vec_block();
 int pose_block();
 int edge_block();

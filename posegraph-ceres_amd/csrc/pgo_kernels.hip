@@ -19,21 +19,45 @@ namespace pgo {
 
 namespace {
 
-constexpr int VEC_BLOCK = 192;  // 32 poses x 6 tangent dims: a pose never straddles a workgroup
+constexpr int VEC_BLOCK = 768;  // 128 poses x 6 tangent dims: a pose never straddles a workgroup
 constexpr int POSE_BLOCK = 256;
 constexpr int EDGE_BLOCK = 256;
 constexpr int NV_LIN = 27;      // 21 (symmetric diagonal block) + 6 (gradient)
 constexpr int SPMV_LDS_STRIDE = 7;
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
+// Wave-wide reductions on the DPP crossbar (row_shr 1/2/4/8 inside each 16-lane row, then
+// row_bcast:15 / row_bcast:31 across rows): pure VALU, no LDS round trips, total lands in lane 63
+// and is broadcast with v_readlane.  (A __shfl_down ladder compiles to ds_bpermute + s_waitcnt per
+// step: measured ~2 us for the 7-value CG prologue)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shifted(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-  return v;
+__device__ __forceinline__ double lane63(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_shifted<0x111, 0xf>(v);
+  v += dpp_shifted<0x112, 0xf>(v);
+  v += dpp_shifted<0x114, 0xf>(v);
+  v += dpp_shifted<0x118, 0xf>(v);
+  v += dpp_shifted<0x142, 0xa>(v);
+  v += dpp_shifted<0x143, 0xc>(v);
+  return lane63(v);
+}
+__device__ __forceinline__ double wave_max(double v) {  // v >= 0 everywhere it is used
+  v = fmax(v, dpp_shifted<0x111, 0xf>(v));
+  v = fmax(v, dpp_shifted<0x112, 0xf>(v));
+  v = fmax(v, dpp_shifted<0x114, 0xf>(v));
+  v = fmax(v, dpp_shifted<0x118, 0xf>(v));
+  v = fmax(v, dpp_shifted<0x142, 0xa>(v));
+  v = fmax(v, dpp_shifted<0x143, 0xc>(v));
+  return lane63(v);
 }
 
 // Sum NV values over the workgroup in a fixed order; every thread gets the totals.
@@ -43,7 +67,7 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const double s = wave_sum(v[k]);
+    const double s = wave_sum(v[k]);  // uniform across the wave
     if (lane == 0) scratch[wave * NV + k] = s;
   }
   __syncthreads();
@@ -409,7 +433,7 @@ __global__ __launch_bounds__(128) void k_evaluate_edges(DeviceGraph g, const dou
 // ------------------------------------------------------------------------------------------------
 __global__ void k_pcg_init(DeviceGraph g) {
   __shared__ double rl[VEC_BLOCK];
-  __shared__ double scratch[16];
+  __shared__ double scratch[2 * (VEC_BLOCK / 64)];
   const int tid = threadIdx.x;
   double acc[2] = {0.0, 0.0};
   for (int base = blockIdx.x * VEC_BLOCK; base < 6 * g.N; base += gridDim.x * VEC_BLOCK) {
@@ -455,35 +479,84 @@ __global__ void k_pcg_init(DeviceGraph g) {
 
 // Row-partitioned block SpMV: dst_row = sum_slots B_slot * src[col].  MODE 0: PCG step
 // (src = z + beta p_old, also writes p_new, partial p'q).  MODE 1: plain q = A x for the model change.
+//
+// Latency structure (the kernel is latency- not bandwidth-bound at KITTI/Manhattan sizes): every load
+// that does not depend on another load is issued at the top — CG state, BOTH parities of the partial-sum
+// rows, the slot's column index and its whole 6x6 block — so that the prologue reduction overlaps the
+// block fetch and only the z/p gathers (which need the column index) form a second round trip.
+// `odd` is the parity of the CG iteration number, fixed at launch (batches have even length and
+// start at iteration 1), so the ping-pong buffers are known without waiting for device state.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm) {
-  extern __shared__ double lds[];  // SPMV_LDS_STRIDE * block
-  __shared__ double scratch[32];  // >= 6 sums x 4 waves
+__global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int odd) {
+  extern __shared__ double lds[];  // SPMV_LDS_STRIDE * block (slot results) + 6 * block (own-row p_new)
+  __shared__ double scratch[32];   // >= 7 sums x 4 waves
   const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
-  double beta = 0.0;
-  const double* p_old = nullptr;
-  double* p_new = nullptr;
+  double* lds_p = lds + (size_t)SPMV_LDS_STRIDE * B;
+
+  const int s_begin = g.wg_slot_begin[wg], s_end = g.wg_slot_begin[wg + 1];
+  const int r0 = g.wg_row_begin[wg], nrows = g.wg_row_begin[wg + 1] - r0;
+  const bool single = (s_end - s_begin) == B;
+
+  // ---- independent loads, first chunk ----
+  const double* p_old = odd ? g.cg_p0 : g.cg_p1;
+  double* p_new = odd ? g.cg_p1 : g.cg_p0;
   const double* src = g.cg_x;
-  int it = 0;
-  if (MODE == 0) {
-    if (g.cg->done) return;
-    it = g.cg->cnt_b + 1;
-    const int cur = (it - 1) & 1, prev = it & 1;
-    double sums[6];
-    sums[0] = partial_sum(g.part_rz + (size_t)cur * g.n_part, g.n_vec_wg);   // rho_it
-    sums[1] = partial_sum(g.part_rz + (size_t)prev * g.n_part, g.n_vec_wg);  // rho_{it-1}
-    sums[2] = partial_sum(g.part_q + (size_t)cur * g.n_part, g.n_vec_wg);    // Q(x_{it-1})
-    sums[3] = partial_sum(g.part_q + (size_t)prev * g.n_part, g.n_vec_wg);   // Q(x_{it-2})
-    sums[4] = partial_sum(g.part_rr + (size_t)cur * g.n_part, g.n_vec_wg);   // |r_{it-1}|^2
-    sums[5] = partial_sum(g.part_bb, g.n_vec_wg);                             // |b|^2
+  int t = s_begin + tid;
+  int col = g.slot_col[t];
+  int row = g.slot_row[t];
+  uint8_t side = g.slot_side[t];
+  double2 blk[18];
+  {
+    const double2* bp = reinterpret_cast<const double2*>(g.bsr_val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+#pragma unroll
+    for (int k = 0; k < 18; ++k) blk[k] = bp[(size_t)k * 64];
+  }
+  // row bookkeeping of the segmented sum (first item of this thread)
+  int seg_rb = 0, seg_cnt = 0;
+  if (tid < nrows * 6) { seg_rb = g.row_slot_begin[r0 + tid / 6]; seg_cnt = g.row_slot_cnt[r0 + tid / 6]; }
+  int done = 0, cnt_b = 0;
+  double sums[6] = {0, 0, 0, 0, 0, 0};
+  if (MODE == 0 && !(g.debug & 1)) {
+    done = g.cg->done;
+    cnt_b = g.cg->cnt_b;
+    const double* rz_cur = g.part_rz + (size_t)(odd ? 0 : g.n_part);   // (it-1)&1
+    const double* rz_prev = g.part_rz + (size_t)(odd ? g.n_part : 0);
+    const double* q_cur = g.part_q + (size_t)(odd ? 0 : g.n_part);
+    const double* q_prev = g.part_q + (size_t)(odd ? g.n_part : 0);
+    const double* rr_cur = g.part_rr + (size_t)(odd ? 0 : g.n_part);
+    for (int i = tid; i < g.n_vec_wg; i += B) {
+      sums[0] += rz_cur[i]; sums[1] += rz_prev[i]; sums[2] += q_cur[i]; sums[3] += q_prev[i];
+      sums[4] += rr_cur[i]; sums[5] += g.part_bb[i];
+    }
+  }
+  // gathers of the first chunk: need only the column index
+  double2 gz[3] = {{0, 0}, {0, 0}, {0, 0}}, gp[3] = {{0, 0}, {0, 0}, {0, 0}};
+  if (col >= 0) {
+    if (MODE == 0) {
+      const double2* zs = reinterpret_cast<const double2*>(g.cg_z + 6 * (size_t)col);
+      const double2* ps = reinterpret_cast<const double2*>(p_old + 6 * (size_t)col);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { gz[k] = zs[k]; gp[k] = ps[k]; }
+    } else {
+      const double2* xs = reinterpret_cast<const double2*>(src + 6 * (size_t)col);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gz[k] = xs[k];
+    }
+  }
+
+  double beta = 0.0;
+  int it = 1;
+  if (MODE == 0 && !(g.debug & 1)) {
+    if (done) return;
+    it = cnt_b + 1;
     block_sum<6>(sums, scratch);
-    const double rho = sums[0], rho_prev = sums[1], Q1 = -sums[2], Q0 = -sums[3];
+    const double rho = sums[0], rho_prev = sums[1], Q1 = -sums[2], Q0 = -sums[3], rr = sums[4], bb = sums[5];
     int stop = 0, status = 0;
     if (it > 1) {
       const int done_it = it - 1;
       const double zeta = done_it * (Q1 - Q0) / Q1;
       if (zeta < prm.q_tolerance && done_it >= prm.min_iterations) stop = 1;
-      if (prm.r_tolerance >= 0.0 && sqrt(sums[4]) <= prm.r_tolerance * sqrt(sums[5]) && done_it >= prm.min_iterations) stop = 1;
+      if (prm.r_tolerance >= 0.0 && sqrt(rr) <= prm.r_tolerance * sqrt(bb) && done_it >= prm.min_iterations) stop = 1;
       if (done_it >= prm.max_iterations) stop = 1;
     }
     if (!stop && (rho == 0.0 || !isfinite(rho))) { stop = 1; status = (rho == 0.0) ? 0 : 2; }
@@ -495,61 +568,77 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm) {
       if (wg == 0 && tid == 0) { g.cg->iters = it - 1; g.cg->status = status; g.cg->done = 1; }
       return;
     }
-    p_old = (it & 1) ? g.cg_p0 : g.cg_p1;
-    p_new = (it & 1) ? g.cg_p1 : g.cg_p0;
   }
 
-  const int s_begin = g.wg_slot_begin[wg], s_end = g.wg_slot_begin[wg + 1];
-  const int r0 = g.wg_row_begin[wg], nrows = g.wg_row_begin[wg + 1] - r0;
-  const bool single = (s_end - s_begin) == B;
   double acc = 0.0;
   double pq[1] = {0.0};
-
   for (int cb = s_begin; cb < s_end; cb += B) {
-    const int t = cb + tid;
-    const int col = g.slot_col[t];
-    double y[6] = {0, 0, 0, 0, 0, 0};
-    if (col >= 0) {
-      double x[6];
+    if (cb != s_begin) {  // further chunks of a fat row
+      t = cb + tid;
+      col = g.slot_col[t];
+      row = g.slot_row[t];
+      side = g.slot_side[t];
+      const double2* bp = reinterpret_cast<const double2*>(g.bsr_val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+#pragma unroll
+      for (int k = 0; k < 18; ++k) blk[k] = bp[(size_t)k * 64];
+    }
+    if (cb != s_begin && col >= 0) {
       if (MODE == 0) {
         const double2* zs = reinterpret_cast<const double2*>(g.cg_z + 6 * (size_t)col);
         const double2* ps = reinterpret_cast<const double2*>(p_old + 6 * (size_t)col);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double2 z2 = zs[k], p2 = ps[k];
-          x[2 * k] = z2.x + beta * p2.x;
-          x[2 * k + 1] = z2.y + beta * p2.y;
-        }
-        if (g.slot_side[t] == SIDE_DIAG) {
-          double2* pn = reinterpret_cast<double2*>(p_new + 6 * (size_t)col);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) pn[k] = double2{x[2 * k], x[2 * k + 1]};
-        }
+        for (int k = 0; k < 3; ++k) { gz[k] = zs[k]; gp[k] = ps[k]; }
       } else {
         const double2* xs = reinterpret_cast<const double2*>(src + 6 * (size_t)col);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { const double2 t2 = xs[k]; x[2 * k] = t2.x; x[2 * k + 1] = t2.y; }
+        for (int k = 0; k < 3; ++k) gz[k] = xs[k];
       }
-      const double2* blk = reinterpret_cast<const double2*>(g.bsr_val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+    }
+    double y[6] = {0, 0, 0, 0, 0, 0};
+    if (col >= 0) {
+      double x[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const double2 b0 = blk[(size_t)(3 * i) * 64], b1 = blk[(size_t)(3 * i + 1) * 64], b2 = blk[(size_t)(3 * i + 2) * 64];
-        y[i] = b0.x * x[0] + b0.y * x[1] + b1.x * x[2] + b1.y * x[3] + b2.x * x[4] + b2.y * x[5];
+      for (int k = 0; k < 3; ++k) {
+        x[2 * k] = (MODE == 0) ? gz[k].x + beta * gp[k].x : gz[k].x;
+        x[2 * k + 1] = (MODE == 0) ? gz[k].y + beta * gp[k].y : gz[k].y;
+      }
+      if (MODE == 0 && side == SIDE_DIAG) {
+        double2* pn = reinterpret_cast<double2*>(p_new + 6 * (size_t)col);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pn[k] = double2{x[2 * k], x[2 * k + 1]};
+        if (cb == s_begin) {
+          const int rl = row - r0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) lds_p[6 * rl + k] = x[k];
+        }
+      }
+      if (!(g.debug & 2)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          y[i] = blk[3 * i].x * x[0] + blk[3 * i].y * x[1] + blk[3 * i + 1].x * x[2] + blk[3 * i + 1].y * x[3] +
+                 blk[3 * i + 2].x * x[4] + blk[3 * i + 2].y * x[5];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) y[i] = x[i];
       }
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) lds[tid * SPMV_LDS_STRIDE + k] = y[k];
     __syncthreads();
-    for (int idx = tid; idx < nrows * 6; idx += B) {
+    for (int idx = tid; idx < nrows * 6 && !(g.debug & 4); idx += B) {
       const int rl = idx / 6, k = idx - rl * 6;
-      const int row = r0 + rl;
-      const int rb = g.row_slot_begin[row];
-      const int sb = max(rb, cb) - cb, se = min(rb + g.row_slot_cnt[row], cb + B) - cb;
-      double s = 0.0;
-      for (int j = sb; j < se; ++j) s += lds[j * SPMV_LDS_STRIDE + k];
+      const int rw = r0 + rl;
+      const int rb = (idx == tid) ? seg_rb : g.row_slot_begin[rw];
+      const int rc = (idx == tid) ? seg_cnt : g.row_slot_cnt[rw];
+      const int sb = max(rb, cb) - cb, se = min(rb + rc, cb + B) - cb;
+      double s0 = 0.0, s1 = 0.0;
+      int j = sb;
+      for (; j + 1 < se; j += 2) { s0 += lds[j * SPMV_LDS_STRIDE + k]; s1 += lds[(j + 1) * SPMV_LDS_STRIDE + k]; }
+      if (j < se) s0 += lds[j * SPMV_LDS_STRIDE + k];
+      const double s = s0 + s1;
       if (single) {
-        g.cg_q[6 * (size_t)row + k] = s;
-        if (MODE == 0) pq[0] += s * (g.cg_z[6 * (size_t)row + k] + beta * p_old[6 * (size_t)row + k]);
+        g.cg_q[6 * (size_t)rw + k] = s;
+        if (MODE == 0) pq[0] += s * lds_p[idx];
       } else {
         acc += s;
       }
@@ -558,7 +647,7 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm) {
   }
   if (!single && tid < 6) {
     g.cg_q[6 * (size_t)r0 + tid] = acc;
-    if (MODE == 0) pq[0] += acc * (g.cg_z[6 * (size_t)r0 + tid] + beta * p_old[6 * (size_t)r0 + tid]);
+    if (MODE == 0) pq[0] += acc * lds_p[tid];
   }
   if (MODE == 0) {
     block_sum<1>(pq, scratch);
@@ -569,15 +658,30 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm) {
   }
 }
 
-__global__ void k_pcg_update(DeviceGraph g) {
+// x += alpha p ; r -= alpha q ; z = M^-1 r ; partial r'z, Q = x'(b + r), r'r.  All loads up front.
+__global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd) {
   __shared__ double rl[VEC_BLOCK];
-  __shared__ double scratch[16];
-  if (g.cg->done) return;
+  __shared__ double scratch[3 * (VEC_BLOCK / 64)];
   const int tid = threadIdx.x;
+  const int m = 6 * g.N;
+  // ---- independent loads ----
+  int idx = blockIdx.x * VEC_BLOCK + tid;
+  bool live = idx < m;
+  const double* p = odd ? g.cg_p1 : g.cg_p0;
+  double x0 = 0, pa = 0, r0 = 0, q0 = 0, b0 = 0;
+  double2 mi[3] = {{0, 0}, {0, 0}, {0, 0}};
+  if (live) {
+    x0 = g.cg_x[idx]; pa = p[idx]; r0 = g.cg_r[idx]; q0 = g.cg_q[idx]; b0 = g.cg_b[idx];
+    const double2* Mi = reinterpret_cast<const double2*>(g.Minv + 6 * (size_t)idx);   // row c of block v: 36 v + 6 c = 6 idx
+    mi[0] = Mi[0]; mi[1] = Mi[1]; mi[2] = Mi[2];
+  }
+  const int done = g.cg->done;
   const int it = g.cg->cnt_a;
-  double sums[2];
-  sums[0] = partial_sum(g.part_rz + (size_t)((it - 1) & 1) * g.n_part, g.n_vec_wg);
-  sums[1] = partial_sum(g.part_pq, g.n_wg);
+  double sums[2] = {0, 0};
+  const double* rz_cur = g.part_rz + (size_t)(odd ? 0 : g.n_part);
+  for (int i = tid; i < g.n_vec_wg; i += VEC_BLOCK) sums[0] += rz_cur[i];
+  for (int i = tid; i < g.n_wg; i += VEC_BLOCK) sums[1] += g.part_pq[i];
+  if (done) return;
   block_sum<2>(sums, scratch);
   const double rho = sums[0], pq = sums[1];
   if (!(pq > 0.0) || !isfinite(pq)) {
@@ -586,39 +690,42 @@ __global__ void k_pcg_update(DeviceGraph g) {
     return;
   }
   const double alpha = rho / pq;
-  const double* p = (it & 1) ? g.cg_p1 : g.cg_p0;
   double acc[3] = {0.0, 0.0, 0.0};
-  for (int base = blockIdx.x * VEC_BLOCK; base < 6 * g.N; base += gridDim.x * VEC_BLOCK) {
-    const int idx = base + tid;
-    const bool live = idx < 6 * g.N;
-    double x = 0.0, r = 0.0, b = 0.0;
+  for (int base = blockIdx.x * VEC_BLOCK; base < m; base += gridDim.x * VEC_BLOCK) {
+    if (base != (int)blockIdx.x * VEC_BLOCK) {
+      idx = base + tid;
+      live = idx < m;
+      if (live) {
+        x0 = g.cg_x[idx]; pa = p[idx]; r0 = g.cg_r[idx]; q0 = g.cg_q[idx]; b0 = g.cg_b[idx];
+        const double2* Mi = reinterpret_cast<const double2*>(g.Minv + 6 * (size_t)idx);
+        mi[0] = Mi[0]; mi[1] = Mi[1]; mi[2] = Mi[2];
+      }
+    }
+    double x = 0.0, r = 0.0;
     if (live) {
-      x = g.cg_x[idx] + alpha * p[idx];
-      r = g.cg_r[idx] - alpha * g.cg_q[idx];
-      b = g.cg_b[idx];
+      x = x0 + alpha * pa;
+      r = r0 - alpha * q0;
       g.cg_x[idx] = x;
       g.cg_r[idx] = r;
     }
     rl[tid] = r;
     __syncthreads();
     if (live) {
-      const int v = idx / 6, c = idx - 6 * v, lv = tid / 6;
-      const double* Mi = g.Minv + 36 * (size_t)v + 6 * c;
-      double z = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) z += Mi[k] * rl[6 * lv + k];
+      const double* rv = rl + 6 * (tid / 6);
+      const double z = mi[0].x * rv[0] + mi[0].y * rv[1] + mi[1].x * rv[2] + mi[1].y * rv[3] + mi[2].x * rv[4] + mi[2].y * rv[5];
       g.cg_z[idx] = z;
       acc[0] += r * z;
-      acc[1] += x * (b + r);
+      acc[1] += x * (b0 + r);
       acc[2] += r * r;
     }
     __syncthreads();
   }
   block_sum<3>(acc, scratch);
   if (tid == 0) {
-    g.part_rz[(size_t)(it & 1) * g.n_part + blockIdx.x] = acc[0];
-    g.part_q[(size_t)(it & 1) * g.n_part + blockIdx.x] = acc[1];
-    g.part_rr[(size_t)(it & 1) * g.n_part + blockIdx.x] = acc[2];
+    const size_t o = (size_t)(odd ? g.n_part : 0) + blockIdx.x;
+    g.part_rz[o] = acc[0];
+    g.part_q[o] = acc[1];
+    g.part_rr[o] = acc[2];
     if (blockIdx.x == 0) g.cg->cnt_b = it;
   }
 }
@@ -629,14 +736,14 @@ __global__ void k_pcg_finish(DeviceGraph g, CgParams prm) {
   __shared__ double scratch[16];
   const int tid = threadIdx.x;
   int done = g.cg->done, iters = g.cg->iters, status = g.cg->status;
+  const int it = done ? iters : g.cg->cnt_b;  // completed iterations
+  double sums[4];
+  sums[0] = partial_sum(g.part_q + (size_t)(it & 1) * g.n_part, g.n_vec_wg);
+  sums[1] = partial_sum(g.part_q + (size_t)((it + 1) & 1) * g.n_part, g.n_vec_wg);
+  sums[2] = partial_sum(g.part_rr + (size_t)(it & 1) * g.n_part, g.n_vec_wg);
+  sums[3] = partial_sum(g.part_bb, g.n_vec_wg);
+  block_sum<4>(sums, scratch);
   if (!done) {
-    const int it = g.cg->cnt_b;  // completed
-    double sums[4];
-    sums[0] = partial_sum(g.part_q + (size_t)(it & 1) * g.n_part, g.n_vec_wg);
-    sums[1] = partial_sum(g.part_q + (size_t)((it + 1) & 1) * g.n_part, g.n_vec_wg);
-    sums[2] = partial_sum(g.part_rr + (size_t)(it & 1) * g.n_part, g.n_vec_wg);
-    sums[3] = partial_sum(g.part_bb, g.n_vec_wg);
-    block_sum<4>(sums, scratch);
     iters = it;
     if (it >= 1) {
       const double Q1 = -sums[0], Q0 = -sums[1];
@@ -645,21 +752,18 @@ __global__ void k_pcg_finish(DeviceGraph g, CgParams prm) {
       if (prm.r_tolerance >= 0.0 && sqrt(sums[2]) <= prm.r_tolerance * sqrt(sums[3]) && it >= prm.min_iterations) done = 1;
     }
   }
-  double rr[1] = {0.0};
-  for (int i = tid; i < 6 * g.N; i += blockDim.x) rr[0] += g.cg_r[i] * g.cg_r[i];
-  block_sum<1>(rr, scratch);
   if (tid == 0) {
     if (done && !g.cg->done) { g.cg->done = 1; g.cg->iters = iters; }
     g.scal->cg_iterations = iters;
     g.scal->cg_status = done ? status : -1;  // -1: not finished, host launches another batch
-    g.scal->cg_residual_sq = rr[0];
+    g.scal->cg_residual_sq = sums[2];
   }
 }
 
 // model_cost_change = -(J~ step)'(r + J~ step/2) with step = -x:  x'b - x'(q - D^2 x)/2, q = A x;
 // delta = S * step.
 __global__ void k_model_delta(DeviceGraph g) {
-  __shared__ double scratch[8];
+  __shared__ double scratch[VEC_BLOCK / 64];
   double acc[1] = {0.0};
   for (int idx = blockIdx.x * VEC_BLOCK + threadIdx.x; idx < 6 * g.N; idx += gridDim.x * VEC_BLOCK) {
     const double x = g.cg_x[idx];
@@ -762,6 +866,11 @@ __global__ void k_finalize_scalars(DeviceGraph g, int n_cost_part) {
   }
 }
 
+__global__ void k_empty(DeviceGraph g) {}
+__global__ void k_touch(DeviceGraph g) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < 6 * g.N) g.cg_q[idx] = g.cg_z[idx] + 1.0;
+}
 __global__ void k_copy_delta(DeviceGraph g, const double* step) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < 6 * g.N) g.delta[idx] = step[idx];
@@ -796,32 +905,32 @@ void launch_evaluate_edges(const DeviceGraph& g, const double* poses, double* re
 void launch_pcg_init(const DeviceGraph& g, hipStream_t s) {
   hipLaunchKernelGGL(k_pcg_init, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
 }
-void launch_pcg_iteration(const DeviceGraph& g, const CgParams& p, hipStream_t s) {
-  const size_t lds = (size_t)SPMV_LDS_STRIDE * g.block * sizeof(double);
-  hipLaunchKernelGGL(k_spmv<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, p);
-  hipLaunchKernelGGL(k_pcg_update, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
+void launch_pcg_iteration(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s) {
+  const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
+  hipLaunchKernelGGL(k_spmv<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, p, odd);
+  hipLaunchKernelGGL(k_pcg_update, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, odd);
 }
 void launch_pcg_finish(const DeviceGraph& g, const CgParams& p, hipStream_t s) {
   hipLaunchKernelGGL(k_pcg_finish, dim3(1), dim3(256), 0, s, g, p);
 }
 void launch_model_and_retract(const DeviceGraph& g, hipStream_t s) {
-  const size_t lds = (size_t)SPMV_LDS_STRIDE * g.block * sizeof(double);
+  const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
   CgParams dummy{0.0, -1.0, 0, 0};
-  hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy);
+  hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1);
   hipLaunchKernelGGL(k_model_delta, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
   hipLaunchKernelGGL(k_retract, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g);
 }
 void launch_spmv_plain(const DeviceGraph& g, hipStream_t s) {
-  const size_t lds = (size_t)SPMV_LDS_STRIDE * g.block * sizeof(double);
+  const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
   CgParams dummy{0.0, -1.0, 0, 0};
-  hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy);
+  hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1);
 }
 void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, hipStream_t s) {
-  const size_t lds = (size_t)SPMV_LDS_STRIDE * g.block * sizeof(double);
-  hipLaunchKernelGGL(k_spmv<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, p);
+  const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
+  hipLaunchKernelGGL(k_spmv<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, p, 1);
 }
 void launch_pcg_update_only(const DeviceGraph& g, hipStream_t s) {
-  hipLaunchKernelGGL(k_pcg_update, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
+  hipLaunchKernelGGL(k_pcg_update, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, 1);
 }
 void launch_gradient_norm(const DeviceGraph& g, hipStream_t s) {
   hipLaunchKernelGGL(k_gradient_norm, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g);
@@ -834,6 +943,10 @@ void launch_apply_step(const DeviceGraph& g, const double* step, hipStream_t s) 
   hipLaunchKernelGGL(k_retract, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g);
 }
 
+void launch_debug(const DeviceGraph& g, int which, hipStream_t s) {
+  if (which == 0) hipLaunchKernelGGL(k_empty, dim3(g.n_wg), dim3(g.block), 0, s, g);
+  else hipLaunchKernelGGL(k_touch, dim3(cdiv(6 * g.N, 256)), dim3(256), 0, s, g);
+}
 int vec_block() { return VEC_BLOCK; }
 int pose_block() { return POSE_BLOCK; }
 int edge_block() { return EDGE_BLOCK; }

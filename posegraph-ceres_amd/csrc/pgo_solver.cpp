@@ -77,6 +77,7 @@ struct LmState {
   int reason = 5;
   double radius = 1e4, decrease_factor = 2.0;
   bool reuse_diagonal = false;
+  bool gmax_deferred = false;  // gradient norm of the accepted point is read at the next host sync
   double x_cost = 0, x_norm = 0, gmax = 0, initial_cost = 0;
   int num_successful = 0, num_unsuccessful = 0, num_consecutive_invalid = 0, num_linear_iterations = 0;
   pgo_iteration_record cur{};
@@ -113,12 +114,12 @@ struct pgo_problem {
       d_part_pq, d_part_rr, d_part_bb, d_part_misc, d_tmp_a, d_tmp_b, d_tmp_c;
   DevBuf<pgo::CgState> d_cg;
   pgo::LmScalars* scal = nullptr;  // pinned, device visible
-  // captured CG batch
-  hipGraphExec_t cg_exec = nullptr;
-  hipGraph_t cg_graph = nullptr;
+  // captured CG batches, keyed by the number of iterations in the batch
+  struct CapturedBatch { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+  std::unordered_map<int, CapturedBatch> cg_graphs;
   pgo::CgParams cg_graph_params{};
-  int cg_graph_batch = 0;
   bool use_graph = true;
+  int last_cg_iterations = 0;
 
   pgo_solver_options opt{};
   LmState lm;
@@ -129,9 +130,11 @@ struct pgo_problem {
     if (stream_ready) (void)hipStreamDestroy(stream);
   }
   void drop_graph() {
-    if (cg_exec) { (void)hipGraphExecDestroy(cg_exec); cg_exec = nullptr; }
-    if (cg_graph) { (void)hipGraphDestroy(cg_graph); cg_graph = nullptr; }
-    cg_graph_batch = 0;
+    for (auto& kv : cg_graphs) {
+      if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+      if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    cg_graphs.clear();
   }
 };
 
@@ -372,48 +375,64 @@ int fill_scale_one(pgo_problem* P) {
 }
 
 // ---- CG driver: batches of iterations, one host check per batch ----
+// A batch is a captured hipGraph of `batch` x (SpMV kernel, update kernel) + the finish kernel.  The
+// kernels stop by themselves (device-side `done` flag), so an over-long batch only costs early-exit
+// launches; the batch length follows the previous solve's iteration count.
+int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch) {
+  hipStream_t s = P->stream;
+  if (P->use_graph) {
+    if (memcmp(&P->cg_graph_params, &prm, sizeof prm) != 0) { P->drop_graph(); P->cg_graph_params = prm; }
+    auto it = P->cg_graphs.find(batch);
+    if (it == P->cg_graphs.end()) {
+      pgo_problem::CapturedBatch cb;
+      hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        for (int i = 0; i < batch; ++i) pgo::launch_pcg_iteration(P->g, prm, (i & 1) ^ 1, s);
+        pgo::launch_pcg_finish(P->g, prm, s);
+        e = hipStreamEndCapture(s, &cb.graph);
+        if (e == hipSuccess) e = hipGraphInstantiate(&cb.exec, cb.graph, nullptr, nullptr, 0);
+      }
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (cb.exec) (void)hipGraphExecDestroy(cb.exec);
+        if (cb.graph) (void)hipGraphDestroy(cb.graph);
+        P->drop_graph();
+        P->use_graph = false;  // fall back to plain stream launches (same kernels)
+      } else {
+        it = P->cg_graphs.emplace(batch, cb).first;
+      }
+    }
+    if (P->use_graph) {
+      HIP_TRY(hipGraphLaunch(it->second.exec, s));
+      return PGO_OK;
+    }
+  }
+  for (int i = 0; i < batch; ++i) pgo::launch_pcg_iteration(P->g, prm, (i & 1) ^ 1, s);
+  pgo::launch_pcg_finish(P->g, prm, s);
+  return PGO_OK;
+}
+
+// Batch schedule: the kernels stop on their own, but an over-long batch still pays ~2.6 us per early-exit
+// launch and an under-long one pays a host sync (~25 us), so batches start small and grow: 16, 32, 64, 64...
+int pick_batch(const pgo::CgParams& prm, int user_batch, int round) {
+  int batch = user_batch > 0 ? user_batch : std::min(64, 16 << std::min(round, 2));
+  batch = std::max(1, std::min(batch, prm.max_iterations));
+  return (batch + 1) & ~1;  // even: every batch starts at an odd iteration (kernels take the parity at launch)
+}
+
 int run_pcg(pgo_problem* P, const pgo::CgParams& prm, int batch, int* iterations, int* status) {
   hipStream_t s = P->stream;
   pgo::launch_pcg_init(P->g, s);
-  if (batch <= 0) batch = 16;
-  batch = std::min(batch, std::max(1, prm.max_iterations));
-  for (;;) {
-    bool launched = false;
-    if (P->use_graph) {
-      const bool same = P->cg_exec && P->cg_graph_batch == batch && memcmp(&P->cg_graph_params, &prm, sizeof prm) == 0;
-      if (!same) {
-        P->drop_graph();
-        hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-        if (e == hipSuccess) {
-          for (int i = 0; i < batch; ++i) pgo::launch_pcg_iteration(P->g, prm, s);
-          pgo::launch_pcg_finish(P->g, prm, s);
-          e = hipStreamEndCapture(s, &P->cg_graph);
-          if (e == hipSuccess) e = hipGraphInstantiate(&P->cg_exec, P->cg_graph, nullptr, nullptr, 0);
-        }
-        if (e != hipSuccess) {
-          (void)hipGetLastError();
-          P->drop_graph();
-          P->use_graph = false;  // fall back to plain stream launches (same kernels)
-        } else {
-          P->cg_graph_batch = batch;
-          P->cg_graph_params = prm;
-        }
-      }
-      if (P->cg_exec) {
-        HIP_TRY(hipGraphLaunch(P->cg_exec, s));
-        launched = true;
-      }
-    }
-    if (!launched) {
-      for (int i = 0; i < batch; ++i) pgo::launch_pcg_iteration(P->g, prm, s);
-      pgo::launch_pcg_finish(P->g, prm, s);
-    }
+  for (int round = 0;; ++round) {
+    int rc = launch_cg_batch(P, prm, pick_batch(prm, batch, round));
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     if (P->scal->cg_status != -1) break;
   }
   HIP_TRY(hipGetLastError());
   *iterations = P->scal->cg_iterations;
   *status = P->scal->cg_status;
+  P->last_cg_iterations = *iterations;
   return PGO_OK;
 }
 
@@ -536,7 +555,7 @@ int lm_advance(pgo_problem* P) {
     terminate(L, PGO_NO_CONVERGENCE, 5, "Maximum number of iterations reached. Number of iterations: %d.", L.cur.iteration);
     return PGO_OK;
   }
-  if (L.cur.step_is_successful && L.cur.gradient_max_norm <= o.gradient_tolerance) {
+  if (!L.gmax_deferred && L.cur.step_is_successful && L.cur.gradient_max_norm <= o.gradient_tolerance) {
     terminate(L, PGO_CONVERGENCE, 3, "Gradient tolerance reached. Gradient max norm: %e <= %e", L.cur.gradient_max_norm, o.gradient_tolerance);
     return PGO_OK;
   }
@@ -547,27 +566,54 @@ int lm_advance(pgo_problem* P) {
 
   pgo_iteration_record nx{};
   nx.iteration = L.cur.iteration + 1;
-  nx.gradient_max_norm = L.cur.gradient_max_norm;
 
-  // ComputeTrustRegionStep
+  // ComputeTrustRegionStep + ComputeCandidatePointAndEvaluateCost, enqueued back to back: damping, one
+  // batch of CG iterations, model cost change / delta / candidate, candidate cost, scalar fold.  ONE host
+  // sync per LM iteration in the common case; if the CG batch was too short, further batches follow and
+  // the (cheap) tail is re-enqueued.
   const auto t_lin = Clock::now();
+  const pgo::CgParams prm = cg_params_for(o);
   pgo::launch_damping(P->g, L.radius, o.min_lm_diagonal, o.max_lm_diagonal, L.reuse_diagonal ? 1 : 0, s);
-  int cg_it = 0, cg_status = 0;
-  int rc = run_pcg(P, cg_params_for(o), o.cg_batch, &cg_it, &cg_status);
+  pgo::launch_pcg_init(P->g, s);
+  int rc = launch_cg_batch(P, prm, pick_batch(prm, o.cg_batch, 0));
   if (rc) return rc;
+  for (int round = 1;; ++round) {
+    // the tail is enqueued speculatively behind the first batch; later batches sync first
+    pgo::launch_model_and_retract(P->g, s);
+    pgo::launch_cost(P->g, P->g.pose_c, 0, s);
+    pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s);
+    HIP_TRY(hipStreamSynchronize(s));
+    if (P->scal->cg_status != -1) break;
+    for (;; ++round) {
+      rc = launch_cg_batch(P, prm, pick_batch(prm, o.cg_batch, round));
+      if (rc) return rc;
+      HIP_TRY(hipStreamSynchronize(s));
+      if (P->scal->cg_status != -1) break;
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  const pgo::LmScalars sc = *P->scal;
+  const int cg_it = sc.cg_iterations, cg_status = sc.cg_status;
+  P->last_cg_iterations = cg_it;
   L.reuse_diagonal = true;
   L.num_linear_iterations += cg_it;
   nx.linear_solver_iterations = cg_it;
-  // model cost change, delta, candidate, candidate cost — one more sync
-  pgo::launch_model_and_retract(P->g, s);
   L.t_linear += seconds_since(t_lin);
-  const auto t_res = Clock::now();
-  pgo::launch_cost(P->g, P->g.pose_c, 0, s);
-  pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s);
-  HIP_TRY(hipStreamSynchronize(s));
-  HIP_TRY(hipGetLastError());
-  L.t_residual += seconds_since(t_res);
-  const pgo::LmScalars sc = *P->scal;
+
+  if (L.gmax_deferred) {
+    // the gradient test of FinalizeIterationAndCheckIfMinimizerCanContinue for the point accepted last
+    // iteration: if it fires, the step just computed is discarded (x was not touched)
+    L.gmax_deferred = false;
+    L.gmax = sc.gradient_max;
+    L.cur.gradient_max_norm = L.gmax;
+    if (!L.records.empty()) L.records.back().gradient_max_norm = L.gmax;
+    if (L.gmax <= o.gradient_tolerance) {
+      L.num_linear_iterations -= cg_it;
+      terminate(L, PGO_CONVERGENCE, 3, "Gradient tolerance reached. Gradient max norm: %e <= %e", L.gmax, o.gradient_tolerance);
+      return PGO_OK;
+    }
+  }
+  nx.gradient_max_norm = L.cur.gradient_max_norm;
   const bool lin_ok = (cg_status != 2) && std::isfinite(sc.model_change) && !sc.linearize_bad;
   const double model_cost_change = sc.model_change;
   const bool step_valid = lin_ok && model_cost_change > 0.0;
@@ -619,12 +665,9 @@ int lm_advance(pgo_problem* P) {
     L.x_cost = cand_cost;
     rc = evaluate_gradient_and_jacobian(P, false);
     if (rc) return rc;
-    pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s);
-    HIP_TRY(hipStreamSynchronize(s));
-    L.gmax = P->scal->gradient_max;
+    L.gmax_deferred = true;  // filled in at the next host sync (or in pgo_solver_end)
     nx.step_is_successful = 1;
     nx.cost = L.x_cost;
-    nx.gradient_max_norm = L.gmax;
     L.radius = L.radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * nx.relative_decrease - 1.0, 3));
     L.radius = std::min(o.max_trust_region_radius, L.radius);
     L.decrease_factor = 2.0;
@@ -646,6 +689,14 @@ int lm_advance(pgo_problem* P) {
 int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* records, int capacity) {
   LmState& L = P->lm;
   if (!L.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_end without pgo_solver_begin");
+  if (L.gmax_deferred) {
+    pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, P->stream);
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    L.gmax = P->scal->gradient_max;
+    L.cur.gradient_max_norm = L.gmax;
+    if (!L.pending_record && !L.records.empty()) L.records.back().gradient_max_norm = L.gmax;
+    L.gmax_deferred = false;
+  }
   if (L.pending_record) {
     if (L.cur.step_is_successful) ++L.num_successful; else ++L.num_unsuccessful;
     L.cur.trust_region_radius = L.radius;
@@ -868,6 +919,7 @@ int pgo_solver_reset(pgo_problem* P) {
   L.decrease_factor = 2.0;
   L.reuse_diagonal = false;
   L.terminated = false;
+  L.gmax_deferred = false;
   L.num_consecutive_invalid = 0;
   pgo_iteration_record r{};
   r.iteration = 0;  // the iteration budget restarts with the state
@@ -1070,6 +1122,7 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
   hipStream_t s = P->stream;
   const std::string k = kernel;
   pgo::CgParams prm = cg_params_for(P->opt);
+  { const char* d = getenv("PGO_DEBUG"); P->g.debug = d ? atoi(d) : 0; }
   if (k == "evaluate") {
     HIP_TRY(P->d_tmp_a.alloc((size_t)6 * P->g.E));
     HIP_TRY(P->d_tmp_b.alloc((size_t)36 * P->g.E));
@@ -1089,10 +1142,38 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     else if (k == "spmv") pgo::launch_spmv_plain(P->g, s);
     else if (k == "pcg_spmv") pgo::launch_pcg_spmv_only(P->g, prm, s);
     else if (k == "pcg_update") pgo::launch_pcg_update_only(P->g, s);
-    else if (k == "pcg_iteration") pgo::launch_pcg_iteration(P->g, prm, s);
+    else if (k == "pcg_iteration") pgo::launch_pcg_iteration(P->g, prm, 1, s);
+    else if (k == "empty") pgo::launch_debug(P->g, 0, s);
+    else if (k == "touch") pgo::launch_debug(P->g, 1, s);
     else return -1;
     return 0;
   };
+  if (k == "pcg_graph") {
+    // average time of one CG iteration inside a captured batch with every stopping test disabled
+    pgo::CgParams np{-1.0, -1.0, 1 << 30, 0};
+    const int batch = 200;
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    pgo::launch_damping(P->g, P->lm.radius, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, 0, s);
+    double total = 0;
+    for (int r = 0; r < repeats + 1; ++r) {
+      pgo::launch_pcg_init(P->g, s);
+      HIP_TRY(hipEventRecord(a, s));
+      int rc = launch_cg_batch(P, np, batch);
+      if (rc) return rc;
+      HIP_TRY(hipEventRecord(b, s));
+      HIP_TRY(hipEventSynchronize(b));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, a, b));
+      if (r > 0) total += ms;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    P->drop_graph();
+    *avg_ms = total / repeats / batch;
+    return PGO_OK;
+  }
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
