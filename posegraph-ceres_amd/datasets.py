@@ -367,10 +367,13 @@ def read_g2o(path):
     return g
 
 
-def write_g2o(path, g, fixed=(0,)):
+def write_g2o(path, g, fixed=(0,), exact=False):
+    """exact=True prints 17 significant digits (lossless round trip) instead of the 6 g2o tools print."""
+    fmt = (lambda v: "%.17g" % v) if exact else _g6
+    _g = fmt
     with open(path, "w") as f:
         for i, p in enumerate(g.poses):
-            f.write("VERTEX_SE3:QUAT %d %s \n" % (i, " ".join(_g6(v) for v in p)))
+            f.write("VERTEX_SE3:QUAT %d %s \n" % (i, " ".join(_g(v) for v in p)))
             if i in fixed:
                 f.write("FIX %d\n" % i)
         for e in range(g.E):
@@ -380,5 +383,5 @@ def write_g2o(path, g, fixed=(0,)):
                 L = g.sqrt_info[e].reshape(6, 6)
                 info = L @ L.T
             up = [info[r, c] for r in range(6) for c in range(r, 6)]
-            f.write("EDGE_SE3:QUAT %d %d %s %s \n" % (g.ia[e], g.ib[e], " ".join(_g6(v) for v in g.meas[e]),
-                                                    " ".join(_g6(v) for v in up)))
+            f.write("EDGE_SE3:QUAT %d %d %s %s \n" % (g.ia[e], g.ib[e], " ".join(_g(v) for v in g.meas[e]),
+                                                    " ".join(_g(v) for v in up)))
