@@ -120,8 +120,18 @@ def main():
         b_lin = 640 * E + 392 * N
         b_eval = 976 * E + 56 * N
         ach = b_spmv / (t_spmv * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes of this same command (tools/rocprof_pmc.py -> profiles/), if present
+        traffic = None
+        try:
+            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
+            if pmcs and (N, E) == (N_POSES, N_EDGES):
+                pm = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
+                traffic = pm["kernels"]["k_spmv<0>"]["hbm_bytes_per_launch_corrected"]
+                extra["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE)" % pmcs[-1]
+        except Exception:
+            traffic = None
         roofline = {"kernel": "k_spmv<0> (PCG block SpMV, FP64 6x6 BSR)", "bound": "hbm", "achieved": round(ach, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": b_spmv, "avg_launch_us": round(t_spmv * 1e3, 3)}
         ach_lin = b_lin / (t_lin * 1e-3) / 1e9
         ach_eval = b_eval / (t_eval * 1e-3) / 1e9
