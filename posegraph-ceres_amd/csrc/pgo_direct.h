@@ -1,0 +1,60 @@
+// pgo_direct.h — exact linear solve of (H~ + D^2) x = S g on the GPU: block-sparse Cholesky over 6x6 pose
+// blocks with a nested-dissection ordering and an elimination-tree level schedule.  This is the path behind
+// ceres::SPARSE_NORMAL_CHOLESKY (finial.cpp:536; role of SparseNormalCholeskySolver + CHOLMOD in the
+// reference).  The symbolic phase runs once per topology on the host; the numeric
+// factorisation and both triangular solves run on the device every LM iteration.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "pgo_kernels.h"
+
+namespace pgo {
+
+// Device view of the symbolic structure (all indices in the PERMUTED numbering unless noted).
+struct DirectPlan {
+  int n;            // block columns (= poses)
+  int nb;           // blocks of L (diagonal + strictly lower)
+  int n_levels;
+  const int* perm;        // [n]  new -> old pose index
+  const int* col_ptr;     // [n+1] first block of a column is its diagonal block
+  const int* blk_row;     // [nb] row of each block
+  const int* asrc_ptr;    // [nb+1] BSR slots whose values initialise the block (summed)
+  const int* asrc_slot;
+  const int* upd_ptr;     // [nb+1] update pairs: block -= L[upd_a] * L[upd_b]^T
+  const int* upd_a;
+  const int* upd_b;
+  const int* level_ptr;   // [n_levels+1] columns by elimination-tree level
+  const int* level_cols;  // [n]
+  const int* rowl_ptr;    // [n+1] forward solve: blocks (j,k), k < j, of row j ...
+  const int* rowl_blk;    //       ... block index
+  const int* rowl_col;    //       ... column k
+  double* Lval;           // [nb][36] row-major blocks of the factor
+  double* y;              // [6n] permuted work vector
+};
+
+struct DirectSymbolic {
+  // host copies (kept for tests / statistics)
+  std::vector<int> perm, iperm, col_ptr, blk_row, asrc_ptr, asrc_slot, upd_ptr, upd_a, upd_b, level_ptr, level_cols,
+      rowl_ptr, rowl_blk, rowl_col;
+  int n = 0, nb = 0, n_levels = 0;
+  long long n_pairs = 0;
+  int fused_from_level = 0;  // levels >= this are processed by one single-workgroup launch
+  double flops = 0;
+  double est_steps = 0;      // critical-path length of the schedule in update-pair steps (cost model)
+};
+
+// Host symbolic analysis.  slot_* describe the incidence-slot BSR (pgo_solver.cpp prepare()).
+// Returns false when the factorisation would be impractical (caller falls back to the iterative path).
+bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib, int n_slots,
+                    const std::vector<int>& slot_row, const std::vector<int>& slot_col,
+                    const std::vector<uint8_t>& slot_side, const std::vector<int>& row_slot_begin,
+                    DirectSymbolic* out);
+
+// Device launches.  flags[2] is set when a pivot is not positive.
+void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const int* level_ptr_host, int fused_from_level, hipStream_t s);
+void launch_direct_solve(const DeviceGraph& g, const DirectPlan& p, const int* level_ptr_host, int fused_from_level, hipStream_t s);
+
+}  // namespace pgo

@@ -1,0 +1,293 @@
+// pgo_direct_kernels.hip — numeric phase of the GPU block-sparse Cholesky (pgo_direct.h): level-scheduled
+// left-looking factorisation over 6x6 blocks and the two triangular solves.
+//
+// One wave per block column.  Ten 6-lane groups work on ten blocks of the column at a time; lane r of a group
+// owns row r of its block in registers: it gathers the block from the BSR slots, subtracts its L_ik L_jk^T
+// updates (fixed order), and — once the diagonal block of the column has been factored by group 0 and
+// published through LDS — finishes its row with the triangular solve against L_jj.  Nothing produced inside a
+// launch is re-read from global memory inside the same wave, and a column only reads columns of lower levels.
+// At these sizes (10^4..10^5 blocks) the schedule is launch-latency bound, so the elimination-tree levels
+// that hold at most 8 columns are folded into ONE single-workgroup launch (barrier between levels).
+#include "pgo_direct.h"
+
+namespace pgo {
+namespace {
+
+constexpr int FUSED_WAVES = 8;
+
+// row `r` of block `b`, 6 doubles
+__device__ __forceinline__ void load_row(const double* Lval, int b, int r, double* out) {
+  const double2* p = reinterpret_cast<const double2*>(Lval + 36 * (size_t)b + 6 * r);
+  const double2 a = p[0], c = p[1], d = p[2];
+  out[0] = a.x; out[1] = a.y; out[2] = c.x; out[3] = c.y; out[4] = d.x; out[5] = d.y;
+}
+
+// Partial assembly of row r of block `bi`: BSR sources (only when sub == 0) minus the update pairs
+// q = first + sub, first + sub + stride, ... ; the `stride` partial results are summed by the caller.
+__device__ __forceinline__ void assemble_row(const DeviceGraph& g, const DirectPlan& p, int bi, int r, int sub, int stride, double* v) {
+#pragma unroll
+  for (int c = 0; c < 6; ++c) v[c] = 0.0;
+  if (sub == 0) {
+    for (int s = p.asrc_ptr[bi]; s < p.asrc_ptr[bi + 1]; ++s) {
+      const int slot = p.asrc_slot[s];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v[c] += g.bsr_val[bsr_index(slot, 6 * r + c)];
+    }
+  }
+  for (int q = p.upd_ptr[bi] + sub; q < p.upd_ptr[bi + 1]; q += stride) {
+    double a[6];
+    load_row(p.Lval, p.upd_a[q], r, a);
+    const double* B = p.Lval + 36 * (size_t)p.upd_b[q];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s += a[k] * B[6 * c + k];
+      v[c] -= s;
+    }
+  }
+}
+
+// Factorises column j with one wave.  sh: 360 doubles of LDS private to the wave (10 groups x 6 rows x 6).
+// The ten 6-lane groups share the work of a chunk of up to ten blocks: with fewer blocks than groups the
+// update list of each block is split over several groups and the partial rows are summed through LDS
+// (fixed order), so the long lists of the separator columns near the root do not serialise on 6 lanes.
+__device__ void factor_column(const DeviceGraph& g, const DirectPlan& p, int j, double* sh) {
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / 6, r = lane - 6 * grp;
+  const bool in_grp = grp < 10;
+  const int b0 = p.col_ptr[j], nblk = p.col_ptr[j + 1] - b0;
+  // ---- diagonal block: its update list is split over all ten groups ----
+  if (in_grp) {
+    double v[6];
+    assemble_row(g, p, b0, r, grp, 10, v);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) sh[(grp * 6 + r) * 6 + c] = v[c];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  double Ljj[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) {
+    double s = 0.0;
+#pragma unroll
+    for (int gq = 0; gq < 10; ++gq) s += sh[gq * 36 + k];
+    Ljj[k] = s;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double d = Ljj[7 * c];
+#pragma unroll
+    for (int k = 0; k < c; ++k) d -= Ljj[6 * c + k] * Ljj[6 * c + k];
+    if (!(d > 0.0)) { ok = false; d = 1.0; }
+    d = sqrt(d);
+    Ljj[7 * c] = d;
+    const double inv = 1.0 / d;
+#pragma unroll
+    for (int i = c + 1; i < 6; ++i) {
+      double s = Ljj[6 * i + c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) s -= Ljj[6 * i + k] * Ljj[6 * c + k];
+      Ljj[6 * i + c] = s * inv;
+    }
+#pragma unroll
+    for (int i = 0; i < c; ++i) Ljj[6 * i + c] = 0.0;
+  }
+  if (!ok && lane == 0) atomicOr(&g.flags[2], 1);
+  if (lane < 36) p.Lval[36 * (size_t)b0 + lane] = Ljj[lane];
+  // ---- off-diagonal blocks in chunks of up to ten: row r of L_ij = (row r of V_ij) * L_jj^-T ----
+  for (int t0 = 1; t0 < nblk; t0 += 10) {
+    const int bc = min(10, nblk - t0);
+    const int gpb = 10 / bc;                       // groups per block
+    const int my = grp / gpb, sub = grp - my * gpb;
+    const bool active = in_grp && my < bc;
+    double v[6];
+    if (active) {
+      assemble_row(g, p, b0 + t0 + my, r, sub, gpb, v);
+      if (gpb > 1) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sh[(grp * 6 + r) * 6 + c] = v[c];
+      }
+    }
+    if (gpb > 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (active && sub == 0) {
+        for (int q = 1; q < gpb; ++q) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) v[c] += sh[((grp + q) * 6 + r) * 6 + c];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (active && sub == 0) {
+      double x[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double s = v[c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) s -= x[k] * Ljj[6 * c + k];
+        x[c] = s / Ljj[7 * c];
+      }
+      double2* o = reinterpret_cast<double2*>(p.Lval + 36 * (size_t)(b0 + t0 + my) + 6 * r);
+      o[0] = double2{x[0], x[1]}; o[1] = double2{x[2], x[3]}; o[2] = double2{x[4], x[5]};
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_chol_level(DeviceGraph g, DirectPlan p, int level) {
+  __shared__ double sh[360];
+  const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
+  factor_column(g, p, j, sh);
+}
+
+__global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_tail(DeviceGraph g, DirectPlan p, int from_level) {
+  __shared__ double sh[FUSED_WAVES][360];
+  const int wave = threadIdx.x >> 6;
+  for (int l = from_level; l < p.n_levels; ++l) {
+    const int c0 = p.level_ptr[l], nc = p.level_ptr[l + 1] - c0;
+    if (wave < nc) factor_column(g, p, p.level_cols[c0 + wave], sh[wave]);
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+// ---- forward solve  L y = P (S g):  y_j = L_jj^-1 (b_j - sum_k L_jk y_k) ----
+__device__ void forward_column(const DeviceGraph& g, const DirectPlan& p, int j, double* sh) {
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / 6, r = lane - 6 * grp;
+  double acc = 0.0;
+  if (grp < 10) {
+    for (int q = p.rowl_ptr[j] + grp; q < p.rowl_ptr[j + 1]; q += 10) {
+      double a[6];
+      load_row(p.Lval, p.rowl_blk[q], r, a);
+      const double* yk = p.y + 6 * (size_t)p.rowl_col[q];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc += a[c] * yk[c];
+    }
+    sh[lane] = acc;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane == 0) {
+    const int old = p.perm[j];
+    double rhs[6], y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double b = g.scale[6 * (size_t)old + i] * g.grad[6 * (size_t)old + i];
+      g.cg_b[6 * (size_t)old + i] = b;
+      double s = 0.0;
+      for (int gq = 0; gq < 10; ++gq) s += sh[6 * gq + i];
+      rhs[i] = b - s;
+    }
+    const double* L = p.Lval + 36 * (size_t)p.col_ptr[j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double s = rhs[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
+      y[i] = s / L[7 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p.y[6 * (size_t)j + i] = y[i];
+  }
+}
+
+// ---- backward solve  L^T x = y:  x_j = L_jj^-T (y_j - sum_{i in struct(j)} L_ij^T x_i) ----
+__device__ void backward_column(const DeviceGraph& g, const DirectPlan& p, int j, double* sh) {
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / 6, c = lane - 6 * grp;   // lane owns COLUMN c of L_ij (component c of L_ij^T x_i)
+  const int b0 = p.col_ptr[j], nblk = p.col_ptr[j + 1] - b0;
+  double acc = 0.0;
+  if (grp < 10) {
+    for (int t = 1 + grp; t < nblk; t += 10) {
+      const double* B = p.Lval + 36 * (size_t)(b0 + t);
+      const double* xi = p.y + 6 * (size_t)p.blk_row[b0 + t];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc += B[6 * k + c] * xi[k];
+    }
+    sh[lane] = acc;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane == 0) {
+    double rhs[6], x[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double s = 0.0;
+      for (int gq = 0; gq < 10; ++gq) s += sh[6 * gq + i];
+      rhs[i] = p.y[6 * (size_t)j + i] - s;
+    }
+    const double* L = p.Lval + 36 * (size_t)b0;
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      double s = rhs[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
+      x[i] = s / L[7 * i];
+    }
+    const int old = p.perm[j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { p.y[6 * (size_t)j + i] = x[i]; g.cg_x[6 * (size_t)old + i] = x[i]; }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_fwd_level(DeviceGraph g, DirectPlan p, int level) {
+  __shared__ double sh[64];
+  forward_column(g, p, p.level_cols[p.level_ptr[level] + blockIdx.x], sh);
+}
+__global__ __launch_bounds__(64) void k_bwd_level(DeviceGraph g, DirectPlan p, int level) {
+  __shared__ double sh[64];
+  backward_column(g, p, p.level_cols[p.level_ptr[level] + blockIdx.x], sh);
+}
+__global__ __launch_bounds__(64 * FUSED_WAVES) void k_fwd_tail(DeviceGraph g, DirectPlan p, int from_level) {
+  __shared__ double sh[FUSED_WAVES][64];
+  const int wave = threadIdx.x >> 6;
+  for (int l = from_level; l < p.n_levels; ++l) {
+    const int c0 = p.level_ptr[l], nc = p.level_ptr[l + 1] - c0;
+    if (wave < nc) forward_column(g, p, p.level_cols[c0 + wave], sh[wave]);
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(64 * FUSED_WAVES) void k_bwd_tail(DeviceGraph g, DirectPlan p, int from_level) {
+  __shared__ double sh[FUSED_WAVES][64];
+  const int wave = threadIdx.x >> 6;
+  for (int l = p.n_levels - 1; l >= from_level; --l) {
+    const int c0 = p.level_ptr[l], nc = p.level_ptr[l + 1] - c0;
+    if (wave < nc) backward_column(g, p, p.level_cols[c0 + wave], sh[wave]);
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const int* level_ptr_host, int fused_from_level, hipStream_t s) {
+  for (int l = 0; l < fused_from_level; ++l) {
+    const int nc = level_ptr_host[l + 1] - level_ptr_host[l];
+    hipLaunchKernelGGL(k_chol_level, dim3(nc), dim3(64), 0, s, g, p, l);
+  }
+  if (fused_from_level < p.n_levels) hipLaunchKernelGGL(k_chol_tail, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, fused_from_level);
+}
+
+void launch_direct_solve(const DeviceGraph& g, const DirectPlan& p, const int* level_ptr_host, int fused_from_level, hipStream_t s) {
+  for (int l = 0; l < fused_from_level; ++l) {
+    const int nc = level_ptr_host[l + 1] - level_ptr_host[l];
+    hipLaunchKernelGGL(k_fwd_level, dim3(nc), dim3(64), 0, s, g, p, l);
+  }
+  if (fused_from_level < p.n_levels) {
+    hipLaunchKernelGGL(k_fwd_tail, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, fused_from_level);
+    hipLaunchKernelGGL(k_bwd_tail, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, fused_from_level);
+  }
+  for (int l = fused_from_level - 1; l >= 0; --l) {
+    const int nc = level_ptr_host[l + 1] - level_ptr_host[l];
+    hipLaunchKernelGGL(k_bwd_level, dim3(nc), dim3(64), 0, s, g, p, l);
+  }
+}
+
+}  // namespace pgo

@@ -862,7 +862,9 @@ __global__ void k_finalize_scalars(DeviceGraph g, int n_cost_part) {
     g.scal->step_norm_sq = s[2];
     g.scal->x_norm_sq = s[3];
     g.scal->gradient_max = t;
-    g.scal->linearize_bad = g.flags[1];
+    g.scal->linearize_bad = g.flags[1] | (g.flags[2] << 1);  // bit0: block inverse failed, bit1: Cholesky pivot
+    g.flags[1] = 0;
+    g.flags[2] = 0;
   }
 }
 
