@@ -59,7 +59,9 @@ typedef struct pgo_solver_options {
   int min_linear_solver_iterations;       /* 0 */
   int max_num_consecutive_invalid_steps;  /* 5 */
   int cg_batch;                           /* CG iterations enqueued per host check (0 = auto) */
-  int reserved0;
+  int pcg_cluster_poses;                  /* poses per Jacobi block of the PCG preconditioner: 1 = 6x6 pose blocks (default;
+                                             Ceres JACOBI is per parameter block), 2 = 12x12, 4 = 24x24 pieces of the odometry
+                                             chain (Ceres CLUSTER_JACOBI analogue) */
   double function_tolerance;              /* 1e-6 */
   double gradient_tolerance;              /* 1e-10 */
   double parameter_tolerance;             /* 1e-8 */

@@ -689,18 +689,61 @@ struct SparseChol {
 // iterations) with a block-Jacobi preconditioner on the 6x6 pose blocks of H + D^2.
 // Solves (H + D^2) x = b, x0 = 0.  Returns iterations used; *ok=false on breakdown.
 // ---------------------------------------------------------------------------------------------
+// Dense SPD solve helpers for the cluster preconditioner (n <= 6 * cluster)
+bool chol_dense(std::vector<double>& A, int n) {
+  for (int j = 0; j < n; ++j) {
+    double d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(d > 0.0)) return false;
+    d = std::sqrt(d);
+    A[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double t = A[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) t -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+      A[(size_t)i * n + j] = t / d;
+    }
+  }
+  return true;
+}
+void chol_dense_solve(const std::vector<double>& L, int n, const double* b, double* x) {
+  std::vector<double> y(n);
+  for (int i = 0; i < n; ++i) { double t = b[i]; for (int k = 0; k < i; ++k) t -= L[(size_t)i * n + k] * y[k]; y[i] = t / L[(size_t)i * n + i]; }
+  for (int i = n - 1; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < n; ++k) t -= L[(size_t)k * n + i] * x[k]; x[i] = t / L[(size_t)i * n + i]; }
+}
+
 int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, double q_tol,
-              int max_it, int min_it, int residual_reset_period, bool* ok, double* final_rnorm) {
+              int max_it, int min_it, int residual_reset_period, bool* ok, double* final_rnorm, int cluster = 1) {
   const int n = H.n;
   const size_t m = (size_t)6 * n;
-  std::vector<Blk> Minv(n);
-  for (int v = 0; v < n; ++v) {
-    Blk A = H.val[H.colptr[v]];
-    for (int i = 0; i < 6; ++i) A[7 * i] += d2[6 * (size_t)v + i];
-    // symmetrise from the stored full block, factor
-    if (!chol6(A.data())) { *ok = false; return 0; }
-    Minv[v] = A;  // keep the Cholesky factor; apply by solves
+  // block-Jacobi preconditioner; cluster > 1 groups `cluster` consecutive poses (a piece of the odometry
+  // chain) into one dense diagonal block of H + D^2 (the product's cluster-Jacobi option)
+  if (cluster < 1) cluster = 1;
+  const int ncl = (n + cluster - 1) / cluster;
+  std::vector<std::vector<double>> Mfac(ncl);
+  for (int c = 0; c < ncl; ++c) {
+    const int v0 = c * cluster, v1 = std::min(n, v0 + cluster), dim = 6 * (v1 - v0);
+    std::vector<double>& A = Mfac[c];
+    A.assign((size_t)dim * dim, 0.0);
+    for (int j = v0; j < v1; ++j)
+      for (int p = H.colptr[j]; p < H.colptr[j + 1]; ++p) {
+        const int i = H.rowidx[p];
+        if (i < v0 || i >= v1) continue;
+        for (int r = 0; r < 6; ++r)
+          for (int cc = 0; cc < 6; ++cc) {
+            const double val = H.val[p][6 * r + cc];
+            A[(size_t)(6 * (i - v0) + r) * dim + 6 * (j - v0) + cc] = val;
+            A[(size_t)(6 * (j - v0) + cc) * dim + 6 * (i - v0) + r] = val;
+          }
+      }
+    for (int k = 0; k < dim; ++k) A[(size_t)k * dim + k] += d2[6 * (size_t)v0 + k];
+    if (!chol_dense(A, dim)) { *ok = false; return 0; }
   }
+  auto apply_M = [&](const double* rin, double* zout) {
+    for (int c = 0; c < ncl; ++c) {
+      const int v0 = c * cluster, v1 = std::min(n, v0 + cluster);
+      chol_dense_solve(Mfac[c], 6 * (v1 - v0), rin + 6 * (size_t)v0, zout + 6 * (size_t)v0);
+    }
+  };
   std::vector<double> r(b, b + m), z(m), p(m, 0.0), q(m), tmp(m);
   std::fill(x, x + m, 0.0);
   double rho = 1.0;
@@ -710,7 +753,7 @@ int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, d
   *ok = true;
   int it = 1;
   for (;; ++it) {
-    for (int v = 0; v < n; ++v) chol6_solve(Minv[v].data(), &r[6 * (size_t)v], &z[6 * (size_t)v]);
+    apply_M(r.data(), z.data());
     const double last_rho = rho;
     rho = dot(r.data(), z.data());
     if (rho == 0.0 || !std::isfinite(rho)) { *ok = (rho == 0.0); break; }
@@ -771,6 +814,8 @@ struct oracle_options {
   double min_lm_diagonal;              // 1e-6
   double max_lm_diagonal;              // 1e32
   double eta;                          // 0.1
+  int pcg_cluster;                     // poses per Jacobi block of the PCG preconditioner (1 = 6x6 blocks, Ceres JACOBI-like)
+  int reserved;
 };
 
 struct oracle_summary {
@@ -814,6 +859,8 @@ void oracle_default_options(oracle_options* o) {
   o->min_lm_diagonal = 1e-6;
   o->max_lm_diagonal = 1e32;
   o->eta = 0.1;
+  o->pcg_cluster = 1;
+  o->reserved = 0;
 }
 
 void oracle_edge_eval_autodiff(const double* pa, const double* qa, const double* pb, const double* qb,
@@ -902,7 +949,7 @@ int oracle_linear_solve(int N, int E, const double* poses, const uint8_t* cmask,
     return 0;
   }
   bool ok;
-  int it = pcg_solve(H, d2, b, x, q_tol, max_it, 0, 10, &ok, nullptr);
+  int it = pcg_solve(H, d2, b, x, q_tol, max_it, 0, 10, &ok, nullptr, linear_solver >= 100 ? linear_solver - 100 : 1);
   return ok ? it : -1;
 }
 
@@ -1040,7 +1087,7 @@ int oracle_solve(int N, int E, double* poses, const uint8_t* cmask, const int* i
       sum->factor_flops = chol.flops;
     } else {
       lin_it = pcg_solve(H, d2.data(), gs.data(), step.data(), opt->eta, opt->max_linear_solver_iterations,
-                         opt->min_linear_solver_iterations, opt->residual_reset_period, &lin_ok, nullptr);
+                         opt->min_linear_solver_iterations, opt->residual_reset_period, &lin_ok, nullptr, opt->pcg_cluster);
       sum->num_linear_iterations += lin_it;
     }
     if (lin_ok) for (size_t i = 0; i < m; ++i) { if (!std::isfinite(step[i])) { lin_ok = false; break; } }

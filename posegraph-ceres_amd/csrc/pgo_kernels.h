@@ -100,6 +100,9 @@ struct DeviceGraph {
   LmScalars* scal;    // device-visible pinned host memory
   int* flags;         // [4] device flags: [0] linearize saw non-finite
   int debug;          // development ablation switches (0 in production)
+  int cluster;        // poses per Jacobi block of the preconditioner: 1 (6x6), 2 (12x12) or 4 (24x24)
+  const int* cl_ptr;  // [n_clusters+1] BSR slots whose row AND column lie inside the cluster (off-diagonal ones)
+  const int* cl_slot;
 };
 
 struct CgParams {

@@ -319,11 +319,67 @@ __global__ void k_damping(DeviceGraph g, double radius, double min_diag, double 
   const int slot = g.row_slot_begin[v];
 #pragma unroll
   for (int k = 0; k < 36; ++k) g.bsr_val[bsr_index(slot, k)] = A[k];
+  if (g.cluster > 1) return;  // the cluster preconditioner kernel builds M^-1
   double Ai[36];
   if (!spd6_inverse(A, Ai)) atomicOr(&g.flags[1], 1);
   double2* dst = reinterpret_cast<double2*>(g.Minv + 36 * (size_t)v);
 #pragma unroll
   for (int k = 0; k < 18; ++k) dst[k] = double2{Ai[2 * k], Ai[2 * k + 1]};
+}
+
+// Cluster-Jacobi preconditioner: CL consecutive poses (a piece of the odometry chain, plus whatever loop
+// edges fall inside it) form one dense (6 CL)^2 diagonal block of H~ + D^2, inverted in LDS by in-place
+// Gauss-Jordan (SPD, no pivoting).  One wave per cluster.  Row r of the inverse is what lane r of the
+// vector kernels reads (contiguous 6 CL doubles).
+template <int CL>
+__global__ __launch_bounds__(64) void k_cluster_precond(DeviceGraph g) {
+  constexpr int DIM = 6 * CL, LD = DIM + 1;
+  __shared__ double A[DIM * LD];
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const int v0 = c * CL;
+  for (int e = lane; e < DIM * LD; e += 64) A[e] = 0.0;
+  __syncthreads();
+  for (int lp = 0; lp < CL; ++lp) {
+    const int v = v0 + lp;
+    if (lane < 36) {
+      const int i = lane / 6, j = lane - 6 * i;
+      double val = (i == j) ? 1.0 : 0.0;   // poses past the end: identity
+      if (v < g.N) val = g.Hdiag[36 * (size_t)v + lane] + ((i == j) ? g.d2[6 * (size_t)v + i] : 0.0);
+      A[(6 * lp + i) * LD + 6 * lp + j] = val;
+    }
+  }
+  __syncthreads();
+  for (int s = g.cl_ptr[c]; s < g.cl_ptr[c + 1]; ++s) {   // in-cluster off-diagonal blocks, serial over slots
+    const int slot = g.cl_slot[s];
+    const int ro = 6 * (g.slot_row[slot] - v0), co = 6 * (g.slot_col[slot] - v0);
+    if (lane < 36) {
+      const int i = lane / 6, j = lane - 6 * i;
+      A[(ro + i) * LD + co + j] += g.bsr_val[bsr_index(slot, lane)];
+    }
+    __syncthreads();
+  }
+  bool ok = true;
+  for (int k = 0; k < DIM; ++k) {
+    const double pk = A[k * LD + k];
+    if (!(pk > 0.0)) ok = false;
+    const double ip = 1.0 / pk;
+    for (int e = lane; e < DIM * DIM; e += 64) {
+      const int i = e / DIM, j = e - i * DIM;
+      if (i != k && j != k) A[i * LD + j] -= A[i * LD + k] * A[k * LD + j] * ip;
+    }
+    __syncthreads();
+    for (int e = lane; e < DIM; e += 64) {
+      if (e != k) { A[k * LD + e] *= ip; }
+    }
+    for (int e = lane; e < DIM; e += 64) {
+      if (e != k) { A[e * LD + k] *= -ip; }
+    }
+    if (lane == 0) A[k * LD + k] = ip;
+    __syncthreads();
+  }
+  if (!ok && lane == 0) atomicOr(&g.flags[1], 1);
+  double* out = g.Minv + (size_t)c * DIM * DIM;
+  for (int e = lane; e < DIM * DIM; e += 64) { const int i = e / DIM, j = e - i * DIM; out[e] = A[i * LD + j]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -431,6 +487,7 @@ __global__ __launch_bounds__(128) void k_evaluate_edges(DeviceGraph g, const dou
 // re-derived by every workgroup from per-workgroup partial sums (fixed order), so there is no host
 // round trip, no atomics and no grid barrier inside the iteration.
 // ------------------------------------------------------------------------------------------------
+template <int CL>
 __global__ void k_pcg_init(DeviceGraph g) {
   __shared__ double rl[VEC_BLOCK];
   __shared__ double scratch[2 * (VEC_BLOCK / 64)];
@@ -451,11 +508,12 @@ __global__ void k_pcg_init(DeviceGraph g) {
     rl[tid] = b;
     __syncthreads();
     if (live) {
-      const int v = idx / 6, c = idx - 6 * v, lv = tid / 6;
-      const double* Mi = g.Minv + 36 * (size_t)v + 6 * c;
+      constexpr int DIM = 6 * CL;
+      const double* Mi = g.Minv + (size_t)idx * DIM;      // row (idx mod DIM) of cluster idx / DIM
+      const double* rv = rl + DIM * (tid / DIM);
       double z = 0.0;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) z += Mi[k] * rl[6 * lv + k];
+      for (int k = 0; k < DIM; ++k) z += Mi[k] * rv[k];
       g.cg_z[idx] = z;
       acc[0] += b * z;
       acc[1] += b * b;
@@ -659,7 +717,9 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
 }
 
 // x += alpha p ; r -= alpha q ; z = M^-1 r ; partial r'z, Q = x'(b + r), r'r.  All loads up front.
+template <int CL>
 __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd) {
+  constexpr int DIM = 6 * CL;
   __shared__ double rl[VEC_BLOCK];
   __shared__ double scratch[3 * (VEC_BLOCK / 64)];
   const int tid = threadIdx.x;
@@ -669,11 +729,14 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd
   bool live = idx < m;
   const double* p = odd ? g.cg_p1 : g.cg_p0;
   double x0 = 0, pa = 0, r0 = 0, q0 = 0, b0 = 0;
-  double2 mi[3] = {{0, 0}, {0, 0}, {0, 0}};
+  double2 mi[DIM / 2];
+#pragma unroll
+  for (int k = 0; k < DIM / 2; ++k) mi[k] = double2{0, 0};
   if (live) {
     x0 = g.cg_x[idx]; pa = p[idx]; r0 = g.cg_r[idx]; q0 = g.cg_q[idx]; b0 = g.cg_b[idx];
-    const double2* Mi = reinterpret_cast<const double2*>(g.Minv + 6 * (size_t)idx);   // row c of block v: 36 v + 6 c = 6 idx
-    mi[0] = Mi[0]; mi[1] = Mi[1]; mi[2] = Mi[2];
+    const double2* Mi = reinterpret_cast<const double2*>(g.Minv + (size_t)idx * DIM);   // row (idx mod DIM) of cluster idx / DIM
+#pragma unroll
+    for (int k = 0; k < DIM / 2; ++k) mi[k] = Mi[k];
   }
   const int done = g.cg->done;
   const int it = g.cg->cnt_a;
@@ -697,8 +760,9 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd
       live = idx < m;
       if (live) {
         x0 = g.cg_x[idx]; pa = p[idx]; r0 = g.cg_r[idx]; q0 = g.cg_q[idx]; b0 = g.cg_b[idx];
-        const double2* Mi = reinterpret_cast<const double2*>(g.Minv + 6 * (size_t)idx);
-        mi[0] = Mi[0]; mi[1] = Mi[1]; mi[2] = Mi[2];
+        const double2* Mi = reinterpret_cast<const double2*>(g.Minv + (size_t)idx * DIM);
+#pragma unroll
+        for (int k = 0; k < DIM / 2; ++k) mi[k] = Mi[k];
       }
     }
     double x = 0.0, r = 0.0;
@@ -711,8 +775,10 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd
     rl[tid] = r;
     __syncthreads();
     if (live) {
-      const double* rv = rl + 6 * (tid / 6);
-      const double z = mi[0].x * rv[0] + mi[0].y * rv[1] + mi[1].x * rv[2] + mi[1].y * rv[3] + mi[2].x * rv[4] + mi[2].y * rv[5];
+      const double* rv = rl + DIM * (tid / DIM);
+      double z = 0.0;
+#pragma unroll
+      for (int k = 0; k < DIM / 2; ++k) z += mi[k].x * rv[2 * k] + mi[k].y * rv[2 * k + 1];
       g.cg_z[idx] = z;
       acc[0] += r * z;
       acc[1] += x * (b0 + r);
@@ -895,6 +961,8 @@ void launch_scale_from_diag(const DeviceGraph& g, hipStream_t s) {
 }
 void launch_damping(const DeviceGraph& g, double radius, double min_diag, double max_diag, int mode, hipStream_t s) {
   hipLaunchKernelGGL(k_damping, dim3(cdiv(g.N, 64)), dim3(64), 0, s, g, radius, min_diag, max_diag, mode);
+  if (g.cluster == 2) hipLaunchKernelGGL(k_cluster_precond<2>, dim3(cdiv(g.N, 2)), dim3(64), 0, s, g);
+  else if (g.cluster == 4) hipLaunchKernelGGL(k_cluster_precond<4>, dim3(cdiv(g.N, 4)), dim3(64), 0, s, g);
 }
 void launch_cost(const DeviceGraph& g, const double* poses, int part_row, hipStream_t s) {
   double* part = g.part_misc + (size_t)part_row * g.n_part;
@@ -905,12 +973,19 @@ void launch_evaluate_edges(const DeviceGraph& g, const double* poses, double* re
   hipLaunchKernelGGL(k_evaluate_edges, dim3(cdiv(g.E, 128)), dim3(128), 0, s, g, poses, res, ja, jb);
 }
 void launch_pcg_init(const DeviceGraph& g, hipStream_t s) {
-  hipLaunchKernelGGL(k_pcg_init, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
+  if (g.cluster == 2) hipLaunchKernelGGL(k_pcg_init<2>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
+  else if (g.cluster == 4) hipLaunchKernelGGL(k_pcg_init<4>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
+  else hipLaunchKernelGGL(k_pcg_init<1>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
+}
+static void launch_update(const DeviceGraph& g, int odd, hipStream_t s) {
+  if (g.cluster == 2) hipLaunchKernelGGL(k_pcg_update<2>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, odd);
+  else if (g.cluster == 4) hipLaunchKernelGGL(k_pcg_update<4>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, odd);
+  else hipLaunchKernelGGL(k_pcg_update<1>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, odd);
 }
 void launch_pcg_iteration(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s) {
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
   hipLaunchKernelGGL(k_spmv<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, p, odd);
-  hipLaunchKernelGGL(k_pcg_update, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, odd);
+  launch_update(g, odd, s);
 }
 void launch_pcg_finish(const DeviceGraph& g, const CgParams& p, hipStream_t s) {
   hipLaunchKernelGGL(k_pcg_finish, dim3(1), dim3(256), 0, s, g, p);
@@ -932,7 +1007,7 @@ void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, hipStream_t s
   hipLaunchKernelGGL(k_spmv<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, p, 1);
 }
 void launch_pcg_update_only(const DeviceGraph& g, hipStream_t s) {
-  hipLaunchKernelGGL(k_pcg_update, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, 1);
+  launch_update(g, 1, s);
 }
 void launch_gradient_norm(const DeviceGraph& g, hipStream_t s) {
   hipLaunchKernelGGL(k_gradient_norm, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g);

@@ -133,6 +133,9 @@ struct pgo_problem {
   DevBuf<double> dd_Lval, dd_y;
   hipGraph_t direct_graph = nullptr;
   hipGraphExec_t direct_exec = nullptr;
+  // cluster-Jacobi preconditioner topology (built when the option asks for clusters of 2 or 4 poses)
+  DevBuf<int> d_cl_ptr, d_cl_slot;
+  int cluster_built = 0;
 
   pgo_solver_options opt{};
   LmState lm;
@@ -290,7 +293,7 @@ int prepare(pgo_problem* P) {
   }
 
   P->h_slot_row = slot_row; P->h_slot_col = slot_col; P->h_slot_side = slot_side; P->h_row_slot_begin = row_slot_begin;
-  P->direct_analyzed = false; P->direct_usable = false;
+  P->direct_analyzed = false; P->direct_usable = false; P->cluster_built = 0; P->g.cluster = 1;
   HIP_TRY(P->d_slot_col.upload(slot_col, s));
   HIP_TRY(P->d_slot_row.upload(slot_row, s));
   HIP_TRY(P->d_slot_side.upload(slot_side, s));
@@ -456,6 +459,39 @@ int run_pcg(pgo_problem* P, const pgo::CgParams& prm, int batch, int* iterations
   return PGO_OK;
 }
 
+// ---- cluster-Jacobi preconditioner: which BSR slots fall inside a cluster of CL consecutive poses ----
+int prepare_clusters(pgo_problem* P, int CL) {
+  if (CL != 2 && CL != 4) CL = 1;
+  if (P->cluster_built == CL) { P->g.cluster = CL; return PGO_OK; }
+  P->drop_graph();  // captured CG batches hold the DeviceGraph by value
+  const int N = P->g.N;
+  if (CL > 1) {
+    const int ncl = (N + CL - 1) / CL;
+    std::vector<int> ptr(ncl + 1, 0), slots;
+    for (int pass = 0; pass < 2; ++pass) {
+      std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+      for (int t = 0; t < P->g.n_slots; ++t) {
+        if (P->h_slot_side[t] > pgo::SIDE_END) continue;
+        const int r = P->h_slot_row[t], c = P->h_slot_col[t];
+        if (r / CL != c / CL) continue;
+        if (pass == 0) ++ptr[r / CL + 1]; else slots[fill[r / CL]++] = t;
+      }
+      if (pass == 0) { for (int k = 0; k < ncl; ++k) ptr[k + 1] += ptr[k]; slots.resize(ptr[ncl]); }
+    }
+    HIP_TRY(P->d_cl_ptr.upload(ptr, P->stream));
+    HIP_TRY(P->d_cl_slot.upload(slots, P->stream));
+    if (slots.empty()) HIP_TRY(P->d_cl_slot.alloc(1));
+    const size_t need = (size_t)ncl * 36 * CL * CL;
+    if (P->d_Minv.n < need) HIP_TRY(P->d_Minv.alloc(need));
+    P->g.Minv = P->d_Minv.p;
+    P->g.cl_ptr = P->d_cl_ptr.p;
+    P->g.cl_slot = P->d_cl_slot.p;
+  }
+  P->g.cluster = CL;
+  P->cluster_built = CL;
+  return PGO_OK;
+}
+
 // ---- exact solver: GPU block-sparse Cholesky (pgo_direct.*) ----
 int prepare_direct(pgo_problem* P) {
   if (P->direct_analyzed) return PGO_OK;
@@ -570,6 +606,8 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   P->g.loss_a = P->loss_a;
   P->g.pose_x = P->d_pose_x.p;
   P->g.pose_c = P->d_pose_c.p;
+  rc = prepare_clusters(P, P->opt.pcg_cluster_poses);
+  if (rc) return rc;
   if (P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY) {
     const auto t_sym = Clock::now();
     rc = prepare_direct(P);
@@ -971,6 +1009,7 @@ void pgo_solver_options_init(pgo_solver_options* o) {
   o->min_linear_solver_iterations = 0;
   o->max_num_consecutive_invalid_steps = 5;
   o->cg_batch = 0;
+  o->pcg_cluster_poses = 1;
   o->function_tolerance = 1e-6;
   o->gradient_tolerance = 1e-10;
   o->parameter_tolerance = 1e-8;
@@ -1188,6 +1227,8 @@ int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const do
   rc = fill_scale_one(P);
   if (rc) return rc;
   const size_t m = (size_t)6 * P->g.N;
+  rc = prepare_clusters(P, options->pcg_cluster_poses);
+  if (rc) return rc;
   pgo::launch_linearize(P->g, s);
   HIP_TRY(hipMemcpyAsync(P->g.d2, d2, m * sizeof(double), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(P->g.grad, b, m * sizeof(double), hipMemcpyHostToDevice, s));  // rhs = scale(=1) * grad

@@ -235,10 +235,12 @@ def sphere_layers(n_spheres=10, rings=50, per_ring=50, radius=50.0, seed=2026093
     return PoseGraphData(init, ia, ib, meas, np.repeat(L, len(ia), axis=0), truth=truth, name="sphere_layers_%d_%d" % (n, len(ia)))
 
 
-def graph_from_candidates(poses, candidates, seed=20260929, sigma_t=0.05, sigma_r=0.01, smooth=True):
+def graph_from_candidates(poses, candidates, seed=20260929, sigma_t=0.05, sigma_r=0.01, init="trajectory"):
     """SURVEY.md §8d C3 (KITTI-00 dense): every id in Edge_Candidates_index.txt becomes an edge
     (id_begin = line key, id_end = candidate id); measurements synthesised from the given trajectory
-    taken as ground truth + noise; initial guess = dead reckoning of the noisy odometry edges."""
+    taken as ground truth + noise.  Initial guess: the given trajectory itself (init="trajectory", what the
+    reference starts from: the poses of trajectory_origin.txt) or dead reckoning of the noisy odometry edges."""
+    init_mode = init
     rng = np.random.default_rng(seed)
     truth = np.array(poses, dtype=np.float64)
     truth[:, 3:] /= np.linalg.norm(truth[:, 3:], axis=1, keepdims=True)
@@ -255,7 +257,7 @@ def graph_from_candidates(poses, candidates, seed=20260929, sigma_t=0.05, sigma_
     odo = np.where(ia - ib == 1)[0]
     order = odo[np.argsort(ia[odo])]
     init = truth.copy()
-    if len(order) == len(truth) - 1:
+    if init_mode == "dead_reckoning" and len(order) == len(truth) - 1:
         init = _dead_reckon(truth[0], meas[order])
     return PoseGraphData(init, ia, ib, meas, None, truth=truth, name="candidates_%d_%d" % (len(truth), len(ia)))
 

@@ -199,3 +199,29 @@ def test_api_misuse_reports_errors(gpu):
         p.add_se3_between([1], [1], np.zeros((1, 7)))       # self edge
     with pytest.raises(gpu.PgoError):
         p.set_loss(gpu.HUBER, -1.0)
+
+
+@pytest.mark.parametrize("cluster", [2, 4])
+def test_cluster_jacobi_pcg_matches_oracle(gpu, O, ds, cluster):
+    """Cluster-Jacobi preconditioner (12x12 / 24x24 chain blocks): same iterates and iteration counts as the
+    oracle's PCG with the same blocks; the exact solution is unchanged."""
+    g = ds.manhattan_se3(301, 1100, seed=12)          # 301: the last cluster is partial
+    prob, poses, og = _pair(gpu, O, g)
+    rng = np.random.default_rng(1)
+    d2 = rng.uniform(0.01, 0.5, size=g.N * 6)
+    b = rng.normal(size=g.N * 6)
+    b[:6] = 0.0
+    x, it = prob.linear_solve(d2, b, gpu.SolverOptions(linear_solver_type=gpu.BLOCK_JACOBI_PCG, eta=0.1, pcg_cluster_poses=cluster))
+    xo, ito = O.linear_solve(og, d2, b, linear_solver=100 + cluster, q_tol=0.1, max_it=500)
+    assert it == ito
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    x1, it1 = prob.linear_solve(d2, b, gpu.SolverOptions(linear_solver_type=gpu.BLOCK_JACOBI_PCG, eta=0.1, pcg_cluster_poses=1))
+    assert it <= it1
+    # LM with the cluster preconditioner follows the oracle's LM with the same preconditioner
+    opt = gpu.SolverOptions(max_num_iterations=25, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=cluster)
+    s = gpu.solve(opt, prob)
+    op, osum, otr = O.solve(og, O.default_options(max_num_iterations=25, linear_solver=1, pcg_cluster=cluster))
+    n = min(len(s.iterations), len(otr), 10)
+    assert list(s.iterations["linear_solver_iterations"][:n]) == [int(v) for v in otr[:n, 7]]
+    assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-7)
+    assert s.final_cost == pytest.approx(osum.final_cost, rel=1e-5)
