@@ -418,66 +418,99 @@ __global__ void k_cost(DeviceGraph g, const double* poses, double* part) {
 // Materialising evaluation (the Problem::Evaluate analogue): per edge r (6), J_begin, J_end (6x6
 // row-major, local tangent columns [dp|dtheta]) with the loss corrector and constant masks applied.
 // ------------------------------------------------------------------------------------------------
+// Writes a [count][W] row-major matrix whose rows were produced one per lane: staged through LDS (row stride 37
+// doubles: conflict-free 8-byte writes) so that the global stores are 16 B per lane, contiguous across the wave.
+template <int W>
+__device__ __forceinline__ void store_rows_coalesced(double* lds_w, double* out, int e0, int count, int lane) {
+  __syncthreads();
+  double2* dst = reinterpret_cast<double2*>(out + (size_t)e0 * W);
+  const int n2 = count * W / 2;
+  for (int i = lane; i < n2; i += 64) {
+    const int d0 = 2 * i, el = d0 / W, kk = d0 - el * W;
+    dst[i] = double2{lds_w[el * 37 + kk], lds_w[el * 37 + kk + 1]};
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(128) void k_evaluate_edges(DeviceGraph g, const double* poses, double* res, double* ja, double* jb) {
+  __shared__ double stage[2][64 * 37];
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= g.E) return;
-  const int a = g.edge_a[e], b = g.edge_b[e];
-  const PoseRec A = load_pose(poses, a), B = load_pose(poses, b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* lds_w = stage[wave];
+  const int e0 = blockIdx.x * blockDim.x + wave * 64;
+  const int count = max(0, min(64, g.E - e0));
+  const bool live = e < g.E;
   const size_t E = (size_t)g.E;
-  const V3 mp{g.emeas[e], g.emeas[E + e], g.emeas[2 * E + e]};
-  const Q4 mq{g.emeas[3 * E + e], g.emeas[4 * E + e], g.emeas[5 * E + e], g.emeas[6 * E + e]};
-  const EdgeGeom eg = edge_geometry(A.p, A.q, B.p, B.q, mp, mq);
-  double Aa[36], Ab[36];
+  double r[6] = {0, 0, 0, 0, 0, 0}, sc = 1.0;
+  double L[36], Aa[36], Ab[36];
+  uint8_t ma = 0, mb = 0;
 #pragma unroll
-  for (int k = 0; k < 36; ++k) { Aa[k] = 0.0; Ab[k] = 0.0; }
+  for (int k = 0; k < 36; ++k) { Aa[k] = 0.0; Ab[k] = 0.0; L[k] = (k % 7 == 0) ? 1.0 : 0.0; }
+  if (live) {
+    const int a = g.edge_a[e], b = g.edge_b[e];
+    const PoseRec A = load_pose(poses, a), B = load_pose(poses, b);
+    const V3 mp{g.emeas[e], g.emeas[E + e], g.emeas[2 * E + e]};
+    const Q4 mq{g.emeas[3 * E + e], g.emeas[4 * E + e], g.emeas[5 * E + e], g.emeas[6 * E + e]};
+    const EdgeGeom eg = edge_geometry(A.p, A.q, B.p, B.q, mp, mq);
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      Aa[6 * i + j] = -eg.Rt.m[3 * i + j];
-      Aa[6 * i + 3 + j] = eg.G.m[3 * i + j];
-      Aa[6 * (3 + i) + 3 + j] = 2.0 * eg.M.m[3 * i + j];
-      Ab[6 * i + j] = eg.Rt.m[3 * i + j];
-      Ab[6 * (3 + i) + 3 + j] = -2.0 * eg.M.m[3 * i + j];
+      for (int j = 0; j < 3; ++j) {
+        Aa[6 * i + j] = -eg.Rt.m[3 * i + j];
+        Aa[6 * i + 3 + j] = eg.G.m[3 * i + j];
+        Aa[6 * (3 + i) + 3 + j] = 2.0 * eg.M.m[3 * i + j];
+        Ab[6 * i + j] = eg.Rt.m[3 * i + j];
+        Ab[6 * (3 + i) + 3 + j] = -2.0 * eg.M.m[3 * i + j];
+      }
+    if (g.eL) {
+#pragma unroll
+      for (int k = 0; k < 36; ++k) L[k] = g.eL[(size_t)k * E + e];
     }
-  double L[36];
-  if (g.eL) {
+    double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < 36; ++k) L[k] = g.eL[(size_t)k * E + e];
-  } else {
+    for (int i = 0; i < 6; ++i) {
+      double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < 36; ++k) L[k] = (k % 7 == 0) ? 1.0 : 0.0;
+      for (int j = 0; j < 6; ++j) t += L[6 * i + j] * eg.e[j];
+      r[i] = t;
+      s += t * t;
+    }
+    double rho0, rho1;
+    loss_eval(g.loss_kind, g.loss_a, s, &rho0, &rho1);
+    sc = sqrt(rho1);
+    ma = g.cmask[a];
+    mb = g.cmask[b];
   }
-  double r[6], s = 0.0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    double t = 0.0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) t += L[6 * i + j] * eg.e[j];
-    r[i] = t;
-    s += t * t;
-  }
-  double rho0, rho1;
-  loss_eval(g.loss_kind, g.loss_a, s, &rho0, &rho1);
-  const double sc = sqrt(rho1);
-  const uint8_t ma = g.cmask[a], mb = g.cmask[b];
   if (res) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) res[6 * (size_t)e + i] = sc * r[i];
+    for (int i = 0; i < 6; ++i) lds_w[lane * 37 + i] = sc * r[i];
+    store_rows_coalesced<6>(lds_w, res, e0, count, lane);
   }
-  if (ja || jb) {
+  if (ja) {
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        double ta = 0.0, tb = 0.0;
+        double ta = 0.0;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { ta += L[6 * i + j] * Aa[6 * j + c]; tb += L[6 * i + j] * Ab[6 * j + c]; }
+        for (int j = 0; j < 6; ++j) ta += L[6 * i + j] * Aa[6 * j + c];
         const bool ca = (c < 3) ? (ma & 1) : (ma & 2);
-        const bool cb = (c < 3) ? (mb & 1) : (mb & 2);
-        if (ja) ja[36 * (size_t)e + 6 * i + c] = ca ? 0.0 : sc * ta;
-        if (jb) jb[36 * (size_t)e + 6 * i + c] = cb ? 0.0 : sc * tb;
+        lds_w[lane * 37 + 6 * i + c] = ca ? 0.0 : sc * ta;
       }
+    store_rows_coalesced<36>(lds_w, ja, e0, count, lane);
+  }
+  if (jb) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double tb = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) tb += L[6 * i + j] * Ab[6 * j + c];
+        const bool cb = (c < 3) ? (mb & 1) : (mb & 2);
+        lds_w[lane * 37 + 6 * i + c] = cb ? 0.0 : sc * tb;
+      }
+    store_rows_coalesced<36>(lds_w, jb, e0, count, lane);
   }
 }
 

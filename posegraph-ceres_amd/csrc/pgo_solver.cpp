@@ -436,9 +436,16 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch) {
 }
 
 // Batch schedule: the kernels stop on their own, but an over-long batch still pays ~2.6 us per early-exit
-// launch and an under-long one pays a host sync (~25 us), so batches start small and grow: 16, 32, 64, 64...
-int pick_batch(const pgo::CgParams& prm, int user_batch, int round) {
-  int batch = user_batch > 0 ? user_batch : std::min(64, 16 << std::min(round, 2));
+// launch and an under-long one pays a host sync (~25 us), so batches start small and grow: 6, 12, 24, 48, 64...
+int pick_batch(const pgo::CgParams& prm, int user_batch, int round, int last_iterations = 0) {
+  static const int env_b0 = getenv("PGO_CG_BATCH0") ? atoi(getenv("PGO_CG_BATCH0")) : 0;
+  static const int env_adapt = getenv("PGO_CG_ADAPT") ? atoi(getenv("PGO_CG_ADAPT")) : 0;
+  int b0 = env_b0 > 0 ? env_b0 : 6;   // measured on C2: 4..8 is the flat optimum (early-exit launches cost ~2.6 us each)
+  if (env_adapt && round == 0 && last_iterations > 0) {
+    // the previous solve is a fair predictor for the easy (late) LM iterations: cover it with some slack
+    b0 = std::max(8, std::min(64, (last_iterations + last_iterations / 2 + 7) / 8 * 8));
+  }
+  int batch = user_batch > 0 ? user_batch : std::min(64, b0 << std::min(round, 4));
   batch = std::max(1, std::min(batch, prm.max_iterations));
   return (batch + 1) & ~1;  // even: every batch starts at an odd iteration (kernels take the parity at launch)
 }
@@ -708,7 +715,7 @@ int lm_advance(pgo_problem* P) {
     rc = run_direct(P);
   } else {
     pgo::launch_pcg_init(P->g, s);
-    rc = launch_cg_batch(P, prm, pick_batch(prm, o.cg_batch, 0));
+    rc = launch_cg_batch(P, prm, pick_batch(prm, o.cg_batch, 0, P->last_cg_iterations));
   }
   if (rc) return rc;
   for (int round = 1;; ++round) {
