@@ -209,7 +209,17 @@ int pgo_time_kernel(pgo_problem* problem, const char* kernel, int repeats, doubl
 int pgo_shard_range(long long n, int rank, int world, long long* begin, long long* end);
 /* 128-byte RCCL unique id created on rank 0 and handed to every rank by the launcher */
 int pgo_comm_get_unique_id(unsigned char id[128]);
+/* Attaches rank `rank` of `world` to the problem BEFORE the first solve/evaluate.  Every rank must hold the same problem
+ * (same poses, same edges in the same order); rank r then owns a contiguous range of pose rows, evaluates every edge
+ * incident to them, and the ranks exchange one all-gather per CG iteration (q = A p and the p'q partials), one per
+ * accepted LM step (J'J diagonal blocks, J'r) and one per LM iteration for cluster preconditioners.  All ranks take
+ * identical decisions from identical scalars, so no other coordination is needed. */
 int pgo_comm_init(pgo_problem* problem, const unsigned char id[128], int rank, int world);
+/* Test transport: `world` virtual ranks = problems driven by host threads of ONE process on one GPU, segments exchanged
+ * by device-to-device copies.  Lets the sharded path be validated on a single-GPU machine. */
+void* pgo_loopback_create(int world);
+void pgo_loopback_destroy(void* group);
+int pgo_comm_init_loopback(pgo_problem* problem, void* group, int rank);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ C_ABI_SYMBOLS = [
     "pgo_solver_options_init", "pgo_solve", "pgo_summary_is_solution_usable", "pgo_summary_full_report",
     "pgo_evaluate", "pgo_normal_equations", "pgo_linear_solve", "pgo_plus", "pgo_solver_begin",
     "pgo_solver_step", "pgo_solver_reset", "pgo_solver_end", "pgo_time_kernel", "pgo_shard_range",
-    "pgo_comm_get_unique_id", "pgo_comm_init",
+    "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_loopback_create", "pgo_loopback_destroy", "pgo_comm_init_loopback",
 ]
 
 
@@ -136,6 +136,21 @@ def shard_range(n, rank, world):
     b, e = C.c_longlong(0), C.c_longlong(0)
     _check(lib().pgo_shard_range(C.c_longlong(n), C.c_int(rank), C.c_int(world), C.byref(b), C.byref(e)))
     return b.value, e.value
+
+
+def comm_unique_id():
+    buf = (C.c_ubyte * 128)()
+    _check(lib().pgo_comm_get_unique_id(buf))
+    return bytes(buf)
+
+
+def loopback_create(world):
+    lib().pgo_loopback_create.restype = C.c_void_p
+    return lib().pgo_loopback_create(C.c_int(world))
+
+
+def loopback_destroy(group):
+    lib().pgo_loopback_destroy(C.c_void_p(group))
 
 
 def _dp(a):
@@ -295,6 +310,14 @@ class Problem:
         _check(lib().pgo_solver_end(self._h, C.byref(s), rec, C.c_int(records_capacity)))
         n = min(s.num_iterations, records_capacity)
         return Summary(s, np.frombuffer(bytes(rec), dtype=RECORD_DTYPE)[:n].copy())
+
+    # ---- one process per GPU (or virtual ranks for tests) ----
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        _check(lib().pgo_comm_init(self._h, buf, C.c_int(rank), C.c_int(world)))
+
+    def comm_init_loopback(self, group, rank):
+        _check(lib().pgo_comm_init_loopback(self._h, C.c_void_p(group), C.c_int(rank)))
 
     def time_kernel(self, name, repeats=100):
         ms = C.c_double(0)

@@ -1,0 +1,45 @@
+// pgo_comm.h — the one collective of the sharded path: an in-place all-gather of equal segments of doubles
+// (rank r contributes buf[r*seg .. (r+1)*seg)).  Two transports:
+//   * RcclComm     : ncclAllGather over RCCL/xGMI, one process per GPU (production)
+//   * LoopbackComm : several "virtual ranks" = pgo_problem instances driven by host threads of ONE process on one
+//                    GPU; segments are exchanged with device-to-device copies ordered by events.  It exists so that
+//                    the sharding logic can be tested on a single-GPU box; it is not capturable into a hipGraph.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#include <condition_variable>
+#include <mutex>
+#include <vector>
+
+namespace pgo {
+
+struct Comm {
+  int world = 1, rank = 0;
+  virtual ~Comm() {}
+  // returns hipSuccess-like 0 or a negative value; `what` receives a static description on failure
+  virtual int all_gather(double* buf, size_t seg_doubles, hipStream_t s, const char** what) = 0;
+  virtual bool capturable() const = 0;
+};
+
+struct LoopbackGroup {
+  explicit LoopbackGroup(int n) : world(n), bufs(n, nullptr), ready(n, nullptr), done(n, nullptr) {}
+  int world;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  long long generation = 0;
+  std::vector<double*> bufs;
+  std::vector<hipEvent_t> ready, done, garbage;
+  ~LoopbackGroup() { for (hipEvent_t e : garbage) (void)hipEventDestroy(e); }
+  bool aborted = false;
+  bool barrier();   // false once any rank has failed
+  void abort();
+};
+
+Comm* make_loopback_comm(LoopbackGroup* group, int rank);
+// RCCL: id is the 128-byte ncclUniqueId created by rccl_unique_id() on rank 0
+int rccl_unique_id(unsigned char id[128], const char** what);
+Comm* make_rccl_comm(const unsigned char id[128], int rank, int world, const char** what);
+
+}  // namespace pgo

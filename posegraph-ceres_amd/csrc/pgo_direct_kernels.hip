@@ -291,3 +291,41 @@ void launch_direct_solve(const DeviceGraph& g, const DirectPlan& p, const int* l
 }
 
 }  // namespace pgo
+
+// ---- development stress test of the exchange transports (tools/comm_stress.py) ----
+#include "pgo_comm.h"
+namespace pgo {
+namespace {
+__global__ void k_stress_fill(double* buf, size_t seg, int rank, int it) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < seg) buf[(size_t)rank * seg + i] = 1000.0 * it + 10.0 * rank + (double)(i % 7);
+}
+__global__ void k_stress_check(const double* buf, size_t seg, int world, int it, int* bad) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= seg * world) return;
+  const int r = (int)(i / seg);
+  const double want = 1000.0 * it + 10.0 * r + (double)((i - (size_t)r * seg) % 7);
+  if (buf[i] != want) atomicAdd(bad, 1);
+}
+}  // namespace
+int comm_stress(Comm* c, int iters, size_t seg, hipStream_t s, int* mismatches) {
+  double* buf = nullptr;
+  int* bad = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&buf), c->world * seg * sizeof(double)) != hipSuccess) return -1;
+  if (hipMalloc(reinterpret_cast<void**>(&bad), sizeof(int)) != hipSuccess) return -1;
+  (void)hipMemsetAsync(bad, 0, sizeof(int), s);
+  (void)hipMemsetAsync(buf, 0, c->world * seg * sizeof(double), s);
+  const char* what = "";
+  for (int it = 0; it < iters; ++it) {
+    hipLaunchKernelGGL(k_stress_fill, dim3((seg + 255) / 256), dim3(256), 0, s, buf, seg, c->rank, it);
+    if (c->all_gather(buf, seg, s, &what) != 0) return -2;
+    hipLaunchKernelGGL(k_stress_check, dim3((seg * c->world + 255) / 256), dim3(256), 0, s, buf, seg, c->world, it, bad);
+    if ((it & 63) == 63) (void)hipStreamSynchronize(s);
+  }
+  (void)hipStreamSynchronize(s);
+  (void)hipMemcpy(mismatches, bad, sizeof(int), hipMemcpyDeviceToHost);
+  (void)hipFree(buf);
+  (void)hipFree(bad);
+  return 0;
+}
+}  // namespace pgo

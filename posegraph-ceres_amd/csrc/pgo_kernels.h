@@ -38,6 +38,7 @@ struct CgState {
   int cnt_a;       // iteration index published by the SpMV kernel for the update kernel
   int cnt_b;       // iterations completed, published by the update kernel for the next SpMV
   int pad[3];
+  double beta;     // beta of the current iteration, published by the SpMV kernel (the update kernel rebuilds p with it)
 };
 
 struct DeviceGraph {
@@ -81,14 +82,13 @@ struct DeviceGraph {
   double* cg_x;       // [6N]
   double* cg_r;       // [6N]
   double* cg_z;       // [6N]
-  double* cg_q;       // [6N]
+  double* cg_q;       // exchange buffer [world][seg]: q = A p of the owned rows + p'q partials (q_index())
   double* cg_p0;      // [6N] p ping
   double* cg_p1;      // [6N] p pong
   double* delta;      // [6N] tangent step actually applied (S * step)
   // partial sums
   double* part_rz;    // [2][n_part]
   double* part_q;     // [2][n_part]
-  double* part_pq;    // [n_part]
   double* part_rr;    // [2][n_part]  |r|^2
   double* part_bb;    // [n_part]     |b|^2 (written by pcg_init)
   double* part_misc;  // [8][n_part] scratch partials for LM scalars
@@ -100,6 +100,8 @@ struct DeviceGraph {
   LmScalars* scal;    // device-visible pinned host memory
   int* flags;         // [4] device flags: [0] linearize saw non-finite
   int debug;          // development ablation switches (0 in production)
+  // one process per GPU: contiguous row ownership (all rows when world == 1)
+  int world, rank, rows_per, row_lo, row_hi, pq_cap, seg;
   int cluster;        // poses per Jacobi block of the preconditioner: 1 (6x6), 2 (12x12) or 4 (24x24)
   const int* cl_ptr;  // [n_clusters+1] BSR slots whose row AND column lie inside the cluster (off-diagonal ones)
   const int* cl_slot;
@@ -126,8 +128,9 @@ void launch_gradient_norm(const DeviceGraph& g, hipStream_t s);
 void launch_finalize_scalars(const DeviceGraph& g, int n_cost_part, hipStream_t s);
 void launch_apply_step(const DeviceGraph& g, const double* step, hipStream_t s);     // for tests: delta -> candidate
 void launch_spmv_plain(const DeviceGraph& g, hipStream_t s);
-void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, hipStream_t s);
-void launch_pcg_update_only(const DeviceGraph& g, hipStream_t s);
+void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s);
+void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s);
+void launch_model_delta_and_retract(const DeviceGraph& g, hipStream_t s);
 void launch_debug(const DeviceGraph& g, int which, hipStream_t s);
 int vec_block();
 int pose_block();

@@ -87,6 +87,17 @@ __device__ __forceinline__ double partial_sum(const double* p, int n) {
   return s;
 }
 
+// Index of component k of pose `row` in the exchange buffer g.cg_q.  Each rank owns `rows_per` consecutive poses and
+// a segment of `seg` doubles: [rows_per*6 entries of q = A p][pq_cap partial sums of p'q].  With one rank this is 6*row+k.
+__device__ __forceinline__ size_t q_index(const DeviceGraph& g, int row, int k) {
+  const int rk = row / g.rows_per;
+  return (size_t)rk * g.seg + (size_t)(row - rk * g.rows_per) * 6 + k;
+}
+__device__ __forceinline__ size_t q_index_flat(const DeviceGraph& g, int idx) {   // idx = 6*row + k
+  const int row = idx / 6;
+  return q_index(g, row, idx - 6 * row);
+}
+
 struct PoseRec { V3 p; Q4 q; };
 __device__ __forceinline__ PoseRec load_pose(const double* poses, int v) {
   const double2* s = reinterpret_cast<const double2*>(poses + (size_t)POSE_STRIDE * v);
@@ -316,9 +327,11 @@ __global__ void k_damping(DeviceGraph g, double radius, double min_diag, double 
     }
     A[7 * i] += d2;
   }
-  const int slot = g.row_slot_begin[v];
+  if (g.row_slot_cnt[v] > 0) {   // rows owned by this rank (all rows with one rank)
+    const int slot = g.row_slot_begin[v];
 #pragma unroll
-  for (int k = 0; k < 36; ++k) g.bsr_val[bsr_index(slot, k)] = A[k];
+    for (int k = 0; k < 36; ++k) g.bsr_val[bsr_index(slot, k)] = A[k];
+  }
   if (g.cluster > 1) return;  // the cluster preconditioner kernel builds M^-1
   double Ai[36];
   if (!spd6_inverse(A, Ai)) atomicOr(&g.flags[1], 1);
@@ -335,7 +348,7 @@ template <int CL>
 __global__ __launch_bounds__(64) void k_cluster_precond(DeviceGraph g) {
   constexpr int DIM = 6 * CL, LD = DIM + 1;
   __shared__ double A[DIM * LD];
-  const int c = blockIdx.x, lane = threadIdx.x;
+  const int c = g.row_lo / CL + blockIdx.x, lane = threadIdx.x;   // clusters of the rows this rank owns
   const int v0 = c * CL;
   for (int e = lane; e < DIM * LD; e += 64) A[e] = 0.0;
   __syncthreads();
@@ -349,7 +362,7 @@ __global__ __launch_bounds__(64) void k_cluster_precond(DeviceGraph g) {
     }
   }
   __syncthreads();
-  for (int s = g.cl_ptr[c]; s < g.cl_ptr[c + 1]; ++s) {   // in-cluster off-diagonal blocks, serial over slots
+  for (int s = g.cl_ptr[blockIdx.x]; s < g.cl_ptr[blockIdx.x + 1]; ++s) {   // in-cluster off-diagonal blocks, serial over slots
     const int slot = g.cl_slot[s];
     const int ro = 6 * (g.slot_row[slot] - v0), co = 6 * (g.slot_col[slot] - v0);
     if (lane < 36) {
@@ -728,7 +741,7 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
       if (j < se) s0 += lds[j * SPMV_LDS_STRIDE + k];
       const double s = s0 + s1;
       if (single) {
-        g.cg_q[6 * (size_t)rw + k] = s;
+        g.cg_q[q_index(g, rw, k)] = s;
         if (MODE == 0) pq[0] += s * lds_p[idx];
       } else {
         acc += s;
@@ -737,14 +750,14 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
     __syncthreads();
   }
   if (!single && tid < 6) {
-    g.cg_q[6 * (size_t)r0 + tid] = acc;
+    g.cg_q[q_index(g, r0, tid)] = acc;
     if (MODE == 0) pq[0] += acc * lds_p[tid];
   }
   if (MODE == 0) {
     block_sum<1>(pq, scratch);
     if (tid == 0) {
-      g.part_pq[wg] = pq[0];
-      if (wg == 0) g.cg->cnt_a = it;
+      g.cg_q[(size_t)g.rank * g.seg + (size_t)g.rows_per * 6 + wg] = pq[0];   // p'q partial rides in the exchange segment
+      if (wg == 0) { g.cg->cnt_a = it; g.cg->beta = beta; }
     }
   }
 }
@@ -760,23 +773,32 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd
   // ---- independent loads ----
   int idx = blockIdx.x * VEC_BLOCK + tid;
   bool live = idx < m;
-  const double* p = odd ? g.cg_p1 : g.cg_p0;
-  double x0 = 0, pa = 0, r0 = 0, q0 = 0, b0 = 0;
+  // p of this iteration: the SpMV kernel wrote it for the rows this rank owns; with several ranks the vector update
+  // is replicated over ALL rows, so p = z + beta p_old is rebuilt here from the (replicated) previous vectors.
+  const bool rebuild_p = g.world > 1;
+  double* p = odd ? g.cg_p1 : g.cg_p0;
+  const double* p_prev = odd ? g.cg_p0 : g.cg_p1;
+  double x0 = 0, pa = 0, zo = 0, r0 = 0, q0 = 0, b0 = 0;
   double2 mi[DIM / 2];
 #pragma unroll
   for (int k = 0; k < DIM / 2; ++k) mi[k] = double2{0, 0};
   if (live) {
-    x0 = g.cg_x[idx]; pa = p[idx]; r0 = g.cg_r[idx]; q0 = g.cg_q[idx]; b0 = g.cg_b[idx];
+    x0 = g.cg_x[idx]; r0 = g.cg_r[idx]; q0 = g.cg_q[q_index_flat(g, idx)]; b0 = g.cg_b[idx];
+    if (rebuild_p) { pa = p_prev[idx]; zo = g.cg_z[idx]; } else { pa = p[idx]; }
     const double2* Mi = reinterpret_cast<const double2*>(g.Minv + (size_t)idx * DIM);   // row (idx mod DIM) of cluster idx / DIM
 #pragma unroll
     for (int k = 0; k < DIM / 2; ++k) mi[k] = Mi[k];
   }
   const int done = g.cg->done;
   const int it = g.cg->cnt_a;
+  const double beta = g.cg->beta;   // NOT re-derived here: this kernel overwrites the partial row rho_{it-1} lives in
   double sums[2] = {0, 0};
   const double* rz_cur = g.part_rz + (size_t)(odd ? 0 : g.n_part);
   for (int i = tid; i < g.n_vec_wg; i += VEC_BLOCK) sums[0] += rz_cur[i];
-  for (int i = tid; i < g.n_wg; i += VEC_BLOCK) sums[1] += g.part_pq[i];
+  for (int i = tid; i < g.world * g.pq_cap; i += VEC_BLOCK) {   // unused partial slots stay zero
+    const int rk = i / g.pq_cap;
+    sums[1] += g.cg_q[(size_t)rk * g.seg + (size_t)g.rows_per * 6 + (i - rk * g.pq_cap)];
+  }
   if (done) return;
   block_sum<2>(sums, scratch);
   const double rho = sums[0], pq = sums[1];
@@ -792,7 +814,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd
       idx = base + tid;
       live = idx < m;
       if (live) {
-        x0 = g.cg_x[idx]; pa = p[idx]; r0 = g.cg_r[idx]; q0 = g.cg_q[idx]; b0 = g.cg_b[idx];
+        x0 = g.cg_x[idx]; r0 = g.cg_r[idx]; q0 = g.cg_q[q_index_flat(g, idx)]; b0 = g.cg_b[idx];
+        if (rebuild_p) { pa = p_prev[idx]; zo = g.cg_z[idx]; } else { pa = p[idx]; }
         const double2* Mi = reinterpret_cast<const double2*>(g.Minv + (size_t)idx * DIM);
 #pragma unroll
         for (int k = 0; k < DIM / 2; ++k) mi[k] = Mi[k];
@@ -800,6 +823,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd
     }
     double x = 0.0, r = 0.0;
     if (live) {
+      if (rebuild_p) { pa = zo + beta * pa; p[idx] = pa; }
       x = x0 + alpha * pa;
       r = r0 - alpha * q0;
       g.cg_x[idx] = x;
@@ -866,7 +890,7 @@ __global__ void k_model_delta(DeviceGraph g) {
   double acc[1] = {0.0};
   for (int idx = blockIdx.x * VEC_BLOCK + threadIdx.x; idx < 6 * g.N; idx += gridDim.x * VEC_BLOCK) {
     const double x = g.cg_x[idx];
-    const double hx = g.cg_q[idx] - g.d2[idx] * x;
+    const double hx = g.cg_q[q_index_flat(g, idx)] - g.d2[idx] * x;
     const int v = idx / 6, i = idx - 6 * v;
     const bool c = (i < 3) ? (g.cmask[v] & 1) : (g.cmask[v] & 2);
     acc[0] += c ? 0.0 : (x * g.cg_b[idx] - 0.5 * x * hx);
@@ -970,7 +994,7 @@ __global__ void k_finalize_scalars(DeviceGraph g, int n_cost_part) {
 __global__ void k_empty(DeviceGraph g) {}
 __global__ void k_touch(DeviceGraph g) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < 6 * g.N) g.cg_q[idx] = g.cg_z[idx] + 1.0;
+  if (idx < 6 * g.N) g.cg_r[idx] = g.cg_z[idx] + 1.0;
 }
 __global__ void k_copy_delta(DeviceGraph g, const double* step) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -994,8 +1018,9 @@ void launch_scale_from_diag(const DeviceGraph& g, hipStream_t s) {
 }
 void launch_damping(const DeviceGraph& g, double radius, double min_diag, double max_diag, int mode, hipStream_t s) {
   hipLaunchKernelGGL(k_damping, dim3(cdiv(g.N, 64)), dim3(64), 0, s, g, radius, min_diag, max_diag, mode);
-  if (g.cluster == 2) hipLaunchKernelGGL(k_cluster_precond<2>, dim3(cdiv(g.N, 2)), dim3(64), 0, s, g);
-  else if (g.cluster == 4) hipLaunchKernelGGL(k_cluster_precond<4>, dim3(cdiv(g.N, 4)), dim3(64), 0, s, g);
+  const int owned = g.row_hi - g.row_lo;
+  if (g.cluster == 2 && owned > 0) hipLaunchKernelGGL(k_cluster_precond<2>, dim3(cdiv(owned, 2)), dim3(64), 0, s, g);
+  else if (g.cluster == 4 && owned > 0) hipLaunchKernelGGL(k_cluster_precond<4>, dim3(cdiv(owned, 4)), dim3(64), 0, s, g);
 }
 void launch_cost(const DeviceGraph& g, const double* poses, int part_row, hipStream_t s) {
   double* part = g.part_misc + (size_t)part_row * g.n_part;
@@ -1035,12 +1060,16 @@ void launch_spmv_plain(const DeviceGraph& g, hipStream_t s) {
   CgParams dummy{0.0, -1.0, 0, 0};
   hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1);
 }
-void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, hipStream_t s) {
+void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s) {
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
-  hipLaunchKernelGGL(k_spmv<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, p, 1);
+  hipLaunchKernelGGL(k_spmv<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, p, odd);
 }
-void launch_pcg_update_only(const DeviceGraph& g, hipStream_t s) {
-  launch_update(g, 1, s);
+void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s) {
+  launch_update(g, odd, s);
+}
+void launch_model_delta_and_retract(const DeviceGraph& g, hipStream_t s) {
+  hipLaunchKernelGGL(k_model_delta, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
+  hipLaunchKernelGGL(k_retract, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g);
 }
 void launch_gradient_norm(const DeviceGraph& g, hipStream_t s) {
   hipLaunchKernelGGL(k_gradient_norm, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g);

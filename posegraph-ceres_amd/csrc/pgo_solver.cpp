@@ -11,6 +11,9 @@
 #include "../../include/pgo.h"
 #include "pgo_kernels.h"
 #include "pgo_direct.h"
+#include "pgo_comm.h"
+
+namespace pgo { int comm_stress(Comm* c, int iters, size_t seg, hipStream_t s, int* mismatches); }
 
 #include <algorithm>
 #include <chrono>
@@ -137,11 +140,15 @@ struct pgo_problem {
   DevBuf<int> d_cl_ptr, d_cl_slot;
   int cluster_built = 0;
 
+  // one process per GPU: the communicator of the row-sharded path (null = single rank)
+  pgo::Comm* comm = nullptr;
+
   pgo_solver_options opt{};
   LmState lm;
 
   ~pgo_problem() {
     drop_graph();
+    delete comm;
     if (scal) (void)hipHostFree(scal);
     if (stream_ready) (void)hipStreamDestroy(stream);
   }
@@ -183,6 +190,48 @@ int ensure_device(pgo_problem* P) {
   return PGO_OK;
 }
 
+// In-place all-gather of equal segments (rank r owns buf[r*seg, (r+1)*seg)); no-op with a single rank.
+int exchange(pgo_problem* P, double* buf, size_t seg_doubles) {
+  static const bool force = getenv("PGO_FORCE_EXCHANGE") && getenv("PGO_FORCE_EXCHANGE")[0] == '1';   // exercise the transport at world 1
+  if (!P->comm || (P->comm->world <= 1 && !force)) return PGO_OK;
+  const char* what = "";
+  if (P->comm->all_gather(buf, seg_doubles, P->stream, &what) != 0) return set_error(PGO_ERR_HIP, "all-gather failed: %s", what);
+  return PGO_OK;
+}
+
+// linearise the owned rows, then make J'J diagonal blocks and J'r of ALL rows available on every rank
+int linearize_all(pgo_problem* P) {
+  pgo::launch_linearize(P->g, P->stream);
+  int rc = exchange(P, P->g.Hdiag, (size_t)36 * P->g.rows_per);
+  if (rc) return rc;
+  return exchange(P, P->g.grad, (size_t)6 * P->g.rows_per);
+}
+
+// LM damping + preconditioner.  6x6 blocks are rebuilt on every rank from the gathered diagonal; cluster blocks need
+// the in-cluster off-diagonal blocks, which only the owner holds, so their inverses are exchanged.
+int damping_all(pgo_problem* P, double radius, double min_diag, double max_diag, int mode) {
+  pgo::launch_damping(P->g, radius, min_diag, max_diag, mode, P->stream);
+  if (P->g.cluster > 1) return exchange(P, P->g.Minv, (size_t)36 * P->g.cluster * P->g.rows_per);
+  return PGO_OK;
+}
+
+// one CG iteration: SpMV on the owned rows, exchange of q (+ p'q partials), replicated vector update
+int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd) {
+  pgo::launch_pcg_spmv_only(P->g, prm, odd, P->stream);
+  int rc = exchange(P, P->g.cg_q, (size_t)P->g.seg);
+  if (rc) return rc;
+  pgo::launch_pcg_update_only(P->g, odd, P->stream);
+  return PGO_OK;
+}
+
+int model_and_retract_all(pgo_problem* P) {
+  pgo::launch_spmv_plain(P->g, P->stream);
+  int rc = exchange(P, P->g.cg_q, (size_t)P->g.seg);
+  if (rc) return rc;
+  pgo::launch_model_delta_and_retract(P->g, P->stream);
+  return PGO_OK;
+}
+
 int choose_block(long long total_slots) {
   if (total_slots >= 256LL * 512) return 256;
   if (total_slots >= 128LL * 384) return 128;
@@ -204,45 +253,59 @@ int prepare(pgo_problem* P) {
   for (int e = 0; e < E; ++e) { ++deg[P->ia[e]]; ++deg[P->ib[e]]; }
   long long total = 0;
   for (int v = 0; v < N; ++v) total += 1 + deg[v];
-  const int B = choose_block(total);
 
-  // rows -> workgroups
-  std::vector<int> wg_row_begin, wg_slot_begin, row_slot_begin(N), row_slot_cnt(N);
+  // ---- row ownership: rank r owns the poses [r*rows_per, (r+1)*rows_per); cut edges are evaluated by
+  // the owners of both endpoints.  rows_per is a multiple of 4 so that preconditioner clusters never straddle ranks.
+  const int world = P->comm ? P->comm->world : 1, rank = P->comm ? P->comm->rank : 0;
+  int rows_per = (N + world - 1) / world;
+  rows_per = std::max(4, (rows_per + 3) / 4 * 4);
+  const int row_lo = std::min(N, rank * rows_per), row_hi = std::min(N, (rank + 1) * rows_per);
+  const int NP = world * rows_per;   // padded pose count of every replicated / exchanged array
+  const int B = choose_block(total / world);
+
+  // rows -> workgroups (greedy packing of `block` slots; a row with more incidences gets its own multi-chunk group)
+  std::vector<int> wg_row_begin, wg_slot_begin, row_slot_begin(N, 0), row_slot_cnt(N, 0);
   long long slot = 0;
-  int cur = 0;
-  wg_row_begin.push_back(0);
-  wg_slot_begin.push_back(0);
-  auto close_wg = [&](int next_row) {
-    slot = (slot + B - 1) / B * B;
-    wg_row_begin.push_back(next_row);
-    wg_slot_begin.push_back((int)slot);
-    cur = 0;
-  };
-  for (int v = 0; v < N; ++v) {
-    const int c = 1 + deg[v];
-    if (c > B) {
-      if (cur > 0) close_wg(v);
-      row_slot_begin[v] = (int)slot;
-      row_slot_cnt[v] = c;
-      slot += c;
-      close_wg(v + 1);
-      continue;
+  auto pack = [&](int lo, int hi, bool record) -> int {
+    long long sl = 0;
+    int cur = 0, n = 0;
+    if (record) { wg_row_begin.assign(1, lo); wg_slot_begin.assign(1, 0); }
+    auto close_wg = [&](int next_row) {
+      sl = (sl + B - 1) / B * B;
+      ++n;
+      if (record) { wg_row_begin.push_back(next_row); wg_slot_begin.push_back((int)sl); }
+      cur = 0;
+    };
+    for (int v = lo; v < hi; ++v) {
+      const int c = 1 + deg[v];
+      if (c > B) {
+        if (cur > 0) close_wg(v);
+        if (record) { row_slot_begin[v] = (int)sl; row_slot_cnt[v] = c; }
+        sl += c;
+        close_wg(v + 1);
+        continue;
+      }
+      if (cur + c > B) close_wg(v);
+      if (record) { row_slot_begin[v] = (int)sl; row_slot_cnt[v] = c; }
+      sl += c;
+      cur += c;
     }
-    if (cur + c > B) close_wg(v);
-    row_slot_begin[v] = (int)slot;
-    row_slot_cnt[v] = c;
-    slot += c;
-    cur += c;
-  }
-  if (cur > 0) close_wg(N);
+    if (cur > 0) close_wg(hi);
+    if (n == 0) { sl += B; close_wg(hi); }   // a rank without rows still launches one (empty) workgroup
+    if (record) slot = sl;
+    return n;
+  };
+  int pq_cap = 1;
+  for (int r = 0; r < world; ++r) pq_cap = std::max(pq_cap, pack(std::min(N, r * rows_per), std::min(N, (r + 1) * rows_per), false));
+  const int n_wg = pack(row_lo, row_hi, true);
   if (slot > 0x7fffffffLL - 1024) return set_error(PGO_ERR_UNSUPPORTED, "graph too large for 32-bit slot indices");
-  const int n_wg = (int)wg_row_begin.size() - 1;
   const int n_slots = (int)slot;
+  const int seg = rows_per * 6 + pq_cap;
 
-  // slots: diagonal first, then the row's incidences in edge order
-  std::vector<int> slot_col(n_slots, -1), slot_row(n_slots, 0), slot_edge(n_slots, -1), fill(N);
+  // slots: diagonal first, then the row's incidences in edge order (owned rows only)
+  std::vector<int> slot_col(n_slots, -1), slot_row(n_slots, 0), slot_edge(n_slots, -1), fill(N, 0);
   std::vector<uint8_t> slot_side(n_slots, pgo::SIDE_PAD);
-  for (int v = 0; v < N; ++v) {
+  for (int v = row_lo; v < row_hi; ++v) {
     const int sb = row_slot_begin[v];
     slot_col[sb] = v; slot_row[sb] = v; slot_side[sb] = pgo::SIDE_DIAG;
     fill[v] = sb + 1;
@@ -250,15 +313,19 @@ int prepare(pgo_problem* P) {
   P->edge_begin_slot.assign(E, -1);
   for (int e = 0; e < E; ++e) {
     const int a = P->ia[e], b = P->ib[e];
-    int t = fill[a]++;
-    slot_col[t] = b; slot_row[t] = a; slot_side[t] = pgo::SIDE_BEGIN; slot_edge[t] = e;
-    P->edge_begin_slot[e] = t;
-    t = fill[b]++;
-    slot_col[t] = a; slot_row[t] = b; slot_side[t] = pgo::SIDE_END; slot_edge[t] = e;
+    if (a >= row_lo && a < row_hi) {
+      const int t = fill[a]++;
+      slot_col[t] = b; slot_row[t] = a; slot_side[t] = pgo::SIDE_BEGIN; slot_edge[t] = e;
+      P->edge_begin_slot[e] = t;
+    }
+    if (b >= row_lo && b < row_hi) {
+      const int t = fill[b]++;
+      slot_col[t] = a; slot_row[t] = b; slot_side[t] = pgo::SIDE_END; slot_edge[t] = e;
+    }
   }
   // pad slots keep a valid row index so that loads stay in range
   for (int w = 0; w < n_wg; ++w) {
-    const int r = std::min(wg_row_begin[w], N - 1);
+    const int r = std::max(0, std::min(wg_row_begin[w], N - 1));
     for (int t = wg_slot_begin[w]; t < wg_slot_begin[w + 1]; ++t) if (slot_side[t] == pgo::SIDE_PAD) slot_row[t] = r;
   }
 
@@ -310,25 +377,28 @@ int prepare(pgo_problem* P) {
   HIP_TRY(P->d_eW.upload(eW, s));
   HIP_TRY(P->d_eL.upload(eL, s));
 
-  const size_t m = (size_t)6 * N;
+  const size_t m = (size_t)6 * NP;
   HIP_TRY(P->d_pose_x.alloc((size_t)pgo::POSE_STRIDE * N));
   HIP_TRY(P->d_pose_c.alloc((size_t)pgo::POSE_STRIDE * N));
   HIP_TRY(P->d_pose_0.alloc((size_t)pgo::POSE_STRIDE * N));
   HIP_TRY(P->d_bsr.alloc((size_t)n_slots * 36));
   HIP_TRY(P->d_bsr.zero(s));
-  HIP_TRY(P->d_Hdiag.alloc((size_t)36 * N));
-  HIP_TRY(P->d_Minv.alloc((size_t)36 * N));
+  HIP_TRY(P->d_Hdiag.alloc((size_t)36 * NP));
+  HIP_TRY(P->d_Hdiag.zero(s));
+  HIP_TRY(P->d_Minv.alloc((size_t)36 * NP));
+  HIP_TRY(P->d_Minv.zero(s));
   DevBuf<double>* vecs[] = {&P->d_grad, &P->d_scale, &P->d_d2, &P->d_diagc, &P->d_cg_b, &P->d_cg_x, &P->d_cg_r,
-                            &P->d_cg_z, &P->d_cg_q, &P->d_cg_p0, &P->d_cg_p1, &P->d_delta};
+                            &P->d_cg_z, &P->d_cg_p0, &P->d_cg_p1, &P->d_delta};
   for (DevBuf<double>* b : vecs) { HIP_TRY(b->alloc(m)); HIP_TRY(b->zero(s)); }
-  const int n_vec_wg = std::max(1, std::min((int)((m + pgo::vec_block() - 1) / pgo::vec_block()), 128));
+  HIP_TRY(P->d_cg_q.alloc((size_t)world * seg));   // exchange buffer: q segments + p'q partials (unused partial slots stay 0)
+  HIP_TRY(P->d_cg_q.zero(s));
+  const int n_vec_wg = std::max(1, std::min((int)(((size_t)6 * N + pgo::vec_block() - 1) / pgo::vec_block()), 128));
   const int n_edge_wg = std::max(1, (E + pgo::edge_block() - 1) / pgo::edge_block());
   const int n_pose_wg = (N + pgo::pose_block() - 1) / pgo::pose_block();
   const int n_part = std::max(std::max(n_wg, n_vec_wg), std::max(n_edge_wg, n_pose_wg));
   HIP_TRY(P->d_part_rz.alloc((size_t)2 * n_part));
   HIP_TRY(P->d_part_q.alloc((size_t)2 * n_part));
   HIP_TRY(P->d_part_rr.alloc((size_t)2 * n_part));
-  HIP_TRY(P->d_part_pq.alloc((size_t)n_part));
   HIP_TRY(P->d_part_bb.alloc((size_t)n_part));
   HIP_TRY(P->d_part_misc.alloc((size_t)8 * n_part));
   HIP_TRY(P->d_part_misc.zero(s));
@@ -339,6 +409,8 @@ int prepare(pgo_problem* P) {
 
   pgo::DeviceGraph& g = P->g;
   g.N = N; g.E = E; g.n_wg = n_wg; g.n_slots = n_slots; g.block = B;
+  g.world = world; g.rank = rank; g.rows_per = rows_per; g.row_lo = row_lo; g.row_hi = row_hi; g.pq_cap = pq_cap; g.seg = seg;
+  if (P->comm && !P->comm->capturable()) P->use_graph = false;
   g.info_mode = P->has_info ? 1 : 0;
   g.loss_kind = P->loss_kind; g.loss_a = P->loss_a;
   g.slot_col = P->d_slot_col.p; g.slot_row = P->d_slot_row.p; g.slot_side = P->d_slot_side.p;
@@ -350,7 +422,7 @@ int prepare(pgo_problem* P) {
   g.Minv = P->d_Minv.p; g.grad = P->d_grad.p; g.scale = P->d_scale.p; g.d2 = P->d_d2.p;
   g.diag_clamped = P->d_diagc.p; g.cg_b = P->d_cg_b.p; g.cg_x = P->d_cg_x.p; g.cg_r = P->d_cg_r.p;
   g.cg_z = P->d_cg_z.p; g.cg_q = P->d_cg_q.p; g.cg_p0 = P->d_cg_p0.p; g.cg_p1 = P->d_cg_p1.p;
-  g.delta = P->d_delta.p; g.part_rz = P->d_part_rz.p; g.part_q = P->d_part_q.p; g.part_pq = P->d_part_pq.p;
+  g.delta = P->d_delta.p; g.part_rz = P->d_part_rz.p; g.part_q = P->d_part_q.p;
   g.part_rr = P->d_part_rr.p; g.part_bb = P->d_part_bb.p; g.part_misc = P->d_part_misc.p;
   g.n_part = n_part; g.n_vec_wg = n_vec_wg; g.n_edge_wg = n_edge_wg; g.n_pose_wg = n_pose_wg;
   g.cg = P->d_cg.p; g.flags = P->d_flags.p;
@@ -410,7 +482,8 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch) {
       pgo_problem::CapturedBatch cb;
       hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
       if (e == hipSuccess) {
-        for (int i = 0; i < batch; ++i) pgo::launch_pcg_iteration(P->g, prm, (i & 1) ^ 1, s);
+        int rc_it = PGO_OK;
+        for (int i = 0; i < batch && rc_it == PGO_OK; ++i) rc_it = cg_iteration(P, prm, (i & 1) ^ 1);
         pgo::launch_pcg_finish(P->g, prm, s);
         e = hipStreamEndCapture(s, &cb.graph);
         if (e == hipSuccess) e = hipGraphInstantiate(&cb.exec, cb.graph, nullptr, nullptr, 0);
@@ -430,7 +503,7 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch) {
       return PGO_OK;
     }
   }
-  for (int i = 0; i < batch; ++i) pgo::launch_pcg_iteration(P->g, prm, (i & 1) ^ 1, s);
+  for (int i = 0; i < batch; ++i) { int rc = cg_iteration(P, prm, (i & 1) ^ 1); if (rc) return rc; }
   pgo::launch_pcg_finish(P->g, prm, s);
   return PGO_OK;
 }
@@ -471,9 +544,10 @@ int prepare_clusters(pgo_problem* P, int CL) {
   if (CL != 2 && CL != 4) CL = 1;
   if (P->cluster_built == CL) { P->g.cluster = CL; return PGO_OK; }
   P->drop_graph();  // captured CG batches hold the DeviceGraph by value
-  const int N = P->g.N;
   if (CL > 1) {
-    const int ncl = (N + CL - 1) / CL;
+    // clusters of the rows this rank owns (row_lo is a multiple of 4); indices local to the rank
+    const int c0 = P->g.row_lo / CL;
+    const int ncl = std::max(1, (P->g.row_hi - P->g.row_lo + CL - 1) / CL);
     std::vector<int> ptr(ncl + 1, 0), slots;
     for (int pass = 0; pass < 2; ++pass) {
       std::vector<int> fill(ptr.begin(), ptr.end() - 1);
@@ -481,15 +555,15 @@ int prepare_clusters(pgo_problem* P, int CL) {
         if (P->h_slot_side[t] > pgo::SIDE_END) continue;
         const int r = P->h_slot_row[t], c = P->h_slot_col[t];
         if (r / CL != c / CL) continue;
-        if (pass == 0) ++ptr[r / CL + 1]; else slots[fill[r / CL]++] = t;
+        if (pass == 0) ++ptr[r / CL - c0 + 1]; else slots[fill[r / CL - c0]++] = t;
       }
       if (pass == 0) { for (int k = 0; k < ncl; ++k) ptr[k + 1] += ptr[k]; slots.resize(ptr[ncl]); }
     }
     HIP_TRY(P->d_cl_ptr.upload(ptr, P->stream));
     HIP_TRY(P->d_cl_slot.upload(slots, P->stream));
     if (slots.empty()) HIP_TRY(P->d_cl_slot.alloc(1));
-    const size_t need = (size_t)ncl * 36 * CL * CL;
-    if (P->d_Minv.n < need) HIP_TRY(P->d_Minv.alloc(need));
+    const size_t need = (size_t)P->g.world * P->g.rows_per * 36 * CL;   // every rank's clusters, padded
+    if (P->d_Minv.n < need) { HIP_TRY(P->d_Minv.alloc(need)); HIP_TRY(P->d_Minv.zero(P->stream)); }
     P->g.Minv = P->d_Minv.p;
     P->g.cl_ptr = P->d_cl_ptr.p;
     P->g.cl_slot = P->d_cl_slot.p;
@@ -506,6 +580,7 @@ int prepare_direct(pgo_problem* P) {
   P->direct_usable = false;
   const char* off = getenv("PGO_NO_DIRECT");
   if (off && off[0] == '1') return PGO_OK;
+  if (P->comm && P->comm->world > 1) return PGO_OK;   // the factorisation needs every row: sharded runs use PCG to 1e-13
   pgo::DirectSymbolic& S = P->dsym;
   if (!pgo::direct_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side,
                            P->h_row_slot_begin, &S))
@@ -587,13 +662,16 @@ int evaluate_gradient_and_jacobian(pgo_problem* P, bool first) {
   if (first) {
     int rc = fill_scale_one(P);
     if (rc) return rc;
-    pgo::launch_linearize(P->g, s);
+    rc = linearize_all(P);
+    if (rc) return rc;
     if (P->opt.jacobi_scaling) {
       pgo::launch_scale_from_diag(P->g, s);
-      pgo::launch_linearize(P->g, s);
+      rc = linearize_all(P);
+      if (rc) return rc;
     }
   } else {
-    pgo::launch_linearize(P->g, s);
+    int rc = linearize_all(P);
+    if (rc) return rc;
   }
   pgo::launch_gradient_norm(P->g, s);
   P->lm.t_jacobian += seconds_since(t0);
@@ -706,9 +784,9 @@ int lm_advance(pgo_problem* P) {
   // the (cheap) tail is re-enqueued.
   const auto t_lin = Clock::now();
   const pgo::CgParams prm = cg_params_for(o);
-  pgo::launch_damping(P->g, L.radius, o.min_lm_diagonal, o.max_lm_diagonal, L.reuse_diagonal ? 1 : 0, s);
+  int rc = damping_all(P, L.radius, o.min_lm_diagonal, o.max_lm_diagonal, L.reuse_diagonal ? 1 : 0);
+  if (rc) return rc;
   const bool direct = o.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY && P->direct_usable;
-  int rc;
   if (direct) {
     P->scal->cg_status = 0;       // host-visible block: the CG kernels that normally fill these do not run
     P->scal->cg_iterations = 0;
@@ -720,7 +798,8 @@ int lm_advance(pgo_problem* P) {
   if (rc) return rc;
   for (int round = 1;; ++round) {
     // the tail is enqueued speculatively behind the first batch; later batches sync first
-    pgo::launch_model_and_retract(P->g, s);
+    rc = model_and_retract_all(P);
+    if (rc) return rc;
     pgo::launch_cost(P->g, P->g.pose_c, 0, s);
     pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s);
     HIP_TRY(hipStreamSynchronize(s));
@@ -1183,7 +1262,8 @@ int pgo_evaluate(pgo_problem* P, double* cost, double* residuals, double* jac_be
   if (gradient) {
     rc = fill_scale_one(P);
     if (rc) return rc;
-    pgo::launch_linearize(P->g, s);
+    rc = linearize_all(P);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(gradient, P->g.grad, sizeof(double) * 6 * N, hipMemcpyDeviceToHost, s));
   }
   HIP_TRY(hipStreamSynchronize(s));
@@ -1203,7 +1283,8 @@ int pgo_normal_equations(pgo_problem* P, double* diag, double* offdiag, double* 
   if (rc) return rc;
   rc = fill_scale_one(P);
   if (rc) return rc;
-  pgo::launch_linearize(P->g, s);
+  rc = linearize_all(P);
+  if (rc) return rc;
   const int N = P->g.N, E = P->g.E;
   if (diag) HIP_TRY(hipMemcpyAsync(diag, P->g.Hdiag, sizeof(double) * 36 * N, hipMemcpyDeviceToHost, s));
   if (gradient) HIP_TRY(hipMemcpyAsync(gradient, P->g.grad, sizeof(double) * 6 * N, hipMemcpyDeviceToHost, s));
@@ -1236,11 +1317,13 @@ int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const do
   const size_t m = (size_t)6 * P->g.N;
   rc = prepare_clusters(P, options->pcg_cluster_poses);
   if (rc) return rc;
-  pgo::launch_linearize(P->g, s);
+  rc = linearize_all(P);
+  if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(P->g.d2, d2, m * sizeof(double), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(P->g.grad, b, m * sizeof(double), hipMemcpyHostToDevice, s));  // rhs = scale(=1) * grad
   HIP_TRY(hipStreamSynchronize(s));
-  pgo::launch_damping(P->g, 1.0, 0.0, 0.0, 2, s);
+  rc = damping_all(P, 1.0, 0.0, 0.0, 2);
+  if (rc) return rc;
   int it = 0, status = 0;
   if (options->linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY) {
     rc = prepare_direct(P);
@@ -1298,14 +1381,14 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     pgo::launch_damping(P->g, P->lm.radius, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, 0, s);
     pgo::launch_pcg_init(P->g, s);
   }
-  if (k == "pcg_update") pgo::launch_pcg_spmv_only(P->g, prm, s);
+  if (k == "pcg_update") pgo::launch_pcg_spmv_only(P->g, prm, 1, s);
   auto once = [&]() -> int {
     if (k == "linearize") pgo::launch_linearize(P->g, s);
     else if (k == "cost") pgo::launch_cost(P->g, P->g.pose_x, 5, s);
     else if (k == "evaluate") pgo::launch_evaluate_edges(P->g, P->g.pose_x, P->d_tmp_a.p, P->d_tmp_b.p, P->d_tmp_c.p, s);
     else if (k == "spmv") pgo::launch_spmv_plain(P->g, s);
-    else if (k == "pcg_spmv") pgo::launch_pcg_spmv_only(P->g, prm, s);
-    else if (k == "pcg_update") pgo::launch_pcg_update_only(P->g, s);
+    else if (k == "pcg_spmv") pgo::launch_pcg_spmv_only(P->g, prm, 1, s);
+    else if (k == "pcg_update") pgo::launch_pcg_update_only(P->g, 1, s);
     else if (k == "pcg_iteration") pgo::launch_pcg_iteration(P->g, prm, 1, s);
     else if (k == "empty") pgo::launch_debug(P->g, 0, s);
     else if (k == "touch") pgo::launch_debug(P->g, 1, s);
@@ -1365,12 +1448,44 @@ int pgo_shard_range(long long n, int rank, int world, long long* begin, long lon
 }
 
 int pgo_comm_get_unique_id(unsigned char id[128]) {
-  (void)id;
-  return set_error(PGO_ERR_UNSUPPORTED, "RCCL sharding is not wired in this build");
+  if (!id) return set_error(PGO_ERR_INVALID_ARGUMENT, "null id");
+  const char* what = "";
+  if (pgo::rccl_unique_id(id, &what) != 0) return set_error(PGO_ERR_HIP, "ncclGetUniqueId failed: %s", what);
+  return PGO_OK;
 }
-int pgo_comm_init(pgo_problem* problem, const unsigned char id[128], int rank, int world) {
-  (void)problem; (void)id; (void)rank; (void)world;
-  return set_error(PGO_ERR_UNSUPPORTED, "RCCL sharding is not wired in this build");
+
+static int attach_comm(pgo_problem* P, pgo::Comm* c) {
+  delete P->comm;
+  P->comm = c;
+  P->topo_dirty = true;   // ownership changes the slot topology
+  return PGO_OK;
+}
+
+int pgo_comm_init(pgo_problem* P, const unsigned char id[128], int rank, int world) {
+  if (!P || !id || world < 1 || rank < 0 || rank >= world) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_comm_init");
+  int rc = ensure_device(P);
+  if (rc) return rc;
+  const char* what = "";
+  pgo::Comm* c = pgo::make_rccl_comm(id, rank, world, &what);
+  if (!c) return set_error(PGO_ERR_HIP, "ncclCommInitRank failed: %s", what);
+  return attach_comm(P, c);
+}
+
+// development hook (not part of include/pgo.h): stress the attached transport, returns mismatching words
+int pgo_debug_comm_stress(pgo_problem* P, int iters, int seg_doubles) {
+  if (!P || !P->comm) return -1;
+  if (ensure_device(P)) return -1;
+  int bad = -1;
+  if (pgo::comm_stress(P->comm, iters, (size_t)seg_doubles, P->stream, &bad) != 0) return -2;
+  return bad;
+}
+
+void* pgo_loopback_create(int world) { return world >= 1 ? new (std::nothrow) pgo::LoopbackGroup(world) : nullptr; }
+void pgo_loopback_destroy(void* group) { delete static_cast<pgo::LoopbackGroup*>(group); }
+int pgo_comm_init_loopback(pgo_problem* P, void* group, int rank) {
+  pgo::LoopbackGroup* g = static_cast<pgo::LoopbackGroup*>(group);
+  if (!P || !g || rank < 0 || rank >= g->world) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_comm_init_loopback");
+  return attach_comm(P, pgo::make_loopback_comm(g, rank));
 }
 
 }  // extern "C"
