@@ -50,7 +50,7 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    use_dist = world > 1
+    use_dist = world > 1 or os.environ.get("PGO_BENCH_FORCE_DIST", "0") == "1"   # the latter: exercise the N>1 code path on one GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -65,10 +65,21 @@ def main():
     pkg.build()
     pkg.set_device(local_rank)
 
-    # every rank owns one graph of the same size (weak scaling; see DESIGN.md §8 for the sharded variant)
-    g = ds.manhattan_se3(args.poses, args.edges, seed=SEED + rank)
+    # Weak scaling: ONE graph of world x (poses, edges), identical on every rank (same seed); rank r owns a contiguous
+    # share of the pose rows and the ranks exchange one RCCL all-gather per CG iteration.
+    # PGO_BENCH_REPLICAS=1 runs one independent graph per GPU instead (no data-path collective).
+    replicas = os.environ.get("PGO_BENCH_REPLICAS", "0") == "1"
+    sharded = use_dist and not replicas
+    if sharded:
+        g = ds.manhattan_se3(args.poses * world, args.edges * world, seed=SEED)
+    else:
+        g = ds.manhattan_se3(args.poses, args.edges, seed=SEED + rank)
     N, E = g.N, g.E
     prob, poses = pkg.problem_from_graph(g)
+    if sharded:
+        box = [pkg.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        prob.comm_init(box[0], rank, world)
     opt = pkg.SolverOptions(max_num_iterations=2 ** 30, linear_solver_type=pkg.BLOCK_JACOBI_PCG, eta=0.1,
                             max_linear_solver_iterations=500, function_tolerance=0.0, parameter_tolerance=0.0,
                             gradient_tolerance=0.0, pcg_cluster_poses=args.cluster)
@@ -151,7 +162,7 @@ def main():
                                   "evaluate_edges": round(t_eval * 1e3, 3)}
     summary = prob.solver_end()
     # the same K steps with plain 6x6 pose-block Jacobi (Ceres JACOBI-like), for transparency
-    if rank == 0 and args.cluster != 1:
+    if rank == 0 and args.cluster != 1 and world == 1:
         opt.pcg_cluster_poses = 1
         poses[:] = g.poses          # solver_end wrote the optimised poses back: restart from dead reckoning
         prob.solver_begin(opt)
@@ -194,18 +205,21 @@ def main():
         extra["cpu_jacobian_eval_edges_per_sec"] = round(E / (O.time_jacobian_eval(og, 10) / 10), 1)
 
     if rank == 0:
-        total_edges = E * world
+        total_edges = E if sharded else E * world
         value = total_edges * args.steps / elapsed
         out = {
             "metric": "lm_edge_iterations_per_sec", "value": round(value, 1), "unit": "edge-LM-iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Synthetic Manhattan SE3 graph, %d poses / %d odom+loop edges per GPU, block-Jacobi PCG "
-                                   "(eta=0.1, <=500 it), Huber(1.0), LM from dead reckoning" % (N, E),
-                       "poses_per_gpu": N, "edges_per_gpu": E, "seed": SEED,
+                                   "(eta=0.1, <=500 it), Huber(1.0), LM from dead reckoning" % (args.poses, args.edges),
+                       "poses_per_gpu": args.poses, "edges_per_gpu": args.edges, "total_poses": N if sharded or world == 1 else N * world,
+                       "total_edges": total_edges, "seed": SEED,
                        "preconditioner": "block-Jacobi, %d-pose chain clusters (%dx%d blocks)" % (args.cluster, 6 * args.cluster, 6 * args.cluster),
-                       "parallelism": "1 graph per GPU" if world > 1 else "single GPU"},
-            "lm_iters_per_sec": round(args.steps * world / elapsed, 2),
+                       "parallelism": ("single GPU" if world == 1 else
+                                       "one graph row-sharded over %d ranks, 1 RCCL all-gather per CG iteration" % world if sharded else
+                                       "replicas: 1 independent graph per GPU, no data-path collective")},
+            "lm_iters_per_sec": round(args.steps * (1 if sharded else world) / elapsed, 2),
             "cg_iterations_in_solver_state": summary.num_linear_solver_iterations,
             "final_cost": summary.final_cost, "resets": resets,
             "roofline": roofline, "cpu_baseline": cpu,

@@ -1,0 +1,58 @@
+"""-m gpu: BASELINE.json's full-size configurations through size-independent properties (the oracle still finishes
+in seconds for one evaluation sweep, not for a solve): cost/gradient agreement, descent, determinism, constant pose."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big(ds):
+    return ds.manhattan_se3(100000, 1000000, seed=20260930, loop_radius=3.0)   # 100 k poses / 1 M edges
+
+
+def test_c4_cost_gradient_and_lm_descent(gpu, ds, O, big):
+    g = big
+    assert (g.N, g.E) == (100000, 1000000)
+    prob, poses = gpu.problem_from_graph(g)
+    cost, _, _, _, grad = prob.evaluate(residuals=False, jacobians=False, gradient=True)
+    og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
+    assert cost == pytest.approx(O.cost(og), rel=1e-11)
+    # gradient against the oracle on a random subset of edges' endpoints is expensive; use linearity instead:
+    # the directional derivative of the cost along d equals grad . d (central difference through Plus)
+    rng = np.random.default_rng(0)
+    d = rng.normal(size=(g.N, 6)) * 1e-6
+    d[0] = 0
+    base = poses.copy()
+    prob.plus(d)
+    cp = prob.evaluate(False, False, False)[0]
+    poses[:] = base
+    prob.plus(-d)
+    cm = prob.evaluate(False, False, False)[0]
+    poses[:] = base
+    assert (cp - cm) / 2 == pytest.approx(float((grad * d).sum()), rel=2e-5)
+    assert not grad[0].any()                                   # constant first pose
+    # a few LM iterations: monotone descent of accepted steps, bitwise reproducible, pose 0 untouched
+    opt = gpu.SolverOptions(max_num_iterations=4, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2)
+    s1 = gpu.solve(opt, prob)
+    acc = s1.iterations["cost"][s1.iterations["step_is_successful"] == 1]
+    assert len(acc) >= 2 and np.all(np.diff(acc) < 0)
+    assert np.array_equal(poses[0], g.poses[0])
+    prob2, poses2 = gpu.problem_from_graph(g)
+    s2 = gpu.solve(opt, prob2)
+    assert np.array_equal(poses, poses2) and s1.final_cost == s2.final_cost
+
+
+def test_c5_sphere_layers(gpu, ds, O):
+    """SURVEY C5 shape: 10 sphere2500-style layers, 25 k poses / 250 k edges (single GPU here)."""
+    g = ds.sphere_layers(n_spheres=10, rings=50, per_ring=50, n_edges=250000, seed=20260931)
+    assert (g.N, g.E) == (25000, 250000)
+    prob, poses = gpu.problem_from_graph(g)
+    cost = prob.evaluate(False, False, False)[0]
+    og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
+    assert cost == pytest.approx(O.cost(og), rel=1e-11)
+    s = gpu.solve(gpu.SolverOptions(max_num_iterations=6, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2), prob)
+    op, osum, otr = O.solve(og, O.default_options(max_num_iterations=6, linear_solver=1, pcg_cluster=2))
+    n = min(len(s.iterations), len(otr))
+    assert list(s.iterations["linear_solver_iterations"][:n]) == [int(v) for v in otr[:n, 7]]
+    assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-7)
