@@ -410,7 +410,10 @@ int prepare(pgo_problem* P) {
   pgo::DeviceGraph& g = P->g;
   g.N = N; g.E = E; g.n_wg = n_wg; g.n_slots = n_slots; g.block = B;
   g.world = world; g.rank = rank; g.rows_per = rows_per; g.row_lo = row_lo; g.row_hi = row_hi; g.pq_cap = pq_cap; g.seg = seg;
-  if (P->comm && !P->comm->capturable()) P->use_graph = false;
+  // Several ranks: RCCL collectives are enqueued eagerly by default (capturing them into the CG batch graph is only
+  // validated at world size 1 on the development box; PGO_COMM_GRAPH=1 opts in).  The per-iteration cost is then
+  // dominated by the all-gather latency, not by launch overhead.
+  if (P->comm && (!P->comm->capturable() || (world > 1 && !(getenv("PGO_COMM_GRAPH") && getenv("PGO_COMM_GRAPH")[0] == '1')))) P->use_graph = false;
   g.info_mode = P->has_info ? 1 : 0;
   g.loss_kind = P->loss_kind; g.loss_a = P->loss_a;
   g.slot_col = P->d_slot_col.p; g.slot_row = P->d_slot_row.p; g.slot_side = P->d_slot_side.p;
