@@ -32,5 +32,44 @@ class HuberLoss : public LossFunction {
  private:
   const double a_, b_;
 };
+class SoftLOneLoss : public LossFunction {
+ public:
+  explicit SoftLOneLoss(double a) : a_(a), b_(a * a), c_(1.0 / (a * a)) {}
+  virtual void Evaluate(double s, double rho[3]) const {
+    const double sum = 1.0 + s * c_, tmp = std::sqrt(sum);
+    rho[0] = 2.0 * b_ * (tmp - 1.0);
+    rho[1] = std::max(std::numeric_limits<double>::min(), 1.0 / tmp);
+    rho[2] = -(c_ * rho[1]) / (2.0 * sum);
+  }
+  double a() const { return a_; }
+ private:
+  const double a_, b_, c_;
+};
+class CauchyLoss : public LossFunction {
+ public:
+  explicit CauchyLoss(double a) : a_(a), b_(a * a), c_(1.0 / (a * a)) {}
+  virtual void Evaluate(double s, double rho[3]) const {
+    const double sum = 1.0 + s * c_, inv = 1.0 / sum;
+    rho[0] = b_ * std::log(sum);
+    rho[1] = std::max(std::numeric_limits<double>::min(), inv);
+    rho[2] = -c_ * (inv * inv);
+  }
+  double a() const { return a_; }
+ private:
+  const double a_, b_, c_;
+};
+class ArctanLoss : public LossFunction {
+ public:
+  explicit ArctanLoss(double a) : a_(a), b_(1.0 / (a * a)) {}
+  virtual void Evaluate(double s, double rho[3]) const {
+    const double sum = 1.0 + s * s * b_, inv = 1.0 / sum;
+    rho[0] = a_ * std::atan2(s, a_);
+    rho[1] = std::max(std::numeric_limits<double>::min(), inv);
+    rho[2] = -2.0 * s * b_ * (inv * inv);
+  }
+  double a() const { return a_; }
+ private:
+  const double a_, b_;
+};
 }  // namespace ceres
 #endif

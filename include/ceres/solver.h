@@ -304,8 +304,15 @@ inline void Solver::Solve(const Options& options, Problem* problem, Summary* sum
   if (!rbs.empty() && pgo_problem_add_se3_between_batch(P, (int)rbs.size(), &ia[0], &ib[0], &t_be[0], identity ? 0 : &sqrt_info[0]) < 0)
     return internal::Fail(summary, pgo_last_error());
   if (loss) {
-    if (const HuberLoss* h = dynamic_cast<const HuberLoss*>(loss)) { if (pgo_problem_set_loss(P, PGO_LOSS_HUBER, h->a()) < 0) return internal::Fail(summary, pgo_last_error()); }
-    else if (!dynamic_cast<const TrivialLoss*>(loss)) return internal::Fail(summary, "unsupported LossFunction (HuberLoss, TrivialLoss or NULL)");
+    int kind = -1;
+    double a = 1.0;
+    if (const HuberLoss* h = dynamic_cast<const HuberLoss*>(loss)) { kind = PGO_LOSS_HUBER; a = h->a(); }
+    else if (const SoftLOneLoss* h = dynamic_cast<const SoftLOneLoss*>(loss)) { kind = PGO_LOSS_SOFT_L_ONE; a = h->a(); }
+    else if (const CauchyLoss* h = dynamic_cast<const CauchyLoss*>(loss)) { kind = PGO_LOSS_CAUCHY; a = h->a(); }
+    else if (const ArctanLoss* h = dynamic_cast<const ArctanLoss*>(loss)) { kind = PGO_LOSS_ARCTAN; a = h->a(); }
+    else if (dynamic_cast<const TrivialLoss*>(loss)) kind = PGO_LOSS_TRIVIAL;
+    if (kind < 0) return internal::Fail(summary, "unsupported LossFunction (TrivialLoss, HuberLoss, SoftLOneLoss, CauchyLoss, ArctanLoss or NULL)");
+    if (kind != PGO_LOSS_TRIVIAL && pgo_problem_set_loss(P, kind, a) < 0) return internal::Fail(summary, pgo_last_error());
   }
   for (std::set<double*>::const_iterator it = problem->constant_blocks().begin(); it != problem->constant_blocks().end(); ++it)
     if (pgo_problem_set_parameter_block_constant(P, *it) < 0) { /* constant block that appears in no residual: nothing to do */ }

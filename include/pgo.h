@@ -38,7 +38,10 @@ typedef enum pgo_status {
 } pgo_status;
 
 /* ceres::LossFunction kinds (REF/test/pose_graph_ceres_plus_finial.cpp:495 uses HuberLoss(1.0)). */
-typedef enum pgo_loss_kind { PGO_LOSS_TRIVIAL = 0, PGO_LOSS_HUBER = 1 } pgo_loss_kind;
+typedef enum pgo_loss_kind {
+  PGO_LOSS_TRIVIAL = 0, PGO_LOSS_HUBER = 1,          /* the reference's */
+  PGO_LOSS_SOFT_L_ONE = 2, PGO_LOSS_CAUCHY = 3, PGO_LOSS_ARCTAN = 4   /* other Ceres 1.13 losses with rho'' <= 0 */
+} pgo_loss_kind;
 
 /* ceres::LinearSolverType values the path understands (finial.cpp:536 sets SPARSE_NORMAL_CHOLESKY). */
 typedef enum pgo_linear_solver {

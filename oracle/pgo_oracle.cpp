@@ -250,17 +250,37 @@ void edge_eval_analytic(const double* pa, const double* qa, const double* pb, co
   }
 }
 
-// ceres::HuberLoss::Evaluate [Ceres 1.13; SURVEY.md App. E @0xbccc0].  a<=0 means "no loss".
+// ceres::LossFunction::Evaluate restated for HuberLoss (kind 1; the reference's, SURVEY.md App. E @0xbccc0),
+// SoftLOneLoss (2), CauchyLoss (3), ArctanLoss (4) [Ceres 1.13 loss_function.cc]; kind 0 / a<=0 = trivial.
 void loss_eval(int kind, double a, double s, double rho[3]) {
+  const double tiny = std::numeric_limits<double>::min();
   if (kind == 1 && a > 0) {
     const double b = a * a;
     if (s > b) {
       const double r = std::sqrt(s);
       rho[0] = 2.0 * a * r - b;
-      rho[1] = std::max(std::numeric_limits<double>::min(), a / r);
+      rho[1] = std::max(tiny, a / r);
       rho[2] = -rho[1] / (2.0 * s);
       return;
     }
+  } else if (kind == 2 && a > 0) {
+    const double b = a * a, c = 1.0 / b, sum = 1.0 + s * c, tmp = std::sqrt(sum);
+    rho[0] = 2.0 * b * (tmp - 1.0);
+    rho[1] = std::max(tiny, 1.0 / tmp);
+    rho[2] = -(c * rho[1]) / (2.0 * sum);
+    return;
+  } else if (kind == 3 && a > 0) {
+    const double b = a * a, c = 1.0 / b, sum = 1.0 + s * c, inv = 1.0 / sum;
+    rho[0] = b * std::log(sum);
+    rho[1] = std::max(tiny, inv);
+    rho[2] = -c * (inv * inv);
+    return;
+  } else if (kind == 4 && a > 0) {
+    const double b = 1.0 / (a * a), sum = 1.0 + s * s * b, inv = 1.0 / sum;
+    rho[0] = a * std::atan2(s, a);
+    rho[1] = std::max(tiny, inv);
+    rho[2] = -2.0 * s * b * (inv * inv);
+    return;
   }
   rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
 }

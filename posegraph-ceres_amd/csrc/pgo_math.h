@@ -159,17 +159,35 @@ PGO_HD void edge_error(const V3& pa, const Q4& qa, const V3& pb, const Q4& qb, c
   e[5] = 2.0 * dq.z;
 }
 
-// ceres::HuberLoss(a) [Ceres 1.13; SURVEY.md A.4]: rho, rho'.  kind 0 = trivial loss.
+// ceres::LossFunction::Evaluate for the kinds of include/pgo.h [Ceres 1.13 definitions; SURVEY.md A.4]: rho, rho'.
+// Every kind here has rho'' <= 0, so Ceres' corrector reduces to scaling r and J by sqrt(rho') (alpha = 0 branch).
 PGO_HD void loss_eval(int kind, double a, double s, double* rho0, double* rho1) {
-  if (kind == 1) {
+  const double tiny = 2.2250738585072014e-308;
+  if (kind == 1) {                       // HuberLoss(a)
     const double b = a * a;
     if (s > b) {
       const double r = sqrt(s);
       *rho0 = 2.0 * a * r - b;
       const double q = a / r;
-      *rho1 = q > 2.2250738585072014e-308 ? q : 2.2250738585072014e-308;
+      *rho1 = q > tiny ? q : tiny;
       return;
     }
+  } else if (kind == 2) {                // SoftLOneLoss(a)
+    const double b = a * a, sum = 1.0 + s / b, tmp = sqrt(sum);
+    *rho0 = 2.0 * b * (tmp - 1.0);
+    const double q = 1.0 / tmp;
+    *rho1 = q > tiny ? q : tiny;
+    return;
+  } else if (kind == 3) {                // CauchyLoss(a)
+    const double b = a * a, sum = 1.0 + s / b, inv = 1.0 / sum;
+    *rho0 = b * log(sum);
+    *rho1 = inv > tiny ? inv : tiny;
+    return;
+  } else if (kind == 4) {                // ArctanLoss(a)
+    const double sum = 1.0 + s * s / (a * a), inv = 1.0 / sum;
+    *rho0 = a * atan2(s, a);
+    *rho1 = inv > tiny ? inv : tiny;
+    return;
   }
   *rho0 = s;
   *rho1 = 1.0;

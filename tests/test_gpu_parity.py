@@ -225,3 +225,21 @@ def test_cluster_jacobi_pcg_matches_oracle(gpu, O, ds, cluster):
     assert list(s.iterations["linear_solver_iterations"][:n]) == [int(v) for v in otr[:n, 7]]
     assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-7)
     assert s.final_cost == pytest.approx(osum.final_cost, rel=1e-5)
+
+
+@pytest.mark.parametrize("kind,a", [(2, 1.3), (3, 0.8), (4, 2.0)])
+def test_other_ceres_losses(gpu, O, ds, kind, a):
+    """SoftLOne / Cauchy / Arctan: evaluation and LM trace against the oracle."""
+    g = _random_graph(ds, 150, 600, seed=21, info="diag")
+    prob, poses, og = _pair(gpu, O, g, loss=kind, loss_a=a)
+    cost, r, ja, jb, grad = prob.evaluate()
+    ocost, orr, oja, ojb = O.evaluate(og, loss_kind=kind, loss_a=a)
+    assert cost == pytest.approx(ocost, rel=1e-12)
+    assert np.abs(r - orr).max() <= 1e-11 * max(1.0, np.abs(orr).max())
+    assert np.abs(ja - oja).max() <= 1e-11 * max(1.0, np.abs(oja).max())
+    g2 = ds.manhattan_se3(200, 700, seed=6)
+    prob2, poses2, og2 = _pair(gpu, O, g2, loss=kind, loss_a=a)
+    s = gpu.solve(gpu.SolverOptions(max_num_iterations=15, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY), prob2)
+    op, osum, otr = O.solve(og2, O.default_options(max_num_iterations=15, linear_solver=0, loss_kind=kind, loss_a=a))
+    n = min(len(s.iterations), len(otr), 8)
+    assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-7)
