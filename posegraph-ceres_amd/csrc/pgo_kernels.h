@@ -28,7 +28,7 @@ struct LmScalars {
   int cg_iterations;
   int cg_status;           // 0 ok, 1 p'q <= 0 (no further progress), 2 non-finite
   int linearize_bad;       // non-finite values seen while linearising
-  int pad;
+  int seq;                 // hand-off flag: cleared by the host, set last by the publishing kernel (host spins on it)
 };
 
 struct CgState {
@@ -118,19 +118,23 @@ struct CgParams {
 void launch_linearize(const DeviceGraph& g, hipStream_t s);
 void launch_scale_from_diag(const DeviceGraph& g, hipStream_t s);
 void launch_damping(const DeviceGraph& g, double radius, double min_diag, double max_diag, int mode, hipStream_t s);
-void launch_cost(const DeviceGraph& g, const double* poses, int part_row, hipStream_t s);
+void launch_cost(const DeviceGraph& g, const double* poses, int part_row, hipStream_t s, int gate = 0);
 void launch_evaluate_edges(const DeviceGraph& g, const double* poses, double* res, double* ja, double* jb, hipStream_t s);
 void launch_pcg_init(const DeviceGraph& g, hipStream_t s);
 void launch_pcg_iteration(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s);   // SpMV + update kernels of an odd/even iteration
-void launch_pcg_finish(const DeviceGraph& g, const CgParams& p, hipStream_t s);      // final termination bookkeeping
+void launch_pcg_finish(const DeviceGraph& g, const CgParams& p, hipStream_t s, int publish = 1);   // termination bookkeeping; publish: hand off to the host
 void launch_model_and_retract(const DeviceGraph& g, hipStream_t s);                  // A x, model change, delta, candidate
 void launch_gradient_norm(const DeviceGraph& g, hipStream_t s);
-void launch_finalize_scalars(const DeviceGraph& g, int n_cost_part, hipStream_t s);
+void launch_finalize_scalars(const DeviceGraph& g, int n_cost_part, hipStream_t s, int gate = 0);   // always hands off to the host
 void launch_apply_step(const DeviceGraph& g, const double* step, hipStream_t s);     // for tests: delta -> candidate
 void launch_spmv_plain(const DeviceGraph& g, hipStream_t s);
+// q = A x of the step tail.  finish: CG termination bookkeeping first, run only once the CG has stopped; candidates: the
+// diagonal lanes also write delta and the candidate poses (rows of this rank)
+void launch_spmv_tail(const DeviceGraph& g, const CgParams& p, hipStream_t s, int finish, int candidates);
+void launch_step_tail(const DeviceGraph& g, hipStream_t s, int gate);                  // fused model change / candidate / cost / scalar fold + hand-off
 void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s);
 void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s);
-void launch_model_delta_and_retract(const DeviceGraph& g, hipStream_t s);
+void launch_model_delta_and_retract(const DeviceGraph& g, hipStream_t s, int gate = 0);
 void launch_debug(const DeviceGraph& g, int which, hipStream_t s);
 int vec_block();
 int pose_block();

@@ -399,8 +399,9 @@ __global__ __launch_bounds__(64) void k_cluster_precond(DeviceGraph g) {
 // Cost only: 0.5 * sum rho(|L e|^2) over edges at `poses` (ComputeCandidatePointAndEvaluateCost).
 // ------------------------------------------------------------------------------------------------
 template <int INFO>
-__global__ void k_cost(DeviceGraph g, const double* poses, double* part) {
+__global__ void k_cost(DeviceGraph g, const double* poses, double* part, int gate) {
   __shared__ double scratch[8];
+  if (gate && !g.cg->done) return;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   double c[1] = {0.0};
   if (e < g.E) {
@@ -597,6 +598,34 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
   const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
   double* lds_p = lds + (size_t)SPMV_LDS_STRIDE * B;
 
+  if (MODE == 1 && (odd & 2)) {
+    // Step tail behind a CG batch: this kernel first does what k_pcg_finish does (every workgroup evaluates the stop test
+    // of the last completed iteration from the same partial rows, workgroup 0 publishes the state), and computes
+    // q = A x only once the CG has stopped.
+    int done = g.cg->done;
+    const int iters0 = g.cg->iters, status = g.cg->status;
+    const int it = done ? iters0 : g.cg->cnt_b;
+    double fs[4];
+    fs[0] = partial_sum(g.part_q + (size_t)(it & 1) * g.n_part, g.n_vec_wg);
+    fs[1] = partial_sum(g.part_q + (size_t)((it + 1) & 1) * g.n_part, g.n_vec_wg);
+    fs[2] = partial_sum(g.part_rr + (size_t)(it & 1) * g.n_part, g.n_vec_wg);
+    fs[3] = partial_sum(g.part_bb, g.n_vec_wg);
+    block_sum<4>(fs, scratch);
+    const int was_done = done;
+    if (!done && it >= 1) {
+      const double Q1 = -fs[0], Q0 = -fs[1];
+      const double zeta = it * (Q1 - Q0) / Q1;
+      if ((zeta < prm.q_tolerance && it >= prm.min_iterations) || it >= prm.max_iterations) done = 1;
+      if (prm.r_tolerance >= 0.0 && sqrt(fs[2]) <= prm.r_tolerance * sqrt(fs[3]) && it >= prm.min_iterations) done = 1;
+    }
+    if (wg == 0 && tid == 0) {
+      if (done && !was_done) { g.cg->iters = it; __threadfence(); g.cg->done = 1; }
+      g.scal->cg_iterations = it;
+      g.scal->cg_status = done ? status : -1;
+      g.scal->cg_residual_sq = fs[2];
+    }
+    if (!done) return;
+  }
   const int s_begin = g.wg_slot_begin[wg], s_end = g.wg_slot_begin[wg + 1];
   const int r0 = g.wg_row_begin[wg], nrows = g.wg_row_begin[wg + 1] - r0;
   const bool single = (s_end - s_begin) == B;
@@ -705,6 +734,27 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
       for (int k = 0; k < 3; ++k) {
         x[2 * k] = (MODE == 0) ? gz[k].x + beta * gp[k].x : gz[k].x;
         x[2 * k + 1] = (MODE == 0) ? gz[k].y + beta * gp[k].y : gz[k].y;
+      }
+      if (MODE == 1 && (odd & 4) && side == SIDE_DIAG && cb == s_begin) {
+        // step tail: delta = -S x and the candidate Plus(x, delta) of this row (k_retract's job, one launch fewer)
+        const PoseRec P = load_pose(g.pose_x, row);
+        const uint8_t m = g.cmask[row];
+        double d[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const bool c = (i < 3) ? (m & 1) : (m & 2);
+          d[i] = c ? 0.0 : -g.scale[6 * (size_t)row + i] * x[i];
+          g.delta[6 * (size_t)row + i] = d[i];
+        }
+        V3 pc = P.p;
+        Q4 qc = P.q;
+        if (!(m & 1)) pc = V3{P.p.x + d[0], P.p.y + d[1], P.p.z + d[2]};
+        if (!(m & 2)) qc = quat_plus(P.q, V3{d[3], d[4], d[5]});
+        double2* o = reinterpret_cast<double2*>(g.pose_c + (size_t)POSE_STRIDE * row);
+        o[0] = double2{pc.x, pc.y};
+        o[1] = double2{pc.z, qc.x};
+        o[2] = double2{qc.y, qc.z};
+        o[3] = double2{qc.w, 0.0};
       }
       if (MODE == 0 && side == SIDE_DIAG) {
         double2* pn = reinterpret_cast<double2*>(p_new + 6 * (size_t)col);
@@ -853,9 +903,16 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd
   }
 }
 
+// Host hand-off without a stream synchronise: the host clears LmScalars::seq before it enqueues a sequence, the last
+// kernel of the sequence sets it AFTER its results (system-scope fence), and the host spins on that word.
+__device__ __forceinline__ void publish_sequence(const DeviceGraph& g) {
+  __threadfence_system();
+  __hip_atomic_store(&g.scal->seq, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Runs after a batch of iterations: applies the termination test to the last completed iteration
 // (the SpMV kernel of the next iteration would do it) and publishes the CG state for the host.
-__global__ void k_pcg_finish(DeviceGraph g, CgParams prm) {
+__global__ void k_pcg_finish(DeviceGraph g, CgParams prm, int publish) {
   __shared__ double scratch[16];
   const int tid = threadIdx.x;
   int done = g.cg->done, iters = g.cg->iters, status = g.cg->status;
@@ -880,13 +937,16 @@ __global__ void k_pcg_finish(DeviceGraph g, CgParams prm) {
     g.scal->cg_iterations = iters;
     g.scal->cg_status = done ? status : -1;  // -1: not finished, host launches another batch
     g.scal->cg_residual_sq = sums[2];
+    if (publish) publish_sequence(g);
   }
 }
 
 // model_cost_change = -(J~ step)'(r + J~ step/2) with step = -x:  x'b - x'(q - D^2 x)/2, q = A x;
 // delta = S * step.
-__global__ void k_model_delta(DeviceGraph g) {
+// `gate`: the step tail rides behind every CG batch; it runs only once the CG has stopped (device flag).
+__global__ void k_model_delta(DeviceGraph g, int gate) {
   __shared__ double scratch[VEC_BLOCK / 64];
+  if (gate && !g.cg->done) return;
   double acc[1] = {0.0};
   for (int idx = blockIdx.x * VEC_BLOCK + threadIdx.x; idx < 6 * g.N; idx += gridDim.x * VEC_BLOCK) {
     const double x = g.cg_x[idx];
@@ -901,8 +961,9 @@ __global__ void k_model_delta(DeviceGraph g) {
 }
 
 // x_cand = Plus(x, delta) per pose (p += dp ; q <- exp(dtheta) (x) q); ambient step / state norms.
-__global__ void k_retract(DeviceGraph g) {
+__global__ void k_retract(DeviceGraph g, int gate) {
   __shared__ double scratch[16];
+  if (gate && !g.cg->done) return;
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   double acc[2] = {0.0, 0.0};
   if (v < g.N) {
@@ -963,8 +1024,12 @@ __global__ void k_gradient_norm(DeviceGraph g) {
 }
 
 // One workgroup folds the partial rows into the pinned scalar block the host reads.
-__global__ void k_finalize_scalars(DeviceGraph g, int n_cost_part) {
+__global__ void k_finalize_scalars(DeviceGraph g, int n_cost_part, int gate) {
   __shared__ double scratch[32];
+  if (gate && !g.cg->done) {   // CG still running: only hand the (unfinished) status over to the host
+    if (threadIdx.x == 0) publish_sequence(g);
+    return;
+  }
   double s[4];
   s[0] = partial_sum(g.part_misc, n_cost_part);
   s[1] = partial_sum(g.part_misc + 1 * (size_t)g.n_part, g.n_vec_wg);
@@ -988,6 +1053,104 @@ __global__ void k_finalize_scalars(DeviceGraph g, int n_cost_part) {
     g.scal->linearize_bad = g.flags[1] | (g.flags[2] << 1);  // bit0: block inverse failed, bit1: Cholesky pivot
     g.flags[1] = 0;
     g.flags[2] = 0;
+    publish_sequence(g);
+  }
+}
+
+// Fused step tail (one launch instead of k_model_delta + k_cost + k_finalize_scalars; every kernel boundary costs ~4 us
+// at pose-graph sizes).  The candidate poses were written by the preceding k_spmv<1> launch (diagonal lanes).  Pose
+// part = model cost change and step / state norms; edge part = candidate cost; the LAST workgroup to finish (ticket
+// counter) folds the partial rows and hands off to the host.
+template <int INFO>
+__global__ __launch_bounds__(EDGE_BLOCK) void k_step_tail(DeviceGraph g, int gate) {
+  __shared__ double scratch[4 * (EDGE_BLOCK / 64)];
+  __shared__ int is_last;
+  const int tid = threadIdx.x;
+  if (gate && !g.cg->done) {   // CG still running: only hand the (unfinished) status over to the host
+    if (blockIdx.x == 0 && tid == 0) publish_sequence(g);
+    return;
+  }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};   // candidate cost, model change, |step|^2, |x|^2
+  // workgroups [0, n_edge_wg) take the edges, [n_edge_wg, n_edge_wg + n_pose_wg) the poses: both parts run side by side
+  const int pose_wg = (int)blockIdx.x - g.n_edge_wg;
+  for (int v = pose_wg * EDGE_BLOCK + tid; pose_wg >= 0 && v < g.N; v += g.n_pose_wg * EDGE_BLOCK) {
+    const PoseRec P = load_pose(g.pose_x, v), C = load_pose(g.pose_c, v);
+    const uint8_t m = g.cmask[v];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const size_t idx = 6 * (size_t)v + i;
+      const double x = g.cg_x[idx];
+      const double hx = g.cg_q[q_index(g, v, i)] - g.d2[idx] * x;
+      const bool c = (i < 3) ? (m & 1) : (m & 2);
+      acc[1] += c ? 0.0 : (x * g.cg_b[idx] - 0.5 * x * hx);
+    }
+    if (!(m & 1)) {
+      const double dx = P.p.x - C.p.x, dy = P.p.y - C.p.y, dz = P.p.z - C.p.z;
+      acc[2] += dx * dx + dy * dy + dz * dz;
+      acc[3] += P.p.x * P.p.x + P.p.y * P.p.y + P.p.z * P.p.z;
+    }
+    if (!(m & 2)) {
+      const double dx = P.q.x - C.q.x, dy = P.q.y - C.q.y, dz = P.q.z - C.q.z, dw = P.q.w - C.q.w;
+      acc[2] += dx * dx + dy * dy + dz * dz + dw * dw;
+      acc[3] += P.q.x * P.q.x + P.q.y * P.q.y + P.q.z * P.q.z + P.q.w * P.q.w;
+    }
+  }
+  const int e = blockIdx.x * EDGE_BLOCK + tid;
+  if (pose_wg < 0 && e < g.E) {
+    const PoseRec A = load_pose(g.pose_c, g.edge_a[e]), B = load_pose(g.pose_c, g.edge_b[e]);
+    const size_t E = (size_t)g.E;
+    const V3 mp{g.emeas[e], g.emeas[E + e], g.emeas[2 * E + e]};
+    const Q4 mq{g.emeas[3 * E + e], g.emeas[4 * E + e], g.emeas[5 * E + e], g.emeas[6 * E + e]};
+    double er[6];
+    edge_error(A.p, A.q, B.p, B.q, mp, mq, er);
+    double sq;
+    if (INFO) {
+      const WBlocks W = load_W(g.eW, E, (size_t)e);
+      const V3 ep{er[0], er[1], er[2]}, eq{er[3], er[4], er[5]};
+      const V3 a1 = mulv(W.pp, ep), a2 = mulv(W.pr, eq), b1 = mulTv(W.pr, ep), b2 = mulv(W.rr, eq);
+      sq = dot(ep, V3{a1.x + a2.x, a1.y + a2.y, a1.z + a2.z}) + dot(eq, V3{b1.x + b2.x, b1.y + b2.y, b1.z + b2.z});
+    } else {
+      sq = er[0] * er[0] + er[1] * er[1] + er[2] * er[2] + er[3] * er[3] + er[4] * er[4] + er[5] * er[5];
+    }
+    double rho0, rho1;
+    loss_eval(g.loss_kind, g.loss_a, sq, &rho0, &rho1);
+    acc[0] = 0.5 * rho0;
+  }
+  block_sum<4>(acc, scratch);
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g.part_misc[(size_t)k * g.n_part + blockIdx.x] = acc[k];
+    __threadfence();
+    is_last = (atomicAdd(&g.flags[3], 1) == (int)gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = tid; i < (int)gridDim.x; i += EDGE_BLOCK) {   // other workgroups' partials: read at device scope (not from this CU's L1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] += __hip_atomic_load(&g.part_misc[(size_t)k * g.n_part + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  block_sum<4>(s, scratch);
+  double m = 0.0;
+  for (int i = tid; i < g.n_pose_wg; i += EDGE_BLOCK) m = fmax(m, g.part_misc[4 * (size_t)g.n_part + i]);
+  m = wave_max(m);
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane == 0) scratch[wave] = m;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < EDGE_BLOCK / 64; ++w) t = fmax(t, scratch[w]);
+    g.scal->cand_cost = s[0];
+    g.scal->model_change = s[1];
+    g.scal->step_norm_sq = s[2];
+    g.scal->x_norm_sq = s[3];
+    g.scal->gradient_max = t;
+    g.scal->linearize_bad = g.flags[1] | (g.flags[2] << 1);
+    g.flags[1] = 0;
+    g.flags[2] = 0;
+    g.flags[3] = 0;
+    publish_sequence(g);
   }
 }
 
@@ -1022,10 +1185,10 @@ void launch_damping(const DeviceGraph& g, double radius, double min_diag, double
   if (g.cluster == 2 && owned > 0) hipLaunchKernelGGL(k_cluster_precond<2>, dim3(cdiv(owned, 2)), dim3(64), 0, s, g);
   else if (g.cluster == 4 && owned > 0) hipLaunchKernelGGL(k_cluster_precond<4>, dim3(cdiv(owned, 4)), dim3(64), 0, s, g);
 }
-void launch_cost(const DeviceGraph& g, const double* poses, int part_row, hipStream_t s) {
+void launch_cost(const DeviceGraph& g, const double* poses, int part_row, hipStream_t s, int gate) {
   double* part = g.part_misc + (size_t)part_row * g.n_part;
-  if (g.info_mode) hipLaunchKernelGGL(k_cost<1>, dim3(g.n_edge_wg), dim3(EDGE_BLOCK), 0, s, g, poses, part);
-  else hipLaunchKernelGGL(k_cost<0>, dim3(g.n_edge_wg), dim3(EDGE_BLOCK), 0, s, g, poses, part);
+  if (g.info_mode) hipLaunchKernelGGL(k_cost<1>, dim3(g.n_edge_wg), dim3(EDGE_BLOCK), 0, s, g, poses, part, gate);
+  else hipLaunchKernelGGL(k_cost<0>, dim3(g.n_edge_wg), dim3(EDGE_BLOCK), 0, s, g, poses, part, gate);
 }
 void launch_evaluate_edges(const DeviceGraph& g, const double* poses, double* res, double* ja, double* jb, hipStream_t s) {
   hipLaunchKernelGGL(k_evaluate_edges, dim3(cdiv(g.E, 128)), dim3(128), 0, s, g, poses, res, ja, jb);
@@ -1045,20 +1208,29 @@ void launch_pcg_iteration(const DeviceGraph& g, const CgParams& p, int odd, hipS
   hipLaunchKernelGGL(k_spmv<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, p, odd);
   launch_update(g, odd, s);
 }
-void launch_pcg_finish(const DeviceGraph& g, const CgParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(k_pcg_finish, dim3(1), dim3(256), 0, s, g, p);
+void launch_pcg_finish(const DeviceGraph& g, const CgParams& p, hipStream_t s, int publish) {
+  hipLaunchKernelGGL(k_pcg_finish, dim3(1), dim3(256), 0, s, g, p, publish);
 }
 void launch_model_and_retract(const DeviceGraph& g, hipStream_t s) {
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
   CgParams dummy{0.0, -1.0, 0, 0};
   hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1);
-  hipLaunchKernelGGL(k_model_delta, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
-  hipLaunchKernelGGL(k_retract, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g);
+  hipLaunchKernelGGL(k_model_delta, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, 0);
+  hipLaunchKernelGGL(k_retract, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g, 0);
 }
 void launch_spmv_plain(const DeviceGraph& g, hipStream_t s) {
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
   CgParams dummy{0.0, -1.0, 0, 0};
   hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1);
+}
+void launch_spmv_tail(const DeviceGraph& g, const CgParams& p, hipStream_t s, int finish, int candidates) {
+  const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
+  hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, p, 1 | (finish ? 2 : 0) | (candidates ? 4 : 0));
+}
+void launch_step_tail(const DeviceGraph& g, hipStream_t s, int gate) {
+  const int grid = g.n_edge_wg + g.n_pose_wg;   // <= 2 * n_part
+  if (g.info_mode) hipLaunchKernelGGL(k_step_tail<1>, dim3(grid), dim3(EDGE_BLOCK), 0, s, g, gate);
+  else hipLaunchKernelGGL(k_step_tail<0>, dim3(grid), dim3(EDGE_BLOCK), 0, s, g, gate);
 }
 void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s) {
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
@@ -1067,19 +1239,19 @@ void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipS
 void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s) {
   launch_update(g, odd, s);
 }
-void launch_model_delta_and_retract(const DeviceGraph& g, hipStream_t s) {
-  hipLaunchKernelGGL(k_model_delta, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
-  hipLaunchKernelGGL(k_retract, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g);
+void launch_model_delta_and_retract(const DeviceGraph& g, hipStream_t s, int gate) {
+  hipLaunchKernelGGL(k_model_delta, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, gate);
+  hipLaunchKernelGGL(k_retract, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g, gate);
 }
 void launch_gradient_norm(const DeviceGraph& g, hipStream_t s) {
   hipLaunchKernelGGL(k_gradient_norm, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g);
 }
-void launch_finalize_scalars(const DeviceGraph& g, int n_cost_part, hipStream_t s) {
-  hipLaunchKernelGGL(k_finalize_scalars, dim3(1), dim3(256), 0, s, g, n_cost_part);
+void launch_finalize_scalars(const DeviceGraph& g, int n_cost_part, hipStream_t s, int gate) {
+  hipLaunchKernelGGL(k_finalize_scalars, dim3(1), dim3(256), 0, s, g, n_cost_part, gate);
 }
 void launch_apply_step(const DeviceGraph& g, const double* step, hipStream_t s) {
   hipLaunchKernelGGL(k_copy_delta, dim3(cdiv(6 * g.N, 256)), dim3(256), 0, s, g, step);
-  hipLaunchKernelGGL(k_retract, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g);
+  hipLaunchKernelGGL(k_retract, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g, 0);
 }
 
 void launch_debug(const DeviceGraph& g, int which, hipStream_t s) {

@@ -224,14 +224,6 @@ int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd) {
   return PGO_OK;
 }
 
-int model_and_retract_all(pgo_problem* P) {
-  pgo::launch_spmv_plain(P->g, P->stream);
-  int rc = exchange(P, P->g.cg_q, (size_t)P->g.seg);
-  if (rc) return rc;
-  pgo::launch_model_delta_and_retract(P->g, P->stream);
-  return PGO_OK;
-}
-
 int choose_block(long long total_slots) {
   if (total_slots >= 256LL * 512) return 256;
   if (total_slots >= 128LL * 384) return 128;
@@ -395,7 +387,7 @@ int prepare(pgo_problem* P) {
   const int n_vec_wg = std::max(1, std::min((int)(((size_t)6 * N + pgo::vec_block() - 1) / pgo::vec_block()), 128));
   const int n_edge_wg = std::max(1, (E + pgo::edge_block() - 1) / pgo::edge_block());
   const int n_pose_wg = (N + pgo::pose_block() - 1) / pgo::pose_block();
-  const int n_part = std::max(std::max(n_wg, n_vec_wg), std::max(n_edge_wg, n_pose_wg));
+  const int n_part = std::max(std::max(n_wg, n_vec_wg), n_edge_wg + n_pose_wg);   // the fused step tail runs n_edge_wg + n_pose_wg workgroups
   HIP_TRY(P->d_part_rz.alloc((size_t)2 * n_part));
   HIP_TRY(P->d_part_q.alloc((size_t)2 * n_part));
   HIP_TRY(P->d_part_rr.alloc((size_t)2 * n_part));
@@ -473,22 +465,69 @@ int fill_scale_one(pgo_problem* P) {
 }
 
 // ---- CG driver: batches of iterations, one host check per batch ----
+// Host <-> device hand-off (publish_sequence in pgo_kernels.hip): clear the flag, enqueue a sequence whose last kernel
+// sets it, spin on the pinned word.  A stream synchronise costs ~20-30 us of wake-up latency per LM iteration phase;
+// the spin sees the result ~2 us after the kernel stored it.  Falls back to the blocking call after 50 ms.
+inline void arm_handoff(pgo_problem* P) { __atomic_store_n(&P->scal->seq, 0, __ATOMIC_SEQ_CST); }
+int wait_handoff(pgo_problem* P) {
+  static const bool no_spin = getenv("PGO_NO_SPIN") && getenv("PGO_NO_SPIN")[0] == '1';
+  if (!no_spin) {
+    const auto t0 = Clock::now();
+    for (unsigned spins = 1;; ++spins) {
+      if (__atomic_load_n(&P->scal->seq, __ATOMIC_ACQUIRE) != 0) return PGO_OK;
+      __builtin_ia32_pause();
+      if ((spins & 0x3ff) == 0 && seconds_since(t0) > 0.05) break;
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(P->stream));
+  if (__atomic_load_n(&P->scal->seq, __ATOMIC_ACQUIRE) == 0) return set_error(PGO_ERR_HIP, "device hand-off flag was not set by the enqueued sequence");
+  return PGO_OK;
+}
+
+// The step tail (model cost change, delta, candidate, candidate cost, scalar fold).  `gate`: the kernels run only once
+// the device-side CG state says "stopped", so the tail can ride behind every CG batch (no host round trip between the
+// last CG iteration and the tail); the scalar fold always hands off to the host.
+int enqueue_tail(pgo_problem* P, const pgo::CgParams* finish_prm) {
+  hipStream_t s = P->stream;
+  const pgo::CgParams none{0.0, -1.0, 0, 0};
+  const int gate = finish_prm ? 1 : 0;
+  if (P->g.world == 1) {
+    // two launches: q = A x + candidate poses (diagonal lanes), then model change / norms / candidate cost / fold
+    pgo::launch_spmv_tail(P->g, finish_prm ? *finish_prm : none, s, gate, 1);
+    pgo::launch_step_tail(P->g, s, gate);
+    return PGO_OK;
+  }
+  // several ranks: the vector kernels are replicated over all rows, q crosses the wire in between
+  pgo::launch_spmv_tail(P->g, finish_prm ? *finish_prm : none, s, gate, 0);
+  int rc = exchange(P, P->g.cg_q, (size_t)P->g.seg);
+  if (rc) return rc;
+  pgo::launch_model_delta_and_retract(P->g, s, gate);
+  pgo::launch_cost(P->g, P->g.pose_c, 0, s, gate);
+  pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s, gate);
+  return PGO_OK;
+}
+
 // A batch is a captured hipGraph of `batch` x (SpMV kernel, update kernel) + the finish kernel.  The
 // kernels stop by themselves (device-side `done` flag), so an over-long batch only costs early-exit
 // launches; the batch length follows the previous solve's iteration count.
-int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch) {
+// with_tail: the gated step tail follows in the same graph and its scalar fold hands off; otherwise the finish kernel does.
+int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool with_tail = false) {
   hipStream_t s = P->stream;
   if (P->use_graph) {
     if (memcmp(&P->cg_graph_params, &prm, sizeof prm) != 0) { P->drop_graph(); P->cg_graph_params = prm; }
-    auto it = P->cg_graphs.find(batch);
+    // the captured kernels hold the DeviceGraph by value; the tail touches the pose ping-pong, so the key carries its parity
+    const int key = 4 * batch + (with_tail ? 2 : 0) + ((with_tail && P->g.pose_x != P->d_pose_x.p) ? 1 : 0);
+    auto it = P->cg_graphs.find(key);
     if (it == P->cg_graphs.end()) {
       pgo_problem::CapturedBatch cb;
       hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
       if (e == hipSuccess) {
         int rc_it = PGO_OK;
         for (int i = 0; i < batch && rc_it == PGO_OK; ++i) rc_it = cg_iteration(P, prm, (i & 1) ^ 1);
-        pgo::launch_pcg_finish(P->g, prm, s);
+        if (!with_tail) pgo::launch_pcg_finish(P->g, prm, s, 1);
+        else if (rc_it == PGO_OK) rc_it = enqueue_tail(P, &prm);
         e = hipStreamEndCapture(s, &cb.graph);
+        if (e == hipSuccess && rc_it != PGO_OK) e = hipErrorUnknown;
         if (e == hipSuccess) e = hipGraphInstantiate(&cb.exec, cb.graph, nullptr, nullptr, 0);
       }
       if (e != hipSuccess) {
@@ -498,7 +537,7 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch) {
         P->drop_graph();
         P->use_graph = false;  // fall back to plain stream launches (same kernels)
       } else {
-        it = P->cg_graphs.emplace(batch, cb).first;
+        it = P->cg_graphs.emplace(key, cb).first;
       }
     }
     if (P->use_graph) {
@@ -507,7 +546,8 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch) {
     }
   }
   for (int i = 0; i < batch; ++i) { int rc = cg_iteration(P, prm, (i & 1) ^ 1); if (rc) return rc; }
-  pgo::launch_pcg_finish(P->g, prm, s);
+  if (with_tail) return enqueue_tail(P, &prm);
+  pgo::launch_pcg_finish(P->g, prm, s, 1);
   return PGO_OK;
 }
 
@@ -530,11 +570,14 @@ int run_pcg(pgo_problem* P, const pgo::CgParams& prm, int batch, int* iterations
   hipStream_t s = P->stream;
   pgo::launch_pcg_init(P->g, s);
   for (int round = 0;; ++round) {
+    arm_handoff(P);
     int rc = launch_cg_batch(P, prm, pick_batch(prm, batch, round));
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(s));
+    rc = wait_handoff(P);
+    if (rc) return rc;
     if (P->scal->cg_status != -1) break;
   }
+  HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
   *iterations = P->scal->cg_iterations;
   *status = P->scal->cg_status;
@@ -790,28 +833,27 @@ int lm_advance(pgo_problem* P) {
   int rc = damping_all(P, L.radius, o.min_lm_diagonal, o.max_lm_diagonal, L.reuse_diagonal ? 1 : 0);
   if (rc) return rc;
   const bool direct = o.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY && P->direct_usable;
+  arm_handoff(P);
   if (direct) {
     P->scal->cg_status = 0;       // host-visible block: the CG kernels that normally fill these do not run
     P->scal->cg_iterations = 0;
     rc = run_direct(P);
-  } else {
-    pgo::launch_pcg_init(P->g, s);
-    rc = launch_cg_batch(P, prm, pick_batch(prm, o.cg_batch, 0, P->last_cg_iterations));
-  }
-  if (rc) return rc;
-  for (int round = 1;; ++round) {
-    // the tail is enqueued speculatively behind the first batch; later batches sync first
-    rc = model_and_retract_all(P);
     if (rc) return rc;
-    pgo::launch_cost(P->g, P->g.pose_c, 0, s);
-    pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s);
-    HIP_TRY(hipStreamSynchronize(s));
-    if (P->scal->cg_status != -1) break;
-    for (;; ++round) {
-      rc = launch_cg_batch(P, prm, pick_batch(prm, o.cg_batch, round));
+    rc = enqueue_tail(P, nullptr);
+    if (rc) return rc;
+    rc = wait_handoff(P);
+    if (rc) return rc;
+  } else {
+    // every batch carries the gated tail: the host hears back once per batch and finds the step scalars ready
+    // as soon as the CG has stopped
+    pgo::launch_pcg_init(P->g, s);
+    for (int round = 0;; ++round) {
+      rc = launch_cg_batch(P, prm, pick_batch(prm, o.cg_batch, round, P->last_cg_iterations), true);
       if (rc) return rc;
-      HIP_TRY(hipStreamSynchronize(s));
+      rc = wait_handoff(P);
+      if (rc) return rc;
       if (P->scal->cg_status != -1) break;
+      arm_handoff(P);
     }
   }
   HIP_TRY(hipGetLastError());
