@@ -207,6 +207,16 @@ int pgo_solver_end(pgo_problem* problem, pgo_solver_summary* summary, pgo_iterat
  * "pcg_update". */
 int pgo_time_kernel(pgo_problem* problem, const char* kernel, int repeats, double* avg_ms);
 
+/* ---- loop-closure candidate search ----
+ * Replaces getCandidatesIndex / isInSearchRange of PLUS/test/generate_edges_from_trajectory_origion.cpp:58-111 (the
+ * generator of Edge_Candidates_index.txt): for frame k >= 1 the list is k-1 followed by every i < k - gap (reference:
+ * gap = 100) with float32 squared distance <= search_radius^2 (reference: Config search_radius = 6), ascending.
+ * xyz: n x 3 float32 camera centres.  Output in CSR form: row_ptr[n+1] (row 0 is empty), indices[row_ptr[n]].
+ * Call with indices = NULL to obtain row_ptr (sizes) only; capacity = entries available in `indices`.
+ * kernel_ms (optional): device time of the search kernels (HIP events).  GPU only: PGO_ERR_NO_DEVICE without one. */
+int pgo_generate_candidates(const float* xyz, int n, float search_radius, int gap, long long* row_ptr, int* indices,
+                            long long capacity, double* kernel_ms);
+
 /* ---- one process per GPU: edge/row sharding over RCCL ---- */
 /* contiguous share [begin,end) of n units for `rank` of `world` (host-only helper, no GPU needed) */
 int pgo_shard_range(long long n, int rank, int world, long long* begin, long long* end);

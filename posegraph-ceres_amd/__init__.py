@@ -41,6 +41,7 @@ C_ABI_SYMBOLS = [
     "pgo_evaluate", "pgo_normal_equations", "pgo_linear_solve", "pgo_plus", "pgo_solver_begin",
     "pgo_solver_step", "pgo_solver_reset", "pgo_solver_end", "pgo_time_kernel", "pgo_shard_range",
     "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_loopback_create", "pgo_loopback_destroy", "pgo_comm_init_loopback",
+    "pgo_generate_candidates",
 ]
 
 
@@ -136,6 +137,25 @@ def shard_range(n, rank, world):
     b, e = C.c_longlong(0), C.c_longlong(0)
     _check(lib().pgo_shard_range(C.c_longlong(n), C.c_int(rank), C.c_int(world), C.byref(b), C.byref(e)))
     return b.value, e.value
+
+
+def generate_candidates(xyz, search_radius=6.0, gap=100, return_ms=False):
+    """GPU loop-closure candidate search (pgo_generate_candidates; role of
+    generate_edges_from_trajectory_origion.cpp:58-111).  Returns {frame id: [id-1, matches...]} for id >= 1, the same
+    structure as datasets.generate_candidates / read_candidates."""
+    import numpy as np
+    p = np.ascontiguousarray(np.asarray(xyz, dtype=np.float32).reshape(-1, 3))
+    n = p.shape[0]
+    row_ptr = np.zeros(n + 1, dtype=np.int64)
+    fp = p.ctypes.data_as(C.POINTER(C.c_float))
+    rp = row_ptr.ctypes.data_as(C.POINTER(C.c_longlong))
+    _check(lib().pgo_generate_candidates(fp, C.c_int(n), C.c_float(search_radius), C.c_int(gap), rp, None, C.c_longlong(0), None))
+    idx = np.zeros(max(1, int(row_ptr[n])), dtype=np.int32)
+    ms = C.c_double(0)
+    _check(lib().pgo_generate_candidates(fp, C.c_int(n), C.c_float(search_radius), C.c_int(gap), rp,
+                                         idx.ctypes.data_as(C.POINTER(C.c_int)), C.c_longlong(idx.shape[0]), C.byref(ms)))
+    out = {k: idx[row_ptr[k]:row_ptr[k + 1]].tolist() for k in range(1, n)}
+    return (out, ms.value) if return_ms else out
 
 
 def comm_unique_id():

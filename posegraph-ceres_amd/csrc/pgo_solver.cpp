@@ -1009,6 +1009,9 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
 // =================================================================================================
 // C ABI
 // =================================================================================================
+// error channel for the other translation units of the library
+int pgo_candidates_set_error(int code, const char* msg) { return set_error(code, "%s", msg); }
+
 extern "C" {
 
 int pgo_version(void) { return PGO_VERSION; }
