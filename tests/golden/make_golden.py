@@ -16,6 +16,9 @@ Fixtures are DATA: inputs + expected outputs.
   * edge_vectors.npz   — 32 random edges: inputs and the oracle's r / J_begin / J_end (autodiff and analytic).
   * toy_graph.npz      — 120-pose ring + chords, non-identity information: LM trace and final poses (exact steps).
   * kitti00_trace.npz  — LM trace + tightly converged poses of the replay graph (oracle, exact steps).
+  * g2o_00_excerpt.g2o — data file of the reference's first-iteration package (src/POSE_GRAPH/result/g2o/00.g2o):
+                         the lines of vertices 0..199, "FIX 0" and every edge between them, verbatim (format vector
+                         for the g2o reader: VERTEX_SE3:QUAT / FIX / EDGE_SE3:QUAT + 21 information entries).
 The oracle outputs stored here pin the oracle against regressions and are what the GPU path is compared to on
 the GPU box.  PARITY UNPINNED against the reference itself (see oracle/pgo_oracle.cpp header).
 """
@@ -80,8 +83,26 @@ def odometry_float32(poses):
     return out
 
 
+def g2o_excerpt(n_vertices=200):
+    src = "/root/reference/src/POSE_GRAPH/result/g2o/00.g2o"
+    out = []
+    for line in open(src):
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "VERTEX_SE3:QUAT" and int(t[1]) < n_vertices:
+            out.append(line)
+        elif t[0] == "FIX" and int(t[1]) < n_vertices:
+            out.append(line)
+        elif t[0] == "EDGE_SE3:QUAT" and int(t[1]) < n_vertices and int(t[2]) < n_vertices:
+            out.append(line)
+    open(os.path.join(HERE, "g2o_00_excerpt.g2o"), "w").write("".join(out))
+    print("g2o excerpt: %d lines" % len(out))
+
+
 def main():
     rng = np.random.default_rng(20260928)
+    g2o_excerpt()
 
     # ---------------- reference data files ----------------
     ids, origin = ds.read_poses(os.path.join(REF, "result/trajectory/trajectory_origin.txt"))

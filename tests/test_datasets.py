@@ -33,3 +33,20 @@ def test_sphere_generator(ds):
     g = ds.sphere_layers(n_spheres=2, rings=10, per_ring=10, n_edges=900, seed=1)
     assert g.N == 200 and g.E == 900
     assert (g.ia != g.ib).all()
+
+
+def test_g2o_reader_on_the_reference_file_excerpt(ds, O):
+    """tests/golden/g2o_00_excerpt.g2o holds lines of the reference's own POSE_GRAPH/result/g2o/00.g2o verbatim.  Its
+    edges were written from trajectory-relative transforms, so with the right reading of the format (edge i j =
+    pose of j in the frame of i -> id_begin = i, id_end = j; information upper triangle; FIX) the graph is
+    consistent at the file's vertex values; with the direction swapped it is not."""
+    import os
+    g = ds.read_g2o(os.path.join(os.path.dirname(__file__), "golden", "g2o_00_excerpt.g2o"))
+    assert (g.N, g.E) == (200, 201) and g.fixed == [0] and g.sqrt_info is None
+    assert np.array_equal(g.ids, np.arange(200))
+    assert np.allclose(g.poses[0], [0, 0, 0, 0, 0, 0, 1])
+    right = O.cost(O.Graph(g.poses, g.ia, g.ib, g.meas, None))
+    swapped = O.cost(O.Graph(g.poses, g.ib, g.ia, g.meas, None))
+    assert right < 1e-2 and swapped > 1e2
+    # two edges of the excerpt skip a frame (the reference's accepted loop edges inside this window)
+    assert sorted(zip(g.ia[np.abs(g.ia - g.ib) > 1].tolist(), g.ib[np.abs(g.ia - g.ib) > 1].tolist())) == [(145, 147), (186, 188)]
