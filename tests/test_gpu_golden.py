@@ -103,3 +103,22 @@ def test_kitti00_dense_candidates_config3(gpu, ds, O):
     dq = np.minimum(np.abs(poses[:, 3:] - op[:, 3:]).max(axis=1), np.abs(poses[:, 3:] + op[:, 3:]).max(axis=1))
     assert dq.max() < 1e-6
     assert np.array_equal(poses[0], g.poses[0])
+
+
+def test_reference_g2o_excerpt_solve(gpu, ds, O):
+    """Lines of the reference's own 00.g2o (tests/golden/g2o_00_excerpt.g2o): read, perturb the vertices, solve with the
+    reference's options on the GPU and with the oracle — same trace, same poses."""
+    g = ds.read_g2o(os.path.join(G, "g2o_00_excerpt.g2o"))
+    rng = np.random.default_rng(7)
+    start = g.poses.copy()
+    start[1:, :3] += rng.normal(0, 0.2, (g.N - 1, 3))
+    start[1:, 3:] = ds.qmul(ds.qexp_half(rng.normal(0, 0.02, (g.N - 1, 3))), start[1:, 3:])
+    h = ds.PoseGraphData(start, g.ia, g.ib, g.meas, None)
+    prob, poses = gpu.problem_from_graph(h)
+    s = gpu.solve(gpu.SolverOptions(max_num_iterations=1000, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY), prob)
+    op, osum, otr = O.solve(O.Graph(start, g.ia, g.ib, g.meas, None), O.default_options(max_num_iterations=1000))
+    assert s.num_iterations == osum.num_iterations and s.termination_type == gpu.CONVERGENCE
+    assert np.allclose(s.iterations["cost"], otr[:, 1], rtol=1e-7, atol=1e-12)
+    assert np.abs(poses - op).max() < 1e-6
+    assert s.final_cost == pytest.approx(osum.final_cost, rel=1e-7)
+    assert s.final_cost < 1e-3 * s.initial_cost      # (an open chain: the far end is weakly constrained, poses are not compared to the file)
