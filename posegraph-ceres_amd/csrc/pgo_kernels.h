@@ -105,6 +105,7 @@ struct DeviceGraph {
   int cluster;        // poses per Jacobi block of the preconditioner: 1 (6x6), 2 (12x12) or 4 (24x24)
   const int* cl_ptr;  // [n_clusters+1] BSR slots whose row AND column lie inside the cluster (off-diagonal ones)
   const int* cl_slot;
+  const uint8_t* cl_rc;  // per entry: (row - cluster base) << 4 | (col - cluster base)
 };
 
 struct CgParams {

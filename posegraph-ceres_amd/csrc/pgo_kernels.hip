@@ -345,54 +345,108 @@ __global__ void k_damping(DeviceGraph g, double radius, double min_diag, double 
 // Gauss-Jordan (SPD, no pivoting).  One wave per cluster.  Row r of the inverse is what lane r of the
 // vector kernels reads (contiguous 6 CL doubles).
 template <int CL>
-__global__ __launch_bounds__(64) void k_cluster_precond(DeviceGraph g) {
-  constexpr int DIM = 6 * CL, LD = DIM + 1;
-  __shared__ double A[DIM * LD];
-  const int c = g.row_lo / CL + blockIdx.x, lane = threadIdx.x;   // clusters of the rows this rank owns
+__global__ __launch_bounds__(64) void k_cluster_precond(DeviceGraph g, double radius, double min_diag, double max_diag, int mode) {
+  // mode >= 0: this kernel also does k_damping's job for its poses (D^2, clamped diagonal, damped diagonal BSR slot) —
+  // one launch fewer per LM iteration; mode < 0: k_damping ran before (several ranks: D^2 is needed for ALL rows).
+  //
+  // Register-resident Gauss-Jordan: lane j of a group of DIM lanes holds COLUMN j of the cluster matrix (DIM doubles),
+  // 64/DIM clusters per wave.  Pivot k: column k is broadcast from lane k of the group (ds_bpermute), row k is the k-th
+  // register of every lane; no LDS array, no barriers (the LDS version spent ~1.2 us per pivot on dependent LDS
+  // round trips).
+  constexpr int DIM = 6 * CL, CPW = 64 / DIM;
+  const int lane = threadIdx.x;
+  const int grp = lane / DIM, j = lane - grp * DIM;
+  const int n_cl = (g.row_hi - g.row_lo + CL - 1) / CL;
+  const int cl_local = blockIdx.x * CPW + grp;              // cluster index among this rank's clusters
+  const bool live = grp < CPW && cl_local < n_cl;
+  const int base = grp * DIM;
+  const int c = g.row_lo / CL + cl_local;
   const int v0 = c * CL;
-  for (int e = lane; e < DIM * LD; e += 64) A[e] = 0.0;
-  __syncthreads();
-  for (int lp = 0; lp < CL; ++lp) {
-    const int v = v0 + lp;
-    if (lane < 36) {
-      const int i = lane / 6, j = lane - 6 * i;
-      double val = (i == j) ? 1.0 : 0.0;   // poses past the end: identity
-      if (v < g.N) val = g.Hdiag[36 * (size_t)v + lane] + ((i == j) ? g.d2[6 * (size_t)v + i] : 0.0);
-      A[(6 * lp + i) * LD + 6 * lp + j] = val;
+  const int lp = j / 6, jc = j - 6 * lp;                    // this lane's column: pose lp of the cluster, component jc
+  const int v = v0 + lp;
+  double a[DIM];
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) a[i] = (i == j) ? 1.0 : 0.0;   // poses past the end: identity
+  if (live && v < g.N) {
+    // own diagonal block: rows of pose lp, column jc
+#pragma unroll
+    for (int ic = 0; ic < 6; ++ic) {
+      const double hv = g.Hdiag[36 * (size_t)v + 6 * ic + jc];
+#pragma unroll
+      for (int q = 0; q < CL; ++q) if (q == lp) a[6 * q + ic] = hv;
+    }
+    double d2 = 0.0, diag = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) if (i == j) diag = a[i];
+    if (mode < 0 || mode == 2) d2 = g.d2[6 * (size_t)v + jc];
+    else if (mode == 1) d2 = g.diag_clamped[6 * (size_t)v + jc] / radius;
+    else {
+      const double dc = fmin(fmax(diag, min_diag), max_diag);
+      g.diag_clamped[6 * (size_t)v + jc] = dc;
+      d2 = dc / radius;
+    }
+    if (mode == 0 || mode == 1) g.d2[6 * (size_t)v + jc] = d2;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) if (i == j) a[i] += d2;
+    if (mode >= 0) {   // damped diagonal BSR slot (k_damping's job)
+      const int slot = g.row_slot_begin[v];
+#pragma unroll
+      for (int ic = 0; ic < 6; ++ic) {
+        double val = 0.0;
+#pragma unroll
+        for (int q = 0; q < CL; ++q) if (q == lp) val = a[6 * q + ic];
+        g.bsr_val[bsr_index(slot, 6 * ic + jc)] = val;
+      }
     }
   }
-  __syncthreads();
-  for (int s = g.cl_ptr[blockIdx.x]; s < g.cl_ptr[blockIdx.x + 1]; ++s) {   // in-cluster off-diagonal blocks, serial over slots
-    const int slot = g.cl_slot[s];
-    const int ro = 6 * (g.slot_row[slot] - v0), co = 6 * (g.slot_col[slot] - v0);
-    if (lane < 36) {
-      const int i = lane / 6, j = lane - 6 * i;
-      A[(ro + i) * LD + co + j] += g.bsr_val[bsr_index(slot, lane)];
+  if (live) {
+    // in-cluster off-diagonal blocks (BEGIN slots only; the matrix is symmetric, this lane needs column j)
+    for (int sidx = g.cl_ptr[cl_local]; sidx < g.cl_ptr[cl_local + 1]; ++sidx) {
+      const int slot = g.cl_slot[sidx];
+      const int rc = g.cl_rc[sidx];
+      const int r = rc >> 4, cc = rc & 15;    // block H_{r,cc}: rows of pose r, columns of pose cc
+      if (cc == lp) {           // A[6r + a][j] += B[a][jc]
+#pragma unroll
+        for (int ai = 0; ai < 6; ++ai) {
+          const double bv = g.bsr_val[bsr_index(slot, 6 * ai + jc)];
+#pragma unroll
+          for (int q = 0; q < CL; ++q) if (q == r) a[6 * q + ai] += bv;
+        }
+      } else if (r == lp) {     // A[6cc + b][j] += B[jc][b]   (mirror)
+#pragma unroll
+        for (int bi = 0; bi < 6; ++bi) {
+          const double bv = g.bsr_val[bsr_index(slot, 6 * jc + bi)];
+#pragma unroll
+          for (int q = 0; q < CL; ++q) if (q == cc) a[6 * q + bi] += bv;
+        }
+      }
     }
-    __syncthreads();
   }
   bool ok = true;
+#pragma unroll
   for (int k = 0; k < DIM; ++k) {
-    const double pk = A[k * LD + k];
+    double colk[DIM];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) colk[i] = __shfl(a[i], base + k);   // A[i][k], held by lane k of the group
+    const double pk = colk[k];
     if (!(pk > 0.0)) ok = false;
     const double ip = 1.0 / pk;
-    for (int e = lane; e < DIM * DIM; e += 64) {
-      const int i = e / DIM, j = e - i * DIM;
-      if (i != k && j != k) A[i * LD + j] -= A[i * LD + k] * A[k * LD + j] * ip;
+    const double rowk = a[k];                                          // A[k][j]
+    if (j != k) {
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) if (i != k) a[i] -= colk[i] * rowk * ip;
+      a[k] = rowk * ip;
+    } else {
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) a[i] = (i == k) ? ip : colk[i] * -ip;
     }
-    __syncthreads();
-    for (int e = lane; e < DIM; e += 64) {
-      if (e != k) { A[k * LD + e] *= ip; }
-    }
-    for (int e = lane; e < DIM; e += 64) {
-      if (e != k) { A[e * LD + k] *= -ip; }
-    }
-    if (lane == 0) A[k * LD + k] = ip;
-    __syncthreads();
   }
-  if (!ok && lane == 0) atomicOr(&g.flags[1], 1);
-  double* out = g.Minv + (size_t)c * DIM * DIM;
-  for (int e = lane; e < DIM * DIM; e += 64) { const int i = e / DIM, j = e - i * DIM; out[e] = A[i * LD + j]; }
+  if (live) {
+    if (!ok && j == 0) atomicOr(&g.flags[1], 1);
+    double* out = g.Minv + (size_t)c * DIM * DIM;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) out[i * DIM + j] = a[i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1180,10 +1234,14 @@ void launch_scale_from_diag(const DeviceGraph& g, hipStream_t s) {
   hipLaunchKernelGGL(k_scale_from_diag, dim3(cdiv(6 * g.N, 256)), dim3(256), 0, s, g);
 }
 void launch_damping(const DeviceGraph& g, double radius, double min_diag, double max_diag, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(k_damping, dim3(cdiv(g.N, 64)), dim3(64), 0, s, g, radius, min_diag, max_diag, mode);
   const int owned = g.row_hi - g.row_lo;
-  if (g.cluster == 2 && owned > 0) hipLaunchKernelGGL(k_cluster_precond<2>, dim3(cdiv(owned, 2)), dim3(64), 0, s, g);
-  else if (g.cluster == 4 && owned > 0) hipLaunchKernelGGL(k_cluster_precond<4>, dim3(cdiv(owned, 4)), dim3(64), 0, s, g);
+  // one rank + cluster preconditioner: the cluster kernel does the damping of its poses itself (every pose is in a cluster)
+  const bool fused = g.cluster > 1 && g.world == 1 && owned > 0;
+  if (!fused) hipLaunchKernelGGL(k_damping, dim3(cdiv(g.N, 64)), dim3(64), 0, s, g, radius, min_diag, max_diag, mode);
+  const int cm = fused ? mode : -1;
+  // 64 / (6 CL) clusters per wave: 5 (CL = 2) or 2 (CL = 4)
+  if (g.cluster == 2 && owned > 0) hipLaunchKernelGGL(k_cluster_precond<2>, dim3(cdiv(cdiv(owned, 2), 5)), dim3(64), 0, s, g, radius, min_diag, max_diag, cm);
+  else if (g.cluster == 4 && owned > 0) hipLaunchKernelGGL(k_cluster_precond<4>, dim3(cdiv(cdiv(owned, 4), 2)), dim3(64), 0, s, g, radius, min_diag, max_diag, cm);
 }
 void launch_cost(const DeviceGraph& g, const double* poses, int part_row, hipStream_t s, int gate) {
   double* part = g.part_misc + (size_t)part_row * g.n_part;

@@ -138,6 +138,7 @@ struct pgo_problem {
   hipGraphExec_t direct_exec = nullptr;
   // cluster-Jacobi preconditioner topology (built when the option asks for clusters of 2 or 4 poses)
   DevBuf<int> d_cl_ptr, d_cl_slot;
+  DevBuf<uint8_t> d_cl_rc;
   int cluster_built = 0;
 
   // one process per GPU: the communicator of the row-sharded path (null = single rank)
@@ -594,25 +595,30 @@ int prepare_clusters(pgo_problem* P, int CL) {
     // clusters of the rows this rank owns (row_lo is a multiple of 4); indices local to the rank
     const int c0 = P->g.row_lo / CL;
     const int ncl = std::max(1, (P->g.row_hi - P->g.row_lo + CL - 1) / CL);
+    // the BEGIN slot of every edge whose two poses share a cluster (the END twin holds the transposed block: the kernel mirrors)
     std::vector<int> ptr(ncl + 1, 0), slots;
+    std::vector<uint8_t> rcs;
     for (int pass = 0; pass < 2; ++pass) {
       std::vector<int> fill(ptr.begin(), ptr.end() - 1);
       for (int t = 0; t < P->g.n_slots; ++t) {
-        if (P->h_slot_side[t] > pgo::SIDE_END) continue;
+        if (P->h_slot_side[t] != pgo::SIDE_BEGIN) continue;
         const int r = P->h_slot_row[t], c = P->h_slot_col[t];
         if (r / CL != c / CL) continue;
-        if (pass == 0) ++ptr[r / CL - c0 + 1]; else slots[fill[r / CL - c0]++] = t;
+        if (pass == 0) ++ptr[r / CL - c0 + 1];
+        else { const int q = fill[r / CL - c0]++; slots[q] = t; rcs[q] = (uint8_t)(((r % CL) << 4) | (c % CL)); }
       }
-      if (pass == 0) { for (int k = 0; k < ncl; ++k) ptr[k + 1] += ptr[k]; slots.resize(ptr[ncl]); }
+      if (pass == 0) { for (int k = 0; k < ncl; ++k) ptr[k + 1] += ptr[k]; slots.resize(ptr[ncl]); rcs.resize(ptr[ncl]); }
     }
     HIP_TRY(P->d_cl_ptr.upload(ptr, P->stream));
     HIP_TRY(P->d_cl_slot.upload(slots, P->stream));
-    if (slots.empty()) HIP_TRY(P->d_cl_slot.alloc(1));
+    HIP_TRY(P->d_cl_rc.upload(rcs, P->stream));
+    if (slots.empty()) { HIP_TRY(P->d_cl_slot.alloc(1)); HIP_TRY(P->d_cl_rc.alloc(1)); }
     const size_t need = (size_t)P->g.world * P->g.rows_per * 36 * CL;   // every rank's clusters, padded
     if (P->d_Minv.n < need) { HIP_TRY(P->d_Minv.alloc(need)); HIP_TRY(P->d_Minv.zero(P->stream)); }
     P->g.Minv = P->d_Minv.p;
     P->g.cl_ptr = P->d_cl_ptr.p;
     P->g.cl_slot = P->d_cl_slot.p;
+    P->g.cl_rc = P->d_cl_rc.p;
   }
   P->g.cluster = CL;
   P->cluster_built = CL;

@@ -1,5 +1,5 @@
 """Kernel timeline of ONE LM iteration from a rocprofv3 kernel-trace database (rocpd): start offset, duration and the idle
-gap before each kernel, between two consecutive k_damping launches in the middle of the run.
+gap before each kernel, between two consecutive k_pcg_init launches in the middle of the run.
 usage: python tools/timeline.py <results.db> [which_iteration]"""
 import re
 import sqlite3
@@ -12,7 +12,7 @@ def main(db, which=None):
     sc = "start" if "start" in cols else "start_timestamp"
     ec = "end" if "end" in cols else "end_timestamp"
     rows = c.execute("select name, %s, %s from kernels order by %s" % (sc, ec, sc)).fetchall()
-    idx = [i for i, r in enumerate(rows) if "k_damping" in r[0]]
+    idx = [i for i, r in enumerate(rows) if "k_pcg_init" in r[0]]
     k = int(which) if which is not None else len(idx) // 2
     a, b = idx[k], idx[k + 1]
     t0 = rows[a][1]
