@@ -19,7 +19,7 @@ namespace pgo {
 
 namespace {
 
-constexpr int VEC_BLOCK = 768;  // 128 poses x 6 tangent dims: a pose never straddles a workgroup
+constexpr int VEC_BLOCK = 384;  // 64 poses x 6 tangent dims (a pose or 2-/4-pose cluster never straddles a workgroup); measured 192/384/768: 384 best on C2
 constexpr int POSE_BLOCK = 256;
 constexpr int EDGE_BLOCK = 256;
 constexpr int NV_LIN = 27;      // 21 (symmetric diagonal block) + 6 (gradient)

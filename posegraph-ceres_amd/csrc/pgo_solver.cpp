@@ -385,7 +385,7 @@ int prepare(pgo_problem* P) {
   for (DevBuf<double>* b : vecs) { HIP_TRY(b->alloc(m)); HIP_TRY(b->zero(s)); }
   HIP_TRY(P->d_cg_q.alloc((size_t)world * seg));   // exchange buffer: q segments + p'q partials (unused partial slots stay 0)
   HIP_TRY(P->d_cg_q.zero(s));
-  const int n_vec_wg = std::max(1, std::min((int)(((size_t)6 * N + pgo::vec_block() - 1) / pgo::vec_block()), 128));
+  const int n_vec_wg = std::max(1, std::min((int)(((size_t)6 * N + pgo::vec_block() - 1) / pgo::vec_block()), 256));
   const int n_edge_wg = std::max(1, (E + pgo::edge_block() - 1) / pgo::edge_block());
   const int n_pose_wg = (N + pgo::pose_block() - 1) / pgo::pose_block();
   const int n_part = std::max(std::max(n_wg, n_vec_wg), n_edge_wg + n_pose_wg);   // the fused step tail runs n_edge_wg + n_pose_wg workgroups
