@@ -226,6 +226,8 @@ int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd) {
 }
 
 int choose_block(long long total_slots) {
+  static const int env_block = getenv("PGO_BLOCK") ? atoi(getenv("PGO_BLOCK")) : 0;   // tuning experiments: 64, 128 or 256
+  if (env_block == 64 || env_block == 128 || env_block == 256) return env_block;
   if (total_slots >= 256LL * 512) return 256;
   if (total_slots >= 128LL * 384) return 128;
   return 64;
@@ -552,17 +554,30 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool wi
   return PGO_OK;
 }
 
-// Batch schedule: the kernels stop on their own, but an over-long batch still pays ~2.6 us per early-exit
-// launch and an under-long one pays a host sync (~25 us), so batches start small and grow: 6, 12, 24, 48, 64...
-int pick_batch(const pgo::CgParams& prm, int user_batch, int round, int last_iterations = 0) {
+// Batch schedule.  The kernels stop on their own, but every iteration enqueued past the stopping point still costs two
+// early-exit launches (~5 us, ~10 us under the profiler) and every extra batch a host hand-off plus two gated tail
+// launches (~12-17 us).  With n iterations expected, the cheapest fixed batch is ~sqrt(3.4 n); n is not known, so the
+// first batch follows the previous solve's count (capped at 8: early LM iterations are poor predictors, late ones need
+// 3-6 iterations) and later batches grow like sqrt(3.4 * iterations already enqueued) — not by doubling, which wastes up
+// to half of the last batch.  Sizes are quantised so that only a handful of graphs is ever captured.
+int pick_batch(const pgo::CgParams& prm, int user_batch, int round, int enqueued, int last_iterations) {
   static const int env_b0 = getenv("PGO_CG_BATCH0") ? atoi(getenv("PGO_CG_BATCH0")) : 0;
-  static const int env_adapt = getenv("PGO_CG_ADAPT") ? atoi(getenv("PGO_CG_ADAPT")) : 0;
-  int b0 = env_b0 > 0 ? env_b0 : 6;   // measured on C2: 4..8 is the flat optimum (early-exit launches cost ~2.6 us each)
-  if (env_adapt && round == 0 && last_iterations > 0) {
-    // the previous solve is a fair predictor for the easy (late) LM iterations: cover it with some slack
-    b0 = std::max(8, std::min(64, (last_iterations + last_iterations / 2 + 7) / 8 * 8));
+  static const int env_double = getenv("PGO_CG_DOUBLING") ? atoi(getenv("PGO_CG_DOUBLING")) : 0;   // the r01 schedule 6,12,24,48,64
+  static const double env_c = getenv("PGO_CG_SQRTC") ? atof(getenv("PGO_CG_SQRTC")) : 3.4;
+  static const int env_cap0 = getenv("PGO_CG_CAP0") ? atoi(getenv("PGO_CG_CAP0")) : 8;
+  static const int sizes[] = {2, 4, 6, 8, 12, 16, 24, 32, 48, 64};
+  int batch;
+  if (user_batch > 0) {
+    batch = user_batch;
+  } else if (env_double) {
+    batch = std::min(64, (env_b0 > 0 ? env_b0 : 6) << std::min(round, 4));
+  } else {
+    double target;
+    if (round == 0) target = env_b0 > 0 ? env_b0 : (last_iterations > 0 ? std::min(last_iterations, env_cap0) : 6);
+    else target = std::sqrt(env_c * std::max(1, enqueued));
+    batch = 64;
+    for (int sz : sizes) if (sz >= target) { batch = sz; break; }
   }
-  int batch = user_batch > 0 ? user_batch : std::min(64, b0 << std::min(round, 4));
   batch = std::max(1, std::min(batch, prm.max_iterations));
   return (batch + 1) & ~1;  // even: every batch starts at an odd iteration (kernels take the parity at launch)
 }
@@ -570,9 +585,11 @@ int pick_batch(const pgo::CgParams& prm, int user_batch, int round, int last_ite
 int run_pcg(pgo_problem* P, const pgo::CgParams& prm, int batch, int* iterations, int* status) {
   hipStream_t s = P->stream;
   pgo::launch_pcg_init(P->g, s);
-  for (int round = 0;; ++round) {
+  for (int round = 0, enqueued = 0;; ++round) {
     arm_handoff(P);
-    int rc = launch_cg_batch(P, prm, pick_batch(prm, batch, round));
+    const int nb = pick_batch(prm, batch, round, enqueued, 0);
+    enqueued += nb;
+    int rc = launch_cg_batch(P, prm, nb);
     if (rc) return rc;
     rc = wait_handoff(P);
     if (rc) return rc;
@@ -853,8 +870,10 @@ int lm_advance(pgo_problem* P) {
     // every batch carries the gated tail: the host hears back once per batch and finds the step scalars ready
     // as soon as the CG has stopped
     pgo::launch_pcg_init(P->g, s);
-    for (int round = 0;; ++round) {
-      rc = launch_cg_batch(P, prm, pick_batch(prm, o.cg_batch, round, P->last_cg_iterations), true);
+    for (int round = 0, enqueued = 0;; ++round) {
+      const int nb = pick_batch(prm, o.cg_batch, round, enqueued, P->last_cg_iterations);
+      enqueued += nb;
+      rc = launch_cg_batch(P, prm, nb, true);
       if (rc) return rc;
       rc = wait_handoff(P);
       if (rc) return rc;
