@@ -243,3 +243,48 @@ def test_other_ceres_losses(gpu, O, ds, kind, a):
     op, osum, otr = O.solve(og2, O.default_options(max_num_iterations=15, linear_solver=0, loss_kind=kind, loss_a=a))
     n = min(len(s.iterations), len(otr), 8)
     assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-7)
+
+
+@pytest.mark.parametrize("cluster", [1, 2, 4])
+def test_awkward_topologies_match_oracle(gpu, O, ds, cluster):
+    """Duplicate edges, an isolated free pose, partial constancy (p only / q only), non-unit quaternions, pose count
+    not a multiple of the preconditioner cluster: same LM trace as the oracle with the same policy."""
+    g = _random_graph(ds, 37, 90, seed=11, info="diag", unit=False)
+    ia = np.concatenate([g.ia, g.ia[:7]])                 # duplicates of the first seven edges
+    ib = np.concatenate([g.ib, g.ib[:7]])
+    keep = (ia != 36) & (ib != 36)                        # pose 36 keeps no edge at all
+    g = ds.PoseGraphData(g.poses, ia[keep], ib[keep], np.concatenate([g.meas, g.meas[:7]])[keep],
+                         np.concatenate([g.sqrt_info, g.sqrt_info[:7]])[keep])
+    cmask = np.zeros(37, dtype=np.uint8)
+    cmask[0], cmask[5], cmask[9] = 3, 1, 2
+    prob, poses, og = _pair(gpu, O, g, cmask)
+    before = poses.copy()
+    s = gpu.solve(gpu.SolverOptions(max_num_iterations=12, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=cluster), prob)
+    op, osum, otr = O.solve(og, O.default_options(max_num_iterations=12, linear_solver=1, pcg_cluster=cluster))
+    n = min(len(otr), len(s.iterations))
+    assert list(s.iterations["step_is_successful"][:n]) == [int(x) for x in otr[:n, 8]]
+    assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-7)
+    assert np.array_equal(poses[0], before[0]) and np.array_equal(poses[36], before[36])   # constant / unconstrained
+    assert np.array_equal(poses[5, :3], before[5, :3]) and np.array_equal(poses[9, 3:], before[9, 3:])
+    assert not np.array_equal(poses[5, 3:], before[5, 3:]) and not np.array_equal(poses[9, :3], before[9, :3])
+    assert np.abs(poses - op).max() < 1e-6
+
+
+def test_degenerate_problems_terminate_like_ceres(gpu, ds):
+    g = _random_graph(ds, 6, 10, seed=3, info=None)
+    # every parameter block constant: nothing to optimise, solution usable, poses untouched
+    prob, poses = gpu.problem_from_graph(g, constant_first=False)
+    for v in range(6):
+        prob.set_pose_constant(v)
+    before = poses.copy()
+    s = gpu.solve(gpu.SolverOptions(), prob)
+    assert s.is_solution_usable() and s.num_iterations <= 1 and np.array_equal(poses, before)
+    assert s.final_cost == pytest.approx(s.initial_cost, rel=1e-15)
+    # a non-finite pose: evaluation fails, the solve reports FAILURE and leaves the parameters alone
+    bad = g.poses.copy()
+    bad[2, 1] = np.nan
+    prob2, poses2 = gpu.problem_from_graph(ds.PoseGraphData(bad, g.ia, g.ib, g.meas, None))
+    before2 = poses2.copy()
+    s2 = gpu.solve(gpu.SolverOptions(), prob2)
+    assert s2.termination_type == gpu.FAILURE and not s2.is_solution_usable()
+    assert np.array_equal(poses2, before2, equal_nan=True)
