@@ -124,7 +124,6 @@ void launch_evaluate_edges(const DeviceGraph& g, const double* poses, double* re
 void launch_pcg_init(const DeviceGraph& g, hipStream_t s);
 void launch_pcg_iteration(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s);   // SpMV + update kernels of an odd/even iteration
 void launch_pcg_finish(const DeviceGraph& g, const CgParams& p, hipStream_t s, int publish = 1);   // termination bookkeeping; publish: hand off to the host
-void launch_model_and_retract(const DeviceGraph& g, hipStream_t s);                  // A x, model change, delta, candidate
 void launch_gradient_norm(const DeviceGraph& g, hipStream_t s);
 void launch_finalize_scalars(const DeviceGraph& g, int n_cost_part, hipStream_t s, int gate = 0);   // always hands off to the host
 void launch_apply_step(const DeviceGraph& g, const double* step, hipStream_t s);     // for tests: delta -> candidate

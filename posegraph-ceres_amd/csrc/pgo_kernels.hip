@@ -1269,13 +1269,6 @@ void launch_pcg_iteration(const DeviceGraph& g, const CgParams& p, int odd, hipS
 void launch_pcg_finish(const DeviceGraph& g, const CgParams& p, hipStream_t s, int publish) {
   hipLaunchKernelGGL(k_pcg_finish, dim3(1), dim3(256), 0, s, g, p, publish);
 }
-void launch_model_and_retract(const DeviceGraph& g, hipStream_t s) {
-  const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
-  CgParams dummy{0.0, -1.0, 0, 0};
-  hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1);
-  hipLaunchKernelGGL(k_model_delta, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, 0);
-  hipLaunchKernelGGL(k_retract, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g, 0);
-}
 void launch_spmv_plain(const DeviceGraph& g, hipStream_t s) {
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
   CgParams dummy{0.0, -1.0, 0, 0};

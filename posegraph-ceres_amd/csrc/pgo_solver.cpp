@@ -115,7 +115,7 @@ struct pgo_problem {
   DevBuf<uint8_t> d_slot_side, d_cmask;
   DevBuf<double> d_smeas, d_sW, d_emeas, d_eW, d_eL, d_pose_x, d_pose_c, d_pose_0, d_bsr, d_Hdiag, d_Minv, d_grad,
       d_scale, d_d2, d_diagc, d_cg_b, d_cg_x, d_cg_r, d_cg_z, d_cg_q, d_cg_p0, d_cg_p1, d_delta, d_part_rz, d_part_q,
-      d_part_pq, d_part_rr, d_part_bb, d_part_misc, d_tmp_a, d_tmp_b, d_tmp_c;
+      d_part_rr, d_part_bb, d_part_misc, d_tmp_a, d_tmp_b, d_tmp_c;
   DevBuf<pgo::CgState> d_cg;
   pgo::LmScalars* scal = nullptr;  // pinned, device visible
   // captured CG batches, keyed by the number of iterations in the batch
