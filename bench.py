@@ -162,8 +162,10 @@ def main():
         t_cost = prob.time_kernel("cost", reps)
         t_eval = prob.time_kernel("evaluate", 100)
         # algorithmic bytes, SURVEY.md §8d: block SpMV (symmetric BSR accounting) and fused Jacobian+J'J
-        b_spmv = (N + E) * 288 + 2 * N * 48
-        b_lin = 640 * E + 392 * N
+        # (sharded: rank 0 runs the row kernels on its share of the rows only; the edge-parallel evaluate kernel is not sharded)
+        share = world if sharded else 1
+        b_spmv = ((N + E) * 288 + 2 * N * 48) // share
+        b_lin = (640 * E + 392 * N) // share
         b_eval = 976 * E + 56 * N
         ach = b_spmv / (t_spmv * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes of this same command (tools/rocprof_pmc.py -> profiles/), if present
