@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--poses", type=int, default=N_POSES)
     ap.add_argument("--edges", type=int, default=N_EDGES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=12)
+    ap.add_argument("--cpu-iters", type=int, default=60, help="LM iterations of the CPU baseline sample (~11 s of host work)")
     ap.add_argument("--cluster", type=int, default=2, help="poses per Jacobi block of the PCG preconditioner (1, 2 or 4)")
     args = ap.parse_args()
 

@@ -288,3 +288,36 @@ def test_degenerate_problems_terminate_like_ceres(gpu, ds):
     s2 = gpu.solve(gpu.SolverOptions(), prob2)
     assert s2.termination_type == gpu.FAILURE and not s2.is_solution_usable()
     assert np.array_equal(poses2, before2, equal_nan=True)
+
+
+def test_incremental_problem_growth(gpu, O, ds):
+    """The reference builds its graph once, but the C ABI allows adding poses / edges between solves (SLAM back-ends
+    do): a problem grown in two steps and solved twice ends where a problem built in one go ends."""
+    g = ds.manhattan_se3(400, 1200, seed=5)
+    n1 = 250
+    e1 = np.nonzero((g.ia < n1) & (g.ib < n1))[0]
+    e2 = np.nonzero(~((g.ia < n1) & (g.ib < n1)))[0]
+    poses = g.poses.copy()
+    p = gpu.Problem()
+    p.add_poses(poses[:n1])
+    p.set_loss(gpu.HUBER, 1.0)
+    p.set_pose_constant(0)
+    p.add_se3_between(g.ia[e1], g.ib[e1], g.meas[e1], g.sqrt_info[e1])
+    opt = gpu.SolverOptions(max_num_iterations=40, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY, function_tolerance=1e-12)
+    s1 = gpu.solve(opt, p)
+    assert s1.num_poses == n1 and s1.final_cost < s1.initial_cost
+    first = poses[:n1].copy()
+    p.add_poses(poses[n1:])
+    p.add_se3_between(g.ia[e2], g.ib[e2], g.meas[e2], g.sqrt_info[e2])
+    s2 = gpu.solve(opt, p)
+    assert s2.num_poses == g.N and s2.num_edges == g.E
+    # the same state reached by a problem built in one go from the intermediate poses
+    start = g.poses.copy()
+    start[:n1] = first
+    order = np.concatenate([e1, e2])
+    h = ds.PoseGraphData(start, g.ia[order], g.ib[order], g.meas[order], g.sqrt_info[order])
+    q, qposes = gpu.problem_from_graph(h)
+    s3 = gpu.solve(opt, q)
+    assert s2.initial_cost == pytest.approx(s3.initial_cost, rel=1e-13)
+    assert s2.final_cost == pytest.approx(s3.final_cost, rel=1e-10)
+    assert np.abs(poses - qposes).max() < 1e-8
