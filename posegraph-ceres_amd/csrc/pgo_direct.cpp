@@ -302,11 +302,14 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
         S.rowl_col[q] = k;
       }
   }
-  // ---- 5. cost model of the one-wave-per-column schedule: serial "pair steps" on the critical path ----
-  // a column is processed ten blocks at a time; a block's update list is walked serially by its 6-lane group(s)
-  double steps = 0.0;
+  // ---- 5. schedule + cost model: serial "pair steps" on the critical path ----
+  // COLUMN/FUSED: a column is processed ten blocks at a time by one wave; a block's update list is walked serially by its
+  // 6-lane group(s).  SPLIT: every block of the level has its own wave (ten groups share its list), then a cheap
+  // per-column pass.  A level is split when its one-wave-per-column cost exceeds HEAVY steps.
+  const double HEAVY = 48.0;
+  std::vector<double> level_cost(S.n_levels, 0.0), split_cost(S.n_levels, 0.0);
   for (int l = 0; l < S.n_levels; ++l) {
-    double worst = 0.0;
+    double worst = 0.0, worst_blk = 0.0, worst_fin = 0.0;
     for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
       const int j = S.level_cols[q];
       const int b0 = S.col_ptr[j], nblk = S.col_ptr[j + 1] - b0;
@@ -318,16 +321,58 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
         col += 1.0 + mx;
       }
       worst = std::max(worst, col);
+      for (int u = 0; u < nblk; ++u) worst_blk = std::max(worst_blk, 1.0 + (S.upd_ptr[b0 + u + 1] - S.upd_ptr[b0 + u] + 9) / 10);
+      worst_fin = std::max(worst_fin, 2.0 + (nblk + 9) / 10);
     }
-    steps += worst;
+    level_cost[l] = worst;
+    (void)worst_fin;
+    split_cost[l] = worst_blk + 2.0 + 4.0;   // assemble critical path + one scaling step + one more launch
+  }
+  S.steps.clear();
+  S.split_blk.clear(); S.split_diag.clear(); S.split_sub.clear(); S.split_sub_diag.clear();
+  double steps = 0.0;
+  for (int l = 0; l < S.n_levels;) {
+    const bool heavy = level_cost[l] > HEAVY && split_cost[l] < level_cost[l];
+    if (heavy) {
+      DirectStep st{DirectStep::SPLIT, l, l + 1, (int)S.split_blk.size(), 0, (int)S.split_sub.size(), 0};
+      for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
+        const int j = S.level_cols[q];
+        for (int bi = S.col_ptr[j]; bi < S.col_ptr[j + 1]; ++bi) {
+          S.split_blk.push_back(bi);
+          S.split_diag.push_back(bi == S.col_ptr[j] ? 1 : 0);
+          if (bi != S.col_ptr[j]) { S.split_sub.push_back(bi); S.split_sub_diag.push_back(S.col_ptr[j]); }
+        }
+      }
+      st.blk_end = (int)S.split_blk.size();
+      st.sub_end = (int)S.split_sub.size();
+      S.steps.push_back(st);
+      steps += split_cost[l];
+      ++l;
+    } else if (l >= S.fused_from_level) {
+      int e = l;
+      while (e < S.n_levels && !(level_cost[e] > HEAVY && split_cost[e] < level_cost[e])) { steps += level_cost[e]; ++e; }
+      S.steps.push_back(DirectStep{DirectStep::FUSED, l, e, 0, 0, 0, 0});
+      l = e;
+    } else {
+      S.steps.push_back(DirectStep{DirectStep::COLUMN, l, l + 1, 0, 0, 0, 0});
+      steps += level_cost[l];
+      ++l;
+    }
   }
   S.est_steps = steps;
-  if (getenv("PGO_VERBOSE"))
-    std::fprintf(stderr, "[pgo] direct: n=%d blocks=%d pairs=%lld levels=%d (fused from %d) est_steps=%.0f\n", S.n, S.nb,
-                 S.n_pairs, S.n_levels, S.fused_from_level, steps);
-  // dense separators (Manhattan/sphere-like graphs) need supernodal fronts; this schedule is for chain-like
-  // graphs with small separators (the reference's KITTI runs).  Beyond the budget the iterative path is faster.
-  if (S.fused_from_level > 1500 || steps > 60000.0) return false;
+  {
+    int n_split = 0;
+    for (const DirectStep& st : S.steps) n_split += st.type == DirectStep::SPLIT;
+    if (getenv("PGO_VERBOSE"))
+      std::fprintf(stderr, "[pgo] direct: n=%d blocks=%d pairs=%lld levels=%d (fused from %d, %d split, %zu launches) est_steps=%.0f\n",
+                   S.n, S.nb, S.n_pairs, S.n_levels, S.fused_from_level, n_split, S.steps.size() + n_split, steps);
+  }
+  // The alternative for an exact request is PCG run to 1e-13, whose cost depends on the conditioning, not on the fill:
+  // ~8 ms per solve on Manhattan 10 k (well conditioned, est 8.7 k steps = 12 ms direct), ~40 ms on KITTI-00 dense (est
+  // 3.2 k steps = 4.8 ms direct), seconds on the open chain of the KITTI-00 replay.  One step is ~1.4 us; the budget below
+  // (PGO_DIRECT_MAX_STEPS to override) sends the well-conditioned mesh-like graphs to PCG and keeps the rest direct.
+  static const double max_steps = getenv("PGO_DIRECT_MAX_STEPS") ? atof(getenv("PGO_DIRECT_MAX_STEPS")) : 6000.0;
+  if (S.steps.size() > 4000 || steps > max_steps) return false;
   return true;
 }
 

@@ -31,8 +31,24 @@ struct DirectPlan {
   const int* rowl_ptr;    // [n+1] forward solve: blocks (j,k), k < j, of row j ...
   const int* rowl_blk;    //       ... block index
   const int* rowl_col;    //       ... column k
+  const int* split_blk;       // blocks of the "split" levels (heavy levels: one wave per BLOCK assembles, see DirectStep)
+  const uint8_t* split_diag;  // ... 1 when the block is the diagonal block of its column
+  const int* split_sub;       // sub-diagonal blocks of the split levels ...
+  const int* split_sub_diag;  // ... and the diagonal block of their column
   double* Lval;           // [nb][36] row-major blocks of the factor
   double* y;              // [6n] permuted work vector
+};
+
+// Launch schedule of the factorisation.  A level of the elimination tree is processed either
+//   COLUMN : one wave per block column does everything (assemble, 6x6 Cholesky, scale) — many light columns;
+//   FUSED  : a run of consecutive light levels with <= 8 columns each in ONE single-workgroup launch (chain-like tops);
+//   SPLIT  : heavy level (long update lists: dense separators) — one wave per BLOCK assembles V = A - sum L L^T across
+//            the whole GPU, then one wave per column factors the diagonal block and scales the column.
+struct DirectStep {
+  enum Type { COLUMN = 0, FUSED = 1, SPLIT = 2 };
+  int type, level_begin, level_end;   // levels [begin, end)
+  int blk_begin, blk_end;             // SPLIT: range in split_blk
+  int sub_begin, sub_end;             // SPLIT: range in split_sub
 };
 
 struct DirectSymbolic {
@@ -41,7 +57,10 @@ struct DirectSymbolic {
       rowl_ptr, rowl_blk, rowl_col;
   int n = 0, nb = 0, n_levels = 0;
   long long n_pairs = 0;
-  int fused_from_level = 0;  // levels >= this are processed by one single-workgroup launch
+  int fused_from_level = 0;  // first level of the suffix whose levels hold <= 8 columns (forward/backward solves fuse it)
+  std::vector<DirectStep> steps;   // factorisation schedule
+  std::vector<int> split_blk, split_sub, split_sub_diag;
+  std::vector<uint8_t> split_diag;
   double flops = 0;
   double est_steps = 0;      // critical-path length of the schedule in update-pair steps (cost model)
 };
@@ -54,7 +73,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
                     DirectSymbolic* out);
 
 // Device launches.  flags[2] is set when a pivot is not positive.
-void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const int* level_ptr_host, int fused_from_level, hipStream_t s);
+void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const DirectSymbolic& sym, hipStream_t s);
 void launch_direct_solve(const DeviceGraph& g, const DirectPlan& p, const int* level_ptr_host, int fused_from_level, hipStream_t s);
 
 }  // namespace pgo

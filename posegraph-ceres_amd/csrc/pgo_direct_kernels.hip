@@ -139,16 +139,101 @@ __device__ void factor_column(const DeviceGraph& g, const DirectPlan& p, int j, 
   }
 }
 
+// In-register Cholesky of a 6x6 block held (row-major, 36 doubles) by every lane; returns false on a non-positive pivot.
+__device__ __forceinline__ bool chol6_inplace(double* Ljj) {
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double d = Ljj[7 * c];
+#pragma unroll
+    for (int k = 0; k < c; ++k) d -= Ljj[6 * c + k] * Ljj[6 * c + k];
+    if (!(d > 0.0)) { ok = false; d = 1.0; }
+    d = sqrt(d);
+    Ljj[7 * c] = d;
+    const double inv = 1.0 / d;
+#pragma unroll
+    for (int i = c + 1; i < 6; ++i) {
+      double s = Ljj[6 * i + c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) s -= Ljj[6 * i + k] * Ljj[6 * c + k];
+      Ljj[6 * i + c] = s * inv;
+    }
+#pragma unroll
+    for (int i = 0; i < c; ++i) Ljj[6 * i + c] = 0.0;
+  }
+  return ok;
+}
+
+// ---- SPLIT levels (dense separators): phase 1, one wave per BLOCK: V = A - sum_q L[upd_a] L[upd_b]^T, the update list
+// shared by the ten 6-lane groups, partial rows summed through LDS in a fixed order.  A diagonal block is factorised on
+// the spot (L_jj), an off-diagonal block is left as V in Lval for phase 2. ----
+__global__ __launch_bounds__(64) void k_chol_assemble(DeviceGraph g, DirectPlan p, int blk_begin) {
+  __shared__ double sh[360];
+  const int bi = p.split_blk[blk_begin + blockIdx.x];
+  const int lane = threadIdx.x;
+  const int grp = lane / 6, r = lane - 6 * grp;
+  if (grp < 10) {
+    double v[6];
+    assemble_row(g, p, bi, r, grp, 10, v);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) sh[(grp * 6 + r) * 6 + c] = v[c];
+  }
+  __syncthreads();
+  const bool diagonal = p.split_diag[blk_begin + blockIdx.x] != 0;
+  if (!diagonal) {
+    if (lane < 36) {
+      double s = 0.0;
+#pragma unroll
+      for (int gq = 0; gq < 10; ++gq) s += sh[gq * 36 + lane];
+      p.Lval[36 * (size_t)bi + lane] = s;
+    }
+    return;
+  }
+  double Ljj[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) {
+    double s = 0.0;
+#pragma unroll
+    for (int gq = 0; gq < 10; ++gq) s += sh[gq * 36 + k];
+    Ljj[k] = s;
+  }
+  const bool ok = chol6_inplace(Ljj);
+  if (!ok && lane == 0) atomicOr(&g.flags[2], 1);
+  if (lane < 36) p.Lval[36 * (size_t)bi + lane] = Ljj[lane];
+}
+
+// phase 2, one 6-lane group per sub-diagonal block of the level (ten per wave, lane = row): L_ij = V_ij L_jj^-T
+__global__ __launch_bounds__(64) void k_chol_scale(DeviceGraph g, DirectPlan p, int sub_begin, int sub_end) {
+  const int lane = threadIdx.x;
+  const int grp = lane / 6, r = lane - 6 * grp;
+  const int q = sub_begin + blockIdx.x * 10 + grp;
+  if (grp >= 10 || q >= sub_end) return;
+  const int bi = p.split_sub[q];
+  const double* L = p.Lval + 36 * (size_t)p.split_sub_diag[q];   // L_jj of the block's column (lower triangular)
+  double2* o = reinterpret_cast<double2*>(p.Lval + 36 * (size_t)bi + 6 * r);
+  const double2 a = o[0], b = o[1], c2 = o[2];
+  const double v[6] = {a.x, a.y, b.x, b.y, c2.x, c2.y};
+  double x[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double s = v[c];
+#pragma unroll
+    for (int k = 0; k < c; ++k) s -= x[k] * L[6 * c + k];
+    x[c] = s / L[7 * c];
+  }
+  o[0] = double2{x[0], x[1]}; o[1] = double2{x[2], x[3]}; o[2] = double2{x[4], x[5]};
+}
+
 __global__ __launch_bounds__(64) void k_chol_level(DeviceGraph g, DirectPlan p, int level) {
   __shared__ double sh[360];
   const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
   factor_column(g, p, j, sh);
 }
 
-__global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_tail(DeviceGraph g, DirectPlan p, int from_level) {
+__global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_tail(DeviceGraph g, DirectPlan p, int from_level, int to_level) {
   __shared__ double sh[FUSED_WAVES][360];
   const int wave = threadIdx.x >> 6;
-  for (int l = from_level; l < p.n_levels; ++l) {
+  for (int l = from_level; l < to_level; ++l) {
     const int c0 = p.level_ptr[l], nc = p.level_ptr[l + 1] - c0;
     if (wave < nc) factor_column(g, p, p.level_cols[c0 + wave], sh[wave]);
     __threadfence_block();
@@ -157,12 +242,14 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_tail(DeviceGraph g, D
 }
 
 // ---- forward solve  L y = P (S g):  y_j = L_jj^-1 (b_j - sum_k L_jk y_k) ----
-__device__ void forward_column(const DeviceGraph& g, const DirectPlan& p, int j, double* sh) {
+// The row list of column j is shared by `nsub` waves x ten 6-lane groups; partial sums land in sh[64] of each wave
+// (sh_all = the first of the nsub consecutive per-wave arrays), the finishing lane adds them in a fixed order.
+__device__ __forceinline__ void forward_partial(const DirectPlan& p, int j, int sub, int nsub, double* sh) {
   const int lane = threadIdx.x & 63;
   const int grp = lane / 6, r = lane - 6 * grp;
   double acc = 0.0;
   if (grp < 10) {
-    for (int q = p.rowl_ptr[j] + grp; q < p.rowl_ptr[j + 1]; q += 10) {
+    for (int q = p.rowl_ptr[j] + sub * 10 + grp; q < p.rowl_ptr[j + 1]; q += 10 * nsub) {
       double a[6];
       load_row(p.Lval, p.rowl_blk[q], r, a);
       const double* yk = p.y + 6 * (size_t)p.rowl_col[q];
@@ -171,40 +258,39 @@ __device__ void forward_column(const DeviceGraph& g, const DirectPlan& p, int j,
     }
     sh[lane] = acc;
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (lane == 0) {
-    const int old = p.perm[j];
-    double rhs[6], y[6];
+}
+__device__ __forceinline__ void forward_finish(const DeviceGraph& g, const DirectPlan& p, int j, int nsub, const double* sh_all) {
+  const int old = p.perm[j];
+  double rhs[6], y[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const double b = g.scale[6 * (size_t)old + i] * g.grad[6 * (size_t)old + i];
-      g.cg_b[6 * (size_t)old + i] = b;
-      double s = 0.0;
-      for (int gq = 0; gq < 10; ++gq) s += sh[6 * gq + i];
-      rhs[i] = b - s;
-    }
-    const double* L = p.Lval + 36 * (size_t)p.col_ptr[j];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      double s = rhs[i];
-#pragma unroll
-      for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
-      y[i] = s / L[7 * i];
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) p.y[6 * (size_t)j + i] = y[i];
+  for (int i = 0; i < 6; ++i) {
+    const double b = g.scale[6 * (size_t)old + i] * g.grad[6 * (size_t)old + i];
+    g.cg_b[6 * (size_t)old + i] = b;
+    double s = 0.0;
+    for (int w = 0; w < nsub; ++w)
+      for (int gq = 0; gq < 10; ++gq) s += sh_all[64 * w + 6 * gq + i];
+    rhs[i] = b - s;
   }
+  const double* L = p.Lval + 36 * (size_t)p.col_ptr[j];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double s = rhs[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
+    y[i] = s / L[7 * i];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) p.y[6 * (size_t)j + i] = y[i];
 }
 
 // ---- backward solve  L^T x = y:  x_j = L_jj^-T (y_j - sum_{i in struct(j)} L_ij^T x_i) ----
-__device__ void backward_column(const DeviceGraph& g, const DirectPlan& p, int j, double* sh) {
+__device__ __forceinline__ void backward_partial(const DirectPlan& p, int j, int sub, int nsub, double* sh) {
   const int lane = threadIdx.x & 63;
   const int grp = lane / 6, c = lane - 6 * grp;   // lane owns COLUMN c of L_ij (component c of L_ij^T x_i)
   const int b0 = p.col_ptr[j], nblk = p.col_ptr[j + 1] - b0;
   double acc = 0.0;
   if (grp < 10) {
-    for (int t = 1 + grp; t < nblk; t += 10) {
+    for (int t = 1 + sub * 10 + grp; t < nblk; t += 10 * nsub) {
       const double* B = p.Lval + 36 * (size_t)(b0 + t);
       const double* xi = p.y + 6 * (size_t)p.blk_row[b0 + t];
 #pragma unroll
@@ -212,54 +298,70 @@ __device__ void backward_column(const DeviceGraph& g, const DirectPlan& p, int j
     }
     sh[lane] = acc;
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (lane == 0) {
-    double rhs[6], x[6];
+}
+__device__ __forceinline__ void backward_finish(const DeviceGraph& g, const DirectPlan& p, int j, int nsub, const double* sh_all) {
+  const int b0 = p.col_ptr[j];
+  double rhs[6], x[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      double s = 0.0;
-      for (int gq = 0; gq < 10; ++gq) s += sh[6 * gq + i];
-      rhs[i] = p.y[6 * (size_t)j + i] - s;
-    }
-    const double* L = p.Lval + 36 * (size_t)b0;
-#pragma unroll
-    for (int i = 5; i >= 0; --i) {
-      double s = rhs[i];
-#pragma unroll
-      for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
-      x[i] = s / L[7 * i];
-    }
-    const int old = p.perm[j];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { p.y[6 * (size_t)j + i] = x[i]; g.cg_x[6 * (size_t)old + i] = x[i]; }
+  for (int i = 0; i < 6; ++i) {
+    double s = 0.0;
+    for (int w = 0; w < nsub; ++w)
+      for (int gq = 0; gq < 10; ++gq) s += sh_all[64 * w + 6 * gq + i];
+    rhs[i] = p.y[6 * (size_t)j + i] - s;
   }
+  const double* L = p.Lval + 36 * (size_t)b0;
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double s = rhs[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
+    x[i] = s / L[7 * i];
+  }
+  const int old = p.perm[j];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { p.y[6 * (size_t)j + i] = x[i]; g.cg_x[6 * (size_t)old + i] = x[i]; }
 }
 
 __global__ __launch_bounds__(64) void k_fwd_level(DeviceGraph g, DirectPlan p, int level) {
   __shared__ double sh[64];
-  forward_column(g, p, p.level_cols[p.level_ptr[level] + blockIdx.x], sh);
+  const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
+  forward_partial(p, j, 0, 1, sh);
+  __syncthreads();
+  if (threadIdx.x == 0) forward_finish(g, p, j, 1, sh);
 }
 __global__ __launch_bounds__(64) void k_bwd_level(DeviceGraph g, DirectPlan p, int level) {
   __shared__ double sh[64];
-  backward_column(g, p, p.level_cols[p.level_ptr[level] + blockIdx.x], sh);
+  const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
+  backward_partial(p, j, 0, 1, sh);
+  __syncthreads();
+  if (threadIdx.x == 0) backward_finish(g, p, j, 1, sh);
 }
+// Fused tail (levels with <= FUSED_WAVES columns): the FUSED_WAVES waves of the single workgroup are divided among the
+// columns of the level, so the long row lists of a dense separator chain (one column per level) are walked 80-wide.
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_fwd_tail(DeviceGraph g, DirectPlan p, int from_level) {
   __shared__ double sh[FUSED_WAVES][64];
-  const int wave = threadIdx.x >> 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int l = from_level; l < p.n_levels; ++l) {
     const int c0 = p.level_ptr[l], nc = p.level_ptr[l + 1] - c0;
-    if (wave < nc) forward_column(g, p, p.level_cols[c0 + wave], sh[wave]);
+    const int nsub = max(1, FUSED_WAVES / nc);
+    const int col = wave / nsub, sub = wave - col * nsub;
+    if (col < nc) forward_partial(p, p.level_cols[c0 + col], sub, nsub, sh[wave]);
+    __syncthreads();
+    if (col < nc && sub == 0 && lane == 0) forward_finish(g, p, p.level_cols[c0 + col], nsub, sh[wave]);
     __threadfence_block();
     __syncthreads();
   }
 }
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_bwd_tail(DeviceGraph g, DirectPlan p, int from_level) {
   __shared__ double sh[FUSED_WAVES][64];
-  const int wave = threadIdx.x >> 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int l = p.n_levels - 1; l >= from_level; --l) {
     const int c0 = p.level_ptr[l], nc = p.level_ptr[l + 1] - c0;
-    if (wave < nc) backward_column(g, p, p.level_cols[c0 + wave], sh[wave]);
+    const int nsub = max(1, FUSED_WAVES / nc);
+    const int col = wave / nsub, sub = wave - col * nsub;
+    if (col < nc) backward_partial(p, p.level_cols[c0 + col], sub, nsub, sh[wave]);
+    __syncthreads();
+    if (col < nc && sub == 0 && lane == 0) backward_finish(g, p, p.level_cols[c0 + col], nsub, sh[wave]);
     __threadfence_block();
     __syncthreads();
   }
@@ -267,12 +369,19 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_bwd_tail(DeviceGraph g, Di
 
 }  // namespace
 
-void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const int* level_ptr_host, int fused_from_level, hipStream_t s) {
-  for (int l = 0; l < fused_from_level; ++l) {
-    const int nc = level_ptr_host[l + 1] - level_ptr_host[l];
-    hipLaunchKernelGGL(k_chol_level, dim3(nc), dim3(64), 0, s, g, p, l);
+void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const DirectSymbolic& sym, hipStream_t s) {
+  for (const DirectStep& st : sym.steps) {
+    if (st.type == DirectStep::COLUMN) {
+      const int nc = sym.level_ptr[st.level_begin + 1] - sym.level_ptr[st.level_begin];
+      hipLaunchKernelGGL(k_chol_level, dim3(nc), dim3(64), 0, s, g, p, st.level_begin);
+    } else if (st.type == DirectStep::FUSED) {
+      hipLaunchKernelGGL(k_chol_tail, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, st.level_begin, st.level_end);
+    } else {
+      hipLaunchKernelGGL(k_chol_assemble, dim3(st.blk_end - st.blk_begin), dim3(64), 0, s, g, p, st.blk_begin);
+      const int nsub = st.sub_end - st.sub_begin;
+      if (nsub > 0) hipLaunchKernelGGL(k_chol_scale, dim3((nsub + 9) / 10), dim3(64), 0, s, g, p, st.sub_begin, st.sub_end);
+    }
   }
-  if (fused_from_level < p.n_levels) hipLaunchKernelGGL(k_chol_tail, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, fused_from_level);
 }
 
 void launch_direct_solve(const DeviceGraph& g, const DirectPlan& p, const int* level_ptr_host, int fused_from_level, hipStream_t s) {

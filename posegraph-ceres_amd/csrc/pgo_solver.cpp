@@ -131,6 +131,8 @@ struct pgo_problem {
   pgo::DirectSymbolic dsym;
   pgo::DirectPlan dplan{};
   bool direct_analyzed = false, direct_usable = false;
+  DevBuf<int> dd_split_blk, dd_split_sub, dd_split_sub_diag;
+  DevBuf<uint8_t> dd_split_diag;
   DevBuf<int> dd_perm, dd_col_ptr, dd_blk_row, dd_asrc_ptr, dd_asrc_slot, dd_upd_ptr, dd_upd_a, dd_upd_b, dd_level_ptr,
       dd_level_cols, dd_rowl_ptr, dd_rowl_blk, dd_rowl_col;
   DevBuf<double> dd_Lval, dd_y;
@@ -668,6 +670,12 @@ int prepare_direct(pgo_problem* P) {
   HIP_TRY(P->dd_rowl_ptr.upload(S.rowl_ptr, s));
   HIP_TRY(P->dd_rowl_blk.upload(S.rowl_blk, s));
   HIP_TRY(P->dd_rowl_col.upload(S.rowl_col, s));
+  HIP_TRY(P->dd_split_blk.upload(S.split_blk, s));
+  HIP_TRY(P->dd_split_diag.upload(S.split_diag, s));
+  HIP_TRY(P->dd_split_sub.upload(S.split_sub, s));
+  HIP_TRY(P->dd_split_sub_diag.upload(S.split_sub_diag, s));
+  if (S.split_blk.empty()) { HIP_TRY(P->dd_split_blk.alloc(1)); HIP_TRY(P->dd_split_diag.alloc(1)); }
+  if (S.split_sub.empty()) { HIP_TRY(P->dd_split_sub.alloc(1)); HIP_TRY(P->dd_split_sub_diag.alloc(1)); }
   HIP_TRY(P->dd_Lval.alloc((size_t)36 * S.nb));
   HIP_TRY(P->dd_y.alloc((size_t)6 * S.n));
   pgo::DirectPlan& d = P->dplan;
@@ -676,7 +684,8 @@ int prepare_direct(pgo_problem* P) {
   d.asrc_ptr = P->dd_asrc_ptr.p; d.asrc_slot = P->dd_asrc_slot.p; d.upd_ptr = P->dd_upd_ptr.p;
   d.upd_a = P->dd_upd_a.p; d.upd_b = P->dd_upd_b.p; d.level_ptr = P->dd_level_ptr.p; d.level_cols = P->dd_level_cols.p;
   d.rowl_ptr = P->dd_rowl_ptr.p; d.rowl_blk = P->dd_rowl_blk.p; d.rowl_col = P->dd_rowl_col.p;
-  d.Lval = P->dd_Lval.p; d.y = P->dd_y.p;
+  d.Lval = P->dd_Lval.p; d.y = P->dd_y.p; d.split_blk = P->dd_split_blk.p;
+  d.split_diag = P->dd_split_diag.p; d.split_sub = P->dd_split_sub.p; d.split_sub_diag = P->dd_split_sub_diag.p;
   P->drop_direct_graph();
   P->direct_usable = true;
   return PGO_OK;
@@ -689,7 +698,7 @@ int run_direct(pgo_problem* P) {
   if (P->use_graph && !P->direct_exec) {
     hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
-      pgo::launch_direct_factor(P->g, P->dplan, S.level_ptr.data(), S.fused_from_level, s);
+      pgo::launch_direct_factor(P->g, P->dplan, S, s);
       pgo::launch_direct_solve(P->g, P->dplan, S.level_ptr.data(), S.fused_from_level, s);
       e = hipStreamEndCapture(s, &P->direct_graph);
       if (e == hipSuccess) e = hipGraphInstantiate(&P->direct_exec, P->direct_graph, nullptr, nullptr, 0);
@@ -699,7 +708,7 @@ int run_direct(pgo_problem* P) {
   if (P->direct_exec) {
     HIP_TRY(hipGraphLaunch(P->direct_exec, s));
   } else {
-    pgo::launch_direct_factor(P->g, P->dplan, S.level_ptr.data(), S.fused_from_level, s);
+    pgo::launch_direct_factor(P->g, P->dplan, S, s);
     pgo::launch_direct_solve(P->g, P->dplan, S.level_ptr.data(), S.fused_from_level, s);
   }
   return PGO_OK;
