@@ -34,16 +34,38 @@ __device__ __forceinline__ void assemble_row(const DeviceGraph& g, const DirectP
       for (int c = 0; c < 6; ++c) v[c] += g.bsr_val[bsr_index(slot, 6 * r + c)];
     }
   }
-  for (int q = p.upd_ptr[bi] + sub; q < p.upd_ptr[bi + 1]; q += stride) {
-    double a[6];
-    load_row(p.Lval, p.upd_a[q], r, a);
-    const double* B = p.Lval + 36 * (size_t)p.upd_b[q];
+  // two pairs per trip, all loads of both issued before the arithmetic (the walk is latency-bound: each pair is two
+  // dependent round trips — index, then 48 + 288 bytes of L)
+  const int q_end = p.upd_ptr[bi + 1];
+  int q = p.upd_ptr[bi] + sub;
+  for (; q + stride < q_end; q += 2 * stride) {
+    const int ia0 = p.upd_a[q], ib0 = p.upd_b[q], ia1 = p.upd_a[q + stride], ib1 = p.upd_b[q + stride];
+    double a0[6], a1[6];
+    load_row(p.Lval, ia0, r, a0);
+    load_row(p.Lval, ia1, r, a1);
+    const double2* B0 = reinterpret_cast<const double2*>(p.Lval + 36 * (size_t)ib0);
+    const double2* B1 = reinterpret_cast<const double2*>(p.Lval + 36 * (size_t)ib1);
+    double2 b0[18], b1[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) { b0[k] = B0[k]; b1[k] = B1[k]; }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      double s = 0.0;
+      const double s0 = a0[0] * b0[3 * c].x + a0[1] * b0[3 * c].y + a0[2] * b0[3 * c + 1].x + a0[3] * b0[3 * c + 1].y +
+                        a0[4] * b0[3 * c + 2].x + a0[5] * b0[3 * c + 2].y;
+      const double s1 = a1[0] * b1[3 * c].x + a1[1] * b1[3 * c].y + a1[2] * b1[3 * c + 1].x + a1[3] * b1[3 * c + 1].y +
+                        a1[4] * b1[3 * c + 2].x + a1[5] * b1[3 * c + 2].y;
+      v[c] -= s0;
+      v[c] -= s1;
+    }
+  }
+  if (q < q_end) {
+    double a[6];
+    load_row(p.Lval, p.upd_a[q], r, a);
+    const double2* B = reinterpret_cast<const double2*>(p.Lval + 36 * (size_t)p.upd_b[q]);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) s += a[k] * B[6 * c + k];
-      v[c] -= s;
+    for (int c = 0; c < 6; ++c) {
+      const double2 x0 = B[3 * c], x1 = B[3 * c + 1], x2 = B[3 * c + 2];
+      v[c] -= a[0] * x0.x + a[1] * x0.y + a[2] * x1.x + a[3] * x1.y + a[4] * x2.x + a[5] * x2.y;
     }
   }
 }
