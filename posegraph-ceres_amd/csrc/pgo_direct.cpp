@@ -329,11 +329,81 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
     split_cost[l] = worst_blk + 2.0 + 4.0;   // assemble critical path + one scaling step + one more launch
   }
   S.steps.clear();
-  S.split_blk.clear(); S.split_diag.clear(); S.split_sub.clear(); S.split_sub_diag.clear();
+  S.split_blk.clear(); S.split_diag.clear(); S.split_sub.clear(); S.split_sub_diag.clear(); S.panel_cols.clear();
+  S.upd_split.assign(S.nb, 0);
+  for (int t = 0; t < S.nb; ++t) S.upd_split[t] = S.upd_ptr[t + 1];
+  std::vector<int> blk_col(S.nb);                 // column of every block of L (source column of an update pair)
+  for (int j = 0; j < N; ++j) for (int bi = S.col_ptr[j]; bi < S.col_ptr[j + 1]; ++bi) blk_col[bi] = j;
+  static const int PANEL_MAX = getenv("PGO_DIRECT_PANEL") ? std::max(1, std::min(16, atoi(getenv("PGO_DIRECT_PANEL")))) : 8;
+  auto is_heavy = [&](int l) { return level_cost[l] > HEAVY && split_cost[l] < level_cost[l]; };
+  std::vector<int> tmp_a, tmp_b, tmp_pa, tmp_pb;
   double steps = 0.0;
   for (int l = 0; l < S.n_levels;) {
-    const bool heavy = level_cost[l] > HEAVY && split_cost[l] < level_cost[l];
-    if (heavy) {
+    if (is_heavy(l)) {
+      // grow a panel: the next level has the same number of columns (<= 8), each the etree parent of one column here
+      const int nc = S.level_ptr[l + 1] - S.level_ptr[l];
+      std::vector<std::vector<int>> chain(nc);
+      for (int c = 0; c < nc; ++c) chain[c].push_back(S.level_cols[S.level_ptr[l] + c]);
+      int w = 1;
+      while (nc <= 8 && w < PANEL_MAX && l + w < S.n_levels && is_heavy(l + w) &&
+             S.level_ptr[l + w + 1] - S.level_ptr[l + w] == nc) {
+        std::vector<int> next(nc, -1);
+        bool ok = true;
+        for (int c = 0; c < nc && ok; ++c) {
+          const int par = parent[chain[c].back()];
+          bool found = false;
+          for (int q = S.level_ptr[l + w]; q < S.level_ptr[l + w + 1]; ++q) if (S.level_cols[q] == par) found = true;
+          for (int c2 = 0; c2 < c; ++c2) if (next[c2] == par) found = false;   // two chains merging: stop here
+          if (!found) ok = false; else next[c] = par;
+        }
+        if (!ok) break;
+        for (int c = 0; c < nc; ++c) chain[c].push_back(next[c]);
+        ++w;
+      }
+      if (w >= 2) {
+        DirectStep st{DirectStep::PANEL, l, l + w, (int)S.split_blk.size(), 0, (int)S.panel_cols.size(), nc};
+        double p1 = 0.0, p2 = 0.0;
+        for (int c = 0; c < nc; ++c) {
+          const int first = chain[c][0];     // columns of one chain are consecutive in the elimination order? not assumed
+          double chain_p2 = 0.0;
+          for (int i = 0; i < w; ++i) {
+            const int j = chain[c][i];
+            S.panel_cols.push_back(j);
+            const int nblk = S.col_ptr[j + 1] - S.col_ptr[j];
+            for (int bi = S.col_ptr[j]; bi < S.col_ptr[j + 1]; ++bi) {
+              S.split_blk.push_back(bi);
+              S.split_diag.push_back(0);
+              // in-panel pairs = those whose source column is one of this chain's earlier panel columns; they are moved
+              // (stably) behind the pairs of the columns before the panel, whose L blocks are final when phase 1 runs
+              int q = S.upd_ptr[bi + 1];
+              if (i > 0) {
+                tmp_a.clear(); tmp_b.clear(); tmp_pa.clear(); tmp_pb.clear();
+                for (int u = S.upd_ptr[bi]; u < S.upd_ptr[bi + 1]; ++u) {
+                  const int k = blk_col[S.upd_a[u]];
+                  bool in_panel = false;
+                  for (int i2 = 0; i2 < i; ++i2) if (chain[c][i2] == k) in_panel = true;
+                  (in_panel ? tmp_pa : tmp_a).push_back(S.upd_a[u]);
+                  (in_panel ? tmp_pb : tmp_b).push_back(S.upd_b[u]);
+                }
+                int u = S.upd_ptr[bi];
+                for (size_t z = 0; z < tmp_a.size(); ++z, ++u) { S.upd_a[u] = tmp_a[z]; S.upd_b[u] = tmp_b[z]; }
+                q = u;
+                for (size_t z = 0; z < tmp_pa.size(); ++z, ++u) { S.upd_a[u] = tmp_pa[z]; S.upd_b[u] = tmp_pb[z]; }
+              }
+              S.upd_split[bi] = q;
+              p1 = std::max(p1, 1.0 + (q - S.upd_ptr[bi] + 9) / 10);
+            }
+            chain_p2 += 3.0 + ((nblk - 1 + 79) / 80) * (1.0 + i);
+          }
+          (void)first;
+          p2 = std::max(p2, chain_p2);
+        }
+        st.blk_end = (int)S.split_blk.size();
+        S.steps.push_back(st);
+        steps += p1 + p2 + 8.0;
+        l += w;
+        continue;
+      }
       DirectStep st{DirectStep::SPLIT, l, l + 1, (int)S.split_blk.size(), 0, (int)S.split_sub.size(), 0};
       for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
         const int j = S.level_cols[q];
@@ -350,7 +420,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
       ++l;
     } else if (l >= S.fused_from_level) {
       int e = l;
-      while (e < S.n_levels && !(level_cost[e] > HEAVY && split_cost[e] < level_cost[e])) { steps += level_cost[e]; ++e; }
+      while (e < S.n_levels && !is_heavy(e)) { steps += level_cost[e]; ++e; }
       S.steps.push_back(DirectStep{DirectStep::FUSED, l, e, 0, 0, 0, 0});
       l = e;
     } else {
@@ -359,19 +429,30 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
       ++l;
     }
   }
+  // triangular solves: two launches per level before the fused tail, ~6 us of in-workgroup hand-over per tail level plus
+  // the row / column lists shared by 80 six-lane groups
+  for (int l = 0; l < S.n_levels; ++l) {
+    if (l < S.fused_from_level) { steps += 8.0; continue; }
+    double worst = 0.0;
+    for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
+      const int j = S.level_cols[q];
+      worst = std::max(worst, (double)(S.rowl_ptr[j + 1] - S.rowl_ptr[j] + S.col_ptr[j + 1] - S.col_ptr[j]) / 80.0);
+    }
+    steps += 8.0 + worst;
+  }
   S.est_steps = steps;
   {
-    int n_split = 0;
-    for (const DirectStep& st : S.steps) n_split += st.type == DirectStep::SPLIT;
+    int n_split = 0, n_panel = 0;
+    for (const DirectStep& st : S.steps) { n_split += st.type == DirectStep::SPLIT; n_panel += st.type == DirectStep::PANEL; }
     if (getenv("PGO_VERBOSE"))
-      std::fprintf(stderr, "[pgo] direct: n=%d blocks=%d pairs=%lld levels=%d (fused from %d, %d split, %zu launches) est_steps=%.0f\n",
-                   S.n, S.nb, S.n_pairs, S.n_levels, S.fused_from_level, n_split, S.steps.size() + n_split, steps);
+      std::fprintf(stderr, "[pgo] direct: n=%d blocks=%d pairs=%lld levels=%d (fused from %d, %d split, %d panels, %zu launches) est_steps=%.0f\n",
+                   S.n, S.nb, S.n_pairs, S.n_levels, S.fused_from_level, n_split, n_panel, S.steps.size() + n_split + n_panel, steps);
   }
   // The alternative for an exact request is PCG run to 1e-13, whose cost depends on the conditioning, not on the fill:
   // ~8 ms per solve on Manhattan 10 k (well conditioned, est 8.7 k steps = 12 ms direct), ~40 ms on KITTI-00 dense (est
-  // 3.2 k steps = 4.8 ms direct), seconds on the open chain of the KITTI-00 replay.  One step is ~1.4 us; the budget below
+  // 4.2 ms direct), seconds on the open chain of the KITTI-00 replay.  One step is ~1 us; the budget below
   // (PGO_DIRECT_MAX_STEPS to override) sends the well-conditioned mesh-like graphs to PCG and keeps the rest direct.
-  static const double max_steps = getenv("PGO_DIRECT_MAX_STEPS") ? atof(getenv("PGO_DIRECT_MAX_STEPS")) : 6000.0;
+  static const double max_steps = getenv("PGO_DIRECT_MAX_STEPS") ? atof(getenv("PGO_DIRECT_MAX_STEPS")) : 7000.0;
   if (S.steps.size() > 4000 || steps > max_steps) return false;
   return true;
 }

@@ -35,6 +35,8 @@ struct DirectPlan {
   const uint8_t* split_diag;  // ... 1 when the block is the diagonal block of its column
   const int* split_sub;       // sub-diagonal blocks of the split levels ...
   const int* split_sub_diag;  // ... and the diagonal block of their column
+  const int* upd_split;       // [nb] PANEL steps: update pairs [upd_ptr, upd_split) come from columns before the panel
+  const int* panel_cols;      // PANEL steps: chains of columns, chain c of a step at [begin + c*width, begin + (c+1)*width)
   double* Lval;           // [nb][36] row-major blocks of the factor
   double* y;              // [6n] permuted work vector
 };
@@ -43,12 +45,16 @@ struct DirectPlan {
 //   COLUMN : one wave per block column does everything (assemble, 6x6 Cholesky, scale) — many light columns;
 //   FUSED  : a run of consecutive light levels with <= 8 columns each in ONE single-workgroup launch (chain-like tops);
 //   SPLIT  : heavy level (long update lists: dense separators) — one wave per BLOCK assembles V = A - sum L L^T across
-//            the whole GPU, then one wave per column factors the diagonal block and scales the column.
+//            the whole GPU (the diagonal block is factorised on the spot), then one 6-lane group per block scales;
+//   PANEL  : `width` consecutive heavy levels whose columns form parent chains (a dense separator): the contributions
+//            of all columns BEFORE the panel are assembled one wave per block for every block of the panel at once,
+//            then one workgroup per chain finishes its columns in order (the few in-panel pairs, 6x6 Cholesky, scaling)
+//            — two launches for `width` levels instead of two per level, and one critical path instead of `width`.
 struct DirectStep {
-  enum Type { COLUMN = 0, FUSED = 1, SPLIT = 2 };
+  enum Type { COLUMN = 0, FUSED = 1, SPLIT = 2, PANEL = 3 };
   int type, level_begin, level_end;   // levels [begin, end)
   int blk_begin, blk_end;             // SPLIT: range in split_blk
-  int sub_begin, sub_end;             // SPLIT: range in split_sub
+  int sub_begin, sub_end;             // SPLIT: range in split_sub;  PANEL: sub_begin = offset in panel_cols, sub_end = chains
 };
 
 struct DirectSymbolic {
@@ -59,7 +65,7 @@ struct DirectSymbolic {
   long long n_pairs = 0;
   int fused_from_level = 0;  // first level of the suffix whose levels hold <= 8 columns (forward/backward solves fuse it)
   std::vector<DirectStep> steps;   // factorisation schedule
-  std::vector<int> split_blk, split_sub, split_sub_diag;
+  std::vector<int> split_blk, split_sub, split_sub_diag, upd_split, panel_cols;
   std::vector<uint8_t> split_diag;
   double flops = 0;
   double est_steps = 0;      // critical-path length of the schedule in update-pair steps (cost model)

@@ -22,22 +22,11 @@ __device__ __forceinline__ void load_row(const double* Lval, int b, int r, doubl
   out[0] = a.x; out[1] = a.y; out[2] = c.x; out[3] = c.y; out[4] = d.x; out[5] = d.y;
 }
 
-// Partial assembly of row r of block `bi`: BSR sources (only when sub == 0) minus the update pairs
-// q = first + sub, first + sub + stride, ... ; the `stride` partial results are summed by the caller.
-__device__ __forceinline__ void assemble_row(const DeviceGraph& g, const DirectPlan& p, int bi, int r, int sub, int stride, double* v) {
-#pragma unroll
-  for (int c = 0; c < 6; ++c) v[c] = 0.0;
-  if (sub == 0) {
-    for (int s = p.asrc_ptr[bi]; s < p.asrc_ptr[bi + 1]; ++s) {
-      const int slot = p.asrc_slot[s];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) v[c] += g.bsr_val[bsr_index(slot, 6 * r + c)];
-    }
-  }
+// v -= sum over the update pairs q = q_begin + sub, + stride, ... < q_end of (row r of L[upd_a[q]]) * L[upd_b[q]]^T
+__device__ __forceinline__ void subtract_pairs(const DirectPlan& p, int q_begin, int q_end, int r, int sub, int stride, double* v) {
   // two pairs per trip, all loads of both issued before the arithmetic (the walk is latency-bound: each pair is two
   // dependent round trips — index, then 48 + 288 bytes of L)
-  const int q_end = p.upd_ptr[bi + 1];
-  int q = p.upd_ptr[bi] + sub;
+  int q = q_begin + sub;
   for (; q + stride < q_end; q += 2 * stride) {
     const int ia0 = p.upd_a[q], ib0 = p.upd_b[q], ia1 = p.upd_a[q + stride], ib1 = p.upd_b[q + stride];
     double a0[6], a1[6];
@@ -68,6 +57,25 @@ __device__ __forceinline__ void assemble_row(const DeviceGraph& g, const DirectP
       v[c] -= a[0] * x0.x + a[1] * x0.y + a[2] * x1.x + a[3] * x1.y + a[4] * x2.x + a[5] * x2.y;
     }
   }
+}
+
+// Partial assembly of row r of block `bi`: BSR sources (only when sub == 0) minus the update pairs up to q_end
+// (upd_ptr[bi+1] = all of them; upd_split[bi] = those of the columns before the block's panel);
+// the `stride` partial results are summed by the caller.
+__device__ __forceinline__ void assemble_row(const DeviceGraph& g, const DirectPlan& p, int bi, int r, int sub, int stride, double* v, int q_end) {
+#pragma unroll
+  for (int c = 0; c < 6; ++c) v[c] = 0.0;
+  if (sub == 0) {
+    for (int s = p.asrc_ptr[bi]; s < p.asrc_ptr[bi + 1]; ++s) {
+      const int slot = p.asrc_slot[s];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v[c] += g.bsr_val[bsr_index(slot, 6 * r + c)];
+    }
+  }
+  subtract_pairs(p, p.upd_ptr[bi], q_end, r, sub, stride, v);
+}
+__device__ __forceinline__ void assemble_row(const DeviceGraph& g, const DirectPlan& p, int bi, int r, int sub, int stride, double* v) {
+  assemble_row(g, p, bi, r, sub, stride, v, p.upd_ptr[bi + 1]);
 }
 
 // Factorises column j with one wave.  sh: 360 doubles of LDS private to the wave (10 groups x 6 rows x 6).
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(64) void k_chol_assemble(DeviceGraph g, DirectPlan 
   const int grp = lane / 6, r = lane - 6 * grp;
   if (grp < 10) {
     double v[6];
-    assemble_row(g, p, bi, r, grp, 10, v);
+    assemble_row(g, p, bi, r, grp, 10, v, p.upd_split[bi]);   // = the whole list outside PANEL steps
 #pragma unroll
     for (int c = 0; c < 6; ++c) sh[(grp * 6 + r) * 6 + c] = v[c];
   }
@@ -244,6 +252,64 @@ __global__ __launch_bounds__(64) void k_chol_scale(DeviceGraph g, DirectPlan p, 
     x[c] = s / L[7 * c];
   }
   o[0] = double2{x[0], x[1]}; o[1] = double2{x[2], x[3]}; o[2] = double2{x[4], x[5]};
+}
+
+// ---- PANEL steps, phase 2: one workgroup per chain of `width` columns; the contributions of every column before the
+// panel are already in Lval (phase 1 = k_chol_assemble over all blocks of the panel).  Column by column: wave 0 adds the
+// in-panel pairs of the diagonal block and factorises it, then all eight waves finish the sub-diagonal blocks (their
+// few in-panel pairs, then L_jj^-T), one 6-lane group per block. ----
+__global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_panel(DeviceGraph g, DirectPlan p, int cols_begin, int width) {
+  __shared__ double sh[360];
+  __shared__ double Ld[36];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = lane / 6, r = lane - 6 * grp;
+  for (int i = 0; i < width; ++i) {
+    const int j = p.panel_cols[cols_begin + blockIdx.x * width + i];
+    const int b0 = p.col_ptr[j], nblk = p.col_ptr[j + 1] - b0;
+    if (wave == 0) {
+      if (grp < 10) {
+        double v[6] = {0, 0, 0, 0, 0, 0};
+        subtract_pairs(p, p.upd_split[b0], p.upd_ptr[b0 + 1], r, grp, 10, v);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sh[(grp * 6 + r) * 6 + c] = v[c];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      double Ljj[36];
+#pragma unroll
+      for (int k = 0; k < 36; ++k) {
+        double s = p.Lval[36 * (size_t)b0 + k];
+#pragma unroll
+        for (int gq = 0; gq < 10; ++gq) s += sh[gq * 36 + k];
+        Ljj[k] = s;
+      }
+      const bool ok = chol6_inplace(Ljj);
+      if (!ok && lane == 0) atomicOr(&g.flags[2], 1);
+      if (lane < 36) { p.Lval[36 * (size_t)b0 + lane] = Ljj[lane]; Ld[lane] = Ljj[lane]; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (grp < 10) {
+      for (int t = 1 + wave * 10 + grp; t < nblk; t += 10 * FUSED_WAVES) {
+        const int bi = b0 + t;
+        double2* o = reinterpret_cast<double2*>(p.Lval + 36 * (size_t)bi + 6 * r);
+        const double2 a = o[0], b = o[1], c2 = o[2];
+        double v[6] = {a.x, a.y, b.x, b.y, c2.x, c2.y};
+        subtract_pairs(p, p.upd_split[bi], p.upd_ptr[bi + 1], r, 0, 1, v);
+        double x[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double s = v[c];
+#pragma unroll
+          for (int k = 0; k < c; ++k) s -= x[k] * Ld[6 * c + k];
+          x[c] = s / Ld[7 * c];
+        }
+        o[0] = double2{x[0], x[1]}; o[1] = double2{x[2], x[3]}; o[2] = double2{x[4], x[5]};
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
 }
 
 __global__ __launch_bounds__(64) void k_chol_level(DeviceGraph g, DirectPlan p, int level) {
@@ -398,6 +464,9 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
       hipLaunchKernelGGL(k_chol_level, dim3(nc), dim3(64), 0, s, g, p, st.level_begin);
     } else if (st.type == DirectStep::FUSED) {
       hipLaunchKernelGGL(k_chol_tail, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, st.level_begin, st.level_end);
+    } else if (st.type == DirectStep::PANEL) {
+      hipLaunchKernelGGL(k_chol_assemble, dim3(st.blk_end - st.blk_begin), dim3(64), 0, s, g, p, st.blk_begin);
+      hipLaunchKernelGGL(k_chol_panel, dim3(st.sub_end), dim3(64 * FUSED_WAVES), 0, s, g, p, st.sub_begin, st.level_end - st.level_begin);
     } else {
       hipLaunchKernelGGL(k_chol_assemble, dim3(st.blk_end - st.blk_begin), dim3(64), 0, s, g, p, st.blk_begin);
       const int nsub = st.sub_end - st.sub_begin;
