@@ -321,3 +321,24 @@ def test_incremental_problem_growth(gpu, O, ds):
     assert s2.initial_cost == pytest.approx(s3.initial_cost, rel=1e-13)
     assert s2.final_cost == pytest.approx(s3.final_cost, rel=1e-10)
     assert np.abs(poses - qposes).max() < 1e-8
+
+
+def test_direct_solver_with_dense_separators(gpu, O, ds):
+    """A lattice walk with many loop closures: the elimination tree ends in dense separator chains, which the GPU
+    factorisation processes as SPLIT levels and PANEL steps.  Same solution as the oracle's exact
+    solve, and the LM run reports the factorisation (not the PCG stand-in) as the solver used."""
+    g = ds.manhattan_se3(2000, 8000, seed=3)
+    prob, poses, og = _pair(gpu, O, g)
+    rng = np.random.default_rng(5)
+    d2 = rng.uniform(0.05, 2.0, size=g.N * 6)
+    b = rng.normal(size=g.N * 6)
+    b[:6] = 0.0
+    x, it = prob.linear_solve(d2, b, gpu.SolverOptions(linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY))
+    xo, _ = O.linear_solve(og, d2, b, linear_solver=0)
+    assert it == 0
+    assert np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max()
+    s = gpu.solve(gpu.SolverOptions(max_num_iterations=5, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY), prob)
+    _, osum, otr = O.solve(og, O.default_options(max_num_iterations=5, linear_solver=0))
+    assert s.linear_solver_used == 0 and s.factor_levels > 100
+    n = min(len(otr), len(s.iterations))
+    assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-8)
