@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 N_POSES = 10000
 N_EDGES = 40000
 SEED = 20260928
+SHARDED_LIMIT_S = int(os.environ.get("PGO_BENCH_SHARDED_LIMIT_S", "300"))   # N > 1: the row-sharded run is abandoned (replica figures printed instead) after this long
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -75,22 +76,11 @@ def main():
     # PGO_BENCH_REPLICAS=1 runs one independent graph per GPU instead (no data-path collective).
     replicas = os.environ.get("PGO_BENCH_REPLICAS", "0") == "1"
     sharded = use_dist and not replicas
-    if sharded:
-        g = ds.manhattan_se3(args.poses * world, args.edges * world, seed=SEED)
-    else:
-        g = ds.manhattan_se3(args.poses, args.edges, seed=SEED + rank)
-    N, E = g.N, g.E
-    prob, poses = pkg.problem_from_graph(g)
-    if sharded:
-        box = [pkg.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        prob.comm_init(box[0], rank, world)
     opt = pkg.SolverOptions(max_num_iterations=2 ** 30, linear_solver_type=pkg.BLOCK_JACOBI_PCG, eta=0.1,
                             max_linear_solver_iterations=500, function_tolerance=0.0, parameter_tolerance=0.0,
                             gradient_tolerance=0.0, pcg_cluster_poses=args.cluster)
-    prob.solver_begin(opt)
 
-    def run_steps(k):
+    def run_steps(prob, k):
         left = k
         resets = 0
         while left > 0:
@@ -109,45 +99,77 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(args.warmup)
-    prob.solver_reset()
-    barrier()
-    t0 = time.perf_counter()
-    resets = run_steps(args.steps)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
+    def timed_region(prob):
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+        run_steps(prob, args.warmup)
+        prob.solver_reset()
+        barrier()
+        t0 = time.perf_counter()
+        resets = run_steps(prob, args.steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+            dist.barrier()
+        return el, resets
 
-    # ---- N > 1 only, outside the timed region: the same K steps with one INDEPENDENT graph per GPU (no data-path
-    # collective).  A 10 k-pose graph is latency-bound ("multi-GPU pointless there, report replicas"), so the
-    # sharded `value` above pays one all-gather per ~15 us of kernels; this figure says what the node delivers on
-    # KITTI-scale graphs served side by side.
+    def record(value, elapsed, parallelism, total_poses, total_edges):
+        return {
+            "metric": "lm_edge_iterations_per_sec", "value": round(value, 1), "unit": "edge-LM-iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Synthetic Manhattan SE3 graph, %d poses / %d odom+loop edges per GPU, block-Jacobi PCG "
+                                   "(eta=0.1, <=500 it), Huber(1.0), LM from dead reckoning" % (args.poses, args.edges),
+                       "poses_per_gpu": args.poses, "edges_per_gpu": args.edges, "total_poses": total_poses,
+                       "total_edges": total_edges, "seed": SEED,
+                       "preconditioner": "block-Jacobi, %d-pose chain clusters (%dx%d blocks)" % (args.cluster, 6 * args.cluster, 6 * args.cluster),
+                       "parallelism": parallelism}}
+
+    # ---- N > 1: first the same K steps with one INDEPENDENT graph per GPU (no data-path collective).  A 10 k-pose graph
+    # is latency-bound (SURVEY §8e: "multi-GPU pointless there, report replicas"), so the sharded `value` below pays one
+    # all-gather per ~15 us of kernels; this figure says what the node delivers on KITTI-scale graphs served side by
+    # side.  It is also the line that gets printed if the sharded run does not complete on this node (watchdog below).
     replica_extra = None
     if sharded:
         gr = ds.manhattan_se3(args.poses, args.edges, seed=SEED + rank)
         prob_r, poses_r = pkg.problem_from_graph(gr)
         prob_r.solver_begin(opt)
-        main_prob, prob = prob, prob_r
-        run_steps(args.warmup)
-        prob.solver_reset()
-        barrier()
-        t0 = time.perf_counter()
-        run_steps(args.steps)
-        torch.cuda.synchronize()
-        el_r = time.perf_counter() - t0
-        t = torch.tensor([el_r], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el_r = float(t.item())
-        dist.barrier()
-        prob.solver_end()
-        prob = main_prob
+        el_r, _ = timed_region(prob_r)
+        prob_r.solver_end()
         replica_extra = {"value": round(gr.E * world * args.steps / el_r, 1), "unit": "edge-LM-iterations/s",
                          "ms_per_step": round(1e3 * el_r / args.steps, 4),
                          "note": "one independent %d-pose graph per GPU, no collective; not the headline value" % gr.N}
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out = record(gr.E * world * args.steps / el_r, el_r,
+                             "replicas: 1 independent graph per GPU (the row-sharded run over %d ranks did not complete within "
+                             "%d s on this node and was abandoned)" % (world, SHARDED_LIMIT_S), gr.N * world, gr.E * world)
+                out.update({"roofline": None, "cpu_baseline": None, "sharded_run": "timed out"})
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+
+        watchdog = threading.Timer(SHARDED_LIMIT_S, give_up)
+        watchdog.daemon = True
+
+    if sharded:
+        g = ds.manhattan_se3(args.poses * world, args.edges * world, seed=SEED)
+    else:
+        g = ds.manhattan_se3(args.poses, args.edges, seed=SEED + rank)
+    N, E = g.N, g.E
+    prob, poses = pkg.problem_from_graph(g)
+    if sharded:
+        watchdog.start()
+        box = [pkg.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        prob.comm_init(box[0], rank, world)
+    prob.solver_begin(opt)
+    elapsed, resets = timed_region(prob)
+    if sharded:
+        watchdog.cancel()
 
     # ---- per-kernel durations, HIP events on the solver stream (rank 0) ----
     roofline = None
@@ -202,11 +224,11 @@ def main():
         opt.pcg_cluster_poses = 1
         poses[:] = g.poses          # solver_end wrote the optimised poses back: restart from dead reckoning
         prob.solver_begin(opt)
-        run_steps(args.warmup)
+        run_steps(prob, args.warmup)
         prob.solver_reset()
         torch.cuda.synchronize()
         t6 = time.perf_counter()
-        run_steps(args.steps)
+        run_steps(prob, args.steps)
         torch.cuda.synchronize()
         dt6 = time.perf_counter() - t6
         s6 = prob.solver_end()
@@ -242,24 +264,17 @@ def main():
 
     if rank == 0:
         total_edges = E if sharded else E * world
-        value = total_edges * args.steps / elapsed
-        out = {
-            "metric": "lm_edge_iterations_per_sec", "value": round(value, 1), "unit": "edge-LM-iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Synthetic Manhattan SE3 graph, %d poses / %d odom+loop edges per GPU, block-Jacobi PCG "
-                                   "(eta=0.1, <=500 it), Huber(1.0), LM from dead reckoning" % (args.poses, args.edges),
-                       "poses_per_gpu": args.poses, "edges_per_gpu": args.edges, "total_poses": N if sharded or world == 1 else N * world,
-                       "total_edges": total_edges, "seed": SEED,
-                       "preconditioner": "block-Jacobi, %d-pose chain clusters (%dx%d blocks)" % (args.cluster, 6 * args.cluster, 6 * args.cluster),
-                       "parallelism": ("single GPU" if world == 1 else
-                                       "one graph row-sharded over %d ranks, 1 RCCL all-gather per CG iteration" % world if sharded else
-                                       "replicas: 1 independent graph per GPU, no data-path collective")},
+        out = record(total_edges * args.steps / elapsed, elapsed,
+                     ("single GPU" if world == 1 else
+                      "one graph row-sharded over %d ranks, 1 RCCL all-gather per CG iteration" % world if sharded else
+                      "replicas: 1 independent graph per GPU, no data-path collective"),
+                     N if sharded or world == 1 else N * world, total_edges)
+        out.update({
             "lm_iters_per_sec": round(args.steps * (1 if sharded else world) / elapsed, 2),
             "cg_iterations_in_solver_state": summary.num_linear_solver_iterations,
             "final_cost": summary.final_cost, "resets": resets,
             "roofline": roofline, "cpu_baseline": cpu,
-        }
+        })
         out.update(extra)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
