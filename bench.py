@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--poses", type=int, default=N_POSES)
     ap.add_argument("--edges", type=int, default=N_EDGES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c4-kernels", action="store_true", help="skip the C4-size (100k poses / 1M edges) kernel roofline block")
     ap.add_argument("--cpu-iters", type=int, default=60, help="LM iterations of the CPU baseline sample (~11 s of host work)")
     ap.add_argument("--cluster", type=int, default=2, help="poses per Jacobi block of the PCG preconditioner (1, 2 or 4)")
     args = ap.parse_args()
@@ -241,6 +242,29 @@ def main():
         extra["jacobi_6x6_blocks"] = {"value": round(E * args.steps / dt6, 1), "unit": "edge-LM-iterations/s",
                                       "ms_per_step": round(dt6 / args.steps * 1e3, 4), "final_cost": s6.final_cost,
                                       "cg_iterations": s6.num_linear_solver_iterations}
+
+    # ---- kernel rooflines at C4 size (at <= 25 k poses the kernels are latency-bound, "quote HBM fraction
+    # only for C4"): same kernels, 100 k poses / 1 M edges on this one GPU, outside the timed region ----
+    if rank == 0 and world == 1 and not args.no_c4_kernels and (args.poses, args.edges) == (N_POSES, N_EDGES):
+        g4 = ds.manhattan_se3(100000, 1000000, seed=20260930, loop_radius=3.0)
+        p4, _ = pkg.problem_from_graph(g4)
+        o4 = pkg.SolverOptions(max_num_iterations=2 ** 30, linear_solver_type=pkg.BLOCK_JACOBI_PCG, eta=0.1,
+                               function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0,
+                               pcg_cluster_poses=args.cluster)
+        p4.solver_begin(o4)
+        p4.solver_step(2)
+        N4, E4 = g4.N, g4.E
+        blocks = {}
+        for key, kern, nbytes, reps4 in (("k_evaluate_edges", "evaluate", 976 * E4 + 56 * N4, 30),
+                                         ("k_linearize", "linearize", 640 * E4 + 392 * N4, 50),
+                                         ("k_spmv<0>", "pcg_spmv", (N4 + E4) * 288 + 2 * N4 * 48, 100)):
+            t4 = p4.time_kernel(kern, reps4)
+            gbs = nbytes / (t4 * 1e-3) / 1e9
+            blocks[key] = {"avg_launch_us": round(t4 * 1e3, 2), "algorithmic_bytes_per_launch": nbytes,
+                           "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        blocks["k_evaluate_edges"]["edge_jacobians_per_sec"] = round(E4 / (blocks["k_evaluate_edges"]["avg_launch_us"] * 1e-6), 1)
+        p4.solver_end()
+        extra["rooflines_at_c4_size"] = {"poses": N4, "edges": E4, "bound": "hbm", "peak": HBM_PEAK_GBS, "kernels": blocks}
 
     # ---- CPU baseline on this box's host cores, rank 0, bounded sample ----
     cpu = None
