@@ -20,6 +20,8 @@ namespace pgo { int comm_stress(Comm* c, int iters, size_t seg, hipStream_t s, i
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <memory>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -70,7 +72,25 @@ struct DevBuf {
     if (e != hipSuccess) return e;
     return hipStreamSynchronize(s);  // h may be a temporary
   }
+  hipError_t upload(const T* h, size_t count, hipStream_t s) {
+    hipError_t e = alloc(count);
+    if (e != hipSuccess || count == 0) return e;
+    e = hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(s);
+  }
   hipError_t zero(hipStream_t s) { return n ? hipMemsetAsync(p, 0, n * sizeof(T), s) : hipSuccess; }
+};
+
+// Host staging array WITHOUT value initialisation: the big slot-ordered arrays are first touched (and fully written) by the
+// threads of parallel_for, not zero-filled by the caller.
+struct HostArray {
+  std::unique_ptr<double[]> p;
+  size_t n = 0;
+  void resize(size_t count) { p.reset(count ? new double[count] : nullptr); n = count; }
+  double& operator[](size_t i) { return p[i]; }
+  const double* data() const { return p.get(); }
+  bool empty() const { return n == 0; }
 };
 
 struct LmState {
@@ -227,6 +247,21 @@ int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd) {
   return PGO_OK;
 }
 
+// Splits [0, n) into contiguous ranges over a few host threads (topology build of large graphs; nothing on the LM path).
+template <class F>
+void parallel_for(int n, F&& fn) {
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int nt = (n < 65536 || hw < 2) ? 1 : std::min(std::min(hw, 32), n / 32768);
+  if (nt <= 1) { fn(0, n); return; }
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (int i = 0; i < nt; ++i) {
+    const int lo = (int)((long long)n * i / nt), hi = (int)((long long)n * (i + 1) / nt);
+    th.emplace_back([&fn, lo, hi]() { fn(lo, hi); });
+  }
+  for (std::thread& t : th) t.join();
+}
+
 int choose_block(long long total_slots) {
   static const int env_block = getenv("PGO_BLOCK") ? atoi(getenv("PGO_BLOCK")) : 0;   // tuning experiments: 64, 128 or 256
   if (env_block == 64 || env_block == 128 || env_block == 256) return env_block;
@@ -246,6 +281,11 @@ int prepare(pgo_problem* P) {
   hipStream_t s = P->stream;
   P->drop_graph();
 
+  const bool verbose = getenv("PGO_VERBOSE") != nullptr;
+  auto lap = [&, tl = Clock::now()](const char* what) mutable {
+    if (verbose) std::fprintf(stderr, "[pgo] prepare: %-28s %.2f ms\n", what, 1e3 * seconds_since(tl));
+    tl = Clock::now();
+  };
   std::vector<int> deg(N, 0);
   for (int e = 0; e < E; ++e) { ++deg[P->ia[e]]; ++deg[P->ib[e]]; }
   long long total = 0;
@@ -326,36 +366,55 @@ int prepare(pgo_problem* P) {
     for (int t = wg_slot_begin[w]; t < wg_slot_begin[w + 1]; ++t) if (slot_side[t] == pgo::SIDE_PAD) slot_row[t] = r;
   }
 
-  // measurements: edge order and slot order, component major
-  std::vector<double> emeas((size_t)7 * E), smeas((size_t)7 * n_slots, 0.0);
-  for (int e = 0; e < E; ++e) for (int c = 0; c < 7; ++c) emeas[(size_t)c * E + e] = P->meas[(size_t)7 * e + c];
-  for (int t = 0; t < n_slots; ++t) {
-    const int e = slot_edge[t];
-    if (e < 0) { smeas[(size_t)6 * n_slots + t] = 1.0; continue; }
-    for (int c = 0; c < 7; ++c) smeas[(size_t)c * n_slots + t] = P->meas[(size_t)7 * e + c];
-  }
-  std::vector<double> eW, sW, eL;
-  if (P->has_info) {
-    eW.resize((size_t)21 * E); eL.resize((size_t)36 * E); sW.assign((size_t)21 * n_slots, 0.0);
-    for (int e = 0; e < E; ++e) {
-      const double* L = &P->sqrt_info[(size_t)36 * e];
-      int k = 0;
-      for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 6; ++j) {
-          double w = 0;
-          for (int r = 0; r < 6; ++r) w += L[6 * r + i] * L[6 * r + j];  // W = L^T L
-          eW[(size_t)k * E + e] = w;
-          ++k;
-        }
-      for (int q = 0; q < 36; ++q) eL[(size_t)q * E + e] = L[q];
-    }
-    for (int t = 0; t < n_slots; ++t) {
+  lap("rows -> workgroups, slots");
+  // measurements: edge order and slot order, component major.  The gathers into slot order are cache-hostile (21-36
+  // strided streams indexed by a random edge): split over host threads, each owning a contiguous range.
+  HostArray emeas, smeas, eW, sW, eL;
+  emeas.resize((size_t)7 * E);
+  smeas.resize((size_t)7 * n_slots);
+  parallel_for(E, [&](int lo, int hi) {
+    for (int e = lo; e < hi; ++e) for (int c = 0; c < 7; ++c) emeas[(size_t)c * E + e] = P->meas[(size_t)7 * e + c];
+  });
+  parallel_for(n_slots, [&](int lo, int hi) {
+    for (int t = lo; t < hi; ++t) {
       const int e = slot_edge[t];
-      if (e < 0) continue;
-      for (int k = 0; k < 21; ++k) sW[(size_t)k * n_slots + t] = eW[(size_t)k * E + e];
+      for (int c = 0; c < 7; ++c) smeas[(size_t)c * n_slots + t] = e < 0 ? (c == 6 ? 1.0 : 0.0) : P->meas[(size_t)7 * e + c];
     }
+  });
+  if (P->has_info) {
+    eW.resize((size_t)21 * E); eL.resize((size_t)36 * E); sW.resize((size_t)21 * n_slots);
+    parallel_for(E, [&](int lo, int hi) {
+      for (int e = lo; e < hi; ++e) {
+        const double* L = &P->sqrt_info[(size_t)36 * e];
+        int k = 0;
+        for (int i = 0; i < 6; ++i)
+          for (int j = i; j < 6; ++j) {
+            double w = 0;
+            for (int r = 0; r < 6; ++r) w += L[6 * r + i] * L[6 * r + j];  // W = L^T L
+            eW[(size_t)k * E + e] = w;
+            ++k;
+          }
+        for (int q = 0; q < 36; ++q) eL[(size_t)q * E + e] = L[q];
+      }
+    });
+    parallel_for(n_slots, [&](int lo, int hi) {
+      for (int t = lo; t < hi; ++t) {
+        const int e = slot_edge[t];
+        if (e < 0) { for (int k = 0; k < 21; ++k) sW[(size_t)k * n_slots + t] = 0.0; continue; }
+        // W of the slot's edge, recomputed from L (contiguous 288 B) instead of 21 strided reads of eW
+        const double* L = &P->sqrt_info[(size_t)36 * e];
+        int k = 0;
+        for (int i = 0; i < 6; ++i)
+          for (int j = i; j < 6; ++j) {
+            double w = 0;
+            for (int r = 0; r < 6; ++r) w += L[6 * r + i] * L[6 * r + j];
+            sW[(size_t)k * n_slots + t] = w;
+            ++k;
+          }
+      }
+    });
   }
-
+  lap("measurement / W arrays");
   P->h_slot_row = slot_row; P->h_slot_col = slot_col; P->h_slot_side = slot_side; P->h_row_slot_begin = row_slot_begin;
   P->direct_analyzed = false; P->direct_usable = false; P->cluster_built = 0; P->g.cluster = 1;
   HIP_TRY(P->d_slot_col.upload(slot_col, s));
@@ -368,12 +427,13 @@ int prepare(pgo_problem* P) {
   HIP_TRY(P->d_cmask.upload(P->cmask, s));
   HIP_TRY(P->d_edge_a.upload(P->ia, s));
   HIP_TRY(P->d_edge_b.upload(P->ib, s));
-  HIP_TRY(P->d_smeas.upload(smeas, s));
-  HIP_TRY(P->d_emeas.upload(emeas, s));
-  HIP_TRY(P->d_sW.upload(sW, s));
-  HIP_TRY(P->d_eW.upload(eW, s));
-  HIP_TRY(P->d_eL.upload(eL, s));
+  HIP_TRY(P->d_smeas.upload(smeas.data(), smeas.n, s));
+  HIP_TRY(P->d_emeas.upload(emeas.data(), emeas.n, s));
+  HIP_TRY(P->d_sW.upload(sW.data(), sW.n, s));
+  HIP_TRY(P->d_eW.upload(eW.data(), eW.n, s));
+  HIP_TRY(P->d_eL.upload(eL.data(), eL.n, s));
 
+  lap("uploads");
   const size_t m = (size_t)6 * NP;
   HIP_TRY(P->d_pose_x.alloc((size_t)pgo::POSE_STRIDE * N));
   HIP_TRY(P->d_pose_c.alloc((size_t)pgo::POSE_STRIDE * N));
@@ -430,6 +490,7 @@ int prepare(pgo_problem* P) {
   HIP_TRY(hipHostGetDevicePointer(&dscal, P->scal, 0));
   g.scal = reinterpret_cast<pgo::LmScalars*>(dscal);
   HIP_TRY(hipStreamSynchronize(s));
+  lap("device buffers");
   P->topo_dirty = false;
   P->lm.t_setup = seconds_since(t0);
   return PGO_OK;
