@@ -42,3 +42,17 @@ def test_empty_and_capacity_errors(pkg):
                                            rp.ctypes.data_as(C.POINTER(C.c_longlong)), idx.ctypes.data_as(C.POINTER(C.c_int)),
                                            C.c_longlong(4), None)
     assert rc == pkg.ERR_INVALID_ARGUMENT
+
+
+def test_candidates_property(pkg, ds):
+    """hypothesis: random small clouds on a coarse lattice (many exact ties with the threshold), random radius / gap."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(0, 400), st.integers(0, 2 ** 31 - 1), st.sampled_from([1.0, 2.0, 3.0, 5.0]), st.integers(0, 120))
+    def check(n, seed, radius, gap):
+        rng = np.random.default_rng(seed)
+        xyz = rng.integers(-4, 5, size=(n, 3)).astype(np.float64)
+        assert pkg.generate_candidates(xyz, radius, gap) == ds.generate_candidates(xyz, radius, gap)
+
+    check()

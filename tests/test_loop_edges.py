@@ -111,3 +111,24 @@ def test_overwrite_y(le):
     out = le.overwrite_y(poses, xyz)
     assert np.array_equal(out[:, 1], np.float32([0.1, 0.2, 0.3]).astype(np.float64))
     assert np.array_equal(np.delete(out, 1, axis=1), np.delete(poses, 1, axis=1))
+
+
+def test_to_pose3d_roundtrip_property(le):
+    """hypothesis: any rigid transform survives toPose3d -> rotation matrix (both quaternion signs are the same pose)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.lists(st.floats(-3.2, 3.2, allow_nan=False), min_size=3, max_size=3),
+           st.lists(st.floats(-1e3, 1e3, allow_nan=False), min_size=3, max_size=3))
+    def check(rv, tv):
+        T = np.eye(4)
+        T[:3, :3] = le.rodrigues(rv)
+        T[:3, 3] = tv
+        p = le.to_pose3d(T)
+        assert np.array_equal(p[:3], np.asarray(tv, dtype=np.float64))
+        assert abs(np.linalg.norm(p[3:]) - 1.0) < 1e-12
+        assert np.allclose(Rotation.from_quat(p[3:]).as_matrix(), T[:3, :3], atol=1e-12)
+        # inverse composed with itself is the identity (relative_transform of a frame with itself)
+        assert np.allclose(le.relative_transform(T, T), np.eye(4), atol=1e-9)
+
+    check()
