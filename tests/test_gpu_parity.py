@@ -342,3 +342,48 @@ def test_direct_solver_with_dense_separators(gpu, O, ds):
     assert s.linear_solver_used == 0 and s.factor_levels > 100
     n = min(len(otr), len(s.iterations))
     assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-8)
+
+
+def test_evaluate_special_configurations(gpu, O, ds):
+    """Hand-picked edge states: zero residual, identical poses, antipodal quaternion representatives, half-turn relative
+    rotation, non-unit quaternions, large translations; plus Plus() with a zero rotation step (the sin(x)/x branch)."""
+    s2 = np.sqrt(0.5)
+    poses = np.array([
+        [0, 0, 0, 0, 0, 0, 1.0],
+        [1, 2, 3, 0, 0, s2, s2],
+        [1, 2, 3, 0, 0, -s2, -s2],          # same rotation as pose 1, other representative
+        [-4, 0.5, 2, 1, 0, 0, 0.0],         # half turn about x
+        [1e4, -2e4, 3e3, 0.1, 0.2, 0.3, 0.9],   # far away, not unit
+        [0, 0, 0, 0, 0, 0, 1.0],            # identical to pose 0
+    ])
+    ia = np.array([0, 1, 2, 3, 4, 5, 1, 3], dtype=np.int32)
+    ib = np.array([1, 2, 3, 4, 5, 0, 0, 0], dtype=np.int32)
+    unit = poses.copy()
+    unit[:, 3:] /= np.linalg.norm(unit[:, 3:], axis=1, keepdims=True)
+    meas = ds.relative_pose(unit[ia], unit[ib])
+    meas[1] = [0, 0, 0, 0, 0, 0, 1.0]        # identity measurement between two representatives of one pose
+    meas[5] = [0, 0, 0, 0, 0, 0, -1.0]       # identical poses, measurement = -identity quaternion
+    meas[6, :3] += 0.25                      # a genuinely non-zero residual
+    meas[7, 3:] = [s2, 0, s2, 0.0]
+    g = ds.PoseGraphData(poses, ia, ib, meas, None)
+    for loss in (0, 1):
+        prob, p2, og = _pair(gpu, O, g, loss=loss)
+        cost, r, ja, jb, grad = prob.evaluate()
+        ocost, orr, oja, ojb = O.evaluate(og, loss_kind=loss)
+        scale = max(1.0, np.abs(oja).max())
+        assert np.abs(r - orr).max() <= 1e-9 * max(1.0, np.abs(orr).max())      # poses 1e4 m away: absolute cancellation error
+        assert np.abs(ja - oja).max() <= 1e-11 * scale and np.abs(jb - ojb).max() <= 1e-11 * scale
+        assert cost == pytest.approx(ocost, rel=1e-10, abs=1e-12)
+    # Plus with zero rotation increments on some poses and zero translation on others
+    prob, p2, og = _pair(gpu, O, g)
+    d = np.zeros((6, 6))
+    d[1, :3] = [0.1, -0.2, 0.3]
+    d[2, 3:] = [0.0, 0.0, 1e-12]
+    d[3, 3:] = [0.4, 0.0, -0.1]
+    expect = p2.copy()
+    for v in range(6):
+        expect[v, :3] += d[v, :3]
+        expect[v, 3:] = O.quat_plus(expect[v, 3:], d[v, 3:])
+    prob.plus(d)
+    assert np.abs(p2 - expect).max() <= 1e-15 * 3e4
+    assert np.array_equal(p2[0], poses[0]) and np.array_equal(p2[1, 3:], poses[1, 3:])
