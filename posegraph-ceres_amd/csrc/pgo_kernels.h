@@ -39,6 +39,7 @@ struct CgState {
   int cnt_b;       // iterations completed, published by the update kernel for the next SpMV
   int pad[3];
   double beta;     // beta of the current iteration, published by the SpMV kernel (the update kernel rebuilds p with it)
+  double rho;      // r'z of the current iteration, likewise (the update kernel needs it for alpha = rho / p'q)
 };
 
 struct DeviceGraph {

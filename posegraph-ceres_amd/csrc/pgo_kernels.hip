@@ -711,9 +711,10 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
     const double* q_cur = g.part_q + (size_t)(odd ? 0 : g.n_part);
     const double* q_prev = g.part_q + (size_t)(odd ? g.n_part : 0);
     const double* rr_cur = g.part_rr + (size_t)(odd ? 0 : g.n_part);
+    const bool need_rr = prm.r_tolerance >= 0.0;   // |r| <= tol |b| is tested only by the exact-request (PCG to 1e-13) path
     for (int i = tid; i < g.n_vec_wg; i += B) {
       sums[0] += rz_cur[i]; sums[1] += rz_prev[i]; sums[2] += q_cur[i]; sums[3] += q_prev[i];
-      sums[4] += rr_cur[i]; sums[5] += g.part_bb[i];
+      if (need_rr) { sums[4] += rr_cur[i]; sums[5] += g.part_bb[i]; }
     }
   }
   // gathers of the first chunk: need only the column index
@@ -731,13 +732,22 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
     }
   }
 
-  double beta = 0.0;
+  double beta = 0.0, rho_pub = 0.0;
   int it = 1;
   if (MODE == 0 && !(g.debug & 1)) {
     if (done) return;
     it = cnt_b + 1;
-    block_sum<6>(sums, scratch);
-    const double rho = sums[0], rho_prev = sums[1], Q1 = -sums[2], Q0 = -sums[3], rr = sums[4], bb = sums[5];
+    double rr = 0.0, bb = 0.0;
+    if (prm.r_tolerance >= 0.0) {
+      block_sum<6>(sums, scratch);
+      rr = sums[4]; bb = sums[5];
+    } else {
+      double s4[4] = {sums[0], sums[1], sums[2], sums[3]};
+      block_sum<4>(s4, scratch);
+      sums[0] = s4[0]; sums[1] = s4[1]; sums[2] = s4[2]; sums[3] = s4[3];
+    }
+    const double rho = sums[0], rho_prev = sums[1], Q1 = -sums[2], Q0 = -sums[3];
+    rho_pub = rho;
     int stop = 0, status = 0;
     if (it > 1) {
       const int done_it = it - 1;
@@ -861,7 +871,7 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
     block_sum<1>(pq, scratch);
     if (tid == 0) {
       g.cg_q[(size_t)g.rank * g.seg + (size_t)g.rows_per * 6 + wg] = pq[0];   // p'q partial rides in the exchange segment
-      if (wg == 0) { g.cg->cnt_a = it; g.cg->beta = beta; }
+      if (wg == 0) { g.cg->cnt_a = it; g.cg->beta = beta; g.cg->rho = rho_pub; }
     }
   }
 }
@@ -896,16 +906,15 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd
   const int done = g.cg->done;
   const int it = g.cg->cnt_a;
   const double beta = g.cg->beta;   // NOT re-derived here: this kernel overwrites the partial row rho_{it-1} lives in
-  double sums[2] = {0, 0};
-  const double* rz_cur = g.part_rz + (size_t)(odd ? 0 : g.n_part);
-  for (int i = tid; i < g.n_vec_wg; i += VEC_BLOCK) sums[0] += rz_cur[i];
+  const double rho = g.cg->rho;     // r'z of this iteration as the SpMV kernel summed it (one reduction fewer here)
+  double sums[1] = {0};
   for (int i = tid; i < g.world * g.pq_cap; i += VEC_BLOCK) {   // unused partial slots stay zero
     const int rk = i / g.pq_cap;
-    sums[1] += g.cg_q[(size_t)rk * g.seg + (size_t)g.rows_per * 6 + (i - rk * g.pq_cap)];
+    sums[0] += g.cg_q[(size_t)rk * g.seg + (size_t)g.rows_per * 6 + (i - rk * g.pq_cap)];
   }
   if (done) return;
-  block_sum<2>(sums, scratch);
-  const double rho = sums[0], pq = sums[1];
+  block_sum<1>(sums, scratch);
+  const double pq = sums[0];
   if (!(pq > 0.0) || !isfinite(pq)) {
     // "Matrix is indefinite, no more progress can be made": keep x of the previous iteration
     if (blockIdx.x == 0 && tid == 0) { g.cg->iters = it - 1; g.cg->status = 1; g.cg->done = 1; }
