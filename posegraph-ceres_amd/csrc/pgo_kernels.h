@@ -40,6 +40,8 @@ struct CgState {
   int pad[3];
   double beta;     // beta of the current iteration, published by the SpMV kernel (the update kernel rebuilds p with it)
   double rho;      // r'z of the current iteration, likewise (the update kernel needs it for alpha = rho / p'q)
+  double rho_hist[2];  // r'z and Q of the iterations, by iteration parity: the next SpMV launch reads the other slot
+  double q_hist[2];    //   (written during the previous launch), so it re-reduces two partial rows instead of four
 };
 
 struct DeviceGraph {

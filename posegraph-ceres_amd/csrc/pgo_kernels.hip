@@ -702,6 +702,7 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
   int seg_rb = 0, seg_cnt = 0;
   if (tid < nrows * 6) { seg_rb = g.row_slot_begin[r0 + tid / 6]; seg_cnt = g.row_slot_cnt[r0 + tid / 6]; }
   int done = 0, cnt_b = 0;
+  double hist_rho = 0.0, hist_q = 0.0;
   double sums[6] = {0, 0, 0, 0, 0, 0};
   if (MODE == 0 && !(g.debug & 1)) {
     done = g.cg->done;
@@ -712,8 +713,11 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
     const double* q_prev = g.part_q + (size_t)(odd ? g.n_part : 0);
     const double* rr_cur = g.part_rr + (size_t)(odd ? 0 : g.n_part);
     const bool need_rr = prm.r_tolerance >= 0.0;   // |r| <= tol |b| is tested only by the exact-request (PCG to 1e-13) path
+    (void)rz_prev; (void)q_prev;                   // rho and Q of the previous iteration come from CgState (see below)
+    hist_rho = g.cg->rho_hist[odd ? 0 : 1];        // slot (it-1)&1... it is odd <=> `odd`: previous iteration is even -> slot 0
+    hist_q = g.cg->q_hist[odd ? 0 : 1];
     for (int i = tid; i < g.n_vec_wg; i += B) {
-      sums[0] += rz_cur[i]; sums[1] += rz_prev[i]; sums[2] += q_cur[i]; sums[3] += q_prev[i];
+      sums[0] += rz_cur[i]; sums[2] += q_cur[i];
       if (need_rr) { sums[4] += rr_cur[i]; sums[5] += g.part_bb[i]; }
     }
   }
@@ -732,7 +736,7 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
     }
   }
 
-  double beta = 0.0, rho_pub = 0.0;
+  double beta = 0.0, rho_pub = 0.0, q_pub = 0.0;
   int it = 1;
   if (MODE == 0 && !(g.debug & 1)) {
     if (done) return;
@@ -742,12 +746,13 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
       block_sum<6>(sums, scratch);
       rr = sums[4]; bb = sums[5];
     } else {
-      double s4[4] = {sums[0], sums[1], sums[2], sums[3]};
-      block_sum<4>(s4, scratch);
-      sums[0] = s4[0]; sums[1] = s4[1]; sums[2] = s4[2]; sums[3] = s4[3];
+      double s2[2] = {sums[0], sums[2]};
+      block_sum<2>(s2, scratch);
+      sums[0] = s2[0]; sums[2] = s2[1];
     }
-    const double rho = sums[0], rho_prev = sums[1], Q1 = -sums[2], Q0 = -sums[3];
+    const double rho = sums[0], rho_prev = hist_rho, Q1 = -sums[2], Q0 = hist_q;
     rho_pub = rho;
+    q_pub = Q1;
     int stop = 0, status = 0;
     if (it > 1) {
       const int done_it = it - 1;
@@ -871,7 +876,11 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
     block_sum<1>(pq, scratch);
     if (tid == 0) {
       g.cg_q[(size_t)g.rank * g.seg + (size_t)g.rows_per * 6 + wg] = pq[0];   // p'q partial rides in the exchange segment
-      if (wg == 0) { g.cg->cnt_a = it; g.cg->beta = beta; g.cg->rho = rho_pub; }
+      if (wg == 0) {
+        g.cg->cnt_a = it; g.cg->beta = beta; g.cg->rho = rho_pub;
+        g.cg->rho_hist[odd ? 1 : 0] = rho_pub;   // slot it&1: read by the SpMV launch of iteration it+1
+        g.cg->q_hist[odd ? 1 : 0] = q_pub;
+      }
     }
   }
 }
