@@ -716,9 +716,13 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
     (void)rz_prev; (void)q_prev;                   // rho and Q of the previous iteration come from CgState (see below)
     hist_rho = g.cg->rho_hist[odd ? 0 : 1];        // slot (it-1)&1... it is odd <=> `odd`: previous iteration is even -> slot 0
     hist_q = g.cg->q_hist[odd ? 0 : 1];
-    for (int i = tid; i < g.n_vec_wg; i += B) {
-      sums[0] += rz_cur[i]; sums[2] += q_cur[i];
-      if (need_rr) { sums[4] += rr_cur[i]; sums[5] += g.part_bb[i]; }
+    if (need_rr) {
+      for (int i = tid; i < g.n_vec_wg; i += B) {
+        sums[0] += rz_cur[i]; sums[2] += q_cur[i]; sums[4] += rr_cur[i]; sums[5] += g.part_bb[i];
+      }
+    } else {
+      // LM mode: every WAVE folds the two partial rows on its own (lane-strided, then DPP) — no LDS hop, no barriers
+      for (int i = tid & 63; i < g.n_vec_wg; i += 64) { sums[0] += rz_cur[i]; sums[2] += q_cur[i]; }
     }
   }
   // gathers of the first chunk: need only the column index
@@ -746,9 +750,8 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
       block_sum<6>(sums, scratch);
       rr = sums[4]; bb = sums[5];
     } else {
-      double s2[2] = {sums[0], sums[2]};
-      block_sum<2>(s2, scratch);
-      sums[0] = s2[0]; sums[2] = s2[1];
+      sums[0] = wave_sum(sums[0]);
+      sums[2] = wave_sum(sums[2]);
     }
     const double rho = sums[0], rho_prev = hist_rho, Q1 = -sums[2], Q0 = hist_q;
     rho_pub = rho;
