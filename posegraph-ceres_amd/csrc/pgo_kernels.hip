@@ -90,10 +90,12 @@ __device__ __forceinline__ double partial_sum(const double* p, int n) {
 // Index of component k of pose `row` in the exchange buffer g.cg_q.  Each rank owns `rows_per` consecutive poses and
 // a segment of `seg` doubles: [rows_per*6 entries of q = A p][pq_cap partial sums of p'q].  With one rank this is 6*row+k.
 __device__ __forceinline__ size_t q_index(const DeviceGraph& g, int row, int k) {
+  if (g.world == 1) return (size_t)row * 6 + k;   // one rank: no integer division on the hot path
   const int rk = row / g.rows_per;
   return (size_t)rk * g.seg + (size_t)(row - rk * g.rows_per) * 6 + k;
 }
 __device__ __forceinline__ size_t q_index_flat(const DeviceGraph& g, int idx) {   // idx = 6*row + k
+  if (g.world == 1) return (size_t)idx;
   const int row = idx / 6;
   return q_index(g, row, idx - 6 * row);
 }
@@ -920,9 +922,14 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd
   const double beta = g.cg->beta;   // NOT re-derived here: this kernel overwrites the partial row rho_{it-1} lives in
   const double rho = g.cg->rho;     // r'z of this iteration as the SpMV kernel summed it (one reduction fewer here)
   double sums[1] = {0};
-  for (int i = tid; i < g.world * g.pq_cap; i += VEC_BLOCK) {   // unused partial slots stay zero
-    const int rk = i / g.pq_cap;
-    sums[0] += g.cg_q[(size_t)rk * g.seg + (size_t)g.rows_per * 6 + (i - rk * g.pq_cap)];
+  if (g.world == 1) {
+    const double* pqp = g.cg_q + (size_t)g.rows_per * 6;
+    for (int i = tid; i < g.pq_cap; i += VEC_BLOCK) sums[0] += pqp[i];
+  } else {
+    for (int i = tid; i < g.world * g.pq_cap; i += VEC_BLOCK) {   // unused partial slots stay zero
+      const int rk = i / g.pq_cap;
+      sums[0] += g.cg_q[(size_t)rk * g.seg + (size_t)g.rows_per * 6 + (i - rk * g.pq_cap)];
+    }
   }
   if (done) return;
   block_sum<1>(sums, scratch);
