@@ -217,6 +217,38 @@ int pgo_time_kernel(pgo_problem* problem, const char* kernel, int repeats, doubl
 int pgo_generate_candidates(const float* xyz, int n, float search_radius, int gap, long long* row_ptr, int* indices,
                             long long capacity, double* kernel_ms);
 
+/* ---- batched MotionEstimate solves ----
+ * Replaces MotionEstimate::BuildOptimizationProblem / SolveOptimizationProblem (REF/src/MotionEstimate.cc:71-129) and the
+ * ReprojectionError3Dto2D functor (REF/include/MotionEstimate.h:34-91) for MANY candidate frame pairs at once: problem k
+ * has the points [point_ptr[k], point_ptr[k+1]) of `points` ([total][3], 3-D points in the last frame) and
+ * `observations` ([total][2], pixels in the current frame), the shared intrinsics fx fy cx cy, and the parameter blocks
+ * q[k] (xyzw, EigenQuaternionParameterization) and t[k], updated in place.  The reference keeps q constant (:108) and
+ * estimates t with HuberLoss(1.0), max_num_iterations = 1000, exact steps: those are the defaults.
+ * summaries (optional) [n_problems]; kernel_ms (optional) = device time of the one launch.  GPU only. */
+typedef struct pgo_reproj_options {
+  int max_num_iterations;
+  int q_constant, t_constant;
+  int loss_kind;                 /* pgo_loss_kind */
+  int jacobi_scaling;
+  int max_num_consecutive_invalid_steps;
+  double loss_a;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;
+  double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+} pgo_reproj_options;
+typedef struct pgo_reproj_summary {
+  int termination_type;          /* pgo_termination_type */
+  int reason;                    /* 1 function tol, 2 parameter tol, 3 gradient tol, 4 min radius, 5 max iterations, 6 invalid steps */
+  int num_iterations;            /* iteration 0 included, as Ceres counts */
+  int num_successful_steps, num_unsuccessful_steps;
+  int num_points;
+  double initial_cost, final_cost;
+} pgo_reproj_summary;
+void pgo_reproj_options_init(pgo_reproj_options* options);
+int pgo_reproj_solve_batch(int n_problems, const long long* point_ptr, const double* points, const double* observations,
+                           const double intrinsics[4], double* q, double* t, const pgo_reproj_options* options,
+                           pgo_reproj_summary* summaries, double* kernel_ms);
+
 /* ---- one process per GPU: edge/row sharding over RCCL ---- */
 /* contiguous share [begin,end) of n units for `rank` of `world` (host-only helper, no GPU needed) */
 int pgo_shard_range(long long n, int rank, int world, long long* begin, long long* end);

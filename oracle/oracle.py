@@ -183,3 +183,26 @@ def time_jacobian_eval(g, repeats=1, loss_kind=1, loss_a=1.0):
     chk = C.c_double(0)
     t = lib().oracle_time_jacobian_eval(*g._args(), C.c_int(loss_kind), C.c_double(loss_a), C.c_int(repeats), C.byref(chk))
     return t
+
+
+# ---- MotionEstimate reprojection problem ----
+def reproj_eval(points, obs, intr, q, t):
+    """Residuals (n,2) and local Jacobians (n,2,6: columns dtheta | dt) of the reprojection blocks (autodiff chain)."""
+    points, obs, intr, q, t = (_f64(a) for a in (points, obs, intr, q, t))
+    n = points.shape[0]
+    r, J = np.zeros((n, 2)), np.zeros((n, 2, 6))
+    lib().oracle_reproj_eval(C.c_int(n), _p(points), _p(obs), _p(intr), _p(q), _p(t), _p(r), _p(J))
+    return r, J
+
+
+def reproj_solve(points, obs, intr, q, t, cmask=2, options=None, trace_capacity=1100):
+    """Ceres-style LM on one (q, t) pair; cmask bit0: t constant, bit1: q constant (the reference's setting).
+    Returns (q, t, Summary, trace)."""
+    o = options or default_options(max_num_iterations=1000)
+    points, obs, intr = _f64(points), _f64(obs), _f64(intr)
+    q, t = _f64(q).copy(), _f64(t).copy()
+    s = Summary()
+    trace = np.zeros((trace_capacity, TRACE_COLS))
+    lib().oracle_reproj_solve(C.c_int(points.shape[0]), _p(points), _p(obs), _p(intr), _p(q), _p(t), C.c_int(cmask),
+                              C.byref(o), C.byref(s), _p(trace), C.c_int(trace_capacity))
+    return q, t, s, trace[: min(s.num_iterations, trace_capacity)].copy()

@@ -131,6 +131,52 @@ void quat_plus(const double* x, const double* delta, double* out) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MotionEstimate reprojection problem: REF/include/MotionEstimate.h:34-91.
+// predictions = K * (q * P + t) with Eigen's quaternion-vector product, residual = prediction - observation;
+// AutoDiffCostFunction<ReprojectionError3Dto2D, 2, 4, 3, 3> -> Jet over (q[4], t[3]) (the 3-D point is constant:
+// MotionEstimate.cc:111-114), then the 4x3 Jacobian of EigenQuaternionParameterization::Plus.
+// ---------------------------------------------------------------------------------------------
+template <int N> Jet<N> operator/(const Jet<N>& f, const Jet<N>& g) {
+  Jet<N> h;
+  const double inv = 1.0 / g.a;
+  h.a = f.a * inv;
+  for (int i = 0; i < N; ++i) h.v[i] = (f.v[i] - h.a * g.v[i]) * inv;
+  return h;
+}
+inline double operator_div(double a, double b) { return a / b; }
+
+template <class T>
+void reproj_functor(const double* intr, const double* obs, const T* q, const T* t, const double* p, T* res) {
+  Q4<T> Q{q[0], q[1], q[2], q[3]};
+  V3<T> P{T(p[0]), T(p[1]), T(p[2])};
+  V3<T> r = qrot(Q, P);                                             // MotionEstimate.h:44  p_p = q*p + t
+  T x = r.x + t[0], y = r.y + t[1], z = r.z + t[2];
+  res[0] = (T(intr[0]) * x) / z + T(intr[2]) - T(obs[0]);           // :57, :78   (fx * x) / z + cx - u
+  res[1] = (T(intr[1]) * y) / z + T(intr[3]) - T(obs[1]);           // :58, :79
+}
+
+// residual (2) and local Jacobian (2x6: columns dtheta(3) of q's Plus, dt(3)) of one observation
+void reproj_eval_point(const double* intr, const double* obs, const double* q, const double* t, const double* p,
+                       double* r, double* J) {
+  typedef Jet<7> J7;
+  J7 jq[4], jt[3], jr[2];
+  for (int i = 0; i < 4; ++i) jq[i] = J7(q[i], i);
+  for (int i = 0; i < 3; ++i) jt[i] = J7(t[i], 4 + i);
+  reproj_functor<J7>(intr, obs, jq, jt, p, jr);
+  double PJ[12];
+  quat_plus_jacobian(q, PJ);
+  for (int a = 0; a < 2; ++a) {
+    r[a] = jr[a].a;
+    for (int c = 0; c < 3; ++c) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += jr[a].v[k] * PJ[3 * k + c];
+      J[6 * a + c] = s;
+      J[6 * a + 3 + c] = jr[a].v[4 + c];
+    }
+  }
+}
+
 const double kIdentity6[36] = {1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0,
                                0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1};
 
@@ -1209,6 +1255,180 @@ double oracle_time_jacobian_eval(int N, int E, const double* poses, const uint8_
   const auto t1 = std::chrono::steady_clock::now();
   if (checksum) *checksum = acc;
   return std::chrono::duration<double>(t1 - t0).count();
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// MotionEstimate: the small dense Ceres problem of REF/src/MotionEstimate.cc:71-129 —
+// one quaternion block (EigenQuaternionParameterization; the reference sets it CONSTANT, :108) + one translation block,
+// n reprojection residual blocks with HuberLoss(1.0) sharing them, max_num_iterations = 1000, SPARSE_NORMAL_CHOLESKY
+// (= an exact solve of the 6x6 / 3x3 normal equations).  Same trust-region rules as oracle_solve above.
+// cmask bit0: t constant, bit1: q constant.  trace rows as oracle_solve (ORACLE_TRACE_COLS).
+// ---------------------------------------------------------------------------------------------
+void oracle_reproj_eval(int n, const double* points, const double* obs, const double* intr, const double* q, const double* t,
+                        double* residuals, double* jacobians) {
+  for (int i = 0; i < n; ++i) reproj_eval_point(intr, obs + 2 * i, q, t, points + 3 * i, residuals + 2 * i, jacobians + 12 * i);
+}
+
+int oracle_reproj_solve(int n, const double* points, const double* obs, const double* intr, double* q, double* t, int cmask,
+                        const oracle_options* opt, oracle_summary* sum, double* trace, int trace_capacity) {
+  std::memset(sum, 0, sizeof *sum);
+  const bool t_const = (cmask & 1) != 0, q_const = (cmask & 2) != 0;
+  auto is_const = [&](int i) { return i < 3 ? q_const : t_const; };   // local dims: [dtheta(3) | dt(3)]
+  double x[7] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2]}, cand[7];
+  double H[36], g[6], scale[6] = {1, 1, 1, 1, 1, 1}, diag[6], gs[6], step[6], delta[6];
+  double x_cost = 0, radius = opt->initial_trust_region_radius, decrease_factor = 2.0, gradient_max_norm = 0;
+  bool reuse_diagonal = false, scaled_once = false;
+  int n_trace = 0;
+
+  auto cost_at = [&](const double* xx) {
+    double c = 0;
+    for (int i = 0; i < n; ++i) {
+      double r[2], J[12], rho[3];
+      reproj_eval_point(intr, obs + 2 * i, xx, xx + 4, points + 3 * i, r, J);
+      loss_eval(opt->loss_kind, opt->loss_a, r[0] * r[0] + r[1] * r[1], rho);
+      c += 0.5 * rho[0];
+    }
+    return c;
+  };
+  auto plus = [&](const double* xx, const double* dl, double* out) {
+    if (q_const) { for (int i = 0; i < 4; ++i) out[i] = xx[i]; } else quat_plus(xx, dl, out);
+    for (int i = 0; i < 3; ++i) out[4 + i] = t_const ? xx[4 + i] : xx[4 + i] + dl[3 + i];
+  };
+  auto x_norm_of = [&](const double* xx) {
+    double s = 0;
+    if (!q_const) for (int i = 0; i < 4; ++i) s += xx[i] * xx[i];
+    if (!t_const) for (int i = 4; i < 7; ++i) s += xx[i] * xx[i];
+    return std::sqrt(s);
+  };
+  auto evaluate_gradient_and_jacobian = [&]() {
+    for (int k = 0; k < 36; ++k) H[k] = 0;
+    for (int k = 0; k < 6; ++k) g[k] = 0;
+    double c = 0;
+    for (int i = 0; i < n; ++i) {
+      double r[2], J[12], rho[3];
+      reproj_eval_point(intr, obs + 2 * i, x, x + 4, points + 3 * i, r, J);
+      loss_eval(opt->loss_kind, opt->loss_a, r[0] * r[0] + r[1] * r[1], rho);
+      c += 0.5 * rho[0];
+      const double w = rho[1];          // corrector with rho'' <= 0: residual and Jacobian scaled by sqrt(rho')
+      for (int a = 0; a < 2; ++a)
+        for (int u = 0; u < 6; ++u) {
+          if (is_const(u)) continue;
+          g[u] += w * J[6 * a + u] * r[a];
+          for (int v = 0; v < 6; ++v) if (!is_const(v)) H[6 * u + v] += w * J[6 * a + u] * J[6 * a + v];
+        }
+    }
+    for (int u = 0; u < 6; ++u) if (is_const(u)) H[7 * u] = 1.0;
+    x_cost = c;
+    if (opt->jacobi_scaling) {
+      if (!scaled_once) {
+        for (int u = 0; u < 6; ++u) scale[u] = 1.0 / (1.0 + std::sqrt(is_const(u) ? 0.0 : H[7 * u]));
+        scaled_once = true;
+      }
+      for (int u = 0; u < 6; ++u) for (int v = 0; v < 6; ++v) H[6 * u + v] *= scale[u] * scale[v];
+      for (int u = 0; u < 6; ++u) if (is_const(u)) H[7 * u] = 1.0;
+    }
+    for (int u = 0; u < 6; ++u) gs[u] = g[u] * scale[u];
+    double neg[6];
+    for (int u = 0; u < 6; ++u) neg[u] = -g[u];
+    plus(x, neg, cand);
+    double gm = 0;
+    if (!q_const) for (int i = 0; i < 4; ++i) gm = std::max(gm, std::fabs(x[i] - cand[i]));
+    if (!t_const) for (int i = 4; i < 7; ++i) gm = std::max(gm, std::fabs(x[i] - cand[i]));
+    gradient_max_norm = gm;
+  };
+  struct Iter { int iteration; double cost, cost_change, gmax, step_norm, rel_dec, radius; bool ok; } it{};
+  auto push_trace = [&]() {
+    if (trace && n_trace < trace_capacity) {
+      double* tr = trace + (size_t)ORACLE_TRACE_COLS * n_trace;
+      tr[0] = it.iteration; tr[1] = it.cost; tr[2] = it.cost_change; tr[3] = it.gmax; tr[4] = it.step_norm;
+      tr[5] = it.rel_dec; tr[6] = it.radius; tr[7] = 0; tr[8] = it.ok ? 1.0 : 0.0;
+    }
+    ++n_trace;
+  };
+  double x_norm = x_norm_of(x);
+  evaluate_gradient_and_jacobian();
+  sum->initial_cost = x_cost;
+  it = Iter{0, x_cost, 0, gradient_max_norm, 0, 0, radius, true};
+  int num_consecutive_invalid = 0, term = 1, reason = 5;
+  for (;;) {
+    if (it.ok) ++sum->num_successful_steps; else ++sum->num_unsuccessful_steps;
+    it.radius = radius;
+    push_trace();
+    if (it.iteration >= opt->max_num_iterations) { term = 1; reason = 5; break; }
+    if (it.ok && it.gmax <= opt->gradient_tolerance) { term = 0; reason = 3; break; }
+    if (it.radius <= opt->min_trust_region_radius) { term = 0; reason = 4; break; }
+    Iter nx{};
+    nx.iteration = it.iteration + 1;
+    nx.gmax = it.gmax;
+    if (!reuse_diagonal) for (int u = 0; u < 6; ++u) diag[u] = std::min(std::max(H[7 * u], opt->min_lm_diagonal), opt->max_lm_diagonal);
+    std::vector<double> A(H, H + 36);
+    for (int u = 0; u < 6; ++u) A[7 * u] += diag[u] / radius;
+    bool lin_ok = chol_dense(A, 6);
+    if (lin_ok) chol_dense_solve(A, 6, gs, step);
+    if (lin_ok) for (int u = 0; u < 6; ++u) if (!std::isfinite(step[u])) lin_ok = false;
+    for (int u = 0; u < 6; ++u) step[u] = -step[u];
+    reuse_diagonal = true;
+    double model_cost_change = 0;
+    bool step_valid = false;
+    if (lin_ok) {
+      double a = 0, b = 0;
+      for (int u = 0; u < 6; ++u) {
+        if (is_const(u)) continue;
+        double hs = 0;
+        for (int v = 0; v < 6; ++v) hs += H[6 * u + v] * step[v];
+        a += step[u] * gs[u];
+        b += step[u] * hs;
+      }
+      model_cost_change = -a - 0.5 * b;
+      step_valid = model_cost_change > 0.0;
+    }
+    if (!step_valid) {
+      ++num_consecutive_invalid;
+      if (num_consecutive_invalid >= opt->max_num_consecutive_invalid_steps) { term = 2; reason = 6; it = nx; break; }
+      radius *= 0.5;
+      nx.cost = x_cost; nx.ok = false;
+      it = nx;
+      continue;
+    }
+    num_consecutive_invalid = 0;
+    for (int u = 0; u < 6; ++u) delta[u] = is_const(u) ? 0.0 : step[u] * scale[u];
+    plus(x, delta, cand);
+    const double cand_cost = cost_at(cand);
+    {
+      double sq = 0;
+      if (!q_const) for (int i = 0; i < 4; ++i) sq += (x[i] - cand[i]) * (x[i] - cand[i]);
+      if (!t_const) for (int i = 4; i < 7; ++i) sq += (x[i] - cand[i]) * (x[i] - cand[i]);
+      nx.step_norm = std::sqrt(sq);
+    }
+    if (nx.step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) { term = 0; reason = 2; it = nx; it.cost = x_cost; break; }
+    nx.cost_change = x_cost - cand_cost;
+    if (std::fabs(nx.cost_change) <= opt->function_tolerance * x_cost) { term = 0; reason = 1; it = nx; it.cost = x_cost; break; }
+    nx.rel_dec = nx.cost_change / model_cost_change;
+    if (nx.rel_dec > opt->min_relative_decrease) {
+      for (int i = 0; i < 7; ++i) x[i] = cand[i];
+      x_norm = x_norm_of(x);
+      evaluate_gradient_and_jacobian();
+      nx.ok = true; nx.cost = x_cost; nx.gmax = gradient_max_norm;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * nx.rel_dec - 1.0, 3));
+      radius = std::min(opt->max_trust_region_radius, radius);
+      decrease_factor = 2.0;
+      reuse_diagonal = false;
+    } else {
+      nx.ok = false; nx.cost = cand_cost;
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+      reuse_diagonal = true;
+    }
+    it = nx;
+  }
+  for (int i = 0; i < 4; ++i) q[i] = x[i];
+  for (int i = 0; i < 3; ++i) t[i] = x[4 + i];
+  sum->termination_type = term;
+  sum->reason = reason;
+  sum->final_cost = x_cost;
+  sum->num_iterations = n_trace;
+  return term == 2 ? -1 : 0;
 }
 
 }  // extern "C"

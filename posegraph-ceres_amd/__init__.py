@@ -41,7 +41,7 @@ C_ABI_SYMBOLS = [
     "pgo_evaluate", "pgo_normal_equations", "pgo_linear_solve", "pgo_plus", "pgo_solver_begin",
     "pgo_solver_step", "pgo_solver_reset", "pgo_solver_end", "pgo_time_kernel", "pgo_shard_range",
     "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_loopback_create", "pgo_loopback_destroy", "pgo_comm_init_loopback",
-    "pgo_generate_candidates",
+    "pgo_generate_candidates", "pgo_reproj_options_init", "pgo_reproj_solve_batch",
 ]
 
 
@@ -156,6 +156,52 @@ def generate_candidates(xyz, search_radius=6.0, gap=100, return_ms=False):
                                          idx.ctypes.data_as(C.POINTER(C.c_int)), C.c_longlong(idx.shape[0]), C.byref(ms)))
     out = {k: idx[row_ptr[k]:row_ptr[k + 1]].tolist() for k in range(1, n)}
     return (out, ms.value) if return_ms else out
+
+
+class ReprojOptions(C.Structure):
+    """Mirror of pgo_reproj_options (include/pgo.h); defaults = MotionEstimate.cc:71-125."""
+    _fields_ = [("max_num_iterations", C.c_int), ("q_constant", C.c_int), ("t_constant", C.c_int), ("loss_kind", C.c_int),
+                ("jacobi_scaling", C.c_int), ("max_num_consecutive_invalid_steps", C.c_int), ("loss_a", C.c_double),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+                ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+                ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        lib().pgo_reproj_options_init(C.byref(self))
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError(k)
+            setattr(self, k, v)
+
+
+REPROJ_SUMMARY_DTYPE = None
+
+
+def reproj_solve_batch(point_ptr, points, observations, intrinsics, q, t, options=None, return_ms=False):
+    """Batched MotionEstimate solves (pgo_reproj_solve_batch).  q (n,4 xyzw) and t (n,3) are updated IN PLACE.
+    Returns a structured array of per-problem summaries (and the kernel time in ms when return_ms)."""
+    import numpy as np
+    global REPROJ_SUMMARY_DTYPE
+    if REPROJ_SUMMARY_DTYPE is None:
+        REPROJ_SUMMARY_DTYPE = np.dtype([("termination_type", "i4"), ("reason", "i4"), ("num_iterations", "i4"),
+                                         ("num_successful_steps", "i4"), ("num_unsuccessful_steps", "i4"), ("num_points", "i4"),
+                                         ("initial_cost", "f8"), ("final_cost", "f8")])
+    ptr = np.ascontiguousarray(point_ptr, dtype=np.int64)
+    n = ptr.shape[0] - 1
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    ob = np.ascontiguousarray(observations, dtype=np.float64).reshape(-1, 2)
+    K = np.ascontiguousarray(intrinsics, dtype=np.float64).reshape(4)
+    for a, w in ((q, 4), (t, 3)):
+        if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and a.shape == (n, w)):
+            raise ValueError("q / t must be C-contiguous float64 arrays of shape (n_problems, 4) / (n_problems, 3)")
+    o = options or ReprojOptions()
+    summ = np.zeros(max(n, 1), dtype=REPROJ_SUMMARY_DTYPE)
+    ms = C.c_double(0)
+    _check(lib().pgo_reproj_solve_batch(C.c_int(n), ptr.ctypes.data_as(C.POINTER(C.c_longlong)), _dp(pts), _dp(ob), _dp(K), _dp(q), _dp(t),
+                                        C.byref(o), summ.ctypes.data_as(C.c_void_p), C.byref(ms)))
+    return (summ[:n], ms.value) if return_ms else summ[:n]
 
 
 def comm_unique_id():

@@ -89,7 +89,9 @@ def test_compute_calls_fail_loudly_without_a_gpu(pkg):
     p.add_poses(poses)
     p.add_se3_between([1], [0], [[1, 0, 0, 0, 0, 0, 1.0]])
     for call in (lambda: pkg.solve(pkg.SolverOptions(), p), lambda: p.evaluate(), lambda: p.normal_equations(),
-                 lambda: p.plus(np.zeros((2, 6))), lambda: pkg.generate_candidates(np.zeros((5, 3)))):
+                 lambda: p.plus(np.zeros((2, 6))), lambda: pkg.generate_candidates(np.zeros((5, 3))),
+                 lambda: pkg.reproj_solve_batch(np.array([0, 1]), np.ones((1, 3)), np.zeros((1, 2)), np.ones(4),
+                                                np.array([[0, 0, 0, 1.0]]), np.zeros((1, 3)))):
         with pytest.raises(pkg.PgoError) as ei:
             call()
         assert ei.value.code == pkg.ERR_NO_DEVICE and "no CPU fallback" in str(ei.value)
