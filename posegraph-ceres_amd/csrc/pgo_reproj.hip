@@ -137,6 +137,8 @@ __device__ __forceinline__ double diff_max(const State& a, const State& b, bool 
 __global__ __launch_bounds__(64) void k_reproj_solve(int n_problems, const long long* __restrict__ ptr, const double* __restrict__ points,
                                                      const double* __restrict__ obs, Intr K, double* __restrict__ qs, double* __restrict__ ts,
                                                      pgo_reproj_options o, pgo_reproj_summary* __restrict__ out) {
+  __shared__ double red[28 * 65];
+  __shared__ double tot[28];
   const int pb = blockIdx.x, lane = threadIdx.x;
   if (pb >= n_problems) return;
   const long long p0 = ptr[pb], p1 = ptr[pb + 1];
@@ -176,8 +178,25 @@ __global__ __launch_bounds__(64) void k_reproj_solve(int n_problems, const long 
         acc[21 + u] += rho1 * (J[u] * r[0] + J[6 + u] * r[1]);
       }
     }
+    // fold the 28 per-lane sums through LDS: lane k < 28 adds column k in lane order, the totals are read back by all
+    // (28 DPP wave reductions cost as much as the point loop itself; ~120 LDS operations instead of ~1700 DPP moves)
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < 28; ++k) acc[k] = wave_sum_r(acc[k]);
+    for (int k = 0; k < 28; ++k) red[k * 65 + lane] = acc[k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 28) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int l = 0; l < 64; l += 4) {
+        s0 += red[lane * 65 + l]; s1 += red[lane * 65 + l + 1]; s2 += red[lane * 65 + l + 2]; s3 += red[lane * 65 + l + 3];
+      }
+      tot[lane] = (s0 + s1) + (s2 + s3);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = tot[k];
     int k = 0;
 #pragma unroll
     for (int u = 0; u < 6; ++u)
