@@ -258,6 +258,127 @@ inline void Fail(Solver::Summary* s, const std::string& why) {
   s->message = why;
 }
 
+// ---- the MotionEstimate problem (REF/src/MotionEstimate.cc:71-129): residual blocks of
+// AutoDiffCostFunction<ReprojectionError3Dto2D, 2, 4, 3, 3> over ONE quaternion block, ONE translation block and constant
+// 3-D points.  The functor hides the pixel and reads the intrinsics from a config singleton (MotionEstimate.h:52-58): probing
+// Evaluate recovers  r = (fx x/z + c0, fy y/z + c1)  with  c0 = cx - u, c1 = cy - v.
+struct RecoveredReprojection { double fx, fy, c0, c1; };
+
+inline void ReprojResidual(const RecoveredReprojection& k, const double* q, const double* t, const double* p, double* r) {
+  const double u[3] = {q[0], q[1], q[2]}, w = q[3];
+  const double uv[3] = {2 * (u[1] * p[2] - u[2] * p[1]), 2 * (u[2] * p[0] - u[0] * p[2]), 2 * (u[0] * p[1] - u[1] * p[0])};
+  const double c[3] = {u[1] * uv[2] - u[2] * uv[1], u[2] * uv[0] - u[0] * uv[2], u[0] * uv[1] - u[1] * uv[0]};
+  const double x = p[0] + w * uv[0] + c[0] + t[0], y = p[1] + w * uv[1] + c[1] + t[1], z = p[2] + w * uv[2] + c[2] + t[2];
+  r[0] = (k.fx * x) / z + k.c0;
+  r[1] = (k.fy * y) / z + k.c1;
+}
+
+inline bool RecoverReprojection(const CostFunction* cost, RecoveredReprojection* out) {
+  const std::vector<int32>& sz = cost->parameter_block_sizes();
+  if (cost->num_residuals() != 2 || sz.size() != 3 || sz[0] != 4 || sz[1] != 3 || sz[2] != 3) return false;
+  const double q[4] = {0, 0, 0, 1}, t[3] = {0, 0, 0};
+  double p[3] = {0, 0, 1};
+  const double* blocks[3] = {q, t, p};
+  double r0[2], r[2];
+  if (!cost->Evaluate(blocks, r0, 0)) return false;
+  out->c0 = r0[0]; out->c1 = r0[1];
+  p[0] = 1.0;
+  if (!cost->Evaluate(blocks, r, 0)) return false;
+  out->fx = r[0] - r0[0];
+  if (std::fabs(r[1] - r0[1]) > 1e-9 * (1.0 + std::fabs(r0[1]))) return false;
+  p[0] = 0.0; p[1] = 1.0;
+  if (!cost->Evaluate(blocks, r, 0)) return false;
+  out->fy = r[1] - r0[1];
+  if (std::fabs(r[0] - r0[0]) > 1e-9 * (1.0 + std::fabs(r0[0]))) return false;
+  unsigned seed = 54321u;
+  for (int trial = 0; trial < 3; ++trial) {
+    double v[10];
+    for (int i = 0; i < 10; ++i) { seed = seed * 1664525u + 1013904223u; v[i] = ((seed >> 8) & 0xffff) / 32768.0 - 1.0; }
+    const double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+    for (int i = 0; i < 4; ++i) v[i] /= n;
+    v[9] = 6.0 + v[9];                                        // keep the point in front of the camera
+    const double* bl[3] = {v, v + 4, v + 7};
+    double want[2], got[2];
+    if (!cost->Evaluate(bl, want, 0)) return false;
+    ReprojResidual(*out, v, v + 4, v + 7, got);
+    for (int i = 0; i < 2; ++i) if (!(std::fabs(want[i] - got[i]) <= 1e-9 * (1.0 + std::fabs(want[i])))) return false;
+  }
+  return true;
+}
+
+inline int LossKind(const LossFunction* loss, double* a) {
+  *a = 1.0;
+  if (!loss) return PGO_LOSS_TRIVIAL;
+  if (const HuberLoss* h = dynamic_cast<const HuberLoss*>(loss)) { *a = h->a(); return PGO_LOSS_HUBER; }
+  if (const SoftLOneLoss* h = dynamic_cast<const SoftLOneLoss*>(loss)) { *a = h->a(); return PGO_LOSS_SOFT_L_ONE; }
+  if (const CauchyLoss* h = dynamic_cast<const CauchyLoss*>(loss)) { *a = h->a(); return PGO_LOSS_CAUCHY; }
+  if (const ArctanLoss* h = dynamic_cast<const ArctanLoss*>(loss)) { *a = h->a(); return PGO_LOSS_ARCTAN; }
+  if (dynamic_cast<const TrivialLoss*>(loss)) return PGO_LOSS_TRIVIAL;
+  return -1;
+}
+
+// ceres::Solve for the MotionEstimate problem -> pgo_reproj_solve_batch with one problem (the batched entry point is what a
+// caller with many candidate pairs should use directly).
+inline void SolveReprojection(const Solver::Options& options, Problem* problem, Solver::Summary* summary) {
+  const std::vector<ResidualBlock*>& rbs = problem->residual_blocks();
+  double* q = rbs[0]->blocks[0];
+  double* t = rbs[0]->blocks[1];
+  const LossFunction* loss = rbs[0]->loss;
+  std::vector<double> points(3 * rbs.size()), obs(2 * rbs.size());
+  RecoveredReprojection k0 = {0, 0, 0, 0};
+  for (size_t i = 0; i < rbs.size(); ++i) {
+    const ResidualBlock* rb = rbs[i];
+    RecoveredReprojection k;
+    if (!RecoverReprojection(rb->cost, &k))
+      return Fail(summary, "unsupported cost function: residual block is neither an SE(3) between factor nor a 3D-to-2D reprojection factor");
+    if (rb->blocks[0] != q || rb->blocks[1] != t) return Fail(summary, "unsupported: reprojection blocks must share one quaternion and one translation block");
+    if (rb->loss != loss) return Fail(summary, "unsupported: residual blocks use different LossFunction instances");
+    if (!problem->IsParameterBlockConstant(rb->blocks[2])) return Fail(summary, "unsupported: the 3-D points of the reprojection problem must be constant (MotionEstimate.cc:111-114)");
+    if (i == 0) k0 = k;
+    if (std::fabs(k.fx - k0.fx) > 1e-9 * std::fabs(k0.fx) || std::fabs(k.fy - k0.fy) > 1e-9 * std::fabs(k0.fy))
+      return Fail(summary, "unsupported: reprojection blocks with different focal lengths");
+    for (int c = 0; c < 3; ++c) points[3 * i + c] = rb->blocks[2][c];
+    obs[2 * i] = -k.c0;      // with cx = cy = 0 the pixel is -(cx - u)
+    obs[2 * i + 1] = -k.c1;
+  }
+  if (!dynamic_cast<const EigenQuaternionParameterization*>(problem->GetParameterization(q)))
+    return Fail(summary, "unsupported: the quaternion block must use EigenQuaternionParameterization");
+  if (problem->GetParameterization(t)) return Fail(summary, "unsupported: the translation block must be Euclidean");
+  pgo_reproj_options o;
+  pgo_reproj_options_init(&o);
+  o.loss_kind = LossKind(loss, &o.loss_a);
+  if (o.loss_kind < 0) return Fail(summary, "unsupported LossFunction (TrivialLoss, HuberLoss, SoftLOneLoss, CauchyLoss, ArctanLoss or NULL)");
+  o.max_num_iterations = options.max_num_iterations;
+  o.q_constant = problem->IsParameterBlockConstant(q) ? 1 : 0;
+  o.t_constant = problem->IsParameterBlockConstant(t) ? 1 : 0;
+  o.jacobi_scaling = options.jacobi_scaling ? 1 : 0;
+  o.max_num_consecutive_invalid_steps = options.max_num_consecutive_invalid_steps;
+  o.function_tolerance = options.function_tolerance; o.gradient_tolerance = options.gradient_tolerance;
+  o.parameter_tolerance = options.parameter_tolerance;
+  o.initial_trust_region_radius = options.initial_trust_region_radius; o.max_trust_region_radius = options.max_trust_region_radius;
+  o.min_trust_region_radius = options.min_trust_region_radius; o.min_relative_decrease = options.min_relative_decrease;
+  o.min_lm_diagonal = options.min_lm_diagonal; o.max_lm_diagonal = options.max_lm_diagonal;
+  const long long ptr[2] = {0, (long long)rbs.size()};
+  const double intr[4] = {k0.fx, k0.fy, 0.0, 0.0};
+  pgo_reproj_summary rs;
+  double ms = 0.0;
+  if (pgo_reproj_solve_batch(1, ptr, &points[0], &obs[0], intr, q, t, &o, &rs, &ms) < 0) return Fail(summary, pgo_last_error());
+  summary->termination_type = rs.termination_type == PGO_CONVERGENCE ? CONVERGENCE : rs.termination_type == PGO_NO_CONVERGENCE ? NO_CONVERGENCE : FAILURE;
+  static const char* const kReason[] = {"", "Function tolerance reached.", "Parameter tolerance reached.", "Gradient tolerance reached.",
+                                        "Minimum trust region radius reached.", "Maximum number of iterations reached.",
+                                        "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps."};
+  summary->message = kReason[rs.reason >= 1 && rs.reason <= 6 ? rs.reason : 0];
+  summary->initial_cost = rs.initial_cost;
+  summary->final_cost = rs.final_cost;
+  summary->num_successful_steps = rs.num_successful_steps;
+  summary->num_unsuccessful_steps = rs.num_unsuccessful_steps;
+  summary->total_time_in_seconds = ms * 1e-3;
+  summary->raw.termination_type = rs.termination_type; summary->raw.reason = rs.reason; summary->raw.num_iterations = rs.num_iterations;
+  summary->raw.num_successful_steps = rs.num_successful_steps; summary->raw.num_unsuccessful_steps = rs.num_unsuccessful_steps;
+  summary->raw.initial_cost = rs.initial_cost; summary->raw.final_cost = rs.final_cost; summary->raw.total_time_in_seconds = ms * 1e-3;
+  summary->raw.num_edges = rs.num_points;
+}
+
 }  // namespace internal
 
 inline void Solver::Solve(const Options& options, Problem* problem, Summary* summary) {
@@ -271,6 +392,8 @@ inline void Solver::Solve(const Options& options, Problem* problem, Summary* sum
   struct Guard { pgo_problem* p; ~Guard() { pgo_problem_destroy(p); } } guard = {P};
 
   const std::vector<internal::ResidualBlock*>& rbs = problem->residual_blocks();
+  if (!rbs.empty() && rbs[0]->cost->num_residuals() == 2 && rbs[0]->blocks.size() == 3)
+    return internal::SolveReprojection(options, problem, summary);      // MotionEstimate.cc problem
   const LossFunction* loss = rbs.empty() ? 0 : rbs[0]->loss;
   std::vector<int> ia(rbs.size()), ib(rbs.size());
   std::vector<double> t_be(7 * rbs.size()), sqrt_info(36 * rbs.size());

@@ -20,8 +20,17 @@ def tools(pkg):
 def test_facade_selftest(tools):
     out = subprocess.run([os.path.join(tools, "facade_selftest")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    for name in ("recover", "autodiff", "parameterization", "problem"):
+    for name in ("recover", "autodiff", "parameterization", "problem", "motion_estimate"):
         assert "OK " + name in out.stdout
+
+
+@pytest.mark.gpu
+def test_facade_selftest_on_the_gpu(tools, gpu):
+    """The same binary with a device present: ceres::Solve succeeds on the pose-graph problem and on the MotionEstimate
+    problem (REF/src/MotionEstimate.cc:71-129) built through ceres::Problem (translation recovered, rotation untouched)."""
+    out = subprocess.run([os.path.join(tools, "facade_selftest")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK problem" in out.stdout and "OK motion_estimate" in out.stdout and "   t = " in out.stdout
 
 
 def test_reference_flow_fails_loudly_without_gpu(tools, pkg, ds, tmp_path):

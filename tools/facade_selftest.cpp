@@ -46,6 +46,21 @@ struct CountingLp : ceres::EigenQuaternionParameterization { ~CountingLp() { ++g
 struct NotBetween { template <typename T> bool operator()(const T* const a, const T* const, const T* const, const T* const, T* r) const {
   for (int i = 0; i < 6; ++i) r[i] = a[0] * a[0] + T(double(i)); return true; } };
 
+// the MotionEstimate functor (REF/include/MotionEstimate.h:34-91): intrinsics and pixel hidden inside, Eigen's q*p + t
+struct Reproj {
+  double fx, fy, cx, cy, u, v;
+  template <typename T> bool operator()(const T* const q, const T* const t, const T* const p, T* r) const {
+    const T uu[3] = {q[0], q[1], q[2]}, w = q[3];
+    T uv[3] = {uu[1] * p[2] - uu[2] * p[1], uu[2] * p[0] - uu[0] * p[2], uu[0] * p[1] - uu[1] * p[0]};
+    for (int i = 0; i < 3; ++i) uv[i] = uv[i] + uv[i];
+    const T c[3] = {uu[1] * uv[2] - uu[2] * uv[1], uu[2] * uv[0] - uu[0] * uv[2], uu[0] * uv[1] - uu[1] * uv[0]};
+    const T x = p[0] + w * uv[0] + c[0] + t[0], y = p[1] + w * uv[1] + c[1] + t[1], z = p[2] + w * uv[2] + c[2] + t[2];
+    r[0] = (T(fx) * x) / z + T(cx) - T(u);
+    r[1] = (T(fy) * y) / z + T(cy) - T(v);
+    return true;
+  }
+};
+
 static Term* RandomTerm(bool identity) {
   Term* t = new Term;
   double n = 0;
@@ -160,5 +175,49 @@ int main() {
     CHECK_OR_DIE(g_cost_deleted == 2 && g_loss_deleted == 1 && g_lp_deleted == 1);
   }
   std::printf("OK problem\n");
+
+  // ---- the MotionEstimate problem (MotionEstimate.cc:71-129) through ceres::Problem / ceres::Solve ----
+  {
+    const double fx = 718.856, fy = 718.856, cx = 607.1928, cy = 185.2157;
+    const double t_true[3] = {0.3, -0.1, 0.9};
+    const int n = 120;
+    static double pts[120][3];
+    double q[4] = {0, 0, 0, 1}, t[3] = {0, 0, 0};
+    ceres::Problem problem;
+    ceres::LossFunction* loss = new ceres::HuberLoss(1.0);
+    ceres::LocalParameterization* lp = new ceres::EigenQuaternionParameterization;
+    ceres::CostFunction* first = 0;
+    for (int i = 0; i < n; ++i) {
+      pts[i][0] = 10 * rnd(); pts[i][1] = 3 * rnd(); pts[i][2] = 20 + 15 * rnd();
+      const double X = pts[i][0] + t_true[0], Y = pts[i][1] + t_true[1], Z = pts[i][2] + t_true[2];
+      Reproj* f = new Reproj;
+      f->fx = fx; f->fy = fy; f->cx = cx; f->cy = cy;
+      f->u = fx * X / Z + cx + 0.3 * rnd(); f->v = fy * Y / Z + cy + 0.3 * rnd();
+      ceres::CostFunction* c = new ceres::AutoDiffCostFunction<Reproj, 2, 4, 3, 3>(f);
+      if (!first) first = c;
+      problem.AddResidualBlock(c, loss, q, t, pts[i]);
+      problem.SetParameterization(q, lp);
+    }
+    problem.SetParameterBlockConstant(q);
+    for (int i = 0; i < n; ++i) problem.SetParameterBlockConstant(pts[i]);
+    ceres::internal::RecoveredReprojection k;
+    CHECK_OR_DIE(ceres::internal::RecoverReprojection(first, &k));
+    CHECK_OR_DIE(std::fabs(k.fx - fx) < 1e-9 && std::fabs(k.fy - fy) < 1e-9);
+    ceres::Solver::Options options;
+    options.max_num_iterations = 1000;
+    options.linear_solver_type = ceres::SPARSE_NORMAL_CHOLESKY;
+    ceres::Solver::Summary summary;
+    ceres::Solve(options, &problem, &summary);
+    if (pgo_device_count() == 0) {
+      CHECK_OR_DIE(summary.termination_type == ceres::FAILURE && summary.message.find("no CPU fallback") != std::string::npos);
+      CHECK_OR_DIE(t[0] == 0.0 && t[1] == 0.0 && t[2] == 0.0);
+    } else {
+      CHECK_OR_DIE(summary.termination_type == ceres::CONVERGENCE && summary.final_cost < summary.initial_cost);
+      for (int i = 0; i < 3; ++i) CHECK_OR_DIE(std::fabs(t[i] - t_true[i]) < 0.05);
+      CHECK_OR_DIE(q[0] == 0.0 && q[3] == 1.0);
+      std::printf("   t = %.4f %.4f %.4f  cost %.3f -> %.3f\n", t[0], t[1], t[2], summary.initial_cost, summary.final_cost);
+    }
+  }
+  std::printf("OK motion_estimate\n");
   return 0;
 }
