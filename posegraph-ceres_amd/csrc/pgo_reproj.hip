@@ -134,17 +134,22 @@ __device__ __forceinline__ double diff_max(const State& a, const State& b, bool 
 }
 
 // one wave = one problem
-__global__ __launch_bounds__(64) void k_reproj_solve(int n_problems, const long long* __restrict__ ptr, const double* __restrict__ points,
+__global__ __launch_bounds__(64, 2) void k_reproj_solve(int n_problems, const long long* __restrict__ ptr, const double* __restrict__ points,
                                                      const double* __restrict__ obs, Intr K, double* __restrict__ qs, double* __restrict__ ts,
                                                      pgo_reproj_options o, pgo_reproj_summary* __restrict__ out) {
   __shared__ double red[28 * 65];
   __shared__ double tot[28];
+  // lane-uniform LM state lives in LDS (one wave per workgroup), not in vector registers: with it in VGPRs the kernel
+  // needed 256 VGPRs + AGPRs and ran one wave per SIMD
+  __shared__ double H[36], g[6], gs[6], scale[6], diag[6];
   const int pb = blockIdx.x, lane = threadIdx.x;
   if (pb >= n_problems) return;
   const long long p0 = ptr[pb], p1 = ptr[pb + 1];
   const bool q_const = o.q_constant != 0, t_const = o.t_constant != 0;
   State x{Q4{qs[4 * pb], qs[4 * pb + 1], qs[4 * pb + 2], qs[4 * pb + 3]}, V3{ts[3 * pb], ts[3 * pb + 1], ts[3 * pb + 2]}};
-  double H[36], g[6], gs[6], scale[6] = {1, 1, 1, 1, 1, 1}, diag[6] = {0, 0, 0, 0, 0, 0};
+  if (lane < 6) { scale[lane] = 1.0; diag[lane] = 0.0; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   double x_cost = 0.0, gmax = 0.0;
   bool scaled_once = false;
   auto is_const = [&](int i) { return i < 3 ? q_const : t_const; };
@@ -195,32 +200,26 @@ __global__ __launch_bounds__(64) void k_reproj_solve(int n_problems, const long 
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < 28; ++k) acc[k] = tot[k];
-    int k = 0;
-#pragma unroll
-    for (int u = 0; u < 6; ++u)
-#pragma unroll
-      for (int v = u; v < 6; ++v) { const double hv = (is_const(u) || is_const(v)) ? 0.0 : acc[k]; H[6 * u + v] = hv; H[6 * v + u] = hv; ++k; }
-#pragma unroll
-    for (int u = 0; u < 6; ++u) { g[u] = is_const(u) ? 0.0 : acc[21 + u]; if (is_const(u)) H[7 * u] = 1.0; }
-    x_cost = acc[27];
-    if (o.jacobi_scaling) {
-      if (!scaled_once) {
-#pragma unroll
-        for (int u = 0; u < 6; ++u) scale[u] = 1.0 / (1.0 + sqrt(is_const(u) ? 0.0 : H[7 * u]));
-        scaled_once = true;
-      }
-#pragma unroll
-      for (int u = 0; u < 6; ++u)
-#pragma unroll
-        for (int v = 0; v < 6; ++v) H[6 * u + v] *= scale[u] * scale[v];
-#pragma unroll
-      for (int u = 0; u < 6; ++u) if (is_const(u)) H[7 * u] = 1.0;
-    }
+    // lane 0 builds the (scaled) system in LDS
     double neg[6];
+    if (lane == 0) {
+      int k = 0;
+      for (int u = 0; u < 6; ++u)
+        for (int v = u; v < 6; ++v) { const double hv = (is_const(u) || is_const(v)) ? 0.0 : tot[k]; H[6 * u + v] = hv; H[6 * v + u] = hv; ++k; }
+      for (int u = 0; u < 6; ++u) { g[u] = is_const(u) ? 0.0 : tot[21 + u]; if (is_const(u)) H[7 * u] = 1.0; }
+      if (o.jacobi_scaling) {
+        if (!scaled_once) for (int u = 0; u < 6; ++u) scale[u] = 1.0 / (1.0 + sqrt(is_const(u) ? 0.0 : H[7 * u]));
+        for (int u = 0; u < 6; ++u) for (int v = 0; v < 6; ++v) H[6 * u + v] *= scale[u] * scale[v];
+        for (int u = 0; u < 6; ++u) if (is_const(u)) H[7 * u] = 1.0;
+      }
+      for (int u = 0; u < 6; ++u) gs[u] = g[u] * scale[u];
+    }
+    scaled_once = true;
+    x_cost = tot[27];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int u = 0; u < 6; ++u) { gs[u] = g[u] * scale[u]; neg[u] = -g[u]; }
+    for (int u = 0; u < 6; ++u) neg[u] = -g[u];
     gmax = diff_max(x, plus_state(x, neg, q_const, t_const), q_const, t_const);
   };
   auto x_norm_of = [&](const State& s) {
@@ -246,8 +245,9 @@ __global__ __launch_bounds__(64) void k_reproj_solve(int n_problems, const long 
     if (radius <= o.min_trust_region_radius) { term = 0; reason = 4; break; }
     ++iteration;
     if (!reuse_diagonal) {
-#pragma unroll
-      for (int u = 0; u < 6; ++u) diag[u] = fmin(fmax(H[7 * u], o.min_lm_diagonal), o.max_lm_diagonal);
+      if (lane < 6) diag[lane] = fmin(fmax(H[7 * lane], o.min_lm_diagonal), o.max_lm_diagonal);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
     double A[36], step[6];
 #pragma unroll
