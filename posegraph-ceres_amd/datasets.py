@@ -133,6 +133,12 @@ def _dead_reckon(first_pose, meas_odo):
 
 def _loop_pairs(xyz, count, rng, radius, min_gap):
     from scipy.spatial import cKDTree
+    n = len(xyz)
+    possible = max(0, n - min_gap - 1) * max(0, n - min_gap) // 2      # pairs more than min_gap apart, at any distance
+    if count > possible:
+        raise ValueError("cannot place %d loop edges: %d poses admit only %d pairs more than %d ids apart" % (count, n, possible, min_gap))
+    if count <= 0:
+        return np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32), radius
     tree = cKDTree(xyz)
     r = radius
     while True:

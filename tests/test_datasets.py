@@ -1,5 +1,6 @@
 """CPU: synthetic generators and g2o text format (data formats either side of the path)."""
 import numpy as np
+import pytest
 
 
 def test_manhattan_generator_is_seeded_and_consistent(ds, O):
@@ -50,3 +51,10 @@ def test_g2o_reader_on_the_reference_file_excerpt(ds, O):
     assert right < 1e-2 and swapped > 1e2
     # two edges of the excerpt skip a frame (the reference's accepted loop edges inside this window)
     assert sorted(zip(g.ia[np.abs(g.ia - g.ib) > 1].tolist(), g.ib[np.abs(g.ia - g.ib) > 1].tolist())) == [(145, 147), (186, 188)]
+
+
+def test_generator_rejects_impossible_loop_counts(ds):
+    with pytest.raises(ValueError):
+        ds.manhattan_se3(30, 200)                 # 30 poses admit 45 pairs with an id gap > 20
+    g = ds.manhattan_se3(30, 29)                  # odometry only
+    assert (g.N, g.E) == (30, 29)

@@ -1,0 +1,103 @@
+"""Randomised parity sweep: random graphs / options, GPU solve vs the oracle with the same policy.  Prints every mismatch.
+usage: python tools/fuzz_parity.py [n_cases] [first_seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pgo_loader  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+pkg = pgo_loader.load()
+ds = pgo_loader.datasets()
+
+
+def random_case(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(2, 400))
+    kind = rng.integers(0, 3)
+    if kind == 0:      # lattice walk with loop closures
+        possible = max(0, n - 21) * max(0, n - 20) // 2        # loop pairs the generator can place (id gap > 20)
+        e = n - 1 + int(rng.integers(0, min(3 * n + 2, possible) + 1))
+        g = ds.manhattan_se3(n, e, seed=int(rng.integers(1 << 30)))
+    else:              # random connected graph: chain + random chords, random measurements
+        poses = np.zeros((n, 7))
+        poses[:, :3] = rng.normal(0, 2.0, (n, 3))
+        q = rng.normal(size=(n, 4))
+        poses[:, 3:] = q / np.linalg.norm(q, axis=1, keepdims=True)
+        extra = int(rng.integers(0, 3 * n))
+        ia = np.concatenate([np.arange(1, n), rng.integers(0, n, extra)]).astype(np.int32)
+        ib = np.concatenate([np.arange(0, n - 1), rng.integers(0, n, extra)]).astype(np.int32)
+        keep = ia != ib
+        ia, ib = ia[keep], ib[keep]
+        truth = poses.copy()
+        meas = ds.relative_pose(truth[ia], truth[ib])
+        meas[:, :3] += rng.normal(0, 0.05 if kind == 1 else 0.5, (len(ia), 3))
+        meas[:, 3:] = ds.qmul(ds.qexp_half(rng.normal(0, 0.01 if kind == 1 else 0.2, (len(ia), 3))), meas[:, 3:])
+        info = None
+        t = rng.integers(0, 3)
+        if t == 1:
+            info = np.repeat(np.diag(rng.uniform(0.5, 3.0, 6)).reshape(1, 36), len(ia), axis=0)
+        elif t == 2:
+            A = rng.normal(size=(len(ia), 6, 6))
+            info = (np.linalg.cholesky(A @ np.transpose(A, (0, 2, 1)) + 6 * np.eye(6)) * 0.3).reshape(-1, 36)
+        start = truth.copy()
+        start[1:, :3] += rng.normal(0, 0.3, (n - 1, 3))
+        start[1:, 3:] = ds.qmul(ds.qexp_half(rng.normal(0, 0.05, (n - 1, 3))), start[1:, 3:])
+        g = ds.PoseGraphData(start, ia, ib, meas, info)
+    cmask = np.zeros(g.N, dtype=np.uint8)
+    cmask[0] = 3
+    for v in rng.integers(0, g.N, int(rng.integers(0, 3))):
+        cmask[v] = rng.integers(1, 4)
+    loss = int(rng.integers(0, 5))
+    loss_a = float(rng.uniform(0.3, 3.0))
+    exact = bool(rng.integers(0, 2))
+    cluster = int(rng.choice([1, 2, 4]))
+    return g, cmask, loss, loss_a, exact, cluster
+
+
+def main(n_cases=200, first=0):
+    bad = 0
+    t0 = time.time()
+    for seed in range(first, first + n_cases):
+        g, cmask, loss, loss_a, exact, cluster = random_case(seed)
+        prob, poses = pkg.problem_from_graph(g, loss=loss, loss_a=loss_a, constant_first=False)
+        for v in np.nonzero(cmask)[0]:
+            prob.set_pose_constant(int(v), int(cmask[v]))
+        nit = 12
+        opt = pkg.SolverOptions(max_num_iterations=nit, linear_solver_type=pkg.SPARSE_NORMAL_CHOLESKY if exact else pkg.BLOCK_JACOBI_PCG,
+                                pcg_cluster_poses=cluster)
+        tc = time.time()
+        try:
+            s = pkg.solve(opt, prob)
+        except Exception as exc:   # noqa: BLE001
+            print("seed", seed, "GPU EXCEPTION", exc)
+            bad += 1
+            continue
+        og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info, cmask)
+        op, osum, otr = O.solve(og, O.default_options(max_num_iterations=nit, linear_solver=0 if exact else 1, pcg_cluster=cluster,
+                                                      loss_kind=loss, loss_a=loss_a))
+        if time.time() - tc > 2.0 or os.environ.get("FUZZ_VERBOSE"):
+            print("seed", seed, "N", g.N, "E", g.E, "exact", exact, "cluster", cluster, "loss", loss, "used", s.linear_solver_used,
+                  "cg", s.num_linear_solver_iterations, "took %.2f s" % (time.time() - tc), flush=True)
+        n = min(len(otr), len(s.iterations))
+        ok = (len(otr) == len(s.iterations) and list(s.iterations["step_is_successful"][:n]) == [int(x) for x in otr[:n, 8]]
+              and np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-6, atol=1e-12)
+              and s.termination_type == osum.termination_type)
+        if not exact:   # Q-tolerance ties at rounding level move a long CG run by one iteration (the oracle refreshes r every 10)
+            a = np.array(s.iterations["linear_solver_iterations"][:n], dtype=np.int64)
+            b = np.array([int(x) for x in otr[:n, 7]], dtype=np.int64)
+            ok = ok and bool(np.all(np.abs(a - b) <= np.maximum(0, b // 100)))
+        if not ok:
+            bad += 1
+            print("seed", seed, "MISMATCH N", g.N, "E", g.E, "loss", loss, "exact", exact, "cluster", cluster, "used", s.linear_solver_used,
+                  "its", len(s.iterations), len(otr), "cost", s.final_cost, osum.final_cost,
+                  "cg", list(s.iterations["linear_solver_iterations"][:n]), [int(x) for x in otr[:n, 7]])
+    print("cases", n_cases, "mismatches", bad, "seconds %.1f" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    main(*[int(a) for a in sys.argv[1:]])
