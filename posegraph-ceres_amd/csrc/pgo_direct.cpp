@@ -177,6 +177,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   S.iperm.assign(N, -1);
   for (int k = 0; k < N; ++k) S.iperm[S.perm[k]] = k;
 
+  static const long long max_pairs = getenv("PGO_DIRECT_MAX_PAIRS") ? atoll(getenv("PGO_DIRECT_MAX_PAIRS")) : 16000000LL;
   // ---- 2. symbolic factorisation ----
   std::vector<std::vector<int>> st(N);   // struct(j): rows > j, sorted
   std::vector<int> parent(N, -1);
@@ -198,7 +199,10 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
     if (!tmp.empty()) { parent[j] = tmp[0]; children[tmp[0]].push_back(j); }
     nb += 1 + (long long)tmp.size();
     pairs += (long long)tmp.size() * ((long long)tmp.size() + 1) / 2;
-    if (nb > 60000000LL || pairs > 400000000LL) return false;   // too much fill for the enumerated schedule
+    // too much fill for the enumerated schedule.  The gate below accepts ~7000 critical-path steps (Manhattan 10 k: 6.4 M
+    // pairs = 9.5 k steps, rejected; KITTI-00 dense: 1.2 M pairs, accepted): a graph past this budget is going to be
+    // rejected anyway, so stop before the pair lists (seconds of host time and GBs) are built.
+    if (nb > 3000000LL || pairs > max_pairs) return false;
   }
   S.nb = (int)nb;
   S.n_pairs = pairs;

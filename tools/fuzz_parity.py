@@ -15,9 +15,12 @@ pkg = pgo_loader.load()
 ds = pgo_loader.datasets()
 
 
+MAX_N = int(os.environ.get("FUZZ_MAX_N", "400"))
+
+
 def random_case(seed):
     rng = np.random.default_rng(seed)
-    n = int(rng.integers(2, 400))
+    n = int(rng.integers(2, MAX_N))
     kind = rng.integers(0, 3)
     if kind == 0:      # lattice walk with loop closures
         possible = max(0, n - 21) * max(0, n - 20) // 2        # loop pairs the generator can place (id gap > 20)
