@@ -81,6 +81,11 @@ def main(n_cases=200, first=0):
             bad += 1
             continue
         t_gpu = time.time() - tc
+        if exact and g.N > 800:      # the oracle's exact solve takes up to a minute here: sanity checks only
+            if t_gpu > 2.0 or not (s.final_cost <= s.initial_cost * (1 + 1e-12)) or not s.is_solution_usable():
+                bad += 1
+                print("seed", seed, "SANITY N", g.N, "E", g.E, "GPU solve %.2f s" % t_gpu, "cost", s.initial_cost, s.final_cost, s.message)
+            continue
         og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info, cmask)
         op, osum, otr = O.solve(og, O.default_options(max_num_iterations=nit, linear_solver=0 if exact else 1, pcg_cluster=cluster,
                                                       loss_kind=loss, loss_a=loss_a))
