@@ -78,6 +78,11 @@ __device__ __forceinline__ void assemble_row(const DeviceGraph& g, const DirectP
   assemble_row(g, p, bi, r, sub, stride, v, p.upd_ptr[bi + 1]);
 }
 
+// forward-substitution pieces (defined below): the forward solve L y = P (S g) is fused into the factorisation — as soon
+// as L_jj exists, y_j = L_jj^-1 (b_j - sum_k L_jk y_k) needs only columns of earlier levels
+__device__ __forceinline__ void forward_partial(const DirectPlan& p, int j, int sub, int nsub, double* sh);
+__device__ __forceinline__ void forward_finish(const DeviceGraph& g, const DirectPlan& p, int j, int nsub, const double* sh_all, const double* Ljj);
+
 // Factorises column j with one wave.  sh: 360 doubles of LDS private to the wave (10 groups x 6 rows x 6).
 // The ten 6-lane groups share the work of a chunk of up to ten blocks: with fewer blocks than groups the
 // update list of each block is split over several groups and the partial rows are summed through LDS
@@ -167,6 +172,13 @@ __device__ void factor_column(const DeviceGraph& g, const DirectPlan& p, int j, 
       o[0] = double2{x[0], x[1]}; o[1] = double2{x[2], x[3]}; o[2] = double2{x[4], x[5]};
     }
   }
+  // fused forward substitution for this column (row j of L lives in columns of earlier levels)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  forward_partial(p, j, 0, 1, sh);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) forward_finish(g, p, j, 1, sh, Ljj);
 }
 
 // In-register Cholesky of a 6x6 block held (row-major, 36 doubles) by every lane; returns false on a non-positive pivot.
@@ -230,6 +242,12 @@ __global__ __launch_bounds__(64) void k_chol_assemble(DeviceGraph g, DirectPlan 
   const bool ok = chol6_inplace(Ljj);
   if (!ok && lane == 0) atomicOr(&g.flags[2], 1);
   if (lane < 36) p.Lval[36 * (size_t)bi + lane] = Ljj[lane];
+  // fused forward substitution for this column
+  const int j = p.blk_row[bi];
+  __syncthreads();
+  forward_partial(p, j, 0, 1, sh);
+  __syncthreads();
+  if (lane == 0) forward_finish(g, p, j, 1, sh, Ljj);
 }
 
 // phase 2, one 6-lane group per sub-diagonal block of the level (ten per wave, lane = row): L_ij = V_ij L_jj^-T
@@ -261,6 +279,7 @@ __global__ __launch_bounds__(64) void k_chol_scale(DeviceGraph g, DirectPlan p, 
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_panel(DeviceGraph g, DirectPlan p, int cols_begin, int width) {
   __shared__ double sh[360];
   __shared__ double Ld[36];
+  __shared__ double shf[FUSED_WAVES][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int grp = lane / 6, r = lane - 6 * grp;
   for (int i = 0; i < width; ++i) {
@@ -289,6 +308,10 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_panel(DeviceGraph g, 
     }
     __threadfence_block();
     __syncthreads();
+    // fused forward substitution: the row list of column j shared by all waves, finished by one lane
+    forward_partial(p, j, wave, FUSED_WAVES, shf[wave]);
+    __syncthreads();
+    if (wave == 0 && lane == 0) forward_finish(g, p, j, FUSED_WAVES, shf[0], Ld);
     if (grp < 10) {
       for (int t = 1 + wave * 10 + grp; t < nblk; t += 10 * FUSED_WAVES) {
         const int bi = b0 + t;
@@ -347,7 +370,7 @@ __device__ __forceinline__ void forward_partial(const DirectPlan& p, int j, int 
     sh[lane] = acc;
   }
 }
-__device__ __forceinline__ void forward_finish(const DeviceGraph& g, const DirectPlan& p, int j, int nsub, const double* sh_all) {
+__device__ __forceinline__ void forward_finish(const DeviceGraph& g, const DirectPlan& p, int j, int nsub, const double* sh_all, const double* L) {
   const int old = p.perm[j];
   double rhs[6], y[6];
 #pragma unroll
@@ -359,7 +382,6 @@ __device__ __forceinline__ void forward_finish(const DeviceGraph& g, const Direc
       for (int gq = 0; gq < 10; ++gq) s += sh_all[64 * w + 6 * gq + i];
     rhs[i] = b - s;
   }
-  const double* L = p.Lval + 36 * (size_t)p.col_ptr[j];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     double s = rhs[i];
@@ -410,13 +432,6 @@ __device__ __forceinline__ void backward_finish(const DeviceGraph& g, const Dire
   for (int i = 0; i < 6; ++i) { p.y[6 * (size_t)j + i] = x[i]; g.cg_x[6 * (size_t)old + i] = x[i]; }
 }
 
-__global__ __launch_bounds__(64) void k_fwd_level(DeviceGraph g, DirectPlan p, int level) {
-  __shared__ double sh[64];
-  const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
-  forward_partial(p, j, 0, 1, sh);
-  __syncthreads();
-  if (threadIdx.x == 0) forward_finish(g, p, j, 1, sh);
-}
 __global__ __launch_bounds__(64) void k_bwd_level(DeviceGraph g, DirectPlan p, int level) {
   __shared__ double sh[64];
   const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
@@ -424,22 +439,8 @@ __global__ __launch_bounds__(64) void k_bwd_level(DeviceGraph g, DirectPlan p, i
   __syncthreads();
   if (threadIdx.x == 0) backward_finish(g, p, j, 1, sh);
 }
-// Fused tail (levels with <= FUSED_WAVES columns): the FUSED_WAVES waves of the single workgroup are divided among the
-// columns of the level, so the long row lists of a dense separator chain (one column per level) are walked 80-wide.
-__global__ __launch_bounds__(64 * FUSED_WAVES) void k_fwd_tail(DeviceGraph g, DirectPlan p, int from_level) {
-  __shared__ double sh[FUSED_WAVES][64];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int l = from_level; l < p.n_levels; ++l) {
-    const int c0 = p.level_ptr[l], nc = p.level_ptr[l + 1] - c0;
-    const int nsub = max(1, FUSED_WAVES / nc);
-    const int col = wave / nsub, sub = wave - col * nsub;
-    if (col < nc) forward_partial(p, p.level_cols[c0 + col], sub, nsub, sh[wave]);
-    __syncthreads();
-    if (col < nc && sub == 0 && lane == 0) forward_finish(g, p, p.level_cols[c0 + col], nsub, sh[wave]);
-    __threadfence_block();
-    __syncthreads();
-  }
-}
+// Fused tail of the backward solve (levels with <= FUSED_WAVES columns): the FUSED_WAVES waves of the single workgroup are
+// divided among the columns of the level, so the long lists of a dense separator chain (one column per level) are walked 80-wide.
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_bwd_tail(DeviceGraph g, DirectPlan p, int from_level) {
   __shared__ double sh[FUSED_WAVES][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -475,15 +476,9 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
   }
 }
 
+// backward solve only: the forward substitution runs inside the factorisation kernels
 void launch_direct_solve(const DeviceGraph& g, const DirectPlan& p, const int* level_ptr_host, int fused_from_level, hipStream_t s) {
-  for (int l = 0; l < fused_from_level; ++l) {
-    const int nc = level_ptr_host[l + 1] - level_ptr_host[l];
-    hipLaunchKernelGGL(k_fwd_level, dim3(nc), dim3(64), 0, s, g, p, l);
-  }
-  if (fused_from_level < p.n_levels) {
-    hipLaunchKernelGGL(k_fwd_tail, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, fused_from_level);
-    hipLaunchKernelGGL(k_bwd_tail, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, fused_from_level);
-  }
+  if (fused_from_level < p.n_levels) hipLaunchKernelGGL(k_bwd_tail, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, fused_from_level);
   for (int l = fused_from_level - 1; l >= 0; --l) {
     const int nc = level_ptr_host[l + 1] - level_ptr_host[l];
     hipLaunchKernelGGL(k_bwd_level, dim3(nc), dim3(64), 0, s, g, p, l);
