@@ -834,14 +834,18 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   P->g.loss_a = P->loss_a;
   P->g.pose_x = P->d_pose_x.p;
   P->g.pose_c = P->d_pose_c.p;
-  rc = prepare_clusters(P, P->opt.pcg_cluster_poses);
-  if (rc) return rc;
+  int cluster = P->opt.pcg_cluster_poses;
   if (P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY) {
     const auto t_sym = Clock::now();
     rc = prepare_direct(P);
     if (rc) return rc;
     L.t_setup += seconds_since(t_sym);
+    // exact request served by PCG to exact_r_tolerance: the preconditioner is ours to choose — 2-pose chain clusters need
+    // ~2.5x fewer iterations than 6x6 blocks at almost the same cost per iteration
+    if (!P->direct_usable && cluster < 2) cluster = 2;
   }
+  rc = prepare_clusters(P, cluster);
+  if (rc) return rc;
   rc = upload_poses(P, P->g.pose_x);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(P->d_pose_0.p, P->g.pose_x, P->d_pose_0.n * sizeof(double), hipMemcpyDeviceToDevice, P->stream));
