@@ -65,6 +65,10 @@ typedef struct pgo_solver_options {
   int pcg_cluster_poses;                  /* poses per Jacobi block of the PCG preconditioner: 1 = 6x6 pose blocks (default;
                                              Ceres JACOBI is per parameter block), 2 = 12x12, 4 = 24x24 pieces of the odometry
                                              chain (Ceres CLUSTER_JACOBI analogue) */
+  int cg_residual_reset_period;           /* 10: every so many CG iterations r is recomputed as b - A x instead of updated
+                                             (Ceres conjugate_gradients_solver.cc, LinearSolver::Options::residual_reset_period);
+                                             0 = never */
+  int reserved0;
   double function_tolerance;              /* 1e-6 */
   double gradient_tolerance;              /* 1e-10 */
   double parameter_tolerance;             /* 1e-8 */

@@ -56,6 +56,7 @@ class _COptions(C.Structure):
         ("max_num_iterations", C.c_int), ("linear_solver_type", C.c_int), ("jacobi_scaling", C.c_int),
         ("max_linear_solver_iterations", C.c_int), ("min_linear_solver_iterations", C.c_int),
         ("max_num_consecutive_invalid_steps", C.c_int), ("cg_batch", C.c_int), ("pcg_cluster_poses", C.c_int),
+        ("cg_residual_reset_period", C.c_int), ("reserved0", C.c_int),
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
         ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
         ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),

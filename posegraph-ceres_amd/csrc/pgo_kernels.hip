@@ -654,6 +654,7 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
   const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
   double* lds_p = lds + (size_t)SPMV_LDS_STRIDE * B;
 
+  if (MODE == 1 && (odd & 8) && g.cg->done) return;   // A x of a residual refresh: nothing to do once the CG has stopped
   if (MODE == 1 && (odd & 2)) {
     // Step tail behind a CG batch: this kernel first does what k_pcg_finish does (every workgroup evaluates the stop test
     // of the last completed iteration from the same partial rows, workgroup 0 publishes the state), and computes
@@ -891,8 +892,11 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
 }
 
 // x += alpha p ; r -= alpha q ; z = M^-1 r ; partial r'z, Q = x'(b + r), r'r.  All loads up front.
+// mode 0: the normal iteration.  Every residual_reset_period-th iteration Ceres recomputes r = b - A x instead
+// (conjugate_gradients_solver.cc): mode 1 = only x += alpha p (then k_spmv<1> puts A x into cg_q), mode 2 = r = b - cg_q,
+// z, partial sums and the iteration counter.
 template <int CL>
-__global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd) {
+__global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd, int mode) {
   constexpr int DIM = 6 * CL;
   __shared__ double rl[VEC_BLOCK];
   __shared__ double scratch[3 * (VEC_BLOCK / 64)];
@@ -932,14 +936,17 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd
     }
   }
   if (done) return;
-  block_sum<1>(sums, scratch);
-  const double pq = sums[0];
-  if (!(pq > 0.0) || !isfinite(pq)) {
-    // "Matrix is indefinite, no more progress can be made": keep x of the previous iteration
-    if (blockIdx.x == 0 && tid == 0) { g.cg->iters = it - 1; g.cg->status = 1; g.cg->done = 1; }
-    return;
+  double alpha = 0.0;
+  if (mode != 2) {
+    block_sum<1>(sums, scratch);
+    const double pq = sums[0];
+    if (!(pq > 0.0) || !isfinite(pq)) {
+      // "Matrix is indefinite, no more progress can be made": keep x of the previous iteration
+      if (blockIdx.x == 0 && tid == 0) { g.cg->iters = it - 1; g.cg->status = 1; g.cg->done = 1; }
+      return;
+    }
+    alpha = rho / pq;
   }
-  const double alpha = rho / pq;
   double acc[3] = {0.0, 0.0, 0.0};
   for (int base = blockIdx.x * VEC_BLOCK; base < m; base += gridDim.x * VEC_BLOCK) {
     if (base != (int)blockIdx.x * VEC_BLOCK) {
@@ -955,12 +962,18 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd
     }
     double x = 0.0, r = 0.0;
     if (live) {
-      if (rebuild_p) { pa = zo + beta * pa; p[idx] = pa; }
-      x = x0 + alpha * pa;
-      r = r0 - alpha * q0;
-      g.cg_x[idx] = x;
-      g.cg_r[idx] = r;
+      if (mode == 2) {              // refresh: cg_q holds A x
+        x = x0;
+        r = b0 - q0;
+        g.cg_r[idx] = r;
+      } else {
+        if (rebuild_p) { pa = zo + beta * pa; p[idx] = pa; }
+        x = x0 + alpha * pa;
+        g.cg_x[idx] = x;
+        if (mode == 0) { r = r0 - alpha * q0; g.cg_r[idx] = r; }
+      }
     }
+    if (mode == 1) continue;        // x only: r, z and the partial sums follow in the mode-2 launch
     rl[tid] = r;
     __syncthreads();
     if (live) {
@@ -975,6 +988,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd
     }
     __syncthreads();
   }
+  if (mode == 1) return;
   block_sum<3>(acc, scratch);
   if (tid == 0) {
     const size_t o = (size_t)(odd ? g.n_part : 0) + blockIdx.x;
@@ -1284,10 +1298,10 @@ void launch_pcg_init(const DeviceGraph& g, hipStream_t s) {
   else if (g.cluster == 4) hipLaunchKernelGGL(k_pcg_init<4>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
   else hipLaunchKernelGGL(k_pcg_init<1>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
 }
-static void launch_update(const DeviceGraph& g, int odd, hipStream_t s) {
-  if (g.cluster == 2) hipLaunchKernelGGL(k_pcg_update<2>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, odd);
-  else if (g.cluster == 4) hipLaunchKernelGGL(k_pcg_update<4>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, odd);
-  else hipLaunchKernelGGL(k_pcg_update<1>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, odd);
+static void launch_update(const DeviceGraph& g, int odd, hipStream_t s, int mode = 0) {
+  if (g.cluster == 2) hipLaunchKernelGGL(k_pcg_update<2>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, odd, mode);
+  else if (g.cluster == 4) hipLaunchKernelGGL(k_pcg_update<4>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, odd, mode);
+  else hipLaunchKernelGGL(k_pcg_update<1>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, odd, mode);
 }
 void launch_pcg_iteration(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s) {
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
@@ -1315,8 +1329,13 @@ void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipS
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
   hipLaunchKernelGGL(k_spmv<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, p, odd);
 }
-void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s) {
-  launch_update(g, odd, s);
+void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s, int mode) {
+  launch_update(g, odd, s, mode);
+}
+void launch_spmv_refresh(const DeviceGraph& g, hipStream_t s) {   // A x -> cg_q for the residual refresh; skipped once the CG has stopped
+  const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
+  CgParams dummy{0.0, -1.0, 0, 0};
+  hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1 | 8);
 }
 void launch_model_delta_and_retract(const DeviceGraph& g, hipStream_t s, int gate) {
   hipLaunchKernelGGL(k_model_delta, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, gate);

@@ -239,11 +239,21 @@ int damping_all(pgo_problem* P, double radius, double min_diag, double max_diag,
 }
 
 // one CG iteration: SpMV on the owned rows, exchange of q (+ p'q partials), replicated vector update
-int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd) {
+// `refresh`: this is a residual_reset_period-th iteration — r is recomputed as b - A x (Ceres conjugate_gradients_solver.cc)
+// instead of updated: x-only update, A x into the exchange buffer, then r / z / partial sums.
+int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd, bool refresh) {
   pgo::launch_pcg_spmv_only(P->g, prm, odd, P->stream);
   int rc = exchange(P, P->g.cg_q, (size_t)P->g.seg);
   if (rc) return rc;
-  pgo::launch_pcg_update_only(P->g, odd, P->stream);
+  if (!refresh) {
+    pgo::launch_pcg_update_only(P->g, odd, P->stream);
+    return PGO_OK;
+  }
+  pgo::launch_pcg_update_only(P->g, odd, P->stream, 1);
+  pgo::launch_spmv_refresh(P->g, P->stream);
+  rc = exchange(P, P->g.cg_q, (size_t)P->g.seg);
+  if (rc) return rc;
+  pgo::launch_pcg_update_only(P->g, odd, P->stream, 2);
   return PGO_OK;
 }
 
@@ -577,19 +587,24 @@ int enqueue_tail(pgo_problem* P, const pgo::CgParams* finish_prm) {
 // kernels stop by themselves (device-side `done` flag), so an over-long batch only costs early-exit
 // launches; the batch length follows the previous solve's iteration count.
 // with_tail: the gated step tail follows in the same graph and its scalar fold hands off; otherwise the finish kernel does.
-int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool with_tail = false) {
+// start_it: absolute index (1-based) of the batch's first CG iteration — decides which iterations refresh the residual.
+int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool with_tail = false, int start_it = 1) {
   hipStream_t s = P->stream;
+  const int period = P->opt.cg_residual_reset_period;
+  auto refresh_at = [&](int i) { return period > 0 && ((start_it + i) % period) == 0; };
   if (P->use_graph) {
     if (memcmp(&P->cg_graph_params, &prm, sizeof prm) != 0) { P->drop_graph(); P->cg_graph_params = prm; }
     // the captured kernels hold the DeviceGraph by value; the tail touches the pose ping-pong, so the key carries its parity
-    const int key = 4 * batch + (with_tail ? 2 : 0) + ((with_tail && P->g.pose_x != P->d_pose_x.p) ? 1 : 0);
+    // ... and the positions of the residual refreshes depend on the start index modulo the period
+    const int key = (4 * batch + (with_tail ? 2 : 0) + ((with_tail && P->g.pose_x != P->d_pose_x.p) ? 1 : 0)) * 64 +
+                    (period > 0 ? start_it % period : 0);
     auto it = P->cg_graphs.find(key);
     if (it == P->cg_graphs.end()) {
       pgo_problem::CapturedBatch cb;
       hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
       if (e == hipSuccess) {
         int rc_it = PGO_OK;
-        for (int i = 0; i < batch && rc_it == PGO_OK; ++i) rc_it = cg_iteration(P, prm, (i & 1) ^ 1);
+        for (int i = 0; i < batch && rc_it == PGO_OK; ++i) rc_it = cg_iteration(P, prm, (i & 1) ^ 1, refresh_at(i));
         if (!with_tail) pgo::launch_pcg_finish(P->g, prm, s, 1);
         else if (rc_it == PGO_OK) rc_it = enqueue_tail(P, &prm);
         e = hipStreamEndCapture(s, &cb.graph);
@@ -611,7 +626,7 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool wi
       return PGO_OK;
     }
   }
-  for (int i = 0; i < batch; ++i) { int rc = cg_iteration(P, prm, (i & 1) ^ 1); if (rc) return rc; }
+  for (int i = 0; i < batch; ++i) { int rc = cg_iteration(P, prm, (i & 1) ^ 1, refresh_at(i)); if (rc) return rc; }
   if (with_tail) return enqueue_tail(P, &prm);
   pgo::launch_pcg_finish(P->g, prm, s, 1);
   return PGO_OK;
@@ -651,8 +666,8 @@ int run_pcg(pgo_problem* P, const pgo::CgParams& prm, int batch, int* iterations
   for (int round = 0, enqueued = 0;; ++round) {
     arm_handoff(P);
     const int nb = pick_batch(prm, batch, round, enqueued, 0);
+    int rc = launch_cg_batch(P, prm, nb, false, enqueued + 1);
     enqueued += nb;
-    int rc = launch_cg_batch(P, prm, nb);
     if (rc) return rc;
     rc = wait_handoff(P);
     if (rc) return rc;
@@ -950,8 +965,8 @@ int lm_advance(pgo_problem* P) {
     pgo::launch_pcg_init(P->g, s);
     for (int round = 0, enqueued = 0;; ++round) {
       const int nb = pick_batch(prm, o.cg_batch, round, enqueued, P->last_cg_iterations);
+      rc = launch_cg_batch(P, prm, nb, true, enqueued + 1);
       enqueued += nb;
-      rc = launch_cg_batch(P, prm, nb, true);
       if (rc) return rc;
       rc = wait_handoff(P);
       if (rc) return rc;
@@ -1247,6 +1262,8 @@ void pgo_solver_options_init(pgo_solver_options* o) {
   o->max_num_consecutive_invalid_steps = 5;
   o->cg_batch = 0;
   o->pcg_cluster_poses = 1;
+  o->cg_residual_reset_period = 10;   // LinearSolver::Options::residual_reset_period of Ceres 1.13
+  o->reserved0 = 0;
   o->function_tolerance = 1e-6;
   o->gradient_tolerance = 1e-10;
   o->parameter_tolerance = 1e-8;
@@ -1487,6 +1504,7 @@ int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const do
     HIP_TRY(hipStreamSynchronize(s));
     if (P->scal->linearize_bad) status = 2;
   } else {
+    P->opt.cg_residual_reset_period = options->cg_residual_reset_period;   // launch_cg_batch reads the refresh period from P->opt
     rc = run_pcg(P, cg_params_for(*options), options->cg_batch, &it, &status);
   }
   if (rc) return rc;
