@@ -137,7 +137,7 @@ void launch_spmv_tail(const DeviceGraph& g, const CgParams& p, hipStream_t s, in
 void launch_step_tail(const DeviceGraph& g, hipStream_t s, int gate);                  // fused model change / candidate / cost / scalar fold + hand-off
 void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s);
 void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s, int mode = 0);   // mode: see k_pcg_update
-void launch_spmv_refresh(const DeviceGraph& g, hipStream_t s);
+void launch_spmv_refresh(const DeviceGraph& g, hipStream_t s, int on_the_fly = 0, int it_odd = 0);
 void launch_model_delta_and_retract(const DeviceGraph& g, hipStream_t s, int gate = 0);
 void launch_debug(const DeviceGraph& g, int which, hipStream_t s);
 int vec_block();

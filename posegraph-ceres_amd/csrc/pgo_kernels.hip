@@ -728,10 +728,28 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
       for (int i = tid & 63; i < g.n_vec_wg; i += 64) { sums[0] += rz_cur[i]; sums[2] += q_cur[i]; }
     }
   }
+  // residual refresh on one rank (flags 16 | parity 32): x of this iteration is not stored yet — gather x_old and p and
+  // form x = x_old + alpha p on the fly, alpha = rho / p'q as the update kernel computes it
+  const bool fly = MODE == 1 && (odd & 16);
+  const double* p_cur = (odd & 32) ? g.cg_p1 : g.cg_p0;
+  double alpha_fly = 0.0;
+  if (fly) {
+    double pqs[1] = {0.0};
+    const double* pqp = g.cg_q + (size_t)g.rows_per * 6;
+    for (int i = tid; i < g.pq_cap; i += B) pqs[0] += pqp[i];
+    block_sum<1>(pqs, scratch);
+    if (!(pqs[0] > 0.0) || !isfinite(pqs[0])) return;     // indefinite: the update kernel stops the CG
+    alpha_fly = g.cg->rho / pqs[0];
+  }
   // gathers of the first chunk: need only the column index
   double2 gz[3] = {{0, 0}, {0, 0}, {0, 0}}, gp[3] = {{0, 0}, {0, 0}, {0, 0}};
   if (col >= 0) {
-    if (MODE == 0) {
+    if (fly) {
+      const double2* xs = reinterpret_cast<const double2*>(src + 6 * (size_t)col);
+      const double2* ps = reinterpret_cast<const double2*>(p_cur + 6 * (size_t)col);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { gz[k] = xs[k]; gp[k] = ps[k]; }
+    } else if (MODE == 0) {
       const double2* zs = reinterpret_cast<const double2*>(g.cg_z + 6 * (size_t)col);
       const double2* ps = reinterpret_cast<const double2*>(p_old + 6 * (size_t)col);
 #pragma unroll
@@ -791,7 +809,12 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
       for (int k = 0; k < 18; ++k) blk[k] = bp[(size_t)k * 64];
     }
     if (cb != s_begin && col >= 0) {
-      if (MODE == 0) {
+      if (fly) {
+        const double2* xs = reinterpret_cast<const double2*>(src + 6 * (size_t)col);
+        const double2* ps = reinterpret_cast<const double2*>(p_cur + 6 * (size_t)col);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { gz[k] = xs[k]; gp[k] = ps[k]; }
+      } else if (MODE == 0) {
         const double2* zs = reinterpret_cast<const double2*>(g.cg_z + 6 * (size_t)col);
         const double2* ps = reinterpret_cast<const double2*>(p_old + 6 * (size_t)col);
 #pragma unroll
@@ -807,8 +830,9 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
       double x[6];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        x[2 * k] = (MODE == 0) ? gz[k].x + beta * gp[k].x : gz[k].x;
-        x[2 * k + 1] = (MODE == 0) ? gz[k].y + beta * gp[k].y : gz[k].y;
+        const double f = (MODE == 0) ? beta : alpha_fly;      // MODE 1 without `fly`: gp = 0
+        x[2 * k] = gz[k].x + f * gp[k].x;
+        x[2 * k + 1] = gz[k].y + f * gp[k].y;
       }
       if (MODE == 1 && (odd & 4) && side == SIDE_DIAG && cb == s_begin) {
         // step tail: delta = -S x and the candidate Plus(x, delta) of this row (k_retract's job, one launch fewer)
@@ -893,8 +917,9 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
 
 // x += alpha p ; r -= alpha q ; z = M^-1 r ; partial r'z, Q = x'(b + r), r'r.  All loads up front.
 // mode 0: the normal iteration.  Every residual_reset_period-th iteration Ceres recomputes r = b - A x instead
-// (conjugate_gradients_solver.cc): mode 1 = only x += alpha p (then k_spmv<1> puts A x into cg_q), mode 2 = r = b - cg_q,
-// z, partial sums and the iteration counter.
+// (conjugate_gradients_solver.cc).  Several ranks: mode 1 = only x += alpha p, then k_spmv<1> puts A x into cg_q, then
+// mode 2 = r = b - cg_q, z, partial sums and the iteration counter.  One rank: k_spmv<1> forms x = x_old + alpha p on the
+// fly and mode 3 = x += alpha p AND r = b - cg_q in one launch.
 template <int CL>
 __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd, int mode) {
   constexpr int DIM = 6 * CL;
@@ -965,6 +990,11 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_pcg_update(DeviceGraph g, int odd
       if (mode == 2) {              // refresh: cg_q holds A x
         x = x0;
         r = b0 - q0;
+        g.cg_r[idx] = r;
+      } else if (mode == 3) {       // refresh, one rank: cg_q holds A (x + alpha p)
+        x = x0 + alpha * pa;
+        r = b0 - q0;
+        g.cg_x[idx] = x;
         g.cg_r[idx] = r;
       } else {
         if (rebuild_p) { pa = zo + beta * pa; p[idx] = pa; }
@@ -1332,10 +1362,12 @@ void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipS
 void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s, int mode) {
   launch_update(g, odd, s, mode);
 }
-void launch_spmv_refresh(const DeviceGraph& g, hipStream_t s) {   // A x -> cg_q for the residual refresh; skipped once the CG has stopped
+// A x -> cg_q for the residual refresh; skipped once the CG has stopped.  on_the_fly (one rank): x = x_old + alpha p is
+// formed while gathering (it_odd = parity of the iteration, selects the p buffer)
+void launch_spmv_refresh(const DeviceGraph& g, hipStream_t s, int on_the_fly, int it_odd) {
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
   CgParams dummy{0.0, -1.0, 0, 0};
-  hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1 | 8);
+  hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1 | 8 | (on_the_fly ? 16 : 0) | (it_odd ? 32 : 0));
 }
 void launch_model_delta_and_retract(const DeviceGraph& g, hipStream_t s, int gate) {
   hipLaunchKernelGGL(k_model_delta, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, gate);

@@ -142,7 +142,7 @@ struct pgo_problem {
   struct CapturedBatch { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
   std::unordered_map<int, CapturedBatch> cg_graphs;
   pgo::CgParams cg_graph_params{};
-  bool use_graph = true;
+  bool use_graph = false;
   int last_cg_iterations = 0;
 
   // exact solver (GPU block-sparse Cholesky), built lazily when SPARSE_NORMAL_CHOLESKY is requested
@@ -203,8 +203,12 @@ int ensure_device(pgo_problem* P) {
   if (!P->stream_ready) {
     HIP_TRY(hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking));
     P->stream_ready = true;
+    // Launch sequences are enqueued eagerly by default: on this stack (ROCm 7.2, MI355X) the host runs ahead of the GPU and a
+    // captured hipGraph of the same kernels is no faster (C2: 0.317 vs 0.317 ms per LM iteration without residual refreshes,
+    // 0.322 eager vs 0.353 graph with them; KITTI-00 exact 0.79 vs 0.81 ms).  PGO_GRAPH=1 replays captured batches instead.
+    const char* gr = getenv("PGO_GRAPH");
     const char* ng = getenv("PGO_NO_GRAPH");
-    P->use_graph = !(ng && ng[0] == '1');
+    P->use_graph = (gr && gr[0] == '1') && !(ng && ng[0] == '1');
   }
   if (!P->scal) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&P->scal), sizeof(pgo::LmScalars), hipHostMallocMapped));
@@ -247,6 +251,11 @@ int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd, bool refresh
   if (rc) return rc;
   if (!refresh) {
     pgo::launch_pcg_update_only(P->g, odd, P->stream);
+    return PGO_OK;
+  }
+  if (P->g.world == 1) {   // x = x_old + alpha p formed on the fly by the SpMV, one combined vector launch
+    pgo::launch_spmv_refresh(P->g, P->stream, 1, odd);
+    pgo::launch_pcg_update_only(P->g, odd, P->stream, 3);
     return PGO_OK;
   }
   pgo::launch_pcg_update_only(P->g, odd, P->stream, 1);
