@@ -305,6 +305,8 @@ def main():
             "final_cost": summary.final_cost, "resets": resets,
             "roofline": roofline, "cpu_baseline": cpu,
         })
+        out["mfma"] = {"utilisation": 0.0, "note": "no MFMA instruction on this path: FP64 6x6 blocks with structural zeros against 16x16x4 tiles, "
+                       "arithmetic intensity ~1 flop/B (HBM/latency-bound); reserved for dense fronts of a supernodal factorisation (DESIGN.md sections 4, 9)"}
         out.update(extra)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
