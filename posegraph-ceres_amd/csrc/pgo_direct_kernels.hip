@@ -81,7 +81,22 @@ __device__ __forceinline__ void assemble_row(const DeviceGraph& g, const DirectP
 // forward-substitution pieces (defined below): the forward solve L y = P (S g) is fused into the factorisation — as soon
 // as L_jj exists, y_j = L_jj^-1 (b_j - sum_k L_jk y_k) needs only columns of earlier levels
 __device__ __forceinline__ void forward_partial(const DirectPlan& p, int j, int sub, int nsub, double* sh);
-__device__ __forceinline__ void forward_finish(const DeviceGraph& g, const DirectPlan& p, int j, int nsub, const double* sh_all, const double* Ljj);
+__device__ __forceinline__ double forward_rhs(const DeviceGraph& g, int old);
+__device__ __forceinline__ void forward_finish(const DirectPlan& p, int j, double b, int nsub, const double* sh_all, const double* Ljj);
+// the ten partial copies of a 6x6 block in sh[10][36] -> their sum (fixed order) in every lane of the wave
+__device__ __forceinline__ void sum_partials(double* sh, double* out, const double* base) {
+  const int lane = threadIdx.x & 63;
+  if (lane < 36) {
+    double s = base ? base[lane] : 0.0;
+#pragma unroll
+    for (int gq = 0; gq < 10; ++gq) s += sh[gq * 36 + lane];
+    sh[lane] = s;          // entry `lane` of copy 0 is read by this lane only
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < 36; ++k) out[k] = sh[k];
+}
 
 // Factorises column j with one wave.  sh: 360 doubles of LDS private to the wave (10 groups x 6 rows x 6).
 // The ten 6-lane groups share the work of a chunk of up to ten blocks: with fewer blocks than groups the
@@ -92,6 +107,7 @@ __device__ void factor_column(const DeviceGraph& g, const DirectPlan& p, int j, 
   const int grp = lane / 6, r = lane - 6 * grp;
   const bool in_grp = grp < 10;
   const int b0 = p.col_ptr[j], nblk = p.col_ptr[j + 1] - b0;
+  const int old = p.perm[j];                    // static data of the fused forward step, fetched behind the assembly
   // ---- diagonal block: its update list is split over all ten groups ----
   if (in_grp) {
     double v[6];
@@ -99,16 +115,11 @@ __device__ void factor_column(const DeviceGraph& g, const DirectPlan& p, int j, 
 #pragma unroll
     for (int c = 0; c < 6; ++c) sh[(grp * 6 + r) * 6 + c] = v[c];
   }
+  const double bj = forward_rhs(g, old);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   double Ljj[36];
-#pragma unroll
-  for (int k = 0; k < 36; ++k) {
-    double s = 0.0;
-#pragma unroll
-    for (int gq = 0; gq < 10; ++gq) s += sh[gq * 36 + k];
-    Ljj[k] = s;
-  }
+  sum_partials(sh, Ljj, nullptr);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   bool ok = true;
@@ -178,7 +189,7 @@ __device__ void factor_column(const DeviceGraph& g, const DirectPlan& p, int j, 
   forward_partial(p, j, 0, 1, sh);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) forward_finish(g, p, j, 1, sh, Ljj);
+  forward_finish(p, j, bj, 1, sh, Ljj);
 }
 
 // In-register Cholesky of a 6x6 block held (row-major, 36 doubles) by every lane; returns false on a non-positive pivot.
@@ -231,23 +242,18 @@ __global__ __launch_bounds__(64) void k_chol_assemble(DeviceGraph g, DirectPlan 
     }
     return;
   }
+  const int j = p.blk_row[bi];
+  const double bj = forward_rhs(g, p.perm[j]);
   double Ljj[36];
-#pragma unroll
-  for (int k = 0; k < 36; ++k) {
-    double s = 0.0;
-#pragma unroll
-    for (int gq = 0; gq < 10; ++gq) s += sh[gq * 36 + k];
-    Ljj[k] = s;
-  }
+  sum_partials(sh, Ljj, nullptr);
   const bool ok = chol6_inplace(Ljj);
   if (!ok && lane == 0) atomicOr(&g.flags[2], 1);
   if (lane < 36) p.Lval[36 * (size_t)bi + lane] = Ljj[lane];
   // fused forward substitution for this column
-  const int j = p.blk_row[bi];
   __syncthreads();
   forward_partial(p, j, 0, 1, sh);
   __syncthreads();
-  if (lane == 0) forward_finish(g, p, j, 1, sh, Ljj);
+  forward_finish(p, j, bj, 1, sh, Ljj);
 }
 
 // phase 2, one 6-lane group per sub-diagonal block of the level (ten per wave, lane = row): L_ij = V_ij L_jj^-T
@@ -285,7 +291,9 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_panel(DeviceGraph g, 
   for (int i = 0; i < width; ++i) {
     const int j = p.panel_cols[cols_begin + blockIdx.x * width + i];
     const int b0 = p.col_ptr[j], nblk = p.col_ptr[j + 1] - b0;
+    double bj = 0.0;
     if (wave == 0) {
+      bj = forward_rhs(g, p.perm[j]);
       if (grp < 10) {
         double v[6] = {0, 0, 0, 0, 0, 0};
         subtract_pairs(p, p.upd_split[b0], p.upd_ptr[b0 + 1], r, grp, 10, v);
@@ -295,13 +303,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_panel(DeviceGraph g, 
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       double Ljj[36];
-#pragma unroll
-      for (int k = 0; k < 36; ++k) {
-        double s = p.Lval[36 * (size_t)b0 + k];
-#pragma unroll
-        for (int gq = 0; gq < 10; ++gq) s += sh[gq * 36 + k];
-        Ljj[k] = s;
-      }
+      sum_partials(sh, Ljj, p.Lval + 36 * (size_t)b0);
       const bool ok = chol6_inplace(Ljj);
       if (!ok && lane == 0) atomicOr(&g.flags[2], 1);
       if (lane < 36) { p.Lval[36 * (size_t)b0 + lane] = Ljj[lane]; Ld[lane] = Ljj[lane]; }
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_panel(DeviceGraph g, 
     // fused forward substitution: the row list of column j shared by all waves, finished by one lane
     forward_partial(p, j, wave, FUSED_WAVES, shf[wave]);
     __syncthreads();
-    if (wave == 0 && lane == 0) forward_finish(g, p, j, FUSED_WAVES, shf[0], Ld);
+    if (wave == 0) forward_finish(p, j, bj, FUSED_WAVES, shf[0], Ld);
     if (grp < 10) {
       for (int t = 1 + wave * 10 + grp; t < nblk; t += 10 * FUSED_WAVES) {
         const int bi = b0 + t;
@@ -370,27 +372,37 @@ __device__ __forceinline__ void forward_partial(const DirectPlan& p, int j, int 
     sh[lane] = acc;
   }
 }
-__device__ __forceinline__ void forward_finish(const DeviceGraph& g, const DirectPlan& p, int j, int nsub, const double* sh_all, const double* L) {
-  const int old = p.perm[j];
+// component `lane` (lanes 0..5) of the right-hand side row of old pose `old`: b = S g; also written to cg_b
+__device__ __forceinline__ double forward_rhs(const DeviceGraph& g, int old) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane < 6 ? lane : 0;
+  const double b = g.scale[6 * (size_t)old + i] * g.grad[6 * (size_t)old + i];
+  if (lane < 6) g.cg_b[6 * (size_t)old + lane] = b;
+  return b;
+}
+// called by a whole wave: lanes 0..5 add the partial sums of one component each (fixed order), the 6x6 triangular solve
+// runs redundantly in every lane, lanes 0..5 store
+__device__ __forceinline__ void forward_finish(const DirectPlan& p, int j, double b, int nsub, const double* sh_all, const double* L) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane < 6 ? lane : 0;
+  double s = 0.0;
+  for (int w = 0; w < nsub; ++w)
+    for (int gq = 0; gq < 10; ++gq) s += sh_all[64 * w + 6 * gq + i];
+  const double mine = b - s;
   double rhs[6], y[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const double b = g.scale[6 * (size_t)old + i] * g.grad[6 * (size_t)old + i];
-    g.cg_b[6 * (size_t)old + i] = b;
-    double s = 0.0;
-    for (int w = 0; w < nsub; ++w)
-      for (int gq = 0; gq < 10; ++gq) s += sh_all[64 * w + 6 * gq + i];
-    rhs[i] = b - s;
+  for (int k = 0; k < 6; ++k) rhs[k] = __shfl(mine, k);
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    double t = rhs[r];
+#pragma unroll
+    for (int k = 0; k < r; ++k) t -= L[6 * r + k] * y[k];
+    y[r] = t / L[7 * r];
   }
+  double out = y[0];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    double s = rhs[i];
-#pragma unroll
-    for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
-    y[i] = s / L[7 * i];
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) p.y[6 * (size_t)j + i] = y[i];
+  for (int k = 1; k < 6; ++k) out = lane == k ? y[k] : out;
+  if (lane < 6) p.y[6 * (size_t)j + lane] = out;
 }
 
 // ---- backward solve  L^T x = y:  x_j = L_jj^-T (y_j - sum_{i in struct(j)} L_ij^T x_i) ----

@@ -1,6 +1,6 @@
 // tools/direct_analyze_cli.cpp — runs the HOST symbolic analysis of the GPU Cholesky (pgo_direct.cpp) on an edge list, no
 // GPU needed: timing / statistics of the ordering, fill and launch schedule.  Build: see tools/Makefile (hipcc, host only).
-// usage: direct_analyze_cli <edges.txt>     (first line: N E, then E lines "id_begin id_end")
+// usage: direct_analyze_cli <edges.txt> [-v]     (first line: N E, then E lines "id_begin id_end")
 #include <chrono>
 #include <cstdio>
 #include <vector>
@@ -34,5 +34,24 @@ int main(int argc, char** argv) {
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::printf("N %d E %d usable %d seconds %.3f blocks %d pairs %lld levels %d steps %zu est_steps %.0f\n", N, E, ok ? 1 : 0, dt, S.nb,
               S.n_pairs, S.n_levels, S.steps.size(), S.est_steps);
+  if (argc > 2) {   // per-step detail: levels, columns, blocks, update pairs, longest per-column pair list
+    static const char* names[] = {"COLUMN", "FUSED", "SPLIT", "PANEL"};
+    for (const pgo::DirectStep& st : S.steps) {
+      long long cols = 0, blks = 0, pairs = 0, worst = 0, rowl = 0, crit = 0;
+      for (int l = st.level_begin; l < st.level_end; ++l) {
+        long long level_worst = 0;
+        for (int c = S.level_ptr[l]; c < S.level_ptr[l + 1]; ++c) {
+          const int j = S.level_cols[c];
+          const long long pj = S.upd_ptr[S.col_ptr[j + 1]] - S.upd_ptr[S.col_ptr[j]];
+          ++cols; blks += S.col_ptr[j + 1] - S.col_ptr[j]; pairs += pj; rowl += S.rowl_ptr[j + 1] - S.rowl_ptr[j];
+          if (pj > level_worst) level_worst = pj;
+        }
+        if (level_worst > worst) worst = level_worst;
+        crit += level_worst;
+      }
+      std::printf("%-6s levels [%d,%d) cols %lld blocks %lld pairs %lld worst-column pairs %lld sum-of-level-worst %lld row-list %lld\n",
+                  names[st.type], st.level_begin, st.level_end, cols, blks, pairs, worst, crit, rowl);
+    }
+  }
   return 0;
 }
