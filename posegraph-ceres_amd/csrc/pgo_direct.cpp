@@ -288,6 +288,12 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
     std::vector<int> fill(S.level_ptr.begin(), S.level_ptr.end() - 1);
     for (int j = 0; j < N; ++j) S.level_cols[fill[level[j]]++] = j;
   }
+  S.blk_lpos.resize(S.nb);
+  {
+    std::vector<int> lpos(N);
+    for (int q = 0; q < N; ++q) lpos[S.level_cols[q]] = q;
+    for (int b = 0; b < S.nb; ++b) S.blk_lpos[b] = lpos[S.blk_row[b]];
+  }
   // fused tail: the longest suffix of levels that each hold at most 8 columns
   S.fused_from_level = S.n_levels;
   while (S.fused_from_level > 0 && S.level_ptr[S.fused_from_level] - S.level_ptr[S.fused_from_level - 1] <= 8) --S.fused_from_level;

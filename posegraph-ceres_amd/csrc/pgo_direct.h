@@ -37,6 +37,7 @@ struct DirectPlan {
   const int* split_sub_diag;  // ... and the diagonal block of their column
   const int* upd_split;       // [nb] PANEL steps: update pairs [upd_ptr, upd_split) come from columns before the panel
   const int* panel_cols;      // PANEL steps: chains of columns, chain c of a step at [begin + c*width, begin + (c+1)*width)
+  const int* blk_lpos;        // [nb] position in level_cols of the block's ROW (backward tail: x of the tail lives in LDS)
   double* Lval;           // [nb][36] row-major blocks of the factor
   double* y;              // [6n] permuted work vector
 };
@@ -65,7 +66,7 @@ struct DirectSymbolic {
   long long n_pairs = 0;
   int fused_from_level = 0;  // first level of the suffix whose levels hold <= 8 columns (forward/backward solves fuse it)
   std::vector<DirectStep> steps;   // factorisation schedule
-  std::vector<int> split_blk, split_sub, split_sub_diag, upd_split, panel_cols;
+  std::vector<int> split_blk, split_sub, split_sub_diag, upd_split, panel_cols, blk_lpos;
   std::vector<uint8_t> split_diag;
   double flops = 0;
   double est_steps = 0;      // critical-path length of the schedule in update-pair steps (cost model)

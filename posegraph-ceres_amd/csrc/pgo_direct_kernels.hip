@@ -386,8 +386,13 @@ __device__ __forceinline__ void forward_finish(const DirectPlan& p, int j, doubl
   const int lane = threadIdx.x & 63;
   const int i = lane < 6 ? lane : 0;
   double s = 0.0;
-  for (int w = 0; w < nsub; ++w)
-    for (int gq = 0; gq < 10; ++gq) s += sh_all[64 * w + 6 * gq + i];
+  for (int w = 0; w < nsub; ++w) {                 // ten reads in flight, then the adds in the fixed order
+    double t[10];
+#pragma unroll
+    for (int gq = 0; gq < 10; ++gq) t[gq] = sh_all[64 * w + 6 * gq + i];
+#pragma unroll
+    for (int gq = 0; gq < 10; ++gq) s += t[gq];
+  }
   const double mine = b - s;
   double rhs[6], y[6];
 #pragma unroll
@@ -453,17 +458,83 @@ __global__ __launch_bounds__(64) void k_bwd_level(DeviceGraph g, DirectPlan p, i
 }
 // Fused tail of the backward solve (levels with <= FUSED_WAVES columns): the FUSED_WAVES waves of the single workgroup are
 // divided among the columns of the level, so the long lists of a dense separator chain (one column per level) are walked 80-wide.
+// The rows of a tail column are its ancestors, i.e. tail columns too: with XLDS the x of the whole tail stays in LDS
+// (indexed by position in level_cols), so the level-to-level dependency never leaves the CU; everything else a level
+// reads (L, y, the indices) is final before the launch and is fetched ahead of the barrier.
+constexpr int BWD_TAIL_LDS_COLS = 1200;
+template <bool XLDS>
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_bwd_tail(DeviceGraph g, DirectPlan p, int from_level) {
   __shared__ double sh[FUSED_WAVES][64];
+  __shared__ double xs[XLDS ? 6 * BWD_TAIL_LDS_COLS : 6];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = lane / 6, c = lane - 6 * grp;      // lane owns COLUMN c of L_ij (component c of L_ij^T x_i)
+  const int tail_begin = p.level_ptr[from_level];
   for (int l = p.n_levels - 1; l >= from_level; --l) {
     const int c0 = p.level_ptr[l], nc = p.level_ptr[l + 1] - c0;
     const int nsub = max(1, FUSED_WAVES / nc);
     const int col = wave / nsub, sub = wave - col * nsub;
-    if (col < nc) backward_partial(p, p.level_cols[c0 + col], sub, nsub, sh[wave]);
+    const bool mine = col < nc, finisher = mine && sub == 0;
+    int j = 0, b0 = 0, nblk = 0;
+    if (mine) { j = p.level_cols[c0 + col]; b0 = p.col_ptr[j]; nblk = p.col_ptr[j + 1] - b0; }
+    double acc = 0.0;
+    if (mine && grp < 10) {
+      for (int t = 1 + sub * 10 + grp; t < nblk; t += 10 * nsub) {
+        const double* B = p.Lval + 36 * (size_t)(b0 + t);
+        double bk[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bk[k] = B[6 * k + c];
+        const double* xi = XLDS ? xs + 6 * (p.blk_lpos[b0 + t] - tail_begin) : p.y + 6 * (size_t)p.blk_row[b0 + t];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc += bk[k] * xi[k];
+      }
+    }
+    if (grp < 10) sh[wave][lane] = acc;
+    // the finisher's inputs do not depend on this level: fetched beside the partial sums, ahead of the barrier
+    double yj = 0.0, Ld[21];
+    int old = 0;
+    if (finisher) {
+      old = p.perm[j];
+      yj = p.y[6 * (size_t)j + (lane < 6 ? lane : 0)];
+      const double* L = p.Lval + 36 * (size_t)b0;
+#pragma unroll
+      for (int i = 0, q = 0; i < 6; ++i)
+#pragma unroll
+        for (int k = i; k < 6; ++k) Ld[q++] = L[6 * k + i];     // row i of L^T from the diagonal on
+    }
     __syncthreads();
-    if (col < nc && sub == 0 && lane == 0) backward_finish(g, p, p.level_cols[c0 + col], nsub, sh[wave]);
-    __threadfence_block();
+    if (finisher) {
+      const int i = lane < 6 ? lane : 0;
+      double s = 0.0;
+      for (int w = 0; w < nsub; ++w) {               // ten reads in flight, then the adds in the fixed order
+        double t[10];
+#pragma unroll
+        for (int gq = 0; gq < 10; ++gq) t[gq] = sh[wave + w][6 * gq + i];
+#pragma unroll
+        for (int gq = 0; gq < 10; ++gq) s += t[gq];
+      }
+      const double my_rhs = yj - s;
+      double rhs[6], x[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) rhs[k] = __shfl(my_rhs, k);
+      int q = 21;
+#pragma unroll
+      for (int r = 5; r >= 0; --r) {
+        q -= 6 - r;                                  // Ld[q] = L[7r], Ld[q + (k - r)] = L[6k + r]
+        double t = rhs[r];
+#pragma unroll
+        for (int k = r + 1; k < 6; ++k) t -= Ld[q + (k - r)] * x[k];
+        x[r] = t / Ld[q];
+      }
+      double out = x[0];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) out = lane == k ? x[k] : out;
+      if (lane < 6) {
+        p.y[6 * (size_t)j + lane] = out;
+        g.cg_x[6 * (size_t)old + lane] = out;
+        if (XLDS) xs[6 * (c0 + col - tail_begin) + lane] = out;
+      }
+    }
+    if (!XLDS) __threadfence_block();
     __syncthreads();
   }
 }
@@ -490,7 +561,12 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
 
 // backward solve only: the forward substitution runs inside the factorisation kernels
 void launch_direct_solve(const DeviceGraph& g, const DirectPlan& p, const int* level_ptr_host, int fused_from_level, hipStream_t s) {
-  if (fused_from_level < p.n_levels) hipLaunchKernelGGL(k_bwd_tail, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, fused_from_level);
+  if (fused_from_level < p.n_levels) {
+    if (p.n - level_ptr_host[fused_from_level] <= BWD_TAIL_LDS_COLS)
+      hipLaunchKernelGGL(k_bwd_tail<true>, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, fused_from_level);
+    else
+      hipLaunchKernelGGL(k_bwd_tail<false>, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, fused_from_level);
+  }
   for (int l = fused_from_level - 1; l >= 0; --l) {
     const int nc = level_ptr_host[l + 1] - level_ptr_host[l];
     hipLaunchKernelGGL(k_bwd_level, dim3(nc), dim3(64), 0, s, g, p, l);

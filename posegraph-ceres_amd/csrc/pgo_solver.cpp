@@ -151,7 +151,7 @@ struct pgo_problem {
   pgo::DirectSymbolic dsym;
   pgo::DirectPlan dplan{};
   bool direct_analyzed = false, direct_usable = false;
-  DevBuf<int> dd_split_blk, dd_split_sub, dd_split_sub_diag, dd_upd_split, dd_panel_cols;
+  DevBuf<int> dd_split_blk, dd_split_sub, dd_split_sub_diag, dd_upd_split, dd_panel_cols, dd_blk_lpos;
   DevBuf<uint8_t> dd_split_diag;
   DevBuf<int> dd_perm, dd_col_ptr, dd_blk_row, dd_asrc_ptr, dd_asrc_slot, dd_upd_ptr, dd_upd_a, dd_upd_b, dd_level_ptr,
       dd_level_cols, dd_rowl_ptr, dd_rowl_blk, dd_rowl_col;
@@ -761,6 +761,7 @@ int prepare_direct(pgo_problem* P) {
   HIP_TRY(P->dd_split_sub_diag.upload(S.split_sub_diag, s));
   HIP_TRY(P->dd_upd_split.upload(S.upd_split, s));
   HIP_TRY(P->dd_panel_cols.upload(S.panel_cols, s));
+  HIP_TRY(P->dd_blk_lpos.upload(S.blk_lpos, s));
   if (S.panel_cols.empty()) HIP_TRY(P->dd_panel_cols.alloc(1));
   if (S.split_blk.empty()) { HIP_TRY(P->dd_split_blk.alloc(1)); HIP_TRY(P->dd_split_diag.alloc(1)); }
   if (S.split_sub.empty()) { HIP_TRY(P->dd_split_sub.alloc(1)); HIP_TRY(P->dd_split_sub_diag.alloc(1)); }
@@ -774,7 +775,7 @@ int prepare_direct(pgo_problem* P) {
   d.rowl_ptr = P->dd_rowl_ptr.p; d.rowl_blk = P->dd_rowl_blk.p; d.rowl_col = P->dd_rowl_col.p;
   d.Lval = P->dd_Lval.p; d.y = P->dd_y.p; d.split_blk = P->dd_split_blk.p;
   d.split_diag = P->dd_split_diag.p; d.split_sub = P->dd_split_sub.p; d.split_sub_diag = P->dd_split_sub_diag.p;
-  d.upd_split = P->dd_upd_split.p; d.panel_cols = P->dd_panel_cols.p;
+  d.upd_split = P->dd_upd_split.p; d.panel_cols = P->dd_panel_cols.p; d.blk_lpos = P->dd_blk_lpos.p;
   P->drop_direct_graph();
   P->direct_usable = true;
   return PGO_OK;
