@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64) void k_bwd_level(DeviceGraph g, DirectPlan p, i
 // The rows of a tail column are its ancestors, i.e. tail columns too: with XLDS the x of the whole tail stays in LDS
 // (indexed by position in level_cols), so the level-to-level dependency never leaves the CU; everything else a level
 // reads (L, y, the indices) is final before the launch and is fetched ahead of the barrier.
-constexpr int BWD_TAIL_LDS_COLS = 1200;
+constexpr int BWD_TAIL_LDS_COLS = 896;
 template <bool XLDS>
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_bwd_tail(DeviceGraph g, DirectPlan p, int from_level) {
   __shared__ double sh[FUSED_WAVES][64];
@@ -469,13 +469,30 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_bwd_tail(DeviceGraph g, Di
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int grp = lane / 6, c = lane - 6 * grp;      // lane owns COLUMN c of L_ij (component c of L_ij^T x_i)
   const int tail_begin = p.level_ptr[from_level];
+  // with XLDS the column descriptors and level bounds of the whole tail are staged once, so a level's index chain
+  // (level -> column -> first block) is three LDS reads instead of three dependent trips to memory
+  __shared__ int tj[XLDS ? BWD_TAIL_LDS_COLS : 1], tb0[XLDS ? BWD_TAIL_LDS_COLS : 1], tnb[XLDS ? BWD_TAIL_LDS_COLS : 1];
+  __shared__ int tl[XLDS ? BWD_TAIL_LDS_COLS + 1 : 1];
+  if (XLDS) {
+    for (int q = threadIdx.x; q < p.n - tail_begin; q += blockDim.x) {
+      const int jq = p.level_cols[tail_begin + q];
+      const int b = p.col_ptr[jq];
+      tj[q] = jq; tb0[q] = b; tnb[q] = p.col_ptr[jq + 1] - b;
+    }
+    for (int q = threadIdx.x; q <= p.n_levels - from_level; q += blockDim.x) tl[q] = p.level_ptr[from_level + q];
+    __syncthreads();
+  }
   for (int l = p.n_levels - 1; l >= from_level; --l) {
-    const int c0 = p.level_ptr[l], nc = p.level_ptr[l + 1] - c0;
+    const int c0 = XLDS ? tl[l - from_level] : p.level_ptr[l];
+    const int nc = (XLDS ? tl[l - from_level + 1] : p.level_ptr[l + 1]) - c0;
     const int nsub = max(1, FUSED_WAVES / nc);
     const int col = wave / nsub, sub = wave - col * nsub;
     const bool mine = col < nc, finisher = mine && sub == 0;
     int j = 0, b0 = 0, nblk = 0;
-    if (mine) { j = p.level_cols[c0 + col]; b0 = p.col_ptr[j]; nblk = p.col_ptr[j + 1] - b0; }
+    if (mine) {
+      if (XLDS) { const int q = c0 + col - tail_begin; j = tj[q]; b0 = tb0[q]; nblk = tnb[q]; }
+      else { j = p.level_cols[c0 + col]; b0 = p.col_ptr[j]; nblk = p.col_ptr[j + 1] - b0; }
+    }
     double acc = 0.0;
     if (mine && grp < 10) {
       for (int t = 1 + sub * 10 + grp; t < nblk; t += 10 * nsub) {
