@@ -348,28 +348,41 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   auto is_heavy = [&](int l) { return level_cost[l] > HEAVY && split_cost[l] < level_cost[l]; };
   std::vector<int> tmp_a, tmp_b, tmp_pa, tmp_pb;
   double steps = 0.0;
-  for (int l = 0; l < S.n_levels;) {
-    if (is_heavy(l)) {
-      // grow a panel: the next level has the same number of columns (<= 8), each the etree parent of one column here
-      const int nc = S.level_ptr[l + 1] - S.level_ptr[l];
-      std::vector<std::vector<int>> chain(nc);
-      for (int c = 0; c < nc; ++c) chain[c].push_back(S.level_cols[S.level_ptr[l] + c]);
-      int w = 1;
-      while (nc <= 8 && w < PANEL_MAX && l + w < S.n_levels && is_heavy(l + w) &&
-             S.level_ptr[l + w + 1] - S.level_ptr[l + w] == nc) {
-        std::vector<int> next(nc, -1);
-        bool ok = true;
-        for (int c = 0; c < nc && ok; ++c) {
-          const int par = parent[chain[c].back()];
-          bool found = false;
-          for (int q = S.level_ptr[l + w]; q < S.level_ptr[l + w + 1]; ++q) if (S.level_cols[q] == par) found = true;
-          for (int c2 = 0; c2 < c; ++c2) if (next[c2] == par) found = false;   // two chains merging: stop here
-          if (!found) ok = false; else next[c] = par;
-        }
-        if (!ok) break;
-        for (int c = 0; c < nc; ++c) chain[c].push_back(next[c]);
-        ++w;
+  // Light levels of the fused tail (chain-like tops: one wave per column, ~10 us per level of dependent round trips) also
+  // go through PANEL when at least LIGHT_PANEL_MIN consecutive levels form parent chains: two launches, then ~3 us per
+  // column with eight waves on each column.
+  const int LIGHT_PANEL_MIN = 3;
+  auto panel_ok = [&](int l) { return is_heavy(l) || l >= S.fused_from_level; };
+  // chains of columns starting at level l: the next level has the same number of columns (<= 8), each the etree parent
+  // of one column here; returns the width
+  auto grow = [&](int l, std::vector<std::vector<int>>& chain) {
+    const int nc = S.level_ptr[l + 1] - S.level_ptr[l];
+    chain.assign(nc, std::vector<int>());
+    for (int c = 0; c < nc; ++c) chain[c].push_back(S.level_cols[S.level_ptr[l] + c]);
+    int w = 1;
+    while (nc <= 8 && w < PANEL_MAX && l + w < S.n_levels && panel_ok(l + w) && is_heavy(l + w) == is_heavy(l) &&
+           S.level_ptr[l + w + 1] - S.level_ptr[l + w] == nc) {
+      std::vector<int> next(nc, -1);
+      bool ok = true;
+      for (int c = 0; c < nc && ok; ++c) {
+        const int par = parent[chain[c].back()];
+        bool found = false;
+        for (int q = S.level_ptr[l + w]; q < S.level_ptr[l + w + 1]; ++q) if (S.level_cols[q] == par) found = true;
+        for (int c2 = 0; c2 < c; ++c2) if (next[c2] == par) found = false;   // two chains merging: stop here
+        if (!found) ok = false; else next[c] = par;
       }
+      if (!ok) break;
+      for (int c = 0; c < nc; ++c) chain[c].push_back(next[c]);
+      ++w;
+    }
+    return w;
+  };
+  std::vector<std::vector<int>> chain, probe;
+  auto light_panel_at = [&](int l) { return !is_heavy(l) && l >= S.fused_from_level && grow(l, probe) >= LIGHT_PANEL_MIN; };
+  for (int l = 0; l < S.n_levels;) {
+    if (panel_ok(l) && (is_heavy(l) || light_panel_at(l))) {
+      const int nc = S.level_ptr[l + 1] - S.level_ptr[l];
+      const int w = grow(l, chain);
       if (w >= 2) {
         DirectStep st{DirectStep::PANEL, l, l + w, (int)S.split_blk.size(), 0, (int)S.panel_cols.size(), nc};
         double p1 = 0.0, p2 = 0.0;
@@ -430,7 +443,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
       ++l;
     } else if (l >= S.fused_from_level) {
       int e = l;
-      while (e < S.n_levels && !is_heavy(e)) { steps += level_cost[e]; ++e; }
+      while (e < S.n_levels && !is_heavy(e) && !(e > l && light_panel_at(e))) { steps += level_cost[e]; ++e; }
       S.steps.push_back(DirectStep{DirectStep::FUSED, l, e, 0, 0, 0, 0});
       l = e;
     } else {
