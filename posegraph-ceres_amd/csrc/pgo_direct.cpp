@@ -316,7 +316,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   // COLUMN/FUSED: a column is processed ten blocks at a time by one wave; a block's update list is walked serially by its
   // 6-lane group(s).  SPLIT: every block of the level has its own wave (ten groups share its list), then a cheap
   // per-column pass.  A level is split when its one-wave-per-column cost exceeds HEAVY steps.
-  const double HEAVY = 48.0;
+  static const double HEAVY = getenv("PGO_DIRECT_HEAVY") ? atof(getenv("PGO_DIRECT_HEAVY")) : 16.0;
   std::vector<double> level_cost(S.n_levels, 0.0), split_cost(S.n_levels, 0.0);
   for (int l = 0; l < S.n_levels; ++l) {
     double worst = 0.0, worst_blk = 0.0, worst_fin = 0.0;
