@@ -11,10 +11,12 @@
 #include "pgo_direct.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <numeric>
+#include <thread>
 
 namespace pgo {
 
@@ -223,33 +225,75 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
     return (it != hi && *it == i) ? (int)(it - &S.blk_row[0]) : -1;
   };
 
-  // ---- 3a. update pairs per target block ----
-  S.upd_ptr.assign(S.nb + 1, 0);
-  for (int k = 0; k < N; ++k) {
-    const std::vector<int>& sk = st[k];
-    for (size_t a = 0; a < sk.size(); ++a)
-      for (size_t b = a; b < sk.size(); ++b) {
-        const int t = block_of(sk[b], sk[a]);
-        if (t < 0) return false;  // cannot happen: struct(k) \ {j} is contained in struct(j) for j = parent chain
-        ++S.upd_ptr[t + 1];
+  // ---- 3a. row lists (forward solve; also the source columns of every target column below) ----
+  S.rowl_ptr.assign(N + 1, 0);
+  for (int k = 0; k < N; ++k) for (int i : st[k]) ++S.rowl_ptr[i + 1];
+  for (int j = 0; j < N; ++j) S.rowl_ptr[j + 1] += S.rowl_ptr[j];
+  S.rowl_blk.resize(S.rowl_ptr[N]);
+  S.rowl_col.resize(S.rowl_ptr[N]);
+  {
+    std::vector<int> fill(S.rowl_ptr.begin(), S.rowl_ptr.end() - 1);
+    for (int k = 0; k < N; ++k)
+      for (size_t a = 0; a < st[k].size(); ++a) {
+        const int q = fill[st[k][a]]++;
+        S.rowl_blk[q] = S.col_ptr[k] + 1 + (int)a;
+        S.rowl_col[q] = k;
       }
   }
+  // ---- 3b'. update pairs per target block ----
+  // Target-centric: the pairs of the blocks (i, j) of column j come from the columns k of row j (ascending k = the fixed
+  // summation order): with a = position of j in struct(k), the targets (sk[b], j), b >= a, are found by one forward
+  // walk through column j's row list.  All writes of column j fall in its own range of the pair arrays, so columns are
+  // processed by several host threads; two passes (count, fill) around one prefix sum.
+  S.upd_ptr.assign(S.nb + 1, 0);
+  std::atomic<bool> broken(false);
+  auto walk_column = [&](int j, auto&& emit) {
+    const int* lo = &S.blk_row[0] + S.col_ptr[j] + 1;
+    const int* hi = &S.blk_row[0] + S.col_ptr[j + 1];
+    for (int q = S.rowl_ptr[j]; q < S.rowl_ptr[j + 1]; ++q) {
+      const int k = S.rowl_col[q];
+      const std::vector<int>& sk = st[k];
+      const int base = S.col_ptr[k] + 1;
+      const size_t a = (size_t)(S.rowl_blk[q] - base);
+      emit(S.col_ptr[j], base + (int)a, base + (int)a);
+      const int* it = lo;
+      for (size_t b = a + 1; b < sk.size(); ++b) {
+        const int i = sk[b];
+        for (int hop = 0; hop < 4 && it != hi && *it < i; ++hop) ++it;
+        if (it != hi && *it < i) it = std::lower_bound(it, hi, i);
+        if (it == hi || *it != i) { broken = true; return; }   // cannot happen: struct(k) \ {j} is contained in struct(j)
+        emit((int)(it - &S.blk_row[0]), base + (int)b, base + (int)a);   // L(i,k), i = sk[b];  L(j,k)
+      }
+    }
+  };
+  auto for_columns = [&](auto&& body) {
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nt = (pairs < 200000 || hw < 2) ? 1 : std::min(hw, 16);
+    if (nt <= 1) { for (int j = 0; j < N; ++j) body(j); return; }
+    std::atomic<int> next(0);
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    for (int t = 0; t < nt; ++t)
+      th.emplace_back([&]() {
+        for (;;) {   // the work sits in the separator columns at the end: small chunks, handed out from the end
+          const int c = next.fetch_add(16);
+          if (c >= N) return;
+          for (int j = N - 1 - c; j >= std::max(0, N - 16 - c); --j) body(j);
+        }
+      });
+    for (std::thread& t : th) t.join();
+  };
+  for_columns([&](int j) { walk_column(j, [&](int t, int, int) { ++S.upd_ptr[t + 1]; }); });
+  if (broken) return false;
   for (int t = 0; t < S.nb; ++t) S.upd_ptr[t + 1] += S.upd_ptr[t];
+  if ((long long)S.upd_ptr[S.nb] != pairs) return false;
   S.upd_a.resize(S.upd_ptr[S.nb]);
   S.upd_b.resize(S.upd_ptr[S.nb]);
   {
     std::vector<int> fill(S.upd_ptr.begin(), S.upd_ptr.end() - 1);
-    for (int k = 0; k < N; ++k) {   // ascending k: fixed summation order
-      const std::vector<int>& sk = st[k];
-      const int base = S.col_ptr[k] + 1;
-      for (size_t a = 0; a < sk.size(); ++a)
-        for (size_t b = a; b < sk.size(); ++b) {
-          const int t = block_of(sk[b], sk[a]);
-          const int q = fill[t]++;
-          S.upd_a[q] = base + (int)b;   // L(i,k), i = sk[b]
-          S.upd_b[q] = base + (int)a;   // L(j,k), j = sk[a]
-        }
-    }
+    for_columns([&](int j) {
+      walk_column(j, [&](int t, int la, int lb) { const int q = fill[t]++; S.upd_a[q] = la; S.upd_b[q] = lb; });
+    });
   }
 
   // ---- 3b. BSR sources per block ----
@@ -298,20 +342,6 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   S.fused_from_level = S.n_levels;
   while (S.fused_from_level > 0 && S.level_ptr[S.fused_from_level] - S.level_ptr[S.fused_from_level - 1] <= 8) --S.fused_from_level;
 
-  S.rowl_ptr.assign(N + 1, 0);
-  for (int k = 0; k < N; ++k) for (int i : st[k]) ++S.rowl_ptr[i + 1];
-  for (int j = 0; j < N; ++j) S.rowl_ptr[j + 1] += S.rowl_ptr[j];
-  S.rowl_blk.resize(S.rowl_ptr[N]);
-  S.rowl_col.resize(S.rowl_ptr[N]);
-  {
-    std::vector<int> fill(S.rowl_ptr.begin(), S.rowl_ptr.end() - 1);
-    for (int k = 0; k < N; ++k)
-      for (size_t a = 0; a < st[k].size(); ++a) {
-        const int q = fill[st[k][a]]++;
-        S.rowl_blk[q] = S.col_ptr[k] + 1 + (int)a;
-        S.rowl_col[q] = k;
-      }
-  }
   // ---- 5. schedule + cost model: serial "pair steps" on the critical path ----
   // COLUMN/FUSED: a column is processed ten blocks at a time by one wave; a block's update list is walked serially by its
   // 6-lane group(s).  SPLIT: every block of the level has its own wave (ten groups share its list), then a cheap
