@@ -21,6 +21,7 @@ namespace pgo { int comm_stress(Comm* c, int iters, size_t seg, hipStream_t s, i
 #include <cstdarg>
 #include <cstdio>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <cstdlib>
 #include <cstring>
@@ -53,6 +54,34 @@ int set_error(int code, const char* fmt, ...) {
 typedef std::chrono::steady_clock Clock;
 inline double seconds_since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
 
+// Host-to-device copy through a process-wide pinned staging buffer.  A hipMemcpyAsync from pageable memory makes the
+// runtime register the user pages with the device on the fly; once a problem's large device allocations exist that
+// registration was measured to stall the copy for 6-25 ms on this stack (a 20 KB list!), while a copy from memory
+// pinned once costs microseconds.  Same for the way back.
+inline hipError_t staged_copy(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t s) {
+  static std::mutex mu;
+  static char* stage = nullptr;
+  static const size_t cap = (size_t)4 << 20;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!stage) {
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&stage), cap, hipHostMallocDefault);
+    if (e != hipSuccess) { stage = nullptr; return e; }
+  }
+  for (size_t off = 0; off < bytes; off += cap) {
+    const size_t len = std::min(cap, bytes - off);
+    if (to_device) std::memcpy(stage, static_cast<const char*>(src) + off, len);
+    hipError_t e = to_device ? hipMemcpyAsync(static_cast<char*>(dst) + off, stage, len, hipMemcpyHostToDevice, s)
+                             : hipMemcpyAsync(stage, static_cast<const char*>(src) + off, len, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    if (!to_device) std::memcpy(static_cast<char*>(dst) + off, stage, len);
+  }
+  return hipSuccess;
+}
+inline hipError_t staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t s) { return staged_copy(dst, src, bytes, true, s); }
+inline hipError_t staged_d2h(void* dst, const void* src, size_t bytes, hipStream_t s) { return staged_copy(dst, src, bytes, false, s); }
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
@@ -68,16 +97,18 @@ struct DevBuf {
   hipError_t upload(const std::vector<T>& h, hipStream_t s) {
     hipError_t e = alloc(h.size());
     if (e != hipSuccess || h.empty()) return e;
-    e = hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) return e;
-    return hipStreamSynchronize(s);  // h may be a temporary
+    return staged_h2d(p, h.data(), h.size() * sizeof(T), s);
   }
   hipError_t upload(const T* h, size_t count, hipStream_t s) {
     hipError_t e = alloc(count);
     if (e != hipSuccess || count == 0) return e;
-    e = hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) return e;
-    return hipStreamSynchronize(s);
+    return staged_h2d(p, h, count * sizeof(T), s);
+  }
+  // copy into the existing allocation (capacity n), no hipMalloc
+  hipError_t store(const std::vector<T>& h, hipStream_t s) {
+    if (h.size() > n) return hipErrorInvalidValue;
+    if (h.empty()) return hipSuccess;
+    return staged_h2d(p, h.data(), h.size() * sizeof(T), s);
   }
   hipError_t zero(hipStream_t s) { return n ? hipMemsetAsync(p, 0, n * sizeof(T), s) : hipSuccess; }
 };
@@ -451,6 +482,11 @@ int prepare(pgo_problem* P) {
   HIP_TRY(P->d_sW.upload(sW.data(), sW.n, s));
   HIP_TRY(P->d_eW.upload(eW.data(), eW.n, s));
   HIP_TRY(P->d_eL.upload(eL.data(), eL.n, s));
+  // cluster-preconditioner lists (prepare_clusters fills them): allocated here, at their upper bounds, because on this
+  // stack an upload into a buffer allocated AFTER the large allocations below takes 6-25 ms to complete
+  HIP_TRY(P->d_cl_ptr.alloc((size_t)N + 2));
+  HIP_TRY(P->d_cl_slot.alloc((size_t)E + 1));
+  HIP_TRY(P->d_cl_rc.alloc((size_t)E + 1));
 
   lap("uploads");
   const size_t m = (size_t)6 * NP;
@@ -461,7 +497,7 @@ int prepare(pgo_problem* P) {
   HIP_TRY(P->d_bsr.zero(s));
   HIP_TRY(P->d_Hdiag.alloc((size_t)36 * NP));
   HIP_TRY(P->d_Hdiag.zero(s));
-  HIP_TRY(P->d_Minv.alloc((size_t)36 * NP));
+  HIP_TRY(P->d_Minv.alloc((size_t)36 * NP * 4 + (size_t)world * 144 * 4));   // room for 4-pose clusters of every rank, padded
   HIP_TRY(P->d_Minv.zero(s));
   DevBuf<double>* vecs[] = {&P->d_grad, &P->d_scale, &P->d_d2, &P->d_diagc, &P->d_cg_b, &P->d_cg_x, &P->d_cg_r,
                             &P->d_cg_z, &P->d_cg_p0, &P->d_cg_p1, &P->d_delta};
@@ -523,16 +559,14 @@ int upload_poses(pgo_problem* P, double* dst) {
     o[0] = P->pp[v][0]; o[1] = P->pp[v][1]; o[2] = P->pp[v][2];
     o[3] = P->qq[v][0]; o[4] = P->qq[v][1]; o[5] = P->qq[v][2]; o[6] = P->qq[v][3];
   }
-  HIP_TRY(hipMemcpyAsync(dst, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, P->stream));
-  HIP_TRY(hipStreamSynchronize(P->stream));
+  HIP_TRY(staged_h2d(dst, h.data(), h.size() * sizeof(double), P->stream));
   return PGO_OK;
 }
 
 int download_poses(pgo_problem* P, const double* src) {
   const int N = (int)P->pp.size();
   std::vector<double> h((size_t)pgo::POSE_STRIDE * N);
-  HIP_TRY(hipMemcpyAsync(h.data(), src, h.size() * sizeof(double), hipMemcpyDeviceToHost, P->stream));
-  HIP_TRY(hipStreamSynchronize(P->stream));
+  HIP_TRY(staged_d2h(h.data(), src, h.size() * sizeof(double), P->stream));
   for (int v = 0; v < N; ++v) {
     const double* o = &h[(size_t)pgo::POSE_STRIDE * v];
     // constant blocks are never written (row 0 of the reference's before/after files is identical)
@@ -544,8 +578,7 @@ int download_poses(pgo_problem* P, const double* src) {
 
 int fill_scale_one(pgo_problem* P) {
   std::vector<double> one((size_t)6 * P->g.N, 1.0);
-  HIP_TRY(hipMemcpyAsync(P->g.scale, one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice, P->stream));
-  HIP_TRY(hipStreamSynchronize(P->stream));
+  HIP_TRY(staged_h2d(P->g.scale, one.data(), one.size() * sizeof(double), P->stream));
   return PGO_OK;
 }
 
@@ -717,17 +750,11 @@ int prepare_clusters(pgo_problem* P, int CL) {
       }
       if (pass == 0) { for (int k = 0; k < ncl; ++k) ptr[k + 1] += ptr[k]; slots.resize(ptr[ncl]); rcs.resize(ptr[ncl]); }
     }
-    const auto tq = Clock::now();
-    const bool vb = getenv("PGO_VERBOSE") != nullptr;
-    HIP_TRY(P->d_cl_ptr.upload(ptr, P->stream));
-    if (vb) std::fprintf(stderr, "[pgo] clusters: upload ptr %.2f ms\n", 1e3 * seconds_since(tq));
-    HIP_TRY(P->d_cl_slot.upload(slots, P->stream));
-    HIP_TRY(P->d_cl_rc.upload(rcs, P->stream));
-    if (vb) std::fprintf(stderr, "[pgo] clusters: upload slots %.2f ms\n", 1e3 * seconds_since(tq));
-    if (slots.empty()) { HIP_TRY(P->d_cl_slot.alloc(1)); HIP_TRY(P->d_cl_rc.alloc(1)); }
+    HIP_TRY(P->d_cl_ptr.store(ptr, P->stream));
+    HIP_TRY(P->d_cl_slot.store(slots, P->stream));
+    HIP_TRY(P->d_cl_rc.store(rcs, P->stream));
     const size_t need = (size_t)P->g.world * P->g.rows_per * 36 * CL;   // every rank's clusters, padded
     if (P->d_Minv.n < need) { HIP_TRY(P->d_Minv.alloc(need)); HIP_TRY(P->d_Minv.zero(P->stream)); }
-    if (vb) std::fprintf(stderr, "[pgo] clusters: Minv %.2f ms\n", 1e3 * seconds_since(tq));
     P->g.Minv = P->d_Minv.p;
     P->g.cl_ptr = P->d_cl_ptr.p;
     P->g.cl_slot = P->d_cl_slot.p;
@@ -879,7 +906,7 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
     if (!P->direct_usable && cluster < 2) cluster = 2;
   }
   static const bool verbose = getenv("PGO_VERBOSE") != nullptr;
-  if (verbose) std::fprintf(stderr, "[pgo] lm_begin: before clusters            %.2f ms\n", 1e3 * seconds_since(t0));
+  if (verbose) { std::fprintf(stderr, "[pgo] lm_begin: before clusters            %.2f ms\n", 1e3 * seconds_since(t0)); HIP_TRY(hipStreamSynchronize(P->stream)); std::fprintf(stderr, "[pgo] lm_begin: idle check                  %.2f ms\n", 1e3 * seconds_since(t0)); }
   rc = prepare_clusters(P, cluster);
   if (rc) return rc;
   if (verbose) std::fprintf(stderr, "[pgo] lm_begin: clusters prepared          %.2f ms\n", 1e3 * seconds_since(t0));
@@ -1443,9 +1470,9 @@ int pgo_evaluate(pgo_problem* P, double* cost, double* residuals, double* jac_be
     if (jac_end) HIP_TRY(P->d_tmp_c.alloc((size_t)36 * E));
     if (E > 0) pgo::launch_evaluate_edges(P->g, P->g.pose_x, residuals ? P->d_tmp_a.p : nullptr, jac_begin ? P->d_tmp_b.p : nullptr,
                                jac_end ? P->d_tmp_c.p : nullptr, s);
-    if (residuals && E) HIP_TRY(hipMemcpyAsync(residuals, P->d_tmp_a.p, sizeof(double) * 6 * E, hipMemcpyDeviceToHost, s));
-    if (jac_begin && E) HIP_TRY(hipMemcpyAsync(jac_begin, P->d_tmp_b.p, sizeof(double) * 36 * E, hipMemcpyDeviceToHost, s));
-    if (jac_end && E) HIP_TRY(hipMemcpyAsync(jac_end, P->d_tmp_c.p, sizeof(double) * 36 * E, hipMemcpyDeviceToHost, s));
+    if (residuals && E) HIP_TRY(staged_d2h(residuals, P->d_tmp_a.p, sizeof(double) * 6 * E, s));
+    if (jac_begin && E) HIP_TRY(staged_d2h(jac_begin, P->d_tmp_b.p, sizeof(double) * 36 * E, s));
+    if (jac_end && E) HIP_TRY(staged_d2h(jac_end, P->d_tmp_c.p, sizeof(double) * 36 * E, s));
   }
   if (cost) {
     pgo::launch_cost(P->g, P->g.pose_x, 0, s);
@@ -1456,7 +1483,7 @@ int pgo_evaluate(pgo_problem* P, double* cost, double* residuals, double* jac_be
     if (rc) return rc;
     rc = linearize_all(P);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(gradient, P->g.grad, sizeof(double) * 6 * N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(staged_d2h(gradient, P->g.grad, sizeof(double) * 6 * N, s));
   }
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
@@ -1478,12 +1505,12 @@ int pgo_normal_equations(pgo_problem* P, double* diag, double* offdiag, double* 
   rc = linearize_all(P);
   if (rc) return rc;
   const int N = P->g.N, E = P->g.E;
-  if (diag) HIP_TRY(hipMemcpyAsync(diag, P->g.Hdiag, sizeof(double) * 36 * N, hipMemcpyDeviceToHost, s));
-  if (gradient) HIP_TRY(hipMemcpyAsync(gradient, P->g.grad, sizeof(double) * 6 * N, hipMemcpyDeviceToHost, s));
+  if (diag) HIP_TRY(staged_d2h(diag, P->g.Hdiag, sizeof(double) * 36 * N, s));
+  if (gradient) HIP_TRY(staged_d2h(gradient, P->g.grad, sizeof(double) * 6 * N, s));
   std::vector<double> bsr;
   if (offdiag) {
     bsr.resize((size_t)P->g.n_slots * 36);
-    HIP_TRY(hipMemcpyAsync(bsr.data(), P->g.bsr_val, bsr.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(staged_d2h(bsr.data(), P->g.bsr_val, bsr.size() * sizeof(double), s));
   }
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
@@ -1511,8 +1538,8 @@ int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const do
   if (rc) return rc;
   rc = linearize_all(P);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(P->g.d2, d2, m * sizeof(double), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(P->g.grad, b, m * sizeof(double), hipMemcpyHostToDevice, s));  // rhs = scale(=1) * grad
+  HIP_TRY(staged_h2d(P->g.d2, d2, m * sizeof(double), s));
+  HIP_TRY(staged_h2d(P->g.grad, b, m * sizeof(double), s));  // rhs = scale(=1) * grad
   HIP_TRY(hipStreamSynchronize(s));
   rc = damping_all(P, 1.0, 0.0, 0.0, 2);
   if (rc) return rc;
@@ -1532,7 +1559,7 @@ int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const do
     rc = run_pcg(P, cg_params_for(*options), options->cg_batch, &it, &status);
   }
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(x, P->g.cg_x, m * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(staged_d2h(x, P->g.cg_x, m * sizeof(double), s));
   HIP_TRY(hipStreamSynchronize(s));
   if (iterations) *iterations = it;
   if (status == 2) return set_error(PGO_ERR_NUMERICAL, "PCG broke down with non-finite values");
@@ -1549,7 +1576,7 @@ int pgo_plus(pgo_problem* P, const double* delta) {
   if (rc) return rc;
   const size_t m = (size_t)6 * P->g.N;
   HIP_TRY(P->d_tmp_a.alloc(m));
-  HIP_TRY(hipMemcpyAsync(P->d_tmp_a.p, delta, m * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(staged_h2d(P->d_tmp_a.p, delta, m * sizeof(double), s));
   pgo::launch_apply_step(P->g, P->d_tmp_a.p, s);
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
