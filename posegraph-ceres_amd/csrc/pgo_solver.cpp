@@ -62,6 +62,10 @@ inline hipError_t staged_copy(void* dst, const void* src, size_t bytes, bool to_
   static std::mutex mu;
   static char* stage = nullptr;
   static const size_t cap = (size_t)4 << 20;
+  if (bytes > 2 * cap) {   // the big topology arrays: uploaded before the problem's device allocations, where the direct copy is fast
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+  }
   std::lock_guard<std::mutex> lock(mu);
   if (!stage) {
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&stage), cap, hipHostMallocDefault);
@@ -301,7 +305,7 @@ int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd, bool refresh
 template <class F>
 void parallel_for(int n, F&& fn) {
   const int hw = (int)std::thread::hardware_concurrency();
-  const int nt = (n < 65536 || hw < 2) ? 1 : std::min(std::min(hw, 32), n / 32768);
+  const int nt = (n < 16384 || hw < 2) ? 1 : std::min(std::min(hw, 32), n / 8192);   // a thread costs ~50 us to start; 8 k items of these loops ~0.5 ms
   if (nt <= 1) { fn(0, n); return; }
   std::vector<std::thread> th;
   th.reserve(nt);
