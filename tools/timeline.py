@@ -1,19 +1,19 @@
 """Kernel timeline of ONE LM iteration from a rocprofv3 kernel-trace database (rocpd): start offset, duration and the idle
 gap before each kernel, between two consecutive k_pcg_init launches in the middle of the run.
-usage: python tools/timeline.py <results.db> [which_iteration]"""
+usage: python tools/timeline.py <results.db> [which_iteration] [anchor kernel, default k_pcg_init; k_linearize for the exact path]"""
 import re
 import sqlite3
 import sys
 
 
-def main(db, which=None):
+def main(db, which=None, anchor="k_pcg_init"):
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     sc = "start" if "start" in cols else "start_timestamp"
     ec = "end" if "end" in cols else "end_timestamp"
     rows = c.execute("select name, %s, %s from kernels order by %s" % (sc, ec, sc)).fetchall()
-    idx = [i for i, r in enumerate(rows) if "k_pcg_init" in r[0]]
-    k = int(which) if which is not None else len(idx) // 2
+    idx = [i for i, r in enumerate(rows) if anchor in r[0]]
+    k = int(which) if which not in (None, "-") else len(idx) // 2
     a, b = idx[k], idx[k + 1]
     t0 = rows[a][1]
     prev_end = rows[a - 1][2]
