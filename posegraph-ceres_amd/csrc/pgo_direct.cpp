@@ -240,7 +240,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
         S.rowl_col[q] = k;
       }
   }
-  // ---- 3b'. update pairs per target block ----
+  // ---- 3b. update pairs per target block ----
   // Target-centric: the pairs of the blocks (i, j) of column j come from the columns k of row j (ascending k = the fixed
   // summation order): with a = position of j in struct(k), the targets (sk[b], j), b >= a, are found by one forward
   // walk through column j's row list.  All writes of column j fall in its own range of the pair arrays, so columns are
@@ -296,7 +296,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
     });
   }
 
-  // ---- 3b. BSR sources per block ----
+  // ---- 3c. BSR sources per block ----
   S.asrc_ptr.assign(S.nb + 1, 0);
   std::vector<int> src_block(n_slots, -1);
   for (int t = 0; t < n_slots; ++t) {
@@ -316,7 +316,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   }
   (void)row_slot_begin;
 
-  // ---- 4. levels and row lists ----
+  // ---- 4. levels ----
   std::vector<int> level(N, 0);
   int max_level = 0;
   for (int j = 0; j < N; ++j) {   // children have smaller indices
