@@ -10,6 +10,8 @@
 // that hold at most 8 columns are folded into ONE single-workgroup launch (barrier between levels).
 #include "pgo_direct.h"
 
+#include <cstdlib>
+
 namespace pgo {
 namespace {
 
@@ -337,6 +339,126 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_panel(DeviceGraph g, 
   }
 }
 
+// The same column by three cooperating waves: the diagonal block (gather, pair walk, 6x6 Cholesky), the first ten
+// off-diagonal blocks (gather, pair walk) and the partial sums of the fused forward step do not depend on each other, so
+// their chains of dependent round trips run side by side; after one barrier L_jj is in LDS and the off-diagonal rows are
+// scaled while the forward step finishes.  Arithmetic and summation order are those of factor_column.
+__device__ void factor_column_roles(const DeviceGraph& g, const DirectPlan& p, int j, int role, double* shd, double* sho,
+                                    double* shf, double* Ld) {
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / 6, r = lane - 6 * grp;
+  const bool in_grp = grp < 10;
+  const int b0 = p.col_ptr[j], nblk = p.col_ptr[j + 1] - b0;
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  bool active = false;
+  int my = 0, sub = 0;
+  double bj = 0.0;
+  if (role == 0) {
+    if (in_grp) {
+      double d[6];
+      assemble_row(g, p, b0, r, grp, 10, d);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) shd[(grp * 6 + r) * 6 + c] = d[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double Ljj[36];
+    sum_partials(shd, Ljj, nullptr);
+    const bool ok = chol6_inplace(Ljj);
+    if (!ok && lane == 0) atomicOr(&g.flags[2], 1);
+    if (lane < 36) { p.Lval[36 * (size_t)b0 + lane] = Ljj[lane]; Ld[lane] = Ljj[lane]; }
+  } else if (role == 1) {
+    if (nblk > 1) {
+      const int bc = min(10, nblk - 1);
+      const int gpb = 10 / bc;
+      my = grp / gpb; sub = grp - my * gpb;
+      active = in_grp && my < bc;
+      if (active) {
+        assemble_row(g, p, b0 + 1 + my, r, sub, gpb, v);
+        if (gpb > 1) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) sho[(grp * 6 + r) * 6 + c] = v[c];
+        }
+      }
+      if (gpb > 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (active && sub == 0) {
+          for (int q = 1; q < gpb; ++q) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] += sho[((grp + q) * 6 + r) * 6 + c];
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  } else {
+    bj = forward_rhs(g, p.perm[j]);
+    forward_partial(p, j, 0, 1, shf);
+  }
+  __syncthreads();
+  if (role == 1) {
+    if (active && sub == 0) {
+      double x[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double s = v[c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) s -= x[k] * Ld[6 * c + k];
+        x[c] = s / Ld[7 * c];
+      }
+      double2* o = reinterpret_cast<double2*>(p.Lval + 36 * (size_t)(b0 + 1 + my) + 6 * r);
+      o[0] = double2{x[0], x[1]}; o[1] = double2{x[2], x[3]}; o[2] = double2{x[4], x[5]};
+    }
+    for (int t0 = 11; t0 < nblk; t0 += 10) {     // columns with more than ten off-diagonal blocks: the rest, as factor_column
+      const int bc = min(10, nblk - t0);
+      const int gpb = 10 / bc;
+      my = grp / gpb; sub = grp - my * gpb;
+      active = in_grp && my < bc;
+      if (active) {
+        assemble_row(g, p, b0 + t0 + my, r, sub, gpb, v);
+        if (gpb > 1) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) sho[(grp * 6 + r) * 6 + c] = v[c];
+        }
+      }
+      if (gpb > 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (active && sub == 0) {
+          for (int q = 1; q < gpb; ++q) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] += sho[((grp + q) * 6 + r) * 6 + c];
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (active && sub == 0) {
+        double x[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double s = v[c];
+#pragma unroll
+          for (int k = 0; k < c; ++k) s -= x[k] * Ld[6 * c + k];
+          x[c] = s / Ld[7 * c];
+        }
+        double2* o = reinterpret_cast<double2*>(p.Lval + 36 * (size_t)(b0 + t0 + my) + 6 * r);
+        o[0] = double2{x[0], x[1]}; o[1] = double2{x[2], x[3]}; o[2] = double2{x[4], x[5]};
+      }
+    }
+  } else if (role == 2) {
+    forward_finish(p, j, bj, 1, shf, Ld);
+  }
+}
+
+__global__ __launch_bounds__(192) void k_chol_level3(DeviceGraph g, DirectPlan p, int level) {
+  __shared__ double shd[360], sho[360], shf[64], Ld[36];
+  const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
+  factor_column_roles(g, p, j, threadIdx.x >> 6, shd, sho, shf, Ld);
+}
+
 __global__ __launch_bounds__(64) void k_chol_level(DeviceGraph g, DirectPlan p, int level) {
   __shared__ double sh[360];
   const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
@@ -562,7 +684,11 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
   for (const DirectStep& st : sym.steps) {
     if (st.type == DirectStep::COLUMN) {
       const int nc = sym.level_ptr[st.level_begin + 1] - sym.level_ptr[st.level_begin];
-      hipLaunchKernelGGL(k_chol_level, dim3(nc), dim3(64), 0, s, g, p, st.level_begin);
+      // three waves per column by default (every COLUMN level of KITTI-00 gains 1-4 us); PGO_DIRECT_ROLES=<columns per level
+      // up to which they are used>, 0 = one wave per column
+      static const int roles_max = getenv("PGO_DIRECT_ROLES") ? atoi(getenv("PGO_DIRECT_ROLES")) : (1 << 30);
+      if (nc <= roles_max) hipLaunchKernelGGL(k_chol_level3, dim3(nc), dim3(192), 0, s, g, p, st.level_begin);
+      else hipLaunchKernelGGL(k_chol_level, dim3(nc), dim3(64), 0, s, g, p, st.level_begin);
     } else if (st.type == DirectStep::FUSED) {
       hipLaunchKernelGGL(k_chol_tail, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, st.level_begin, st.level_end);
     } else if (st.type == DirectStep::PANEL) {
