@@ -281,26 +281,31 @@ __global__ __launch_bounds__(64) void k_chol_scale(DeviceGraph g, DirectPlan p, 
 }
 
 // ---- PANEL steps, phase 2: one workgroup per chain of `width` columns; the contributions of every column before the
-// panel are already in Lval (phase 1 = k_chol_assemble over all blocks of the panel).  Column by column: wave 0 adds the
-// in-panel pairs of the diagonal block and factorises it, then all eight waves finish the sub-diagonal blocks (their
-// few in-panel pairs, then L_jj^-T), one 6-lane group per block. ----
+// panel are already in Lval (phase 1 = k_chol_assemble over all blocks of the panel).  Column by column, two phases:
+// wave 0 adds the in-panel pairs of the diagonal block and factorises it WHILE waves 1..7 walk the row list of the fused
+// forward step and bring the sub-diagonal blocks up to date (their few in-panel pairs; one 6-lane group per block) —
+// none of that needs L_jj; after the barrier wave 0 finishes the forward step and the others apply L_jj^-T. ----
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_panel(DeviceGraph g, DirectPlan p, int cols_begin, int width) {
   __shared__ double sh[360];
   __shared__ double Ld[36];
   __shared__ double shf[FUSED_WAVES][64];
+  constexpr int W = FUSED_WAVES - 1;            // waves on the forward step and the sub-diagonal blocks
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int grp = lane / 6, r = lane - 6 * grp;
   for (int i = 0; i < width; ++i) {
     const int j = p.panel_cols[cols_begin + blockIdx.x * width + i];
     const int b0 = p.col_ptr[j], nblk = p.col_ptr[j + 1] - b0;
     double bj = 0.0;
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    int t = 1 + (wave - 1) * 10 + grp;
+    const bool first = wave > 0 && grp < 10 && t < nblk;
     if (wave == 0) {
       bj = forward_rhs(g, p.perm[j]);
       if (grp < 10) {
-        double v[6] = {0, 0, 0, 0, 0, 0};
-        subtract_pairs(p, p.upd_split[b0], p.upd_ptr[b0 + 1], r, grp, 10, v);
+        double d[6] = {0, 0, 0, 0, 0, 0};
+        subtract_pairs(p, p.upd_split[b0], p.upd_ptr[b0 + 1], r, grp, 10, d);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) sh[(grp * 6 + r) * 6 + c] = v[c];
+        for (int c = 0; c < 6; ++c) sh[(grp * 6 + r) * 6 + c] = d[c];
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -309,20 +314,27 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_panel(DeviceGraph g, 
       const bool ok = chol6_inplace(Ljj);
       if (!ok && lane == 0) atomicOr(&g.flags[2], 1);
       if (lane < 36) { p.Lval[36 * (size_t)b0 + lane] = Ljj[lane]; Ld[lane] = Ljj[lane]; }
+    } else {
+      forward_partial(p, j, wave - 1, W, shf[wave]);
+      if (first) {
+        const double2* o = reinterpret_cast<const double2*>(p.Lval + 36 * (size_t)(b0 + t) + 6 * r);
+        const double2 a = o[0], b = o[1], c2 = o[2];
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c2.x; v[5] = c2.y;
+        subtract_pairs(p, p.upd_split[b0 + t], p.upd_ptr[b0 + t + 1], r, 0, 1, v);
+      }
     }
-    __threadfence_block();
     __syncthreads();
-    // fused forward substitution: the row list of column j shared by all waves, finished by one lane
-    forward_partial(p, j, wave, FUSED_WAVES, shf[wave]);
-    __syncthreads();
-    if (wave == 0) forward_finish(p, j, bj, FUSED_WAVES, shf[0], Ld);
-    if (grp < 10) {
-      for (int t = 1 + wave * 10 + grp; t < nblk; t += 10 * FUSED_WAVES) {
+    if (wave == 0) {
+      forward_finish(p, j, bj, W, shf[1], Ld);
+    } else if (grp < 10) {
+      for (bool pre = first; t < nblk; t += 10 * W, pre = false) {
         const int bi = b0 + t;
         double2* o = reinterpret_cast<double2*>(p.Lval + 36 * (size_t)bi + 6 * r);
-        const double2 a = o[0], b = o[1], c2 = o[2];
-        double v[6] = {a.x, a.y, b.x, b.y, c2.x, c2.y};
-        subtract_pairs(p, p.upd_split[bi], p.upd_ptr[bi + 1], r, 0, 1, v);
+        if (!pre) {
+          const double2 a = o[0], b = o[1], c2 = o[2];
+          v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c2.x; v[5] = c2.y;
+          subtract_pairs(p, p.upd_split[bi], p.upd_ptr[bi + 1], r, 0, 1, v);
+        }
         double x[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
