@@ -376,7 +376,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   for (int j = 0; j < N; ++j) for (int bi = S.col_ptr[j]; bi < S.col_ptr[j + 1]; ++bi) blk_col[bi] = j;
   static const int PANEL_MAX = getenv("PGO_DIRECT_PANEL") ? std::max(1, std::min(16, atoi(getenv("PGO_DIRECT_PANEL")))) : 8;
   auto is_heavy = [&](int l) { return level_cost[l] > HEAVY && split_cost[l] < level_cost[l]; };
-  std::vector<int> tmp_a, tmp_b, tmp_pa, tmp_pb;
+  std::vector<int> tmp_a, tmp_b, tmp_pa, tmp_pb, chain_pos(N, -1);
   double steps = 0.0;
   // Light levels of the fused tail (chain-like tops: one wave per column, ~10 us per level of dependent round trips) also
   // go through PANEL when at least LIGHT_PANEL_MIN consecutive levels form parent chains: two launches, then ~3 us per
@@ -418,6 +418,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
         double p1 = 0.0, p2 = 0.0;
         for (int c = 0; c < nc; ++c) {
           const int first = chain[c][0];     // columns of one chain are consecutive in the elimination order? not assumed
+          for (int i = 0; i < w; ++i) chain_pos[chain[c][i]] = i;   // position within this chain, -1 elsewhere
           double chain_p2 = 0.0;
           for (int i = 0; i < w; ++i) {
             const int j = chain[c][i];
@@ -433,8 +434,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
                 tmp_a.clear(); tmp_b.clear(); tmp_pa.clear(); tmp_pb.clear();
                 for (int u = S.upd_ptr[bi]; u < S.upd_ptr[bi + 1]; ++u) {
                   const int k = blk_col[S.upd_a[u]];
-                  bool in_panel = false;
-                  for (int i2 = 0; i2 < i; ++i2) if (chain[c][i2] == k) in_panel = true;
+                  const bool in_panel = chain_pos[k] >= 0 && chain_pos[k] < i;
                   (in_panel ? tmp_pa : tmp_a).push_back(S.upd_a[u]);
                   (in_panel ? tmp_pb : tmp_b).push_back(S.upd_b[u]);
                 }
@@ -449,6 +449,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
             chain_p2 += 3.0 + ((nblk - 1 + 79) / 80) * (1.0 + i);
           }
           (void)first;
+          for (int i = 0; i < w; ++i) chain_pos[chain[c][i]] = -1;
           p2 = std::max(p2, chain_p2);
         }
         st.blk_end = (int)S.split_blk.size();
