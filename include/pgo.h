@@ -94,7 +94,8 @@ typedef struct pgo_solver_summary {
   int reason;                   /* 1 function tol, 2 parameter tol, 3 gradient tol, 4 min radius, 5 max iterations,
                                    6 invalid steps, 7 linear solver failure */
   int linear_solver_used;       /* 0 GPU block-sparse Cholesky, 1 block-Jacobi PCG (eta), 2 PCG run to exact_r_tolerance
-                                   (exact solve requested but the factorisation schedule was impractical) */
+                                   (exact solve requested but the factorisation schedule was impractical), 3 exact solve
+                                   requested, factorisation or PCG to exact_r_tolerance chosen per LM iteration */
   int factor_nnz_blocks;        /* 6x6 blocks of the Cholesky factor (0 when not used) */
   int factor_levels;            /* elimination-tree levels = dependent launches per factorisation */
   int reserved1;

@@ -506,8 +506,13 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   // ~8 ms per solve on Manhattan 10 k (well conditioned, est 8.7 k steps = 12 ms direct), ~40 ms on KITTI-00 dense (est
   // 4.2 ms direct), seconds on the open chain of the KITTI-00 replay.  One step is ~1 us; the budget below
   // (PGO_DIRECT_MAX_STEPS to override) sends the well-conditioned mesh-like graphs to PCG and keeps the rest direct.
-  static const double max_steps = getenv("PGO_DIRECT_MAX_STEPS") ? atof(getenv("PGO_DIRECT_MAX_STEPS")) : 7000.0;
-  if (S.steps.size() > 4000 || steps > max_steps) return false;
+  // Between that budget and PGO_DIRECT_HYBRID_STEPS the factorisation is kept as one of two ways to serve an iteration
+  // (`hybrid`): early LM iterations of a mesh are ill-conditioned (Manhattan 10 k: ~3000 CG iterations = 42 ms vs 6.9 ms
+  // direct), late ones are not (~90 CG iterations = 1.3 ms).
+  const double max_steps = getenv("PGO_DIRECT_MAX_STEPS") ? atof(getenv("PGO_DIRECT_MAX_STEPS")) : 7000.0;
+  const double hybrid_steps = getenv("PGO_DIRECT_HYBRID_STEPS") ? atof(getenv("PGO_DIRECT_HYBRID_STEPS")) : 30000.0;
+  if (S.steps.size() > 4000 || steps > std::max(max_steps, hybrid_steps)) return false;
+  S.hybrid = steps > max_steps;
   return true;
 }
 

@@ -70,6 +70,8 @@ struct DirectSymbolic {
   std::vector<uint8_t> split_diag;
   double flops = 0;
   double est_steps = 0;      // critical-path length of the schedule in update-pair steps (cost model)
+  bool hybrid = false;       // est_steps above the always-direct budget: the LM driver chooses per iteration between this
+                             // factorisation and PCG run to exact_r_tolerance (whichever the last iterations made cheaper)
 };
 
 // Host symbolic analysis.  slot_* describe the incidence-slot BSR (pgo_solver.cpp prepare()).

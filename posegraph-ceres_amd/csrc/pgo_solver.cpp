@@ -142,6 +142,11 @@ struct LmState {
   pgo_iteration_record cur{};
   std::vector<pgo_iteration_record> records;
   double t_total = 0, t_linear = 0, t_jacobian = 0, t_residual = 0, t_setup = 0;
+  // exact request with both a factorisation and PCG available (DirectSymbolic::hybrid): which one serves the next iteration
+  bool hybrid_pcg = false;        // PCG served the last iteration within its budget
+  int hybrid_direct_run = 0;      // consecutive iterations served by the factorisation
+  int hybrid_probe_after = 1;     // ... after which PCG is tried again (doubles on every failed try, up to 16)
+  int hybrid_direct = 0, hybrid_pcg_ok = 0, hybrid_pcg_over = 0;   // statistics (PGO_VERBOSE)
   std::string message;
 };
 
@@ -907,7 +912,7 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
     L.t_setup += seconds_since(t_sym);
     // exact request served by PCG to exact_r_tolerance: the preconditioner is ours to choose — 2-pose chain clusters need
     // ~2.5x fewer iterations than 6x6 blocks at almost the same cost per iteration
-    if (!P->direct_usable && cluster < 2) cluster = 2;
+    if ((!P->direct_usable || P->dsym.hybrid) && cluster < 2) cluster = 2;
   }
   static const bool verbose = getenv("PGO_VERBOSE") != nullptr;
   if (verbose) { std::fprintf(stderr, "[pgo] lm_begin: before clusters            %.2f ms\n", 1e3 * seconds_since(t0)); HIP_TRY(hipStreamSynchronize(P->stream)); std::fprintf(stderr, "[pgo] lm_begin: idle check                  %.2f ms\n", 1e3 * seconds_since(t0)); }
@@ -1004,8 +1009,50 @@ int lm_advance(pgo_problem* P) {
   int rc = damping_all(P, L.radius, o.min_lm_diagonal, o.max_lm_diagonal, L.reuse_diagonal ? 1 : 0);
   if (rc) return rc;
   const bool direct = o.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY && P->direct_usable;
+  // Both available (hybrid): PCG gets the budget of ~1.5 factorisations, in CG iterations priced by the same deterministic
+  // cost model that admitted the factorisation (0.7 us per schedule step; 10 us + 42 ps per slot per CG iteration), so the
+  // choice depends on iteration counts only, never on a clock.  Over budget = redo the iteration with the factorisation.
+  const bool hybrid = direct && P->dsym.hybrid;
+  const char* budget_env = getenv("PGO_HYBRID_BUDGET");     // experiments / tests: CG iterations a PCG try may take
+  const int cg_budget = !hybrid ? 0 : budget_env ? std::max(1, atoi(budget_env))
+                                : std::max(50, (int)(1.5 * 0.7 * P->dsym.est_steps / (10.0 + 4.2e-5 * (double)P->g.n_slots)));
+  bool use_direct = direct;
+  if (hybrid && (L.hybrid_pcg || L.hybrid_direct_run >= L.hybrid_probe_after)) use_direct = false;
+  int wasted_cg = 0;
   arm_handoff(P);
-  if (direct) {
+  if (!use_direct) {
+    // every batch carries the gated tail: the host hears back once per batch and finds the step scalars ready
+    // as soon as the CG has stopped
+    pgo::CgParams run_prm = prm;
+    if (hybrid) run_prm.max_iterations = cg_budget;
+    pgo::launch_pcg_init(P->g, s);
+    for (int round = 0, enqueued = 0;; ++round) {
+      const int nb = pick_batch(run_prm, o.cg_batch, round, enqueued, P->last_cg_iterations);
+      rc = launch_cg_batch(P, run_prm, nb, true, enqueued + 1);
+      enqueued += nb;
+      if (rc) return rc;
+      rc = wait_handoff(P);
+      if (rc) return rc;
+      if (P->scal->cg_status != -1) break;
+      arm_handoff(P);
+    }
+    if (hybrid) {
+      if (P->scal->cg_iterations >= cg_budget && P->scal->cg_status == 0) {   // not converged within the budget
+        wasted_cg = P->scal->cg_iterations;
+        L.hybrid_probe_after = L.hybrid_pcg ? 2 : std::min(16, 2 * L.hybrid_probe_after);
+        L.hybrid_pcg = false;
+        L.hybrid_direct_run = 0;
+        ++L.hybrid_pcg_over;
+        use_direct = true;
+        arm_handoff(P);
+      } else {
+        L.hybrid_pcg = true;
+        L.hybrid_probe_after = 1;
+        ++L.hybrid_pcg_ok;
+      }
+    }
+  }
+  if (use_direct) {
     P->scal->cg_status = 0;       // host-visible block: the CG kernels that normally fill these do not run
     P->scal->cg_iterations = 0;
     rc = run_direct(P);
@@ -1014,27 +1061,14 @@ int lm_advance(pgo_problem* P) {
     if (rc) return rc;
     rc = wait_handoff(P);
     if (rc) return rc;
-  } else {
-    // every batch carries the gated tail: the host hears back once per batch and finds the step scalars ready
-    // as soon as the CG has stopped
-    pgo::launch_pcg_init(P->g, s);
-    for (int round = 0, enqueued = 0;; ++round) {
-      const int nb = pick_batch(prm, o.cg_batch, round, enqueued, P->last_cg_iterations);
-      rc = launch_cg_batch(P, prm, nb, true, enqueued + 1);
-      enqueued += nb;
-      if (rc) return rc;
-      rc = wait_handoff(P);
-      if (rc) return rc;
-      if (P->scal->cg_status != -1) break;
-      arm_handoff(P);
-    }
+    if (hybrid) { ++L.hybrid_direct_run; ++L.hybrid_direct; }
   }
   HIP_TRY(hipGetLastError());
   const pgo::LmScalars sc = *P->scal;
   const int cg_it = sc.cg_iterations, cg_status = sc.cg_status;
   P->last_cg_iterations = cg_it;
   L.reuse_diagonal = true;
-  L.num_linear_iterations += cg_it;
+  L.num_linear_iterations += cg_it + wasted_cg;   // the iterations of an over-budget PCG try are work done, counted in the summary
   nx.linear_solver_iterations = cg_it;
   L.t_linear += seconds_since(t_lin);
 
@@ -1142,6 +1176,9 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
     L.pending_record = false;
   }
   if (!L.terminated) terminate(L, PGO_NO_CONVERGENCE, 5, "Stepping stopped by the caller after %d iterations.", L.cur.iteration);
+  if (P->dsym.hybrid && P->direct_usable && getenv("PGO_VERBOSE"))
+    std::fprintf(stderr, "[pgo] exact request, per-iteration choice: %d factorisations, %d PCG solves within budget, %d over budget (redone)\n",
+                 L.hybrid_direct, L.hybrid_pcg_ok, L.hybrid_pcg_over);
   int rc = download_poses(P, P->g.pose_x);
   if (rc) return rc;
   if (summary) {
@@ -1155,7 +1192,7 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
     summary->num_poses = P->g.N;
     summary->num_edges = P->g.E;
     const bool want_exact = P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY;
-    summary->linear_solver_used = want_exact ? (P->direct_usable ? 0 : 2) : 1;
+    summary->linear_solver_used = want_exact ? (P->direct_usable ? (P->dsym.hybrid ? 3 : 0) : 2) : 1;
     summary->factor_nnz_blocks = (want_exact && P->direct_usable) ? P->dsym.nb : 0;
     summary->factor_levels = (want_exact && P->direct_usable) ? P->dsym.n_levels : 0;
     summary->initial_cost = L.initial_cost;
@@ -1421,8 +1458,9 @@ size_t pgo_summary_full_report(const pgo_solver_summary* s, const pgo_iteration_
   add("Minimizer                        TRUST_REGION\n");
   add("Trust region strategy     LEVENBERG_MARQUARDT\n");
   static const char* ls[] = {"SPARSE_NORMAL_CHOLESKY (GPU block Cholesky, nested dissection)", "CGNR / block-Jacobi PCG (Q-tolerance eta)",
-                             "SPARSE_NORMAL_CHOLESKY served by PCG to 1e-13 (factor schedule impractical)"};
-  add("Linear solver    %s\n", ls[(s->linear_solver_used >= 0 && s->linear_solver_used <= 2) ? s->linear_solver_used : 1]);
+                             "SPARSE_NORMAL_CHOLESKY served by PCG to 1e-13 (factor schedule impractical)",
+                             "SPARSE_NORMAL_CHOLESKY (GPU block Cholesky or PCG to 1e-13, chosen per iteration)"};
+  add("Linear solver    %s\n", ls[(s->linear_solver_used >= 0 && s->linear_solver_used <= 3) ? s->linear_solver_used : 1]);
   if (s->factor_nnz_blocks > 0) add("Factor blocks / levels  %12d / %d\n", s->factor_nnz_blocks, s->factor_levels);
   add("Compute device              HIP gfx950 (FP64)\n\n");
   add("Cost:\n");

@@ -367,6 +367,28 @@ def test_exact_request_served_by_pcg_converges(gpu, O, ds, monkeypatch):
     assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-7)
 
 
+@pytest.mark.parametrize("budget", [None, "100000", "40"])
+def test_exact_request_with_per_iteration_choice(gpu, O, ds, monkeypatch, budget):
+    """Factorisation admitted but above the always-direct budget (forced here): every LM iteration is served either by
+    the factorisation or by PCG to 1e-13, an over-budget PCG try is redone with the factorisation.  Whatever the mix
+    (default budget: mostly factorisations; huge: PCG after the first; tiny: every try over budget), the LM trace is
+    the oracle's exact-solve trace."""
+    monkeypatch.setenv("PGO_DIRECT_MAX_STEPS", "10")
+    if budget:
+        monkeypatch.setenv("PGO_HYBRID_BUDGET", budget)
+    g = ds.manhattan_se3(2000, 8000, seed=3)
+    prob, poses, og = _pair(gpu, O, g)
+    s = gpu.solve(gpu.SolverOptions(max_num_iterations=8, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY), prob)
+    _, osum, otr = O.solve(og, O.default_options(max_num_iterations=8, linear_solver=0))
+    assert s.linear_solver_used == 3 and s.factor_nnz_blocks > 2000
+    if budget == "100000":
+        assert s.num_linear_solver_iterations > 0            # PCG did serve iterations
+    n = min(len(otr), len(s.iterations))
+    assert n == len(otr) == len(s.iterations)
+    assert list(s.iterations["step_is_successful"][:n]) == [int(x) for x in otr[:n, 8]]
+    assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-7)
+
+
 def test_evaluate_special_configurations(gpu, O, ds):
     """Hand-picked edge states: zero residual, identical poses, antipodal quaternion representatives, half-turn relative
     rotation, non-unit quaternions, large translations; plus Plus() with a zero rotation step (the sin(x)/x branch)."""

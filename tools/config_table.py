@@ -28,7 +28,7 @@ def run(name, g, opt, repeat=2):
     dt, s = best
     its = max(1, s.num_iterations)
     print("| %s | %d / %d | %s | %d | %d | %.6e -> %.6e | %.1f ms (%.1f ms setup) | %.3f ms |" % (
-        name, g.N, g.E, {0: "direct", 1: "PCG", 2: "PCG to 1e-13"}[s.linear_solver_used], s.num_iterations,
+        name, g.N, g.E, {0: "direct", 1: "PCG", 2: "PCG to 1e-13", 3: "direct or PCG to 1e-13 per iteration"}[s.linear_solver_used], s.num_iterations,
         s.num_linear_solver_iterations, s.initial_cost, s.final_cost, 1e3 * dt, 1e3 * s.setup_time_in_seconds,
         1e3 * (s.total_time_in_seconds) / its), flush=True)
 
