@@ -258,6 +258,50 @@ __global__ __launch_bounds__(64) void k_chol_assemble(DeviceGraph g, DirectPlan 
   forward_finish(p, j, bj, 1, sh, Ljj);
 }
 
+// The same with four waves per block (long update lists: dense separators): forty 6-lane groups share the list, the forward
+// step of a diagonal block's column is shared by the four waves too.
+constexpr int ASM_WAVES = 4;
+__global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_assemble4(DeviceGraph g, DirectPlan p, int blk_begin) {
+  __shared__ double sh[ASM_WAVES][360];
+  __shared__ double shf[ASM_WAVES][64];
+  __shared__ double Ld[36];
+  const int bi = p.split_blk[blk_begin + blockIdx.x];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = lane / 6, r = lane - 6 * grp;
+  if (grp < 10) {
+    double v[6];
+    assemble_row(g, p, bi, r, wave * 10 + grp, 10 * ASM_WAVES, v, p.upd_split[bi]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) sh[wave][(grp * 6 + r) * 6 + c] = v[c];
+  }
+  __syncthreads();
+  const bool diagonal = p.split_diag[blk_begin + blockIdx.x] != 0;
+  if (wave == 0 && lane < 36) {        // fixed order: wave by wave, group by group
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < ASM_WAVES; ++w)
+#pragma unroll
+      for (int gq = 0; gq < 10; ++gq) s += sh[w][gq * 36 + lane];
+    if (!diagonal) p.Lval[36 * (size_t)bi + lane] = s;
+    else Ld[lane] = s;
+  }
+  if (!diagonal) return;
+  const int j = p.blk_row[bi];
+  double bj = 0.0;
+  if (wave == 0) bj = forward_rhs(g, p.perm[j]);
+  forward_partial(p, j, wave, ASM_WAVES, shf[wave]);
+  __syncthreads();
+  if (wave == 0) {
+    double Ljj[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) Ljj[k] = Ld[k];
+    const bool ok = chol6_inplace(Ljj);
+    if (!ok && lane == 0) atomicOr(&g.flags[2], 1);
+    if (lane < 36) p.Lval[36 * (size_t)bi + lane] = Ljj[lane];
+    forward_finish(p, j, bj, ASM_WAVES, shf[0], Ljj);
+  }
+}
+
 // phase 2, one 6-lane group per sub-diagonal block of the level (ten per wave, lane = row): L_ij = V_ij L_jj^-T
 __global__ __launch_bounds__(64) void k_chol_scale(DeviceGraph g, DirectPlan p, int sub_begin, int sub_end) {
   const int lane = threadIdx.x;
@@ -693,6 +737,8 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_bwd_tail(DeviceGraph g, Di
 }  // namespace
 
 void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const DirectSymbolic& sym, hipStream_t s) {
+  // block assembly with four waves per block (default; PGO_DIRECT_ASM4=0: one wave) — KITTI-00 dense 10.7 -> ~8 us per launch
+  static const bool asm4 = !(getenv("PGO_DIRECT_ASM4") && getenv("PGO_DIRECT_ASM4")[0] == '0');
   for (const DirectStep& st : sym.steps) {
     if (st.type == DirectStep::COLUMN) {
       const int nc = sym.level_ptr[st.level_begin + 1] - sym.level_ptr[st.level_begin];
@@ -704,10 +750,12 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
     } else if (st.type == DirectStep::FUSED) {
       hipLaunchKernelGGL(k_chol_tail, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, st.level_begin, st.level_end);
     } else if (st.type == DirectStep::PANEL) {
-      hipLaunchKernelGGL(k_chol_assemble, dim3(st.blk_end - st.blk_begin), dim3(64), 0, s, g, p, st.blk_begin);
+      if (asm4) hipLaunchKernelGGL(k_chol_assemble4, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin);
+      else hipLaunchKernelGGL(k_chol_assemble, dim3(st.blk_end - st.blk_begin), dim3(64), 0, s, g, p, st.blk_begin);
       hipLaunchKernelGGL(k_chol_panel, dim3(st.sub_end), dim3(64 * FUSED_WAVES), 0, s, g, p, st.sub_begin, st.level_end - st.level_begin);
     } else {
-      hipLaunchKernelGGL(k_chol_assemble, dim3(st.blk_end - st.blk_begin), dim3(64), 0, s, g, p, st.blk_begin);
+      if (asm4) hipLaunchKernelGGL(k_chol_assemble4, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin);
+      else hipLaunchKernelGGL(k_chol_assemble, dim3(st.blk_end - st.blk_begin), dim3(64), 0, s, g, p, st.blk_begin);
       const int nsub = st.sub_end - st.sub_begin;
       if (nsub > 0) hipLaunchKernelGGL(k_chol_scale, dim3((nsub + 9) / 10), dim3(64), 0, s, g, p, st.sub_begin, st.sub_end);
     }
