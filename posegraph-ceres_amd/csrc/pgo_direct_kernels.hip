@@ -634,6 +634,58 @@ __global__ __launch_bounds__(64) void k_bwd_level(DeviceGraph g, DirectPlan p, i
   __syncthreads();
   if (threadIdx.x == 0) backward_finish(g, p, j, 1, sh);
 }
+// The same with four waves per column (forty 6-lane groups on the column's blocks) and the six-lane finish of the tail,
+// its inputs (y_j, L_jj, the permutation) fetched beside the partial sums.
+constexpr int BWD_WAVES = 4;
+__global__ __launch_bounds__(64 * BWD_WAVES) void k_bwd_level4(DeviceGraph g, DirectPlan p, int level) {
+  __shared__ double sh[BWD_WAVES][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
+  backward_partial(p, j, wave, BWD_WAVES, sh[wave]);
+  double yj = 0.0, Ld[21];
+  int old = 0;
+  if (wave == 0) {
+    old = p.perm[j];
+    yj = p.y[6 * (size_t)j + (lane < 6 ? lane : 0)];
+    const double* L = p.Lval + 36 * (size_t)p.col_ptr[j];
+#pragma unroll
+    for (int i = 0, q = 0; i < 6; ++i)
+#pragma unroll
+      for (int k = i; k < 6; ++k) Ld[q++] = L[6 * k + i];     // row i of L^T from the diagonal on
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  const int i = lane < 6 ? lane : 0;
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < BWD_WAVES; ++w) {
+    double t[10];
+#pragma unroll
+    for (int gq = 0; gq < 10; ++gq) t[gq] = sh[w][6 * gq + i];
+#pragma unroll
+    for (int gq = 0; gq < 10; ++gq) s += t[gq];
+  }
+  const double my_rhs = yj - s;
+  double rhs[6], x[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) rhs[k] = __shfl(my_rhs, k);
+  int q = 21;
+#pragma unroll
+  for (int r = 5; r >= 0; --r) {
+    q -= 6 - r;                                  // Ld[q] = L[7r], Ld[q + (k - r)] = L[6k + r]
+    double t = rhs[r];
+#pragma unroll
+    for (int k = r + 1; k < 6; ++k) t -= Ld[q + (k - r)] * x[k];
+    x[r] = t / Ld[q];
+  }
+  double out = x[0];
+#pragma unroll
+  for (int k = 1; k < 6; ++k) out = lane == k ? x[k] : out;
+  if (lane < 6) {
+    p.y[6 * (size_t)j + lane] = out;
+    g.cg_x[6 * (size_t)old + lane] = out;
+  }
+}
 // Fused tail of the backward solve (levels with <= FUSED_WAVES columns): the FUSED_WAVES waves of the single workgroup are
 // divided among the columns of the level, so the long lists of a dense separator chain (one column per level) are walked 80-wide.
 // The rows of a tail column are its ancestors, i.e. tail columns too: with XLDS the x of the whole tail stays in LDS
@@ -764,6 +816,8 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
 
 // backward solve only: the forward substitution runs inside the factorisation kernels
 void launch_direct_solve(const DeviceGraph& g, const DirectPlan& p, const int* level_ptr_host, int fused_from_level, hipStream_t s) {
+  // four waves per column in the backward levels (default; PGO_DIRECT_BWD4=0: one wave, serial finish)
+  static const bool bwd4 = !(getenv("PGO_DIRECT_BWD4") && getenv("PGO_DIRECT_BWD4")[0] == '0');
   if (fused_from_level < p.n_levels) {
     if (p.n - level_ptr_host[fused_from_level] <= BWD_TAIL_LDS_COLS)
       hipLaunchKernelGGL(k_bwd_tail<true>, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, fused_from_level);
@@ -772,7 +826,8 @@ void launch_direct_solve(const DeviceGraph& g, const DirectPlan& p, const int* l
   }
   for (int l = fused_from_level - 1; l >= 0; --l) {
     const int nc = level_ptr_host[l + 1] - level_ptr_host[l];
-    hipLaunchKernelGGL(k_bwd_level, dim3(nc), dim3(64), 0, s, g, p, l);
+    if (bwd4) hipLaunchKernelGGL(k_bwd_level4, dim3(nc), dim3(64 * BWD_WAVES), 0, s, g, p, l);
+    else hipLaunchKernelGGL(k_bwd_level, dim3(nc), dim3(64), 0, s, g, p, l);
   }
 }
 
