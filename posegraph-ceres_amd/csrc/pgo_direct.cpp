@@ -369,7 +369,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
     split_cost[l] = worst_blk + 2.0 + 4.0;   // assemble critical path + one scaling step + one more launch
   }
   S.steps.clear();
-  S.split_blk.clear(); S.split_diag.clear(); S.split_sub.clear(); S.split_sub_diag.clear(); S.panel_cols.clear();
+  S.split_blk.clear(); S.split_diag.clear(); S.split_sub.clear(); S.split_sub_diag.clear(); S.panel_cols.clear(); S.split_dblk.clear();
   S.upd_split.assign(S.nb, 0);
   for (int t = 0; t < S.nb; ++t) S.upd_split[t] = S.upd_ptr[t + 1];
   std::vector<int> blk_col(S.nb);                 // column of every block of L (source column of an update pair)
@@ -427,6 +427,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
             for (int bi = S.col_ptr[j]; bi < S.col_ptr[j + 1]; ++bi) {
               S.split_blk.push_back(bi);
               S.split_diag.push_back(0);
+              S.split_dblk.push_back(S.col_ptr[j]);
               // in-panel pairs = those whose source column is one of this chain's earlier panel columns; they are moved
               // (stably) behind the pairs of the columns before the panel, whose L blocks are final when phase 1 runs
               int q = S.upd_ptr[bi + 1];
@@ -464,6 +465,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
         for (int bi = S.col_ptr[j]; bi < S.col_ptr[j + 1]; ++bi) {
           S.split_blk.push_back(bi);
           S.split_diag.push_back(bi == S.col_ptr[j] ? 1 : 0);
+          S.split_dblk.push_back(S.col_ptr[j]);
           if (bi != S.col_ptr[j]) { S.split_sub.push_back(bi); S.split_sub_diag.push_back(S.col_ptr[j]); }
         }
       }

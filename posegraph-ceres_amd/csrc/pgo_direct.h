@@ -38,6 +38,8 @@ struct DirectPlan {
   const int* upd_split;       // [nb] PANEL steps: update pairs [upd_ptr, upd_split) come from columns before the panel
   const int* panel_cols;      // PANEL steps: chains of columns, chain c of a step at [begin + c*width, begin + (c+1)*width)
   const int* blk_lpos;        // [nb] position in level_cols of the block's ROW (backward tail: x of the tail lives in LDS)
+  const int* split_dblk;      // per split_blk entry: the diagonal block of the block's column (fused SPLIT steps wait on it)
+  int* col_flag;              // [nb] indexed by diagonal block: epoch of the factorisation that last published L_jj
   double* Lval;           // [nb][36] row-major blocks of the factor
   double* y;              // [6n] permuted work vector
 };
@@ -66,7 +68,7 @@ struct DirectSymbolic {
   long long n_pairs = 0;
   int fused_from_level = 0;  // first level of the suffix whose levels hold <= 8 columns (forward/backward solves fuse it)
   std::vector<DirectStep> steps;   // factorisation schedule
-  std::vector<int> split_blk, split_sub, split_sub_diag, upd_split, panel_cols, blk_lpos;
+  std::vector<int> split_blk, split_sub, split_sub_diag, upd_split, panel_cols, blk_lpos, split_dblk;
   std::vector<uint8_t> split_diag;
   double flops = 0;
   double est_steps = 0;      // critical-path length of the schedule in update-pair steps (cost model)
@@ -82,7 +84,9 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
                     DirectSymbolic* out);
 
 // Device launches.  flags[2] is set when a pivot is not positive.
-void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const DirectSymbolic& sym, hipStream_t s);
+// epoch > 0 (a new value per factorisation): SPLIT steps run as ONE launch, sub-diagonal blocks waiting in-kernel for their
+// column's L_jj; 0 (stream capture: the argument would be frozen): assemble + scale launches.
+void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const DirectSymbolic& sym, hipStream_t s, int epoch = 0);
 void launch_direct_solve(const DeviceGraph& g, const DirectPlan& p, const int* level_ptr_host, int fused_from_level, hipStream_t s);
 
 }  // namespace pgo

@@ -302,6 +302,84 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_assemble4(DeviceGraph g
   }
 }
 
+// SPLIT step as ONE launch: as k_chol_assemble4, but a sub-diagonal block does not leave V behind for a scaling launch —
+// its workgroup waits (flag = this factorisation's epoch, polled by one lane, bounded) until the column's diagonal block
+// has been published by ITS workgroup, then applies L_jj^-T itself.  The launcher uses this only while every workgroup of
+// the step is resident at once (<= SPLIT_FUSED_MAX blocks), so a waiting workgroup cannot keep its producer off the chip;
+// a wait that runs out sets the failure flag instead of hanging.
+constexpr int SPLIT_FUSED_MAX = 1024;
+__global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_split(DeviceGraph g, DirectPlan p, int blk_begin, int epoch) {
+  __shared__ double sh[ASM_WAVES][360];
+  __shared__ double shf[ASM_WAVES][64];
+  __shared__ double Ld[36];
+  const int bi = p.split_blk[blk_begin + blockIdx.x];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = lane / 6, r = lane - 6 * grp;
+  if (grp < 10) {
+    double v[6];
+    assemble_row(g, p, bi, r, wave * 10 + grp, 10 * ASM_WAVES, v, p.upd_split[bi]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) sh[wave][(grp * 6 + r) * 6 + c] = v[c];
+  }
+  __syncthreads();
+  const bool diagonal = p.split_diag[blk_begin + blockIdx.x] != 0;
+  if (wave == 0) {
+    if (lane < 36) {        // fixed order: wave by wave, group by group
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < ASM_WAVES; ++w)
+#pragma unroll
+        for (int gq = 0; gq < 10; ++gq) s += sh[w][gq * 36 + lane];
+      Ld[lane] = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!diagonal) {
+    if (wave != 0) return;
+    const int dblk = p.split_dblk[blk_begin + blockIdx.x];
+    if (lane == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(&p.col_flag[dblk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        if (++spins > (1 << 22)) { atomicOr(&g.flags[2], 2); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 6) {
+      const double* L = p.Lval + 36 * (size_t)dblk;     // lower triangular L_jj, published before the flag
+      double x[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double s = Ld[6 * lane + c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) s -= x[k] * L[6 * c + k];
+        x[c] = s / L[7 * c];
+      }
+      double2* o = reinterpret_cast<double2*>(p.Lval + 36 * (size_t)bi + 6 * lane);
+      o[0] = double2{x[0], x[1]}; o[1] = double2{x[2], x[3]}; o[2] = double2{x[4], x[5]};
+    }
+    return;
+  }
+  const int j = p.blk_row[bi];
+  double bj = 0.0;
+  double Ljj[36];
+  if (wave == 0) {          // publish L_jj first: the column's other workgroups are waiting for it
+#pragma unroll
+    for (int k = 0; k < 36; ++k) Ljj[k] = Ld[k];
+    const bool ok = chol6_inplace(Ljj);
+    if (!ok && lane == 0) atomicOr(&g.flags[2], 1);
+    if (lane < 36) p.Lval[36 * (size_t)bi + lane] = Ljj[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_store(&p.col_flag[bi], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bj = forward_rhs(g, p.perm[j]);
+  }
+  forward_partial(p, j, wave, ASM_WAVES, shf[wave]);
+  __syncthreads();
+  if (wave == 0) forward_finish(p, j, bj, ASM_WAVES, shf[0], Ljj);
+}
+
 // phase 2, one 6-lane group per sub-diagonal block of the level (ten per wave, lane = row): L_ij = V_ij L_jj^-T
 __global__ __launch_bounds__(64) void k_chol_scale(DeviceGraph g, DirectPlan p, int sub_begin, int sub_end) {
   const int lane = threadIdx.x;
@@ -788,7 +866,8 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_bwd_tail(DeviceGraph g, Di
 
 }  // namespace
 
-void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const DirectSymbolic& sym, hipStream_t s) {
+void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const DirectSymbolic& sym, hipStream_t s, int epoch) {
+  static const bool fuse_split = getenv("PGO_DIRECT_FUSE_SPLIT") != nullptr;
   // block assembly with four waves per block (default; PGO_DIRECT_ASM4=0: one wave) — KITTI-00 dense 10.7 -> ~8 us per launch
   static const bool asm4 = !(getenv("PGO_DIRECT_ASM4") && getenv("PGO_DIRECT_ASM4")[0] == '0');
   for (const DirectStep& st : sym.steps) {
@@ -805,6 +884,8 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
       if (asm4) hipLaunchKernelGGL(k_chol_assemble4, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin);
       else hipLaunchKernelGGL(k_chol_assemble, dim3(st.blk_end - st.blk_begin), dim3(64), 0, s, g, p, st.blk_begin);
       hipLaunchKernelGGL(k_chol_panel, dim3(st.sub_end), dim3(64 * FUSED_WAVES), 0, s, g, p, st.sub_begin, st.level_end - st.level_begin);
+    } else if (fuse_split && epoch > 0 && st.blk_end - st.blk_begin <= SPLIT_FUSED_MAX) {
+      hipLaunchKernelGGL(k_chol_split, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin, epoch);
     } else {
       if (asm4) hipLaunchKernelGGL(k_chol_assemble4, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin);
       else hipLaunchKernelGGL(k_chol_assemble, dim3(st.blk_end - st.blk_begin), dim3(64), 0, s, g, p, st.blk_begin);

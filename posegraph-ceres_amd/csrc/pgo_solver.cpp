@@ -191,7 +191,8 @@ struct pgo_problem {
   pgo::DirectSymbolic dsym;
   pgo::DirectPlan dplan{};
   bool direct_analyzed = false, direct_usable = false;
-  DevBuf<int> dd_split_blk, dd_split_sub, dd_split_sub_diag, dd_upd_split, dd_panel_cols, dd_blk_lpos;
+  DevBuf<int> dd_split_blk, dd_split_sub, dd_split_sub_diag, dd_upd_split, dd_panel_cols, dd_blk_lpos, dd_split_dblk, dd_col_flag;
+  int direct_epoch = 0;
   DevBuf<uint8_t> dd_split_diag;
   DevBuf<int> dd_perm, dd_col_ptr, dd_blk_row, dd_asrc_ptr, dd_asrc_slot, dd_upd_ptr, dd_upd_a, dd_upd_b, dd_level_ptr,
       dd_level_cols, dd_rowl_ptr, dd_rowl_blk, dd_rowl_col;
@@ -808,7 +809,11 @@ int prepare_direct(pgo_problem* P) {
   HIP_TRY(P->dd_panel_cols.upload(S.panel_cols, s));
   HIP_TRY(P->dd_blk_lpos.upload(S.blk_lpos, s));
   if (S.panel_cols.empty()) HIP_TRY(P->dd_panel_cols.alloc(1));
-  if (S.split_blk.empty()) { HIP_TRY(P->dd_split_blk.alloc(1)); HIP_TRY(P->dd_split_diag.alloc(1)); }
+  HIP_TRY(P->dd_split_dblk.upload(S.split_dblk, s));
+  if (S.split_blk.empty()) { HIP_TRY(P->dd_split_blk.alloc(1)); HIP_TRY(P->dd_split_diag.alloc(1)); HIP_TRY(P->dd_split_dblk.alloc(1)); }
+  HIP_TRY(P->dd_col_flag.alloc((size_t)S.nb));
+  HIP_TRY(P->dd_col_flag.zero(s));
+  P->direct_epoch = 0;
   if (S.split_sub.empty()) { HIP_TRY(P->dd_split_sub.alloc(1)); HIP_TRY(P->dd_split_sub_diag.alloc(1)); }
   HIP_TRY(P->dd_Lval.alloc((size_t)36 * S.nb));
   HIP_TRY(P->dd_y.alloc((size_t)6 * S.n));
@@ -821,6 +826,7 @@ int prepare_direct(pgo_problem* P) {
   d.Lval = P->dd_Lval.p; d.y = P->dd_y.p; d.split_blk = P->dd_split_blk.p;
   d.split_diag = P->dd_split_diag.p; d.split_sub = P->dd_split_sub.p; d.split_sub_diag = P->dd_split_sub_diag.p;
   d.upd_split = P->dd_upd_split.p; d.panel_cols = P->dd_panel_cols.p; d.blk_lpos = P->dd_blk_lpos.p;
+  d.split_dblk = P->dd_split_dblk.p; d.col_flag = P->dd_col_flag.p;
   P->drop_direct_graph();
   P->direct_usable = true;
   return PGO_OK;
@@ -843,7 +849,8 @@ int run_direct(pgo_problem* P) {
   if (P->direct_exec) {
     HIP_TRY(hipGraphLaunch(P->direct_exec, s));
   } else {
-    pgo::launch_direct_factor(P->g, P->dplan, S, s);
+    if (++P->direct_epoch == 0x7fffffff) { P->direct_epoch = 1; HIP_TRY(P->dd_col_flag.zero(s)); }
+    pgo::launch_direct_factor(P->g, P->dplan, S, s, P->direct_epoch);
     pgo::launch_direct_solve(P->g, P->dplan, S.level_ptr.data(), S.fused_from_level, s);
   }
   return PGO_OK;
