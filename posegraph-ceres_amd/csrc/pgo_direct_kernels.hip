@@ -8,6 +8,15 @@
 // launch is re-read from global memory inside the same wave, and a column only reads columns of lower levels.
 // At these sizes (10^4..10^5 blocks) the schedule is launch-latency bound, so the elimination-tree levels
 // that hold at most 8 columns are folded into ONE single-workgroup launch (barrier between levels).
+// What bounds a column is a chain of dependent round trips (index -> index -> value) and FP64 sqrt/div latency, not
+// bandwidth; the kernels below therefore run the independent chains of a column on different waves of one workgroup:
+//   k_chol_level3     COLUMN levels: diagonal block | first ten off-diagonal blocks | forward partial sums
+//   k_chol_assemble4  SPLIT/PANEL assembly: four waves share a block's update list
+//   k_chol_panel      PANEL chains: wave 0 factorises L_jj while waves 1..7 walk the forward row list and the sub-diagonal blocks
+//   k_bwd_level4      backward levels: four waves share a column's blocks, six-lane finish
+//   k_bwd_tail        backward tail: x of the tail and its column descriptors in LDS
+// (k_chol_level, k_chol_assemble, k_bwd_level are the one-wave forms, kept behind PGO_DIRECT_ROLES/ASM4/BWD4=0;
+//  k_chol_split is the opt-in single-launch SPLIT step, PGO_DIRECT_FUSE_SPLIT=1.)
 #include "pgo_direct.h"
 
 #include <cstdlib>
