@@ -56,3 +56,34 @@ def test_c5_sphere_layers(gpu, ds, O):
     n = min(len(s.iterations), len(otr))
     assert list(s.iterations["linear_solver_iterations"][:n]) == [int(v) for v in otr[:n, 7]]
     assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-7)
+
+
+def test_c2_exact_request_is_served_either_way_with_the_same_answer(gpu, ds, monkeypatch):
+    """C2 (10 k poses / 40 k edges) with the reference's linear solver setting: the factorisation is admitted but costly,
+    so each LM iteration is served by it or by PCG to 1e-13 (linear_solver_used = 3).  Size-independent properties: the
+    LM trace equals the one obtained with the factorisation switched off (PCG to 1e-13 alone) and the one with the
+    factorisation alone, and a repeated run is bit-identical."""
+    g = ds.manhattan_se3(10000, 40000)
+    opt = lambda: gpu.SolverOptions(max_num_iterations=10, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
+
+    def run():
+        prob, poses = gpu.problem_from_graph(g)
+        return gpu.solve(opt(), prob), poses
+
+    s, x = run()
+    assert s.linear_solver_used == 3 and s.factor_nnz_blocks > 100000
+    s2, x2 = run()
+    assert s2.final_cost == s.final_cost and np.array_equal(x, x2)
+    monkeypatch.setenv("PGO_DIRECT_MAX_STEPS", "1000000")          # factorisation for every iteration
+    sd, xd = run()
+    assert sd.linear_solver_used == 0
+    monkeypatch.delenv("PGO_DIRECT_MAX_STEPS")
+    monkeypatch.setenv("PGO_NO_DIRECT", "1")                       # PCG to 1e-13 for every iteration
+    sp, xp = run()
+    assert sp.linear_solver_used == 2
+    for other in (sd, sp):
+        n = len(s.iterations)
+        assert len(other.iterations) == n
+        assert list(other.iterations["step_is_successful"]) == list(s.iterations["step_is_successful"])
+        assert np.allclose(other.iterations["cost"], s.iterations["cost"], rtol=1e-7)
+    assert np.abs(xd - x).max() < 1e-5 and np.abs(xp - x).max() < 1e-5
