@@ -822,7 +822,14 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_bwd_tail(DeviceGraph g, Di
         for (int k = 0; k < 6; ++k) acc += bk[k] * xi[k];
       }
     }
-    if (grp < 10) sh[wave][lane] = acc;
+    {   // the wave's ten group sums per component, folded in registers (fixed order); six values per wave go to LDS
+      const double mine = grp < 10 ? acc : 0.0;
+      const int comp = lane < 6 ? lane : 0;
+      double fold = 0.0;
+#pragma unroll
+      for (int gq = 0; gq < 10; ++gq) fold += __shfl(mine, 6 * gq + comp);
+      if (lane < 6) sh[wave][lane] = fold;
+    }
     // the finisher's inputs do not depend on this level: fetched beside the partial sums, ahead of the barrier
     double yj = 0.0, Ld[21];
     int old = 0;
@@ -839,12 +846,12 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_bwd_tail(DeviceGraph g, Di
     if (finisher) {
       const int i = lane < 6 ? lane : 0;
       double s = 0.0;
-      for (int w = 0; w < nsub; ++w) {               // ten reads in flight, then the adds in the fixed order
-        double t[10];
+      {                                              // the column's waves, in order (nsub <= FUSED_WAVES)
+        double t[FUSED_WAVES];
 #pragma unroll
-        for (int gq = 0; gq < 10; ++gq) t[gq] = sh[wave + w][6 * gq + i];
+        for (int w = 0; w < FUSED_WAVES; ++w) t[w] = w < nsub ? sh[wave + w][i] : 0.0;
 #pragma unroll
-        for (int gq = 0; gq < 10; ++gq) s += t[gq];
+        for (int w = 0; w < FUSED_WAVES; ++w) s += t[w];
       }
       const double my_rhs = yj - s;
       double rhs[6], x[6];

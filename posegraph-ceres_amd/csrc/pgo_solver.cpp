@@ -68,7 +68,7 @@ inline hipError_t staged_copy(void* dst, const void* src, size_t bytes, bool to_
   }
   std::lock_guard<std::mutex> lock(mu);
   if (!stage) {
-    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&stage), cap, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&stage), cap, hipHostMallocPortable);   // one buffer for every device the process uses; kept for the process lifetime
     if (e != hipSuccess) { stage = nullptr; return e; }
   }
   for (size_t off = 0; off < bytes; off += cap) {
