@@ -922,7 +922,6 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
     if ((!P->direct_usable || P->dsym.hybrid) && cluster < 2) cluster = 2;
   }
   static const bool verbose = getenv("PGO_VERBOSE") != nullptr;
-  if (verbose) { std::fprintf(stderr, "[pgo] lm_begin: before clusters            %.2f ms\n", 1e3 * seconds_since(t0)); HIP_TRY(hipStreamSynchronize(P->stream)); std::fprintf(stderr, "[pgo] lm_begin: idle check                  %.2f ms\n", 1e3 * seconds_since(t0)); }
   rc = prepare_clusters(P, cluster);
   if (rc) return rc;
   if (verbose) std::fprintf(stderr, "[pgo] lm_begin: clusters prepared          %.2f ms\n", 1e3 * seconds_since(t0));
