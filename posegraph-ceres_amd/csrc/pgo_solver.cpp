@@ -146,6 +146,7 @@ struct LmState {
   bool hybrid_pcg = false;        // PCG served the last iteration within its budget
   int hybrid_direct_run = 0;      // consecutive iterations served by the factorisation
   int hybrid_probe_after = 1;     // ... after which PCG is tried again (doubles on every failed try, up to 16)
+  double hybrid_fail_radius = 0;  // trust-region radius of the last over-budget try: a 10x smaller radius (10x the damping) earns an early try
   int hybrid_direct = 0, hybrid_pcg_ok = 0, hybrid_pcg_over = 0;   // statistics (PGO_VERBOSE)
   std::string message;
 };
@@ -1023,7 +1024,9 @@ int lm_advance(pgo_problem* P) {
   const int cg_budget = !hybrid ? 0 : budget_env ? std::max(1, atoi(budget_env))
                                 : std::max(50, (int)(1.5 * 0.7 * P->dsym.est_steps / (10.0 + 4.2e-5 * (double)P->g.n_slots)));
   bool use_direct = direct;
-  if (hybrid && (L.hybrid_pcg || L.hybrid_direct_run >= L.hybrid_probe_after)) use_direct = false;
+  if (hybrid && (L.hybrid_pcg || L.hybrid_direct_run >= L.hybrid_probe_after ||
+                 (L.hybrid_direct_run >= 1 && L.hybrid_fail_radius > 0.0 && L.radius < 0.1 * L.hybrid_fail_radius)))
+    use_direct = false;
   int wasted_cg = 0;
   arm_handoff(P);
   if (!use_direct) {
@@ -1048,6 +1051,7 @@ int lm_advance(pgo_problem* P) {
         L.hybrid_probe_after = L.hybrid_pcg ? 2 : std::min(16, 2 * L.hybrid_probe_after);
         L.hybrid_pcg = false;
         L.hybrid_direct_run = 0;
+        L.hybrid_fail_radius = L.radius;
         ++L.hybrid_pcg_over;
         use_direct = true;
         arm_handoff(P);
