@@ -16,7 +16,7 @@
 //   k_bwd_level4      backward levels: four waves share a column's blocks, six-lane finish
 //   k_bwd_tail        backward tail: x of the tail and its column descriptors in LDS
 // (k_chol_level, k_chol_assemble, k_bwd_level are the one-wave forms, kept behind PGO_DIRECT_ROLES/ASM4/BWD4=0;
-//  k_chol_split is the opt-in single-launch SPLIT step, PGO_DIRECT_FUSE_SPLIT=1.)
+//  k_chol_split is the single-launch SPLIT step, used while the step has at most one workgroup per CU.)
 #include "pgo_direct.h"
 
 #include <cstdlib>
@@ -883,7 +883,10 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_bwd_tail(DeviceGraph g, Di
 }  // namespace
 
 void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const DirectSymbolic& sym, hipStream_t s, int epoch) {
-  static const bool fuse_split = getenv("PGO_DIRECT_FUSE_SPLIT") != nullptr;
+  // single-launch SPLIT steps: by default only while the step has at most one workgroup per CU (every workgroup resident
+  // from the start; chain-like graphs: KITTI-00 replay -56 us per LM iteration); PGO_DIRECT_FUSE_SPLIT=1 raises the limit
+  // to SPLIT_FUSED_MAX (no gain measured on dense separators: the wait costs what the launch did), =0 switches it off
+  static const int fuse_split_max = !getenv("PGO_DIRECT_FUSE_SPLIT") ? 256 : getenv("PGO_DIRECT_FUSE_SPLIT")[0] == '0' ? 0 : SPLIT_FUSED_MAX;
   // block assembly with four waves per block (default; PGO_DIRECT_ASM4=0: one wave) — KITTI-00 dense 10.7 -> ~8 us per launch
   static const bool asm4 = !(getenv("PGO_DIRECT_ASM4") && getenv("PGO_DIRECT_ASM4")[0] == '0');
   for (const DirectStep& st : sym.steps) {
@@ -900,7 +903,7 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
       if (asm4) hipLaunchKernelGGL(k_chol_assemble4, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin);
       else hipLaunchKernelGGL(k_chol_assemble, dim3(st.blk_end - st.blk_begin), dim3(64), 0, s, g, p, st.blk_begin);
       hipLaunchKernelGGL(k_chol_panel, dim3(st.sub_end), dim3(64 * FUSED_WAVES), 0, s, g, p, st.sub_begin, st.level_end - st.level_begin);
-    } else if (fuse_split && epoch > 0 && st.blk_end - st.blk_begin <= SPLIT_FUSED_MAX) {
+    } else if (epoch > 0 && st.blk_end - st.blk_begin <= fuse_split_max) {
       hipLaunchKernelGGL(k_chol_split, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin, epoch);
     } else {
       if (asm4) hipLaunchKernelGGL(k_chol_assemble4, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin);
