@@ -98,7 +98,7 @@ typedef struct pgo_solver_summary {
                                    requested, factorisation or PCG to exact_r_tolerance chosen per LM iteration */
   int factor_nnz_blocks;        /* 6x6 blocks of the Cholesky factor (0 when not used) */
   int factor_levels;            /* elimination-tree levels = dependent launches per factorisation */
-  int reserved1;
+  int num_factorizations;       /* LM iterations served by the GPU factorisation (the others of an exact request: PCG) */
   double initial_cost;
   double final_cost;
   double total_time_in_seconds;

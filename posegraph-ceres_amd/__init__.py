@@ -70,7 +70,7 @@ class _CSummary(C.Structure):
         ("termination_type", C.c_int), ("num_successful_steps", C.c_int), ("num_unsuccessful_steps", C.c_int),
         ("num_iterations", C.c_int), ("num_linear_solver_iterations", C.c_int), ("num_poses", C.c_int),
         ("num_edges", C.c_int), ("reason", C.c_int), ("linear_solver_used", C.c_int), ("factor_nnz_blocks", C.c_int),
-        ("factor_levels", C.c_int), ("reserved1", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+        ("factor_levels", C.c_int), ("num_factorizations", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
         ("total_time_in_seconds", C.c_double), ("setup_time_in_seconds", C.c_double),
         ("linear_solver_time_in_seconds", C.c_double), ("jacobian_evaluation_time_in_seconds", C.c_double),
         ("residual_evaluation_time_in_seconds", C.c_double), ("final_gradient_max_norm", C.c_double),

@@ -148,6 +148,7 @@ struct LmState {
   int hybrid_probe_after = 1;     // ... after which PCG is tried again (doubles on every failed try, up to 16)
   double hybrid_fail_radius = 0;  // trust-region radius of the last over-budget try: a 10x smaller radius (10x the damping) earns an early try
   int hybrid_direct = 0, hybrid_pcg_ok = 0, hybrid_pcg_over = 0;   // statistics (PGO_VERBOSE)
+  int n_factorizations = 0;       // LM iterations served by the GPU factorisation
   std::string message;
 };
 
@@ -1071,6 +1072,7 @@ int lm_advance(pgo_problem* P) {
     if (rc) return rc;
     rc = wait_handoff(P);
     if (rc) return rc;
+    ++L.n_factorizations;
     if (hybrid) { ++L.hybrid_direct_run; ++L.hybrid_direct; }
   }
   HIP_TRY(hipGetLastError());
@@ -1205,6 +1207,7 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
     summary->linear_solver_used = want_exact ? (P->direct_usable ? (P->dsym.hybrid ? 3 : 0) : 2) : 1;
     summary->factor_nnz_blocks = (want_exact && P->direct_usable) ? P->dsym.nb : 0;
     summary->factor_levels = (want_exact && P->direct_usable) ? P->dsym.n_levels : 0;
+    summary->num_factorizations = L.n_factorizations;
     summary->initial_cost = L.initial_cost;
     summary->final_cost = L.x_cost;
     summary->total_time_in_seconds = L.t_total;
@@ -1472,6 +1475,7 @@ size_t pgo_summary_full_report(const pgo_solver_summary* s, const pgo_iteration_
                              "SPARSE_NORMAL_CHOLESKY (GPU block Cholesky or PCG to 1e-13, chosen per iteration)"};
   add("Linear solver    %s\n", ls[(s->linear_solver_used >= 0 && s->linear_solver_used <= 3) ? s->linear_solver_used : 1]);
   if (s->factor_nnz_blocks > 0) add("Factor blocks / levels  %12d / %d\n", s->factor_nnz_blocks, s->factor_levels);
+  if (s->factor_nnz_blocks > 0) add("Factorisations          %12d\n", s->num_factorizations);
   add("Compute device              HIP gfx950 (FP64)\n\n");
   add("Cost:\n");
   add("%-28s %e\n", "Initial", s->initial_cost);

@@ -381,8 +381,11 @@ def test_exact_request_with_per_iteration_choice(gpu, O, ds, monkeypatch, budget
     s = gpu.solve(gpu.SolverOptions(max_num_iterations=8, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY), prob)
     _, osum, otr = O.solve(og, O.default_options(max_num_iterations=8, linear_solver=0))
     assert s.linear_solver_used == 3 and s.factor_nnz_blocks > 2000
+    solves = len(s.iterations) - 1                           # iteration 0 has no linear solve
     if budget == "100000":
-        assert s.num_linear_solver_iterations > 0            # PCG did serve iterations
+        assert s.num_linear_solver_iterations > 0 and 1 <= s.num_factorizations < solves   # PCG did serve iterations
+    if budget == "40":
+        assert s.num_factorizations == solves                # every PCG try over budget, every iteration factorised
     n = min(len(otr), len(s.iterations))
     assert n == len(otr) == len(s.iterations)
     assert list(s.iterations["step_is_successful"][:n]) == [int(x) for x in otr[:n, 8]]
