@@ -28,22 +28,31 @@ struct Csr {
 };
 
 Csr build_adjacency(int N, const std::vector<int>& ia, const std::vector<int>& ib) {
-  std::vector<std::pair<int, int>> e;
-  e.reserve(2 * ia.size());
+  // neighbour lists, each sorted and without duplicates (bucket by vertex, then sort the short lists)
+  Csr g;
+  std::vector<int> ptr(N + 1, 0);
   for (size_t k = 0; k < ia.size(); ++k) {
     if (ia[k] == ib[k]) continue;
-    e.emplace_back(ia[k], ib[k]);
-    e.emplace_back(ib[k], ia[k]);
+    ++ptr[ia[k] + 1];
+    ++ptr[ib[k] + 1];
   }
-  std::sort(e.begin(), e.end());
-  e.erase(std::unique(e.begin(), e.end()), e.end());
-  Csr g;
+  for (int v = 0; v < N; ++v) ptr[v + 1] += ptr[v];
+  std::vector<int> idx(ptr[N]), fill(ptr.begin(), ptr.end() - 1);
+  for (size_t k = 0; k < ia.size(); ++k) {
+    if (ia[k] == ib[k]) continue;
+    idx[fill[ia[k]]++] = ib[k];
+    idx[fill[ib[k]]++] = ia[k];
+  }
   g.ptr.assign(N + 1, 0);
-  for (auto& p : e) ++g.ptr[p.first + 1];
-  for (int v = 0; v < N; ++v) g.ptr[v + 1] += g.ptr[v];
-  g.idx.resize(e.size());
-  std::vector<int> fill(g.ptr.begin(), g.ptr.end() - 1);
-  for (auto& p : e) g.idx[fill[p.first]++] = p.second;
+  g.idx.reserve(idx.size());
+  for (int v = 0; v < N; ++v) {
+    int* lo = idx.data() + ptr[v];
+    int* hi = idx.data() + ptr[v + 1];
+    std::sort(lo, hi);
+    hi = std::unique(lo, hi);
+    g.idx.insert(g.idx.end(), lo, hi);
+    g.ptr[v + 1] = (int)g.idx.size();
+  }
   return g;
 }
 
@@ -71,31 +80,39 @@ struct Dissector {
   void clear_dist() { for (int v : queue) dist[v] = -1; }
 
   void run(std::vector<int> verts) {
-    // iterative worklist of subsets; `order` is produced back to front (separators last)
-    struct Item { std::vector<int> verts; };
-    std::vector<Item> stack;
-    stack.push_back(Item{std::move(verts)});
+    // iterative worklist of subsets = ranges [begin, end) of one work array, partitioned in place (A | B, the separator
+    // leaves); `order` is produced back to front (separators last).  Subsets keep the vertex order the recursion sees
+    // (BFS order of the parent), which decides the BFS start vertices.
+    std::vector<int> work = std::move(verts), tmp(work.size()), lvl_cnt;
+    std::vector<std::pair<int, int>> stack;
+    stack.emplace_back(0, (int)work.size());
     std::vector<int> result_rev;
+    result_rev.reserve(work.size());
     while (!stack.empty()) {
-      std::vector<int> S = std::move(stack.back().verts);
+      const int sb = stack.back().first, se = stack.back().second;
       stack.pop_back();
-      if (S.empty()) continue;
-      if (S.size() <= 2) {
-        for (int i = (int)S.size() - 1; i >= 0; --i) result_rev.push_back(S[i]);
+      const int total = se - sb;
+      if (total <= 0) continue;
+      int* S = work.data() + sb;
+      if (total <= 2) {
+        for (int i = total - 1; i >= 0; --i) result_rev.push_back(S[i]);
         continue;
       }
       const int id = next_label++;
-      for (int v : S) label[v] = id;
+      for (int i = 0; i < total; ++i) label[S[i]] = id;
       // one connected component at a time
-      int start = S[0];
-      bfs(start, id);
-      if (queue.size() < S.size()) {
-        std::vector<int> comp(queue.begin(), queue.end()), rest;
-        for (int v : S) if (dist[v] < 0) rest.push_back(v);
+      bfs(S[0], id);
+      if ((int)queue.size() < total) {
+        // [rest (subset order) | component (BFS order)]: the component is processed first (it is pushed last)
+        int nr = 0;
+        for (int i = 0; i < total; ++i) if (dist[S[i]] < 0) tmp[nr++] = S[i];
+        const int ncomp = (int)queue.size();
+        for (int i = 0; i < ncomp; ++i) tmp[nr + i] = queue[i];
         clear_dist();
-        for (int v : S) label[v] = 0;
-        stack.push_back(Item{std::move(rest)});
-        stack.push_back(Item{std::move(comp)});
+        for (int i = 0; i < total; ++i) label[S[i]] = 0;
+        std::copy(tmp.begin(), tmp.begin() + total, S);
+        stack.emplace_back(sb, sb + nr);
+        stack.emplace_back(sb + nr, se);
         continue;
       }
       // pseudo-peripheral vertex: two more sweeps
@@ -106,17 +123,16 @@ struct Dissector {
       bfs(far, id);
       const int depth = dist[queue.back()];
       if (depth < 2) {
-        // (nearly) a clique: no useful separator, eliminate in BFS order
+        // (nearly) a clique: no useful separator, eliminate in subset order
         clear_dist();
-        for (int v : S) label[v] = 0;
-        for (int i = (int)S.size() - 1; i >= 0; --i) result_rev.push_back(S[i]);
+        for (int i = 0; i < total; ++i) label[S[i]] = 0;
+        for (int i = total - 1; i >= 0; --i) result_rev.push_back(S[i]);
         continue;
       }
       // level sizes; separator = smallest level among those whose prefix holds 35..65 % of the vertices
-      std::vector<int> lvl_cnt(depth + 1, 0);
+      lvl_cnt.assign(depth + 1, 0);
       for (int v : queue) ++lvl_cnt[dist[v]];
       int best = -1, acc = 0;
-      const int total = (int)S.size();
       for (int l = 0; l <= depth; ++l) {
         const int before = acc;
         acc += lvl_cnt[l];
@@ -133,24 +149,28 @@ struct Dissector {
           acc += lvl_cnt[l];
         }
       }
-      std::vector<int> A, B, Sep;
+      // A from the front of tmp, B from its back (reversed below), the separator to the result; all in BFS order
+      int na = 0, nb = 0;
+      const size_t sep_begin = result_rev.size();
       for (int v : queue) {
-        if (dist[v] < best) A.push_back(v);
-        else if (dist[v] > best) B.push_back(v);
+        if (dist[v] < best) tmp[na++] = v;
+        else if (dist[v] > best) tmp[total - 1 - nb++] = v;
         else {
           bool touches = false;
           for (int p = g.ptr[v]; p < g.ptr[v + 1] && !touches; ++p) {
             const int u = g.idx[p];
             if (label[u] == id && dist[u] == best + 1) touches = true;
           }
-          (touches ? Sep : A).push_back(v);
+          if (touches) result_rev.push_back(v); else tmp[na++] = v;
         }
       }
+      std::reverse(result_rev.begin() + sep_begin, result_rev.end());    // the separator enters back to front
       clear_dist();
-      for (int v : S) label[v] = 0;
-      for (int i = (int)Sep.size() - 1; i >= 0; --i) result_rev.push_back(Sep[i]);
-      stack.push_back(Item{std::move(A)});
-      stack.push_back(Item{std::move(B)});
+      for (int i = 0; i < total; ++i) label[S[i]] = 0;
+      std::copy(tmp.begin(), tmp.begin() + na, S);
+      for (int i = 0; i < nb; ++i) S[na + i] = tmp[total - 1 - i];
+      stack.emplace_back(sb, sb + na);
+      stack.emplace_back(sb + na, sb + na + nb);
     }
     order.assign(result_rev.rbegin(), result_rev.rend());
   }

@@ -786,9 +786,12 @@ int prepare_direct(pgo_problem* P) {
   if (off && off[0] == '1') return PGO_OK;
   if (P->comm && P->comm->world > 1) return PGO_OK;   // the factorisation needs every row: sharded runs use PCG to 1e-13
   pgo::DirectSymbolic& S = P->dsym;
-  if (!pgo::direct_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side,
-                           P->h_row_slot_begin, &S))
-    return PGO_OK;  // too much fill / too deep for the enumerated schedule: the iterative path serves the request
+  const auto t_an = Clock::now();
+  const bool usable = pgo::direct_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side,
+                                          P->h_row_slot_begin, &S);
+  if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: symbolic analysis %.2f ms\n", 1e3 * seconds_since(t_an));
+  if (!usable) return PGO_OK;  // too much fill / too deep for the enumerated schedule: the iterative path serves the request
+  const auto t_up = Clock::now();
   hipStream_t s = P->stream;
   HIP_TRY(P->dd_perm.upload(S.perm, s));
   HIP_TRY(P->dd_col_ptr.upload(S.col_ptr, s));
@@ -831,6 +834,7 @@ int prepare_direct(pgo_problem* P) {
   d.split_dblk = P->dd_split_dblk.p; d.col_flag = P->dd_col_flag.p;
   P->drop_direct_graph();
   P->direct_usable = true;
+  if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: plan upload %.2f ms\n", 1e3 * seconds_since(t_up));
   return PGO_OK;
 }
 
