@@ -109,6 +109,10 @@ typedef struct pgo_solver_summary {
   double final_gradient_max_norm;
   double final_trust_region_radius;
   char message[256];
+  int factor_kind;              /* 0 no factorisation, 1 enumerated 6x6 block pairs (pgo_direct), 2 supernodal multifrontal
+                                   with FP64 MFMA fronts (pgo_front) */
+  int factor_max_front;         /* multifrontal: largest dense front (scalars) */
+  double factor_flops;          /* flops of one numeric factorisation */
 } pgo_solver_summary;
 
 /* One row per iteration, the numbers Summary::FullReport() tabulates with

@@ -75,6 +75,7 @@ class _CSummary(C.Structure):
         ("linear_solver_time_in_seconds", C.c_double), ("jacobian_evaluation_time_in_seconds", C.c_double),
         ("residual_evaluation_time_in_seconds", C.c_double), ("final_gradient_max_norm", C.c_double),
         ("final_trust_region_radius", C.c_double), ("message", C.c_char * 256),
+        ("factor_kind", C.c_int), ("factor_max_front", C.c_int), ("factor_flops", C.c_double),
     ]
 
 
@@ -97,10 +98,11 @@ _lib = None
 def build(force=False):
     """Compiles csrc/ into libpgo_hip.so with hipcc --offload-arch=gfx950 (works without a GPU)."""
     src = os.path.join(_HERE, "csrc")
-    deps = [os.path.join(src, f) for f in os.listdir(src)] + [os.path.join(_HERE, "..", "include", "pgo.h")]
+    deps = [os.path.join(src, f) for f in os.listdir(src) if os.path.isfile(os.path.join(src, f))]
+    deps.append(os.path.join(_HERE, "..", "include", "pgo.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps)
     if force or stale:
-        subprocess.check_call(["make", "-C", src] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-j8", "-C", src] + (["-B"] if force else []))
     return LIB_PATH
 
 

@@ -178,6 +178,16 @@ struct Dissector {
 
 }  // namespace
 
+bool nested_dissection_order(int N, const std::vector<int>& ia, const std::vector<int>& ib, std::vector<int>* perm) {
+  const Csr g = build_adjacency(N, ia, ib);
+  Dissector d(g);
+  std::vector<int> all(N);
+  std::iota(all.begin(), all.end(), 0);
+  d.run(std::move(all));
+  *perm = d.order;
+  return (int)perm->size() == N;
+}
+
 bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib, int n_slots,
                     const std::vector<int>& slot_row, const std::vector<int>& slot_col,
                     const std::vector<uint8_t>& slot_side, const std::vector<int>& row_slot_begin,

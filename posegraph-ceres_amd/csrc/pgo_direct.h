@@ -76,6 +76,9 @@ struct DirectSymbolic {
                              // factorisation and PCG run to exact_r_tolerance (whichever the last iterations made cheaper)
 };
 
+// Nested-dissection ordering of the pose graph (perm[new] = old); shared with the multifrontal solver (pgo_front.h).
+bool nested_dissection_order(int N, const std::vector<int>& ia, const std::vector<int>& ib, std::vector<int>* perm);
+
 // Host symbolic analysis.  slot_* describe the incidence-slot BSR (pgo_solver.cpp prepare()).
 // Returns false when the factorisation would be impractical (caller falls back to the iterative path).
 bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib, int n_slots,

@@ -1,0 +1,402 @@
+// pgo_front.cpp — host symbolic phase of the multifrontal GPU Cholesky (see pgo_front.h).
+//
+//  1. nested-dissection ordering (pgo_direct.cpp), block symbolic factorisation through the elimination tree;
+//  2. fundamental supernodes, then relaxed amalgamation: a child is merged into its parent when the merged supernode is
+//     small or the explicit zeros stay below a fraction of its entries (CHOLMOD's idea with much looser thresholds — an
+//     MI355X retires the extra flops in microseconds, a tree level costs tens of microseconds of dependent launches);
+//  3. postorder renumbering so every supernode owns consecutive columns; row structures recomputed in that numbering;
+//  4. fronts numbered level by level (leaves first), child -> parent index maps, BSR source lists per front block;
+//  5. the launch schedule: per level and panel step one POTRF, one TRSM and one GEMM launch over all fronts of the level.
+#include "pgo_front.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+
+#include "pgo_direct.h"
+
+namespace pgo {
+
+namespace {
+
+double env_or(const char* name, double dflt) {
+  const char* v = getenv(name);
+  return v ? atof(v) : dflt;
+}
+
+}  // namespace
+
+bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib, int n_slots,
+                   const std::vector<int>& slot_row, const std::vector<int>& slot_col,
+                   const std::vector<uint8_t>& slot_side, long long max_bytes, FrontSymbolic* out) {
+  FrontSymbolic& S = *out;
+  S = FrontSymbolic();
+  S.n = N;
+  if (N <= 0) return false;
+  // ---- 1. ordering + adjacency in that ordering ----
+  std::vector<int> perm0;
+  if (!nested_dissection_order(N, ia, ib, &perm0)) return false;
+  std::vector<int> iperm0(N);
+  for (int k = 0; k < N; ++k) iperm0[perm0[k]] = k;
+  std::vector<int> aptr(N + 1, 0), aidx;   // full neighbour lists in the perm0 numbering (duplicates allowed)
+  for (size_t e = 0; e < ia.size(); ++e) {
+    if (ia[e] == ib[e]) continue;
+    ++aptr[iperm0[ia[e]] + 1];
+    ++aptr[iperm0[ib[e]] + 1];
+  }
+  for (int v = 0; v < N; ++v) aptr[v + 1] += aptr[v];
+  aidx.resize(aptr[N]);
+  {
+    std::vector<int> fill(aptr.begin(), aptr.end() - 1);
+    for (size_t e = 0; e < ia.size(); ++e) {
+      if (ia[e] == ib[e]) continue;
+      const int a = iperm0[ia[e]], b = iperm0[ib[e]];
+      aidx[fill[a]++] = b;
+      aidx[fill[b]++] = a;
+    }
+  }
+  // ---- 2. column structures through the elimination tree (only the sizes and the parents are kept) ----
+  std::vector<int> parent(N, -1), st_len(N, 0), nchild(N, 0);
+  {
+    std::vector<std::vector<int>> st(N);
+    std::vector<std::vector<int>> children(N);
+    std::vector<int> mark(N, -1), tmp;
+    for (int j = 0; j < N; ++j) {
+      tmp.clear();
+      mark[j] = j;
+      for (int p = aptr[j]; p < aptr[j + 1]; ++p) {
+        const int i = aidx[p];
+        if (i > j && mark[i] != j) { mark[i] = j; tmp.push_back(i); }
+      }
+      for (int c : children[j]) {
+        for (int i : st[c]) if (i > j && mark[i] != j) { mark[i] = j; tmp.push_back(i); }
+        std::vector<int>().swap(st[c]);   // a child's structure is needed by its parent only
+      }
+      st_len[j] = (int)tmp.size();
+      if (!tmp.empty()) {
+        const int par = *std::min_element(tmp.begin(), tmp.end());
+        parent[j] = par;
+        children[par].push_back(j);
+        ++nchild[par];
+      }
+      st[j].swap(tmp);
+    }
+  }
+  // ---- 3. fundamental supernodes ----
+  std::vector<int> sn_start;
+  sn_start.push_back(0);
+  for (int j = 1; j < N; ++j) {
+    if (parent[j - 1] == j && st_len[j - 1] == st_len[j] + 1 && nchild[j] == 1) continue;
+    sn_start.push_back(j);
+  }
+  const int ns0 = (int)sn_start.size();
+  sn_start.push_back(N);
+  std::vector<int> sn_of(N);
+  for (int s = 0; s < ns0; ++s) for (int j = sn_start[s]; j < sn_start[s + 1]; ++j) sn_of[j] = s;
+  std::vector<long long> cols(ns0), rows(ns0), zeros(ns0, 0);
+  std::vector<int> sparent(ns0, -1);
+  std::vector<std::vector<int>> kids(ns0), members(ns0);
+  for (int s = 0; s < ns0; ++s) {
+    const int last = sn_start[s + 1] - 1;
+    cols[s] = sn_start[s + 1] - sn_start[s];
+    rows[s] = st_len[last];
+    sparent[s] = parent[last] >= 0 ? sn_of[parent[last]] : -1;
+    members[s].push_back(s);
+  }
+  for (int s = 0; s < ns0; ++s) if (sparent[s] >= 0) kids[sparent[s]].push_back(s);
+  // ---- 4. relaxed amalgamation (parents have larger indices than their children) ----
+  const double zfrac = env_or("PGO_FRONT_ZFRAC", 0.25);
+  const long long small = (long long)env_or("PGO_FRONT_SMALL", 8);
+  const long long max_cols = (long long)env_or("PGO_FRONT_MAXCOLS", 1 << 30);
+  std::vector<char> alive(ns0, 1);
+  for (int p = 0; p < ns0; ++p) {
+    std::vector<int> ch = kids[p], keep;
+    std::sort(ch.begin(), ch.end(), [&](int a, int b) { return rows[a] != rows[b] ? rows[a] > rows[b] : a < b; });
+    for (int c : ch) {
+      const long long add = cols[c] * (cols[p] + rows[p] - rows[c]);
+      const long long C = cols[c] + cols[p], R = rows[p];
+      const long long tot = C * (C + 1) / 2 + C * R;
+      const long long z = zeros[c] + zeros[p] + add;
+      if (C <= max_cols && (C <= small || (double)z <= zfrac * (double)tot)) {
+        cols[p] = C;
+        zeros[p] = z;
+        alive[c] = 0;
+        members[p].insert(members[p].end(), members[c].begin(), members[c].end());
+        for (int gc : kids[c]) { keep.push_back(gc); sparent[gc] = p; }
+      } else {
+        keep.push_back(c);
+      }
+    }
+    kids[p].swap(keep);
+  }
+  // ---- 5. postorder renumbering of the amalgamated tree ----
+  std::vector<int> post;   // supernodes (old ids) in postorder
+  post.reserve(ns0);
+  {
+    std::vector<std::pair<int, size_t>> stack;
+    for (int r = 0; r < ns0; ++r) {
+      if (!alive[r] || sparent[r] >= 0) continue;
+      stack.emplace_back(r, 0);
+      while (!stack.empty()) {
+        const int s = stack.back().first;
+        if (stack.back().second == 0) std::sort(kids[s].begin(), kids[s].end());
+        if (stack.back().second < kids[s].size()) {
+          const int c = kids[s][stack.back().second++];
+          stack.emplace_back(c, 0);
+        } else {
+          post.push_back(s);
+          stack.pop_back();
+        }
+      }
+    }
+  }
+  const int nf = (int)post.size();
+  S.nf = nf;
+  std::vector<int> sn_new(ns0, -1);   // old supernode id -> postorder id
+  for (int k = 0; k < nf; ++k) sn_new[post[k]] = k;
+  std::vector<int> first(nf), ccount(nf), fparent(nf, -1);
+  std::vector<int> newidx(N, -1);     // perm0 index -> new index
+  {
+    int next = 0;
+    for (int k = 0; k < nf; ++k) {
+      const int s = post[k];
+      std::sort(members[s].begin(), members[s].end());
+      first[k] = next;
+      for (int m : members[s]) for (int j = sn_start[m]; j < sn_start[m + 1]; ++j) newidx[j] = next++;
+      ccount[k] = next - first[k];
+      fparent[k] = sparent[s] >= 0 ? sn_new[sparent[s]] : -1;
+    }
+    if (next != N) return false;
+  }
+  S.perm.resize(N);
+  S.iperm.resize(N);
+  for (int j = 0; j < N; ++j) { S.perm[newidx[j]] = perm0[j]; }
+  for (int k = 0; k < N; ++k) S.iperm[S.perm[k]] = k;
+  std::vector<int> colf(N);           // postorder front id of each new column
+  for (int k = 0; k < nf; ++k) for (int j = first[k]; j < first[k] + ccount[k]; ++j) colf[j] = k;
+  // adjacency in the new numbering (old vertex -> neighbours), reuse aptr/aidx through newidx
+  // ---- 6. row structures in the new numbering ----
+  std::vector<std::vector<int>> R(nf);
+  std::vector<std::vector<int>> fkids(nf);
+  for (int k = 0; k < nf; ++k) if (fparent[k] >= 0) fkids[fparent[k]].push_back(k);
+  {
+    std::vector<int> mark(N, -1), tmp;
+    for (int k = 0; k < nf; ++k) {
+      const int last = first[k] + ccount[k] - 1;
+      tmp.clear();
+      for (int jn = first[k]; jn <= last; ++jn) {
+        const int j0 = iperm0[S.perm[jn]];
+        for (int p = aptr[j0]; p < aptr[j0 + 1]; ++p) {
+          const int i = newidx[aidx[p]];
+          if (i > last && mark[i] != k) { mark[i] = k; tmp.push_back(i); }
+        }
+      }
+      for (int c : fkids[k]) for (int i : R[c]) if (i > last && mark[i] != k) { mark[i] = k; tmp.push_back(i); }
+      std::sort(tmp.begin(), tmp.end());
+      R[k] = tmp;
+      if (!tmp.empty() && colf[tmp[0]] != fparent[k]) return false;   // tree consistency
+    }
+  }
+  // ---- 7. levels (leaves first); fronts renumbered level by level, fronts with children last inside a level ----
+  std::vector<int> level(nf, 0);
+  int n_levels = 1;
+  for (int k = 0; k < nf; ++k) {
+    for (int c : fkids[k]) level[k] = std::max(level[k], level[c] + 1);
+    n_levels = std::max(n_levels, level[k] + 1);
+  }
+  S.n_levels = n_levels;
+  std::vector<int> order(nf);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    if (level[a] != level[b]) return level[a] < level[b];
+    const bool ca = !fkids[a].empty(), cb = !fkids[b].empty();
+    if (ca != cb) return cb;
+    return false;
+  });
+  std::vector<int> fid(nf);   // postorder id -> final id
+  for (int k = 0; k < nf; ++k) fid[order[k]] = k;
+  S.fronts.resize(nf);
+  S.col_front.resize(N);
+  long long fbase = 0, wbase = 0, blocks = 0;
+  double flops = 0;
+  for (int f = 0; f < nf; ++f) {
+    const int k = order[f];
+    FrontDesc& D = S.fronts[f];
+    D.first = first[k];
+    D.c = ccount[k];
+    D.r = (int)R[k].size();
+    const int n = 6 * (D.c + D.r);
+    D.ld = n + 2;
+    D.fbase = fbase;
+    fbase += ((long long)(n + 1) * D.ld + 15) / 16 * 16;
+    D.idx_begin = (int)S.idx.size();
+    S.idx.insert(S.idx.end(), R[k].begin(), R[k].end());
+    D.child_begin = (int)S.child.size();
+    for (int c : fkids[k]) S.child.push_back(fid[c]);
+    std::sort(S.child.begin() + D.child_begin, S.child.end());
+    D.child_end = (int)S.child.size();
+    D.parent = fparent[k] >= 0 ? fid[fparent[k]] : -1;
+    const int npanels = (6 * D.c + FRONT_NB - 1) / FRONT_NB;
+    D.wbase = (int)wbase;
+    wbase += (long long)npanels * FRONT_NB * FRONT_NB;
+    D.ntp = (D.c + D.r + FRONT_ASM_TP - 1) / FRONT_ASM_TP;
+    D.asm_wg_begin = 0;
+    D.rel_begin = 0;
+    for (int j = D.first; j < D.first + D.c; ++j) S.col_front[j] = f;
+    S.max_front = std::max(S.max_front, n);
+    const double c6 = 6.0 * D.c, r6 = 6.0 * D.r;
+    flops += c6 * c6 * c6 / 3.0 + c6 * c6 * r6 + c6 * r6 * r6;
+    blocks += (long long)D.c * (D.c + 1) / 2 + (long long)D.c * D.r;
+  }
+  S.fval_size = fbase;
+  S.winv_size = std::max(1LL, wbase);
+  S.flops = flops;
+  S.factor_blocks = blocks;
+  if (wbase > 0x7fffffffLL) return false;
+  if ((S.fval_size + S.winv_size) * 8 > max_bytes) {
+    if (getenv("PGO_VERBOSE"))
+      std::fprintf(stderr, "[pgo] front: %.2f GB of fronts exceed the budget of %.2f GB\n", 8e-9 * (double)S.fval_size, 1e-9 * (double)max_bytes);
+    return false;
+  }
+  // ---- 8. child -> parent maps ----
+  for (int f = 0; f < nf; ++f) {
+    FrontDesc& D = S.fronts[f];
+    D.rel_begin = (int)S.rel.size();
+    if (D.parent < 0) continue;
+    const FrontDesc& Pd = S.fronts[D.parent];
+    const int* pr = S.idx.data() + Pd.idx_begin;
+    int q = 0;
+    for (int t = 0; t < D.r; ++t) {
+      const int i = S.idx[D.idx_begin + t];
+      if (i < Pd.first + Pd.c) {
+        if (i < Pd.first) return false;
+        S.rel.push_back(i - Pd.first);
+      } else {
+        while (q < Pd.r && pr[q] < i) ++q;
+        if (q >= Pd.r || pr[q] != i) return false;
+        S.rel.push_back(Pd.c + q);
+      }
+    }
+  }
+  if (S.rel.empty()) S.rel.push_back(0);
+  if (S.idx.empty()) S.idx.push_back(0);
+  if (S.child.empty()) S.child.push_back(0);
+  // ---- 9. BSR sources per front block ----
+  {
+    struct Ent { long long key; int slot; };
+    std::vector<Ent> ents;
+    ents.reserve(n_slots);
+    for (int t = 0; t < n_slots; ++t) {
+      const uint8_t side = slot_side[t];
+      if (side == SIDE_PAD) continue;
+      const int i = S.iperm[slot_row[t]];
+      const int j = side == SIDE_DIAG ? i : S.iperm[slot_col[t]];
+      if (i < j) continue;   // the twin slot carries the transposed block
+      if (i == j && side != SIDE_DIAG) continue;
+      const int f = S.col_front[j];
+      const FrontDesc& D = S.fronts[f];
+      const int bj = j - D.first;
+      int bi;
+      if (i < D.first + D.c) bi = i - D.first;
+      else {
+        const int* lo = S.idx.data() + D.idx_begin;
+        const int* hi = lo + D.r;
+        const int* it = std::lower_bound(lo, hi, i);
+        if (it == hi || *it != i) return false;
+        bi = D.c + (int)(it - lo);
+      }
+      if (bi >= 32768 || bj >= 65536) return false;
+      ents.push_back(Ent{((long long)f << 32) | ((long long)bi << 16) | bj, t});
+    }
+    std::sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key != b.key ? a.key < b.key : a.slot < b.slot; });
+    S.ablk_ptr.push_back(0);
+    for (size_t e = 0; e < ents.size(); ++e) {
+      if (e == 0 || ents[e].key != ents[e - 1].key) {
+        if (e) S.ablk_ptr.push_back((int)e);
+        S.ablk_front.push_back((int)(ents[e].key >> 32));
+        S.ablk_pos.push_back((int)(ents[e].key & 0xffffffffLL));
+      }
+      S.ablk_slot.push_back(ents[e].slot);
+    }
+    S.ablk_ptr.push_back((int)ents.size());
+  }
+  // ---- 10. schedule ----
+  S.levels.resize(n_levels);
+  {
+    int f = 0;
+    for (int l = 0; l < n_levels; ++l) {
+      FrontLevel& L = S.levels[l];
+      L.front_begin = f;
+      while (f < nf && level[order[f]] == l) ++f;
+      L.front_end = f;
+      L.asm_front_begin = L.front_end;
+      for (int q = L.front_begin; q < L.front_end; ++q)
+        if (S.fronts[q].child_end > S.fronts[q].child_begin) { L.asm_front_begin = q; break; }
+      int wg = 0;
+      for (int q = L.asm_front_begin; q < L.front_end; ++q) {
+        S.fronts[q].asm_wg_begin = wg;
+        wg += (S.fronts[q].ntp + 1) * S.fronts[q].ntp;
+      }
+      L.asm_wg = wg;
+      L.max_threads_bwd = 0;
+      L.launch_begin = (int)S.launches.size();
+      int max_steps = 0;
+      for (int q = L.front_begin; q < L.front_end; ++q) max_steps = std::max(max_steps, (6 * S.fronts[q].c + FRONT_NB - 1) / FRONT_NB);
+      for (int step = 0; step < max_steps; ++step) {
+        FrontLaunch lp{FrontLaunch::POTRF, (int)S.jobs.size(), 0, 0};
+        for (int q = L.front_begin; q < L.front_end; ++q) {
+          const FrontDesc& D = S.fronts[q];
+          const int c6 = 6 * D.c, k0 = step * FRONT_NB;
+          if (k0 >= c6) continue;
+          const int nb = std::min<int>(FRONT_NB, c6 - k0);
+          FrontJob J{D.fbase, D.ld, k0, k0 + nb, k0, k0 + nb, k0, nb, D.wbase + step * FRONT_NB * FRONT_NB, lp.n_wg, 1};
+          S.jobs.push_back(J);
+          lp.n_wg += 1;
+        }
+        lp.job_end = (int)S.jobs.size();
+        S.launches.push_back(lp);
+        FrontLaunch lt{FrontLaunch::TRSM, (int)S.jobs.size(), 0, 0};
+        for (int q = L.front_begin; q < L.front_end; ++q) {
+          const FrontDesc& D = S.fronts[q];
+          const int c6 = 6 * D.c, n = 6 * (D.c + D.r), k0 = step * FRONT_NB;
+          if (k0 >= c6) continue;
+          const int nb = std::min<int>(FRONT_NB, c6 - k0), kend = k0 + nb;
+          FrontJob J{D.fbase, D.ld, kend, n + 1, k0, kend, k0, nb, D.wbase + step * FRONT_NB * FRONT_NB, lt.n_wg, 1};
+          S.jobs.push_back(J);
+          lt.n_wg += (n + 1 - kend + FRONT_TILE - 1) / FRONT_TILE;
+        }
+        lt.job_end = (int)S.jobs.size();
+        S.launches.push_back(lt);
+        FrontLaunch lg{FrontLaunch::GEMM, (int)S.jobs.size(), 0, 0};
+        for (int q = L.front_begin; q < L.front_end; ++q) {
+          const FrontDesc& D = S.fronts[q];
+          const int c6 = 6 * D.c, n = 6 * (D.c + D.r), k0 = step * FRONT_NB;
+          if (k0 >= c6) continue;
+          const int nb = std::min<int>(FRONT_NB, c6 - k0), kend = k0 + nb;
+          const int ostart = (k0 / FRONT_NBO) * FRONT_NBO, oend = std::min(c6, ostart + FRONT_NBO);
+          int r0, r1, cc0, cc1, kk0, klen;
+          if (kend < oend) { r0 = kend; r1 = n + 1; cc0 = kend; cc1 = oend; kk0 = k0; klen = nb; }
+          else if (oend < c6) { r0 = oend; r1 = n + 1; cc0 = oend; cc1 = c6; kk0 = ostart; klen = oend - ostart; }
+          else { r0 = c6; r1 = n + 1; cc0 = c6; cc1 = n; kk0 = 0; klen = c6; }
+          if (cc1 <= cc0) continue;
+          const int ntr = (r1 - r0 + FRONT_TILE - 1) / FRONT_TILE, ntc = (cc1 - cc0 + FRONT_TILE - 1) / FRONT_TILE;
+          FrontJob J{D.fbase, D.ld, r0, r1, cc0, cc1, kk0, klen, 0, lg.n_wg, ntc};
+          S.jobs.push_back(J);
+          lg.n_wg += ntr * ntc;
+        }
+        lg.job_end = (int)S.jobs.size();
+        if (lg.n_wg > 0) S.launches.push_back(lg);
+      }
+      L.launch_end = (int)S.launches.size();
+    }
+  }
+  S.n_launches = (int)S.launches.size() + 2 * n_levels + 2;
+  S.est_us = 4.0 * S.n_launches + flops / 2.0e7;   // ~4 us per dependent launch, ~20 TFLOP/s sustained
+  if (getenv("PGO_VERBOSE"))
+    std::fprintf(stderr, "[pgo] front: n=%d supernodes %d -> %d fronts, %d levels, %d launches, largest front %d, %.3g flops, %.1f MB, est %.0f us\n",
+                 N, ns0, nf, n_levels, S.n_launches, S.max_front, flops, 8e-6 * (double)(S.fval_size + S.winv_size), S.est_us);
+  return true;
+}
+
+}  // namespace pgo

@@ -11,6 +11,7 @@
 #include "../../include/pgo.h"
 #include "pgo_kernels.h"
 #include "pgo_direct.h"
+#include "pgo_front.h"
 #include "pgo_comm.h"
 
 namespace pgo { int comm_stress(Comm* c, int iters, size_t seg, hipStream_t s, int* mismatches); }
@@ -201,6 +202,14 @@ struct pgo_problem {
   DevBuf<double> dd_Lval, dd_y;
   hipGraph_t direct_graph = nullptr;
   hipGraphExec_t direct_exec = nullptr;
+  // exact solver for mesh-like graphs: supernodal multifrontal Cholesky with FP64 MFMA fronts (pgo_front.*)
+  pgo::FrontSymbolic fsym;
+  pgo::FrontPlan fplan{};
+  bool front_usable = false;
+  DevBuf<int> df_perm, df_idx, df_child, df_rel, df_col_front, df_ablk_ptr, df_ablk_slot, df_ablk_front, df_ablk_pos;
+  DevBuf<pgo::FrontDesc> df_fronts;
+  DevBuf<pgo::FrontJob> df_jobs;
+  DevBuf<double> df_Fval, df_Winv, df_x;
   // cluster-Jacobi preconditioner topology (built when the option asks for clusters of 2 or 4 poses)
   DevBuf<int> d_cl_ptr, d_cl_slot;
   DevBuf<uint8_t> d_cl_rc;
@@ -478,7 +487,7 @@ int prepare(pgo_problem* P) {
   }
   lap("measurement / W arrays");
   P->h_slot_row = slot_row; P->h_slot_col = slot_col; P->h_slot_side = slot_side; P->h_row_slot_begin = row_slot_begin;
-  P->direct_analyzed = false; P->direct_usable = false; P->cluster_built = 0; P->g.cluster = 1;
+  P->direct_analyzed = false; P->direct_usable = false; P->front_usable = false; P->cluster_built = 0; P->g.cluster = 1;
   HIP_TRY(P->d_slot_col.upload(slot_col, s));
   HIP_TRY(P->d_slot_row.upload(slot_row, s));
   HIP_TRY(P->d_slot_side.upload(slot_side, s));
@@ -778,18 +787,74 @@ int prepare_clusters(pgo_problem* P, int CL) {
 }
 
 // ---- exact solver: GPU block-sparse Cholesky (pgo_direct.*) ----
+// Multifrontal solver: symbolic analysis + plan upload.  Leaves front_usable false when the fronts do not fit.
+int prepare_front(pgo_problem* P) {
+  pgo::FrontSymbolic& S = P->fsym;
+  const auto t_an = Clock::now();
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const char* cap = getenv("PGO_FRONT_MAX_GB");
+  const long long budget = cap ? (long long)(atof(cap) * 1e9) : (long long)(0.6 * (double)free_b);
+  const bool ok = pgo::front_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side, budget, &S);
+  if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] front: symbolic analysis %.2f ms (%s)\n", 1e3 * seconds_since(t_an), ok ? "usable" : "declined");
+  if (!ok) return PGO_OK;
+  const auto t_up = Clock::now();
+  hipStream_t s = P->stream;
+  HIP_TRY(P->df_perm.upload(S.perm, s));
+  HIP_TRY(P->df_idx.upload(S.idx, s));
+  HIP_TRY(P->df_child.upload(S.child, s));
+  HIP_TRY(P->df_rel.upload(S.rel, s));
+  HIP_TRY(P->df_col_front.upload(S.col_front, s));
+  HIP_TRY(P->df_ablk_ptr.upload(S.ablk_ptr, s));
+  HIP_TRY(P->df_ablk_slot.upload(S.ablk_slot, s));
+  HIP_TRY(P->df_ablk_front.upload(S.ablk_front, s));
+  HIP_TRY(P->df_ablk_pos.upload(S.ablk_pos, s));
+  HIP_TRY(P->df_fronts.upload(S.fronts, s));
+  HIP_TRY(P->df_jobs.upload(S.jobs, s));
+  HIP_TRY(P->df_Fval.alloc((size_t)S.fval_size));
+  HIP_TRY(P->df_Winv.alloc((size_t)S.winv_size));
+  HIP_TRY(P->df_x.alloc((size_t)6 * S.n));
+  HIP_TRY(P->df_x.zero(s));
+  pgo::FrontPlan& f = P->fplan;
+  f.n = S.n; f.nf = S.nf;
+  f.perm = P->df_perm.p; f.fronts = P->df_fronts.p; f.idx = P->df_idx.p; f.child = P->df_child.p; f.rel = P->df_rel.p;
+  f.col_front = P->df_col_front.p; f.ablk_ptr = P->df_ablk_ptr.p; f.ablk_slot = P->df_ablk_slot.p;
+  f.ablk_front = P->df_ablk_front.p; f.ablk_pos = P->df_ablk_pos.p; f.n_ablk = (int)S.ablk_front.size();
+  f.jobs = P->df_jobs.p; f.Fval = P->df_Fval.p; f.Winv = P->df_Winv.p; f.x = P->df_x.p;
+  P->front_usable = true;
+  if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] front: plan upload %.2f ms\n", 1e3 * seconds_since(t_up));
+  return PGO_OK;
+}
+
 int prepare_direct(pgo_problem* P) {
   if (P->direct_analyzed) return PGO_OK;
   P->direct_analyzed = true;
   P->direct_usable = false;
+  P->front_usable = false;
   const char* off = getenv("PGO_NO_DIRECT");
   if (off && off[0] == '1') return PGO_OK;
   if (P->comm && P->comm->world > 1) return PGO_OK;   // the factorisation needs every row: sharded runs use PCG to 1e-13
+  // PGO_FRONT=1: always the multifrontal solver; 0: never; default: for the graphs the enumerated schedule declines or
+  // would only serve per iteration (mesh-like: dense separators)
+  const char* fr = getenv("PGO_FRONT");
+  const int front_mode = !fr ? -1 : (fr[0] == '1' ? 1 : 0);
   pgo::DirectSymbolic& S = P->dsym;
-  const auto t_an = Clock::now();
-  const bool usable = pgo::direct_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side,
-                                          P->h_row_slot_begin, &S);
-  if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: symbolic analysis %.2f ms\n", 1e3 * seconds_since(t_an));
+  bool usable = false;
+  if (front_mode != 1) {
+    const auto t_an = Clock::now();
+    usable = pgo::direct_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side,
+                                 P->h_row_slot_begin, &S);
+    if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: symbolic analysis %.2f ms\n", 1e3 * seconds_since(t_an));
+  }
+  if (front_mode == 1 || (front_mode < 0 && (!usable || S.hybrid))) {
+    const int rc = prepare_front(P);
+    if (rc) return rc;
+    if (P->front_usable) {
+      S.hybrid = false;
+      P->direct_usable = true;
+      return PGO_OK;
+    }
+  }
   if (!usable) return PGO_OK;  // too much fill / too deep for the enumerated schedule: the iterative path serves the request
   const auto t_up = Clock::now();
   hipStream_t s = P->stream;
@@ -841,6 +906,11 @@ int prepare_direct(pgo_problem* P) {
 // factorise (H~ + D^2) and solve for cg_x = (H~ + D^2)^-1 S g; the launch sequence is static -> one hipGraph
 int run_direct(pgo_problem* P) {
   hipStream_t s = P->stream;
+  if (P->front_usable) {
+    pgo::launch_front_factor(P->g, P->fplan, P->fsym, s);
+    pgo::launch_front_solve(P->g, P->fplan, P->fsym, s);
+    return PGO_OK;
+  }
   const pgo::DirectSymbolic& S = P->dsym;
   if (P->use_graph && !P->direct_exec) {
     hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
@@ -1209,8 +1279,11 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
     summary->num_edges = P->g.E;
     const bool want_exact = P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY;
     summary->linear_solver_used = want_exact ? (P->direct_usable ? (P->dsym.hybrid ? 3 : 0) : 2) : 1;
-    summary->factor_nnz_blocks = (want_exact && P->direct_usable) ? P->dsym.nb : 0;
-    summary->factor_levels = (want_exact && P->direct_usable) ? P->dsym.n_levels : 0;
+    summary->factor_nnz_blocks = (want_exact && P->direct_usable) ? (P->front_usable ? (int)std::min<long long>(P->fsym.factor_blocks, 0x7fffffff) : P->dsym.nb) : 0;
+    summary->factor_levels = (want_exact && P->direct_usable) ? (P->front_usable ? P->fsym.n_levels : P->dsym.n_levels) : 0;
+    summary->factor_kind = (want_exact && P->direct_usable) ? (P->front_usable ? 2 : 1) : 0;
+    summary->factor_max_front = (want_exact && P->front_usable) ? P->fsym.max_front : 0;
+    summary->factor_flops = (want_exact && P->direct_usable) ? (P->front_usable ? P->fsym.flops : P->dsym.flops) : 0.0;
     summary->num_factorizations = L.n_factorizations;
     summary->initial_cost = L.initial_cost;
     summary->final_cost = L.x_cost;
@@ -1662,7 +1735,17 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     pgo::launch_pcg_init(P->g, s);
   }
   if (k == "pcg_update") pgo::launch_pcg_spmv_only(P->g, prm, 1, s);
+  const bool wants_factor = k == "direct" || k == "front_factor" || k == "front_solve";
+  if (wants_factor) {
+    if (!P->direct_usable) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): no GPU factorisation prepared for this problem", kernel);
+    if ((k != "direct") && !P->front_usable) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): the multifrontal solver is not in use", kernel);
+    pgo::launch_damping(P->g, P->lm.radius, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, 0, s);
+    if (k == "front_solve") pgo::launch_front_factor(P->g, P->fplan, P->fsym, s);
+  }
   auto once = [&]() -> int {
+    if (k == "direct") return run_direct(P);
+    if (k == "front_factor") { pgo::launch_front_factor(P->g, P->fplan, P->fsym, s); return 0; }
+    if (k == "front_solve") { pgo::launch_front_solve(P->g, P->fplan, P->fsym, s); return 0; }
     if (k == "linearize") pgo::launch_linearize(P->g, s);
     else if (k == "cost") pgo::launch_cost(P->g, P->g.pose_x, 5, s);
     else if (k == "evaluate") pgo::launch_evaluate_edges(P->g, P->g.pose_x, P->d_tmp_a.p, P->d_tmp_b.p, P->d_tmp_c.p, s);

@@ -1,0 +1,208 @@
+// tools/front_check_cli.cpp — development check of the multifrontal solver's HOST analysis (pgo_front.cpp) without a GPU:
+// runs front_analyze on an edge list, then executes the launch schedule with plain scalar loops that state what every
+// kernel of pgo_front_kernels.hip has to do (scatter, extend-add, POTRF + inverse, TRSM, GEMM, backward substitution) on
+// a random symmetric positive definite block matrix of that sparsity, and reports |A x - b| / |b|.
+// Test infrastructure only; the product never contains these loops.  Build: tools/Makefile (hipcc, host code only).
+// usage: front_check_cli <edges.txt>     (first line: N E, then E lines "id_begin id_end")
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../posegraph-ceres_amd/csrc/pgo_front.h"
+
+using namespace pgo;
+
+int main(int argc, char** argv) {
+  if (argc < 2) { std::fprintf(stderr, "usage: %s edges.txt\n", argv[0]); return 2; }
+  FILE* f = std::fopen(argv[1], "r");
+  if (!f) return 2;
+  int N = 0, E = 0;
+  if (std::fscanf(f, "%d %d", &N, &E) != 2) return 2;
+  std::vector<int> ia(E), ib(E);
+  for (int e = 0; e < E; ++e) if (std::fscanf(f, "%d %d", &ia[e], &ib[e]) != 2) return 2;
+  std::fclose(f);
+  std::vector<int> deg(N, 0), row_slot_begin(N, 0);
+  for (int e = 0; e < E; ++e) { ++deg[ia[e]]; ++deg[ib[e]]; }
+  int n_slots = 0;
+  for (int v = 0; v < N; ++v) { row_slot_begin[v] = n_slots; n_slots += 1 + deg[v]; }
+  std::vector<int> slot_row(n_slots), slot_col(n_slots), fill(N), slot_edge(n_slots, -1);
+  std::vector<uint8_t> slot_side(n_slots);
+  for (int v = 0; v < N; ++v) { const int t = row_slot_begin[v]; slot_row[t] = v; slot_col[t] = v; slot_side[t] = SIDE_DIAG; fill[v] = t + 1; }
+  for (int e = 0; e < E; ++e) {
+    int t = fill[ia[e]]++; slot_row[t] = ia[e]; slot_col[t] = ib[e]; slot_side[t] = SIDE_BEGIN; slot_edge[t] = e;
+    t = fill[ib[e]]++; slot_row[t] = ib[e]; slot_col[t] = ia[e]; slot_side[t] = SIDE_END; slot_edge[t] = e;
+  }
+  FrontSymbolic S;
+  const auto t0 = std::chrono::steady_clock::now();
+  const bool ok = front_analyze(N, ia, ib, n_slots, slot_row, slot_col, slot_side, 200LL << 30, &S);
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::printf("N %d E %d ok %d seconds %.3f fronts %d levels %d launches %d jobs %zu largest %d flops %.3e MB %.1f blocks %lld\n", N, E, ok ? 1 : 0, dt,
+              S.nf, S.n_levels, S.n_launches, S.jobs.size(), S.max_front, S.flops, 8e-6 * (double)S.fval_size, S.factor_blocks);
+  if (!ok) return 1;
+  if (argc > 2) {
+    for (int l = 0; l < S.n_levels; ++l) {
+      const FrontLevel& L = S.levels[l];
+      int mc = 0, mr = 0;
+      for (int q = L.front_begin; q < L.front_end; ++q) { mc = std::max(mc, S.fronts[q].c); mr = std::max(mr, S.fronts[q].r); }
+      std::printf("level %d fronts %d (with children %d) launches %d max c %d max r %d asm_wg %d\n", l, L.front_end - L.front_begin,
+                  L.front_end - L.asm_front_begin, L.launch_end - L.launch_begin, mc, mr, L.asm_wg);
+    }
+    if (argv[2][0] == 's') return 0;
+  }
+  // random SPD matrix in slot form: off-diagonal blocks random, diagonal = strictly dominant
+  std::mt19937_64 rng(7);
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  std::vector<double> eb((size_t)36 * E), slot_val((size_t)36 * n_slots, 0.0), b(6 * (size_t)N);
+  for (double& v : eb) v = U(rng);
+  for (double& v : b) v = U(rng);
+  std::vector<double> rowsum(6 * (size_t)N, 0.0);
+  for (int t = 0; t < n_slots; ++t) {
+    if (slot_side[t] == SIDE_DIAG) continue;
+    const double* B = &eb[(size_t)36 * slot_edge[t]];
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) {
+        const double v = slot_side[t] == SIDE_BEGIN ? B[6 * r + c] : B[6 * c + r];
+        slot_val[(size_t)36 * t + 6 * r + c] = v;
+        rowsum[6 * (size_t)slot_row[t] + r] += std::fabs(v);
+      }
+  }
+  for (int v = 0; v < N; ++v) {
+    double* D = &slot_val[(size_t)36 * row_slot_begin[v]];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c <= r; ++c) { const double x = 0.1 * U(rng); D[6 * r + c] += x; if (c != r) D[6 * c + r] += x; }
+    for (int r = 0; r < 6; ++r) D[7 * r] += 1.0 + rowsum[6 * (size_t)v + r];
+  }
+  // ---- the device algorithm, in scalar loops ----
+  std::vector<double> F((size_t)S.fval_size, 0.0), W((size_t)S.winv_size, 0.0), x(6 * (size_t)N, 0.0);
+  // scatter: BSR blocks and the right-hand side row
+  for (size_t a = 0; a + 1 < S.ablk_ptr.size(); ++a) {
+    const FrontDesc& D = S.fronts[S.ablk_front[a]];
+    const int bi = S.ablk_pos[a] >> 16, bj = S.ablk_pos[a] & 0xffff;
+    for (int q = S.ablk_ptr[a]; q < S.ablk_ptr[a + 1]; ++q)
+      for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c)
+        F[D.fbase + (size_t)(6 * bi + r) * D.ld + 6 * bj + c] += slot_val[(size_t)36 * S.ablk_slot[q] + 6 * r + c];
+  }
+  for (int j = 0; j < N; ++j) {
+    const FrontDesc& D = S.fronts[S.col_front[j]];
+    const int n = 6 * (D.c + D.r);
+    for (int k = 0; k < 6; ++k) F[D.fbase + (size_t)n * D.ld + 6 * (j - D.first) + k] = b[6 * (size_t)S.perm[j] + k];
+  }
+  bool bad_pivot = false;
+  for (int l = 0; l < S.n_levels; ++l) {
+    const FrontLevel& L = S.levels[l];
+    // extend-add (children in list order)
+    for (int q = L.asm_front_begin; q < L.front_end; ++q) {
+      const FrontDesc& P = S.fronts[q];
+      const int np = 6 * (P.c + P.r);
+      for (int ci = P.child_begin; ci < P.child_end; ++ci) {
+        const FrontDesc& C = S.fronts[S.child[ci]];
+        const int nc = 6 * (C.c + C.r);
+        const int* rel = &S.rel[C.rel_begin];
+        for (int k = 0; k <= C.r; ++k) {          // k == C.r: the right-hand side row
+          const int prow = k < C.r ? 6 * rel[k] : np;
+          const int crow = k < C.r ? 6 * (C.c + k) : nc;
+          const int nr = k < C.r ? 6 : 1;
+          for (int m = 0; m <= std::min(k, C.r - 1); ++m)
+            for (int a = 0; a < nr; ++a) for (int bb = 0; bb < 6; ++bb)
+              F[P.fbase + (size_t)(prow + a) * P.ld + 6 * rel[m] + bb] += F[C.fbase + (size_t)(crow + a) * C.ld + 6 * (C.c + m) + bb];
+        }
+      }
+    }
+    for (int li = L.launch_begin; li < L.launch_end; ++li) {
+      const FrontLaunch& La = S.launches[li];
+      for (int ji = La.job_begin; ji < La.job_end; ++ji) {
+        const FrontJob& J = S.jobs[ji];
+        double* A = &F[J.fbase];
+        if (La.type == FrontLaunch::POTRF) {
+          const int nb = J.klen;
+          double* Wp = &W[J.wbase];
+          for (int k = 0; k < nb; ++k) {
+            double d = A[(size_t)(J.k0 + k) * J.ld + J.k0 + k];
+            for (int m = 0; m < k; ++m) { const double v = A[(size_t)(J.k0 + k) * J.ld + J.k0 + m]; d -= v * v; }
+            if (!(d > 0.0)) bad_pivot = true;
+            d = std::sqrt(d);
+            A[(size_t)(J.k0 + k) * J.ld + J.k0 + k] = d;
+            for (int i = k + 1; i < nb; ++i) {
+              double s = A[(size_t)(J.k0 + i) * J.ld + J.k0 + k];
+              for (int m = 0; m < k; ++m) s -= A[(size_t)(J.k0 + i) * J.ld + J.k0 + m] * A[(size_t)(J.k0 + k) * J.ld + J.k0 + m];
+              A[(size_t)(J.k0 + i) * J.ld + J.k0 + k] = s / d;
+            }
+          }
+          for (int j = 0; j < FRONT_NB * FRONT_NB; ++j) Wp[j] = 0.0;
+          for (int j = 0; j < nb; ++j)
+            for (int i = j; i < nb; ++i) {
+              double s = i == j ? 1.0 : 0.0;
+              for (int m = j; m < i; ++m) s -= A[(size_t)(J.k0 + i) * J.ld + J.k0 + m] * Wp[m * FRONT_NB + j];
+              Wp[i * FRONT_NB + j] = s / A[(size_t)(J.k0 + i) * J.ld + J.k0 + i];
+            }
+        } else if (La.type == FrontLaunch::TRSM) {
+          const int nb = J.klen;
+          const double* Wp = &W[J.wbase];
+          double tmp[FRONT_NB];
+          for (int i = J.r0; i < J.r1; ++i) {
+            for (int c = 0; c < nb; ++c) {
+              double s = 0.0;
+              for (int m = 0; m < nb; ++m) s += A[(size_t)i * J.ld + J.k0 + m] * Wp[c * FRONT_NB + m];
+              tmp[c] = s;
+            }
+            for (int c = 0; c < nb; ++c) A[(size_t)i * J.ld + J.k0 + c] = tmp[c];
+          }
+        } else {
+          for (int i = J.r0; i < J.r1; ++i)
+            for (int c = J.c0; c < std::min(J.c1, i + 1); ++c) {
+              double s = 0.0;
+              for (int m = 0; m < J.klen; ++m) s += A[(size_t)i * J.ld + J.k0 + m] * A[(size_t)c * J.ld + J.k0 + m];
+              A[(size_t)i * J.ld + c] -= s;
+            }
+        }
+      }
+    }
+  }
+  // backward substitution, top level first
+  for (int l = S.n_levels - 1; l >= 0; --l) {
+    const FrontLevel& L = S.levels[l];
+    for (int q = L.front_begin; q < L.front_end; ++q) {
+      const FrontDesc& D = S.fronts[q];
+      const int c6 = 6 * D.c, n = 6 * (D.c + D.r);
+      const double* A = &F[D.fbase];
+      std::vector<double> t(c6);
+      for (int j = 0; j < c6; ++j) {
+        double s = A[(size_t)n * D.ld + j];
+        for (int i = c6; i < n; ++i) s -= A[(size_t)i * D.ld + j] * x[6 * (size_t)S.idx[D.idx_begin + (i - c6) / 6] + (i - c6) % 6];
+        t[j] = s;
+      }
+      const int npanels = (c6 + FRONT_NB - 1) / FRONT_NB;
+      for (int p = npanels - 1; p >= 0; --p) {
+        const int k0 = p * FRONT_NB, nb = std::min<int>(FRONT_NB, c6 - k0);
+        const double* Wp = &W[D.wbase + (size_t)p * FRONT_NB * FRONT_NB];
+        double xs[FRONT_NB];
+        for (int a = 0; a < nb; ++a) {
+          double s = 0.0;
+          for (int bq = a; bq < nb; ++bq) s += Wp[bq * FRONT_NB + a] * t[k0 + bq];
+          xs[a] = s;
+        }
+        for (int a = 0; a < nb; ++a) x[6 * (size_t)D.first + k0 + a] = xs[a];
+        for (int j = 0; j < k0; ++j) {
+          double s = 0.0;
+          for (int a = 0; a < nb; ++a) s += A[(size_t)(k0 + a) * D.ld + j] * xs[a];
+          t[j] -= s;
+        }
+      }
+    }
+  }
+  // residual in the original numbering
+  std::vector<double> xo(6 * (size_t)N), res(b);
+  for (int j = 0; j < N; ++j) for (int k = 0; k < 6; ++k) xo[6 * (size_t)S.perm[j] + k] = x[6 * (size_t)j + k];
+  for (int t = 0; t < n_slots; ++t)
+    for (int r = 0; r < 6; ++r) {
+      double s = 0.0;
+      for (int c = 0; c < 6; ++c) s += slot_val[(size_t)36 * t + 6 * r + c] * xo[6 * (size_t)slot_col[t] + c];
+      res[6 * (size_t)slot_row[t] + r] -= s;
+    }
+  double rn = 0.0, bn = 0.0;
+  for (size_t i = 0; i < res.size(); ++i) { rn += res[i] * res[i]; bn += b[i] * b[i]; }
+  std::printf("bad_pivot %d relative residual %.3e\n", bad_pivot ? 1 : 0, std::sqrt(rn / bn));
+  return std::sqrt(rn / bn) < 1e-10 && !bad_pivot ? 0 : 1;
+}
