@@ -6,7 +6,8 @@
 //     MI355X retires the extra flops in microseconds, a tree level costs tens of microseconds of dependent launches);
 //  3. postorder renumbering so every supernode owns consecutive columns; row structures recomputed in that numbering;
 //  4. fronts numbered level by level (leaves first), child -> parent index maps, BSR source lists per front block;
-//  5. the launch schedule: per level and panel step one POTRF, one TRSM and one GEMM launch over all fronts of the level.
+//  5. the launch schedule: per level and 48-column panel step ONE launch over all fronts of the level, plus one GEMM launch
+//     behind every finished 192-column outer panel / for the Schur updates.
 #include "pgo_front.h"
 
 #include <algorithm>
@@ -279,6 +280,21 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
       }
     }
   }
+  // tile starts of every child inside its parent (extend-add: no searching on the device)
+  for (int f = 0; f < nf; ++f) {
+    FrontDesc& D = S.fronts[f];
+    D.cs_begin = (int)S.cstart.size();
+    D.pad = 0;
+    if (D.parent < 0) continue;
+    const int ntp = S.fronts[D.parent].ntp;
+    const int* rel = S.rel.data() + D.rel_begin;
+    int k = 0;
+    for (int t = 0; t <= ntp; ++t) {
+      while (k < D.r && rel[k] < FRONT_ASM_TP * t) ++k;
+      S.cstart.push_back(k);
+    }
+  }
+  if (S.cstart.empty()) S.cstart.push_back(0);
   if (S.rel.empty()) S.rel.push_back(0);
   if (S.idx.empty()) S.idx.push_back(0);
   if (S.child.empty()) S.child.push_back(0);
@@ -322,6 +338,9 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
     S.ablk_ptr.push_back((int)ents.size());
   }
   // ---- 10. schedule ----
+  // Per level and panel step s: one PANEL launch over every front of the level that has a panel s, then (if any front
+  // needs it) one GEMM launch: the right-looking update behind an outer panel that just finished, or the Schur update of
+  // a front whose last panel was s.
   S.levels.resize(n_levels);
   {
     int f = 0;
@@ -339,59 +358,60 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
         wg += (S.fronts[q].ntp + 1) * S.fronts[q].ntp;
       }
       L.asm_wg = wg;
-      L.max_threads_bwd = 0;
+      L.bwd_wg_begin = (int)S.bwd_front.size();
+      for (int q = L.front_begin; q < L.front_end; ++q)
+        for (int ch = 0; ch < (6 * S.fronts[q].c + 63) / 64; ++ch) { S.bwd_front.push_back(q); S.bwd_chunk.push_back(ch); }
+      L.bwd_wg = (int)S.bwd_front.size() - L.bwd_wg_begin;
       L.launch_begin = (int)S.launches.size();
       int max_steps = 0;
       for (int q = L.front_begin; q < L.front_end; ++q) max_steps = std::max(max_steps, (6 * S.fronts[q].c + FRONT_NB - 1) / FRONT_NB);
       for (int step = 0; step < max_steps; ++step) {
-        FrontLaunch lp{FrontLaunch::POTRF, (int)S.jobs.size(), 0, 0};
-        for (int q = L.front_begin; q < L.front_end; ++q) {
-          const FrontDesc& D = S.fronts[q];
-          const int c6 = 6 * D.c, k0 = step * FRONT_NB;
-          if (k0 >= c6) continue;
-          const int nb = std::min<int>(FRONT_NB, c6 - k0);
-          FrontJob J{D.fbase, D.ld, k0, k0 + nb, k0, k0 + nb, k0, nb, D.wbase + step * FRONT_NB * FRONT_NB, lp.n_wg, 1};
-          S.jobs.push_back(J);
-          lp.n_wg += 1;
-        }
-        lp.job_end = (int)S.jobs.size();
-        S.launches.push_back(lp);
-        FrontLaunch lt{FrontLaunch::TRSM, (int)S.jobs.size(), 0, 0};
+        FrontLaunch lp{FrontLaunch::PANEL, 0, (int)S.wg_job.size()};
         for (int q = L.front_begin; q < L.front_end; ++q) {
           const FrontDesc& D = S.fronts[q];
           const int c6 = 6 * D.c, n = 6 * (D.c + D.r), k0 = step * FRONT_NB;
           if (k0 >= c6) continue;
           const int nb = std::min<int>(FRONT_NB, c6 - k0), kend = k0 + nb;
-          FrontJob J{D.fbase, D.ld, kend, n + 1, k0, kend, k0, nb, D.wbase + step * FRONT_NB * FRONT_NB, lt.n_wg, 1};
-          S.jobs.push_back(J);
-          lt.n_wg += (n + 1 - kend + FRONT_TILE - 1) / FRONT_TILE;
+          const int ostart = (k0 / FRONT_NBO) * FRONT_NBO;
+          const int job = (int)S.jobs.size();
+          S.jobs.push_back(FrontJob{D.fbase, D.ld, kend, n + 1, ostart, 0, k0, nb, D.wbase + step * FRONT_NB * FRONT_NB});
+          const int ntr = (n + 1 - kend + FRONT_TILE - 1) / FRONT_TILE;
+          for (int t = 0; t < ntr; ++t) { S.wg_job.push_back(job); S.wg_tile.push_back(t << 16); }
         }
-        lt.job_end = (int)S.jobs.size();
-        S.launches.push_back(lt);
-        FrontLaunch lg{FrontLaunch::GEMM, (int)S.jobs.size(), 0, 0};
+        lp.n_wg = (int)S.wg_job.size() - lp.wg_begin;
+        S.launches.push_back(lp);
+        FrontLaunch lg{FrontLaunch::GEMM, 0, (int)S.wg_job.size()};
         for (int q = L.front_begin; q < L.front_end; ++q) {
           const FrontDesc& D = S.fronts[q];
           const int c6 = 6 * D.c, n = 6 * (D.c + D.r), k0 = step * FRONT_NB;
           if (k0 >= c6) continue;
           const int nb = std::min<int>(FRONT_NB, c6 - k0), kend = k0 + nb;
           const int ostart = (k0 / FRONT_NBO) * FRONT_NBO, oend = std::min(c6, ostart + FRONT_NBO);
+          if (kend < oend) continue;                    // still inside the outer panel
           int r0, r1, cc0, cc1, kk0, klen;
-          if (kend < oend) { r0 = kend; r1 = n + 1; cc0 = kend; cc1 = oend; kk0 = k0; klen = nb; }
-          else if (oend < c6) { r0 = oend; r1 = n + 1; cc0 = oend; cc1 = c6; kk0 = ostart; klen = oend - ostart; }
+          if (oend < c6) { r0 = oend; r1 = n + 1; cc0 = oend; cc1 = c6; kk0 = ostart; klen = oend - ostart; }
           else { r0 = c6; r1 = n + 1; cc0 = c6; cc1 = n; kk0 = 0; klen = c6; }
           if (cc1 <= cc0) continue;
+          const int job = (int)S.jobs.size();
+          S.jobs.push_back(FrontJob{D.fbase, D.ld, r0, r1, cc0, cc1, kk0, klen, 0});
           const int ntr = (r1 - r0 + FRONT_TILE - 1) / FRONT_TILE, ntc = (cc1 - cc0 + FRONT_TILE - 1) / FRONT_TILE;
-          FrontJob J{D.fbase, D.ld, r0, r1, cc0, cc1, kk0, klen, 0, lg.n_wg, ntc};
-          S.jobs.push_back(J);
-          lg.n_wg += ntr * ntc;
+          for (int ti = 0; ti < ntr; ++ti)
+            for (int tj = 0; tj < ntc; ++tj) {
+              const int row_last = std::min(r0 + FRONT_TILE * (ti + 1), r1) - 1;
+              if (row_last < cc0 + FRONT_TILE * tj) continue;   // entirely above the diagonal
+              S.wg_job.push_back(job);
+              S.wg_tile.push_back((ti << 16) | tj);
+            }
         }
-        lg.job_end = (int)S.jobs.size();
+        lg.n_wg = (int)S.wg_job.size() - lg.wg_begin;
         if (lg.n_wg > 0) S.launches.push_back(lg);
       }
       L.launch_end = (int)S.launches.size();
     }
   }
-  S.n_launches = (int)S.launches.size() + 2 * n_levels + 2;
+  if (S.wg_job.empty()) { S.wg_job.push_back(0); S.wg_tile.push_back(0); }
+  if (S.bwd_front.empty()) { S.bwd_front.push_back(0); S.bwd_chunk.push_back(0); }
+  S.n_launches = (int)S.launches.size() + 3 * n_levels + 2;
   S.est_us = 4.0 * S.n_launches + flops / 2.0e7;   // ~4 us per dependent launch, ~20 TFLOP/s sustained
   if (getenv("PGO_VERBOSE"))
     std::fprintf(stderr, "[pgo] front: n=%d supernodes %d -> %d fronts, %d levels, %d launches, largest front %d, %.3g flops, %.1f MB, est %.0f us\n",

@@ -11,11 +11,12 @@
 //                              [F11 . ; F21 F22] over its c own poses + r update poses, tree levels, launch schedule;
 //   device, every LM iteration: scatter the BSR blocks + the right-hand side into the fronts, then per tree level
 //                              (leaves first): extend-add of the children's update matrices (gather per parent tile,
-//                              fixed child order: deterministic, no atomics), blocked right-looking factorisation of
-//                              the c own columns (48-wide panels: POTRF + explicit inverse of the diagonal block in
-//                              one workgroup; TRSM and all updates as v_mfma_f64_16x16x4_f64 GEMMs; two-level blocking,
-//                              192-wide outer panels, so the trailing updates run with K = 192), Schur update
-//                              U = F22 - L21 L21^T with K = 6c in one GEMM launch.
+//                              fixed child order: deterministic, no atomics), blocked factorisation of the c own
+//                              columns with ONE launch per 48-wide panel (left-looking inside 192-wide outer panels:
+//                              every row-tile workgroup forms and factorises the 48 x 48 diagonal block itself — one
+//                              wave, registers — and does its own TRSM; all sums and the TRSM are
+//                              v_mfma_f64_16x16x4_f64), one right-looking GEMM launch per outer panel (K = 192) and the
+//                              Schur update U = F22 - L21 L21^T with K = 6c.
 //                              The right-hand side rides along as ONE EXTRA ROW of every front (Cholesky of the
 //                              bordered matrix [[A b],[b' .]] leaves y = L^-1 b in that row), so the forward
 //                              substitution costs nothing of its own; the backward substitution walks the tree
@@ -35,22 +36,27 @@ namespace pgo {
 
 enum { FRONT_NB = 48, FRONT_NBO = 192, FRONT_TILE = 64, FRONT_ASM_TP = 8 };
 
-// One unit of dense work on a front.  POTRF: the diagonal block [k0, k0+klen); TRSM: rows [r0, r1) of the panel
-// [k0, k0+klen) times W^T (W = inverse of the panel's diagonal block); GEMM: C[r0:r1, c0:c1] -= F[r0:r1, k0:k0+klen) *
-// F[c0:c1, k0:k0+klen)^T, tiles entirely above the diagonal skipped.
+// One unit of dense work on a front.
+//   PANEL: columns [k0, k0 + klen) (klen <= 48), left-looking inside the 192-wide outer panel that starts at column c0:
+//          every workgroup (one per 64-row tile of the rows [r0, r1) below the diagonal block) forms
+//          D = F[kb, kb] - sum_{m in [c0, k0)} L[kb, m] L[kb, m]^T, factorises it (one wave, registers) and inverts the
+//          factor (W = L_kk^-1, also stored at Winv + wbase for the backward substitution), then computes ITS rows
+//          L[i, kb] = (F[i, kb] - sum_m L[i, m] L[kb, m]^T) W^T on the matrix cores.  The diagonal block itself is
+//          never written back (nothing reads L_kk: the triangular solves use W).
+//   GEMM : C[r0:r1, c0:c1] -= F[r0:r1, k0:k0+klen) * F[c0:c1, k0:k0+klen)^T (right-looking update of everything
+//          behind an outer panel, K = 192; Schur update U = F22 - L21 L21^T, K = 6c), lower tiles only.
 struct FrontJob {
   long long fbase;   // offset of the front in Fval (doubles)
   int ld;
   int r0, r1, c0, c1;
   int k0, klen;
-  int wbase;         // offset of the panel's W in Winv (doubles)
-  int wg_begin;      // first workgroup of the job inside its launch
-  int ntc;           // GEMM: tiles per tile row
+  int wbase;         // PANEL: offset of the panel's W in Winv (doubles)
 };
 
 struct FrontLaunch {
-  enum Type { POTRF = 0, TRSM = 1, GEMM = 2 };
-  int type, job_begin, job_end, n_wg;
+  enum Type { PANEL = 0, GEMM = 2 };
+  int type, n_wg;
+  int wg_begin;      // workgroup w of the launch runs job wg_job[wg_begin + w] on tile wg_tile[wg_begin + w] = (ti << 16) | tj
 };
 
 struct FrontLevel {
@@ -58,7 +64,7 @@ struct FrontLevel {
   int launch_begin, launch_end;
   int asm_front_begin;            // fronts [asm_front_begin, front_end) have children (sorted last inside the level)
   int asm_wg;                     // grid of the extend-add launch
-  int max_threads_bwd;            // (unused on the device; statistics)
+  int bwd_wg_begin, bwd_wg;       // backward substitution, phase A: workgroup w handles columns 64 * bwd_chunk[.] of front bwd_front[.]
 };
 
 // Per-front descriptor on the device.
@@ -70,10 +76,12 @@ struct FrontDesc {
   int idx_begin;    // update rows: idx[idx_begin .. idx_begin + r)   (new numbering, ascending)
   int child_begin, child_end;   // children: child[child_begin .. child_end)
   int rel_begin;    // as a child: rel[rel_begin .. rel_begin + r) = position (pose units) of each update row in the parent's front
+  int cs_begin;     // as a child: cstart[cs_begin + t] = first update row whose parent position is >= 8 t, t = 0 .. parent ntp
   int wbase;        // W of panel p at Winv + wbase + p * FRONT_NB * FRONT_NB
   int asm_wg_begin; // first workgroup of this front in its level's extend-add launch
   int ntp;          // pose tiles of FRONT_ASM_TP per side
   int parent;
+  int pad;
 };
 
 struct FrontPlan {
@@ -83,6 +91,7 @@ struct FrontPlan {
   const int* idx;
   const int* child;
   const int* rel;
+  const int* cstart;
   const int* col_front;     // [n] front owning each column (new numbering)
   const int* ablk_ptr;      // [n_ablk+1] BSR slots summed into one 6x6 block of a front
   const int* ablk_slot;
@@ -90,16 +99,20 @@ struct FrontPlan {
   const int* ablk_pos;      // [n_ablk] (bi << 16) | bj, pose units inside the front
   int n_ablk;
   const FrontJob* jobs;
+  const int* wg_job;
+  const int* wg_tile;
+  const int* bwd_front;
+  const int* bwd_chunk;
   double* Fval;
   double* Winv;
-  double* x;                // [6n] solution, new numbering
+  double* x;                // [6n] solution, new numbering (the backward substitution keeps t = y - L21^T x_r here in between)
 };
 
 struct FrontSymbolic {
   int n = 0, nf = 0, n_levels = 0;
   std::vector<int> perm, iperm;
   std::vector<FrontDesc> fronts;
-  std::vector<int> idx, child, rel, col_front;
+  std::vector<int> idx, child, rel, cstart, col_front, wg_job, wg_tile, bwd_front, bwd_chunk;
   std::vector<int> ablk_ptr, ablk_slot, ablk_front, ablk_pos;
   std::vector<FrontJob> jobs;
   std::vector<FrontLaunch> launches;

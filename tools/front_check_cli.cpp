@@ -112,42 +112,55 @@ int main(int argc, char** argv) {
     }
     for (int li = L.launch_begin; li < L.launch_end; ++li) {
       const FrontLaunch& La = S.launches[li];
-      for (int ji = La.job_begin; ji < La.job_end; ++ji) {
+      // the jobs of a launch = the distinct entries of its workgroup -> job map (consecutive)
+      int prev = -1;
+      for (int w = La.wg_begin; w < La.wg_begin + La.n_wg; ++w) {
+        const int ji = S.wg_job[w];
+        if (ji == prev) continue;
+        prev = ji;
         const FrontJob& J = S.jobs[ji];
         double* A = &F[J.fbase];
-        if (La.type == FrontLaunch::POTRF) {
-          const int nb = J.klen;
+        if (La.type == FrontLaunch::PANEL) {
+          const int nb = J.klen, k0 = J.k0;
+          double Dk[FRONT_NB][FRONT_NB], Lk[FRONT_NB][FRONT_NB];
           double* Wp = &W[J.wbase];
+          for (int i = 0; i < nb; ++i)
+            for (int j = 0; j <= i; ++j) {
+              double s = A[(size_t)(k0 + i) * J.ld + k0 + j];
+              for (int m = J.c0; m < k0; ++m) s -= A[(size_t)(k0 + i) * J.ld + m] * A[(size_t)(k0 + j) * J.ld + m];
+              Dk[i][j] = s;
+            }
           for (int k = 0; k < nb; ++k) {
-            double d = A[(size_t)(J.k0 + k) * J.ld + J.k0 + k];
-            for (int m = 0; m < k; ++m) { const double v = A[(size_t)(J.k0 + k) * J.ld + J.k0 + m]; d -= v * v; }
+            double d = Dk[k][k];
+            for (int m = 0; m < k; ++m) d -= Lk[k][m] * Lk[k][m];
             if (!(d > 0.0)) bad_pivot = true;
             d = std::sqrt(d);
-            A[(size_t)(J.k0 + k) * J.ld + J.k0 + k] = d;
+            Lk[k][k] = d;
             for (int i = k + 1; i < nb; ++i) {
-              double s = A[(size_t)(J.k0 + i) * J.ld + J.k0 + k];
-              for (int m = 0; m < k; ++m) s -= A[(size_t)(J.k0 + i) * J.ld + J.k0 + m] * A[(size_t)(J.k0 + k) * J.ld + J.k0 + m];
-              A[(size_t)(J.k0 + i) * J.ld + J.k0 + k] = s / d;
+              double s = Dk[i][k];
+              for (int m = 0; m < k; ++m) s -= Lk[i][m] * Lk[k][m];
+              Lk[i][k] = s / d;
             }
           }
           for (int j = 0; j < FRONT_NB * FRONT_NB; ++j) Wp[j] = 0.0;
           for (int j = 0; j < nb; ++j)
             for (int i = j; i < nb; ++i) {
               double s = i == j ? 1.0 : 0.0;
-              for (int m = j; m < i; ++m) s -= A[(size_t)(J.k0 + i) * J.ld + J.k0 + m] * Wp[m * FRONT_NB + j];
-              Wp[i * FRONT_NB + j] = s / A[(size_t)(J.k0 + i) * J.ld + J.k0 + i];
+              for (int m = j; m < i; ++m) s -= Lk[i][m] * Wp[m * FRONT_NB + j];
+              Wp[i * FRONT_NB + j] = s / Lk[i][i];
             }
-        } else if (La.type == FrontLaunch::TRSM) {
-          const int nb = J.klen;
-          const double* Wp = &W[J.wbase];
-          double tmp[FRONT_NB];
+          double pr[FRONT_NB];
           for (int i = J.r0; i < J.r1; ++i) {
             for (int c = 0; c < nb; ++c) {
-              double s = 0.0;
-              for (int m = 0; m < nb; ++m) s += A[(size_t)i * J.ld + J.k0 + m] * Wp[c * FRONT_NB + m];
-              tmp[c] = s;
+              double s = A[(size_t)i * J.ld + k0 + c];
+              for (int m = J.c0; m < k0; ++m) s -= A[(size_t)i * J.ld + m] * A[(size_t)(k0 + c) * J.ld + m];
+              pr[c] = s;
             }
-            for (int c = 0; c < nb; ++c) A[(size_t)i * J.ld + J.k0 + c] = tmp[c];
+            for (int c = 0; c < nb; ++c) {
+              double s = 0.0;
+              for (int m = 0; m <= c; ++m) s += pr[m] * Wp[c * FRONT_NB + m];
+              A[(size_t)i * J.ld + k0 + c] = s;
+            }
           }
         } else {
           for (int i = J.r0; i < J.r1; ++i)
