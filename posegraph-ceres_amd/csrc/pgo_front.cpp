@@ -362,6 +362,30 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
       for (int q = L.front_begin; q < L.front_end; ++q)
         for (int ch = 0; ch < (6 * S.fronts[q].c + 63) / 64; ++ch) { S.bwd_front.push_back(q); S.bwd_chunk.push_back(ch); }
       L.bwd_wg = (int)S.bwd_front.size() - L.bwd_wg_begin;
+      // phase B: x_c = L11^-T t in 192-column blocks, last block first.  Step s: every front with more than s blocks lets
+      // its block nblk - s update the chunks below it (one workgroup per chunk); the workgroup of chunk nblk - 1 - s then
+      // solves that chunk's diagonal block.  Step 0 has no source block: the last chunk is solved.
+      {
+        int max_blk = 0;
+        for (int q = L.front_begin; q < L.front_end; ++q) max_blk = std::max(max_blk, (6 * S.fronts[q].c + FRONT_NBO - 1) / FRONT_NBO);
+        L.bwd_step_begin = (int)S.bwd_step_ptr.size();
+        L.bwd_steps = max_blk;
+        for (int st = 0; st < max_blk; ++st) {
+          S.bwd_step_ptr.push_back((int)S.bwdb_front.size());
+          for (int q = L.front_begin; q < L.front_end; ++q) {
+            const int nblk = (6 * S.fronts[q].c + FRONT_NBO - 1) / FRONT_NBO;
+            if (st >= nblk) continue;
+            const int src = nblk - st;            // == nblk at step 0: no source block
+            const int solver = nblk - 1 - st;
+            for (int ch = 0; ch <= solver; ++ch) {
+              if (st == 0 && ch != solver) continue;
+              S.bwdb_front.push_back(q);
+              S.bwdb_chunk.push_back(((st == 0 ? solver : src) << 16) | ch);
+            }
+          }
+        }
+        S.bwd_step_ptr.push_back((int)S.bwdb_front.size());
+      }
       L.launch_begin = (int)S.launches.size();
       int max_steps = 0;
       for (int q = L.front_begin; q < L.front_end; ++q) max_steps = std::max(max_steps, (6 * S.fronts[q].c + FRONT_NB - 1) / FRONT_NB);
@@ -411,6 +435,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
   }
   if (S.wg_job.empty()) { S.wg_job.push_back(0); S.wg_tile.push_back(0); }
   if (S.bwd_front.empty()) { S.bwd_front.push_back(0); S.bwd_chunk.push_back(0); }
+  if (S.bwdb_front.empty()) { S.bwdb_front.push_back(0); S.bwdb_chunk.push_back(0); }
   S.n_launches = (int)S.launches.size() + 3 * n_levels + 2;
   S.est_us = 4.0 * S.n_launches + flops / 2.0e7;   // ~4 us per dependent launch, ~20 TFLOP/s sustained
   if (getenv("PGO_VERBOSE"))

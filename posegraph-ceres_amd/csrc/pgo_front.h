@@ -65,6 +65,7 @@ struct FrontLevel {
   int asm_front_begin;            // fronts [asm_front_begin, front_end) have children (sorted last inside the level)
   int asm_wg;                     // grid of the extend-add launch
   int bwd_wg_begin, bwd_wg;       // backward substitution, phase A: workgroup w handles columns 64 * bwd_chunk[.] of front bwd_front[.]
+  int bwd_step_begin, bwd_steps;  // phase B: steps [bwd_step_begin, +bwd_steps) of bwd_step_ptr (one launch each)
 };
 
 // Per-front descriptor on the device.
@@ -103,6 +104,8 @@ struct FrontPlan {
   const int* wg_tile;
   const int* bwd_front;
   const int* bwd_chunk;
+  const int* bwdb_front;    // phase B workgroups: front ...
+  const int* bwdb_chunk;    // ... and (source block << 16) | target chunk, FRONT_NBO columns per chunk; source == target: solve only
   double* Fval;
   double* Winv;
   double* x;                // [6n] solution, new numbering (the backward substitution keeps t = y - L21^T x_r here in between)
@@ -112,7 +115,7 @@ struct FrontSymbolic {
   int n = 0, nf = 0, n_levels = 0;
   std::vector<int> perm, iperm;
   std::vector<FrontDesc> fronts;
-  std::vector<int> idx, child, rel, cstart, col_front, wg_job, wg_tile, bwd_front, bwd_chunk;
+  std::vector<int> idx, child, rel, cstart, col_front, wg_job, wg_tile, bwd_front, bwd_chunk, bwdb_front, bwdb_chunk, bwd_step_ptr;
   std::vector<int> ablk_ptr, ablk_slot, ablk_front, ablk_pos;
   std::vector<FrontJob> jobs;
   std::vector<FrontLaunch> launches;

@@ -8,7 +8,7 @@
 //                          (c) TRSM  L_i = P_i W^T                                                     v_mfma_f64_16x16x4_f64
 //   k_front_gemm         right-looking update behind an outer panel / Schur update  C -= A B^T        v_mfma_f64_16x16x4_f64
 //   k_front_bwd_gemv     backward substitution, t = y_c - L21^T x_r, 64 columns per workgroup
-//   k_front_bwd_tri      backward substitution, x_c = L11^-T t through the stored W blocks, one workgroup per front
+//   k_front_bwd_block    backward substitution, x_c = L11^-T t in 192-column blocks through the stored W blocks
 //
 // MFMA operand mapping (v_mfma_f64_16x16x4_f64, guide cdna_hip_programming.md §3): lane l supplies A[i = l & 15][k = l >> 4]
 // and B[k = l >> 4][j = l & 15]; it receives D[row = (l >> 4) + 4 reg][col = l & 15], reg = 0..3.  Every product here is
@@ -430,47 +430,85 @@ __global__ __launch_bounds__(BWD_T) void k_front_bwd_gemv(FrontPlan p, int wg_be
   }
 }
 
-// Phase B: x_c = L11^-T t, panels last to first: x_k = W_k^T t_k, then t[j] -= sum_a L[k0 + a][j] x_k[a] for j < k0.
-// One workgroup per front.  Dynamic LDS: t[c6] | red[512].
-__global__ __launch_bounds__(BWD_T) void k_front_bwd_tri(DeviceGraph g, FrontPlan p, int front_begin) {
-  extern __shared__ double sh[];
-  const FrontDesc D = p.fronts[front_begin + blockIdx.x];
+// Phase B: x_c = L11^-T t in 192-column blocks, last block first (schedule: pgo_front.cpp).  One workgroup per
+// (source block, target chunk): t_chunk -= L[source rows, chunk columns]^T x_source; the workgroup of the chunk right
+// below the source then solves the chunk's own diagonal block panel by panel (x_k = W_k^T t_k, then
+// t[j] -= sum_a L[k0 + a][j] x_k[a] for the chunk's columns j < k0) and publishes x.
+__global__ __launch_bounds__(BWD_T) void k_front_bwd_block(DeviceGraph g, FrontPlan p, int wg_begin) {
+  __shared__ double xs[FRONT_NBO];
+  __shared__ double tv[FRONT_NBO];
+  __shared__ double red[BWD_T];
+  const int wgi = wg_begin + blockIdx.x;
+  const FrontDesc D = p.fronts[p.bwdb_front[wgi]];
+  const int code = p.bwdb_chunk[wgi], src = code >> 16, ch = code & 0xffff;
   const int c6 = 6 * D.c, tid = threadIdx.x;
-  double* tv = sh;
-  double* red = sh + c6;
+  const int c0 = FRONT_NBO * ch, c1 = min(c0 + FRONT_NBO, c6), ncol = c1 - c0;
+  const bool solve_only = src == ch, solver = solve_only || ch == src - 1;
+  double* xb = p.x + 6 * (size_t)D.first;
   const double* F = p.Fval + D.fbase;
   const int ld = D.ld;
-  for (int j = tid; j < c6; j += BWD_T) tv[j] = p.x[6 * (size_t)D.first + j];
-  __syncthreads();
   const int jl = tid & 63, rg = tid >> 6;
   constexpr int NG = BWD_T / 64;
-  const int npanels = (c6 + FRONT_NB - 1) / FRONT_NB;
-  for (int pn = npanels - 1; pn >= 0; --pn) {
-    const int k0 = pn * FRONT_NB, nb = min((int)FRONT_NB, c6 - k0);
+  if (tid < ncol) tv[tid] = xb[c0 + tid];
+  if (!solve_only) {
+    const int s0 = FRONT_NBO * src, nsrc = min(s0 + FRONT_NBO, c6) - s0;
+    if (tid < nsrc) xs[tid] = xb[s0 + tid];
+    __syncthreads();
+    for (int jc = 0; jc < ncol; jc += 64) {
+      const int j = jc + jl;
+      double sa = 0.0, sb = 0.0;
+      if (j < ncol) {
+        const double* col = F + (size_t)s0 * ld + c0 + j;
+        int a = rg;
+        for (; a + NG < nsrc; a += 2 * NG) {
+          sa = fma(col[(size_t)a * ld], xs[a], sa);
+          sb = fma(col[(size_t)(a + NG) * ld], xs[a + NG], sb);
+        }
+        if (a < nsrc) sa = fma(col[(size_t)a * ld], xs[a], sa);
+      }
+      red[tid] = sa + sb;
+      __syncthreads();
+      if (rg == 0 && j < ncol) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < NG; ++q) tot += red[64 * q + jl];
+        tv[j] -= tot;
+      }
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
+  }
+  if (!solver) {
+    if (tid < ncol) xb[c0 + tid] = tv[tid];
+    return;
+  }
+  for (int pn = (c1 - 1) / FRONT_NB; pn >= c0 / FRONT_NB; --pn) {
+    const int k0 = pn * FRONT_NB, nb = min((int)FRONT_NB, c6 - k0), kl = k0 - c0;
     const double* W = p.Winv + D.wbase + (size_t)pn * FRONT_NB * FRONT_NB;
     {
       double s = 0.0;
-      if (jl < nb) for (int b = jl + rg; b < nb; b += NG) s = fma(W[b * FRONT_NB + jl], tv[k0 + b], s);
+      if (jl < nb) for (int b = jl + rg; b < nb; b += NG) s = fma(W[b * FRONT_NB + jl], tv[kl + b], s);
       red[tid] = s;
       __syncthreads();
       if (rg == 0 && jl < nb) {
         double tot = 0.0;
 #pragma unroll
         for (int q = 0; q < NG; ++q) tot += red[64 * q + jl];
-        tv[k0 + jl] = tot;
+        tv[kl + jl] = tot;
         const int col = D.first + (k0 + jl) / 6, kk = (k0 + jl) % 6;
-        p.x[6 * (size_t)col + kk] = tot;
+        xb[k0 + jl] = tot;
         g.cg_x[6 * (size_t)p.perm[col] + kk] = tot;
       }
       __syncthreads();
     }
-    for (int jc = 0; jc < k0; jc += 64) {
+    for (int jc = 0; jc < kl; jc += 64) {
       const int j = jc + jl;
       double s = 0.0;
-      if (j < k0) for (int a = rg; a < nb; a += NG) s = fma(F[(size_t)(k0 + a) * ld + j], tv[k0 + a], s);
+      if (j < kl) for (int a = rg; a < nb; a += NG) s = fma(F[(size_t)(k0 + a) * ld + c0 + j], tv[kl + a], s);
       red[tid] = s;
       __syncthreads();
-      if (rg == 0 && j < k0) {
+      if (rg == 0 && j < kl) {
         double tot = 0.0;
 #pragma unroll
         for (int q = 0; q < NG; ++q) tot += red[64 * q + jl];
@@ -502,18 +540,17 @@ void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSym
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_bwd_gemv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_bwd_tri), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     attr_set = true;
   }
   for (int l = sym.n_levels - 1; l >= 0; --l) {
     const FrontLevel& L = sym.levels[l];
-    size_t lds_a = 0, lds_b = 0;
-    for (int q = L.front_begin; q < L.front_end; ++q) {
-      lds_a = std::max(lds_a, (size_t)(6 * sym.fronts[q].r + BWD_T) * sizeof(double));
-      lds_b = std::max(lds_b, (size_t)(6 * sym.fronts[q].c + BWD_T) * sizeof(double));
-    }
+    size_t lds_a = 0;
+    for (int q = L.front_begin; q < L.front_end; ++q) lds_a = std::max(lds_a, (size_t)(6 * sym.fronts[q].r + BWD_T) * sizeof(double));
     if (L.bwd_wg > 0) hipLaunchKernelGGL(k_front_bwd_gemv, dim3(L.bwd_wg), dim3(BWD_T), lds_a, s, p, L.bwd_wg_begin);
-    hipLaunchKernelGGL(k_front_bwd_tri, dim3(L.front_end - L.front_begin), dim3(BWD_T), lds_b, s, g, p, L.front_begin);
+    for (int st = 0; st < L.bwd_steps; ++st) {
+      const int b = sym.bwd_step_ptr[L.bwd_step_begin + st], e = sym.bwd_step_ptr[L.bwd_step_begin + st + 1];
+      if (e > b) hipLaunchKernelGGL(k_front_bwd_block, dim3(e - b), dim3(BWD_T), 0, s, g, p, b);
+    }
   }
 }
 

@@ -207,7 +207,7 @@ struct pgo_problem {
   pgo::FrontPlan fplan{};
   bool front_usable = false;
   DevBuf<int> df_perm, df_idx, df_child, df_rel, df_cstart, df_col_front, df_ablk_ptr, df_ablk_slot, df_ablk_front, df_ablk_pos, df_wg_job, df_wg_tile,
-      df_bwd_front, df_bwd_chunk;
+      df_bwd_front, df_bwd_chunk, df_bwdb_front, df_bwdb_chunk;
   DevBuf<pgo::FrontDesc> df_fronts;
   DevBuf<pgo::FrontJob> df_jobs;
   DevBuf<double> df_Fval, df_Winv, df_x;
@@ -810,6 +810,8 @@ int prepare_front(pgo_problem* P) {
   HIP_TRY(P->df_wg_tile.upload(S.wg_tile, s));
   HIP_TRY(P->df_bwd_front.upload(S.bwd_front, s));
   HIP_TRY(P->df_bwd_chunk.upload(S.bwd_chunk, s));
+  HIP_TRY(P->df_bwdb_front.upload(S.bwdb_front, s));
+  HIP_TRY(P->df_bwdb_chunk.upload(S.bwdb_chunk, s));
   HIP_TRY(P->df_col_front.upload(S.col_front, s));
   HIP_TRY(P->df_ablk_ptr.upload(S.ablk_ptr, s));
   HIP_TRY(P->df_ablk_slot.upload(S.ablk_slot, s));
@@ -825,6 +827,7 @@ int prepare_front(pgo_problem* P) {
   f.n = S.n; f.nf = S.nf;
   f.perm = P->df_perm.p; f.fronts = P->df_fronts.p; f.idx = P->df_idx.p; f.child = P->df_child.p; f.rel = P->df_rel.p; f.cstart = P->df_cstart.p;
   f.wg_job = P->df_wg_job.p; f.wg_tile = P->df_wg_tile.p; f.bwd_front = P->df_bwd_front.p; f.bwd_chunk = P->df_bwd_chunk.p;
+  f.bwdb_front = P->df_bwdb_front.p; f.bwdb_chunk = P->df_bwdb_chunk.p;
   f.col_front = P->df_col_front.p; f.ablk_ptr = P->df_ablk_ptr.p; f.ablk_slot = P->df_ablk_slot.p;
   f.ablk_front = P->df_ablk_front.p; f.ablk_pos = P->df_ablk_pos.p; f.n_ablk = (int)S.ablk_front.size();
   f.jobs = P->df_jobs.p; f.Fval = P->df_Fval.p; f.Winv = P->df_Winv.p; f.x = P->df_x.p;
