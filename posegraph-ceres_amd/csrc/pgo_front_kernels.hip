@@ -136,82 +136,119 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   return h + h;
 }
 
-// 48 x 48 Cholesky by one wave.  DL: on entry the lower triangle of D (row-major, stride LDW); on exit L with 1 / L_kk on the
-// diagonal (nothing needs L_kk itself; the inverse needs its reciprocal).  Lane i < 48 owns row i in registers (compile-time
-// indices only); column k travels through LDS and is read back as broadcasts.  Returns true when a pivot was not positive.
-// Kept out of line (and the LDS pointers typed as such): inlined into the panel kernel the two unrolled phases drove the
-// register allocator into thousands of spills.
+// ---- the 48 x 48 diagonal block, one wave ------------------------------------------------------------------------------
+// Blocked by 16 columns with the matrix resident in LDS (DL, row-major, stride LDW):
+//   per block  load its 16 columns, lane i = row i (16 registers);
+//              16 scalar steps: pivot by v_readlane, 1/sqrt by v_rsq_f64 + Newton, the NEXT column is updated with a second
+//              v_readlane (so the pivot chain never waits for LDS), the other columns of the block through an LDS
+//              broadcast of column k;
+//              store the block column; update the trailing 16 x 16 tiles on the matrix cores (K = 16).
+//   then       the three 16 x 16 diagonal blocks are inverted, lane = (block, column), right-looking.
+// Result: DL = L with 1 / L_kk on the diagonal, Wd[16 b + r][c] = (L_bb^-1)[r][c].  The consumers (TRSM below, backward
+// substitution) work with M = [[W00 0 0], [L10 W11 0], [L20 L21 W22]] blockwise; the 48 x 48 inverse is never formed.
+// Returns true when a pivot was not positive.  Kept out of line with typed LDS pointers (inlined, the unrolled code drove
+// the register allocator into thousands of spills).
 typedef __attribute__((address_space(3))) double lds_double;
+constexpr int LDWD = 18;
 
-__device__ __noinline__ bool potrf_wave(lds_double* DL, lds_double* colbuf) {
-  const int lane = threadIdx.x & 63;
+__device__ __noinline__ bool diag_block_wave(lds_double* DL, lds_double* Wd, lds_double* cbuf) {
+  const int lane = threadIdx.x & 63, li = lane & 15, g4 = lane >> 4;
   const int i = lane < FRONT_NB ? lane : FRONT_NB - 1;
-  double a[FRONT_NB];
-#pragma unroll
-  for (int j = 0; j < FRONT_NB; ++j) {
-    const double v = DL[i * LDW + j];
-    a[j] = j <= i ? v : 0.0;
-  }
   bool bad = false;
 #pragma unroll
-  for (int k = 0; k < FRONT_NB; ++k) {
-    const double d = readlane_d(a[k], k);
-    bad |= !(d > 0.0);
-    const double rs = rsqrt_nr(d);
-    const double l = a[k] * rs;
-    a[k] = lane == k ? rs : l;
-    lds_double* cb = colbuf + (k & 1) * 64;
-    cb[lane] = l;
+  for (int b = 0; b < 3; ++b) {
+    const int c0 = 16 * b;
+    double a[16];
 #pragma unroll
-    for (int j = k + 1; j < FRONT_NB; ++j) a[j] = fma(-l, cb[j], a[j]);
-  }
-  if (lane < FRONT_NB) {
+    for (int j = 0; j < 16; ++j) {
+      const double v = DL[i * LDW + c0 + j];
+      a[j] = c0 + j <= i ? v : 0.0;
+    }
 #pragma unroll
-    for (int j = 0; j < FRONT_NB; ++j) DL[i * LDW + j] = a[j];
-  }
-  return bad;
-}
-
-// W = L^-1 by one wave, right-looking: lane j owns column j of W; once w[m] is final every later row receives its
-// contribution (independent FMAs; column m of L is read as broadcasts).
-__device__ __noinline__ void inverse_wave(const lds_double* DL, lds_double* Wl) {
-  const int lane = threadIdx.x & 63;
-  double a[FRONT_NB];
+    for (int k = 0; k < 16; ++k) {
+      const double d = readlane_d(a[k], c0 + k);
+      bad |= !(d > 0.0);
+      const double rs = rsqrt_nr(d);
+      const double l = a[k] * rs;
+      a[k] = lane == c0 + k ? rs : l;
+      if (k < 15) {
+        const double ln = readlane_d(l, c0 + k + 1);
+        a[k + 1] = fma(-l, ln, a[k + 1]);
+        if (k < 14) {
+          lds_double* cb = cbuf + (k & 1) * 64;
+          cb[lane] = l;
 #pragma unroll
-  for (int m = 0; m < FRONT_NB; ++m) {
-    const double e = m == lane ? 1.0 : 0.0;
-    const double w = (m == 0 ? e : a[m] + e) * DL[m * LDW + m];
-    a[m] = w;
+          for (int j = k + 2; j < 16; ++j) a[j] = fma(-l, cb[c0 + j], a[j]);
+        }
+      }
+    }
+    if (lane < FRONT_NB) {
 #pragma unroll
-    for (int r = m + 1; r < FRONT_NB; ++r) {
-      const double l = DL[r * LDW + m];
-      a[r] = m == 0 ? -l * w : fma(-l, w, a[r]);
+      for (int j = 0; j < 16; ++j) DL[i * LDW + c0 + j] = a[j];
+    }
+    if (b < 2) {
+#pragma unroll
+      for (int qa = b + 1; qa < 3; ++qa) {
+        double fa[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) fa[s4] = DL[(16 * qa + li) * LDW + c0 + 4 * s4 + g4];
+#pragma unroll
+        for (int qb = b + 1; qb <= qa; ++qb) {
+          double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const double fb = DL[(16 * qb + li) * LDW + c0 + 4 * s4 + g4];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s4], fb, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) DL[(16 * qa + g4 + 4 * r) * LDW + 16 * qb + li] -= acc[r];
+        }
+      }
     }
   }
-  if (lane < FRONT_NB) {
+  // inverses of the diagonal 16 x 16 blocks: lane = (block, column)
+  {
+    const int base = 16 * (i >> 4), j = i & 15;
+    double w[16];
 #pragma unroll
-    for (int r = 0; r < FRONT_NB; ++r) Wl[r * LDW + lane] = a[r];
+    for (int m = 0; m < 16; ++m) {
+      const double e = m == j ? 1.0 : 0.0;
+      const double wv = (m == 0 ? e : w[m] + e) * DL[(base + m) * LDW + base + m];
+      w[m] = wv;
+#pragma unroll
+      for (int r = m + 1; r < 16; ++r) {
+        const double l = DL[(base + r) * LDW + base + m];
+        w[r] = m == 0 ? -l * wv : fma(-l, wv, w[r]);
+      }
+    }
+    if (lane < FRONT_NB) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Wd[(base + r) * LDWD + j] = w[r];
+    }
   }
+  return bad;
 }
 
 // One 48-column panel step (see FrontJob).  320 lanes = 5 waves: waves 0..3 own rows [16 w, 16 w + 16) of the 64-row tile
 // (sums and TRSM on the matrix cores), wave 4 factorises the diagonal block in between.
 __global__ __launch_bounds__(320) void k_front_panel(FrontPlan p, int wg_begin, int* flags) {
   __shared__ double DL[FRONT_NB * LDW];
-  __shared__ double Wl[FRONT_NB * LDW];
-  __shared__ double colbuf[128];
+  __shared__ double Wd[FRONT_NB * LDWD];
+  __shared__ double cbuf[128];
   const int wgi = wg_begin + blockIdx.x;
   const FrontJob J = p.jobs[p.wg_job[wgi]];
   const int tile = p.wg_tile[wgi] >> 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g4 = lane >> 4;
   if (wave == 4) {
     __syncthreads();
-    const bool bad = potrf_wave((lds_double*)DL, (lds_double*)colbuf);
-    inverse_wave((lds_double*)DL, (lds_double*)Wl);
+    const bool bad = diag_block_wave((lds_double*)DL, (lds_double*)Wd, (lds_double*)cbuf);
     if (tile == 0) {
       if (bad && lane == 0) atomicOr(&flags[2], 1);
-      double* Wg = p.Winv + J.wbase;
-      for (int e = lane; e < FRONT_NB * FRONT_NB; e += 64) Wg[e] = Wl[(e / FRONT_NB) * LDW + e % FRONT_NB];
+      double* Wg = p.Winv + J.wbase;     // M, row-major 48 x 48
+      for (int e = lane; e < FRONT_NB * FRONT_NB; e += 64) {
+        const int r = e / FRONT_NB, c = e - r * FRONT_NB;
+        Wg[e] = (r >> 4) == (c >> 4) ? Wd[r * LDWD + (c & 15)] : (r > c ? DL[r * LDW + c] : 0.0);
+      }
     }
     __syncthreads();
     return;
@@ -231,30 +268,46 @@ __global__ __launch_bounds__(320) void k_front_panel(FrontPlan p, int wg_begin, 
   for (int q = 0; q < 3; ++q) sp[q] = double4_t{0.0, 0.0, 0.0, 0.0};
   sd[0] = double4_t{0.0, 0.0, 0.0, 0.0};
   sd[1] = double4_t{0.0, 0.0, 0.0, 0.0};
-  const int ksum = k0 - J.c0;   // 0, 48, 96 or 144
+  const int ksum = k0 - J.c0;   // 0, 48, 96 or 144: three 8-wide steps per trip, all loads of a trip issued first
   {
     const double* Ao = F + (size_t)orow * ld + J.c0 + 2 * g4;
     const double* Bk[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) Bk[q] = F + (size_t)(k0 + min(16 * q + li, nb - 1)) * ld + J.c0 + 2 * g4;
-    for (int kc = 0; kc < ksum; kc += 8) {
-      const double2 ao = *reinterpret_cast<const double2*>(Ao + kc);
-      double2 bk[3];
+    for (int kc = 0; kc < ksum; kc += 24) {
+      double2 ao[3], bk[3][3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) bk[q] = *reinterpret_cast<const double2*>(Bk[q] + kc);
+      for (int u = 0; u < 3; ++u) {
+        ao[u] = *reinterpret_cast<const double2*>(Ao + kc + 8 * u);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        sp[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[q].x, ao.x, sp[q], 0, 0, 0);
-        sp[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[q].y, ao.y, sp[q], 0, 0, 0);
+        for (int q = 0; q < 3; ++q) bk[u][q] = *reinterpret_cast<const double2*>(Bk[q] + kc + 8 * u);
       }
-      // D tiles: the operand of tile row qa is bk[qa], of tile column qb is bk[qb]
-      const double2 da0 = dqa0 == 0 ? bk[0] : dqa0 == 1 ? bk[1] : bk[2];
-      const double2 db0 = dqb0 == 0 ? bk[0] : dqb0 == 1 ? bk[1] : bk[2];
-      sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(da0.x, db0.x, sd[0], 0, 0, 0);
-      sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(da0.y, db0.y, sd[0], 0, 0, 0);
-      const double2 da1 = dqa1 == 1 ? bk[1] : bk[2];
-      sd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(da1.x, bk[0].x, sd[1], 0, 0, 0);
-      sd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(da1.y, bk[0].y, sd[1], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          sp[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][q].x, ao[u].x, sp[q], 0, 0, 0);
+          sp[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][q].y, ao[u].y, sp[q], 0, 0, 0);
+        }
+        // D tiles (wave-uniform branches: selecting the operands by index sent the fragment array to scratch memory)
+        if (wave == 0) {
+          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][0].x, bk[u][0].x, sd[0], 0, 0, 0);
+          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][0].y, bk[u][0].y, sd[0], 0, 0, 0);
+          sd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][1].x, bk[u][0].x, sd[1], 0, 0, 0);
+          sd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][1].y, bk[u][0].y, sd[1], 0, 0, 0);
+        } else if (wave == 1) {
+          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][1].x, bk[u][1].x, sd[0], 0, 0, 0);
+          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][1].y, bk[u][1].y, sd[0], 0, 0, 0);
+          sd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][2].x, bk[u][0].x, sd[1], 0, 0, 0);
+          sd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][2].y, bk[u][0].y, sd[1], 0, 0, 0);
+        } else if (wave == 2) {
+          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][2].x, bk[u][1].x, sd[0], 0, 0, 0);
+          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][2].y, bk[u][1].y, sd[0], 0, 0, 0);
+        } else {
+          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][2].x, bk[u][2].x, sd[0], 0, 0, 0);
+          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][2].y, bk[u][2].y, sd[0], 0, 0, 0);
+        }
+      }
     }
   }
   // D = F[kb, kb] - S_D into LDS (identity beyond nb); loads from clamped (always valid) addresses, masked afterwards
@@ -272,7 +325,7 @@ __global__ __launch_bounds__(320) void k_front_panel(FrontPlan p, int wg_begin, 
       if (u == 0 || two_d) DL[row * LDW + col] = v;
     }
   }
-  // P^T = F[own rows, kb]^T - S_P^T, kept in registers in the layout the TRSM consumes as its A operand:
+  // P^T = F[own rows, kb]^T - S_P^T, kept in registers in the layout every later product consumes as its B operand:
   // lane (li, g4) holds P[own row li][column 16 q + g4 + 4 r]
   double4_t pt[3];
   {
@@ -287,31 +340,33 @@ __global__ __launch_bounds__(320) void k_front_panel(FrontPlan p, int wg_begin, 
       for (int r = 0; r < 4; ++r) pt[q][r] = (16 * q + g4 + 4 * r < nb) ? c[4 * q + r] - sp[q][r] : 0.0;
   }
   __syncthreads();
-  // ---- (b) wave 4: Cholesky + inverse of the diagonal block ----
+  // ---- (b) wave 4: the diagonal block ----
   __syncthreads();
   if (!wave_on) return;
-  // ---- (c) TRSM: out[a][b] = sum_m P[a][m] W[b][m], W lower triangular: tile qb needs m < 16 (qb + 1) ----
-  double4_t out[3];
+  // ---- (c) TRSM by 16-column blocks, everything kept transposed (lane (li, g4), register r = entry [own row li][16 q +
+  // g4 + 4 r]): Y0^T = W00 P0^T;  Y1^T = W11 (P1^T - L10 Y0^T);  Y2^T = W22 (P2^T - L20 Y0^T - L21 Y1^T) ----
+  auto mul16 = [&](const double* Mrow, int stride, const double4_t& x, double4_t acc) {
+    // acc += M[16 x 16 block, rows li] * x^T-operand; Mrow points at M[block row 0][block column 0]
 #pragma unroll
-  for (int qb = 0; qb < 3; ++qb) {
-    out[qb] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Mrow[li * stride + 4 * r + g4], x[r], acc, 0, 0, 0);
+    return acc;
+  };
+  const double4_t zero4 = double4_t{0.0, 0.0, 0.0, 0.0};
+  double4_t y[3];
+  y[0] = mul16(Wd, LDWD, pt[0], zero4);
+  double4_t s1 = mul16(DL + 16 * LDW, LDW, y[0], zero4);
+  y[1] = mul16(Wd + 16 * LDWD, LDWD, pt[1] - s1, zero4);
+  double4_t s2 = mul16(DL + 32 * LDW, LDW, y[0], zero4);
+  s2 = mul16(DL + 32 * LDW + 16, LDW, y[1], s2);
+  y[2] = mul16(Wd + 32 * LDWD, LDWD, pt[2] - s2, zero4);
+  if (rbase + li < J.r1) {
 #pragma unroll
-    for (int q = 0; q <= qb; ++q) {
+    for (int q = 0; q < 3; ++q)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double w = Wl[(16 * qb + li) * LDW + 16 * q + 4 * r + g4];
-        out[qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(pt[q][r], w, out[qb], 0, 0, 0);
+        const int col = 16 * q + g4 + 4 * r;
+        if (col < nb) F[(size_t)orow * ld + k0 + col] = y[q][r];
       }
-    }
-  }
-#pragma unroll
-  for (int qb = 0; qb < 3; ++qb) {
-    const int col = 16 * qb + li;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = rbase + g4 + 4 * r;
-      if (row < J.r1 && col < nb) F[(size_t)row * ld + k0 + col] = out[qb][r];
-    }
   }
 }
 
@@ -438,6 +493,7 @@ __global__ __launch_bounds__(BWD_T) void k_front_bwd_block(DeviceGraph g, FrontP
   __shared__ double xs[FRONT_NBO];
   __shared__ double tv[FRONT_NBO];
   __shared__ double red[BWD_T];
+  __shared__ double Ms[FRONT_NB * (FRONT_NB + 1)];
   const int wgi = wg_begin + blockIdx.x;
   const FrontDesc D = p.fronts[p.bwdb_front[wgi]];
   const int code = p.bwdb_chunk[wgi], src = code >> 16, ch = code & 0xffff;
@@ -449,7 +505,7 @@ __global__ __launch_bounds__(BWD_T) void k_front_bwd_block(DeviceGraph g, FrontP
   const int ld = D.ld;
   const int jl = tid & 63, rg = tid >> 6;
   constexpr int NG = BWD_T / 64;
-  if (tid < ncol) tv[tid] = xb[c0 + tid];
+  if (tid < FRONT_NBO) tv[tid] = tid < ncol ? xb[c0 + tid] : 0.0;
   if (!solve_only) {
     const int s0 = FRONT_NBO * src, nsrc = min(s0 + FRONT_NBO, c6) - s0;
     if (tid < nsrc) xs[tid] = xb[s0 + tid];
@@ -485,20 +541,32 @@ __global__ __launch_bounds__(BWD_T) void k_front_bwd_block(DeviceGraph g, FrontP
   }
   for (int pn = (c1 - 1) / FRONT_NB; pn >= c0 / FRONT_NB; --pn) {
     const int k0 = pn * FRONT_NB, nb = min((int)FRONT_NB, c6 - k0), kl = k0 - c0;
-    const double* W = p.Winv + D.wbase + (size_t)pn * FRONT_NB * FRONT_NB;
-    {
-      double s = 0.0;
-      if (jl < nb) for (int b = jl + rg; b < nb; b += NG) s = fma(W[b * FRONT_NB + jl], tv[kl + b], s);
-      red[tid] = s;
+    // x_k = L_kk^-T t_k through M = [[W00 0 0], [L10 W11 0], [L20 L21 W22]] (16 x 16 blocks), last block first:
+    // x_b = W_bb^T t_b, then t_a -= L_ba^T x_b for the blocks a < b
+    const double* M = p.Winv + D.wbase + (size_t)pn * FRONT_NB * FRONT_NB;
+    for (int e = tid; e < FRONT_NB * FRONT_NB; e += BWD_T) Ms[(e / FRONT_NB) * (FRONT_NB + 1) + e % FRONT_NB] = M[e];
+    __syncthreads();
+    for (int bb = 2; bb >= 0; --bb) {
+      if (tid < 16) {
+        double s = 0.0;
+        for (int b = tid; b < 16; ++b) s = fma(Ms[(16 * bb + b) * (FRONT_NB + 1) + 16 * bb + tid], tv[kl + 16 * bb + b], s);
+        xs[tid] = s;
+      }
       __syncthreads();
-      if (rg == 0 && jl < nb) {
-        double tot = 0.0;
+      if (tid < 16) {
+        const int e = 16 * bb + tid;
+        tv[kl + e] = xs[tid];
+        if (e < nb) {
+          const int col = D.first + (k0 + e) / 6, kk = (k0 + e) % 6;
+          xb[k0 + e] = xs[tid];
+          g.cg_x[6 * (size_t)p.perm[col] + kk] = xs[tid];
+        }
+      } else if (tid >= 64 && tid < 64 + 16 * bb) {
+        const int a = tid - 64;
+        double s = 0.0;
 #pragma unroll
-        for (int q = 0; q < NG; ++q) tot += red[64 * q + jl];
-        tv[kl + jl] = tot;
-        const int col = D.first + (k0 + jl) / 6, kk = (k0 + jl) % 6;
-        xb[k0 + jl] = tot;
-        g.cg_x[6 * (size_t)p.perm[col] + kk] = tot;
+        for (int b = 0; b < 16; ++b) s = fma(Ms[(16 * bb + b) * (FRONT_NB + 1) + a], xs[b], s);
+        tv[kl + a] -= s;
       }
       __syncthreads();
     }
