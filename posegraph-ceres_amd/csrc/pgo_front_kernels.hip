@@ -26,6 +26,62 @@ namespace {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// ---- the 16 x 16 x 4 product, two ways -------------------------------------------------------------------------------------
+// Measured on MI355X (tools/bench/fma_rate.hip, mfma_rate.hip): v_mfma_f64_16x16x4_f64 retires 2048 flops per ~61 ns per wave
+// (32 TFLOP/s with one wave per SIMD, 46 saturated); v_mfma_f64_4x4x4_4b_f64 512 flops per ~8 ns (64-67 TFLOP/s) — the small
+// form is the faster FP64 matrix instruction of this chip in isolation.  It multiplies the four DIAGONAL 4 x 4 blocks of a
+// 16 x 16 tile (lane l: A/B operand = row / column (l & 15), k = l >> 4; result row block = column block = (l & 15) >> 2, row
+// inside the block = l >> 4 — tools/bench/mfma4_layout.hip); rotating the A operand by four lanes inside every row of 16
+// (DPP row_ror:4) shifts the row blocks, so four instructions with A rotated 0..3 times cover the tile: accumulator t of lane
+// (i, c) holds C[4 ((c / 4 - t) mod 4) + i][c] (tools/bench/mfma4_tile.hip), and `unrot` restores the register layout of the
+// 16x16x4 instruction.  In THESE kernels the small form measured 5-8 % slower end to end (C2 factorisation 5.4 -> 5.8 ms,
+// C5 32.6 -> 35.1 ms: they are bound by operand delivery and dependent latency, not by the matrix pipe), so the large form
+// is the default; PGO_FRONT_MFMA4=1 at compile time selects the other.
+#ifndef PGO_FRONT_MFMA4
+#define PGO_FRONT_MFMA4 0
+#endif
+#if PGO_FRONT_MFMA4
+__device__ __forceinline__ double ror4(double v) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_mov_dpp(u.i[0], 0x124, 0xf, 0xf, true);
+  u.i[1] = __builtin_amdgcn_mov_dpp(u.i[1], 0x124, 0xf, 0xf, true);
+  return u.d;
+}
+struct Rot4 { double v[4]; };
+__device__ __forceinline__ Rot4 rot4(double a) {
+  Rot4 r;
+  r.v[0] = a;
+  r.v[1] = ror4(a);
+  r.v[2] = ror4(r.v[1]);
+  r.v[3] = ror4(r.v[2]);
+  return r;
+}
+__device__ __forceinline__ void mma16(double4_t& acc, const Rot4& a, double b) {
+  acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v[0], b, acc[0], 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v[1], b, acc[1], 0, 0, 0);
+  acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v[2], b, acc[2], 0, 0, 0);
+  acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v[3], b, acc[3], 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(double4_t& acc, double a, double b) { mma16(acc, rot4(a), b); }
+__device__ __forceinline__ double4_t unrot(const double4_t& acc) {
+  const int cb = (threadIdx.x & 15) >> 2;
+  double4_t o;
+  o[0] = cb == 0 ? acc[0] : cb == 1 ? acc[1] : cb == 2 ? acc[2] : acc[3];
+  o[1] = cb == 0 ? acc[3] : cb == 1 ? acc[0] : cb == 2 ? acc[1] : acc[2];
+  o[2] = cb == 0 ? acc[2] : cb == 1 ? acc[3] : cb == 2 ? acc[0] : acc[1];
+  o[3] = cb == 0 ? acc[1] : cb == 1 ? acc[2] : cb == 2 ? acc[3] : acc[0];
+  return o;
+}
+#else
+typedef double Rot4;
+__device__ __forceinline__ Rot4 rot4(double a) { return a; }
+__device__ __forceinline__ void mma16(double4_t& acc, double a, double b) {
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ double4_t unrot(const double4_t& acc) { return acc; }
+#endif
+
 __global__ __launch_bounds__(256) void k_front_scatter(DeviceGraph g, FrontPlan p) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long na = (long long)p.n_ablk * 36;
@@ -189,19 +245,17 @@ __device__ __noinline__ bool diag_block_wave(lds_double* DL, lds_double* Wd, lds
     if (b < 2) {
 #pragma unroll
       for (int qa = b + 1; qa < 3; ++qa) {
-        double fa[4];
+        Rot4 fa[4];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) fa[s4] = DL[(16 * qa + li) * LDW + c0 + 4 * s4 + g4];
+        for (int s4 = 0; s4 < 4; ++s4) { const double t = DL[(16 * qa + li) * LDW + c0 + 4 * s4 + g4]; fa[s4] = rot4(t); }
 #pragma unroll
         for (int qb = b + 1; qb <= qa; ++qb) {
           double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            const double fb = DL[(16 * qb + li) * LDW + c0 + 4 * s4 + g4];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s4], fb, acc, 0, 0, 0);
-          }
+          for (int s4 = 0; s4 < 4; ++s4) { const double t = DL[(16 * qb + li) * LDW + c0 + 4 * s4 + g4]; mma16(acc, fa[s4], t); }
+          const double4_t res = unrot(acc);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) DL[(16 * qa + g4 + 4 * r) * LDW + 16 * qb + li] -= acc[r];
+          for (int r = 0; r < 4; ++r) DL[(16 * qa + g4 + 4 * r) * LDW + 16 * qb + li] -= res[r];
         }
       }
     }
@@ -284,32 +338,32 @@ __global__ __launch_bounds__(320) void k_front_panel(FrontPlan p, int wg_begin, 
       }
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
+        Rot4 rx[3], ry[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          sp[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][q].x, ao[u].x, sp[q], 0, 0, 0);
-          sp[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][q].y, ao[u].y, sp[q], 0, 0, 0);
-        }
+        for (int q = 0; q < 3; ++q) { rx[q] = rot4(bk[u][q].x); ry[q] = rot4(bk[u][q].y); }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) mma16(sp[q], rx[q], ao[u].x);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) mma16(sp[q], ry[q], ao[u].y);
         // D tiles (wave-uniform branches: selecting the operands by index sent the fragment array to scratch memory)
         if (wave == 0) {
-          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][0].x, bk[u][0].x, sd[0], 0, 0, 0);
-          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][0].y, bk[u][0].y, sd[0], 0, 0, 0);
-          sd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][1].x, bk[u][0].x, sd[1], 0, 0, 0);
-          sd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][1].y, bk[u][0].y, sd[1], 0, 0, 0);
+          mma16(sd[0], rx[0], bk[u][0].x); mma16(sd[0], ry[0], bk[u][0].y);
+          mma16(sd[1], rx[1], bk[u][0].x); mma16(sd[1], ry[1], bk[u][0].y);
         } else if (wave == 1) {
-          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][1].x, bk[u][1].x, sd[0], 0, 0, 0);
-          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][1].y, bk[u][1].y, sd[0], 0, 0, 0);
-          sd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][2].x, bk[u][0].x, sd[1], 0, 0, 0);
-          sd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][2].y, bk[u][0].y, sd[1], 0, 0, 0);
+          mma16(sd[0], rx[1], bk[u][1].x); mma16(sd[0], ry[1], bk[u][1].y);
+          mma16(sd[1], rx[2], bk[u][0].x); mma16(sd[1], ry[2], bk[u][0].y);
         } else if (wave == 2) {
-          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][2].x, bk[u][1].x, sd[0], 0, 0, 0);
-          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][2].y, bk[u][1].y, sd[0], 0, 0, 0);
+          mma16(sd[0], rx[2], bk[u][1].x); mma16(sd[0], ry[2], bk[u][1].y);
         } else {
-          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][2].x, bk[u][2].x, sd[0], 0, 0, 0);
-          sd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bk[u][2].y, bk[u][2].y, sd[0], 0, 0, 0);
+          mma16(sd[0], rx[2], bk[u][2].x); mma16(sd[0], ry[2], bk[u][2].y);
         }
       }
     }
   }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) sp[q] = unrot(sp[q]);
+  sd[0] = unrot(sd[0]);
+  sd[1] = unrot(sd[1]);
   // D = F[kb, kb] - S_D into LDS (identity beyond nb); loads from clamped (always valid) addresses, masked afterwards
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -347,9 +401,12 @@ __global__ __launch_bounds__(320) void k_front_panel(FrontPlan p, int wg_begin, 
   // g4 + 4 r]): Y0^T = W00 P0^T;  Y1^T = W11 (P1^T - L10 Y0^T);  Y2^T = W22 (P2^T - L20 Y0^T - L21 Y1^T) ----
   auto mul16 = [&](const double* Mrow, int stride, const double4_t& x, double4_t acc) {
     // acc += M[16 x 16 block, rows li] * x^T-operand; Mrow points at M[block row 0][block column 0]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Mrow[li * stride + 4 * r + g4], x[r], acc, 0, 0, 0);
-    return acc;
+    double4_t ra = double4_t{0.0, 0.0, 0.0, 0.0}, rb = double4_t{0.0, 0.0, 0.0, 0.0};
+    mma16(ra, Mrow[li * stride + g4], x[0]);
+    mma16(rb, Mrow[li * stride + 4 + g4], x[1]);
+    mma16(ra, Mrow[li * stride + 8 + g4], x[2]);
+    mma16(rb, Mrow[li * stride + 12 + g4], x[3]);
+    return acc + unrot(ra + rb);
   };
   const double4_t zero4 = double4_t{0.0, 0.0, 0.0, 0.0};
   double4_t y[3];
@@ -370,8 +427,13 @@ __global__ __launch_bounds__(320) void k_front_panel(FrontPlan p, int wg_begin, 
   }
 }
 
-// C tile of 64 x 64 per workgroup; wave w owns rows [16 w, 16 w + 16) x 64 columns (four MFMA tiles).  C -= A B^T, K in
-// register-prefetched steps of 16.
+// C tile of 64 x 64 per workgroup; wave w owns rows [16 w, 16 w + 16) x 64 columns (four 16 x 16 tiles).  C -= A B^T.
+// K runs in steps of 16 through two register buffers (the loads of the next step are in flight while the matrix cores
+// work on the current one); every fragment is loaded from a clamped, always valid address and out-of-range k is masked in
+// the A fragment afterwards, so no load sits behind a branch.  Tiles entirely above the diagonal are computed and dropped
+// in the epilogue (only the workgroups that straddle the diagonal have any).
+struct GemmFrag { double2 a[2], b[4][2]; };
+
 __global__ __launch_bounds__(256) void k_front_gemm(FrontPlan p, int wg_begin) {
   const int wgi = wg_begin + blockIdx.x;
   const FrontJob J = p.jobs[p.wg_job[wgi]];
@@ -383,61 +445,50 @@ __global__ __launch_bounds__(256) void k_front_gemm(FrontPlan p, int wg_begin) {
   const int wrow0 = row0 + 16 * wave;
   if (wrow0 >= J.r1) return;
   const int wrow_last = min(wrow0 + 15, J.r1 - 1);
-  const int arow = min(wrow0 + li, J.r1 - 1);
-  const double* Ap = F + (size_t)arow * ld + J.k0 + 2 * g4;
+  if (col0 > wrow_last) return;
+  const double* Ap = F + (size_t)min(wrow0 + li, J.r1 - 1) * ld + J.k0;
   const double* Bp[4];
-  bool tile_on[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int c = col0 + 16 * q;
-    tile_on[q] = c < J.c1 && c <= wrow_last;
-    const int brow = min(c + li, J.c1 - 1);
-    Bp[q] = F + (size_t)brow * ld + J.k0 + 2 * g4;
-  }
-  if (!tile_on[0]) return;
+  for (int q = 0; q < 4; ++q) Bp[q] = F + (size_t)min(col0 + 16 * q + li, J.c1 - 1) * ld + J.k0;
   double4_t acc[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
-  const int klen = J.klen;
-  double2 a0, a1, b0[4], b1[4];
-  auto load = [&](int kc, double2& x0, double2& x1, double2* y0, double2* y1) {
-    // addresses clamped into the row (always valid), out-of-range k masked to zero afterwards: no branches around loads
-    const int k0c = min(kc, klen - 2 - 2 * g4), k1c = min(kc + 8, klen - 2 - 2 * g4);
-    const bool v0 = kc + 2 * g4 < klen, v1 = kc + 8 + 2 * g4 < klen;
-    x0 = *reinterpret_cast<const double2*>(Ap + k0c);
-    x1 = *reinterpret_cast<const double2*>(Ap + k1c);
+  const int klen = J.klen, kmax = klen - 2;
+  auto load = [&](int kc, GemmFrag& f) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      y0[q] = *reinterpret_cast<const double2*>(Bp[q] + k0c);
-      y1[q] = *reinterpret_cast<const double2*>(Bp[q] + k1c);
+    for (int h = 0; h < 2; ++h) {
+      const int k = kc + 8 * h + 2 * g4, kk = min(k, kmax);
+      f.a[h] = *reinterpret_cast<const double2*>(Ap + kk);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) f.b[q][h] = *reinterpret_cast<const double2*>(Bp[q] + kk);
+      if (k > kmax) f.a[h] = double2{0.0, 0.0};
     }
-    if (!v0) x0 = double2{0.0, 0.0};
-    if (!v1) x1 = double2{0.0, 0.0};
   };
-  load(0, a0, a1, b0, b1);
-  for (int kc = 0; kc < klen; kc += 16) {
-    double2 na0 = a0, na1 = a1, nb0[4], nb1[4];
+  auto compute = [&](const GemmFrag& f) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { nb0[q] = b0[q]; nb1[q] = b1[q]; }
-    if (kc + 16 < klen) load(kc + 16, na0, na1, nb0, nb1);
+    for (int h = 0; h < 2; ++h) {
+      const Rot4 rx = rot4(f.a[h].x), ry = rot4(f.a[h].y);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (tile_on[q]) {
-        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0[q].x, acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0[q].y, acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1[q].x, acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1[q].y, acc[q], 0, 0, 0);
-      }
+      for (int q = 0; q < 4; ++q) mma16(acc[q], rx, f.b[q][h].x);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mma16(acc[q], ry, f.b[q][h].y);
     }
-    a0 = na0; a1 = na1;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { b0[q] = nb0[q]; b1[q] = nb1[q]; }
+  };
+  GemmFrag f0, f1;
+  load(0, f0);
+  for (int kc = 0; kc < klen; kc += 32) {
+    if (kc + 16 < klen) load(kc + 16, f1);
+    compute(f0);
+    if (kc + 16 >= klen) break;
+    if (kc + 32 < klen) load(kc + 32, f0);
+    compute(f1);
   }
 #pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = unrot(acc[q]);
+#pragma unroll
   for (int q = 0; q < 4; ++q) {
-    if (!tile_on[q]) continue;
     const int c = col0 + 16 * q + li;
-    if (c >= J.c1) continue;
+    if (c >= J.c1 || col0 + 16 * q > wrow_last) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = wrow0 + g4 + 4 * r;

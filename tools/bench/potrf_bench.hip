@@ -1,8 +1,12 @@
+// tools/bench/potrf_bench.hip — micro-benchmark of the diagonal-block wave of pgo_front_kernels.hip (the function text is
+// pasted from there by tools/bench/make_potrf_bench.py); prints cycles of one call and checks L L^T = A, W_bb L_bb = I.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <cmath>
 enum { FRONT_NB = 48 };
-constexpr int LDW = FRONT_NB + 2;
-typedef __attribute__((address_space(3))) double lds_double;
-typedef __attribute__((address_space(3))) double2 lds_double2;
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int LDW = FRONT_NB + 2;   // LDS row stride (doubles): rows stay 16-byte aligned, 16 lanes x b64/b128 conflict-free
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
   union { double d; int i[2]; } u;
@@ -11,6 +15,9 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
   u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
   return u.d;
 }
+
+// 1/sqrt(d): v_rsq_f64 seed + coupled Newton (Goldschmidt) steps; the result is used both for the diagonal (d * rs) and
+// for scaling the column, so the factor is self-consistent to an ulp or two
 __device__ __forceinline__ double rsqrt_nr(double d) {
   const double y = __builtin_amdgcn_rsq(d);
   double g = d * y, h = 0.5 * y;
@@ -24,110 +31,137 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   h = fma(h, r, h);
   return h + h;
 }
-__device__ __noinline__ bool potrf_wave(lds_double* DL, lds_double* colbuf) {
-  const int lane = threadIdx.x & 63;
+
+// ---- the 48 x 48 diagonal block, one wave ------------------------------------------------------------------------------
+// Blocked by 16 columns with the matrix resident in LDS (DL, row-major, stride LDW):
+//   per block  load its 16 columns, lane i = row i (16 registers);
+//              16 scalar steps: pivot by v_readlane, 1/sqrt by v_rsq_f64 + Newton, the NEXT column is updated with a second
+//              v_readlane (so the pivot chain never waits for LDS), the other columns of the block through an LDS
+//              broadcast of column k;
+//              store the block column; update the trailing 16 x 16 tiles on the matrix cores (K = 16).
+//   then       the three 16 x 16 diagonal blocks are inverted, lane = (block, column), right-looking.
+// Result: DL = L with 1 / L_kk on the diagonal, Wd[16 b + r][c] = (L_bb^-1)[r][c].  The consumers (TRSM below, backward
+// substitution) work with M = [[W00 0 0], [L10 W11 0], [L20 L21 W22]] blockwise; the 48 x 48 inverse is never formed.
+// Returns true when a pivot was not positive.  Kept out of line with typed LDS pointers (inlined, the unrolled code drove
+// the register allocator into thousands of spills).
+typedef __attribute__((address_space(3))) double lds_double;
+constexpr int LDWD = 18;
+
+__device__ __noinline__ bool diag_block_wave(lds_double* DL, lds_double* Wd, lds_double* cbuf) {
+  const int lane = threadIdx.x & 63, li = lane & 15, g4 = lane >> 4;
   const int i = lane < FRONT_NB ? lane : FRONT_NB - 1;
-  double a[FRONT_NB];
-#pragma unroll
-  for (int j = 0; j < FRONT_NB; j += 2) {
-    const double2 v = double2{DL[i * LDW + j], DL[i * LDW + j + 1]};
-    a[j] = j <= i ? v.x : 0.0;
-    a[j + 1] = j + 1 <= i ? v.y : 0.0;
-  }
   bool bad = false;
 #pragma unroll
-  for (int k = 0; k < FRONT_NB; ++k) {
-    const double d = readlane_d(a[k], k);
-    bad |= !(d > 0.0);
-    const double rs = rsqrt_nr(d);
-    const double l = a[k] * rs;
-    a[k] = lane == k ? rs : l;      // the diagonal of the stored factor holds 1 / L_kk (what the inverse needs)
-    lds_double* cb = colbuf + (k & 1) * 64;
-    cb[lane] = l;
+  for (int b = 0; b < 3; ++b) {
+    const int c0 = 16 * b;
+    double a[16];
 #pragma unroll
-    for (int jb = (k + 1) & ~1; jb < FRONT_NB; jb += 2) {
-      const double2 c = double2{cb[jb], cb[jb + 1]};
-      if (jb > k) a[jb] = fma(-l, c.x, a[jb]);
-      a[jb + 1] = fma(-l, c.y, a[jb + 1]);
+    for (int j = 0; j < 16; ++j) {
+      const double v = DL[i * LDW + c0 + j];
+      a[j] = c0 + j <= i ? v : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const double d = readlane_d(a[k], c0 + k);
+      bad |= !(d > 0.0);
+      const double rs = rsqrt_nr(d);
+      const double l = a[k] * rs;
+      a[k] = lane == c0 + k ? rs : l;
+      if (k < 15) {
+        const double ln = readlane_d(l, c0 + k + 1);
+        a[k + 1] = fma(-l, ln, a[k + 1]);
+        if (k < 14) {
+          lds_double* cb = cbuf + (k & 1) * 64;
+          cb[lane] = l;
+#pragma unroll
+          for (int j = k + 2; j < 16; ++j) a[j] = fma(-l, cb[c0 + j], a[j]);
+        }
+      }
+    }
+    if (lane < FRONT_NB) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) DL[i * LDW + c0 + j] = a[j];
+    }
+    if (b < 2) {
+#pragma unroll
+      for (int qa = b + 1; qa < 3; ++qa) {
+        double fa[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) fa[s4] = DL[(16 * qa + li) * LDW + c0 + 4 * s4 + g4];
+#pragma unroll
+        for (int qb = b + 1; qb <= qa; ++qb) {
+          double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const double fb = DL[(16 * qb + li) * LDW + c0 + 4 * s4 + g4];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s4], fb, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) DL[(16 * qa + g4 + 4 * r) * LDW + 16 * qb + li] -= acc[r];
+        }
+      }
     }
   }
-  if (lane < FRONT_NB) {
+  // inverses of the diagonal 16 x 16 blocks: lane = (block, column)
+  {
+    const int base = 16 * (i >> 4), j = i & 15;
+    double w[16];
 #pragma unroll
-    for (int j = 0; j < FRONT_NB; j += 2) { DL[i * LDW + j] = a[j]; DL[i * LDW + j + 1] = a[j + 1]; }
+    for (int m = 0; m < 16; ++m) {
+      const double e = m == j ? 1.0 : 0.0;
+      const double wv = (m == 0 ? e : w[m] + e) * DL[(base + m) * LDW + base + m];
+      w[m] = wv;
+#pragma unroll
+      for (int r = m + 1; r < 16; ++r) {
+        const double l = DL[(base + r) * LDW + base + m];
+        w[r] = m == 0 ? -l * wv : fma(-l, wv, w[r]);
+      }
+    }
+    if (lane < FRONT_NB) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Wd[(base + r) * LDWD + j] = w[r];
+    }
   }
   return bad;
 }
-__device__ __noinline__ void inverse_wave(const lds_double* DL, lds_double* Wl) {
-  const int lane = threadIdx.x & 63;
-  double a[FRONT_NB];
-#pragma unroll
-  for (int m = 0; m < FRONT_NB; ++m) {
-    const double e = m == lane ? 1.0 : 0.0;
-    const double w = (m == 0 ? e : a[m] + e) * DL[m * LDW + m];
-    a[m] = w;
-#pragma unroll
-    for (int r = m + 1; r < FRONT_NB; ++r) {
-      const double l = DL[r * LDW + m];
-      a[r] = m == 0 ? -l * w : fma(-l, w, a[r]);
-    }
-  }
-  if (lane < FRONT_NB) {
-#pragma unroll
-    for (int r = 0; r < FRONT_NB; ++r) Wl[r * LDW + lane] = a[r];
-  }
-}
 
-template <int MODE>
+
 __global__ __launch_bounds__(64) void kt(const double* in, double* out, int* flags, long long* cycles) {
   __shared__ double DL[FRONT_NB * LDW];
-  __shared__ double Wl[FRONT_NB * LDW];
-  __shared__ double colbuf[128];
+  __shared__ double Wd[FRONT_NB * LDWD];
+  __shared__ double cbuf[128];
   const int lane = threadIdx.x;
-  for (int e = lane; e < 48*48; e += 64) { DL[(e/48)*LDW + e%48] = in[e]; Wl[(e/48)*LDW + e%48] = 0.0; }
+  for (int e = lane; e < 48*48; e += 64) DL[(e/48)*LDW + e%48] = in[e];
   __syncthreads();
   const long long t0 = __builtin_readcyclecounter();
-  bool bad = false;
-  if (MODE != 2) bad = potrf_wave((lds_double*)DL, (lds_double*)colbuf);
+  const bool bad = diag_block_wave((lds_double*)DL, (lds_double*)Wd, (lds_double*)cbuf);
   const long long t1 = __builtin_readcyclecounter();
-  if (MODE != 1) inverse_wave((lds_double*)DL, (lds_double*)Wl);
-  const long long t2 = __builtin_readcyclecounter();
   if (bad) flags[0] = 1;
-  if (lane == 0 && blockIdx.x == 0) { cycles[0] = t1 - t0; cycles[1] = t2 - t1; }
-  for (int e = lane; e < 48*48; e += 64) { out[e] = Wl[(e/48)*LDW + e%48]; out[2304+e] = DL[(e/48)*LDW + e%48]; }
+  if (lane == 0 && blockIdx.x == 0) cycles[0] = t1 - t0;
+  for (int e = lane; e < 48*48; e += 64) { out[2304+e] = DL[(e/48)*LDW + e%48]; }
+  for (int e = lane; e < 48*16; e += 64) { out[e] = Wd[(e/16)*LDWD + e%16]; }
 }
-
-#include <cstdio>
-#include <vector>
-#include <cmath>
 int main() {
   std::vector<double> A(2304), B(2304);
-  for (int i = 0; i < 48; ++i) for (int j = 0; j < 48; ++j) B[i*48+j] = std::sin(1.0 + i*7 + j*3) ;
+  for (int i = 0; i < 48; ++i) for (int j = 0; j < 48; ++j) B[i*48+j] = std::sin(1.0 + i*7 + j*3);
   for (int i = 0; i < 48; ++i) for (int j = 0; j < 48; ++j) { double s = 0; for (int k = 0; k < 48; ++k) s += B[i*48+k]*B[j*48+k]; A[i*48+j] = s + (i==j ? 48.0 : 0.0); }
   double *din, *dout; int* df; long long* dc;
   hipMalloc(&din, 2304*8); hipMalloc(&dout, 2*2304*8); hipMalloc(&df, 4); hipMalloc(&dc, 16);
   hipMemcpy(din, A.data(), 2304*8, hipMemcpyHostToDevice); hipMemset(df, 0, 4);
-  for (int mode = 0; mode < 3; ++mode) {
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int rep = 0; rep < 2; ++rep) {
-      hipEventRecord(e0);
-      for (int it = 0; it < 200; ++it) {
-        if (mode == 0) kt<0><<<1, 64>>>(din, dout, df, dc);
-        else if (mode == 1) kt<1><<<1, 64>>>(din, dout, df, dc);
-        else kt<2><<<1, 64>>>(din, dout, df, dc);
-      }
-      hipEventRecord(e1); hipEventSynchronize(e1);
-    }
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    long long cyc[2]; hipMemcpy(cyc, dc, 16, hipMemcpyDeviceToHost);
-    printf("mode %d: %.2f us per launch; cycles potrf %lld inverse %lld (100 MHz counter: x10 ns)\n", mode, 1e3*ms/200, cyc[0], cyc[1]);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0);
+    for (int it = 0; it < 200; ++it) kt<<<1, 64>>>(din, dout, df, dc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
   }
-  // check W L = I
-  kt<0><<<1, 64>>>(din, dout, df, dc);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  long long cyc; hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost);
+  printf("%.2f us per launch; diag_block_wave %lld ticks of s_memtime\n", 1e3*ms/200, cyc);
   std::vector<double> O(2*2304); hipMemcpy(O.data(), dout, 2*2304*8, hipMemcpyDeviceToHost);
-  double err = 0, errl = 0;
-  // L has 1/diag on the diagonal
-  for (int i = 0; i < 48; ++i) for (int j = 0; j <= i; ++j) { double s = 0; for (int k = 0; k <= j; ++k) { double lik = k==i ? 1.0/O[2304+i*48+k] : O[2304+i*48+k]; double ljk = k==j ? 1.0/O[2304+j*48+k] : O[2304+j*48+k]; s += lik*ljk; } errl = fmax(errl, fabs(s - A[i*48+j])); }
-  for (int i = 0; i < 48; ++i) for (int j = 0; j < 48; ++j) { double s = 0; for (int k = 0; k < 48; ++k) { double lkj = k==j ? 1.0/O[2304+k*48+j] : (k>j ? O[2304+k*48+j] : 0.0); s += O[i*48+k]*lkj; } err = fmax(err, fabs(s - (i==j))); }
-  printf("|LL^T - A| %.3e  |W L - I| %.3e\n", errl, err);
+  auto L = [&](int i, int k) { return k == i ? 1.0 / O[2304+i*48+k] : (k < i ? O[2304+i*48+k] : 0.0); };
+  double errl = 0, errw = 0;
+  for (int i = 0; i < 48; ++i) for (int j = 0; j <= i; ++j) { double s = 0; for (int k = 0; k <= j; ++k) s += L(i,k)*L(j,k); errl = fmax(errl, fabs(s - A[i*48+j])); }
+  for (int b = 0; b < 3; ++b) for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { double s = 0; for (int k = 0; k < 16; ++k) s += O[(16*b+i)*16+k]*L(16*b+k,16*b+j); errw = fmax(errw, fabs(s - (i==j))); }
+  printf("|LL^T - A| %.3e  |W_bb L_bb - I| %.3e\n", errl, errw);
   return 0;
 }
