@@ -342,6 +342,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
   // needs it) one GEMM launch: the right-looking update behind an outer panel that just finished, or the Schur update of
   // a front whose last panel was s.
   S.levels.resize(n_levels);
+  const long long tile32_below = (long long)env_or("PGO_FRONT_TILE32_BELOW", 192);
   {
     int f = 0;
     for (int l = 0; l < n_levels; ++l) {
@@ -390,7 +391,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
       int max_steps = 0;
       for (int q = L.front_begin; q < L.front_end; ++q) max_steps = std::max(max_steps, (6 * S.fronts[q].c + FRONT_NB - 1) / FRONT_NB);
       for (int step = 0; step < max_steps; ++step) {
-        FrontLaunch lp{FrontLaunch::PANEL, 0, (int)S.wg_job.size()};
+        FrontLaunch lp{FrontLaunch::PANEL, 0, FRONT_TILE, (int)S.wg_job.size()};
         for (int q = L.front_begin; q < L.front_end; ++q) {
           const FrontDesc& D = S.fronts[q];
           const int c6 = 6 * D.c, n = 6 * (D.c + D.r), k0 = step * FRONT_NB;
@@ -404,7 +405,9 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
         }
         lp.n_wg = (int)S.wg_job.size() - lp.wg_begin;
         S.launches.push_back(lp);
-        FrontLaunch lg{FrontLaunch::GEMM, 0, (int)S.wg_job.size()};
+        // GEMM jobs of this step; launches with few 64 x 64 tiles are cut into 32 x 32 tiles instead
+        std::vector<int> gjobs;
+        long long tiles64 = 0;
         for (int q = L.front_begin; q < L.front_end; ++q) {
           const FrontDesc& D = S.fronts[q];
           const int c6 = 6 * D.c, n = 6 * (D.c + D.r), k0 = step * FRONT_NB;
@@ -416,13 +419,19 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
           if (oend < c6) { r0 = oend; r1 = n + 1; cc0 = oend; cc1 = c6; kk0 = ostart; klen = oend - ostart; }
           else { r0 = c6; r1 = n + 1; cc0 = c6; cc1 = n; kk0 = 0; klen = c6; }
           if (cc1 <= cc0) continue;
-          const int job = (int)S.jobs.size();
+          gjobs.push_back((int)S.jobs.size());
           S.jobs.push_back(FrontJob{D.fbase, D.ld, r0, r1, cc0, cc1, kk0, klen, 0});
-          const int ntr = (r1 - r0 + FRONT_TILE - 1) / FRONT_TILE, ntc = (cc1 - cc0 + FRONT_TILE - 1) / FRONT_TILE;
+          tiles64 += (long long)((r1 - r0 + 63) / 64) * ((cc1 - cc0 + 63) / 64);
+        }
+        const int T = tiles64 <= tile32_below ? 32 : 64;
+        FrontLaunch lg{FrontLaunch::GEMM, 0, T, (int)S.wg_job.size()};
+        for (int job : gjobs) {
+          const FrontJob& J = S.jobs[job];
+          const int ntr = (J.r1 - J.r0 + T - 1) / T, ntc = (J.c1 - J.c0 + T - 1) / T;
           for (int ti = 0; ti < ntr; ++ti)
             for (int tj = 0; tj < ntc; ++tj) {
-              const int row_last = std::min(r0 + FRONT_TILE * (ti + 1), r1) - 1;
-              if (row_last < cc0 + FRONT_TILE * tj) continue;   // entirely above the diagonal
+              const int row_last = std::min(J.r0 + T * (ti + 1), J.r1) - 1;
+              if (row_last < J.c0 + T * tj) continue;   // entirely above the diagonal
               S.wg_job.push_back(job);
               S.wg_tile.push_back((ti << 16) | tj);
             }

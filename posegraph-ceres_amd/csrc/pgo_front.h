@@ -56,6 +56,7 @@ struct FrontJob {
 struct FrontLaunch {
   enum Type { PANEL = 0, GEMM = 2 };
   int type, n_wg;
+  int tile;          // GEMM: rows = columns of a workgroup's tile, 64 or 32 (launches with few tiles)
   int wg_begin;      // workgroup w of the launch runs job wg_job[wg_begin + w] on tile wg_tile[wg_begin + w] = (ti << 16) | tj
 };
 

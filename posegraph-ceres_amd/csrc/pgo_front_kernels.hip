@@ -176,28 +176,27 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
   return u.d;
 }
 
-// 1/sqrt(d): v_rsq_f64 seed + coupled Newton (Goldschmidt) steps; the result is used both for the diagonal (d * rs) and
-// for scaling the column, so the factor is self-consistent to an ulp or two
-__device__ __forceinline__ double rsqrt_nr(double d) {
+// 1/sqrt(d): v_rsq_f64 seed + two coupled Newton (Goldschmidt) steps, returned as h = 1 / (2 sqrt(d)) so the caller folds the
+// doubling into an operand that is ready early ((a + a) * h): six dependent operations on the pivot chain.  The result is used
+// both for the diagonal and for scaling the column, so the factor is self-consistent to an ulp or two
+// (tools/bench/potrf_bench.hip: |L L^T - A| at the 1e-14 level for a 48 x 48 block of norm ~100).
+__device__ __forceinline__ double half_rsqrt_nr(double d) {
   const double y = __builtin_amdgcn_rsq(d);
   double g = d * y, h = 0.5 * y;
   double r = fma(-h, g, 0.5);
   g = fma(g, r, g);
   h = fma(h, r, h);
   r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
   h = fma(h, r, h);
-  r = fma(-h, g, 0.5);
-  h = fma(h, r, h);
-  return h + h;
+  return h;
 }
 
 // ---- the 48 x 48 diagonal block, one wave ------------------------------------------------------------------------------
 // Blocked by 16 columns with the matrix resident in LDS (DL, row-major, stride LDW):
 //   per block  load its 16 columns, lane i = row i (16 registers);
-//              16 scalar steps: pivot by v_readlane, 1/sqrt by v_rsq_f64 + Newton, the NEXT column is updated with a second
-//              v_readlane (so the pivot chain never waits for LDS), the other columns of the block through an LDS
-//              broadcast of column k;
+//              16 scalar steps: pivot by v_readlane, 1/sqrt by v_rsq_f64 + Newton; the next pivot is formed in its own lane
+//              from that lane's multiplier (the pivot chain never waits for LDS or a second broadcast), the next column is
+//              updated through a v_readlane, the other columns of the block through an LDS broadcast of column k;
 //              store the block column; update the trailing 16 x 16 tiles on the matrix cores (K = 16).
 //   then       the three 16 x 16 diagonal blocks are inverted, lane = (block, column), right-looking.
 // Result: DL = L with 1 / L_kk on the diagonal, Wd[16 b + r][c] = (L_bb^-1)[r][c].  The consumers (TRSM below, backward
@@ -220,14 +219,17 @@ __device__ __noinline__ bool diag_block_wave(lds_double* DL, lds_double* Wd, lds
       const double v = DL[i * LDW + c0 + j];
       a[j] = c0 + j <= i ? v : 0.0;
     }
+    double dn = a[0];     // the next pivot, valid in the lane that owns it
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const double d = readlane_d(a[k], c0 + k);
+      const double d = readlane_d(dn, c0 + k);
       bad |= !(d > 0.0);
-      const double rs = rsqrt_nr(d);
-      const double l = a[k] * rs;
-      a[k] = lane == c0 + k ? rs : l;
+      const double a2 = a[k] + a[k];
+      const double h = half_rsqrt_nr(d);
+      const double l = a2 * h;
+      a[k] = lane == c0 + k ? h + h : l;
       if (k < 15) {
+        dn = fma(-l, l, a[k + 1]);            // lane c0 + k + 1: its own l is the multiplier of its diagonal entry
         const double ln = readlane_d(l, c0 + k + 1);
         a[k + 1] = fma(-l, ln, a[k + 1]);
         if (k < 14) {
@@ -432,49 +434,55 @@ __global__ __launch_bounds__(320) void k_front_panel(FrontPlan p, int wg_begin, 
 // work on the current one); every fragment is loaded from a clamped, always valid address and out-of-range k is masked in
 // the A fragment afterwards, so no load sits behind a branch.  Tiles entirely above the diagonal are computed and dropped
 // in the epilogue (only the workgroups that straddle the diagonal have any).
-struct GemmFrag { double2 a[2], b[4][2]; };
+// Launches with few tiles (the top of the tree) use 32 x 32 tiles, one 16 x 16 tile per wave: a wave's K loop is bound by
+// the matrix pipe (~61 ns per instruction), so a quarter of the tile per wave is a quarter of the time, and the extra
+// workgroups are free on a mostly idle chip.
+template <int NQ>
+struct GemmFrag { double2 a[2], b[NQ][2]; };
 
+template <int TILE>
 __global__ __launch_bounds__(256) void k_front_gemm(FrontPlan p, int wg_begin) {
+  constexpr int NQ = TILE == 64 ? 4 : 1;
   const int wgi = wg_begin + blockIdx.x;
   const FrontJob J = p.jobs[p.wg_job[wgi]];
   const int tt = p.wg_tile[wgi], ti = tt >> 16, tj = tt & 0xffff;
-  const int row0 = J.r0 + FRONT_TILE * ti, col0 = J.c0 + FRONT_TILE * tj;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g4 = lane >> 4;
+  const int wrow0 = J.r0 + TILE * ti + (TILE == 64 ? 16 * wave : 16 * (wave >> 1));
+  const int col0 = J.c0 + TILE * tj + (TILE == 64 ? 0 : 16 * (wave & 1));
   double* F = p.Fval + J.fbase;
   const int ld = J.ld;
-  const int wrow0 = row0 + 16 * wave;
-  if (wrow0 >= J.r1) return;
+  if (wrow0 >= J.r1 || col0 >= J.c1) return;
   const int wrow_last = min(wrow0 + 15, J.r1 - 1);
   if (col0 > wrow_last) return;
   const double* Ap = F + (size_t)min(wrow0 + li, J.r1 - 1) * ld + J.k0;
-  const double* Bp[4];
+  const double* Bp[NQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) Bp[q] = F + (size_t)min(col0 + 16 * q + li, J.c1 - 1) * ld + J.k0;
-  double4_t acc[4];
+  for (int q = 0; q < NQ; ++q) Bp[q] = F + (size_t)min(col0 + 16 * q + li, J.c1 - 1) * ld + J.k0;
+  double4_t acc[NQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+  for (int q = 0; q < NQ; ++q) acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
   const int klen = J.klen, kmax = klen - 2;
-  auto load = [&](int kc, GemmFrag& f) {
+  auto load = [&](int kc, GemmFrag<NQ>& f) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int k = kc + 8 * h + 2 * g4, kk = min(k, kmax);
       f.a[h] = *reinterpret_cast<const double2*>(Ap + kk);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) f.b[q][h] = *reinterpret_cast<const double2*>(Bp[q] + kk);
+      for (int q = 0; q < NQ; ++q) f.b[q][h] = *reinterpret_cast<const double2*>(Bp[q] + kk);
       if (k > kmax) f.a[h] = double2{0.0, 0.0};
     }
   };
-  auto compute = [&](const GemmFrag& f) {
+  auto compute = [&](const GemmFrag<NQ>& f) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const Rot4 rx = rot4(f.a[h].x), ry = rot4(f.a[h].y);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) mma16(acc[q], rx, f.b[q][h].x);
+      for (int q = 0; q < NQ; ++q) mma16(acc[q], rx, f.b[q][h].x);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) mma16(acc[q], ry, f.b[q][h].y);
+      for (int q = 0; q < NQ; ++q) mma16(acc[q], ry, f.b[q][h].y);
     }
   };
-  GemmFrag f0, f1;
+  GemmFrag<NQ> f0, f1;
   load(0, f0);
   for (int kc = 0; kc < klen; kc += 32) {
     if (kc + 16 < klen) load(kc + 16, f1);
@@ -484,9 +492,9 @@ __global__ __launch_bounds__(256) void k_front_gemm(FrontPlan p, int wg_begin) {
     compute(f1);
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = unrot(acc[q]);
+  for (int q = 0; q < NQ; ++q) acc[q] = unrot(acc[q]);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int c = col0 + 16 * q + li;
     if (c >= J.c1 || col0 + 16 * q > wrow_last) continue;
 #pragma unroll
@@ -593,46 +601,59 @@ __global__ __launch_bounds__(BWD_T) void k_front_bwd_block(DeviceGraph g, FrontP
   for (int pn = (c1 - 1) / FRONT_NB; pn >= c0 / FRONT_NB; --pn) {
     const int k0 = pn * FRONT_NB, nb = min((int)FRONT_NB, c6 - k0), kl = k0 - c0;
     // x_k = L_kk^-T t_k through M = [[W00 0 0], [L10 W11 0], [L20 L21 W22]] (16 x 16 blocks), last block first:
-    // x_b = W_bb^T t_b, then t_a -= L_ba^T x_b for the blocks a < b
+    // x_b = W_bb^T t_b, then t_a -= L_ba^T x_b for the blocks a < b.  M goes to LDS with all lanes; the three dependent
+    // stages run on wave 0 alone (wave-level ordering only, no workgroup barriers inside).
     const double* M = p.Winv + D.wbase + (size_t)pn * FRONT_NB * FRONT_NB;
     for (int e = tid; e < FRONT_NB * FRONT_NB; e += BWD_T) Ms[(e / FRONT_NB) * (FRONT_NB + 1) + e % FRONT_NB] = M[e];
     __syncthreads();
-    for (int bb = 2; bb >= 0; --bb) {
-      if (tid < 16) {
-        double s = 0.0;
-        for (int b = tid; b < 16; ++b) s = fma(Ms[(16 * bb + b) * (FRONT_NB + 1) + 16 * bb + tid], tv[kl + 16 * bb + b], s);
-        xs[tid] = s;
-      }
-      __syncthreads();
-      if (tid < 16) {
-        const int e = 16 * bb + tid;
-        tv[kl + e] = xs[tid];
-        if (e < nb) {
-          const int col = D.first + (k0 + e) / 6, kk = (k0 + e) % 6;
-          xb[k0 + e] = xs[tid];
-          g.cg_x[6 * (size_t)p.perm[col] + kk] = xs[tid];
+    if (tid < 64) {
+      double* tp = tv + kl;
+#pragma unroll
+      for (int bb = 2; bb >= 0; --bb) {
+        // the diagonal blocks of M hold the full 16 x 16 inverse (zeros above its diagonal): fixed 16-term sums
+        double sx = 0.0;
+        if ((tid >> 4) == bb) {
+#pragma unroll
+          for (int bq = 0; bq < 16; ++bq) sx = fma(Ms[(16 * bb + bq) * (FRONT_NB + 1) + tid], tp[16 * bb + bq], sx);
         }
-      } else if (tid >= 64 && tid < 64 + 16 * bb) {
-        const int a = tid - 64;
-        double s = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if ((tid >> 4) == bb) tp[tid] = sx;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (tid < 16 * bb) {
+          double su = 0.0;
 #pragma unroll
-        for (int b = 0; b < 16; ++b) s = fma(Ms[(16 * bb + b) * (FRONT_NB + 1) + a], xs[b], s);
-        tv[kl + a] -= s;
+          for (int bq = 0; bq < 16; ++bq) su = fma(Ms[(16 * bb + bq) * (FRONT_NB + 1) + tid], tp[16 * bb + bq], su);
+          tp[tid] -= su;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
-      __syncthreads();
+      if (tid < nb) {
+        const int col = D.first + (k0 + tid) / 6, kk = (k0 + tid) % 6;
+        xb[k0 + tid] = tp[tid];
+        g.cg_x[6 * (size_t)p.perm[col] + kk] = tp[tid];
+      }
     }
-    for (int jc = 0; jc < kl; jc += 64) {
-      const int j = jc + jl;
-      double s = 0.0;
-      if (j < kl) for (int a = rg; a < nb; a += NG) s = fma(F[(size_t)(k0 + a) * ld + c0 + j], tv[kl + a], s);
-      red[tid] = s;
-      __syncthreads();
-      if (rg == 0 && j < kl) {
-        double tot = 0.0;
+    __syncthreads();
+    // t[j] -= sum_a L[k0 + a][c0 + j] x_k[a] for the chunk's columns before the panel (at most 144): lane = (column j, third
+    // of the panel's rows), 16 independent loads each
+    if (kl > 0) {
+      const int j = tid % 160, part = tid / 160;
+      double s0 = 0.0;
+      if (j < kl && part < 3) {
+        const double* col = F + (size_t)k0 * ld + c0 + j;
 #pragma unroll
-        for (int q = 0; q < NG; ++q) tot += red[64 * q + jl];
-        tv[j] -= tot;
+        for (int a2 = 0; a2 < 16; ++a2) {
+          const int row = 16 * part + a2;
+          const double v = col[(size_t)min(row, nb - 1) * ld];
+          s0 = fma(row < nb ? v : 0.0, tv[kl + row], s0);
+        }
       }
+      red[tid] = s0;
+      __syncthreads();
+      if (tid < kl) tv[tid] -= red[tid] + red[tid + 160] + red[tid + 320];
       __syncthreads();
     }
   }
@@ -650,7 +671,8 @@ void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSy
       const FrontLaunch& La = sym.launches[li];
       if (La.n_wg <= 0) continue;
       if (La.type == FrontLaunch::PANEL) hipLaunchKernelGGL(k_front_panel, dim3(La.n_wg), dim3(320), 0, s, p, La.wg_begin, g.flags);
-      else hipLaunchKernelGGL(k_front_gemm, dim3(La.n_wg), dim3(256), 0, s, p, La.wg_begin);
+      else if (La.tile == 32) hipLaunchKernelGGL(k_front_gemm<32>, dim3(La.n_wg), dim3(256), 0, s, p, La.wg_begin);
+      else hipLaunchKernelGGL(k_front_gemm<64>, dim3(La.n_wg), dim3(256), 0, s, p, La.wg_begin);
     }
   }
 }

@@ -6,6 +6,51 @@
 #include <cmath>
 enum { FRONT_NB = 48 };
 typedef double double4_t __attribute__((ext_vector_type(4)));
+#ifndef PGO_FRONT_MFMA4
+#define PGO_FRONT_MFMA4 0
+#endif
+#if PGO_FRONT_MFMA4
+__device__ __forceinline__ double ror4(double v) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_mov_dpp(u.i[0], 0x124, 0xf, 0xf, true);
+  u.i[1] = __builtin_amdgcn_mov_dpp(u.i[1], 0x124, 0xf, 0xf, true);
+  return u.d;
+}
+struct Rot4 { double v[4]; };
+__device__ __forceinline__ Rot4 rot4(double a) {
+  Rot4 r;
+  r.v[0] = a;
+  r.v[1] = ror4(a);
+  r.v[2] = ror4(r.v[1]);
+  r.v[3] = ror4(r.v[2]);
+  return r;
+}
+__device__ __forceinline__ void mma16(double4_t& acc, const Rot4& a, double b) {
+  acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v[0], b, acc[0], 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v[1], b, acc[1], 0, 0, 0);
+  acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v[2], b, acc[2], 0, 0, 0);
+  acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v[3], b, acc[3], 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(double4_t& acc, double a, double b) { mma16(acc, rot4(a), b); }
+__device__ __forceinline__ double4_t unrot(const double4_t& acc) {
+  const int cb = (threadIdx.x & 15) >> 2;
+  double4_t o;
+  o[0] = cb == 0 ? acc[0] : cb == 1 ? acc[1] : cb == 2 ? acc[2] : acc[3];
+  o[1] = cb == 0 ? acc[3] : cb == 1 ? acc[0] : cb == 2 ? acc[1] : acc[2];
+  o[2] = cb == 0 ? acc[2] : cb == 1 ? acc[3] : cb == 2 ? acc[0] : acc[1];
+  o[3] = cb == 0 ? acc[1] : cb == 1 ? acc[2] : cb == 2 ? acc[3] : acc[0];
+  return o;
+}
+#else
+typedef double Rot4;
+__device__ __forceinline__ Rot4 rot4(double a) { return a; }
+__device__ __forceinline__ void mma16(double4_t& acc, double a, double b) {
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ double4_t unrot(const double4_t& acc) { return acc; }
+#endif
+
 constexpr int LDW = FRONT_NB + 2;   // LDS row stride (doubles): rows stay 16-byte aligned, 16 lanes x b64/b128 conflict-free
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -16,28 +61,27 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
   return u.d;
 }
 
-// 1/sqrt(d): v_rsq_f64 seed + coupled Newton (Goldschmidt) steps; the result is used both for the diagonal (d * rs) and
-// for scaling the column, so the factor is self-consistent to an ulp or two
-__device__ __forceinline__ double rsqrt_nr(double d) {
+// 1/sqrt(d): v_rsq_f64 seed + two coupled Newton (Goldschmidt) steps, returned as h = 1 / (2 sqrt(d)) so the caller folds the
+// doubling into an operand that is ready early ((a + a) * h): six dependent operations on the pivot chain.  The result is used
+// both for the diagonal and for scaling the column, so the factor is self-consistent to an ulp or two
+// (tools/bench/potrf_bench.hip: |L L^T - A| at the 1e-14 level for a 48 x 48 block of norm ~100).
+__device__ __forceinline__ double half_rsqrt_nr(double d) {
   const double y = __builtin_amdgcn_rsq(d);
   double g = d * y, h = 0.5 * y;
   double r = fma(-h, g, 0.5);
   g = fma(g, r, g);
   h = fma(h, r, h);
   r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
   h = fma(h, r, h);
-  r = fma(-h, g, 0.5);
-  h = fma(h, r, h);
-  return h + h;
+  return h;
 }
 
 // ---- the 48 x 48 diagonal block, one wave ------------------------------------------------------------------------------
 // Blocked by 16 columns with the matrix resident in LDS (DL, row-major, stride LDW):
 //   per block  load its 16 columns, lane i = row i (16 registers);
-//              16 scalar steps: pivot by v_readlane, 1/sqrt by v_rsq_f64 + Newton, the NEXT column is updated with a second
-//              v_readlane (so the pivot chain never waits for LDS), the other columns of the block through an LDS
-//              broadcast of column k;
+//              16 scalar steps: pivot by v_readlane, 1/sqrt by v_rsq_f64 + Newton; the next pivot is formed in its own lane
+//              from that lane's multiplier (the pivot chain never waits for LDS or a second broadcast), the next column is
+//              updated through a v_readlane, the other columns of the block through an LDS broadcast of column k;
 //              store the block column; update the trailing 16 x 16 tiles on the matrix cores (K = 16).
 //   then       the three 16 x 16 diagonal blocks are inverted, lane = (block, column), right-looking.
 // Result: DL = L with 1 / L_kk on the diagonal, Wd[16 b + r][c] = (L_bb^-1)[r][c].  The consumers (TRSM below, backward
@@ -60,14 +104,17 @@ __device__ __noinline__ bool diag_block_wave(lds_double* DL, lds_double* Wd, lds
       const double v = DL[i * LDW + c0 + j];
       a[j] = c0 + j <= i ? v : 0.0;
     }
+    double dn = a[0];     // the next pivot, valid in the lane that owns it
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const double d = readlane_d(a[k], c0 + k);
+      const double d = readlane_d(dn, c0 + k);
       bad |= !(d > 0.0);
-      const double rs = rsqrt_nr(d);
-      const double l = a[k] * rs;
-      a[k] = lane == c0 + k ? rs : l;
+      const double a2 = a[k] + a[k];
+      const double h = half_rsqrt_nr(d);
+      const double l = a2 * h;
+      a[k] = lane == c0 + k ? h + h : l;
       if (k < 15) {
+        dn = fma(-l, l, a[k + 1]);            // lane c0 + k + 1: its own l is the multiplier of its diagonal entry
         const double ln = readlane_d(l, c0 + k + 1);
         a[k + 1] = fma(-l, ln, a[k + 1]);
         if (k < 14) {
@@ -85,19 +132,17 @@ __device__ __noinline__ bool diag_block_wave(lds_double* DL, lds_double* Wd, lds
     if (b < 2) {
 #pragma unroll
       for (int qa = b + 1; qa < 3; ++qa) {
-        double fa[4];
+        Rot4 fa[4];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) fa[s4] = DL[(16 * qa + li) * LDW + c0 + 4 * s4 + g4];
+        for (int s4 = 0; s4 < 4; ++s4) { const double t = DL[(16 * qa + li) * LDW + c0 + 4 * s4 + g4]; fa[s4] = rot4(t); }
 #pragma unroll
         for (int qb = b + 1; qb <= qa; ++qb) {
           double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            const double fb = DL[(16 * qb + li) * LDW + c0 + 4 * s4 + g4];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s4], fb, acc, 0, 0, 0);
-          }
+          for (int s4 = 0; s4 < 4; ++s4) { const double t = DL[(16 * qb + li) * LDW + c0 + 4 * s4 + g4]; mma16(acc, fa[s4], t); }
+          const double4_t res = unrot(acc);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) DL[(16 * qa + g4 + 4 * r) * LDW + 16 * qb + li] -= acc[r];
+          for (int r = 0; r < 4; ++r) DL[(16 * qa + g4 + 4 * r) * LDW + 16 * qb + li] -= res[r];
         }
       }
     }
@@ -124,7 +169,6 @@ __device__ __noinline__ bool diag_block_wave(lds_double* DL, lds_double* Wd, lds
   }
   return bad;
 }
-
 
 __global__ __launch_bounds__(64) void kt(const double* in, double* out, int* flags, long long* cycles) {
   __shared__ double DL[FRONT_NB * LDW];
