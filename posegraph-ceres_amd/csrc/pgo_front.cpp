@@ -353,12 +353,45 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
       L.asm_front_begin = L.front_end;
       for (int q = L.front_begin; q < L.front_end; ++q)
         if (S.fronts[q].child_end > S.fronts[q].child_begin) { L.asm_front_begin = q; break; }
-      int wg = 0;
-      for (int q = L.asm_front_begin; q < L.front_end; ++q) {
-        S.fronts[q].asm_wg_begin = wg;
-        wg += (S.fronts[q].ntp + 1) * S.fronts[q].ntp;
+      // extend-add: one workgroup per parent tile (8 x 8 poses, or the right-hand-side row x 8 poses) that receives
+      // anything, with the list of the children that contribute and their row ranges (children in list order)
+      L.asm_wg_begin = (int)(S.asm_tile.size() / 4);
+      {
+        struct Rec { long long key; int child, kk, mm; };
+        std::vector<Rec> recs;
+        std::vector<int> occ;
+        for (int q = L.asm_front_begin; q < L.front_end; ++q) {
+          const FrontDesc& P = S.fronts[q];
+          recs.clear();
+          for (int ci = P.child_begin; ci < P.child_end; ++ci) {
+            const FrontDesc& C = S.fronts[S.child[ci]];
+            const int* cs = S.cstart.data() + C.cs_begin;
+            occ.clear();
+            for (int t = 0; t < P.ntp; ++t) if (cs[t + 1] > cs[t]) occ.push_back(t);
+            for (size_t a = 0; a <= occ.size(); ++a) {            // a == occ.size(): the right-hand-side row
+              const bool rhs = a == occ.size();
+              const int ti = rhs ? P.ntp : occ[a];
+              const int kk = rhs ? (C.r << 16) | (C.r + 1) : (cs[ti] << 16) | cs[ti + 1];
+              for (size_t b = 0; b < occ.size() && (rhs || b <= a); ++b) {
+                const int tj = occ[b];
+                recs.push_back(Rec{((long long)ti << 40) | ((long long)tj << 20) | (long long)(ci - P.child_begin), S.child[ci], kk, (cs[tj] << 16) | cs[tj + 1]});
+              }
+            }
+          }
+          std::sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.key < b.key; });
+          for (size_t e = 0; e < recs.size();) {
+            size_t f2 = e;
+            while (f2 < recs.size() && (recs[f2].key >> 20) == (recs[e].key >> 20)) ++f2;
+            S.asm_tile.push_back(q);
+            S.asm_tile.push_back((int)(((recs[e].key >> 40) << 16) | ((recs[e].key >> 20) & 0xfffff)));
+            S.asm_tile.push_back((int)(S.asm_contrib.size() / 3));
+            for (size_t u = e; u < f2; ++u) { S.asm_contrib.push_back(recs[u].child); S.asm_contrib.push_back(recs[u].kk); S.asm_contrib.push_back(recs[u].mm); }
+            S.asm_tile.push_back((int)(S.asm_contrib.size() / 3));
+            e = f2;
+          }
+        }
       }
-      L.asm_wg = wg;
+      L.asm_wg = (int)(S.asm_tile.size() / 4) - L.asm_wg_begin;
       L.bwd_wg_begin = (int)S.bwd_front.size();
       for (int q = L.front_begin; q < L.front_end; ++q)
         for (int ch = 0; ch < (6 * S.fronts[q].c + 63) / 64; ++ch) { S.bwd_front.push_back(q); S.bwd_chunk.push_back(ch); }
@@ -443,6 +476,8 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
     }
   }
   if (S.wg_job.empty()) { S.wg_job.push_back(0); S.wg_tile.push_back(0); }
+  if (S.asm_tile.empty()) S.asm_tile.assign(4, 0);
+  if (S.asm_contrib.empty()) S.asm_contrib.assign(3, 0);
   if (S.bwd_front.empty()) { S.bwd_front.push_back(0); S.bwd_chunk.push_back(0); }
   if (S.bwdb_front.empty()) { S.bwdb_front.push_back(0); S.bwdb_chunk.push_back(0); }
   S.n_launches = (int)S.launches.size() + 3 * n_levels + 2;

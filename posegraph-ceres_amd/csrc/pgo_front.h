@@ -64,7 +64,7 @@ struct FrontLevel {
   int front_begin, front_end;     // fronts are numbered level by level
   int launch_begin, launch_end;
   int asm_front_begin;            // fronts [asm_front_begin, front_end) have children (sorted last inside the level)
-  int asm_wg;                     // grid of the extend-add launch
+  int asm_wg_begin, asm_wg;       // extend-add launch: workgroups [asm_wg_begin, +asm_wg) of asm_tile
   int bwd_wg_begin, bwd_wg;       // backward substitution, phase A: workgroup w handles columns 64 * bwd_chunk[.] of front bwd_front[.]
   int bwd_step_begin, bwd_steps;  // phase B: steps [bwd_step_begin, +bwd_steps) of bwd_step_ptr (one launch each)
 };
@@ -80,7 +80,7 @@ struct FrontDesc {
   int rel_begin;    // as a child: rel[rel_begin .. rel_begin + r) = position (pose units) of each update row in the parent's front
   int cs_begin;     // as a child: cstart[cs_begin + t] = first update row whose parent position is >= 8 t, t = 0 .. parent ntp
   int wbase;        // W of panel p at Winv + wbase + p * FRONT_NB * FRONT_NB
-  int asm_wg_begin; // first workgroup of this front in its level's extend-add launch
+  int asm_wg_begin; // (unused)
   int ntp;          // pose tiles of FRONT_ASM_TP per side
   int parent;
   int pad;
@@ -103,6 +103,8 @@ struct FrontPlan {
   const FrontJob* jobs;
   const int* wg_job;
   const int* wg_tile;
+  const int* asm_tile;      // extend-add workgroups, 4 ints each: parent front, (ti << 16) | tj, first / end contributor
+  const int* asm_contrib;   // contributors, 3 ints each: child front, (ks << 16) | ke, (ms << 16) | me (child update rows)
   const int* bwd_front;
   const int* bwd_chunk;
   const int* bwdb_front;    // phase B workgroups: front ...
@@ -116,7 +118,7 @@ struct FrontSymbolic {
   int n = 0, nf = 0, n_levels = 0;
   std::vector<int> perm, iperm;
   std::vector<FrontDesc> fronts;
-  std::vector<int> idx, child, rel, cstart, col_front, wg_job, wg_tile, bwd_front, bwd_chunk, bwdb_front, bwdb_chunk, bwd_step_ptr;
+  std::vector<int> idx, child, rel, cstart, col_front, wg_job, wg_tile, asm_tile, asm_contrib, bwd_front, bwd_chunk, bwdb_front, bwdb_chunk, bwd_step_ptr;
   std::vector<int> ablk_ptr, ablk_slot, ablk_front, ablk_pos;
   std::vector<FrontJob> jobs;
   std::vector<FrontLaunch> launches;

@@ -105,39 +105,20 @@ __global__ __launch_bounds__(256) void k_front_scatter(DeviceGraph g, FrontPlan 
 
 constexpr int ASM_T = 6 * FRONT_ASM_TP;   // 48 scalars per tile side
 
-__global__ __launch_bounds__(256) void k_front_extend_add(FrontPlan p, int front_begin, int front_end) {
+__global__ __launch_bounds__(256) void k_front_extend_add(FrontPlan p, int wg_begin) {
   __shared__ double acc[ASM_T][ASM_T + 1];
-  // front of this workgroup
-  int lo = front_begin, hi = front_end - 1;
-  const int wg = blockIdx.x;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (p.fronts[mid].asm_wg_begin <= wg) lo = mid; else hi = mid - 1;
-  }
-  const FrontDesc P = p.fronts[lo];
-  const int t = wg - P.asm_wg_begin;
-  const int ti = t / P.ntp, tj = t - ti * P.ntp;
+  const int* rec = p.asm_tile + 4 * (size_t)(wg_begin + blockIdx.x);
+  const FrontDesc P = p.fronts[rec[0]];
+  const int ti = rec[1] >> 16, tj = rec[1] & 0xffff, cb = rec[2], ce = rec[3];
   const bool rhs_tile = ti == P.ntp;
-  if (!rhs_tile && tj > ti) return;
   const int tid = threadIdx.x;
-  // children that touch this tile
-  bool any = false;
-  for (int ci = P.child_begin; ci < P.child_end && !any; ++ci) {
-    const FrontDesc& C = p.fronts[p.child[ci]];
-    const int* cs = p.cstart + C.cs_begin;
-    any = cs[tj + 1] > cs[tj] && (rhs_tile || cs[ti + 1] > cs[ti]);
-  }
-  if (!any) return;
   for (int e = tid; e < ASM_T * (ASM_T + 1); e += 256) (&acc[0][0])[e] = 0.0;
   __syncthreads();
   const int np = 6 * (P.c + P.r);
-  for (int ci = P.child_begin; ci < P.child_end; ++ci) {
-    const FrontDesc C = p.fronts[p.child[ci]];
-    const int* cs = p.cstart + C.cs_begin;
-    const int ms = cs[tj], me = cs[tj + 1];
-    if (me <= ms) continue;
-    const int ks = rhs_tile ? C.r : cs[ti], ke = rhs_tile ? C.r + 1 : cs[ti + 1];
-    if (ke <= ks) continue;
+  for (int ci = cb; ci < ce; ++ci) {
+    const int* cr = p.asm_contrib + 3 * (size_t)ci;
+    const FrontDesc C = p.fronts[cr[0]];
+    const int ks = cr[1] >> 16, ke = cr[1] & 0xffff, ms = cr[2] >> 16, me = cr[2] & 0xffff;
     const int* rel = p.rel + C.rel_begin;
     const int nrow = rhs_tile ? 1 : 6 * (ke - ks), ncol = 6 * (me - ms);
     const double* Fc = p.Fval + C.fbase;
@@ -165,6 +146,7 @@ __global__ __launch_bounds__(256) void k_front_extend_add(FrontPlan p, int front
   }
 }
 
+// ---- the diagonal block ------------------------------------------------------------------------------------------------
 // ---- 48 x 48 Cholesky + inverse by ONE wave ---------------------------------------------------------------------------
 constexpr int LDW = FRONT_NB + 2;   // LDS row stride (doubles): rows stay 16-byte aligned, 16 lanes x b64/b128 conflict-free
 
@@ -666,7 +648,7 @@ void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSy
   const long long nt = (long long)p.n_ablk * 36 + 6LL * p.n;
   hipLaunchKernelGGL(k_front_scatter, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, g, p);
   for (const FrontLevel& L : sym.levels) {
-    if (L.asm_wg > 0) hipLaunchKernelGGL(k_front_extend_add, dim3(L.asm_wg), dim3(256), 0, s, p, L.asm_front_begin, L.front_end);
+    if (L.asm_wg > 0) hipLaunchKernelGGL(k_front_extend_add, dim3(L.asm_wg), dim3(256), 0, s, p, L.asm_wg_begin);
     for (int li = L.launch_begin; li < L.launch_end; ++li) {
       const FrontLaunch& La = sym.launches[li];
       if (La.n_wg <= 0) continue;

@@ -207,7 +207,7 @@ struct pgo_problem {
   pgo::FrontPlan fplan{};
   bool front_usable = false;
   DevBuf<int> df_perm, df_idx, df_child, df_rel, df_cstart, df_col_front, df_ablk_ptr, df_ablk_slot, df_ablk_front, df_ablk_pos, df_wg_job, df_wg_tile,
-      df_bwd_front, df_bwd_chunk, df_bwdb_front, df_bwdb_chunk;
+      df_bwd_front, df_bwd_chunk, df_bwdb_front, df_bwdb_chunk, df_asm_tile, df_asm_contrib;
   DevBuf<pgo::FrontDesc> df_fronts;
   DevBuf<pgo::FrontJob> df_jobs;
   DevBuf<double> df_Fval, df_Winv, df_x;
@@ -788,17 +788,21 @@ int prepare_clusters(pgo_problem* P, int CL) {
 }
 
 // ---- exact solver: GPU block-sparse Cholesky (pgo_direct.*) ----
-// Multifrontal solver: symbolic analysis + plan upload.  Leaves front_usable false when the fronts do not fit.
-int prepare_front(pgo_problem* P) {
+// Multifrontal solver: host analysis (front_analyzed_ok) and, once chosen, plan upload (front_usable).
+int analyze_front(pgo_problem* P, bool* ok) {
   pgo::FrontSymbolic& S = P->fsym;
   const auto t_an = Clock::now();
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   const char* cap = getenv("PGO_FRONT_MAX_GB");
   const long long budget = cap ? (long long)(atof(cap) * 1e9) : (long long)(0.6 * (double)free_b);
-  const bool ok = pgo::front_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side, budget, &S);
-  if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] front: symbolic analysis %.2f ms (%s)\n", 1e3 * seconds_since(t_an), ok ? "usable" : "declined");
-  if (!ok) return PGO_OK;
+  *ok = pgo::front_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side, budget, &S);
+  if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] front: symbolic analysis %.2f ms (%s)\n", 1e3 * seconds_since(t_an), *ok ? "usable" : "declined");
+  return PGO_OK;
+}
+
+int upload_front(pgo_problem* P) {
+  pgo::FrontSymbolic& S = P->fsym;
   const auto t_up = Clock::now();
   hipStream_t s = P->stream;
   HIP_TRY(P->df_perm.upload(S.perm, s));
@@ -812,6 +816,8 @@ int prepare_front(pgo_problem* P) {
   HIP_TRY(P->df_bwd_chunk.upload(S.bwd_chunk, s));
   HIP_TRY(P->df_bwdb_front.upload(S.bwdb_front, s));
   HIP_TRY(P->df_bwdb_chunk.upload(S.bwdb_chunk, s));
+  HIP_TRY(P->df_asm_tile.upload(S.asm_tile, s));
+  HIP_TRY(P->df_asm_contrib.upload(S.asm_contrib, s));
   HIP_TRY(P->df_col_front.upload(S.col_front, s));
   HIP_TRY(P->df_ablk_ptr.upload(S.ablk_ptr, s));
   HIP_TRY(P->df_ablk_slot.upload(S.ablk_slot, s));
@@ -828,6 +834,7 @@ int prepare_front(pgo_problem* P) {
   f.perm = P->df_perm.p; f.fronts = P->df_fronts.p; f.idx = P->df_idx.p; f.child = P->df_child.p; f.rel = P->df_rel.p; f.cstart = P->df_cstart.p;
   f.wg_job = P->df_wg_job.p; f.wg_tile = P->df_wg_tile.p; f.bwd_front = P->df_bwd_front.p; f.bwd_chunk = P->df_bwd_chunk.p;
   f.bwdb_front = P->df_bwdb_front.p; f.bwdb_chunk = P->df_bwdb_chunk.p;
+  f.asm_tile = P->df_asm_tile.p; f.asm_contrib = P->df_asm_contrib.p;
   f.col_front = P->df_col_front.p; f.ablk_ptr = P->df_ablk_ptr.p; f.ablk_slot = P->df_ablk_slot.p;
   f.ablk_front = P->df_ablk_front.p; f.ablk_pos = P->df_ablk_pos.p; f.n_ablk = (int)S.ablk_front.size();
   f.jobs = P->df_jobs.p; f.Fval = P->df_Fval.p; f.Winv = P->df_Winv.p; f.x = P->df_x.p;
@@ -844,11 +851,25 @@ int prepare_direct(pgo_problem* P) {
   const char* off = getenv("PGO_NO_DIRECT");
   if (off && off[0] == '1') return PGO_OK;
   if (P->comm && P->comm->world > 1) return PGO_OK;   // the factorisation needs every row: sharded runs use PCG to 1e-13
-  // PGO_FRONT=1: always the multifrontal solver; 0: never; default: for the graphs the enumerated schedule declines or
-  // would only serve per iteration (mesh-like: dense separators)
+  // Two GPU factorisations serve an exact request (measured, tools/front_vs_direct.py: KITTI-00 replay 0.34 ms with the
+  // enumerated 6x6 pairs vs 0.44 ms multifrontal; KITTI-00 dense 2.1 vs 2.8 ms; Manhattan 2 k 8.6 vs 1.6 ms; Manhattan 10 k
+  // 6.3 vs 5.6 ms; sphere x10: declined vs 39 ms).  The multifrontal analysis is the cheap one and runs first; chain-like
+  // graphs (largest front below PGO_FRONT_MIN scalars, default 192) then go to the enumerated schedule, everything else stays
+  // multifrontal.  PGO_FRONT=1: always multifrontal; 0: never.
   const char* fr = getenv("PGO_FRONT");
   const int front_mode = !fr ? -1 : (fr[0] == '1' ? 1 : 0);
+  const int front_min = getenv("PGO_FRONT_MIN") ? atoi(getenv("PGO_FRONT_MIN")) : 192;
   pgo::DirectSymbolic& S = P->dsym;
+  bool front_ok = false;
+  if (front_mode != 0) {
+    const int rc = analyze_front(P, &front_ok);
+    if (rc) return rc;
+    if (front_ok && (front_mode == 1 || P->fsym.max_front > front_min)) {
+      S = pgo::DirectSymbolic();
+      P->direct_usable = true;
+      return upload_front(P);
+    }
+  }
   bool usable = false;
   if (front_mode != 1) {
     const auto t_an = Clock::now();
@@ -856,14 +877,10 @@ int prepare_direct(pgo_problem* P) {
                                  P->h_row_slot_begin, &S);
     if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: symbolic analysis %.2f ms\n", 1e3 * seconds_since(t_an));
   }
-  if (front_mode == 1 || (front_mode < 0 && (!usable || S.hybrid))) {
-    const int rc = prepare_front(P);
-    if (rc) return rc;
-    if (P->front_usable) {
-      S.hybrid = false;
-      P->direct_usable = true;
-      return PGO_OK;
-    }
+  if (front_ok && (!usable || S.hybrid)) {
+    S.hybrid = false;
+    P->direct_usable = true;
+    return upload_front(P);
   }
   if (!usable) return PGO_OK;  // too much fill / too deep for the enumerated schedule: the iterative path serves the request
   const auto t_up = Clock::now();

@@ -59,10 +59,12 @@ def test_c5_sphere_layers(gpu, ds, O):
 
 
 def test_c2_exact_request_is_served_either_way_with_the_same_answer(gpu, ds, monkeypatch):
-    """C2 (10 k poses / 40 k edges) with the reference's linear solver setting: the factorisation is admitted but costly,
-    so each LM iteration is served by it or by PCG to 1e-13 (linear_solver_used = 3).  Size-independent properties: the
+    """C2 (10 k poses / 40 k edges) with the reference's linear solver setting and the multifrontal solver switched off
+    (PGO_FRONT=0; the default path for this graph is tests/test_gpu_front.py): the enumerated factorisation is admitted but
+    costly, so each LM iteration is served by it or by PCG to 1e-13 (linear_solver_used = 3).  Size-independent properties: the
     LM trace equals the one obtained with the factorisation switched off (PCG to 1e-13 alone) and the one with the
     factorisation alone, and a repeated run is bit-identical."""
+    monkeypatch.setenv("PGO_FRONT", "0")
     g = ds.manhattan_se3(10000, 40000)
     opt = lambda: gpu.SolverOptions(max_num_iterations=10, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
 

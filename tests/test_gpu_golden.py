@@ -97,7 +97,7 @@ def test_kitti00_dense_candidates_config3(gpu, ds, O):
     og = O.Graph(g.poses, g.ia, g.ib, g.meas, None)
     op, osum, otr = O.solve(og, O.default_options(linear_solver=0, **opt))
     assert s.is_solution_usable()
-    assert s.linear_solver_used == 0 and s.factor_nnz_blocks > 60000     # GPU factorisation (SPLIT / PANEL schedule), not the PCG stand-in
+    assert s.linear_solver_used == 0 and s.factor_nnz_blocks > 60000     # a GPU factorisation (multifrontal by default), not the PCG stand-in
     assert s.initial_cost == pytest.approx(osum.initial_cost, rel=1e-12)
     assert s.final_cost == pytest.approx(osum.final_cost, rel=1e-9)
     assert np.abs(poses[:, :3] - op[:, :3]).max() < 1e-5            # metres

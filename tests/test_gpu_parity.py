@@ -323,10 +323,12 @@ def test_incremental_problem_growth(gpu, O, ds):
     assert np.abs(poses - qposes).max() < 1e-8
 
 
-def test_direct_solver_with_dense_separators(gpu, O, ds):
-    """A lattice walk with many loop closures: the elimination tree ends in dense separator chains, which the GPU
-    factorisation processes as SPLIT levels and PANEL steps.  Same solution as the oracle's exact
-    solve, and the LM run reports the factorisation (not the PCG stand-in) as the solver used."""
+def test_direct_solver_with_dense_separators(gpu, O, ds, monkeypatch):
+    """A lattice walk with many loop closures: the elimination tree ends in dense separator chains, which the enumerated
+    6x6 factorisation (pinned here with PGO_FRONT=0; by default this graph goes to the multifrontal solver,
+    tests/test_gpu_front.py) processes as SPLIT levels and PANEL steps.  Same solution as the
+    oracle's exact solve, and the LM run reports the factorisation (not the PCG stand-in) as the solver used."""
+    monkeypatch.setenv("PGO_FRONT", "0")
     g = ds.manhattan_se3(2000, 8000, seed=3)
     prob, poses, og = _pair(gpu, O, g)
     rng = np.random.default_rng(5)
@@ -373,6 +375,7 @@ def test_exact_request_with_per_iteration_choice(gpu, O, ds, monkeypatch, budget
     the factorisation or by PCG to 1e-13, an over-budget PCG try is redone with the factorisation.  Whatever the mix
     (default budget: mostly factorisations; huge: PCG after the first; tiny: every try over budget), the LM trace is
     the oracle's exact-solve trace."""
+    monkeypatch.setenv("PGO_FRONT", "0")                      # the per-iteration choice belongs to the enumerated factorisation
     monkeypatch.setenv("PGO_DIRECT_MAX_STEPS", "10")
     if budget:
         monkeypatch.setenv("PGO_HYBRID_BUDGET", budget)
