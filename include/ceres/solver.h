@@ -332,7 +332,11 @@ inline void SolveReprojection(const Solver::Options& options, Problem* problem, 
     if (!RecoverReprojection(rb->cost, &k))
       return Fail(summary, "unsupported cost function: residual block is neither an SE(3) between factor nor a 3D-to-2D reprojection factor");
     if (rb->blocks[0] != q || rb->blocks[1] != t) return Fail(summary, "unsupported: reprojection blocks must share one quaternion and one translation block");
-    if (rb->loss != loss) return Fail(summary, "unsupported: residual blocks use different LossFunction instances");
+    if (rb->loss != loss) {   // one instance per AddResidualBlock is the usual Ceres pattern: equal kind and scale is what matters
+      double a0 = 0.0, a1 = 0.0;
+      const int k0 = LossKind(loss, &a0), k1 = LossKind(rb->loss, &a1);
+      if (k0 < 0 || k0 != k1 || a0 != a1) return Fail(summary, "unsupported: residual blocks use LossFunctions of different kind or scale");
+    }
     if (!problem->IsParameterBlockConstant(rb->blocks[2])) return Fail(summary, "unsupported: the 3-D points of the reprojection problem must be constant (MotionEstimate.cc:111-114)");
     if (i == 0) k0 = k;
     if (std::fabs(k.fx - k0.fx) > 1e-9 * std::fabs(k0.fx) || std::fabs(k.fy - k0.fy) > 1e-9 * std::fabs(k0.fy))
@@ -399,7 +403,12 @@ inline void Solver::Solve(const Options& options, Problem* problem, Summary* sum
   std::vector<double> t_be(7 * rbs.size()), sqrt_info(36 * rbs.size());
   for (size_t e = 0; e < rbs.size(); ++e) {
     const internal::ResidualBlock* rb = rbs[e];
-    if (rb->loss != loss) return internal::Fail(summary, "unsupported: residual blocks use different LossFunction instances");
+    if (rb->loss != loss) {   // one instance per AddResidualBlock is the usual Ceres pattern: equal kind and scale is what matters
+      double a0 = 0.0, a1 = 0.0;
+      const int k0 = internal::LossKind(loss, &a0), k1 = internal::LossKind(rb->loss, &a1);
+      if (k0 < 0 || k0 != k1 || a0 != a1)
+        return internal::Fail(summary, "unsupported: residual blocks use LossFunctions of different kind or scale");
+    }
     internal::RecoveredFactor f;
     if (!internal::RecoverBetweenFactor(rb->cost, &f))
       return internal::Fail(summary, "unsupported cost function: residual block is not an SE(3) between factor "

@@ -113,6 +113,10 @@ typedef struct pgo_solver_summary {
                                    with FP64 MFMA fronts (pgo_front) */
   int factor_max_front;         /* multifrontal: largest dense front (scalars) */
   double factor_flops;          /* flops of one numeric factorisation */
+  int num_parameter_blocks_reduced;     /* FullReport's Reduced column: constant blocks removed */
+  int num_parameters_reduced;
+  int num_effective_parameters_reduced;
+  int reserved1;
 } pgo_solver_summary;
 
 /* One row per iteration, the numbers Summary::FullReport() tabulates with

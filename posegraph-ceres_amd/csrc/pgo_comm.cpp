@@ -41,11 +41,18 @@ struct LoopbackComm : Comm {
     g->abort();   // release the peers waiting in a barrier
     return -1;
   }
+  // One event pair per rank, created once and re-recorded on every exchange: a stream wait binds to the record that was
+  // current when the wait was enqueued, and the third barrier below guarantees every peer has enqueued its waits before
+  // the owner records again (exact requests run tens of thousands of exchanges per LM step: no per-call allocation).
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  ~LoopbackComm() override {
+    if (ev_ready) (void)hipEventDestroy(ev_ready);
+    if (ev_done) (void)hipEventDestroy(ev_done);
+  }
   int all_gather(double* buf, size_t seg, hipStream_t s, const char** what) override {
-    hipEvent_t ev_ready, ev_done;
     hipError_t e;
-    if ((e = hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming)) != hipSuccess) return fail(what, "hipEventCreate", e);
-    if ((e = hipEventCreateWithFlags(&ev_done, hipEventDisableTiming)) != hipSuccess) return fail(what, "hipEventCreate", e);
+    if (!ev_ready && (e = hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming)) != hipSuccess) return fail(what, "hipEventCreate", e);
+    if (!ev_done && (e = hipEventCreateWithFlags(&ev_done, hipEventDisableTiming)) != hipSuccess) return fail(what, "hipEventCreate", e);
     if ((e = hipEventRecord(ev_ready, s)) != hipSuccess) return fail(what, "hipEventRecord", e);
     { std::lock_guard<std::mutex> lk(g->mu); g->bufs[rank] = buf; g->ready[rank] = ev_ready; g->done[rank] = ev_done; }
     if (!g->barrier()) { *what = "a peer rank failed"; return -1; }   // every rank has published buffer + "segment ready" event
@@ -59,9 +66,7 @@ struct LoopbackComm : Comm {
     if (!g->barrier()) { *what = "a peer rank failed"; return -1; }   // every rank has enqueued its copies
     for (int p = 0; p < world; ++p)                                   // nobody overwrites a segment a peer is still reading
       if (p != rank && (e = hipStreamWaitEvent(s, g->done[p], 0)) != hipSuccess) return fail(what, "hipStreamWaitEvent", e);
-    if (!g->barrier()) { *what = "a peer rank failed"; return -1; }   // the published events may now be replaced
-    // Peers have stream-waits pending on these events: they are destroyed with the group, not here.
-    { std::lock_guard<std::mutex> lk(g->mu); g->garbage.push_back(ev_ready); g->garbage.push_back(ev_done); }
+    if (!g->barrier()) { *what = "a peer rank failed"; return -1; }   // every peer has enqueued its waits: the events may be re-recorded
     return 0;
   }
 };

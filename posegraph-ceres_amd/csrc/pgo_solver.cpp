@@ -150,6 +150,7 @@ struct LmState {
   double hybrid_fail_radius = 0;  // trust-region radius of the last over-budget try: a 10x smaller radius (10x the damping) earns an early try
   int hybrid_direct = 0, hybrid_pcg_ok = 0, hybrid_pcg_over = 0;   // statistics (PGO_VERBOSE)
   int n_factorizations = 0;       // LM iterations served by the GPU factorisation
+  int num_trial_steps = 0;        // linear solves + step tails enqueued (pgo_solver_step counts executed iterations with it)
   std::string message;
 };
 
@@ -861,7 +862,17 @@ int prepare_direct(pgo_problem* P) {
   const int front_min = getenv("PGO_FRONT_MIN") ? atoi(getenv("PGO_FRONT_MIN")) : 192;
   pgo::DirectSymbolic& S = P->dsym;
   bool front_ok = false;
-  if (front_mode != 0) {
+  // a trajectory with a few chords (KITTI-00 replay: 1.14 edges per pose) is the enumerated schedule's case: its analysis runs
+  // first there and the multifrontal one is skipped (one-shot solves pay every millisecond of host analysis)
+  bool pair_first_done = false, usable = false;
+  if (front_mode < 0 && (double)P->g.E < 1.5 * (double)P->g.N) {
+    const auto t_an = Clock::now();
+    usable = pgo::direct_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side,
+                                 P->h_row_slot_begin, &S);
+    if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: symbolic analysis %.2f ms\n", 1e3 * seconds_since(t_an));
+    pair_first_done = true;
+  }
+  if (front_mode != 0 && !(pair_first_done && usable && !S.hybrid)) {
     const int rc = analyze_front(P, &front_ok);
     if (rc) return rc;
     if (front_ok && (front_mode == 1 || P->fsym.max_front > front_min)) {
@@ -870,8 +881,7 @@ int prepare_direct(pgo_problem* P) {
       return upload_front(P);
     }
   }
-  bool usable = false;
-  if (front_mode != 1) {
+  if (front_mode != 1 && !pair_first_done) {
     const auto t_an = Clock::now();
     usable = pgo::direct_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side,
                                  P->h_row_slot_begin, &S);
@@ -1177,6 +1187,7 @@ int lm_advance(pgo_problem* P) {
     if (hybrid) { ++L.hybrid_direct_run; ++L.hybrid_direct; }
   }
   HIP_TRY(hipGetLastError());
+  ++L.num_trial_steps;
   const pgo::LmScalars sc = *P->scal;
   const int cg_it = sc.cg_iterations, cg_status = sc.cg_status;
   P->last_cg_iterations = cg_it;
@@ -1308,6 +1319,13 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
     summary->linear_solver_used = want_exact ? (P->direct_usable ? (P->dsym.hybrid ? 3 : 0) : 2) : 1;
     summary->factor_nnz_blocks = (want_exact && P->direct_usable) ? (P->front_usable ? (int)std::min<long long>(P->fsym.factor_blocks, 0x7fffffff) : P->dsym.nb) : 0;
     summary->factor_levels = (want_exact && P->direct_usable) ? (P->front_usable ? P->fsym.n_levels : P->dsym.n_levels) : 0;
+    {
+      int const_p = 0, const_q = 0;
+      for (uint8_t m : P->cmask) { const_p += m & 1; const_q += (m >> 1) & 1; }
+      summary->num_parameter_blocks_reduced = 2 * P->g.N - const_p - const_q;
+      summary->num_parameters_reduced = 7 * P->g.N - 3 * const_p - 4 * const_q;
+      summary->num_effective_parameters_reduced = 6 * P->g.N - 3 * const_p - 3 * const_q;
+    }
     summary->factor_kind = (want_exact && P->direct_usable) ? (P->front_usable ? 2 : 1) : 0;
     summary->factor_max_front = (want_exact && P->front_usable) ? P->fsym.max_front : 0;
     summary->factor_flops = (want_exact && P->direct_usable) ? (P->front_usable ? P->fsym.flops : P->dsym.flops) : 0.0;
@@ -1495,11 +1513,12 @@ int pgo_solver_step(pgo_problem* P, int n, int* executed, int* done) {
   if (!P || !P->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_step without pgo_solver_begin");
   int ran = 0;
   for (int i = 0; i < n && !P->lm.terminated; ++i) {
-    const int before = P->lm.cur.iteration;
+    const int solves_before = P->lm.num_trial_steps;
     int rc = lm_advance(P);
-    if (rc) return rc;
-    // an iteration counts when a trial step was computed (a pure termination check does not)
-    if (P->lm.cur.iteration != before || !P->lm.terminated) ++ran;
+    if (rc) { P->lm.active = false; return rc; }   // a failed session is closed: the device state is not trustworthy any more
+    // an iteration counts when a trial step was computed (a pure termination check does not), also when that step ended the
+    // run on the parameter or function tolerance
+    if (P->lm.num_trial_steps != solves_before) ++ran;
   }
   if (executed) *executed = ran;
   if (done) *done = P->lm.terminated ? 1 : 0;
@@ -1545,7 +1564,7 @@ int pgo_solve(pgo_problem* P, const pgo_solver_options* options, pgo_solver_summ
   if (rc) return rc;
   while (!P->lm.terminated) {
     rc = lm_advance(P);
-    if (rc) return rc;
+    if (rc) { P->lm.active = false; return rc; }   // caller memory keeps the poses it came with; the session is closed
   }
   return lm_end(P, summary, records, capacity);
 }
@@ -1565,36 +1584,54 @@ size_t pgo_summary_full_report(const pgo_solver_summary* s, const pgo_iteration_
     r += line;
   };
   static const char* term[] = {"CONVERGENCE", "NO_CONVERGENCE", "FAILURE"};
+  // Layout of Ceres 1.13 Solver::Summary::FullReport (solver.cc): two columns Original / Reduced, Given / Used, the same
+  // row labels and widths, so that parsers of the reference's stdout (finial.cpp:541) keep working; what Ceres has no row
+  // for (factorisation statistics, device) follows in a block of its own.
   add("\nSolver Summary (v %d.%d.%d-hip-gfx950)\n\n", PGO_VERSION / 100, (PGO_VERSION / 10) % 10, PGO_VERSION % 10);
-  add("%-28s %12s\n", "", "Original");
-  add("%-28s %12d\n", "Parameter blocks", 2 * s->num_poses);
-  add("%-28s %12d\n", "Parameters", 7 * s->num_poses);
-  add("%-28s %12d\n", "Effective parameters", 6 * s->num_poses);
-  add("%-28s %12d\n", "Residual blocks", s->num_edges);
-  add("%-28s %12d\n\n", "Residual", 6 * s->num_edges);
-  add("Minimizer                        TRUST_REGION\n");
-  add("Trust region strategy     LEVENBERG_MARQUARDT\n");
-  static const char* ls[] = {"SPARSE_NORMAL_CHOLESKY (GPU block Cholesky, nested dissection)", "CGNR / block-Jacobi PCG (Q-tolerance eta)",
-                             "SPARSE_NORMAL_CHOLESKY served by PCG to 1e-13 (factor schedule impractical)",
-                             "SPARSE_NORMAL_CHOLESKY (GPU block Cholesky or PCG to 1e-13, chosen per iteration)"};
-  add("Linear solver    %s\n", ls[(s->linear_solver_used >= 0 && s->linear_solver_used <= 3) ? s->linear_solver_used : 1]);
-  if (s->factor_nnz_blocks > 0) add("Factor blocks / levels  %12d / %d\n", s->factor_nnz_blocks, s->factor_levels);
-  if (s->factor_nnz_blocks > 0) add("Factorisations          %12d\n", s->num_factorizations);
-  add("Compute device              HIP gfx950 (FP64)\n\n");
-  add("Cost:\n");
-  add("%-28s %e\n", "Initial", s->initial_cost);
-  add("%-28s %e\n", "Final", s->final_cost);
-  add("%-28s %e\n\n", "Change", s->initial_cost - s->final_cost);
-  add("Minimizer iterations         %12d\n", s->num_iterations);
-  add("Successful steps             %12d\n", s->num_successful_steps);
-  add("Unsuccessful steps           %12d\n", s->num_unsuccessful_steps);
-  add("Linear solver iterations     %12d\n\n", s->num_linear_solver_iterations);
-  add("Time (in seconds):\n");
-  add("Preprocessor (topology+upload) %10.6f\n\n", s->setup_time_in_seconds);
-  add("  Residual evaluation          %10.6f\n", s->residual_evaluation_time_in_seconds);
-  add("  Jacobian evaluation          %10.6f\n", s->jacobian_evaluation_time_in_seconds);
-  add("  Linear solver                %10.6f\n", s->linear_solver_time_in_seconds);
-  add("Minimizer                      %10.6f\n\n", s->total_time_in_seconds);
+  add("%45s    %21s\n", "Original", "Reduced");
+  add("Parameter blocks    % 25d% 25d\n", 2 * s->num_poses, s->num_parameter_blocks_reduced);
+  add("Parameters          % 25d% 25d\n", 7 * s->num_poses, s->num_parameters_reduced);
+  add("Effective parameters% 25d% 25d\n", 6 * s->num_poses, s->num_effective_parameters_reduced);
+  add("Residual blocks     % 25d% 25d\n", s->num_edges, s->num_edges);
+  add("Residual            % 25d% 25d\n", 6 * s->num_edges, 6 * s->num_edges);
+  add("\nMinimizer                 %19s\n", "TRUST_REGION");
+  add("\nSparse linear algebra library %15s\n", "HIP_GFX950");
+  add("Trust region strategy     %19s\n", "LEVENBERG_MARQUARDT");
+  add("\n%45s    %21s\n", "Given", "Used");
+  const bool exact = s->linear_solver_used != 1;
+  add("Linear solver       %25s%25s\n", exact ? "SPARSE_NORMAL_CHOLESKY" : "CGNR",
+      s->linear_solver_used == 2 ? "CGNR" : exact ? "SPARSE_NORMAL_CHOLESKY" : "CGNR");
+  if (!exact || s->linear_solver_used == 2) add("Preconditioner      %25s%25s\n", "JACOBI", "JACOBI");
+  add("Threads             % 25d% 25d\n", 1, 1);
+  add("Linear solver threads % 23d% 25d\n", 1, 1);
+  if (exact) add("Linear solver ordering %22s% 25d\n", "AUTOMATIC", s->num_parameter_blocks_reduced);
+  add("\nCost:\n");
+  add("Initial        % 30e\n", s->initial_cost);
+  add("Final          % 30e\n", s->final_cost);
+  add("Change         % 30e\n", s->initial_cost - s->final_cost);
+  add("\nMinimizer iterations         % 16d\n", s->num_iterations);
+  add("Successful steps             % 16d\n", s->num_successful_steps);
+  add("Unsuccessful steps           % 16d\n", s->num_unsuccessful_steps);
+  add("\nTime (in seconds):\n");
+  add("Preprocessor        %25.4f\n", s->setup_time_in_seconds);
+  add("\n  Residual evaluation %23.4f\n", s->residual_evaluation_time_in_seconds);
+  add("  Jacobian evaluation %23.4f\n", s->jacobian_evaluation_time_in_seconds);
+  add("  Linear solver       %23.4f\n", s->linear_solver_time_in_seconds);
+  add("Minimizer           %25.4f\n", s->total_time_in_seconds);
+  add("\nPostprocessor       %25.4f\n", 0.0);
+  add("Total               %25.4f\n", s->total_time_in_seconds + s->setup_time_in_seconds);
+  static const char* ls[] = {"GPU factorisation", "block-Jacobi PCG (Q-tolerance eta)", "PCG to exact_r_tolerance (factorisation declined)",
+                             "GPU factorisation or PCG to exact_r_tolerance, chosen per iteration"};
+  add("\nGPU path (no Ceres counterpart):\n");
+  add("Compute device              HIP gfx950 (FP64)\n");
+  add("Linear solves served by     %s\n", ls[(s->linear_solver_used >= 0 && s->linear_solver_used <= 3) ? s->linear_solver_used : 1]);
+  add("Linear solver iterations     % 16d\n", s->num_linear_solver_iterations);
+  if (s->factor_nnz_blocks > 0) {
+    add("Factorisation               %s\n", s->factor_kind == 2 ? "supernodal multifrontal, FP64 MFMA fronts" : "enumerated 6x6 block pairs, nested dissection");
+    add("Factor blocks / levels       % 16d / %d\n", s->factor_nnz_blocks, s->factor_levels);
+    add("Factorisations               % 16d\n", s->num_factorizations);
+  }
+  add("\n");
   if (rec && n_rec > 0) {
     add("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  ls_iter\n");
     for (int i = 0; i < n_rec; ++i)
@@ -1604,7 +1641,7 @@ size_t pgo_summary_full_report(const pgo_solver_summary* s, const pgo_iteration_
     add("\n");
   }
   const int t = (s->termination_type >= 0 && s->termination_type <= 2) ? s->termination_type : 2;
-  add("Termination: %24s (%s)\n", term[t], s->message);
+  add("Termination: %24s (%s)\n", term[t], s->message);   // "Termination:   %25s (%s)" in Ceres, same tokens
   if (buffer && capacity) {
     const size_t n = std::min(capacity - 1, r.size());
     memcpy(buffer, r.data(), n);
@@ -1615,6 +1652,7 @@ size_t pgo_summary_full_report(const pgo_solver_summary* s, const pgo_iteration_
 
 // ---- evaluation entry points -------------------------------------------------------------------
 int pgo_evaluate(pgo_problem* P, double* cost, double* residuals, double* jac_begin, double* jac_end, double* gradient) {
+  if (P && P->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_evaluate during a solver session: it would overwrite the device-resident LM state (pose buffers, Jacobi scaling, linearisation); call pgo_solver_end first");
   if (!P) return set_error(PGO_ERR_INVALID_ARGUMENT, "null problem");
   int rc = prepare(P);
   if (rc) return rc;
@@ -1652,6 +1690,7 @@ int pgo_evaluate(pgo_problem* P, double* cost, double* residuals, double* jac_be
 }
 
 int pgo_normal_equations(pgo_problem* P, double* diag, double* offdiag, double* gradient) {
+  if (P && P->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_normal_equations during a solver session: it would overwrite the device-resident LM state (pose buffers, Jacobi scaling, linearisation); call pgo_solver_end first");
   if (!P) return set_error(PGO_ERR_INVALID_ARGUMENT, "null problem");
   int rc = prepare(P);
   if (rc) return rc;
@@ -1683,6 +1722,7 @@ int pgo_normal_equations(pgo_problem* P, double* diag, double* offdiag, double* 
 }
 
 int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const double* d2, const double* b, double* x, int* iterations) {
+  if (P && P->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_linear_solve during a solver session: it would overwrite the device-resident LM state (pose buffers, Jacobi scaling, linearisation); call pgo_solver_end first");
   if (!P || !options || !d2 || !b || !x) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_linear_solve");
   int rc = prepare(P);
   if (rc) return rc;
@@ -1727,6 +1767,7 @@ int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const do
 }
 
 int pgo_plus(pgo_problem* P, const double* delta) {
+  if (P && P->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_plus during a solver session: it would overwrite the device-resident LM state (pose buffers, Jacobi scaling, linearisation); call pgo_solver_end first");
   if (!P || !delta) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_plus");
   int rc = prepare(P);
   if (rc) return rc;

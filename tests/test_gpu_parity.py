@@ -438,3 +438,26 @@ def test_evaluate_special_configurations(gpu, O, ds):
     prob.plus(d)
     assert np.abs(p2 - expect).max() <= 1e-15 * 3e4
     assert np.array_equal(p2[0], poses[0]) and np.array_equal(p2[1, 3:], poses[1, 3:])
+
+
+def test_evaluation_entry_points_are_refused_during_a_session(gpu, ds):
+    """pgo_evaluate / pgo_normal_equations / pgo_linear_solve / pgo_plus would overwrite the device-resident LM state (pose
+    ping-pong, Jacobi scaling, linearisation): between solver_begin and solver_end they return an error, and the session
+    continues unharmed (same result as an uninterrupted one)."""
+    g = ds.manhattan_se3(300, 1000, seed=4)
+    opt = gpu.SolverOptions(max_num_iterations=12, linear_solver_type=gpu.BLOCK_JACOBI_PCG)
+    prob, poses = gpu.problem_from_graph(g)
+    ref = gpu.solve(opt, prob)
+    prob2, poses2 = gpu.problem_from_graph(g)
+    prob2.solver_begin(opt)
+    prob2.solver_step(3)
+    for call in (prob2.evaluate, prob2.normal_equations, lambda: prob2.plus(np.zeros((g.N, 6))),
+                 lambda: prob2.linear_solve(np.ones(6 * g.N), np.zeros(6 * g.N))):
+        with pytest.raises(gpu.PgoError) as ei:
+            call()
+        assert "solver session" in str(ei.value)
+    prob2.solver_step(100)
+    s2 = prob2.solver_end()
+    assert s2.final_cost == ref.final_cost and np.array_equal(poses, poses2)
+    cost, *_ = prob2.evaluate()            # allowed again after solver_end
+    assert cost == pytest.approx(s2.final_cost, rel=1e-12)

@@ -176,6 +176,31 @@ int main() {
   }
   std::printf("OK problem\n");
 
+  // ---- one LossFunction instance per residual block (the usual Ceres pattern): accepted when kind and scale agree,
+  // refused when they differ ----
+  {
+    for (int differ = 0; differ < 2; ++differ) {
+      double poses[3][7] = {{0, 0, 0, 0, 0, 0, 1}, {1, 0, 0, 0, 0, 0, 1}, {2, 0, 0, 0, 0, 0, 1}};
+      ceres::Problem problem;
+      ceres::LocalParameterization* lp = new ceres::EigenQuaternionParameterization;
+      for (int e = 0; e < 2; ++e) {
+        ceres::LossFunction* loss = new ceres::HuberLoss(differ && e == 1 ? 2.0 : 1.0);
+        problem.AddResidualBlock(new ceres::AutoDiffCostFunction<Term, 6, 3, 4, 3, 4>(RandomTerm(true)), loss, poses[e + 1],
+                                 poses[e + 1] + 3, poses[e], poses[e] + 3);
+        problem.SetParameterization(poses[e + 1] + 3, lp);
+        problem.SetParameterization(poses[e] + 3, lp);
+      }
+      problem.SetParameterBlockConstant(poses[0]);
+      problem.SetParameterBlockConstant(poses[0] + 3);
+      ceres::Solver::Options options;
+      ceres::Solver::Summary summary;
+      ceres::Solve(options, &problem, &summary);
+      if (differ) CHECK_OR_DIE(summary.termination_type == ceres::FAILURE && summary.message.find("different kind or scale") != std::string::npos);
+      else if (pgo_device_count() > 0) CHECK_OR_DIE(summary.IsSolutionUsable());
+    }
+  }
+  std::printf("OK per-block loss instances\n");
+
   // ---- the MotionEstimate problem (MotionEstimate.cc:71-129) through ceres::Problem / ceres::Solve ----
   {
     const double fx = 718.856, fy = 718.856, cx = 607.1928, cy = 185.2157;

@@ -2,7 +2,9 @@
 written as profiles/<tag>_pmc.json.  gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE counts 128-B
 requests as 64 B for wide coalesced streams, so the read side is doubled; WRITE_SIZE is reported as counted.
 usage: python tools/rocprof_pmc.py <fetch.db> <write.db> <out.json>"""
+import hashlib
 import json
+import os
 import re
 import sqlite3
 import statistics
@@ -31,8 +33,10 @@ def main(fetch_db, write_db, out):
         res[k] = {"dispatches": len(fv), "fetch_kib_median_active": statistics.median(fa), "write_kib_median_active": statistics.median(wa),
                   "hbm_bytes_per_launch_corrected": int(2 * statistics.median(fa) * 1024 + statistics.median(wa) * 1024),
                   "hbm_bytes_per_launch_raw": int(statistics.median(fa) * 1024 + statistics.median(wa) * 1024)}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sha = hashlib.sha256(open(os.path.join(root, "posegraph-ceres_amd", "csrc", "pgo_kernels.hip"), "rb").read()).hexdigest()[:16]
     json.dump({"note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); WRITE_SIZE uncalibrated",
-               "kernels": res}, open(out, "w"), indent=1)
+               "kernel_source_sha256_16": sha, "kernels": res}, open(out, "w"), indent=1)
     for k, v in res.items():
         print("%-22s n=%5d fetch %10.1f KiB write %10.1f KiB -> corrected %.2f MB" % (k, v["dispatches"], v["fetch_kib_median_active"], v["write_kib_median_active"], v["hbm_bytes_per_launch_corrected"] / 1e6))
 
