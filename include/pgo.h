@@ -230,6 +230,47 @@ int pgo_time_kernel(pgo_problem* problem, const char* kernel, int repeats, doubl
 int pgo_generate_candidates(const float* xyz, int n, float search_radius, int gap, long long* row_ptr, int* indices,
                             long long capacity, double* kernel_ms);
 
+/* ---- graph construction around the solve ----
+ * pgo_read_trajectory: GroundTruth::loadPoses1 / loadPoses2 (REF/src/GroundTruth.cc:22-73).  format 1: rows
+ * "x y z qx qy qz qw" — INCLUDING the reference's quaternion scramble (GroundTruth.cc:59-62: the file's qw lands in Eigen's
+ * x, qx in y, qy in z, qz in w); format 2: KITTI rows of a 3x4 matrix.  Output: camera-to-world
+ * transforms Twc, row-major 4x4, 16 doubles per pose holding the float32 values the reference keeps (CV_32F).  count receives
+ * the number of complete rows in the file (also when it exceeds capacity; only `capacity` poses are written).  Host only.
+ * (The reference's `while (inFile.good())` loop appends one more, unread, pose at the end of the file; not reproduced.) */
+int pgo_read_trajectory(const char* path, int format, double* Twc, int capacity, int* count);
+
+/* Odometry measurements of ALL consecutive frames at once on the GPU (finial.cpp:206-224): edge e has id_begin = e + 1,
+ * id_end = e, t_be[e] = Converter::toPose3d(float32(Tcw(e + 1) * Twc(e))) (converter.cc:150-155, 221-234), 7 doubles
+ * p[3] q[4] (xyzw).  kernel_ms optional.  GPU only. */
+int pgo_build_odometry_edges(int n_frames, const double* Twc, double* t_be, double* kernel_ms);
+
+/* checkFrame's acceptance rules (finial.cpp:162-293, 486-489) over RECORDED front-end results — ORB matching and PnP are
+ * outside the path, their outputs per candidate pair come in `obs` (parallel to cand_idx; may be NULL: odometry only).
+ * Frames are visited in id order, the candidates of frame f are cand_idx[cand_ptr[f] .. cand_ptr[f+1]) in file order
+ * (Edge_Candidates_index.txt): a candidate one frame back yields the odometry edge; any other needs nmatches >
+ * match_threshold, inliers > inlier_threshold, normofTransform(rvec, tvec) < norm_threshold, at most one loop edge per
+ * current frame, and is skipped when it obtained a loop edge as a current frame itself.  Output edges in the reference's
+ * order (id_begin = current, id_end = earlier frame, t_be = toPose3d of the float32 transform); loop_list = the
+ * "cur prev" rows of edges_for_loop.txt (pairs more than loop_list_gap frames apart), 2 ints per row.  n_edges / n_loop_list
+ * always receive the required counts.  The odometry measurements are computed on the GPU (pgo_build_odometry_edges). */
+typedef struct pgo_pair_observation {
+  int nmatches;        /* ORBmatcher::MatcheTwoFrames */
+  int inliers;         /* PnP-RANSAC inliers */
+  double rvec[3];      /* rotation vector of T_cur<-prev (cv::Rodrigues convention) */
+  double tvec[3];
+} pgo_pair_observation;
+typedef struct pgo_edge_rules {
+  int match_threshold;     /* 280, finial.cpp:226 */
+  int inlier_threshold;    /* 100, finial.cpp:234 */
+  double norm_threshold;   /* 0.7, finial.cpp:234 */
+  int loop_list_gap;       /* 100, finial.cpp:285 */
+  int reserved;
+} pgo_edge_rules;
+void pgo_edge_rules_init(pgo_edge_rules* rules);
+int pgo_build_edges(int n_frames, const double* Twc, const long long* cand_ptr, const int* cand_idx, const pgo_pair_observation* obs,
+                    const pgo_edge_rules* rules, int* id_begin, int* id_end, double* t_be, long long capacity, long long* n_edges,
+                    int* loop_list, long long loop_capacity, long long* n_loop_list);
+
 /* ---- batched MotionEstimate solves ----
  * Replaces MotionEstimate::BuildOptimizationProblem / SolveOptimizationProblem (REF/src/MotionEstimate.cc:71-129) and the
  * ReprojectionError3Dto2D functor (REF/include/MotionEstimate.h:34-91) for MANY candidate frame pairs at once: problem k

@@ -42,6 +42,7 @@ C_ABI_SYMBOLS = [
     "pgo_solver_step", "pgo_solver_reset", "pgo_solver_end", "pgo_time_kernel", "pgo_shard_range",
     "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_loopback_create", "pgo_loopback_destroy", "pgo_comm_init_loopback",
     "pgo_generate_candidates", "pgo_reproj_options_init", "pgo_reproj_solve_batch",
+    "pgo_read_trajectory", "pgo_build_odometry_edges", "pgo_edge_rules_init", "pgo_build_edges",
 ]
 
 
@@ -161,6 +162,83 @@ def generate_candidates(xyz, search_radius=6.0, gap=100, return_ms=False):
                                          idx.ctypes.data_as(C.POINTER(C.c_int)), C.c_longlong(idx.shape[0]), C.byref(ms)))
     out = {k: idx[row_ptr[k]:row_ptr[k + 1]].tolist() for k in range(1, n)}
     return (out, ms.value) if return_ms else out
+
+
+def read_trajectory(path, fmt):
+    """pgo_read_trajectory: GroundTruth::loadPoses1 (fmt 1, with the reference's quaternion scramble) / loadPoses2 (fmt 2, KITTI
+    3x4).  Returns Twc (n, 4, 4) float64 holding the float32 values the reference keeps.  Host only (no GPU needed)."""
+    import numpy as np
+    cnt = C.c_int(0)
+    _check(lib().pgo_read_trajectory(str(path).encode(), C.c_int(fmt), None, C.c_int(0), C.byref(cnt)))
+    out = np.zeros((max(1, cnt.value), 16))
+    _check(lib().pgo_read_trajectory(str(path).encode(), C.c_int(fmt), _dp(out), C.c_int(cnt.value), C.byref(cnt)))
+    return out[:cnt.value].reshape(-1, 4, 4)
+
+
+def build_odometry_edges(Twc, return_ms=False):
+    """pgo_build_odometry_edges: t_be of every consecutive frame pair on the GPU, (n-1, 7)."""
+    import numpy as np
+    T = np.ascontiguousarray(np.asarray(Twc, dtype=np.float64).reshape(-1, 16))
+    n = T.shape[0]
+    out = np.zeros((max(1, n - 1), 7))
+    ms = C.c_double(0)
+    _check(lib().pgo_build_odometry_edges(C.c_int(n), _dp(T), _dp(out), C.byref(ms)))
+    out = out[:max(0, n - 1)]
+    return (out, ms.value) if return_ms else out
+
+
+class PairObservation(C.Structure):
+    """Mirror of pgo_pair_observation."""
+    _fields_ = [("nmatches", C.c_int), ("inliers", C.c_int), ("rvec", C.c_double * 3), ("tvec", C.c_double * 3)]
+
+
+class EdgeRules(C.Structure):
+    """Mirror of pgo_edge_rules; defaults = finial.cpp:226, 234, 285."""
+    _fields_ = [("match_threshold", C.c_int), ("inlier_threshold", C.c_int), ("norm_threshold", C.c_double),
+                ("loop_list_gap", C.c_int), ("reserved", C.c_int)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        lib().pgo_edge_rules_init(C.byref(self))
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def build_edges(Twc, candidates, observations=None, rules=None):
+    """pgo_build_edges: checkFrame's rules over recorded front-end results.  candidates: {frame: [ids...]} (file order);
+    observations(cur, prev) -> None or dict(nmatches, inliers, rvec, tvec) (as loop_edges.LoopEdgeBuilder takes).
+    Returns (id_begin, id_end, t_be (E,7), loop_list (L,2))."""
+    import numpy as np
+    T = np.ascontiguousarray(np.asarray(Twc, dtype=np.float64).reshape(-1, 16))
+    n = T.shape[0]
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    flat = []
+    for f in range(n):
+        c = list(candidates.get(f, ()))
+        flat.extend(c)
+        ptr[f + 1] = len(flat)
+    idx = np.asarray(flat if flat else [0], dtype=np.int32)
+    obs = (PairObservation * max(1, len(flat)))()
+    if observations is not None:
+        k = 0
+        for f in range(n):
+            for prev in candidates.get(f, ()):
+                o = observations(f, prev) if f - prev > 1 else None
+                if o is not None:
+                    obs[k].nmatches, obs[k].inliers = int(o["nmatches"]), int(o["inliers"])
+                    obs[k].rvec[:] = [float(x) for x in o["rvec"]]
+                    obs[k].tvec[:] = [float(x) for x in o["tvec"]]
+                k += 1
+    rules = rules or EdgeRules()
+    ne, nl = C.c_longlong(0), C.c_longlong(0)
+    cap = len(flat) + 1
+    ia, ib, m = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32), np.zeros((cap, 7))
+    ll = np.zeros((cap, 2), dtype=np.int32)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    _check(lib().pgo_build_edges(C.c_int(n), _dp(T), ptr.ctypes.data_as(C.POINTER(C.c_longlong)), ip(idx),
+                                 obs if observations is not None else None, C.byref(rules), ip(ia), ip(ib), _dp(m), C.c_longlong(cap),
+                                 C.byref(ne), ip(ll), C.c_longlong(cap), C.byref(nl)))
+    return ia[:ne.value], ib[:ne.value], m[:ne.value], ll[:nl.value]
 
 
 class ReprojOptions(C.Structure):

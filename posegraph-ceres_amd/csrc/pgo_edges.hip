@@ -1,0 +1,253 @@
+// pgo_edges.hip — graph construction around the solve behind the C ABI:
+//   pgo_read_trajectory      GroundTruth::loadPoses1 / loadPoses2 (REF/src/GroundTruth.cc:22-73), host C++
+//   pgo_build_odometry_edges t_be = toPose3d(float32(Tcw(cur) * Twc(prev))) for all consecutive frames at once, one lane
+//                            per edge (finial.cpp:206-224, converter.cc:150-155, 221-234)
+//   pgo_build_edges          the acceptance rules of checkFrame (finial.cpp:162-293, 486-489) over RECORDED front-end
+//                            results (ORB matching and PnP are out of scope), host C++; odometry measurements come from the
+//                            kernel above, loop measurements from (rvec, tvec) by Rodrigues + toPose3d on the host
+//
+// Arithmetic contract (what "bit-for-bit" in tests/test_gpu_edges.py means): the relative transform is formed in FP64 with
+// every product and sum rounded separately, in index order (no FMA contraction: __dmul_rn / __dadd_rn), then the 4 x 4 result
+// is rounded to float32 (the reference keeps Tcl in CV_32F), then toPose3d runs in FP64 on those float32 values with Eigen's
+// matrix -> quaternion branches.  posegraph-ceres_amd/loop_edges.py states the same sequence in plain Python floats.
+// (The reference itself inverts Twc with cv::Mat::inv() in float32 — an LU factorisation inside OpenCV that cannot be
+// reproduced bit for bit; the rigid inverse is the same transform.)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/pgo.h"
+
+int pgo_candidates_set_error(int code, const char* msg);   // pgo_solver.cpp
+
+namespace {
+
+#define EDGES_HIP_TRY(expr)                                                          \
+  do {                                                                               \
+    hipError_t e_ = (expr);                                                          \
+    if (e_ != hipSuccess) return pgo_candidates_set_error(PGO_ERR_HIP, hipGetErrorString(e_)); \
+  } while (0)
+
+// Eigen::Quaterniond(Matrix3d) (converter.cc:150-155): Shepperd's branch on the trace; q = x y z w.  m row-major 3x3.
+__host__ __device__ inline void quaternion_from_matrix(const double* m, double* q) {
+  double t = (m[0] + m[4]) + m[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (m[7] - m[5]) * t;
+    q[1] = (m[2] - m[6]) * t;
+    q[2] = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    t = sqrt(((m[4 * i] - m[4 * j]) - m[4 * k]) + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+    q[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+    q[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+  }
+}
+
+// Converter::toPose3d on a row-major 4x4 whose entries are float32 values: p = translation, q from the rotation block
+__host__ __device__ inline void to_pose3d(const float* T, double* out) {
+  double m[9];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) m[3 * r + c] = (double)T[4 * r + c];
+  out[0] = (double)T[3]; out[1] = (double)T[7]; out[2] = (double)T[11];
+  quaternion_from_matrix(m, out + 3);
+}
+
+// one lane per edge (cur = i + 1, prev = i)
+__global__ void k_odometry_edges(const double* Twc, int n, double* t_be) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n - 1) return;
+  const double* C = Twc + 16 * (size_t)(e + 1);   // current frame, camera to world
+  const double* P = Twc + 16 * (size_t)e;         // previous frame
+  double Tcw[16];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) Tcw[4 * i + j] = C[4 * j + i];
+    const double s = __dadd_rn(__dadd_rn(__dmul_rn(C[i], C[3]), __dmul_rn(C[4 + i], C[7])), __dmul_rn(C[8 + i], C[11]));
+    Tcw[4 * i + 3] = -s;
+  }
+  Tcw[12] = 0.0; Tcw[13] = 0.0; Tcw[14] = 0.0; Tcw[15] = 1.0;
+  float T[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = __dmul_rn(Tcw[4 * i], P[j]);
+      s = __dadd_rn(s, __dmul_rn(Tcw[4 * i + 1], P[4 + j]));
+      s = __dadd_rn(s, __dmul_rn(Tcw[4 * i + 2], P[8 + j]));
+      s = __dadd_rn(s, __dmul_rn(Tcw[4 * i + 3], P[12 + j]));
+      T[4 * i + j] = (float)s;
+    }
+  to_pose3d(T, t_be + 7 * (size_t)e);
+}
+
+// cv::Rodrigues (finial.cpp:256): rotation vector -> rotation matrix, the formula loop_edges.rodrigues states
+void rodrigues(const double* r, double* R) {
+  const double th = std::sqrt((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+  if (th < 2.2204460492503131e-16) {
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    return;
+  }
+  const double k[3] = {r[0] / th, r[1] / th, r[2] / th};
+  const double c = std::cos(th), s = std::sin(th), omc = 1.0 - c;
+  const double K[9] = {0.0, -k[2], k[1], k[2], 0.0, -k[0], -k[1], k[0], 0.0};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[3 * i + j] = (c * (i == j ? 1.0 : 0.0) + omc * (k[i] * k[j])) + s * K[3 * i + j];
+}
+
+// finial.cpp:486-489
+double norm_of_transform(const double* rvec, const double* tvec) {
+  const double r = std::sqrt((rvec[0] * rvec[0] + rvec[1] * rvec[1]) + rvec[2] * rvec[2]);
+  const double t = std::sqrt((tvec[0] * tvec[0] + tvec[1] * tvec[1]) + tvec[2] * tvec[2]);
+  return std::fabs(std::fmin(r, 2.0 * M_PI - r)) + std::fabs(t);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pgo_read_trajectory(const char* path, int format, double* Twc, int capacity, int* count) {
+  if (!path || (format != 1 && format != 2) || !count || capacity < 0 || (capacity > 0 && !Twc))
+    return pgo_candidates_set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_read_trajectory (format 1: x y z qx qy qz qw, format 2: KITTI 3x4)");
+  std::ifstream in(path);
+  if (!in.good()) return pgo_candidates_set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_read_trajectory: cannot open the file");
+  int n = 0;
+  const int per_row = format == 1 ? 7 : 12;
+  std::vector<double> v(per_row);
+  for (;;) {
+    bool ok = true;
+    for (int k = 0; k < per_row && ok; ++k) ok = static_cast<bool>(in >> v[k]);
+    if (!ok) break;   // (the reference's `while (inFile.good())` pushes one more, unread, pose at the end of the file: not reproduced)
+    if (n < capacity) {
+      float T[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
+      if (format == 2) {
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) T[4 * r + c] = (float)v[4 * r + c];   // P.convertTo(P, CV_32FC1)
+      } else {
+        // GroundTruth.cc:59-62: the file's (qx qy qz qw) are read into trans[1], trans[2], trans[3], trans[0] and handed to
+        // Eigen::Quaterniond(const double*), which takes x y z w: Eigen's (x, y, z, w) = (file qw, file qx, file qy, file qz).
+        // Kept as is: every rotation is a valid but different unit quaternion.
+        const double x = v[6], y = v[3], z = v[4], w = v[5];
+        // Eigen::Quaternion::toRotationMatrix
+        const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+        const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+        const double R[9] = {1.0 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.0 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1.0 - (txx + tyy)};
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T[4 * r + c] = (float)R[3 * r + c]; T[4 * r + 3] = (float)v[r]; }   // Converter::toCvMat(Pose3d): CV_32F
+      }
+      for (int k = 0; k < 16; ++k) Twc[16 * (size_t)n + k] = (double)T[k];
+    }
+    ++n;
+  }
+  *count = n;
+  return PGO_OK;
+}
+
+int pgo_build_odometry_edges(int n_frames, const double* Twc, double* t_be, double* kernel_ms) {
+  if (n_frames < 0 || (n_frames > 0 && !Twc) || (n_frames > 1 && !t_be))
+    return pgo_candidates_set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_build_odometry_edges");
+  if (kernel_ms) *kernel_ms = 0.0;
+  if (n_frames < 2) return PGO_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return pgo_candidates_set_error(PGO_ERR_NO_DEVICE, "no HIP device: the edge construction has no CPU fallback");
+  }
+  double *d_T = nullptr, *d_e = nullptr;
+  EDGES_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_T), sizeof(double) * 16 * (size_t)n_frames));
+  EDGES_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_e), sizeof(double) * 7 * (size_t)(n_frames - 1)));
+  EDGES_HIP_TRY(hipMemcpy(d_T, Twc, sizeof(double) * 16 * (size_t)n_frames, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  EDGES_HIP_TRY(hipEventCreate(&e0));
+  EDGES_HIP_TRY(hipEventCreate(&e1));
+  EDGES_HIP_TRY(hipEventRecord(e0, nullptr));
+  hipLaunchKernelGGL(k_odometry_edges, dim3((n_frames - 1 + 255) / 256), dim3(256), 0, nullptr, d_T, n_frames, d_e);
+  EDGES_HIP_TRY(hipEventRecord(e1, nullptr));
+  EDGES_HIP_TRY(hipMemcpy(t_be, d_e, sizeof(double) * 7 * (size_t)(n_frames - 1), hipMemcpyDeviceToHost));
+  float ms = 0.f;
+  EDGES_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  if (kernel_ms) *kernel_ms = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d_T);
+  (void)hipFree(d_e);
+  return PGO_OK;
+}
+
+void pgo_edge_rules_init(pgo_edge_rules* r) {
+  if (!r) return;
+  r->match_threshold = 280;      // finial.cpp:226
+  r->inlier_threshold = 100;     // finial.cpp:234
+  r->norm_threshold = 0.7;       // finial.cpp:234
+  r->loop_list_gap = 100;        // finial.cpp:285
+}
+
+int pgo_build_edges(int n_frames, const double* Twc, const long long* cand_ptr, const int* cand_idx, const pgo_pair_observation* obs,
+                    const pgo_edge_rules* rules_in, int* id_begin, int* id_end, double* t_be, long long capacity, long long* n_edges,
+                    int* loop_list, long long loop_capacity, long long* n_loop_list) {
+  if (n_frames < 0 || !cand_ptr || !n_edges || (n_frames > 0 && !Twc))
+    return pgo_candidates_set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_build_edges");
+  pgo_edge_rules rules;
+  if (rules_in) rules = *rules_in; else pgo_edge_rules_init(&rules);
+  // odometry measurements of every consecutive pair, one launch
+  std::vector<double> odo(n_frames > 1 ? 7 * (size_t)(n_frames - 1) : 0);
+  if (n_frames > 1) {
+    const int rc = pgo_build_odometry_edges(n_frames, Twc, odo.data(), nullptr);
+    if (rc) return rc;
+  }
+  std::vector<char> have_loop(n_frames > 0 ? n_frames : 0, 0);
+  long long ne = 0, nl = 0;
+  for (int cur = 0; cur < n_frames; ++cur) {
+    bool have = false;
+    for (long long c = cand_ptr[cur]; c < cand_ptr[cur + 1]; ++c) {
+      const int prev = cand_idx[c];
+      if (prev < 0 || prev >= cur) continue;          // frames are registered in id order: later ids are not known yet
+      double m[7];
+      bool accept = false;
+      if (cur - prev == 1) {                          // finial.cpp:206-224: the odometry rule, vision not consulted
+        std::memcpy(m, &odo[7 * (size_t)prev], sizeof m);
+        accept = true;
+      } else {
+        if (!obs) continue;
+        const pgo_pair_observation& o = obs[c];
+        if (!(o.nmatches > rules.match_threshold)) continue;                                         // finial.cpp:226
+        const double norm = norm_of_transform(o.rvec, o.tvec);
+        if (!(o.inliers > rules.inlier_threshold && norm < rules.norm_threshold)) continue;           // finial.cpp:234
+        if (have || have_loop[prev]) continue;                                                        // finial.cpp:238, 288-289
+        double R[9];
+        rodrigues(o.rvec, R);
+        float T[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
+        for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) T[4 * r + cc] = (float)R[3 * r + cc]; T[4 * r + 3] = (float)o.tvec[r]; }
+        to_pose3d(T, m);
+        if (cur - prev > rules.loop_list_gap) {                                                       // finial.cpp:285-286
+          if (loop_list && nl < loop_capacity) { loop_list[2 * nl] = cur; loop_list[2 * nl + 1] = prev; }
+          ++nl;
+        }
+        have = true;
+        accept = true;
+      }
+      if (accept) {
+        if (ne < capacity && id_begin && id_end && t_be) {
+          id_begin[ne] = cur;
+          id_end[ne] = prev;
+          std::memcpy(t_be + 7 * (size_t)ne, m, sizeof m);
+        }
+        ++ne;
+      }
+    }
+    have_loop[cur] = have ? 1 : 0;
+  }
+  *n_edges = ne;
+  if (n_loop_list) *n_loop_list = nl;
+  if (ne > capacity && id_begin) return pgo_candidates_set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_build_edges: edge capacity too small (n_edges holds the required count)");
+  return PGO_OK;
+}
+
+}  // extern "C"

@@ -25,22 +25,31 @@ NORM_THRESHOLD = 0.7       # finial.cpp:234
 LOOP_LIST_GAP = 100        # finial.cpp:285
 
 
+def _norm3(v):
+    """sqrt((x*x + y*y) + z*z) with every operation rounded separately, in this order: the C-ABI twin (csrc/pgo_edges.hip)
+    states the same sequence, so both sides agree bit for bit (np.linalg.norm may go through a scaled BLAS routine)."""
+    x, y, z = (float(c) for c in np.asarray(v, dtype=np.float64).reshape(3))
+    return math.sqrt((x * x + y * y) + z * z)
+
+
 def norm_of_transform(rvec, tvec):
     """finial.cpp:486-489."""
-    r = float(np.linalg.norm(np.asarray(rvec, dtype=np.float64)))
-    t = float(np.linalg.norm(np.asarray(tvec, dtype=np.float64)))
+    r = _norm3(rvec)
+    t = _norm3(tvec)
     return abs(min(r, 2.0 * math.pi - r)) + abs(t)
 
 
 def rodrigues(rvec):
     """Rotation vector -> 3x3 rotation matrix (cv::Rodrigues, finial.cpp:256)."""
-    r = np.asarray(rvec, dtype=np.float64).reshape(3)
-    th = float(np.linalg.norm(r))
+    r = [float(c) for c in np.asarray(rvec, dtype=np.float64).reshape(3)]
+    th = _norm3(r)
     if th < 2.2204460492503131e-16:
         return np.eye(3)
-    k = r / th
-    K = np.array([[0.0, -k[2], k[1]], [k[2], 0.0, -k[0]], [-k[1], k[0], 0.0]])
-    return math.cos(th) * np.eye(3) + (1.0 - math.cos(th)) * np.outer(k, k) + math.sin(th) * K
+    k = [r[0] / th, r[1] / th, r[2] / th]
+    K = [[0.0, -k[2], k[1]], [k[2], 0.0, -k[0]], [-k[1], k[0], 0.0]]
+    c, s = math.cos(th), math.sin(th)
+    omc = 1.0 - c
+    return np.array([[(c * (1.0 if i == j else 0.0) + omc * (k[i] * k[j])) + s * K[i][j] for j in range(3)] for i in range(3)])
 
 
 def quaternion_from_matrix(R):
@@ -78,13 +87,21 @@ def to_pose3d(T):
 
 
 def relative_transform(Twc_cur, Twc_prev):
-    """Tcl = Tcw(cur) * Twc(prev) (finial.cpp:213).  Inputs: 4x4 camera-to-world transforms."""
-    Twc_cur = np.asarray(Twc_cur, dtype=np.float64)
-    R, t = Twc_cur[:3, :3], Twc_cur[:3, 3]
-    Tcw = np.eye(4)
-    Tcw[:3, :3] = R.T
-    Tcw[:3, 3] = -R.T @ t
-    return Tcw @ np.asarray(Twc_prev, dtype=np.float64)
+    """Tcl = Tcw(cur) * Twc(prev) (finial.cpp:213).  Inputs: 4x4 camera-to-world transforms.  Plain Python floats, every
+    product and sum rounded separately in index order (no BLAS): the same arithmetic as the GPU kernel k_odometry_edges."""
+    C = [[float(x) for x in row] for row in np.asarray(Twc_cur, dtype=np.float64)]
+    P = [[float(x) for x in row] for row in np.asarray(Twc_prev, dtype=np.float64)]
+    Tcw = [[0.0] * 4 for _ in range(4)]
+    for i in range(3):
+        for j in range(3):
+            Tcw[i][j] = C[j][i]
+        Tcw[i][3] = -((C[0][i] * C[0][3] + C[1][i] * C[1][3]) + C[2][i] * C[2][3])
+    Tcw[3][3] = 1.0
+    T = np.zeros((4, 4))
+    for i in range(4):
+        for j in range(4):
+            T[i, j] = ((Tcw[i][0] * P[0][j] + Tcw[i][1] * P[1][j]) + Tcw[i][2] * P[2][j]) + Tcw[i][3] * P[3][j]
+    return T
 
 
 class LoopEdgeBuilder:
