@@ -306,6 +306,10 @@ int pgo_reproj_solve_batch(int n_problems, const long long* point_ptr, const dou
 /* ---- one process per GPU: edge/row sharding over RCCL ---- */
 /* contiguous share [begin,end) of n units for `rank` of `world` (host-only helper, no GPU needed) */
 int pgo_shard_range(long long n, int rank, int world, long long* begin, long long* end);
+/* Row ownership of the sharded solve — the rule pgo_comm_init itself applies: rank r owns the poses [r * rows_per,
+ * (r + 1) * rows_per) cut at n_poses, rows_per = ceil(n_poses / world) rounded up to a multiple of 4 (preconditioner
+ * clusters never straddle ranks; equal segments for the all-gather).  rows_per optional. */
+int pgo_row_shard_range(long long n_poses, int rank, int world, long long* begin, long long* end, int* rows_per);
 /* 128-byte RCCL unique id created on rank 0 and handed to every rank by the launcher */
 int pgo_comm_get_unique_id(unsigned char id[128]);
 /* Attaches rank `rank` of `world` to the problem BEFORE the first solve/evaluate.  Every rank must hold the same problem

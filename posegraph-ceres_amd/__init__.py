@@ -42,7 +42,7 @@ C_ABI_SYMBOLS = [
     "pgo_solver_step", "pgo_solver_reset", "pgo_solver_end", "pgo_time_kernel", "pgo_shard_range",
     "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_loopback_create", "pgo_loopback_destroy", "pgo_comm_init_loopback",
     "pgo_generate_candidates", "pgo_reproj_options_init", "pgo_reproj_solve_batch",
-    "pgo_read_trajectory", "pgo_build_odometry_edges", "pgo_edge_rules_init", "pgo_build_edges",
+    "pgo_row_shard_range", "pgo_read_trajectory", "pgo_build_odometry_edges", "pgo_edge_rules_init", "pgo_build_edges",
 ]
 
 
@@ -143,6 +143,13 @@ def shard_range(n, rank, world):
     b, e = C.c_longlong(0), C.c_longlong(0)
     _check(lib().pgo_shard_range(C.c_longlong(n), C.c_int(rank), C.c_int(world), C.byref(b), C.byref(e)))
     return b.value, e.value
+
+
+def row_shard_range(n_poses, rank, world):
+    """pgo_row_shard_range: the row ownership rule of the sharded solve.  Returns (begin, end, rows_per)."""
+    b, e, rp = C.c_longlong(0), C.c_longlong(0), C.c_int(0)
+    _check(lib().pgo_row_shard_range(C.c_longlong(n_poses), C.c_int(rank), C.c_int(world), C.byref(b), C.byref(e), C.byref(rp)))
+    return b.value, e.value, rp.value
 
 
 def generate_candidates(xyz, search_radius=6.0, gap=100, return_ms=False):

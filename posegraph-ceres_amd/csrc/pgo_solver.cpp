@@ -367,9 +367,10 @@ int prepare(pgo_problem* P) {
   // ---- row ownership: rank r owns the poses [r*rows_per, (r+1)*rows_per); cut edges are evaluated by
   // the owners of both endpoints.  rows_per is a multiple of 4 so that preconditioner clusters never straddle ranks.
   const int world = P->comm ? P->comm->world : 1, rank = P->comm ? P->comm->rank : 0;
-  int rows_per = (N + world - 1) / world;
-  rows_per = std::max(4, (rows_per + 3) / 4 * 4);
-  const int row_lo = std::min(N, rank * rows_per), row_hi = std::min(N, (rank + 1) * rows_per);
+  long long rl = 0, rh = 0;
+  int rows_per = 0;
+  if (pgo_row_shard_range(N, rank, world, &rl, &rh, &rows_per) != PGO_OK) return PGO_ERR_INVALID_ARGUMENT;   // THE ownership rule
+  const int row_lo = (int)rl, row_hi = (int)rh;
   const int NP = world * rows_per;   // padded pose count of every replicated / exchanged array
   const int B = choose_block(total / world);
 
@@ -1875,6 +1876,19 @@ int pgo_shard_range(long long n, int rank, int world, long long* begin, long lon
   const long long base = n / world, rem = n % world;
   *begin = base * rank + std::min<long long>(rank, rem);
   *end = *begin + base + (rank < rem ? 1 : 0);
+  return PGO_OK;
+}
+
+// Row ownership of the sharded solve: equal segments (the all-gather exchanges equal-sized pieces) of rows_per poses, rows_per a
+// multiple of 4 so that the 2- and 4-pose preconditioner clusters never straddle two ranks; the last ranks may own fewer
+// rows or none.  prepare() calls this very function.
+int pgo_row_shard_range(long long n_poses, int rank, int world, long long* begin, long long* end, int* rows_per_out) {
+  if (n_poses < 0 || world <= 0 || rank < 0 || rank >= world || !begin || !end) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_row_shard_range");
+  long long rows_per = (n_poses + world - 1) / world;
+  rows_per = std::max<long long>(4, (rows_per + 3) / 4 * 4);
+  *begin = std::min(n_poses, (long long)rank * rows_per);
+  *end = std::min(n_poses, (long long)(rank + 1) * rows_per);
+  if (rows_per_out) *rows_per_out = (int)rows_per;
   return PGO_OK;
 }
 

@@ -97,6 +97,17 @@ def test_compute_calls_fail_loudly_without_a_gpu(pkg):
         assert ei.value.code == pkg.ERR_NO_DEVICE and "no CPU fallback" in str(ei.value)
 
 
+def test_row_shard_range_is_the_solver_rule(pkg):
+    for n in (0, 1, 7, 300, 10000, 100003):
+        for world in (1, 2, 3, 8):
+            parts = [pkg.row_shard_range(n, r, world) for r in range(world)]
+            rp = parts[0][2]
+            assert rp % 4 == 0 and rp >= 4 and rp * world >= n and all(p[2] == rp for p in parts)
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            assert all(p[1] - p[0] <= rp for p in parts)
+
+
 def test_full_report_renders(pkg):
     from posegraph_ceres_amd import _CSummary, RECORD_DTYPE, Summary
     s = _CSummary()
@@ -106,4 +117,5 @@ def test_full_report_renders(pkg):
     rec["iteration"] = [0, 1]
     text = Summary(s, rec).full_report()
     assert "Solver Summary" in text and "Residual blocks" in text and "CONVERGENCE" in text
+    assert "Original" in text and "Reduced" in text and "Given" in text and "Used" in text      # Ceres 1.13's two-column layout
     assert Summary(s, rec).is_solution_usable()

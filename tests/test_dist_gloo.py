@@ -1,5 +1,5 @@
 """CPU, world_size 2 over gloo: the multi-process decomposition of the path.
-Each rank owns a contiguous share of the pose rows (pgo_shard_range) and every edge incident to them;
+Each rank owns a contiguous share of the pose rows (pgo_row_shard_range: the rule pgo_comm_init itself applies) and every edge incident to them;
 the per-rank pieces of J'r, of the diagonal J'J blocks and of one block SpMV, all-gathered over gloo,
 must equal the single-process result.  The arithmetic here is the CPU oracle's (no GPU in this
 container); the partition logic is the product's."""
@@ -27,7 +27,7 @@ def _worker(rank, world, port, out):
     g = ds.manhattan_se3(300, 1000, seed=21)
     og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
     _, r, ja, jb = O.evaluate(og)
-    lo, hi = pkg.shard_range(g.N, rank, world)
+    lo, hi, seg = pkg.row_shard_range(g.N, rank, world)
     # rows owned by this rank: gradient and diagonal blocks from every incident edge (cut edges are
     # evaluated by both owners, never exchanged)
     grad = np.zeros((hi - lo, 6))
@@ -45,7 +45,6 @@ def _worker(rank, world, port, out):
             diag[b - lo] += jb[e].T @ jb[e]
             y[b - lo] += jb[e].T @ (ja[e] @ x[a] + jb[e] @ x[b])
     # one all-gather per operator application (padded equal-size segments, as RCCL all-gather needs)
-    seg = max(pkg.shard_range(g.N, k, world)[1] - pkg.shard_range(g.N, k, world)[0] for k in range(world))
     def gather(local, width):
         buf = torch.zeros(seg * width, dtype=torch.float64)
         buf[: local.size] = torch.from_numpy(local.reshape(-1))
@@ -53,7 +52,7 @@ def _worker(rank, world, port, out):
         dist.all_gather(outs, buf)
         parts = []
         for k in range(world):
-            b0, b1 = pkg.shard_range(g.N, k, world)
+            b0, b1, _ = pkg.row_shard_range(g.N, k, world)
             parts.append(outs[k][: (b1 - b0) * width].numpy().reshape(b1 - b0, width))
         return np.concatenate(parts)
     full_grad, full_y = gather(grad, 6), gather(y, 6)
