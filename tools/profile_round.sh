@@ -1,0 +1,26 @@
+# tools/profile_round.sh <tag> — run ON THE GPU BOX (gpurun): collects the rocprofv3 evidence of a round under gpurun_out/<tag>/
+# and writes the summaries that get committed under profiles/<tag>_*.  Counters are collected in passes of their own
+# (--pmc without any trace domain besides the kernel trace), as the pool requires.
+#   1. kernel trace of the bench command (C2 PCG timed region + exact blocks), per-kernel summary
+#   2. FETCH_SIZE / WRITE_SIZE passes of the same command -> HBM bytes per launch (tools/rocprof_pmc.py)
+#   3. kernel trace of the multifrontal factorisation on C2 and C5
+#   4. FP64 MFMA counters of the multifrontal factorisation on C5
+TAG=${1:-r02}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+BENCH="python bench.py --no-c4-kernels --cpu-iters 0 --no-cpu-baseline --no-exact-blocks --repeats 2"
+rocprofv3 --kernel-trace -d $OUT/bench_trace -o bench -- $BENCH > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+python tools/rocprof_summary.py $OUT/bench_trace/bench_results.db $OUT/${TAG}_bench_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- $BENCH > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- $BENCH > /dev/null 2> $OUT/pmc_write.err
+python tools/rocprof_pmc.py $OUT/pmc_fetch/f_results.db $OUT/pmc_write/w_results.db $OUT/${TAG}_pmc.json > $OUT/pmc.log 2>&1
+for c in c2 c5; do
+  rocprofv3 --kernel-trace -d $OUT/front_$c -o front -- python tools/front_prof.py $c 5 > $OUT/front_$c.log 2>&1
+  python tools/rocprof_summary.py $OUT/front_$c/front_results.db $OUT/${TAG}_front_${c}_kernel_stats.csv
+done
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/front_mfma -o m -- python tools/front_prof.py c5 3 > $OUT/front_mfma.log 2>&1
+python tools/rocprof_mfma.py $OUT/front_mfma/m_results.db $OUT/${TAG}_front_c5_mfma_pmc.json > $OUT/front_mfma_summary.log 2>&1
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+tail -n 3 $OUT/pmc.log $OUT/front_mfma_summary.log $OUT/front_c2.log $OUT/front_c5.log
+# then, in the build container: cp gpurun_out/<tag>/<tag>_* profiles/ (gpurun merges only gpurun_out/ back)
