@@ -80,7 +80,7 @@ __device__ __forceinline__ void assemble_row(const DeviceGraph& g, const DirectP
     for (int s = p.asrc_ptr[bi]; s < p.asrc_ptr[bi + 1]; ++s) {
       const int slot = p.asrc_slot[s];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) v[c] += g.bsr_val[bsr_index(slot, 6 * r + c)];
+      for (int c = 0; c < 6; ++c) v[c] += bsr_elem(g, slot, g.slot_side[slot], 6 * r + c);
     }
   }
   subtract_pairs(p, p.upd_ptr[bi], q_end, r, sub, stride, v);

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_front_scatter(DeviceGraph g, FrontPlan 
   if (t < na) {
     const int a = (int)(t / 36), e = (int)(t - 36LL * a);
     double s = 0.0;
-    for (int q = p.ablk_ptr[a]; q < p.ablk_ptr[a + 1]; ++q) s += g.bsr_val[bsr_index(p.ablk_slot[q], e)];
+    for (int q = p.ablk_ptr[a]; q < p.ablk_ptr[a + 1]; ++q) { const int slot = p.ablk_slot[q]; s += bsr_elem(g, slot, g.slot_side[slot], e); }
     const FrontDesc& D = p.fronts[p.ablk_front[a]];
     const int pos = p.ablk_pos[a], bi = pos >> 16, bj = pos & 0xffff;
     p.Fval[D.fbase + (size_t)(6 * bi + e / 6) * D.ld + 6 * bj + e % 6] = s;

@@ -17,6 +17,25 @@ __host__ __device__ inline size_t bsr_index(int slot, int k) {
 
 enum SlotSide : uint8_t { SIDE_BEGIN = 0, SIDE_END = 1, SIDE_DIAG = 2, SIDE_PAD = 3 };
 
+// ---- packed 27-entry slots (DeviceGraph::blk_packed) -------------------------------------------------------------------
+// With identity or block-diagonal information (W_pr = 0: the reference's I_6, diag(1/sigma^2)) the off-diagonal block
+// H_ab = rho' S_a A^T W B S_b has an exactly zero translation-rotation quadrant: [[-C1, 0], [(RU)^T, -(..)]] — its top-right
+// 3x3 for the BEGIN slot, the bottom-left one for the mirrored END slot — and the diagonal block is symmetric.  All three
+// kinds of slot then need 27 entries: positions 0..8 = top-left 3x3 (row-major), 9..17 = bottom-right 3x3, 18..26 = the one
+// stored off-diagonal quadrant Q (BEGIN and DIAG: bottom-left; END: top-right).  14 pairs per slot are written and read
+// instead of 18 (same tile layout and stride: the unused rows of a tile are simply never touched), whatever the side — so
+// the SpMV issues its block loads without knowing the side first.  General information keeps the full 36-entry layout
+// (position = element).  bsr_pos: position of element k of a slot, or -1 for a structural zero.
+enum { BLK_PAIRS_FULL = 18, BLK_PAIRS_PACKED = 14 };
+__host__ __device__ inline int bsr_pos(int packed, int side, int k) {
+  if (!packed) return k;
+  const int r = k / 6, c = k - 6 * r;
+  if (r < 3 && c < 3) return 3 * r + c;
+  if (r >= 3 && c >= 3) return 9 + 3 * (r - 3) + (c - 3);
+  if (r >= 3) return side == SIDE_END ? -1 : 18 + 3 * (r - 3) + c;            // bottom-left
+  return side == SIDE_END ? 18 + 3 * r + (c - 3) : side == SIDE_DIAG ? 18 + 3 * (c - 3) + r : -1;   // top-right (DIAG: mirror)
+}
+
 // Scalars the host reads once per LM iteration (pinned, device-visible).
 struct LmScalars {
   double cand_cost;        // 0.5 * sum rho(s) at the candidate point
@@ -49,7 +68,8 @@ struct DeviceGraph {
   int n_wg;          // workgroups of the row partition
   int n_slots;       // padded (multiple of block)
   int block;         // threads per workgroup of the row-partitioned kernels = slots per chunk
-  int info_mode;     // 0 identity information, 1 general W = L^T L
+  int info_mode;     // 0 identity information, 1 general W = L^T L, 2 block-diagonal W (W_pr = 0: only W_pp, W_rr are read)
+  int blk_packed;    // 1: 27-entry slots (info_mode 0 or 2), see bsr_pos
   int loss_kind;
   double loss_a;
 
@@ -110,6 +130,12 @@ struct DeviceGraph {
   const int* cl_slot;
   const uint8_t* cl_rc;  // per entry: (row - cluster base) << 4 | (col - cluster base)
 };
+
+// element k (row-major 6x6) of slot `slot`, whatever the layout
+__device__ __forceinline__ double bsr_elem(const DeviceGraph& g, int slot, int side, int k) {
+  const int p = bsr_pos(g.blk_packed, side, k);
+  return p < 0 ? 0.0 : g.bsr_val[bsr_index(slot, p)];
+}
 
 struct CgParams {
   double q_tolerance;   // eta

@@ -126,8 +126,24 @@ __device__ __forceinline__ WBlocks load_W(const double* W, size_t stride, size_t
   return w;
 }
 
+__device__ __forceinline__ WBlocks load_W_blockdiag(const double* W, size_t stride, size_t idx) {
+  WBlocks w;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i; j < 3; ++j) {
+      const double a = W[(size_t)upper_index(i, j) * stride + idx], b = W[(size_t)upper_index(3 + i, 3 + j) * stride + idx];
+      w.pp.m[3 * i + j] = a; w.pp.m[3 * j + i] = a;
+      w.rr.m[3 * i + j] = b; w.rr.m[3 * j + i] = b;
+    }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w.pr.m[k] = 0.0;
+  return w;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K_linearize: residual + closed-form Jacobians + Huber corrector + J^T J / J^T r, fused.
+// INFO: 0 identity information, 1 general W, 2 block-diagonal W.  0 and 2 write the packed 27-entry slots (pgo_kernels.h).
 // ------------------------------------------------------------------------------------------------
 template <int INFO>
 __global__ __launch_bounds__(256) void k_linearize(DeviceGraph g) {
@@ -158,7 +174,17 @@ __global__ __launch_bounds__(256) void k_linearize(DeviceGraph g) {
 
       V3 wep, wer;
       M3 C1, C2, RU, GP, MQ, GU;
-      if (INFO) {
+      if (INFO == 2) {
+        // block-diagonal information (W_pr = 0): only W_pp and W_rr are read (12 of 21 entries); every term that carries W_pr
+        // in the general branch below is exactly zero there, so both branches give the same numbers
+        const WBlocks W = load_W_blockdiag(g.sW, ns, (size_t)t);
+        wep = mulv(W.pp, ep);
+        wer = mulv(W.rr, er);
+        const M3 X = mul(W.pp, eg.Rt), Qm = mul(W.rr, eg.M), U = mul(W.pp, eg.G);
+        C1 = mulT(eg.Rt, X); RU = mulT(eg.Rt, U); MQ = mulT(eg.M, Qm); GU = mulT(eg.G, U);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { C2.m[k] = 0.0; GP.m[k] = 0.0; }
+      } else if (INFO) {
         const WBlocks W = load_W(g.sW, ns, (size_t)t);
         const V3 a1 = mulv(W.pp, ep), a2 = mulv(W.pr, er), b1 = mulTv(W.pr, ep), b2 = mulv(W.rr, er);
         wep = V3{a1.x + a2.x, a1.y + a2.y, a1.z + a2.z};
@@ -228,13 +254,32 @@ __global__ __launch_bounds__(256) void k_linearize(DeviceGraph g) {
         st[i] = ct ? 0.0 : g.scale[6 * (size_t)col + i];
       }
       double2* out = reinterpret_cast<double2*>(g.bsr_val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+      if (INFO != 1) {
+        // packed slot: positions 0..8 top-left, 9..17 bottom-right, 18..26 the stored off-diagonal quadrant (bottom-left of
+        // H_ab for the BEGIN slot, top-right of H_ba for the END slot), 27 unused.  Same products as the full layout.
+        double wv[28];
 #pragma unroll
-      for (int kk = 0; kk < 18; ++kk) {
-        const int k0 = 2 * kk, k1 = 2 * kk + 1;
-        double2 w;
-        w.x = rho1 * so[k0 / 6] * st[k0 % 6] * off[k0];
-        w.y = rho1 * so[k1 / 6] * st[k1 % 6] * off[k1];
-        out[(size_t)kk * 64] = w;
+        for (int q = 0; q < 9; ++q) {
+          const int i = q / 3, j = q % 3;
+          const int ktl = 6 * i + j, kbr = 6 * (3 + i) + 3 + j, kbl = 6 * (3 + i) + j, ktr = 6 * i + 3 + j;
+          wv[q] = rho1 * so[ktl / 6] * st[ktl % 6] * off[ktl];
+          wv[9 + q] = rho1 * so[kbr / 6] * st[kbr % 6] * off[kbr];
+          const double vbl = rho1 * so[kbl / 6] * st[kbl % 6] * off[kbl];
+          const double vtr = rho1 * so[ktr / 6] * st[ktr % 6] * off[ktr];
+          wv[18 + q] = side == SIDE_BEGIN ? vbl : vtr;
+        }
+        wv[27] = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < BLK_PAIRS_PACKED; ++kk) out[(size_t)kk * 64] = double2{wv[2 * kk], wv[2 * kk + 1]};
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 18; ++kk) {
+          const int k0 = 2 * kk, k1 = 2 * kk + 1;
+          double2 w;
+          w.x = rho1 * so[k0 / 6] * st[k0 % 6] * off[k0];
+          w.y = rho1 * so[k1 / 6] * st[k1 % 6] * off[k1];
+          out[(size_t)kk * 64] = w;
+        }
       }
       int k = 0;
 #pragma unroll
@@ -332,7 +377,7 @@ __global__ void k_damping(DeviceGraph g, double radius, double min_diag, double 
   if (g.row_slot_cnt[v] > 0) {   // rows owned by this rank (all rows with one rank)
     const int slot = g.row_slot_begin[v];
 #pragma unroll
-    for (int k = 0; k < 36; ++k) g.bsr_val[bsr_index(slot, k)] = A[k];
+    for (int k = 0; k < 36; ++k) g.bsr_val[bsr_index(slot, bsr_pos(g.blk_packed, SIDE_DIAG, k))] = A[k];   // packed: the mirrored quadrant writes the same values twice
   }
   if (g.cluster > 1) return;  // the cluster preconditioner kernel builds M^-1
   double Ai[36];
@@ -397,7 +442,7 @@ __global__ __launch_bounds__(64) void k_cluster_precond(DeviceGraph g, double ra
         double val = 0.0;
 #pragma unroll
         for (int q = 0; q < CL; ++q) if (q == lp) val = a[6 * q + ic];
-        g.bsr_val[bsr_index(slot, 6 * ic + jc)] = val;
+        g.bsr_val[bsr_index(slot, bsr_pos(g.blk_packed, SIDE_DIAG, 6 * ic + jc))] = val;
       }
     }
   }
@@ -410,14 +455,14 @@ __global__ __launch_bounds__(64) void k_cluster_precond(DeviceGraph g, double ra
       if (cc == lp) {           // A[6r + a][j] += B[a][jc]
 #pragma unroll
         for (int ai = 0; ai < 6; ++ai) {
-          const double bv = g.bsr_val[bsr_index(slot, 6 * ai + jc)];
+          const double bv = bsr_elem(g, slot, SIDE_BEGIN, 6 * ai + jc);
 #pragma unroll
           for (int q = 0; q < CL; ++q) if (q == r) a[6 * q + ai] += bv;
         }
       } else if (r == lp) {     // A[6cc + b][j] += B[jc][b]   (mirror)
 #pragma unroll
         for (int bi = 0; bi < 6; ++bi) {
-          const double bv = g.bsr_val[bsr_index(slot, 6 * jc + bi)];
+          const double bv = bsr_elem(g, slot, SIDE_BEGIN, 6 * jc + bi);
 #pragma unroll
           for (int q = 0; q < CL; ++q) if (q == cc) a[6 * q + bi] += bv;
         }
@@ -647,8 +692,9 @@ __global__ void k_pcg_init(DeviceGraph g) {
 // block fetch and only the z/p gathers (which need the column index) form a second round trip.
 // `odd` is the parity of the CG iteration number, fixed at launch (batches have even length and
 // start at iteration 1), so the ping-pong buffers are known without waiting for device state.
-template <int MODE>
+template <int MODE, bool PACKED>
 __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int odd) {
+  constexpr int NPAIR = PACKED ? BLK_PAIRS_PACKED : BLK_PAIRS_FULL;   // 16-byte loads per slot (pgo_kernels.h: packed 27-entry slots)
   extern __shared__ double lds[];  // SPMV_LDS_STRIDE * block (slot results) + 6 * block (own-row p_new)
   __shared__ double scratch[32];   // >= 7 sums x 4 waves
   const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
@@ -695,11 +741,11 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
   int col = g.slot_col[t];
   int row = g.slot_row[t];
   uint8_t side = g.slot_side[t];
-  double2 blk[18];
+  double2 blk[NPAIR];
   {
     const double2* bp = reinterpret_cast<const double2*>(g.bsr_val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
 #pragma unroll
-    for (int k = 0; k < 18; ++k) blk[k] = bp[(size_t)k * 64];
+    for (int k = 0; k < NPAIR; ++k) blk[k] = bp[(size_t)k * 64];
   }
   // row bookkeeping of the segmented sum (first item of this thread)
   int seg_rb = 0, seg_cnt = 0;
@@ -806,7 +852,7 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
       side = g.slot_side[t];
       const double2* bp = reinterpret_cast<const double2*>(g.bsr_val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
 #pragma unroll
-      for (int k = 0; k < 18; ++k) blk[k] = bp[(size_t)k * 64];
+      for (int k = 0; k < NPAIR; ++k) blk[k] = bp[(size_t)k * 64];
     }
     if (cb != s_begin && col >= 0) {
       if (fly) {
@@ -866,10 +912,29 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
         }
       }
       if (!(g.debug & 2)) {
+        if (PACKED) {
+          // packed slot: TL = positions 0..8, BR = 9..17, Q = 18..26 (bottom-left for BEGIN / DIAG, top-right for END); the
+          // row sums keep the expression of the full layout (entries that are structurally zero there are zero here), so
+          // both layouts round identically
+          double el[28];
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-          y[i] = blk[3 * i].x * x[0] + blk[3 * i].y * x[1] + blk[3 * i + 1].x * x[2] + blk[3 * i + 1].y * x[3] +
-                 blk[3 * i + 2].x * x[4] + blk[3 * i + 2].y * x[5];
+          for (int k = 0; k < BLK_PAIRS_PACKED; ++k) { el[2 * k] = blk[k].x; el[2 * k + 1] = blk[k].y; }
+          const bool is_end = side == SIDE_END, is_diag = side == SIDE_DIAG;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const double a3 = is_end ? el[18 + 3 * i] : is_diag ? el[18 + i] : 0.0;
+            const double a4 = is_end ? el[18 + 3 * i + 1] : is_diag ? el[21 + i] : 0.0;
+            const double a5 = is_end ? el[18 + 3 * i + 2] : is_diag ? el[24 + i] : 0.0;
+            y[i] = el[3 * i] * x[0] + el[3 * i + 1] * x[1] + el[3 * i + 2] * x[2] + a3 * x[3] + a4 * x[4] + a5 * x[5];
+            const double b0 = is_end ? 0.0 : el[18 + 3 * i], b1 = is_end ? 0.0 : el[18 + 3 * i + 1], b2 = is_end ? 0.0 : el[18 + 3 * i + 2];
+            y[3 + i] = b0 * x[0] + b1 * x[1] + b2 * x[2] + el[9 + 3 * i] * x[3] + el[9 + 3 * i + 1] * x[4] + el[9 + 3 * i + 2] * x[5];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+            y[i] = blk[3 * i].x * x[0] + blk[3 * i].y * x[1] + blk[3 * i + 1].x * x[2] + blk[3 * i + 1].y * x[3] +
+                   blk[3 * i + 2].x * x[4] + blk[3 * i + 2].y * x[5];
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < 6; ++i) y[i] = x[i];
@@ -1299,7 +1364,8 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 void launch_linearize(const DeviceGraph& g, hipStream_t s) {
   const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);
-  if (g.info_mode) hipLaunchKernelGGL(k_linearize<1>, dim3(g.n_wg), dim3(g.block), lds, s, g);
+  if (g.info_mode == 2) hipLaunchKernelGGL(k_linearize<2>, dim3(g.n_wg), dim3(g.block), lds, s, g);
+  else if (g.info_mode) hipLaunchKernelGGL(k_linearize<1>, dim3(g.n_wg), dim3(g.block), lds, s, g);
   else hipLaunchKernelGGL(k_linearize<0>, dim3(g.n_wg), dim3(g.block), lds, s, g);
 }
 void launch_scale_from_diag(const DeviceGraph& g, hipStream_t s) {
@@ -1335,7 +1401,8 @@ static void launch_update(const DeviceGraph& g, int odd, hipStream_t s, int mode
 }
 void launch_pcg_iteration(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s) {
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
-  hipLaunchKernelGGL(k_spmv<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, p, odd);
+  if (g.blk_packed) hipLaunchKernelGGL((k_spmv<0, true>), dim3(g.n_wg), dim3(g.block), lds, s, g, p, odd);
+  else hipLaunchKernelGGL((k_spmv<0, false>), dim3(g.n_wg), dim3(g.block), lds, s, g, p, odd);
   launch_update(g, odd, s);
 }
 void launch_pcg_finish(const DeviceGraph& g, const CgParams& p, hipStream_t s, int publish) {
@@ -1344,11 +1411,13 @@ void launch_pcg_finish(const DeviceGraph& g, const CgParams& p, hipStream_t s, i
 void launch_spmv_plain(const DeviceGraph& g, hipStream_t s) {
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
   CgParams dummy{0.0, -1.0, 0, 0};
-  hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1);
+  if (g.blk_packed) hipLaunchKernelGGL((k_spmv<1, true>), dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1);
+  else hipLaunchKernelGGL((k_spmv<1, false>), dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1);
 }
 void launch_spmv_tail(const DeviceGraph& g, const CgParams& p, hipStream_t s, int finish, int candidates) {
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
-  hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, p, 1 | (finish ? 2 : 0) | (candidates ? 4 : 0));
+  if (g.blk_packed) hipLaunchKernelGGL((k_spmv<1, true>), dim3(g.n_wg), dim3(g.block), lds, s, g, p, 1 | (finish ? 2 : 0) | (candidates ? 4 : 0));
+  else hipLaunchKernelGGL((k_spmv<1, false>), dim3(g.n_wg), dim3(g.block), lds, s, g, p, 1 | (finish ? 2 : 0) | (candidates ? 4 : 0));
 }
 void launch_step_tail(const DeviceGraph& g, hipStream_t s, int gate) {
   const int grid = g.n_edge_wg + g.n_pose_wg;   // <= 2 * n_part
@@ -1357,7 +1426,8 @@ void launch_step_tail(const DeviceGraph& g, hipStream_t s, int gate) {
 }
 void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s) {
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
-  hipLaunchKernelGGL(k_spmv<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, p, odd);
+  if (g.blk_packed) hipLaunchKernelGGL((k_spmv<0, true>), dim3(g.n_wg), dim3(g.block), lds, s, g, p, odd);
+  else hipLaunchKernelGGL((k_spmv<0, false>), dim3(g.n_wg), dim3(g.block), lds, s, g, p, odd);
 }
 void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s, int mode) {
   launch_update(g, odd, s, mode);
@@ -1367,7 +1437,8 @@ void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s, int mo
 void launch_spmv_refresh(const DeviceGraph& g, hipStream_t s, int on_the_fly, int it_odd) {
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
   CgParams dummy{0.0, -1.0, 0, 0};
-  hipLaunchKernelGGL(k_spmv<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1 | 8 | (on_the_fly ? 16 : 0) | (it_odd ? 32 : 0));
+  if (g.blk_packed) hipLaunchKernelGGL((k_spmv<1, true>), dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1 | 8 | (on_the_fly ? 16 : 0) | (it_odd ? 32 : 0));
+  else hipLaunchKernelGGL((k_spmv<1, false>), dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1 | 8 | (on_the_fly ? 16 : 0) | (it_odd ? 32 : 0));
 }
 void launch_model_delta_and_retract(const DeviceGraph& g, hipStream_t s, int gate) {
   hipLaunchKernelGGL(k_model_delta, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g, gate);

@@ -17,6 +17,7 @@
 namespace pgo { int comm_stress(Comm* c, int iters, size_t seg, hipStream_t s, int* mismatches); }
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -455,6 +456,7 @@ int prepare(pgo_problem* P) {
       for (int c = 0; c < 7; ++c) smeas[(size_t)c * n_slots + t] = e < 0 ? (c == 6 ? 1.0 : 0.0) : P->meas[(size_t)7 * e + c];
     }
   });
+  std::atomic<int> w_has_pr(0);
   if (P->has_info) {
     eW.resize((size_t)21 * E); eL.resize((size_t)36 * E); sW.resize((size_t)21 * n_slots);
     parallel_for(E, [&](int lo, int hi) {
@@ -465,6 +467,7 @@ int prepare(pgo_problem* P) {
           for (int j = i; j < 6; ++j) {
             double w = 0;
             for (int r = 0; r < 6; ++r) w += L[6 * r + i] * L[6 * r + j];  // W = L^T L
+            if (i < 3 && j >= 3 && w != 0.0) w_has_pr.store(1, std::memory_order_relaxed);
             eW[(size_t)k * E + e] = w;
             ++k;
           }
@@ -488,6 +491,7 @@ int prepare(pgo_problem* P) {
       }
     });
   }
+  const bool w_blockdiag = P->has_info && w_has_pr.load() == 0;
   lap("measurement / W arrays");
   P->h_slot_row = slot_row; P->h_slot_col = slot_col; P->h_slot_side = slot_side; P->h_row_slot_begin = row_slot_begin;
   P->direct_analyzed = false; P->direct_usable = false; P->front_usable = false; P->cluster_built = 0; P->g.cluster = 1;
@@ -550,7 +554,14 @@ int prepare(pgo_problem* P) {
   // validated at world size 1 on the development box; PGO_COMM_GRAPH=1 opts in).  The per-iteration cost is then
   // dominated by the all-gather latency, not by launch overhead.
   if (P->comm && (!P->comm->capturable() || (world > 1 && !(getenv("PGO_COMM_GRAPH") && getenv("PGO_COMM_GRAPH")[0] == '1')))) P->use_graph = false;
-  g.info_mode = P->has_info ? 1 : 0;
+  // 0 identity, 1 general, 2 block-diagonal W (every W_pr entry exactly zero: diag(1/sigma^2) and the like); 0 and 2 use the packed
+  // 27-entry slots.  PGO_BLK_FULL=1 keeps the general kernels and the full layout (A/B measurements).
+  {
+    const char* full = getenv("PGO_BLK_FULL");
+    const bool force_full = full && full[0] == '1';
+    g.info_mode = !P->has_info ? 0 : (w_blockdiag && !force_full) ? 2 : 1;
+    g.blk_packed = (g.info_mode != 1 && !force_full) ? 1 : 0;
+  }
   g.loss_kind = P->loss_kind; g.loss_a = P->loss_a;
   g.slot_col = P->d_slot_col.p; g.slot_row = P->d_slot_row.p; g.slot_side = P->d_slot_side.p;
   g.wg_slot_begin = P->d_wg_slot_begin.p; g.wg_row_begin = P->d_wg_row_begin.p;
@@ -1717,7 +1728,10 @@ int pgo_normal_equations(pgo_problem* P, double* diag, double* offdiag, double* 
   if (offdiag)
     for (int e = 0; e < E; ++e) {
       const int t = P->edge_begin_slot[e];
-      for (int k = 0; k < 36; ++k) offdiag[(size_t)36 * e + k] = bsr[pgo::bsr_index(t, k)];
+      for (int k = 0; k < 36; ++k) {
+        const int pos = pgo::bsr_pos(P->g.blk_packed, pgo::SIDE_BEGIN, k);
+        offdiag[(size_t)36 * e + k] = pos < 0 ? 0.0 : bsr[pgo::bsr_index(t, pos)];
+      }
     }
   return PGO_OK;
 }
