@@ -337,30 +337,45 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
     }
     S.ablk_ptr.push_back((int)ents.size());
   }
-  // ---- 10. schedule ----
-  // Per level and panel step s: one PANEL launch over every front of the level that has a panel s, then (if any front
-  // needs it) one GEMM launch: the right-looking update behind an outer panel that just finished, or the Schur update of
-  // a front whose last panel was s.
+  // ---- 10. schedule: rounds over the whole tree, not level by level ----
+  // A front runs the chain  [extend-add] -> panel 0 -> [GEMM] -> panel 1 -> ... ; it may start as soon as ITS children are
+  // done.  Every round issues up to three launches — extend-add, panel, GEMM — each carrying the next phase of every front
+  // that is ready for it, whatever its tree level.  The number of rounds is the longest chain of panel steps from a leaf to
+  // the root (Manhattan 10 k: 69 instead of the 133 a level-by-level schedule needs; sphere x10: 248 instead of 508), and
+  // the chain, not the flops, is what bounds these factorisations.  The backward substitution is scheduled the same way from
+  // the root down.
   S.levels.resize(n_levels);
-  const long long tile32_below = (long long)env_or("PGO_FRONT_TILE32_BELOW", 192);
   {
     int f = 0;
     for (int l = 0; l < n_levels; ++l) {
-      FrontLevel& L = S.levels[l];
-      L.front_begin = f;
+      S.levels[l].front_begin = f;
       while (f < nf && level[order[f]] == l) ++f;
-      L.front_end = f;
-      L.asm_front_begin = L.front_end;
-      for (int q = L.front_begin; q < L.front_end; ++q)
-        if (S.fronts[q].child_end > S.fronts[q].child_begin) { L.asm_front_begin = q; break; }
-      // extend-add: one workgroup per parent tile (8 x 8 poses, or the right-hand-side row x 8 poses) that receives
-      // anything, with the list of the children that contribute and their row ranges (children in list order)
-      L.asm_wg_begin = (int)(S.asm_tile.size() / 4);
+      S.levels[l].front_end = f;
+    }
+  }
+  const long long tile32_below = (long long)env_or("PGO_FRONT_TILE32_BELOW", 192);
+  {
+    std::vector<int> next_step(nf, 0), nsteps(nf), kids_left(nf), pending(nf, -1);
+    std::vector<char> asm_done(nf, 0), finished(nf, 0);
+    for (int q = 0; q < nf; ++q) {
+      nsteps[q] = (6 * S.fronts[q].c + FRONT_NB - 1) / FRONT_NB;
+      kids_left[q] = S.fronts[q].child_end - S.fronts[q].child_begin;
+      asm_done[q] = kids_left[q] == 0;
+    }
+    int n_finished = 0;
+    std::vector<int> done_now, gjobs;
+    struct Rec { long long key; int child, kk, mm; };
+    std::vector<Rec> recs;
+    std::vector<int> occ;
+    while (n_finished < nf) {
+      done_now.clear();
+      // (1) extend-add of every front whose children are all done: one workgroup per parent tile (8 x 8 poses, or the
+      // right-hand-side row x 8 poses) that receives anything, with the list of contributing children (list order)
       {
-        struct Rec { long long key; int child, kk, mm; };
-        std::vector<Rec> recs;
-        std::vector<int> occ;
-        for (int q = L.asm_front_begin; q < L.front_end; ++q) {
+        FrontLaunch la{FrontLaunch::ASM, 0, 0, (int)(S.asm_tile.size() / 4)};
+        for (int q = 0; q < nf; ++q) {
+          if (asm_done[q] || kids_left[q] > 0) continue;
+          asm_done[q] = 1;
           const FrontDesc& P = S.fronts[q];
           recs.clear();
           for (int ci = P.child_begin; ci < P.child_end; ++ci) {
@@ -372,13 +387,13 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
               const bool rhs = a == occ.size();
               const int ti = rhs ? P.ntp : occ[a];
               const int kk = rhs ? (C.r << 16) | (C.r + 1) : (cs[ti] << 16) | cs[ti + 1];
-              for (size_t b = 0; b < occ.size() && (rhs || b <= a); ++b) {
-                const int tj = occ[b];
+              for (size_t b2 = 0; b2 < occ.size() && (rhs || b2 <= a); ++b2) {
+                const int tj = occ[b2];
                 recs.push_back(Rec{((long long)ti << 40) | ((long long)tj << 20) | (long long)(ci - P.child_begin), S.child[ci], kk, (cs[tj] << 16) | cs[tj + 1]});
               }
             }
           }
-          std::sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.key < b.key; });
+          std::sort(recs.begin(), recs.end(), [](const Rec& x, const Rec& y) { return x.key < y.key; });
           for (size_t e = 0; e < recs.size();) {
             size_t f2 = e;
             while (f2 < recs.size() && (recs[f2].key >> 20) == (recs[e].key >> 20)) ++f2;
@@ -390,71 +405,49 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
             e = f2;
           }
         }
+        la.n_wg = (int)(S.asm_tile.size() / 4) - la.wg_begin;
+        if (la.n_wg > 0) S.launches.push_back(la);
       }
-      L.asm_wg = (int)(S.asm_tile.size() / 4) - L.asm_wg_begin;
-      L.bwd_wg_begin = (int)S.bwd_front.size();
-      for (int q = L.front_begin; q < L.front_end; ++q)
-        for (int ch = 0; ch < (6 * S.fronts[q].c + 63) / 64; ++ch) { S.bwd_front.push_back(q); S.bwd_chunk.push_back(ch); }
-      L.bwd_wg = (int)S.bwd_front.size() - L.bwd_wg_begin;
-      // phase B: x_c = L11^-T t in 192-column blocks, last block first.  Step s: every front with more than s blocks lets
-      // its block nblk - s update the chunks below it (one workgroup per chunk); the workgroup of chunk nblk - 1 - s then
-      // solves that chunk's diagonal block.  Step 0 has no source block: the last chunk is solved.
+      // (2) the next 48-column panel of every front that is assembled and not waiting for a GEMM
       {
-        int max_blk = 0;
-        for (int q = L.front_begin; q < L.front_end; ++q) max_blk = std::max(max_blk, (6 * S.fronts[q].c + FRONT_NBO - 1) / FRONT_NBO);
-        L.bwd_step_begin = (int)S.bwd_step_ptr.size();
-        L.bwd_steps = max_blk;
-        for (int st = 0; st < max_blk; ++st) {
-          S.bwd_step_ptr.push_back((int)S.bwdb_front.size());
-          for (int q = L.front_begin; q < L.front_end; ++q) {
-            const int nblk = (6 * S.fronts[q].c + FRONT_NBO - 1) / FRONT_NBO;
-            if (st >= nblk) continue;
-            const int src = nblk - st;            // == nblk at step 0: no source block
-            const int solver = nblk - 1 - st;
-            for (int ch = 0; ch <= solver; ++ch) {
-              if (st == 0 && ch != solver) continue;
-              S.bwdb_front.push_back(q);
-              S.bwdb_chunk.push_back(((st == 0 ? solver : src) << 16) | ch);
-            }
-          }
-        }
-        S.bwd_step_ptr.push_back((int)S.bwdb_front.size());
-      }
-      L.launch_begin = (int)S.launches.size();
-      int max_steps = 0;
-      for (int q = L.front_begin; q < L.front_end; ++q) max_steps = std::max(max_steps, (6 * S.fronts[q].c + FRONT_NB - 1) / FRONT_NB);
-      for (int step = 0; step < max_steps; ++step) {
         FrontLaunch lp{FrontLaunch::PANEL, 0, FRONT_TILE, (int)S.wg_job.size()};
-        for (int q = L.front_begin; q < L.front_end; ++q) {
+        for (int q = 0; q < nf; ++q) {
+          if (finished[q] || !asm_done[q] || kids_left[q] > 0 || pending[q] >= 0 || next_step[q] >= nsteps[q]) continue;
           const FrontDesc& D = S.fronts[q];
+          const int step = next_step[q]++;
           const int c6 = 6 * D.c, n = 6 * (D.c + D.r), k0 = step * FRONT_NB;
-          if (k0 >= c6) continue;
           const int nb = std::min<int>(FRONT_NB, c6 - k0), kend = k0 + nb;
-          const int ostart = (k0 / FRONT_NBO) * FRONT_NBO;
+          const int ostart = (k0 / FRONT_NBO) * FRONT_NBO, oend = std::min(c6, ostart + FRONT_NBO);
           const int job = (int)S.jobs.size();
           S.jobs.push_back(FrontJob{D.fbase, D.ld, kend, n + 1, ostart, 0, k0, nb, D.wbase + step * FRONT_NB * FRONT_NB});
           const int ntr = (n + 1 - kend + FRONT_TILE - 1) / FRONT_TILE;
           for (int t = 0; t < ntr; ++t) { S.wg_job.push_back(job); S.wg_tile.push_back(t << 16); }
+          // the GEMM this panel is followed by: right-looking update behind a finished outer panel, or the Schur update
+          if (kend >= oend) {
+            int r0, r1, cc0, cc1, kk0, klen;
+            if (oend < c6) { r0 = oend; r1 = n + 1; cc0 = oend; cc1 = c6; kk0 = ostart; klen = oend - ostart; }
+            else { r0 = c6; r1 = n + 1; cc0 = c6; cc1 = n; kk0 = 0; klen = c6; }
+            if (cc1 > cc0) {
+              pending[q] = (int)S.jobs.size();
+              S.jobs.push_back(FrontJob{D.fbase, D.ld, r0, r1, cc0, cc1, kk0, klen, 0});
+            }
+          }
+          if (next_step[q] >= nsteps[q] && pending[q] < 0) { finished[q] = 1; done_now.push_back(q); }
         }
         lp.n_wg = (int)S.wg_job.size() - lp.wg_begin;
-        S.launches.push_back(lp);
-        // GEMM jobs of this step; launches with few 64 x 64 tiles are cut into 32 x 32 tiles instead
-        std::vector<int> gjobs;
+        if (lp.n_wg > 0) S.launches.push_back(lp);
+      }
+      // (3) the pending GEMMs; launches with few 64 x 64 tiles are cut into 32 x 32 tiles instead
+      {
+        gjobs.clear();
         long long tiles64 = 0;
-        for (int q = L.front_begin; q < L.front_end; ++q) {
-          const FrontDesc& D = S.fronts[q];
-          const int c6 = 6 * D.c, n = 6 * (D.c + D.r), k0 = step * FRONT_NB;
-          if (k0 >= c6) continue;
-          const int nb = std::min<int>(FRONT_NB, c6 - k0), kend = k0 + nb;
-          const int ostart = (k0 / FRONT_NBO) * FRONT_NBO, oend = std::min(c6, ostart + FRONT_NBO);
-          if (kend < oend) continue;                    // still inside the outer panel
-          int r0, r1, cc0, cc1, kk0, klen;
-          if (oend < c6) { r0 = oend; r1 = n + 1; cc0 = oend; cc1 = c6; kk0 = ostart; klen = oend - ostart; }
-          else { r0 = c6; r1 = n + 1; cc0 = c6; cc1 = n; kk0 = 0; klen = c6; }
-          if (cc1 <= cc0) continue;
-          gjobs.push_back((int)S.jobs.size());
-          S.jobs.push_back(FrontJob{D.fbase, D.ld, r0, r1, cc0, cc1, kk0, klen, 0});
-          tiles64 += (long long)((r1 - r0 + 63) / 64) * ((cc1 - cc0 + 63) / 64);
+        for (int q = 0; q < nf; ++q) {
+          if (pending[q] < 0) continue;
+          const FrontJob& J = S.jobs[pending[q]];
+          gjobs.push_back(pending[q]);
+          tiles64 += (long long)((J.r1 - J.r0 + 63) / 64) * ((J.c1 - J.c0 + 63) / 64);
+          pending[q] = -1;
+          if (next_step[q] >= nsteps[q]) { finished[q] = 1; done_now.push_back(q); }
         }
         const int T = tiles64 <= tile32_below ? 32 : 64;
         FrontLaunch lg{FrontLaunch::GEMM, 0, T, (int)S.wg_job.size()};
@@ -472,7 +465,55 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
         lg.n_wg = (int)S.wg_job.size() - lg.wg_begin;
         if (lg.n_wg > 0) S.launches.push_back(lg);
       }
-      L.launch_end = (int)S.launches.size();
+      if (done_now.empty() && S.launches.size() > 100000000u) return false;   // (cannot happen: every round advances some front)
+      for (int q : done_now) {
+        ++n_finished;
+        if (S.fronts[q].parent >= 0) --kids_left[S.fronts[q].parent];
+      }
+    }
+  }
+  // backward substitution, root first: a front may start once its parent is done.  Per round: phase A (t = y - L21^T x_r, 64
+  // columns per workgroup) of the fronts that became ready, then one 192-column block step of every front under way (the
+  // block nblk - s updates the chunks below it, the workgroup of chunk nblk - 1 - s then solves that chunk's diagonal block;
+  // step 0 only solves the last chunk).
+  {
+    std::vector<int> st(nf, -1), nblk(nf);       // st: -1 not started, else next block step
+    std::vector<char> fin(nf, 0), parent_done(nf, 0);
+    for (int q = 0; q < nf; ++q) { nblk[q] = (6 * S.fronts[q].c + FRONT_NBO - 1) / FRONT_NBO; parent_done[q] = S.fronts[q].parent < 0; }
+    int n_fin = 0;
+    std::vector<int> done_now;
+    while (n_fin < nf) {
+      done_now.clear();
+      FrontBwdLaunch la{0, (int)S.bwd_front.size(), 0, 0};
+      size_t lds_a = 0;
+      for (int q = 0; q < nf; ++q) {
+        if (st[q] >= 0 || !parent_done[q]) continue;
+        st[q] = 0;
+        for (int ch = 0; ch < (6 * S.fronts[q].c + 63) / 64; ++ch) { S.bwd_front.push_back(q); S.bwd_chunk.push_back(ch); }
+        lds_a = std::max(lds_a, (size_t)(6 * S.fronts[q].r + 512) * sizeof(double));
+      }
+      la.n_wg = (int)S.bwd_front.size() - la.wg_begin;
+      la.lds_bytes = (int)lds_a;
+      if (la.n_wg > 0) S.bwd_launches.push_back(la);
+      FrontBwdLaunch lb{1, (int)S.bwdb_front.size(), 0, 0};
+      for (int q = 0; q < nf; ++q) {
+        if (st[q] < 0 || fin[q]) continue;
+        const int s2 = st[q]++;
+        const int src = nblk[q] - s2, solver = nblk[q] - 1 - s2;
+        for (int ch = 0; ch <= solver; ++ch) {
+          if (s2 == 0 && ch != solver) continue;
+          S.bwdb_front.push_back(q);
+          S.bwdb_chunk.push_back(((s2 == 0 ? solver : src) << 16) | ch);
+        }
+        if (st[q] >= nblk[q]) { fin[q] = 1; done_now.push_back(q); }
+      }
+      lb.n_wg = (int)S.bwdb_front.size() - lb.wg_begin;
+      if (lb.n_wg > 0) S.bwd_launches.push_back(lb);
+      for (int q : done_now) {
+        ++n_fin;
+        for (int ci = S.fronts[q].child_begin; ci < S.fronts[q].child_end; ++ci) parent_done[S.child[ci]] = 1;
+      }
+      if (done_now.empty() && la.n_wg == 0 && lb.n_wg == 0) return false;
     }
   }
   if (S.wg_job.empty()) { S.wg_job.push_back(0); S.wg_tile.push_back(0); }
@@ -480,7 +521,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
   if (S.asm_contrib.empty()) S.asm_contrib.assign(3, 0);
   if (S.bwd_front.empty()) { S.bwd_front.push_back(0); S.bwd_chunk.push_back(0); }
   if (S.bwdb_front.empty()) { S.bwdb_front.push_back(0); S.bwdb_chunk.push_back(0); }
-  S.n_launches = (int)S.launches.size() + 3 * n_levels + 2;
+  S.n_launches = (int)S.launches.size() + (int)S.bwd_launches.size() + 2;
   S.est_us = 4.0 * S.n_launches + flops / 2.0e7;   // ~4 us per dependent launch, ~20 TFLOP/s sustained
   if (getenv("PGO_VERBOSE"))
     std::fprintf(stderr, "[pgo] front: n=%d supernodes %d -> %d fronts, %d levels, %d launches, largest front %d, %.3g flops, %.1f MB, est %.0f us\n",

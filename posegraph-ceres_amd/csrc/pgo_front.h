@@ -54,19 +54,21 @@ struct FrontJob {
 };
 
 struct FrontLaunch {
-  enum Type { PANEL = 0, GEMM = 2 };
+  enum Type { PANEL = 0, ASM = 1, GEMM = 2 };
   int type, n_wg;
   int tile;          // GEMM: rows = columns of a workgroup's tile, 64 or 32 (launches with few tiles)
-  int wg_begin;      // workgroup w of the launch runs job wg_job[wg_begin + w] on tile wg_tile[wg_begin + w] = (ti << 16) | tj
+  int wg_begin;      // PANEL / GEMM: workgroup w runs job wg_job[wg_begin + w] on tile wg_tile[wg_begin + w] = (ti << 16) | tj;
+                     // ASM: workgroup w handles the extend-add tile record wg_begin + w of asm_tile
+};
+
+// backward substitution: phase A (kind 0: workgroup w handles columns 64 * bwd_chunk[wg_begin + w] of front bwd_front[.]) or
+// one block step (kind 1: bwdb_front / bwdb_chunk)
+struct FrontBwdLaunch {
+  int kind, wg_begin, n_wg, lds_bytes;
 };
 
 struct FrontLevel {
-  int front_begin, front_end;     // fronts are numbered level by level
-  int launch_begin, launch_end;
-  int asm_front_begin;            // fronts [asm_front_begin, front_end) have children (sorted last inside the level)
-  int asm_wg_begin, asm_wg;       // extend-add launch: workgroups [asm_wg_begin, +asm_wg) of asm_tile
-  int bwd_wg_begin, bwd_wg;       // backward substitution, phase A: workgroup w handles columns 64 * bwd_chunk[.] of front bwd_front[.]
-  int bwd_step_begin, bwd_steps;  // phase B: steps [bwd_step_begin, +bwd_steps) of bwd_step_ptr (one launch each)
+  int front_begin, front_end;     // fronts are numbered level by level (statistics; the schedule is not per level)
 };
 
 // Per-front descriptor on the device.
@@ -118,10 +120,11 @@ struct FrontSymbolic {
   int n = 0, nf = 0, n_levels = 0;
   std::vector<int> perm, iperm;
   std::vector<FrontDesc> fronts;
-  std::vector<int> idx, child, rel, cstart, col_front, wg_job, wg_tile, asm_tile, asm_contrib, bwd_front, bwd_chunk, bwdb_front, bwdb_chunk, bwd_step_ptr;
+  std::vector<int> idx, child, rel, cstart, col_front, wg_job, wg_tile, asm_tile, asm_contrib, bwd_front, bwd_chunk, bwdb_front, bwdb_chunk;
   std::vector<int> ablk_ptr, ablk_slot, ablk_front, ablk_pos;
   std::vector<FrontJob> jobs;
   std::vector<FrontLaunch> launches;
+  std::vector<FrontBwdLaunch> bwd_launches;
   std::vector<FrontLevel> levels;
   long long fval_size = 0;   // doubles
   long long winv_size = 0;

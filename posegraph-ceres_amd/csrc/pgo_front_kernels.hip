@@ -647,15 +647,12 @@ void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSy
   (void)hipMemsetAsync(p.Fval, 0, (size_t)sym.fval_size * sizeof(double), s);
   const long long nt = (long long)p.n_ablk * 36 + 6LL * p.n;
   hipLaunchKernelGGL(k_front_scatter, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, g, p);
-  for (const FrontLevel& L : sym.levels) {
-    if (L.asm_wg > 0) hipLaunchKernelGGL(k_front_extend_add, dim3(L.asm_wg), dim3(256), 0, s, p, L.asm_wg_begin);
-    for (int li = L.launch_begin; li < L.launch_end; ++li) {
-      const FrontLaunch& La = sym.launches[li];
-      if (La.n_wg <= 0) continue;
-      if (La.type == FrontLaunch::PANEL) hipLaunchKernelGGL(k_front_panel, dim3(La.n_wg), dim3(320), 0, s, p, La.wg_begin, g.flags);
-      else if (La.tile == 32) hipLaunchKernelGGL(k_front_gemm<32>, dim3(La.n_wg), dim3(256), 0, s, p, La.wg_begin);
-      else hipLaunchKernelGGL(k_front_gemm<64>, dim3(La.n_wg), dim3(256), 0, s, p, La.wg_begin);
-    }
+  for (const FrontLaunch& La : sym.launches) {
+    if (La.n_wg <= 0) continue;
+    if (La.type == FrontLaunch::ASM) hipLaunchKernelGGL(k_front_extend_add, dim3(La.n_wg), dim3(256), 0, s, p, La.wg_begin);
+    else if (La.type == FrontLaunch::PANEL) hipLaunchKernelGGL(k_front_panel, dim3(La.n_wg), dim3(320), 0, s, p, La.wg_begin, g.flags);
+    else if (La.tile == 32) hipLaunchKernelGGL(k_front_gemm<32>, dim3(La.n_wg), dim3(256), 0, s, p, La.wg_begin);
+    else hipLaunchKernelGGL(k_front_gemm<64>, dim3(La.n_wg), dim3(256), 0, s, p, La.wg_begin);
   }
 }
 
@@ -665,15 +662,10 @@ void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSym
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_bwd_gemv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     attr_set = true;
   }
-  for (int l = sym.n_levels - 1; l >= 0; --l) {
-    const FrontLevel& L = sym.levels[l];
-    size_t lds_a = 0;
-    for (int q = L.front_begin; q < L.front_end; ++q) lds_a = std::max(lds_a, (size_t)(6 * sym.fronts[q].r + BWD_T) * sizeof(double));
-    if (L.bwd_wg > 0) hipLaunchKernelGGL(k_front_bwd_gemv, dim3(L.bwd_wg), dim3(BWD_T), lds_a, s, p, L.bwd_wg_begin);
-    for (int st = 0; st < L.bwd_steps; ++st) {
-      const int b = sym.bwd_step_ptr[L.bwd_step_begin + st], e = sym.bwd_step_ptr[L.bwd_step_begin + st + 1];
-      if (e > b) hipLaunchKernelGGL(k_front_bwd_block, dim3(e - b), dim3(BWD_T), 0, s, g, p, b);
-    }
+  for (const FrontBwdLaunch& La : sym.bwd_launches) {
+    if (La.n_wg <= 0) continue;
+    if (La.kind == 0) hipLaunchKernelGGL(k_front_bwd_gemv, dim3(La.n_wg), dim3(BWD_T), (size_t)La.lds_bytes, s, p, La.wg_begin);
+    else hipLaunchKernelGGL(k_front_bwd_block, dim3(La.n_wg), dim3(BWD_T), 0, s, g, p, La.wg_begin);
   }
 }
 

@@ -43,13 +43,9 @@ int main(int argc, char** argv) {
               S.nf, S.n_levels, S.n_launches, S.jobs.size(), S.max_front, S.flops, 8e-6 * (double)S.fval_size, S.factor_blocks);
   if (!ok) return 1;
   if (argc > 2) {
-    for (int l = 0; l < S.n_levels; ++l) {
-      const FrontLevel& L = S.levels[l];
-      int mc = 0, mr = 0;
-      for (int q = L.front_begin; q < L.front_end; ++q) { mc = std::max(mc, S.fronts[q].c); mr = std::max(mr, S.fronts[q].r); }
-      std::printf("level %d fronts %d (with children %d) launches %d max c %d max r %d asm_wg %d\n", l, L.front_end - L.front_begin,
-                  L.front_end - L.asm_front_begin, L.launch_end - L.launch_begin, mc, mr, L.asm_wg);
-    }
+    int np = 0, ng = 0, na = 0;
+    for (const FrontLaunch& La : S.launches) { np += La.type == FrontLaunch::PANEL; ng += La.type == FrontLaunch::GEMM; na += La.type == FrontLaunch::ASM; }
+    std::printf("factor launches: %d panel, %d gemm, %d extend-add; backward launches: %zu\n", np, ng, na, S.bwd_launches.size());
     if (argv[2][0] == 's') return 0;
   }
   // random SPD matrix in slot form: off-diagonal blocks random, diagonal = strictly dominant
@@ -90,28 +86,35 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 6; ++k) F[D.fbase + (size_t)n * D.ld + 6 * (j - D.first) + k] = b[6 * (size_t)S.perm[j] + k];
   }
   bool bad_pivot = false;
-  for (int l = 0; l < S.n_levels; ++l) {
-    const FrontLevel& L = S.levels[l];
-    // extend-add (children in list order)
-    for (int q = L.asm_front_begin; q < L.front_end; ++q) {
-      const FrontDesc& P = S.fronts[q];
-      const int np = 6 * (P.c + P.r);
-      for (int ci = P.child_begin; ci < P.child_end; ++ci) {
-        const FrontDesc& C = S.fronts[S.child[ci]];
-        const int nc = 6 * (C.c + C.r);
-        const int* rel = &S.rel[C.rel_begin];
-        for (int k = 0; k <= C.r; ++k) {          // k == C.r: the right-hand side row
-          const int prow = k < C.r ? 6 * rel[k] : np;
-          const int crow = k < C.r ? 6 * (C.c + k) : nc;
-          const int nr = k < C.r ? 6 : 1;
-          for (int m = 0; m <= std::min(k, C.r - 1); ++m)
-            for (int a = 0; a < nr; ++a) for (int bb = 0; bb < 6; ++bb)
-              F[P.fbase + (size_t)(prow + a) * P.ld + 6 * rel[m] + bb] += F[C.fbase + (size_t)(crow + a) * C.ld + 6 * (C.c + m) + bb];
-        }
-      }
-    }
-    for (int li = L.launch_begin; li < L.launch_end; ++li) {
+  {
+    for (size_t li = 0; li < S.launches.size(); ++li) {
       const FrontLaunch& La = S.launches[li];
+      if (La.type == FrontLaunch::ASM) {
+        // extend-add (children in list order) of every parent front named by the launch's tile records
+        int prevq = -1;
+        for (int w = La.wg_begin; w < La.wg_begin + La.n_wg; ++w) {
+          const int q = S.asm_tile[4 * (size_t)w];
+          if (q == prevq) continue;
+          prevq = q;
+          const FrontDesc& P = S.fronts[q];
+          const int np = 6 * (P.c + P.r);
+          for (int ci = P.child_begin; ci < P.child_end; ++ci) {
+            const FrontDesc& C = S.fronts[S.child[ci]];
+            const int nc = 6 * (C.c + C.r);
+            const int* rel = &S.rel[C.rel_begin];
+            for (int k = 0; k <= C.r; ++k) {          // k == C.r: the right-hand side row
+              const int prow = k < C.r ? 6 * rel[k] : np;
+              const int crow = k < C.r ? 6 * (C.c + k) : nc;
+              const int nr = k < C.r ? 6 : 1;
+              for (int m = 0; m <= std::min(k, C.r - 1); ++m)
+                for (int a = 0; a < nr; ++a) for (int bb = 0; bb < 6; ++bb)
+                  F[P.fbase + (size_t)(prow + a) * P.ld + 6 * rel[m] + bb] += F[C.fbase + (size_t)(crow + a) * C.ld + 6 * (C.c + m) + bb];
+            }
+          }
+        }
+        continue;
+      }
+
       // the jobs of a launch = the distinct entries of its workgroup -> job map (consecutive)
       int prev = -1;
       for (int w = La.wg_begin; w < La.wg_begin + La.n_wg; ++w) {
@@ -174,9 +177,15 @@ int main(int argc, char** argv) {
     }
   }
   // backward substitution, top level first
-  for (int l = S.n_levels - 1; l >= 0; --l) {
-    const FrontLevel& L = S.levels[l];
-    for (int q = L.front_begin; q < L.front_end; ++q) {
+  // (order of the device schedule: bwd_launches; numerically any parent-before-child order gives the same x)
+  {
+    std::vector<int> order_b;
+    std::vector<char> seen(S.nf, 0);
+    for (const FrontBwdLaunch& La : S.bwd_launches)
+      if (La.kind == 0) for (int w = La.wg_begin; w < La.wg_begin + La.n_wg; ++w) if (!seen[S.bwd_front[w]]) { seen[S.bwd_front[w]] = 1; order_b.push_back(S.bwd_front[w]); }
+    if ((int)order_b.size() != S.nf) { std::printf("backward schedule covers %zu of %d fronts\n", order_b.size(), S.nf); return 1; }
+    for (int q : order_b) {
+      if (S.fronts[q].parent >= 0 && !seen[S.fronts[q].parent]) { std::printf("child before parent\n"); return 1; }
       const FrontDesc& D = S.fronts[q];
       const int c6 = 6 * D.c, n = 6 * (D.c + D.r);
       const double* A = &F[D.fbase];
