@@ -372,7 +372,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
       // (1) extend-add of every front whose children are all done: one workgroup per parent tile (8 x 8 poses, or the
       // right-hand-side row x 8 poses) that receives anything, with the list of contributing children (list order)
       {
-        FrontLaunch la{FrontLaunch::ASM, 0, 0, (int)(S.asm_tile.size() / 4)};
+        FrontLaunch la{FrontLaunch::ASM, 0, 0, (int)(S.asm_tile.size() / 8)};
         for (int q = 0; q < nf; ++q) {
           if (asm_done[q] || kids_left[q] > 0) continue;
           asm_done[q] = 1;
@@ -397,15 +397,30 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
           for (size_t e = 0; e < recs.size();) {
             size_t f2 = e;
             while (f2 < recs.size() && (recs[f2].key >> 20) == (recs[e].key >> 20)) ++f2;
+            // records carry everything the kernel needs of the parent / child fronts (one dependent load each, not three)
             S.asm_tile.push_back(q);
             S.asm_tile.push_back((int)(((recs[e].key >> 40) << 16) | ((recs[e].key >> 20) & 0xfffff)));
-            S.asm_tile.push_back((int)(S.asm_contrib.size() / 3));
-            for (size_t u = e; u < f2; ++u) { S.asm_contrib.push_back(recs[u].child); S.asm_contrib.push_back(recs[u].kk); S.asm_contrib.push_back(recs[u].mm); }
-            S.asm_tile.push_back((int)(S.asm_contrib.size() / 3));
+            S.asm_tile.push_back((int)(S.asm_contrib.size() / 8));
+            for (size_t u = e; u < f2; ++u) {
+              const FrontDesc& C = S.fronts[recs[u].child];
+              S.asm_contrib.push_back((int)(C.fbase & 0xffffffffLL));
+              S.asm_contrib.push_back((int)(C.fbase >> 32));
+              S.asm_contrib.push_back(C.ld);
+              S.asm_contrib.push_back(C.c);
+              S.asm_contrib.push_back(recs[u].kk);
+              S.asm_contrib.push_back(recs[u].mm);
+              S.asm_contrib.push_back(C.rel_begin);
+              S.asm_contrib.push_back(C.r);
+            }
+            S.asm_tile.push_back((int)(S.asm_contrib.size() / 8));
+            S.asm_tile.push_back((int)(P.fbase & 0xffffffffLL));
+            S.asm_tile.push_back((int)(P.fbase >> 32));
+            S.asm_tile.push_back(P.ld);
+            S.asm_tile.push_back(6 * (P.c + P.r) | (P.ntp << 20));
             e = f2;
           }
         }
-        la.n_wg = (int)(S.asm_tile.size() / 4) - la.wg_begin;
+        la.n_wg = (int)(S.asm_tile.size() / 8) - la.wg_begin;
         if (la.n_wg > 0) S.launches.push_back(la);
       }
       // (2) the next 48-column panel of every front that is assembled and not waiting for a GEMM
@@ -517,8 +532,8 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
     }
   }
   if (S.wg_job.empty()) { S.wg_job.push_back(0); S.wg_tile.push_back(0); }
-  if (S.asm_tile.empty()) S.asm_tile.assign(4, 0);
-  if (S.asm_contrib.empty()) S.asm_contrib.assign(3, 0);
+  if (S.asm_tile.empty()) S.asm_tile.assign(8, 0);
+  if (S.asm_contrib.empty()) S.asm_contrib.assign(8, 0);
   if (S.bwd_front.empty()) { S.bwd_front.push_back(0); S.bwd_chunk.push_back(0); }
   if (S.bwdb_front.empty()) { S.bwdb_front.push_back(0); S.bwdb_chunk.push_back(0); }
   S.n_launches = (int)S.launches.size() + (int)S.bwd_launches.size() + 2;

@@ -105,8 +105,10 @@ struct FrontPlan {
   const FrontJob* jobs;
   const int* wg_job;
   const int* wg_tile;
-  const int* asm_tile;      // extend-add workgroups, 4 ints each: parent front, (ti << 16) | tj, first / end contributor
-  const int* asm_contrib;   // contributors, 3 ints each: child front, (ks << 16) | ke, (ms << 16) | me (child update rows)
+  const int* asm_tile;      // extend-add workgroups, 8 ints each: parent front, (ti << 16) | tj, first / end contributor, parent fbase lo / hi,
+                            // parent ld, parent size (scalars) | ntp << 20
+  const int* asm_contrib;   // contributors, 8 ints each: child fbase lo / hi, ld, c, (ks << 16) | ke, (ms << 16) | me (child update rows),
+                            // rel_begin, r
   const int* bwd_front;
   const int* bwd_chunk;
   const int* bwdb_front;    // phase B workgroups: front ...

@@ -107,42 +107,43 @@ constexpr int ASM_T = 6 * FRONT_ASM_TP;   // 48 scalars per tile side
 
 __global__ __launch_bounds__(256) void k_front_extend_add(FrontPlan p, int wg_begin) {
   __shared__ double acc[ASM_T][ASM_T + 1];
-  const int* rec = p.asm_tile + 4 * (size_t)(wg_begin + blockIdx.x);
-  const FrontDesc P = p.fronts[rec[0]];
+  const int* rec = p.asm_tile + 8 * (size_t)(wg_begin + blockIdx.x);
   const int ti = rec[1] >> 16, tj = rec[1] & 0xffff, cb = rec[2], ce = rec[3];
-  const bool rhs_tile = ti == P.ntp;
+  const long long pbase = ((long long)rec[5] << 32) | (unsigned)rec[4];
+  const int pld = rec[6], np = rec[7] & 0xfffff, ntp = rec[7] >> 20;
+  const bool rhs_tile = ti == ntp;
   const int tid = threadIdx.x;
   for (int e = tid; e < ASM_T * (ASM_T + 1); e += 256) (&acc[0][0])[e] = 0.0;
   __syncthreads();
-  const int np = 6 * (P.c + P.r);
   for (int ci = cb; ci < ce; ++ci) {
-    const int* cr = p.asm_contrib + 3 * (size_t)ci;
-    const FrontDesc C = p.fronts[cr[0]];
-    const int ks = cr[1] >> 16, ke = cr[1] & 0xffff, ms = cr[2] >> 16, me = cr[2] & 0xffff;
-    const int* rel = p.rel + C.rel_begin;
+    const int* cr = p.asm_contrib + 8 * (size_t)ci;
+    const long long cbase = ((long long)cr[1] << 32) | (unsigned)cr[0];
+    const int cld = cr[2], cc = cr[3], cr_rows = cr[7];
+    const int ks = cr[4] >> 16, ke = cr[4] & 0xffff, ms = cr[5] >> 16, me = cr[5] & 0xffff;
+    const int* rel = p.rel + cr[6];
     const int nrow = rhs_tile ? 1 : 6 * (ke - ks), ncol = 6 * (me - ms);
-    const double* Fc = p.Fval + C.fbase;
+    const double* Fc = p.Fval + cbase;
     for (int e = tid; e < nrow * ncol; e += 256) {
       const int lr = e / ncol, lc = e - lr * ncol;
       const int m = ms + lc / 6, b = lc % 6;
       int srow, drow;
-      if (rhs_tile) { srow = 6 * (C.c + C.r); drow = 0; }
+      if (rhs_tile) { srow = 6 * (cc + cr_rows); drow = 0; }
       else {
         const int k = ks + lr / 6, a = lr % 6;
         if (k < m) continue;
-        srow = 6 * (C.c + k) + a;
+        srow = 6 * (cc + k) + a;
         drow = 6 * (rel[k] - FRONT_ASM_TP * ti) + a;
       }
-      acc[drow][6 * (rel[m] - FRONT_ASM_TP * tj) + b] += Fc[(size_t)srow * C.ld + 6 * (C.c + m) + b];
+      acc[drow][6 * (rel[m] - FRONT_ASM_TP * tj) + b] += Fc[(size_t)srow * cld + 6 * (cc + m) + b];
     }
     __syncthreads();
   }
-  double* Fp = p.Fval + P.fbase;
+  double* Fp = p.Fval + pbase;
   const int row0 = rhs_tile ? np : ASM_T * ti, col0 = ASM_T * tj;
   const int nrow = rhs_tile ? 1 : min(ASM_T, np - row0), ncol = min(ASM_T, np - col0);
   for (int e = tid; e < nrow * ASM_T; e += 256) {
     const int lr = e / ASM_T, lc = e - lr * ASM_T;
-    if (lc < ncol) Fp[(size_t)(row0 + lr) * P.ld + col0 + lc] += acc[lr][lc];
+    if (lc < ncol) Fp[(size_t)(row0 + lr) * pld + col0 + lc] += acc[lr][lc];
   }
 }
 

@@ -93,7 +93,7 @@ int main(int argc, char** argv) {
         // extend-add (children in list order) of every parent front named by the launch's tile records
         int prevq = -1;
         for (int w = La.wg_begin; w < La.wg_begin + La.n_wg; ++w) {
-          const int q = S.asm_tile[4 * (size_t)w];
+          const int q = S.asm_tile[8 * (size_t)w];
           if (q == prevq) continue;
           prevq = q;
           const FrontDesc& P = S.fronts[q];
