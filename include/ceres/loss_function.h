@@ -71,5 +71,20 @@ class ArctanLoss : public LossFunction {
  private:
   const double a_, b_;
 };
+// Not a Ceres class: the switchable-constraint edge of Suenderhauf & Protzel with its switch variable eliminated in closed
+// form, rho(s) = Phi s / (Phi + s) (PGO_LOSS_SWITCHABLE, include/pgo.h).  Offered through the same LossFunction interface.
+class SwitchableConstraintLoss : public LossFunction {
+ public:
+  explicit SwitchableConstraintLoss(double phi) : a_(phi) {}
+  virtual void Evaluate(double s, double rho[3]) const {
+    const double q = a_ / (a_ + s);
+    rho[0] = s * q;
+    rho[1] = std::max(std::numeric_limits<double>::min(), q * q);
+    rho[2] = -2.0 * q * q / (a_ + s);
+  }
+  double a() const { return a_; }
+ private:
+  const double a_;
+};
 }  // namespace ceres
 #endif

@@ -313,6 +313,7 @@ inline int LossKind(const LossFunction* loss, double* a) {
   if (const SoftLOneLoss* h = dynamic_cast<const SoftLOneLoss*>(loss)) { *a = h->a(); return PGO_LOSS_SOFT_L_ONE; }
   if (const CauchyLoss* h = dynamic_cast<const CauchyLoss*>(loss)) { *a = h->a(); return PGO_LOSS_CAUCHY; }
   if (const ArctanLoss* h = dynamic_cast<const ArctanLoss*>(loss)) { *a = h->a(); return PGO_LOSS_ARCTAN; }
+  if (const SwitchableConstraintLoss* h = dynamic_cast<const SwitchableConstraintLoss*>(loss)) { *a = h->a(); return PGO_LOSS_SWITCHABLE; }
   if (dynamic_cast<const TrivialLoss*>(loss)) return PGO_LOSS_TRIVIAL;
   return -1;
 }

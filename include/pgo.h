@@ -40,7 +40,12 @@ typedef enum pgo_status {
 /* ceres::LossFunction kinds (REF/test/pose_graph_ceres_plus_finial.cpp:495 uses HuberLoss(1.0)). */
 typedef enum pgo_loss_kind {
   PGO_LOSS_TRIVIAL = 0, PGO_LOSS_HUBER = 1,          /* the reference's */
-  PGO_LOSS_SOFT_L_ONE = 2, PGO_LOSS_CAUCHY = 3, PGO_LOSS_ARCTAN = 4   /* other Ceres 1.13 losses with rho'' <= 0 */
+  PGO_LOSS_SOFT_L_ONE = 2, PGO_LOSS_CAUCHY = 3, PGO_LOSS_ARCTAN = 4,  /* other Ceres 1.13 losses with rho'' <= 0 */
+  /* Switchable constraint (Suenderhauf & Protzel) in closed form: the edge cost min_w [ w^2 s + Phi (1 - w)^2 ] over its
+   * switch variable w has w* = Phi / (Phi + s), i.e. the robust kernel rho(s) = Phi s / (Phi + s) (rho' = (Phi / (Phi + s))^2
+   * = w*^2, rho'' < 0), so loop-closure rejection needs no extra parameter block and no 7th row in the 6x6 BSR; loss_a = Phi
+   * (SURVEY.md section 8f rank 3).  Same corrector branch as the Ceres kinds above (alpha = 0). */
+  PGO_LOSS_SWITCHABLE = 5
 } pgo_loss_kind;
 
 /* ceres::LinearSolverType values the path understands (finial.cpp:536 sets SPARSE_NORMAL_CHOLESKY). */

@@ -328,6 +328,13 @@ void loss_eval(int kind, double a, double s, double rho[3]) {
     rho[2] = -2.0 * s * b * (inv * inv);
     return;
   }
+  else if (kind == 5 && a > 0) {   // switchable constraint, switch eliminated: rho = Phi s / (Phi + s), Phi = a (include/pgo.h)
+    const double q = a / (a + s);
+    rho[0] = s * q;
+    rho[1] = std::max(tiny, q * q);
+    rho[2] = -2.0 * q * q / (a + s);
+    return;
+  }
   rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
 }
 

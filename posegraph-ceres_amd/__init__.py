@@ -24,7 +24,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpgo_hip.so")
 
-TRIVIAL, HUBER, SOFT_L_ONE, CAUCHY, ARCTAN = 0, 1, 2, 3, 4
+TRIVIAL, HUBER, SOFT_L_ONE, CAUCHY, ARCTAN, SWITCHABLE = 0, 1, 2, 3, 4, 5
 SPARSE_NORMAL_CHOLESKY, BLOCK_JACOBI_PCG = 0, 1
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 TERMINATION_NAMES = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE"}

@@ -189,6 +189,13 @@ PGO_HD void loss_eval(int kind, double a, double s, double* rho0, double* rho1) 
     *rho1 = inv > tiny ? inv : tiny;
     return;
   }
+  else if (kind == 5) {                  // switchable constraint with the switch eliminated (a = Phi), see include/pgo.h
+    const double q = a / (a + s);
+    *rho0 = s * q;
+    const double w = q * q;
+    *rho1 = w > tiny ? w : tiny;
+    return;
+  }
   *rho0 = s;
   *rho1 = 1.0;
 }

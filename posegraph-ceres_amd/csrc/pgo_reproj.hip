@@ -361,7 +361,7 @@ extern "C" int pgo_reproj_solve_batch(int n_problems, const long long* point_ptr
                                       pgo_reproj_summary* summaries, double* kernel_ms) {
   if (n_problems < 0 || !point_ptr || !intrinsics || !q || !t || !options)
     return pgo_candidates_set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_reproj_solve_batch");
-  if (options->loss_kind < PGO_LOSS_TRIVIAL || options->loss_kind > PGO_LOSS_ARCTAN || (options->loss_kind != PGO_LOSS_TRIVIAL && !(options->loss_a > 0.0)))
+  if (options->loss_kind < PGO_LOSS_TRIVIAL || options->loss_kind > PGO_LOSS_SWITCHABLE || (options->loss_kind != PGO_LOSS_TRIVIAL && !(options->loss_a > 0.0)))
     return pgo_candidates_set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_reproj_solve_batch: bad loss");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {

@@ -1466,7 +1466,7 @@ int pgo_problem_add_se3_between(pgo_problem* P, int pose_begin, int pose_end, co
 
 int pgo_problem_set_loss(pgo_problem* P, int kind, double a) {
   if (!P) return set_error(PGO_ERR_INVALID_ARGUMENT, "null problem");
-  if (kind < PGO_LOSS_TRIVIAL || kind > PGO_LOSS_ARCTAN) return set_error(PGO_ERR_UNSUPPORTED, "unknown loss kind %d", kind);
+  if (kind < PGO_LOSS_TRIVIAL || kind > PGO_LOSS_SWITCHABLE) return set_error(PGO_ERR_UNSUPPORTED, "unknown loss kind %d", kind);
   if (kind != PGO_LOSS_TRIVIAL && !(a > 0.0)) return set_error(PGO_ERR_INVALID_ARGUMENT, "loss scale must be positive");
   P->loss_kind = kind;
   P->loss_a = a;

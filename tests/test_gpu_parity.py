@@ -227,9 +227,9 @@ def test_cluster_jacobi_pcg_matches_oracle(gpu, O, ds, cluster):
     assert s.final_cost == pytest.approx(osum.final_cost, rel=1e-5)
 
 
-@pytest.mark.parametrize("kind,a", [(2, 1.3), (3, 0.8), (4, 2.0)])
+@pytest.mark.parametrize("kind,a", [(2, 1.3), (3, 0.8), (4, 2.0), (5, 5.0)])
 def test_other_ceres_losses(gpu, O, ds, kind, a):
-    """SoftLOne / Cauchy / Arctan: evaluation and LM trace against the oracle."""
+    """SoftLOne / Cauchy / Arctan / switchable constraint in closed form: evaluation and LM trace against the oracle."""
     g = _random_graph(ds, 150, 600, seed=21, info="diag")
     prob, poses, og = _pair(gpu, O, g, loss=kind, loss_a=a)
     cost, r, ja, jb, grad = prob.evaluate()

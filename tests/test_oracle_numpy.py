@@ -40,6 +40,19 @@ def test_autodiff_chain_equals_closed_form_also_off_the_sphere(O):
         assert np.abs(r1 - r2).max() < 1e-12 and np.abs(a1 - a2).max() < 1e-11 and np.abs(b1 - b2).max() < 1e-11
 
 
+def test_switchable_constraint_loss_is_the_eliminated_switch(O):
+    """PGO_LOSS_SWITCHABLE: rho(s) = min_w [w^2 s + Phi (1 - w)^2] with w* = Phi / (Phi + s); rho' = w*^2 = d rho / d s."""
+    for phi in (0.5, 5.0):
+        for s in (0.0, 0.3, 2.0, 50.0):
+            rho = O.loss(5, phi, s)
+            w = np.linspace(0.0, 1.0, 200001)
+            assert rho[0] == pytest.approx((w * w * s + phi * (1 - w) ** 2).min(), abs=1e-9)
+            assert rho[1] == pytest.approx((phi / (phi + s)) ** 2, rel=1e-14)
+            h = 1e-6 * max(1.0, s)
+            assert rho[1] == pytest.approx((O.loss(5, phi, s + h)[0] - O.loss(5, phi, max(0.0, s - h))[0]) / (h + min(h, s)), rel=1e-5)
+            assert rho[2] < 0.0
+
+
 def test_huber_and_plus(O):
     for s in [0.0, 0.5, 1.0, 1.5, 100.0]:
         rho = O.loss(1, 1.0, s)
