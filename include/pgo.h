@@ -189,6 +189,22 @@ void pgo_solver_options_init(pgo_solver_options* options);
 int pgo_solve(pgo_problem* problem, const pgo_solver_options* options, pgo_solver_summary* summary,
               pgo_iteration_record* records, int records_capacity);
 /* Summary::IsSolutionUsable (finial.cpp:543) */
+/* Device memory of destroyed problems is kept in a process-wide pool and reused by later problems (hipFree synchronises the
+ * device: tearing a problem down the blocking way costs as much as a KITTI-scale solve).  This call returns the pooled blocks
+ * to the driver; PGO_POOL_MAX_GB bounds the pool (default 16 GB, 0 = no pooling). */
+int pgo_release_device_memory(void);
+
+/* Several INDEPENDENT problems solved together on one GPU (KITTI-scale graphs leave the machine idle: an LM iteration is a
+ * chain of small dependent launches).  The problems become the components of one block-diagonal problem — one launch
+ * sequence, n times the work per launch — while everything ceres::Solve decides stays per problem: trust-region radius,
+ * accept / reject, every termination test (finial.cpp:534-543 per problem), iteration records, summary.  Each problem follows
+ * the trace it follows through pgo_solve (to rounding).  Requirements: linear_solver_type PGO_SPARSE_NORMAL_CHOLESKY (the
+ * reference's), one loss function shared by all problems, no communicator attached.  summaries: [n_problems];
+ * records: [n_problems][capacity] or NULL.  total/setup times in the summaries are those of the whole batch.  Poses are
+ * updated in caller memory exactly as by pgo_solve.  GPU only. */
+int pgo_solve_batch(pgo_problem* const* problems, int n_problems, const pgo_solver_options* options, pgo_solver_summary* summaries,
+                    pgo_iteration_record* records, int capacity);
+
 int pgo_summary_is_solution_usable(const pgo_solver_summary* summary);
 /* Summary::FullReport (finial.cpp:541): writes a NUL-terminated report, returns the length needed */
 size_t pgo_summary_full_report(const pgo_solver_summary* summary, const pgo_iteration_record* records,

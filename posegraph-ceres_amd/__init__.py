@@ -43,6 +43,7 @@ C_ABI_SYMBOLS = [
     "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_loopback_create", "pgo_loopback_destroy", "pgo_comm_init_loopback",
     "pgo_generate_candidates", "pgo_reproj_options_init", "pgo_reproj_solve_batch",
     "pgo_row_shard_range", "pgo_read_trajectory", "pgo_build_odometry_edges", "pgo_edge_rules_init", "pgo_build_edges",
+    "pgo_solve_batch", "pgo_release_device_memory",
 ]
 
 
@@ -488,6 +489,27 @@ def solve(options, problem, records_capacity=4096):
     _check(lib().pgo_solve(problem._h, C.byref(options.c), C.byref(s), rec, C.c_int(records_capacity)))
     n = min(s.num_iterations, records_capacity)
     return Summary(s, np.frombuffer(bytes(rec), dtype=RECORD_DTYPE)[:n].copy())
+
+
+def release_device_memory():
+    """Return the device blocks pooled from destroyed problems to the driver."""
+    _check(lib().pgo_release_device_memory())
+
+
+def solve_batch(options, problems, records_capacity=256):
+    """pgo_solve_batch: several independent problems as the components of one block-diagonal problem, every LM decision per
+    problem.  Returns one Summary per problem; every problem's pose array is updated in place."""
+    n = len(problems)
+    handles = (C.c_void_p * n)(*[p._h.value for p in problems])
+    sums = (_CSummary * n)()
+    rec = (_CRecord * (n * records_capacity))()
+    _check(lib().pgo_solve_batch(handles, C.c_int(n), C.byref(options.c), sums, rec, C.c_int(records_capacity)))
+    allrec = np.frombuffer(rec, dtype=RECORD_DTYPE).reshape(n, records_capacity)
+    out = []
+    for c in range(n):
+        s = _CSummary.from_buffer_copy(sums[c])
+        out.append(Summary(s, allrec[c, :min(s.num_iterations, records_capacity)].copy()))
+    return out
 
 
 def problem_from_graph(g, loss=HUBER, loss_a=1.0, constant_first=True):

@@ -12,9 +12,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <memory>
 #include <numeric>
 #include <thread>
 
@@ -178,14 +180,86 @@ struct Dissector {
 
 }  // namespace
 
+// Connected components (vertices of a component in ascending order, components by their smallest vertex).
+struct Components {
+  std::vector<int> ptr, verts, of;
+  int count() const { return (int)ptr.size() - 1; }
+};
+static Components find_components(const Csr& g) {
+  const int N = (int)g.ptr.size() - 1;
+  Components C;
+  C.of.assign(N, -1);
+  std::vector<int> queue;
+  int nc = 0;
+  for (int v0 = 0; v0 < N; ++v0) {
+    if (C.of[v0] >= 0) continue;
+    queue.assign(1, v0);
+    C.of[v0] = nc;
+    for (size_t h = 0; h < queue.size(); ++h) {
+      const int v = queue[h];
+      for (int p = g.ptr[v]; p < g.ptr[v + 1]; ++p) {
+        const int u = g.idx[p];
+        if (C.of[u] < 0) { C.of[u] = nc; queue.push_back(u); }
+      }
+    }
+    ++nc;
+  }
+  C.ptr.assign(nc + 1, 0);
+  for (int v = 0; v < N; ++v) ++C.ptr[C.of[v] + 1];
+  for (int c = 0; c < nc; ++c) C.ptr[c + 1] += C.ptr[c];
+  C.verts.resize(N);
+  std::vector<int> fill(C.ptr.begin(), C.ptr.end() - 1);
+  for (int v = 0; v < N; ++v) C.verts[fill[C.of[v]]++] = v;
+  return C;
+}
+
+static int component_workers(const Components& C) {
+  static const int cap = getenv("PGO_ANALYSIS_THREADS") ? std::max(1, atoi(getenv("PGO_ANALYSIS_THREADS"))) : 16;
+  return std::max(1, std::min(std::min(C.count(), cap), (int)std::thread::hardware_concurrency()));
+}
+
+// body(component, worker index) for every component, on up to 16 host threads when there are several components (the
+// graphs of a batched solve, pgo_solve_batch); one component = the calling thread, no thread is started.
+template <class Body>
+static void for_components(const Components& C, Body&& body) {
+  const int nc = C.count();
+  const int nt = component_workers(C);
+  if (nt <= 1) { for (int c = 0; c < nc; ++c) body(c, 0); return; }
+  std::atomic<int> next(0);
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t]() {
+      for (;;) {
+        const int c = next.fetch_add(1);
+        if (c >= nc) return;
+        body(c, t);
+      }
+    });
+  for (std::thread& t : th) t.join();
+}
+
+// Nested dissection of every component on its own (a component gets the order it gets as a graph of its own), components
+// one after the other in the permutation.
+static bool order_components(const Csr& g, const Components& C, std::vector<int>* perm) {
+  const int N = (int)g.ptr.size() - 1;
+  perm->assign(N, -1);
+  std::vector<std::unique_ptr<Dissector>> workers(component_workers(C));
+  std::atomic<bool> ok(true);
+  for_components(C, [&](int c, int w) {
+    if (!workers[w]) workers[w].reset(new Dissector(g));
+    Dissector& d = *workers[w];
+    d.run(std::vector<int>(C.verts.begin() + C.ptr[c], C.verts.begin() + C.ptr[c + 1]));
+    if ((int)d.order.size() != C.ptr[c + 1] - C.ptr[c]) { ok = false; return; }
+    std::copy(d.order.begin(), d.order.end(), perm->begin() + C.ptr[c]);
+  });
+  return ok;
+}
+
 bool nested_dissection_order(int N, const std::vector<int>& ia, const std::vector<int>& ib, std::vector<int>* perm) {
   const Csr g = build_adjacency(N, ia, ib);
-  Dissector d(g);
-  std::vector<int> all(N);
-  std::iota(all.begin(), all.end(), 0);
-  d.run(std::move(all));
-  *perm = d.order;
-  return (int)perm->size() == N;
+  const Components C = find_components(g);
+  return order_components(g, C, perm) && (int)perm->size() == N;
 }
 
 bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib, int n_slots,
@@ -195,57 +269,89 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   DirectSymbolic& S = *out;
   S = DirectSymbolic();
   S.n = N;
+  const bool verbose = getenv("PGO_VERBOSE") != nullptr;
+  auto t_phase = std::chrono::steady_clock::now();
+  auto phase = [&](const char* what) {
+    if (!verbose) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[pgo] direct analysis: %-28s %.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_phase).count());
+    t_phase = now;
+  };
   const Csr g = build_adjacency(N, ia, ib);
+  phase("adjacency");
 
-  // ---- 1. ordering ----
-  {
-    Dissector d(g);
-    std::vector<int> all(N);
-    std::iota(all.begin(), all.end(), 0);
-    d.run(std::move(all));
-    S.perm = d.order;
-    if ((int)S.perm.size() != N) return false;
-  }
+  // ---- 1. ordering: nested dissection per connected component ----
+  const Components comps = find_components(g);
+  if (!order_components(g, comps, &S.perm)) return false;
   S.iperm.assign(N, -1);
   for (int k = 0; k < N; ++k) S.iperm[S.perm[k]] = k;
+  phase("nested dissection");
 
   static const long long max_pairs = getenv("PGO_DIRECT_MAX_PAIRS") ? atoll(getenv("PGO_DIRECT_MAX_PAIRS")) : 16000000LL;
   // ---- 2. symbolic factorisation ----
-  std::vector<std::vector<int>> st(N);   // struct(j): rows > j, sorted
-  std::vector<int> parent(N, -1);
-  std::vector<std::vector<int>> children(N);
-  std::vector<int> mark(N, -1), tmp;
+  // struct(j) = rows > j of column j, sorted: the neighbours of j plus the structures of its etree children.  Flat storage
+  // (st_ptr / st_idx), children as sibling lists; a component's columns are a contiguous range of the new numbering and
+  // touch nothing outside it, so the components of a batched solve are processed side by side.
+  std::vector<int> parent(N, -1), first_child(N, -1), next_sibling(N, -1), mark(N, -1);
+  std::vector<int> st_ptr(N + 1, 0), st_idx;
   long long nb = 0, pairs = 0;
-  for (int j = 0; j < N; ++j) {
-    tmp.clear();
-    mark[j] = j;
-    const int old = S.perm[j];
-    for (int p = g.ptr[old]; p < g.ptr[old + 1]; ++p) {
-      const int i = S.iperm[g.idx[p]];
-      if (i > j && mark[i] != j) { mark[i] = j; tmp.push_back(i); }
-    }
-    for (int c : children[j])
-      for (int i : st[c]) if (i > j && mark[i] != j) { mark[i] = j; tmp.push_back(i); }
-    std::sort(tmp.begin(), tmp.end());
-    st[j] = tmp;
-    if (!tmp.empty()) { parent[j] = tmp[0]; children[tmp[0]].push_back(j); }
-    nb += 1 + (long long)tmp.size();
-    pairs += (long long)tmp.size() * ((long long)tmp.size() + 1) / 2;
-    // too much fill for the enumerated schedule.  The gate below accepts ~7000 critical-path steps (Manhattan 10 k: 6.4 M
-    // pairs = 9.5 k steps, rejected; KITTI-00 dense: 1.2 M pairs, accepted): a graph past this budget is going to be
-    // rejected anyway, so stop before the pair lists (seconds of host time and GBs) are built.
+  {
+    const int ncomp = comps.count();
+    std::vector<std::vector<int>> comp_idx(ncomp);          // struct entries of each component, columns in order
+    std::vector<long long> comp_nb(ncomp, 0), comp_pairs(ncomp, 0);
+    std::atomic<bool> too_big(false);
+    for_components(comps, [&](int c, int) {
+      const int j0 = comps.ptr[c], j1 = comps.ptr[c + 1];
+      std::vector<int>& idx = comp_idx[c];
+      std::vector<int> tmp, lptr(j1 - j0 + 1, 0);            // lptr: column starts inside idx
+      long long lnb = 0, lpairs = 0;
+      for (int j = j0; j < j1 && !too_big; ++j) {
+        tmp.clear();
+        mark[j] = j;
+        const int old = S.perm[j];
+        for (int p = g.ptr[old]; p < g.ptr[old + 1]; ++p) {
+          const int i = S.iperm[g.idx[p]];
+          if (i > j && mark[i] != j) { mark[i] = j; tmp.push_back(i); }
+        }
+        for (int ch = first_child[j]; ch >= 0; ch = next_sibling[ch])
+          for (int q = lptr[ch - j0]; q < lptr[ch - j0 + 1]; ++q) {
+            const int i = idx[q];
+            if (i > j && mark[i] != j) { mark[i] = j; tmp.push_back(i); }
+          }
+        std::sort(tmp.begin(), tmp.end());
+        idx.insert(idx.end(), tmp.begin(), tmp.end());
+        lptr[j - j0 + 1] = (int)idx.size();
+        st_ptr[j + 1] = (int)tmp.size();                      // sizes first, prefix sum below
+        if (!tmp.empty()) { parent[j] = tmp[0]; next_sibling[j] = first_child[tmp[0]]; first_child[tmp[0]] = j; }
+        lnb += 1 + (long long)tmp.size();
+        lpairs += (long long)tmp.size() * ((long long)tmp.size() + 1) / 2;
+        // too much fill for the enumerated schedule.  The gate below accepts ~7000 critical-path steps (Manhattan 10 k: 6.4 M
+        // pairs = 9.5 k steps, rejected; KITTI-00 dense: 1.2 M pairs, accepted): a graph past this budget is going to be
+        // rejected anyway, so stop before the pair lists (seconds of host time and GBs) are built.
+        if (lnb > 3000000LL || lpairs > max_pairs) too_big = true;
+      }
+      comp_nb[c] = lnb;
+      comp_pairs[c] = lpairs;
+    });
+    if (too_big) return false;
+    for (int c = 0; c < ncomp; ++c) { nb += comp_nb[c]; pairs += comp_pairs[c]; }
     if (nb > 3000000LL || pairs > max_pairs) return false;
+    for (int j = 0; j < N; ++j) st_ptr[j + 1] += st_ptr[j];
+    st_idx.reserve((size_t)st_ptr[N]);
+    for (int c = 0; c < ncomp; ++c) st_idx.insert(st_idx.end(), comp_idx[c].begin(), comp_idx[c].end());
   }
+  auto st_size = [&](int j) { return st_ptr[j + 1] - st_ptr[j]; };
+  auto st_at = [&](int j) { return st_idx.data() + st_ptr[j]; };
   S.nb = (int)nb;
   S.n_pairs = pairs;
   S.flops = 432.0 * (double)pairs + 650.0 * (double)nb;
   S.col_ptr.assign(N + 1, 0);
-  for (int j = 0; j < N; ++j) S.col_ptr[j + 1] = S.col_ptr[j] + 1 + (int)st[j].size();
+  for (int j = 0; j < N; ++j) S.col_ptr[j + 1] = S.col_ptr[j] + 1 + st_size(j);
   S.blk_row.resize(S.nb);
   for (int j = 0; j < N; ++j) {
     int p = S.col_ptr[j];
     S.blk_row[p++] = j;
-    for (int i : st[j]) S.blk_row[p++] = i;
+    for (int a = 0; a < st_size(j); ++a) S.blk_row[p++] = st_at(j)[a];
   }
   auto block_of = [&](int i, int j) -> int {   // i >= j
     if (i == j) return S.col_ptr[j];
@@ -255,21 +361,23 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
     return (it != hi && *it == i) ? (int)(it - &S.blk_row[0]) : -1;
   };
 
+  phase("symbolic factorisation");
   // ---- 3a. row lists (forward solve; also the source columns of every target column below) ----
   S.rowl_ptr.assign(N + 1, 0);
-  for (int k = 0; k < N; ++k) for (int i : st[k]) ++S.rowl_ptr[i + 1];
+  for (int q = 0; q < st_ptr[N]; ++q) ++S.rowl_ptr[st_idx[q] + 1];
   for (int j = 0; j < N; ++j) S.rowl_ptr[j + 1] += S.rowl_ptr[j];
   S.rowl_blk.resize(S.rowl_ptr[N]);
   S.rowl_col.resize(S.rowl_ptr[N]);
   {
     std::vector<int> fill(S.rowl_ptr.begin(), S.rowl_ptr.end() - 1);
     for (int k = 0; k < N; ++k)
-      for (size_t a = 0; a < st[k].size(); ++a) {
-        const int q = fill[st[k][a]]++;
-        S.rowl_blk[q] = S.col_ptr[k] + 1 + (int)a;
+      for (int a = 0; a < st_size(k); ++a) {
+        const int q = fill[st_at(k)[a]]++;
+        S.rowl_blk[q] = S.col_ptr[k] + 1 + a;
         S.rowl_col[q] = k;
       }
   }
+  phase("row lists");
   // ---- 3b. update pairs per target block ----
   // Target-centric: the pairs of the blocks (i, j) of column j come from the columns k of row j (ascending k = the fixed
   // summation order): with a = position of j in struct(k), the targets (sk[b], j), b >= a, are found by one forward
@@ -282,12 +390,13 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
     const int* hi = &S.blk_row[0] + S.col_ptr[j + 1];
     for (int q = S.rowl_ptr[j]; q < S.rowl_ptr[j + 1]; ++q) {
       const int k = S.rowl_col[q];
-      const std::vector<int>& sk = st[k];
+      const int* sk = st_at(k);
+      const size_t sk_size = (size_t)st_size(k);
       const int base = S.col_ptr[k] + 1;
       const size_t a = (size_t)(S.rowl_blk[q] - base);
       emit(S.col_ptr[j], base + (int)a, base + (int)a);
       const int* it = lo;
-      for (size_t b = a + 1; b < sk.size(); ++b) {
+      for (size_t b = a + 1; b < sk_size; ++b) {
         const int i = sk[b];
         for (int hop = 0; hop < 4 && it != hi && *it < i; ++hop) ++it;
         if (it != hi && *it < i) it = std::lower_bound(it, hi, i);
@@ -297,6 +406,10 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
     }
   };
   auto for_columns = [&](auto&& body) {
+    if (comps.count() > 1) {   // the graphs of a batched solve: one component at a time per thread
+      for_components(comps, [&](int c, int) { for (int j = comps.ptr[c + 1] - 1; j >= comps.ptr[c]; --j) body(j); });
+      return;
+    }
     const int hw = (int)std::thread::hardware_concurrency();
     const int nt = (pairs < 200000 || hw < 2) ? 1 : std::min(hw, 16);
     if (nt <= 1) { for (int j = 0; j < N; ++j) body(j); return; }
@@ -326,6 +439,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
     });
   }
 
+  phase("update pairs");
   // ---- 3c. BSR sources per block ----
   S.asrc_ptr.assign(S.nb + 1, 0);
   std::vector<int> src_block(n_slots, -1);
@@ -346,12 +460,13 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   }
   (void)row_slot_begin;
 
+  phase("slot sources");
   // ---- 4. levels ----
   std::vector<int> level(N, 0);
   int max_level = 0;
-  for (int j = 0; j < N; ++j) {   // children have smaller indices
-    for (int c : children[j]) level[j] = std::max(level[j], level[c] + 1);
+  for (int j = 0; j < N; ++j) {   // children have smaller indices: level[j] is final when j is reached
     max_level = std::max(max_level, level[j]);
+    if (parent[j] >= 0) level[parent[j]] = std::max(level[parent[j]], level[j] + 1);
   }
   S.n_levels = max_level + 1;
   S.level_ptr.assign(S.n_levels + 1, 0);
@@ -372,6 +487,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   S.fused_from_level = S.n_levels;
   while (S.fused_from_level > 0 && S.level_ptr[S.fused_from_level] - S.level_ptr[S.fused_from_level - 1] <= 8) --S.fused_from_level;
 
+  phase("levels");
   // ---- 5. schedule + cost model: serial "pair steps" on the critical path ----
   // COLUMN/FUSED: a column is processed ten blocks at a time by one wave; a block's update list is walked serially by its
   // 6-lane group(s).  SPLIT: every block of the level has its own wave (ten groups share its list), then a cheap
@@ -527,6 +643,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
     steps += 8.0 + worst;
   }
   S.est_steps = steps;
+  phase("schedule");
   {
     int n_split = 0, n_panel = 0;
     for (const DirectStep& st : S.steps) { n_split += st.type == DirectStep::SPLIT; n_panel += st.type == DirectStep::PANEL; }

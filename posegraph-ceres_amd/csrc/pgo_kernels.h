@@ -137,6 +137,25 @@ __device__ __forceinline__ double bsr_elem(const DeviceGraph& g, int slot, int s
   return p < 0 ? 0.0 : g.bsr_val[bsr_index(slot, p)];
 }
 
+// ---- batched solve of independent graphs (pgo_solve_batch): the graphs are the components of one block-diagonal problem;
+// poses and edges of component c are the contiguous ranges [pose_begin[c], pose_begin[c+1]) / [edge_begin[c], edge_begin[c+1]).
+// Every LM scalar exists once per component. ----
+struct BatchScalars {
+  double cand_cost, model_change, step_norm_sq, x_norm_sq, gradient_max;
+  double pad[3];
+};
+struct BatchPlan {
+  int n_comp;
+  const int* pose_begin;     // [n_comp + 1] device
+  const int* edge_begin;     // [n_comp + 1] device
+  const int* pose_comp;      // [N] device
+  const double* radius;      // [n_comp] trust-region radius per component (pinned host memory, device visible)
+  const int* accept;         // [n_comp] 1: the candidate of this component becomes its current point (pinned)
+  BatchScalars* out;         // [n_comp] (pinned)
+  double* partial;           // [n_comp][split][5] device scratch of launch_batch_scalars
+  int split;                 // workgroups per component
+};
+
 struct CgParams {
   double q_tolerance;   // eta
   double r_tolerance;   // |r| <= r_tolerance * |b| stop; negative disables (Ceres LM passes -1)
@@ -166,6 +185,11 @@ void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s, int mo
 void launch_spmv_refresh(const DeviceGraph& g, hipStream_t s, int on_the_fly = 0, int it_odd = 0);
 void launch_model_delta_and_retract(const DeviceGraph& g, hipStream_t s, int gate = 0);
 void launch_debug(const DeviceGraph& g, int which, hipStream_t s);
+// batched solve: D^2 = clamp(diag(H~)) / radius[component] into g.d2 (then launch_damping mode 2), per-component step scalars
+// (after launch_spmv_tail wrote q = A x, delta and the candidates), candidate -> current for the accepted components
+void launch_batch_d2(const DeviceGraph& g, const BatchPlan& b, double min_diag, double max_diag, hipStream_t s);
+void launch_batch_scalars(const DeviceGraph& g, const BatchPlan& b, hipStream_t s);
+void launch_batch_accept(const DeviceGraph& g, const BatchPlan& b, hipStream_t s);
 int vec_block();
 int pose_block();
 int edge_block();

@@ -1345,6 +1345,115 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_step_tail(DeviceGraph g, int gat
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Batched solve of independent graphs (BatchPlan): the per-component pieces of the LM iteration.
+// ------------------------------------------------------------------------------------------------
+// LevenbergMarquardtStrategy's diagonal with the radius of the pose's own component (k_damping mode 0 does the same with
+// one radius; the quotient is formed by the same operation, so a component gets the bits it gets when solved alone).
+__global__ void k_batch_d2(DeviceGraph g, BatchPlan b, double min_diag, double max_diag) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 6 * g.N) return;
+  const int v = idx / 6, i = idx - 6 * v;
+  const double radius = b.radius[b.pose_comp[v]];
+  const double dc = fmin(fmax(g.Hdiag[36 * (size_t)v + 7 * i], min_diag), max_diag);
+  g.diag_clamped[idx] = dc;
+  g.d2[idx] = dc / radius;
+}
+
+// b.split workgroups per component: candidate cost over its edges, model cost change / step norm / state norm / gradient norm
+// over its poses (the arithmetic of k_step_tail and k_gradient_norm, reduced per component) -> partials, folded in a fixed
+// order by k_batch_fold into pinned memory.
+template <int INFO>
+__global__ __launch_bounds__(256) void k_batch_scalars(DeviceGraph g, BatchPlan b) {
+  __shared__ double scratch[4 * 4];
+  __shared__ double smax[4];
+  const int c = blockIdx.x / b.split, part = blockIdx.x - c * b.split, tid = threadIdx.x;
+  const int stride = 256 * b.split;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};   // candidate cost, model change, |step|^2, |x|^2
+  double gm = 0.0;
+  for (int v = b.pose_begin[c] + part * 256 + tid; v < b.pose_begin[c + 1]; v += stride) {
+    const PoseRec P = load_pose(g.pose_x, v), C = load_pose(g.pose_c, v);
+    const uint8_t m = g.cmask[v];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const size_t idx = 6 * (size_t)v + i;
+      const double x = g.cg_x[idx];
+      const double hx = g.cg_q[q_index(g, v, i)] - g.d2[idx] * x;
+      const bool cst = (i < 3) ? (m & 1) : (m & 2);
+      acc[1] += cst ? 0.0 : (x * g.cg_b[idx] - 0.5 * x * hx);
+    }
+    const double* gr = g.grad + 6 * (size_t)v;
+    if (!(m & 1)) {
+      const double dx = P.p.x - C.p.x, dy = P.p.y - C.p.y, dz = P.p.z - C.p.z;
+      acc[2] += dx * dx + dy * dy + dz * dz;
+      acc[3] += P.p.x * P.p.x + P.p.y * P.p.y + P.p.z * P.p.z;
+      gm = fmax(gm, fmax(fabs(gr[0]), fmax(fabs(gr[1]), fabs(gr[2]))));
+    }
+    if (!(m & 2)) {
+      const double dx = P.q.x - C.q.x, dy = P.q.y - C.q.y, dz = P.q.z - C.q.z, dw = P.q.w - C.q.w;
+      acc[2] += dx * dx + dy * dy + dz * dz + dw * dw;
+      acc[3] += P.q.x * P.q.x + P.q.y * P.q.y + P.q.z * P.q.z + P.q.w * P.q.w;
+      const Q4 q = quat_plus(P.q, V3{-gr[3], -gr[4], -gr[5]});
+      gm = fmax(gm, fmax(fmax(fabs(P.q.x - q.x), fabs(P.q.y - q.y)), fmax(fabs(P.q.z - q.z), fabs(P.q.w - q.w))));
+    }
+  }
+  for (int e = b.edge_begin[c] + part * 256 + tid; e < b.edge_begin[c + 1]; e += stride) {
+    const PoseRec A = load_pose(g.pose_c, g.edge_a[e]), B = load_pose(g.pose_c, g.edge_b[e]);
+    const size_t E = (size_t)g.E;
+    const V3 mp{g.emeas[e], g.emeas[E + e], g.emeas[2 * E + e]};
+    const Q4 mq{g.emeas[3 * E + e], g.emeas[4 * E + e], g.emeas[5 * E + e], g.emeas[6 * E + e]};
+    double er[6];
+    edge_error(A.p, A.q, B.p, B.q, mp, mq, er);
+    double sq;
+    if (INFO) {
+      const WBlocks W = load_W(g.eW, E, (size_t)e);
+      const V3 ep{er[0], er[1], er[2]}, eq{er[3], er[4], er[5]};
+      const V3 a1 = mulv(W.pp, ep), a2 = mulv(W.pr, eq), b1 = mulTv(W.pr, ep), b2 = mulv(W.rr, eq);
+      sq = dot(ep, V3{a1.x + a2.x, a1.y + a2.y, a1.z + a2.z}) + dot(eq, V3{b1.x + b2.x, b1.y + b2.y, b1.z + b2.z});
+    } else {
+      sq = er[0] * er[0] + er[1] * er[1] + er[2] * er[2] + er[3] * er[3] + er[4] * er[4] + er[5] * er[5];
+    }
+    double rho0, rho1;
+    loss_eval(g.loss_kind, g.loss_a, sq, &rho0, &rho1);
+    acc[0] += 0.5 * rho0;
+  }
+  block_sum<4>(acc, scratch);
+  gm = wave_max(gm);
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane == 0) smax[wave] = gm;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 4; ++w) t = fmax(t, smax[w]);
+    double* o = b.partial + 5 * (size_t)blockIdx.x;
+    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3]; o[4] = t;
+  }
+}
+
+__global__ void k_batch_fold(BatchPlan b) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= b.n_comp) return;
+  double s[4] = {0.0, 0.0, 0.0, 0.0}, t = 0.0;
+  for (int j = 0; j < b.split; ++j) {
+    const double* q = b.partial + 5 * ((size_t)c * b.split + j);
+    s[0] += q[0]; s[1] += q[1]; s[2] += q[2]; s[3] += q[3];
+    t = fmax(t, q[4]);
+  }
+  BatchScalars o;
+  o.cand_cost = s[0]; o.model_change = s[1]; o.step_norm_sq = s[2]; o.x_norm_sq = s[3]; o.gradient_max = t;
+  o.pad[0] = o.pad[1] = o.pad[2] = 0.0;
+  b.out[c] = o;
+}
+
+__global__ void k_batch_accept(DeviceGraph g, BatchPlan b) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // one lane per 16 bytes of a pose record
+  if (idx >= 4 * g.N) return;
+  const int v = idx >> 2;
+  if (!b.accept[b.pose_comp[v]]) return;
+  reinterpret_cast<double2*>(g.pose_x)[idx] = reinterpret_cast<const double2*>(g.pose_c)[idx];
+}
+
 __global__ void k_empty(DeviceGraph g) {}
 __global__ void k_touch(DeviceGraph g) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1455,6 +1564,17 @@ void launch_apply_step(const DeviceGraph& g, const double* step, hipStream_t s) 
   hipLaunchKernelGGL(k_retract, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g, 0);
 }
 
+void launch_batch_d2(const DeviceGraph& g, const BatchPlan& b, double min_diag, double max_diag, hipStream_t s) {
+  hipLaunchKernelGGL(k_batch_d2, dim3(cdiv(6 * g.N, 256)), dim3(256), 0, s, g, b, min_diag, max_diag);
+}
+void launch_batch_scalars(const DeviceGraph& g, const BatchPlan& b, hipStream_t s) {
+  if (g.info_mode) hipLaunchKernelGGL(k_batch_scalars<1>, dim3(b.n_comp * b.split), dim3(256), 0, s, g, b);
+  else hipLaunchKernelGGL(k_batch_scalars<0>, dim3(b.n_comp * b.split), dim3(256), 0, s, g, b);
+  hipLaunchKernelGGL(k_batch_fold, dim3(cdiv(b.n_comp, 64)), dim3(64), 0, s, b);
+}
+void launch_batch_accept(const DeviceGraph& g, const BatchPlan& b, hipStream_t s) {
+  hipLaunchKernelGGL(k_batch_accept, dim3(cdiv(4 * g.N, 256)), dim3(256), 0, s, g, b);
+}
 void launch_debug(const DeviceGraph& g, int which, hipStream_t s) {
   if (which == 0) hipLaunchKernelGGL(k_empty, dim3(g.n_wg), dim3(g.block), 0, s, g);
   else hipLaunchKernelGGL(k_touch, dim3(cdiv(6 * g.N, 256)), dim3(256), 0, s, g);

@@ -23,6 +23,7 @@ namespace pgo { int comm_stress(Comm* c, int iters, size_t seg, hipStream_t s, i
 #include <cstdarg>
 #include <cstdio>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <cstdlib>
@@ -88,17 +89,75 @@ inline hipError_t staged_copy(void* dst, const void* src, size_t bytes, bool to_
 inline hipError_t staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t s) { return staged_copy(dst, src, bytes, true, s); }
 inline hipError_t staged_d2h(void* dst, const void* src, size_t bytes, hipStream_t s) { return staged_copy(dst, src, bytes, false, s); }
 
+// Device blocks of destroyed problems are kept in a process-wide, size-keyed free list and handed to the next allocation they
+// fit: hipFree synchronises the whole device and costs ~0.1 ms per block — releasing the ~70 buffers of a problem took 2-9 ms,
+// as much as a KITTI-scale solve.  Only whole-problem teardown goes through the pool (the owner synchronises its stream
+// first); a buffer that is re-allocated in mid-life is freed the blocking way, since work in flight may still read it.
+// PGO_POOL_MAX_GB bounds the cached bytes (default 16; 0 switches the pool off); pgo_release_device_memory() empties it.
+struct DevicePool {
+  std::mutex mu;
+  std::multimap<std::pair<int, size_t>, void*> blocks;   // (device, capacity in bytes) -> block
+  size_t cached = 0;
+  static size_t limit() {
+    static const size_t lim = (size_t)((getenv("PGO_POOL_MAX_GB") ? atof(getenv("PGO_POOL_MAX_GB")) : 16.0) * 1e9);
+    return lim;
+  }
+  hipError_t get(size_t bytes, void** out, size_t* cap, int* dev) {
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) return e;
+    *dev = d;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = blocks.lower_bound(std::make_pair(d, bytes));
+      if (it != blocks.end() && it->first.first == d && it->first.second <= std::max(2 * bytes, bytes + (1u << 20))) {
+        *out = it->second;
+        *cap = it->first.second;
+        cached -= *cap;
+        blocks.erase(it);
+        return hipSuccess;
+      }
+    }
+    *cap = bytes;
+    return hipMalloc(out, bytes);
+  }
+  void put(void* p, size_t cap, int dev) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (cached + cap <= limit()) { blocks.emplace(std::make_pair(dev, cap), p); cached += cap; return; }
+    }
+    (void)hipFree(p);
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& kv : blocks) (void)hipFree(kv.second);
+    blocks.clear();
+    cached = 0;
+  }
+};
+inline DevicePool& device_pool() { static DevicePool* pool = new DevicePool(); return *pool; }   // never destroyed: no HIP calls at exit
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
-  ~DevBuf() { release(); }
-  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  size_t cap_bytes = 0;
+  int dev = 0;
+  ~DevBuf() { release(true); }
+  void release(bool to_pool = false) {
+    if (!p) return;
+    if (to_pool) device_pool().put(p, cap_bytes, dev); else (void)hipFree(p);
+    p = nullptr; n = 0; cap_bytes = 0;
+  }
   hipError_t alloc(size_t count) {
-    release();
+    release(false);
     n = count;
     if (count == 0) return hipSuccess;
-    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    void* q = nullptr;
+    const hipError_t e = device_pool().get(count * sizeof(T), &q, &cap_bytes, &dev);
+    p = static_cast<T*>(q);
+    if (e != hipSuccess) { p = nullptr; n = 0; cap_bytes = 0; }
+    return e;
   }
   hipError_t upload(const std::vector<T>& h, hipStream_t s) {
     hipError_t e = alloc(h.size());
@@ -225,6 +284,7 @@ struct pgo_problem {
   LmState lm;
 
   ~pgo_problem() {
+    if (stream_ready) (void)hipStreamSynchronize(stream);   // the device buffers go back to the pool: nothing may be in flight
     drop_graph();
     delete comm;
     if (scal) (void)hipHostFree(scal);
@@ -536,10 +596,16 @@ int prepare(pgo_problem* P) {
   const int n_edge_wg = std::max(1, (E + pgo::edge_block() - 1) / pgo::edge_block());
   const int n_pose_wg = (N + pgo::pose_block() - 1) / pgo::pose_block();
   const int n_part = std::max(std::max(n_wg, n_vec_wg), n_edge_wg + n_pose_wg);   // the fused step tail runs n_edge_wg + n_pose_wg workgroups
+  // (blocks may come from the pool with a previous problem's contents: everything that is not fully written before it is read
+  // is cleared here)
   HIP_TRY(P->d_part_rz.alloc((size_t)2 * n_part));
+  HIP_TRY(P->d_part_rz.zero(s));
   HIP_TRY(P->d_part_q.alloc((size_t)2 * n_part));
+  HIP_TRY(P->d_part_q.zero(s));
   HIP_TRY(P->d_part_rr.alloc((size_t)2 * n_part));
+  HIP_TRY(P->d_part_rr.zero(s));
   HIP_TRY(P->d_part_bb.alloc((size_t)n_part));
+  HIP_TRY(P->d_part_bb.zero(s));
   HIP_TRY(P->d_part_misc.alloc((size_t)8 * n_part));
   HIP_TRY(P->d_part_misc.zero(s));
   HIP_TRY(P->d_cg.alloc(1));
@@ -936,6 +1002,7 @@ int prepare_direct(pgo_problem* P) {
   if (S.split_sub.empty()) { HIP_TRY(P->dd_split_sub.alloc(1)); HIP_TRY(P->dd_split_sub_diag.alloc(1)); }
   HIP_TRY(P->dd_Lval.alloc((size_t)36 * S.nb));
   HIP_TRY(P->dd_y.alloc((size_t)6 * S.n));
+  HIP_TRY(P->dd_y.zero(s));
   pgo::DirectPlan& d = P->dplan;
   d.n = S.n; d.nb = S.nb; d.n_levels = S.n_levels;
   d.perm = P->dd_perm.p; d.col_ptr = P->dd_col_ptr.p; d.blk_row = P->dd_blk_row.p;
@@ -1100,15 +1167,17 @@ void terminate(LmState& L, int termination, int reason, const char* fmt, ...) {
   L.message = buf;
 }
 
-// One pass of the TrustRegionMinimizer loop body (SURVEY.md A.6 step 7 order).
-int lm_advance(pgo_problem* P) {
-  LmState& L = P->lm;
-  const pgo_solver_options& o = P->opt;
-  hipStream_t s = P->stream;
-  if (L.terminated) return PGO_OK;
-  const auto t_it = Clock::now();
+// ---- the host half of one TrustRegionMinimizer pass (SURVEY.md A.6 step 7 order), shared by the single-problem driver and
+// the batched one (one LmState per component there): pure bookkeeping on LmState, no device work ----
+// What the device hands back after a trial step.
+struct StepScalars {
+  double cand_cost, model_change, step_norm_sq, x_norm_sq, gradient_max;
+  int cg_iterations, cg_status, linearize_bad;
+};
+enum StepAction { STEP_NONE = 0, STEP_ACCEPT = 1, STEP_REJECT = 2 };   // NONE: terminated or invalid step
 
-  // FinalizeIterationAndCheckIfMinimizerCanContinue
+// FinalizeIterationAndCheckIfMinimizerCanContinue.  Returns false when the minimizer stops here.
+bool lm_pre_step(LmState& L, const pgo_solver_options& o) {
   if (L.pending_record) {
     if (L.cur.step_is_successful) ++L.num_successful; else ++L.num_unsuccessful;
     L.cur.trust_region_radius = L.radius;
@@ -1117,19 +1186,121 @@ int lm_advance(pgo_problem* P) {
   }
   if (L.cur.iteration >= o.max_num_iterations) {
     terminate(L, PGO_NO_CONVERGENCE, 5, "Maximum number of iterations reached. Number of iterations: %d.", L.cur.iteration);
-    return PGO_OK;
+    return false;
   }
   if (!L.gmax_deferred && L.cur.step_is_successful && L.cur.gradient_max_norm <= o.gradient_tolerance) {
     terminate(L, PGO_CONVERGENCE, 3, "Gradient tolerance reached. Gradient max norm: %e <= %e", L.cur.gradient_max_norm, o.gradient_tolerance);
-    return PGO_OK;
+    return false;
   }
   if (L.radius <= o.min_trust_region_radius) {
     terminate(L, PGO_CONVERGENCE, 4, "Minimum trust region radius reached. Trust region radius: %e <= %e", L.radius, o.min_trust_region_radius);
-    return PGO_OK;
+    return false;
   }
+  return true;
+}
 
+// Everything after the trial step came back: deferred gradient test, step validity, parameter / function tolerance,
+// IsStepSuccessful, radius update.  STEP_ACCEPT: the caller makes the candidate the current point and re-linearises.
+StepAction lm_post_step(LmState& L, const pgo_solver_options& o, const StepScalars& sc, int extra_linear_iterations) {
   pgo_iteration_record nx{};
   nx.iteration = L.cur.iteration + 1;
+  ++L.num_trial_steps;
+  const int cg_it = sc.cg_iterations, cg_status = sc.cg_status;
+  L.reuse_diagonal = true;
+  L.num_linear_iterations += cg_it + extra_linear_iterations;   // the iterations of an over-budget PCG try are work done, counted in the summary
+  nx.linear_solver_iterations = cg_it;
+
+  if (L.gmax_deferred) {
+    // the gradient test of FinalizeIterationAndCheckIfMinimizerCanContinue for the point accepted last
+    // iteration: if it fires, the step just computed is discarded (x was not touched)
+    L.gmax_deferred = false;
+    L.gmax = sc.gradient_max;
+    L.cur.gradient_max_norm = L.gmax;
+    if (!L.records.empty()) L.records.back().gradient_max_norm = L.gmax;
+    if (L.gmax <= o.gradient_tolerance) {
+      L.num_linear_iterations -= cg_it;
+      terminate(L, PGO_CONVERGENCE, 3, "Gradient tolerance reached. Gradient max norm: %e <= %e", L.gmax, o.gradient_tolerance);
+      return STEP_NONE;
+    }
+  }
+  nx.gradient_max_norm = L.cur.gradient_max_norm;
+  const bool lin_ok = (cg_status != 2) && std::isfinite(sc.model_change) && !sc.linearize_bad;
+  const double model_cost_change = sc.model_change;
+  const bool step_valid = lin_ok && model_cost_change > 0.0;
+
+  if (!step_valid) {
+    // HandleInvalidStep
+    ++L.num_consecutive_invalid;
+    if (L.num_consecutive_invalid >= o.max_num_consecutive_invalid_steps) {
+      terminate(L, PGO_FAILURE, 6, "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d",
+                o.max_num_consecutive_invalid_steps);
+      L.cur = nx;
+      return STEP_NONE;
+    }
+    L.radius *= 0.5;
+    L.reuse_diagonal = true;
+    nx.cost = L.x_cost;
+    nx.step_is_successful = 0;
+    L.cur = nx;
+    L.pending_record = true;
+    return STEP_NONE;
+  }
+  L.num_consecutive_invalid = 0;
+
+  // ParameterToleranceReached
+  nx.step_norm = std::sqrt(sc.step_norm_sq);
+  L.x_norm = std::sqrt(sc.x_norm_sq);
+  const double step_size_tolerance = o.parameter_tolerance * (L.x_norm + o.parameter_tolerance);
+  if (nx.step_norm <= step_size_tolerance) {
+    terminate(L, PGO_CONVERGENCE, 2, "Parameter tolerance reached. Relative step_norm: %e <= %e.",
+              nx.step_norm / (L.x_norm + o.parameter_tolerance), o.parameter_tolerance);
+    return STEP_NONE;
+  }
+  // FunctionToleranceReached
+  const double cand_cost = sc.cand_cost;
+  nx.cost_change = L.x_cost - cand_cost;
+  if (std::fabs(nx.cost_change) <= o.function_tolerance * L.x_cost) {
+    terminate(L, PGO_CONVERGENCE, 1, "Function tolerance reached. |cost_change|/cost: %e <= %e",
+              std::fabs(nx.cost_change) / L.x_cost, o.function_tolerance);
+    return STEP_NONE;
+  }
+  // IsStepSuccessful
+  nx.relative_decrease = nx.cost_change / model_cost_change;
+  StepAction action;
+  if (nx.relative_decrease > o.min_relative_decrease) {
+    // HandleSuccessfulStep (host half): LevenbergMarquardtStrategy::StepAccepted
+    L.x_cost = cand_cost;
+    L.gmax_deferred = true;  // filled in at the next host sync (or at the end of the solve)
+    nx.step_is_successful = 1;
+    nx.cost = L.x_cost;
+    L.radius = L.radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * nx.relative_decrease - 1.0, 3));
+    L.radius = std::min(o.max_trust_region_radius, L.radius);
+    L.decrease_factor = 2.0;
+    L.reuse_diagonal = false;
+    action = STEP_ACCEPT;
+  } else {
+    // HandleUnsuccessfulStep / StepRejected
+    nx.step_is_successful = 0;
+    nx.cost = cand_cost;
+    L.radius = L.radius / L.decrease_factor;
+    L.decrease_factor *= 2.0;
+    L.reuse_diagonal = true;
+    action = STEP_REJECT;
+  }
+  L.cur = nx;
+  L.pending_record = true;
+  return action;
+}
+
+// One pass of the TrustRegionMinimizer loop body (SURVEY.md A.6 step 7 order).
+int lm_advance(pgo_problem* P) {
+  LmState& L = P->lm;
+  const pgo_solver_options& o = P->opt;
+  hipStream_t s = P->stream;
+  if (L.terminated) return PGO_OK;
+  const auto t_it = Clock::now();
+
+  if (!lm_pre_step(L, o)) return PGO_OK;
 
   // ComputeTrustRegionStep + ComputeCandidatePointAndEvaluateCost, enqueued back to back: damping, one
   // batch of CG iterations, model cost change / delta / candidate, candidate cost, scalar fold.  ONE host
@@ -1199,97 +1370,18 @@ int lm_advance(pgo_problem* P) {
     if (hybrid) { ++L.hybrid_direct_run; ++L.hybrid_direct; }
   }
   HIP_TRY(hipGetLastError());
-  ++L.num_trial_steps;
-  const pgo::LmScalars sc = *P->scal;
-  const int cg_it = sc.cg_iterations, cg_status = sc.cg_status;
-  P->last_cg_iterations = cg_it;
-  L.reuse_diagonal = true;
-  L.num_linear_iterations += cg_it + wasted_cg;   // the iterations of an over-budget PCG try are work done, counted in the summary
-  nx.linear_solver_iterations = cg_it;
+  const pgo::LmScalars dsc = *P->scal;
+  P->last_cg_iterations = dsc.cg_iterations;
   L.t_linear += seconds_since(t_lin);
-
-  if (L.gmax_deferred) {
-    // the gradient test of FinalizeIterationAndCheckIfMinimizerCanContinue for the point accepted last
-    // iteration: if it fires, the step just computed is discarded (x was not touched)
-    L.gmax_deferred = false;
-    L.gmax = sc.gradient_max;
-    L.cur.gradient_max_norm = L.gmax;
-    if (!L.records.empty()) L.records.back().gradient_max_norm = L.gmax;
-    if (L.gmax <= o.gradient_tolerance) {
-      L.num_linear_iterations -= cg_it;
-      terminate(L, PGO_CONVERGENCE, 3, "Gradient tolerance reached. Gradient max norm: %e <= %e", L.gmax, o.gradient_tolerance);
-      return PGO_OK;
-    }
-  }
-  nx.gradient_max_norm = L.cur.gradient_max_norm;
-  const bool lin_ok = (cg_status != 2) && std::isfinite(sc.model_change) && !sc.linearize_bad;
-  const double model_cost_change = sc.model_change;
-  const bool step_valid = lin_ok && model_cost_change > 0.0;
-
-  if (!step_valid) {
-    // HandleInvalidStep
-    ++L.num_consecutive_invalid;
-    if (L.num_consecutive_invalid >= o.max_num_consecutive_invalid_steps) {
-      terminate(L, PGO_FAILURE, 6, "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d",
-                o.max_num_consecutive_invalid_steps);
-      L.cur = nx;
-      return PGO_OK;
-    }
-    L.radius *= 0.5;
-    L.reuse_diagonal = true;
-    nx.cost = L.x_cost;
-    nx.step_is_successful = 0;
-    L.cur = nx;
-    L.pending_record = true;
-    L.t_total += seconds_since(t_it);
-    return PGO_OK;
-  }
-  L.num_consecutive_invalid = 0;
-
-  // ParameterToleranceReached
-  nx.step_norm = std::sqrt(sc.step_norm_sq);
-  L.x_norm = std::sqrt(sc.x_norm_sq);
-  const double step_size_tolerance = o.parameter_tolerance * (L.x_norm + o.parameter_tolerance);
-  if (nx.step_norm <= step_size_tolerance) {
-    terminate(L, PGO_CONVERGENCE, 2, "Parameter tolerance reached. Relative step_norm: %e <= %e.",
-              nx.step_norm / (L.x_norm + o.parameter_tolerance), o.parameter_tolerance);
-    L.t_total += seconds_since(t_it);
-    return PGO_OK;
-  }
-  // FunctionToleranceReached
-  const double cand_cost = sc.cand_cost;
-  nx.cost_change = L.x_cost - cand_cost;
-  if (std::fabs(nx.cost_change) <= o.function_tolerance * L.x_cost) {
-    terminate(L, PGO_CONVERGENCE, 1, "Function tolerance reached. |cost_change|/cost: %e <= %e",
-              std::fabs(nx.cost_change) / L.x_cost, o.function_tolerance);
-    L.t_total += seconds_since(t_it);
-    return PGO_OK;
-  }
-  // IsStepSuccessful
-  nx.relative_decrease = nx.cost_change / model_cost_change;
-  if (nx.relative_decrease > o.min_relative_decrease) {
-    // HandleSuccessfulStep: x <- candidate, re-linearise, LevenbergMarquardtStrategy::StepAccepted
+  const StepScalars sc{dsc.cand_cost, dsc.model_change, dsc.step_norm_sq, dsc.x_norm_sq, dsc.gradient_max,
+                       dsc.cg_iterations, dsc.cg_status, dsc.linearize_bad};
+  const StepAction action = lm_post_step(L, o, sc, wasted_cg);
+  if (action == STEP_ACCEPT) {
+    // HandleSuccessfulStep (device half): x <- candidate, re-linearise
     std::swap(P->g.pose_x, P->g.pose_c);
-    L.x_cost = cand_cost;
     rc = evaluate_gradient_and_jacobian(P, false);
     if (rc) return rc;
-    L.gmax_deferred = true;  // filled in at the next host sync (or in pgo_solver_end)
-    nx.step_is_successful = 1;
-    nx.cost = L.x_cost;
-    L.radius = L.radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * nx.relative_decrease - 1.0, 3));
-    L.radius = std::min(o.max_trust_region_radius, L.radius);
-    L.decrease_factor = 2.0;
-    L.reuse_diagonal = false;
-  } else {
-    // HandleUnsuccessfulStep / StepRejected
-    nx.step_is_successful = 0;
-    nx.cost = cand_cost;
-    L.radius = L.radius / L.decrease_factor;
-    L.decrease_factor *= 2.0;
-    L.reuse_diagonal = true;
   }
-  L.cur = nx;
-  L.pending_record = true;
   L.t_total += seconds_since(t_it);
   return PGO_OK;
 }
@@ -1358,6 +1450,239 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
     for (int i = 0; i < n; ++i) records[i] = L.records[i];
   }
   L.active = false;
+  return PGO_OK;
+}
+
+
+// ---- batched solve of independent graphs -----------------------------------------------------------------------------------
+// KITTI-scale graphs do not fill the machine: one LM iteration is a chain of ~45 small dependent launches.  n independent
+// problems are therefore solved as ONE block-diagonal problem — the same launch sequence, n times the work per launch — with
+// everything Levenberg-Marquardt decides kept per component: trust-region radius, accept / reject, every termination test,
+// iteration records and summaries.  Device: damping with the radius of the pose's component, the factorisation of the union
+// (a forest: nothing crosses components), per-component step scalars, acceptance by component.  Host: lm_pre_step /
+// lm_post_step per component — the very functions the single-problem driver runs, so a component follows the trace it
+// follows when solved alone (to the rounding of the differently grouped sums).  Exact steps only (SPARSE_NORMAL_CHOLESKY,
+// the reference's setting): a per-component CG would need per-component iteration control.
+int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* options, pgo_solver_summary* summaries,
+                pgo_iteration_record* records, int capacity) {
+  const auto t_begin = Clock::now();
+  const pgo_solver_options& o = *options;
+  if (o.linear_solver_type != PGO_SPARSE_NORMAL_CHOLESKY)
+    return set_error(PGO_ERR_UNSUPPORTED, "pgo_solve_batch serves exact requests (PGO_SPARSE_NORMAL_CHOLESKY) only");
+  // ---- the union ----
+  pgo_problem M;
+  M.device = probs[0]->device;
+  M.loss_kind = probs[0]->loss_kind;
+  M.loss_a = probs[0]->loss_a;
+  std::vector<int> pose_begin(n + 1, 0), edge_begin(n + 1, 0);
+  bool any_info = false;
+  for (int c = 0; c < n; ++c) {
+    const pgo_problem* Q = probs[c];
+    if (!Q || Q->pp.empty()) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solve_batch: problem %d is null or empty", c);
+    if (Q->comm) return set_error(PGO_ERR_UNSUPPORTED, "pgo_solve_batch: problem %d is attached to a communicator", c);
+    if (Q->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solve_batch: problem %d is inside a solver session", c);
+    if (Q->loss_kind != M.loss_kind || Q->loss_a != M.loss_a)
+      return set_error(PGO_ERR_UNSUPPORTED, "pgo_solve_batch: all problems must use the same loss function (problem %d differs)", c);
+    pose_begin[c + 1] = pose_begin[c] + (int)Q->pp.size();
+    edge_begin[c + 1] = edge_begin[c] + (int)Q->ia.size();
+    any_info = any_info || Q->has_info;
+  }
+  const int N = pose_begin[n], E = edge_begin[n];
+  M.pp.reserve(N); M.qq.reserve(N); M.cmask.reserve(N);
+  M.ia.reserve(E); M.ib.reserve(E); M.meas.reserve((size_t)7 * E);
+  if (any_info) M.sqrt_info.reserve((size_t)36 * E);
+  M.has_info = any_info;
+  for (int c = 0; c < n; ++c) {
+    const pgo_problem* Q = probs[c];
+    M.pp.insert(M.pp.end(), Q->pp.begin(), Q->pp.end());
+    M.qq.insert(M.qq.end(), Q->qq.begin(), Q->qq.end());
+    M.cmask.insert(M.cmask.end(), Q->cmask.begin(), Q->cmask.end());
+    for (int v : Q->ia) M.ia.push_back(v + pose_begin[c]);
+    for (int v : Q->ib) M.ib.push_back(v + pose_begin[c]);
+    M.meas.insert(M.meas.end(), Q->meas.begin(), Q->meas.end());
+    if (any_info) {
+      if (Q->has_info) M.sqrt_info.insert(M.sqrt_info.end(), Q->sqrt_info.begin(), Q->sqrt_info.end());
+      else
+        for (size_t e = 0; e < Q->ia.size(); ++e)
+          for (int k = 0; k < 36; ++k) M.sqrt_info.push_back(k % 7 == 0 ? 1.0 : 0.0);
+    }
+  }
+  pgo_problem* P = &M;
+  int rc = prepare(P);
+  if (rc) return rc;
+  P->opt = o;
+  P->g.loss_kind = P->loss_kind;
+  P->g.loss_a = P->loss_a;
+  P->g.pose_x = P->d_pose_x.p;
+  P->g.pose_c = P->d_pose_c.p;
+  rc = prepare_direct(P);
+  if (rc) return rc;
+  if (!P->direct_usable || P->dsym.hybrid)
+    return set_error(PGO_ERR_UNSUPPORTED, "pgo_solve_batch: the union of the problems is beyond the factorisation's budget; solve them one by one");
+  rc = prepare_clusters(P, 1);
+  if (rc) return rc;
+  hipStream_t s = P->stream;
+  // component tables (device) and the per-component hand-over block (pinned, device visible)
+  std::vector<int> pose_comp(N);
+  for (int c = 0; c < n; ++c) std::fill(pose_comp.begin() + pose_begin[c], pose_comp.begin() + pose_begin[c + 1], c);
+  DevBuf<int> d_pose_begin, d_edge_begin, d_pose_comp;
+  HIP_TRY(d_pose_begin.upload(pose_begin, s));
+  HIP_TRY(d_edge_begin.upload(edge_begin, s));
+  HIP_TRY(d_pose_comp.upload(pose_comp, s));
+  struct Pinned {
+    void* p = nullptr;
+    ~Pinned() { if (p) (void)hipHostFree(p); }
+  } pin;
+  const size_t pin_bytes = (size_t)n * (sizeof(pgo::BatchScalars) + sizeof(double) + sizeof(int)) + 64;
+  HIP_TRY(hipHostMalloc(&pin.p, pin_bytes, hipHostMallocMapped));
+  memset(pin.p, 0, pin_bytes);
+  pgo::BatchScalars* out = static_cast<pgo::BatchScalars*>(pin.p);
+  double* radius = reinterpret_cast<double*>(out + n);
+  int* accept = reinterpret_cast<int*>(radius + n);
+  // workgroups per component of the scalar reduction: enough of them to cover the machine, no more than the largest component needs
+  int max_items = 1;
+  for (int c = 0; c < n; ++c) max_items = std::max(max_items, std::max(pose_begin[c + 1] - pose_begin[c], edge_begin[c + 1] - edge_begin[c]));
+  const int split = std::max(1, std::min((max_items + 255) / 256, std::max(1, 1024 / n)));
+  DevBuf<double> d_partial;
+  HIP_TRY(d_partial.alloc((size_t)5 * n * split));
+  const pgo::BatchPlan plan{n, d_pose_begin.p, d_edge_begin.p, d_pose_comp.p, radius, accept, out, d_partial.p, split};
+
+  rc = upload_poses(P, P->g.pose_x);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(P->g.pose_c, P->g.pose_x, P->d_pose_x.n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(P->d_flags.zero(s));
+  HIP_TRY(P->d_cg_x.zero(s));
+  HIP_TRY(P->d_cg_q.zero(s));
+  HIP_TRY(P->d_cg_b.zero(s));
+  HIP_TRY(P->d_d2.zero(s));
+  const double t_setup = seconds_since(t_begin);
+  // Init + IterationZero: cost, state norm and gradient norm of every component at its start (candidate == current point)
+  rc = evaluate_gradient_and_jacobian(P, true);
+  if (rc) return rc;
+  pgo::launch_batch_scalars(P->g, plan, s);
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  std::vector<LmState> Ls(n);
+  for (int c = 0; c < n; ++c) {
+    LmState& L = Ls[c];
+    L.x_cost = out[c].cand_cost;
+    L.initial_cost = L.x_cost;
+    L.x_norm = std::sqrt(out[c].x_norm_sq);
+    L.gmax = out[c].gradient_max;
+    L.radius = o.initial_trust_region_radius;
+    L.cur = pgo_iteration_record{};
+    L.cur.step_is_successful = 1;
+    L.cur.cost = L.x_cost;
+    L.cur.gradient_max_norm = L.gmax;
+    L.pending_record = true;
+    L.active = true;
+    L.t_setup = t_setup;
+    if (!std::isfinite(L.x_cost)) terminate(L, PGO_FAILURE, 7, "Initial cost is not finite.");
+    radius[c] = L.radius;
+  }
+  int n_rounds = 0;
+  for (;;) {
+    int alive = 0;
+    for (int c = 0; c < n; ++c) {
+      LmState& L = Ls[c];
+      if (L.terminated) continue;
+      if (lm_pre_step(L, o)) { ++alive; radius[c] = L.radius; }
+    }
+    if (!alive) break;
+    // the trial step of every component at once
+    pgo::launch_batch_d2(P->g, plan, o.min_lm_diagonal, o.max_lm_diagonal, s);
+    rc = damping_all(P, 1.0, o.min_lm_diagonal, o.max_lm_diagonal, 2);
+    if (rc) return rc;
+    rc = run_direct(P);
+    if (rc) return rc;
+    const pgo::CgParams none{0.0, -1.0, 0, 0};
+    pgo::launch_spmv_tail(P->g, none, s, 0, 1);
+    pgo::launch_batch_scalars(P->g, plan, s);
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    ++n_rounds;
+    bool any_accept = false;
+    for (int c = 0; c < n; ++c) {
+      LmState& L = Ls[c];
+      accept[c] = 0;
+      if (L.terminated) continue;
+      // a pivot that fails inside one component leaves NaNs in that component's step only (nothing crosses components):
+      // its model change is not finite and the step is handled as invalid; the device-wide flag is not consulted
+      const StepScalars sc{out[c].cand_cost, out[c].model_change, out[c].step_norm_sq, out[c].x_norm_sq, out[c].gradient_max, 0, 0, 0};
+      ++L.n_factorizations;
+      if (lm_post_step(L, o, sc, 0) == STEP_ACCEPT) { accept[c] = 1; any_accept = true; }
+    }
+    if (any_accept) {
+      pgo::launch_batch_accept(P->g, plan, s);
+      rc = evaluate_gradient_and_jacobian(P, false);   // every component: the unchanged ones reproduce their values bit for bit
+      if (rc) return rc;
+    }
+  }
+  // gradient norm of the points accepted last (deferred like in the single-problem driver)
+  bool need_g = false;
+  for (int c = 0; c < n; ++c) need_g = need_g || Ls[c].gmax_deferred;
+  if (need_g) {
+    HIP_TRY(hipMemcpyAsync(P->g.pose_c, P->g.pose_x, P->d_pose_x.n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    pgo::launch_batch_scalars(P->g, plan, s);
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  rc = download_poses(P, P->g.pose_x);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(P->d_flags.p, 0, P->d_flags.n * sizeof(int), s));
+  const double t_total = seconds_since(t_begin);
+  for (int c = 0; c < n; ++c) {
+    LmState& L = Ls[c];
+    if (L.gmax_deferred) {
+      L.gmax = out[c].gradient_max;
+      L.cur.gradient_max_norm = L.gmax;
+      if (!L.pending_record && !L.records.empty()) L.records.back().gradient_max_norm = L.gmax;
+      L.gmax_deferred = false;
+    }
+    if (L.pending_record) {
+      if (L.cur.step_is_successful) ++L.num_successful; else ++L.num_unsuccessful;
+      L.cur.trust_region_radius = L.radius;
+      L.records.push_back(L.cur);
+      L.pending_record = false;
+    }
+    if (summaries) {
+      pgo_solver_summary* sm = summaries + c;
+      memset(sm, 0, sizeof *sm);
+      sm->termination_type = L.termination;
+      sm->reason = L.reason;
+      sm->num_successful_steps = L.num_successful;
+      sm->num_unsuccessful_steps = L.num_unsuccessful;
+      sm->num_iterations = (int)L.records.size();
+      sm->num_poses = pose_begin[c + 1] - pose_begin[c];
+      sm->num_edges = edge_begin[c + 1] - edge_begin[c];
+      sm->linear_solver_used = 0;
+      // the factorisation is the union's: fill, levels and flops are those of all components together
+      sm->factor_nnz_blocks = P->front_usable ? (int)std::min<long long>(P->fsym.factor_blocks, 0x7fffffff) : P->dsym.nb;
+      sm->factor_levels = P->front_usable ? P->fsym.n_levels : P->dsym.n_levels;
+      int const_p = 0, const_q = 0;
+      for (int v = pose_begin[c]; v < pose_begin[c + 1]; ++v) { const_p += P->cmask[v] & 1; const_q += (P->cmask[v] >> 1) & 1; }
+      sm->num_parameter_blocks_reduced = 2 * sm->num_poses - const_p - const_q;
+      sm->num_parameters_reduced = 7 * sm->num_poses - 3 * const_p - 4 * const_q;
+      sm->num_effective_parameters_reduced = 6 * sm->num_poses - 3 * const_p - 3 * const_q;
+      sm->factor_kind = P->front_usable ? 2 : 1;
+      sm->factor_max_front = P->front_usable ? P->fsym.max_front : 0;
+      sm->factor_flops = P->front_usable ? P->fsym.flops : P->dsym.flops;
+      sm->num_factorizations = L.n_factorizations;
+      sm->initial_cost = L.initial_cost;
+      sm->final_cost = L.x_cost;
+      sm->total_time_in_seconds = t_total;        // of the whole batch
+      sm->setup_time_in_seconds = t_setup;
+      sm->final_gradient_max_norm = L.gmax;
+      sm->final_trust_region_radius = L.radius;
+      snprintf(sm->message, sizeof sm->message, "%s", L.message.c_str());
+    }
+    if (records) {
+      const int k = std::min(capacity, (int)L.records.size());
+      for (int i = 0; i < k; ++i) records[(size_t)c * capacity + i] = L.records[i];
+    }
+  }
+  if (getenv("PGO_VERBOSE"))
+    std::fprintf(stderr, "[pgo] batch: %d problems, %d poses, %d edges, %d rounds, setup %.2f ms, total %.2f ms\n", n, N, E, n_rounds, 1e3 * t_setup, 1e3 * t_total);
+  HIP_TRY(hipStreamSynchronize(s));   // the component tables below go back to the pool
   return PGO_OK;
 }
 
@@ -1579,6 +1904,20 @@ int pgo_solve(pgo_problem* P, const pgo_solver_options* options, pgo_solver_summ
     if (rc) { P->lm.active = false; return rc; }   // caller memory keeps the poses it came with; the session is closed
   }
   return lm_end(P, summary, records, capacity);
+}
+
+int pgo_release_device_memory(void) {
+  device_pool().trim();
+  return PGO_OK;
+}
+
+int pgo_solve_batch(pgo_problem* const* problems, int n_problems, const pgo_solver_options* options, pgo_solver_summary* summaries,
+                    pgo_iteration_record* records, int capacity) {
+  if (!problems || n_problems <= 0 || !options || (records && capacity < 0)) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_solve_batch");
+  const auto t0 = Clock::now();
+  const int rc = solve_batch(problems, n_problems, options, summaries, records, capacity);
+  if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] batch: call returned after %.2f ms (the union's device memory released)\n", 1e3 * seconds_since(t0));
+  return rc;
 }
 
 int pgo_summary_is_solution_usable(const pgo_solver_summary* s) {

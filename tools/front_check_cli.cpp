@@ -46,6 +46,10 @@ int main(int argc, char** argv) {
     int np = 0, ng = 0, na = 0;
     for (const FrontLaunch& La : S.launches) { np += La.type == FrontLaunch::PANEL; ng += La.type == FrontLaunch::GEMM; na += La.type == FrontLaunch::ASM; }
     std::printf("factor launches: %d panel, %d gemm, %d extend-add; backward launches: %zu\n", np, ng, na, S.bwd_launches.size());
+    if (argv[2][0] == 'd') {   // per-front dump: id c r parent
+      for (int f = 0; f < S.nf; ++f) std::printf("F %d %d %d %d\n", f, S.fronts[f].c, S.fronts[f].r, S.fronts[f].parent);
+      return 0;
+    }
     if (argv[2][0] == 's') return 0;
   }
   // random SPD matrix in slot form: off-diagonal blocks random, diagonal = strictly dominant
