@@ -320,6 +320,31 @@ def main():
                           "factorisation": {1: "enumerated 6x6 pairs", 2: "multifrontal"}.get(last.c.factor_kind, "none"),
                           "cpu_restatement_wall_ms": round(1e3 * ow, 2), "cpu_restatement_iterations": osk.num_iterations - 1,
                           "cpu_restatement_final_cost": osk.final_cost, "speedup_vs_cpu_restatement_1_core": round(ow / walls[2], 2)}
+        # many KITTI-00-scale graphs at once (pgo_solve_batch: one block-diagonal launch sequence, LM decisions per graph):
+        # 16 copies of the replay graph, host buffers in and out, setup included; next to it what 16 calls of pgo_solve cost
+        gk = graphs["kitti00_exact"]
+        opt_k = pkg.SolverOptions(max_num_iterations=1000, linear_solver_type=pkg.SPARSE_NORMAL_CHOLESKY)
+        NB = 16
+        walls, sums = [], None
+        for _ in range(5):
+            pairs = [pkg.problem_from_graph(gk) for _ in range(NB)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sums = pkg.solve_batch(opt_k, [pb for pb, _ in pairs])
+            walls.append(time.perf_counter() - t0)
+        walls.sort()
+        its_b = sum(sb.num_iterations - 1 for sb in sums)
+        one = extra["kitti00_exact"]["wall_ms_median_of_5"] * 1e-3
+        it_phase = walls[2] - sums[0].setup_time_in_seconds
+        extra["kitti00_batch16"] = {
+            "graphs": NB, "poses_each": gk.N, "edges_each": gk.E, "options": extra["kitti00_exact"]["options"],
+            "wall_ms_median_of_5": round(1e3 * walls[2], 3), "wall_ms_min": round(1e3 * walls[0], 3),
+            "setup_ms": round(1e3 * sums[0].setup_time_in_seconds, 3), "ms_per_graph": round(1e3 * walls[2] / NB, 3),
+            "lm_iterations_total": its_b, "lm_iters_per_sec_aggregate": round(its_b / walls[2], 1),
+            "lm_iters_per_sec_iteration_phase": round(its_b / it_phase, 1),
+            "throughput_vs_one_at_a_time": round(NB * one / walls[2], 2),
+            "final_cost_spread": float(max(sb.final_cost for sb in sums) - min(sb.final_cost for sb in sums)),
+            "final_cost": sums[0].final_cost}
         # multifrontal factorisation (FP64 MFMA fronts): C2 and C5 graphs, factor + solve per LM iteration
         fr = {}
         for key, gk in (("c2_manhattan_10k_40k", g), ("c5_sphere_x10_25k_250k", ds.sphere_layers(n_spheres=10, rings=50, per_ring=50, n_edges=250000, seed=20260931))):

@@ -608,6 +608,130 @@ __global__ __launch_bounds__(64) void k_chol_level(DeviceGraph g, DirectPlan p, 
   factor_column(g, p, j, sh);
 }
 
+
+// ---- wide levels (the union of a batched solve: tens of thousands of light columns per level) -------------------------------
+// One 6-lane GROUP per column, ten columns per wave, forty per workgroup: a level of n columns keeps 30 x fewer waves busy
+// than k_chol_level3 (three waves per column — the right shape when a level has a few hundred columns and latency is all that
+// matters).  Lane r of a group owns row r of every block of its column: assembly (the whole update list, in list order),
+// the 6 x 6 factor redundantly in the six lanes (rows exchanged through LDS), scaling, and the fused forward step.
+constexpr int GRP_WAVES = 4;
+__global__ __launch_bounds__(64 * GRP_WAVES) void k_chol_level_grp(DeviceGraph g, DirectPlan p, int level) {
+  __shared__ double sh[GRP_WAVES * 10 * 36];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = lane / 6, r = lane - 6 * grp;
+  const int c0 = p.level_ptr[level], nc = p.level_ptr[level + 1] - c0;
+  const int col = (blockIdx.x * GRP_WAVES + wave) * 10 + grp;
+  const bool on = grp < 10 && col < nc;
+  double* my = sh + (wave * 10 + (grp < 10 ? grp : 0)) * 36;
+  int j = 0, b0 = 0, nblk = 0, old = 0;
+  double v[6];
+  if (on) {
+    j = p.level_cols[c0 + col];
+    b0 = p.col_ptr[j];
+    nblk = p.col_ptr[j + 1] - b0;
+    old = p.perm[j];
+    assemble_row(g, p, b0, r, 0, 1, v);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) my[6 * r + c] = v[c];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  double Ljj[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) Ljj[k] = on ? my[k] : (k % 7 == 0 ? 1.0 : 0.0);
+  const bool ok = chol6_inplace(Ljj);
+  if (on) {
+    if (!ok && r == 0) atomicOr(&g.flags[2], 1);
+    double2* o = reinterpret_cast<double2*>(p.Lval + 36 * (size_t)b0 + 6 * r);
+    o[0] = double2{Ljj[6 * r], Ljj[6 * r + 1]}; o[1] = double2{Ljj[6 * r + 2], Ljj[6 * r + 3]}; o[2] = double2{Ljj[6 * r + 4], Ljj[6 * r + 5]};
+    // off-diagonal blocks: row r of L_ij = (row r of V_ij) L_jj^-T
+    for (int t = 1; t < nblk; ++t) {
+      assemble_row(g, p, b0 + t, r, 0, 1, v);
+      double x[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double t2 = v[c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) t2 -= x[k] * Ljj[6 * c + k];
+        x[c] = t2 / Ljj[7 * c];
+      }
+      double2* ob = reinterpret_cast<double2*>(p.Lval + 36 * (size_t)(b0 + t) + 6 * r);
+      ob[0] = double2{x[0], x[1]}; ob[1] = double2{x[2], x[3]}; ob[2] = double2{x[4], x[5]};
+    }
+    // fused forward step: component r of b_j - sum_k L_jk y_k
+    const double b = g.scale[6 * (size_t)old + r] * g.grad[6 * (size_t)old + r];
+    g.cg_b[6 * (size_t)old + r] = b;
+    double acc = 0.0;
+    for (int q = p.rowl_ptr[j]; q < p.rowl_ptr[j + 1]; ++q) {
+      double a[6];
+      load_row(p.Lval, p.rowl_blk[q], r, a);
+      const double* yk = p.y + 6 * (size_t)p.rowl_col[q];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc += a[c] * yk[c];
+    }
+    my[r] = b - acc;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (on) {
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double t2 = my[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) t2 -= Ljj[6 * i + k] * y[k];
+      y[i] = t2 / Ljj[7 * i];
+    }
+    double out = y[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) out = r == k ? y[k] : out;
+    p.y[6 * (size_t)j + r] = out;
+  }
+}
+
+// backward level, one group per column: lane c owns component c of y_j - sum_i L_ij^T x_i
+__global__ __launch_bounds__(64 * GRP_WAVES) void k_bwd_level_grp(DeviceGraph g, DirectPlan p, int level) {
+  __shared__ double sh[GRP_WAVES * 10 * 6];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = lane / 6, c = lane - 6 * grp;
+  const int c0 = p.level_ptr[level], nc = p.level_ptr[level + 1] - c0;
+  const int col = (blockIdx.x * GRP_WAVES + wave) * 10 + grp;
+  const bool on = grp < 10 && col < nc;
+  double* my = sh + (wave * 10 + (grp < 10 ? grp : 0)) * 6;
+  int j = 0, b0 = 0;
+  if (on) {
+    j = p.level_cols[c0 + col];
+    b0 = p.col_ptr[j];
+    const int nblk = p.col_ptr[j + 1] - b0;
+    double acc = 0.0;
+    for (int t = 1; t < nblk; ++t) {
+      const double* B = p.Lval + 36 * (size_t)(b0 + t);
+      const double* xi = p.y + 6 * (size_t)p.blk_row[b0 + t];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc += B[6 * k + c] * xi[k];
+    }
+    my[c] = p.y[6 * (size_t)j + c] - acc;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (on) {
+    const double* L = p.Lval + 36 * (size_t)b0;
+    double x[6];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      double t2 = my[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; ++k) t2 -= L[6 * k + i] * x[k];
+      x[i] = t2 / L[7 * i];
+    }
+    double out = x[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) out = c == k ? x[k] : out;
+    p.y[6 * (size_t)j + c] = out;
+    g.cg_x[6 * (size_t)p.perm[j] + c] = out;
+  }
+}
+
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_tail(DeviceGraph g, DirectPlan p, int from_level, int to_level) {
   __shared__ double sh[FUSED_WAVES][360];
   const int wave = threadIdx.x >> 6;
@@ -895,7 +1019,10 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
       // three waves per column by default (every COLUMN level of KITTI-00 gains 1-4 us); PGO_DIRECT_ROLES=<columns per level
       // up to which they are used>, 0 = one wave per column
       static const int roles_max = getenv("PGO_DIRECT_ROLES") ? atoi(getenv("PGO_DIRECT_ROLES")) : (1 << 30);
-      if (nc <= roles_max) hipLaunchKernelGGL(k_chol_level3, dim3(nc), dim3(192), 0, s, g, p, st.level_begin);
+      // wide levels (batched solves): one 6-lane group per column from PGO_DIRECT_GROUPS columns on (default 4096)
+      static const int grp_min = getenv("PGO_DIRECT_GROUPS") ? atoi(getenv("PGO_DIRECT_GROUPS")) : 4096;
+      if (nc >= grp_min) hipLaunchKernelGGL(k_chol_level_grp, dim3((nc + 10 * GRP_WAVES - 1) / (10 * GRP_WAVES)), dim3(64 * GRP_WAVES), 0, s, g, p, st.level_begin);
+      else if (nc <= roles_max) hipLaunchKernelGGL(k_chol_level3, dim3(nc), dim3(192), 0, s, g, p, st.level_begin);
       else hipLaunchKernelGGL(k_chol_level, dim3(nc), dim3(64), 0, s, g, p, st.level_begin);
     } else if (st.type == DirectStep::FUSED) {
       hipLaunchKernelGGL(k_chol_tail, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, st.level_begin, st.level_end);
@@ -926,7 +1053,9 @@ void launch_direct_solve(const DeviceGraph& g, const DirectPlan& p, const int* l
   }
   for (int l = fused_from_level - 1; l >= 0; --l) {
     const int nc = level_ptr_host[l + 1] - level_ptr_host[l];
-    if (bwd4) hipLaunchKernelGGL(k_bwd_level4, dim3(nc), dim3(64 * BWD_WAVES), 0, s, g, p, l);
+    static const int grp_min = getenv("PGO_DIRECT_GROUPS") ? atoi(getenv("PGO_DIRECT_GROUPS")) : 4096;
+    if (nc >= grp_min) hipLaunchKernelGGL(k_bwd_level_grp, dim3((nc + 10 * GRP_WAVES - 1) / (10 * GRP_WAVES)), dim3(64 * GRP_WAVES), 0, s, g, p, l);
+    else if (bwd4) hipLaunchKernelGGL(k_bwd_level4, dim3(nc), dim3(64 * BWD_WAVES), 0, s, g, p, l);
     else hipLaunchKernelGGL(k_bwd_level, dim3(nc), dim3(64), 0, s, g, p, l);
   }
 }
