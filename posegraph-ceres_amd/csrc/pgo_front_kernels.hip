@@ -420,6 +420,11 @@ __global__ __launch_bounds__(320) void k_front_panel(FrontPlan p, int wg_begin, 
 // Launches with few tiles (the top of the tree) use 32 x 32 tiles, one 16 x 16 tile per wave: a wave's K loop is bound by
 // the matrix pipe (~61 ns per instruction), so a quarter of the tile per wave is a quarter of the time, and the extra
 // workgroups are free on a mostly idle chip.
+// Measured in isolation (tools/bench/gemm_bench.hip, one 4096 x 4096 x K job): 25 TFLOP/s at K = 192 (the outer-panel
+// updates), 32-33 at K >= 768 (Schur updates of wide fronts) = the rate of one wave per SIMD issuing v_mfma_f64_16x16x4
+// back to back (61 ns each).  A 128 x 128 tile with 64 x 32 per wave (6 fragment loads per 16 instructions instead of 5 per
+// 8, prologue and read-modify-write epilogue amortised over four times the tile) measured the same 25 / 33: operand
+// delivery is not what bounds this kernel, the matrix pipe's issue rate is; it was not kept.
 template <int NQ>
 struct GemmFrag { double2 a[2], b[NQ][2]; };
 
@@ -489,6 +494,7 @@ __global__ __launch_bounds__(256) void k_front_gemm(FrontPlan p, int wg_begin) {
     }
   }
 }
+
 
 // ---- backward substitution --------------------------------------------------------------------------------------------
 // Phase A: t = y_c - L21^T x_r for 64 columns of one front; 512 lanes = 64 columns x 8 row groups.  t is parked in p.x at the
