@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_assemble4(DeviceGraph g
 // the step is resident at once (<= SPLIT_FUSED_MAX blocks), so a waiting workgroup cannot keep its producer off the chip;
 // a wait that runs out sets the failure flag instead of hanging.
 constexpr int SPLIT_FUSED_MAX = 1024;
-__global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_split(DeviceGraph g, DirectPlan p, int blk_begin, int epoch) {
+__global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_split(DeviceGraph g, DirectPlan p, int blk_begin, int epoch, int max_spins) {
   __shared__ double sh[ASM_WAVES][360];
   __shared__ double shf[ASM_WAVES][64];
   __shared__ double Ld[36];
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_split(DeviceGraph g, Di
     if (lane == 0) {
       int spins = 0;
       while (__hip_atomic_load(&p.col_flag[dblk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-        if (++spins > (1 << 22)) { atomicOr(&g.flags[2], 2); break; }
+        if (++spins > max_spins) { atomicOr(&g.flags[2], 2); break; }
         __builtin_amdgcn_s_sleep(1);
       }
     }
@@ -1031,7 +1031,11 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
       else hipLaunchKernelGGL(k_chol_assemble, dim3(st.blk_end - st.blk_begin), dim3(64), 0, s, g, p, st.blk_begin);
       hipLaunchKernelGGL(k_chol_panel, dim3(st.sub_end), dim3(64 * FUSED_WAVES), 0, s, g, p, st.sub_begin, st.level_end - st.level_begin);
     } else if (epoch > 0 && st.blk_end - st.blk_begin <= fuse_split_max) {
-      hipLaunchKernelGGL(k_chol_split, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin, epoch);
+      // bounded wait (PGO_DIRECT_SPLIT_SPINS, default 2^22 polls ~ 1 s): when it runs out — the workgroups of the step were
+      // not all resident, e.g. on a partitioned or shared GPU — the solve is flagged and the LM driver repeats the
+      // factorisation in the two-launch form (epoch 0) and keeps to it for this problem
+      static const int max_spins = getenv("PGO_DIRECT_SPLIT_SPINS") ? atoi(getenv("PGO_DIRECT_SPLIT_SPINS")) : (1 << 22);
+      hipLaunchKernelGGL(k_chol_split, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin, epoch, max_spins);
     } else {
       if (asm4) hipLaunchKernelGGL(k_chol_assemble4, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin);
       else hipLaunchKernelGGL(k_chol_assemble, dim3(st.blk_end - st.blk_begin), dim3(64), 0, s, g, p, st.blk_begin);

@@ -257,6 +257,7 @@ struct pgo_problem {
   bool direct_analyzed = false, direct_usable = false;
   DevBuf<int> dd_split_blk, dd_split_sub, dd_split_sub_diag, dd_upd_split, dd_panel_cols, dd_blk_lpos, dd_split_dblk, dd_col_flag;
   int direct_epoch = 0;
+  bool split_two_launch = false;   // a single-launch SPLIT step timed out once: this problem keeps to the two-launch form
   DevBuf<uint8_t> dd_split_diag;
   DevBuf<int> dd_perm, dd_col_ptr, dd_blk_row, dd_asrc_ptr, dd_asrc_slot, dd_upd_ptr, dd_upd_a, dd_upd_b, dd_level_ptr,
       dd_level_cols, dd_rowl_ptr, dd_rowl_blk, dd_rowl_col;
@@ -1042,7 +1043,7 @@ int run_direct(pgo_problem* P) {
     HIP_TRY(hipGraphLaunch(P->direct_exec, s));
   } else {
     if (++P->direct_epoch == 0x7fffffff) { P->direct_epoch = 1; HIP_TRY(P->dd_col_flag.zero(s)); }
-    pgo::launch_direct_factor(P->g, P->dplan, S, s, P->direct_epoch);
+    pgo::launch_direct_factor(P->g, P->dplan, S, s, P->split_two_launch ? 0 : P->direct_epoch);
     pgo::launch_direct_solve(P->g, P->dplan, S.level_ptr.data(), S.fused_from_level, s);
   }
   return PGO_OK;
@@ -1366,6 +1367,19 @@ int lm_advance(pgo_problem* P) {
     if (rc) return rc;
     rc = wait_handoff(P);
     if (rc) return rc;
+    if ((P->scal->linearize_bad & 4) && !P->front_usable && !P->split_two_launch) {
+      // a single-launch SPLIT step waited in vain for a column's diagonal block (its workgroups were not all resident):
+      // not a numerical failure — repeat this factorisation in the two-launch form and keep to it
+      P->split_two_launch = true;
+      if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: single-launch SPLIT step timed out; two-launch form from now on\n");
+      arm_handoff(P);
+      rc = run_direct(P);
+      if (rc) return rc;
+      rc = enqueue_tail(P, nullptr);
+      if (rc) return rc;
+      rc = wait_handoff(P);
+      if (rc) return rc;
+    }
     ++L.n_factorizations;
     if (hybrid) { ++L.hybrid_direct_run; ++L.hybrid_direct; }
   }
@@ -1519,6 +1533,7 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
   if (rc) return rc;
   if (!P->direct_usable || P->dsym.hybrid)
     return set_error(PGO_ERR_UNSUPPORTED, "pgo_solve_batch: the union of the problems is beyond the factorisation's budget; solve them one by one");
+  P->split_two_launch = true;   // the device-wide failure flag is not consulted per component: no in-kernel waits in a batch
   rc = prepare_clusters(P, 1);
   if (rc) return rc;
   hipStream_t s = P->stream;
@@ -2107,6 +2122,13 @@ int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const do
     if (rc) return rc;
     pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s);
     HIP_TRY(hipStreamSynchronize(s));
+    if ((P->scal->linearize_bad & 4) && !P->front_usable && !P->split_two_launch) {   // SPLIT wait ran out: two-launch form (lm_advance)
+      P->split_two_launch = true;
+      rc = run_direct(P);
+      if (rc) return rc;
+      pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s);
+      HIP_TRY(hipStreamSynchronize(s));
+    }
     if (P->scal->linearize_bad) status = 2;
   } else {
     P->opt.cg_residual_reset_period = options->cg_residual_reset_period;   // launch_cg_batch reads the refresh period from P->opt

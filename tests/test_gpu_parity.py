@@ -1,5 +1,7 @@
 """-m gpu parity tests: the HIP path (through the C ABI of include/pgo.h) against the CPU oracle on the
 same seeded inputs.  Tolerances are stated per test; everything is FP64."""
+import os
+
 import numpy as np
 import pytest
 
@@ -461,3 +463,23 @@ def test_evaluation_entry_points_are_refused_during_a_session(gpu, ds):
     assert s2.final_cost == ref.final_cost and np.array_equal(poses, poses2)
     cost, *_ = prob2.evaluate()            # allowed again after solver_end
     assert cost == pytest.approx(s2.final_cost, rel=1e-12)
+
+
+def test_split_step_timeout_falls_back_to_two_launches(gpu, O, ds, monkeypatch):
+    """The single-launch SPLIT steps of the 6x6-block factorisation wait in-kernel for a column's diagonal block.  With the
+    wait budget forced to zero (PGO_DIRECT_SPLIT_SPINS=0: what a GPU that cannot keep the step's work-groups resident looks
+    like) the solve must not fail: the driver repeats the factorisation in the two-launch form and the LM trace is the
+    oracle's (same accept / reject sequence, costs 1e-7)."""
+    monkeypatch.setenv("PGO_DIRECT_SPLIT_SPINS", "0")
+    monkeypatch.setenv("PGO_FRONT", "0")
+    k = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti00.npz"))
+    g = ds.PoseGraphData(k["origin"], k["ia"], k["ib"], k["meas"], None)
+    prob, poses = gpu.problem_from_graph(g)
+    s = gpu.solve(gpu.SolverOptions(max_num_iterations=8, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY), prob)
+    og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
+    _, osum, otr = O.solve(og, O.default_options(max_num_iterations=8, linear_solver=0))
+    assert s.linear_solver_used == 0 and s.c.factor_kind == 1
+    n = min(len(otr), len(s.iterations))
+    assert n == len(otr) == len(s.iterations)
+    assert list(s.iterations["step_is_successful"][:n]) == [int(v) for v in otr[:n, 8]]
+    assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-7)

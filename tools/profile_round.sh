@@ -21,6 +21,7 @@ for c in c2 c5; do
 done
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/front_mfma -o m -- python tools/front_prof.py c5 3 > $OUT/front_mfma.log 2>&1
 python tools/rocprof_mfma.py $OUT/front_mfma/m_results.db $OUT/${TAG}_front_c5_mfma_pmc.json > $OUT/front_mfma_summary.log 2>&1
+cp $OUT/${TAG}_pmc.json profiles/ 2>/dev/null   # on this box only: the final bench run quotes the traffic measured above, on these very sources
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -n 3 $OUT/pmc.log $OUT/front_mfma_summary.log $OUT/front_c2.log $OUT/front_c5.log
 # then, in the build container: cp gpurun_out/<tag>/<tag>_* profiles/ (gpurun merges only gpurun_out/ back)
