@@ -483,3 +483,28 @@ def test_split_step_timeout_falls_back_to_two_launches(gpu, O, ds, monkeypatch):
     assert n == len(otr) == len(s.iterations)
     assert list(s.iterations["step_is_successful"][:n]) == [int(v) for v in otr[:n, 8]]
     assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-7)
+
+
+@pytest.mark.parametrize("name,exact", [("manhattan1000", True), ("sphere2x20", True), ("manhattan2000", True), ("manhattan1000", False)])
+def test_traces_to_convergence_match_oracle(gpu, O, ds, name, exact):
+    """The WHOLE trust-region trajectory, not its first iterations: the reference's options (max 300 iterations, default
+    tolerances) until the minimizer stops by itself — same number of iterations (40 / 18 / 60 with exact steps, 64 with
+    truncated PCG), same accept / reject decision at every one, same stopping reason, costs to 1e-8 relative along the way
+    (measured 1e-12 exact, 4e-11 PCG), final poses to 1e-7 (exact steps) / 1e-5 (truncated PCG: 2e-6 measured — the inexact
+    steps leave the flat directions of the graph to the rounding of the CG recurrences)."""
+    g = {"manhattan1000": lambda: ds.manhattan_se3(1000, 3500, seed=17),
+         "sphere2x20": lambda: ds.sphere_layers(n_spheres=2, rings=20, per_ring=20),
+         "manhattan2000": lambda: ds.manhattan_se3(2000, 8000, seed=3)}[name]()
+    prob, poses = gpu.problem_from_graph(g)
+    ls, cl = (gpu.SPARSE_NORMAL_CHOLESKY, 1) if exact else (gpu.BLOCK_JACOBI_PCG, 2)
+    s = gpu.solve(gpu.SolverOptions(max_num_iterations=300, linear_solver_type=ls, pcg_cluster_poses=cl), prob)
+    og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
+    oposes, osum, otr = O.solve(og, O.default_options(max_num_iterations=300, linear_solver=0 if exact else 1, pcg_cluster=cl))
+    assert len(s.iterations) == len(otr) and 15 < len(otr) < 300
+    assert list(s.iterations["step_is_successful"]) == [int(v) for v in otr[:, 8]]
+    assert np.allclose(s.iterations["cost"], otr[:, 1], rtol=1e-8)
+    assert s.termination_type == gpu.CONVERGENCE and s.termination_type == osum.termination_type
+    assert s.final_cost == pytest.approx(osum.final_cost, rel=1e-9)
+    assert np.abs(poses - oposes).max() <= (1e-7 if exact else 1e-5)
+    if not exact:
+        assert s.num_linear_solver_iterations == osum.num_linear_iterations
