@@ -164,7 +164,7 @@ struct CgParams {
 };
 
 // launches (all asynchronous on `s`)
-void launch_linearize(const DeviceGraph& g, hipStream_t s);
+void launch_linearize(const DeviceGraph& g, hipStream_t s, int gate = 0);   // gate: run only once the CG has stopped (speculative launch behind a step tail)
 void launch_scale_from_diag(const DeviceGraph& g, hipStream_t s);
 void launch_damping(const DeviceGraph& g, double radius, double min_diag, double max_diag, int mode, hipStream_t s);
 void launch_cost(const DeviceGraph& g, const double* poses, int part_row, hipStream_t s, int gate = 0);

@@ -145,9 +145,12 @@ __device__ __forceinline__ WBlocks load_W_blockdiag(const double* W, size_t stri
 // K_linearize: residual + closed-form Jacobians + Huber corrector + J^T J / J^T r, fused.
 // INFO: 0 identity information, 1 general W, 2 block-diagonal W.  0 and 2 write the packed 27-entry slots (pgo_kernels.h).
 // ------------------------------------------------------------------------------------------------
+// gate: a speculative launch behind the step tail of a CG batch (the linearisation of the candidate point into the spare buffers)
+// runs only once the CG has stopped, like the tail itself.
 template <int INFO>
-__global__ __launch_bounds__(256) void k_linearize(DeviceGraph g) {
+__global__ __launch_bounds__(256) void k_linearize(DeviceGraph g, int gate) {
   extern __shared__ double lds[];  // NV_LIN * block
+  if (gate && !g.cg->done) return;
   const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
   const int s_begin = g.wg_slot_begin[wg], s_end = g.wg_slot_begin[wg + 1];
   const int r0 = g.wg_row_begin[wg], nrows = g.wg_row_begin[wg + 1] - r0;
@@ -1471,11 +1474,11 @@ __global__ void k_copy_delta(DeviceGraph g, const double* step) {
 // ------------------------------------------------------------------------------------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-void launch_linearize(const DeviceGraph& g, hipStream_t s) {
+void launch_linearize(const DeviceGraph& g, hipStream_t s, int gate) {
   const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);
-  if (g.info_mode == 2) hipLaunchKernelGGL(k_linearize<2>, dim3(g.n_wg), dim3(g.block), lds, s, g);
-  else if (g.info_mode) hipLaunchKernelGGL(k_linearize<1>, dim3(g.n_wg), dim3(g.block), lds, s, g);
-  else hipLaunchKernelGGL(k_linearize<0>, dim3(g.n_wg), dim3(g.block), lds, s, g);
+  if (g.info_mode == 2) hipLaunchKernelGGL(k_linearize<2>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
+  else if (g.info_mode) hipLaunchKernelGGL(k_linearize<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
+  else hipLaunchKernelGGL(k_linearize<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
 }
 void launch_scale_from_diag(const DeviceGraph& g, hipStream_t s) {
   hipLaunchKernelGGL(k_scale_from_diag, dim3(cdiv(6 * g.N, 256)), dim3(256), 0, s, g);

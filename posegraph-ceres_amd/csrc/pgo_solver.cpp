@@ -241,6 +241,10 @@ struct pgo_problem {
       d_scale, d_d2, d_diagc, d_cg_b, d_cg_x, d_cg_r, d_cg_z, d_cg_q, d_cg_p0, d_cg_p1, d_delta, d_part_rz, d_part_q,
       d_part_rr, d_part_bb, d_part_misc, d_tmp_a, d_tmp_b, d_tmp_c;
   DevBuf<pgo::CgState> d_cg;
+  // spare set of the linearisation (blocks, diagonal blocks, gradient): the candidate point is linearised into it right behind
+  // the step tail, before the host has decided; an accepted step swaps the sets (one rank, eager enqueue)
+  DevBuf<double> d_bsr2, d_Hdiag2, d_grad2;
+  bool spec_ready = false;
   pgo::LmScalars* scal = nullptr;  // pinned, device visible
   // captured CG batches, keyed by the number of iterations in the batch
   struct CapturedBatch { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
@@ -584,6 +588,7 @@ int prepare(pgo_problem* P) {
   HIP_TRY(P->d_pose_0.alloc((size_t)pgo::POSE_STRIDE * N));
   HIP_TRY(P->d_bsr.alloc((size_t)n_slots * 36));
   HIP_TRY(P->d_bsr.zero(s));
+  P->spec_ready = false;     // the spare linearisation set follows the new sizes when it is next needed
   HIP_TRY(P->d_Hdiag.alloc((size_t)36 * NP));
   HIP_TRY(P->d_Hdiag.zero(s));
   HIP_TRY(P->d_Minv.alloc((size_t)36 * NP * 4 + (size_t)world * 144 * 4));   // room for 4-pose clusters of every rank, padded
@@ -1168,6 +1173,41 @@ void terminate(LmState& L, int termination, int reason, const char* fmt, ...) {
   L.message = buf;
 }
 
+// ---- speculative linearisation -----------------------------------------------------------------------------------------
+// Between the step tail and the re-linearisation of an accepted point the GPU used to wait for the host (hand-off, decision,
+// launch: 11-16 us of the 130-300 us LM iteration of Manhattan 10 k).  The candidate is therefore linearised at once, behind the
+// tail, into a spare set of buffers; the host decides meanwhile.  Accepted (the usual case): the sets are swapped, nothing
+// is recomputed.  Rejected: the current set was never touched.  Same kernel, same inputs: results are bit-identical.
+// One rank (the exchange of the diagonal blocks would have to ride along), eager enqueue (captured batches hold pointers).
+int ensure_spec_buffers(pgo_problem* P) {
+  if (P->spec_ready) return PGO_OK;
+  hipStream_t s = P->stream;
+  HIP_TRY(P->d_bsr2.alloc(P->d_bsr.n));
+  HIP_TRY(P->d_bsr2.zero(s));
+  HIP_TRY(P->d_Hdiag2.alloc(P->d_Hdiag.n));
+  HIP_TRY(P->d_Hdiag2.zero(s));
+  HIP_TRY(P->d_grad2.alloc(P->d_grad.n));
+  HIP_TRY(P->d_grad2.zero(s));
+  P->spec_ready = true;
+  return PGO_OK;
+}
+bool speculation_on(const pgo_problem* P) {
+  static const bool off = getenv("PGO_NO_SPECULATION") && getenv("PGO_NO_SPECULATION")[0] == '1';
+  return !off && P->g.world == 1 && !P->use_graph && !(P->comm && P->comm->world > 1);
+}
+struct SpareSet { double *bsr, *Hdiag, *grad; };
+inline SpareSet spare_set(pgo_problem* P) {
+  const bool primary_in_use = P->g.bsr_val == P->d_bsr.p;
+  return primary_in_use ? SpareSet{P->d_bsr2.p, P->d_Hdiag2.p, P->d_grad2.p} : SpareSet{P->d_bsr.p, P->d_Hdiag.p, P->d_grad.p};
+}
+void launch_speculative_linearize(pgo_problem* P, int gate) {
+  pgo::DeviceGraph gs = P->g;
+  const SpareSet sp = spare_set(P);
+  gs.pose_x = P->g.pose_c;
+  gs.bsr_val = sp.bsr; gs.Hdiag = sp.Hdiag; gs.grad = sp.grad;
+  pgo::launch_linearize(gs, P->stream, gate);
+}
+
 // ---- the host half of one TrustRegionMinimizer pass (SURVEY.md A.6 step 7 order), shared by the single-problem driver and
 // the batched one (one LmState per component there): pure bookkeeping on LmState, no device work ----
 // What the device hands back after a trial step.
@@ -1324,6 +1364,9 @@ int lm_advance(pgo_problem* P) {
                  (L.hybrid_direct_run >= 1 && L.hybrid_fail_radius > 0.0 && L.radius < 0.1 * L.hybrid_fail_radius)))
     use_direct = false;
   int wasted_cg = 0;
+  const bool spec = speculation_on(P);
+  bool spec_in_flight = false;   // the candidate's linearisation was enqueued behind the tail that produced the scalars read below
+  if (spec) { rc = ensure_spec_buffers(P); if (rc) return rc; }
   arm_handoff(P);
   if (!use_direct) {
     // every batch carries the gated tail: the host hears back once per batch and finds the step scalars ready
@@ -1336,9 +1379,14 @@ int lm_advance(pgo_problem* P) {
       rc = launch_cg_batch(P, run_prm, nb, true, enqueued + 1);
       enqueued += nb;
       if (rc) return rc;
+      // the speculative launch costs an early-exit launch (~3.5 us) in a batch the CG does not finish in and saves the
+      // host gap (~12 us) in the one it does: skipped in a first batch shorter than the previous solve's iteration count
+      spec_in_flight = spec && (round > 0 || P->last_cg_iterations <= nb);
+      if (spec_in_flight) launch_speculative_linearize(P, 1);
       rc = wait_handoff(P);
       if (rc) return rc;
       if (P->scal->cg_status != -1) break;
+      spec_in_flight = false;      // gated out: the CG was still running
       arm_handoff(P);
     }
     if (hybrid) {
@@ -1365,6 +1413,8 @@ int lm_advance(pgo_problem* P) {
     if (rc) return rc;
     rc = enqueue_tail(P, nullptr);
     if (rc) return rc;
+    spec_in_flight = spec;
+    if (spec) launch_speculative_linearize(P, 0);
     rc = wait_handoff(P);
     if (rc) return rc;
     if ((P->scal->linearize_bad & 4) && !P->front_usable && !P->split_two_launch) {
@@ -1377,6 +1427,7 @@ int lm_advance(pgo_problem* P) {
       if (rc) return rc;
       rc = enqueue_tail(P, nullptr);
       if (rc) return rc;
+      if (spec) launch_speculative_linearize(P, 0);
       rc = wait_handoff(P);
       if (rc) return rc;
     }
@@ -1393,8 +1444,14 @@ int lm_advance(pgo_problem* P) {
   if (action == STEP_ACCEPT) {
     // HandleSuccessfulStep (device half): x <- candidate, re-linearise
     std::swap(P->g.pose_x, P->g.pose_c);
-    rc = evaluate_gradient_and_jacobian(P, false);
-    if (rc) return rc;
+    if (spec_in_flight) {   // the candidate was linearised behind the tail: its set becomes the current one
+      const SpareSet sp = spare_set(P);
+      P->g.bsr_val = sp.bsr; P->g.Hdiag = sp.Hdiag; P->g.grad = sp.grad;
+      pgo::launch_gradient_norm(P->g, s);
+    } else {
+      rc = evaluate_gradient_and_jacobian(P, false);
+      if (rc) return rc;
+    }
   }
   L.t_total += seconds_since(t_it);
   return PGO_OK;
