@@ -317,7 +317,7 @@ def main():
                           "setup_ms": round(1e3 * last.setup_time_in_seconds, 3), "lm_iterations": its,
                           "ms_per_lm_iteration": round(1e3 * (walls[2] - last.setup_time_in_seconds) / its, 4),
                           "lm_iters_per_sec": round(its / walls[2], 1), "final_cost": last.final_cost,
-                          "factorisation": {1: "enumerated 6x6 pairs", 2: "multifrontal"}.get(last.c.factor_kind, "none"),
+                          "factorisation": {1: "enumerated 6x6 pairs", 2: "multifrontal", 3: "multifrontal, fronts in LDS"}.get(last.c.factor_kind, "none"),
                           "cpu_restatement_wall_ms": round(1e3 * ow, 2), "cpu_restatement_iterations": osk.num_iterations - 1,
                           "cpu_restatement_final_cost": osk.final_cost, "speedup_vs_cpu_restatement_1_core": round(ow / walls[2], 2)}
         # many KITTI-00-scale graphs at once (pgo_solve_batch: one block-diagonal launch sequence, LM decisions per graph):

@@ -115,7 +115,8 @@ typedef struct pgo_solver_summary {
   double final_trust_region_radius;
   char message[256];
   int factor_kind;              /* 0 no factorisation, 1 enumerated 6x6 block pairs (pgo_direct), 2 supernodal multifrontal
-                                   with FP64 MFMA fronts (pgo_front) */
+                                   with FP64 MFMA fronts (pgo_front), 3 supernodal multifrontal with every front in the LDS of
+                                   one workgroup (chain-like graphs) */
   int factor_max_front;         /* multifrontal: largest dense front (scalars) */
   double factor_flops;          /* flops of one numeric factorisation */
   int num_parameter_blocks_reduced;     /* FullReport's Reduced column: constant blocks removed */

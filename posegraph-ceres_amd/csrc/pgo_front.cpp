@@ -11,6 +11,7 @@
 #include "pgo_front.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
@@ -30,11 +31,19 @@ double env_or(const char* name, double dflt) {
 
 bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib, int n_slots,
                    const std::vector<int>& slot_row, const std::vector<int>& slot_col,
-                   const std::vector<uint8_t>& slot_side, long long max_bytes, FrontSymbolic* out) {
+                   const std::vector<uint8_t>& slot_side, long long max_bytes, FrontSymbolic* out, int small_max) {
   FrontSymbolic& S = *out;
   S = FrontSymbolic();
   S.n = N;
   if (N <= 0) return false;
+  const bool verbose = getenv("PGO_VERBOSE") != nullptr;
+  auto t_phase = std::chrono::steady_clock::now();
+  auto phase = [&](const char* what) {
+    if (!verbose) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[pgo] front analysis: %-30s %.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_phase).count());
+    t_phase = now;
+  };
   // ---- 1. ordering + adjacency in that ordering ----
   std::vector<int> perm0;
   if (!nested_dissection_order(N, ia, ib, &perm0)) return false;
@@ -57,12 +66,13 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
       aidx[fill[b]++] = a;
     }
   }
+  phase("ordering + adjacency");
   // ---- 2. column structures through the elimination tree (only the sizes and the parents are kept) ----
   std::vector<int> parent(N, -1), st_len(N, 0), nchild(N, 0);
   {
-    std::vector<std::vector<int>> st(N);
-    std::vector<std::vector<int>> children(N);
-    std::vector<int> mark(N, -1), tmp;
+    // flat storage (column j's structure at st_idx[st_ptr[j] .. st_ptr[j + 1])), children as sibling lists: no per-column heap blocks
+    std::vector<int> st_ptr(N + 1, 0), st_idx, first_child(N, -1), next_sibling(N, -1), mark(N, -1), tmp;
+    st_idx.reserve((size_t)4 * N);
     for (int j = 0; j < N; ++j) {
       tmp.clear();
       mark[j] = j;
@@ -70,20 +80,24 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
         const int i = aidx[p];
         if (i > j && mark[i] != j) { mark[i] = j; tmp.push_back(i); }
       }
-      for (int c : children[j]) {
-        for (int i : st[c]) if (i > j && mark[i] != j) { mark[i] = j; tmp.push_back(i); }
-        std::vector<int>().swap(st[c]);   // a child's structure is needed by its parent only
-      }
+      for (int c = first_child[j]; c >= 0; c = next_sibling[c])
+        for (int q = st_ptr[c]; q < st_ptr[c + 1]; ++q) {
+          const int i = st_idx[q];
+          if (i > j && mark[i] != j) { mark[i] = j; tmp.push_back(i); }
+        }
       st_len[j] = (int)tmp.size();
       if (!tmp.empty()) {
         const int par = *std::min_element(tmp.begin(), tmp.end());
         parent[j] = par;
-        children[par].push_back(j);
+        next_sibling[j] = first_child[par];
+        first_child[par] = j;
         ++nchild[par];
       }
-      st[j].swap(tmp);
+      st_idx.insert(st_idx.end(), tmp.begin(), tmp.end());
+      st_ptr[j + 1] = (int)st_idx.size();
     }
   }
+  phase("column structures");
   // ---- 3. fundamental supernodes ----
   std::vector<int> sn_start;
   sn_start.push_back(0);
@@ -106,6 +120,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
     members[s].push_back(s);
   }
   for (int s = 0; s < ns0; ++s) if (sparent[s] >= 0) kids[sparent[s]].push_back(s);
+  phase("supernodes");
   // ---- 4. relaxed amalgamation (parents have larger indices than their children) ----
   const double zfrac = env_or("PGO_FRONT_ZFRAC", 0.25);
   const long long small = (long long)env_or("PGO_FRONT_SMALL", 8);
@@ -131,6 +146,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
     }
     kids[p].swap(keep);
   }
+  phase("amalgamation");
   // ---- 5. postorder renumbering of the amalgamated tree ----
   std::vector<int> post;   // supernodes (old ids) in postorder
   post.reserve(ns0);
@@ -177,6 +193,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
   std::vector<int> colf(N);           // postorder front id of each new column
   for (int k = 0; k < nf; ++k) for (int j = first[k]; j < first[k] + ccount[k]; ++j) colf[j] = k;
   // adjacency in the new numbering (old vertex -> neighbours), reuse aptr/aidx through newidx
+  phase("postorder");
   // ---- 6. row structures in the new numbering ----
   std::vector<std::vector<int>> R(nf);
   std::vector<std::vector<int>> fkids(nf);
@@ -199,6 +216,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
       if (!tmp.empty() && colf[tmp[0]] != fparent[k]) return false;   // tree consistency
     }
   }
+  phase("row structures");
   // ---- 7. levels (leaves first); fronts renumbered level by level, fronts with children last inside a level ----
   std::vector<int> level(nf, 0);
   int n_levels = 1;
@@ -260,6 +278,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
       std::fprintf(stderr, "[pgo] front: %.2f GB of fronts exceed the budget of %.2f GB\n", 8e-9 * (double)S.fval_size, 1e-9 * (double)max_bytes);
     return false;
   }
+  phase("levels + fronts");
   // ---- 8. child -> parent maps ----
   for (int f = 0; f < nf; ++f) {
     FrontDesc& D = S.fronts[f];
@@ -298,6 +317,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
   if (S.rel.empty()) S.rel.push_back(0);
   if (S.idx.empty()) S.idx.push_back(0);
   if (S.child.empty()) S.child.push_back(0);
+  phase("child maps");
   // ---- 9. BSR sources per front block ----
   {
     struct Ent { long long key; int slot; };
@@ -325,7 +345,17 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
       if (bi >= 32768 || bj >= 65536) return false;
       ents.push_back(Ent{((long long)f << 32) | ((long long)bi << 16) | bj, t});
     }
-    std::sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key != b.key ? a.key < b.key : a.slot < b.slot; });
+    {   // order by (front, block row, block column, slot): bucket by front (the fronts' entries are few), then sort each bucket
+      std::vector<int> fptr(nf + 1, 0);
+      for (const Ent& en : ents) ++fptr[(int)(en.key >> 32) + 1];
+      for (int f = 0; f < nf; ++f) fptr[f + 1] += fptr[f];
+      std::vector<Ent> sorted(ents.size());
+      std::vector<int> fill(fptr.begin(), fptr.end() - 1);
+      for (const Ent& en : ents) sorted[fill[(int)(en.key >> 32)]++] = en;
+      for (int f = 0; f < nf; ++f)
+        std::sort(sorted.begin() + fptr[f], sorted.begin() + fptr[f + 1], [](const Ent& a, const Ent& b) { return a.key != b.key ? a.key < b.key : a.slot < b.slot; });
+      ents.swap(sorted);
+    }
     S.ablk_ptr.push_back(0);
     for (size_t e = 0; e < ents.size(); ++e) {
       if (e == 0 || ents[e].key != ents[e - 1].key) {
@@ -337,13 +367,6 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
     }
     S.ablk_ptr.push_back((int)ents.size());
   }
-  // ---- 10. schedule: rounds over the whole tree, not level by level ----
-  // A front runs the chain  [extend-add] -> panel 0 -> [GEMM] -> panel 1 -> ... ; it may start as soon as ITS children are
-  // done.  Every round issues up to three launches — extend-add, panel, GEMM — each carrying the next phase of every front
-  // that is ready for it, whatever its tree level.  The number of rounds is the longest chain of panel steps from a leaf to
-  // the root (Manhattan 10 k: 69 instead of the 133 a level-by-level schedule needs; sphere x10: 248 instead of 508), and
-  // the chain, not the flops, is what bounds these factorisations.  The backward substitution is scheduled the same way from
-  // the root down.
   S.levels.resize(n_levels);
   {
     int f = 0;
@@ -353,6 +376,95 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
       S.levels[l].front_end = f;
     }
   }
+  phase("slot sources");
+  // ---- 9b. small fronts only: compact storage, one launch per level, no schedule ----
+  if (small_max > 0 && S.max_front <= small_max) {
+    S.small = true;
+    S.sfronts.resize(nf);
+    long long lb = 0, ub = 0, wb = 0;
+    S.urel.clear();
+    for (int f = 0; f < nf; ++f) {
+      const FrontDesc& D = S.fronts[f];
+      const int c6 = 6 * D.c, r6 = 6 * D.r;
+      const long long ucnt = D.parent >= 0 ? (long long)r6 * (r6 + 1) / 2 + r6 : 0;
+      S.sfronts[f] = SFront{(int)lb, (int)ub, (int)ucnt, (int)S.urel.size(), 0, 0, 0, (int)wb};
+      lb += ((long long)(c6 + r6 + 1) * c6 + 1) / 2 * 2;
+      ub += (ucnt + 1) / 2 * 2;
+      wb += (long long)c6 * c6;
+      if (D.parent < 0) continue;
+      const int* rel = S.rel.data() + D.rel_begin;
+      for (int t = 0; t < D.r; ++t) for (int a = 0; a < 6; ++a) S.urel.push_back(6 * rel[t] + a);   // parent column of column 6 t + a
+    }
+    // extend-add as a gather per PARENT ROW: the rows of the children's packed update matrices that land in it, in child order
+    // (one 8-lane group walks a parent row's list: fixed order, no two groups touch the same row, one barrier in all)
+    S.cr_ptr.clear();
+    S.cr_ent.clear();
+    {
+      std::vector<int> cnt;
+      for (int f = 0; f < nf; ++f) {
+        const FrontDesc& D = S.fronts[f];
+        const int n = 6 * (D.c + D.r);
+        S.sfronts[f].cr_base = (int)S.cr_ptr.size();
+        cnt.assign(n + 2, 0);
+        for (int ci = D.child_begin; ci < D.child_end; ++ci) {
+          const FrontDesc& C = S.fronts[S.child[ci]];
+          const int* rel = S.rel.data() + C.rel_begin;
+          for (int t = 0; t < C.r; ++t) for (int a = 0; a < 6; ++a) ++cnt[6 * rel[t] + a + 1];
+          ++cnt[n + 1];
+        }
+        for (int R = 0; R <= n; ++R) cnt[R + 1] += cnt[R];
+        const int base = (int)(S.cr_ent.size() / 3);
+        for (int R = 0; R <= n + 1; ++R) S.cr_ptr.push_back(base + cnt[R]);
+        S.cr_ent.resize(S.cr_ent.size() + 3 * (size_t)cnt[n + 1]);
+        std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+        for (int ci = D.child_begin; ci < D.child_end; ++ci) {
+          const int ch = S.child[ci];
+          const FrontDesc& C = S.fronts[ch];
+          const int rc6 = 6 * C.r;
+          const int* rel = S.rel.data() + C.rel_begin;
+          for (int i = 0; i <= rc6; ++i) {
+            const int R = i < rc6 ? 6 * rel[i / 6] + i % 6 : n;
+            int* e = S.cr_ent.data() + 3 * (size_t)(base + fill[R]++);
+            e[0] = S.sfronts[ch].ubase + (i < rc6 ? i * (i + 1) / 2 : rc6 * (rc6 + 1) / 2);
+            e[1] = S.sfronts[ch].urel;
+            e[2] = i < rc6 ? i + 1 : rc6;
+          }
+        }
+      }
+      if (S.cr_ent.empty()) S.cr_ent.assign(3, 0);
+    }
+    if (S.urel.empty()) S.urel.push_back(0);
+    if (lb > 0x7fffffffLL || ub > 0x7fffffffLL || wb > 0x7fffffffLL) return false;
+    S.sl_size = std::max(2LL, lb);
+    S.su_size = std::max(2LL, ub);
+    S.sw_size = std::max(2LL, wb);
+    S.osrc.assign(S.ablk_front.size() + 1, -1);
+    for (size_t a = 0; a < S.ablk_front.size(); ++a)
+      if (S.ablk_ptr[a + 1] - S.ablk_ptr[a] == 1) {
+        const int slot = S.ablk_slot[S.ablk_ptr[a]];
+        if (slot < (1 << 28)) S.osrc[a] = slot | ((int)slot_side[slot] << 28);
+      }
+    const int na = (int)S.ablk_front.size();
+    for (int a = 0; a < na; ++a) {       // ablk entries are sorted by front
+      SFront& F = S.sfronts[S.ablk_front[a]];
+      if (F.ablk_end == F.ablk_begin) F.ablk_begin = a;
+      F.ablk_end = a + 1;
+    }
+    phase("small-front plan");
+    S.n_launches = 2 * n_levels + 2;
+    S.est_us = 8.0 * S.n_launches;
+    if (getenv("PGO_VERBOSE"))
+      std::fprintf(stderr, "[pgo] front: n=%d supernodes %d -> %d small fronts (largest %d scalars), %d levels = %d launches, %.3g flops\n", N, ns0, nf,
+                   S.max_front, n_levels, S.n_launches, flops);
+    return true;
+  }
+  // ---- 10. schedule: rounds over the whole tree, not level by level ----
+  // A front runs the chain  [extend-add] -> panel 0 -> [GEMM] -> panel 1 -> ... ; it may start as soon as ITS children are
+  // done.  Every round issues up to three launches — extend-add, panel, GEMM — each carrying the next phase of every front
+  // that is ready for it, whatever its tree level.  The number of rounds is the longest chain of panel steps from a leaf to
+  // the root (Manhattan 10 k: 69 instead of the 133 a level-by-level schedule needs; sphere x10: 248 instead of 508), and
+  // the chain, not the flops, is what bounds these factorisations.  The backward substitution is scheduled the same way from
+  // the root down.
   const long long tile32_below = (long long)env_or("PGO_FRONT_TILE32_BELOW", 192);
   {
     std::vector<int> next_step(nf, 0), nsteps(nf), kids_left(nf), pending(nf, -1);

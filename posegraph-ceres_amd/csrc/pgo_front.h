@@ -88,6 +88,34 @@ struct FrontDesc {
   int pad;
 };
 
+// ---- small fronts (chain-like graphs: every front of KITTI-00 has at most 84 scalars) -------------------------------------
+// When no front exceeds SFRONT_MAX scalars the whole front lives in the LDS of one workgroup, and a tree level is ONE launch:
+// zero + original entries + right-hand side, extend-add of the children's update matrices, blocked (6 columns = one pose)
+// right-looking Cholesky with the 6 x 6 pivot block factorised redundantly in registers, then the L panel and the update
+// matrix go to compact global arrays.  The backward substitution is one launch per level as well.  No 48-column panels, no
+// GEMM launches, no round schedule.
+enum { SFRONT_MAX = 96 };
+struct SFront {
+  int lbase;        // L panel: (n + 1) x c6 row-major (row n = y) at Lval + lbase
+  int ubase, ucnt;  // update matrix, PACKED: the lower triangle of the r6 x r6 block row by row (row i at i (i + 1) / 2), then the
+                    // right-hand side row (r6 entries) at r6 (r6 + 1) / 2
+  int urel;         // urel[urel + j], j < r6: the parent's column that receives column j of the update matrix
+  int cr_base;      // as a parent: cr_ptr[cr_base + R .. + R + 1), R <= n: the rows of its children's update matrices that are
+                    // added to its row R, in child order, each {offset in Uval, offset in urel, length} in cr_ent
+  int ablk_begin, ablk_end;   // the front's range of ablk_* entries
+  int wbase;        // W = L11^-1, c6 x c6 row-major lower triangular at Wval + wbase (backward substitution = two gemv)
+};
+struct SFrontPlan {
+  const SFront* sf;   // [nf]
+  const int* urel;    // see SFront::urel
+  const int* cr_ptr;  // see SFront::cr_base
+  const int* cr_ent;
+  const int* osrc;    // [n_ablk] the one BSR slot of an original block | side << 28, or -1 (several slots: ablk_ptr / ablk_slot)
+  double* Lval;
+  double* Uval;
+  double* Wval;
+};
+
 struct FrontPlan {
   int n, nf;
   const int* perm;          // [n] new -> old
@@ -135,16 +163,25 @@ struct FrontSymbolic {
   double est_us = 0;         // rough time estimate of factor + solve (launch floor + flops), microseconds
   int max_front = 0;         // largest front dimension (scalars)
   int n_launches = 0;
+  // small-front path (every front <= SFRONT_MAX scalars): per-front storage offsets, no launch schedule
+  bool small = false;
+  std::vector<SFront> sfronts;
+  std::vector<int> urel, osrc, cr_ptr, cr_ent;
+  long long sl_size = 0, su_size = 0, sw_size = 0;   // doubles of Lval / Uval / Wval
 };
 
 // Host analysis.  Returns false when the fronts would not fit the memory budget (bytes).
+// small_max > 0: when no front exceeds that many scalars the analysis stops at the small-front plan (out->small).
 bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib, int n_slots,
                    const std::vector<int>& slot_row, const std::vector<int>& slot_col,
-                   const std::vector<uint8_t>& slot_side, long long max_bytes, FrontSymbolic* out);
+                   const std::vector<uint8_t>& slot_side, long long max_bytes, FrontSymbolic* out, int small_max = 0);
 
 // Device launches: factorisation (includes the forward substitution) and backward substitution into g.cg_x.
 // flags[2] is set when a pivot is not positive.
 void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s);
 void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s);
+// the small-front path: one launch per tree level each
+void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s);
+void launch_sfront_solve(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s);
 
 }  // namespace pgo

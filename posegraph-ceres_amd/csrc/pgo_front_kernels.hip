@@ -648,6 +648,234 @@ __global__ __launch_bounds__(BWD_T) void k_front_bwd_block(DeviceGraph g, FrontP
   }
 }
 
+
+// ---- small fronts: the whole front in LDS, one launch per tree level (pgo_front.h) -------------------------------------------
+constexpr int SF_T = 256;
+
+__global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan p, SFrontPlan sp, int front_begin, int dbg) {
+  extern __shared__ double F[];     // (n + 1) x ld, ld = n + 1 (n is a multiple of 6: the stride is odd)
+  const int f = front_begin + blockIdx.x, tid = threadIdx.x;
+  const FrontDesc D = p.fronts[f];
+  const SFront S = sp.sf[f];
+  const int c6 = 6 * D.c, r6 = 6 * D.r, n = c6 + r6, ld = n + 1;
+  // original entries H~ + D^2 (lower blocks; a diagonal block comes whole) and the right-hand side S g: fetched first, the
+  // LDS is cleared while the loads are in flight
+  constexpr int OMAX = 6;            // 256 lanes x 6 entries: fronts of up to 42 original blocks in one pass
+  double ov[OMAX];
+  int op[OMAX];
+  const int no = (S.ablk_end - S.ablk_begin) * 36;
+#pragma unroll
+  for (int u = 0; u < OMAX; ++u) {
+    const int e = tid + u * SF_T;
+    ov[u] = 0.0;
+    op[u] = -1;
+    if (e < no) {
+      const int a = S.ablk_begin + e / 36, k = e % 36;
+      const int src = sp.osrc[a];
+      double s = 0.0;
+      if (src >= 0) s = bsr_elem(g, src & 0x0fffffff, src >> 28, k);
+      else for (int q = p.ablk_ptr[a]; q < p.ablk_ptr[a + 1]; ++q) { const int slot = p.ablk_slot[q]; s += bsr_elem(g, slot, g.slot_side[slot], k); }
+      const int pos = p.ablk_pos[a], bi = pos >> 16, bj = pos & 0xffff;
+      ov[u] = s;
+      op[u] = (6 * bi + k / 6) * ld + 6 * bj + k % 6;
+    }
+  }
+  double rhs = 0.0;
+  if (tid < c6) {
+    const size_t io = 6 * (size_t)p.perm[D.first + tid / 6] + tid % 6;
+    rhs = g.scale[io] * g.grad[io];
+    g.cg_b[io] = rhs;
+  }
+  for (int e = tid; e < (n + 1) * ld; e += SF_T) F[e] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < OMAX; ++u) if (op[u] >= 0) F[op[u]] = ov[u];
+  for (int e = tid + OMAX * SF_T; e < no; e += SF_T) {       // (fronts with more original blocks than one pass holds)
+    const int a = S.ablk_begin + e / 36, k = e % 36;
+    double s = 0.0;
+    for (int q = p.ablk_ptr[a]; q < p.ablk_ptr[a + 1]; ++q) { const int slot = p.ablk_slot[q]; s += bsr_elem(g, slot, g.slot_side[slot], k); }
+    const int pos = p.ablk_pos[a], bi = pos >> 16, bj = pos & 0xffff;
+    F[(6 * bi + k / 6) * ld + 6 * bj + k % 6] = s;
+  }
+  if (tid < c6) F[n * ld + tid] = rhs;
+  __syncthreads();
+  // extend-add, gathered per row of this front: an 8-lane group walks the list of child rows that land in its row (child
+  // order: fixed summation order, no atomics; no two groups share a row, so one barrier serves all children)
+  if (!(dbg & 2)) {
+    const int* rp = sp.cr_ptr + S.cr_base;
+    for (int R = tid >> 3; R <= n; R += SF_T >> 3) {
+      double* row = F + R * ld;
+      for (int q = rp[R]; q < rp[R + 1]; ++q) {
+        const int* en = sp.cr_ent + 3 * (size_t)q;
+        const double* U = sp.Uval + en[0];
+        const int* pcol = sp.urel + en[1];
+        const int len = en[2];
+        for (int jj = tid & 7; jj < len; jj += 8) row[pcol[jj]] += U[jj];
+      }
+    }
+    __syncthreads();
+  }
+  // right-looking Cholesky of the c6 own columns, one pose (6 columns) per step: the 6 x 6 pivot block is factorised by every
+  // lane for itself (registers), the rows below are scaled one per lane, then the trailing lower triangle is updated
+  bool bad = false;
+  for (int kb = 0; kb < ((dbg & 1) ? 0 : c6); kb += 6) {
+    double L[21], inv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = F[(kb + i) * ld + kb + j];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double d = L[c * (c + 1) / 2 + c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) d = fma(-L[c * (c + 1) / 2 + k], L[c * (c + 1) / 2 + k], d);
+      if (!(d > 0.0)) { bad = true; d = 1.0; }
+      const double h = half_rsqrt_nr(d);
+      inv[c] = h + h;
+      L[c * (c + 1) / 2 + c] = d * inv[c];
+#pragma unroll
+      for (int i = c + 1; i < 6; ++i) {
+        double s = L[i * (i + 1) / 2 + c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) s = fma(-L[i * (i + 1) / 2 + k], L[c * (c + 1) / 2 + k], s);
+        L[i * (i + 1) / 2 + c] = s * inv[c];
+      }
+    }
+    const int below = n + 1 - (kb + 6);            // rows kb + 6 .. n (row n: the right-hand side -> y)
+    for (int t = tid; t < below; t += SF_T) {
+      double* row = F + (kb + 6 + t) * ld + kb;
+      double x[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double s = row[c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) s = fma(-x[k], L[c * (c + 1) / 2 + k], s);
+        x[c] = s * inv[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) row[c] = x[c];
+    }
+    if (tid == SF_T - 1) {                         // the factor of the pivot block itself (read back by the write-out below)
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) F[(kb + i) * ld + kb + j] = L[i * (i + 1) / 2 + j];
+    }
+    __syncthreads();
+    const int mt = n - (kb + 6);                   // trailing columns; rows: mt + 1 (with the right-hand side)
+    for (int ii = tid >> 3; ii <= mt; ii += SF_T >> 3) {       // 8 lanes share a row, strided over its columns
+      const double* a = F + (kb + 6 + ii) * ld + kb;
+      const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
+      const int jmax = ii < mt ? ii : mt - 1;
+      for (int jj = tid & 7; jj <= jmax; jj += 8) {
+        const double* b = F + (kb + 6 + jj) * ld + kb;
+        F[(kb + 6 + ii) * ld + kb + 6 + jj] -= a0 * b[0] + a1 * b[1] + a2 * b[2] + a3 * b[3] + a4 * b[4] + a5 * b[5];
+      }
+    }
+    __syncthreads();
+  }
+  if (bad && tid == 0) atomicOr(&g.flags[2], 1);
+  // the update matrix first (the parent's launch is next in line), then the L panel (rows 0 .. n, the last one is y)
+  if (dbg & 4) return;
+  if (S.ucnt > 0) {
+    double* Ug = sp.Uval + S.ubase;
+    for (int ii = tid >> 3; ii <= r6; ii += SF_T >> 3) {
+      const int e0 = ii < r6 ? ii * (ii + 1) / 2 : r6 * (r6 + 1) / 2;
+      const int jmax = ii < r6 ? ii : r6 - 1;
+      const double* row = F + (c6 + ii) * ld + c6;
+      for (int jj = tid & 7; jj <= jmax; jj += 8) Ug[e0 + jj] = row[jj];
+    }
+  }
+  double* Lg = sp.Lval + S.lbase;
+  for (int i = tid / 64; i <= n; i += SF_T / 64)
+    for (int j = tid & 63; j < c6; j += 64) Lg[i * c6 + j] = F[i * ld + j];
+}
+
+// W = L11^-1 of every front at once (nothing of the factorisation waits for it), by 6 x 6 blocks: block row i of W needs the
+// block rows above it, W_ij = -W_ii sum_{k = j}^{i - 1} L_ik W_kj, all its entries side by side (two barriers per block row).
+__global__ __launch_bounds__(SF_T) void k_sfront_invert(FrontPlan p, SFrontPlan sp) {
+  extern __shared__ double sh[];     // L11: c6 x ld | W: c6 x ld | T: 6 x ld
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const FrontDesc D = p.fronts[f];
+  const SFront S = sp.sf[f];
+  const int c6 = 6 * D.c, ld = c6 + 1;
+  double* Ls = sh;
+  double* Ws = sh + c6 * ld;
+  double* Ts = Ws + c6 * ld;
+  const double* Lg = sp.Lval + S.lbase;
+  for (int e = tid; e < c6 * c6; e += SF_T) { const int i = e / c6, j = e - i * c6; Ls[i * ld + j] = j <= i ? Lg[e] : 0.0; Ws[i * ld + j] = 0.0; }
+  __syncthreads();
+  for (int ib = 0; ib < c6; ib += 6) {
+    // T = sum_k L[ib.., k] W[k, 0 .. ib): entry (r, c), c < ib
+    for (int e = tid; e < 6 * ib; e += SF_T) {
+      const int r = e / ib, c = e - r * ib;
+      double s = 0.0;
+      for (int k = c - c % 6; k < ib; ++k) s = fma(Ls[(ib + r) * ld + k], Ws[k * ld + c], s);     // W[k][c] = 0 for k < c's block start
+      Ts[r * ld + c] = s;
+    }
+    // the diagonal block of W: inverse of the 6 x 6 lower triangle, one lane per column
+    if (tid < 6) {
+      const int q = tid;
+      double w[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        double s = r == q ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) s = k >= q ? fma(-Ls[(ib + r) * ld + ib + k], w[k], s) : s;
+        w[r] = r >= q ? s / Ls[(ib + r) * ld + ib + r] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) Ws[(ib + r) * ld + ib + q] = w[r];
+    }
+    __syncthreads();
+    for (int e = tid; e < 6 * ib; e += SF_T) {
+      const int r = e / ib, c = e - r * ib;
+      double s = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) s = fma(Ws[(ib + r) * ld + ib + m], Ts[m * ld + c], s);
+      Ws[(ib + r) * ld + c] = -s;
+    }
+    __syncthreads();
+  }
+  double* Wg = sp.Wval + S.wbase;
+  for (int e = tid; e < c6 * c6; e += SF_T) { const int i = e / c6, j = e - i * c6; Wg[e] = Ws[i * ld + j]; }
+}
+
+// backward substitution of one level (parents first): t = y_c - L21^T x_r, x_c = W^T t
+__global__ __launch_bounds__(SF_T) void k_sfront_bwd(DeviceGraph g, FrontPlan p, SFrontPlan sp, int front_begin) {
+  __shared__ double xr[SFRONT_MAX], tv[SFRONT_MAX], red[SF_T];
+  const int f = front_begin + blockIdx.x, tid = threadIdx.x;
+  const FrontDesc D = p.fronts[f];
+  const SFront S = sp.sf[f];
+  const int c6 = 6 * D.c, r6 = 6 * D.r, n = c6 + r6;
+  const double* Lg = sp.Lval + S.lbase;
+  const double* Wg = sp.Wval + S.wbase;
+  for (int i = tid; i < r6; i += SF_T) xr[i] = p.x[6 * (size_t)p.idx[D.idx_begin + i / 6] + i % 6];
+  __syncthreads();
+  const int parts = SF_T / c6, j = tid % c6, part = tid / c6;    // c6 <= 96: at least two lanes per column
+  double s = 0.0;
+  if (part < parts) for (int i = part; i < r6; i += parts) s += Lg[(size_t)(c6 + i) * c6 + j] * xr[i];
+  red[tid] = s;
+  __syncthreads();
+  if (tid < c6) {
+    double tot = 0.0;
+    for (int q = 0; q < parts; ++q) tot += red[q * c6 + tid];
+    tv[tid] = Lg[(size_t)n * c6 + tid] - tot;
+  }
+  __syncthreads();
+  s = 0.0;
+  if (part < parts) for (int i = j + part; i < c6; i += parts) s += Wg[(size_t)i * c6 + j] * tv[i];     // (W^T t)_j = sum_{i >= j} W[i][j] t[i]
+  red[tid] = s;
+  __syncthreads();
+  if (tid < c6) {
+    double x = 0.0;
+    for (int q = 0; q < parts; ++q) x += red[q * c6 + tid];
+    const int col = D.first + tid / 6;
+    p.x[6 * (size_t)col + tid % 6] = x;
+    g.cg_x[6 * (size_t)p.perm[col] + tid % 6] = x;
+  }
+}
+
 }  // namespace
 
 void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s) {
@@ -673,6 +901,33 @@ void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSym
     if (La.n_wg <= 0) continue;
     if (La.kind == 0) hipLaunchKernelGGL(k_front_bwd_gemv, dim3(La.n_wg), dim3(BWD_T), (size_t)La.lds_bytes, s, p, La.wg_begin);
     else hipLaunchKernelGGL(k_front_bwd_block, dim3(La.n_wg), dim3(BWD_T), 0, s, g, p, La.wg_begin);
+  }
+}
+
+
+void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s) {
+  static bool attr_set = false;
+  const size_t lds_max = (size_t)(SFRONT_MAX + 1) * (SFRONT_MAX + 1) * sizeof(double);
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sfront_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sfront_invert), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((2 * (size_t)SFRONT_MAX + 6) * (SFRONT_MAX + 1) * sizeof(double)));
+    attr_set = true;
+  }
+  const size_t lds = (size_t)(sym.max_front + 1) * (sym.max_front + 1) * sizeof(double);
+  static const int dbg = getenv("PGO_SF_DBG") ? atoi(getenv("PGO_SF_DBG")) : 0;   // timing ablations (results are wrong with any bit set)
+  for (const FrontLevel& L : sym.levels)
+    if (L.front_end > L.front_begin)
+      hipLaunchKernelGGL(k_sfront_factor, dim3(L.front_end - L.front_begin), dim3(SF_T), lds, s, g, p, sp, L.front_begin, dbg);
+  int c6max = 0;
+  for (const FrontDesc& D : sym.fronts) c6max = std::max(c6max, 6 * D.c);
+  hipLaunchKernelGGL(k_sfront_invert, dim3(sym.nf), dim3(SF_T), (2 * (size_t)c6max + 6) * (c6max + 1) * sizeof(double), s, p, sp);
+}
+
+void launch_sfront_solve(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s) {
+  for (int l = (int)sym.levels.size() - 1; l >= 0; --l) {
+    const FrontLevel& L = sym.levels[l];
+    if (L.front_end > L.front_begin) hipLaunchKernelGGL(k_sfront_bwd, dim3(L.front_end - L.front_begin), dim3(SF_T), 0, s, g, p, sp, L.front_begin);
   }
 }
 

@@ -272,6 +272,11 @@ struct pgo_problem {
   pgo::FrontSymbolic fsym;
   pgo::FrontPlan fplan{};
   bool front_usable = false;
+  bool sfront_usable = false;      // every front fits the LDS: one launch per tree level (pgo_front.h, SFRONT_MAX)
+  pgo::SFrontPlan splan{};
+  DevBuf<pgo::SFront> ds_sf;
+  DevBuf<double> ds_L, ds_U, ds_W;
+  DevBuf<int> ds_urel, ds_osrc, ds_cr_ptr, ds_cr_ent;
   DevBuf<int> df_perm, df_idx, df_child, df_rel, df_cstart, df_col_front, df_ablk_ptr, df_ablk_slot, df_ablk_front, df_ablk_pos, df_wg_job, df_wg_tile,
       df_bwd_front, df_bwd_chunk, df_bwdb_front, df_bwdb_chunk, df_asm_tile, df_asm_contrib;
   DevBuf<pgo::FrontDesc> df_fronts;
@@ -559,7 +564,7 @@ int prepare(pgo_problem* P) {
   const bool w_blockdiag = P->has_info && w_has_pr.load() == 0;
   lap("measurement / W arrays");
   P->h_slot_row = slot_row; P->h_slot_col = slot_col; P->h_slot_side = slot_side; P->h_row_slot_begin = row_slot_begin;
-  P->direct_analyzed = false; P->direct_usable = false; P->front_usable = false; P->cluster_built = 0; P->g.cluster = 1;
+  P->direct_analyzed = false; P->direct_usable = false; P->front_usable = false; P->sfront_usable = false; P->cluster_built = 0; P->g.cluster = 1;
   HIP_TRY(P->d_slot_col.upload(slot_col, s));
   HIP_TRY(P->d_slot_row.upload(slot_row, s));
   HIP_TRY(P->d_slot_side.upload(slot_side, s));
@@ -874,14 +879,14 @@ int prepare_clusters(pgo_problem* P, int CL) {
 
 // ---- exact solver: GPU block-sparse Cholesky (pgo_direct.*) ----
 // Multifrontal solver: host analysis (front_analyzed_ok) and, once chosen, plan upload (front_usable).
-int analyze_front(pgo_problem* P, bool* ok) {
+int analyze_front(pgo_problem* P, bool* ok, int small_max = 0) {
   pgo::FrontSymbolic& S = P->fsym;
   const auto t_an = Clock::now();
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   const char* cap = getenv("PGO_FRONT_MAX_GB");
   const long long budget = cap ? (long long)(atof(cap) * 1e9) : (long long)(0.6 * (double)free_b);
-  *ok = pgo::front_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side, budget, &S);
+  *ok = pgo::front_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side, budget, &S, small_max);
   if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] front: symbolic analysis %.2f ms (%s)\n", 1e3 * seconds_since(t_an), *ok ? "usable" : "declined");
   return PGO_OK;
 }
@@ -928,11 +933,46 @@ int upload_front(pgo_problem* P) {
   return PGO_OK;
 }
 
+int upload_sfront(pgo_problem* P) {
+  pgo::FrontSymbolic& S = P->fsym;
+  const auto t_up = Clock::now();
+  hipStream_t s = P->stream;
+  HIP_TRY(P->df_perm.upload(S.perm, s));
+  HIP_TRY(P->df_idx.upload(S.idx, s));
+  HIP_TRY(P->df_child.upload(S.child, s));
+  HIP_TRY(P->df_rel.upload(S.rel, s));
+  HIP_TRY(P->df_ablk_ptr.upload(S.ablk_ptr, s));
+  HIP_TRY(P->df_ablk_slot.upload(S.ablk_slot, s));
+  HIP_TRY(P->df_ablk_pos.upload(S.ablk_pos, s));
+  HIP_TRY(P->df_fronts.upload(S.fronts, s));
+  HIP_TRY(P->ds_sf.upload(S.sfronts, s));
+  HIP_TRY(P->ds_urel.upload(S.urel, s));
+  HIP_TRY(P->ds_cr_ptr.upload(S.cr_ptr, s));
+  HIP_TRY(P->ds_cr_ent.upload(S.cr_ent, s));
+  HIP_TRY(P->ds_osrc.upload(S.osrc, s));
+  HIP_TRY(P->ds_L.alloc((size_t)S.sl_size));
+  HIP_TRY(P->ds_U.alloc((size_t)S.su_size));
+  HIP_TRY(P->ds_W.alloc((size_t)S.sw_size));
+  HIP_TRY(P->df_x.alloc((size_t)6 * S.n));
+  HIP_TRY(P->df_x.zero(s));
+  pgo::FrontPlan& f = P->fplan;
+  f = pgo::FrontPlan{};
+  f.n = S.n; f.nf = S.nf;
+  f.perm = P->df_perm.p; f.fronts = P->df_fronts.p; f.idx = P->df_idx.p; f.child = P->df_child.p; f.rel = P->df_rel.p;
+  f.ablk_ptr = P->df_ablk_ptr.p; f.ablk_slot = P->df_ablk_slot.p; f.ablk_pos = P->df_ablk_pos.p; f.n_ablk = (int)S.ablk_front.size();
+  f.x = P->df_x.p;
+  P->splan = pgo::SFrontPlan{P->ds_sf.p, P->ds_urel.p, P->ds_cr_ptr.p, P->ds_cr_ent.p, P->ds_osrc.p, P->ds_L.p, P->ds_U.p, P->ds_W.p};
+  P->sfront_usable = true;
+  if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] front: small-front plan upload %.2f ms\n", 1e3 * seconds_since(t_up));
+  return PGO_OK;
+}
+
 int prepare_direct(pgo_problem* P) {
   if (P->direct_analyzed) return PGO_OK;
   P->direct_analyzed = true;
   P->direct_usable = false;
   P->front_usable = false;
+  P->sfront_usable = false;
   const char* off = getenv("PGO_NO_DIRECT");
   if (off && off[0] == '1') return PGO_OK;
   if (P->comm && P->comm->world > 1) return PGO_OK;   // the factorisation needs every row: sharded runs use PCG to 1e-13
@@ -948,7 +988,23 @@ int prepare_direct(pgo_problem* P) {
   bool front_ok = false;
   // a trajectory with a few chords (KITTI-00 replay: 1.14 edges per pose) is the enumerated schedule's case: its analysis runs
   // first there and the multifrontal one is skipped (one-shot solves pay every millisecond of host analysis)
-  bool pair_first_done = false, usable = false;
+  bool pair_first_done = false, usable = false, front_done = false;
+  // PGO_SFRONT=1: graphs whose fronts all fit the LDS of one workgroup (<= 96 scalars: chain-like graphs, KITTI-00 replay 84) use
+  // the small-front plan — one launch per tree level (pgo_front.h).  Opt-in: measured on KITTI-00 it is 2-4 % faster per LM
+  // iteration than the enumerated schedule (0.455 vs 0.47 ms) but its analysis costs 0.3 ms more, and a batched union of such
+  // graphs is slower with it (one 58 KB workgroup per front: 37 vs 25 ms for 16 graphs) — DESIGN.md section 6.
+  const char* sfe = getenv("PGO_SFRONT");
+  const int sf_mode = (sfe && sfe[0] == '1') ? 1 : 0;
+  if (front_mode != 0 && sf_mode == 1) {
+    const int rc = analyze_front(P, &front_ok, pgo::SFRONT_MAX);
+    if (rc) return rc;
+    front_done = true;
+    if (front_ok && P->fsym.small) {
+      S = pgo::DirectSymbolic();
+      P->direct_usable = true;
+      return upload_sfront(P);
+    }
+  }
   if (front_mode < 0 && (double)P->g.E < 1.5 * (double)P->g.N) {
     const auto t_an = Clock::now();
     usable = pgo::direct_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side,
@@ -957,8 +1013,10 @@ int prepare_direct(pgo_problem* P) {
     pair_first_done = true;
   }
   if (front_mode != 0 && !(pair_first_done && usable && !S.hybrid)) {
-    const int rc = analyze_front(P, &front_ok);
-    if (rc) return rc;
+    if (!front_done) {
+      const int rc = analyze_front(P, &front_ok);
+      if (rc) return rc;
+    }
     if (front_ok && (front_mode == 1 || P->fsym.max_front > front_min)) {
       S = pgo::DirectSymbolic();
       P->direct_usable = true;
@@ -1028,6 +1086,11 @@ int prepare_direct(pgo_problem* P) {
 // factorise (H~ + D^2) and solve for cg_x = (H~ + D^2)^-1 S g; the launch sequence is static -> one hipGraph
 int run_direct(pgo_problem* P) {
   hipStream_t s = P->stream;
+  if (P->sfront_usable) {
+    pgo::launch_sfront_factor(P->g, P->fplan, P->splan, P->fsym, s);
+    pgo::launch_sfront_solve(P->g, P->fplan, P->splan, P->fsym, s);
+    return PGO_OK;
+  }
   if (P->front_usable) {
     pgo::launch_front_factor(P->g, P->fplan, P->fsym, s);
     pgo::launch_front_solve(P->g, P->fplan, P->fsym, s);
@@ -1417,7 +1480,7 @@ int lm_advance(pgo_problem* P) {
     if (spec) launch_speculative_linearize(P, 0);
     rc = wait_handoff(P);
     if (rc) return rc;
-    if ((P->scal->linearize_bad & 4) && !P->front_usable && !P->split_two_launch) {
+    if ((P->scal->linearize_bad & 4) && !P->front_usable && !P->sfront_usable && !P->split_two_launch) {
       // a single-launch SPLIT step waited in vain for a column's diagonal block (its workgroups were not all resident):
       // not a numerical failure — repeat this factorisation in the two-launch form and keep to it
       P->split_two_launch = true;
@@ -1492,8 +1555,9 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
     summary->num_edges = P->g.E;
     const bool want_exact = P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY;
     summary->linear_solver_used = want_exact ? (P->direct_usable ? (P->dsym.hybrid ? 3 : 0) : 2) : 1;
-    summary->factor_nnz_blocks = (want_exact && P->direct_usable) ? (P->front_usable ? (int)std::min<long long>(P->fsym.factor_blocks, 0x7fffffff) : P->dsym.nb) : 0;
-    summary->factor_levels = (want_exact && P->direct_usable) ? (P->front_usable ? P->fsym.n_levels : P->dsym.n_levels) : 0;
+    const bool fronts = P->front_usable || P->sfront_usable;
+    summary->factor_nnz_blocks = (want_exact && P->direct_usable) ? (fronts ? (int)std::min<long long>(P->fsym.factor_blocks, 0x7fffffff) : P->dsym.nb) : 0;
+    summary->factor_levels = (want_exact && P->direct_usable) ? (fronts ? P->fsym.n_levels : P->dsym.n_levels) : 0;
     {
       int const_p = 0, const_q = 0;
       for (uint8_t m : P->cmask) { const_p += m & 1; const_q += (m >> 1) & 1; }
@@ -1501,9 +1565,9 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
       summary->num_parameters_reduced = 7 * P->g.N - 3 * const_p - 4 * const_q;
       summary->num_effective_parameters_reduced = 6 * P->g.N - 3 * const_p - 3 * const_q;
     }
-    summary->factor_kind = (want_exact && P->direct_usable) ? (P->front_usable ? 2 : 1) : 0;
-    summary->factor_max_front = (want_exact && P->front_usable) ? P->fsym.max_front : 0;
-    summary->factor_flops = (want_exact && P->direct_usable) ? (P->front_usable ? P->fsym.flops : P->dsym.flops) : 0.0;
+    summary->factor_kind = (want_exact && P->direct_usable) ? (P->sfront_usable ? 3 : P->front_usable ? 2 : 1) : 0;
+    summary->factor_max_front = (want_exact && fronts) ? P->fsym.max_front : 0;
+    summary->factor_flops = (want_exact && P->direct_usable) ? (fronts ? P->fsym.flops : P->dsym.flops) : 0.0;
     summary->num_factorizations = L.n_factorizations;
     summary->initial_cost = L.initial_cost;
     summary->final_cost = L.x_cost;
@@ -1728,16 +1792,17 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
       sm->num_edges = edge_begin[c + 1] - edge_begin[c];
       sm->linear_solver_used = 0;
       // the factorisation is the union's: fill, levels and flops are those of all components together
-      sm->factor_nnz_blocks = P->front_usable ? (int)std::min<long long>(P->fsym.factor_blocks, 0x7fffffff) : P->dsym.nb;
-      sm->factor_levels = P->front_usable ? P->fsym.n_levels : P->dsym.n_levels;
+      const bool fronts = P->front_usable || P->sfront_usable;
+      sm->factor_nnz_blocks = fronts ? (int)std::min<long long>(P->fsym.factor_blocks, 0x7fffffff) : P->dsym.nb;
+      sm->factor_levels = fronts ? P->fsym.n_levels : P->dsym.n_levels;
       int const_p = 0, const_q = 0;
       for (int v = pose_begin[c]; v < pose_begin[c + 1]; ++v) { const_p += P->cmask[v] & 1; const_q += (P->cmask[v] >> 1) & 1; }
       sm->num_parameter_blocks_reduced = 2 * sm->num_poses - const_p - const_q;
       sm->num_parameters_reduced = 7 * sm->num_poses - 3 * const_p - 4 * const_q;
       sm->num_effective_parameters_reduced = 6 * sm->num_poses - 3 * const_p - 3 * const_q;
-      sm->factor_kind = P->front_usable ? 2 : 1;
-      sm->factor_max_front = P->front_usable ? P->fsym.max_front : 0;
-      sm->factor_flops = P->front_usable ? P->fsym.flops : P->dsym.flops;
+      sm->factor_kind = P->sfront_usable ? 3 : P->front_usable ? 2 : 1;
+      sm->factor_max_front = fronts ? P->fsym.max_front : 0;
+      sm->factor_flops = fronts ? P->fsym.flops : P->dsym.flops;
       sm->num_factorizations = L.n_factorizations;
       sm->initial_cost = L.initial_cost;
       sm->final_cost = L.x_cost;
@@ -2050,7 +2115,7 @@ size_t pgo_summary_full_report(const pgo_solver_summary* s, const pgo_iteration_
   add("Linear solves served by     %s\n", ls[(s->linear_solver_used >= 0 && s->linear_solver_used <= 3) ? s->linear_solver_used : 1]);
   add("Linear solver iterations     % 16d\n", s->num_linear_solver_iterations);
   if (s->factor_nnz_blocks > 0) {
-    add("Factorisation               %s\n", s->factor_kind == 2 ? "supernodal multifrontal, FP64 MFMA fronts" : "enumerated 6x6 block pairs, nested dissection");
+    add("Factorisation               %s\n", s->factor_kind == 3 ? "supernodal multifrontal, fronts in LDS" : s->factor_kind == 2 ? "supernodal multifrontal, FP64 MFMA fronts" : "enumerated 6x6 block pairs, nested dissection");
     add("Factor blocks / levels       % 16d / %d\n", s->factor_nnz_blocks, s->factor_levels);
     add("Factorisations               % 16d\n", s->num_factorizations);
   }

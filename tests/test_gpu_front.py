@@ -138,3 +138,34 @@ def test_indefinite_matrix_is_reported_not_hidden(gpu, ds, monkeypatch):
     s = gpu.solve(gpu.SolverOptions(max_num_iterations=5, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY, min_lm_diagonal=1e-6), prob)
     assert np.isfinite(s.final_cost) and s.final_cost <= s.initial_cost
     assert np.all(np.isfinite(poses))
+
+
+def test_small_front_plan_on_chain_like_graphs(gpu, O, ds, monkeypatch):
+    """PGO_SFRONT=1: every front of the KITTI-00 replay fits the LDS of one workgroup (84 scalars at most), the factorisation is
+    one launch per tree level (factor_kind 3).  Linear solve vs the oracle's exact solve <= 1e-9 (measured 1e-13), bit-identical
+    when repeated; the LM run with the reference's options follows the oracle: same 12 iterations, same accept / reject
+    sequence, costs to 1e-9 relative.  A banded graph (chain + chords three poses back) with diagonal information goes the same way."""
+    monkeypatch.setenv("PGO_SFRONT", "1")
+    k = np.load(os.path.join(G, "kitti00.npz"))
+    chain = ds.manhattan_se3(700, 699, seed=5)
+    rng = np.random.default_rng(11)
+    ia = np.concatenate([chain.ia, np.arange(3, 700, 2, dtype=np.int32)])
+    ib = np.concatenate([chain.ib, np.arange(0, 697, 2, dtype=np.int32)])
+    meas = np.concatenate([chain.meas, ds._noisy_measurements(chain.truth, ia[699:], ib[699:], rng, 0.05, 0.01)])
+    band = ds.PoseGraphData(chain.poses, ia, ib, meas, np.repeat(chain.sqrt_info[:1], len(ia), axis=0))
+    graphs = [ds.PoseGraphData(k["origin"], k["ia"], k["ib"], k["meas"], None), band]
+    for g in graphs:
+        prob, poses, og = _pair(gpu, O, g)
+        d2, b = _rhs(g, 3)
+        opt = gpu.SolverOptions(linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
+        x, it = prob.linear_solve(d2, b, opt)
+        xo, _ = O.linear_solve(og, d2, b, linear_solver=0)
+        assert it == 0 and np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+        x2, _ = prob.linear_solve(d2, b, opt)
+        assert np.array_equal(x, x2)
+        s = gpu.solve(gpu.SolverOptions(max_num_iterations=1000, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY), prob)
+        _, osum, otr = O.solve(og, O.default_options(max_num_iterations=1000, linear_solver=0))
+        assert s.linear_solver_used == 0 and s.c.factor_kind == 3 and 0 < s.c.factor_max_front <= 96
+        assert len(s.iterations) == len(otr)
+        assert list(s.iterations["step_is_successful"]) == [int(v) for v in otr[:, 8]]
+        assert np.allclose(s.iterations["cost"], otr[:, 1], rtol=1e-9)

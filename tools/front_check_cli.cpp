@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
   }
   FrontSymbolic S;
   const auto t0 = std::chrono::steady_clock::now();
-  const bool ok = front_analyze(N, ia, ib, n_slots, slot_row, slot_col, slot_side, 200LL << 30, &S);
+  const bool ok = front_analyze(N, ia, ib, n_slots, slot_row, slot_col, slot_side, 200LL << 30, &S, getenv("SMALL_MAX") ? atoi(getenv("SMALL_MAX")) : 0);
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::printf("N %d E %d ok %d seconds %.3f fronts %d levels %d launches %d jobs %zu largest %d flops %.3e MB %.1f blocks %lld\n", N, E, ok ? 1 : 0, dt,
               S.nf, S.n_levels, S.n_launches, S.jobs.size(), S.max_front, S.flops, 8e-6 * (double)S.fval_size, S.factor_blocks);

@@ -16,8 +16,9 @@ def per_kernel(db, counter):
     rows = c.execute("select kernel_name, value from counters_collection where counter_name=?", (counter,)).fetchall()
     d = {}
     for n, v in rows:
-        m = re.search(r"(k_[a-z_]+(<\d>)?)", n)
-        d.setdefault(m.group(1) if m else n, []).append(v)
+        m = re.search(r"(k_[a-z_]+)(?:<(\d+)[,>])?", n)      # kernel + its first template argument: k_spmv<0, true> -> k_spmv<0>
+        key = (m.group(1) + ("<%s>" % m.group(2) if m.group(2) is not None else "")) if m else n
+        d.setdefault(key, []).append(v)
     return d
 
 
