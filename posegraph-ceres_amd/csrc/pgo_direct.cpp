@@ -15,6 +15,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
+#include <mutex>
 #include <functional>
 #include <memory>
 #include <numeric>
@@ -59,124 +61,195 @@ Csr build_adjacency(int N, const std::vector<int>& ia, const std::vector<int>& i
 }
 
 // Nested dissection.  `label` marks the subset being ordered (label[v] == id).
-struct Dissector {
+// The subsets are ranges [begin, end) of ONE work array, partitioned in place as [A | B | separator]; the final content of the
+// array IS the elimination order (A's order, then B's, the separator last), so disjoint ranges are independent tasks: large
+// subsets are split by whichever host thread picks them up, the two halves go back to a shared task list, and subsets below
+// kSequential vertices are finished by one thread.  The order does not depend on the number of threads or on timing: a
+// subset's result is a function of its vertex sequence alone (labels are unique ids, nothing else is shared).
+struct DissectShared {
   const Csr& g;
-  std::vector<int> label, dist, queue, order;
-  int next_label = 1;
-  explicit Dissector(const Csr& graph) : g(graph), label(graph.ptr.size() - 1, 0), dist(graph.ptr.size() - 1, -1) {}
+  std::vector<int> label, dist;      // per vertex; a vertex belongs to one live subset at a time
+  std::vector<int>& work;
+  std::atomic<int> next_worker{0};   // label ids are (worker << 22) | counter: unique without a shared counter in the hot loop
+  DissectShared(const Csr& graph, std::vector<int>& w) : g(graph), label(graph.ptr.size() - 1, 0), dist(graph.ptr.size() - 1, -1), work(w) {}
+  int label_of(int v) const { return __atomic_load_n(&label[v], __ATOMIC_RELAXED); }     // neighbours may belong to a subset another thread is relabelling
+  void set_label(int v, int id) { __atomic_store_n(&label[v], id, __ATOMIC_RELAXED); }
+};
+
+struct Dissector {
+  DissectShared& sh;
+  std::vector<int> queue, tmp, lvl_cnt, sep;
+  int label_base, label_next = 1;
+  explicit Dissector(DissectShared& shared) : sh(shared), label_base(shared.next_worker.fetch_add(1) << 22) {}
 
   // BFS inside the subset `id` from `start`; fills queue (visit order) and dist; returns the last vertex visited
   int bfs(int start, int id) {
+    const Csr& g = sh.g;
     queue.clear();
     queue.push_back(start);
-    dist[start] = 0;
+    sh.dist[start] = 0;
     for (size_t h = 0; h < queue.size(); ++h) {
       const int v = queue[h];
       for (int p = g.ptr[v]; p < g.ptr[v + 1]; ++p) {
         const int u = g.idx[p];
-        if (label[u] == id && dist[u] < 0) { dist[u] = dist[v] + 1; queue.push_back(u); }
+        if (sh.label_of(u) == id && sh.dist[u] < 0) { sh.dist[u] = sh.dist[v] + 1; queue.push_back(u); }
       }
     }
     return queue.back();
   }
-  void clear_dist() { for (int v : queue) dist[v] = -1; }
+  void clear_dist() { for (int v : queue) sh.dist[v] = -1; }
 
-  void run(std::vector<int> verts) {
-    // iterative worklist of subsets = ranges [begin, end) of one work array, partitioned in place (A | B, the separator
-    // leaves); `order` is produced back to front (separators last).  Subsets keep the vertex order the recursion sees
-    // (BFS order of the parent), which decides the BFS start vertices.
-    std::vector<int> work = std::move(verts), tmp(work.size()), lvl_cnt;
-    std::vector<std::pair<int, int>> stack;
-    stack.emplace_back(0, (int)work.size());
-    std::vector<int> result_rev;
-    result_rev.reserve(work.size());
-    while (!stack.empty()) {
-      const int sb = stack.back().first, se = stack.back().second;
-      stack.pop_back();
-      const int total = se - sb;
-      if (total <= 0) continue;
-      int* S = work.data() + sb;
-      if (total <= 2) {
-        for (int i = total - 1; i >= 0; --i) result_rev.push_back(S[i]);
-        continue;
-      }
-      const int id = next_label++;
-      for (int i = 0; i < total; ++i) label[S[i]] = id;
-      // one connected component at a time
-      bfs(S[0], id);
-      if ((int)queue.size() < total) {
-        // [rest (subset order) | component (BFS order)]: the component is processed first (it is pushed last)
-        int nr = 0;
-        for (int i = 0; i < total; ++i) if (dist[S[i]] < 0) tmp[nr++] = S[i];
-        const int ncomp = (int)queue.size();
-        for (int i = 0; i < ncomp; ++i) tmp[nr + i] = queue[i];
-        clear_dist();
-        for (int i = 0; i < total; ++i) label[S[i]] = 0;
-        std::copy(tmp.begin(), tmp.begin() + total, S);
-        stack.emplace_back(sb, sb + nr);
-        stack.emplace_back(sb + nr, se);
-        continue;
-      }
-      // pseudo-peripheral vertex: two more sweeps
-      int far = queue.back();
+  // One step on the subset [sb, se): either it is final (returns false), or it has been rearranged into two sub-ranges
+  // [a0, a1) and [b0, b1) that remain to be ordered (returns true).
+  bool split(int sb, int se, int* a0, int* a1, int* b0, int* b1) {
+    const Csr& g = sh.g;
+    const int total = se - sb;
+    if (total <= 2) return false;                      // kept in subset order
+    int* S = sh.work.data() + sb;
+    if ((int)tmp.size() < total) tmp.resize(total);
+    if (label_next >= (1 << 22)) label_next = 1;      // (a worker reuses an id only after 4 M subsets: none of the earlier ones is live)
+    const int id = label_base | label_next++;
+    for (int i = 0; i < total; ++i) sh.set_label(S[i], id);
+    // one connected component at a time
+    bfs(S[0], id);
+    if ((int)queue.size() < total) {
+      // [rest (subset order) | component (BFS order)]
+      int nr = 0;
+      for (int i = 0; i < total; ++i) if (sh.dist[S[i]] < 0) tmp[nr++] = S[i];
+      const int ncomp = (int)queue.size();
+      for (int i = 0; i < ncomp; ++i) tmp[nr + i] = queue[i];
       clear_dist();
-      far = bfs(far, id);
-      clear_dist();
-      bfs(far, id);
-      const int depth = dist[queue.back()];
-      if (depth < 2) {
-        // (nearly) a clique: no useful separator, eliminate in subset order
-        clear_dist();
-        for (int i = 0; i < total; ++i) label[S[i]] = 0;
-        for (int i = total - 1; i >= 0; --i) result_rev.push_back(S[i]);
-        continue;
-      }
-      // level sizes; separator = smallest level among those whose prefix holds 35..65 % of the vertices
-      lvl_cnt.assign(depth + 1, 0);
-      for (int v : queue) ++lvl_cnt[dist[v]];
-      int best = -1, acc = 0;
-      for (int l = 0; l <= depth; ++l) {
-        const int before = acc;
-        acc += lvl_cnt[l];
-        if (l == 0 || l == depth) continue;
-        if (before >= total * 0.35 && before <= total * 0.65) {
-          if (best < 0 || lvl_cnt[l] < lvl_cnt[best]) best = l;
-        }
-      }
-      if (best < 0) {  // no level in the window: take the one closest to the middle
-        acc = 0;
-        int bd = total;
-        for (int l = 0; l <= depth; ++l) {
-          if (l > 0 && l < depth) { const int d = std::abs(2 * acc - total); if (d < bd) { bd = d; best = l; } }
-          acc += lvl_cnt[l];
-        }
-      }
-      // A from the front of tmp, B from its back (reversed below), the separator to the result; all in BFS order
-      int na = 0, nb = 0;
-      const size_t sep_begin = result_rev.size();
-      for (int v : queue) {
-        if (dist[v] < best) tmp[na++] = v;
-        else if (dist[v] > best) tmp[total - 1 - nb++] = v;
-        else {
-          bool touches = false;
-          for (int p = g.ptr[v]; p < g.ptr[v + 1] && !touches; ++p) {
-            const int u = g.idx[p];
-            if (label[u] == id && dist[u] == best + 1) touches = true;
-          }
-          if (touches) result_rev.push_back(v); else tmp[na++] = v;
-        }
-      }
-      std::reverse(result_rev.begin() + sep_begin, result_rev.end());    // the separator enters back to front
-      clear_dist();
-      for (int i = 0; i < total; ++i) label[S[i]] = 0;
-      std::copy(tmp.begin(), tmp.begin() + na, S);
-      for (int i = 0; i < nb; ++i) S[na + i] = tmp[total - 1 - i];
-      stack.emplace_back(sb, sb + na);
-      stack.emplace_back(sb + na, sb + na + nb);
+      for (int i = 0; i < total; ++i) sh.set_label(S[i], 0);
+      std::copy(tmp.begin(), tmp.begin() + total, S);
+      *a0 = sb; *a1 = sb + nr; *b0 = sb + nr; *b1 = se;
+      return true;
     }
-    order.assign(result_rev.rbegin(), result_rev.rend());
+    // pseudo-peripheral vertex: two more sweeps
+    int far = queue.back();
+    clear_dist();
+    far = bfs(far, id);
+    clear_dist();
+    bfs(far, id);
+    const int depth = sh.dist[queue.back()];
+    if (depth < 2) {
+      // (nearly) a clique: no useful separator, eliminate in subset order
+      clear_dist();
+      for (int i = 0; i < total; ++i) sh.set_label(S[i], 0);
+      return false;
+    }
+    // level sizes; separator = smallest level among those whose prefix holds 35..65 % of the vertices
+    lvl_cnt.assign(depth + 1, 0);
+    for (int v : queue) ++lvl_cnt[sh.dist[v]];
+    int best = -1, acc = 0;
+    for (int l = 0; l <= depth; ++l) {
+      const int before = acc;
+      acc += lvl_cnt[l];
+      if (l == 0 || l == depth) continue;
+      if (before >= total * 0.35 && before <= total * 0.65) {
+        if (best < 0 || lvl_cnt[l] < lvl_cnt[best]) best = l;
+      }
+    }
+    if (best < 0) {  // no level in the window: take the one closest to the middle
+      acc = 0;
+      int bd = total;
+      for (int l = 0; l <= depth; ++l) {
+        if (l > 0 && l < depth) { const int d = std::abs(2 * acc - total); if (d < bd) { bd = d; best = l; } }
+        acc += lvl_cnt[l];
+      }
+    }
+    // A from the front of tmp, B from its back (reversed below), the separator behind both; all in BFS order
+    int na = 0, nb = 0;
+    sep.clear();
+    for (int v : queue) {
+      if (sh.dist[v] < best) tmp[na++] = v;
+      else if (sh.dist[v] > best) tmp[total - 1 - nb++] = v;
+      else {
+        bool touches = false;
+        for (int p = g.ptr[v]; p < g.ptr[v + 1] && !touches; ++p) {
+          const int u = g.idx[p];
+          if (sh.label_of(u) == id && sh.dist[u] == best + 1) touches = true;
+        }
+        if (touches) sep.push_back(v); else tmp[na++] = v;
+      }
+    }
+    clear_dist();
+    for (int i = 0; i < total; ++i) sh.set_label(S[i], 0);
+    std::copy(tmp.begin(), tmp.begin() + na, S);
+    for (int i = 0; i < nb; ++i) S[na + i] = tmp[total - 1 - i];
+    std::copy(sep.begin(), sep.end(), S + na + nb);
+    *a0 = sb; *a1 = sb + na; *b0 = sb + na; *b1 = sb + na + nb;
+    return true;
+  }
+
+  // the whole subtree below [sb, se) on this thread
+  void finish(int sb, int se) {
+    std::vector<std::pair<int, int>> stack;
+    stack.emplace_back(sb, se);
+    while (!stack.empty()) {
+      const std::pair<int, int> r = stack.back();
+      stack.pop_back();
+      int a0, a1, b0, b1;
+      if (!split(r.first, r.second, &a0, &a1, &b0, &b1)) continue;
+      if (a1 > a0) stack.emplace_back(a0, a1);
+      if (b1 > b0) stack.emplace_back(b0, b1);
+    }
   }
 };
+
+// Orders every range of `roots` (disjoint ranges of sh.work).  Ranges above kSequential vertices are split by the thread that
+// takes them and their halves handed back; up to `max_threads` host threads, none when everything is small.
+void dissect_ranges(DissectShared& sh, std::vector<std::pair<int, int>> roots, int max_threads) {
+  constexpr int kSequential = 3000;
+  size_t big = 0;
+  for (const auto& r : roots) big += (r.second - r.first) > kSequential;
+  const int nt = (big == 0 && roots.size() < 4) ? 1 : std::max(1, std::min(max_threads, (int)std::thread::hardware_concurrency()));
+  if (nt <= 1) {
+    Dissector d(sh);
+    for (const auto& r : roots) d.finish(r.first, r.second);
+    return;
+  }
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<std::pair<int, int>> tasks = std::move(roots);
+  int in_flight = 0;                                  // tasks taken and not yet retired
+  auto worker = [&]() {
+    Dissector d(sh);
+    for (;;) {
+      std::pair<int, int> r;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !tasks.empty() || in_flight == 0; });
+        if (tasks.empty()) return;                    // nothing queued and nobody working: done
+        // largest first: the big splits are the critical path
+        size_t bi = 0;
+        for (size_t i = 1; i < tasks.size(); ++i) if (tasks[i].second - tasks[i].first > tasks[bi].second - tasks[bi].first) bi = i;
+        r = tasks[bi];
+        tasks[bi] = tasks.back();
+        tasks.pop_back();
+        ++in_flight;
+      }
+      if (r.second - r.first <= kSequential) {
+        d.finish(r.first, r.second);
+        std::lock_guard<std::mutex> lk(mu);
+        --in_flight;
+      } else {
+        int a0, a1, b0, b1;
+        const bool more = d.split(r.first, r.second, &a0, &a1, &b0, &b1);
+        std::lock_guard<std::mutex> lk(mu);
+        if (more) {
+          if (a1 > a0) tasks.emplace_back(a0, a1);
+          if (b1 > b0) tasks.emplace_back(b0, b1);
+        }
+        --in_flight;
+      }
+      cv.notify_all();
+    }
+  };
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (int t = 0; t < nt; ++t) th.emplace_back(worker);
+  for (std::thread& t : th) t.join();
+}
 
 }  // namespace
 
@@ -242,18 +315,14 @@ static void for_components(const Components& C, Body&& body) {
 // Nested dissection of every component on its own (a component gets the order it gets as a graph of its own), components
 // one after the other in the permutation.
 static bool order_components(const Csr& g, const Components& C, std::vector<int>* perm) {
-  const int N = (int)g.ptr.size() - 1;
-  perm->assign(N, -1);
-  std::vector<std::unique_ptr<Dissector>> workers(component_workers(C));
-  std::atomic<bool> ok(true);
-  for_components(C, [&](int c, int w) {
-    if (!workers[w]) workers[w].reset(new Dissector(g));
-    Dissector& d = *workers[w];
-    d.run(std::vector<int>(C.verts.begin() + C.ptr[c], C.verts.begin() + C.ptr[c + 1]));
-    if ((int)d.order.size() != C.ptr[c + 1] - C.ptr[c]) { ok = false; return; }
-    std::copy(d.order.begin(), d.order.end(), perm->begin() + C.ptr[c]);
-  });
-  return ok;
+  *perm = C.verts;                                    // component c occupies [C.ptr[c], C.ptr[c + 1]), vertices ascending
+  DissectShared sh(g, *perm);
+  std::vector<std::pair<int, int>> roots;
+  roots.reserve(C.count());
+  for (int c = 0; c < C.count(); ++c) roots.emplace_back(C.ptr[c], C.ptr[c + 1]);
+  static const int cap = getenv("PGO_ANALYSIS_THREADS") ? std::max(1, atoi(getenv("PGO_ANALYSIS_THREADS"))) : 16;
+  dissect_ranges(sh, std::move(roots), cap);
+  return true;
 }
 
 bool nested_dissection_order(int N, const std::vector<int>& ia, const std::vector<int>& ib, std::vector<int>* perm) {
