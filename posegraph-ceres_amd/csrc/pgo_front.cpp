@@ -395,44 +395,6 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
       const int* rel = S.rel.data() + D.rel_begin;
       for (int t = 0; t < D.r; ++t) for (int a = 0; a < 6; ++a) S.urel.push_back(6 * rel[t] + a);   // parent column of column 6 t + a
     }
-    // extend-add as a gather per PARENT ROW: the rows of the children's packed update matrices that land in it, in child order
-    // (one 8-lane group walks a parent row's list: fixed order, no two groups touch the same row, one barrier in all)
-    S.cr_ptr.clear();
-    S.cr_ent.clear();
-    {
-      std::vector<int> cnt;
-      for (int f = 0; f < nf; ++f) {
-        const FrontDesc& D = S.fronts[f];
-        const int n = 6 * (D.c + D.r);
-        S.sfronts[f].cr_base = (int)S.cr_ptr.size();
-        cnt.assign(n + 2, 0);
-        for (int ci = D.child_begin; ci < D.child_end; ++ci) {
-          const FrontDesc& C = S.fronts[S.child[ci]];
-          const int* rel = S.rel.data() + C.rel_begin;
-          for (int t = 0; t < C.r; ++t) for (int a = 0; a < 6; ++a) ++cnt[6 * rel[t] + a + 1];
-          ++cnt[n + 1];
-        }
-        for (int R = 0; R <= n; ++R) cnt[R + 1] += cnt[R];
-        const int base = (int)(S.cr_ent.size() / 3);
-        for (int R = 0; R <= n + 1; ++R) S.cr_ptr.push_back(base + cnt[R]);
-        S.cr_ent.resize(S.cr_ent.size() + 3 * (size_t)cnt[n + 1]);
-        std::vector<int> fill(cnt.begin(), cnt.end() - 1);
-        for (int ci = D.child_begin; ci < D.child_end; ++ci) {
-          const int ch = S.child[ci];
-          const FrontDesc& C = S.fronts[ch];
-          const int rc6 = 6 * C.r;
-          const int* rel = S.rel.data() + C.rel_begin;
-          for (int i = 0; i <= rc6; ++i) {
-            const int R = i < rc6 ? 6 * rel[i / 6] + i % 6 : n;
-            int* e = S.cr_ent.data() + 3 * (size_t)(base + fill[R]++);
-            e[0] = S.sfronts[ch].ubase + (i < rc6 ? i * (i + 1) / 2 : rc6 * (rc6 + 1) / 2);
-            e[1] = S.sfronts[ch].urel;
-            e[2] = i < rc6 ? i + 1 : rc6;
-          }
-        }
-      }
-      if (S.cr_ent.empty()) S.cr_ent.assign(3, 0);
-    }
     if (S.urel.empty()) S.urel.push_back(0);
     if (lb > 0x7fffffffLL || ub > 0x7fffffffLL || wb > 0x7fffffffLL) return false;
     S.sl_size = std::max(2LL, lb);

@@ -100,16 +100,14 @@ struct SFront {
   int ubase, ucnt;  // update matrix, PACKED: the lower triangle of the r6 x r6 block row by row (row i at i (i + 1) / 2), then the
                     // right-hand side row (r6 entries) at r6 (r6 + 1) / 2
   int urel;         // urel[urel + j], j < r6: the parent's column that receives column j of the update matrix
-  int cr_base;      // as a parent: cr_ptr[cr_base + R .. + R + 1), R <= n: the rows of its children's update matrices that are
-                    // added to its row R, in child order, each {offset in Uval, offset in urel, length} in cr_ent
+  int pad;
   int ablk_begin, ablk_end;   // the front's range of ablk_* entries
   int wbase;        // W = L11^-1, c6 x c6 row-major lower triangular at Wval + wbase (backward substitution = two gemv)
 };
 struct SFrontPlan {
   const SFront* sf;   // [nf]
   const int* urel;    // see SFront::urel
-  const int* cr_ptr;  // see SFront::cr_base
-  const int* cr_ent;
+  int* upos;          // [su_size] LDS offset in the PARENT's front of every packed update entry (filled once on the device)
   const int* osrc;    // [n_ablk] the one BSR slot of an original block | side << 28, or -1 (several slots: ablk_ptr / ablk_slot)
   double* Lval;
   double* Uval;
@@ -166,7 +164,7 @@ struct FrontSymbolic {
   // small-front path (every front <= SFRONT_MAX scalars): per-front storage offsets, no launch schedule
   bool small = false;
   std::vector<SFront> sfronts;
-  std::vector<int> urel, osrc, cr_ptr, cr_ent;
+  std::vector<int> urel, osrc;
   long long sl_size = 0, su_size = 0, sw_size = 0;   // doubles of Lval / Uval / Wval
 };
 
@@ -181,6 +179,8 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
 void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s);
 void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s);
 // the small-front path: one launch per tree level each
+// once per topology: fills SFrontPlan::upos
+void launch_sfront_prepare(const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s);
 void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s);
 void launch_sfront_solve(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s);
 

@@ -660,6 +660,14 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
   const int c6 = 6 * D.c, r6 = 6 * D.r, n = c6 + r6, ld = n + 1;
   // original entries H~ + D^2 (lower blocks; a diagonal block comes whole) and the right-hand side S g: fetched first, the
   // LDS is cleared while the loads are in flight
+  // the children's descriptors too (two dependent loads each), parked in LDS for the extend-add below
+  constexpr int KMAX = 24;
+  __shared__ int kc_ubase[KMAX], kc_ucnt[KMAX];
+  const int nkids = D.child_end - D.child_begin;
+  if (tid < nkids && tid < KMAX) {
+    const SFront C = sp.sf[p.child[D.child_begin + tid]];
+    kc_ubase[tid] = C.ubase; kc_ucnt[tid] = C.ucnt;
+  }
   constexpr int OMAX = 6;            // 256 lanes x 6 entries: fronts of up to 42 original blocks in one pass
   double ov[OMAX];
   int op[OMAX];
@@ -702,18 +710,41 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
   // extend-add, gathered per row of this front: an 8-lane group walks the list of child rows that land in its row (child
   // order: fixed summation order, no atomics; no two groups share a row, so one barrier serves all children)
   if (!(dbg & 2)) {
-    const int* rp = sp.cr_ptr + S.cr_base;
-    for (int R = tid >> 3; R <= n; R += SF_T >> 3) {
-      double* row = F + R * ld;
-      for (int q = rp[R]; q < rp[R + 1]; ++q) {
-        const int* en = sp.cr_ent + 3 * (size_t)q;
-        const double* U = sp.Uval + en[0];
-        const int* pcol = sp.urel + en[1];
-        const int len = en[2];
-        for (int jj = tid & 7; jj < len; jj += 8) row[pcol[jj]] += U[jj];
+    // child by child (fixed order, a barrier between two children: their entries may meet), a child's packed entries side by
+    // side over the 256 lanes, eight per lane with all loads issued before the first add
+    // four children at a time: the loads of all four are in flight together (a child's update matrix was written by another
+    // workgroup of the previous launch, usually on another XCD: every first touch is a trip to memory), then they are added
+    // one child after the other
+    constexpr int KG = 4;
+    for (int k0 = 0; k0 < nkids; k0 += KG) {
+      double v[KG][8];
+      int pos[KG][8];
+      int ub[KG], uc[KG];
+#pragma unroll
+      for (int kk = 0; kk < KG; ++kk) {
+        const int k = k0 + kk;
+        ub[kk] = 0; uc[kk] = 0;
+        if (k < nkids) {
+          if (k < KMAX) { ub[kk] = kc_ubase[k]; uc[kk] = kc_ucnt[k]; }
+          else { const SFront C = sp.sf[p.child[D.child_begin + k]]; ub[kk] = C.ubase; uc[kk] = C.ucnt; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {       // clamped index, always loaded, masked afterwards: no load sits behind a branch
+          const int e0 = u * SF_T + tid, e = ub[kk] + min(e0, max(uc[kk] - 1, 0));
+          v[kk][u] = sp.Uval[e];
+          const int q = sp.upos[e];
+          pos[kk][u] = e0 < uc[kk] ? q : -1;
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < KG; ++kk) {
+        if (k0 + kk >= nkids) break;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (pos[kk][u] >= 0) F[pos[kk][u]] += v[kk][u];
+        for (int e = 8 * SF_T + tid; e < uc[kk]; e += SF_T) F[sp.upos[ub[kk] + e]] += sp.Uval[ub[kk] + e];   // (children beyond 2048 packed entries)
+        __syncthreads();
       }
     }
-    __syncthreads();
   }
   // right-looking Cholesky of the c6 own columns, one pose (6 columns) per step: the 6 x 6 pivot block is factorised by every
   // lane for itself (registers), the rows below are scaled one per lane, then the trailing lower triangle is updated
@@ -767,9 +798,24 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
       const double* a = F + (kb + 6 + ii) * ld + kb;
       const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
       const int jmax = ii < mt ? ii : mt - 1;
-      for (int jj = tid & 7; jj <= jmax; jj += 8) {
+      double* frow = F + (kb + 6 + ii) * ld + kb + 6;
+      int jj = tid & 7;
+      for (; jj + 24 <= jmax; jj += 32) {                      // four entries per trip: 28 LDS reads in flight, then the arithmetic
+        double b[4][6], fv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double* bp = F + (kb + 6 + jj + 8 * u) * ld + kb;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) b[u][c] = bp[c];
+          fv[u] = frow[jj + 8 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          frow[jj + 8 * u] = fv[u] - (a0 * b[u][0] + a1 * b[u][1] + a2 * b[u][2] + a3 * b[u][3] + a4 * b[u][4] + a5 * b[u][5]);
+      }
+      for (; jj <= jmax; jj += 8) {
         const double* b = F + (kb + 6 + jj) * ld + kb;
-        F[(kb + 6 + ii) * ld + kb + 6 + jj] -= a0 * b[0] + a1 * b[1] + a2 * b[2] + a3 * b[3] + a4 * b[4] + a5 * b[5];
+        frow[jj] -= a0 * b[0] + a1 * b[1] + a2 * b[2] + a3 * b[3] + a4 * b[4] + a5 * b[5];
       }
     }
     __syncthreads();
@@ -791,11 +837,33 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
     for (int j = tid & 63; j < c6; j += 64) Lg[i * c6 + j] = F[i * ld + j];
 }
 
+// once per topology: where every packed update entry of every front goes in its parent's LDS front
+__global__ __launch_bounds__(SF_T) void k_sfront_upos(FrontPlan p, SFrontPlan sp) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const FrontDesc D = p.fronts[f];
+  if (D.parent < 0) return;
+  const SFront S = sp.sf[f];
+  const FrontDesc Pd = p.fronts[D.parent];
+  const int rc6 = 6 * D.r, tri = rc6 * (rc6 + 1) / 2, pn = 6 * (Pd.c + Pd.r), pld = pn + 1;
+  const int* pcol = sp.urel + S.urel;
+  for (int e = tid; e < S.ucnt; e += SF_T) {
+    int i, j;
+    if (e >= tri) { i = rc6; j = e - tri; }
+    else {
+      i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+      while (i * (i + 1) / 2 > e) --i;
+      while ((i + 1) * (i + 2) / 2 <= e) ++i;
+      j = e - i * (i + 1) / 2;
+    }
+    sp.upos[S.ubase + e] = (i < rc6 ? pcol[i] : pn) * pld + pcol[j];
+  }
+}
+
 // W = L11^-1 of every front at once (nothing of the factorisation waits for it), by 6 x 6 blocks: block row i of W needs the
 // block rows above it, W_ij = -W_ii sum_{k = j}^{i - 1} L_ik W_kj, all its entries side by side (two barriers per block row).
-__global__ __launch_bounds__(SF_T) void k_sfront_invert(FrontPlan p, SFrontPlan sp) {
+__global__ __launch_bounds__(SF_T) void k_sfront_invert(FrontPlan p, SFrontPlan sp, int front_begin) {
   extern __shared__ double sh[];     // L11: c6 x ld | W: c6 x ld | T: 6 x ld
-  const int f = blockIdx.x, tid = threadIdx.x;
+  const int f = front_begin + blockIdx.x, tid = threadIdx.x;
   const FrontDesc D = p.fronts[f];
   const SFront S = sp.sf[f];
   const int c6 = 6 * D.c, ld = c6 + 1;
@@ -809,9 +877,17 @@ __global__ __launch_bounds__(SF_T) void k_sfront_invert(FrontPlan p, SFrontPlan 
     // T = sum_k L[ib.., k] W[k, 0 .. ib): entry (r, c), c < ib
     for (int e = tid; e < 6 * ib; e += SF_T) {
       const int r = e / ib, c = e - r * ib;
-      double s = 0.0;
-      for (int k = c - c % 6; k < ib; ++k) s = fma(Ls[(ib + r) * ld + k], Ws[k * ld + c], s);     // W[k][c] = 0 for k < c's block start
-      Ts[r * ld + c] = s;
+      // (W[k][c] = 0 for k above c's block; four independent partial sums: the loop is bound by LDS latency, not by arithmetic)
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      const double* lrow = Ls + (ib + r) * ld;
+      int k = c - c % 6;
+      for (; k + 3 < ib; k += 4) {
+        const double l0 = lrow[k], l1 = lrow[k + 1], l2 = lrow[k + 2], l3 = lrow[k + 3];
+        const double w0 = Ws[k * ld + c], w1 = Ws[(k + 1) * ld + c], w2 = Ws[(k + 2) * ld + c], w3 = Ws[(k + 3) * ld + c];
+        s0 = fma(l0, w0, s0); s1 = fma(l1, w1, s1); s2 = fma(l2, w2, s2); s3 = fma(l3, w3, s3);
+      }
+      for (; k < ib; ++k) s0 = fma(lrow[k], Ws[k * ld + c], s0);
+      Ts[r * ld + c] = (s0 + s1) + (s2 + s3);
     }
     // the diagonal block of W: inverse of the 6 x 6 lower triangle, one lane per column
     if (tid < 6) {
@@ -850,21 +926,41 @@ __global__ __launch_bounds__(SF_T) void k_sfront_bwd(DeviceGraph g, FrontPlan p,
   const int c6 = 6 * D.c, r6 = 6 * D.r, n = c6 + r6;
   const double* Lg = sp.Lval + S.lbase;
   const double* Wg = sp.Wval + S.wbase;
+  const int parts = SF_T / c6, j = tid % c6, part = tid / c6;    // c6 <= 96: at least two lanes per column
+  // this lane's share of column j of L21 and of column j of W: fetched before x_r is known (the panel was written by another
+  // workgroup, usually on another XCD: a first touch is a trip to memory; twelve values each cover every front up to 96)
+  constexpr int PB = 12;
+  double lv[PB], wv[PB];
+  const bool on = part < parts;
+#pragma unroll
+  for (int u = 0; u < PB; ++u) {
+    const int i = part + u * parts, iw = j + part + u * parts;
+    lv[u] = (on && i < r6) ? Lg[(size_t)(c6 + i) * c6 + j] : 0.0;
+    wv[u] = (on && iw < c6) ? Wg[(size_t)iw * c6 + j] : 0.0;
+  }
+  const double yj = tid < c6 ? Lg[(size_t)n * c6 + tid] : 0.0;
   for (int i = tid; i < r6; i += SF_T) xr[i] = p.x[6 * (size_t)p.idx[D.idx_begin + i / 6] + i % 6];
   __syncthreads();
-  const int parts = SF_T / c6, j = tid % c6, part = tid / c6;    // c6 <= 96: at least two lanes per column
   double s = 0.0;
-  if (part < parts) for (int i = part; i < r6; i += parts) s += Lg[(size_t)(c6 + i) * c6 + j] * xr[i];
+  if (on) {
+#pragma unroll
+    for (int u = 0; u < PB; ++u) { const int i = part + u * parts; if (i < r6) s = fma(lv[u], xr[i], s); }
+    for (int i = part + PB * parts; i < r6; i += parts) s += Lg[(size_t)(c6 + i) * c6 + j] * xr[i];
+  }
   red[tid] = s;
   __syncthreads();
   if (tid < c6) {
     double tot = 0.0;
     for (int q = 0; q < parts; ++q) tot += red[q * c6 + tid];
-    tv[tid] = Lg[(size_t)n * c6 + tid] - tot;
+    tv[tid] = yj - tot;
   }
   __syncthreads();
   s = 0.0;
-  if (part < parts) for (int i = j + part; i < c6; i += parts) s += Wg[(size_t)i * c6 + j] * tv[i];     // (W^T t)_j = sum_{i >= j} W[i][j] t[i]
+  if (on) {                                                       // (W^T t)_j = sum_{i >= j} W[i][j] t[i]
+#pragma unroll
+    for (int u = 0; u < PB; ++u) { const int i = j + part + u * parts; if (i < c6) s = fma(wv[u], tv[i], s); }
+    for (int i = j + part + PB * parts; i < c6; i += parts) s += Wg[(size_t)i * c6 + j] * tv[i];
+  }
   red[tid] = s;
   __syncthreads();
   if (tid < c6) {
@@ -905,6 +1001,10 @@ void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSym
 }
 
 
+void launch_sfront_prepare(const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s) {
+  hipLaunchKernelGGL(k_sfront_upos, dim3(sym.nf), dim3(SF_T), 0, s, p, sp);
+}
+
 void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s) {
   static bool attr_set = false;
   const size_t lds_max = (size_t)(SFRONT_MAX + 1) * (SFRONT_MAX + 1) * sizeof(double);
@@ -919,9 +1019,12 @@ void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p, const SFront
   for (const FrontLevel& L : sym.levels)
     if (L.front_end > L.front_begin)
       hipLaunchKernelGGL(k_sfront_factor, dim3(L.front_end - L.front_begin), dim3(SF_T), lds, s, g, p, sp, L.front_begin, dbg);
+  // the inverses W = L11^-1 of all fronts in one launch.  (Forming them level by level on a side stream, in the shadow of the
+  // upper levels, was measured: the event hand-overs between the streams cost more than the launch — KITTI-00 0.51 vs 0.43 ms
+  // per LM iteration.)
   int c6max = 0;
   for (const FrontDesc& D : sym.fronts) c6max = std::max(c6max, 6 * D.c);
-  hipLaunchKernelGGL(k_sfront_invert, dim3(sym.nf), dim3(SF_T), (2 * (size_t)c6max + 6) * (c6max + 1) * sizeof(double), s, p, sp);
+  hipLaunchKernelGGL(k_sfront_invert, dim3(sym.nf), dim3(SF_T), (2 * (size_t)c6max + 6) * (c6max + 1) * sizeof(double), s, p, sp, 0);
 }
 
 void launch_sfront_solve(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s) {

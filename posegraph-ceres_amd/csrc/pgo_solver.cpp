@@ -272,11 +272,12 @@ struct pgo_problem {
   pgo::FrontSymbolic fsym;
   pgo::FrontPlan fplan{};
   bool front_usable = false;
+  bool no_sfront = false;          // the union of a batched solve keeps to the enumerated schedule
   bool sfront_usable = false;      // every front fits the LDS: one launch per tree level (pgo_front.h, SFRONT_MAX)
   pgo::SFrontPlan splan{};
   DevBuf<pgo::SFront> ds_sf;
   DevBuf<double> ds_L, ds_U, ds_W;
-  DevBuf<int> ds_urel, ds_osrc, ds_cr_ptr, ds_cr_ent;
+  DevBuf<int> ds_urel, ds_osrc, ds_upos;
   DevBuf<int> df_perm, df_idx, df_child, df_rel, df_cstart, df_col_front, df_ablk_ptr, df_ablk_slot, df_ablk_front, df_ablk_pos, df_wg_job, df_wg_tile,
       df_bwd_front, df_bwd_chunk, df_bwdb_front, df_bwdb_chunk, df_asm_tile, df_asm_contrib;
   DevBuf<pgo::FrontDesc> df_fronts;
@@ -947,12 +948,11 @@ int upload_sfront(pgo_problem* P) {
   HIP_TRY(P->df_fronts.upload(S.fronts, s));
   HIP_TRY(P->ds_sf.upload(S.sfronts, s));
   HIP_TRY(P->ds_urel.upload(S.urel, s));
-  HIP_TRY(P->ds_cr_ptr.upload(S.cr_ptr, s));
-  HIP_TRY(P->ds_cr_ent.upload(S.cr_ent, s));
   HIP_TRY(P->ds_osrc.upload(S.osrc, s));
   HIP_TRY(P->ds_L.alloc((size_t)S.sl_size));
   HIP_TRY(P->ds_U.alloc((size_t)S.su_size));
   HIP_TRY(P->ds_W.alloc((size_t)S.sw_size));
+  HIP_TRY(P->ds_upos.alloc((size_t)S.su_size));
   HIP_TRY(P->df_x.alloc((size_t)6 * S.n));
   HIP_TRY(P->df_x.zero(s));
   pgo::FrontPlan& f = P->fplan;
@@ -961,7 +961,8 @@ int upload_sfront(pgo_problem* P) {
   f.perm = P->df_perm.p; f.fronts = P->df_fronts.p; f.idx = P->df_idx.p; f.child = P->df_child.p; f.rel = P->df_rel.p;
   f.ablk_ptr = P->df_ablk_ptr.p; f.ablk_slot = P->df_ablk_slot.p; f.ablk_pos = P->df_ablk_pos.p; f.n_ablk = (int)S.ablk_front.size();
   f.x = P->df_x.p;
-  P->splan = pgo::SFrontPlan{P->ds_sf.p, P->ds_urel.p, P->ds_cr_ptr.p, P->ds_cr_ent.p, P->ds_osrc.p, P->ds_L.p, P->ds_U.p, P->ds_W.p};
+  P->splan = pgo::SFrontPlan{P->ds_sf.p, P->ds_urel.p, P->ds_upos.p, P->ds_osrc.p, P->ds_L.p, P->ds_U.p, P->ds_W.p};
+  pgo::launch_sfront_prepare(P->fplan, P->splan, S, s);
   P->sfront_usable = true;
   if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] front: small-front plan upload %.2f ms\n", 1e3 * seconds_since(t_up));
   return PGO_OK;
@@ -989,12 +990,12 @@ int prepare_direct(pgo_problem* P) {
   // a trajectory with a few chords (KITTI-00 replay: 1.14 edges per pose) is the enumerated schedule's case: its analysis runs
   // first there and the multifrontal one is skipped (one-shot solves pay every millisecond of host analysis)
   bool pair_first_done = false, usable = false, front_done = false;
-  // PGO_SFRONT=1: graphs whose fronts all fit the LDS of one workgroup (<= 96 scalars: chain-like graphs, KITTI-00 replay 84) use
-  // the small-front plan — one launch per tree level (pgo_front.h).  Opt-in: measured on KITTI-00 it is 2-4 % faster per LM
-  // iteration than the enumerated schedule (0.455 vs 0.47 ms) but its analysis costs 0.3 ms more, and a batched union of such
-  // graphs is slower with it (one 58 KB workgroup per front: 37 vs 25 ms for 16 graphs) — DESIGN.md section 6.
+  // Chain-like graphs (E < 1.5 N) first try the small-front plan: when every front fits the LDS of one workgroup (<= 96 scalars;
+  // KITTI-00 replay: 84) the factorisation is one launch per tree level (pgo_front.h) — KITTI-00 0.41 vs 0.46 ms per LM
+  // iteration, 7.1 vs 7.6 ms per solve against the enumerated schedule.  Not for the union of a batched solve (one 58 KB
+  // workgroup per front: 37 vs 25 ms for 16 graphs).  PGO_SFRONT=0 never, =1 for any graph whose fronts are small enough.
   const char* sfe = getenv("PGO_SFRONT");
-  const int sf_mode = (sfe && sfe[0] == '1') ? 1 : 0;
+  const int sf_mode = !sfe ? ((!P->no_sfront && (double)P->g.E < 1.5 * (double)P->g.N) ? 1 : 0) : (sfe[0] == '1' ? 1 : 0);
   if (front_mode != 0 && sf_mode == 1) {
     const int rc = analyze_front(P, &front_ok, pgo::SFRONT_MAX);
     if (rc) return rc;
@@ -1643,6 +1644,7 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
     }
   }
   pgo_problem* P = &M;
+  P->no_sfront = true;
   int rc = prepare(P);
   if (rc) return rc;
   P->opt = o;

@@ -117,12 +117,13 @@ def test_c5_linear_solve_residual(gpu, ds):
 
 
 def test_solver_choice_by_graph_shape(gpu, ds):
-    """Chain-like graphs (largest front < 192 scalars) keep the enumerated 6x6 factorisation, mesh-like ones get the fronts."""
+    """Chain-like graphs whose fronts all fit the LDS (KITTI-00 replay: 84 scalars at most) get the small-front plan (factor_kind
+    3; PGO_SFRONT=0: the enumerated 6x6 factorisation, kind 1), mesh-like ones the MFMA fronts (kind 2)."""
     k = np.load(os.path.join(G, "kitti00.npz"))
     c1 = ds.PoseGraphData(k["origin"], k["ia"], k["ib"], k["meas"], None)
     prob, _ = gpu.problem_from_graph(c1)
     s = gpu.solve(gpu.SolverOptions(max_num_iterations=2, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY), prob)
-    assert s.linear_solver_used == 0 and s.c.factor_kind == 1
+    assert s.linear_solver_used == 0 and s.c.factor_kind == 3 and 0 < s.c.factor_max_front <= 96
     g = ds.manhattan_se3(2000, 8000, seed=3)
     prob, _ = gpu.problem_from_graph(g)
     s = gpu.solve(gpu.SolverOptions(max_num_iterations=2, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY), prob)

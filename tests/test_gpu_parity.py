@@ -472,6 +472,7 @@ def test_split_step_timeout_falls_back_to_two_launches(gpu, O, ds, monkeypatch):
     oracle's (same accept / reject sequence, costs 1e-7)."""
     monkeypatch.setenv("PGO_DIRECT_SPLIT_SPINS", "0")
     monkeypatch.setenv("PGO_FRONT", "0")
+    monkeypatch.setenv("PGO_SFRONT", "0")
     k = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti00.npz"))
     g = ds.PoseGraphData(k["origin"], k["ia"], k["ib"], k["meas"], None)
     prob, poses = gpu.problem_from_graph(g)
