@@ -273,6 +273,11 @@ struct pgo_problem {
   pgo::FrontPlan fplan{};
   bool front_usable = false;
   bool no_sfront = false;          // the union of a batched solve keeps to the enumerated schedule
+  // host analysis of the factorisation on a helper thread, started inside prepare() as soon as the slot topology exists and
+  // joined by prepare_direct(): it overlaps the array fills, the uploads and the evaluation of iteration zero
+  std::thread analysis_thread;
+  int analysis_kind = 0;           // what it chose: 0 none (iterative path), 1 enumerated 6x6 pairs, 2 MFMA fronts, 3 small fronts
+  bool want_direct = false;        // set by lm_begin around prepare(): an exact request is coming
   bool sfront_usable = false;      // every front fits the LDS: one launch per tree level (pgo_front.h, SFRONT_MAX)
   pgo::SFrontPlan splan{};
   DevBuf<pgo::SFront> ds_sf;
@@ -295,6 +300,7 @@ struct pgo_problem {
   LmState lm;
 
   ~pgo_problem() {
+    if (analysis_thread.joinable()) analysis_thread.join();
     if (stream_ready) (void)hipStreamSynchronize(stream);   // the device buffers go back to the pool: nothing may be in flight
     drop_graph();
     delete comm;
@@ -415,11 +421,15 @@ int choose_block(long long total_slots) {
   return 64;
 }
 
+int decide_direct_host(pgo_problem* P, int N, int E, int n_slots, long long front_budget);
+long long front_memory_budget();
+
 // Builds the incidence-slot topology and uploads every static array.
 int prepare(pgo_problem* P) {
   int rc = ensure_device(P);
   if (rc) return rc;
   if (!P->topo_dirty) return PGO_OK;
+  if (P->analysis_thread.joinable()) P->analysis_thread.join();     // (of a topology that is being replaced)
   const auto t0 = Clock::now();
   const int N = (int)P->pp.size(), E = (int)P->ia.size();
   if (N == 0) return set_error(PGO_ERR_INVALID_ARGUMENT, "problem has no poses");
@@ -513,6 +523,15 @@ int prepare(pgo_problem* P) {
   }
 
   lap("rows -> workgroups, slots");
+  P->h_slot_row = slot_row; P->h_slot_col = slot_col; P->h_slot_side = slot_side; P->h_row_slot_begin = row_slot_begin;
+  P->direct_analyzed = false; P->direct_usable = false; P->front_usable = false; P->sfront_usable = false; P->cluster_built = 0; P->g.cluster = 1;
+  if (P->want_direct && !(getenv("PGO_NO_ANALYSIS_THREAD") && getenv("PGO_NO_ANALYSIS_THREAD")[0] == '1')) {
+    // an exact request: its host analysis (ordering, symbolic factorisation, schedule) needs nothing but the slot topology
+    const long long budget = front_memory_budget();
+    const int ns = (int)n_slots;
+    P->analysis_kind = 0;
+    P->analysis_thread = std::thread([P, N, E, ns, budget]() { P->analysis_kind = decide_direct_host(P, N, E, ns, budget); });
+  }
   // measurements: edge order and slot order, component major.  The gathers into slot order are cache-hostile (21-36
   // strided streams indexed by a random edge): split over host threads, each owning a contiguous range.
   HostArray emeas, smeas, eW, sW, eL;
@@ -564,8 +583,6 @@ int prepare(pgo_problem* P) {
   }
   const bool w_blockdiag = P->has_info && w_has_pr.load() == 0;
   lap("measurement / W arrays");
-  P->h_slot_row = slot_row; P->h_slot_col = slot_col; P->h_slot_side = slot_side; P->h_row_slot_begin = row_slot_begin;
-  P->direct_analyzed = false; P->direct_usable = false; P->front_usable = false; P->sfront_usable = false; P->cluster_built = 0; P->g.cluster = 1;
   HIP_TRY(P->d_slot_col.upload(slot_col, s));
   HIP_TRY(P->d_slot_row.upload(slot_row, s));
   HIP_TRY(P->d_slot_side.upload(slot_side, s));
@@ -880,16 +897,18 @@ int prepare_clusters(pgo_problem* P, int CL) {
 
 // ---- exact solver: GPU block-sparse Cholesky (pgo_direct.*) ----
 // Multifrontal solver: host analysis (front_analyzed_ok) and, once chosen, plan upload (front_usable).
-int analyze_front(pgo_problem* P, bool* ok, int small_max = 0) {
+long long front_memory_budget() {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)64 << 30; }
+  const char* cap = getenv("PGO_FRONT_MAX_GB");
+  return cap ? (long long)(atof(cap) * 1e9) : (long long)(0.6 * (double)free_b);
+}
+// host only (runs on the analysis thread)
+void analyze_front(pgo_problem* P, int N, int n_slots, long long budget, bool* ok, int small_max = 0) {
   pgo::FrontSymbolic& S = P->fsym;
   const auto t_an = Clock::now();
-  size_t free_b = 0, total_b = 0;
-  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  const char* cap = getenv("PGO_FRONT_MAX_GB");
-  const long long budget = cap ? (long long)(atof(cap) * 1e9) : (long long)(0.6 * (double)free_b);
-  *ok = pgo::front_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side, budget, &S, small_max);
+  *ok = pgo::front_analyze(N, P->ia, P->ib, n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side, budget, &S, small_max);
   if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] front: symbolic analysis %.2f ms (%s)\n", 1e3 * seconds_since(t_an), *ok ? "usable" : "declined");
-  return PGO_OK;
 }
 
 int upload_front(pgo_problem* P) {
@@ -968,15 +987,13 @@ int upload_sfront(pgo_problem* P) {
   return PGO_OK;
 }
 
-int prepare_direct(pgo_problem* P) {
-  if (P->direct_analyzed) return PGO_OK;
-  P->direct_analyzed = true;
-  P->direct_usable = false;
-  P->front_usable = false;
-  P->sfront_usable = false;
+// Which factorisation serves an exact request on this topology: the host analyses and the choice between them.  No HIP calls
+// (it runs on the analysis thread); returns 0 none (the iterative path serves the request), 1 enumerated 6x6 pairs (P->dsym),
+// 2 MFMA fronts, 3 small fronts (P->fsym).
+int decide_direct_host(pgo_problem* P, int N, int E, int n_slots, long long front_budget) {
   const char* off = getenv("PGO_NO_DIRECT");
-  if (off && off[0] == '1') return PGO_OK;
-  if (P->comm && P->comm->world > 1) return PGO_OK;   // the factorisation needs every row: sharded runs use PCG to 1e-13
+  if (off && off[0] == '1') return 0;
+  if (P->comm && P->comm->world > 1) return 0;   // the factorisation needs every row: sharded runs use PCG to 1e-13
   // Two GPU factorisations serve an exact request (measured, tools/front_vs_direct.py: KITTI-00 replay 0.34 ms with the
   // enumerated 6x6 pairs vs 0.44 ms multifrontal; KITTI-00 dense 2.1 vs 2.8 ms; Manhattan 2 k 8.6 vs 1.6 ms; Manhattan 10 k
   // 6.3 vs 5.6 ms; sphere x10: declined vs 39 ms).  The multifrontal analysis is the cheap one and runs first; chain-like
@@ -995,47 +1012,46 @@ int prepare_direct(pgo_problem* P) {
   // iteration, 7.1 vs 7.6 ms per solve against the enumerated schedule.  Not for the union of a batched solve (one 58 KB
   // workgroup per front: 37 vs 25 ms for 16 graphs).  PGO_SFRONT=0 never, =1 for any graph whose fronts are small enough.
   const char* sfe = getenv("PGO_SFRONT");
-  const int sf_mode = !sfe ? ((!P->no_sfront && (double)P->g.E < 1.5 * (double)P->g.N) ? 1 : 0) : (sfe[0] == '1' ? 1 : 0);
+  const int sf_mode = !sfe ? ((!P->no_sfront && (double)E < 1.5 * (double)N) ? 1 : 0) : (sfe[0] == '1' ? 1 : 0);
   if (front_mode != 0 && sf_mode == 1) {
-    const int rc = analyze_front(P, &front_ok, pgo::SFRONT_MAX);
-    if (rc) return rc;
+    analyze_front(P, N, n_slots, front_budget, &front_ok, pgo::SFRONT_MAX);
     front_done = true;
-    if (front_ok && P->fsym.small) {
-      S = pgo::DirectSymbolic();
-      P->direct_usable = true;
-      return upload_sfront(P);
-    }
+    if (front_ok && P->fsym.small) { S = pgo::DirectSymbolic(); return 3; }
   }
-  if (front_mode < 0 && (double)P->g.E < 1.5 * (double)P->g.N) {
+  auto pairs = [&]() {
     const auto t_an = Clock::now();
-    usable = pgo::direct_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side,
-                                 P->h_row_slot_begin, &S);
+    usable = pgo::direct_analyze(N, P->ia, P->ib, n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side, P->h_row_slot_begin, &S);
     if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: symbolic analysis %.2f ms\n", 1e3 * seconds_since(t_an));
-    pair_first_done = true;
-  }
+  };
+  if (front_mode < 0 && (double)E < 1.5 * (double)N) { pairs(); pair_first_done = true; }
   if (front_mode != 0 && !(pair_first_done && usable && !S.hybrid)) {
-    if (!front_done) {
-      const int rc = analyze_front(P, &front_ok);
-      if (rc) return rc;
-    }
-    if (front_ok && (front_mode == 1 || P->fsym.max_front > front_min)) {
-      S = pgo::DirectSymbolic();
-      P->direct_usable = true;
-      return upload_front(P);
-    }
+    if (!front_done) analyze_front(P, N, n_slots, front_budget, &front_ok);
+    if (front_ok && (front_mode == 1 || P->fsym.max_front > front_min)) { S = pgo::DirectSymbolic(); return 2; }
   }
-  if (front_mode != 1 && !pair_first_done) {
-    const auto t_an = Clock::now();
-    usable = pgo::direct_analyze(P->g.N, P->ia, P->ib, P->g.n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side,
-                                 P->h_row_slot_begin, &S);
-    if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: symbolic analysis %.2f ms\n", 1e3 * seconds_since(t_an));
+  if (front_mode != 1 && !pair_first_done) pairs();
+  if (front_ok && (!usable || S.hybrid)) { S.hybrid = false; return 2; }
+  return usable ? 1 : 0;   // 0: too much fill / too deep for the enumerated schedule: the iterative path serves the request
+}
+
+int prepare_direct(pgo_problem* P) {
+  if (P->direct_analyzed) return PGO_OK;
+  int kind;
+  if (P->analysis_thread.joinable()) {
+    P->analysis_thread.join();
+    kind = P->analysis_kind;
+  } else {
+    kind = decide_direct_host(P, P->g.N, P->g.E, P->g.n_slots, front_memory_budget());
   }
-  if (front_ok && (!usable || S.hybrid)) {
-    S.hybrid = false;
-    P->direct_usable = true;
-    return upload_front(P);
-  }
-  if (!usable) return PGO_OK;  // too much fill / too deep for the enumerated schedule: the iterative path serves the request
+  P->direct_analyzed = true;
+  P->direct_usable = false;
+  P->front_usable = false;
+  P->sfront_usable = false;
+  pgo::DirectSymbolic& S = P->dsym;
+  if (kind == 0) return PGO_OK;
+  P->direct_usable = true;      // (cleared again if an upload fails: the error is returned)
+  if (kind == 3) { const int rc = upload_sfront(P); if (rc) P->direct_usable = false; return rc; }
+  if (kind == 2) { const int rc = upload_front(P); if (rc) P->direct_usable = false; return rc; }
+  P->direct_usable = false;
   const auto t_up = Clock::now();
   hipStream_t s = P->stream;
   HIP_TRY(P->dd_perm.upload(S.perm, s));
@@ -1161,7 +1177,9 @@ int evaluate_gradient_and_jacobian(pgo_problem* P, bool first) {
 }
 
 int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
+  P->want_direct = options->linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY;
   int rc = prepare(P);
+  P->want_direct = false;
   if (rc) return rc;
   P->opt = *options;
   LmState& L = P->lm;
@@ -1173,6 +1191,21 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   P->g.loss_a = P->loss_a;
   P->g.pose_x = P->d_pose_x.p;
   P->g.pose_c = P->d_pose_c.p;
+  static const bool verbose = getenv("PGO_VERBOSE") != nullptr;
+  rc = upload_poses(P, P->g.pose_x);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(P->d_pose_0.p, P->g.pose_x, P->d_pose_0.n * sizeof(double), hipMemcpyDeviceToDevice, P->stream));
+  HIP_TRY(P->d_flags.zero(P->stream));
+  // Init + IterationZero, enqueued before the factorisation's plan is waited for (its host analysis runs on a helper thread
+  // since prepare(), its uploads queue up behind these kernels)
+  P->g.cluster = 1;
+  rc = evaluate_gradient_and_jacobian(P, true);
+  if (rc) return rc;
+  pgo::launch_cost(P->g, P->g.pose_x, 0, P->stream);
+  // x_norm: run the retraction with a zero step (delta is zero after prepare/reset)
+  HIP_TRY(P->d_delta.zero(P->stream));
+  pgo::launch_apply_step(P->g, P->g.delta, P->stream);
+  pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, P->stream);
   int cluster = P->opt.pcg_cluster_poses;
   if (P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY) {
     const auto t_sym = Clock::now();
@@ -1183,23 +1216,9 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
     // ~2.5x fewer iterations than 6x6 blocks at almost the same cost per iteration
     if ((!P->direct_usable || P->dsym.hybrid) && cluster < 2) cluster = 2;
   }
-  static const bool verbose = getenv("PGO_VERBOSE") != nullptr;
   rc = prepare_clusters(P, cluster);
   if (rc) return rc;
-  if (verbose) std::fprintf(stderr, "[pgo] lm_begin: clusters prepared          %.2f ms\n", 1e3 * seconds_since(t0));
-  rc = upload_poses(P, P->g.pose_x);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(P->d_pose_0.p, P->g.pose_x, P->d_pose_0.n * sizeof(double), hipMemcpyDeviceToDevice, P->stream));
-  HIP_TRY(P->d_flags.zero(P->stream));
-  if (verbose) { HIP_TRY(hipStreamSynchronize(P->stream)); std::fprintf(stderr, "[pgo] lm_begin: uploads drained             %.2f ms\n", 1e3 * seconds_since(t0)); }
-  // Init + IterationZero
-  rc = evaluate_gradient_and_jacobian(P, true);
-  if (rc) return rc;
-  pgo::launch_cost(P->g, P->g.pose_x, 0, P->stream);
-  // x_norm: run the retraction with a zero step (delta is zero after prepare/reset)
-  HIP_TRY(P->d_delta.zero(P->stream));
-  pgo::launch_apply_step(P->g, P->g.delta, P->stream);
-  pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, P->stream);
+  if (verbose) std::fprintf(stderr, "[pgo] lm_begin: plan + clusters prepared    %.2f ms\n", 1e3 * seconds_since(t0));
   HIP_TRY(hipStreamSynchronize(P->stream));
   HIP_TRY(hipGetLastError());
   if (verbose) std::fprintf(stderr, "[pgo] lm_begin: iteration zero evaluated    %.2f ms\n", 1e3 * seconds_since(t0));
@@ -1645,7 +1664,9 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
   }
   pgo_problem* P = &M;
   P->no_sfront = true;
+  P->want_direct = true;       // the union's host analysis runs beside the array fills and uploads of prepare()
   int rc = prepare(P);
+  P->want_direct = false;
   if (rc) return rc;
   P->opt = o;
   P->g.loss_kind = P->loss_kind;
