@@ -377,21 +377,47 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
     }
   }
   phase("slot sources");
-  // ---- 9b. small fronts only: compact storage, one launch per level, no schedule ----
-  if (small_max > 0 && S.max_front <= small_max) {
-    S.small = true;
-    S.sfronts.resize(nf);
+  // ---- 9b. small fronts: compact storage, one launch per level, no schedule ----
+  // pure plan: every front is small.  Mixed plan (PGO_FRONT_MIXED=<scalars>, off by default): the fronts whose whole subtree is
+  // small (chains and leaves at the bottom of a mesh: KITTI-00 dense 447 of 562 fronts, Manhattan 10 k 730 of 1243) take the
+  // small-front kernels level by level before the round schedule of the rest starts; the roots of those subtrees hand their
+  // update matrices over in the regular layout.  Measured: no gain on those two graphs (Manhattan 10 k 3.48 vs 3.41 ms per
+  // factorisation, KITTI-00 dense 12.1 vs 11.7 ms per three iterations) — the rounds already run the small fronts beside
+  // the long panel chains of the big ones, which are the critical path; taking them out in front only adds their launches.
+  const bool pure_small = small_max > 0 && S.max_front <= small_max;
+  const int mixed_max = pure_small ? small_max : std::min((int)env_or("PGO_FRONT_MIXED", 0), (int)SFRONT_MAX);
+  std::vector<char> is_small(nf, 0);
+  {
+    int cnt = 0;
+    if (mixed_max > 0)
+      for (int f = 0; f < nf; ++f) {     // children have smaller numbers
+        const FrontDesc& D = S.fronts[f];
+        bool ok = 6 * (D.c + D.r) <= mixed_max;
+        for (int ci = D.child_begin; ci < D.child_end && ok; ++ci) ok = is_small[S.child[ci]] != 0;
+        is_small[f] = ok ? 1 : 0;
+        cnt += ok ? 1 : 0;
+      }
+    S.n_small = cnt;
+    S.mixed = !pure_small && cnt >= 32;
+    if (!pure_small && !S.mixed) std::fill(is_small.begin(), is_small.end(), 0);
+  }
+  if (pure_small || S.mixed) {
+    S.small = pure_small;
+    S.sfronts.assign(nf, SFront{0, 0, 0, 0, 0, 0, 0, 0});
     long long lb = 0, ub = 0, wb = 0;
     S.urel.clear();
     for (int f = 0; f < nf; ++f) {
-      const FrontDesc& D = S.fronts[f];
+      if (!is_small[f]) continue;
+      FrontDesc& D = S.fronts[f];
+      D.pad = S.mixed ? 1 : 0;
       const int c6 = 6 * D.c, r6 = 6 * D.r;
-      const long long ucnt = D.parent >= 0 ? (long long)r6 * (r6 + 1) / 2 + r6 : 0;
-      S.sfronts[f] = SFront{(int)lb, (int)ub, (int)ucnt, (int)S.urel.size(), 0, 0, 0, (int)wb};
+      const bool packed = D.parent >= 0 && is_small[D.parent];
+      const long long ucnt = packed ? (long long)r6 * (r6 + 1) / 2 + r6 : 0;
+      S.sfronts[f] = SFront{(int)lb, (int)ub, (int)ucnt, (int)S.urel.size(), (D.parent >= 0 && !packed) ? 1 : 0, 0, 0, (int)wb};
       lb += ((long long)(c6 + r6 + 1) * c6 + 1) / 2 * 2;
       ub += (ucnt + 1) / 2 * 2;
       wb += (long long)c6 * c6;
-      if (D.parent < 0) continue;
+      if (!packed) continue;
       const int* rel = S.rel.data() + D.rel_begin;
       for (int t = 0; t < D.r; ++t) for (int a = 0; a < 6; ++a) S.urel.push_back(6 * rel[t] + a);   // parent column of column 6 t + a
     }
@@ -412,7 +438,17 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
       if (F.ablk_end == F.ablk_begin) F.ablk_begin = a;
       F.ablk_end = a + 1;
     }
+    // the small fronts of every level (fronts are numbered level by level)
+    S.slevel_ptr.assign(1, 0);
+    S.slevel_front.clear();
+    for (int l = 0; l < n_levels; ++l) {
+      for (int f = S.levels[l].front_begin; f < S.levels[l].front_end; ++f) if (is_small[f]) S.slevel_front.push_back(f);
+      S.slevel_ptr.push_back((int)S.slevel_front.size());
+    }
+    if (S.slevel_front.empty()) S.slevel_front.push_back(0);
     phase("small-front plan");
+  }
+  if (pure_small) {
     S.n_launches = 2 * n_levels + 2;
     S.est_us = 8.0 * S.n_launches;
     if (getenv("PGO_VERBOSE"))
@@ -434,9 +470,15 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
     for (int q = 0; q < nf; ++q) {
       nsteps[q] = (6 * S.fronts[q].c + FRONT_NB - 1) / FRONT_NB;
       kids_left[q] = S.fronts[q].child_end - S.fronts[q].child_begin;
-      asm_done[q] = kids_left[q] == 0;
+      asm_done[q] = kids_left[q] == 0;           // a leaf has nothing to assemble
     }
     int n_finished = 0;
+    for (int q = 0; q < nf; ++q)                 // mixed plan: the small fronts are done when the rounds start
+      if (is_small[q]) {
+        finished[q] = 1; asm_done[q] = 1; next_step[q] = nsteps[q];
+        ++n_finished;
+        if (S.fronts[q].parent >= 0) --kids_left[S.fronts[q].parent];
+      }
     std::vector<int> done_now, gjobs;
     struct Rec { long long key; int child, kk, mm; };
     std::vector<Rec> recs;
@@ -570,6 +612,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
     std::vector<char> fin(nf, 0), parent_done(nf, 0);
     for (int q = 0; q < nf; ++q) { nblk[q] = (6 * S.fronts[q].c + FRONT_NBO - 1) / FRONT_NBO; parent_done[q] = S.fronts[q].parent < 0; }
     int n_fin = 0;
+    for (int q = 0; q < nf; ++q) if (is_small[q]) { fin[q] = 1; st[q] = 0; ++n_fin; }     // (their backward levels follow the rounds)
     std::vector<int> done_now;
     while (n_fin < nf) {
       done_now.clear();

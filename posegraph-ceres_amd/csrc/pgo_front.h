@@ -100,12 +100,13 @@ struct SFront {
   int ubase, ucnt;  // update matrix, PACKED: the lower triangle of the r6 x r6 block row by row (row i at i (i + 1) / 2), then the
                     // right-hand side row (r6 entries) at r6 (r6 + 1) / 2
   int urel;         // urel[urel + j], j < r6: the parent's column that receives column j of the update matrix
-  int pad;
+  int to_fval;      // mixed plan: the parent is a regular front — the update matrix goes to Fval in the regular front layout
   int ablk_begin, ablk_end;   // the front's range of ablk_* entries
   int wbase;        // W = L11^-1, c6 x c6 row-major lower triangular at Wval + wbase (backward substitution = two gemv)
 };
 struct SFrontPlan {
   const SFront* sf;   // [nf]
+  const int* list;    // mixed plan: the small fronts level by level (a launch covers list[front_begin .. )); null: all fronts are small
   const int* urel;    // see SFront::urel
   int* upos;          // [su_size] LDS offset in the PARENT's front of every packed update entry (filled once on the device)
   const int* osrc;    // [n_ablk] the one BSR slot of an original block | side << 28, or -1 (several slots: ablk_ptr / ablk_slot)
@@ -163,6 +164,11 @@ struct FrontSymbolic {
   int n_launches = 0;
   // small-front path (every front <= SFRONT_MAX scalars): per-front storage offsets, no launch schedule
   bool small = false;
+  // mixed plan: the fronts whose whole subtree is small take the small-front kernels (FrontDesc::pad = 1), level by level,
+  // before the round schedule of the others starts
+  bool mixed = false;
+  int n_small = 0;
+  std::vector<int> slevel_ptr, slevel_front;
   std::vector<SFront> sfronts;
   std::vector<int> urel, osrc;
   long long sl_size = 0, su_size = 0, sw_size = 0;   // doubles of Lval / Uval / Wval
@@ -176,8 +182,9 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
 
 // Device launches: factorisation (includes the forward substitution) and backward substitution into g.cg_x.
 // flags[2] is set when a pivot is not positive.
-void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s);
-void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s);
+// sp: the small-front arrays of a mixed plan (sym.mixed), else null
+void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s, const SFrontPlan* sp = nullptr);
+void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s, const SFrontPlan* sp = nullptr);
 // the small-front path: one launch per tree level each
 // once per topology: fills SFrontPlan::upos
 void launch_sfront_prepare(const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s);

@@ -90,11 +90,13 @@ __global__ __launch_bounds__(256) void k_front_scatter(DeviceGraph g, FrontPlan 
     double s = 0.0;
     for (int q = p.ablk_ptr[a]; q < p.ablk_ptr[a + 1]; ++q) { const int slot = p.ablk_slot[q]; s += bsr_elem(g, slot, g.slot_side[slot], e); }
     const FrontDesc& D = p.fronts[p.ablk_front[a]];
+    if (D.pad) return;                 // mixed plan: a small front builds itself in LDS (k_sfront_factor)
     const int pos = p.ablk_pos[a], bi = pos >> 16, bj = pos & 0xffff;
     p.Fval[D.fbase + (size_t)(6 * bi + e / 6) * D.ld + 6 * bj + e % 6] = s;
   } else if (t < na + 6LL * p.n) {
     const int u = (int)(t - na), j = u / 6, k = u - 6 * j;
     const FrontDesc& D = p.fronts[p.col_front[j]];
+    if (D.pad) return;
     const int n = 6 * (D.c + D.r);
     const size_t io = 6 * (size_t)p.perm[j] + k;
     const double b = g.scale[io] * g.grad[io];   // right-hand side S g (as pgo_direct_kernels forward_rhs); the step tail reads cg_b
@@ -654,7 +656,7 @@ constexpr int SF_T = 256;
 
 __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan p, SFrontPlan sp, int front_begin, int dbg) {
   extern __shared__ double F[];     // (n + 1) x ld, ld = n + 1 (n is a multiple of 6: the stride is odd)
-  const int f = front_begin + blockIdx.x, tid = threadIdx.x;
+  const int f = sp.list ? sp.list[front_begin + blockIdx.x] : front_begin + blockIdx.x, tid = threadIdx.x;
   const FrontDesc D = p.fronts[f];
   const SFront S = sp.sf[f];
   const int c6 = 6 * D.c, r6 = 6 * D.r, n = c6 + r6, ld = n + 1;
@@ -823,7 +825,15 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
   if (bad && tid == 0) atomicOr(&g.flags[2], 1);
   // the update matrix first (the parent's launch is next in line), then the L panel (rows 0 .. n, the last one is y)
   if (dbg & 4) return;
-  if (S.ucnt > 0) {
+  if (S.to_fval) {
+    // mixed plan: the parent is a regular front, its extend-add reads this update matrix from Fval in the regular layout
+    // (whole 6 x 6 blocks: the upper halves of the diagonal blocks are mirrored)
+    double* Fv = p.Fval + D.fbase;
+    for (int e = tid; e < (r6 + 1) * r6; e += SF_T) {
+      const int i = e / r6, j = e - i * r6;
+      Fv[(size_t)(c6 + i) * D.ld + c6 + j] = (j <= i) ? F[(c6 + i) * ld + c6 + j] : F[(c6 + j) * ld + c6 + i];
+    }
+  } else if (S.ucnt > 0) {
     double* Ug = sp.Uval + S.ubase;
     for (int ii = tid >> 3; ii <= r6; ii += SF_T >> 3) {
       const int e0 = ii < r6 ? ii * (ii + 1) / 2 : r6 * (r6 + 1) / 2;
@@ -839,10 +849,10 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
 
 // once per topology: where every packed update entry of every front goes in its parent's LDS front
 __global__ __launch_bounds__(SF_T) void k_sfront_upos(FrontPlan p, SFrontPlan sp) {
-  const int f = blockIdx.x, tid = threadIdx.x;
+  const int f = sp.list ? sp.list[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
   const FrontDesc D = p.fronts[f];
-  if (D.parent < 0) return;
   const SFront S = sp.sf[f];
+  if (D.parent < 0 || S.ucnt == 0) return;
   const FrontDesc Pd = p.fronts[D.parent];
   const int rc6 = 6 * D.r, tri = rc6 * (rc6 + 1) / 2, pn = 6 * (Pd.c + Pd.r), pld = pn + 1;
   const int* pcol = sp.urel + S.urel;
@@ -863,7 +873,7 @@ __global__ __launch_bounds__(SF_T) void k_sfront_upos(FrontPlan p, SFrontPlan sp
 // block rows above it, W_ij = -W_ii sum_{k = j}^{i - 1} L_ik W_kj, all its entries side by side (two barriers per block row).
 __global__ __launch_bounds__(SF_T) void k_sfront_invert(FrontPlan p, SFrontPlan sp, int front_begin) {
   extern __shared__ double sh[];     // L11: c6 x ld | W: c6 x ld | T: 6 x ld
-  const int f = front_begin + blockIdx.x, tid = threadIdx.x;
+  const int f = sp.list ? sp.list[front_begin + blockIdx.x] : front_begin + blockIdx.x, tid = threadIdx.x;
   const FrontDesc D = p.fronts[f];
   const SFront S = sp.sf[f];
   const int c6 = 6 * D.c, ld = c6 + 1;
@@ -920,7 +930,7 @@ __global__ __launch_bounds__(SF_T) void k_sfront_invert(FrontPlan p, SFrontPlan 
 // backward substitution of one level (parents first): t = y_c - L21^T x_r, x_c = W^T t
 __global__ __launch_bounds__(SF_T) void k_sfront_bwd(DeviceGraph g, FrontPlan p, SFrontPlan sp, int front_begin) {
   __shared__ double xr[SFRONT_MAX], tv[SFRONT_MAX], red[SF_T];
-  const int f = front_begin + blockIdx.x, tid = threadIdx.x;
+  const int f = sp.list ? sp.list[front_begin + blockIdx.x] : front_begin + blockIdx.x, tid = threadIdx.x;
   const FrontDesc D = p.fronts[f];
   const SFront S = sp.sf[f];
   const int c6 = 6 * D.c, r6 = 6 * D.r, n = c6 + r6;
@@ -974,10 +984,32 @@ __global__ __launch_bounds__(SF_T) void k_sfront_bwd(DeviceGraph g, FrontPlan p,
 
 }  // namespace
 
-void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s) {
+static void sfront_attributes() {
+  static bool attr_set = false;
+  if (attr_set) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sfront_factor), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((size_t)(SFRONT_MAX + 1) * (SFRONT_MAX + 1) * sizeof(double)));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sfront_invert), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((2 * (size_t)SFRONT_MAX + 6) * (SFRONT_MAX + 1) * sizeof(double)));
+  attr_set = true;
+}
+static const int sf_dbg = getenv("PGO_SF_DBG") ? atoi(getenv("PGO_SF_DBG")) : 0;   // timing ablations of k_sfront_factor (results are wrong with any bit set)
+
+void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s, const SFrontPlan* sp) {
   (void)hipMemsetAsync(p.Fval, 0, (size_t)sym.fval_size * sizeof(double), s);
   const long long nt = (long long)p.n_ablk * 36 + 6LL * p.n;
   hipLaunchKernelGGL(k_front_scatter, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, g, p);
+  if (sym.mixed && sp) {
+    // the fronts whose whole subtree is small: level by level in LDS, before the rounds of the others (their subtree roots
+    // leave their update matrices in Fval for the regular extend-add), and their inverses for the backward levels
+    sfront_attributes();
+    const size_t lds = (size_t)(SFRONT_MAX + 1) * (SFRONT_MAX + 1) * sizeof(double);
+    for (size_t l = 0; l + 1 < sym.slevel_ptr.size(); ++l) {
+      const int cnt = sym.slevel_ptr[l + 1] - sym.slevel_ptr[l];
+      if (cnt > 0) hipLaunchKernelGGL(k_sfront_factor, dim3(cnt), dim3(SF_T), lds, s, g, p, *sp, sym.slevel_ptr[l], sf_dbg);
+    }
+    hipLaunchKernelGGL(k_sfront_invert, dim3(sym.n_small), dim3(SF_T), (2 * (size_t)SFRONT_MAX + 6) * (SFRONT_MAX + 1) * sizeof(double), s, p, *sp, 0);
+  }
   for (const FrontLaunch& La : sym.launches) {
     if (La.n_wg <= 0) continue;
     if (La.type == FrontLaunch::ASM) hipLaunchKernelGGL(k_front_extend_add, dim3(La.n_wg), dim3(256), 0, s, p, La.wg_begin);
@@ -987,7 +1019,7 @@ void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSy
   }
 }
 
-void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s) {
+void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s, const SFrontPlan* sp) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_bwd_gemv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
@@ -998,27 +1030,23 @@ void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSym
     if (La.kind == 0) hipLaunchKernelGGL(k_front_bwd_gemv, dim3(La.n_wg), dim3(BWD_T), (size_t)La.lds_bytes, s, p, La.wg_begin);
     else hipLaunchKernelGGL(k_front_bwd_block, dim3(La.n_wg), dim3(BWD_T), 0, s, g, p, La.wg_begin);
   }
+  if (sym.mixed && sp)
+    for (int l = (int)sym.slevel_ptr.size() - 2; l >= 0; --l) {
+      const int cnt = sym.slevel_ptr[l + 1] - sym.slevel_ptr[l];
+      if (cnt > 0) hipLaunchKernelGGL(k_sfront_bwd, dim3(cnt), dim3(SF_T), 0, s, g, p, *sp, sym.slevel_ptr[l]);
+    }
 }
 
-
 void launch_sfront_prepare(const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s) {
-  hipLaunchKernelGGL(k_sfront_upos, dim3(sym.nf), dim3(SF_T), 0, s, p, sp);
+  hipLaunchKernelGGL(k_sfront_upos, dim3(sym.mixed ? sym.n_small : sym.nf), dim3(SF_T), 0, s, p, sp);
 }
 
 void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s) {
-  static bool attr_set = false;
-  const size_t lds_max = (size_t)(SFRONT_MAX + 1) * (SFRONT_MAX + 1) * sizeof(double);
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sfront_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sfront_invert), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((2 * (size_t)SFRONT_MAX + 6) * (SFRONT_MAX + 1) * sizeof(double)));
-    attr_set = true;
-  }
+  sfront_attributes();
   const size_t lds = (size_t)(sym.max_front + 1) * (sym.max_front + 1) * sizeof(double);
-  static const int dbg = getenv("PGO_SF_DBG") ? atoi(getenv("PGO_SF_DBG")) : 0;   // timing ablations (results are wrong with any bit set)
   for (const FrontLevel& L : sym.levels)
     if (L.front_end > L.front_begin)
-      hipLaunchKernelGGL(k_sfront_factor, dim3(L.front_end - L.front_begin), dim3(SF_T), lds, s, g, p, sp, L.front_begin, dbg);
+      hipLaunchKernelGGL(k_sfront_factor, dim3(L.front_end - L.front_begin), dim3(SF_T), lds, s, g, p, sp, L.front_begin, sf_dbg);
   // the inverses W = L11^-1 of all fronts in one launch.  (Forming them level by level on a side stream, in the shadow of the
   // upper levels, was measured: the event hand-overs between the streams cost more than the launch — KITTI-00 0.51 vs 0.43 ms
   // per LM iteration.)

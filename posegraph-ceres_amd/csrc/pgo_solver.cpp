@@ -282,7 +282,7 @@ struct pgo_problem {
   pgo::SFrontPlan splan{};
   DevBuf<pgo::SFront> ds_sf;
   DevBuf<double> ds_L, ds_U, ds_W;
-  DevBuf<int> ds_urel, ds_osrc, ds_upos;
+  DevBuf<int> ds_urel, ds_osrc, ds_upos, ds_list;
   DevBuf<int> df_perm, df_idx, df_child, df_rel, df_cstart, df_col_front, df_ablk_ptr, df_ablk_slot, df_ablk_front, df_ablk_pos, df_wg_job, df_wg_tile,
       df_bwd_front, df_bwd_chunk, df_bwdb_front, df_bwdb_chunk, df_asm_tile, df_asm_contrib;
   DevBuf<pgo::FrontDesc> df_fronts;
@@ -948,6 +948,19 @@ int upload_front(pgo_problem* P) {
   f.col_front = P->df_col_front.p; f.ablk_ptr = P->df_ablk_ptr.p; f.ablk_slot = P->df_ablk_slot.p;
   f.ablk_front = P->df_ablk_front.p; f.ablk_pos = P->df_ablk_pos.p; f.n_ablk = (int)S.ablk_front.size();
   f.jobs = P->df_jobs.p; f.Fval = P->df_Fval.p; f.Winv = P->df_Winv.p; f.x = P->df_x.p;
+  if (S.mixed) {
+    // the small fronts at the bottom of the tree take the small-front kernels (pgo_front.h): their compact arrays
+    HIP_TRY(P->ds_sf.upload(S.sfronts, s));
+    HIP_TRY(P->ds_urel.upload(S.urel, s));
+    HIP_TRY(P->ds_osrc.upload(S.osrc, s));
+    HIP_TRY(P->ds_list.upload(S.slevel_front, s));
+    HIP_TRY(P->ds_L.alloc((size_t)S.sl_size));
+    HIP_TRY(P->ds_U.alloc((size_t)S.su_size));
+    HIP_TRY(P->ds_W.alloc((size_t)S.sw_size));
+    HIP_TRY(P->ds_upos.alloc((size_t)S.su_size));
+    P->splan = pgo::SFrontPlan{P->ds_sf.p, P->ds_list.p, P->ds_urel.p, P->ds_upos.p, P->ds_osrc.p, P->ds_L.p, P->ds_U.p, P->ds_W.p};
+    pgo::launch_sfront_prepare(P->fplan, P->splan, S, s);
+  }
   P->front_usable = true;
   if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] front: plan upload %.2f ms\n", 1e3 * seconds_since(t_up));
   return PGO_OK;
@@ -980,7 +993,7 @@ int upload_sfront(pgo_problem* P) {
   f.perm = P->df_perm.p; f.fronts = P->df_fronts.p; f.idx = P->df_idx.p; f.child = P->df_child.p; f.rel = P->df_rel.p;
   f.ablk_ptr = P->df_ablk_ptr.p; f.ablk_slot = P->df_ablk_slot.p; f.ablk_pos = P->df_ablk_pos.p; f.n_ablk = (int)S.ablk_front.size();
   f.x = P->df_x.p;
-  P->splan = pgo::SFrontPlan{P->ds_sf.p, P->ds_urel.p, P->ds_upos.p, P->ds_osrc.p, P->ds_L.p, P->ds_U.p, P->ds_W.p};
+  P->splan = pgo::SFrontPlan{P->ds_sf.p, nullptr, P->ds_urel.p, P->ds_upos.p, P->ds_osrc.p, P->ds_L.p, P->ds_U.p, P->ds_W.p};
   pgo::launch_sfront_prepare(P->fplan, P->splan, S, s);
   P->sfront_usable = true;
   if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] front: small-front plan upload %.2f ms\n", 1e3 * seconds_since(t_up));
@@ -1109,8 +1122,8 @@ int run_direct(pgo_problem* P) {
     return PGO_OK;
   }
   if (P->front_usable) {
-    pgo::launch_front_factor(P->g, P->fplan, P->fsym, s);
-    pgo::launch_front_solve(P->g, P->fplan, P->fsym, s);
+    pgo::launch_front_factor(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr);
+    pgo::launch_front_solve(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr);
     return PGO_OK;
   }
   const pgo::DirectSymbolic& S = P->dsym;
@@ -2329,12 +2342,12 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     if (!P->direct_usable) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): no GPU factorisation prepared for this problem", kernel);
     if ((k != "direct") && !P->front_usable) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): the multifrontal solver is not in use", kernel);
     pgo::launch_damping(P->g, P->lm.radius, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, 0, s);
-    if (k == "front_solve") pgo::launch_front_factor(P->g, P->fplan, P->fsym, s);
+    if (k == "front_solve") pgo::launch_front_factor(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr);
   }
   auto once = [&]() -> int {
     if (k == "direct") return run_direct(P);
-    if (k == "front_factor") { pgo::launch_front_factor(P->g, P->fplan, P->fsym, s); return 0; }
-    if (k == "front_solve") { pgo::launch_front_solve(P->g, P->fplan, P->fsym, s); return 0; }
+    if (k == "front_factor") { pgo::launch_front_factor(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr); return 0; }
+    if (k == "front_solve") { pgo::launch_front_solve(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr); return 0; }
     if (k == "linearize") pgo::launch_linearize(P->g, s);
     else if (k == "cost") pgo::launch_cost(P->g, P->g.pose_x, 5, s);
     else if (k == "evaluate") pgo::launch_evaluate_edges(P->g, P->g.pose_x, P->d_tmp_a.p, P->d_tmp_b.p, P->d_tmp_c.p, s);

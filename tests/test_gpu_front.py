@@ -170,3 +170,24 @@ def test_small_front_plan_on_chain_like_graphs(gpu, O, ds, monkeypatch):
         assert len(s.iterations) == len(otr)
         assert list(s.iterations["step_is_successful"]) == [int(v) for v in otr[:, 8]]
         assert np.allclose(s.iterations["cost"], otr[:, 1], rtol=1e-9)
+
+
+def test_mixed_plan_small_subtrees_before_the_rounds(gpu, O, ds, monkeypatch):
+    """PGO_FRONT_MIXED=96: the fronts whose whole subtree fits the LDS are factorised by the small-front kernels level by level,
+    the rest by the round schedule (their subtree roots hand their update matrices over in the regular front layout).  Same
+    answers: linear solve vs the oracle <= 1e-9, bit-identical when repeated, on a mesh and on the dense KITTI-like graph."""
+    monkeypatch.setenv("PGO_FRONT_MIXED", "96")
+    monkeypatch.setenv("PGO_FRONT", "1")
+    for g in (ds.manhattan_se3(2000, 8000, seed=3), ds.manhattan_se3(1500, 9000, seed=21, loop_radius=4.0), ds.sphere_layers(n_spheres=3, rings=30, per_ring=30)):
+        prob, poses, og = _pair(gpu, O, g)
+        d2, b = _rhs(g, 2)
+        opt = gpu.SolverOptions(linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
+        x, it = prob.linear_solve(d2, b, opt)
+        xo, _ = O.linear_solve(og, d2, b, linear_solver=0)
+        assert it == 0 and np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+        x2, _ = prob.linear_solve(d2, b, opt)
+        assert np.array_equal(x, x2)
+    s = gpu.solve(gpu.SolverOptions(max_num_iterations=6, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY), prob)
+    _, osum, otr = O.solve(og, O.default_options(max_num_iterations=6, linear_solver=0))
+    assert s.c.factor_kind == 2 and list(s.iterations["step_is_successful"]) == [int(v) for v in otr[:, 8]]
+    assert np.allclose(s.iterations["cost"], otr[:, 1], rtol=1e-7)
