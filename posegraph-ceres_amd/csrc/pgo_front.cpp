@@ -464,6 +464,8 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
   // the chain, not the flops, is what bounds these factorisations.  The backward substitution is scheduled the same way from
   // the root down.
   const long long tile32_below = (long long)env_or("PGO_FRONT_TILE32_BELOW", 192);
+  // width of the outer panels of the factorisation (left-looking inside, one right-looking GEMM behind each): a multiple of 48
+  const int nbo = std::max((int)FRONT_NB, (int)env_or("PGO_FRONT_NBO", FRONT_NBO) / FRONT_NB * FRONT_NB);
   {
     std::vector<int> next_step(nf, 0), nsteps(nf), kids_left(nf), pending(nf, -1);
     std::vector<char> asm_done(nf, 0), finished(nf, 0);
@@ -548,7 +550,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
           const int step = next_step[q]++;
           const int c6 = 6 * D.c, n = 6 * (D.c + D.r), k0 = step * FRONT_NB;
           const int nb = std::min<int>(FRONT_NB, c6 - k0), kend = k0 + nb;
-          const int ostart = (k0 / FRONT_NBO) * FRONT_NBO, oend = std::min(c6, ostart + FRONT_NBO);
+          const int ostart = (k0 / nbo) * nbo, oend = std::min(c6, ostart + nbo);
           const int job = (int)S.jobs.size();
           S.jobs.push_back(FrontJob{D.fbase, D.ld, kend, n + 1, ostart, 0, k0, nb, D.wbase + step * FRONT_NB * FRONT_NB});
           const int ntr = (n + 1 - kend + FRONT_TILE - 1) / FRONT_TILE;
