@@ -899,9 +899,10 @@ __global__ __launch_bounds__(SF_T) void k_sfront_invert(FrontPlan p, SFrontPlan 
       for (; k < ib; ++k) s0 = fma(lrow[k], Ws[k * ld + c], s0);
       Ts[r * ld + c] = (s0 + s1) + (s2 + s3);
     }
-    // the diagonal block of W: inverse of the 6 x 6 lower triangle, one lane per column
-    if (tid < 6) {
-      const int q = tid;
+    // the diagonal block of W: inverse of the 6 x 6 lower triangle, one lane per column (the last six lanes: the first ones
+    // are busy with T)
+    if (tid >= SF_T - 6) {
+      const int q = tid - (SF_T - 6);
       double w[6];
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
