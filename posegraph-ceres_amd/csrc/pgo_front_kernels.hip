@@ -788,13 +788,15 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
 #pragma unroll
       for (int c = 0; c < 6; ++c) row[c] = x[c];
     }
-    if (tid == SF_T - 1) {                         // the factor of the pivot block itself (read back by the write-out below)
+    __syncthreads();
+    // the factor of the pivot block itself (read back by the write-out below; nothing in the trailing update reads it).  AFTER the
+    // barrier: every lane reads the unfactorised block at the top of the step, and a wave that is scheduled late must still find it
+    if (tid == SF_T - 1) {
 #pragma unroll
       for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j) F[(kb + i) * ld + kb + j] = L[i * (i + 1) / 2 + j];
     }
-    __syncthreads();
     const int mt = n - (kb + 6);                   // trailing columns; rows: mt + 1 (with the right-hand side)
     for (int ii = tid >> 3; ii <= mt; ii += SF_T >> 3) {       // 8 lanes share a row, strided over its columns
       const double* a = F + (kb + 6 + ii) * ld + kb;

@@ -137,6 +137,56 @@ struct DevicePool {
 };
 inline DevicePool& device_pool() { static DevicePool* pool = new DevicePool(); return *pool; }   // never destroyed: no HIP calls at exit
 
+// Streams and small pinned blocks are recycled as well: on this stack hipStreamDestroy takes 1.5-3 ms and hipStreamCreate /
+// hipHostMalloc + hipHostFree ~0.5 ms together, i.e. a third of a KITTI-00-scale solve for a caller that builds and destroys
+// one problem per solve (the facade's ceres::Problem does).  A stream is handed back idle (its owner synchronised it); a
+// pinned block is handed back with whatever it held and is cleared by the next owner.  pgo_release_device_memory() empties both.
+struct HostSidePool {
+  std::mutex mu;
+  std::vector<std::pair<int, hipStream_t>> streams;             // (device, stream)
+  std::multimap<size_t, void*> pinned;                          // capacity -> mapped, portable host block
+  static bool off() { static const bool v = getenv("PGO_NO_HOST_POOL") && getenv("PGO_NO_HOST_POOL")[0] == '1'; return v; }
+  hipError_t get_stream(int dev, hipStream_t* out) {
+    if (!off()) {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t i = 0; i < streams.size(); ++i)
+        if (streams[i].first == dev) { *out = streams[i].second; streams[i] = streams.back(); streams.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+  }
+  void put_stream(int dev, hipStream_t s) {
+    if (!off()) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (streams.size() < 64) { streams.emplace_back(dev, s); return; }
+    }
+    (void)hipStreamDestroy(s);
+  }
+  hipError_t get_pinned(size_t bytes, void** out, size_t* cap) {
+    if (!off()) {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = pinned.lower_bound(bytes);
+      if (it != pinned.end() && it->first <= std::max<size_t>(4 * bytes, 4096)) { *out = it->second; *cap = it->first; pinned.erase(it); return hipSuccess; }
+    }
+    *cap = (bytes + 4095) / 4096 * 4096;
+    return hipHostMalloc(out, *cap, hipHostMallocMapped | hipHostMallocPortable);
+  }
+  void put_pinned(void* p, size_t cap) {
+    if (!off()) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (pinned.size() < 64 && cap <= (1u << 20)) { pinned.emplace(cap, p); return; }
+    }
+    (void)hipHostFree(p);
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& ds : streams) (void)hipStreamDestroy(ds.second);
+    streams.clear();
+    for (auto& kv : pinned) (void)hipHostFree(kv.second);
+    pinned.clear();
+  }
+};
+inline HostSidePool& host_side_pool() { static HostSidePool* pool = new HostSidePool(); return *pool; }
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
@@ -246,6 +296,7 @@ struct pgo_problem {
   DevBuf<double> d_bsr2, d_Hdiag2, d_grad2;
   bool spec_ready = false;
   pgo::LmScalars* scal = nullptr;  // pinned, device visible
+  size_t scal_cap = 0;
   // captured CG batches, keyed by the number of iterations in the batch
   struct CapturedBatch { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
   std::unordered_map<int, CapturedBatch> cg_graphs;
@@ -300,12 +351,18 @@ struct pgo_problem {
   LmState lm;
 
   ~pgo_problem() {
+    const bool verbose = getenv("PGO_VERBOSE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms = [&] { return 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     if (analysis_thread.joinable()) analysis_thread.join();
     if (stream_ready) (void)hipStreamSynchronize(stream);   // the device buffers go back to the pool: nothing may be in flight
     drop_graph();
     delete comm;
-    if (scal) (void)hipHostFree(scal);
-    if (stream_ready) (void)hipStreamDestroy(stream);
+    const double t1 = ms();
+    if (scal) host_side_pool().put_pinned(scal, scal_cap);
+    const double t2 = ms();
+    if (stream_ready) host_side_pool().put_stream(device, stream);
+    if (verbose && stream_ready) std::fprintf(stderr, "[pgo] problem teardown: sync %.2f, pinned block %.2f, stream %.2f ms (members follow)\n", t1, t2 - t1, ms() - t2);
   }
   void drop_direct_graph() {
     if (direct_exec) { (void)hipGraphExecDestroy(direct_exec); direct_exec = nullptr; }
@@ -333,7 +390,7 @@ int ensure_device(pgo_problem* P) {
   }
   HIP_TRY(hipSetDevice(P->device));
   if (!P->stream_ready) {
-    HIP_TRY(hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking));
+    HIP_TRY(host_side_pool().get_stream(P->device, &P->stream));
     P->stream_ready = true;
     // Launch sequences are enqueued eagerly by default: on this stack (ROCm 7.2, MI355X) the host runs ahead of the GPU and a
     // captured hipGraph of the same kernels is no faster (C2: 0.317 vs 0.317 ms per LM iteration without residual refreshes,
@@ -343,7 +400,9 @@ int ensure_device(pgo_problem* P) {
     P->use_graph = (gr && gr[0] == '1') && !(ng && ng[0] == '1');
   }
   if (!P->scal) {
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&P->scal), sizeof(pgo::LmScalars), hipHostMallocMapped));
+    void* blk = nullptr;
+    HIP_TRY(host_side_pool().get_pinned(sizeof(pgo::LmScalars), &blk, &P->scal_cap));
+    P->scal = static_cast<pgo::LmScalars*>(blk);
     memset(P->scal, 0, sizeof(pgo::LmScalars));
   }
   return PGO_OK;
@@ -1656,6 +1715,10 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
     any_info = any_info || Q->has_info;
   }
   const int N = pose_begin[n], E = edge_begin[n];
+  static const bool verbose = getenv("PGO_VERBOSE") != nullptr;
+  auto mark = [&](const char* what) {
+    if (verbose) std::fprintf(stderr, "[pgo] batch: %-34s at %.2f ms\n", what, 1e3 * seconds_since(t_begin));
+  };
   M.pp.reserve(N); M.qq.reserve(N); M.cmask.reserve(N);
   M.ia.reserve(E); M.ib.reserve(E); M.meas.reserve((size_t)7 * E);
   if (any_info) M.sqrt_info.reserve((size_t)36 * E);
@@ -1676,11 +1739,13 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
     }
   }
   pgo_problem* P = &M;
+  mark("union built");
   P->no_sfront = true;
   P->want_direct = true;       // the union's host analysis runs beside the array fills and uploads of prepare()
   int rc = prepare(P);
   P->want_direct = false;
   if (rc) return rc;
+  mark("prepare");
   P->opt = o;
   P->g.loss_kind = P->loss_kind;
   P->g.loss_a = P->loss_a;
@@ -1688,11 +1753,13 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
   P->g.pose_c = P->d_pose_c.p;
   rc = prepare_direct(P);
   if (rc) return rc;
+  mark("prepare_direct");
   if (!P->direct_usable || P->dsym.hybrid)
     return set_error(PGO_ERR_UNSUPPORTED, "pgo_solve_batch: the union of the problems is beyond the factorisation's budget; solve them one by one");
   P->split_two_launch = true;   // the device-wide failure flag is not consulted per component: no in-kernel waits in a batch
   rc = prepare_clusters(P, 1);
   if (rc) return rc;
+  mark("prepare_clusters");
   hipStream_t s = P->stream;
   // component tables (device) and the per-component hand-over block (pinned, device visible)
   std::vector<int> pose_comp(N);
@@ -1703,10 +1770,17 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
   HIP_TRY(d_pose_comp.upload(pose_comp, s));
   struct Pinned {
     void* p = nullptr;
-    ~Pinned() { if (p) (void)hipHostFree(p); }
+    size_t cap = 0;
+    hipStream_t s = nullptr;
+    ~Pinned() {
+      if (!p) return;
+      (void)hipStreamSynchronize(s);          // an error return may leave kernels that write the block in flight
+      host_side_pool().put_pinned(p, cap);
+    }
   } pin;
+  pin.s = s;
   const size_t pin_bytes = (size_t)n * (sizeof(pgo::BatchScalars) + sizeof(double) + sizeof(int)) + 64;
-  HIP_TRY(hipHostMalloc(&pin.p, pin_bytes, hipHostMallocMapped));
+  HIP_TRY(host_side_pool().get_pinned(pin_bytes, &pin.p, &pin.cap));
   memset(pin.p, 0, pin_bytes);
   pgo::BatchScalars* out = static_cast<pgo::BatchScalars*>(pin.p);
   double* radius = reinterpret_cast<double*>(out + n);
@@ -1719,6 +1793,7 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
   HIP_TRY(d_partial.alloc((size_t)5 * n * split));
   const pgo::BatchPlan plan{n, d_pose_begin.p, d_edge_begin.p, d_pose_comp.p, radius, accept, out, d_partial.p, split};
 
+  mark("component tables");
   rc = upload_poses(P, P->g.pose_x);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(P->g.pose_c, P->g.pose_x, P->d_pose_x.n * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1727,6 +1802,7 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
   HIP_TRY(P->d_cg_q.zero(s));
   HIP_TRY(P->d_cg_b.zero(s));
   HIP_TRY(P->d_d2.zero(s));
+  mark("poses uploaded");
   const double t_setup = seconds_since(t_begin);
   // Init + IterationZero: cost, state norm and gradient norm of every component at its start (candidate == current point)
   rc = evaluate_gradient_and_jacobian(P, true);
@@ -1734,6 +1810,7 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
   pgo::launch_batch_scalars(P->g, plan, s);
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
+  mark("iteration zero");
   std::vector<LmState> Ls(n);
   for (int c = 0; c < n; ++c) {
     LmState& L = Ls[c];
@@ -1798,8 +1875,10 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
     pgo::launch_batch_scalars(P->g, plan, s);
     HIP_TRY(hipStreamSynchronize(s));
   }
+  mark("rounds done");
   rc = download_poses(P, P->g.pose_x);
   if (rc) return rc;
+  mark("poses downloaded");
   HIP_TRY(hipMemsetAsync(P->d_flags.p, 0, P->d_flags.n * sizeof(int), s));
   const double t_total = seconds_since(t_begin);
   for (int c = 0; c < n; ++c) {
@@ -2081,6 +2160,7 @@ int pgo_solve(pgo_problem* P, const pgo_solver_options* options, pgo_solver_summ
 
 int pgo_release_device_memory(void) {
   device_pool().trim();
+  host_side_pool().trim();
   return PGO_OK;
 }
 

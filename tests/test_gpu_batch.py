@@ -87,3 +87,24 @@ def test_batch_refuses_what_it_does_not_serve(gpu, ds):
         gpu.solve_batch(gpu.SolverOptions(linear_solver_type=gpu.BLOCK_JACOBI_PCG), [pa])
     with pytest.raises(gpu.PgoError):
         gpu.solve_batch(gpu.SolverOptions(linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY), [pa, pb])
+
+
+def test_small_front_plan_with_many_workgroups_in_flight_is_reproducible(gpu, ds, monkeypatch):
+    """Regression (r02): 48 KITTI-00 graphs through the small-front plan = ~14 000 LDS fronts per level, several workgroups per
+    CU, so the waves of one workgroup drift apart.  A pose step of k_sfront_factor used to write the factorised pivot block
+    before every wave had read the unfactorised one: a few components of such a batch came out with 13-15 iterations and a cost
+    off in the 7th digit (and a single solve did so once in ~1000 runs).  The components must agree bit for bit and follow the single solve."""
+    k = np.load(os.path.join(G, "kitti00.npz"))
+    g = ds.PoseGraphData(k["origin"], k["ia"], k["ib"], k["meas"], None)
+    opt = gpu.SolverOptions(max_num_iterations=1000, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
+    monkeypatch.setenv("PGO_SFRONT", "1")
+    prob, _ = gpu.problem_from_graph(g)
+    single = gpu.solve(opt, prob)
+    assert single.c.factor_kind == 3
+    for _ in range(2):
+        pairs = [gpu.problem_from_graph(g) for _ in range(48)]
+        sums = gpu.solve_batch(opt, [p for p, _ in pairs])
+        assert all(s.c.factor_kind == 3 for s in sums)
+        assert {len(s.iterations) for s in sums} == {len(single.iterations)}
+        assert len({s.final_cost for s in sums}) == 1                       # bit for bit among the components
+        assert sums[0].final_cost == pytest.approx(single.final_cost, rel=1e-12)
