@@ -451,9 +451,19 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
   if (pure_small) {
     S.n_launches = 2 * n_levels + 2;
     S.est_us = 8.0 * S.n_launches;
-    if (getenv("PGO_VERBOSE"))
+    if (getenv("PGO_VERBOSE")) {
       std::fprintf(stderr, "[pgo] front: n=%d supernodes %d -> %d small fronts (largest %d scalars), %d levels = %d launches, %.3g flops\n", N, ns0, nf,
                    S.max_front, n_levels, S.n_launches, flops);
+      for (int l = 0; l < n_levels; ++l) {     // what bounds a level's launch: its largest front, its longest pivot chain, its widest fan-in
+        int mc = 0, mn = 0, mk = 0;
+        for (int f = S.levels[l].front_begin; f < S.levels[l].front_end; ++f) {
+          const FrontDesc& D = S.fronts[f];
+          mc = std::max(mc, D.c); mn = std::max(mn, D.c + D.r); mk = std::max(mk, D.child_end - D.child_begin);
+        }
+        std::fprintf(stderr, "[pgo] front:   level %2d: %4d fronts, at most %2d pivot poses, %2d poses per front, %2d children\n", l,
+                     S.levels[l].front_end - S.levels[l].front_begin, mc, mn, mk);
+      }
+    }
     return true;
   }
   // ---- 10. schedule: rounds over the whole tree, not level by level ----
