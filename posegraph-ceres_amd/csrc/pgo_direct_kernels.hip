@@ -1034,7 +1034,8 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
       // bounded wait (PGO_DIRECT_SPLIT_SPINS, default 2^22 polls ~ 1 s): when it runs out — the workgroups of the step were
       // not all resident, e.g. on a partitioned or shared GPU — the solve is flagged and the LM driver repeats the
       // factorisation in the two-launch form (epoch 0) and keeps to it for this problem
-      static const int max_spins = getenv("PGO_DIRECT_SPLIT_SPINS") ? atoi(getenv("PGO_DIRECT_SPLIT_SPINS")) : (1 << 22);
+      const char* spins_env = getenv("PGO_DIRECT_SPLIT_SPINS");     // (read per call: the tests change it within one process)
+      const int max_spins = spins_env ? atoi(spins_env) : (1 << 22);
       hipLaunchKernelGGL(k_chol_split, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin, epoch, max_spins);
     } else {
       if (asm4) hipLaunchKernelGGL(k_chol_assemble4, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin);

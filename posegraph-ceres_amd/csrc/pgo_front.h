@@ -113,6 +113,19 @@ struct SFrontPlan {
   double* Lval;
   double* Uval;
   double* Wval;
+  int* done;          // [2 (nf + 1)] single-launch form: done[f] = epoch once front f has published its update matrix, done[nf]: the ticket
+                      // counter; the second half: the same for the backward substitution (x of front f published)
+};
+// The single-launch form of the small-front factorisation (all levels in one launch): workgroups take fronts in ticket order
+// (children have smaller numbers than their parents, so whatever a workgroup waits for is held by a workgroup that started
+// before it: no residency assumption), a parent polls its children's flags.  epoch: this factorisation's flag value;
+// ticket_base: tickets handed out by the launches before this one; max_spins: a wait that runs out raises flags[2] |= 2 and the
+// host repeats the factorisation level by level (and keeps to that).  done == nullptr: one launch per level, no waiting.
+struct SFrontSync {
+  int* done;
+  unsigned ticket_base;
+  int epoch;
+  int max_spins;
 };
 
 struct FrontPlan {
@@ -188,7 +201,9 @@ void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSym
 // the small-front path: one launch per tree level each
 // once per topology: fills SFrontPlan::upos
 void launch_sfront_prepare(const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s);
-void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s);
-void launch_sfront_solve(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s);
+void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s,
+                          const SFrontSync* fused = nullptr);
+void launch_sfront_solve(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s,
+                         const SFrontSync* fused = nullptr);
 
 }  // namespace pgo

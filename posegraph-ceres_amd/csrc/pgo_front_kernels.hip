@@ -653,10 +653,21 @@ __global__ __launch_bounds__(BWD_T) void k_front_bwd_block(DeviceGraph g, FrontP
 
 // ---- small fronts: the whole front in LDS, one launch per tree level (pgo_front.h) -------------------------------------------
 constexpr int SF_T = 256;
+#ifndef SF_POLL_SLEEP
+#define SF_POLL_SLEEP 1
+#endif
 
-__global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan p, SFrontPlan sp, int front_begin, int dbg) {
+__global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan p, SFrontPlan sp, int front_begin, int dbg, SFrontSync sy) {
   extern __shared__ double F[];     // (n + 1) x ld, ld = n + 1 (n is a multiple of 6: the stride is odd)
-  const int f = sp.list ? sp.list[front_begin + blockIdx.x] : front_begin + blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
+  int fi = blockIdx.x;
+  if (sy.done) {                    // single-launch form: fronts in ticket order (SFrontSync)
+    __shared__ int ticket;
+    if (tid == 0) ticket = (int)(atomicAdd(reinterpret_cast<unsigned*>(sy.done + p.nf), 1u) - sy.ticket_base);
+    __syncthreads();
+    fi = ticket;
+  }
+  const int f = sp.list ? sp.list[front_begin + fi] : front_begin + fi;
   const FrontDesc D = p.fronts[f];
   const SFront S = sp.sf[f];
   const int c6 = 6 * D.c, r6 = 6 * D.r, n = c6 + r6, ld = n + 1;
@@ -709,6 +720,23 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
   }
   if (tid < c6) F[n * ld + tid] = rhs;
   __syncthreads();
+  if (sy.done && nkids > 0) {
+    // single-launch form: the children's update matrices are published by their workgroups (flag after the data, agent scope)
+    // (one lane polls, one child after the other: every poll is a trip to memory, and hundreds of waiting fronts polling all
+    // their children at once slow down the very stores they wait for)
+    if (tid == 0) {
+      int spins = 0;
+      for (int k = 0; k < nkids; ++k) {
+        const int* flag = sy.done + p.child[D.child_begin + k];
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sy.epoch) {
+          if (++spins > sy.max_spins) { atomicOr(&g.flags[2], 2); break; }
+          __builtin_amdgcn_s_sleep(SF_POLL_SLEEP);
+        }
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
   // extend-add, gathered per row of this front: an 8-lane group walks the list of child rows that land in its row (child
   // order: fixed summation order, no atomics; no two groups share a row, so one barrier serves all children)
   if (!(dbg & 2)) {
@@ -844,9 +872,66 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
       for (int jj = tid & 7; jj <= jmax; jj += 8) Ug[e0 + jj] = row[jj];
     }
   }
+  if (sy.done) {                    // publish: every lane's stores first, then the flag
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_store(sy.done + f, sy.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   double* Lg = sp.Lval + S.lbase;
   for (int i = tid / 64; i <= n; i += SF_T / 64)
     for (int j = tid & 63; j < c6; j += 64) Lg[i * c6 + j] = F[i * ld + j];
+  if (!sy.done) return;
+  // single-launch form: W = L11^-1 here as well (k_sfront_invert's block recurrence on the L11 that is still in LDS), in the
+  // shadow of the ancestors' factorisations: only the root's inverse is left on the critical path, and one launch less
+  {
+    const int lw = c6 + 1;
+    double* Ws = F + (n + 1) * ld;
+    double* Ts = Ws + c6 * lw;
+    for (int e = tid; e < c6 * lw; e += SF_T) Ws[e] = 0.0;
+    __syncthreads();
+    for (int ib = 0; ib < c6; ib += 6) {
+      for (int e = tid; e < 6 * ib; e += SF_T) {
+        const int r = e / ib, c = e - r * ib;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        const double* lrow = F + (ib + r) * ld;
+        int k = c - c % 6;
+        for (; k + 3 < ib; k += 4) {
+          const double l0 = lrow[k], l1 = lrow[k + 1], l2 = lrow[k + 2], l3 = lrow[k + 3];
+          const double w0 = Ws[k * lw + c], w1 = Ws[(k + 1) * lw + c], w2 = Ws[(k + 2) * lw + c], w3 = Ws[(k + 3) * lw + c];
+          s0 = fma(l0, w0, s0); s1 = fma(l1, w1, s1); s2 = fma(l2, w2, s2); s3 = fma(l3, w3, s3);
+        }
+        for (; k < ib; ++k) s0 = fma(lrow[k], Ws[k * lw + c], s0);
+        Ts[r * lw + c] = (s0 + s1) + (s2 + s3);
+      }
+      if (tid >= SF_T - 6) {
+        const int q = tid - (SF_T - 6);
+        double w[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          double s = r == q ? 1.0 : 0.0;
+#pragma unroll
+          for (int k = 0; k < r; ++k) s = k >= q ? fma(-F[(ib + r) * ld + ib + k], w[k], s) : s;
+          w[r] = r >= q ? s / F[(ib + r) * ld + ib + r] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) Ws[(ib + r) * lw + ib + q] = w[r];
+      }
+      __syncthreads();
+      for (int e = tid; e < 6 * ib; e += SF_T) {
+        const int r = e / ib, c = e - r * ib;
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) s = fma(Ws[(ib + r) * lw + ib + m], Ts[m * lw + c], s);
+        Ws[(ib + r) * lw + c] = -s;
+      }
+      __syncthreads();
+    }
+    double* Wg = sp.Wval + S.wbase;
+    for (int e = tid; e < c6 * c6; e += SF_T) { const int i = e / c6, j = e - i * c6; Wg[e] = Ws[i * lw + j]; }
+  }
 }
 
 // once per topology: where every packed update entry of every front goes in its parent's LDS front
@@ -931,9 +1016,17 @@ __global__ __launch_bounds__(SF_T) void k_sfront_invert(FrontPlan p, SFrontPlan 
 }
 
 // backward substitution of one level (parents first): t = y_c - L21^T x_r, x_c = W^T t
-__global__ __launch_bounds__(SF_T) void k_sfront_bwd(DeviceGraph g, FrontPlan p, SFrontPlan sp, int front_begin) {
+__global__ __launch_bounds__(SF_T) void k_sfront_bwd(DeviceGraph g, FrontPlan p, SFrontPlan sp, int front_begin, SFrontSync sy) {
   __shared__ double xr[SFRONT_MAX], tv[SFRONT_MAX], red[SF_T];
-  const int f = sp.list ? sp.list[front_begin + blockIdx.x] : front_begin + blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
+  int fi = blockIdx.x;
+  if (sy.done) {                    // single-launch form: the root first, a front waits for its parent (tickets as in k_sfront_factor)
+    __shared__ int ticket;
+    if (tid == 0) ticket = (int)(atomicAdd(reinterpret_cast<unsigned*>(sy.done + p.nf), 1u) - sy.ticket_base);
+    __syncthreads();
+    fi = p.nf - 1 - ticket;
+  }
+  const int f = sp.list ? sp.list[front_begin + fi] : front_begin + fi;
   const FrontDesc D = p.fronts[f];
   const SFront S = sp.sf[f];
   const int c6 = 6 * D.c, r6 = 6 * D.r, n = c6 + r6;
@@ -952,6 +1045,17 @@ __global__ __launch_bounds__(SF_T) void k_sfront_bwd(DeviceGraph g, FrontPlan p,
     wv[u] = (on && iw < c6) ? Wg[(size_t)iw * c6 + j] : 0.0;
   }
   const double yj = tid < c6 ? Lg[(size_t)n * c6 + tid] : 0.0;
+  if (sy.done && D.parent >= 0) {   // x of every ancestor is published once the parent's flag is up (it waited for its own parent)
+    if (tid == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(sy.done + D.parent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sy.epoch) {
+        if (++spins > sy.max_spins) { atomicOr(&g.flags[2], 2); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
   for (int i = tid; i < r6; i += SF_T) xr[i] = p.x[6 * (size_t)p.idx[D.idx_begin + i / 6] + i % 6];
   __syncthreads();
   double s = 0.0;
@@ -983,6 +1087,14 @@ __global__ __launch_bounds__(SF_T) void k_sfront_bwd(DeviceGraph g, FrontPlan p,
     p.x[6 * (size_t)col + tid % 6] = x;
     g.cg_x[6 * (size_t)p.perm[col] + tid % 6] = x;
   }
+  if (sy.done) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_store(sy.done + f, sy.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 }  // namespace
@@ -991,7 +1103,7 @@ static void sfront_attributes() {
   static bool attr_set = false;
   if (attr_set) return;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sfront_factor), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)((size_t)(SFRONT_MAX + 1) * (SFRONT_MAX + 1) * sizeof(double)));
+                            (int)(((size_t)(SFRONT_MAX + 1) * (SFRONT_MAX + 1) + (SFRONT_MAX + 6) * (SFRONT_MAX + 1)) * sizeof(double)));   // front + W and scratch of its inversion (single-launch form)
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sfront_invert), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)((2 * (size_t)SFRONT_MAX + 6) * (SFRONT_MAX + 1) * sizeof(double)));
   attr_set = true;
@@ -1009,7 +1121,7 @@ void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSy
     const size_t lds = (size_t)(SFRONT_MAX + 1) * (SFRONT_MAX + 1) * sizeof(double);
     for (size_t l = 0; l + 1 < sym.slevel_ptr.size(); ++l) {
       const int cnt = sym.slevel_ptr[l + 1] - sym.slevel_ptr[l];
-      if (cnt > 0) hipLaunchKernelGGL(k_sfront_factor, dim3(cnt), dim3(SF_T), lds, s, g, p, *sp, sym.slevel_ptr[l], sf_dbg);
+      if (cnt > 0) hipLaunchKernelGGL(k_sfront_factor, dim3(cnt), dim3(SF_T), lds, s, g, p, *sp, sym.slevel_ptr[l], sf_dbg, SFrontSync{nullptr, 0u, 0, 0});
     }
     hipLaunchKernelGGL(k_sfront_invert, dim3(sym.n_small), dim3(SF_T), (2 * (size_t)SFRONT_MAX + 6) * (SFRONT_MAX + 1) * sizeof(double), s, p, *sp, 0);
   }
@@ -1036,7 +1148,7 @@ void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSym
   if (sym.mixed && sp)
     for (int l = (int)sym.slevel_ptr.size() - 2; l >= 0; --l) {
       const int cnt = sym.slevel_ptr[l + 1] - sym.slevel_ptr[l];
-      if (cnt > 0) hipLaunchKernelGGL(k_sfront_bwd, dim3(cnt), dim3(SF_T), 0, s, g, p, *sp, sym.slevel_ptr[l]);
+      if (cnt > 0) hipLaunchKernelGGL(k_sfront_bwd, dim3(cnt), dim3(SF_T), 0, s, g, p, *sp, sym.slevel_ptr[l], SFrontSync{nullptr, 0u, 0, 0});
     }
 }
 
@@ -1044,12 +1156,24 @@ void launch_sfront_prepare(const FrontPlan& p, const SFrontPlan& sp, const Front
   hipLaunchKernelGGL(k_sfront_upos, dim3(sym.mixed ? sym.n_small : sym.nf), dim3(SF_T), 0, s, p, sp);
 }
 
-void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s) {
+void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s,
+                          const SFrontSync* fused) {
   sfront_attributes();
   const size_t lds = (size_t)(sym.max_front + 1) * (sym.max_front + 1) * sizeof(double);
-  for (const FrontLevel& L : sym.levels)
-    if (L.front_end > L.front_begin)
-      hipLaunchKernelGGL(k_sfront_factor, dim3(L.front_end - L.front_begin), dim3(SF_T), lds, s, g, p, sp, L.front_begin, sf_dbg);
+  if (fused && fused->done) {
+    // (the front, then room for W and the six-row scratch of its inversion)
+    size_t lds_inv = 0;
+    for (const FrontDesc& D : sym.fronts) {
+      const size_t c6 = 6 * (size_t)D.c, n = c6 + 6 * (size_t)D.r;
+      lds_inv = std::max(lds_inv, ((n + 1) * (n + 1) + (c6 + 6) * (c6 + 1)) * sizeof(double));
+    }
+    hipLaunchKernelGGL(k_sfront_factor, dim3(sym.nf), dim3(SF_T), lds_inv, s, g, p, sp, 0, sf_dbg, *fused);
+    return;
+  } else {
+    for (const FrontLevel& L : sym.levels)
+      if (L.front_end > L.front_begin)
+        hipLaunchKernelGGL(k_sfront_factor, dim3(L.front_end - L.front_begin), dim3(SF_T), lds, s, g, p, sp, L.front_begin, sf_dbg, SFrontSync{nullptr, 0u, 0, 0});
+  }
   // the inverses W = L11^-1 of all fronts in one launch.  (Forming them level by level on a side stream, in the shadow of the
   // upper levels, was measured: the event hand-overs between the streams cost more than the launch — KITTI-00 0.51 vs 0.43 ms
   // per LM iteration.)
@@ -1058,10 +1182,15 @@ void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p, const SFront
   hipLaunchKernelGGL(k_sfront_invert, dim3(sym.nf), dim3(SF_T), (2 * (size_t)c6max + 6) * (c6max + 1) * sizeof(double), s, p, sp, 0);
 }
 
-void launch_sfront_solve(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s) {
+void launch_sfront_solve(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s,
+                         const SFrontSync* fused) {
+  if (fused && fused->done) {
+    hipLaunchKernelGGL(k_sfront_bwd, dim3(sym.nf), dim3(SF_T), 0, s, g, p, sp, 0, *fused);
+    return;
+  }
   for (int l = (int)sym.levels.size() - 1; l >= 0; --l) {
     const FrontLevel& L = sym.levels[l];
-    if (L.front_end > L.front_begin) hipLaunchKernelGGL(k_sfront_bwd, dim3(L.front_end - L.front_begin), dim3(SF_T), 0, s, g, p, sp, L.front_begin);
+    if (L.front_end > L.front_begin) hipLaunchKernelGGL(k_sfront_bwd, dim3(L.front_end - L.front_begin), dim3(SF_T), 0, s, g, p, sp, L.front_begin, SFrontSync{nullptr, 0u, 0, 0});
   }
 }
 

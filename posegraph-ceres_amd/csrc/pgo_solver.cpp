@@ -313,6 +313,9 @@ struct pgo_problem {
   DevBuf<int> dd_split_blk, dd_split_sub, dd_split_sub_diag, dd_upd_split, dd_panel_cols, dd_blk_lpos, dd_split_dblk, dd_col_flag;
   int direct_epoch = 0;
   bool split_two_launch = false;   // a single-launch SPLIT step timed out once: this problem keeps to the two-launch form
+  bool sfront_levels = false;      // small-front plan: one launch per level (a wait of the single-launch form ran out, or PGO_SFRONT_FUSED=0)
+  int sfront_epoch = 0;
+  unsigned sfront_tickets = 0;     // tickets handed out by the single-launch factorisations so far
   DevBuf<uint8_t> dd_split_diag;
   DevBuf<int> dd_perm, dd_col_ptr, dd_blk_row, dd_asrc_ptr, dd_asrc_slot, dd_upd_ptr, dd_upd_a, dd_upd_b, dd_level_ptr,
       dd_level_cols, dd_rowl_ptr, dd_rowl_blk, dd_rowl_col;
@@ -333,7 +336,7 @@ struct pgo_problem {
   pgo::SFrontPlan splan{};
   DevBuf<pgo::SFront> ds_sf;
   DevBuf<double> ds_L, ds_U, ds_W;
-  DevBuf<int> ds_urel, ds_osrc, ds_upos, ds_list;
+  DevBuf<int> ds_urel, ds_osrc, ds_upos, ds_list, ds_done;
   DevBuf<int> df_perm, df_idx, df_child, df_rel, df_cstart, df_col_front, df_ablk_ptr, df_ablk_slot, df_ablk_front, df_ablk_pos, df_wg_job, df_wg_tile,
       df_bwd_front, df_bwd_chunk, df_bwdb_front, df_bwdb_chunk, df_asm_tile, df_asm_contrib;
   DevBuf<pgo::FrontDesc> df_fronts;
@@ -1017,7 +1020,7 @@ int upload_front(pgo_problem* P) {
     HIP_TRY(P->ds_U.alloc((size_t)S.su_size));
     HIP_TRY(P->ds_W.alloc((size_t)S.sw_size));
     HIP_TRY(P->ds_upos.alloc((size_t)S.su_size));
-    P->splan = pgo::SFrontPlan{P->ds_sf.p, P->ds_list.p, P->ds_urel.p, P->ds_upos.p, P->ds_osrc.p, P->ds_L.p, P->ds_U.p, P->ds_W.p};
+    P->splan = pgo::SFrontPlan{P->ds_sf.p, P->ds_list.p, P->ds_urel.p, P->ds_upos.p, P->ds_osrc.p, P->ds_L.p, P->ds_U.p, P->ds_W.p, nullptr};
     pgo::launch_sfront_prepare(P->fplan, P->splan, S, s);
   }
   P->front_usable = true;
@@ -1052,7 +1055,15 @@ int upload_sfront(pgo_problem* P) {
   f.perm = P->df_perm.p; f.fronts = P->df_fronts.p; f.idx = P->df_idx.p; f.child = P->df_child.p; f.rel = P->df_rel.p;
   f.ablk_ptr = P->df_ablk_ptr.p; f.ablk_slot = P->df_ablk_slot.p; f.ablk_pos = P->df_ablk_pos.p; f.n_ablk = (int)S.ablk_front.size();
   f.x = P->df_x.p;
-  P->splan = pgo::SFrontPlan{P->ds_sf.p, nullptr, P->ds_urel.p, P->ds_upos.p, P->ds_osrc.p, P->ds_L.p, P->ds_U.p, P->ds_W.p};
+  HIP_TRY(P->ds_done.alloc(2 * ((size_t)S.nf + 1)));      // flags of the single-launch forms (factorisation, backward substitution) + their ticket counters
+  HIP_TRY(P->ds_done.zero(s));
+  P->sfront_epoch = 0;
+  P->sfront_tickets = 0;
+  {
+    const char* fu = getenv("PGO_SFRONT_FUSED");
+    P->sfront_levels = fu && fu[0] == '0';
+  }
+  P->splan = pgo::SFrontPlan{P->ds_sf.p, nullptr, P->ds_urel.p, P->ds_upos.p, P->ds_osrc.p, P->ds_L.p, P->ds_U.p, P->ds_W.p, P->ds_done.p};
   pgo::launch_sfront_prepare(P->fplan, P->splan, S, s);
   P->sfront_usable = true;
   if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] front: small-front plan upload %.2f ms\n", 1e3 * seconds_since(t_up));
@@ -1176,8 +1187,27 @@ int prepare_direct(pgo_problem* P) {
 int run_direct(pgo_problem* P) {
   hipStream_t s = P->stream;
   if (P->sfront_usable) {
-    pgo::launch_sfront_factor(P->g, P->fplan, P->splan, P->fsym, s);
-    pgo::launch_sfront_solve(P->g, P->fplan, P->splan, P->fsym, s);
+    if (!P->sfront_levels) {
+      // all levels in one launch (SFrontSync): a parent waits for its children's flags instead of for the end of their launch
+      const char* sp_env = getenv("PGO_SFRONT_SPINS");
+      const int max_spins = sp_env ? atoi(sp_env) : 4000000;
+      if (++P->sfront_epoch == 0x7fffffff) {     // (the ticket counters keep counting: they wrap with the host's copy)
+        P->sfront_epoch = 1;
+        HIP_TRY(hipMemsetAsync(P->ds_done.p, 0, (size_t)P->fsym.nf * sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(P->ds_done.p + P->fsym.nf + 1, 0, (size_t)P->fsym.nf * sizeof(int), s));
+      }
+      const pgo::SFrontSync sy{P->ds_done.p, P->sfront_tickets, P->sfront_epoch, max_spins};
+      const pgo::SFrontSync sy_bwd{P->ds_done.p + P->fsym.nf + 1, P->sfront_tickets, P->sfront_epoch, max_spins};
+      P->sfront_tickets += (unsigned)P->fsym.nf;
+      pgo::launch_sfront_factor(P->g, P->fplan, P->splan, P->fsym, s, &sy);
+      // The backward substitution stays one launch per level: in its single-launch form (PGO_SFRONT_FUSED_BWD=1) every front of
+      // the tree polls its parent's flag at once and the ten hand-overs take 88 us against 50 us for the ten launches (KITTI-00).
+      static const bool fused_bwd = getenv("PGO_SFRONT_FUSED_BWD") && getenv("PGO_SFRONT_FUSED_BWD")[0] == '1';
+      pgo::launch_sfront_solve(P->g, P->fplan, P->splan, P->fsym, s, fused_bwd ? &sy_bwd : nullptr);
+    } else {
+      pgo::launch_sfront_factor(P->g, P->fplan, P->splan, P->fsym, s);
+      pgo::launch_sfront_solve(P->g, P->fplan, P->splan, P->fsym, s);
+    }
     return PGO_OK;
   }
   if (P->front_usable) {
@@ -1572,11 +1602,12 @@ int lm_advance(pgo_problem* P) {
     if (spec) launch_speculative_linearize(P, 0);
     rc = wait_handoff(P);
     if (rc) return rc;
-    if ((P->scal->linearize_bad & 4) && !P->front_usable && !P->sfront_usable && !P->split_two_launch) {
-      // a single-launch SPLIT step waited in vain for a column's diagonal block (its workgroups were not all resident):
-      // not a numerical failure — repeat this factorisation in the two-launch form and keep to it
-      P->split_two_launch = true;
-      if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: single-launch SPLIT step timed out; two-launch form from now on\n");
+    if ((P->scal->linearize_bad & 4) && !P->front_usable && (P->sfront_usable ? !P->sfront_levels : !P->split_two_launch)) {
+      // a single-launch SPLIT step waited in vain for a column's diagonal block (its workgroups were not all resident), or a
+      // front of the single-launch small-front factorisation for a child: not a numerical failure — repeat this factorisation
+      // in the form without in-kernel waits and keep to it
+      if (P->sfront_usable) P->sfront_levels = true; else P->split_two_launch = true;
+      if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: an in-kernel wait of the single-launch factorisation timed out; one launch per step from now on\n");
       arm_handoff(P);
       rc = run_direct(P);
       if (rc) return rc;
@@ -1757,6 +1788,7 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
   if (!P->direct_usable || P->dsym.hybrid)
     return set_error(PGO_ERR_UNSUPPORTED, "pgo_solve_batch: the union of the problems is beyond the factorisation's budget; solve them one by one");
   P->split_two_launch = true;   // the device-wide failure flag is not consulted per component: no in-kernel waits in a batch
+  P->sfront_levels = true;
   rc = prepare_clusters(P, 1);
   if (rc) return rc;
   mark("prepare_clusters");
@@ -2360,8 +2392,8 @@ int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const do
     if (rc) return rc;
     pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s);
     HIP_TRY(hipStreamSynchronize(s));
-    if ((P->scal->linearize_bad & 4) && !P->front_usable && !P->split_two_launch) {   // SPLIT wait ran out: two-launch form (lm_advance)
-      P->split_two_launch = true;
+    if ((P->scal->linearize_bad & 4) && !P->front_usable && (P->sfront_usable ? !P->sfront_levels : !P->split_two_launch)) {   // an in-kernel wait ran out (lm_advance)
+      if (P->sfront_usable) P->sfront_levels = true; else P->split_two_launch = true;
       rc = run_direct(P);
       if (rc) return rc;
       pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s);

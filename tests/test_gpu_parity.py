@@ -486,6 +486,31 @@ def test_split_step_timeout_falls_back_to_two_launches(gpu, O, ds, monkeypatch):
     assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-7)
 
 
+def test_small_front_single_launch_timeout_falls_back_to_levels(gpu, O, ds, monkeypatch):
+    """The single-launch form of the small-front factorisation (all tree levels in one launch, a front polls its children's
+    flags) with the wait budget forced to zero (PGO_SFRONT_SPINS=0): the driver repeats the factorisation level by level, keeps
+    to that form, and the LM trace is the oracle's; and both forms give bit-identical traces when nothing times out."""
+    k = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti00.npz"))
+    g = ds.PoseGraphData(k["origin"], k["ia"], k["ib"], k["meas"], None)
+    opt = gpu.SolverOptions(max_num_iterations=8, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
+    og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
+    _, osum, otr = O.solve(og, O.default_options(max_num_iterations=8, linear_solver=0))
+    traces = []
+    for env in ({"PGO_SFRONT_SPINS": "0"}, {"PGO_SFRONT_FUSED": "0"}, {}):
+        for key in ("PGO_SFRONT_SPINS", "PGO_SFRONT_FUSED"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        prob, poses = gpu.problem_from_graph(g)
+        s = gpu.solve(opt, prob)
+        assert s.linear_solver_used == 0 and s.c.factor_kind == 3
+        assert len(otr) == len(s.iterations)
+        assert list(s.iterations["step_is_successful"]) == [int(v) for v in otr[:, 8]]
+        assert np.allclose(s.iterations["cost"], otr[:, 1], rtol=1e-7)
+        traces.append((tuple(float(c) for c in s.iterations["cost"]), poses.tobytes()))
+    assert traces[0] == traces[1] == traces[2]
+
+
 @pytest.mark.parametrize("name,exact", [("manhattan1000", True), ("sphere2x20", True), ("manhattan2000", True), ("manhattan1000", False)])
 def test_traces_to_convergence_match_oracle(gpu, O, ds, name, exact):
     """The WHOLE trust-region trajectory, not its first iterations: the reference's options (max 300 iterations, default
