@@ -733,9 +733,12 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
           __builtin_amdgcn_s_sleep(SF_POLL_SLEEP);
         }
       }
+      // ONE wave acquires at agent scope (the invalidation acts on this CU's vector cache and this XCD's L2, which the four
+      // waves share); the barrier orders the others behind it.  With an acquire fence in every wave and a release fence in
+      // every wave before the flag, a tree level's hand-over took ~12 us; this way ~5 (KITTI-00: 231 -> 174 us per factorisation).
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   // extend-add, gathered per row of this front: an 8-lane group walks the list of child rows that land in its row (child
   // order: fixed summation order, no atomics; no two groups share a row, so one barrier serves all children)
@@ -872,8 +875,7 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
       for (int jj = tid & 7; jj <= jmax; jj += 8) Ug[e0 + jj] = row[jj];
     }
   }
-  if (sy.done) {                    // publish: every lane's stores first, then the flag
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (sy.done) {                    // publish: every lane's stores are in the L2 behind the barrier, ONE wave writes them back, then the flag
     __syncthreads();
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1052,9 +1054,9 @@ __global__ __launch_bounds__(SF_T) void k_sfront_bwd(DeviceGraph g, FrontPlan p,
         if (++spins > sy.max_spins) { atomicOr(&g.flags[2], 2); break; }
         __builtin_amdgcn_s_sleep(1);
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // one wave acquires, the barrier orders the others behind it (k_sfront_factor)
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   for (int i = tid; i < r6; i += SF_T) xr[i] = p.x[6 * (size_t)p.idx[D.idx_begin + i / 6] + i % 6];
   __syncthreads();
@@ -1088,7 +1090,6 @@ __global__ __launch_bounds__(SF_T) void k_sfront_bwd(DeviceGraph g, FrontPlan p,
     g.cg_x[6 * (size_t)p.perm[col] + tid % 6] = x;
   }
   if (sy.done) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
