@@ -9,6 +9,7 @@
 //  3. for every block of L: the BSR slots that initialise it and the list of (L_ik, L_jk) update pairs.
 //  4. elimination-tree levels = the launch schedule; row lists for the forward solve.
 #include "pgo_direct.h"
+#include "pgo_pool.h"
 
 #include <algorithm>
 #include <atomic>
@@ -31,6 +32,14 @@ struct Csr {
   int deg(int v) const { return ptr[v + 1] - ptr[v]; }
 };
 
+// fn(lo, hi) over contiguous pieces of [0, n) on the host worker pool (one piece per `grain` items at least)
+template <class F>
+void parallel_ranges(int n, int grain, F&& fn) {
+  const int nt = n < 2 * grain ? 1 : std::min(HostPool::get().width(), n / grain);
+  if (nt <= 1) { fn(0, n); return; }
+  HostPool::get().run(nt, [&](int i) { fn((int)((long long)n * i / nt), (int)((long long)n * (i + 1) / nt)); });
+}
+
 Csr build_adjacency(int N, const std::vector<int>& ia, const std::vector<int>& ib) {
   // neighbour lists, each sorted and without duplicates (bucket by vertex, then sort the short lists)
   Csr g;
@@ -47,16 +56,21 @@ Csr build_adjacency(int N, const std::vector<int>& ia, const std::vector<int>& i
     idx[fill[ia[k]]++] = ib[k];
     idx[fill[ib[k]]++] = ia[k];
   }
+  // sort + unique in place (fill[v] <- the number of distinct neighbours), prefix sum, compaction: vertex ranges side by side
+  parallel_ranges(N, 8192, [&](int lo, int hi) {
+    for (int v = lo; v < hi; ++v) {
+      int* b = idx.data() + ptr[v];
+      int* e = idx.data() + ptr[v + 1];
+      std::sort(b, e);
+      fill[v] = (int)(std::unique(b, e) - b);
+    }
+  });
   g.ptr.assign(N + 1, 0);
-  g.idx.reserve(idx.size());
-  for (int v = 0; v < N; ++v) {
-    int* lo = idx.data() + ptr[v];
-    int* hi = idx.data() + ptr[v + 1];
-    std::sort(lo, hi);
-    hi = std::unique(lo, hi);
-    g.idx.insert(g.idx.end(), lo, hi);
-    g.ptr[v + 1] = (int)g.idx.size();
-  }
+  for (int v = 0; v < N; ++v) g.ptr[v + 1] = g.ptr[v] + fill[v];
+  g.idx.resize(g.ptr[N]);
+  parallel_ranges(N, 8192, [&](int lo, int hi) {
+    for (int v = lo; v < hi; ++v) std::copy(idx.data() + ptr[v], idx.data() + ptr[v] + fill[v], g.idx.data() + g.ptr[v]);
+  });
   return g;
 }
 
@@ -247,10 +261,7 @@ void dissect_ranges(DissectShared& sh, std::vector<std::pair<int, int>> roots, i
       cv.notify_all();
     }
   };
-  std::vector<std::thread> th;
-  th.reserve(nt);
-  for (int t = 0; t < nt; ++t) th.emplace_back(worker);
-  for (std::thread& t : th) t.join();
+  HostPool::get().run(nt, [&](int) { worker(); });    // (a worker only waits while another one is at work: slots need not overlap)
 }
 
 }  // namespace
@@ -301,17 +312,13 @@ static void for_components(const Components& C, Body&& body) {
   const int nt = component_workers(C);
   if (nt <= 1) { for (int c = 0; c < nc; ++c) body(c, 0); return; }
   std::atomic<int> next(0);
-  std::vector<std::thread> th;
-  th.reserve(nt);
-  for (int t = 0; t < nt; ++t)
-    th.emplace_back([&, t]() {
-      for (;;) {
-        const int c = next.fetch_add(1);
-        if (c >= nc) return;
-        body(c, t);
-      }
-    });
-  for (std::thread& t : th) t.join();
+  HostPool::get().run(nt, [&](int t) {
+    for (;;) {
+      const int c = next.fetch_add(1);
+      if (c >= nc) return;
+      body(c, t);
+    }
+  });
 }
 
 // Nested dissection of every component on its own (a component gets the order it gets as a graph of its own), components
@@ -440,13 +447,16 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   S.rowl_blk.resize(S.rowl_ptr[N]);
   S.rowl_col.resize(S.rowl_ptr[N]);
   {
+    // (a row and the columns that reach it belong to one component: the components of a batched solve side by side)
     std::vector<int> fill(S.rowl_ptr.begin(), S.rowl_ptr.end() - 1);
-    for (int k = 0; k < N; ++k)
-      for (int a = 0; a < st_size(k); ++a) {
-        const int q = fill[st_at(k)[a]]++;
-        S.rowl_blk[q] = S.col_ptr[k] + 1 + a;
-        S.rowl_col[q] = k;
-      }
+    for_components(comps, [&](int c, int) {
+      for (int k = comps.ptr[c]; k < comps.ptr[c + 1]; ++k)
+        for (int a = 0; a < st_size(k); ++a) {
+          const int q = fill[st_at(k)[a]]++;
+          S.rowl_blk[q] = S.col_ptr[k] + 1 + a;
+          S.rowl_col[q] = k;
+        }
+    });
   }
   phase("row lists");
   // ---- 3b. update pairs per target block ----
@@ -485,17 +495,13 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
     const int nt = (pairs < 200000 || hw < 2) ? 1 : std::min(hw, 16);
     if (nt <= 1) { for (int j = 0; j < N; ++j) body(j); return; }
     std::atomic<int> next(0);
-    std::vector<std::thread> th;
-    th.reserve(nt);
-    for (int t = 0; t < nt; ++t)
-      th.emplace_back([&]() {
-        for (;;) {   // the work sits in the separator columns at the end: small chunks, handed out from the end
-          const int c = next.fetch_add(16);
-          if (c >= N) return;
-          for (int j = N - 1 - c; j >= std::max(0, N - 16 - c); --j) body(j);
-        }
-      });
-    for (std::thread& t : th) t.join();
+    HostPool::get().run(nt, [&](int) {
+      for (;;) {   // the work sits in the separator columns at the end: small chunks, handed out from the end
+        const int c = next.fetch_add(16);
+        if (c >= N) return;
+        for (int j = N - 1 - c; j >= std::max(0, N - 16 - c); --j) body(j);
+      }
+    });
   };
   for_columns([&](int j) { walk_column(j, [&](int t, int, int) { ++S.upd_ptr[t + 1]; }); });
   if (broken) return false;
@@ -514,14 +520,16 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   // ---- 3c. BSR sources per block ----
   S.asrc_ptr.assign(S.nb + 1, 0);
   std::vector<int> src_block(n_slots, -1);
-  for (int t = 0; t < n_slots; ++t) {
-    const uint8_t side = slot_side[t];
-    if (side == SIDE_PAD) continue;
-    const int i = S.iperm[slot_row[t]];
-    if (side == SIDE_DIAG) { src_block[t] = S.col_ptr[i]; continue; }
-    const int j = S.iperm[slot_col[t]];
-    if (i > j) src_block[t] = block_of(i, j);   // the (j,i) twin slot carries the transposed block: skipped
-  }
+  parallel_ranges(n_slots, 16384, [&](int lo, int hi) {
+    for (int t = lo; t < hi; ++t) {
+      const uint8_t side = slot_side[t];
+      if (side == SIDE_PAD) continue;
+      const int i = S.iperm[slot_row[t]];
+      if (side == SIDE_DIAG) { src_block[t] = S.col_ptr[i]; continue; }
+      const int j = S.iperm[slot_col[t]];
+      if (i > j) src_block[t] = block_of(i, j);   // the (j,i) twin slot carries the transposed block: skipped
+    }
+  });
   for (int t = 0; t < n_slots; ++t) if (src_block[t] >= 0) ++S.asrc_ptr[src_block[t] + 1];
   for (int t = 0; t < S.nb; ++t) S.asrc_ptr[t + 1] += S.asrc_ptr[t];
   S.asrc_slot.resize(S.asrc_ptr[S.nb]);
@@ -552,7 +560,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   {
     std::vector<int> lpos(N);
     for (int q = 0; q < N; ++q) lpos[S.level_cols[q]] = q;
-    for (int b = 0; b < S.nb; ++b) S.blk_lpos[b] = lpos[S.blk_row[b]];
+    parallel_ranges(S.nb, 32768, [&](int lo, int hi) { for (int b = lo; b < hi; ++b) S.blk_lpos[b] = lpos[S.blk_row[b]]; });
   }
   // fused tail: the longest suffix of levels that each hold at most 8 columns
   S.fused_from_level = S.n_levels;
@@ -565,32 +573,41 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   // per-column pass.  A level is split when its one-wave-per-column cost exceeds HEAVY steps.
   static const double HEAVY = getenv("PGO_DIRECT_HEAVY") ? atof(getenv("PGO_DIRECT_HEAVY")) : 16.0;
   std::vector<double> level_cost(S.n_levels, 0.0), split_cost(S.n_levels, 0.0);
-  for (int l = 0; l < S.n_levels; ++l) {
-    double worst = 0.0, worst_blk = 0.0, worst_fin = 0.0;
-    for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; ++q) {
-      const int j = S.level_cols[q];
-      const int b0 = S.col_ptr[j], nblk = S.col_ptr[j + 1] - b0;
-      double col = 1.0 + (S.upd_ptr[b0 + 1] - S.upd_ptr[b0] + 9) / 10;
-      for (int t = 1; t < nblk; t += 10) {
-        const int bc = std::min(10, nblk - t), gpb = 10 / bc;
-        int mx = 0;
-        for (int u = t; u < t + bc; ++u) mx = std::max(mx, (S.upd_ptr[b0 + u + 1] - S.upd_ptr[b0 + u] + gpb - 1) / gpb);
-        col += 1.0 + mx;
+  {
+    // per column: the cost of walking it with one wave, and of its heaviest block; maxima per level (positions of level_cols
+    // side by side, every piece with maxima of its own, folded afterwards)
+    std::mutex fold;
+    std::vector<double> worst_blk(S.n_levels, 0.0);
+    parallel_ranges(N, 8192, [&](int qlo, int qhi) {
+      std::vector<double> w(S.n_levels, 0.0), wb(S.n_levels, 0.0);
+      int l = (int)(std::upper_bound(S.level_ptr.begin(), S.level_ptr.end(), qlo) - S.level_ptr.begin()) - 1;
+      for (int q = qlo; q < qhi; ++q) {
+        while (q >= S.level_ptr[l + 1]) ++l;
+        const int j = S.level_cols[q];
+        const int b0 = S.col_ptr[j], nblk = S.col_ptr[j + 1] - b0;
+        double col = 1.0 + (S.upd_ptr[b0 + 1] - S.upd_ptr[b0] + 9) / 10;
+        for (int t = 1; t < nblk; t += 10) {
+          const int bc = std::min(10, nblk - t), gpb = 10 / bc;
+          int mx = 0;
+          for (int u = t; u < t + bc; ++u) mx = std::max(mx, (S.upd_ptr[b0 + u + 1] - S.upd_ptr[b0 + u] + gpb - 1) / gpb);
+          col += 1.0 + mx;
+        }
+        w[l] = std::max(w[l], col);
+        for (int u = 0; u < nblk; ++u) wb[l] = std::max(wb[l], 1.0 + (S.upd_ptr[b0 + u + 1] - S.upd_ptr[b0 + u] + 9) / 10);
       }
-      worst = std::max(worst, col);
-      for (int u = 0; u < nblk; ++u) worst_blk = std::max(worst_blk, 1.0 + (S.upd_ptr[b0 + u + 1] - S.upd_ptr[b0 + u] + 9) / 10);
-      worst_fin = std::max(worst_fin, 2.0 + (nblk + 9) / 10);
-    }
-    level_cost[l] = worst;
-    (void)worst_fin;
-    split_cost[l] = worst_blk + 2.0 + 4.0;   // assemble critical path + one scaling step + one more launch
+      std::lock_guard<std::mutex> lk(fold);
+      for (int k = 0; k < S.n_levels; ++k) { level_cost[k] = std::max(level_cost[k], w[k]); worst_blk[k] = std::max(worst_blk[k], wb[k]); }
+    });
+    for (int l = 0; l < S.n_levels; ++l) split_cost[l] = worst_blk[l] + 2.0 + 4.0;   // assemble critical path + one scaling step + one more launch
   }
   S.steps.clear();
   S.split_blk.clear(); S.split_diag.clear(); S.split_sub.clear(); S.split_sub_diag.clear(); S.panel_cols.clear(); S.split_dblk.clear();
   S.upd_split.assign(S.nb, 0);
-  for (int t = 0; t < S.nb; ++t) S.upd_split[t] = S.upd_ptr[t + 1];
+  parallel_ranges(S.nb, 32768, [&](int lo, int hi) { for (int t = lo; t < hi; ++t) S.upd_split[t] = S.upd_ptr[t + 1]; });
   std::vector<int> blk_col(S.nb);                 // column of every block of L (source column of an update pair)
-  for (int j = 0; j < N; ++j) for (int bi = S.col_ptr[j]; bi < S.col_ptr[j + 1]; ++bi) blk_col[bi] = j;
+  parallel_ranges(N, 8192, [&](int lo, int hi) {
+    for (int j = lo; j < hi; ++j) for (int bi = S.col_ptr[j]; bi < S.col_ptr[j + 1]; ++bi) blk_col[bi] = j;
+  });
   static const int PANEL_MAX = getenv("PGO_DIRECT_PANEL") ? std::max(1, std::min(16, atoi(getenv("PGO_DIRECT_PANEL")))) : 8;
   auto is_heavy = [&](int l) { return level_cost[l] > HEAVY && split_cost[l] < level_cost[l]; };
   std::vector<int> tmp_a, tmp_b, tmp_pa, tmp_pb, chain_pos(N, -1);

@@ -13,6 +13,7 @@
 #include "pgo_direct.h"
 #include "pgo_front.h"
 #include "pgo_comm.h"
+#include "pgo_pool.h"
 
 namespace pgo { int comm_stress(Comm* c, int iters, size_t seg, hipStream_t s, int* mismatches); }
 
@@ -460,19 +461,15 @@ int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd, bool refresh
   return PGO_OK;
 }
 
-// Splits [0, n) into contiguous ranges over a few host threads (topology build of large graphs; nothing on the LM path).
+// Splits [0, n) into contiguous ranges over the host worker pool (topology build of large graphs; nothing on the LM path).
 template <class F>
 void parallel_for(int n, F&& fn) {
-  const int hw = (int)std::thread::hardware_concurrency();
-  const int nt = (n < 16384 || hw < 2) ? 1 : std::min(std::min(hw, 32), n / 8192);   // a thread costs ~50 us to start; 8 k items of these loops ~0.5 ms
+  const int nt = n < 8192 ? 1 : std::min(pgo::HostPool::get().width(), n / 4096);   // handing a range to a pool worker costs a few us; 4 k items of these loops ~0.25 ms
   if (nt <= 1) { fn(0, n); return; }
-  std::vector<std::thread> th;
-  th.reserve(nt);
-  for (int i = 0; i < nt; ++i) {
+  pgo::HostPool::get().run(nt, [&](int i) {
     const int lo = (int)((long long)n * i / nt), hi = (int)((long long)n * (i + 1) / nt);
-    th.emplace_back([&fn, lo, hi]() { fn(lo, hi); });
-  }
-  for (std::thread& t : th) t.join();
+    fn(lo, hi);
+  });
 }
 
 int choose_block(long long total_slots) {
