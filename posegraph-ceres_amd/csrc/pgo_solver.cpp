@@ -1187,7 +1187,7 @@ int run_direct(pgo_problem* P) {
     if (!P->sfront_levels) {
       // all levels in one launch (SFrontSync): a parent waits for its children's flags instead of for the end of their launch
       const char* sp_env = getenv("PGO_SFRONT_SPINS");
-      const int max_spins = sp_env ? atoi(sp_env) : 4000000;
+      const int max_spins = sp_env ? atoi(sp_env) : (1 << 20);     // ~1 s of polling before the fallback
       if (++P->sfront_epoch == 0x7fffffff) {     // (the ticket counters keep counting: they wrap with the host's copy)
         P->sfront_epoch = 1;
         HIP_TRY(hipMemsetAsync(P->ds_done.p, 0, (size_t)P->fsym.nf * sizeof(int), s));
