@@ -213,12 +213,15 @@ struct Dissector {
 // Orders every range of `roots` (disjoint ranges of sh.work).  Ranges above kSequential vertices are split by the thread that
 // takes them and their halves handed back; up to `max_threads` host threads, none when everything is small.
 void dissect_ranges(DissectShared& sh, std::vector<std::pair<int, int>> roots, int max_threads) {
-  constexpr int kSequential = 3000;
+  static const int kSequential = getenv("PGO_ND_SEQ") ? std::max(8, atoi(getenv("PGO_ND_SEQ"))) : 600;
   long long total = 0;
   for (const auto& r : roots) total += r.second - r.first;
-  // one host thread per ~2000 vertices (starting a thread costs tens of microseconds: KITTI-00's 4541 poses are ordered in
-  // 0.8 ms by one thread or by sixteen; Manhattan 10 k 6.0 -> 3.8 ms, sphere x10 29 -> 14 ms, a batch of 16 graphs 10 -> 1.7 ms)
-  const int nt = (int)std::max<long long>(1, std::min<long long>(std::min(max_threads, (int)std::thread::hardware_concurrency()), total / 2000));
+  // one pool worker per ~500 vertices, subsets above 600 vertices split as tasks (PGO_ND_PER_THREAD / PGO_ND_SEQ).  With a fresh
+  // std::thread per worker these were 2000 / 3000 (a start cost tens of microseconds); handing a task to a pool worker costs a
+  // few: KITTI-00's 4541 poses are ordered in 0.43 instead of 0.68 ms, the setup of a solve 1.72 -> 1.45 ms.  The order is the same
+  // whatever the numbers (a subset's result is a function of its vertex sequence alone).
+  static const int per_thread = getenv("PGO_ND_PER_THREAD") ? std::max(8, atoi(getenv("PGO_ND_PER_THREAD"))) : 500;
+  const int nt = (int)std::max<long long>(1, std::min<long long>(std::min(max_threads, (int)std::thread::hardware_concurrency()), total / per_thread));
   if (nt <= 1) {
     Dissector d(sh);
     for (const auto& r : roots) d.finish(r.first, r.second);
