@@ -62,24 +62,71 @@ inline double seconds_since(Clock::time_point t0) { return std::chrono::duration
 // runtime register the user pages with the device on the fly; once a problem's large device allocations exist that
 // registration was measured to stall the copy for 6-25 ms on this stack (a 20 KB list!), while a copy from memory
 // pinned once costs microseconds.  Same for the way back.
+struct Staging {
+  std::mutex mu;
+  char* buf = nullptr;
+  static constexpr size_t cap = (size_t)4 << 20;
+  hipError_t ensure() {
+    if (buf) return hipSuccess;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&buf), cap, hipHostMallocPortable);   // one buffer for every device the process uses; kept for the process lifetime
+    if (e != hipSuccess) buf = nullptr;
+    return e;
+  }
+};
+inline Staging& staging() { static Staging* st = new Staging(); return *st; }
+
+// While an UploadScope is alive on this thread, host-to-device copies of its stream are packed side by side into the staging
+// buffer and enqueued WITHOUT waiting for each other; the one wait is at the end of the scope (or when the buffer is full).  A
+// topology upload is 10-20 small arrays: a wait per array was 15-20 us each, 0.2-0.3 ms of a KITTI-00-scale setup.  The scope
+// holds the staging buffer for its lifetime (other host threads' copies wait, as they did per copy).
+struct UploadScope {
+  hipStream_t stream;
+  size_t used = 0;
+  std::unique_lock<std::mutex> lock;
+  UploadScope* outer;
+  static UploadScope*& current() { static thread_local UploadScope* cur = nullptr; return cur; }
+  explicit UploadScope(hipStream_t s) : stream(s), outer(current()) {
+    if (!outer) { lock = std::unique_lock<std::mutex>(staging().mu); current() = this; }
+  }
+  hipError_t finish() {
+    if (outer || used == 0) return hipSuccess;
+    used = 0;
+    return hipStreamSynchronize(stream);
+  }
+  ~UploadScope() {
+    if (outer) return;
+    (void)finish();
+    current() = nullptr;
+  }
+};
+
 inline hipError_t staged_copy(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t s) {
-  static std::mutex mu;
-  static char* stage = nullptr;
-  static const size_t cap = (size_t)4 << 20;
+  Staging& st = staging();
+  const size_t cap = Staging::cap;
+  UploadScope* scope = UploadScope::current();
+  if (scope && scope->stream != s) scope = nullptr;           // (not this scope's stream: the plain, waiting copy below — the scope's thread holds the lock)
   if (bytes > 2 * cap) {   // the big topology arrays: uploaded before the problem's device allocations, where the direct copy is fast
     hipError_t e = hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, s);
     return e != hipSuccess ? e : hipStreamSynchronize(s);
   }
-  std::lock_guard<std::mutex> lock(mu);
-  if (!stage) {
-    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&stage), cap, hipHostMallocPortable);   // one buffer for every device the process uses; kept for the process lifetime
-    if (e != hipSuccess) { stage = nullptr; return e; }
+  std::unique_lock<std::mutex> lock;
+  if (!UploadScope::current()) lock = std::unique_lock<std::mutex>(st.mu);
+  hipError_t e = st.ensure();
+  if (e != hipSuccess) return e;
+  char* stage = st.buf;
+  if (scope && to_device && bytes <= cap) {
+    if (scope->used + bytes > cap) { e = scope->finish(); if (e != hipSuccess) return e; }
+    std::memcpy(stage + scope->used, src, bytes);
+    e = hipMemcpyAsync(dst, stage + scope->used, bytes, hipMemcpyHostToDevice, s);
+    scope->used += (bytes + 255) / 256 * 256;
+    return e;
   }
+  if (UploadScope::current()) { e = UploadScope::current()->finish(); if (e != hipSuccess) return e; }   // the buffer is about to be reused from its start
   for (size_t off = 0; off < bytes; off += cap) {
     const size_t len = std::min(cap, bytes - off);
     if (to_device) std::memcpy(stage, static_cast<const char*>(src) + off, len);
-    hipError_t e = to_device ? hipMemcpyAsync(static_cast<char*>(dst) + off, stage, len, hipMemcpyHostToDevice, s)
-                             : hipMemcpyAsync(stage, static_cast<const char*>(src) + off, len, hipMemcpyDeviceToHost, s);
+    e = to_device ? hipMemcpyAsync(static_cast<char*>(dst) + off, stage, len, hipMemcpyHostToDevice, s)
+                  : hipMemcpyAsync(stage, static_cast<const char*>(src) + off, len, hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return e;
     e = hipStreamSynchronize(s);
     if (e != hipSuccess) return e;
@@ -642,6 +689,7 @@ int prepare(pgo_problem* P) {
   }
   const bool w_blockdiag = P->has_info && w_has_pr.load() == 0;
   lap("measurement / W arrays");
+  UploadScope upload_scope(s);     // the copies below are enqueued side by side; this function's final synchronisation is their wait
   HIP_TRY(P->d_slot_col.upload(slot_col, s));
   HIP_TRY(P->d_slot_row.upload(slot_row, s));
   HIP_TRY(P->d_slot_side.upload(slot_side, s));
@@ -974,6 +1022,7 @@ int upload_front(pgo_problem* P) {
   pgo::FrontSymbolic& S = P->fsym;
   const auto t_up = Clock::now();
   hipStream_t s = P->stream;
+  UploadScope upload_scope(s);
   HIP_TRY(P->df_perm.upload(S.perm, s));
   HIP_TRY(P->df_idx.upload(S.idx, s));
   HIP_TRY(P->df_child.upload(S.child, s));
@@ -1021,6 +1070,7 @@ int upload_front(pgo_problem* P) {
     pgo::launch_sfront_prepare(P->fplan, P->splan, S, s);
   }
   P->front_usable = true;
+  HIP_TRY(upload_scope.finish());
   if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] front: plan upload %.2f ms\n", 1e3 * seconds_since(t_up));
   return PGO_OK;
 }
@@ -1029,6 +1079,7 @@ int upload_sfront(pgo_problem* P) {
   pgo::FrontSymbolic& S = P->fsym;
   const auto t_up = Clock::now();
   hipStream_t s = P->stream;
+  UploadScope upload_scope(s);
   HIP_TRY(P->df_perm.upload(S.perm, s));
   HIP_TRY(P->df_idx.upload(S.idx, s));
   HIP_TRY(P->df_child.upload(S.child, s));
@@ -1063,6 +1114,7 @@ int upload_sfront(pgo_problem* P) {
   P->splan = pgo::SFrontPlan{P->ds_sf.p, nullptr, P->ds_urel.p, P->ds_upos.p, P->ds_osrc.p, P->ds_L.p, P->ds_U.p, P->ds_W.p, P->ds_done.p};
   pgo::launch_sfront_prepare(P->fplan, P->splan, S, s);
   P->sfront_usable = true;
+  HIP_TRY(upload_scope.finish());
   if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] front: small-front plan upload %.2f ms\n", 1e3 * seconds_since(t_up));
   return PGO_OK;
 }
@@ -1134,6 +1186,7 @@ int prepare_direct(pgo_problem* P) {
   P->direct_usable = false;
   const auto t_up = Clock::now();
   hipStream_t s = P->stream;
+  UploadScope upload_scope(s);
   HIP_TRY(P->dd_perm.upload(S.perm, s));
   HIP_TRY(P->dd_col_ptr.upload(S.col_ptr, s));
   HIP_TRY(P->dd_blk_row.upload(S.blk_row, s));
@@ -1176,6 +1229,7 @@ int prepare_direct(pgo_problem* P) {
   d.split_dblk = P->dd_split_dblk.p; d.col_flag = P->dd_col_flag.p;
   P->drop_direct_graph();
   P->direct_usable = true;
+  HIP_TRY(upload_scope.finish());
   if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: plan upload %.2f ms\n", 1e3 * seconds_since(t_up));
   return PGO_OK;
 }
