@@ -126,6 +126,7 @@ struct SFrontSync {
   unsigned ticket_base;
   int epoch;
   int max_spins;
+  long long* stamps;   // development aid (PGO_SF_STAMPS=1): six s_memrealtime stamps per front, null otherwise
 };
 
 struct FrontPlan {

@@ -653,6 +653,10 @@ __global__ __launch_bounds__(BWD_T) void k_front_bwd_block(DeviceGraph g, FrontP
 
 // ---- small fronts: the whole front in LDS, one launch per tree level (pgo_front.h) -------------------------------------------
 constexpr int SF_T = 256;
+#ifndef SF_EA_KG
+#define SF_EA_KG 8
+#define SF_EA_NU 4
+#endif
 #ifndef SF_POLL_SLEEP
 #define SF_POLL_SLEEP 1
 #endif
@@ -671,6 +675,8 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
   const FrontDesc D = p.fronts[f];
   const SFront S = sp.sf[f];
   const int c6 = 6 * D.c, r6 = 6 * D.r, n = c6 + r6, ld = n + 1;
+  auto stamp = [&](int k) { if (sy.stamps && tid == 0) sy.stamps[6 * (size_t)f + k] = (long long)__builtin_amdgcn_s_memrealtime(); };
+  stamp(0);
   // original entries H~ + D^2 (lower blocks; a diagonal block comes whole) and the right-hand side S g: fetched first, the
   // LDS is cleared while the loads are in flight
   // the children's descriptors too (two dependent loads each), parked in LDS for the extend-add below
@@ -740,6 +746,7 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
     }
     __syncthreads();
   }
+  stamp(1);
   // extend-add, gathered per row of this front: an 8-lane group walks the list of child rows that land in its row (child
   // order: fixed summation order, no atomics; no two groups share a row, so one barrier serves all children)
   if (!(dbg & 2)) {
@@ -748,10 +755,10 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
     // four children at a time: the loads of all four are in flight together (a child's update matrix was written by another
     // workgroup of the previous launch, usually on another XCD: every first touch is a trip to memory), then they are added
     // one child after the other
-    constexpr int KG = 4;
+    constexpr int KG = SF_EA_KG, NU = SF_EA_NU;       // children per batch, 256-lane passes per child held in registers
     for (int k0 = 0; k0 < nkids; k0 += KG) {
-      double v[KG][8];
-      int pos[KG][8];
+      double v[KG][NU];
+      int pos[KG][NU];
       int ub[KG], uc[KG];
 #pragma unroll
       for (int kk = 0; kk < KG; ++kk) {
@@ -762,7 +769,7 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
           else { const SFront C = sp.sf[p.child[D.child_begin + k]]; ub[kk] = C.ubase; uc[kk] = C.ucnt; }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {       // clamped index, always loaded, masked afterwards: no load sits behind a branch
+        for (int u = 0; u < NU; ++u) {       // clamped index, always loaded, masked afterwards: no load sits behind a branch
           const int e0 = u * SF_T + tid, e = ub[kk] + min(e0, max(uc[kk] - 1, 0));
           v[kk][u] = sp.Uval[e];
           const int q = sp.upos[e];
@@ -773,12 +780,13 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
       for (int kk = 0; kk < KG; ++kk) {
         if (k0 + kk >= nkids) break;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (pos[kk][u] >= 0) F[pos[kk][u]] += v[kk][u];
-        for (int e = 8 * SF_T + tid; e < uc[kk]; e += SF_T) F[sp.upos[ub[kk] + e]] += sp.Uval[ub[kk] + e];   // (children beyond 2048 packed entries)
+        for (int u = 0; u < NU; ++u) if (pos[kk][u] >= 0) F[pos[kk][u]] += v[kk][u];
+        for (int e = NU * SF_T + tid; e < uc[kk]; e += SF_T) F[sp.upos[ub[kk] + e]] += sp.Uval[ub[kk] + e];   // (children beyond NU x 256 packed entries)
         __syncthreads();
       }
     }
   }
+  stamp(2);
   // right-looking Cholesky of the c6 own columns, one pose (6 columns) per step: the 6 x 6 pivot block is factorised by every
   // lane for itself (registers), the rows below are scaled one per lane, then the trailing lower triangle is updated
   bool bad = false;
@@ -856,6 +864,7 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
     __syncthreads();
   }
   if (bad && tid == 0) atomicOr(&g.flags[2], 1);
+  stamp(3);
   // the update matrix first (the parent's launch is next in line), then the L panel (rows 0 .. n, the last one is y)
   if (dbg & 4) return;
   if (S.to_fval) {
@@ -882,6 +891,7 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
       __hip_atomic_store(sy.done + f, sy.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  stamp(4);
   double* Lg = sp.Lval + S.lbase;
   for (int i = tid / 64; i <= n; i += SF_T / 64)
     for (int j = tid & 63; j < c6; j += 64) Lg[i * c6 + j] = F[i * ld + j];
@@ -934,6 +944,7 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
     double* Wg = sp.Wval + S.wbase;
     for (int e = tid; e < c6 * c6; e += SF_T) { const int i = e / c6, j = e - i * c6; Wg[e] = Ws[i * lw + j]; }
   }
+  stamp(5);
 }
 
 // once per topology: where every packed update entry of every front goes in its parent's LDS front
@@ -1122,7 +1133,7 @@ void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSy
     const size_t lds = (size_t)(SFRONT_MAX + 1) * (SFRONT_MAX + 1) * sizeof(double);
     for (size_t l = 0; l + 1 < sym.slevel_ptr.size(); ++l) {
       const int cnt = sym.slevel_ptr[l + 1] - sym.slevel_ptr[l];
-      if (cnt > 0) hipLaunchKernelGGL(k_sfront_factor, dim3(cnt), dim3(SF_T), lds, s, g, p, *sp, sym.slevel_ptr[l], sf_dbg, SFrontSync{nullptr, 0u, 0, 0});
+      if (cnt > 0) hipLaunchKernelGGL(k_sfront_factor, dim3(cnt), dim3(SF_T), lds, s, g, p, *sp, sym.slevel_ptr[l], sf_dbg, SFrontSync{nullptr, 0u, 0, 0, nullptr});
     }
     hipLaunchKernelGGL(k_sfront_invert, dim3(sym.n_small), dim3(SF_T), (2 * (size_t)SFRONT_MAX + 6) * (SFRONT_MAX + 1) * sizeof(double), s, p, *sp, 0);
   }
@@ -1149,7 +1160,7 @@ void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSym
   if (sym.mixed && sp)
     for (int l = (int)sym.slevel_ptr.size() - 2; l >= 0; --l) {
       const int cnt = sym.slevel_ptr[l + 1] - sym.slevel_ptr[l];
-      if (cnt > 0) hipLaunchKernelGGL(k_sfront_bwd, dim3(cnt), dim3(SF_T), 0, s, g, p, *sp, sym.slevel_ptr[l], SFrontSync{nullptr, 0u, 0, 0});
+      if (cnt > 0) hipLaunchKernelGGL(k_sfront_bwd, dim3(cnt), dim3(SF_T), 0, s, g, p, *sp, sym.slevel_ptr[l], SFrontSync{nullptr, 0u, 0, 0, nullptr});
     }
 }
 
@@ -1173,7 +1184,7 @@ void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p, const SFront
   } else {
     for (const FrontLevel& L : sym.levels)
       if (L.front_end > L.front_begin)
-        hipLaunchKernelGGL(k_sfront_factor, dim3(L.front_end - L.front_begin), dim3(SF_T), lds, s, g, p, sp, L.front_begin, sf_dbg, SFrontSync{nullptr, 0u, 0, 0});
+        hipLaunchKernelGGL(k_sfront_factor, dim3(L.front_end - L.front_begin), dim3(SF_T), lds, s, g, p, sp, L.front_begin, sf_dbg, SFrontSync{nullptr, 0u, 0, 0, nullptr});
   }
   // the inverses W = L11^-1 of all fronts in one launch.  (Forming them level by level on a side stream, in the shadow of the
   // upper levels, was measured: the event hand-overs between the streams cost more than the launch — KITTI-00 0.51 vs 0.43 ms
@@ -1191,7 +1202,7 @@ void launch_sfront_solve(const DeviceGraph& g, const FrontPlan& p, const SFrontP
   }
   for (int l = (int)sym.levels.size() - 1; l >= 0; --l) {
     const FrontLevel& L = sym.levels[l];
-    if (L.front_end > L.front_begin) hipLaunchKernelGGL(k_sfront_bwd, dim3(L.front_end - L.front_begin), dim3(SF_T), 0, s, g, p, sp, L.front_begin, SFrontSync{nullptr, 0u, 0, 0});
+    if (L.front_end > L.front_begin) hipLaunchKernelGGL(k_sfront_bwd, dim3(L.front_end - L.front_begin), dim3(SF_T), 0, s, g, p, sp, L.front_begin, SFrontSync{nullptr, 0u, 0, 0, nullptr});
   }
 }
 

@@ -385,6 +385,7 @@ struct pgo_problem {
   DevBuf<pgo::SFront> ds_sf;
   DevBuf<double> ds_L, ds_U, ds_W;
   DevBuf<int> ds_urel, ds_osrc, ds_upos, ds_list, ds_done;
+  DevBuf<long long> ds_stamps;     // PGO_SF_STAMPS=1 (development aid)
   DevBuf<int> df_perm, df_idx, df_child, df_rel, df_cstart, df_col_front, df_ablk_ptr, df_ablk_slot, df_ablk_front, df_ablk_pos, df_wg_job, df_wg_tile,
       df_bwd_front, df_bwd_chunk, df_bwdb_front, df_bwdb_chunk, df_asm_tile, df_asm_contrib;
   DevBuf<pgo::FrontDesc> df_fronts;
@@ -1247,10 +1248,31 @@ int run_direct(pgo_problem* P) {
         HIP_TRY(hipMemsetAsync(P->ds_done.p, 0, (size_t)P->fsym.nf * sizeof(int), s));
         HIP_TRY(hipMemsetAsync(P->ds_done.p + P->fsym.nf + 1, 0, (size_t)P->fsym.nf * sizeof(int), s));
       }
-      const pgo::SFrontSync sy{P->ds_done.p, P->sfront_tickets, P->sfront_epoch, max_spins};
-      const pgo::SFrontSync sy_bwd{P->ds_done.p + P->fsym.nf + 1, P->sfront_tickets, P->sfront_epoch, max_spins};
+      static const bool want_stamps = getenv("PGO_SF_STAMPS") && getenv("PGO_SF_STAMPS")[0] == '1';
+      if (want_stamps && P->ds_stamps.n == 0) HIP_TRY(P->ds_stamps.alloc(6 * (size_t)P->fsym.nf));
+      const pgo::SFrontSync sy{P->ds_done.p, P->sfront_tickets, P->sfront_epoch, max_spins, want_stamps ? P->ds_stamps.p : nullptr};
+      const pgo::SFrontSync sy_bwd{P->ds_done.p + P->fsym.nf + 1, P->sfront_tickets, P->sfront_epoch, max_spins, nullptr};
       P->sfront_tickets += (unsigned)P->fsym.nf;
       pgo::launch_sfront_factor(P->g, P->fplan, P->splan, P->fsym, s, &sy);
+      if (want_stamps && P->sfront_epoch == 3) {      // development aid: the critical path of the third factorisation, from the root down
+        HIP_TRY(hipStreamSynchronize(s));
+        std::vector<long long> st(6 * (size_t)P->fsym.nf);
+        HIP_TRY(hipMemcpy(st.data(), P->ds_stamps.p, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        const pgo::FrontSymbolic& S = P->fsym;
+        long long t0 = st[0];
+        for (int q = 0; q < S.nf; ++q) t0 = std::min(t0, st[6 * (size_t)q]);
+        auto us = [&](long long t) { return (double)(t - t0) / 100.0; };     // s_memrealtime: 100 MHz
+        int q = S.nf - 1;
+        std::fprintf(stderr, "[pgo] sfront stamps (us since the first front started): front c r kids | start wait_done extend_done factor_done published end\n");
+        while (q >= 0) {
+          const pgo::FrontDesc& D = S.fronts[q];
+          std::fprintf(stderr, "[pgo]   front %4d c %2d r %2d kids %2d | %7.2f %7.2f %7.2f %7.2f %7.2f %7.2f\n", q, D.c, D.r, D.child_end - D.child_begin,
+                       us(st[6 * (size_t)q]), us(st[6 * (size_t)q + 1]), us(st[6 * (size_t)q + 2]), us(st[6 * (size_t)q + 3]), us(st[6 * (size_t)q + 4]), us(st[6 * (size_t)q + 5]));
+          int last = -1;
+          for (int ci = D.child_begin; ci < D.child_end; ++ci) { const int ch = S.child[ci]; if (last < 0 || st[6 * (size_t)ch + 4] > st[6 * (size_t)last + 4]) last = ch; }
+          q = last;
+        }
+      }
       // The backward substitution stays one launch per level: in its single-launch form (PGO_SFRONT_FUSED_BWD=1) every front of
       // the tree polls its parent's flag at once and the ten hand-overs take 88 us against 50 us for the ten launches (KITTI-00).
       static const bool fused_bwd = getenv("PGO_SFRONT_FUSED_BWD") && getenv("PGO_SFRONT_FUSED_BWD")[0] == '1';
