@@ -563,6 +563,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
           const int ostart = (k0 / nbo) * nbo, oend = std::min(c6, ostart + nbo);
           const int job = (int)S.jobs.size();
           S.jobs.push_back(FrontJob{D.fbase, D.ld, kend, n + 1, ostart, 0, k0, nb, D.wbase + step * FRONT_NB * FRONT_NB});
+          S.job_front.push_back(q);
           const int ntr = (n + 1 - kend + FRONT_TILE - 1) / FRONT_TILE;
           for (int t = 0; t < ntr; ++t) { S.wg_job.push_back(job); S.wg_tile.push_back(t << 16); }
           // the GEMM this panel is followed by: right-looking update behind a finished outer panel, or the Schur update
@@ -573,6 +574,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
             if (cc1 > cc0) {
               pending[q] = (int)S.jobs.size();
               S.jobs.push_back(FrontJob{D.fbase, D.ld, r0, r1, cc0, cc1, kk0, klen, 0});
+              S.job_front.push_back(q);
             }
           }
           if (next_step[q] >= nsteps[q] && pending[q] < 0) { finished[q] = 1; done_now.push_back(q); }
@@ -614,6 +616,50 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
         if (S.fronts[q].parent >= 0) --kids_left[S.fronts[q].parent];
       }
     }
+  }
+  // ---- 10b. the same work as stages for the single-launch form (FrontStages): a stage = one job or one front's extend-add ----
+  S.st_table.clear(); S.st_pred_ptr.assign(1, 0); S.st_pred.clear(); S.st_need.clear();
+  if (!S.mixed) {
+    std::vector<int> last_stage(nf, -1), stage_of_job(S.jobs.size(), -1), asm_stage(nf, -1), touched;
+    for (const FrontLaunch& La : S.launches) {
+      touched.clear();
+      for (int w = La.wg_begin; w < La.wg_begin + La.n_wg; ++w) {
+        int stage, q;
+        if (La.type == FrontLaunch::ASM) {
+          q = S.asm_tile[8 * (size_t)w];
+          if (asm_stage[q] < 0) {
+            asm_stage[q] = (int)S.st_need.size();
+            S.st_need.push_back(0);
+            for (int ci = S.fronts[q].child_begin; ci < S.fronts[q].child_end; ++ci) S.st_pred.push_back(last_stage[S.child[ci]]);
+            S.st_pred_ptr.push_back((int)S.st_pred.size());
+            touched.push_back(q);
+          }
+          stage = asm_stage[q];
+        } else {
+          const int job = S.wg_job[w];
+          q = S.job_front[job];
+          if (stage_of_job[job] < 0) {
+            stage_of_job[job] = (int)S.st_need.size();
+            S.st_need.push_back(0);
+            if (last_stage[q] >= 0) S.st_pred.push_back(last_stage[q]);
+            S.st_pred_ptr.push_back((int)S.st_pred.size());
+            touched.push_back(q);
+          }
+          stage = stage_of_job[job];
+        }
+        ++S.st_need[stage];
+        const int kind = La.type == FrontLaunch::ASM ? 0 : La.type == FrontLaunch::PANEL ? 1 : La.tile == 64 ? 2 : 3;
+        S.st_table.push_back(kind | (w << 2));
+        S.st_table.push_back(stage);
+      }
+      // a front has one stage per launch: its chain moves on once the launch has been walked
+      for (int q : touched) {
+        if (La.type == FrontLaunch::ASM) last_stage[q] = asm_stage[q];
+      }
+      if (La.type != FrontLaunch::ASM)
+        for (int w = La.wg_begin; w < La.wg_begin + La.n_wg; ++w) last_stage[S.job_front[S.wg_job[w]]] = stage_of_job[S.wg_job[w]];
+    }
+    for (int v : S.st_pred) if (v < 0) { S.st_table.clear(); break; }     // (cannot happen: a child is finished before its parent's extend-add is scheduled)
   }
   // backward substitution, root first: a front may start once its parent is done.  Per round: phase A (t = y - L21^T x_r, 64
   // columns per workgroup) of the fronts that became ready, then one 192-column block step of every front under way (the

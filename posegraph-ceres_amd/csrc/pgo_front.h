@@ -157,6 +157,24 @@ struct FrontPlan {
   double* Fval;
   double* Winv;
   double* x;                // [6n] solution, new numbering (the backward substitution keeps t = y - L21^T x_r here in between)
+  // single-launch form of the factorisation (FrontStages below): null when not in use
+  const int* st_table;      // [n_tickets][2]: (kind | index << 2), stage — kind 0 extend-add record, 1 panel, 2 GEMM 64, 3 GEMM 32 work-group
+  const int* st_pred_ptr;   // [n_stages + 1] the stages a stage waits for ...
+  const int* st_pred;       // ... (one: the front's previous stage; an extend-add: the last stage of every child)
+  const int* st_need;       // [n_stages] work-groups of the stage
+  unsigned long long* st_count;   // [n_stages + 1] finished work-groups, never reset: stage s of factorisation e is complete at need[s] * e; [n_stages]: tickets
+};
+// The single-launch form of the regular multifrontal factorisation: every work-group of every round of the launch schedule in ONE
+// grid, taken in ticket order (= the order of the launches, a topological order of the stages), a work-group waits until the
+// stages its own stage depends on are complete (counters, agent scope; one wave acquires / releases, as in the small-front plan).
+// A front then advances at the pace of its own chain extend-add -> panel -> panel ... -> GEMM, not at the pace of the rounds,
+// in which every launch waits for the slowest front of the one before and a round costs the SUM of its three launches.
+struct FrontStages {
+  unsigned long long epoch;       // this factorisation's number (1, 2, ...)
+  unsigned long long ticket_base; // tickets handed out before this launch
+  int n_tickets;
+  int n_stages;
+  int max_spins;
 };
 
 struct FrontSymbolic {
@@ -166,6 +184,8 @@ struct FrontSymbolic {
   std::vector<int> idx, child, rel, cstart, col_front, wg_job, wg_tile, asm_tile, asm_contrib, bwd_front, bwd_chunk, bwdb_front, bwdb_chunk;
   std::vector<int> ablk_ptr, ablk_slot, ablk_front, ablk_pos;
   std::vector<FrontJob> jobs;
+  std::vector<int> job_front;       // front of every job
+  std::vector<int> st_table, st_pred_ptr, st_pred, st_need;   // FrontPlan::st_* (single-launch form)
   std::vector<FrontLaunch> launches;
   std::vector<FrontBwdLaunch> bwd_launches;
   std::vector<FrontLevel> levels;
@@ -197,7 +217,8 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
 // Device launches: factorisation (includes the forward substitution) and backward substitution into g.cg_x.
 // flags[2] is set when a pivot is not positive.
 // sp: the small-front arrays of a mixed plan (sym.mixed), else null
-void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s, const SFrontPlan* sp = nullptr);
+void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s, const SFrontPlan* sp = nullptr,
+                         const FrontStages* stages = nullptr);
 void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s, const SFrontPlan* sp = nullptr);
 // the small-front path: one launch per tree level each
 // once per topology: fills SFrontPlan::upos

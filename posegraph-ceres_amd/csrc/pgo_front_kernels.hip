@@ -107,9 +107,8 @@ __global__ __launch_bounds__(256) void k_front_scatter(DeviceGraph g, FrontPlan 
 
 constexpr int ASM_T = 6 * FRONT_ASM_TP;   // 48 scalars per tile side
 
-__global__ __launch_bounds__(256) void k_front_extend_add(FrontPlan p, int wg_begin) {
-  __shared__ double acc[ASM_T][ASM_T + 1];
-  const int* rec = p.asm_tile + 8 * (size_t)(wg_begin + blockIdx.x);
+__device__ __forceinline__ void front_extend_add_body(const FrontPlan& p, int w, double (*acc)[ASM_T + 1]) {
+  const int* rec = p.asm_tile + 8 * (size_t)w;
   const int ti = rec[1] >> 16, tj = rec[1] & 0xffff, cb = rec[2], ce = rec[3];
   const long long pbase = ((long long)rec[5] << 32) | (unsigned)rec[4];
   const int pld = rec[6], np = rec[7] & 0xfffff, ntp = rec[7] >> 20;
@@ -147,6 +146,10 @@ __global__ __launch_bounds__(256) void k_front_extend_add(FrontPlan p, int wg_be
     const int lr = e / ASM_T, lc = e - lr * ASM_T;
     if (lc < ncol) Fp[(size_t)(row0 + lr) * pld + col0 + lc] += acc[lr][lc];
   }
+}
+__global__ __launch_bounds__(256) void k_front_extend_add(FrontPlan p, int wg_begin) {
+  __shared__ double acc[ASM_T][ASM_T + 1];
+  front_extend_add_body(p, wg_begin + blockIdx.x, acc);
 }
 
 // ---- the diagonal block ------------------------------------------------------------------------------------------------
@@ -272,11 +275,7 @@ __device__ __noinline__ bool diag_block_wave(lds_double* DL, lds_double* Wd, lds
 
 // One 48-column panel step (see FrontJob).  320 lanes = 5 waves: waves 0..3 own rows [16 w, 16 w + 16) of the 64-row tile
 // (sums and TRSM on the matrix cores), wave 4 factorises the diagonal block in between.
-__global__ __launch_bounds__(320) void k_front_panel(FrontPlan p, int wg_begin, int* flags) {
-  __shared__ double DL[FRONT_NB * LDW];
-  __shared__ double Wd[FRONT_NB * LDWD];
-  __shared__ double cbuf[128];
-  const int wgi = wg_begin + blockIdx.x;
+__device__ __forceinline__ void front_panel_body(const FrontPlan& p, int wgi, int* flags, double* DL, double* Wd, double* cbuf) {
   const FrontJob J = p.jobs[p.wg_job[wgi]];
   const int tile = p.wg_tile[wgi] >> 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g4 = lane >> 4;
@@ -413,6 +412,12 @@ __global__ __launch_bounds__(320) void k_front_panel(FrontPlan p, int wg_begin, 
       }
   }
 }
+__global__ __launch_bounds__(320) void k_front_panel(FrontPlan p, int wg_begin, int* flags) {
+  __shared__ double DL[FRONT_NB * LDW];
+  __shared__ double Wd[FRONT_NB * LDWD];
+  __shared__ double cbuf[128];
+  front_panel_body(p, wg_begin + blockIdx.x, flags, DL, Wd, cbuf);
+}
 
 // C tile of 64 x 64 per workgroup; wave w owns rows [16 w, 16 w + 16) x 64 columns (four 16 x 16 tiles).  C -= A B^T.
 // K runs in steps of 16 through two register buffers (the loads of the next step are in flight while the matrix cores
@@ -431,9 +436,8 @@ template <int NQ>
 struct GemmFrag { double2 a[2], b[NQ][2]; };
 
 template <int TILE>
-__global__ __launch_bounds__(256) void k_front_gemm(FrontPlan p, int wg_begin) {
+__device__ __forceinline__ void front_gemm_body(const FrontPlan& p, int wgi) {
   constexpr int NQ = TILE == 64 ? 4 : 1;
-  const int wgi = wg_begin + blockIdx.x;
   const FrontJob J = p.jobs[p.wg_job[wgi]];
   const int tt = p.wg_tile[wgi], ti = tt >> 16, tj = tt & 0xffff;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g4 = lane >> 4;
@@ -494,6 +498,49 @@ __global__ __launch_bounds__(256) void k_front_gemm(FrontPlan p, int wg_begin) {
       double* dst = F + (size_t)row * ld + c;
       *dst -= acc[q][r];
     }
+  }
+}
+template <int TILE>
+__global__ __launch_bounds__(256) void k_front_gemm(FrontPlan p, int wg_begin) {
+  front_gemm_body<TILE>(p, wg_begin + blockIdx.x);
+}
+
+#ifndef FRONT_POLL_SLEEP
+#define FRONT_POLL_SLEEP 8
+#endif
+// ---- the single-launch form (FrontStages, pgo_front.h): every work-group of the launch schedule in one grid ------------------
+__global__ __launch_bounds__(320) void k_front_stages(DeviceGraph g, FrontPlan p, FrontStages fs) {
+  __shared__ double smem[FRONT_NB * LDW + FRONT_NB * LDWD + 128];
+  __shared__ int tk;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    const int n_stages_slot = fs.n_stages;
+    tk = (int)(atomicAdd(p.st_count + n_stages_slot, 1ull) - fs.ticket_base);
+  }
+  __syncthreads();
+  const int kind = p.st_table[2 * (size_t)tk] & 3, w = p.st_table[2 * (size_t)tk] >> 2, stage = p.st_table[2 * (size_t)tk + 1];
+  if (tid == 0) {
+    int spins = 0;
+    for (int q = p.st_pred_ptr[stage]; q < p.st_pred_ptr[stage + 1]; ++q) {
+      const int ps = p.st_pred[q];
+      const unsigned long long target = (unsigned long long)p.st_need[ps] * fs.epoch;
+      while (__hip_atomic_load(p.st_count + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (++spins > fs.max_spins) { atomicOr(&g.flags[2], 2); break; }
+        __builtin_amdgcn_s_sleep(FRONT_POLL_SLEEP);       // (polling more rarely, or rarely while far from complete, changes nothing)
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // one wave acquires, the barrier orders the others behind it (k_sfront_factor)
+  }
+  __syncthreads();
+  if (kind != 1 && tid >= 256) return;                     // only a panel step has work for the fifth wave
+  if (kind == 1) front_panel_body(p, w, g.flags, smem, smem + FRONT_NB * LDW, smem + FRONT_NB * LDW + FRONT_NB * LDWD);
+  else if (kind == 0) front_extend_add_body(p, w, reinterpret_cast<double (*)[ASM_T + 1]>(smem));
+  else if (kind == 2) front_gemm_body<64>(p, w);
+  else front_gemm_body<32>(p, w);
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    atomicAdd(p.st_count + stage, 1ull);
   }
 }
 
@@ -1122,10 +1169,15 @@ static void sfront_attributes() {
 }
 static const int sf_dbg = getenv("PGO_SF_DBG") ? atoi(getenv("PGO_SF_DBG")) : 0;   // timing ablations of k_sfront_factor (results are wrong with any bit set)
 
-void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s, const SFrontPlan* sp) {
+void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s, const SFrontPlan* sp,
+                         const FrontStages* stages) {
   (void)hipMemsetAsync(p.Fval, 0, (size_t)sym.fval_size * sizeof(double), s);
   const long long nt = (long long)p.n_ablk * 36 + 6LL * p.n;
   hipLaunchKernelGGL(k_front_scatter, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, g, p);
+  if (stages && p.st_table && !sym.mixed) {
+    hipLaunchKernelGGL(k_front_stages, dim3(stages->n_tickets), dim3(320), 0, s, g, p, *stages);
+    return;
+  }
   if (sym.mixed && sp) {
     // the fronts whose whole subtree is small: level by level in LDS, before the rounds of the others (their subtree roots
     // leave their update matrices in Fval for the regular extend-add), and their inverses for the backward levels

@@ -386,6 +386,10 @@ struct pgo_problem {
   DevBuf<double> ds_L, ds_U, ds_W;
   DevBuf<int> ds_urel, ds_osrc, ds_upos, ds_list, ds_done;
   DevBuf<long long> ds_stamps;     // PGO_SF_STAMPS=1 (development aid)
+  DevBuf<int> df_st_table, df_st_pred_ptr, df_st_pred, df_st_need;
+  DevBuf<unsigned long long> df_st_count;
+  bool front_launches = false;     // multifrontal plan: one launch per phase of a round (a wait of the single-launch form ran out, or PGO_FRONT_FUSED=0)
+  unsigned long long front_epoch = 0, front_tickets = 0;
   DevBuf<int> df_perm, df_idx, df_child, df_rel, df_cstart, df_col_front, df_ablk_ptr, df_ablk_slot, df_ablk_front, df_ablk_pos, df_wg_job, df_wg_tile,
       df_bwd_front, df_bwd_chunk, df_bwdb_front, df_bwdb_chunk, df_asm_tile, df_asm_contrib;
   DevBuf<pgo::FrontDesc> df_fronts;
@@ -1057,6 +1061,31 @@ int upload_front(pgo_problem* P) {
   f.col_front = P->df_col_front.p; f.ablk_ptr = P->df_ablk_ptr.p; f.ablk_slot = P->df_ablk_slot.p;
   f.ablk_front = P->df_ablk_front.p; f.ablk_pos = P->df_ablk_pos.p; f.n_ablk = (int)S.ablk_front.size();
   f.jobs = P->df_jobs.p; f.Fval = P->df_Fval.p; f.Winv = P->df_Winv.p; f.x = P->df_x.p;
+  // the stages of the single-launch form (pgo_front.h FrontStages); PGO_FRONT_FUSED=0: one launch per phase of a round
+  f.st_table = nullptr; f.st_pred_ptr = nullptr; f.st_pred = nullptr; f.st_need = nullptr; f.st_count = nullptr;
+  P->front_epoch = 0; P->front_tickets = 0;
+  {
+    // Measured (factorisation, single launch vs one launch per phase of a round): Manhattan 2 k / 8 k 1.09 vs 1.23 ms, KITTI-00
+    // dense (0.9 GFLOP) 28.1 vs 32.0 ms per 14-iteration solve, Manhattan 10 k (4.5 GFLOP) 3.54 vs 3.57 ms, sphere x10 (383
+    // GFLOP) 46 vs 28 ms: every work-group pays a cache write-back and an invalidation of its XCD's L2 where a kernel boundary
+    // pays them once, which the GEMM-heavy factorisations cannot afford.  Default: single launch up to 3 GFLOP
+    // (PGO_FRONT_FUSED=1 always, =0 never; PGO_FRONT_FUSED_GFLOP moves the limit).
+    const char* fu = getenv("PGO_FRONT_FUSED");
+    const double limit = getenv("PGO_FRONT_FUSED_GFLOP") ? atof(getenv("PGO_FRONT_FUSED_GFLOP")) : 3.0;
+    const bool on = fu ? fu[0] == '1' : S.flops <= limit * 1e9;
+    P->front_launches = !on || S.st_table.empty();
+  }
+  if (!S.st_table.empty()) {
+    HIP_TRY(P->df_st_table.upload(S.st_table, s));
+    HIP_TRY(P->df_st_pred_ptr.upload(S.st_pred_ptr, s));
+    HIP_TRY(P->df_st_pred.upload(S.st_pred, s));
+    if (S.st_pred.empty()) HIP_TRY(P->df_st_pred.alloc(1));
+    HIP_TRY(P->df_st_need.upload(S.st_need, s));
+    HIP_TRY(P->df_st_count.alloc(S.st_need.size() + 1));
+    HIP_TRY(P->df_st_count.zero(s));
+    f.st_table = P->df_st_table.p; f.st_pred_ptr = P->df_st_pred_ptr.p; f.st_pred = P->df_st_pred.p; f.st_need = P->df_st_need.p;
+    f.st_count = P->df_st_count.p;
+  }
   if (S.mixed) {
     // the small fronts at the bottom of the tree take the small-front kernels (pgo_front.h): their compact arrays
     HIP_TRY(P->ds_sf.upload(S.sfronts, s));
@@ -1235,6 +1264,20 @@ int prepare_direct(pgo_problem* P) {
   return PGO_OK;
 }
 
+// the multifrontal factorisation: all stages in one launch (pgo_front.h FrontStages), or one launch per phase of a round
+void enqueue_front_factor(pgo_problem* P) {
+  hipStream_t s = P->stream;
+  if (!P->front_launches) {
+    const char* sp_env = getenv("PGO_FRONT_SPINS");
+    const int n_tickets = (int)(P->fsym.st_table.size() / 2);
+    const pgo::FrontStages fs{++P->front_epoch, P->front_tickets, n_tickets, (int)P->fsym.st_need.size(), sp_env ? atoi(sp_env) : (1 << 20)};
+    P->front_tickets += (unsigned long long)n_tickets;
+    pgo::launch_front_factor(P->g, P->fplan, P->fsym, s, nullptr, &fs);
+  } else {
+    pgo::launch_front_factor(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr);
+  }
+}
+
 // factorise (H~ + D^2) and solve for cg_x = (H~ + D^2)^-1 S g; the launch sequence is static -> one hipGraph
 int run_direct(pgo_problem* P) {
   hipStream_t s = P->stream;
@@ -1284,7 +1327,7 @@ int run_direct(pgo_problem* P) {
     return PGO_OK;
   }
   if (P->front_usable) {
-    pgo::launch_front_factor(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr);
+    enqueue_front_factor(P);
     pgo::launch_front_solve(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr);
     return PGO_OK;
   }
@@ -1675,11 +1718,11 @@ int lm_advance(pgo_problem* P) {
     if (spec) launch_speculative_linearize(P, 0);
     rc = wait_handoff(P);
     if (rc) return rc;
-    if ((P->scal->linearize_bad & 4) && !P->front_usable && (P->sfront_usable ? !P->sfront_levels : !P->split_two_launch)) {
+    if ((P->scal->linearize_bad & 4) && (P->front_usable ? !P->front_launches : P->sfront_usable ? !P->sfront_levels : !P->split_two_launch)) {
       // a single-launch SPLIT step waited in vain for a column's diagonal block (its workgroups were not all resident), or a
       // front of the single-launch small-front factorisation for a child: not a numerical failure — repeat this factorisation
       // in the form without in-kernel waits and keep to it
-      if (P->sfront_usable) P->sfront_levels = true; else P->split_two_launch = true;
+      if (P->front_usable) P->front_launches = true; else if (P->sfront_usable) P->sfront_levels = true; else P->split_two_launch = true;
       if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: an in-kernel wait of the single-launch factorisation timed out; one launch per step from now on\n");
       arm_handoff(P);
       rc = run_direct(P);
@@ -1862,6 +1905,7 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
     return set_error(PGO_ERR_UNSUPPORTED, "pgo_solve_batch: the union of the problems is beyond the factorisation's budget; solve them one by one");
   P->split_two_launch = true;   // the device-wide failure flag is not consulted per component: no in-kernel waits in a batch
   P->sfront_levels = true;
+  P->front_launches = true;
   rc = prepare_clusters(P, 1);
   if (rc) return rc;
   mark("prepare_clusters");
@@ -2465,8 +2509,8 @@ int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const do
     if (rc) return rc;
     pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s);
     HIP_TRY(hipStreamSynchronize(s));
-    if ((P->scal->linearize_bad & 4) && !P->front_usable && (P->sfront_usable ? !P->sfront_levels : !P->split_two_launch)) {   // an in-kernel wait ran out (lm_advance)
-      if (P->sfront_usable) P->sfront_levels = true; else P->split_two_launch = true;
+    if ((P->scal->linearize_bad & 4) && (P->front_usable ? !P->front_launches : P->sfront_usable ? !P->sfront_levels : !P->split_two_launch)) {   // an in-kernel wait ran out (lm_advance)
+      if (P->front_usable) P->front_launches = true; else if (P->sfront_usable) P->sfront_levels = true; else P->split_two_launch = true;
       rc = run_direct(P);
       if (rc) return rc;
       pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s);
@@ -2527,11 +2571,11 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     if (!P->direct_usable) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): no GPU factorisation prepared for this problem", kernel);
     if ((k != "direct") && !P->front_usable) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): the multifrontal solver is not in use", kernel);
     pgo::launch_damping(P->g, P->lm.radius, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, 0, s);
-    if (k == "front_solve") pgo::launch_front_factor(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr);
+    if (k == "front_solve") enqueue_front_factor(P);
   }
   auto once = [&]() -> int {
     if (k == "direct") return run_direct(P);
-    if (k == "front_factor") { pgo::launch_front_factor(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr); return 0; }
+    if (k == "front_factor") { enqueue_front_factor(P); return 0; }
     if (k == "front_solve") { pgo::launch_front_solve(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr); return 0; }
     if (k == "linearize") pgo::launch_linearize(P->g, s);
     else if (k == "cost") pgo::launch_cost(P->g, P->g.pose_x, 5, s);

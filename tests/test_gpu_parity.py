@@ -511,6 +511,25 @@ def test_small_front_single_launch_timeout_falls_back_to_levels(gpu, O, ds, monk
     assert traces[0] == traces[1] == traces[2]
 
 
+def test_multifrontal_single_launch_timeout_falls_back_to_launches(gpu, ds, monkeypatch):
+    """The single-launch form of the multifrontal factorisation (every work-group of the round schedule in one grid, stages
+    ordered by counters) with the wait budget forced to zero (PGO_FRONT_SPINS=0): the driver repeats the factorisation with one
+    launch per phase, keeps to that form, and the trace is bit-identical to the one of either form when nothing times out."""
+    g = ds.manhattan_se3(1500, 5000, seed=21)
+    opt = gpu.SolverOptions(max_num_iterations=6, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
+    traces = []
+    for env in ({"PGO_FRONT_SPINS": "0"}, {"PGO_FRONT_FUSED": "0"}, {"PGO_FRONT_FUSED": "1"}):
+        for key in ("PGO_FRONT_SPINS", "PGO_FRONT_FUSED"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        prob, poses = gpu.problem_from_graph(g)
+        s = gpu.solve(opt, prob)
+        assert s.linear_solver_used == 0 and s.c.factor_kind == 2
+        traces.append((tuple(float(c) for c in s.iterations["cost"]), poses.tobytes()))
+    assert traces[0] == traces[1] == traces[2]
+
+
 @pytest.mark.parametrize("name,exact", [("manhattan1000", True), ("sphere2x20", True), ("manhattan2000", True), ("manhattan1000", False)])
 def test_traces_to_convergence_match_oracle(gpu, O, ds, name, exact):
     """The WHOLE trust-region trajectory, not its first iterations: the reference's options (max 300 iterations, default
