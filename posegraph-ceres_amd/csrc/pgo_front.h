@@ -175,6 +175,7 @@ struct FrontStages {
   int n_tickets;
   int n_stages;
   int max_spins;
+  long long* stamps;    // development aid (PGO_FRONT_STAMPS=1): three s_memrealtime stamps per ticket, null otherwise
 };
 
 struct FrontSymbolic {

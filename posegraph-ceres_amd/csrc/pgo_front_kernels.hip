@@ -518,6 +518,7 @@ __global__ __launch_bounds__(320) void k_front_stages(DeviceGraph g, FrontPlan p
     tk = (int)(atomicAdd(p.st_count + n_stages_slot, 1ull) - fs.ticket_base);
   }
   __syncthreads();
+  if (fs.stamps && tid == 0) fs.stamps[3 * (size_t)tk] = (long long)__builtin_amdgcn_s_memrealtime();
   const int kind = p.st_table[2 * (size_t)tk] & 3, w = p.st_table[2 * (size_t)tk] >> 2, stage = p.st_table[2 * (size_t)tk + 1];
   if (tid == 0) {
     int spins = 0;
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(320) void k_front_stages(DeviceGraph g, FrontPlan p
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // one wave acquires, the barrier orders the others behind it (k_sfront_factor)
+    if (fs.stamps) fs.stamps[3 * (size_t)tk + 1] = (long long)__builtin_amdgcn_s_memrealtime();
   }
   __syncthreads();
   if (kind != 1 && tid >= 256) return;                     // only a panel step has work for the fifth wave
@@ -541,6 +543,7 @@ __global__ __launch_bounds__(320) void k_front_stages(DeviceGraph g, FrontPlan p
   if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     atomicAdd(p.st_count + stage, 1ull);
+    if (fs.stamps) fs.stamps[3 * (size_t)tk + 2] = (long long)__builtin_amdgcn_s_memrealtime();
   }
 }
 

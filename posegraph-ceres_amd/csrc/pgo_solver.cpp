@@ -1270,9 +1270,39 @@ void enqueue_front_factor(pgo_problem* P) {
   if (!P->front_launches) {
     const char* sp_env = getenv("PGO_FRONT_SPINS");
     const int n_tickets = (int)(P->fsym.st_table.size() / 2);
-    const pgo::FrontStages fs{++P->front_epoch, P->front_tickets, n_tickets, (int)P->fsym.st_need.size(), sp_env ? atoi(sp_env) : (1 << 20)};
+    static const bool want_stamps = getenv("PGO_FRONT_STAMPS") && getenv("PGO_FRONT_STAMPS")[0] == '1';
+    if (want_stamps && P->ds_stamps.n == 0 && P->ds_stamps.alloc(3 * (size_t)n_tickets) != hipSuccess) return;
+    const pgo::FrontStages fs{++P->front_epoch, P->front_tickets, n_tickets, (int)P->fsym.st_need.size(), sp_env ? atoi(sp_env) : (1 << 20),
+                              want_stamps ? P->ds_stamps.p : nullptr};
     P->front_tickets += (unsigned long long)n_tickets;
     pgo::launch_front_factor(P->g, P->fplan, P->fsym, s, nullptr, &fs);
+    if (want_stamps && P->front_epoch == 3) {      // development aid: the chain of stages that ends last, from the last stage back
+      (void)hipStreamSynchronize(s);
+      const pgo::FrontSymbolic& S = P->fsym;
+      std::vector<long long> st(3 * (size_t)n_tickets);
+      (void)hipMemcpy(st.data(), P->ds_stamps.p, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
+      const int ns = (int)S.st_need.size();
+      std::vector<long long> first(ns, (long long)1 << 62), ready(ns, 0), done(ns, 0);
+      std::vector<int> kind(ns, 0), wg1(ns, 0);
+      long long t0 = (long long)1 << 62;
+      for (int t = 0; t < n_tickets; ++t) {
+        const int sg = S.st_table[2 * (size_t)t + 1];
+        first[sg] = std::min(first[sg], st[3 * (size_t)t]); ready[sg] = std::max(ready[sg], st[3 * (size_t)t + 1]); done[sg] = std::max(done[sg], st[3 * (size_t)t + 2]);
+        kind[sg] = S.st_table[2 * (size_t)t] & 3; wg1[sg] = S.st_table[2 * (size_t)t] >> 2;
+        t0 = std::min(t0, st[3 * (size_t)t]);
+      }
+      auto us = [&](long long t) { return (double)(t - t0) / 100.0; };
+      int sg = 0;
+      for (int q = 0; q < ns; ++q) if (done[q] > done[sg]) sg = q;
+      std::fprintf(stderr, "[pgo] front stamps: %d tickets, %d stages; chain from the last stage back: stage kind(0 asm 1 panel 2 gemm64 3 gemm32) front wgs | first start, last ready, last done (us)\n", n_tickets, ns);
+      for (int hops = 0; hops < 400 && sg >= 0; ++hops) {
+        const int front = kind[sg] == 0 ? S.asm_tile[8 * (size_t)wg1[sg]] : S.job_front[S.wg_job[wg1[sg]]];
+        std::fprintf(stderr, "[pgo]   %5d %d front %4d (c %3d r %3d) wgs %4d | %8.2f %8.2f %8.2f\n", sg, kind[sg], front, S.fronts[front].c, S.fronts[front].r, S.st_need[sg], us(first[sg]), us(ready[sg]), us(done[sg]));
+        int best = -1;
+        for (int q = S.st_pred_ptr[sg]; q < S.st_pred_ptr[sg + 1]; ++q) if (best < 0 || done[S.st_pred[q]] > done[best]) best = S.st_pred[q];
+        sg = best;
+      }
+    }
   } else {
     pgo::launch_front_factor(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr);
   }
