@@ -194,6 +194,9 @@ __device__ __forceinline__ double half_rsqrt_nr(double d) {
 typedef __attribute__((address_space(3))) double lds_double;
 constexpr int LDWD = 18;
 
+#ifndef FRONT_DIAG_READLANE
+#define FRONT_DIAG_READLANE 1
+#endif
 __device__ __noinline__ bool diag_block_wave(lds_double* DL, lds_double* Wd, lds_double* cbuf) {
   const int lane = threadIdx.x & 63, li = lane & 15, g4 = lane >> 4;
   const int i = lane < FRONT_NB ? lane : FRONT_NB - 1;
@@ -221,10 +224,16 @@ __device__ __noinline__ bool diag_block_wave(lds_double* DL, lds_double* Wd, lds
         const double ln = readlane_d(l, c0 + k + 1);
         a[k + 1] = fma(-l, ln, a[k + 1]);
         if (k < 14) {
+#if FRONT_DIAG_READLANE
+          // the other columns of the block: L[c0 + j][k] straight out of lane c0 + j (v_readlane, no trip through the LDS)
+#pragma unroll
+          for (int j = k + 2; j < 16; ++j) a[j] = fma(-l, readlane_d(l, c0 + j), a[j]);
+#else
           lds_double* cb = cbuf + (k & 1) * 64;
           cb[lane] = l;
 #pragma unroll
           for (int j = k + 2; j < 16; ++j) a[j] = fma(-l, cb[c0 + j], a[j]);
+#endif
         }
       }
     }
