@@ -318,45 +318,36 @@ __device__ __forceinline__ void front_panel_body(const FrontPlan& p, int wgi, in
   sd[0] = double4_t{0.0, 0.0, 0.0, 0.0};
   sd[1] = double4_t{0.0, 0.0, 0.0, 0.0};
   const int ksum = k0 - J.c0;   // 0, 48, 96 or 144: three 8-wide steps per trip, all loads of a trip issued first
-  {
-    const double* Ao = F + (size_t)orow * ld + J.c0 + 2 * g4;
-    const double* Bk[3];
+  const double* Bk[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) Bk[q] = F + (size_t)(k0 + min(16 * q + li, nb - 1)) * ld + J.c0 + 2 * g4;
-    for (int kc = 0; kc < ksum; kc += 24) {
-      double2 ao[3], bk[3][3];
+  for (int q = 0; q < 3; ++q) Bk[q] = F + (size_t)(k0 + min(16 * q + li, nb - 1)) * ld + J.c0 + 2 * g4;
+  // first the sums of the diagonal block alone: wave 4 can start on it while the row sums below are still being formed
+  for (int kc = 0; kc < ksum; kc += 24) {
+    double2 bk[3][3];
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        ao[u] = *reinterpret_cast<const double2*>(Ao + kc + 8 * u);
+    for (int u = 0; u < 3; ++u)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) bk[u][q] = *reinterpret_cast<const double2*>(Bk[q] + kc + 8 * u);
-      }
+      for (int q = 0; q < 3; ++q) bk[u][q] = *reinterpret_cast<const double2*>(Bk[q] + kc + 8 * u);
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        Rot4 rx[3], ry[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { rx[q] = rot4(bk[u][q].x); ry[q] = rot4(bk[u][q].y); }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) mma16(sp[q], rx[q], ao[u].x);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) mma16(sp[q], ry[q], ao[u].y);
-        // D tiles (wave-uniform branches: selecting the operands by index sent the fragment array to scratch memory)
-        if (wave == 0) {
-          mma16(sd[0], rx[0], bk[u][0].x); mma16(sd[0], ry[0], bk[u][0].y);
-          mma16(sd[1], rx[1], bk[u][0].x); mma16(sd[1], ry[1], bk[u][0].y);
-        } else if (wave == 1) {
-          mma16(sd[0], rx[1], bk[u][1].x); mma16(sd[0], ry[1], bk[u][1].y);
-          mma16(sd[1], rx[2], bk[u][0].x); mma16(sd[1], ry[2], bk[u][0].y);
-        } else if (wave == 2) {
-          mma16(sd[0], rx[2], bk[u][1].x); mma16(sd[0], ry[2], bk[u][1].y);
-        } else {
-          mma16(sd[0], rx[2], bk[u][2].x); mma16(sd[0], ry[2], bk[u][2].y);
-        }
+    for (int u = 0; u < 3; ++u) {
+      // D tiles (wave-uniform branches: selecting the operands by index sent the fragment array to scratch memory)
+      if (wave == 0) {
+        const Rot4 rx0 = rot4(bk[u][0].x), ry0 = rot4(bk[u][0].y), rx1 = rot4(bk[u][1].x), ry1 = rot4(bk[u][1].y);
+        mma16(sd[0], rx0, bk[u][0].x); mma16(sd[0], ry0, bk[u][0].y);
+        mma16(sd[1], rx1, bk[u][0].x); mma16(sd[1], ry1, bk[u][0].y);
+      } else if (wave == 1) {
+        const Rot4 rx1 = rot4(bk[u][1].x), ry1 = rot4(bk[u][1].y), rx2 = rot4(bk[u][2].x), ry2 = rot4(bk[u][2].y);
+        mma16(sd[0], rx1, bk[u][1].x); mma16(sd[0], ry1, bk[u][1].y);
+        mma16(sd[1], rx2, bk[u][0].x); mma16(sd[1], ry2, bk[u][0].y);
+      } else if (wave == 2) {
+        const Rot4 rx2 = rot4(bk[u][2].x), ry2 = rot4(bk[u][2].y);
+        mma16(sd[0], rx2, bk[u][1].x); mma16(sd[0], ry2, bk[u][1].y);
+      } else {
+        const Rot4 rx2 = rot4(bk[u][2].x), ry2 = rot4(bk[u][2].y);
+        mma16(sd[0], rx2, bk[u][2].x); mma16(sd[0], ry2, bk[u][2].y);
       }
     }
   }
-#pragma unroll
-  for (int q = 0; q < 3; ++q) sp[q] = unrot(sp[q]);
   sd[0] = unrot(sd[0]);
   sd[1] = unrot(sd[1]);
   // D = F[kb, kb] - S_D into LDS (identity beyond nb); loads from clamped (always valid) addresses, masked afterwards
@@ -374,6 +365,32 @@ __device__ __forceinline__ void front_panel_body(const FrontPlan& p, int wgi, in
       if (u == 0 || two_d) DL[row * LDW + col] = v;
     }
   }
+  __syncthreads();
+  // ---- (a') the row sums S_P^T (columns of the panel x own rows), beside wave 4's factorisation of the diagonal block ----
+  {
+    const double* Ao = F + (size_t)orow * ld + J.c0 + 2 * g4;
+    for (int kc = 0; kc < ksum; kc += 24) {
+      double2 ao[3], bk[3][3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        ao[u] = *reinterpret_cast<const double2*>(Ao + kc + 8 * u);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bk[u][q] = *reinterpret_cast<const double2*>(Bk[q] + kc + 8 * u);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        Rot4 rx[3], ry[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { rx[q] = rot4(bk[u][q].x); ry[q] = rot4(bk[u][q].y); }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) mma16(sp[q], rx[q], ao[u].x);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) mma16(sp[q], ry[q], ao[u].y);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) sp[q] = unrot(sp[q]);
   // P^T = F[own rows, kb]^T - S_P^T, kept in registers in the layout every later product consumes as its B operand:
   // lane (li, g4) holds P[own row li][column 16 q + g4 + 4 r]
   double4_t pt[3];
@@ -388,7 +405,6 @@ __device__ __forceinline__ void front_panel_body(const FrontPlan& p, int wgi, in
 #pragma unroll
       for (int r = 0; r < 4; ++r) pt[q][r] = (16 * q + g4 + 4 * r < nb) ? c[4 * q + r] - sp[q][r] : 0.0;
   }
-  __syncthreads();
   // ---- (b) wave 4: the diagonal block ----
   __syncthreads();
   if (!wave_on) return;
