@@ -284,22 +284,24 @@ __device__ __noinline__ bool diag_block_wave(lds_double* DL, lds_double* Wd, lds
 
 // One 48-column panel step (see FrontJob).  320 lanes = 5 waves: waves 0..3 own rows [16 w, 16 w + 16) of the 64-row tile
 // (sums and TRSM on the matrix cores), wave 4 factorises the diagonal block in between.
-__device__ __forceinline__ void front_panel_body(const FrontPlan& p, int wgi, int* flags, double* DL, double* Wd, double* cbuf) {
-  const FrontJob J = p.jobs[p.wg_job[wgi]];
-  const int tile = p.wg_tile[wgi] >> 16;
+__device__ __forceinline__ void front_panel_body(const FrontPlan& p, const FrontJob& J, int tile, int* flags, double* DL, double* Wd, double* cbuf) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g4 = lane >> 4;
+  // M (row-major 48 x 48: the 16 x 16 inverses on the diagonal, L below) goes to memory for the backward substitution: by all
+  // five waves of tile 0 BEHIND the second barrier (written by the diagonal-block wave alone in front of it, it was 4 us of every
+  // panel step's critical path)
+  auto store_m = [&]() {
+    double* Wg = p.Winv + J.wbase;
+    for (int e = threadIdx.x; e < FRONT_NB * FRONT_NB; e += 320) {
+      const int r = e / FRONT_NB, c = e - r * FRONT_NB;
+      Wg[e] = (r >> 4) == (c >> 4) ? Wd[r * LDWD + (c & 15)] : (r > c ? DL[r * LDW + c] : 0.0);
+    }
+  };
   if (wave == 4) {
     __syncthreads();
     const bool bad = diag_block_wave((lds_double*)DL, (lds_double*)Wd, (lds_double*)cbuf);
-    if (tile == 0) {
-      if (bad && lane == 0) atomicOr(&flags[2], 1);
-      double* Wg = p.Winv + J.wbase;     // M, row-major 48 x 48
-      for (int e = lane; e < FRONT_NB * FRONT_NB; e += 64) {
-        const int r = e / FRONT_NB, c = e - r * FRONT_NB;
-        Wg[e] = (r >> 4) == (c >> 4) ? Wd[r * LDWD + (c & 15)] : (r > c ? DL[r * LDW + c] : 0.0);
-      }
-    }
+    if (tile == 0 && bad && lane == 0) atomicOr(&flags[2], 1);
     __syncthreads();
+    if (tile == 0) store_m();
     return;
   }
   double* F = p.Fval + J.fbase;
@@ -407,6 +409,7 @@ __device__ __forceinline__ void front_panel_body(const FrontPlan& p, int wgi, in
   }
   // ---- (b) wave 4: the diagonal block ----
   __syncthreads();
+  if (tile == 0) store_m();
   if (!wave_on) return;
   // ---- (c) TRSM by 16-column blocks, everything kept transposed (lane (li, g4), register r = entry [own row li][16 q +
   // g4 + 4 r]): Y0^T = W00 P0^T;  Y1^T = W11 (P1^T - L10 Y0^T);  Y2^T = W22 (P2^T - L20 Y0^T - L21 Y1^T) ----
@@ -441,7 +444,8 @@ __global__ __launch_bounds__(320) void k_front_panel(FrontPlan p, int wg_begin, 
   __shared__ double DL[FRONT_NB * LDW];
   __shared__ double Wd[FRONT_NB * LDWD];
   __shared__ double cbuf[128];
-  front_panel_body(p, wg_begin + blockIdx.x, flags, DL, Wd, cbuf);
+  const int wgi = wg_begin + blockIdx.x;
+  front_panel_body(p, p.jobs[p.wg_job[wgi]], p.wg_tile[wgi] >> 16, flags, DL, Wd, cbuf);
 }
 
 // C tile of 64 x 64 per workgroup; wave w owns rows [16 w, 16 w + 16) x 64 columns (four 16 x 16 tiles).  C -= A B^T.
@@ -461,10 +465,9 @@ template <int NQ>
 struct GemmFrag { double2 a[2], b[NQ][2]; };
 
 template <int TILE>
-__device__ __forceinline__ void front_gemm_body(const FrontPlan& p, int wgi) {
+__device__ __forceinline__ void front_gemm_body(const FrontPlan& p, const FrontJob& J, int tt) {
   constexpr int NQ = TILE == 64 ? 4 : 1;
-  const FrontJob J = p.jobs[p.wg_job[wgi]];
-  const int tt = p.wg_tile[wgi], ti = tt >> 16, tj = tt & 0xffff;
+  const int ti = tt >> 16, tj = tt & 0xffff;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g4 = lane >> 4;
   const int wrow0 = J.r0 + TILE * ti + (TILE == 64 ? 16 * wave : 16 * (wave >> 1));
   const int col0 = J.c0 + TILE * tj + (TILE == 64 ? 0 : 16 * (wave & 1));
@@ -527,7 +530,8 @@ __device__ __forceinline__ void front_gemm_body(const FrontPlan& p, int wgi) {
 }
 template <int TILE>
 __global__ __launch_bounds__(256) void k_front_gemm(FrontPlan p, int wg_begin) {
-  front_gemm_body<TILE>(p, wg_begin + blockIdx.x);
+  const int wgi = wg_begin + blockIdx.x;
+  front_gemm_body<TILE>(p, p.jobs[p.wg_job[wgi]], p.wg_tile[wgi]);
 }
 
 #ifndef FRONT_POLL_SLEEP
@@ -545,6 +549,10 @@ __global__ __launch_bounds__(320) void k_front_stages(DeviceGraph g, FrontPlan p
   __syncthreads();
   if (fs.stamps && tid == 0) fs.stamps[3 * (size_t)tk] = (long long)__builtin_amdgcn_s_memrealtime();
   const int kind = p.st_table[2 * (size_t)tk] & 3, w = p.st_table[2 * (size_t)tk] >> 2, stage = p.st_table[2 * (size_t)tk + 1];
+  // the job descriptor does not depend on the stages waited for: fetched ahead of the wait (two dependent loads off the chain)
+  FrontJob J{};
+  int tt = 0;
+  if (kind != 0) { J = p.jobs[p.wg_job[w]]; tt = p.wg_tile[w]; }
   if (tid == 0) {
     int spins = 0;
     for (int q = p.st_pred_ptr[stage]; q < p.st_pred_ptr[stage + 1]; ++q) {
@@ -560,10 +568,10 @@ __global__ __launch_bounds__(320) void k_front_stages(DeviceGraph g, FrontPlan p
   }
   __syncthreads();
   if (kind != 1 && tid >= 256) return;                     // only a panel step has work for the fifth wave
-  if (kind == 1) front_panel_body(p, w, g.flags, smem, smem + FRONT_NB * LDW, smem + FRONT_NB * LDW + FRONT_NB * LDWD);
+  if (kind == 1) front_panel_body(p, J, tt >> 16, g.flags, smem, smem + FRONT_NB * LDW, smem + FRONT_NB * LDW + FRONT_NB * LDWD);
   else if (kind == 0) front_extend_add_body(p, w, reinterpret_cast<double (*)[ASM_T + 1]>(smem));
-  else if (kind == 2) front_gemm_body<64>(p, w);
-  else front_gemm_body<32>(p, w);
+  else if (kind == 2) front_gemm_body<64>(p, J, tt);
+  else front_gemm_body<32>(p, J, tt);
   __syncthreads();
   if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
