@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_split(DeviceGraph g, Di
     if (lane == 0) {
       int spins = 0;
       while (__hip_atomic_load(&p.col_flag[dblk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-        if (++spins > max_spins) { atomicOr(&g.flags[2], 2); break; }
+        if (++spins > max_spins || ((spins & 255) == 0 && (__hip_atomic_load(&g.flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2))) { atomicOr(&g.flags[2], 2); break; }   // (once one wait has run out nobody waits long: the factorisation is going to be repeated)
         __builtin_amdgcn_s_sleep(1);
       }
     }

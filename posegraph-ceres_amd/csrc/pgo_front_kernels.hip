@@ -559,7 +559,7 @@ __global__ __launch_bounds__(320) void k_front_stages(DeviceGraph g, FrontPlan p
       const int ps = p.st_pred[q];
       const unsigned long long target = (unsigned long long)p.st_need[ps] * fs.epoch;
       while (__hip_atomic_load(p.st_count + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (++spins > fs.max_spins) { atomicOr(&g.flags[2], 2); break; }
+        if (++spins > fs.max_spins || ((spins & 255) == 0 && (__hip_atomic_load(&g.flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2))) { atomicOr(&g.flags[2], 2); break; }   // (once one wait has run out nobody waits long: the factorisation is going to be repeated)
         __builtin_amdgcn_s_sleep(FRONT_POLL_SLEEP);       // (polling more rarely, or rarely while far from complete, changes nothing)
       }
     }
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
       for (int k = 0; k < nkids; ++k) {
         const int* flag = sy.done + p.child[D.child_begin + k];
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sy.epoch) {
-          if (++spins > sy.max_spins) { atomicOr(&g.flags[2], 2); break; }
+          if (++spins > sy.max_spins || ((spins & 255) == 0 && (__hip_atomic_load(&g.flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2))) { atomicOr(&g.flags[2], 2); break; }   // (once one wait has run out nobody waits long: the factorisation is going to be repeated)
           __builtin_amdgcn_s_sleep(SF_POLL_SLEEP);
         }
       }
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(SF_T) void k_sfront_bwd(DeviceGraph g, FrontPlan p,
     if (tid == 0) {
       int spins = 0;
       while (__hip_atomic_load(sy.done + D.parent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sy.epoch) {
-        if (++spins > sy.max_spins) { atomicOr(&g.flags[2], 2); break; }
+        if (++spins > sy.max_spins || ((spins & 255) == 0 && (__hip_atomic_load(&g.flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2))) { atomicOr(&g.flags[2], 2); break; }   // (once one wait has run out nobody waits long: the factorisation is going to be repeated)
         __builtin_amdgcn_s_sleep(1);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // one wave acquires, the barrier orders the others behind it (k_sfront_factor)
