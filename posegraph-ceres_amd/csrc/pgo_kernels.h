@@ -68,7 +68,7 @@ struct DeviceGraph {
   int n_wg;          // workgroups of the row partition
   int n_slots;       // padded (multiple of block)
   int block;         // threads per workgroup of the row-partitioned kernels = slots per chunk
-  int info_mode;     // 0 identity information, 1 general W = L^T L, 2 block-diagonal W (W_pr = 0: only W_pp, W_rr are read)
+  int info_mode;     // 0 identity information, 1 general W = L^T L, 2 block-diagonal W (W_pr = 0: only W_pp, W_rr are read), 3 diagonal W
   int blk_packed;    // 1: 27-entry slots (info_mode 0 or 2), see bsr_pos
   int loss_kind;
   double loss_a;

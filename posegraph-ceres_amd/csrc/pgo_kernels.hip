@@ -141,6 +141,20 @@ __device__ __forceinline__ WBlocks load_W_blockdiag(const double* W, size_t stri
   return w;
 }
 
+// diagonal information (W = diag(w), C2 / C4's diag(1/sigma^2)): six of the 21 planes are read; the entries set to 0.0 here are the
+// exact zeros load_W_blockdiag would have fetched, so the arithmetic behind it is the same to the bit
+__device__ __forceinline__ WBlocks load_W_diag(const double* W, size_t stride, size_t idx) {
+  WBlocks w;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { w.pp.m[k] = 0.0; w.pr.m[k] = 0.0; w.rr.m[k] = 0.0; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    w.pp.m[4 * i] = W[(size_t)upper_index(i, i) * stride + idx];
+    w.rr.m[4 * i] = W[(size_t)upper_index(3 + i, 3 + i) * stride + idx];
+  }
+  return w;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K_linearize: residual + closed-form Jacobians + Huber corrector + J^T J / J^T r, fused.
 // INFO: 0 identity information, 1 general W, 2 block-diagonal W.  0 and 2 write the packed 27-entry slots (pgo_kernels.h).
@@ -177,10 +191,10 @@ __global__ __launch_bounds__(256) void k_linearize(DeviceGraph g, int gate) {
 
       V3 wep, wer;
       M3 C1, C2, RU, GP, MQ, GU;
-      if (INFO == 2) {
-        // block-diagonal information (W_pr = 0): only W_pp and W_rr are read (12 of 21 entries); every term that carries W_pr
-        // in the general branch below is exactly zero there, so both branches give the same numbers
-        const WBlocks W = load_W_blockdiag(g.sW, ns, (size_t)t);
+      if (INFO >= 2) {
+        // block-diagonal information (W_pr = 0): only W_pp and W_rr are read (12 of 21 entries; 6 when W is diagonal, INFO 3);
+        // every term that carries W_pr in the general branch below is exactly zero there, so both branches give the same numbers
+        const WBlocks W = INFO == 3 ? load_W_diag(g.sW, ns, (size_t)t) : load_W_blockdiag(g.sW, ns, (size_t)t);
         wep = mulv(W.pp, ep);
         wer = mulv(W.rr, er);
         const M3 X = mul(W.pp, eg.Rt), Qm = mul(W.rr, eg.M), U = mul(W.pp, eg.G);
@@ -517,7 +531,7 @@ __global__ void k_cost(DeviceGraph g, const double* poses, double* part, int gat
     edge_error(A.p, A.q, B.p, B.q, mp, mq, er);
     double s;
     if (INFO) {
-      const WBlocks W = load_W(g.eW, E, (size_t)e);
+      const WBlocks W = g.info_mode == 3 ? load_W_diag(g.eW, E, (size_t)e) : load_W(g.eW, E, (size_t)e);   // (diagonal W: 6 of the 21 planes)
       const V3 ep{er[0], er[1], er[2]}, eq{er[3], er[4], er[5]};
       const V3 a1 = mulv(W.pp, ep), a2 = mulv(W.pr, eq), b1 = mulTv(W.pr, ep), b2 = mulv(W.rr, eq);
       s = dot(ep, V3{a1.x + a2.x, a1.y + a2.y, a1.z + a2.z}) + dot(eq, V3{b1.x + b2.x, b1.y + b2.y, b1.z + b2.z});
@@ -1299,7 +1313,7 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_step_tail(DeviceGraph g, int gat
     edge_error(A.p, A.q, B.p, B.q, mp, mq, er);
     double sq;
     if (INFO) {
-      const WBlocks W = load_W(g.eW, E, (size_t)e);
+      const WBlocks W = g.info_mode == 3 ? load_W_diag(g.eW, E, (size_t)e) : load_W(g.eW, E, (size_t)e);   // (diagonal W: 6 of the 21 planes)
       const V3 ep{er[0], er[1], er[2]}, eq{er[3], er[4], er[5]};
       const V3 a1 = mulv(W.pp, ep), a2 = mulv(W.pr, eq), b1 = mulTv(W.pr, ep), b2 = mulv(W.rr, eq);
       sq = dot(ep, V3{a1.x + a2.x, a1.y + a2.y, a1.z + a2.z}) + dot(eq, V3{b1.x + b2.x, b1.y + b2.y, b1.z + b2.z});
@@ -1410,7 +1424,7 @@ __global__ __launch_bounds__(256) void k_batch_scalars(DeviceGraph g, BatchPlan 
     edge_error(A.p, A.q, B.p, B.q, mp, mq, er);
     double sq;
     if (INFO) {
-      const WBlocks W = load_W(g.eW, E, (size_t)e);
+      const WBlocks W = g.info_mode == 3 ? load_W_diag(g.eW, E, (size_t)e) : load_W(g.eW, E, (size_t)e);   // (diagonal W: 6 of the 21 planes)
       const V3 ep{er[0], er[1], er[2]}, eq{er[3], er[4], er[5]};
       const V3 a1 = mulv(W.pp, ep), a2 = mulv(W.pr, eq), b1 = mulTv(W.pr, ep), b2 = mulv(W.rr, eq);
       sq = dot(ep, V3{a1.x + a2.x, a1.y + a2.y, a1.z + a2.z}) + dot(eq, V3{b1.x + b2.x, b1.y + b2.y, b1.z + b2.z});
@@ -1476,7 +1490,8 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 void launch_linearize(const DeviceGraph& g, hipStream_t s, int gate) {
   const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);
-  if (g.info_mode == 2) hipLaunchKernelGGL(k_linearize<2>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
+  if (g.info_mode == 3) hipLaunchKernelGGL(k_linearize<3>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
+  else if (g.info_mode == 2) hipLaunchKernelGGL(k_linearize<2>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
   else if (g.info_mode) hipLaunchKernelGGL(k_linearize<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
   else hipLaunchKernelGGL(k_linearize<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
 }

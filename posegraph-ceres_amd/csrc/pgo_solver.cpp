@@ -657,7 +657,7 @@ int prepare(pgo_problem* P) {
       for (int c = 0; c < 7; ++c) smeas[(size_t)c * n_slots + t] = e < 0 ? (c == 6 ? 1.0 : 0.0) : P->meas[(size_t)7 * e + c];
     }
   });
-  std::atomic<int> w_has_pr(0);
+  std::atomic<int> w_has_pr(0), w_has_offdiag(0);
   if (P->has_info) {
     eW.resize((size_t)21 * E); eL.resize((size_t)36 * E); sW.resize((size_t)21 * n_slots);
     parallel_for(E, [&](int lo, int hi) {
@@ -669,6 +669,7 @@ int prepare(pgo_problem* P) {
             double w = 0;
             for (int r = 0; r < 6; ++r) w += L[6 * r + i] * L[6 * r + j];  // W = L^T L
             if (i < 3 && j >= 3 && w != 0.0) w_has_pr.store(1, std::memory_order_relaxed);
+            if (i != j && w != 0.0) w_has_offdiag.store(1, std::memory_order_relaxed);
             eW[(size_t)k * E + e] = w;
             ++k;
           }
@@ -693,6 +694,7 @@ int prepare(pgo_problem* P) {
     });
   }
   const bool w_blockdiag = P->has_info && w_has_pr.load() == 0;
+  const bool w_diag = P->has_info && w_has_offdiag.load() == 0;      // W = diag(w) (the generators' diag(1/sigma^2)): six planes of sW are read
   lap("measurement / W arrays");
   UploadScope upload_scope(s);     // the copies below are enqueued side by side; this function's final synchronisation is their wait
   HIP_TRY(P->d_slot_col.upload(slot_col, s));
@@ -766,7 +768,8 @@ int prepare(pgo_problem* P) {
   {
     const char* full = getenv("PGO_BLK_FULL");
     const bool force_full = full && full[0] == '1';
-    g.info_mode = !P->has_info ? 0 : (w_blockdiag && !force_full) ? 2 : 1;
+    static const bool no_diag = getenv("PGO_NO_DIAG_INFO") && getenv("PGO_NO_DIAG_INFO")[0] == '1';    // (A/B: the 12-entry reads of mode 2)
+    g.info_mode = !P->has_info ? 0 : (w_diag && !force_full && !no_diag) ? 3 : (w_blockdiag && !force_full) ? 2 : 1;
     g.blk_packed = (g.info_mode != 1 && !force_full) ? 1 : 0;
   }
   g.loss_kind = P->loss_kind; g.loss_a = P->loss_a;
