@@ -511,6 +511,26 @@ def test_small_front_single_launch_timeout_falls_back_to_levels(gpu, O, ds, monk
     assert traces[0] == traces[1] == traces[2]
 
 
+def test_diagonal_information_is_read_as_six_planes_with_identical_results(gpu, ds, monkeypatch):
+    """W = diag(1/sigma^2) (the synthetic generators): the kernels read six of the 21 information planes (info_mode 3); the entries
+    they skip are exact zeros, so the LM trace and the poses equal those of the 12-plane reads (PGO_NO_DIAG_INFO=1) bit for bit,
+    for truncated PCG and for exact steps."""
+    g = ds.manhattan_se3(1200, 4200, seed=33)
+    out = []
+    for ls, kw in ((gpu.BLOCK_JACOBI_PCG, dict(eta=0.1, max_linear_solver_iterations=500)), (gpu.SPARSE_NORMAL_CHOLESKY, {})):
+        res = []
+        for off in ("1", None):
+            monkeypatch.delenv("PGO_NO_DIAG_INFO", raising=False)
+            if off:
+                monkeypatch.setenv("PGO_NO_DIAG_INFO", off)
+            prob, poses = gpu.problem_from_graph(g)
+            s = gpu.solve(gpu.SolverOptions(max_num_iterations=8, linear_solver_type=ls, **kw), prob)
+            res.append((tuple(float(c) for c in s.iterations["cost"]), tuple(int(c) for c in s.iterations["linear_solver_iterations"]), poses.tobytes()))
+        assert res[0] == res[1]
+        out.append(res[0])
+    assert len(out) == 2
+
+
 def test_multifrontal_single_launch_timeout_falls_back_to_launches(gpu, ds, monkeypatch):
     """The single-launch form of the multifrontal factorisation (every work-group of the round schedule in one grid, stages
     ordered by counters) with the wait budget forced to zero (PGO_FRONT_SPINS=0): the driver repeats the factorisation with one
