@@ -43,6 +43,27 @@ int main(int argc, char** argv) {
   std::printf("N %d E %d ok %d seconds %.3f fronts %d levels %d launches %d jobs %zu largest %d flops %.3e MB %.1f blocks %lld\n", N, E, ok ? 1 : 0, dt,
               S.nf, S.n_levels, S.n_launches, S.jobs.size(), S.max_front, S.flops, 8e-6 * (double)S.fval_size, S.factor_blocks);
   if (!ok) return 1;
+  // the stages of the single-launch form (FrontStages): the ticket order must be a topological order — every work-group of every
+  // stage a stage waits for holds an EARLIER ticket (that is what makes the in-kernel waits deadlock-free whatever is resident),
+  // every work-group of the launch schedule appears exactly once, and the counts per stage add up
+  if (!S.st_table.empty()) {
+    const int ns = (int)S.st_need.size(), nt = (int)(S.st_table.size() / 2);
+    std::vector<int> first(ns, 1 << 30), last(ns, -1), seen(ns, 0);
+    for (int t = 0; t < nt; ++t) {
+      const int sg = S.st_table[2 * (size_t)t + 1];
+      if (sg < 0 || sg >= ns) { std::printf("stage plan: ticket %d has stage %d of %d\n", t, sg, ns); return 1; }
+      first[sg] = std::min(first[sg], t); last[sg] = std::max(last[sg], t); ++seen[sg];
+    }
+    long long total = 0;
+    for (const FrontLaunch& La : S.launches) total += La.n_wg;
+    bool good = total == nt;
+    for (int sg = 0; sg < ns && good; ++sg) {
+      good = seen[sg] == S.st_need[sg] && seen[sg] > 0;
+      for (int q = S.st_pred_ptr[sg]; q < S.st_pred_ptr[sg + 1] && good; ++q) good = last[S.st_pred[q]] < first[sg];
+    }
+    std::printf("stage plan: %d tickets, %d stages, %s\n", nt, ns, good ? "topological order ok" : "BROKEN");
+    if (!good) return 1;
+  }
   if (argc > 2) {
     int np = 0, ng = 0, na = 0;
     for (const FrontLaunch& La : S.launches) { np += La.type == FrontLaunch::PANEL; ng += La.type == FrontLaunch::GEMM; na += La.type == FrontLaunch::ASM; }
