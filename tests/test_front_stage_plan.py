@@ -49,3 +49,14 @@ def test_stage_plan_is_a_topological_order(cli, ds, tmp_path, name):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "topological order ok" in out.stdout
     assert "relative residual" in out.stdout
+
+
+def test_small_front_numbering_puts_children_first(cli, tmp_path):
+    """The single-launch small-front factorisation takes fronts in the order of their numbers: a front's children must have
+    smaller numbers (KITTI-00 replay, every front <= 96 scalars)."""
+    kz = np.load(os.path.join(ROOT, "tests", "golden", "kitti00.npz"))
+    n = int(max(kz["ia"].max(), kz["ib"].max())) + 1
+    env = dict(os.environ, SMALL_MAX="96")
+    out = subprocess.run([cli, _edges(tmp_path, "kitti", n, kz["ia"], kz["ib"])], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert "children before parents ok" in out.stdout

@@ -43,6 +43,15 @@ int main(int argc, char** argv) {
   std::printf("N %d E %d ok %d seconds %.3f fronts %d levels %d launches %d jobs %zu largest %d flops %.3e MB %.1f blocks %lld\n", N, E, ok ? 1 : 0, dt,
               S.nf, S.n_levels, S.n_launches, S.jobs.size(), S.max_front, S.flops, 8e-6 * (double)S.fval_size, S.factor_blocks);
   if (!ok) return 1;
+  // children before parents in the front numbering: the ticket order of the single-launch small-front factorisation (a front
+  // waits only for fronts with smaller numbers) and of its backward substitution (the root first) rests on it
+  for (int f = 0; f < S.nf; ++f) {
+    for (int ci = S.fronts[f].child_begin; ci < S.fronts[f].child_end; ++ci)
+      if (S.child[ci] >= f || S.fronts[S.child[ci]].parent != f) { std::printf("front %d: child %d out of order\n", f, S.child[ci]); return 1; }
+    if (S.fronts[f].parent >= 0 && S.fronts[f].parent <= f) { std::printf("front %d: parent %d out of order\n", f, S.fronts[f].parent); return 1; }
+  }
+  std::printf("front numbering: children before parents ok\n");
+  if (S.small) return 0;      // (the small-front kernels are checked on the GPU: this tool emulates the round schedule)
   // the stages of the single-launch form (FrontStages): the ticket order must be a topological order — every work-group of every
   // stage a stage waits for holds an EARLIER ticket (that is what makes the in-kernel waits deadlock-free whatever is resident),
   // every work-group of the launch schedule appears exactly once, and the counts per stage add up
