@@ -232,6 +232,7 @@ __device__ __forceinline__ bool chol6_inplace(double* Ljj) {
 // shared by the ten 6-lane groups, partial rows summed through LDS in a fixed order.  A diagonal block is factorised on
 // the spot (L_jj), an off-diagonal block is left as V in Lval for phase 2. ----
 __global__ __launch_bounds__(64) void k_chol_assemble(DeviceGraph g, DirectPlan p, int blk_begin) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double sh[360];
   const int bi = p.split_blk[blk_begin + blockIdx.x];
   const int lane = threadIdx.x;
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(64) void k_chol_assemble(DeviceGraph g, DirectPlan 
 // step of a diagonal block's column is shared by the four waves too.
 constexpr int ASM_WAVES = 4;
 __global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_assemble4(DeviceGraph g, DirectPlan p, int blk_begin) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double sh[ASM_WAVES][360];
   __shared__ double shf[ASM_WAVES][64];
   __shared__ double Ld[36];
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_assemble4(DeviceGraph g
 // a wait that runs out sets the failure flag instead of hanging.
 constexpr int SPLIT_FUSED_MAX = 1024;
 __global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_split(DeviceGraph g, DirectPlan p, int blk_begin, int epoch, int max_spins) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double sh[ASM_WAVES][360];
   __shared__ double shf[ASM_WAVES][64];
   __shared__ double Ld[36];
@@ -391,6 +394,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_split(DeviceGraph g, Di
 
 // phase 2, one 6-lane group per sub-diagonal block of the level (ten per wave, lane = row): L_ij = V_ij L_jj^-T
 __global__ __launch_bounds__(64) void k_chol_scale(DeviceGraph g, DirectPlan p, int sub_begin, int sub_end) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   const int lane = threadIdx.x;
   const int grp = lane / 6, r = lane - 6 * grp;
   const int q = sub_begin + blockIdx.x * 10 + grp;
@@ -417,6 +421,7 @@ __global__ __launch_bounds__(64) void k_chol_scale(DeviceGraph g, DirectPlan p, 
 // forward step and bring the sub-diagonal blocks up to date (their few in-panel pairs; one 6-lane group per block) —
 // none of that needs L_jj; after the barrier wave 0 finishes the forward step and the others apply L_jj^-T. ----
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_panel(DeviceGraph g, DirectPlan p, int cols_begin, int width) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double sh[360];
   __shared__ double Ld[36];
   __shared__ double shf[FUSED_WAVES][64];
@@ -597,12 +602,14 @@ __device__ void factor_column_roles(const DeviceGraph& g, const DirectPlan& p, i
 }
 
 __global__ __launch_bounds__(192) void k_chol_level3(DeviceGraph g, DirectPlan p, int level) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double shd[360], sho[360], shf[64], Ld[36];
   const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
   factor_column_roles(g, p, j, threadIdx.x >> 6, shd, sho, shf, Ld);
 }
 
 __global__ __launch_bounds__(64) void k_chol_level(DeviceGraph g, DirectPlan p, int level) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double sh[360];
   const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
   factor_column(g, p, j, sh);
@@ -616,6 +623,7 @@ __global__ __launch_bounds__(64) void k_chol_level(DeviceGraph g, DirectPlan p, 
 // the 6 x 6 factor redundantly in the six lanes (rows exchanged through LDS), scaling, and the fused forward step.
 constexpr int GRP_WAVES = 4;
 __global__ __launch_bounds__(64 * GRP_WAVES) void k_chol_level_grp(DeviceGraph g, DirectPlan p, int level) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double sh[GRP_WAVES * 10 * 36];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int grp = lane / 6, r = lane - 6 * grp;
@@ -691,6 +699,7 @@ __global__ __launch_bounds__(64 * GRP_WAVES) void k_chol_level_grp(DeviceGraph g
 
 // backward level, one group per column: lane c owns component c of y_j - sum_i L_ij^T x_i
 __global__ __launch_bounds__(64 * GRP_WAVES) void k_bwd_level_grp(DeviceGraph g, DirectPlan p, int level) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double sh[GRP_WAVES * 10 * 6];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int grp = lane / 6, c = lane - 6 * grp;
@@ -733,6 +742,7 @@ __global__ __launch_bounds__(64 * GRP_WAVES) void k_bwd_level_grp(DeviceGraph g,
 }
 
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_chol_tail(DeviceGraph g, DirectPlan p, int from_level, int to_level) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double sh[FUSED_WAVES][360];
   const int wave = threadIdx.x >> 6;
   for (int l = from_level; l < to_level; ++l) {
@@ -839,6 +849,7 @@ __device__ __forceinline__ void backward_finish(const DeviceGraph& g, const Dire
 }
 
 __global__ __launch_bounds__(64) void k_bwd_level(DeviceGraph g, DirectPlan p, int level) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double sh[64];
   const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
   backward_partial(p, j, 0, 1, sh);
@@ -849,6 +860,7 @@ __global__ __launch_bounds__(64) void k_bwd_level(DeviceGraph g, DirectPlan p, i
 // its inputs (y_j, L_jj, the permutation) fetched beside the partial sums.
 constexpr int BWD_WAVES = 4;
 __global__ __launch_bounds__(64 * BWD_WAVES) void k_bwd_level4(DeviceGraph g, DirectPlan p, int level) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double sh[BWD_WAVES][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
@@ -905,6 +917,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void k_bwd_level4(DeviceGraph g, Di
 constexpr int BWD_TAIL_LDS_COLS = 896;
 template <bool XLDS>
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_bwd_tail(DeviceGraph g, DirectPlan p, int from_level) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double sh[FUSED_WAVES][64];
   __shared__ double xs[XLDS ? 6 * BWD_TAIL_LDS_COLS : 6];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -163,6 +163,7 @@ struct FrontPlan {
   const int* st_pred;       // ... (one: the front's previous stage; an extend-add: the last stage of every child)
   const int* st_need;       // [n_stages] work-groups of the stage
   unsigned long long* st_count;   // [n_stages + 1] finished work-groups, never reset: stage s of factorisation e is complete at need[s] * e; [n_stages]: tickets
+  const int* halt;          // device-resident LM (pgo_kernels.h LmDev::halt) or null: kernels that see only the plan exit while *halt != 0
 };
 // The single-launch form of the regular multifrontal factorisation: every work-group of every round of the launch schedule in ONE
 // grid, taken in ticket order (= the order of the launches, a topological order of the stages), a work-group waits until the

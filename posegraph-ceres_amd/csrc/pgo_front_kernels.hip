@@ -26,6 +26,12 @@ namespace {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// A wave's global stores are complete (acknowledged by the XCD's L2) once its vmcnt has drained.  __syncthreads() alone does
+// not wait for that on gfx950 (a work-group-scope release omits vmcnt(0) outside tgsplit mode), so a single-wave agent-scope
+// release behind a barrier would only cover that wave's OWN stores: every wave drains first, then the barrier, then one
+// buffer_wbl2 + flag (r02 advisor finding on the single-launch publishes).
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // ---- the 16 x 16 x 4 product, two ways -------------------------------------------------------------------------------------
 // Measured on MI355X (tools/bench/fma_rate.hip, mfma_rate.hip): v_mfma_f64_16x16x4_f64 retires 2048 flops per ~61 ns per wave
 // (32 TFLOP/s with one wave per SIMD, 46 saturated); v_mfma_f64_4x4x4_4b_f64 512 flops per ~8 ns (64-67 TFLOP/s) — the small
@@ -83,6 +89,7 @@ __device__ __forceinline__ double4_t unrot(const double4_t& acc) { return acc; }
 #endif
 
 __global__ __launch_bounds__(256) void k_front_scatter(DeviceGraph g, FrontPlan p) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long na = (long long)p.n_ablk * 36;
   if (t < na) {
@@ -148,6 +155,7 @@ __device__ __forceinline__ void front_extend_add_body(const FrontPlan& p, int w,
   }
 }
 __global__ __launch_bounds__(256) void k_front_extend_add(FrontPlan p, int wg_begin) {
+  if (p.halt && *p.halt) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double acc[ASM_T][ASM_T + 1];
   front_extend_add_body(p, wg_begin + blockIdx.x, acc);
 }
@@ -441,6 +449,7 @@ __device__ __forceinline__ void front_panel_body(const FrontPlan& p, const Front
   }
 }
 __global__ __launch_bounds__(320) void k_front_panel(FrontPlan p, int wg_begin, int* flags) {
+  if (p.halt && *p.halt) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double DL[FRONT_NB * LDW];
   __shared__ double Wd[FRONT_NB * LDWD];
   __shared__ double cbuf[128];
@@ -530,6 +539,7 @@ __device__ __forceinline__ void front_gemm_body(const FrontPlan& p, const FrontJ
 }
 template <int TILE>
 __global__ __launch_bounds__(256) void k_front_gemm(FrontPlan p, int wg_begin) {
+  if (p.halt && *p.halt) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   const int wgi = wg_begin + blockIdx.x;
   front_gemm_body<TILE>(p, p.jobs[p.wg_job[wgi]], p.wg_tile[wgi]);
 }
@@ -539,6 +549,7 @@ __global__ __launch_bounds__(256) void k_front_gemm(FrontPlan p, int wg_begin) {
 #endif
 // ---- the single-launch form (FrontStages, pgo_front.h): every work-group of the launch schedule in one grid ------------------
 __global__ __launch_bounds__(320) void k_front_stages(DeviceGraph g, FrontPlan p, FrontStages fs) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double smem[FRONT_NB * LDW + FRONT_NB * LDWD + 128];
   __shared__ int tk;
   const int tid = threadIdx.x;
@@ -572,6 +583,7 @@ __global__ __launch_bounds__(320) void k_front_stages(DeviceGraph g, FrontPlan p
   else if (kind == 0) front_extend_add_body(p, w, reinterpret_cast<double (*)[ASM_T + 1]>(smem));
   else if (kind == 2) front_gemm_body<64>(p, J, tt);
   else front_gemm_body<32>(p, J, tt);
+  drain_stores();          // every wave's own stores acknowledged by the L2 before the barrier: wave 0's write-back below then covers them all
   __syncthreads();
   if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -586,6 +598,7 @@ __global__ __launch_bounds__(320) void k_front_stages(DeviceGraph g, FrontPlan p
 // front's own columns (their x is written by phase B).  Dynamic LDS: xr[r6] | red[512].
 constexpr int BWD_T = 512;
 __global__ __launch_bounds__(BWD_T) void k_front_bwd_gemv(FrontPlan p, int wg_begin) {
+  if (p.halt && *p.halt) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   extern __shared__ double sh[];
   const int wgi = wg_begin + blockIdx.x;
   const FrontDesc D = p.fronts[p.bwd_front[wgi]];
@@ -623,6 +636,7 @@ __global__ __launch_bounds__(BWD_T) void k_front_bwd_gemv(FrontPlan p, int wg_be
 // below the source then solves the chunk's own diagonal block panel by panel (x_k = W_k^T t_k, then
 // t[j] -= sum_a L[k0 + a][j] x_k[a] for the chunk's columns j < k0) and publishes x.
 __global__ __launch_bounds__(BWD_T) void k_front_bwd_block(DeviceGraph g, FrontPlan p, int wg_begin) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double xs[FRONT_NBO];
   __shared__ double tv[FRONT_NBO];
   __shared__ double red[BWD_T];
@@ -770,6 +784,7 @@ constexpr int SF_T = 256;
 #endif
 
 __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan p, SFrontPlan sp, int front_begin, int dbg, SFrontSync sy) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   extern __shared__ double F[];     // (n + 1) x ld, ld = n + 1 (n is a multiple of 6: the stride is odd)
   const int tid = threadIdx.x;
   int fi = blockIdx.x;
@@ -992,7 +1007,8 @@ __global__ __launch_bounds__(SF_T) void k_sfront_factor(DeviceGraph g, FrontPlan
       for (int jj = tid & 7; jj <= jmax; jj += 8) Ug[e0 + jj] = row[jj];
     }
   }
-  if (sy.done) {                    // publish: every lane's stores are in the L2 behind the barrier, ONE wave writes them back, then the flag
+  if (sy.done) {                    // publish: every wave waits for the L2's acknowledgement of its own stores, the barrier collects them, ONE wave writes the L2 back, then the flag
+    drain_stores();
     __syncthreads();
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1080,6 +1096,7 @@ __global__ __launch_bounds__(SF_T) void k_sfront_upos(FrontPlan p, SFrontPlan sp
 // W = L11^-1 of every front at once (nothing of the factorisation waits for it), by 6 x 6 blocks: block row i of W needs the
 // block rows above it, W_ij = -W_ii sum_{k = j}^{i - 1} L_ik W_kj, all its entries side by side (two barriers per block row).
 __global__ __launch_bounds__(SF_T) void k_sfront_invert(FrontPlan p, SFrontPlan sp, int front_begin) {
+  if (p.halt && *p.halt) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   extern __shared__ double sh[];     // L11: c6 x ld | W: c6 x ld | T: 6 x ld
   const int f = sp.list ? sp.list[front_begin + blockIdx.x] : front_begin + blockIdx.x, tid = threadIdx.x;
   const FrontDesc D = p.fronts[f];
@@ -1138,6 +1155,7 @@ __global__ __launch_bounds__(SF_T) void k_sfront_invert(FrontPlan p, SFrontPlan 
 
 // backward substitution of one level (parents first): t = y_c - L21^T x_r, x_c = W^T t
 __global__ __launch_bounds__(SF_T) void k_sfront_bwd(DeviceGraph g, FrontPlan p, SFrontPlan sp, int front_begin, SFrontSync sy) {
+  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double xr[SFRONT_MAX], tv[SFRONT_MAX], red[SF_T];
   const int tid = threadIdx.x;
   int fi = blockIdx.x;
@@ -1209,6 +1227,7 @@ __global__ __launch_bounds__(SF_T) void k_sfront_bwd(DeviceGraph g, FrontPlan p,
     g.cg_x[6 * (size_t)p.perm[col] + tid % 6] = x;
   }
   if (sy.done) {
+    drain_stores();
     __syncthreads();
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1230,8 +1249,16 @@ static void sfront_attributes() {
 }
 static const int sf_dbg = getenv("PGO_SF_DBG") ? atoi(getenv("PGO_SF_DBG")) : 0;   // timing ablations of k_sfront_factor (results are wrong with any bit set)
 
-void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s, const SFrontPlan* sp,
+// the kernels that see only the plan gate on FrontPlan::halt = the first word of the device-resident LM state (null without it)
+static inline FrontPlan with_halt(const FrontPlan& p, const DeviceGraph& g) {
+  FrontPlan q = p;
+  q.halt = reinterpret_cast<const int*>(g.lm);
+  return q;
+}
+
+void launch_front_factor(const DeviceGraph& g, const FrontPlan& p_in, const FrontSymbolic& sym, hipStream_t s, const SFrontPlan* sp,
                          const FrontStages* stages) {
+  const FrontPlan p = with_halt(p_in, g);
   (void)hipMemsetAsync(p.Fval, 0, (size_t)sym.fval_size * sizeof(double), s);
   const long long nt = (long long)p.n_ablk * 36 + 6LL * p.n;
   hipLaunchKernelGGL(k_front_scatter, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, g, p);
@@ -1259,7 +1286,8 @@ void launch_front_factor(const DeviceGraph& g, const FrontPlan& p, const FrontSy
   }
 }
 
-void launch_front_solve(const DeviceGraph& g, const FrontPlan& p, const FrontSymbolic& sym, hipStream_t s, const SFrontPlan* sp) {
+void launch_front_solve(const DeviceGraph& g, const FrontPlan& p_in, const FrontSymbolic& sym, hipStream_t s, const SFrontPlan* sp) {
+  const FrontPlan p = with_halt(p_in, g);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_bwd_gemv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
@@ -1281,8 +1309,9 @@ void launch_sfront_prepare(const FrontPlan& p, const SFrontPlan& sp, const Front
   hipLaunchKernelGGL(k_sfront_upos, dim3(sym.mixed ? sym.n_small : sym.nf), dim3(SF_T), 0, s, p, sp);
 }
 
-void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s,
+void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p_in, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s,
                           const SFrontSync* fused) {
+  const FrontPlan p = with_halt(p_in, g);
   sfront_attributes();
   const size_t lds = (size_t)(sym.max_front + 1) * (sym.max_front + 1) * sizeof(double);
   if (fused && fused->done) {
@@ -1307,8 +1336,9 @@ void launch_sfront_factor(const DeviceGraph& g, const FrontPlan& p, const SFront
   hipLaunchKernelGGL(k_sfront_invert, dim3(sym.nf), dim3(SF_T), (2 * (size_t)c6max + 6) * (c6max + 1) * sizeof(double), s, p, sp, 0);
 }
 
-void launch_sfront_solve(const DeviceGraph& g, const FrontPlan& p, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s,
+void launch_sfront_solve(const DeviceGraph& g, const FrontPlan& p_in, const SFrontPlan& sp, const FrontSymbolic& sym, hipStream_t s,
                          const SFrontSync* fused) {
+  const FrontPlan p = with_halt(p_in, g);
   if (fused && fused->done) {
     hipLaunchKernelGGL(k_sfront_bwd, dim3(sym.nf), dim3(SF_T), 0, s, g, p, sp, 0, *fused);
     return;

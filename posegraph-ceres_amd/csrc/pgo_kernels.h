@@ -36,6 +36,53 @@ __host__ __device__ inline int bsr_pos(int packed, int side, int k) {
   return side == SIDE_END ? 18 + 3 * r + (c - 3) : side == SIDE_DIAG ? 18 + 3 * (c - 3) + r : -1;   // top-right (DIAG: mirror)
 }
 
+// ---- device-resident Levenberg-Marquardt state (r03): the trust-region decisions of SURVEY.md A.6 steps 4-7 are taken ON THE
+// DEVICE, by the last work-group of the step tail, so the host can enqueue the kernel sequences of several LM iterations ahead
+// and never sits between two of them (r02: every iteration ended in a hand-off to the host, which decided accept / reject and
+// enqueued the next one: 13 us on the builder's box, ~60 us on the driver's, of a 300 us iteration).
+// A SEQUENCE is what the host enqueues for one prospective LM iteration:
+//   damping(+preconditioner) | CG start | nb x (SpMV, update) | tail SpMV | step tail + DECISION | linearise | accept-finish
+// Kernels read what the host used to pass by value (trust-region radius, "reuse the clamped diagonal") from LmDev and gate
+// themselves on it:  halt != 0 -> every kernel exits at once (terminated, or the host has to step in);  phase CONT -> the CG of
+// the previous sequence has not stopped yet: damping / CG start exit, the CG kernels simply go on;  accepted -> the linearisation
+// of the candidate (in place: nothing needs the old one any more) and the accept-finish kernel (candidate -> current point,
+// gradient norm, gradient-tolerance and minimum-radius tests) run only behind an accepted step.
+enum LmHalt { LM_RUN = 0, LM_HALT_TERMINATED = 1, LM_HALT_CG_STALL = 2, LM_HALT_REFACTOR = 3 };
+enum LmPhase { LM_PHASE_NEW = 0, LM_PHASE_CONT = 1 };
+struct LmRecord {            // layout of pgo_iteration_record (include/pgo.h; static_assert in pgo_solver.cpp)
+  int iteration, step_is_successful, linear_solver_iterations, reserved;
+  double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;
+};
+// What the trust-region rules (pgo_lm_rules.h) read and update, and the tolerances they apply.
+struct LmCore {
+  double radius, decrease_factor, x_cost, x_norm, gmax;
+  int iteration;                 // TrustRegionMinimizer's iteration counter = record index of the current point
+  int reuse_diagonal;
+  int num_consecutive_invalid;
+  int pad;
+};
+struct LmTolerances {
+  double min_relative_decrease, function_tolerance, parameter_tolerance, gradient_tolerance, max_radius, min_radius;
+  int max_num_iterations, max_consecutive_invalid;
+};
+struct LmDev {
+  int halt;                  // LmHalt — FIRST member: kernels that only see a plan struct gate on `const int* halt`
+  int phase;                 // LmPhase
+  int accepted;              // outcome of the last decision (1: the linearise / accept-finish kernels of the sequence run)
+  int termination, reason;   // pgo_termination / reason code once halt == LM_HALT_TERMINATED
+  int lm_done;               // decisions taken since pgo_solver_begin / pgo_solver_reset
+  int num_successful, num_unsuccessful, num_linear_iterations, num_records;
+  int cg_period;             // residual refresh period of the CG (a CG that outlives its sequence goes on in the next one only
+                             // from a multiple of it: the refresh launches sit at fixed positions of every sequence)
+  int last_cg;
+  LmCore core;
+  LmTolerances tol;
+  double min_diag, max_diag; // LevenbergMarquardtStrategy's clamp of the diagonal
+  double term_value;         // the number the termination message quotes (relative step norm, |cost change| / cost, gradient norm, radius)
+  long long t_mark, ticks_linear, ticks_jacobian;   // s_memrealtime (100 MHz): end of the previous phase, time spent per phase
+};
+enum { LM_RING = 64 };       // iteration records in flight between two host polls (the host keeps at most a few sequences ahead)
+
 // Scalars the host reads once per LM iteration (pinned, device-visible).
 struct LmScalars {
   double cand_cost;        // 0.5 * sum rho(s) at the candidate point
@@ -48,6 +95,14 @@ struct LmScalars {
   int cg_status;           // 0 ok, 1 p'q <= 0 (no further progress), 2 non-finite
   int linearize_bad;       // non-finite values seen while linearising
   int seq;                 // hand-off flag: cleared by the host, set last by the publishing kernel (host spins on it)
+  // ---- device-resident LM (LmDev above): what the host polls while sequences are in flight ----
+  int seq_done;            // id of the last sequence whose final kernel has run
+  int lm_done;             // decisions taken
+  int halt;                // mirror of LmDev::halt
+  int last_cg;             // CG iterations of the last decided iteration (batch-length prediction)
+  int pad0;
+  LmDev lm;                // mirror of the device state, complete whenever seq_done == the last enqueued sequence
+  LmRecord ring[LM_RING];  // iteration records, slot = record index % LM_RING
 };
 
 struct CgState {
@@ -120,6 +175,7 @@ struct DeviceGraph {
   int n_edge_wg;      // grid of edge-parallel kernels
   int n_pose_wg;      // grid of pose-parallel kernels
   CgState* cg;        // device
+  LmDev* lm;          // device-resident LM state; null: the host decides and passes radius / mode by value (several ranks, batched solve, tests)
   LmScalars* scal;    // device-visible pinned host memory
   int* flags;         // [4] device flags: [0] linearize saw non-finite
   int debug;          // development ablation switches (0 in production)
@@ -163,8 +219,10 @@ struct CgParams {
   int min_iterations;
 };
 
+__device__ __forceinline__ bool lm_halted(const DeviceGraph& g) { return g.lm && g.lm->halt != 0; }
+
 // launches (all asynchronous on `s`)
-void launch_linearize(const DeviceGraph& g, hipStream_t s, int gate = 0);   // gate: run only once the CG has stopped (speculative launch behind a step tail)
+void launch_linearize(const DeviceGraph& g, hipStream_t s, int gate = 0);   // gate 1: run only once the CG has stopped (speculative launch behind a step tail); 2: device-resident LM, behind an accepted step
 void launch_scale_from_diag(const DeviceGraph& g, hipStream_t s);
 void launch_damping(const DeviceGraph& g, double radius, double min_diag, double max_diag, int mode, hipStream_t s);
 void launch_cost(const DeviceGraph& g, const double* poses, int part_row, hipStream_t s, int gate = 0);
@@ -180,6 +238,11 @@ void launch_spmv_plain(const DeviceGraph& g, hipStream_t s);
 // diagonal lanes also write delta and the candidate poses (rows of this rank)
 void launch_spmv_tail(const DeviceGraph& g, const CgParams& p, hipStream_t s, int finish, int candidates);
 void launch_step_tail(const DeviceGraph& g, hipStream_t s, int gate);                  // fused model change / candidate / cost / scalar fold + hand-off
+                                                                                       // gate bit 0: only once the CG has stopped; bit 1 (g.lm): exact step, no CG ran
+// device-resident LM (g.lm != null): last kernel of a sequence (candidate -> current, gradient norm, opening tests of the next
+// pass, "sequence seq_id is through" for the host), and the host's way back in after a non-terminal halt
+void launch_accept_finish(const DeviceGraph& g, int seq_id, hipStream_t s);
+void launch_lm_resume(const DeviceGraph& g, int cg_goes_on, hipStream_t s);
 void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s);
 void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s, int mode = 0);   // mode: see k_pcg_update
 void launch_spmv_refresh(const DeviceGraph& g, hipStream_t s, int on_the_fly = 0, int it_odd = 0);

@@ -13,6 +13,7 @@
 //   * k_pcg_spmv    : lane multiplies its block with the gathered 6-vector, LDS segmented row sums.
 // Everything is FP64 and HBM/L2 bound; MFMA is deliberately not used for 6x6 blocks.
 #include "pgo_kernels.h"
+#include "pgo_lm_rules.h"
 #include "pgo_math.h"
 
 namespace pgo {
@@ -164,7 +165,8 @@ __device__ __forceinline__ WBlocks load_W_diag(const double* W, size_t stride, s
 template <int INFO>
 __global__ __launch_bounds__(256) void k_linearize(DeviceGraph g, int gate) {
   extern __shared__ double lds[];  // NV_LIN * block
-  if (gate && !g.cg->done) return;
+  if (gate == 1 && !g.cg->done) return;
+  if (gate == 2 && (g.lm->halt || !g.lm->accepted)) return;   // device-resident LM: behind an accepted step only (g.pose_x is the candidate)
   const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
   const int s_begin = g.wg_slot_begin[wg], s_end = g.wg_slot_begin[wg + 1];
   const int r0 = g.wg_row_begin[wg], nrows = g.wg_row_begin[wg + 1] - r0;
@@ -372,6 +374,10 @@ __global__ void k_scale_from_diag(DeviceGraph g) {
 // mode 0: clamp fresh, 1: reuse the clamped diagonal (rejected step), 2: take g.d2 as given (tests)
 __global__ void k_damping(DeviceGraph g, double radius, double min_diag, double max_diag, int mode) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g.lm) {   // device-resident LM: radius and "reuse the clamped diagonal" come from the device state
+    if (g.lm->halt || g.lm->phase == LM_PHASE_CONT) return;
+    radius = g.lm->core.radius; mode = g.lm->core.reuse_diagonal ? 1 : 0;
+  }
   if (v >= g.N) return;
   double A[36];
   const double2* src = reinterpret_cast<const double2*>(g.Hdiag + 36 * (size_t)v);
@@ -418,6 +424,11 @@ __global__ __launch_bounds__(64) void k_cluster_precond(DeviceGraph g, double ra
   // register of every lane; no LDS array, no barriers (the LDS version spent ~1.2 us per pivot on dependent LDS
   // round trips).
   constexpr int DIM = 6 * CL, CPW = 64 / DIM;
+  if (g.lm) {   // device-resident LM (k_damping)
+    if (g.lm->halt || g.lm->phase == LM_PHASE_CONT) return;
+    radius = g.lm->core.radius;
+    if (mode >= 0) mode = g.lm->core.reuse_diagonal ? 1 : 0;
+  }
   const int lane = threadIdx.x;
   const int grp = lane / DIM, j = lane - grp * DIM;
   const int n_cl = (g.row_hi - g.row_lo + CL - 1) / CL;
@@ -657,6 +668,7 @@ __global__ void k_pcg_init(DeviceGraph g) {
   __shared__ double rl[VEC_BLOCK];
   __shared__ double scratch[2 * (VEC_BLOCK / 64)];
   const int tid = threadIdx.x;
+  if (g.lm && (g.lm->halt || g.lm->phase == LM_PHASE_CONT)) return;   // device-resident LM: halted, or the previous sequence's CG goes on
   double acc[2] = {0.0, 0.0};
   for (int base = blockIdx.x * VEC_BLOCK; base < 6 * g.N; base += gridDim.x * VEC_BLOCK) {
     const int idx = base + tid;
@@ -718,6 +730,7 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
   double* lds_p = lds + (size_t)SPMV_LDS_STRIDE * B;
 
   if (MODE == 1 && (odd & 8) && g.cg->done) return;   // A x of a residual refresh: nothing to do once the CG has stopped
+  if (MODE == 1 && !(odd & 8) && lm_halted(g)) return;  // step tail of a sequence enqueued ahead of a halt
   if (MODE == 1 && (odd & 2)) {
     // Step tail behind a CG batch: this kernel first does what k_pcg_finish does (every workgroup evaluates the stop test
     // of the last completed iteration from the same partial rows, workgroup 0 publishes the state), and computes
@@ -1265,6 +1278,76 @@ __global__ void k_finalize_scalars(DeviceGraph g, int n_cost_part, int gate) {
   }
 }
 
+// ---- device-resident LM: the decision (pgo_kernels.h LmDev, pgo_lm_rules.h) ---------------------------------------------
+// Everything below runs on ONE lane (the last work-group of the step tail / of the accept-finish kernel).
+__device__ __forceinline__ void lm_mirror(const DeviceGraph& g) {   // device state -> pinned mirror, then the words the host polls
+  LmDev& D = *g.lm;
+  g.scal->lm = D;
+  g.scal->last_cg = D.last_cg;
+  __threadfence_system();
+  __hip_atomic_store(&g.scal->lm_done, D.lm_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&g.scal->halt, D.halt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void lm_terminate(LmDev& D, int termination, int reason, double value) {
+  D.halt = LM_HALT_TERMINATED; D.termination = termination; D.reason = reason; D.term_value = value; D.accepted = 0;
+}
+// FinalizeIterationAndCheckIfMinimizerCanContinue of the NEXT pass (SURVEY A.6 step 7 order: maximum iterations, gradient
+// tolerance — behind a successful step only —, minimum radius), evaluated as soon as its inputs exist.
+__device__ __forceinline__ void lm_pre_step_checks(LmDev& D, bool successful) {
+  if (D.core.iteration >= D.tol.max_num_iterations) lm_terminate(D, 1 /*NO_CONVERGENCE*/, 5, (double)D.core.iteration);
+  else if (successful && D.core.gmax <= D.tol.gradient_tolerance) lm_terminate(D, 0 /*CONVERGENCE*/, 3, D.core.gmax);
+  else if (D.core.radius <= D.tol.min_radius) lm_terminate(D, 0, 4, D.core.radius);
+}
+// The CG of this sequence has not stopped: it goes on in the next sequence if the refresh launches line up (a multiple of the
+// refresh period has been completed), otherwise the host has to enqueue the continuation.
+__device__ __forceinline__ void lm_cg_unfinished(const DeviceGraph& g) {
+  LmDev& D = *g.lm;
+  const int completed = g.cg->cnt_b;
+  if (D.cg_period <= 0 || completed % D.cg_period == 0) {
+    D.phase = LM_PHASE_CONT;
+  } else {
+    D.halt = LM_HALT_CG_STALL;
+    g.cg->done = 2;            // the CG kernels of the sequences already enqueued exit
+  }
+  D.accepted = 0;
+  lm_mirror(g);
+}
+__device__ __forceinline__ void lm_device_decide(const DeviceGraph& g, double cand_cost, double model_change, double step_norm_sq,
+                                                 double x_norm_sq, int bad, int direct) {
+  LmDev& D = *g.lm;
+  const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+  D.ticks_linear += now - D.t_mark;
+  D.t_mark = now;
+  D.accepted = 0;
+  D.phase = LM_PHASE_NEW;
+  if (bad & 4) {               // an in-kernel wait of a single-launch factorisation ran out: not a numerical event, the host repeats
+    D.halt = LM_HALT_REFACTOR; //   this iteration with the factorisation in its launch-per-step form
+    lm_mirror(g);
+    return;
+  }
+  const LmStepIn in{cand_cost, model_change, step_norm_sq, x_norm_sq, direct ? 0 : g.cg->iters, direct ? 0 : g.cg->status, bad, 0};
+  LmRecord nx;
+  double tv = 0.0;
+  const LmOutcome out = lm_decide(D.core, D.tol, in, nx, tv);
+  D.lm_done += 1;
+  D.num_linear_iterations += in.cg_iterations;
+  D.last_cg = in.cg_iterations;
+  bool record = true;
+  switch (out) {
+    case LM_OUT_INVALID_FAIL: lm_terminate(D, 2 /*FAILURE*/, 6, 0.0); record = false; break;
+    case LM_OUT_PARAM_TOL: lm_terminate(D, 0, 2, tv); record = false; break;
+    case LM_OUT_FUNC_TOL: lm_terminate(D, 0, 1, tv); record = false; break;
+    case LM_OUT_ACCEPT: D.num_successful += 1; D.accepted = 1; break;
+    default: D.num_unsuccessful += 1; break;
+  }
+  if (record) {
+    g.scal->ring[nx.iteration % LM_RING] = nx;
+    D.num_records = nx.iteration + 1;
+    if (out != LM_OUT_ACCEPT) lm_pre_step_checks(D, false);   // behind an accepted step the accept-finish kernel runs them (it has the gradient)
+  }
+  lm_mirror(g);
+}
+
 // Fused step tail (one launch instead of k_model_delta + k_cost + k_finalize_scalars; every kernel boundary costs ~4 us
 // at pose-graph sizes).  The candidate poses were written by the preceding k_spmv<1> launch (diagonal lanes).  Pose
 // part = model cost change and step / state norms; edge part = candidate cost; the LAST workgroup to finish (ticket
@@ -1274,8 +1357,9 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_step_tail(DeviceGraph g, int gat
   __shared__ double scratch[4 * (EDGE_BLOCK / 64)];
   __shared__ int is_last;
   const int tid = threadIdx.x;
-  if (gate && !g.cg->done) {   // CG still running: only hand the (unfinished) status over to the host
-    if (blockIdx.x == 0 && tid == 0) publish_sequence(g);
+  if (lm_halted(g)) return;    // device-resident LM: a sequence enqueued ahead of a halt
+  if ((gate & 1) && !g.cg->done) {   // CG still running: only hand the (unfinished) status over to the host
+    if (blockIdx.x == 0 && tid == 0) { if (g.lm) lm_cg_unfinished(g); else publish_sequence(g); }
     return;
   }
   double acc[4] = {0.0, 0.0, 0.0, 0.0};   // candidate cost, model change, |step|^2, |x|^2
@@ -1354,12 +1438,91 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_step_tail(DeviceGraph g, int gat
     g.scal->step_norm_sq = s[2];
     g.scal->x_norm_sq = s[3];
     g.scal->gradient_max = t;
-    g.scal->linearize_bad = g.flags[1] | (g.flags[2] << 1);
+    const int bad = g.flags[1] | (g.flags[2] << 1);
+    g.scal->linearize_bad = bad;
     g.flags[1] = 0;
     g.flags[2] = 0;
     g.flags[3] = 0;
-    publish_sequence(g);
+    if (g.lm) lm_device_decide(g, s[0], s[1], s[2], s[3], bad, (gate & 2) ? 1 : 0);   // accept / reject / stop, on the spot
+    else publish_sequence(g);
   }
+}
+
+// Device-resident LM: last kernel of a sequence.  Behind an accepted step: candidate -> current point (the linearisation that ran
+// before it read the candidate buffer), gradient_max_norm = |x - Plus(x, -g)|_inf of the new point (k_gradient_norm's job), and the
+// last work-group to finish applies the tests that open the next pass (maximum iterations, gradient tolerance, minimum radius).
+// Whatever happened, ONE lane tells the host that sequence `seq_id` is through.
+__global__ __launch_bounds__(256) void k_accept_finish(DeviceGraph g, int seq_id) {
+  __shared__ double scratch[8];
+  __shared__ int is_last;
+  const int tid = threadIdx.x;
+  LmDev& D = *g.lm;
+  if (D.halt || !D.accepted) {
+    if (blockIdx.x == 0 && tid == 0) {
+      __threadfence_system();
+      __hip_atomic_store(&g.scal->seq_done, seq_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  const int v = blockIdx.x * blockDim.x + tid;
+  double m = 0.0;
+  if (v < g.N) {
+    const PoseRec P = load_pose(g.pose_c, v);
+    const double2* src = reinterpret_cast<const double2*>(g.pose_c + (size_t)POSE_STRIDE * v);
+    double2* dst = reinterpret_cast<double2*>(g.pose_x + (size_t)POSE_STRIDE * v);
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    const uint8_t cm = g.cmask[v];
+    const double* gr = g.grad + 6 * (size_t)v;
+    if (!(cm & 1)) m = fmax(m, fmax(fabs(gr[0]), fmax(fabs(gr[1]), fabs(gr[2]))));
+    if (!(cm & 2)) {
+      const Q4 q = quat_plus(P.q, V3{-gr[3], -gr[4], -gr[5]});
+      m = fmax(m, fmax(fmax(fabs(P.q.x - q.x), fabs(P.q.y - q.y)), fmax(fabs(P.q.z - q.z), fabs(P.q.w - q.w))));
+    }
+  }
+  m = wave_max(m);
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane == 0) scratch[wave] = m;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) t = fmax(t, scratch[w]);
+    g.part_misc[4 * (size_t)g.n_part + blockIdx.x] = t;
+    __threadfence();
+    is_last = (atomicAdd(&g.flags[3], 1) == (int)gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  double mm = 0.0;
+  for (int i = tid; i < (int)gridDim.x; i += blockDim.x)
+    mm = fmax(mm, __hip_atomic_load(&g.part_misc[4 * (size_t)g.n_part + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  mm = wave_max(mm);
+  if (lane == 0) scratch[wave] = mm;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) t = fmax(t, scratch[w]);
+    g.flags[3] = 0;
+    D.core.gmax = t;
+    g.scal->ring[D.core.iteration % LM_RING].gradient_max_norm = t;
+    g.scal->gradient_max = t;
+    lm_pre_step_checks(D, true);
+    const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+    D.ticks_jacobian += now - D.t_mark;
+    D.t_mark = now;
+    lm_mirror(g);
+    __hip_atomic_store(&g.scal->seq_done, seq_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// Device-resident LM: the host steps in behind a halt that is not a termination (LM_HALT_CG_STALL: it enqueues the rest of the
+// CG itself; LM_HALT_REFACTOR: it repeats the factorisation in another form) and lets the sequences run again.
+__global__ void k_lm_resume(DeviceGraph g, int cg_goes_on) {
+  LmDev& D = *g.lm;
+  D.halt = LM_RUN;
+  D.phase = cg_goes_on ? LM_PHASE_CONT : LM_PHASE_NEW;
+  if (cg_goes_on) g.cg->done = 0;
+  g.scal->halt = 0;
 }
 
 
@@ -1573,6 +1736,12 @@ void launch_model_delta_and_retract(const DeviceGraph& g, hipStream_t s, int gat
 }
 void launch_gradient_norm(const DeviceGraph& g, hipStream_t s) {
   hipLaunchKernelGGL(k_gradient_norm, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g);
+}
+void launch_accept_finish(const DeviceGraph& g, int seq_id, hipStream_t s) {
+  hipLaunchKernelGGL(k_accept_finish, dim3(g.n_pose_wg), dim3(POSE_BLOCK), 0, s, g, seq_id);
+}
+void launch_lm_resume(const DeviceGraph& g, int cg_goes_on, hipStream_t s) {
+  hipLaunchKernelGGL(k_lm_resume, dim3(1), dim3(1), 0, s, g, cg_goes_on);
 }
 void launch_finalize_scalars(const DeviceGraph& g, int n_cost_part, hipStream_t s, int gate) {
   hipLaunchKernelGGL(k_finalize_scalars, dim3(1), dim3(256), 0, s, g, n_cost_part, gate);

@@ -10,6 +10,7 @@
 // them and takes the accept/reject decisions from scalars the device reduces.
 #include "../../include/pgo.h"
 #include "pgo_kernels.h"
+#include "pgo_lm_rules.h"
 #include "pgo_direct.h"
 #include "pgo_front.h"
 #include "pgo_comm.h"
@@ -55,6 +56,7 @@ int set_error(int code, const char* fmt, ...) {
                        __FILE__, __LINE__);                                                   \
   } while (0)
 
+static_assert(sizeof(pgo::LmRecord) == sizeof(pgo_iteration_record), "LmRecord mirrors pgo_iteration_record");
 typedef std::chrono::steady_clock Clock;
 inline double seconds_since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
 
@@ -345,6 +347,15 @@ struct pgo_problem {
   bool spec_ready = false;
   pgo::LmScalars* scal = nullptr;  // pinned, device visible
   size_t scal_cap = 0;
+  // device-resident LM (pgo_kernels.h LmDev): the trust-region decisions are taken on the device and the host enqueues the
+  // kernel sequences of the next iterations ahead of them (one rank, eager enqueue; PGO_NO_PIPELINE=1 keeps the host in the loop)
+  DevBuf<pgo::LmDev> d_lm;
+  bool pipelined = false;
+  int pipe_seq = 0;                // id of the last sequence enqueued (LmScalars::seq_done catches up with it)
+  int pipe_last_nb = 0;            // CG iterations in the last sequence enqueued
+  int pipe_pulled = 0;             // next iteration record to copy from the pinned ring into LmState::records
+  bool pipe_dirty = true;          // LmState was (re)initialised by the host: upload it before the next sequence
+  double pipe_t_linear0 = 0, pipe_t_jacobian0 = 0;   // LmState times when the device clocks were last zeroed
   // captured CG batches, keyed by the number of iterations in the batch
   struct CapturedBatch { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
   std::unordered_map<int, CapturedBatch> cg_graphs;
@@ -492,26 +503,27 @@ int damping_all(pgo_problem* P, double radius, double min_diag, double max_diag,
 // one CG iteration: SpMV on the owned rows, exchange of q (+ p'q partials), replicated vector update
 // `refresh`: this is a residual_reset_period-th iteration — r is recomputed as b - A x (Ceres conjugate_gradients_solver.cc)
 // instead of updated: x-only update, A x into the exchange buffer, then r / z / partial sums.
-int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd, bool refresh) {
-  pgo::launch_pcg_spmv_only(P->g, prm, odd, P->stream);
-  int rc = exchange(P, P->g.cg_q, (size_t)P->g.seg);
+int cg_iteration(pgo_problem* P, const pgo::DeviceGraph& g, const pgo::CgParams& prm, int odd, bool refresh) {
+  pgo::launch_pcg_spmv_only(g, prm, odd, P->stream);
+  int rc = exchange(P, g.cg_q, (size_t)g.seg);
   if (rc) return rc;
   if (!refresh) {
-    pgo::launch_pcg_update_only(P->g, odd, P->stream);
+    pgo::launch_pcg_update_only(g, odd, P->stream);
     return PGO_OK;
   }
-  if (P->g.world == 1) {   // x = x_old + alpha p formed on the fly by the SpMV, one combined vector launch
-    pgo::launch_spmv_refresh(P->g, P->stream, 1, odd);
-    pgo::launch_pcg_update_only(P->g, odd, P->stream, 3);
+  if (g.world == 1) {   // x = x_old + alpha p formed on the fly by the SpMV, one combined vector launch
+    pgo::launch_spmv_refresh(g, P->stream, 1, odd);
+    pgo::launch_pcg_update_only(g, odd, P->stream, 3);
     return PGO_OK;
   }
-  pgo::launch_pcg_update_only(P->g, odd, P->stream, 1);
-  pgo::launch_spmv_refresh(P->g, P->stream);
-  rc = exchange(P, P->g.cg_q, (size_t)P->g.seg);
+  pgo::launch_pcg_update_only(g, odd, P->stream, 1);
+  pgo::launch_spmv_refresh(g, P->stream);
+  rc = exchange(P, g.cg_q, (size_t)g.seg);
   if (rc) return rc;
-  pgo::launch_pcg_update_only(P->g, odd, P->stream, 2);
+  pgo::launch_pcg_update_only(g, odd, P->stream, 2);
   return PGO_OK;
 }
+int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd, bool refresh) { return cg_iteration(P, P->g, prm, odd, refresh); }
 
 // Splits [0, n) into contiguous ranges over the host worker pool (topology build of large graphs; nothing on the LM path).
 template <class F>
@@ -1268,7 +1280,7 @@ int prepare_direct(pgo_problem* P) {
 }
 
 // the multifrontal factorisation: all stages in one launch (pgo_front.h FrontStages), or one launch per phase of a round
-void enqueue_front_factor(pgo_problem* P) {
+void enqueue_front_factor(pgo_problem* P, const pgo::DeviceGraph& G) {
   hipStream_t s = P->stream;
   if (!P->front_launches) {
     const char* sp_env = getenv("PGO_FRONT_SPINS");
@@ -1278,7 +1290,7 @@ void enqueue_front_factor(pgo_problem* P) {
     const pgo::FrontStages fs{++P->front_epoch, P->front_tickets, n_tickets, (int)P->fsym.st_need.size(), sp_env ? atoi(sp_env) : (1 << 20),
                               want_stamps ? P->ds_stamps.p : nullptr};
     P->front_tickets += (unsigned long long)n_tickets;
-    pgo::launch_front_factor(P->g, P->fplan, P->fsym, s, nullptr, &fs);
+    pgo::launch_front_factor(G, P->fplan, P->fsym, s, nullptr, &fs);
     if (want_stamps && P->front_epoch == 3) {      // development aid: the chain of stages that ends last, from the last stage back
       (void)hipStreamSynchronize(s);
       const pgo::FrontSymbolic& S = P->fsym;
@@ -1307,12 +1319,13 @@ void enqueue_front_factor(pgo_problem* P) {
       }
     }
   } else {
-    pgo::launch_front_factor(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr);
+    pgo::launch_front_factor(G, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr);
   }
 }
 
 // factorise (H~ + D^2) and solve for cg_x = (H~ + D^2)^-1 S g; the launch sequence is static -> one hipGraph
-int run_direct(pgo_problem* P) {
+// G: P->g, or its copy that carries the device-resident LM state (the kernels then gate themselves on its halt word)
+int run_direct(pgo_problem* P, const pgo::DeviceGraph& G) {
   hipStream_t s = P->stream;
   if (P->sfront_usable) {
     if (!P->sfront_levels) {
@@ -1329,7 +1342,7 @@ int run_direct(pgo_problem* P) {
       const pgo::SFrontSync sy{P->ds_done.p, P->sfront_tickets, P->sfront_epoch, max_spins, want_stamps ? P->ds_stamps.p : nullptr};
       const pgo::SFrontSync sy_bwd{P->ds_done.p + P->fsym.nf + 1, P->sfront_tickets, P->sfront_epoch, max_spins, nullptr};
       P->sfront_tickets += (unsigned)P->fsym.nf;
-      pgo::launch_sfront_factor(P->g, P->fplan, P->splan, P->fsym, s, &sy);
+      pgo::launch_sfront_factor(G, P->fplan, P->splan, P->fsym, s, &sy);
       if (want_stamps && P->sfront_epoch == 3) {      // development aid: the critical path of the third factorisation, from the root down
         HIP_TRY(hipStreamSynchronize(s));
         std::vector<long long> st(6 * (size_t)P->fsym.nf);
@@ -1352,24 +1365,24 @@ int run_direct(pgo_problem* P) {
       // The backward substitution stays one launch per level: in its single-launch form (PGO_SFRONT_FUSED_BWD=1) every front of
       // the tree polls its parent's flag at once and the ten hand-overs take 88 us against 50 us for the ten launches (KITTI-00).
       static const bool fused_bwd = getenv("PGO_SFRONT_FUSED_BWD") && getenv("PGO_SFRONT_FUSED_BWD")[0] == '1';
-      pgo::launch_sfront_solve(P->g, P->fplan, P->splan, P->fsym, s, fused_bwd ? &sy_bwd : nullptr);
+      pgo::launch_sfront_solve(G, P->fplan, P->splan, P->fsym, s, fused_bwd ? &sy_bwd : nullptr);
     } else {
-      pgo::launch_sfront_factor(P->g, P->fplan, P->splan, P->fsym, s);
-      pgo::launch_sfront_solve(P->g, P->fplan, P->splan, P->fsym, s);
+      pgo::launch_sfront_factor(G, P->fplan, P->splan, P->fsym, s);
+      pgo::launch_sfront_solve(G, P->fplan, P->splan, P->fsym, s);
     }
     return PGO_OK;
   }
   if (P->front_usable) {
-    enqueue_front_factor(P);
-    pgo::launch_front_solve(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr);
+    enqueue_front_factor(P, G);
+    pgo::launch_front_solve(G, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr);
     return PGO_OK;
   }
   const pgo::DirectSymbolic& S = P->dsym;
   if (P->use_graph && !P->direct_exec) {
     hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
-      pgo::launch_direct_factor(P->g, P->dplan, S, s);
-      pgo::launch_direct_solve(P->g, P->dplan, S.level_ptr.data(), S.fused_from_level, s);
+      pgo::launch_direct_factor(G, P->dplan, S, s);
+      pgo::launch_direct_solve(G, P->dplan, S.level_ptr.data(), S.fused_from_level, s);
       e = hipStreamEndCapture(s, &P->direct_graph);
       if (e == hipSuccess) e = hipGraphInstantiate(&P->direct_exec, P->direct_graph, nullptr, nullptr, 0);
     }
@@ -1379,11 +1392,12 @@ int run_direct(pgo_problem* P) {
     HIP_TRY(hipGraphLaunch(P->direct_exec, s));
   } else {
     if (++P->direct_epoch == 0x7fffffff) { P->direct_epoch = 1; HIP_TRY(P->dd_col_flag.zero(s)); }
-    pgo::launch_direct_factor(P->g, P->dplan, S, s, P->split_two_launch ? 0 : P->direct_epoch);
-    pgo::launch_direct_solve(P->g, P->dplan, S.level_ptr.data(), S.fused_from_level, s);
+    pgo::launch_direct_factor(G, P->dplan, S, s, P->split_two_launch ? 0 : P->direct_epoch);
+    pgo::launch_direct_solve(G, P->dplan, S.level_ptr.data(), S.fused_from_level, s);
   }
   return PGO_OK;
 }
+int run_direct(pgo_problem* P) { return run_direct(P, P->g); }
 
 pgo::CgParams cg_params_for(const pgo_solver_options& o) {
   pgo::CgParams prm;
@@ -1427,6 +1441,7 @@ int evaluate_gradient_and_jacobian(pgo_problem* P, bool first) {
   return PGO_OK;
 }
 
+bool pipeline_wanted(const pgo_problem* P);
 int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   P->want_direct = options->linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY;
   int rc = prepare(P);
@@ -1487,6 +1502,8 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   L.cur.gradient_max_norm = L.gmax;
   L.pending_record = true;
   L.active = true;
+  P->pipelined = pipeline_wanted(P);
+  P->pipe_dirty = true;
   L.t_total += seconds_since(t0);
   if (!std::isfinite(L.x_cost)) {
     L.terminated = true; L.termination = PGO_FAILURE; L.reason = 7;
@@ -1574,17 +1591,30 @@ bool lm_pre_step(LmState& L, const pgo_solver_options& o) {
   return true;
 }
 
-// Everything after the trial step came back: deferred gradient test, step validity, parameter / function tolerance,
-// IsStepSuccessful, radius update.  STEP_ACCEPT: the caller makes the candidate the current point and re-linearises.
+// Everything after the trial step came back: deferred gradient test, then the rules of pgo_lm_rules.h (step validity,
+// parameter / function tolerance, IsStepSuccessful, radius update) — the very function the device applies when it decides
+// itself.  STEP_ACCEPT: the caller makes the candidate the current point and re-linearises.
+pgo::LmTolerances lm_tolerances(const pgo_solver_options& o) {
+  return pgo::LmTolerances{o.min_relative_decrease, o.function_tolerance, o.parameter_tolerance, o.gradient_tolerance,
+                           o.max_trust_region_radius, o.min_trust_region_radius, o.max_num_iterations, o.max_num_consecutive_invalid_steps};
+}
+inline pgo_iteration_record to_record(const pgo::LmRecord& r) { pgo_iteration_record o; memcpy(&o, &r, sizeof o); return o; }
+void terminate_by_reason(LmState& L, const pgo_solver_options& o, int termination, int reason, double value) {
+  switch (reason) {
+    case 1: terminate(L, termination, 1, "Function tolerance reached. |cost_change|/cost: %e <= %e", value, o.function_tolerance); break;
+    case 2: terminate(L, termination, 2, "Parameter tolerance reached. Relative step_norm: %e <= %e.", value, o.parameter_tolerance); break;
+    case 3: terminate(L, termination, 3, "Gradient tolerance reached. Gradient max norm: %e <= %e", value, o.gradient_tolerance); break;
+    case 4: terminate(L, termination, 4, "Minimum trust region radius reached. Trust region radius: %e <= %e", value, o.min_trust_region_radius); break;
+    case 5: terminate(L, termination, 5, "Maximum number of iterations reached. Number of iterations: %d.", (int)value); break;
+    case 6: terminate(L, termination, 6, "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d",
+                      o.max_num_consecutive_invalid_steps); break;
+    default: terminate(L, termination, reason, "Terminated (reason %d).", reason); break;
+  }
+}
 StepAction lm_post_step(LmState& L, const pgo_solver_options& o, const StepScalars& sc, int extra_linear_iterations) {
-  pgo_iteration_record nx{};
-  nx.iteration = L.cur.iteration + 1;
   ++L.num_trial_steps;
-  const int cg_it = sc.cg_iterations, cg_status = sc.cg_status;
-  L.reuse_diagonal = true;
+  const int cg_it = sc.cg_iterations;
   L.num_linear_iterations += cg_it + extra_linear_iterations;   // the iterations of an over-budget PCG try are work done, counted in the summary
-  nx.linear_solver_iterations = cg_it;
-
   if (L.gmax_deferred) {
     // the gradient test of FinalizeIterationAndCheckIfMinimizerCanContinue for the point accepted last
     // iteration: if it fires, the step just computed is discarded (x was not touched)
@@ -1594,77 +1624,40 @@ StepAction lm_post_step(LmState& L, const pgo_solver_options& o, const StepScala
     if (!L.records.empty()) L.records.back().gradient_max_norm = L.gmax;
     if (L.gmax <= o.gradient_tolerance) {
       L.num_linear_iterations -= cg_it;
-      terminate(L, PGO_CONVERGENCE, 3, "Gradient tolerance reached. Gradient max norm: %e <= %e", L.gmax, o.gradient_tolerance);
+      L.reuse_diagonal = true;
+      terminate_by_reason(L, o, PGO_CONVERGENCE, 3, L.gmax);
       return STEP_NONE;
     }
   }
-  nx.gradient_max_norm = L.cur.gradient_max_norm;
-  const bool lin_ok = (cg_status != 2) && std::isfinite(sc.model_change) && !sc.linearize_bad;
-  const double model_cost_change = sc.model_change;
-  const bool step_valid = lin_ok && model_cost_change > 0.0;
-
-  if (!step_valid) {
-    // HandleInvalidStep
-    ++L.num_consecutive_invalid;
-    if (L.num_consecutive_invalid >= o.max_num_consecutive_invalid_steps) {
-      terminate(L, PGO_FAILURE, 6, "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d",
-                o.max_num_consecutive_invalid_steps);
-      L.cur = nx;
+  pgo::LmCore C{L.radius, L.decrease_factor, L.x_cost, L.x_norm, L.cur.gradient_max_norm, L.cur.iteration, L.reuse_diagonal ? 1 : 0,
+                L.num_consecutive_invalid, 0};
+  const pgo::LmStepIn in{sc.cand_cost, sc.model_change, sc.step_norm_sq, sc.x_norm_sq, cg_it, sc.cg_status, sc.linearize_bad, 0};
+  pgo::LmRecord nx{};
+  double value = 0.0;
+  const pgo::LmOutcome out = pgo::lm_decide(C, lm_tolerances(o), in, nx, value);
+  L.radius = C.radius; L.decrease_factor = C.decrease_factor; L.x_cost = C.x_cost; L.x_norm = C.x_norm;
+  L.reuse_diagonal = C.reuse_diagonal != 0; L.num_consecutive_invalid = C.num_consecutive_invalid;
+  switch (out) {
+    case pgo::LM_OUT_INVALID_FAIL:
+      terminate_by_reason(L, o, PGO_FAILURE, 6, 0.0);
+      L.cur = to_record(nx);
       return STEP_NONE;
-    }
-    L.radius *= 0.5;
-    L.reuse_diagonal = true;
-    nx.cost = L.x_cost;
-    nx.step_is_successful = 0;
-    L.cur = nx;
-    L.pending_record = true;
-    return STEP_NONE;
+    case pgo::LM_OUT_INVALID:
+      L.cur = to_record(nx);
+      L.pending_record = true;
+      return STEP_NONE;
+    case pgo::LM_OUT_PARAM_TOL: terminate_by_reason(L, o, PGO_CONVERGENCE, 2, value); return STEP_NONE;
+    case pgo::LM_OUT_FUNC_TOL: terminate_by_reason(L, o, PGO_CONVERGENCE, 1, value); return STEP_NONE;
+    case pgo::LM_OUT_ACCEPT:
+      L.gmax_deferred = true;  // filled in at the next host sync (or at the end of the solve)
+      L.cur = to_record(nx);
+      L.pending_record = true;
+      return STEP_ACCEPT;
+    default:
+      L.cur = to_record(nx);
+      L.pending_record = true;
+      return STEP_REJECT;
   }
-  L.num_consecutive_invalid = 0;
-
-  // ParameterToleranceReached
-  nx.step_norm = std::sqrt(sc.step_norm_sq);
-  L.x_norm = std::sqrt(sc.x_norm_sq);
-  const double step_size_tolerance = o.parameter_tolerance * (L.x_norm + o.parameter_tolerance);
-  if (nx.step_norm <= step_size_tolerance) {
-    terminate(L, PGO_CONVERGENCE, 2, "Parameter tolerance reached. Relative step_norm: %e <= %e.",
-              nx.step_norm / (L.x_norm + o.parameter_tolerance), o.parameter_tolerance);
-    return STEP_NONE;
-  }
-  // FunctionToleranceReached
-  const double cand_cost = sc.cand_cost;
-  nx.cost_change = L.x_cost - cand_cost;
-  if (std::fabs(nx.cost_change) <= o.function_tolerance * L.x_cost) {
-    terminate(L, PGO_CONVERGENCE, 1, "Function tolerance reached. |cost_change|/cost: %e <= %e",
-              std::fabs(nx.cost_change) / L.x_cost, o.function_tolerance);
-    return STEP_NONE;
-  }
-  // IsStepSuccessful
-  nx.relative_decrease = nx.cost_change / model_cost_change;
-  StepAction action;
-  if (nx.relative_decrease > o.min_relative_decrease) {
-    // HandleSuccessfulStep (host half): LevenbergMarquardtStrategy::StepAccepted
-    L.x_cost = cand_cost;
-    L.gmax_deferred = true;  // filled in at the next host sync (or at the end of the solve)
-    nx.step_is_successful = 1;
-    nx.cost = L.x_cost;
-    L.radius = L.radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * nx.relative_decrease - 1.0, 3));
-    L.radius = std::min(o.max_trust_region_radius, L.radius);
-    L.decrease_factor = 2.0;
-    L.reuse_diagonal = false;
-    action = STEP_ACCEPT;
-  } else {
-    // HandleUnsuccessfulStep / StepRejected
-    nx.step_is_successful = 0;
-    nx.cost = cand_cost;
-    L.radius = L.radius / L.decrease_factor;
-    L.decrease_factor *= 2.0;
-    L.reuse_diagonal = true;
-    action = STEP_REJECT;
-  }
-  L.cur = nx;
-  L.pending_record = true;
-  return action;
 }
 
 // One pass of the TrustRegionMinimizer loop body (SURVEY.md A.6 step 7 order).
@@ -1789,6 +1782,244 @@ int lm_advance(pgo_problem* P) {
     }
   }
   L.t_total += seconds_since(t_it);
+  return PGO_OK;
+}
+
+// ---- device-resident LM: the host enqueues sequences ahead of the decisions (pgo_kernels.h LmDev) -----------------------------
+// r02 ended every LM iteration in a hand-off: the device folded the step scalars, the host decided accept / reject, updated the
+// radius and enqueued the next iteration, the GPU idle meanwhile (13 us on the development box, ~60 us on the driver's: 16 % of
+// the Manhattan 10 k step; half of a KITTI-00 iteration was not GPU work).  Now the last work-group of the step tail applies the
+// rules of pgo_lm_rules.h itself, the kernels read radius / reuse-diagonal / "was the step accepted" from device memory, and the
+// host's only job is to keep the stream fed: it enqueues the sequence of the NEXT iteration while the current one runs, and reads
+// the iteration records afterwards.  What it cannot know when it enqueues — whether the CG will be through within the batch it
+// allots, whether the step will be accepted, whether the solve ends — the kernels find out for themselves (LmDev::phase /
+// accepted / halt): a wrong guess costs early-exit launches (~2.6 us each), never a wrong result.
+bool pipeline_wanted(const pgo_problem* P) {
+  const bool off = getenv("PGO_NO_PIPELINE") && getenv("PGO_NO_PIPELINE")[0] == '1';   // (read per solve: the tests compare both drivers in one process)
+  if (off || P->g.world != 1 || (P->comm && P->comm->world > 1) || P->use_graph) return false;
+  const bool direct = P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY && P->direct_usable;
+  if (direct && P->dsym.hybrid && !P->front_usable && !P->sfront_usable) return false;   // factorisation or PCG chosen per iteration by the host
+  return true;
+}
+
+// host LmState -> device (begin / reset; the stream is idle or the copy is ordered behind what is in flight)
+int lm_upload_state(pgo_problem* P) {
+  LmState& L = P->lm;
+  const pgo_solver_options& o = P->opt;
+  if (P->d_lm.n == 0) HIP_TRY(P->d_lm.alloc(1));
+  pgo::LmDev D{};
+  D.halt = pgo::LM_RUN; D.phase = pgo::LM_PHASE_NEW; D.accepted = 0;
+  D.lm_done = 0;
+  D.num_successful = L.num_successful; D.num_unsuccessful = L.num_unsuccessful; D.num_linear_iterations = L.num_linear_iterations;
+  D.num_records = L.cur.iteration + 1;       // record index = iteration number (the ring slot of record r is r % LM_RING)
+  P->pipe_pulled = L.cur.iteration + 1;
+  const pgo::CgParams prm = cg_params_for(o);
+  D.cg_period = prm.q_tolerance < 0.0 ? 0 : o.cg_residual_reset_period;   // (launch_cg_batch: an exact request served by PCG never refreshes)
+  D.last_cg = P->last_cg_iterations;
+  D.core = pgo::LmCore{L.radius, L.decrease_factor, L.x_cost, L.x_norm, L.gmax, L.cur.iteration, L.reuse_diagonal ? 1 : 0, L.num_consecutive_invalid, 0};
+  D.tol = lm_tolerances(o);
+  D.min_diag = o.min_lm_diagonal; D.max_diag = o.max_lm_diagonal;
+  HIP_TRY(hipStreamSynchronize(P->stream));      // nobody writes the pinned block while the host fills it
+  P->scal->lm = D;
+  P->scal->lm_done = 0; P->scal->halt = 0; P->scal->last_cg = D.last_cg;
+  P->scal->seq_done = P->pipe_seq;
+  HIP_TRY(hipMemcpyAsync(P->d_lm.p, &P->scal->lm, sizeof(pgo::LmDev), hipMemcpyHostToDevice, P->stream));
+  HIP_TRY(hipStreamSynchronize(P->stream));      // (the pinned source doubles as the mirror the device writes)
+  P->pipe_t_linear0 = L.t_linear; P->pipe_t_jacobian0 = L.t_jacobian;
+  return PGO_OK;
+}
+
+// records the device has finished with -> LmState (a record is final once a later one exists, or once everything has drained)
+void lm_pull_records(pgo_problem* P, bool drained) {
+  LmState& L = P->lm;
+  const int have = __atomic_load_n(&P->scal->lm.num_records, __ATOMIC_ACQUIRE);
+  const int upto = drained ? have : have - 1;
+  for (; P->pipe_pulled < upto; ++P->pipe_pulled) L.records.push_back(to_record(P->scal->ring[P->pipe_pulled % pgo::LM_RING]));
+}
+
+// device -> host LmState, everything drained
+void lm_pull_state(pgo_problem* P) {
+  LmState& L = P->lm;
+  lm_pull_records(P, true);
+  const pgo::LmDev& M = P->scal->lm;
+  L.radius = M.core.radius; L.decrease_factor = M.core.decrease_factor; L.x_cost = M.core.x_cost; L.x_norm = M.core.x_norm;
+  L.gmax = M.core.gmax; L.reuse_diagonal = M.core.reuse_diagonal != 0; L.num_consecutive_invalid = M.core.num_consecutive_invalid;
+  L.num_successful = M.num_successful; L.num_unsuccessful = M.num_unsuccessful; L.num_linear_iterations = M.num_linear_iterations;
+  if (!L.records.empty()) L.cur = L.records.back();
+  L.cur.iteration = M.core.iteration;
+  L.pending_record = false;
+  L.gmax_deferred = false;
+  L.t_linear = P->pipe_t_linear0 + 1e-8 * (double)M.ticks_linear;       // s_memrealtime: 100 MHz
+  L.t_jacobian = P->pipe_t_jacobian0 + 1e-8 * (double)M.ticks_jacobian;
+  P->last_cg_iterations = M.last_cg;
+}
+
+// the in-kernel counters of the single-launch factorisations no longer match the host's after launches that exited at a halt
+int resync_direct_counters(pgo_problem* P) {
+  hipStream_t s = P->stream;
+  if (P->front_usable && P->df_st_count.n) { HIP_TRY(P->df_st_count.zero(s)); P->front_epoch = 0; P->front_tickets = 0; }
+  if (P->sfront_usable && P->ds_done.n) { HIP_TRY(P->ds_done.zero(s)); P->sfront_epoch = 0; P->sfront_tickets = 0; }
+  if (P->dd_col_flag.n) { HIP_TRY(P->dd_col_flag.zero(s)); P->direct_epoch = 0; }
+  return PGO_OK;
+}
+
+// CG iterations allotted to a sequence.  The CG stops by itself; an iteration enqueued past its end costs two early-exit
+// launches (~5 us), a CG that outlives its sequence goes on in the next one at the price of that sequence's skipped head and
+// gated tail (~18 us) — provided a multiple of the refresh period has been completed (the refresh launches sit at fixed
+// positions), else the host steps in (~60 us).  Short CGs (the steady state of an LM run: 3-6 iterations) get the last count
+// + 2; long ones a multiple of the period.  cont_streak: sequences that just ended without a decision.
+int pipe_pick_batch(const pgo_problem* P, const pgo::CgParams& prm, int period, int pred, int cont_streak) {
+  int nb;
+  if (P->opt.cg_batch > 0) nb = P->opt.cg_batch;
+  else {
+    if (pred <= 0) pred = 6;
+    if (pred <= 7 && cont_streak == 0) nb = pred + 2;
+    else {
+      const int want = std::max(pred + pred / 4 + 1, 8) << std::min(cont_streak, 3);
+      nb = period > 0 ? (want + period - 1) / period * period : want;
+      nb = std::min(nb, period > 0 ? std::max(period, 60 / period * period) : 64);
+    }
+  }
+  nb = std::max(1, std::min(nb, prm.max_iterations));
+  return (nb + 1) & ~1;
+}
+
+// one sequence: the kernels of one prospective LM iteration (or the continuation of the previous one's CG)
+int enqueue_sequence(pgo_problem* P, const pgo::DeviceGraph& gp, const pgo::DeviceGraph& gl, const pgo::CgParams& prm, bool direct, int nb,
+                     int start_it, bool head) {
+  hipStream_t s = P->stream;
+  const pgo_solver_options& o = P->opt;
+  if (head) pgo::launch_damping(gp, 1.0, o.min_lm_diagonal, o.max_lm_diagonal, 0, s);   // radius and mode: LmDev
+  if (direct) {
+    int rc = run_direct(P, gp);
+    if (rc) return rc;
+    const pgo::CgParams none{0.0, -1.0, 0, 0};
+    pgo::launch_spmv_tail(gp, none, s, 0, 1);
+    pgo::launch_step_tail(gp, s, 2);
+  } else {
+    if (head) pgo::launch_pcg_init(gp, s);
+    const int period = prm.q_tolerance < 0.0 ? 0 : o.cg_residual_reset_period;
+    for (int i = 0; i < nb; ++i) {
+      const bool refresh = period > 0 && ((start_it + i) % period) == 0;
+      int rc = cg_iteration(P, gp, prm, ((start_it + i) & 1), refresh);
+      if (rc) return rc;
+    }
+    pgo::launch_spmv_tail(gp, prm, s, 1, 1);
+    pgo::launch_step_tail(gp, s, 1);
+  }
+  pgo::launch_linearize(gl, s, 2);
+  pgo::launch_accept_finish(gp, ++P->pipe_seq, s);
+  P->pipe_last_nb = nb;
+  return PGO_OK;
+}
+
+// waits until every enqueued sequence is through (pinned counter; the stream synchronise is the fallback for long waits)
+int pipe_drain(pgo_problem* P) {
+  const auto t0 = Clock::now();
+  for (unsigned spins = 1; __atomic_load_n(&P->scal->seq_done, __ATOMIC_ACQUIRE) != P->pipe_seq; ++spins) {
+    __builtin_ia32_pause();
+    if ((spins & 0x3ff) == 0 && seconds_since(t0) > 0.002) {
+      HIP_TRY(hipStreamSynchronize(P->stream));
+      if (__atomic_load_n(&P->scal->seq_done, __ATOMIC_ACQUIRE) != P->pipe_seq)
+        return set_error(PGO_ERR_HIP, "the enqueued LM sequences did not report completion (%d of %d)", P->scal->seq_done, P->pipe_seq);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return PGO_OK;
+}
+
+// Runs up to `budget` LM iterations (decisions; < 0: until the solve terminates).  *ran = iterations executed.
+int lm_run_pipelined(pgo_problem* P, int budget, int* ran) {
+  LmState& L = P->lm;
+  const pgo_solver_options& o = P->opt;
+  if (ran) *ran = 0;
+  if (L.terminated || budget == 0) return PGO_OK;
+  const auto t_run = Clock::now();
+  // the opening tests of the first pass (they push the iteration-0 record; the device applies them from then on)
+  if (!lm_pre_step(L, o)) { L.t_total += seconds_since(t_run); return PGO_OK; }
+  if (P->pipe_dirty) {
+    int rc0 = lm_upload_state(P);
+    if (rc0) return rc0;
+    P->pipe_dirty = false;
+  }
+  static const int lookahead = getenv("PGO_PIPELINE_AHEAD") ? std::max(0, atoi(getenv("PGO_PIPELINE_AHEAD"))) : 1;
+  const bool direct = o.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY && P->direct_usable;
+  const pgo::CgParams prm = cg_params_for(o);
+  const int period = prm.q_tolerance < 0.0 ? 0 : o.cg_residual_reset_period;
+  pgo::DeviceGraph gp = P->g;
+  gp.lm = P->d_lm.p;
+  pgo::DeviceGraph gl = gp;
+  gl.pose_x = gp.pose_c;          // the linearisation of an accepted step reads the candidate buffer
+  const int d0 = __atomic_load_n(&P->scal->lm_done, __ATOMIC_ACQUIRE);
+  const long long target = budget < 0 ? (1LL << 40) : (long long)d0 + budget;
+  int cont_streak = 0, seen_seq = P->pipe_seq, seen_done = d0;
+  int rc = PGO_OK;
+  unsigned idle_spins = 0;
+  auto t_idle = Clock::now();
+  for (;;) {
+    // seq_done first: decisions of sequences counted as in flight may already be in lm_done, never the other way round
+    const int sdone = __atomic_load_n(&P->scal->seq_done, __ATOMIC_ACQUIRE);
+    const int d = __atomic_load_n(&P->scal->lm_done, __ATOMIC_ACQUIRE);
+    const int halt = __atomic_load_n(&P->scal->halt, __ATOMIC_ACQUIRE);
+    const int in_flight = P->pipe_seq - sdone;
+    if (sdone != seen_seq) {        // sequences that ended without a decision: their CG goes on
+      cont_streak = (d == seen_done) ? cont_streak + (sdone - seen_seq) : 0;
+      seen_seq = sdone; seen_done = d;
+      lm_pull_records(P, false);
+    }
+    if (halt) {
+      rc = pipe_drain(P);
+      if (rc) break;
+      const int h = P->scal->lm.halt;
+      if (h == pgo::LM_HALT_TERMINATED) break;
+      rc = resync_direct_counters(P);
+      if (rc) break;
+      P->scal->halt = 0;
+      seen_seq = P->pipe_seq; seen_done = __atomic_load_n(&P->scal->lm_done, __ATOMIC_ACQUIRE);
+      if (h == pgo::LM_HALT_CG_STALL) {
+        // the rest of this iteration's CG, from where it stands, up to the next multiple of the refresh period (from there the
+        // sequences line up again), then the tail
+        const int completed = P->scal->cg_iterations;
+        int nb = pipe_pick_batch(P, prm, period, std::max(P->pipe_last_nb, 8), 1);
+        if (period > 0) nb = ((completed + nb + period - 1) / period) * period - completed;
+        pgo::launch_lm_resume(gp, 1, P->stream);
+        rc = enqueue_sequence(P, gp, gl, prm, false, nb, completed + 1, false);
+        if (rc) break;
+        cont_streak = 1;
+        continue;
+      }
+      // LM_HALT_REFACTOR: a wait inside a single-launch factorisation ran out (its work-groups were not all resident): the
+      // iteration is repeated with one launch per step, and the problem keeps to that form
+      if (P->front_usable) P->front_launches = true; else if (P->sfront_usable) P->sfront_levels = true; else P->split_two_launch = true;
+      if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: an in-kernel wait of the single-launch factorisation timed out; one launch per step from now on\n");
+      pgo::launch_lm_resume(gp, 0, P->stream);
+      continue;
+    }
+    if (d >= target && in_flight == 0) break;
+    if ((long long)d + in_flight < target && in_flight <= lookahead) {
+      const int nb = direct ? 0 : pipe_pick_batch(P, prm, period, __atomic_load_n(&P->scal->last_cg, __ATOMIC_RELAXED), cont_streak);
+      rc = enqueue_sequence(P, gp, gl, prm, direct, nb, 1, true);
+      if (rc) break;
+      idle_spins = 0; t_idle = Clock::now();
+      continue;
+    }
+    __builtin_ia32_pause();
+    if ((++idle_spins & 0xfff) == 0 && seconds_since(t_idle) > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(100));   // long iterations (sphere x10: 34 ms): no need to burn the core
+  }
+  if (rc == PGO_OK) rc = pipe_drain(P);
+  if (rc) return rc;
+  const int d1 = P->scal->lm_done;
+  lm_pull_state(P);
+  L.num_trial_steps += d1 - d0;
+  if (direct) L.n_factorizations += d1 - d0;
+  if (ran) *ran = d1 - d0;
+  const pgo::LmDev& M = P->scal->lm;
+  if (M.halt == pgo::LM_HALT_TERMINATED) {
+    terminate_by_reason(L, o, M.termination, M.reason, M.term_value);
+    rc = resync_direct_counters(P);     // sequences enqueued ahead of the halt left their tickets untouched
+    if (rc) return rc;
+  }
+  L.t_total += seconds_since(t_run);
   return PGO_OK;
 }
 
@@ -2283,6 +2514,13 @@ int pgo_solver_begin(pgo_problem* P, const pgo_solver_options* options) {
 int pgo_solver_step(pgo_problem* P, int n, int* executed, int* done) {
   if (!P || !P->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_step without pgo_solver_begin");
   int ran = 0;
+  if (P->pipelined) {
+    int rc = lm_run_pipelined(P, n, &ran);
+    if (rc) { P->lm.active = false; return rc; }
+    if (executed) *executed = ran;
+    if (done) *done = P->lm.terminated ? 1 : 0;
+    return PGO_OK;
+  }
   for (int i = 0; i < n && !P->lm.terminated; ++i) {
     const int solves_before = P->lm.num_trial_steps;
     int rc = lm_advance(P);
@@ -2320,6 +2558,7 @@ int pgo_solver_reset(pgo_problem* P) {
   r.gradient_max_norm = L.gmax;
   L.cur = r;
   L.pending_record = false;
+  P->pipe_dirty = true;
   return PGO_OK;
 }
 
@@ -2334,7 +2573,7 @@ int pgo_solve(pgo_problem* P, const pgo_solver_options* options, pgo_solver_summ
   int rc = lm_begin(P, options);
   if (rc) return rc;
   while (!P->lm.terminated) {
-    rc = lm_advance(P);
+    rc = P->pipelined ? lm_run_pipelined(P, -1, nullptr) : lm_advance(P);
     if (rc) { P->lm.active = false; return rc; }   // caller memory keeps the poses it came with; the session is closed
   }
   return lm_end(P, summary, records, capacity);
@@ -2604,11 +2843,11 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     if (!P->direct_usable) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): no GPU factorisation prepared for this problem", kernel);
     if ((k != "direct") && !P->front_usable) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): the multifrontal solver is not in use", kernel);
     pgo::launch_damping(P->g, P->lm.radius, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, 0, s);
-    if (k == "front_solve") enqueue_front_factor(P);
+    if (k == "front_solve") enqueue_front_factor(P, P->g);
   }
   auto once = [&]() -> int {
     if (k == "direct") return run_direct(P);
-    if (k == "front_factor") { enqueue_front_factor(P); return 0; }
+    if (k == "front_factor") { enqueue_front_factor(P, P->g); return 0; }
     if (k == "front_solve") { pgo::launch_front_solve(P->g, P->fplan, P->fsym, s, P->fsym.mixed ? &P->splan : nullptr); return 0; }
     if (k == "linearize") pgo::launch_linearize(P->g, s);
     else if (k == "cost") pgo::launch_cost(P->g, P->g.pose_x, 5, s);
