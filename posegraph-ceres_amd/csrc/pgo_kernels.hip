@@ -1519,6 +1519,8 @@ __global__ __launch_bounds__(256) void k_accept_finish(DeviceGraph g, int seq_id
 // CG itself; LM_HALT_REFACTOR: it repeats the factorisation in another form) and lets the sequences run again.
 __global__ void k_lm_resume(DeviceGraph g, int cg_goes_on) {
   LmDev& D = *g.lm;
+  D.t_mark = (long long)__builtin_amdgcn_s_memrealtime();   // the phase clocks do not count the time the stream sat idle
+  if (cg_goes_on < 0) return;                               // (start of a run: only the time mark)
   D.halt = LM_RUN;
   D.phase = cg_goes_on ? LM_PHASE_CONT : LM_PHASE_NEW;
   if (cg_goes_on) g.cg->done = 0;

@@ -1950,6 +1950,7 @@ int lm_run_pipelined(pgo_problem* P, int budget, int* ran) {
   gp.lm = P->d_lm.p;
   pgo::DeviceGraph gl = gp;
   gl.pose_x = gp.pose_c;          // the linearisation of an accepted step reads the candidate buffer
+  pgo::launch_lm_resume(gp, -1, P->stream);    // time mark of the device's phase clocks
   const int d0 = __atomic_load_n(&P->scal->lm_done, __ATOMIC_ACQUIRE);
   const long long target = budget < 0 ? (1LL << 40) : (long long)d0 + budget;
   int cont_streak = 0, seen_seq = P->pipe_seq, seen_done = d0;
