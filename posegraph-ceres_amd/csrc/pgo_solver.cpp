@@ -1799,6 +1799,12 @@ bool pipeline_wanted(const pgo_problem* P) {
   if (off || P->g.world != 1 || (P->comm && P->comm->world > 1) || P->use_graph) return false;
   const bool direct = P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY && P->direct_usable;
   if (direct && P->dsym.hybrid && !P->front_usable && !P->sfront_usable) return false;   // factorisation or PCG chosen per iteration by the host
+  // Exact steps: the launch sequence of an iteration is the same every time, so enqueueing ahead costs nothing.  PCG: the host has
+  // to allot CG iterations to a sequence before it knows how many the CG will take (Manhattan 10 k: 32, 8, 20, 85, 15, 125, 14 ...
+  // then 3-6), every unused one is two early-exit launches and every CG that outlives its sequence a gated tail: measured 0.38 ms
+  // per LM iteration against 0.30 with the host in the loop on a host that answers within 13 us.  PGO_PIPELINE_PCG=1 selects the
+  // sequences for PCG as well (tests do).
+  if (!direct) { const char* e = getenv("PGO_PIPELINE_PCG"); return e && e[0] == '1'; }
   return true;
 }
 

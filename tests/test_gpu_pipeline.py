@@ -17,10 +17,12 @@ FIELDS = ["iteration", "step_is_successful", "linear_solver_iterations", "cost",
 def _solve(gpu, g, host_loop, **opt):
     old = os.environ.get("PGO_NO_PIPELINE")
     os.environ["PGO_NO_PIPELINE"] = "1" if host_loop else "0"
+    os.environ["PGO_PIPELINE_PCG"] = "1"      # (PCG keeps the host in the loop by default: see pipeline_wanted in pgo_solver.cpp)
     try:
         prob, poses = gpu.problem_from_graph(g)
         s = gpu.solve(gpu.SolverOptions(**opt), prob)
     finally:
+        os.environ.pop("PGO_PIPELINE_PCG", None)
         if old is None:
             os.environ.pop("PGO_NO_PIPELINE", None)
         else:
@@ -85,27 +87,31 @@ def test_stepping_in_pieces_equals_one_solve(gpu, ds):
     opt = gpu.SolverOptions(max_num_iterations=40, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2)
     prob, poses = gpu.problem_from_graph(g)
     whole = gpu.solve(opt, prob)
-    prob2, poses2 = gpu.problem_from_graph(g)
-    prob2.solver_begin(opt)
-    total = 0
-    for n in (1, 3, 2, 5, 40):
-        ran, done = prob2.solver_step(n)
-        total += ran
-        if done:
-            break
-    s = prob2.solver_end()
+    os.environ["PGO_PIPELINE_PCG"] = "1"
+    try:
+        prob2, poses2 = gpu.problem_from_graph(g)
+        prob2.solver_begin(opt)
+        total = 0
+        for n in (1, 3, 2, 5, 40):
+            ran, done = prob2.solver_step(n)
+            total += ran
+            if done:
+                break
+        s = prob2.solver_end()
+        prob3, poses3 = gpu.problem_from_graph(g)
+        prob3.solver_begin(opt)
+        prob3.solver_step(6)
+        prob3.solver_reset()
+        ran3, done3 = prob3.solver_step(6)
+        s3 = prob3.solver_end()
+    finally:
+        os.environ.pop("PGO_PIPELINE_PCG", None)
     assert len(s.iterations) == len(whole.iterations)
     for f in FIELDS:
         assert np.array_equal(s.iterations[f], whole.iterations[f]), f
     assert np.array_equal(poses, poses2)
     # reset: the first 6 iterations again, identical to the first 6 of the solve
-    prob3, poses3 = gpu.problem_from_graph(g)
-    prob3.solver_begin(opt)
-    prob3.solver_step(6)
-    prob3.solver_reset()
-    ran, done = prob3.solver_step(6)
-    assert ran == 6 and not done
-    s3 = prob3.solver_end()
+    assert ran3 == 6 and not done3
     last6 = s3.iterations[-6:]
     for f in ("cost", "step_is_successful", "linear_solver_iterations", "trust_region_radius"):
         assert np.array_equal(last6[f], whole.iterations[f][1:7]), f
