@@ -47,7 +47,19 @@ __host__ __device__ inline int bsr_pos(int packed, int side, int k) {
 // the previous sequence has not stopped yet: damping / CG start exit, the CG kernels simply go on;  accepted -> the linearisation
 // of the candidate (in place: nothing needs the old one any more) and the accept-finish kernel (candidate -> current point,
 // gradient norm, gradient-tolerance and minimum-radius tests) run only behind an accepted step.
-enum LmHalt { LM_RUN = 0, LM_HALT_TERMINATED = 1, LM_HALT_CG_STALL = 2, LM_HALT_REFACTOR = 3 };
+enum LmHalt { LM_RUN = 0, LM_HALT_TERMINATED = 1, LM_HALT_CG_STALL = 2, LM_HALT_REFACTOR = 3, LM_HALT_BUDGET = 4 };
+// ---- the universal stream (PCG on one rank, r03) ---------------------------------------------------------------------------
+// How many CG iterations an LM iteration takes is only known when the CG stops, so a host that enqueues kernels ahead of the
+// device either allots too many (every unused pair of launches costs ~5 us) or too few.  The universal stream removes the
+// guess: the host enqueues ONE alternating pattern  V S V S V S ...  of two kernels, a slot-shaped one (k_uni_s: one lane per BSR
+// slot — CG SpMV, tail SpMV, refresh SpMV, linearisation) and a vector-shaped one (k_uni_v: head = accept-finish + damping /
+// preconditioner + CG start, CG vector update, step tail + decision), and every launch does whatever comes next, which it reads
+// from CgState::op_s / op_v.  An LM iteration with n CG iterations is
+//     V head | (S spmv, V update) x n | S tail (the launch that finds the CG stopped multiplies A x at once) | V step tail + decision
+//     | S linearise (accepted) or nothing (rejected)
+// = 2 n + 4 launches, none wasted but the one slot behind a rejected step, whatever n turns out to be and however slow the host is.
+enum UniOp { UNI_EXIT = -1, UNI_NOP = 0, UNI_S_CG = 1, UNI_S_REFRESH = 2, UNI_S_LINEARIZE = 3,
+             UNI_V_HEAD = 1, UNI_V_UPDATE = 2, UNI_V_UPDATE_X = 3, UNI_V_UPDATE_R = 4, UNI_V_STEP_TAIL = 5 };
 enum LmPhase { LM_PHASE_NEW = 0, LM_PHASE_CONT = 1 };
 struct LmRecord {            // layout of pgo_iteration_record (include/pgo.h; static_assert in pgo_solver.cpp)
   int iteration, step_is_successful, linear_solver_iterations, reserved;
@@ -75,6 +87,8 @@ struct LmDev {
   int cg_period;             // residual refresh period of the CG (a CG that outlives its sequence goes on in the next one only
                              // from a multiple of it: the refresh launches sit at fixed positions of every sequence)
   int last_cg;
+  int decision_limit;        // universal stream: the stream pauses (LM_HALT_BUDGET) once lm_done reaches it (pgo_solver_step(n))
+  int pause;                 //   ... set by the decision that reaches the limit: the head launch behind it only finishes the accepted step
   LmCore core;
   LmTolerances tol;
   double min_diag, max_diag; // LevenbergMarquardtStrategy's clamp of the diagonal
@@ -100,7 +114,7 @@ struct LmScalars {
   int lm_done;             // decisions taken
   int halt;                // mirror of LmDev::halt
   int last_cg;             // CG iterations of the last decided iteration (batch-length prediction)
-  int pad0;
+  int slots_done;          // universal stream: vector-shaped launches completed
   LmDev lm;                // mirror of the device state, complete whenever seq_done == the last enqueued sequence
   LmRecord ring[LM_RING];  // iteration records, slot = record index % LM_RING
 };
@@ -111,7 +125,9 @@ struct CgState {
   int status;      // as LmScalars::cg_status
   int cnt_a;       // iteration index published by the SpMV kernel for the update kernel
   int cnt_b;       // iterations completed, published by the update kernel for the next SpMV
-  int pad[3];
+  int op_s;        // universal stream (k_uni_s / k_uni_v below): what the next slot-shaped launch does (UniOp), written by vector-shaped launches
+  int op_v;        //   ... and what the next vector-shaped launch does, written by slot-shaped launches (or by the last work-group of a vector-shaped one)
+  int slots;       // vector-shaped launches so far (mirrored to LmScalars::slots_done: the host keeps a bounded number enqueued ahead)
   double beta;     // beta of the current iteration, published by the SpMV kernel (the update kernel rebuilds p with it)
   double rho;      // r'z of the current iteration, likewise (the update kernel needs it for alpha = rho / p'q)
   double rho_hist[2];  // r'z and Q of the iterations, by iteration parity: the next SpMV launch reads the other slot
@@ -243,6 +259,13 @@ void launch_step_tail(const DeviceGraph& g, hipStream_t s, int gate);           
 // pass, "sequence seq_id is through" for the host), and the host's way back in after a non-terminal halt
 void launch_accept_finish(const DeviceGraph& g, int seq_id, hipStream_t s);
 void launch_lm_resume(const DeviceGraph& g, int cg_goes_on, hipStream_t s);
+// the universal stream (UniOp above): one slot-shaped and one vector-shaped launch; the budget kernel (re)opens the stream for
+// `decisions` more LM iterations; the publish kernel sets LmScalars::seq behind everything enqueued so far
+void launch_uni_s(const DeviceGraph& g, const CgParams& p, int period, hipStream_t s);
+void launch_uni_v(const DeviceGraph& g, const CgParams& p, double min_diag, double max_diag, hipStream_t s);
+void launch_lm_budget(const DeviceGraph& g, int decisions, hipStream_t s);
+void launch_lm_publish(const DeviceGraph& g, hipStream_t s);
+bool uni_supported(const DeviceGraph& g);
 void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s);
 void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s, int mode = 0);   // mode: see k_pcg_update
 void launch_spmv_refresh(const DeviceGraph& g, hipStream_t s, int on_the_fly = 0, int it_odd = 0);

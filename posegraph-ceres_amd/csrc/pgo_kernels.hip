@@ -12,6 +12,8 @@
 //                     per row through LDS in a fixed order (deterministic, no FP64 atomics).
 //   * k_pcg_spmv    : lane multiplies its block with the gathered 6-vector, LDS segmented row sums.
 // Everything is FP64 and HBM/L2 bound; MFMA is deliberately not used for 6x6 blocks.
+#include <algorithm>
+
 #include "pgo_kernels.h"
 #include "pgo_lm_rules.h"
 #include "pgo_math.h"
@@ -64,8 +66,15 @@ __device__ __forceinline__ double wave_max(double v) {  // v >= 0 everywhere it 
 // Sum NV values over the workgroup in a fixed order; every thread gets the totals.
 // scratch: >= NV * (blockDim/64) doubles of LDS.  Ends with a barrier so scratch can be reused.
 template <int NV>
+__device__ __forceinline__ void block_sum_w(double (&v)[NV], double* scratch, int nw);
+template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  block_sum_w<NV>(v, scratch, (blockDim.x + 63) >> 6);
+}
+// nw: the waves that take part (the others of the work-group must have left the kernel: a barrier only counts live waves)
+template <int NV>
+__device__ __forceinline__ void block_sum_w(double (&v)[NV], double* scratch, int nw) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const double s = wave_sum(v[k]);  // uniform across the wave
@@ -162,11 +171,9 @@ __device__ __forceinline__ WBlocks load_W_diag(const double* W, size_t stride, s
 // ------------------------------------------------------------------------------------------------
 // gate: a speculative launch behind the step tail of a CG batch (the linearisation of the candidate point into the spare buffers)
 // runs only once the CG has stopped, like the tail itself.
+// (the body is shared with the universal slot kernel k_uni_s further down)
 template <int INFO>
-__global__ __launch_bounds__(256) void k_linearize(DeviceGraph g, int gate) {
-  extern __shared__ double lds[];  // NV_LIN * block
-  if (gate == 1 && !g.cg->done) return;
-  if (gate == 2 && (g.lm->halt || !g.lm->accepted)) return;   // device-resident LM: behind an accepted step only (g.pose_x is the candidate)
+__device__ __forceinline__ void linearize_body(const DeviceGraph& g, double* lds) {
   const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
   const int s_begin = g.wg_slot_begin[wg], s_end = g.wg_slot_begin[wg + 1];
   const int r0 = g.wg_row_begin[wg], nrows = g.wg_row_begin[wg + 1] - r0;
@@ -358,6 +365,13 @@ __global__ __launch_bounds__(256) void k_linearize(DeviceGraph g, int gate) {
     }
   }
 }
+template <int INFO>
+__global__ __launch_bounds__(256) void k_linearize(DeviceGraph g, int gate) {
+  extern __shared__ double lds[];  // NV_LIN * block
+  if (gate == 1 && !g.cg->done) return;
+  if (gate == 2 && (g.lm->halt || !g.lm->accepted)) return;   // device-resident LM: behind an accepted step only (g.pose_x is the candidate)
+  linearize_body<INFO>(g, lds);
+}
 
 // Jacobi scaling, computed once at iteration 0 from the unscaled diag(J^T J):  S = 1 / (1 + sqrt(d)).
 __global__ void k_scale_from_diag(DeviceGraph g) {
@@ -372,13 +386,7 @@ __global__ void k_scale_from_diag(DeviceGraph g) {
 // LM damping (LevenbergMarquardtStrategy::ComputeStep) per pose:
 //   D^2 = clamp(diag(H~)) / radius, A_vv = H~_vv + D^2 -> diagonal BSR slot, M_v = A_vv^-1.
 // mode 0: clamp fresh, 1: reuse the clamped diagonal (rejected step), 2: take g.d2 as given (tests)
-__global__ void k_damping(DeviceGraph g, double radius, double min_diag, double max_diag, int mode) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g.lm) {   // device-resident LM: radius and "reuse the clamped diagonal" come from the device state
-    if (g.lm->halt || g.lm->phase == LM_PHASE_CONT) return;
-    radius = g.lm->core.radius; mode = g.lm->core.reuse_diagonal ? 1 : 0;
-  }
-  if (v >= g.N) return;
+__device__ __forceinline__ void damping_pose(const DeviceGraph& g, int v, double radius, double min_diag, double max_diag, int mode) {
   double A[36];
   const double2* src = reinterpret_cast<const double2*>(g.Hdiag + 36 * (size_t)v);
 #pragma unroll
@@ -409,13 +417,24 @@ __global__ void k_damping(DeviceGraph g, double radius, double min_diag, double 
 #pragma unroll
   for (int k = 0; k < 18; ++k) dst[k] = double2{Ai[2 * k], Ai[2 * k + 1]};
 }
+__global__ void k_damping(DeviceGraph g, double radius, double min_diag, double max_diag, int mode) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g.lm) {   // device-resident LM: radius and "reuse the clamped diagonal" come from the device state
+    if (g.lm->halt || g.lm->phase == LM_PHASE_CONT) return;
+    radius = g.lm->core.radius; mode = g.lm->core.reuse_diagonal ? 1 : 0;
+  }
+  if (v >= g.N) return;
+  damping_pose(g, v, radius, min_diag, max_diag, mode);
+}
 
 // Cluster-Jacobi preconditioner: CL consecutive poses (a piece of the odometry chain, plus whatever loop
 // edges fall inside it) form one dense (6 CL)^2 diagonal block of H~ + D^2, inverted in LDS by in-place
 // Gauss-Jordan (SPD, no pivoting).  One wave per cluster.  Row r of the inverse is what lane r of the
 // vector kernels reads (contiguous 6 CL doubles).
+// One wave: the clusters [cl_first, cl_first + 64 / (6 CL)) of this rank, as far as they lie below cl_end.
 template <int CL>
-__global__ __launch_bounds__(64) void k_cluster_precond(DeviceGraph g, double radius, double min_diag, double max_diag, int mode) {
+__device__ __forceinline__ void cluster_precond_wave(const DeviceGraph& g, double radius, double min_diag, double max_diag, int mode,
+                                                     int cl_first, int cl_end, int lane) {
   // mode >= 0: this kernel also does k_damping's job for its poses (D^2, clamped diagonal, damped diagonal BSR slot) —
   // one launch fewer per LM iteration; mode < 0: k_damping ran before (several ranks: D^2 is needed for ALL rows).
   //
@@ -424,16 +443,9 @@ __global__ __launch_bounds__(64) void k_cluster_precond(DeviceGraph g, double ra
   // register of every lane; no LDS array, no barriers (the LDS version spent ~1.2 us per pivot on dependent LDS
   // round trips).
   constexpr int DIM = 6 * CL, CPW = 64 / DIM;
-  if (g.lm) {   // device-resident LM (k_damping)
-    if (g.lm->halt || g.lm->phase == LM_PHASE_CONT) return;
-    radius = g.lm->core.radius;
-    if (mode >= 0) mode = g.lm->core.reuse_diagonal ? 1 : 0;
-  }
-  const int lane = threadIdx.x;
   const int grp = lane / DIM, j = lane - grp * DIM;
-  const int n_cl = (g.row_hi - g.row_lo + CL - 1) / CL;
-  const int cl_local = blockIdx.x * CPW + grp;              // cluster index among this rank's clusters
-  const bool live = grp < CPW && cl_local < n_cl;
+  const int cl_local = cl_first + grp;                      // cluster index among this rank's clusters
+  const bool live = grp < CPW && cl_local < cl_end;
   const int base = grp * DIM;
   const int c = g.row_lo / CL + cl_local;
   const int v0 = c * CL;
@@ -522,6 +534,17 @@ __global__ __launch_bounds__(64) void k_cluster_precond(DeviceGraph g, double ra
 #pragma unroll
     for (int i = 0; i < DIM; ++i) out[i * DIM + j] = a[i];
   }
+}
+template <int CL>
+__global__ __launch_bounds__(64) void k_cluster_precond(DeviceGraph g, double radius, double min_diag, double max_diag, int mode) {
+  constexpr int CPW = 64 / (6 * CL);
+  if (g.lm) {   // device-resident LM (k_damping)
+    if (g.lm->halt || g.lm->phase == LM_PHASE_CONT) return;
+    radius = g.lm->core.radius;
+    if (mode >= 0) mode = g.lm->core.reuse_diagonal ? 1 : 0;
+  }
+  const int n_cl = (g.row_hi - g.row_lo + CL - 1) / CL;
+  cluster_precond_wave<CL>(g, radius, min_diag, max_diag, mode, (int)blockIdx.x * CPW, n_cl, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1325,7 +1348,7 @@ __device__ __forceinline__ void lm_device_decide(const DeviceGraph& g, double ca
     lm_mirror(g);
     return;
   }
-  const LmStepIn in{cand_cost, model_change, step_norm_sq, x_norm_sq, direct ? 0 : g.cg->iters, direct ? 0 : g.cg->status, bad, 0};
+  const LmStepIn in{cand_cost, model_change, step_norm_sq, x_norm_sq, (direct & 1) ? 0 : g.cg->iters, (direct & 1) ? 0 : g.cg->status, bad, 0};
   LmRecord nx;
   double tv = 0.0;
   const LmOutcome out = lm_decide(D.core, D.tol, in, nx, tv);
@@ -1345,6 +1368,14 @@ __device__ __forceinline__ void lm_device_decide(const DeviceGraph& g, double ca
     D.num_records = nx.iteration + 1;
     if (out != LM_OUT_ACCEPT) lm_pre_step_checks(D, false);   // behind an accepted step the accept-finish kernel runs them (it has the gradient)
   }
+  if (direct & 2) {            // universal stream: what the next slot-shaped and vector-shaped launches do
+    if (D.halt) { g.cg->op_s = UNI_EXIT; g.cg->op_v = UNI_EXIT; }
+    else {
+      g.cg->op_s = D.accepted ? UNI_S_LINEARIZE : UNI_NOP;
+      g.cg->op_v = UNI_V_HEAD;
+      if (D.lm_done >= D.decision_limit) D.pause = 1;   // pgo_solver_step(n): the head launch only finishes the accepted step, then the stream pauses
+    }
+  }
   lm_mirror(g);
 }
 
@@ -1352,19 +1383,15 @@ __device__ __forceinline__ void lm_device_decide(const DeviceGraph& g, double ca
 // at pose-graph sizes).  The candidate poses were written by the preceding k_spmv<1> launch (diagonal lanes).  Pose
 // part = model cost change and step / state norms; edge part = candidate cost; the LAST workgroup to finish (ticket
 // counter) folds the partial rows and hands off to the host.
+// bid / nblocks: this work-group's index among the n_edge_wg + n_pose_wg that take part; EDGE_BLOCK live threads (the universal
+// vector kernel runs it on the first four waves of its work-groups)
 template <int INFO>
-__global__ __launch_bounds__(EDGE_BLOCK) void k_step_tail(DeviceGraph g, int gate) {
-  __shared__ double scratch[4 * (EDGE_BLOCK / 64)];
-  __shared__ int is_last;
+__device__ __forceinline__ void step_tail_body(const DeviceGraph& g, int gate, int bid, int nblocks, double* scratch, int* is_last_p) {
   const int tid = threadIdx.x;
-  if (lm_halted(g)) return;    // device-resident LM: a sequence enqueued ahead of a halt
-  if ((gate & 1) && !g.cg->done) {   // CG still running: only hand the (unfinished) status over to the host
-    if (blockIdx.x == 0 && tid == 0) { if (g.lm) lm_cg_unfinished(g); else publish_sequence(g); }
-    return;
-  }
+  int& is_last = *is_last_p;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};   // candidate cost, model change, |step|^2, |x|^2
   // workgroups [0, n_edge_wg) take the edges, [n_edge_wg, n_edge_wg + n_pose_wg) the poses: both parts run side by side
-  const int pose_wg = (int)blockIdx.x - g.n_edge_wg;
+  const int pose_wg = bid - g.n_edge_wg;
   for (int v = pose_wg * EDGE_BLOCK + tid; pose_wg >= 0 && v < g.N; v += g.n_pose_wg * EDGE_BLOCK) {
     const PoseRec P = load_pose(g.pose_x, v), C = load_pose(g.pose_c, v);
     const uint8_t m = g.cmask[v];
@@ -1387,7 +1414,7 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_step_tail(DeviceGraph g, int gat
       acc[3] += P.q.x * P.q.x + P.q.y * P.q.y + P.q.z * P.q.z + P.q.w * P.q.w;
     }
   }
-  const int e = blockIdx.x * EDGE_BLOCK + tid;
+  const int e = bid * EDGE_BLOCK + tid;
   if (pose_wg < 0 && e < g.E) {
     const PoseRec A = load_pose(g.pose_c, g.edge_a[e]), B = load_pose(g.pose_c, g.edge_b[e]);
     const size_t E = (size_t)g.E;
@@ -1408,22 +1435,22 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_step_tail(DeviceGraph g, int gat
     loss_eval(g.loss_kind, g.loss_a, sq, &rho0, &rho1);
     acc[0] = 0.5 * rho0;
   }
-  block_sum<4>(acc, scratch);
+  block_sum_w<4>(acc, scratch, EDGE_BLOCK / 64);
   if (tid == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) g.part_misc[(size_t)k * g.n_part + blockIdx.x] = acc[k];
+    for (int k = 0; k < 4; ++k) g.part_misc[(size_t)k * g.n_part + bid] = acc[k];
     __threadfence();
-    is_last = (atomicAdd(&g.flags[3], 1) == (int)gridDim.x - 1);
+    is_last = (atomicAdd(&g.flags[3], 1) == nblocks - 1);
   }
   __syncthreads();
   if (!is_last) return;
   __threadfence();
   double s[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int i = tid; i < (int)gridDim.x; i += EDGE_BLOCK) {   // other workgroups' partials: read at device scope (not from this CU's L1)
+  for (int i = tid; i < nblocks; i += EDGE_BLOCK) {   // other workgroups' partials: read at device scope (not from this CU's L1)
 #pragma unroll
     for (int k = 0; k < 4; ++k) s[k] += __hip_atomic_load(&g.part_misc[(size_t)k * g.n_part + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  block_sum<4>(s, scratch);
+  block_sum_w<4>(s, scratch, EDGE_BLOCK / 64);
   double m = 0.0;
   for (int i = tid; i < g.n_pose_wg; i += EDGE_BLOCK) m = fmax(m, g.part_misc[4 * (size_t)g.n_part + i]);
   m = wave_max(m);
@@ -1443,9 +1470,22 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_step_tail(DeviceGraph g, int gat
     g.flags[1] = 0;
     g.flags[2] = 0;
     g.flags[3] = 0;
-    if (g.lm) lm_device_decide(g, s[0], s[1], s[2], s[3], bad, (gate & 2) ? 1 : 0);   // accept / reject / stop, on the spot
+    if (g.lm) lm_device_decide(g, s[0], s[1], s[2], s[3], bad, ((gate & 2) ? 1 : 0) | ((gate & 4) ? 2 : 0));   // accept / reject / stop, on the spot
     else publish_sequence(g);
   }
+}
+
+template <int INFO>
+__global__ __launch_bounds__(EDGE_BLOCK) void k_step_tail(DeviceGraph g, int gate) {
+  __shared__ double scratch[4 * (EDGE_BLOCK / 64)];
+  __shared__ int is_last;
+  const int tid = threadIdx.x;
+  if (lm_halted(g)) return;    // device-resident LM: a sequence enqueued ahead of a halt
+  if ((gate & 1) && !g.cg->done) {   // CG still running: only hand the (unfinished) status over to the host
+    if (blockIdx.x == 0 && tid == 0) { if (g.lm) lm_cg_unfinished(g); else publish_sequence(g); }
+    return;
+  }
+  step_tail_body<INFO>(g, gate, (int)blockIdx.x, (int)gridDim.x, scratch, &is_last);
 }
 
 // Device-resident LM: last kernel of a sequence.  Behind an accepted step: candidate -> current point (the linearisation that ran
@@ -1527,6 +1567,508 @@ __global__ void k_lm_resume(DeviceGraph g, int cg_goes_on) {
   g.scal->halt = 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The universal stream (pgo_kernels.h UniOp): two kernels, enqueued alternately V S V S ... by a host that does not know what
+// each launch will do.  Every branch below is the arithmetic of the kernel it replaces (k_spmv, k_linearize, k_pcg_update,
+// k_cluster_precond / k_damping + k_pcg_init, k_step_tail, k_accept_finish), in the same work decomposition and the same
+// summation orders, so a solve through the stream is bit-identical to the same solve through those kernels
+// (tests/test_gpu_pipeline.py).  What differs is WHEN things are known: the parity of the CG iteration and the operation itself
+// come from device memory, so everything the likely branch needs and that does not depend on them is requested before the state
+// arrives (both parities of the partial rows and of p), and the state costs no round trip of its own.
+// ------------------------------------------------------------------------------------------------
+constexpr int UNI_V_BLOCK = 512;   // vector-shaped launches: 6 waves of vector update (VEC_BLOCK rows), 4 waves of step tail / accept-finish
+                                   // (EDGE_BLOCK / POSE_BLOCK), up to 8 waves of cluster inverses for the 64 poses of a row chunk
+
+template <bool PACKED, int INFO>
+__global__ __launch_bounds__(256) void k_uni_s(DeviceGraph g, CgParams prm, int period) {
+  constexpr int NPAIR = PACKED ? BLK_PAIRS_PACKED : BLK_PAIRS_FULL;
+  extern __shared__ double lds[];  // NV_LIN * block (linearise); the SpMV uses (SPMV_LDS_STRIDE + 6) * block of it
+  __shared__ double scratch[32];
+  const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
+  double* lds_p = lds + (size_t)SPMV_LDS_STRIDE * B;
+  // ---- requested before the state is known: what the CG / tail / refresh SpMV needs of its first chunk ----
+  const int s_begin = g.wg_slot_begin[wg], s_end = g.wg_slot_begin[wg + 1];
+  const int r0 = g.wg_row_begin[wg], nrows = g.wg_row_begin[wg + 1] - r0;
+  const bool single = (s_end - s_begin) == B;
+  int t = s_begin + tid;
+  int col = g.slot_col[t];
+  int row = g.slot_row[t];
+  uint8_t side = g.slot_side[t];
+  double2 blk[NPAIR];
+  {
+    const double2* bp = reinterpret_cast<const double2*>(g.bsr_val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) blk[k] = bp[(size_t)k * 64];
+  }
+  int seg_rb = 0, seg_cnt = 0;
+  if (tid < nrows * 6) { seg_rb = g.row_slot_begin[r0 + tid / 6]; seg_cnt = g.row_slot_cnt[r0 + tid / 6]; }
+  const int op = g.cg->op_s;
+  const int done0 = g.cg->done, cnt_b = g.cg->cnt_b;
+  const double hr0 = g.cg->rho_hist[0], hr1 = g.cg->rho_hist[1], hq0 = g.cg->q_hist[0], hq1 = g.cg->q_hist[1];
+  const bool need_rr = prm.r_tolerance >= 0.0;
+  double se[6] = {0, 0, 0, 0, 0, 0}, so[6] = {0, 0, 0, 0, 0, 0};   // partial rows as an even / an odd iteration would read them
+  if (need_rr) {
+    for (int i = tid; i < g.n_vec_wg; i += B) {
+      so[0] += g.part_rz[i]; so[2] += g.part_q[i]; so[4] += g.part_rr[i];
+      se[0] += g.part_rz[g.n_part + i]; se[2] += g.part_q[g.n_part + i]; se[4] += g.part_rr[g.n_part + i];
+      const double bb = g.part_bb[i];
+      so[5] += bb; se[5] += bb;
+    }
+  } else {
+    for (int i = tid & 63; i < g.n_vec_wg; i += 64) {
+      so[0] += g.part_rz[i]; so[2] += g.part_q[i];
+      se[0] += g.part_rz[g.n_part + i]; se[2] += g.part_q[g.n_part + i];
+    }
+  }
+  if (op <= UNI_NOP) return;
+  if (op == UNI_S_LINEARIZE) {
+    DeviceGraph gl = g;
+    gl.pose_x = g.pose_c;          // the accepted candidate; the accept-finish part of the next head launch copies it over
+    linearize_body<INFO>(gl, lds);
+    return;
+  }
+  // ---- CG iteration `it`: the stop test of iteration it - 1 first (k_spmv<0>'s prologue), by every work-group alike ----
+  const int it = cnt_b + 1;
+  const int odd = it & 1;
+  bool tail = false;           // this launch multiplies A x for the step tail instead of A p
+  double beta = 0.0, rho_pub = 0.0, q_pub = 0.0;
+  if (op == UNI_S_CG) {
+    double sums[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sums[k] = odd ? so[k] : se[k];
+    const double hist_rho = odd ? hr0 : hr1, hist_q = odd ? hq0 : hq1;
+    int stop = 0, status = 0;
+    if (done0) {
+      tail = true;
+    } else {
+      double rr = 0.0, bb = 0.0;
+      if (need_rr) {
+        block_sum<6>(sums, scratch);
+        rr = sums[4]; bb = sums[5];
+      } else {
+        sums[0] = wave_sum(sums[0]);
+        sums[2] = wave_sum(sums[2]);
+      }
+      const double rho = sums[0], rho_prev = hist_rho, Q1 = -sums[2], Q0 = hist_q;
+      rho_pub = rho;
+      q_pub = Q1;
+      if (it > 1) {
+        const int done_it = it - 1;
+        const double zeta = done_it * (Q1 - Q0) / Q1;
+        if (zeta < prm.q_tolerance && done_it >= prm.min_iterations) stop = 1;
+        if (prm.r_tolerance >= 0.0 && sqrt(rr) <= prm.r_tolerance * sqrt(bb) && done_it >= prm.min_iterations) stop = 1;
+        if (done_it >= prm.max_iterations) stop = 1;
+      }
+      if (!stop && (rho == 0.0 || !isfinite(rho))) { stop = 1; status = (rho == 0.0) ? 0 : 2; }
+      if (!stop && it > 1) {
+        beta = rho / rho_prev;
+        if (beta == 0.0 || !isfinite(beta)) { stop = 1; status = 2; }
+      }
+      if (stop) {
+        tail = true;
+        if (wg == 0 && tid == 0) { g.cg->iters = it - 1; g.cg->status = status; g.cg->done = 1; }
+      }
+    }
+  }
+  const bool cg_step = op == UNI_S_CG && !tail;
+  const double* p_old = odd ? g.cg_p0 : g.cg_p1;
+  double* p_new = odd ? g.cg_p1 : g.cg_p0;
+  // gathers of the first chunk
+  double2 gz[3] = {{0, 0}, {0, 0}, {0, 0}}, gp[3] = {{0, 0}, {0, 0}, {0, 0}};
+  if (col >= 0) {
+    if (cg_step) {
+      const double2* zs = reinterpret_cast<const double2*>(g.cg_z + 6 * (size_t)col);
+      const double2* ps = reinterpret_cast<const double2*>(p_old + 6 * (size_t)col);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { gz[k] = zs[k]; gp[k] = ps[k]; }
+    } else {
+      const double2* xs = reinterpret_cast<const double2*>(g.cg_x + 6 * (size_t)col);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gz[k] = xs[k];
+    }
+  }
+  double acc = 0.0;
+  double pq[1] = {0.0};
+  for (int cb = s_begin; cb < s_end; cb += B) {
+    if (cb != s_begin) {  // further chunks of a fat row
+      t = cb + tid;
+      col = g.slot_col[t];
+      row = g.slot_row[t];
+      side = g.slot_side[t];
+      const double2* bp = reinterpret_cast<const double2*>(g.bsr_val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+#pragma unroll
+      for (int k = 0; k < NPAIR; ++k) blk[k] = bp[(size_t)k * 64];
+      if (col >= 0) {
+        if (cg_step) {
+          const double2* zs = reinterpret_cast<const double2*>(g.cg_z + 6 * (size_t)col);
+          const double2* ps = reinterpret_cast<const double2*>(p_old + 6 * (size_t)col);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { gz[k] = zs[k]; gp[k] = ps[k]; }
+        } else {
+          const double2* xs = reinterpret_cast<const double2*>(g.cg_x + 6 * (size_t)col);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { gz[k] = xs[k]; gp[k] = double2{0, 0}; }
+        }
+      }
+    }
+    double y[6] = {0, 0, 0, 0, 0, 0};
+    if (col >= 0) {
+      double x[6];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double f = cg_step ? beta : 0.0;
+        x[2 * k] = gz[k].x + f * gp[k].x;
+        x[2 * k + 1] = gz[k].y + f * gp[k].y;
+      }
+      if (tail && side == SIDE_DIAG && cb == s_begin) {
+        // step tail: delta = -S x and the candidate Plus(x, delta) of this row
+        const PoseRec P = load_pose(g.pose_x, row);
+        const uint8_t m = g.cmask[row];
+        double d[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const bool c = (i < 3) ? (m & 1) : (m & 2);
+          d[i] = c ? 0.0 : -g.scale[6 * (size_t)row + i] * x[i];
+          g.delta[6 * (size_t)row + i] = d[i];
+        }
+        V3 pc = P.p;
+        Q4 qc = P.q;
+        if (!(m & 1)) pc = V3{P.p.x + d[0], P.p.y + d[1], P.p.z + d[2]};
+        if (!(m & 2)) qc = quat_plus(P.q, V3{d[3], d[4], d[5]});
+        double2* o = reinterpret_cast<double2*>(g.pose_c + (size_t)POSE_STRIDE * row);
+        o[0] = double2{pc.x, pc.y};
+        o[1] = double2{pc.z, qc.x};
+        o[2] = double2{qc.y, qc.z};
+        o[3] = double2{qc.w, 0.0};
+      }
+      if (cg_step && side == SIDE_DIAG) {
+        double2* pn = reinterpret_cast<double2*>(p_new + 6 * (size_t)col);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pn[k] = double2{x[2 * k], x[2 * k + 1]};
+        if (cb == s_begin) {
+          const int rl = row - r0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) lds_p[6 * rl + k] = x[k];
+        }
+      }
+      if (PACKED) {
+        double el[28];
+#pragma unroll
+        for (int k = 0; k < BLK_PAIRS_PACKED; ++k) { el[2 * k] = blk[k].x; el[2 * k + 1] = blk[k].y; }
+        const bool is_end = side == SIDE_END, is_diag = side == SIDE_DIAG;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const double a3 = is_end ? el[18 + 3 * i] : is_diag ? el[18 + i] : 0.0;
+          const double a4 = is_end ? el[18 + 3 * i + 1] : is_diag ? el[21 + i] : 0.0;
+          const double a5 = is_end ? el[18 + 3 * i + 2] : is_diag ? el[24 + i] : 0.0;
+          y[i] = el[3 * i] * x[0] + el[3 * i + 1] * x[1] + el[3 * i + 2] * x[2] + a3 * x[3] + a4 * x[4] + a5 * x[5];
+          const double b0 = is_end ? 0.0 : el[18 + 3 * i], b1 = is_end ? 0.0 : el[18 + 3 * i + 1], b2 = is_end ? 0.0 : el[18 + 3 * i + 2];
+          y[3 + i] = b0 * x[0] + b1 * x[1] + b2 * x[2] + el[9 + 3 * i] * x[3] + el[9 + 3 * i + 1] * x[4] + el[9 + 3 * i + 2] * x[5];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          y[i] = blk[3 * i].x * x[0] + blk[3 * i].y * x[1] + blk[3 * i + 1].x * x[2] + blk[3 * i + 1].y * x[3] +
+                 blk[3 * i + 2].x * x[4] + blk[3 * i + 2].y * x[5];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) lds[tid * SPMV_LDS_STRIDE + k] = y[k];
+    __syncthreads();
+    for (int idx = tid; idx < nrows * 6; idx += B) {
+      const int rl = idx / 6, k = idx - rl * 6;
+      const int rw = r0 + rl;
+      const int rb = (idx == tid) ? seg_rb : g.row_slot_begin[rw];
+      const int rc = (idx == tid) ? seg_cnt : g.row_slot_cnt[rw];
+      const int sb = max(rb, cb) - cb, sE = min(rb + rc, cb + B) - cb;
+      double s0 = 0.0, s1 = 0.0;
+      int j = sb;
+      for (; j + 1 < sE; j += 2) { s0 += lds[j * SPMV_LDS_STRIDE + k]; s1 += lds[(j + 1) * SPMV_LDS_STRIDE + k]; }
+      if (j < sE) s0 += lds[j * SPMV_LDS_STRIDE + k];
+      const double sm = s0 + s1;
+      if (single) {
+        g.cg_q[(size_t)rw * 6 + k] = sm;
+        if (cg_step) pq[0] += sm * lds_p[idx];
+      } else {
+        acc += sm;
+      }
+    }
+    __syncthreads();
+  }
+  if (!single && tid < 6) {
+    g.cg_q[(size_t)r0 * 6 + tid] = acc;
+    if (cg_step) pq[0] += acc * lds_p[tid];
+  }
+  if (cg_step) {
+    block_sum<1>(pq, scratch);
+    if (tid == 0) {
+      g.cg_q[(size_t)g.rows_per * 6 + wg] = pq[0];   // p'q partial rides behind q (one rank: rank 0's segment)
+      if (wg == 0) {
+        g.cg->cnt_a = it; g.cg->beta = beta; g.cg->rho = rho_pub;
+        g.cg->rho_hist[odd ? 1 : 0] = rho_pub;
+        g.cg->q_hist[odd ? 1 : 0] = q_pub;
+        g.cg->op_v = (period > 0 && it % period == 0) ? UNI_V_UPDATE_X : UNI_V_UPDATE;   // residual refresh: x first, then A x, then r = b - A x
+      }
+    }
+  } else if (wg == 0 && tid == 0) {
+    g.cg->op_v = tail ? UNI_V_STEP_TAIL : UNI_V_UPDATE_R;
+  }
+}
+
+// CL: poses per Jacobi block of the preconditioner (1: k_damping's 6x6 inverses)
+template <int CL, int INFO>
+__global__ __launch_bounds__(UNI_V_BLOCK) void k_uni_v(DeviceGraph g, CgParams prm, double min_diag, double max_diag) {
+  constexpr int DIM = 6 * CL;
+  __shared__ double rl[VEC_BLOCK];
+  __shared__ double scratch[4 * (UNI_V_BLOCK / 64)];
+  __shared__ int is_last;
+  const int tid = threadIdx.x, bid = blockIdx.x;
+  const int m = 6 * g.N;
+  // ---- requested before the state is known: the first row chunk of a CG vector update ----
+  int idx = bid * VEC_BLOCK + tid;
+  bool live = tid < VEC_BLOCK && bid < g.n_vec_wg && idx < m;
+  double x0 = 0, p0v = 0, p1v = 0, r0 = 0, q0 = 0, b0 = 0;
+  double2 mi[DIM / 2];
+#pragma unroll
+  for (int k = 0; k < DIM / 2; ++k) mi[k] = double2{0, 0};
+  if (live) {
+    x0 = g.cg_x[idx]; r0 = g.cg_r[idx]; q0 = g.cg_q[idx]; b0 = g.cg_b[idx];
+    p0v = g.cg_p0[idx]; p1v = g.cg_p1[idx];
+    const double2* Mi = reinterpret_cast<const double2*>(g.Minv + (size_t)idx * DIM);
+#pragma unroll
+    for (int k = 0; k < DIM / 2; ++k) mi[k] = Mi[k];
+  }
+  const int op = g.cg->op_v;
+  const int it = g.cg->cnt_a;
+  const double rho = g.cg->rho;
+  double sums[1] = {0};
+  if (tid < VEC_BLOCK && bid < g.n_vec_wg) {
+    const double* pqp = g.cg_q + (size_t)g.rows_per * 6;
+    for (int i = tid; i < g.pq_cap; i += VEC_BLOCK) sums[0] += pqp[i];
+  }
+  if (bid == 0 && tid == 0) {    // the host keeps a bounded number of launches enqueued ahead of this counter
+    const int n = g.cg->slots + 1;
+    g.cg->slots = n;
+    __hip_atomic_store(&g.scal->slots_done, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (op <= UNI_NOP) return;
+
+  if (op == UNI_V_UPDATE || op == UNI_V_UPDATE_X || op == UNI_V_UPDATE_R) {
+    // ---- k_pcg_update, mode 0 / 1 (x only) / 2 (r = b - A x) ----
+    if (tid >= VEC_BLOCK || bid >= g.n_vec_wg) return;
+    const int mode = op == UNI_V_UPDATE ? 0 : op == UNI_V_UPDATE_X ? 1 : 2;
+    const int odd = it & 1;
+    double pa = odd ? p1v : p0v;
+    const double* p = odd ? g.cg_p1 : g.cg_p0;
+    double alpha = 0.0;
+    if (mode != 2) {
+      block_sum_w<1>(sums, scratch, VEC_BLOCK / 64);
+      const double pq = sums[0];
+      if (!(pq > 0.0) || !isfinite(pq)) {
+        // "Matrix is indefinite, no more progress can be made": keep x of the previous iteration; the next slot launch finds the CG stopped
+        if (bid == 0 && tid == 0) { g.cg->iters = it - 1; g.cg->status = 1; g.cg->done = 1; g.cg->op_s = UNI_S_CG; }
+        return;
+      }
+      alpha = rho / pq;
+    }
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int base = bid * VEC_BLOCK; base < m; base += g.n_vec_wg * VEC_BLOCK) {
+      if (base != bid * VEC_BLOCK) {
+        idx = base + tid;
+        live = idx < m;
+        if (live) {
+          x0 = g.cg_x[idx]; r0 = g.cg_r[idx]; q0 = g.cg_q[idx]; b0 = g.cg_b[idx];
+          pa = p[idx];
+          const double2* Mi = reinterpret_cast<const double2*>(g.Minv + (size_t)idx * DIM);
+#pragma unroll
+          for (int k = 0; k < DIM / 2; ++k) mi[k] = Mi[k];
+        }
+      }
+      double x = 0.0, r = 0.0;
+      if (live) {
+        if (mode == 2) {
+          x = x0;
+          r = b0 - q0;
+          g.cg_r[idx] = r;
+        } else {
+          x = x0 + alpha * pa;
+          g.cg_x[idx] = x;
+          if (mode == 0) { r = r0 - alpha * q0; g.cg_r[idx] = r; }
+        }
+      }
+      if (mode == 1) continue;
+      rl[tid] = r;
+      __syncthreads();
+      if (live) {
+        const double* rv = rl + DIM * (tid / DIM);
+        double z = 0.0;
+#pragma unroll
+        for (int k = 0; k < DIM / 2; ++k) z += mi[k].x * rv[2 * k] + mi[k].y * rv[2 * k + 1];
+        g.cg_z[idx] = z;
+        acc[0] += r * z;
+        acc[1] += x * (b0 + r);
+        acc[2] += r * r;
+      }
+      __syncthreads();
+    }
+    if (mode == 1) {
+      if (bid == 0 && tid == 0) g.cg->op_s = UNI_S_REFRESH;
+      return;
+    }
+    block_sum_w<3>(acc, scratch, VEC_BLOCK / 64);
+    if (tid == 0) {
+      const size_t o = (size_t)(odd ? g.n_part : 0) + bid;
+      g.part_rz[o] = acc[0];
+      g.part_q[o] = acc[1];
+      g.part_rr[o] = acc[2];
+      if (bid == 0) { g.cg->cnt_b = it; g.cg->op_s = UNI_S_CG; }
+    }
+    return;
+  }
+
+  if (op == UNI_V_STEP_TAIL) {
+    const int nblocks = g.n_edge_wg + g.n_pose_wg;
+    if (tid >= EDGE_BLOCK || bid >= nblocks) return;
+    step_tail_body<INFO>(g, 4, bid, nblocks, scratch, &is_last);   // gate 4: the decision also sets the stream's next operations
+    return;
+  }
+
+  // ---- UNI_V_HEAD: accept-finish of the step just accepted, then damping / preconditioner and the CG start of the next pass ----
+  LmDev& D = *g.lm;
+  const int accepted = D.accepted, pause = D.pause;
+  double gm = 0.0;
+  if (accepted && tid < POSE_BLOCK && bid < g.n_pose_wg) {
+    const int v = bid * POSE_BLOCK + tid;
+    if (v < g.N) {
+      const PoseRec P = load_pose(g.pose_c, v);
+      const double2* src = reinterpret_cast<const double2*>(g.pose_c + (size_t)POSE_STRIDE * v);
+      double2* dst = reinterpret_cast<double2*>(g.pose_x + (size_t)POSE_STRIDE * v);
+      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+      const uint8_t cm = g.cmask[v];
+      const double* gr = g.grad + 6 * (size_t)v;
+      if (!(cm & 1)) gm = fmax(gm, fmax(fabs(gr[0]), fmax(fabs(gr[1]), fabs(gr[2]))));
+      if (!(cm & 2)) {
+        const Q4 q = quat_plus(P.q, V3{-gr[3], -gr[4], -gr[5]});
+        gm = fmax(gm, fmax(fmax(fabs(P.q.x - q.x), fabs(P.q.y - q.y)), fmax(fabs(P.q.z - q.z), fabs(P.q.w - q.w))));
+      }
+    }
+  }
+  gm = wave_max(gm);
+  if ((tid & 63) == 0) scratch[tid >> 6] = gm;
+  __syncthreads();
+  if (tid == 0 && accepted && bid < g.n_pose_wg) {
+    double t = 0.0;
+    for (int w = 0; w < POSE_BLOCK / 64; ++w) t = fmax(t, scratch[w]);
+    g.part_misc[4 * (size_t)g.n_part + bid] = t;
+  }
+  __syncthreads();
+  if (!pause && bid < g.n_vec_wg) {
+    const double radius = D.core.radius;
+    const int mode = D.core.reuse_diagonal ? 1 : 0;
+    double acc[2] = {0.0, 0.0};
+    for (int chunk = bid; chunk * (VEC_BLOCK / 6) < g.N; chunk += g.n_vec_wg) {
+      const int pose0 = chunk * (VEC_BLOCK / 6);     // 64 poses = VEC_BLOCK rows per chunk
+      // LM damping and the Jacobi blocks of these poses (k_damping / k_cluster_precond)
+      if (CL == 1) {
+        if (tid < 64 && pose0 + tid < g.N) damping_pose(g, pose0 + tid, radius, min_diag, max_diag, mode);
+      } else {
+        constexpr int CPW = 64 / DIM;
+        const int wave = tid >> 6, lane = tid & 63;
+        const int n_cl = (g.N + CL - 1) / CL;
+        for (int cw = wave; cw * CPW < 64 / CL; cw += UNI_V_BLOCK / 64)
+          cluster_precond_wave<CL>(g, radius, min_diag, max_diag, mode, pose0 / CL + cw * CPW, min(n_cl, pose0 / CL + 64 / CL), lane);
+      }
+      __syncthreads();      // the inverses were written by other waves of this work-group
+      // CG start (k_pcg_init)
+      const int ridx = chunk * VEC_BLOCK + tid;
+      const bool rlive = tid < VEC_BLOCK && ridx < m;
+      double b = 0.0;
+      if (rlive) {
+        b = g.scale[ridx] * g.grad[ridx];
+        g.cg_b[ridx] = b;
+        g.cg_x[ridx] = 0.0;
+        g.cg_r[ridx] = b;
+        g.cg_p0[ridx] = 0.0;
+        g.cg_p1[ridx] = 0.0;
+      }
+      if (tid < VEC_BLOCK) rl[tid] = b;
+      __syncthreads();
+      if (rlive) {
+        const double* Mi = g.Minv + (size_t)ridx * DIM;
+        const double* rv = rl + DIM * (tid / DIM);
+        double z = 0.0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) z += Mi[k] * rv[k];
+        g.cg_z[ridx] = z;
+        acc[0] += b * z;
+        acc[1] += b * b;
+      }
+      __syncthreads();
+    }
+    // (waves 6 and 7 carry zeros: the sums of the six row waves are what k_pcg_init's work-group forms)
+    block_sum<2>(acc, scratch);
+    if (tid == 0) {
+      g.part_rz[bid] = acc[0];
+      g.part_rz[g.n_part + bid] = 0.0;
+      g.part_bb[bid] = acc[1];
+      g.part_rr[bid] = acc[1];
+      g.part_rr[g.n_part + bid] = acc[1];
+      g.part_q[bid] = 0.0;
+      g.part_q[g.n_part + bid] = 0.0;
+      if (bid == 0) { g.cg->done = 0; g.cg->iters = 0; g.cg->status = 0; g.cg->cnt_a = 0; g.cg->cnt_b = 0; }
+    }
+  }
+  // the last work-group to finish: gradient norm of the accepted point, the opening tests of the next pass, the next operations
+  if (tid == 0) {
+    __threadfence();
+    is_last = (atomicAdd(&g.flags[3], 1) == (int)gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  double mm = 0.0;
+  if (accepted)
+    for (int i = tid; i < g.n_pose_wg; i += UNI_V_BLOCK)
+      mm = fmax(mm, __hip_atomic_load(&g.part_misc[4 * (size_t)g.n_part + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  mm = wave_max(mm);
+  if ((tid & 63) == 0) scratch[tid >> 6] = mm;
+  __syncthreads();
+  if (tid == 0) {
+    g.flags[3] = 0;
+    const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+    if (accepted) {
+      double t = 0.0;
+      for (int w = 0; w < UNI_V_BLOCK / 64; ++w) t = fmax(t, scratch[w]);
+      D.core.gmax = t;
+      g.scal->ring[D.core.iteration % LM_RING].gradient_max_norm = t;
+      g.scal->gradient_max = t;
+      D.accepted = 0;
+      lm_pre_step_checks(D, true);
+      D.ticks_jacobian += now - D.t_mark;    // (the damping / CG start share of this launch is booked here too: one clock per launch)
+      D.t_mark = now;
+    }
+    if (D.halt) { g.cg->op_s = UNI_EXIT; g.cg->op_v = UNI_EXIT; }
+    else if (pause) { D.halt = LM_HALT_BUDGET; g.cg->op_s = UNI_EXIT; g.cg->op_v = UNI_EXIT; }
+    else { g.cg->op_s = UNI_S_CG; g.cg->op_v = UNI_NOP; }
+    lm_mirror(g);
+  }
+}
+
+// (Re)opens the universal stream for `decisions` more LM iterations; behind LM_HALT_BUDGET the head launch that paused it is due again.
+__global__ void k_lm_budget(DeviceGraph g, int decisions) {
+  LmDev& D = *g.lm;
+  D.t_mark = (long long)__builtin_amdgcn_s_memrealtime();
+  D.decision_limit = decisions < 0 ? 0x7fffffff : D.lm_done + decisions;
+  D.pause = 0;
+  if (D.halt == LM_HALT_BUDGET || D.halt == LM_RUN) {
+    D.halt = LM_RUN;
+    g.cg->op_s = UNI_NOP;
+    g.cg->op_v = UNI_V_HEAD;
+    g.scal->halt = 0;
+  }
+}
+__global__ void k_lm_publish(DeviceGraph g) { publish_sequence(g); }
 
 // ------------------------------------------------------------------------------------------------
 // Batched solve of independent graphs (BatchPlan): the per-component pieces of the LM iteration.
@@ -1745,6 +2287,30 @@ void launch_accept_finish(const DeviceGraph& g, int seq_id, hipStream_t s) {
 void launch_lm_resume(const DeviceGraph& g, int cg_goes_on, hipStream_t s) {
   hipLaunchKernelGGL(k_lm_resume, dim3(1), dim3(1), 0, s, g, cg_goes_on);
 }
+static inline int uni_v_grid(const DeviceGraph& g) { return std::max(g.n_vec_wg, g.n_edge_wg + g.n_pose_wg); }
+bool uni_supported(const DeviceGraph& g) { return g.world == 1 && g.block <= 256; }
+void launch_uni_s(const DeviceGraph& g, const CgParams& p, int period, hipStream_t s) {
+  const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);
+#define PGO_UNI_S(PK, INF) hipLaunchKernelGGL((k_uni_s<PK, INF>), dim3(g.n_wg), dim3(g.block), lds, s, g, p, period)
+  if (g.blk_packed) {         // info modes 0, 2, 3 (prepare(): general information, or PGO_BLK_FULL=1, keeps 36-entry slots and mode 1)
+    if (g.info_mode == 3) PGO_UNI_S(true, 3);
+    else if (g.info_mode == 2) PGO_UNI_S(true, 2);
+    else PGO_UNI_S(true, 0);
+  } else if (g.info_mode == 0) PGO_UNI_S(false, 0);
+  else PGO_UNI_S(false, 1);
+#undef PGO_UNI_S
+}
+void launch_uni_v(const DeviceGraph& g, const CgParams& p, double min_diag, double max_diag, hipStream_t s) {
+  const int grid = uni_v_grid(g);
+#define PGO_UNI_V(CLV) do { if (g.info_mode) hipLaunchKernelGGL((k_uni_v<CLV, 1>), dim3(grid), dim3(UNI_V_BLOCK), 0, s, g, p, min_diag, max_diag); \
+                            else hipLaunchKernelGGL((k_uni_v<CLV, 0>), dim3(grid), dim3(UNI_V_BLOCK), 0, s, g, p, min_diag, max_diag); } while (0)
+  if (g.cluster == 2) PGO_UNI_V(2);
+  else if (g.cluster == 4) PGO_UNI_V(4);
+  else PGO_UNI_V(1);
+#undef PGO_UNI_V
+}
+void launch_lm_budget(const DeviceGraph& g, int decisions, hipStream_t s) { hipLaunchKernelGGL(k_lm_budget, dim3(1), dim3(1), 0, s, g, decisions); }
+void launch_lm_publish(const DeviceGraph& g, hipStream_t s) { hipLaunchKernelGGL(k_lm_publish, dim3(1), dim3(1), 0, s, g); }
 void launch_finalize_scalars(const DeviceGraph& g, int n_cost_part, hipStream_t s, int gate) {
   hipLaunchKernelGGL(k_finalize_scalars, dim3(1), dim3(256), 0, s, g, n_cost_part, gate);
 }

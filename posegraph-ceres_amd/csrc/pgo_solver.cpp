@@ -355,6 +355,8 @@ struct pgo_problem {
   int pipe_last_nb = 0;            // CG iterations in the last sequence enqueued
   int pipe_pulled = 0;             // next iteration record to copy from the pinned ring into LmState::records
   bool pipe_dirty = true;          // LmState was (re)initialised by the host: upload it before the next sequence
+  bool universal = false;          // PCG on one rank: the universal stream (pgo_kernels.h UniOp) instead of allotted sequences
+  int uni_enq = 0;                 // vector-shaped launches of the stream enqueued since the last upload
   double pipe_t_linear0 = 0, pipe_t_jacobian0 = 0;   // LmState times when the device clocks were last zeroed
   // captured CG batches, keyed by the number of iterations in the batch
   struct CapturedBatch { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
@@ -1442,6 +1444,7 @@ int evaluate_gradient_and_jacobian(pgo_problem* P, bool first) {
 }
 
 bool pipeline_wanted(const pgo_problem* P);
+bool universal_wanted(const pgo_problem* P);
 int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   P->want_direct = options->linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY;
   int rc = prepare(P);
@@ -1503,6 +1506,7 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   L.pending_record = true;
   L.active = true;
   P->pipelined = pipeline_wanted(P);
+  P->universal = universal_wanted(P);
   P->pipe_dirty = true;
   L.t_total += seconds_since(t0);
   if (!std::isfinite(L.x_cost)) {
@@ -1826,6 +1830,12 @@ int lm_upload_state(pgo_problem* P) {
   D.tol = lm_tolerances(o);
   D.min_diag = o.min_lm_diagonal; D.max_diag = o.max_lm_diagonal;
   HIP_TRY(hipStreamSynchronize(P->stream));      // nobody writes the pinned block while the host fills it
+  if (P->universal) {
+    HIP_TRY(P->d_cg.zero(P->stream));            // the stream's operation words and its launch counter (the budget kernel opens it)
+    HIP_TRY(P->d_flags.zero(P->stream));
+    P->uni_enq = 0;
+    P->scal->slots_done = 0;
+  }
   P->scal->lm = D;
   P->scal->lm_done = 0; P->scal->halt = 0; P->scal->last_cg = D.last_cg;
   P->scal->seq_done = P->pipe_seq;
@@ -1931,6 +1941,84 @@ int pipe_drain(pgo_problem* P) {
     }
   }
   HIP_TRY(hipGetLastError());
+  return PGO_OK;
+}
+
+// ---- the universal stream (pgo_kernels.h UniOp): PCG on one rank ---------------------------------------------------------------
+// The host enqueues  V S V S ...  and nothing else; what each launch does is the device's business.  It keeps between `lo` and
+// `hi` pairs ahead of the device's launch counter — enough that the GPU never waits for a launch (a pair is ~13 us of work), few
+// enough that the launches left over when the stream stops (terminated, or the step budget of pgo_solver_step used up) drain in
+// well under 0.1 ms.
+bool universal_wanted(const pgo_problem* P) {
+  const bool off = getenv("PGO_NO_PIPELINE") && getenv("PGO_NO_PIPELINE")[0] == '1';
+  const char* u = getenv("PGO_UNI");
+  if (off || (u && u[0] == '0') || P->g.world != 1 || (P->comm && P->comm->world > 1) || P->use_graph) return false;
+  const bool direct = P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY && P->direct_usable;
+  if (direct || !pgo::uni_supported(P->g)) return false;
+  // large graphs (kernels of 100+ us) gain nothing from it and the slot kernel's LDS footprint (the linearisation's) would cost the
+  // SpMV occupancy there: they keep the host-driven loop
+  const long long limit = getenv("PGO_UNI_MAX_SLOTS") ? atoll(getenv("PGO_UNI_MAX_SLOTS")) : 600000;
+  return (u && u[0] == '1') || P->g.n_slots <= limit;
+}
+
+int lm_run_universal(pgo_problem* P, int budget, int* ran) {
+  LmState& L = P->lm;
+  const pgo_solver_options& o = P->opt;
+  hipStream_t s = P->stream;
+  if (ran) *ran = 0;
+  if (L.terminated || budget == 0) return PGO_OK;
+  const auto t_run = Clock::now();
+  if (!lm_pre_step(L, o)) { L.t_total += seconds_since(t_run); return PGO_OK; }
+  if (P->pipe_dirty) {
+    int rc0 = lm_upload_state(P);
+    if (rc0) return rc0;
+    P->pipe_dirty = false;
+  }
+  static const int hi = getenv("PGO_UNI_AHEAD") ? std::max(2, atoi(getenv("PGO_UNI_AHEAD"))) : 12;
+  const int lo = std::max(1, hi / 3);
+  const pgo::CgParams prm = cg_params_for(o);
+  const int period = prm.q_tolerance < 0.0 ? 0 : o.cg_residual_reset_period;
+  pgo::DeviceGraph gp = P->g;
+  gp.lm = P->d_lm.p;
+  const int d0 = __atomic_load_n(&P->scal->lm_done, __ATOMIC_ACQUIRE);
+  P->scal->halt = 0;
+  pgo::launch_lm_budget(gp, budget, s);
+  unsigned idle_spins = 0;
+  auto t_idle = Clock::now();
+  for (;;) {
+    if (__atomic_load_n(&P->scal->halt, __ATOMIC_ACQUIRE)) break;
+    const int pending = P->uni_enq - __atomic_load_n(&P->scal->slots_done, __ATOMIC_ACQUIRE);
+    if (pending <= hi - lo) {
+      for (int i = 0; i < lo; ++i) {
+        pgo::launch_uni_v(gp, prm, o.min_lm_diagonal, o.max_lm_diagonal, s);
+        pgo::launch_uni_s(gp, prm, period, s);
+        ++P->uni_enq;
+      }
+      lm_pull_records(P, false);
+      idle_spins = 0; t_idle = Clock::now();
+      continue;
+    }
+    __builtin_ia32_pause();
+    if ((++idle_spins & 0xfff) == 0 && seconds_since(t_idle) > 0.5) {
+      HIP_TRY(hipStreamSynchronize(s));
+      if (P->uni_enq != __atomic_load_n(&P->scal->slots_done, __ATOMIC_ACQUIRE))
+        return set_error(PGO_ERR_HIP, "the universal LM stream stopped reporting progress (%d of %d launches)", P->scal->slots_done, P->uni_enq);
+      t_idle = Clock::now();
+    }
+  }
+  // whatever was enqueued behind the halt exits at once; one more launch tells the host when the stream has drained
+  arm_handoff(P);
+  pgo::launch_lm_publish(gp, s);
+  int rc = wait_handoff(P);
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  const int d1 = P->scal->lm_done;
+  lm_pull_state(P);
+  L.num_trial_steps += d1 - d0;
+  if (ran) *ran = d1 - d0;
+  const pgo::LmDev& M = P->scal->lm;
+  if (M.halt == pgo::LM_HALT_TERMINATED) terminate_by_reason(L, o, M.termination, M.reason, M.term_value);
+  L.t_total += seconds_since(t_run);
   return PGO_OK;
 }
 
@@ -2521,8 +2609,8 @@ int pgo_solver_begin(pgo_problem* P, const pgo_solver_options* options) {
 int pgo_solver_step(pgo_problem* P, int n, int* executed, int* done) {
   if (!P || !P->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_step without pgo_solver_begin");
   int ran = 0;
-  if (P->pipelined) {
-    int rc = lm_run_pipelined(P, n, &ran);
+  if (P->pipelined || P->universal) {
+    int rc = P->universal ? lm_run_universal(P, n, &ran) : lm_run_pipelined(P, n, &ran);
     if (rc) { P->lm.active = false; return rc; }
     if (executed) *executed = ran;
     if (done) *done = P->lm.terminated ? 1 : 0;
@@ -2580,7 +2668,7 @@ int pgo_solve(pgo_problem* P, const pgo_solver_options* options, pgo_solver_summ
   int rc = lm_begin(P, options);
   if (rc) return rc;
   while (!P->lm.terminated) {
-    rc = P->pipelined ? lm_run_pipelined(P, -1, nullptr) : lm_advance(P);
+    rc = P->universal ? lm_run_universal(P, -1, nullptr) : P->pipelined ? lm_run_pipelined(P, -1, nullptr) : lm_advance(P);
     if (rc) { P->lm.active = false; return rc; }   // caller memory keeps the poses it came with; the session is closed
   }
   return lm_end(P, summary, records, capacity);
