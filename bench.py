@@ -13,6 +13,12 @@ A "step" is one LM iteration (trial step solve + candidate cost + accept/reject 
 acceptance).  The timed region starts from the dead-reckoning state with all inputs resident in HBM and
 runs exactly K LM iterations; `value` = edges x LM-iterations per second over all ranks.
 Prints ONE JSON line on rank 0.
+
+N > 1 (one process per GPU, RCCL): the headline is BASELINE.json configs[3] — ONE synthetic graph of 100 000 poses / 1 000 000
+edges (seed 20260930), pose rows sharded over the N ranks, the same total work whatever N ("scaling": "strong") — with, in the
+same line, the same graph timed on ONE GPU of the node (`one_gpu_same_workload`: the reference point of the scaling curve, since
+the N = 1 run of this script times configs[1]), the weak-scaling run of r01/r02 (N x (10 k, 40 k) sharded) and N independent
+replicas as extras.
 """
 import argparse
 import json
@@ -26,6 +32,7 @@ sys.path.insert(0, ROOT)
 N_POSES = 10000
 N_EDGES = 40000
 SEED = 20260928
+C4_POSES, C4_EDGES, C4_SEED = 100000, 1000000, 20260930     # BASELINE.json configs[3]
 SHARDED_LIMIT_S = int(os.environ.get("PGO_BENCH_SHARDED_LIMIT_S", "300"))   # N > 1: the row-sharded run is abandoned (replica figures printed instead) after this long
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -133,15 +140,16 @@ def main():
         med = order[len(order) // 2]
         return med[0], med[1], [round(1e3 * e / args.steps, 4) for e, _ in samples]
 
-    def record(value, elapsed, parallelism, total_poses, total_edges):
+    def record(value, elapsed, parallelism, total_poses, total_edges, workload=None, scaling="weak", seed=SEED):
         return {
             "metric": "lm_edge_iterations_per_sec", "value": round(value, 1), "unit": "edge-LM-iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Synthetic Manhattan SE3 graph, %d poses / %d odom+loop edges per GPU, block-Jacobi PCG "
-                                   "(eta=0.1, <=500 it), Huber(1.0), LM from dead reckoning" % (args.poses, args.edges),
-                       "poses_per_gpu": args.poses, "edges_per_gpu": args.edges, "total_poses": total_poses,
-                       "total_edges": total_edges, "seed": SEED,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload or ("Synthetic Manhattan SE3 graph, %d poses / %d odom+loop edges per GPU, block-Jacobi PCG "
+                                                "(eta=0.1, <=500 it), Huber(1.0), LM from dead reckoning" % (args.poses, args.edges)),
+                       "poses_per_gpu": total_poses // max(1, world) if scaling == "strong" else args.poses,
+                       "edges_per_gpu": total_edges // max(1, world) if scaling == "strong" else args.edges, "total_poses": total_poses,
+                       "total_edges": total_edges, "seed": seed,
                        "preconditioner": "block-Jacobi, %d-pose chain clusters (%dx%d blocks)" % (args.cluster, 6 * args.cluster, 6 * args.cluster),
                        "parallelism": parallelism}}
 
@@ -173,33 +181,74 @@ def main():
         watchdog = threading.Timer(SHARDED_LIMIT_S, give_up)
         watchdog.daemon = True
 
-    if sharded:
-        g = ds.manhattan_se3(args.poses * world, args.edges * world, seed=SEED)
-    else:
-        g = ds.manhattan_se3(args.poses, args.edges, seed=SEED + rank)
-    N, E = g.N, g.E
-    prob, poses = pkg.problem_from_graph(g)
+    c4_headline = sharded and (args.poses, args.edges) == (N_POSES, N_EDGES)      # N > 1: BASELINE configs[3], strong scaling
+    weak_extra = one_gpu_extra = None
     if sharded:
         watchdog.start()
         try:
-            box = [pkg.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            prob.comm_init(box[0], rank, world)
-            prob.solver_begin(opt)
-            elapsed, resets, samples_ms = timed_region(prob)
+            def sharded_run(graph):
+                pr, _ = pkg.problem_from_graph(graph)
+                box = [pkg.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                pr.comm_init(box[0], rank, world)
+                pr.solver_begin(opt)
+                return (pr,) + timed_region(pr)
+
+            if c4_headline:
+                # the weak-scaling figure of r01 / r02 first (one graph of N x (10 k, 40 k)), as an extra
+                gw = ds.manhattan_se3(args.poses * world, args.edges * world, seed=SEED)
+                pw, el_w, _, _ = sharded_run(gw)
+                pw.solver_end()
+                weak_extra = {"value": round(gw.E * args.steps / el_w, 1), "unit": "edge-LM-iterations/s", "ms_per_step": round(1e3 * el_w / args.steps, 4),
+                              "scaling": "weak", "note": "one graph of %d x (%d poses, %d edges), rows sharded over %d ranks (the headline of r01 / r02)"
+                                                         % (world, args.poses, args.edges, world)}
+                del pw, gw
+                g = ds.manhattan_se3(C4_POSES, C4_EDGES, seed=C4_SEED, loop_radius=3.0)
+                # the same graph on ONE GPU of this node (rank 0, no communicator; the other ranks wait at the barrier): the
+                # N = 1 run of this script times configs[1], so the scaling curve's reference point travels in this line
+                if rank == 0:
+                    p1, _ = pkg.problem_from_graph(g)
+                    p1.solver_begin(opt)
+                    p1.solver_step(args.warmup)
+                    t_pw = time.perf_counter()
+                    while time.perf_counter() - t_pw < args.prewarm:
+                        p1.solver_reset(); run_steps(p1, args.steps); torch.cuda.synchronize()
+                    s1 = []
+                    for _ in range(max(1, args.repeats)):
+                        p1.solver_reset(); torch.cuda.synchronize()
+                        t0 = time.perf_counter(); run_steps(p1, args.steps); torch.cuda.synchronize()
+                        s1.append(time.perf_counter() - t0)
+                    p1.solver_end()
+                    el1 = sorted(s1)[len(s1) // 2]
+                    one_gpu_extra = {"value": round(g.E * args.steps / el1, 1), "unit": "edge-LM-iterations/s",
+                                     "ms_per_step": round(1e3 * el1 / args.steps, 4), "n_gpus": 1,
+                                     "note": "the headline graph (100 k poses / 1 M edges) on one GPU of this node, same options, same K steps"}
+                    del p1
+                barrier()
+            else:
+                g = ds.manhattan_se3(args.poses * world, args.edges * world, seed=SEED)
+            prob, elapsed, resets, samples_ms = sharded_run(g)
         except Exception as exc:   # noqa: BLE001 - any failure of the untested-on-hardware path ends in the labelled fallback line
             sys.stderr.write("sharded run failed on rank %d: %r\n" % (rank, exc))
             give_up("failed: %s" % (str(exc)[:200],))
         watchdog.cancel()
     else:
+        g = ds.manhattan_se3(args.poses, args.edges, seed=SEED + rank)
+        prob, poses = pkg.problem_from_graph(g)
         prob.solver_begin(opt)
         elapsed, resets, samples_ms = timed_region(prob)
+    N, E = g.N, g.E
 
     # ---- per-kernel durations, HIP events on the solver stream (rank 0) ----
     roofline = None
     extra = {}
     if replica_extra is not None:
         extra["independent_replicas"] = replica_extra
+    if weak_extra is not None:
+        extra["weak_scaling_c2_per_gpu"] = weak_extra
+    if one_gpu_extra is not None:
+        extra["one_gpu_same_workload"] = one_gpu_extra
+        extra["speedup_vs_one_gpu_same_workload"] = round(elapsed and (one_gpu_extra["ms_per_step"] / (1e3 * elapsed / args.steps)), 3)
     if rank == 0:
         reps = 400
         t_spmv = prob.time_kernel("pcg_spmv", reps)
@@ -258,7 +307,7 @@ def main():
                                   "evaluate_edges": round(t_eval * 1e3, 3)}
     summary = prob.solver_end()
     # the same K steps with plain 6x6 pose-block Jacobi (Ceres JACOBI-like), for transparency
-    if rank == 0 and args.cluster != 1 and world == 1:
+    if rank == 0 and args.cluster != 1 and world == 1 and not sharded:
         opt.pcg_cluster_poses = 1
         poses[:] = g.poses          # solver_end wrote the optimised poses back: restart from dead reckoning
         prob.solver_begin(opt)
@@ -276,7 +325,7 @@ def main():
 
     # ---- kernel rooflines at C4 size (at <= 25 k poses the kernels are latency-bound, "quote HBM fraction
     # only for C4"): same kernels, 100 k poses / 1 M edges on this one GPU, outside the timed region ----
-    if rank == 0 and world == 1 and not args.no_c4_kernels and (args.poses, args.edges) == (N_POSES, N_EDGES):
+    if rank == 0 and world == 1 and not sharded and not args.no_c4_kernels and (args.poses, args.edges) == (N_POSES, N_EDGES):
         g4 = ds.manhattan_se3(100000, 1000000, seed=20260930, loop_radius=3.0)
         p4, _ = pkg.problem_from_graph(g4)
         o4 = pkg.SolverOptions(max_num_iterations=2 ** 30, linear_solver_type=pkg.BLOCK_JACOBI_PCG, eta=0.1,
@@ -300,7 +349,7 @@ def main():
     # ---- exact requests (the reference's own linear solver setting, SPARSE_NORMAL_CHOLESKY) through pgo_solve: host buffers in
     # and out, setup included — BASELINE.json's metric is quoted on "KITTI-00-scale" graphs ----
     mfma = {"utilisation": 0.0, "note": "exact-solver blocks skipped"}
-    if rank == 0 and world == 1 and not args.no_exact_blocks:
+    if rank == 0 and world == 1 and not sharded and not args.no_exact_blocks:
         from oracle import oracle as O
         kz = np.load(os.path.join(ROOT, "tests", "golden", "kitti00.npz"))
         offs = kz["cand_offsets"]
@@ -381,7 +430,7 @@ def main():
 
     # ---- CPU baseline on this box's host cores, rank 0, bounded sample ----
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and not sharded:
         from oracle import oracle as O
         og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
         k = max(1, args.cpu_iters)
@@ -436,10 +485,13 @@ def main():
     if rank == 0:
         total_edges = E if sharded else E * world
         out = record(total_edges * args.steps / elapsed, elapsed,
-                     ("single GPU" if world == 1 else
-                      "one graph row-sharded over %d ranks, 1 RCCL all-gather per CG iteration" % world if sharded else
+                     ("single GPU" if world == 1 and not sharded else
+                      "one graph, pose rows sharded over %d ranks (one process per GPU), 1 RCCL all-gather over xGMI per CG iteration" % world if sharded else
                       "replicas: 1 independent graph per GPU, no data-path collective"),
-                     N if sharded or world == 1 else N * world, total_edges)
+                     N if sharded or world == 1 else N * world, total_edges,
+                     workload=("BASELINE configs[3]: synthetic Manhattan SE3 graph, %d poses / %d odom+loop edges in TOTAL (seed %d), row-sharded over "
+                               "%d GPUs, block-Jacobi PCG (eta=0.1, <=500 it), Huber(1.0), LM from dead reckoning" % (N, E, C4_SEED, world)) if c4_headline else None,
+                     scaling="strong" if c4_headline else "weak", seed=C4_SEED if c4_headline else SEED)
         out.update({
             "lm_iters_per_sec": round(args.steps * (1 if sharded else world) / elapsed, 2),
             "cg_iterations_in_solver_state": summary.num_linear_solver_iterations,

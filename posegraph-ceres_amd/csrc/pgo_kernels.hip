@@ -13,6 +13,7 @@
 //   * k_pcg_spmv    : lane multiplies its block with the gathered 6-vector, LDS segmented row sums.
 // Everything is FP64 and HBM/L2 bound; MFMA is deliberately not used for 6x6 blocks.
 #include <algorithm>
+#include <cstdlib>
 
 #include "pgo_kernels.h"
 #include "pgo_lm_rules.h"
@@ -172,13 +173,27 @@ __device__ __forceinline__ WBlocks load_W_diag(const double* W, size_t stride, s
 // gate: a speculative launch behind the step tail of a CG batch (the linearisation of the candidate point into the spare buffers)
 // runs only once the CG has stopped, like the tail itself.
 // (the body is shared with the universal slot kernel k_uni_s further down)
-template <int INFO>
+template <int INFO, int PASSES = 1>
 __device__ __forceinline__ void linearize_body(const DeviceGraph& g, double* lds) {
+  constexpr int NVP = (NV_LIN + PASSES - 1) / PASSES;   // values per round
+  constexpr int NVS = NVP | 1;                          // LDS stride per lane (odd)
   const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
   const int s_begin = g.wg_slot_begin[wg], s_end = g.wg_slot_begin[wg + 1];
   const int r0 = g.wg_row_begin[wg], nrows = g.wg_row_begin[wg + 1] - r0;
   const bool single = (s_end - s_begin) == B;
-  double acc = 0.0;
+  double acc[PASSES];
+  // the row bookkeeping of this lane's first sum of every round, requested before anything else (it used to be a dependent global
+  // load behind the barrier)
+  int pre_rb[PASSES], pre_rc[PASSES];
+  uint8_t pre_cm[PASSES];
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    acc[ps] = 0.0; pre_rb[ps] = 0; pre_rc[ps] = 0; pre_cm[ps] = 0;
+    if (tid < nrows * NVP) {
+      const int row = r0 + tid / NVP;
+      pre_rb[ps] = g.row_slot_begin[row]; pre_rc[ps] = g.row_slot_cnt[row]; pre_cm[ps] = g.cmask[row];
+    }
+  }
 
   for (int cb = s_begin; cb < s_end; cb += B) {
     const int t = cb + tid;
@@ -316,52 +331,75 @@ __device__ __forceinline__ void linearize_body(const DeviceGraph& g, double* lds
       for (int i = 0; i < 6; ++i) v[21 + i] = rho1 * mo[i] * gv[i];
     }
 
+    // per-row sums of the 27 values through LDS, in PASSES rounds of NVP values (stride NVS doubles per lane: odd, so the 8-byte
+    // writes of a wave are conflict-free).  One round needs 27 * 8 B of LDS per lane — 55 KB per 256 lanes, two work-groups per CU;
+    // two rounds of 14 / 13 values need 15 * 8 B.  Measured in r03 (100 k poses / 1 M edges): the kernel holds 219 VGPRs (2 waves per
+    // SIMD), so fewer LDS bytes alone buy no occupancy, and capping the registers to 168 / 128 (amdgpu_waves_per_eu 3 / 4) makes the
+    // compiler spill 176 / 372 bytes per lane: 244 us -> 423 / 409 (one / two rounds, 3 waves) -> 602 / 627 us (two / three rounds,
+    // 4 waves).  PASSES stays 1.
 #pragma unroll
-    for (int k = 0; k < NV_LIN; ++k) lds[tid * NV_LIN + k] = v[k];
-    __syncthreads();
-    for (int idx = tid; idx < nrows * NV_LIN; idx += B) {
-      const int rl = idx / NV_LIN, k = idx - rl * NV_LIN;
-      const int row = r0 + rl;
-      const int rb = g.row_slot_begin[row];
-      const int sb = max(rb, cb) - cb, se = min(rb + g.row_slot_cnt[row], cb + B) - cb;
-      double s = 0.0;
-      for (int j = sb; j < se; ++j) s += lds[j * NV_LIN + k];
-      if (single) {
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int k0 = ps * NVP;
+#pragma unroll
+      for (int k = 0; k < NVP; ++k) if (k0 + k < NV_LIN) lds[tid * NVS + k] = v[k0 + k];
+      __syncthreads();
+      for (int idx = tid; idx < nrows * NVP; idx += B) {
+        const int rl = idx / NVP, kk = idx - rl * NVP, k = k0 + kk;
+        if (k >= NV_LIN) continue;
+        const int row = r0 + rl;
+        const bool first = idx == tid && cb == s_begin;
+        const int rb = first ? pre_rb[ps] : g.row_slot_begin[row];
+        const int rc = first ? pre_rc[ps] : g.row_slot_cnt[row];
+        const int sb = max(rb, cb) - cb, se = min(rb + rc, cb + B) - cb;
+        double s0 = 0.0, s1 = 0.0;
+        int j = sb;
+        for (; j + 1 < se; j += 2) { s0 += lds[j * NVS + kk]; s1 += lds[(j + 1) * NVS + kk]; }
+        if (j < se) s0 += lds[j * NVS + kk];
+        double s = s0 + s1;
+        if (single) {
+          if (k < 21) {
+            // k -> (i,j) of the upper triangle
+            int i = 0, base = 0;
+            while (k >= base + (6 - i)) { base += 6 - i; ++i; }
+            const int j2 = i + (k - base);
+            if (i == j2) {
+              const uint8_t cmk = first ? pre_cm[ps] : g.cmask[row];
+              const bool c = (i < 3) ? (cmk & 1) : (cmk & 2);
+              if (c) s = 1.0;  // unit diagonal keeps the constant dims decoupled and the block SPD
+            }
+            g.Hdiag[36 * (size_t)row + 6 * i + j2] = s;
+            g.Hdiag[36 * (size_t)row + 6 * j2 + i] = s;
+          } else {
+            g.grad[6 * (size_t)row + (k - 21)] = s;
+          }
+        } else {
+          acc[ps] += s;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (!single) {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int k = ps * NVP + tid;
+      if (tid < NVP && k < NV_LIN) {
+        const int row = r0;
+        double s = acc[ps];
         if (k < 21) {
-          // k -> (i,j) of the upper triangle
           int i = 0, base = 0;
           while (k >= base + (6 - i)) { base += 6 - i; ++i; }
           const int j = i + (k - base);
           if (i == j) {
             const bool c = (i < 3) ? (g.cmask[row] & 1) : (g.cmask[row] & 2);
-            if (c) s = 1.0;  // unit diagonal keeps the constant dims decoupled and the block SPD
+            if (c) s = 1.0;
           }
           g.Hdiag[36 * (size_t)row + 6 * i + j] = s;
           g.Hdiag[36 * (size_t)row + 6 * j + i] = s;
         } else {
           g.grad[6 * (size_t)row + (k - 21)] = s;
         }
-      } else {
-        acc += s;
       }
-    }
-    __syncthreads();
-  }
-  if (!single && tid < NV_LIN) {
-    const int row = r0, k = tid;
-    double s = acc;
-    if (k < 21) {
-      int i = 0, base = 0;
-      while (k >= base + (6 - i)) { base += 6 - i; ++i; }
-      const int j = i + (k - base);
-      if (i == j) {
-        const bool c = (i < 3) ? (g.cmask[row] & 1) : (g.cmask[row] & 2);
-        if (c) s = 1.0;
-      }
-      g.Hdiag[36 * (size_t)row + 6 * i + j] = s;
-      g.Hdiag[36 * (size_t)row + 6 * j + i] = s;
-    } else {
-      g.grad[6 * (size_t)row + (k - 21)] = s;
     }
   }
 }
