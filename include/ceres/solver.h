@@ -450,6 +450,8 @@ inline void Solver::Solve(const Options& options, Problem* problem, Summary* sum
   for (std::set<double*>::const_iterator it = problem->constant_blocks().begin(); it != problem->constant_blocks().end(); ++it)
     if (pgo_problem_set_parameter_block_constant(P, *it) < 0) { /* constant block that appears in no residual: nothing to do */ }
 
+  if (pgo_version() != PGO_VERSION)    // the library writes sizeof(pgo_solver_summary) bytes of ITS header: a mismatch would overrun summary->raw
+    return internal::Fail(summary, "libpgo_hip.so and include/pgo.h disagree on PGO_VERSION (rebuild against the header of the library in use)");
   pgo_solver_options o;
   pgo_solver_options_init(&o);
   o.max_num_iterations = options.max_num_iterations;

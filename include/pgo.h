@@ -24,7 +24,11 @@
 extern "C" {
 #endif
 
-#define PGO_VERSION 100
+/* ABI version: bumped whenever a struct below changes size or layout (101: pgo_solver_summary grew by the factor_* /
+ * *_reduced fields in r02).  pgo_solve / pgo_solver_end / pgo_solve_batch write sizeof(pgo_solver_summary) bytes: a caller must
+ * check pgo_version() == PGO_VERSION of the header it was compiled against before handing structs over (the facade's
+ * ceres::Solve does, include/ceres/solver.h). */
+#define PGO_VERSION 101
 
 typedef struct pgo_problem pgo_problem;
 

@@ -169,7 +169,13 @@ struct DevicePool {
       }
     }
     *cap = bytes;
-    return hipMalloc(out, bytes);
+    e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {      // the library itself may be holding the memory (blocks of other sizes): give it back and try once more
+      (void)hipGetLastError();
+      trim();
+      e = hipMalloc(out, bytes);
+    }
+    return e;
   }
   void put(void* p, size_t cap, int dev) {
     {
@@ -2202,6 +2208,13 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
   const pgo_solver_options& o = *options;
   if (o.linear_solver_type != PGO_SPARSE_NORMAL_CHOLESKY)
     return set_error(PGO_ERR_UNSUPPORTED, "pgo_solve_batch serves exact requests (PGO_SPARSE_NORMAL_CHOLESKY) only");
+  if (!probs || n <= 0) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solve_batch: no problems");
+  for (int c = 0; c < n; ++c) {
+    if (!probs[c] || probs[c]->pp.empty()) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solve_batch: problem %d is null or empty", c);
+    if (probs[c]->device != probs[0]->device)
+      return set_error(PGO_ERR_UNSUPPORTED, "pgo_solve_batch: problem %d lives on device %d, problem 0 on device %d (one batch = one GPU)", c,
+                       probs[c]->device, probs[0]->device);
+  }
   // ---- the union ----
   pgo_problem M;
   M.device = probs[0]->device;
@@ -2996,6 +3009,22 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *avg_ms = (double)ms / repeats;
+  if (wants_factor) {
+    // the factorisations report through flags[2] (bit 0: pivot, bit 1: an in-kernel wait of a single-launch form ran out); nobody
+    // folds it here, so read and clear it: a timed-out wait means the figure is worthless and the next LM iteration must not
+    // inherit the bit
+    int f2 = 0;
+    HIP_TRY(hipMemcpyAsync(&f2, P->d_flags.p + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(P->d_flags.p + 2, 0, sizeof(int), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (f2 & 2) {
+      if (P->front_usable) P->front_launches = true; else if (P->sfront_usable) P->sfront_levels = true; else P->split_two_launch = true;
+      int rc = resync_direct_counters(P);
+      if (rc) return rc;
+      return set_error(PGO_ERR_NUMERICAL, "pgo_time_kernel('%s'): an in-kernel wait of the single-launch factorisation timed out; the "
+                       "problem now uses one launch per step, time it again", kernel);
+    }
+  }
   return PGO_OK;
 }
 
