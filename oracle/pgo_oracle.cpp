@@ -30,14 +30,66 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <numeric>
 #include <queue>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <set>
+#include <thread>
 #include <vector>
 
 namespace {
+
+// ---- threads (the CPU baseline "single-thread and all-cores") ----------------------------------------------------
+// A fixed pool; run(n, fn) calls fn(i) for i in [0, n) on the pool's threads (dynamic pick) and returns when all are done.  Every
+// threaded routine below produces the bits of its sequential form: work is split by OWNER (a block is only ever added to by one
+// thread, in edge order) or by independent subtrees of the elimination tree, never by a reduction whose order depends on timing.
+class Pool {
+ public:
+  explicit Pool(int nthreads) : n_(std::max(1, nthreads)) {
+    for (int t = 1; t < n_; ++t) workers_.emplace_back([this] { loop(); });
+  }
+  ~Pool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  int width() const { return n_; }
+  void run(int n, const std::function<void(int)>& fn) {
+    if (n_ == 1 || n <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    { std::lock_guard<std::mutex> lk(mu_); fn_ = &fn; total_ = n; next_.store(0); pending_ = (int)workers_.size(); ++gen_; }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [this] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+ private:
+  void work() { for (int i; (i = next_.fetch_add(1)) < total_;) (*fn_)(i); }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return gen_ != seen; }); seen = gen_; if (stop_) return; }
+      work();
+      { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) done_cv_.notify_one(); }
+    }
+  }
+  int n_;
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int total_ = 0, pending_ = 0;
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+};
 
 // ---------------------------------------------------------------------------------------------
 // Forward-mode dual number, the role Jet<double,14> plays in Ceres' AutoDiffCostFunction.
@@ -391,6 +443,19 @@ double total_cost(const Prob& P, const double* poses) {
   for (int e = 0; e < P.E; ++e) c += edge_linearize(P, poses, e, r, nullptr, nullptr, false);
   return c;
 }
+// threaded: the per-edge terms in parallel, their sum in edge order (the bits of total_cost)
+double total_cost_mt(const Prob& P, const double* poses, Pool& pool, std::vector<double>& term) {
+  term.resize((size_t)P.E);
+  const int chunks = pool.width() * 4;
+  pool.run(chunks, [&](int c) {
+    const int lo = (int)((long long)P.E * c / chunks), hi = (int)((long long)P.E * (c + 1) / chunks);
+    double r[6];
+    for (int e = lo; e < hi; ++e) term[(size_t)e] = edge_linearize(P, poses, e, r, nullptr, nullptr, false);
+  });
+  double c = 0;
+  for (int e = 0; e < P.E; ++e) c += term[(size_t)e];
+  return c;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Block-sparse normal equations, 6x6 pose blocks.  Lower triangle by block column:
@@ -480,6 +545,53 @@ double linearize(const Prob& P, const double* poses, BlockSym& H, std::vector<do
       if (c) D[7 * i] = 1.0;
     }
   }
+  return cost;
+}
+
+// threaded linearize: residuals and Jacobians of all edges in parallel, then every thread walks ALL edges in order and adds only
+// into the blocks / gradient rows of the poses it owns (a contiguous range): each block receives its terms in edge order, as in
+// linearize(), so the result is the same to the bit.
+struct EdgeLin { double r[6], Ja[36], Jb[36], cost; };
+double linearize_mt(const Prob& P, const double* poses, BlockSym& H, std::vector<double>& g, Pool& pool, std::vector<EdgeLin>& el) {
+  el.resize((size_t)P.E);
+  g.assign((size_t)6 * P.N, 0.0);
+  const int T = pool.width(), chunks = T * 4;
+  pool.run(chunks, [&](int c) {
+    const int lo = (int)((long long)P.E * c / chunks), hi = (int)((long long)P.E * (c + 1) / chunks);
+    for (int e = lo; e < hi; ++e) { EdgeLin& L = el[(size_t)e]; L.cost = edge_linearize(P, poses, e, L.r, L.Ja, L.Jb, true); }
+  });
+  pool.run(T, [&](int t) {
+    const int v0 = (int)((long long)P.N * t / T), v1 = (int)((long long)P.N * (t + 1) / T);
+    auto mine = [&](int v) { return v >= v0 && v < v1; };
+    for (int v = v0; v < v1; ++v)
+      for (int p = H.colptr[v]; p < H.colptr[v + 1]; ++p) H.val[p].fill(0.0);     // column v: its diagonal block and the blocks below it
+    for (int e = 0; e < P.E; ++e) {
+      const int a = P.ia[e], b = P.ib[e];
+      const bool ma = mine(a), mb = mine(b);
+      if (!ma && !mb) continue;
+      const EdgeLin& L = el[(size_t)e];
+      if (ma) atb_add(L.Ja, L.Ja, H.val[H.colptr[a]].data());
+      if (mb) atb_add(L.Jb, L.Jb, H.val[H.colptr[b]].data());
+      if (a != b && mine(std::min(a, b))) {       // the off-diagonal block lives in column min(a, b)
+        if (H.edge_transposed[e]) atb_add(L.Jb, L.Ja, H.val[H.edge_slot[e]].data());
+        else atb_add(L.Ja, L.Jb, H.val[H.edge_slot[e]].data());
+      }
+      for (int i = 0; i < 6; ++i)
+        for (int k = 0; k < 6; ++k) {
+          if (ma) g[6 * (size_t)a + i] += L.Ja[6 * k + i] * L.r[k];
+          if (mb) g[6 * (size_t)b + i] += L.Jb[6 * k + i] * L.r[k];
+        }
+    }
+    for (int v = v0; v < v1; ++v) {
+      double* D = H.val[H.colptr[v]].data();
+      for (int i = 0; i < 6; ++i) {
+        const bool c = (i < 3) ? (P.cmask[v] & 1) : (P.cmask[v] & 2);
+        if (c) D[7 * i] = 1.0;
+      }
+    }
+  });
+  double cost = 0;
+  for (int e = 0; e < P.E; ++e) cost += el[(size_t)e].cost;
   return cost;
 }
 
@@ -634,14 +746,20 @@ struct SparseChol {
     Lval.assign(n, {});
   }
 
-  // numeric factorisation of H + diag(d2); returns false on a non-positive pivot
-  bool factor(const BlockSym& H, const double* d2) {
-    for (int j = 0; j < n; ++j) { Lrow[j].clear(); Lval[j].clear(); }
-    nnz_blocks = 0;
-    flops = 0;
-    std::vector<Blk> x(n);
-    std::vector<int> mark(n, -1), stack(n), reach(n);
-    for (int k = 0; k < n; ++k) {
+  // numeric factorisation of H + diag(d2); returns false on a non-positive pivot.  Up-looking, one block row at a time; a row only
+  // touches the columns of its descendants in the elimination tree, so disjoint subtrees can be factorised by different threads
+  // (pool != null): the subtrees below a size cut in parallel, the top of the tree — the separators, most of the flops on a mesh
+  // — by the calling thread.  Every row does the same operations in the same order either way: same bits.
+  struct Work {
+    std::vector<Blk> x;
+    std::vector<int> mark, stack, reach;
+    double flops = 0;
+    explicit Work(int n) : x(n), mark(n, -1), stack(n), reach(n) {}
+  };
+  bool factor_row(const BlockSym& H, const double* d2, int k, Work& W) {
+    std::vector<Blk>& x = W.x;
+    std::vector<int>&mark = W.mark, &stack = W.stack, &reach = W.reach;
+    {
       // scatter column k of the permuted upper triangle into x, compute reach
       int top = n;
       mark[k] = k;
@@ -692,7 +810,7 @@ struct SparseChol {
               xi[6 * r + c] -= s;
             }
         }
-        flops += 432.0 * (double)(cnt - 1) + 432.0 + 216.0;
+        W.flops += 432.0 * (double)(cnt - 1) + 432.0 + 216.0;
         // d -= L_kj L_kj^T
         for (int r = 0; r < 6; ++r)
           for (int c = 0; c < 6; ++c) {
@@ -708,6 +826,61 @@ struct SparseChol {
       Lrow[k].push_back(k);
       Lval[k].push_back(d);
     }
+    return true;
+  }
+  // subtrees of the elimination tree handed to the pool (rows of a subtree in ascending order), and the rows left to the caller
+  std::vector<std::vector<int>> par_tasks;
+  std::vector<int> par_top;
+  std::vector<Work> par_work;
+  void plan_parallel(int nthreads) {
+    par_tasks.clear(); par_top.clear();
+    std::vector<int> size(n, 1);
+    for (int k = 0; k < n; ++k) if (parent[k] >= 0) size[parent[k]] += size[k];       // (children have smaller numbers than their parents)
+    const int cap = std::max(64, n / (8 * nthreads));
+    std::vector<int> task_of(n, -1);
+    for (int k = n - 1; k >= 0; --k) {
+      const int pa = parent[k];
+      if (pa >= 0 && task_of[pa] >= 0) { task_of[k] = task_of[pa]; continue; }
+      if (size[k] <= cap) { task_of[k] = (int)par_tasks.size(); par_tasks.emplace_back(); }
+    }
+    for (int k = 0; k < n; ++k) { if (task_of[k] >= 0) par_tasks[task_of[k]].push_back(k); else par_top.push_back(k); }
+    std::sort(par_tasks.begin(), par_tasks.end(), [](const std::vector<int>& a, const std::vector<int>& b) { return a.size() > b.size(); });
+    par_work.clear();
+    for (int t = 0; t < nthreads; ++t) par_work.emplace_back(n);
+  }
+  bool factor(const BlockSym& H, const double* d2, Pool* pool = nullptr) {
+    for (int j = 0; j < n; ++j) { Lrow[j].clear(); Lval[j].clear(); }
+    nnz_blocks = 0;
+    flops = 0;
+    bool ok = true;
+    if (!pool || pool->width() <= 1) {
+      Work W(n);
+      for (int k = 0; k < n && ok; ++k) ok = factor_row(H, d2, k, W);
+      flops = W.flops;
+    } else {
+      if ((int)par_work.size() != pool->width()) plan_parallel(pool->width());
+      for (Work& W : par_work) { W.flops = 0; std::fill(W.mark.begin(), W.mark.end(), -1); }   // (marks are row numbers: stale ones from the last factorisation would cut the reach short)
+      std::atomic<int> slot{0}, bad{0};
+      std::vector<int> who(par_tasks.size(), -1);
+      // a thread keeps one workspace for all the subtrees it picks up
+      std::mutex mu;
+      std::vector<std::thread::id> ids;
+      pool->run((int)par_tasks.size(), [&](int t) {
+        int w;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          const auto id = std::this_thread::get_id();
+          w = (int)(std::find(ids.begin(), ids.end(), id) - ids.begin());
+          if (w == (int)ids.size()) ids.push_back(id);
+        }
+        for (int k : par_tasks[t]) if (!factor_row(H, d2, k, par_work[w])) { bad.store(1); break; }
+      });
+      ok = bad.load() == 0;
+      for (size_t i = 0; i < par_top.size() && ok; ++i) ok = factor_row(H, d2, par_top[i], par_work[0]);
+      for (const Work& W : par_work) flops += W.flops;
+      (void)slot; (void)who;
+    }
+    if (!ok) return false;
     for (int j = 0; j < n; ++j) nnz_blocks += (long long)Lrow[j].size();
     return true;
   }
@@ -888,7 +1061,8 @@ struct oracle_options {
   double max_lm_diagonal;              // 1e32
   double eta;                          // 0.1
   int pcg_cluster;                     // poses per Jacobi block of the PCG preconditioner (1 = 6x6 blocks, Ceres JACOBI-like)
-  int reserved;
+  int num_threads;   /* 0 / 1: sequential (the reference sets num_threads = 1); > 1: Jacobian evaluation, cost evaluation and the
+                        numeric Cholesky on that many threads — same results to the bit */
 };
 
 struct oracle_summary {
@@ -933,7 +1107,7 @@ void oracle_default_options(oracle_options* o) {
   o->max_lm_diagonal = 1e32;
   o->eta = 0.1;
   o->pcg_cluster = 1;
-  o->reserved = 0;
+  o->num_threads = 0;
 }
 
 void oracle_edge_eval_autodiff(const double* pa, const double* qa, const double* pb, const double* qb,
@@ -1045,6 +1219,12 @@ int oracle_solve(int N, int E, double* poses, const uint8_t* cmask, const int* i
   build_structure(P, H);
   SparseChol chol;
   if (opt->linear_solver == 0) chol.analyze(H);
+  std::unique_ptr<Pool> pool;
+  if (opt->num_threads > 1) pool.reset(new Pool(opt->num_threads));
+  std::vector<EdgeLin> mt_edges;
+  std::vector<double> mt_terms;
+  auto do_linearize = [&](const double* xx, std::vector<double>& gg) { return pool ? linearize_mt(P, xx, H, gg, *pool, mt_edges) : linearize(P, xx, H, gg); };
+  auto do_cost = [&](const double* xx) { return pool ? total_cost_mt(P, xx, *pool, mt_terms) : total_cost(P, xx); };
 
   std::vector<double> x(poses, poses + 7 * (size_t)N), cand(7 * (size_t)N);
   std::vector<double> g, scale(m, 1.0), diag(m), d2(m), gs(m), step(m), delta(m), tmp(m);
@@ -1076,7 +1256,7 @@ int oracle_solve(int N, int E, double* poses, const uint8_t* cmask, const int* i
   // EvaluateGradientAndJacobian: H~ = S H S, g (unscaled) kept for the gradient test, gs = S g
   auto evaluate_gradient_and_jacobian = [&]() {
     const auto t0 = Clock::now();
-    x_cost = linearize(P, x.data(), H, g);
+    x_cost = do_linearize(x.data(), g);
     if (opt->jacobi_scaling) {
       if (!scaled_once) {
         for (int v = 0; v < N; ++v)
@@ -1154,7 +1334,7 @@ int oracle_solve(int N, int E, double* poses, const uint8_t* cmask, const int* i
     bool lin_ok = true;
     int lin_it = 0;
     if (opt->linear_solver == 0) {
-      lin_ok = chol.factor(H, d2.data());
+      lin_ok = chol.factor(H, d2.data(), pool.get());
       if (lin_ok) chol.solve(gs.data(), step.data());
       sum->factor_nnz_blocks = chol.nnz_blocks;
       sum->factor_flops = chol.flops;
@@ -1201,7 +1381,7 @@ int oracle_solve(int N, int E, double* poses, const uint8_t* cmask, const int* i
     // ---- ComputeCandidatePointAndEvaluateCost ----
     const auto t_c = Clock::now();
     plus(x, delta.data(), cand);
-    const double cand_cost = total_cost(P, cand.data());
+    const double cand_cost = do_cost(cand.data());
     sum->cost_eval_seconds += secs(t_c, Clock::now());
 
     // ---- ParameterToleranceReached ----
