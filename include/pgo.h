@@ -30,6 +30,13 @@ extern "C" {
  * ceres::Solve does, include/ceres/solver.h). */
 #define PGO_VERSION 101
 
+/* The library is built with -fvisibility=hidden: these entry points are all it exports. */
+#if defined(__GNUC__)
+#define PGO_API __attribute__((visibility("default")))
+#else
+#define PGO_API
+#endif
+
 typedef struct pgo_problem pgo_problem;
 
 typedef enum pgo_status {
@@ -145,59 +152,59 @@ typedef struct pgo_iteration_record {
 } pgo_iteration_record;
 
 /* ---- library ---- */
-int pgo_version(void);
-const char* pgo_last_error(void);
+PGO_API int pgo_version(void);
+PGO_API const char* pgo_last_error(void);
 /* number of HIP devices visible (0 on a CPU-only host; never an error) */
-int pgo_device_count(void);
+PGO_API int pgo_device_count(void);
 /* binds the calling process to a device (one process per GPU); default device 0 */
-int pgo_set_device(int device);
+PGO_API int pgo_set_device(int device);
 
 /* ---- problem construction: ceres::Problem (finial.cpp:58, 491-528) ---- */
-pgo_problem* pgo_problem_create(void);                  /* ceres::Problem::Problem()  */
-void pgo_problem_destroy(pgo_problem* problem);         /* ceres::Problem::~Problem() */
+PGO_API pgo_problem* pgo_problem_create(void);                  /* ceres::Problem::Problem()  */
+PGO_API void pgo_problem_destroy(pgo_problem* problem);         /* ceres::Problem::~Problem() */
 
 /* Declares a pose whose translation lives at p[3] and quaternion at q[4] in CALLER memory; both are
  * updated in place by pgo_solve, exactly like the parameter blocks handed to
  * Problem::AddResidualBlock (finial.cpp:513-517).  Identity is the pointer value: re-adding the same
  * (p,q) pair returns the existing index.  Returns the pose index (>= 0) or a negative status. */
-int pgo_problem_add_pose(pgo_problem* problem, double* p, double* q);
+PGO_API int pgo_problem_add_pose(pgo_problem* problem, double* p, double* q);
 /* n poses laid out at base + i*stride_doubles: p = 3 doubles, q = the 4 doubles after them.
  * Returns the index of the first pose. */
-int pgo_problem_add_poses(pgo_problem* problem, int n, double* base, int stride_doubles);
+PGO_API int pgo_problem_add_poses(pgo_problem* problem, int n, double* base, int stride_doubles);
 
 /* PoseGraph3dErrorTerm::Create(t_be, sqrt_information) + Problem::AddResidualBlock(cost, loss,
  * p_begin, q_begin, p_end, q_end) + SetParameterization(q, EigenQuaternionParameterization)
  * (REF/include/PoseGraph3dError.h:56-61, finial.cpp:508-522).  sqrt_information is the 6x6 row-major
  * matrix applied on the LEFT of the residual (the lower Cholesky factor of the information matrix);
  * NULL means identity. Returns the edge index (>= 0) or a negative status. */
-int pgo_problem_add_se3_between(pgo_problem* problem, int pose_begin, int pose_end, const double* t_be_p,
+PGO_API int pgo_problem_add_se3_between(pgo_problem* problem, int pose_begin, int pose_end, const double* t_be_p,
                                 const double* t_be_q, const double* sqrt_information);
 /* batch form: begin/end [n], t_be [n][7] (p then q), sqrt_information [n][36] or NULL */
-int pgo_problem_add_se3_between_batch(pgo_problem* problem, int n, const int* pose_begin, const int* pose_end,
+PGO_API int pgo_problem_add_se3_between_batch(pgo_problem* problem, int n, const int* pose_begin, const int* pose_end,
                                       const double* t_be, const double* sqrt_information);
 
 /* the single LossFunction instance shared by every residual block (finial.cpp:495,513) */
-int pgo_problem_set_loss(pgo_problem* problem, int loss_kind, double loss_parameter);
+PGO_API int pgo_problem_set_loss(pgo_problem* problem, int loss_kind, double loss_parameter);
 
 /* Problem::SetParameterBlockConstant (finial.cpp:525-527). which: 1 = translation, 2 = rotation, 3 = both */
-int pgo_problem_set_pose_constant(pgo_problem* problem, int pose, int which);
+PGO_API int pgo_problem_set_pose_constant(pgo_problem* problem, int pose, int which);
 /* same, addressed by the parameter-block pointer as Ceres does */
-int pgo_problem_set_parameter_block_constant(pgo_problem* problem, const double* block);
+PGO_API int pgo_problem_set_parameter_block_constant(pgo_problem* problem, const double* block);
 
-int pgo_problem_num_poses(const pgo_problem* problem);
-int pgo_problem_num_edges(const pgo_problem* problem);
+PGO_API int pgo_problem_num_poses(const pgo_problem* problem);
+PGO_API int pgo_problem_num_edges(const pgo_problem* problem);
 
 /* ---- solve: ceres::Solve(options, problem, &summary) (finial.cpp:534-539) ---- */
-void pgo_solver_options_init(pgo_solver_options* options);
+PGO_API void pgo_solver_options_init(pgo_solver_options* options);
 /* Runs the Levenberg-Marquardt trust-region loop on the GPU and writes the result into the caller's
  * p/q memory (also on NO_CONVERGENCE).  records (may be NULL) receives up to records_capacity rows. */
-int pgo_solve(pgo_problem* problem, const pgo_solver_options* options, pgo_solver_summary* summary,
+PGO_API int pgo_solve(pgo_problem* problem, const pgo_solver_options* options, pgo_solver_summary* summary,
               pgo_iteration_record* records, int records_capacity);
 /* Summary::IsSolutionUsable (finial.cpp:543) */
 /* Device memory of destroyed problems is kept in a process-wide pool and reused by later problems (hipFree synchronises the
  * device: tearing a problem down the blocking way costs as much as a KITTI-scale solve).  This call returns the pooled blocks
  * to the driver; PGO_POOL_MAX_GB bounds the pool (default 16 GB, 0 = no pooling). */
-int pgo_release_device_memory(void);
+PGO_API int pgo_release_device_memory(void);
 
 /* Several INDEPENDENT problems solved together on one GPU (KITTI-scale graphs leave the machine idle: an LM iteration is a
  * chain of small dependent launches).  The problems become the components of one block-diagonal problem — one launch
@@ -207,44 +214,44 @@ int pgo_release_device_memory(void);
  * reference's), one loss function shared by all problems, no communicator attached.  summaries: [n_problems];
  * records: [n_problems][capacity] or NULL.  total/setup times in the summaries are those of the whole batch.  Poses are
  * updated in caller memory exactly as by pgo_solve.  GPU only. */
-int pgo_solve_batch(pgo_problem* const* problems, int n_problems, const pgo_solver_options* options, pgo_solver_summary* summaries,
+PGO_API int pgo_solve_batch(pgo_problem* const* problems, int n_problems, const pgo_solver_options* options, pgo_solver_summary* summaries,
                     pgo_iteration_record* records, int capacity);
 
-int pgo_summary_is_solution_usable(const pgo_solver_summary* summary);
+PGO_API int pgo_summary_is_solution_usable(const pgo_solver_summary* summary);
 /* Summary::FullReport (finial.cpp:541): writes a NUL-terminated report, returns the length needed */
-size_t pgo_summary_full_report(const pgo_solver_summary* summary, const pgo_iteration_record* records,
+PGO_API size_t pgo_summary_full_report(const pgo_solver_summary* summary, const pgo_iteration_record* records,
                                int num_records, char* buffer, size_t capacity);
 
 /* ---- evaluation at the current caller-side parameter values (ceres::Problem::Evaluate analogue;
  * what ResidualBlock::Evaluate produces per block: loss-corrected residuals and local-tangent
  * Jacobians, columns [dp(3) | dtheta(3)], constant blocks zeroed).  Any output may be NULL.
  *   residuals [E][6], jacobian_begin/end [E][36] row-major, gradient [N][6] ---- */
-int pgo_evaluate(pgo_problem* problem, double* cost, double* residuals, double* jacobian_begin,
+PGO_API int pgo_evaluate(pgo_problem* problem, double* cost, double* residuals, double* jacobian_begin,
                  double* jacobian_end, double* gradient);
 /* Gauss-Newton blocks of J'J at the current values, without Jacobi scaling or damping:
  *   diag [N][36], offdiag [E][36] = J_begin' J_end per edge.  Any output may be NULL. */
-int pgo_normal_equations(pgo_problem* problem, double* diag, double* offdiag, double* gradient);
+PGO_API int pgo_normal_equations(pgo_problem* problem, double* diag, double* offdiag, double* gradient);
 /* Solves (J'J + diag(d2)) x = b on the GPU with the selected linear solver at the current values
  * (solver-level parity tests).  d2, b, x are [N][6]; returns CG iterations through *iterations. */
-int pgo_linear_solve(pgo_problem* problem, const pgo_solver_options* options, const double* d2,
+PGO_API int pgo_linear_solve(pgo_problem* problem, const pgo_solver_options* options, const double* d2,
                      const double* b, double* x, int* iterations);
 /* Plus: x_plus = x [+] delta for every pose (EigenQuaternionParameterization::Plus on q, p += dp),
  * written back into the caller's p/q memory.  delta [N][6]. */
-int pgo_plus(pgo_problem* problem, const double* delta);
+PGO_API int pgo_plus(pgo_problem* problem, const double* delta);
 
 /* ---- device-resident stepping for benchmarks: poses stay in HBM between calls ---- */
-int pgo_solver_begin(pgo_problem* problem, const pgo_solver_options* options);
+PGO_API int pgo_solver_begin(pgo_problem* problem, const pgo_solver_options* options);
 /* runs up to n LM iterations (successful or not); *executed = iterations actually run, *done becomes 1
  * when a termination test fired (either may be NULL) */
-int pgo_solver_step(pgo_problem* problem, int n, int* executed, int* done);
+PGO_API int pgo_solver_step(pgo_problem* problem, int n, int* executed, int* done);
 /* restores the device state to the poses given at pgo_solver_begin (no host traffic) */
-int pgo_solver_reset(pgo_problem* problem);
-int pgo_solver_end(pgo_problem* problem, pgo_solver_summary* summary, pgo_iteration_record* records,
+PGO_API int pgo_solver_reset(pgo_problem* problem);
+PGO_API int pgo_solver_end(pgo_problem* problem, pgo_solver_summary* summary, pgo_iteration_record* records,
                    int records_capacity);
 /* repeats one kernel of the path `repeats` times on the solver stream between two HIP events and
  * returns the average milliseconds per launch.  kernel: "linearize", "spmv", "cost", "evaluate",
  * "pcg_update". */
-int pgo_time_kernel(pgo_problem* problem, const char* kernel, int repeats, double* avg_ms);
+PGO_API int pgo_time_kernel(pgo_problem* problem, const char* kernel, int repeats, double* avg_ms);
 
 /* ---- loop-closure candidate search ----
  * Replaces getCandidatesIndex / isInSearchRange of PLUS/test/generate_edges_from_trajectory_origion.cpp:58-111 (the
@@ -253,7 +260,7 @@ int pgo_time_kernel(pgo_problem* problem, const char* kernel, int repeats, doubl
  * xyz: n x 3 float32 camera centres.  Output in CSR form: row_ptr[n+1] (row 0 is empty), indices[row_ptr[n]].
  * Call with indices = NULL to obtain row_ptr (sizes) only; capacity = entries available in `indices`.
  * kernel_ms (optional): device time of the search kernels (HIP events).  GPU only: PGO_ERR_NO_DEVICE without one. */
-int pgo_generate_candidates(const float* xyz, int n, float search_radius, int gap, long long* row_ptr, int* indices,
+PGO_API int pgo_generate_candidates(const float* xyz, int n, float search_radius, int gap, long long* row_ptr, int* indices,
                             long long capacity, double* kernel_ms);
 
 /* ---- graph construction around the solve ----
@@ -263,12 +270,12 @@ int pgo_generate_candidates(const float* xyz, int n, float search_radius, int ga
  * transforms Twc, row-major 4x4, 16 doubles per pose holding the float32 values the reference keeps (CV_32F).  count receives
  * the number of complete rows in the file (also when it exceeds capacity; only `capacity` poses are written).  Host only.
  * (The reference's `while (inFile.good())` loop appends one more, unread, pose at the end of the file; not reproduced.) */
-int pgo_read_trajectory(const char* path, int format, double* Twc, int capacity, int* count);
+PGO_API int pgo_read_trajectory(const char* path, int format, double* Twc, int capacity, int* count);
 
 /* Odometry measurements of ALL consecutive frames at once on the GPU (finial.cpp:206-224): edge e has id_begin = e + 1,
  * id_end = e, t_be[e] = Converter::toPose3d(float32(Tcw(e + 1) * Twc(e))) (converter.cc:150-155, 221-234), 7 doubles
  * p[3] q[4] (xyzw).  kernel_ms optional.  GPU only. */
-int pgo_build_odometry_edges(int n_frames, const double* Twc, double* t_be, double* kernel_ms);
+PGO_API int pgo_build_odometry_edges(int n_frames, const double* Twc, double* t_be, double* kernel_ms);
 
 /* checkFrame's acceptance rules (finial.cpp:162-293, 486-489) over RECORDED front-end results — ORB matching and PnP are
  * outside the path, their outputs per candidate pair come in `obs` (parallel to cand_idx; may be NULL: odometry only).
@@ -292,8 +299,8 @@ typedef struct pgo_edge_rules {
   int loop_list_gap;       /* 100, finial.cpp:285 */
   int reserved;
 } pgo_edge_rules;
-void pgo_edge_rules_init(pgo_edge_rules* rules);
-int pgo_build_edges(int n_frames, const double* Twc, const long long* cand_ptr, const int* cand_idx, const pgo_pair_observation* obs,
+PGO_API void pgo_edge_rules_init(pgo_edge_rules* rules);
+PGO_API int pgo_build_edges(int n_frames, const double* Twc, const long long* cand_ptr, const int* cand_idx, const pgo_pair_observation* obs,
                     const pgo_edge_rules* rules, int* id_begin, int* id_end, double* t_be, long long capacity, long long* n_edges,
                     int* loop_list, long long loop_capacity, long long* n_loop_list);
 
@@ -324,31 +331,33 @@ typedef struct pgo_reproj_summary {
   int num_points;
   double initial_cost, final_cost;
 } pgo_reproj_summary;
-void pgo_reproj_options_init(pgo_reproj_options* options);
-int pgo_reproj_solve_batch(int n_problems, const long long* point_ptr, const double* points, const double* observations,
+PGO_API void pgo_reproj_options_init(pgo_reproj_options* options);
+PGO_API int pgo_reproj_solve_batch(int n_problems, const long long* point_ptr, const double* points, const double* observations,
                            const double intrinsics[4], double* q, double* t, const pgo_reproj_options* options,
                            pgo_reproj_summary* summaries, double* kernel_ms);
 
 /* ---- one process per GPU: edge/row sharding over RCCL ---- */
 /* contiguous share [begin,end) of n units for `rank` of `world` (host-only helper, no GPU needed) */
-int pgo_shard_range(long long n, int rank, int world, long long* begin, long long* end);
+PGO_API int pgo_shard_range(long long n, int rank, int world, long long* begin, long long* end);
 /* Row ownership of the sharded solve — the rule pgo_comm_init itself applies: rank r owns the poses [r * rows_per,
  * (r + 1) * rows_per) cut at n_poses, rows_per = ceil(n_poses / world) rounded up to a multiple of 4 (preconditioner
  * clusters never straddle ranks; equal segments for the all-gather).  rows_per optional. */
-int pgo_row_shard_range(long long n_poses, int rank, int world, long long* begin, long long* end, int* rows_per);
+PGO_API int pgo_row_shard_range(long long n_poses, int rank, int world, long long* begin, long long* end, int* rows_per);
 /* 128-byte RCCL unique id created on rank 0 and handed to every rank by the launcher */
-int pgo_comm_get_unique_id(unsigned char id[128]);
+PGO_API int pgo_comm_get_unique_id(unsigned char id[128]);
 /* Attaches rank `rank` of `world` to the problem BEFORE the first solve/evaluate.  Every rank must hold the same problem
  * (same poses, same edges in the same order); rank r then owns a contiguous range of pose rows, evaluates every edge
  * incident to them, and the ranks exchange one all-gather per CG iteration (q = A p and the p'q partials), one per
  * accepted LM step (J'J diagonal blocks, J'r) and one per LM iteration for cluster preconditioners.  All ranks take
  * identical decisions from identical scalars, so no other coordination is needed. */
-int pgo_comm_init(pgo_problem* problem, const unsigned char id[128], int rank, int world);
+PGO_API int pgo_comm_init(pgo_problem* problem, const unsigned char id[128], int rank, int world);
 /* Test transport: `world` virtual ranks = problems driven by host threads of ONE process on one GPU, segments exchanged
  * by device-to-device copies.  Lets the sharded path be validated on a single-GPU machine. */
-void* pgo_loopback_create(int world);
-void pgo_loopback_destroy(void* group);
-int pgo_comm_init_loopback(pgo_problem* problem, void* group, int rank);
+/* development aid (tools/comm_stress.py): `iters` exchanges of a test pattern through the problem's communicator, mismatches counted */
+PGO_API int pgo_debug_comm_stress(pgo_problem* problem, int iters, int seg_doubles);
+PGO_API void* pgo_loopback_create(int world);
+PGO_API void pgo_loopback_destroy(void* group);
+PGO_API int pgo_comm_init_loopback(pgo_problem* problem, void* group, int rank);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,557 @@
+// pgo_problem.cpp — host side of libpgo_hip.so, part 1: ceres::Problem-style bookkeeping (REF/test/pose_graph_ceres_plus_finial.cpp:491-528),
+// the error channel, device set-up, the incidence-slot topology build and its uploads, pose transfers.
+#include "pgo_internal.h"
+
+thread_local std::string g_error;
+
+int set_error(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+const char* last_error_string() { return g_error.c_str(); }
+
+// error channel for the other translation units of the library
+int pgo_candidates_set_error(int code, const char* msg) { return set_error(code, "%s", msg); }
+
+
+int ensure_device(pgo_problem* P) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return set_error(PGO_ERR_NO_DEVICE,
+                     "no HIP device available: the pose-graph path runs on gfx950 only and has no CPU fallback");
+  }
+  HIP_TRY(hipSetDevice(P->device));
+  if (!P->stream_ready) {
+    HIP_TRY(host_side_pool().get_stream(P->device, &P->stream));
+    P->stream_ready = true;
+    // Launch sequences are enqueued eagerly by default: on this stack (ROCm 7.2, MI355X) the host runs ahead of the GPU and a
+    // captured hipGraph of the same kernels is no faster (C2: 0.317 vs 0.317 ms per LM iteration without residual refreshes,
+    // 0.322 eager vs 0.353 graph with them; KITTI-00 exact 0.79 vs 0.81 ms).  PGO_GRAPH=1 replays captured batches instead.
+    const char* gr = getenv("PGO_GRAPH");
+    const char* ng = getenv("PGO_NO_GRAPH");
+    P->use_graph = (gr && gr[0] == '1') && !(ng && ng[0] == '1');
+  }
+  if (!P->scal) {
+    void* blk = nullptr;
+    HIP_TRY(host_side_pool().get_pinned(sizeof(pgo::LmScalars), &blk, &P->scal_cap));
+    P->scal = static_cast<pgo::LmScalars*>(blk);
+    memset(P->scal, 0, sizeof(pgo::LmScalars));
+  }
+  return PGO_OK;
+}
+
+// In-place all-gather of equal segments (rank r owns buf[r*seg, (r+1)*seg)); no-op with a single rank.
+int exchange(pgo_problem* P, double* buf, size_t seg_doubles) {
+  static const bool force = getenv("PGO_FORCE_EXCHANGE") && getenv("PGO_FORCE_EXCHANGE")[0] == '1';   // exercise the transport at world 1
+  if (!P->comm || (P->comm->world <= 1 && !force)) return PGO_OK;
+  const char* what = "";
+  if (P->comm->all_gather(buf, seg_doubles, P->stream, &what) != 0) return set_error(PGO_ERR_HIP, "all-gather failed: %s", what);
+  return PGO_OK;
+}
+
+// linearise the owned rows, then make J'J diagonal blocks and J'r of ALL rows available on every rank
+int linearize_all(pgo_problem* P) {
+  pgo::launch_linearize(P->g, P->stream);
+  int rc = exchange(P, P->g.Hdiag, (size_t)36 * P->g.rows_per);
+  if (rc) return rc;
+  return exchange(P, P->g.grad, (size_t)6 * P->g.rows_per);
+}
+
+// LM damping + preconditioner.  6x6 blocks are rebuilt on every rank from the gathered diagonal; cluster blocks need
+// the in-cluster off-diagonal blocks, which only the owner holds, so their inverses are exchanged.
+int damping_all(pgo_problem* P, double radius, double min_diag, double max_diag, int mode) {
+  pgo::launch_damping(P->g, radius, min_diag, max_diag, mode, P->stream);
+  if (P->g.cluster > 1) return exchange(P, P->g.Minv, (size_t)36 * P->g.cluster * P->g.rows_per);
+  return PGO_OK;
+}
+
+// one CG iteration: SpMV on the owned rows, exchange of q (+ p'q partials), replicated vector update
+// `refresh`: this is a residual_reset_period-th iteration — r is recomputed as b - A x (Ceres conjugate_gradients_solver.cc)
+// instead of updated: x-only update, A x into the exchange buffer, then r / z / partial sums.
+int cg_iteration(pgo_problem* P, const pgo::DeviceGraph& g, const pgo::CgParams& prm, int odd, bool refresh) {
+  pgo::launch_pcg_spmv_only(g, prm, odd, P->stream);
+  int rc = exchange(P, g.cg_q, (size_t)g.seg);
+  if (rc) return rc;
+  if (!refresh) {
+    pgo::launch_pcg_update_only(g, odd, P->stream);
+    return PGO_OK;
+  }
+  if (g.world == 1) {   // x = x_old + alpha p formed on the fly by the SpMV, one combined vector launch
+    pgo::launch_spmv_refresh(g, P->stream, 1, odd);
+    pgo::launch_pcg_update_only(g, odd, P->stream, 3);
+    return PGO_OK;
+  }
+  pgo::launch_pcg_update_only(g, odd, P->stream, 1);
+  pgo::launch_spmv_refresh(g, P->stream);
+  rc = exchange(P, g.cg_q, (size_t)g.seg);
+  if (rc) return rc;
+  pgo::launch_pcg_update_only(g, odd, P->stream, 2);
+  return PGO_OK;
+}
+int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd, bool refresh) { return cg_iteration(P, P->g, prm, odd, refresh); }
+
+int choose_block(long long total_slots) {
+  static const int env_block = getenv("PGO_BLOCK") ? atoi(getenv("PGO_BLOCK")) : 0;   // tuning experiments: 64, 128 or 256
+  if (env_block == 64 || env_block == 128 || env_block == 256) return env_block;
+  if (total_slots >= 256LL * 512) return 256;
+  if (total_slots >= 128LL * 384) return 128;
+  return 64;
+}
+
+
+// Builds the incidence-slot topology and uploads every static array.
+int prepare(pgo_problem* P) {
+  int rc = ensure_device(P);
+  if (rc) return rc;
+  if (!P->topo_dirty) return PGO_OK;
+  if (P->analysis_thread.joinable()) P->analysis_thread.join();     // (of a topology that is being replaced)
+  const auto t0 = Clock::now();
+  const int N = (int)P->pp.size(), E = (int)P->ia.size();
+  if (N == 0) return set_error(PGO_ERR_INVALID_ARGUMENT, "problem has no poses");
+  hipStream_t s = P->stream;
+  P->drop_graph();
+
+  const bool verbose = getenv("PGO_VERBOSE") != nullptr;
+  auto lap = [&, tl = Clock::now()](const char* what) mutable {
+    if (verbose) std::fprintf(stderr, "[pgo] prepare: %-28s %.2f ms\n", what, 1e3 * seconds_since(tl));
+    tl = Clock::now();
+  };
+  std::vector<int> deg(N, 0);
+  for (int e = 0; e < E; ++e) { ++deg[P->ia[e]]; ++deg[P->ib[e]]; }
+  long long total = 0;
+  for (int v = 0; v < N; ++v) total += 1 + deg[v];
+
+  // ---- row ownership: rank r owns the poses [r*rows_per, (r+1)*rows_per); cut edges are evaluated by
+  // the owners of both endpoints.  rows_per is a multiple of 4 so that preconditioner clusters never straddle ranks.
+  const int world = P->comm ? P->comm->world : 1, rank = P->comm ? P->comm->rank : 0;
+  long long rl = 0, rh = 0;
+  int rows_per = 0;
+  if (pgo_row_shard_range(N, rank, world, &rl, &rh, &rows_per) != PGO_OK) return PGO_ERR_INVALID_ARGUMENT;   // THE ownership rule
+  const int row_lo = (int)rl, row_hi = (int)rh;
+  const int NP = world * rows_per;   // padded pose count of every replicated / exchanged array
+  const int B = choose_block(total / world);
+
+  // rows -> workgroups (greedy packing of `block` slots; a row with more incidences gets its own multi-chunk group)
+  std::vector<int> wg_row_begin, wg_slot_begin, row_slot_begin(N, 0), row_slot_cnt(N, 0);
+  long long slot = 0;
+  auto pack = [&](int lo, int hi, bool record) -> int {
+    long long sl = 0;
+    int cur = 0, n = 0;
+    if (record) { wg_row_begin.assign(1, lo); wg_slot_begin.assign(1, 0); }
+    auto close_wg = [&](int next_row) {
+      sl = (sl + B - 1) / B * B;
+      ++n;
+      if (record) { wg_row_begin.push_back(next_row); wg_slot_begin.push_back((int)sl); }
+      cur = 0;
+    };
+    for (int v = lo; v < hi; ++v) {
+      const int c = 1 + deg[v];
+      if (c > B) {
+        if (cur > 0) close_wg(v);
+        if (record) { row_slot_begin[v] = (int)sl; row_slot_cnt[v] = c; }
+        sl += c;
+        close_wg(v + 1);
+        continue;
+      }
+      if (cur + c > B) close_wg(v);
+      if (record) { row_slot_begin[v] = (int)sl; row_slot_cnt[v] = c; }
+      sl += c;
+      cur += c;
+    }
+    if (cur > 0) close_wg(hi);
+    if (n == 0) { sl += B; close_wg(hi); }   // a rank without rows still launches one (empty) workgroup
+    if (record) slot = sl;
+    return n;
+  };
+  int pq_cap = 1;
+  for (int r = 0; r < world; ++r) pq_cap = std::max(pq_cap, pack(std::min(N, r * rows_per), std::min(N, (r + 1) * rows_per), false));
+  const int n_wg = pack(row_lo, row_hi, true);
+  if (slot > 0x7fffffffLL - 1024) return set_error(PGO_ERR_UNSUPPORTED, "graph too large for 32-bit slot indices");
+  const int n_slots = (int)slot;
+  const int seg = rows_per * 6 + pq_cap;
+
+  // slots: diagonal first, then the row's incidences in edge order (owned rows only)
+  std::vector<int> slot_col(n_slots, -1), slot_row(n_slots, 0), slot_edge(n_slots, -1), fill(N, 0);
+  std::vector<uint8_t> slot_side(n_slots, pgo::SIDE_PAD);
+  for (int v = row_lo; v < row_hi; ++v) {
+    const int sb = row_slot_begin[v];
+    slot_col[sb] = v; slot_row[sb] = v; slot_side[sb] = pgo::SIDE_DIAG;
+    fill[v] = sb + 1;
+  }
+  P->edge_begin_slot.assign(E, -1);
+  for (int e = 0; e < E; ++e) {
+    const int a = P->ia[e], b = P->ib[e];
+    if (a >= row_lo && a < row_hi) {
+      const int t = fill[a]++;
+      slot_col[t] = b; slot_row[t] = a; slot_side[t] = pgo::SIDE_BEGIN; slot_edge[t] = e;
+      P->edge_begin_slot[e] = t;
+    }
+    if (b >= row_lo && b < row_hi) {
+      const int t = fill[b]++;
+      slot_col[t] = a; slot_row[t] = b; slot_side[t] = pgo::SIDE_END; slot_edge[t] = e;
+    }
+  }
+  // pad slots keep a valid row index so that loads stay in range
+  for (int w = 0; w < n_wg; ++w) {
+    const int r = std::max(0, std::min(wg_row_begin[w], N - 1));
+    for (int t = wg_slot_begin[w]; t < wg_slot_begin[w + 1]; ++t) if (slot_side[t] == pgo::SIDE_PAD) slot_row[t] = r;
+  }
+
+  lap("rows -> workgroups, slots");
+  P->h_slot_row = slot_row; P->h_slot_col = slot_col; P->h_slot_side = slot_side; P->h_row_slot_begin = row_slot_begin;
+  P->direct_analyzed = false; P->direct_usable = false; P->front_usable = false; P->sfront_usable = false; P->cluster_built = 0; P->g.cluster = 1;
+  if (P->want_direct && !(getenv("PGO_NO_ANALYSIS_THREAD") && getenv("PGO_NO_ANALYSIS_THREAD")[0] == '1')) {
+    // an exact request: its host analysis (ordering, symbolic factorisation, schedule) needs nothing but the slot topology
+    const long long budget = front_memory_budget();
+    const int ns = (int)n_slots;
+    P->analysis_kind = 0;
+    P->analysis_thread = std::thread([P, N, E, ns, budget]() { P->analysis_kind = decide_direct_host(P, N, E, ns, budget); });
+  }
+  // measurements: edge order and slot order, component major.  The gathers into slot order are cache-hostile (21-36
+  // strided streams indexed by a random edge): split over host threads, each owning a contiguous range.
+  HostArray emeas, smeas, eW, sW, eL;
+  emeas.resize((size_t)7 * E);
+  smeas.resize((size_t)7 * n_slots);
+  parallel_for(E, [&](int lo, int hi) {
+    for (int e = lo; e < hi; ++e) for (int c = 0; c < 7; ++c) emeas[(size_t)c * E + e] = P->meas[(size_t)7 * e + c];
+  });
+  parallel_for(n_slots, [&](int lo, int hi) {
+    for (int t = lo; t < hi; ++t) {
+      const int e = slot_edge[t];
+      for (int c = 0; c < 7; ++c) smeas[(size_t)c * n_slots + t] = e < 0 ? (c == 6 ? 1.0 : 0.0) : P->meas[(size_t)7 * e + c];
+    }
+  });
+  std::atomic<int> w_has_pr(0), w_has_offdiag(0);
+  if (P->has_info) {
+    eW.resize((size_t)21 * E); eL.resize((size_t)36 * E); sW.resize((size_t)21 * n_slots);
+    parallel_for(E, [&](int lo, int hi) {
+      for (int e = lo; e < hi; ++e) {
+        const double* L = &P->sqrt_info[(size_t)36 * e];
+        int k = 0;
+        for (int i = 0; i < 6; ++i)
+          for (int j = i; j < 6; ++j) {
+            double w = 0;
+            for (int r = 0; r < 6; ++r) w += L[6 * r + i] * L[6 * r + j];  // W = L^T L
+            if (i < 3 && j >= 3 && w != 0.0) w_has_pr.store(1, std::memory_order_relaxed);
+            if (i != j && w != 0.0) w_has_offdiag.store(1, std::memory_order_relaxed);
+            eW[(size_t)k * E + e] = w;
+            ++k;
+          }
+        for (int q = 0; q < 36; ++q) eL[(size_t)q * E + e] = L[q];
+      }
+    });
+    parallel_for(n_slots, [&](int lo, int hi) {
+      for (int t = lo; t < hi; ++t) {
+        const int e = slot_edge[t];
+        if (e < 0) { for (int k = 0; k < 21; ++k) sW[(size_t)k * n_slots + t] = 0.0; continue; }
+        // W of the slot's edge, recomputed from L (contiguous 288 B) instead of 21 strided reads of eW
+        const double* L = &P->sqrt_info[(size_t)36 * e];
+        int k = 0;
+        for (int i = 0; i < 6; ++i)
+          for (int j = i; j < 6; ++j) {
+            double w = 0;
+            for (int r = 0; r < 6; ++r) w += L[6 * r + i] * L[6 * r + j];
+            sW[(size_t)k * n_slots + t] = w;
+            ++k;
+          }
+      }
+    });
+  }
+  const bool w_blockdiag = P->has_info && w_has_pr.load() == 0;
+  const bool w_diag = P->has_info && w_has_offdiag.load() == 0;      // W = diag(w) (the generators' diag(1/sigma^2)): six planes of sW are read
+  lap("measurement / W arrays");
+  UploadScope upload_scope(s);     // the copies below are enqueued side by side; this function's final synchronisation is their wait
+  HIP_TRY(P->d_slot_col.upload(slot_col, s));
+  HIP_TRY(P->d_slot_row.upload(slot_row, s));
+  HIP_TRY(P->d_slot_side.upload(slot_side, s));
+  HIP_TRY(P->d_wg_slot_begin.upload(wg_slot_begin, s));
+  HIP_TRY(P->d_wg_row_begin.upload(wg_row_begin, s));
+  HIP_TRY(P->d_row_slot_begin.upload(row_slot_begin, s));
+  HIP_TRY(P->d_row_slot_cnt.upload(row_slot_cnt, s));
+  HIP_TRY(P->d_cmask.upload(P->cmask, s));
+  HIP_TRY(P->d_edge_a.upload(P->ia, s));
+  HIP_TRY(P->d_edge_b.upload(P->ib, s));
+  HIP_TRY(P->d_smeas.upload(smeas.data(), smeas.n, s));
+  HIP_TRY(P->d_emeas.upload(emeas.data(), emeas.n, s));
+  HIP_TRY(P->d_sW.upload(sW.data(), sW.n, s));
+  HIP_TRY(P->d_eW.upload(eW.data(), eW.n, s));
+  HIP_TRY(P->d_eL.upload(eL.data(), eL.n, s));
+  // cluster-preconditioner lists (prepare_clusters fills them): allocated here, at their upper bounds, because on this
+  // stack an upload into a buffer allocated AFTER the large allocations below takes 6-25 ms to complete
+  HIP_TRY(P->d_cl_ptr.alloc((size_t)N + 2));
+  HIP_TRY(P->d_cl_slot.alloc((size_t)E + 1));
+  HIP_TRY(P->d_cl_rc.alloc((size_t)E + 1));
+
+  lap("uploads");
+  const size_t m = (size_t)6 * NP;
+  HIP_TRY(P->d_pose_x.alloc((size_t)pgo::POSE_STRIDE * N));
+  HIP_TRY(P->d_pose_c.alloc((size_t)pgo::POSE_STRIDE * N));
+  HIP_TRY(P->d_pose_0.alloc((size_t)pgo::POSE_STRIDE * N));
+  HIP_TRY(P->d_bsr.alloc((size_t)n_slots * 36));
+  HIP_TRY(P->d_bsr.zero(s));
+  P->spec_ready = false;     // the spare linearisation set follows the new sizes when it is next needed
+  HIP_TRY(P->d_Hdiag.alloc((size_t)36 * NP));
+  HIP_TRY(P->d_Hdiag.zero(s));
+  HIP_TRY(P->d_Minv.alloc((size_t)36 * NP * 4 + (size_t)world * 144 * 4));   // room for 4-pose clusters of every rank, padded
+  HIP_TRY(P->d_Minv.zero(s));
+  DevBuf<double>* vecs[] = {&P->d_grad, &P->d_scale, &P->d_d2, &P->d_diagc, &P->d_cg_b, &P->d_cg_x, &P->d_cg_r,
+                            &P->d_cg_z, &P->d_cg_p0, &P->d_cg_p1, &P->d_delta};
+  for (DevBuf<double>* b : vecs) { HIP_TRY(b->alloc(m)); HIP_TRY(b->zero(s)); }
+  HIP_TRY(P->d_cg_q.alloc((size_t)world * seg));   // exchange buffer: q segments + p'q partials (unused partial slots stay 0)
+  HIP_TRY(P->d_cg_q.zero(s));
+  const int n_vec_wg = std::max(1, std::min((int)(((size_t)6 * N + pgo::vec_block() - 1) / pgo::vec_block()), 256));
+  const int n_edge_wg = std::max(1, (E + pgo::edge_block() - 1) / pgo::edge_block());
+  const int n_pose_wg = (N + pgo::pose_block() - 1) / pgo::pose_block();
+  const int n_part = std::max(std::max(n_wg, n_vec_wg), n_edge_wg + n_pose_wg);   // the fused step tail runs n_edge_wg + n_pose_wg workgroups
+  // (blocks may come from the pool with a previous problem's contents: everything that is not fully written before it is read
+  // is cleared here)
+  HIP_TRY(P->d_part_rz.alloc((size_t)2 * n_part));
+  HIP_TRY(P->d_part_rz.zero(s));
+  HIP_TRY(P->d_part_q.alloc((size_t)2 * n_part));
+  HIP_TRY(P->d_part_q.zero(s));
+  HIP_TRY(P->d_part_rr.alloc((size_t)2 * n_part));
+  HIP_TRY(P->d_part_rr.zero(s));
+  HIP_TRY(P->d_part_bb.alloc((size_t)n_part));
+  HIP_TRY(P->d_part_bb.zero(s));
+  HIP_TRY(P->d_part_misc.alloc((size_t)8 * n_part));
+  HIP_TRY(P->d_part_misc.zero(s));
+  HIP_TRY(P->d_cg.alloc(1));
+  HIP_TRY(P->d_cg.zero(s));
+  HIP_TRY(P->d_flags.alloc(4));
+  HIP_TRY(P->d_flags.zero(s));
+
+  pgo::DeviceGraph& g = P->g;
+  g.N = N; g.E = E; g.n_wg = n_wg; g.n_slots = n_slots; g.block = B;
+  g.world = world; g.rank = rank; g.rows_per = rows_per; g.row_lo = row_lo; g.row_hi = row_hi; g.pq_cap = pq_cap; g.seg = seg;
+  // Several ranks: RCCL collectives are enqueued eagerly by default (capturing them into the CG batch graph is only
+  // validated at world size 1 on the development box; PGO_COMM_GRAPH=1 opts in).  The per-iteration cost is then
+  // dominated by the all-gather latency, not by launch overhead.
+  if (P->comm && (!P->comm->capturable() || (world > 1 && !(getenv("PGO_COMM_GRAPH") && getenv("PGO_COMM_GRAPH")[0] == '1')))) P->use_graph = false;
+  // 0 identity, 1 general, 2 block-diagonal W (every W_pr entry exactly zero: diag(1/sigma^2) and the like); 0 and 2 use the packed
+  // 27-entry slots.  PGO_BLK_FULL=1 keeps the general kernels and the full layout (A/B measurements).
+  {
+    const char* full = getenv("PGO_BLK_FULL");
+    const bool force_full = full && full[0] == '1';
+    static const bool no_diag = getenv("PGO_NO_DIAG_INFO") && getenv("PGO_NO_DIAG_INFO")[0] == '1';    // (A/B: the 12-entry reads of mode 2)
+    g.info_mode = !P->has_info ? 0 : (w_diag && !force_full && !no_diag) ? 3 : (w_blockdiag && !force_full) ? 2 : 1;
+    g.blk_packed = (g.info_mode != 1 && !force_full) ? 1 : 0;
+  }
+  g.loss_kind = P->loss_kind; g.loss_a = P->loss_a;
+  g.slot_col = P->d_slot_col.p; g.slot_row = P->d_slot_row.p; g.slot_side = P->d_slot_side.p;
+  g.wg_slot_begin = P->d_wg_slot_begin.p; g.wg_row_begin = P->d_wg_row_begin.p;
+  g.row_slot_begin = P->d_row_slot_begin.p; g.row_slot_cnt = P->d_row_slot_cnt.p; g.cmask = P->d_cmask.p;
+  g.smeas = P->d_smeas.p; g.sW = P->d_sW.p; g.edge_a = P->d_edge_a.p; g.edge_b = P->d_edge_b.p;
+  g.emeas = P->d_emeas.p; g.eW = P->d_eW.p; g.eL = P->d_eL.p;
+  g.pose_x = P->d_pose_x.p; g.pose_c = P->d_pose_c.p; g.bsr_val = P->d_bsr.p; g.Hdiag = P->d_Hdiag.p;
+  g.Minv = P->d_Minv.p; g.grad = P->d_grad.p; g.scale = P->d_scale.p; g.d2 = P->d_d2.p;
+  g.diag_clamped = P->d_diagc.p; g.cg_b = P->d_cg_b.p; g.cg_x = P->d_cg_x.p; g.cg_r = P->d_cg_r.p;
+  g.cg_z = P->d_cg_z.p; g.cg_q = P->d_cg_q.p; g.cg_p0 = P->d_cg_p0.p; g.cg_p1 = P->d_cg_p1.p;
+  g.delta = P->d_delta.p; g.part_rz = P->d_part_rz.p; g.part_q = P->d_part_q.p;
+  g.part_rr = P->d_part_rr.p; g.part_bb = P->d_part_bb.p; g.part_misc = P->d_part_misc.p;
+  g.n_part = n_part; g.n_vec_wg = n_vec_wg; g.n_edge_wg = n_edge_wg; g.n_pose_wg = n_pose_wg;
+  g.cg = P->d_cg.p; g.flags = P->d_flags.p;
+  void* dscal = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&dscal, P->scal, 0));
+  g.scal = reinterpret_cast<pgo::LmScalars*>(dscal);
+  HIP_TRY(hipStreamSynchronize(s));
+  lap("device buffers");
+  P->topo_dirty = false;
+  P->lm.t_setup = seconds_since(t0);
+  return PGO_OK;
+}
+
+int upload_poses(pgo_problem* P, double* dst) {
+  const int N = (int)P->pp.size();
+  std::vector<double> h((size_t)pgo::POSE_STRIDE * N, 0.0);
+  for (int v = 0; v < N; ++v) {
+    double* o = &h[(size_t)pgo::POSE_STRIDE * v];
+    o[0] = P->pp[v][0]; o[1] = P->pp[v][1]; o[2] = P->pp[v][2];
+    o[3] = P->qq[v][0]; o[4] = P->qq[v][1]; o[5] = P->qq[v][2]; o[6] = P->qq[v][3];
+  }
+  HIP_TRY(staged_h2d(dst, h.data(), h.size() * sizeof(double), P->stream));
+  return PGO_OK;
+}
+
+int download_poses(pgo_problem* P, const double* src) {
+  const int N = (int)P->pp.size();
+  std::vector<double> h((size_t)pgo::POSE_STRIDE * N);
+  HIP_TRY(staged_d2h(h.data(), src, h.size() * sizeof(double), P->stream));
+  for (int v = 0; v < N; ++v) {
+    const double* o = &h[(size_t)pgo::POSE_STRIDE * v];
+    // constant blocks are never written (row 0 of the reference's before/after files is identical)
+    if (!(P->cmask[v] & 1)) { P->pp[v][0] = o[0]; P->pp[v][1] = o[1]; P->pp[v][2] = o[2]; }
+    if (!(P->cmask[v] & 2)) { P->qq[v][0] = o[3]; P->qq[v][1] = o[4]; P->qq[v][2] = o[5]; P->qq[v][3] = o[6]; }
+  }
+  return PGO_OK;
+}
+
+int fill_scale_one(pgo_problem* P) {
+  std::vector<double> one((size_t)6 * P->g.N, 1.0);
+  HIP_TRY(staged_h2d(P->g.scale, one.data(), one.size() * sizeof(double), P->stream));
+  return PGO_OK;
+}
+
+// =================================================================================================
+// C ABI (include/pgo.h)
+// =================================================================================================
+extern "C" {
+
+int pgo_version(void) { return PGO_VERSION; }
+const char* pgo_last_error(void) { return last_error_string(); }
+
+int pgo_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return count;
+}
+
+static int g_default_device = 0;
+int pgo_set_device(int device) {
+  if (device < 0) return set_error(PGO_ERR_INVALID_ARGUMENT, "negative device index");
+  g_default_device = device;
+  return PGO_OK;
+}
+
+pgo_problem* pgo_problem_create(void) {
+  pgo_problem* p = new (std::nothrow) pgo_problem();
+  if (p) p->device = g_default_device;
+  return p;
+}
+void pgo_problem_destroy(pgo_problem* problem) { delete problem; }
+
+int pgo_problem_add_pose(pgo_problem* P, double* p, double* q) {
+  if (!P || !p || !q) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_problem_add_pose");
+  auto ip = P->block_of_ptr.find(p), iq = P->block_of_ptr.find(q);
+  if (ip != P->block_of_ptr.end() || iq != P->block_of_ptr.end()) {
+    if (ip != P->block_of_ptr.end() && iq != P->block_of_ptr.end() && (ip->second >> 1) == (iq->second >> 1) &&
+        (ip->second & 1) == 0 && (iq->second & 1) == 1)
+      return ip->second >> 1;
+    return set_error(PGO_ERR_UNSUPPORTED, "a parameter block is already paired with a different translation/rotation block");
+  }
+  const int idx = (int)P->pp.size();
+  P->pp.push_back(p);
+  P->qq.push_back(q);
+  P->cmask.push_back(0);
+  P->block_of_ptr[p] = 2 * idx;
+  P->block_of_ptr[q] = 2 * idx + 1;
+  P->topo_dirty = true;
+  return idx;
+}
+
+int pgo_problem_add_poses(pgo_problem* P, int n, double* base, int stride) {
+  if (!P || !base || n < 0 || stride < 7) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_problem_add_poses");
+  const int first = (int)P->pp.size();
+  P->pp.reserve(first + n); P->qq.reserve(first + n); P->cmask.reserve(first + n);
+  P->block_of_ptr.reserve((size_t)2 * (first + n));
+  for (int i = 0; i < n; ++i) {
+    const int r = pgo_problem_add_pose(P, base + (size_t)i * stride, base + (size_t)i * stride + 3);
+    if (r < 0) return r;
+  }
+  return first;
+}
+
+int pgo_problem_add_se3_between_batch(pgo_problem* P, int n, const int* begin, const int* end, const double* t_be,
+                                      const double* sqrt_information) {
+  if (!P || n < 0 || (n > 0 && (!begin || !end || !t_be))) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_problem_add_se3_between_batch");
+  const int N = (int)P->pp.size();
+  for (int i = 0; i < n; ++i) {
+    if (begin[i] < 0 || begin[i] >= N || end[i] < 0 || end[i] >= N)
+      return set_error(PGO_ERR_INVALID_ARGUMENT, "edge %d references a pose that was never added", i);
+    if (begin[i] == end[i]) return set_error(PGO_ERR_INVALID_ARGUMENT, "edge %d connects a pose to itself", i);
+  }
+  const int first = (int)P->ia.size();
+  if (sqrt_information && !P->has_info) {
+    // earlier edges used the identity
+    P->sqrt_info.assign((size_t)36 * first, 0.0);
+    for (int e = 0; e < first; ++e) for (int d = 0; d < 6; ++d) P->sqrt_info[(size_t)36 * e + 7 * d] = 1.0;
+    P->has_info = true;
+  }
+  P->ia.insert(P->ia.end(), begin, begin + n);
+  P->ib.insert(P->ib.end(), end, end + n);
+  P->meas.insert(P->meas.end(), t_be, t_be + (size_t)7 * n);
+  if (P->has_info) {
+    if (sqrt_information) {
+      P->sqrt_info.insert(P->sqrt_info.end(), sqrt_information, sqrt_information + (size_t)36 * n);
+    } else {
+      const size_t old = P->sqrt_info.size();
+      P->sqrt_info.resize(old + (size_t)36 * n, 0.0);
+      for (int e = 0; e < n; ++e) for (int d = 0; d < 6; ++d) P->sqrt_info[old + (size_t)36 * e + 7 * d] = 1.0;
+    }
+  }
+  P->topo_dirty = true;
+  return first;
+}
+
+int pgo_problem_add_se3_between(pgo_problem* P, int pose_begin, int pose_end, const double* t_be_p, const double* t_be_q,
+                                const double* sqrt_information) {
+  if (!P || !t_be_p || !t_be_q) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_problem_add_se3_between");
+  double t[7] = {t_be_p[0], t_be_p[1], t_be_p[2], t_be_q[0], t_be_q[1], t_be_q[2], t_be_q[3]};
+  return pgo_problem_add_se3_between_batch(P, 1, &pose_begin, &pose_end, t, sqrt_information);
+}
+
+int pgo_problem_set_loss(pgo_problem* P, int kind, double a) {
+  if (!P) return set_error(PGO_ERR_INVALID_ARGUMENT, "null problem");
+  if (kind < PGO_LOSS_TRIVIAL || kind > PGO_LOSS_SWITCHABLE) return set_error(PGO_ERR_UNSUPPORTED, "unknown loss kind %d", kind);
+  if (kind != PGO_LOSS_TRIVIAL && !(a > 0.0)) return set_error(PGO_ERR_INVALID_ARGUMENT, "loss scale must be positive");
+  P->loss_kind = kind;
+  P->loss_a = a;
+  return PGO_OK;
+}
+
+int pgo_problem_set_pose_constant(pgo_problem* P, int pose, int which) {
+  if (!P || pose < 0 || pose >= (int)P->pp.size() || (which & ~3) || which == 0)
+    return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_problem_set_pose_constant");
+  P->cmask[pose] |= (uint8_t)which;
+  P->topo_dirty = true;
+  return PGO_OK;
+}
+
+int pgo_problem_set_parameter_block_constant(pgo_problem* P, const double* block) {
+  if (!P || !block) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument");
+  auto it = P->block_of_ptr.find(block);
+  if (it == P->block_of_ptr.end()) return set_error(PGO_ERR_INVALID_ARGUMENT, "parameter block not found in the problem");
+  return pgo_problem_set_pose_constant(P, it->second >> 1, (it->second & 1) ? 2 : 1);
+}
+
+int pgo_problem_num_poses(const pgo_problem* P) { return P ? (int)P->pp.size() : 0; }
+int pgo_problem_num_edges(const pgo_problem* P) { return P ? (int)P->ia.size() : 0; }
+
+void pgo_solver_options_init(pgo_solver_options* o) {
+  memset(o, 0, sizeof *o);
+  o->max_num_iterations = 50;
+  o->linear_solver_type = PGO_SPARSE_NORMAL_CHOLESKY;
+  o->jacobi_scaling = 1;
+  o->max_linear_solver_iterations = 500;
+  o->min_linear_solver_iterations = 0;
+  o->max_num_consecutive_invalid_steps = 5;
+  o->cg_batch = 0;
+  o->pcg_cluster_poses = 1;
+  o->cg_residual_reset_period = 10;   // LinearSolver::Options::residual_reset_period of Ceres 1.13
+  o->reserved0 = 0;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->eta = 1e-1;
+  o->exact_r_tolerance = 1e-13;
+}
+
+int pgo_release_device_memory(void) {
+  device_pool().trim();
+  host_side_pool().trim();
+  return PGO_OK;
+}
+
+}  // extern "C"
