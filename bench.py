@@ -266,7 +266,16 @@ def main():
         # solver really runs (HIP events around 200 iterations on the solver stream), split between its two kernels in
         # proportion of their isolated durations — this is the figure the rocprofv3 --kernel-trace average of the same
         # command reproduces (profiles/), the isolated back-to-back duration (MALL-warm) is kept next to it
-        t_iter = prob.time_kernel("pcg_graph", 5) if world == 1 else None
+        # (one rank, PCG, graphs of this size: the timed region runs the universal stream — k_uni_s in its CG mode is the SpMV — so the
+        # in-situ figure is a (k_uni_v, k_uni_s) pair of that stream; otherwise a captured batch of the k_spmv / k_pcg_update kernels)
+        uni = False
+        t_iter = None
+        if world == 1 and not sharded:
+            try:
+                t_iter = prob.time_kernel("uni_cg", 5)
+                uni = True
+            except Exception:  # noqa: BLE001 - the session does not use the universal stream
+                t_iter = prob.time_kernel("pcg_graph", 5)
         t_spmv_situ = t_iter * t_spmv / (t_spmv + t_upd) if t_iter else t_spmv
         ach = b_spmv / (t_spmv_situ * 1e-3) / 1e9
         # HBM bytes per launch: only from a PMC profile taken on THESE kernel sources (sha256 of pgo_kernels.hip recorded by
@@ -279,13 +288,15 @@ def main():
             if pmcs and (N, E) == (N_POSES, N_EDGES):
                 pm = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
                 if pm.get("kernel_source_sha256_16") == sha:
-                    traffic = pm["kernels"]["k_spmv<0>"]["hbm_bytes_per_launch_corrected"]
+                    traffic = pm["kernels"]["k_uni_s" if uni else "k_spmv<0>"]["hbm_bytes_per_launch_corrected"]
                     extra["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH+WRITE; same kernel sources %s)" % (pmcs[-1], sha)
                 else:
                     extra["traffic_source"] = "none: profiles/%s was taken on other kernel sources (%s vs %s)" % (pmcs[-1], pm.get("kernel_source_sha256_16"), sha)
         except Exception:
             traffic = None
-        roofline = {"kernel": "k_spmv<0> (PCG block SpMV, FP64 6x6 BSR)", "bound": "hbm", "achieved": round(ach, 1),
+        roofline = {"kernel": ("k_uni_s, CG mode (the universal stream's slot kernel: PCG block SpMV, FP64 6x6 BSR)" if uni else
+                               "k_spmv<0> (PCG block SpMV, FP64 6x6 BSR)"), "rocprof_kernel_name": "k_uni_s" if uni else "k_spmv<0",
+                    "bound": "hbm", "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": b_spmv, "avg_launch_us": round(t_spmv_situ * 1e3, 3),
                     "avg_launch_us_isolated": round(t_spmv * 1e3, 3),

@@ -199,6 +199,38 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     else return -1;
     return 0;
   };
+  if (k == "uni_cg") {
+    // one CG iteration of the universal stream in situ: a head launch starts a CG whose stopping tests are disabled, then 200
+    // (vector, slot) pairs run between two events on the solver stream — what the timed region of bench.py consists of
+    if (!P->universal) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('uni_cg'): this session does not use the universal stream");
+    if (P->pipe_dirty) { int rc = lm_upload_state(P); if (rc) return rc; P->pipe_dirty = false; }
+    pgo::CgParams np{-1.0, -1.0, 1 << 30, 0};
+    pgo::DeviceGraph gp = P->g;
+    gp.lm = P->d_lm.p;
+    const int pairs = 200;
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    double total = 0;
+    for (int r = 0; r < repeats + 1; ++r) {
+      pgo::launch_lm_budget(gp, -1, s);
+      pgo::launch_uni_v(gp, np, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, s);    // head: damping, preconditioner, CG start
+      pgo::launch_uni_s(gp, np, 0, s);
+      HIP_TRY(hipEventRecord(a, s));
+      for (int i = 0; i < pairs; ++i) { pgo::launch_uni_v(gp, np, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, s); pgo::launch_uni_s(gp, np, 0, s); }
+      HIP_TRY(hipEventRecord(b, s));
+      HIP_TRY(hipEventSynchronize(b));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, a, b));
+      if (r > 0) total += ms;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    P->uni_enq = 0;
+    P->pipe_dirty = true;        // the device state (CG counters, operation words) is re-uploaded before the next LM step
+    *avg_ms = total / repeats / pairs;
+    return PGO_OK;
+  }
   if (k == "pcg_graph") {
     // average time of one CG iteration inside a captured batch with every stopping test disabled
     pgo::CgParams np{-1.0, -1.0, 1 << 30, 0};

@@ -475,7 +475,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
   // the root down.
   const long long tile32_below = (long long)env_or("PGO_FRONT_TILE32_BELOW", 192);
   // width of the outer panels of the factorisation (left-looking inside, one right-looking GEMM behind each): a multiple of 48
-  const int nbo = std::max((int)FRONT_NB, (int)env_or("PGO_FRONT_NBO", FRONT_NBO) / FRONT_NB * FRONT_NB);
+  const int nbo = FRONT_NBO;     // (288 / 384 / 576 measured slower in r02 behind PGO_FRONT_NBO: the longer left-looking sums cost more than the longer-K updates gain)
   {
     std::vector<int> next_step(nf, 0), nsteps(nf), kids_left(nf), pending(nf, -1);
     std::vector<char> asm_done(nf, 0), finished(nf, 0);

@@ -485,6 +485,7 @@ bool lm_pre_step(LmState& L, const pgo_solver_options& o);
 StepAction lm_post_step(LmState& L, const pgo_solver_options& o, const StepScalars& sc, int extra_linear_iterations);
 pgo::LmTolerances lm_tolerances(const pgo_solver_options& o);
 int lm_advance(pgo_problem* P);
+int lm_upload_state(pgo_problem* P);
 int lm_run_pipelined(pgo_problem* P, int budget, int* ran);
 int lm_run_universal(pgo_problem* P, int budget, int* ran);
 int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* records, int capacity);

@@ -55,8 +55,7 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool wi
   // The refresh r = b - A x belongs to Ceres' truncated CG (Q-tolerance stop).  An exact request served by PCG runs to a
   // 1e-13 relative residual, below what a recomputed residual can show in FP64 on an ill-conditioned chain: with the
   // refresh the test would never fire (measured: 27x the iterations on sphere x10), so that mode keeps the recurrence.
-  static const bool exact_refresh = getenv("PGO_EXACT_REFRESH") != nullptr;   // experiment switch
-  const int period = (prm.q_tolerance < 0.0 && !exact_refresh) ? 0 : P->opt.cg_residual_reset_period;
+  const int period = prm.q_tolerance < 0.0 ? 0 : P->opt.cg_residual_reset_period;
   auto refresh_at = [&](int i) { return period > 0 && ((start_it + i) % period) == 0; };
   if (P->use_graph) {
     if (memcmp(&P->cg_graph_params, &prm, sizeof prm) != 0) { P->drop_graph(); P->cg_graph_params = prm; }
@@ -105,20 +104,16 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool wi
 // 3-6 iterations) and later batches grow like sqrt(3.4 * iterations already enqueued) — not by doubling, which wastes up
 // to half of the last batch.  Sizes are quantised so that only a handful of graphs is ever captured.
 int pick_batch(const pgo::CgParams& prm, int user_batch, int round, int enqueued, int last_iterations) {
-  static const int env_b0 = getenv("PGO_CG_BATCH0") ? atoi(getenv("PGO_CG_BATCH0")) : 0;
-  static const int env_double = getenv("PGO_CG_DOUBLING") ? atoi(getenv("PGO_CG_DOUBLING")) : 0;   // the r01 schedule 6,12,24,48,64
-  static const double env_c = getenv("PGO_CG_SQRTC") ? atof(getenv("PGO_CG_SQRTC")) : 3.4;
-  static const int env_cap0 = getenv("PGO_CG_CAP0") ? atoi(getenv("PGO_CG_CAP0")) : 8;
+  // (the r01 doubling schedule and the constants 3.4 / 8 were switches PGO_CG_DOUBLING / _SQRTC / _CAP0 / _BATCH0 while they were
+  // being measured — 0.397 -> 0.354 ms per C2 LM iteration in r01; closed in r03)
   static const int sizes[] = {2, 4, 6, 8, 12, 16, 24, 32, 48, 64};
   int batch;
   if (user_batch > 0) {
     batch = user_batch;
-  } else if (env_double) {
-    batch = std::min(64, (env_b0 > 0 ? env_b0 : 6) << std::min(round, 4));
   } else {
     double target;
-    if (round == 0) target = env_b0 > 0 ? env_b0 : (last_iterations > 0 ? std::min(last_iterations, env_cap0) : 6);
-    else target = std::sqrt(env_c * std::max(1, enqueued));
+    if (round == 0) target = last_iterations > 0 ? std::min(last_iterations, 8) : 6;
+    else target = std::sqrt(3.4 * std::max(1, enqueued));
     batch = 64;
     for (int sz : sizes) if (sz >= target) { batch = sz; break; }
   }
@@ -525,10 +520,11 @@ int run_direct(pgo_problem* P, const pgo::DeviceGraph& G) {
           q = last;
         }
       }
-      // The backward substitution stays one launch per level: in its single-launch form (PGO_SFRONT_FUSED_BWD=1) every front of
-      // the tree polls its parent's flag at once and the ten hand-overs take 88 us against 50 us for the ten launches (KITTI-00).
-      static const bool fused_bwd = getenv("PGO_SFRONT_FUSED_BWD") && getenv("PGO_SFRONT_FUSED_BWD")[0] == '1';
-      pgo::launch_sfront_solve(G, P->fplan, P->splan, P->fsym, s, fused_bwd ? &sy_bwd : nullptr);
+      // The backward substitution stays one launch per level: in its single-launch form (measured in r02 behind a switch, closed in
+      // r03) every front of the tree polls its parent's flag at once and the ten hand-overs take 88 us against 50 us for the ten
+      // launches (KITTI-00).
+      (void)sy_bwd;
+      pgo::launch_sfront_solve(G, P->fplan, P->splan, P->fsym, s, nullptr);
     } else {
       pgo::launch_sfront_factor(G, P->fplan, P->splan, P->fsym, s);
       pgo::launch_sfront_solve(G, P->fplan, P->splan, P->fsym, s);
