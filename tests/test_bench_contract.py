@@ -72,4 +72,6 @@ def test_quoted_traffic_and_kernel_statistics_exist_in_the_committed_profiles():
     spmv = [x for x in rows if r.get("rocprof_kernel_name", "k_spmv<0") in x["kernel"]]
     assert spmv and float(spmv[0]["pct"]) > 30.0                      # the roofline kernel IS the dominant kernel of the timed command
     # the in-situ duration of the bench line and the rocprofv3 average of the same command agree within the profiler's overhead
-    assert abs(float(spmv[0]["avg_us"]) - r["avg_launch_us"]) / r["avg_launch_us"] < 0.2
+    # (k_uni_s: one launch in ~20 is the linearisation, ~17 us, and the drain launches are short: the MEDIAN launch is a CG SpMV)
+    col = "median_us" if "k_uni_s" in r["kernel"] else "avg_us"
+    assert abs(float(spmv[0][col]) - r["avg_launch_us"]) / r["avg_launch_us"] < 0.2
