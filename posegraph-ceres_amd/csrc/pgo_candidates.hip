@@ -63,7 +63,7 @@ struct Buf {
 
 }  // namespace
 
-int pgo_candidates_set_error(int code, const char* msg);   // pgo_solver.cpp
+int pgo_candidates_set_error(int code, const char* msg);   // pgo_problem.cpp
 
 #define CAND_TRY(expr)                                                              \
   do {                                                                              \

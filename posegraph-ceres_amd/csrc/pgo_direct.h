@@ -79,7 +79,7 @@ struct DirectSymbolic {
 // Nested-dissection ordering of the pose graph (perm[new] = old); shared with the multifrontal solver (pgo_front.h).
 bool nested_dissection_order(int N, const std::vector<int>& ia, const std::vector<int>& ib, std::vector<int>* perm);
 
-// Host symbolic analysis.  slot_* describe the incidence-slot BSR (pgo_solver.cpp prepare()).
+// Host symbolic analysis.  slot_* describe the incidence-slot BSR (pgo_problem.cpp prepare()).
 // Returns false when the factorisation would be impractical (caller falls back to the iterative path).
 bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib, int n_slots,
                     const std::vector<int>& slot_row, const std::vector<int>& slot_col,

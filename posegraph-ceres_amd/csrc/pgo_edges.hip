@@ -23,7 +23,7 @@
 
 #include "../../include/pgo.h"
 
-int pgo_candidates_set_error(int code, const char* msg);   // pgo_solver.cpp
+int pgo_candidates_set_error(int code, const char* msg);   // pgo_problem.cpp
 
 namespace {
 

@@ -1,4 +1,4 @@
-// pgo_kernels.h — launch interface between the host LM driver (pgo_solver.cpp) and the gfx950
+// pgo_kernels.h — launch interface between the host LM driver (pgo_lm.cpp, pgo_linear.cpp) and the gfx950
 // kernels (pgo_kernels.hip).  Plain structs of device pointers; no torch types.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -61,7 +61,7 @@ enum LmHalt { LM_RUN = 0, LM_HALT_TERMINATED = 1, LM_HALT_CG_STALL = 2, LM_HALT_
 enum UniOp { UNI_EXIT = -1, UNI_NOP = 0, UNI_S_CG = 1, UNI_S_REFRESH = 2, UNI_S_LINEARIZE = 3,
              UNI_V_HEAD = 1, UNI_V_UPDATE = 2, UNI_V_UPDATE_X = 3, UNI_V_UPDATE_R = 4, UNI_V_STEP_TAIL = 5 };
 enum LmPhase { LM_PHASE_NEW = 0, LM_PHASE_CONT = 1 };
-struct LmRecord {            // layout of pgo_iteration_record (include/pgo.h; static_assert in pgo_solver.cpp)
+struct LmRecord {            // layout of pgo_iteration_record (include/pgo.h; static_assert in pgo_internal.h)
   int iteration, step_is_successful, linear_solver_iterations, reserved;
   double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;
 };

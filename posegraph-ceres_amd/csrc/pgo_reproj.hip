@@ -16,7 +16,7 @@
 #include "../../include/pgo.h"
 #include "pgo_math.h"
 
-int pgo_candidates_set_error(int code, const char* msg);   // pgo_solver.cpp (error channel of the library)
+int pgo_candidates_set_error(int code, const char* msg);   // pgo_problem.cpp (error channel of the library)
 
 namespace {
 

@@ -1,6 +1,6 @@
 """-m gpu tests of the device-resident Levenberg-Marquardt loop (r03): the trust-region decisions of SURVEY.md A.6 steps 4-7
 are taken by the last work-group of the step tail and the host enqueues the kernel sequences of the next iterations ahead of
-them (pgo_kernels.h LmDev, pgo_lm_rules.h, pgo_solver.cpp lm_run_pipelined).  The host-in-the-loop driver of r02 is still
+them (pgo_kernels.h LmDev, pgo_lm_rules.h, pgo_lm.cpp lm_run_pipelined / lm_run_universal).  The host-in-the-loop driver of r02 is still
 there (several ranks, batched solve, PGO_NO_PIPELINE=1) and applies the very same rule function, so the two must produce the
 same iteration records BIT FOR BIT: same kernels, same inputs, same decisions."""
 import os
