@@ -184,6 +184,17 @@ PGO_API int pgo_problem_add_se3_between_batch(pgo_problem* problem, int n, const
                                       const double* t_be, const double* sqrt_information);
 
 /* the single LossFunction instance shared by every residual block (finial.cpp:495,513) */
+/* ---- pose / landmark problems (role of g2o's BlockSolver, Thirdparty/g2o/g2o/core/block_solver.hpp:47-87) ----
+ * A 3-D point is a parameter block of size 3 (Euclidean) in CALLER memory, updated in place by pgo_solve; it shares the node
+ * index space of the poses.  An observation is the point expressed in the observing pose's frame,
+ *     r = L3 ( R(q_pose)^T (l - p_pose) - z ),      L3 = 3x3 row-major square-root information (NULL: identity),
+ * with the problem's loss function.  Exact solves eliminate the point blocks first (the Schur complement onto the poses, as
+ * BlockSolver does with Hll^-1), then the poses by nested dissection of the reduced graph.  Returns the index / the first index. */
+PGO_API int pgo_problem_add_point(pgo_problem* problem, double* xyz);
+PGO_API int pgo_problem_add_points(pgo_problem* problem, int n, double* base, int stride_doubles);
+PGO_API int pgo_problem_add_point_observation_batch(pgo_problem* problem, int n, const int* pose, const int* point, const double* z,
+                                                    const double* sqrt_information3);
+
 PGO_API int pgo_problem_set_loss(pgo_problem* problem, int loss_kind, double loss_parameter);
 
 /* Problem::SetParameterBlockConstant (finial.cpp:525-527). which: 1 = translation, 2 = rotation, 3 = both */

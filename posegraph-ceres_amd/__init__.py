@@ -34,6 +34,7 @@ OK, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NUMERICAL
 # every symbol include/pgo.h declares (tests check the built library exports all of them)
 C_ABI_SYMBOLS = [
     "pgo_version", "pgo_last_error", "pgo_device_count", "pgo_set_device", "pgo_problem_create",
+    "pgo_problem_add_point", "pgo_problem_add_points", "pgo_problem_add_point_observation_batch",
     "pgo_problem_destroy", "pgo_problem_add_pose", "pgo_problem_add_poses", "pgo_problem_add_se3_between",
     "pgo_problem_add_se3_between_batch", "pgo_problem_set_loss", "pgo_problem_set_pose_constant",
     "pgo_problem_set_parameter_block_constant", "pgo_problem_num_poses", "pgo_problem_num_edges",
@@ -402,6 +403,26 @@ class Problem:
         if not (len(ia) == len(ib) == len(t)) or (si is not None and len(si) != len(ia)):
             raise ValueError("edge arrays disagree in length")
         return _check(lib().pgo_problem_add_se3_between_batch(self._h, C.c_int(len(ia)), _ip(ia), _ip(ib), _dp(t), _dp(si)))
+
+    # ---- pose / landmark problems ----
+    def add_points(self, points):
+        """points: (M,3) float64 C-contiguous array of 3-D points (size-3 Euclidean blocks), updated IN PLACE by solve().
+        Returns the node index of the first one (points share the index space of the poses)."""
+        if not (isinstance(points, np.ndarray) and points.dtype == np.float64 and points.ndim == 2 and points.shape[1] == 3
+                and points.flags["C_CONTIGUOUS"]):
+            raise ValueError("points must be a C-contiguous float64 (M,3) array")
+        self._keep.append(points)
+        return _check(lib().pgo_problem_add_points(self._h, C.c_int(points.shape[0]), _dp(points), C.c_int(3)))
+
+    def add_point_observations(self, pose, point, z, sqrt_information3=None):
+        """z[i] = the point `point[i]` in the frame of pose `pose[i]` (3 numbers); residual L3 (R(q)^T (l - p) - z)."""
+        ip = np.ascontiguousarray(pose, dtype=np.int32).reshape(-1)
+        il = np.ascontiguousarray(point, dtype=np.int32).reshape(-1)
+        zz = np.ascontiguousarray(z, dtype=np.float64).reshape(-1, 3)
+        si = None if sqrt_information3 is None else np.ascontiguousarray(sqrt_information3, dtype=np.float64).reshape(-1, 9)
+        if not (len(ip) == len(il) == len(zz)) or (si is not None and len(si) != len(ip)):
+            raise ValueError("observation arrays disagree in length")
+        return _check(lib().pgo_problem_add_point_observation_batch(self._h, C.c_int(len(ip)), _ip(ip), _ip(il), _dp(zz), _dp(si)))
 
     def set_loss(self, kind, a=1.0):
         _check(lib().pgo_problem_set_loss(self._h, C.c_int(kind), C.c_double(a)))

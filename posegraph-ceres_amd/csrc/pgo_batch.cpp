@@ -34,6 +34,7 @@ int solve_batch(pgo_problem* const* probs, int n, const pgo_solver_options* opti
     const pgo_problem* Q = probs[c];
     if (!Q || Q->pp.empty()) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solve_batch: problem %d is null or empty", c);
     if (Q->comm) return set_error(PGO_ERR_UNSUPPORTED, "pgo_solve_batch: problem %d is attached to a communicator", c);
+    for (uint8_t f : Q->is_point) if (f) return set_error(PGO_ERR_UNSUPPORTED, "pgo_solve_batch: problem %d has point blocks (pose graphs only)", c);
     if (Q->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solve_batch: problem %d is inside a solver session", c);
     if (Q->loss_kind != M.loss_kind || Q->loss_a != M.loss_a)
       return set_error(PGO_ERR_UNSUPPORTED, "pgo_solve_batch: all problems must use the same loss function (problem %d differs)", c);

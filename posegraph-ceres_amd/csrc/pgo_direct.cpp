@@ -337,16 +337,69 @@ static bool order_components(const Csr& g, const Components& C, std::vector<int>
   return true;
 }
 
-bool nested_dissection_order(int N, const std::vector<int>& ia, const std::vector<int>& ib, std::vector<int>* perm) {
+// Pose / landmark problems (g2o's BlockSolver, Thirdparty/g2o/g2o/core/block_solver.hpp:47-87, splits the
+// Hessian into Hpp, Hll, Hpl and eliminates the landmark blocks by the Schur complement Hpp - Hpl Hll^-1 Hpl'): in a sparse Cholesky
+// that IS an elimination order — every 3-D point first (points are only linked to poses, so they are leaves of the elimination tree
+// and eliminating them creates no fill among themselves), then the poses, ordered by nested dissection of the REDUCED graph in which
+// two poses that observe a common point are neighbours (the pattern of the Schur complement).  Component by component, a component's
+// columns contiguous as the analyses expect.  A point seen by more than 12 poses links its observers as a chain instead of a clique
+// (the links only steer the dissection; the symbolic factorisation works on the true graph).
+static bool order_components_points_first(const Csr& g, const Components& C, const std::vector<uint8_t>& is_point, std::vector<int>* perm) {
+  const int N = (int)g.ptr.size() - 1;
+  std::vector<int> pose_id(N, -1), poses;
+  for (int v = 0; v < N; ++v) if (!is_point[v]) { pose_id[v] = (int)poses.size(); poses.push_back(v); }
+  const int Np = (int)poses.size();
+  std::vector<int> ra, rb, obs;
+  for (int v = 0; v < N; ++v) {
+    if (!is_point[v]) {
+      for (int p = g.ptr[v]; p < g.ptr[v + 1]; ++p) { const int u = g.idx[p]; if (!is_point[u] && u > v) { ra.push_back(pose_id[v]); rb.push_back(pose_id[u]); } }
+      continue;
+    }
+    obs.clear();
+    for (int p = g.ptr[v]; p < g.ptr[v + 1]; ++p) if (!is_point[g.idx[p]]) obs.push_back(pose_id[g.idx[p]]);
+    if (obs.size() <= 12) {
+      for (size_t i = 0; i < obs.size(); ++i) for (size_t j = i + 1; j < obs.size(); ++j) { ra.push_back(obs[i]); rb.push_back(obs[j]); }
+    } else {
+      for (size_t i = 0; i + 1 < obs.size(); ++i) { ra.push_back(obs[i]); rb.push_back(obs[i + 1]); }
+    }
+  }
+  std::vector<int> rperm;
+  if (Np > 0) {
+    const Csr gr = build_adjacency(Np, ra, rb);
+    const Components Cr = find_components(gr);
+    if (!order_components(gr, Cr, &rperm) || (int)rperm.size() != Np) return false;
+  }
+  // position of every pose in the reduced order; a component of the full graph takes its points (ascending), then its poses by that position
+  std::vector<int> rpos(Np, 0);
+  for (int k = 0; k < Np; ++k) rpos[rperm[k]] = k;
+  perm->clear();
+  perm->reserve(N);
+  std::vector<int> cp;
+  for (int c = 0; c < C.count(); ++c) {
+    cp.clear();
+    for (int q = C.ptr[c]; q < C.ptr[c + 1]; ++q) { const int v = C.verts[q]; if (is_point[v]) perm->push_back(v); else cp.push_back(v); }
+    std::sort(cp.begin(), cp.end(), [&](int a, int b) { return rpos[pose_id[a]] < rpos[pose_id[b]]; });
+    perm->insert(perm->end(), cp.begin(), cp.end());
+  }
+  return true;
+}
+static bool has_points(const std::vector<uint8_t>* is_point) {
+  if (!is_point) return false;
+  for (uint8_t f : *is_point) if (f) return true;
+  return false;
+}
+
+bool nested_dissection_order(int N, const std::vector<int>& ia, const std::vector<int>& ib, std::vector<int>* perm, const std::vector<uint8_t>* is_point) {
   const Csr g = build_adjacency(N, ia, ib);
   const Components C = find_components(g);
+  if (has_points(is_point)) return order_components_points_first(g, C, *is_point, perm) && (int)perm->size() == N;
   return order_components(g, C, perm) && (int)perm->size() == N;
 }
 
 bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib, int n_slots,
                     const std::vector<int>& slot_row, const std::vector<int>& slot_col,
                     const std::vector<uint8_t>& slot_side, const std::vector<int>& row_slot_begin,
-                    DirectSymbolic* out) {
+                    DirectSymbolic* out, const std::vector<uint8_t>* is_point) {
   DirectSymbolic& S = *out;
   S = DirectSymbolic();
   S.n = N;
@@ -363,7 +416,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
 
   // ---- 1. ordering: nested dissection per connected component ----
   const Components comps = find_components(g);
-  if (!order_components(g, comps, &S.perm)) return false;
+  if (has_points(is_point) ? !order_components_points_first(g, comps, *is_point, &S.perm) : !order_components(g, comps, &S.perm)) return false;
   S.iperm.assign(N, -1);
   for (int k = 0; k < N; ++k) S.iperm[S.perm[k]] = k;
   phase("nested dissection");

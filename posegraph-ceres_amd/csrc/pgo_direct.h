@@ -77,14 +77,17 @@ struct DirectSymbolic {
 };
 
 // Nested-dissection ordering of the pose graph (perm[new] = old); shared with the multifrontal solver (pgo_front.h).
-bool nested_dissection_order(int N, const std::vector<int>& ia, const std::vector<int>& ib, std::vector<int>* perm);
+// is_point (optional, [N]): 1 for the 3-D point blocks of a pose / landmark problem — they are eliminated first (the Schur
+// complement onto the poses), the poses by nested dissection of the reduced graph
+bool nested_dissection_order(int N, const std::vector<int>& ia, const std::vector<int>& ib, std::vector<int>* perm,
+                             const std::vector<uint8_t>* is_point = nullptr);
 
 // Host symbolic analysis.  slot_* describe the incidence-slot BSR (pgo_problem.cpp prepare()).
 // Returns false when the factorisation would be impractical (caller falls back to the iterative path).
 bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib, int n_slots,
                     const std::vector<int>& slot_row, const std::vector<int>& slot_col,
                     const std::vector<uint8_t>& slot_side, const std::vector<int>& row_slot_begin,
-                    DirectSymbolic* out);
+                    DirectSymbolic* out, const std::vector<uint8_t>* is_point = nullptr);
 
 // Device launches.  flags[2] is set when a pivot is not positive.
 // epoch > 0 (a new value per factorisation): SPLIT steps run as ONE launch, sub-diagonal blocks waiting in-kernel for their

@@ -31,7 +31,8 @@ double env_or(const char* name, double dflt) {
 
 bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib, int n_slots,
                    const std::vector<int>& slot_row, const std::vector<int>& slot_col,
-                   const std::vector<uint8_t>& slot_side, long long max_bytes, FrontSymbolic* out, int small_max) {
+                   const std::vector<uint8_t>& slot_side, long long max_bytes, FrontSymbolic* out, int small_max,
+                   const std::vector<uint8_t>* is_point) {
   FrontSymbolic& S = *out;
   S = FrontSymbolic();
   S.n = N;
@@ -46,7 +47,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
   };
   // ---- 1. ordering + adjacency in that ordering ----
   std::vector<int> perm0;
-  if (!nested_dissection_order(N, ia, ib, &perm0)) return false;
+  if (!nested_dissection_order(N, ia, ib, &perm0, is_point)) return false;
   std::vector<int> iperm0(N);
   for (int k = 0; k < N; ++k) iperm0[perm0[k]] = k;
   std::vector<int> aptr(N + 1, 0), aidx;   // full neighbour lists in the perm0 numbering (duplicates allowed)

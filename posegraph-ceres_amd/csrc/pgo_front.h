@@ -214,7 +214,8 @@ struct FrontSymbolic {
 // small_max > 0: when no front exceeds that many scalars the analysis stops at the small-front plan (out->small).
 bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib, int n_slots,
                    const std::vector<int>& slot_row, const std::vector<int>& slot_col,
-                   const std::vector<uint8_t>& slot_side, long long max_bytes, FrontSymbolic* out, int small_max = 0);
+                   const std::vector<uint8_t>& slot_side, long long max_bytes, FrontSymbolic* out, int small_max = 0,
+                   const std::vector<uint8_t>* is_point = nullptr);
 
 // Device launches: factorisation (includes the forward substitution) and backward substitution into g.cg_x.
 // flags[2] is set when a pivot is not positive.

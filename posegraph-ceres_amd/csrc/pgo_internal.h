@@ -26,6 +26,8 @@ namespace pgo { int comm_stress(Comm* c, int iters, size_t seg, hipStream_t s, i
 #include <thread>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <array>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -310,6 +312,11 @@ struct pgo_problem {
   std::vector<double*> pp, qq;
   std::unordered_map<const double*, int> block_of_ptr;  // pose*2 + (0: p block, 1: q block)
   std::vector<uint8_t> cmask;
+  // pose / landmark problems: a 3-D point is a node whose translation block is the caller's 3 doubles and whose
+  // rotation block is a constant identity quaternion owned by the problem; an observation is a between-factor whose information
+  // has no rotation part.  is_point steers the elimination order (points first = the Schur complement onto the poses, pgo_direct.cpp)
+  std::vector<uint8_t> is_point;
+  std::deque<std::array<double, 4>> point_q;
   std::vector<int> ia, ib;
   std::vector<double> meas;       // 7 per edge
   std::vector<double> sqrt_info;  // 36 per edge once any edge carries a non-identity matrix

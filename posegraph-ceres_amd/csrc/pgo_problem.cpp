@@ -439,10 +439,58 @@ int pgo_problem_add_pose(pgo_problem* P, double* p, double* q) {
   P->pp.push_back(p);
   P->qq.push_back(q);
   P->cmask.push_back(0);
+  P->is_point.push_back(0);
   P->block_of_ptr[p] = 2 * idx;
   P->block_of_ptr[q] = 2 * idx + 1;
   P->topo_dirty = true;
   return idx;
+}
+
+// ---- pose / landmark problems (g2o analogue Thirdparty/g2o/g2o/core/block_solver.hpp:47-87) ----
+int pgo_problem_add_point(pgo_problem* P, double* xyz) {
+  if (!P || !xyz) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_problem_add_point");
+  auto it = P->block_of_ptr.find(xyz);
+  if (it != P->block_of_ptr.end()) {
+    if ((it->second & 1) == 0 && P->is_point[it->second >> 1]) return it->second >> 1;
+    return set_error(PGO_ERR_UNSUPPORTED, "the block is already a pose block");
+  }
+  const int idx = (int)P->pp.size();
+  P->point_q.push_back(std::array<double, 4>{0.0, 0.0, 0.0, 1.0});     // (deque: the address stays put)
+  P->pp.push_back(xyz);
+  P->qq.push_back(P->point_q.back().data());
+  P->cmask.push_back(2);             // the rotation block is constant: the node has three free dimensions
+  P->is_point.push_back(1);
+  P->block_of_ptr[xyz] = 2 * idx;
+  P->topo_dirty = true;
+  return idx;
+}
+
+int pgo_problem_add_points(pgo_problem* P, int n, double* base, int stride) {
+  if (!P || !base || n < 0 || stride < 3) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_problem_add_points");
+  int first = (int)P->pp.size();
+  for (int i = 0; i < n; ++i) {
+    const int r = pgo_problem_add_point(P, base + (size_t)i * stride);
+    if (r < 0) return r;
+    if (i == 0) first = r;         // (blocks added before keep their index)
+  }
+  return first;
+}
+
+int pgo_problem_add_point_observation_batch(pgo_problem* P, int n, const int* pose, const int* point, const double* z, const double* sqrt_information3) {
+  if (!P || n < 0 || (n > 0 && (!pose || !point || !z))) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_problem_add_point_observation_batch");
+  const int N = (int)P->pp.size();
+  for (int i = 0; i < n; ++i) {
+    if (pose[i] < 0 || pose[i] >= N || P->is_point[pose[i]]) return set_error(PGO_ERR_INVALID_ARGUMENT, "observation %d: %d is not a pose", i, pose[i]);
+    if (point[i] < 0 || point[i] >= N || !P->is_point[point[i]]) return set_error(PGO_ERR_INVALID_ARGUMENT, "observation %d: %d is not a point", i, point[i]);
+  }
+  // residual L3 (R(q_pose)^T (l - p_pose) - z): the translation rows of the between-factor from the pose to the point's node, no rotation rows
+  std::vector<double> t((size_t)7 * n, 0.0), L((size_t)36 * n, 0.0);
+  for (int i = 0; i < n; ++i) {
+    t[(size_t)7 * i] = z[3 * i]; t[(size_t)7 * i + 1] = z[3 * i + 1]; t[(size_t)7 * i + 2] = z[3 * i + 2]; t[(size_t)7 * i + 6] = 1.0;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) L[(size_t)36 * i + 6 * r + c] = sqrt_information3 ? sqrt_information3[(size_t)9 * i + 3 * r + c] : (r == c ? 1.0 : 0.0);
+  }
+  return pgo_problem_add_se3_between_batch(P, n, pose, point, t.data(), L.data());
 }
 
 int pgo_problem_add_poses(pgo_problem* P, int n, double* base, int stride) {

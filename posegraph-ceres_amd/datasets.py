@@ -200,6 +200,73 @@ def manhattan_se3(n_poses=10000, n_edges=40000, seed=20260928, sigma_t=0.05, sig
     return PoseGraphData(init, ia, ib, meas, sqrt_info, truth=truth, name="manhattan_se3_%d_%d" % (n, len(ia)))
 
 
+class PoseLandmarkData:
+    """A pose / landmark problem: `graph` = the pose part (odometry between-factors), points (M,3) initial
+    guesses, observations obs_pose / obs_point (indices into poses / points), obs_z (K,3) = the point in the observing pose's
+    frame, obs_sqrt_info3 (K,9).  as_pose_graph(): the same problem as ONE pose graph — every point a node with a constant
+    identity quaternion, every observation a between-factor whose information has no rotation part — which is what both the
+    oracle and the product solve (nodes: poses first, then points; returns the graph and the constant mask)."""
+
+    def __init__(self, graph, points, obs_pose, obs_point, obs_z, obs_sqrt_info3, truth_points=None):
+        self.graph = graph
+        self.points = np.ascontiguousarray(points, dtype=np.float64)
+        self.obs_pose = np.ascontiguousarray(obs_pose, dtype=np.int32)
+        self.obs_point = np.ascontiguousarray(obs_point, dtype=np.int32)
+        self.obs_z = np.ascontiguousarray(obs_z, dtype=np.float64)
+        self.obs_sqrt_info3 = np.ascontiguousarray(obs_sqrt_info3, dtype=np.float64)
+        self.truth_points = truth_points
+
+    def as_pose_graph(self):
+        g = self.graph
+        N, M, K = g.N, self.points.shape[0], len(self.obs_pose)
+        poses = np.zeros((N + M, 7))
+        poses[:N] = g.poses
+        poses[N:, :3] = self.points
+        poses[N:, 6] = 1.0
+        meas = np.zeros((K, 7))
+        meas[:, :3] = self.obs_z
+        meas[:, 6] = 1.0
+        L = np.zeros((K, 6, 6))
+        L[:, :3, :3] = self.obs_sqrt_info3.reshape(K, 3, 3)
+        si_pose = g.sqrt_info if g.sqrt_info is not None else np.repeat(np.eye(6).reshape(1, 36), g.E, axis=0)
+        full = PoseGraphData(poses, np.concatenate([g.ia, self.obs_pose]), np.concatenate([g.ib, N + self.obs_point]),
+                             np.concatenate([g.meas, meas]), np.concatenate([si_pose, L.reshape(K, 36)]))
+        cmask = np.zeros(N + M, dtype=np.uint8)
+        cmask[0] = 3
+        cmask[N:] = 2
+        return full, cmask
+
+
+def pose_landmark_toy(n_poses=150, n_points=1500, seed=20260932, sigma_t=0.05, sigma_r=0.01, sigma_z=0.03, view_radius=4.0, max_views=8):
+    """A trajectory (the Manhattan walk of manhattan_se3, odometry factors only) through a cloud of 3-D points, every point
+    observed from up to `max_views` poses within `view_radius`; observation = the point in the pose's frame + N(0, sigma_z)."""
+    from scipy.spatial import cKDTree
+    g = manhattan_se3(n_poses, n_poses - 1, seed=seed, sigma_t=sigma_t, sigma_r=sigma_r)
+    rng = np.random.default_rng(seed + 1)
+    truth = g.truth
+    anchor = rng.integers(0, n_poses, size=n_points)
+    pts = truth[anchor, :3] + rng.uniform(-2.0, 2.0, size=(n_points, 3))
+    tree = cKDTree(truth[:, :3])
+    op, ol = [], []
+    for j, nb in enumerate(tree.query_ball_point(pts, view_radius)):
+        nb = sorted(nb)
+        if len(nb) > max_views:
+            nb = sorted(rng.choice(nb, size=max_views, replace=False).tolist())
+        if not nb:
+            nb = [int(anchor[j])]
+        op += nb
+        ol += [j] * len(nb)
+    op, ol = np.asarray(op, dtype=np.int32), np.asarray(ol, dtype=np.int32)
+    z = qrot(qconj(truth[op, 3:]), pts[ol] - truth[op, :3]) + rng.normal(0.0, sigma_z, size=(len(op), 3))
+    # initial points: from the first observation and the dead-reckoned pose of its observer
+    first = np.full(n_points, -1)
+    for k in range(len(op) - 1, -1, -1):
+        first[ol[k]] = k
+    init = g.poses[op[first], :3] + qrot(g.poses[op[first], 3:], z[first])
+    L3 = np.repeat((np.eye(3) / sigma_z).reshape(1, 9), len(op), axis=0)
+    return PoseLandmarkData(g, init, op, ol, z, L3, truth_points=pts)
+
+
 def sphere_layers(n_spheres=10, rings=50, per_ring=50, radius=50.0, seed=20260931, chord_radius=8.0,
                   n_edges=None, sigma_t=0.05, sigma_r=0.01):
     """sphere2500-style layouts chained; ring/meridian neighbours + random chords."""

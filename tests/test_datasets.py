@@ -58,3 +58,22 @@ def test_generator_rejects_impossible_loop_counts(ds):
         ds.manhattan_se3(30, 200)                 # 30 poses admit 45 pairs with an id gap > 20
     g = ds.manhattan_se3(30, 29)                  # odometry only
     assert (g.N, g.E) == (30, 29)
+
+
+def test_pose_landmark_toy_and_its_pose_graph_form(ds, O):
+    """SURVEY 8f row 3 toy: observations are consistent with the truth to the stated noise, the pose-graph statement of the problem
+    (points = nodes with a constant identity quaternion, observations = between-factors without rotation information) is what the
+    oracle solves, and solving it brings the points from metres to centimetres of the truth."""
+    import numpy as np
+    pl = ds.pose_landmark_toy(n_poses=60, n_points=400, seed=11)
+    g = pl.graph
+    zt = ds.qrot(ds.qconj(g.truth[pl.obs_pose, 3:]), pl.truth_points[pl.obs_point] - g.truth[pl.obs_pose, :3])
+    assert np.abs(zt - pl.obs_z).max() < 6 * 0.03
+    full, cmask = pl.as_pose_graph()
+    assert full.N == 460 and full.E == g.E + len(pl.obs_pose) and (cmask[60:] == 2).all() and cmask[0] == 3
+    assert np.all(full.sqrt_info[g.E:].reshape(-1, 6, 6)[:, 3:, :] == 0.0) and np.all(full.sqrt_info[g.E:].reshape(-1, 6, 6)[:, :, 3:] == 0.0)
+    og = O.Graph(full.poses, full.ia, full.ib, full.meas, full.sqrt_info, cmask)
+    p, s, tr = O.solve(og, O.default_options(max_num_iterations=40, linear_solver=0))
+    assert s.termination_type == 0 and s.final_cost < 0.2 * s.initial_cost
+    assert np.array_equal(p[60:, 3:], np.tile([0.0, 0.0, 0.0, 1.0], (400, 1)))          # the constant blocks stayed put
+    assert np.abs(p[60:, :3] - pl.truth_points).max() < 0.25 * np.abs(pl.points - pl.truth_points).max()
