@@ -543,6 +543,108 @@ __global__ __launch_bounds__(256) void k_front_gemm(FrontPlan p, int wg_begin) {
   const int wgi = wg_begin + blockIdx.x;
   front_gemm_body<TILE>(p, p.jobs[p.wg_job[wgi]], p.wg_tile[wgi]);
 }
+// (kept for tools/bench/gemm_lds_bench.hip, which times it beside its successor: the 64 x 64 tiles of the solver go through
+// k_front_gemm_lds below since r03)
+
+// ---- LDS-staged Schur / outer-panel update (r03) -----------------------------------------------------------------------------
+// Same job as front_gemm_body<64> — C[64 x 64 tile] -= A[64 x K] B[64 x K]^T, lower tiles — with the operands going global -> LDS
+// once per work-group (the register kernel above fetches every A row for one wave and every B row for each of the four: 320 row
+// segments per k-chunk against 128 here) and 32 x 32 per wave (2 x 2 MFMA tiles, four independent accumulators; wave w: rows
+// 32 (w >> 1), columns 32 (w & 1)).  K runs in chunks of GL_KC through two LDS buffers: the next chunk's 8 doubles per lane are
+// in flight in registers while the matrix cores work on the current one.  The planes are stored k-major ([k][row], GL_LD doubles
+// per k) so that a fragment read — lane (li, g4) takes row li of k = 4 s + g4 — is four runs of sixteen consecutive doubles.
+// ~90 VGPRs and 34 KB of LDS: four work-groups per CU, i.e. the matrix pipe always has several waves to issue from
+// (tools/bench/mfma_rate.hip: 31.5 TFLOP/s with one wave per SIMD, 41 with two, 44 with four).
+constexpr int GL_KC = 16, GL_LD = 64 + 4;
+__device__ __forceinline__ void front_gemm_lds_body(const FrontPlan& p, const FrontJob& J, int tt, double (*As)[GL_KC][GL_LD], double (*Bs)[GL_KC][GL_LD]) {
+  const int ti = tt >> 16, tj = tt & 0xffff;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g4 = lane >> 4;
+  const int row0 = J.r0 + 64 * ti, col0 = J.c0 + 64 * tj;
+  double* F = p.Fval + J.fbase;
+  const int ld = J.ld, klen = J.klen;
+  // global -> registers: lane t fetches 4 consecutive k of row (t >> 2) of the A panel and of the B panel
+  const int lrow = tid >> 2, lseg = tid & 3;
+  const double* Ag = F + (size_t)min(row0 + lrow, J.r1 - 1) * ld + J.k0 + 4 * lseg;
+  const double* Bg = F + (size_t)min(col0 + lrow, J.c1 - 1) * ld + J.k0 + 4 * lseg;
+  double2 ra[2], rb[2];
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = kc + 4 * lseg + 2 * h;
+      const int kk = min(k, klen - 2);                       // (klen is even: 192 or 6 c)
+      ra[h] = *reinterpret_cast<const double2*>(Ag + (kk - 4 * lseg));
+      rb[h] = *reinterpret_cast<const double2*>(Bg + (kk - 4 * lseg));
+      if (k >= klen) { ra[h] = double2{0.0, 0.0}; rb[h] = double2{0.0, 0.0}; }
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      As[buf][4 * lseg + 2 * h][lrow] = ra[h].x; As[buf][4 * lseg + 2 * h + 1][lrow] = ra[h].y;
+      Bs[buf][4 * lseg + 2 * h][lrow] = rb[h].x; Bs[buf][4 * lseg + 2 * h + 1][lrow] = rb[h].y;
+    }
+  };
+  const int wr = 32 * (wave >> 1), wc = 32 * (wave & 1);
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  fetch(0);
+  // the C entries this lane updates, requested now: the epilogue then only subtracts and stores (their latency used to sit at the
+  // end of every tile, where no other load hides it)
+  double cv[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = min(row0 + wr + 16 * a + g4 + 4 * r, J.r1 - 1), c = min(col0 + wc + 16 * b + li, J.c1 - 1);
+        cv[a][b][r] = F[(size_t)row * ld + c];
+      }
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kc = 0; kc < klen; kc += GL_KC) {
+    const bool more = kc + GL_KC < klen;
+    if (more) fetch(kc + GL_KC);
+#pragma unroll
+    for (int s4 = 0; s4 < GL_KC / 4; ++s4) {
+      const double a0 = As[buf][4 * s4 + g4][wr + li], a1 = As[buf][4 * s4 + g4][wr + 16 + li];
+      const double b0 = Bs[buf][4 * s4 + g4][wc + li], b1 = Bs[buf][4 * s4 + g4][wc + 16 + li];
+      mma16(acc[0][0], a0, b0);
+      mma16(acc[0][1], a0, b1);
+      mma16(acc[1][0], a1, b0);
+      mma16(acc[1][1], a1, b1);
+    }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const double4_t v = unrot(acc[a][b]);
+      const int R0 = row0 + wr + 16 * a, C0 = col0 + wc + 16 * b;
+      if (C0 > min(R0 + 15, J.r1 - 1)) continue;            // a 16 x 16 block entirely above the diagonal
+      const int c = C0 + li;
+      if (c >= J.c1) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = R0 + g4 + 4 * r;
+        if (row >= J.r1) continue;
+        F[(size_t)row * ld + c] = cv[a][b][r] - v[r];
+      }
+    }
+}
+__global__ __launch_bounds__(256) void k_front_gemm_lds(FrontPlan p, int wg_begin) {
+  if (p.halt && *p.halt) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
+  __shared__ double As[2][GL_KC][GL_LD], Bs[2][GL_KC][GL_LD];
+  const int wgi = wg_begin + blockIdx.x;
+  front_gemm_lds_body(p, p.jobs[p.wg_job[wgi]], p.wg_tile[wgi], As, Bs);
+}
 
 #ifndef FRONT_POLL_SLEEP
 #define FRONT_POLL_SLEEP 8
@@ -550,7 +652,8 @@ __global__ __launch_bounds__(256) void k_front_gemm(FrontPlan p, int wg_begin) {
 // ---- the single-launch form (FrontStages, pgo_front.h): every work-group of the launch schedule in one grid ------------------
 __global__ __launch_bounds__(320) void k_front_stages(DeviceGraph g, FrontPlan p, FrontStages fs) {
   if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
-  __shared__ double smem[FRONT_NB * LDW + FRONT_NB * LDWD + 128];
+  constexpr int SMEM_PANEL = FRONT_NB * LDW + FRONT_NB * LDWD + 128, SMEM_GEMM = 4 * GL_KC * GL_LD;   // panel step / LDS-staged update
+  __shared__ double smem[SMEM_PANEL > SMEM_GEMM ? SMEM_PANEL : SMEM_GEMM];
   __shared__ int tk;
   const int tid = threadIdx.x;
   if (tid == 0) {
@@ -581,7 +684,7 @@ __global__ __launch_bounds__(320) void k_front_stages(DeviceGraph g, FrontPlan p
   if (kind != 1 && tid >= 256) return;                     // only a panel step has work for the fifth wave
   if (kind == 1) front_panel_body(p, J, tt >> 16, g.flags, smem, smem + FRONT_NB * LDW, smem + FRONT_NB * LDW + FRONT_NB * LDWD);
   else if (kind == 0) front_extend_add_body(p, w, reinterpret_cast<double (*)[ASM_T + 1]>(smem));
-  else if (kind == 2) front_gemm_body<64>(p, J, tt);
+  else if (kind == 2) front_gemm_lds_body(p, J, tt, reinterpret_cast<double (*)[GL_KC][GL_LD]>(smem), reinterpret_cast<double (*)[GL_KC][GL_LD]>(smem + 2 * GL_KC * GL_LD));
   else front_gemm_body<32>(p, J, tt);
   drain_stores();          // every wave's own stores acknowledged by the L2 before the barrier: wave 0's write-back below then covers them all
   __syncthreads();
@@ -1282,7 +1385,7 @@ void launch_front_factor(const DeviceGraph& g, const FrontPlan& p_in, const Fron
     if (La.type == FrontLaunch::ASM) hipLaunchKernelGGL(k_front_extend_add, dim3(La.n_wg), dim3(256), 0, s, p, La.wg_begin);
     else if (La.type == FrontLaunch::PANEL) hipLaunchKernelGGL(k_front_panel, dim3(La.n_wg), dim3(320), 0, s, p, La.wg_begin, g.flags);
     else if (La.tile == 32) hipLaunchKernelGGL(k_front_gemm<32>, dim3(La.n_wg), dim3(256), 0, s, p, La.wg_begin);
-    else hipLaunchKernelGGL(k_front_gemm<64>, dim3(La.n_wg), dim3(256), 0, s, p, La.wg_begin);
+    else hipLaunchKernelGGL(k_front_gemm_lds, dim3(La.n_wg), dim3(256), 0, s, p, La.wg_begin);
   }
 }
 

@@ -35,6 +35,6 @@ template <int NACC> void run(int blocks, int threads) {
 }
 int main() {
   run<1>(1, 64); run<2>(1, 64); run<4>(1, 64); run<8>(1, 64);
-  run<4>(1, 256); run<4>(256, 256); run<4>(1024, 256); run<4>(2048, 512); run<8>(1024, 256);
+  run<4>(1, 256); run<4>(256, 256); run<4>(512, 256); run<4>(768, 256); run<4>(1024, 256); run<4>(2048, 512); run<8>(1024, 256); run<16>(256, 256); run<16>(512, 256);
   return 0;
 }
