@@ -15,7 +15,7 @@
 //   k_chol_panel      PANEL chains: wave 0 factorises L_jj while waves 1..7 walk the forward row list and the sub-diagonal blocks
 //   k_bwd_level4      backward levels: four waves share a column's blocks, six-lane finish
 //   k_bwd_tail        backward tail: x of the tail and its column descriptors in LDS
-// (k_chol_level, k_chol_assemble, k_bwd_level are the one-wave forms, kept behind PGO_DIRECT_ROLES/ASM4/BWD4=0;
+// (the one-wave forms k_chol_level, k_chol_assemble, k_bwd_level were removed in r03 with the switches that selected them;
 //  k_chol_split is the single-launch SPLIT step, used while the step has at most one workgroup per CU.)
 #include "pgo_direct.h"
 
@@ -228,48 +228,9 @@ __device__ __forceinline__ bool chol6_inplace(double* Ljj) {
   return ok;
 }
 
-// ---- SPLIT levels (dense separators): phase 1, one wave per BLOCK: V = A - sum_q L[upd_a] L[upd_b]^T, the update list
-// shared by the ten 6-lane groups, partial rows summed through LDS in a fixed order.  A diagonal block is factorised on
-// the spot (L_jj), an off-diagonal block is left as V in Lval for phase 2. ----
-__global__ __launch_bounds__(64) void k_chol_assemble(DeviceGraph g, DirectPlan p, int blk_begin) {
-  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
-  __shared__ double sh[360];
-  const int bi = p.split_blk[blk_begin + blockIdx.x];
-  const int lane = threadIdx.x;
-  const int grp = lane / 6, r = lane - 6 * grp;
-  if (grp < 10) {
-    double v[6];
-    assemble_row(g, p, bi, r, grp, 10, v, p.upd_split[bi]);   // = the whole list outside PANEL steps
-#pragma unroll
-    for (int c = 0; c < 6; ++c) sh[(grp * 6 + r) * 6 + c] = v[c];
-  }
-  __syncthreads();
-  const bool diagonal = p.split_diag[blk_begin + blockIdx.x] != 0;
-  if (!diagonal) {
-    if (lane < 36) {
-      double s = 0.0;
-#pragma unroll
-      for (int gq = 0; gq < 10; ++gq) s += sh[gq * 36 + lane];
-      p.Lval[36 * (size_t)bi + lane] = s;
-    }
-    return;
-  }
-  const int j = p.blk_row[bi];
-  const double bj = forward_rhs(g, p.perm[j]);
-  double Ljj[36];
-  sum_partials(sh, Ljj, nullptr);
-  const bool ok = chol6_inplace(Ljj);
-  if (!ok && lane == 0) atomicOr(&g.flags[2], 1);
-  if (lane < 36) p.Lval[36 * (size_t)bi + lane] = Ljj[lane];
-  // fused forward substitution for this column
-  __syncthreads();
-  forward_partial(p, j, 0, 1, sh);
-  __syncthreads();
-  forward_finish(p, j, bj, 1, sh, Ljj);
-}
-
-// The same with four waves per block (long update lists: dense separators): forty 6-lane groups share the list, the forward
-// step of a diagonal block's column is shared by the four waves too.
+// ---- SPLIT levels (dense separators): phase 1, four waves per BLOCK: V = A - sum_q L[upd_a] L[upd_b]^T, the update list shared by
+// forty 6-lane groups, partial rows summed through LDS in a fixed order.  A diagonal block is factorised on the spot (L_jj) and the
+// forward step of its column shared by the four waves too; an off-diagonal block is left as V in Lval for phase 2. ----
 constexpr int ASM_WAVES = 4;
 __global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_assemble4(DeviceGraph g, DirectPlan p, int blk_begin) {
   if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
@@ -608,14 +569,6 @@ __global__ __launch_bounds__(192) void k_chol_level3(DeviceGraph g, DirectPlan p
   factor_column_roles(g, p, j, threadIdx.x >> 6, shd, sho, shf, Ld);
 }
 
-__global__ __launch_bounds__(64) void k_chol_level(DeviceGraph g, DirectPlan p, int level) {
-  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
-  __shared__ double sh[360];
-  const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
-  factor_column(g, p, j, sh);
-}
-
-
 // ---- wide levels (the union of a batched solve: tens of thousands of light columns per level) -------------------------------
 // One 6-lane GROUP per column, ten columns per wave, forty per workgroup: a level of n columns keeps 30 x fewer waves busy
 // than k_chol_level3 (three waves per column — the right shape when a level has a few hundred columns and latency is all that
@@ -848,15 +801,7 @@ __device__ __forceinline__ void backward_finish(const DeviceGraph& g, const Dire
   for (int i = 0; i < 6; ++i) { p.y[6 * (size_t)j + i] = x[i]; g.cg_x[6 * (size_t)old + i] = x[i]; }
 }
 
-__global__ __launch_bounds__(64) void k_bwd_level(DeviceGraph g, DirectPlan p, int level) {
-  if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
-  __shared__ double sh[64];
-  const int j = p.level_cols[p.level_ptr[level] + blockIdx.x];
-  backward_partial(p, j, 0, 1, sh);
-  __syncthreads();
-  if (threadIdx.x == 0) backward_finish(g, p, j, 1, sh);
-}
-// The same with four waves per column (forty 6-lane groups on the column's blocks) and the six-lane finish of the tail,
+// Backward level: four waves per column (forty 6-lane groups on the column's blocks) and the six-lane finish of the tail,
 // its inputs (y_j, L_jj, the permutation) fetched beside the partial sums.
 constexpr int BWD_WAVES = 4;
 __global__ __launch_bounds__(64 * BWD_WAVES) void k_bwd_level4(DeviceGraph g, DirectPlan p, int level) {
@@ -1024,24 +969,20 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
   // from the start; chain-like graphs: KITTI-00 replay -56 us per LM iteration); PGO_DIRECT_FUSE_SPLIT=1 raises the limit
   // to SPLIT_FUSED_MAX (no gain measured on dense separators: the wait costs what the launch did), =0 switches it off
   static const int fuse_split_max = !getenv("PGO_DIRECT_FUSE_SPLIT") ? 256 : getenv("PGO_DIRECT_FUSE_SPLIT")[0] == '0' ? 0 : SPLIT_FUSED_MAX;
-  // block assembly with four waves per block (default; PGO_DIRECT_ASM4=0: one wave) — KITTI-00 dense 10.7 -> ~8 us per launch
-  static const bool asm4 = !(getenv("PGO_DIRECT_ASM4") && getenv("PGO_DIRECT_ASM4")[0] == '0');
+  // (block assembly with four waves per block — KITTI-00 dense 10.7 -> ~8 us per launch —, three waves per column in the COLUMN
+  // levels — 1-4 us per level of KITTI-00 — and four per column in the backward levels were switches in r01 / r02
+  // (PGO_DIRECT_ASM4 / _ROLES / _BWD4); the one-wave forms they kept alive went with them in r03)
   for (const DirectStep& st : sym.steps) {
     if (st.type == DirectStep::COLUMN) {
       const int nc = sym.level_ptr[st.level_begin + 1] - sym.level_ptr[st.level_begin];
-      // three waves per column by default (every COLUMN level of KITTI-00 gains 1-4 us); PGO_DIRECT_ROLES=<columns per level
-      // up to which they are used>, 0 = one wave per column
-      static const int roles_max = getenv("PGO_DIRECT_ROLES") ? atoi(getenv("PGO_DIRECT_ROLES")) : (1 << 30);
       // wide levels (batched solves): one 6-lane group per column from PGO_DIRECT_GROUPS columns on (default 4096)
       static const int grp_min = getenv("PGO_DIRECT_GROUPS") ? atoi(getenv("PGO_DIRECT_GROUPS")) : 4096;
       if (nc >= grp_min) hipLaunchKernelGGL(k_chol_level_grp, dim3((nc + 10 * GRP_WAVES - 1) / (10 * GRP_WAVES)), dim3(64 * GRP_WAVES), 0, s, g, p, st.level_begin);
-      else if (nc <= roles_max) hipLaunchKernelGGL(k_chol_level3, dim3(nc), dim3(192), 0, s, g, p, st.level_begin);
-      else hipLaunchKernelGGL(k_chol_level, dim3(nc), dim3(64), 0, s, g, p, st.level_begin);
+      else hipLaunchKernelGGL(k_chol_level3, dim3(nc), dim3(192), 0, s, g, p, st.level_begin);
     } else if (st.type == DirectStep::FUSED) {
       hipLaunchKernelGGL(k_chol_tail, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, st.level_begin, st.level_end);
     } else if (st.type == DirectStep::PANEL) {
-      if (asm4) hipLaunchKernelGGL(k_chol_assemble4, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin);
-      else hipLaunchKernelGGL(k_chol_assemble, dim3(st.blk_end - st.blk_begin), dim3(64), 0, s, g, p, st.blk_begin);
+      hipLaunchKernelGGL(k_chol_assemble4, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin);
       hipLaunchKernelGGL(k_chol_panel, dim3(st.sub_end), dim3(64 * FUSED_WAVES), 0, s, g, p, st.sub_begin, st.level_end - st.level_begin);
     } else if (epoch > 0 && st.blk_end - st.blk_begin <= fuse_split_max) {
       // bounded wait (PGO_DIRECT_SPLIT_SPINS, default 2^22 polls ~ 1 s): when it runs out — the workgroups of the step were
@@ -1051,8 +992,7 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
       const int max_spins = spins_env ? atoi(spins_env) : (1 << 22);
       hipLaunchKernelGGL(k_chol_split, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin, epoch, max_spins);
     } else {
-      if (asm4) hipLaunchKernelGGL(k_chol_assemble4, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin);
-      else hipLaunchKernelGGL(k_chol_assemble, dim3(st.blk_end - st.blk_begin), dim3(64), 0, s, g, p, st.blk_begin);
+      hipLaunchKernelGGL(k_chol_assemble4, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin);
       const int nsub = st.sub_end - st.sub_begin;
       if (nsub > 0) hipLaunchKernelGGL(k_chol_scale, dim3((nsub + 9) / 10), dim3(64), 0, s, g, p, st.sub_begin, st.sub_end);
     }
@@ -1061,8 +1001,6 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
 
 // backward solve only: the forward substitution runs inside the factorisation kernels
 void launch_direct_solve(const DeviceGraph& g, const DirectPlan& p, const int* level_ptr_host, int fused_from_level, hipStream_t s) {
-  // four waves per column in the backward levels (default; PGO_DIRECT_BWD4=0: one wave, serial finish)
-  static const bool bwd4 = !(getenv("PGO_DIRECT_BWD4") && getenv("PGO_DIRECT_BWD4")[0] == '0');
   if (fused_from_level < p.n_levels) {
     if (p.n - level_ptr_host[fused_from_level] <= BWD_TAIL_LDS_COLS)
       hipLaunchKernelGGL(k_bwd_tail<true>, dim3(1), dim3(64 * FUSED_WAVES), 0, s, g, p, fused_from_level);
@@ -1073,8 +1011,7 @@ void launch_direct_solve(const DeviceGraph& g, const DirectPlan& p, const int* l
     const int nc = level_ptr_host[l + 1] - level_ptr_host[l];
     static const int grp_min = getenv("PGO_DIRECT_GROUPS") ? atoi(getenv("PGO_DIRECT_GROUPS")) : 4096;
     if (nc >= grp_min) hipLaunchKernelGGL(k_bwd_level_grp, dim3((nc + 10 * GRP_WAVES - 1) / (10 * GRP_WAVES)), dim3(64 * GRP_WAVES), 0, s, g, p, l);
-    else if (bwd4) hipLaunchKernelGGL(k_bwd_level4, dim3(nc), dim3(64 * BWD_WAVES), 0, s, g, p, l);
-    else hipLaunchKernelGGL(k_bwd_level, dim3(nc), dim3(64), 0, s, g, p, l);
+    else hipLaunchKernelGGL(k_bwd_level4, dim3(nc), dim3(64 * BWD_WAVES), 0, s, g, p, l);
   }
 }
 
