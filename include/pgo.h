@@ -364,6 +364,11 @@ PGO_API int pgo_comm_get_unique_id(unsigned char id[128]);
 PGO_API int pgo_comm_init(pgo_problem* problem, const unsigned char id[128], int rank, int world);
 /* Test transport: `world` virtual ranks = problems driven by host threads of ONE process on one GPU, segments exchanged
  * by device-to-device copies.  Lets the sharded path be validated on a single-GPU machine. */
+/* development / test hook (tests/test_lm_rules_cpu.py): one application of the trust-region rules the device and the host driver share
+ * (csrc/pgo_lm_rules.h), on the host, no GPU.  state[4] = radius, decrease factor, current cost, |x| (in / out); step[4] = candidate
+ * cost, model cost change, |step|^2, |x|^2; out[6] = outcome (0 invalid, 1 invalid and failed, 2 parameter tolerance, 3 function
+ * tolerance, 4 accepted, 5 rejected), step_is_successful, relative decrease, cost change, radius after, the message's number. */
+PGO_API int pgo_debug_lm_decide(const pgo_solver_options* options, double state[4], const double step[4], int cg_status, double out[6]);
 /* development aid (tools/comm_stress.py): `iters` exchanges of a test pattern through the problem's communicator, mismatches counted */
 PGO_API int pgo_debug_comm_stress(pgo_problem* problem, int iters, int seg_doubles);
 PGO_API void* pgo_loopback_create(int world);

@@ -41,7 +41,7 @@ C_ABI_SYMBOLS = [
     "pgo_solver_options_init", "pgo_solve", "pgo_summary_is_solution_usable", "pgo_summary_full_report",
     "pgo_evaluate", "pgo_normal_equations", "pgo_linear_solve", "pgo_plus", "pgo_solver_begin",
     "pgo_solver_step", "pgo_solver_reset", "pgo_solver_end", "pgo_time_kernel", "pgo_shard_range",
-    "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_debug_comm_stress", "pgo_loopback_create", "pgo_loopback_destroy", "pgo_comm_init_loopback",
+    "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_debug_comm_stress", "pgo_debug_lm_decide", "pgo_loopback_create", "pgo_loopback_destroy", "pgo_comm_init_loopback",
     "pgo_generate_candidates", "pgo_reproj_options_init", "pgo_reproj_solve_batch",
     "pgo_row_shard_range", "pgo_read_trajectory", "pgo_build_odometry_edges", "pgo_edge_rules_init", "pgo_build_edges",
     "pgo_solve_batch", "pgo_release_device_memory",

@@ -294,6 +294,22 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
 }
 
 // ---- sharding helpers ------------------------------------------------------------------------------
+// Development / test hook: ONE application of the trust-region rules (pgo_lm_rules.h lm_decide — the function both the device and
+// the host driver apply) on the host, no GPU involved.  state = {radius, decrease_factor, x_cost, x_norm} in and out;
+// step = {cand_cost, model_change, step_norm_sq, x_norm_sq}; out = {outcome, step_is_successful, relative_decrease, cost_change,
+// radius after, value quoted by a termination message}.
+int pgo_debug_lm_decide(const pgo_solver_options* options, double state[4], const double step[4], int cg_status, double out[6]) {
+  if (!options || !state || !step || !out) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_debug_lm_decide");
+  pgo::LmCore C{state[0], state[1], state[2], state[3], 0.0, 0, 0, 0, 0};
+  const pgo::LmStepIn in{step[0], step[1], step[2], step[3], 0, cg_status, 0, 0};
+  pgo::LmRecord nx{};
+  double value = 0.0;
+  const pgo::LmOutcome o = pgo::lm_decide(C, lm_tolerances(*options), in, nx, value);
+  state[0] = C.radius; state[1] = C.decrease_factor; state[2] = C.x_cost; state[3] = C.x_norm;
+  out[0] = (double)o; out[1] = (double)nx.step_is_successful; out[2] = nx.relative_decrease; out[3] = nx.cost_change; out[4] = C.radius; out[5] = value;
+  return PGO_OK;
+}
+
 int pgo_shard_range(long long n, int rank, int world, long long* begin, long long* end) {
   if (n < 0 || world <= 0 || rank < 0 || rank >= world || !begin || !end) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_shard_range");
   const long long base = n / world, rem = n % world;
