@@ -279,5 +279,6 @@ void launch_batch_accept(const DeviceGraph& g, const BatchPlan& b, hipStream_t s
 int vec_block();
 int pose_block();
 int edge_block();
+int max_edge_wg();
 
 }  // namespace pgo

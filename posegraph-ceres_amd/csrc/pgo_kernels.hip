@@ -588,32 +588,38 @@ __global__ __launch_bounds__(64) void k_cluster_precond(DeviceGraph g, double ra
 // ------------------------------------------------------------------------------------------------
 // Cost only: 0.5 * sum rho(|L e|^2) over edges at `poses` (ComputeCandidatePointAndEvaluateCost).
 // ------------------------------------------------------------------------------------------------
+// 0.5 rho(|L e|^2) of edge e at `poses`
+template <int INFO>
+__device__ __forceinline__ double edge_cost(const DeviceGraph& g, const double* poses, int e) {
+  const PoseRec A = load_pose(poses, g.edge_a[e]), B = load_pose(poses, g.edge_b[e]);
+  const size_t E = (size_t)g.E;
+  const V3 mp{g.emeas[e], g.emeas[E + e], g.emeas[2 * E + e]};
+  const Q4 mq{g.emeas[3 * E + e], g.emeas[4 * E + e], g.emeas[5 * E + e], g.emeas[6 * E + e]};
+  double er[6];
+  edge_error(A.p, A.q, B.p, B.q, mp, mq, er);
+  double s;
+  if (INFO) {
+    const WBlocks W = g.info_mode == 3 ? load_W_diag(g.eW, E, (size_t)e) : load_W(g.eW, E, (size_t)e);   // (diagonal W: 6 of the 21 planes)
+    const V3 ep{er[0], er[1], er[2]}, eq{er[3], er[4], er[5]};
+    const V3 a1 = mulv(W.pp, ep), a2 = mulv(W.pr, eq), b1 = mulTv(W.pr, ep), b2 = mulv(W.rr, eq);
+    s = dot(ep, V3{a1.x + a2.x, a1.y + a2.y, a1.z + a2.z}) + dot(eq, V3{b1.x + b2.x, b1.y + b2.y, b1.z + b2.z});
+  } else {
+    s = er[0] * er[0] + er[1] * er[1] + er[2] * er[2] + er[3] * er[3] + er[4] * er[4] + er[5] * er[5];
+  }
+  double rho0, rho1;
+  loss_eval(g.loss_kind, g.loss_a, s, &rho0, &rho1);
+  return 0.5 * rho0;
+}
+
+// n_edge_wg work-groups stride over the edges (one edge per lane up to MAX_EDGE_WG * EDGE_BLOCK edges: beyond that the
+// partial row — and, in the step tail, the ticket counter every work-group bumps — would grow with E; 4 300 tickets on one
+// address cost 0.17 ms at 1 M edges, r03 profile).
 template <int INFO>
 __global__ void k_cost(DeviceGraph g, const double* poses, double* part, int gate) {
   __shared__ double scratch[8];
   if (gate && !g.cg->done) return;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
   double c[1] = {0.0};
-  if (e < g.E) {
-    const PoseRec A = load_pose(poses, g.edge_a[e]), B = load_pose(poses, g.edge_b[e]);
-    const size_t E = (size_t)g.E;
-    const V3 mp{g.emeas[e], g.emeas[E + e], g.emeas[2 * E + e]};
-    const Q4 mq{g.emeas[3 * E + e], g.emeas[4 * E + e], g.emeas[5 * E + e], g.emeas[6 * E + e]};
-    double er[6];
-    edge_error(A.p, A.q, B.p, B.q, mp, mq, er);
-    double s;
-    if (INFO) {
-      const WBlocks W = g.info_mode == 3 ? load_W_diag(g.eW, E, (size_t)e) : load_W(g.eW, E, (size_t)e);   // (diagonal W: 6 of the 21 planes)
-      const V3 ep{er[0], er[1], er[2]}, eq{er[3], er[4], er[5]};
-      const V3 a1 = mulv(W.pp, ep), a2 = mulv(W.pr, eq), b1 = mulTv(W.pr, ep), b2 = mulv(W.rr, eq);
-      s = dot(ep, V3{a1.x + a2.x, a1.y + a2.y, a1.z + a2.z}) + dot(eq, V3{b1.x + b2.x, b1.y + b2.y, b1.z + b2.z});
-    } else {
-      s = er[0] * er[0] + er[1] * er[1] + er[2] * er[2] + er[3] * er[3] + er[4] * er[4] + er[5] * er[5];
-    }
-    double rho0, rho1;
-    loss_eval(g.loss_kind, g.loss_a, s, &rho0, &rho1);
-    c[0] = 0.5 * rho0;
-  }
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < g.E; e += gridDim.x * blockDim.x) c[0] += edge_cost<INFO>(g, poses, e);
   block_sum<1>(c, scratch);
   if (threadIdx.x == 0) part[blockIdx.x] = c[0];
 }
@@ -1452,27 +1458,7 @@ __device__ __forceinline__ void step_tail_body(const DeviceGraph& g, int gate, i
       acc[3] += P.q.x * P.q.x + P.q.y * P.q.y + P.q.z * P.q.z + P.q.w * P.q.w;
     }
   }
-  const int e = bid * EDGE_BLOCK + tid;
-  if (pose_wg < 0 && e < g.E) {
-    const PoseRec A = load_pose(g.pose_c, g.edge_a[e]), B = load_pose(g.pose_c, g.edge_b[e]);
-    const size_t E = (size_t)g.E;
-    const V3 mp{g.emeas[e], g.emeas[E + e], g.emeas[2 * E + e]};
-    const Q4 mq{g.emeas[3 * E + e], g.emeas[4 * E + e], g.emeas[5 * E + e], g.emeas[6 * E + e]};
-    double er[6];
-    edge_error(A.p, A.q, B.p, B.q, mp, mq, er);
-    double sq;
-    if (INFO) {
-      const WBlocks W = g.info_mode == 3 ? load_W_diag(g.eW, E, (size_t)e) : load_W(g.eW, E, (size_t)e);   // (diagonal W: 6 of the 21 planes)
-      const V3 ep{er[0], er[1], er[2]}, eq{er[3], er[4], er[5]};
-      const V3 a1 = mulv(W.pp, ep), a2 = mulv(W.pr, eq), b1 = mulTv(W.pr, ep), b2 = mulv(W.rr, eq);
-      sq = dot(ep, V3{a1.x + a2.x, a1.y + a2.y, a1.z + a2.z}) + dot(eq, V3{b1.x + b2.x, b1.y + b2.y, b1.z + b2.z});
-    } else {
-      sq = er[0] * er[0] + er[1] * er[1] + er[2] * er[2] + er[3] * er[3] + er[4] * er[4] + er[5] * er[5];
-    }
-    double rho0, rho1;
-    loss_eval(g.loss_kind, g.loss_a, sq, &rho0, &rho1);
-    acc[0] = 0.5 * rho0;
-  }
+  for (int e = bid * EDGE_BLOCK + tid; pose_wg < 0 && e < g.E; e += g.n_edge_wg * EDGE_BLOCK) acc[0] += edge_cost<INFO>(g, g.pose_c, e);
   block_sum_w<4>(acc, scratch, EDGE_BLOCK / 64);
   if (tid == 0) {
 #pragma unroll
@@ -2375,5 +2361,6 @@ void launch_debug(const DeviceGraph& g, int which, hipStream_t s) {
 int vec_block() { return VEC_BLOCK; }
 int pose_block() { return POSE_BLOCK; }
 int edge_block() { return EDGE_BLOCK; }
+int max_edge_wg() { return 1024; }
 
 }  // namespace pgo

@@ -307,7 +307,7 @@ int prepare(pgo_problem* P) {
   HIP_TRY(P->d_cg_q.alloc((size_t)world * seg));   // exchange buffer: q segments + p'q partials (unused partial slots stay 0)
   HIP_TRY(P->d_cg_q.zero(s));
   const int n_vec_wg = std::max(1, std::min((int)(((size_t)6 * N + pgo::vec_block() - 1) / pgo::vec_block()), 256));
-  const int n_edge_wg = std::max(1, (E + pgo::edge_block() - 1) / pgo::edge_block());
+  const int n_edge_wg = std::min(std::max(1, (E + pgo::edge_block() - 1) / pgo::edge_block()), pgo::max_edge_wg());   // k_cost and the step tail stride beyond that
   const int n_pose_wg = (N + pgo::pose_block() - 1) / pgo::pose_block();
   const int n_part = std::max(std::max(n_wg, n_vec_wg), n_edge_wg + n_pose_wg);   // the fused step tail runs n_edge_wg + n_pose_wg workgroups
   // (blocks may come from the pool with a previous problem's contents: everything that is not fully written before it is read

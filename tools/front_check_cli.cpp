@@ -81,6 +81,20 @@ int main(int argc, char** argv) {
       for (int f = 0; f < S.nf; ++f) std::printf("F %d %d %d %d\n", f, S.fronts[f].c, S.fronts[f].r, S.fronts[f].parent);
       return 0;
     }
+    if (argv[2][0] == 'g') {   // per GEMM launch: work-groups, tile, flops on the tiles, longest K, jobs
+      for (const FrontLaunch& La : S.launches) {
+        if (La.type != FrontLaunch::GEMM) continue;
+        double fl = 0; int kmax = 0, kmin = 1 << 30, nj = 0, prev = -1;
+        for (int w = La.wg_begin; w < La.wg_begin + La.n_wg; ++w) {
+          const FrontJob& J = S.jobs[S.wg_job[w]];
+          fl += 2.0 * La.tile * La.tile * J.klen;
+          kmax = std::max(kmax, J.klen); kmin = std::min(kmin, J.klen);
+          if (S.wg_job[w] != prev) { prev = S.wg_job[w]; ++nj; }
+        }
+        std::printf("G %d %d %.4g %d %d %d\n", La.n_wg, La.tile, fl, kmin, kmax, nj);
+      }
+      return 0;
+    }
     if (argv[2][0] == 's') return 0;
   }
   // random SPD matrix in slot form: off-diagonal blocks random, diagonal = strictly dominant
@@ -121,6 +135,7 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 6; ++k) F[D.fbase + (size_t)n * D.ld + 6 * (j - D.first) + k] = b[6 * (size_t)S.perm[j] + k];
   }
   bool bad_pivot = false;
+  long long n_updated = 0;
   {
     for (size_t li = 0; li < S.launches.size(); ++li) {
       const FrontLaunch& La = S.launches[li];
@@ -150,14 +165,26 @@ int main(int argc, char** argv) {
         continue;
       }
 
-      // the jobs of a launch = the distinct entries of its workgroup -> job map (consecutive)
+      // the jobs of a launch = the distinct entries of its workgroup -> job map (consecutive); a GEMM launch is executed
+      // work-group by work-group, tile by tile (its tile list is part of what is checked)
       int prev = -1;
       for (int w = La.wg_begin; w < La.wg_begin + La.n_wg; ++w) {
         const int ji = S.wg_job[w];
-        if (ji == prev) continue;
-        prev = ji;
         const FrontJob& J = S.jobs[ji];
         double* A = &F[J.fbase];
+        if (J.c1 > 0) {
+          const int T = La.tile, ti = S.wg_tile[w] >> 16, tj = S.wg_tile[w] & 0xffff;
+          for (int i = J.r0 + T * ti; i < std::min(J.r0 + T * (ti + 1), J.r1); ++i)
+            for (int c = J.c0 + T * tj; c < std::min(std::min(J.c0 + T * (tj + 1), J.c1), i + 1); ++c) {
+              double s = 0.0;
+              for (int m = 0; m < J.klen; ++m) s += A[(size_t)i * J.ld + J.k0 + m] * A[(size_t)c * J.ld + J.k0 + m];
+              A[(size_t)i * J.ld + c] -= s;
+              ++n_updated;
+            }
+          continue;
+        }
+        if (ji == prev) continue;
+        prev = ji;
         if (La.type == FrontLaunch::PANEL) {
           const int nb = J.klen, k0 = J.k0;
           double Dk[FRONT_NB][FRONT_NB], Lk[FRONT_NB][FRONT_NB];
@@ -200,13 +227,6 @@ int main(int argc, char** argv) {
               A[(size_t)i * J.ld + k0 + c] = s;
             }
           }
-        } else {
-          for (int i = J.r0; i < J.r1; ++i)
-            for (int c = J.c0; c < std::min(J.c1, i + 1); ++c) {
-              double s = 0.0;
-              for (int m = 0; m < J.klen; ++m) s += A[(size_t)i * J.ld + J.k0 + m] * A[(size_t)c * J.ld + J.k0 + m];
-              A[(size_t)i * J.ld + c] -= s;
-            }
         }
       }
     }
@@ -260,6 +280,7 @@ int main(int argc, char** argv) {
     }
   double rn = 0.0, bn = 0.0;
   for (size_t i = 0; i < res.size(); ++i) { rn += res[i] * res[i]; bn += b[i] * b[i]; }
+  std::printf("updated entries %lld\n", n_updated);
   std::printf("bad_pivot %d relative residual %.3e\n", bad_pivot ? 1 : 0, std::sqrt(rn / bn));
   return std::sqrt(rn / bn) < 1e-10 && !bad_pivot ? 0 : 1;
 }
