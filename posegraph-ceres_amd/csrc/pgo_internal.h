@@ -335,7 +335,7 @@ struct pgo_problem {
   DevBuf<uint8_t> d_slot_side, d_cmask;
   DevBuf<double> d_smeas, d_sW, d_emeas, d_eW, d_eL, d_pose_x, d_pose_c, d_pose_0, d_bsr, d_Hdiag, d_Minv, d_grad,
       d_scale, d_d2, d_diagc, d_cg_b, d_cg_x, d_cg_r, d_cg_z, d_cg_q, d_cg_p0, d_cg_p1, d_delta, d_part_rz, d_part_q,
-      d_part_rr, d_part_bb, d_part_misc, d_tmp_a, d_tmp_b, d_tmp_c;
+      d_part_rr, d_part_bb, d_part_misc, d_tmp_a, d_tmp_b, d_tmp_c, d_cg_u, d_cg_w, d_cg_s, d_cg_qq, d_pipe_a, d_pipe_b, d_pipe_x;
   DevBuf<pgo::CgState> d_cg;
   // spare set of the linearisation (blocks, diagonal blocks, gradient): the candidate point is linearised into it right behind
   // the step tail, before the host has decided; an accepted step swaps the sets (one rank, eager enqueue)
@@ -464,6 +464,8 @@ int wait_handoff(pgo_problem* P);
 int enqueue_tail(pgo_problem* P, const pgo::CgParams* finish_prm);
 int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool with_tail = false, int start_it = 1);
 int pick_batch(const pgo::CgParams& prm, int user_batch, int round, int enqueued, int last_iterations);
+bool pipe_mode(const pgo_problem* P, const pgo::CgParams& prm);
+int pcg_begin(pgo_problem* P, const pgo::CgParams& prm);
 int run_pcg(pgo_problem* P, const pgo::CgParams& prm, int batch, int* iterations, int* status);
 int prepare_clusters(pgo_problem* P, int CL);
 long long front_memory_budget();

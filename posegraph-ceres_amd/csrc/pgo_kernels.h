@@ -132,6 +132,8 @@ struct CgState {
   double rho;      // r'z of the current iteration, likewise (the update kernel needs it for alpha = rho / p'q)
   double rho_hist[2];  // r'z and Q of the iterations, by iteration parity: the next SpMV launch reads the other slot
   double q_hist[2];    //   (written during the previous launch), so it re-reduces two partial rows instead of four
+  // owner-only CG of the sharded path (k_pipe_cg below): launch `seq` reads pipe[seq & 1] and writes the other slot
+  struct Pipe { int cnt, pad; double gamma_prev, alpha_prev, q_prev; } pipe[2];
 };
 
 struct DeviceGraph {
@@ -180,6 +182,16 @@ struct DeviceGraph {
   double* cg_p0;      // [6N] p ping
   double* cg_p1;      // [6N] p pong
   double* delta;      // [6N] tangent step actually applied (S * step)
+  // Several ranks, truncated CG (pgo_linear.cpp pipe_*): pipelined preconditioned CG (Ghysels & Vanroose 2014) — u = M^-1 r,
+  // w = A u, m = M^-1 w, n = A m and recurrences for z (cg_z), qq, s, p (cg_p0), x, r, u, w — has ONE global reduction per
+  // iteration, so every rank updates the vectors of ITS rows only and the single all-gather per iteration carries the m
+  // segments plus three sums per rank.  pipe_buf[0 / 1]: exchange buffers [world][pipe_seg] (rows_per * 6
+  // doubles of m, then the rank's three sums), read / written by launch parity; pipe_xbuf: [world][rows_per * 6] for x at the end.
+  double* cg_u; double* cg_w; double* cg_s; double* cg_qq;
+  double* pipe_buf[2];
+  double* pipe_xbuf;
+  int pipe_seg;
+  int pairs_whole;    // the row partition keeps poses 2i, 2i + 1 in one single-chunk work-group (several ranks: prepare() sees to it)
   // partial sums
   double* part_rz;    // [2][n_part]
   double* part_q;     // [2][n_part]
@@ -266,6 +278,12 @@ void launch_uni_v(const DeviceGraph& g, const CgParams& p, double min_diag, doub
 void launch_lm_budget(const DeviceGraph& g, int decisions, hipStream_t s);
 void launch_lm_publish(const DeviceGraph& g, hipStream_t s);
 bool uni_supported(const DeviceGraph& g);
+// owner-only pipelined CG of the sharded path: r0 / u0 of the owned rows; one launch per product (seq 0: w0 = A u0, seq i + 1:
+// iteration i; mode 1 / 2: only the stop test the launch `seq` would apply and the CG state for the host, 1: with the hand-over).
+// x needs no buffer of its own: cg_x is laid out like an exchange buffer of rows_per * 6 doubles per rank.
+bool pipe_supported(const DeviceGraph& g, const CgParams& p, int cluster);
+void launch_pipe_init(const DeviceGraph& g, hipStream_t s);
+void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, hipStream_t s);
 void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s);
 void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s, int mode = 0);   // mode: see k_pcg_update
 void launch_spmv_refresh(const DeviceGraph& g, hipStream_t s, int on_the_fly = 0, int it_odd = 0);

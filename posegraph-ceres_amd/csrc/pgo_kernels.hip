@@ -796,6 +796,7 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
   const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
   double* lds_p = lds + (size_t)SPMV_LDS_STRIDE * B;
 
+  if (MODE == 1 && (odd & 64) && !g.cg->done) return;  // step tail behind a batch of the owner-only CG (k_pipe_cg applied the stop test): only once the CG has stopped
   if (MODE == 1 && (odd & 8) && g.cg->done) return;   // A x of a residual refresh: nothing to do once the CG has stopped
   if (MODE == 1 && !(odd & 8) && lm_halted(g)) return;  // step tail of a sequence enqueued ahead of a halt
   if (MODE == 1 && (odd & 2)) {
@@ -2079,6 +2080,266 @@ __global__ __launch_bounds__(UNI_V_BLOCK) void k_uni_v(DeviceGraph g, CgParams p
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Several ranks, truncated CG: owner-only pipelined preconditioned CG (pgo_kernels.h DeviceGraph::pipe_buf; Ghysels & Vanroose
+// 2014).  Standard CG has two global reductions per iteration (p'q before alpha, r'z before beta); with ONE collective per
+// iteration that forces every rank to update all 6 N rows (k_pcg_update).  The pipelined recurrences
+//     u = M^-1 r, w = A u, m = M^-1 w;   gamma = (r,u), delta = (w,u);   beta = gamma / gamma_prev, alpha = gamma / (delta - beta gamma / alpha_prev)
+//     n = A m;   z = n + beta z, qq = m + beta qq, s = w + beta s, p = u + beta p;   x += alpha p, r -= alpha s, u -= alpha qq, w -= alpha z
+// have one: a rank multiplies its rows (gathering m of every row from the exchange buffer), updates the eight vectors of ITS rows,
+// applies its own Jacobi blocks (m = M^-1 w: no exchange of the inverses either) and leaves its m segment and its three sums —
+// (r,u), (w,u), x'(b + r) over its rows — in the buffer the all-gather then completes.  Same iterates as Ceres'
+// ConjugateGradientsSolver in exact arithmetic, same stop rules on the same quantities; no periodic residual refresh (four
+// products): truncated at eta = 0.1 the recurrences do not run long enough to drift, and a request that runs the CG to 1e-13
+// (exact request on several ranks) keeps the standard form.
+// Launch `seq` reads pipe_buf[seq & 1] and CgState::pipe[seq & 1] and writes the other ones: seq 0 multiplies u0 (w0 = A u0),
+// seq i + 1 is iteration i.  mode 1 / 2: only the stop test the launch `seq` would apply, the CG state for the host, and (1) the
+// hand-over.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t pipe_index(const DeviceGraph& g, int row, int k) {
+  const int rk = row / g.rows_per;
+  return (size_t)rk * g.pipe_seg + (size_t)(row - rk * g.rows_per) * 6 + k;
+}
+
+// b = S g of every row (the step tail's model change reads it everywhere); r0 = b, x0 = 0, u0 = M^-1 r0 of the owned rows.
+template <int CL>
+__global__ __launch_bounds__(VEC_BLOCK) void k_pipe_init(DeviceGraph g) {
+  constexpr int DIM = 6 * CL;
+  __shared__ double rl[VEC_BLOCK];
+  const int tid = threadIdx.x;
+  for (int base = blockIdx.x * VEC_BLOCK; base < 6 * g.N; base += gridDim.x * VEC_BLOCK) {   // (a chunk = 64 poses: whole Jacobi blocks, one owner)
+    const int idx = base + tid;
+    const bool live = idx < 6 * g.N;
+    const int row = idx / 6;
+    const bool own = live && row >= g.row_lo && row < g.row_hi;
+    double b = 0.0;
+    if (live) {
+      b = g.scale[idx] * g.grad[idx];
+      g.cg_b[idx] = b;
+      g.cg_x[idx] = 0.0;
+      if (own) g.cg_r[idx] = b;
+    }
+    rl[tid] = b;
+    __syncthreads();
+    if (own) {
+      const double* Mi = g.Minv + (size_t)idx * DIM;
+      const double* rv = rl + DIM * (tid / DIM);
+      double u = 0.0;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) u += Mi[k] * rv[k];
+      g.cg_u[idx] = u;
+      g.pipe_buf[0][pipe_index(g, row, idx - 6 * row)] = u;
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    g.cg->done = 0; g.cg->iters = 0; g.cg->status = 0; g.cg->cnt_a = 0; g.cg->cnt_b = 0;
+    CgState::Pipe n;
+    n.cnt = 0; n.pad = 0; n.gamma_prev = 0.0; n.alpha_prev = 0.0; n.q_prev = 0.0;
+    g.cg->pipe[0] = n;
+    g.cg->pipe[1] = n;
+  }
+}
+
+template <bool PACKED, int CL>
+__global__ __launch_bounds__(256) void k_pipe_cg(DeviceGraph g, CgParams prm, int seq, int mode) {
+  constexpr int NPAIR = PACKED ? BLK_PAIRS_PACKED : BLK_PAIRS_FULL;
+  constexpr int DIM = 6 * CL;
+  extern __shared__ double lds[];  // SPMV_LDS_STRIDE * block (slot results) + 6 * block + 6 (w of the owned rows)
+  __shared__ double scratch[32];
+  const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
+  double* lds_w = lds + (size_t)SPMV_LDS_STRIDE * B;
+  const int rs = seq & 1, ws = rs ^ 1;
+  const double* rd = g.pipe_buf[rs];
+  double* wr = g.pipe_buf[ws];
+  // ---- independent loads: the slot's words and block, the row bookkeeping, the state, every rank's partial sums ----
+  const int s_begin = g.wg_slot_begin[wg];
+  const int r0 = g.wg_row_begin[wg], nrows = g.wg_row_begin[wg + 1] - r0;
+  const int t = s_begin + tid;
+  const int col = g.slot_col[t];
+  double2 blk[NPAIR];
+  if (mode == 0) {
+    const double2* bp = reinterpret_cast<const double2*>(g.bsr_val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) blk[k] = bp[(size_t)k * 64];
+  }
+  const uint8_t side = g.slot_side[t];
+  const int nown = nrows * 6;
+  int seg_rb = 0, seg_cnt = 0;
+  if (tid < nown) { seg_rb = g.row_slot_begin[r0 + tid / 6]; seg_cnt = g.row_slot_cnt[r0 + tid / 6]; }
+  const int done0 = g.cg->done;
+  const CgState::Pipe st = g.cg->pipe[rs];
+  double f_gamma = 0, f_delta = 0, f_q = 0;     // every rank's three sums, added in rank order by every lane alike: same bits everywhere
+  for (int rk = 0; rk < g.world; ++rk) {
+    const double* pp = rd + (size_t)rk * g.pipe_seg + (size_t)g.rows_per * 6;
+    f_gamma += pp[0]; f_delta += pp[1]; f_q += pp[2];
+  }
+  // the first pass of the owned rows' operands, requested with the blocks
+  const bool own0 = mode == 0 && tid < nown;
+  const size_t gi = 6 * (size_t)r0 + tid;
+  double pr = 0, pu = 0, pw = 0, pz = 0, pq = 0, ps = 0, ppv = 0, px = 0, pb = 0, pm = 0;
+  double2 mi[DIM / 2];
+#pragma unroll
+  for (int k = 0; k < DIM / 2; ++k) mi[k] = double2{0, 0};
+  if (own0) {
+    pr = g.cg_r[gi]; pu = g.cg_u[gi];
+    if (seq != 0) {
+      pw = g.cg_w[gi]; pz = g.cg_z[gi]; pq = g.cg_qq[gi]; ps = g.cg_s[gi]; ppv = g.cg_p0[gi]; px = g.cg_x[gi]; pb = g.cg_b[gi];
+      pm = rd[pipe_index(g, r0 + tid / 6, tid % 6)];
+    }
+    const double2* Mi = reinterpret_cast<const double2*>(g.Minv + gi * DIM);
+#pragma unroll
+    for (int k = 0; k < DIM / 2; ++k) mi[k] = Mi[k];
+  }
+  const bool w0 = seq == 0;
+  int stop = 0, status = 0;
+  double alpha = 0.0, beta = 0.0, gamma = 0.0, Q1 = 0.0;
+  const int cnt = st.cnt;
+  if (!done0 && !w0) {
+    gamma = f_gamma;
+    const double delta = f_delta;
+    Q1 = -f_q;
+    if (cnt > 0) {
+      const double zeta = cnt * (Q1 - st.q_prev) / Q1;
+      if (zeta < prm.q_tolerance && cnt >= prm.min_iterations) stop = 1;
+      if (cnt >= prm.max_iterations) stop = 1;
+    }
+    if (!stop && (gamma == 0.0 || !isfinite(gamma))) { stop = 1; status = (gamma == 0.0) ? 0 : 2; }
+    if (!stop && cnt > 0) {
+      beta = gamma / st.gamma_prev;
+      if (beta == 0.0 || !isfinite(beta)) { stop = 1; status = 2; }
+    }
+    if (!stop) {
+      const double den = cnt > 0 ? delta - beta * gamma / st.alpha_prev : delta;
+      if (!(den > 0.0) || !isfinite(den)) { stop = 1; status = 1; }     // "matrix is indefinite": x of the previous iteration stands
+      else alpha = gamma / den;
+    }
+  }
+  if (mode != 0) {      // batch end: the state for the host
+    if (wg == 0 && tid == 0) {
+      int done = done0, iters = done0 ? g.cg->iters : cnt, stat = done0 ? g.cg->status : status;
+      if (!done0 && stop) { g.cg->iters = cnt; g.cg->status = status; __threadfence(); g.cg->done = 1; done = 1; }
+      g.scal->cg_iterations = iters;
+      g.scal->cg_status = done ? stat : -1;
+      g.scal->cg_residual_sq = 0.0;
+      if (mode == 1) publish_sequence(g);
+    }
+    return;
+  }
+  if (done0) return;
+  if (stop) {
+    if (wg == 0 && tid == 0) { g.cg->iters = cnt; g.cg->status = status; __threadfence(); g.cg->done = 1; }
+    return;
+  }
+  if (wg == 0 && tid == 0) {
+    CgState::Pipe n;
+    n.pad = 0;
+    if (w0) { n.cnt = 0; n.gamma_prev = 0.0; n.alpha_prev = 0.0; n.q_prev = 0.0; }
+    else { n.cnt = cnt + 1; n.gamma_prev = gamma; n.alpha_prev = alpha; n.q_prev = Q1; }
+    g.cg->pipe[ws] = n;
+  }
+  // ---- n = A m over this work-group's slots ----
+  double y[6] = {0, 0, 0, 0, 0, 0};
+  if (col >= 0) {
+    const double2* ms = reinterpret_cast<const double2*>(rd + pipe_index(g, col, 0));
+    const double2 g0 = ms[0], g1 = ms[1], g2 = ms[2];
+    const double x[6] = {g0.x, g0.y, g1.x, g1.y, g2.x, g2.y};
+    if (PACKED) {
+      double el[28];
+#pragma unroll
+      for (int k = 0; k < BLK_PAIRS_PACKED; ++k) { el[2 * k] = blk[k].x; el[2 * k + 1] = blk[k].y; }
+      const bool is_end = side == SIDE_END, is_diag = side == SIDE_DIAG;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double a3 = is_end ? el[18 + 3 * i] : is_diag ? el[18 + i] : 0.0;
+        const double a4 = is_end ? el[18 + 3 * i + 1] : is_diag ? el[21 + i] : 0.0;
+        const double a5 = is_end ? el[18 + 3 * i + 2] : is_diag ? el[24 + i] : 0.0;
+        y[i] = el[3 * i] * x[0] + el[3 * i + 1] * x[1] + el[3 * i + 2] * x[2] + a3 * x[3] + a4 * x[4] + a5 * x[5];
+        const double b0 = is_end ? 0.0 : el[18 + 3 * i], b1 = is_end ? 0.0 : el[18 + 3 * i + 1], b2 = is_end ? 0.0 : el[18 + 3 * i + 2];
+        y[3 + i] = b0 * x[0] + b1 * x[1] + b2 * x[2] + el[9 + 3 * i] * x[3] + el[9 + 3 * i + 1] * x[4] + el[9 + 3 * i + 2] * x[5];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        y[i] = blk[3 * i].x * x[0] + blk[3 * i].y * x[1] + blk[3 * i + 1].x * x[2] + blk[3 * i + 1].y * x[3] +
+               blk[3 * i + 2].x * x[4] + blk[3 * i + 2].y * x[5];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) lds[tid * SPMV_LDS_STRIDE + k] = y[k];
+  __syncthreads();
+  // ---- the owned rows: lane idx owns component idx % 6 of row r0 + idx / 6 ----
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int idx = tid; idx < nown; idx += B) {
+    const size_t gj = 6 * (size_t)r0 + idx;
+    if (idx != tid) { seg_rb = g.row_slot_begin[r0 + idx / 6]; seg_cnt = g.row_slot_cnt[r0 + idx / 6]; }
+    const int k = idx % 6;
+    const int sb = seg_rb - s_begin, sE = sb + seg_cnt;
+    double s0 = 0.0, s1 = 0.0;
+    int j = sb;
+    for (; j + 1 < sE; j += 2) { s0 += lds[j * SPMV_LDS_STRIDE + k]; s1 += lds[(j + 1) * SPMV_LDS_STRIDE + k]; }
+    if (j < sE) s0 += lds[j * SPMV_LDS_STRIDE + k];
+    const double sm = s0 + s1;
+    if (idx != tid) {
+      pr = g.cg_r[gj]; pu = g.cg_u[gj];
+      if (!w0) {
+        pw = g.cg_w[gj]; pz = g.cg_z[gj]; pq = g.cg_qq[gj]; ps = g.cg_s[gj]; ppv = g.cg_p0[gj]; px = g.cg_x[gj]; pb = g.cg_b[gj];
+        pm = rd[pipe_index(g, r0 + idx / 6, k)];
+      }
+    }
+    double vr = pr, un = pu, wn;
+    if (w0) {
+      wn = sm;
+      g.cg_w[gj] = wn;
+      g.cg_z[gj] = 0.0; g.cg_qq[gj] = 0.0; g.cg_s[gj] = 0.0; g.cg_p0[gj] = 0.0;
+    } else {
+      const double vw = pw, vm = pm;
+      const double zn = sm + beta * pz, qn = vm + beta * pq, sn = vw + beta * ps, pn = un + beta * ppv;
+      const double xn = px + alpha * pn, rn = vr - alpha * sn;
+      un = un - alpha * qn;
+      wn = vw - alpha * zn;
+      g.cg_z[gj] = zn; g.cg_qq[gj] = qn; g.cg_s[gj] = sn; g.cg_p0[gj] = pn;
+      g.cg_x[gj] = xn; g.cg_r[gj] = rn; g.cg_u[gj] = un; g.cg_w[gj] = wn;
+      acc[2] += xn * (pb + rn);
+      vr = rn;
+    }
+    acc[0] += vr * un;
+    acc[1] += wn * un;
+    lds_w[idx] = wn;
+  }
+  if (tid < 6) lds_w[nown + tid] = 0.0;       // the missing half of a last odd pair
+  __syncthreads();
+  for (int idx = tid; idx < nown; idx += B) {
+    const size_t gj = 6 * (size_t)r0 + idx;
+    if (idx != tid) {
+      const double2* Mi = reinterpret_cast<const double2*>(g.Minv + gj * DIM);
+#pragma unroll
+      for (int k = 0; k < DIM / 2; ++k) mi[k] = Mi[k];
+    }
+    const double* wv = lds_w + DIM * (idx / DIM);
+    double mn = 0.0;
+#pragma unroll
+    for (int k = 0; k < DIM / 2; ++k) mn += mi[k].x * wv[2 * k] + mi[k].y * wv[2 * k + 1];
+    wr[pipe_index(g, r0 + idx / 6, idx % 6)] = mn;
+  }
+  // this rank's three sums: per work-group partials here, folded by k_pipe_fold (one work-group, behind this launch) — the exchange
+  // carries three numbers per rank.  (A ticket for the last work-group to fold them cost more than the launch: > 1000
+  // work-groups per rank bump one counter at 100 k poses / 8 ranks.)
+  block_sum_w<3>(acc, scratch, B / 64);
+  if (tid == 0) { g.part_rz[wg] = acc[0]; g.part_q[wg] = acc[1]; g.part_rr[wg] = acc[2]; }
+}
+__global__ __launch_bounds__(256) void k_pipe_fold(DeviceGraph g, int seq) {
+  __shared__ double scratch[16];
+  if (g.cg->done) return;
+  double t3[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < g.n_wg; i += 256) { t3[0] += g.part_rz[i]; t3[1] += g.part_q[i]; t3[2] += g.part_rr[i]; }
+  block_sum<3>(t3, scratch);
+  if (threadIdx.x == 0) {
+    double* pp = g.pipe_buf[(seq & 1) ^ 1] + (size_t)g.rank * g.pipe_seg + (size_t)g.rows_per * 6;
+    pp[0] = t3[0]; pp[1] = t3[1]; pp[2] = t3[2];
+  }
+}
+
 // (Re)opens the universal stream for `decisions` more LM iterations; behind LM_HALT_BUDGET the head launch that paused it is due again.
 __global__ void k_lm_budget(DeviceGraph g, int decisions) {
   LmDev& D = *g.lm;
@@ -2272,10 +2533,13 @@ void launch_spmv_plain(const DeviceGraph& g, hipStream_t s) {
   if (g.blk_packed) hipLaunchKernelGGL((k_spmv<1, true>), dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1);
   else hipLaunchKernelGGL((k_spmv<1, false>), dim3(g.n_wg), dim3(g.block), lds, s, g, dummy, 1);
 }
+// finish: 1 = apply the stop test of the last CG iteration first and run only once the CG has stopped; 2 = only the latter (the
+// owner-only CG applied its own test)
 void launch_spmv_tail(const DeviceGraph& g, const CgParams& p, hipStream_t s, int finish, int candidates) {
   const size_t lds = (size_t)(SPMV_LDS_STRIDE + 6) * g.block * sizeof(double);
-  if (g.blk_packed) hipLaunchKernelGGL((k_spmv<1, true>), dim3(g.n_wg), dim3(g.block), lds, s, g, p, 1 | (finish ? 2 : 0) | (candidates ? 4 : 0));
-  else hipLaunchKernelGGL((k_spmv<1, false>), dim3(g.n_wg), dim3(g.block), lds, s, g, p, 1 | (finish ? 2 : 0) | (candidates ? 4 : 0));
+  const int flags = 1 | (finish == 1 ? 2 : 0) | (finish == 2 ? 64 : 0) | (candidates ? 4 : 0);
+  if (g.blk_packed) hipLaunchKernelGGL((k_spmv<1, true>), dim3(g.n_wg), dim3(g.block), lds, s, g, p, flags);
+  else hipLaunchKernelGGL((k_spmv<1, false>), dim3(g.n_wg), dim3(g.block), lds, s, g, p, flags);
 }
 void launch_step_tail(const DeviceGraph& g, hipStream_t s, int gate) {
   const int grid = g.n_edge_wg + g.n_pose_wg;   // <= 2 * n_part
@@ -2332,6 +2596,22 @@ void launch_uni_v(const DeviceGraph& g, const CgParams& p, double min_diag, doub
   else if (g.cluster == 4) PGO_UNI_V(4);
   else PGO_UNI_V(1);
 #undef PGO_UNI_V
+}
+bool pipe_supported(const DeviceGraph& g, const CgParams& p, int cluster) {
+  return g.world > 1 && g.pairs_whole && g.pipe_buf[0] && (cluster == 1 || cluster == 2) && p.q_tolerance >= 0.0 && p.r_tolerance < 0.0;
+}
+void launch_pipe_init(const DeviceGraph& g, hipStream_t s) {
+  if (g.cluster == 2) hipLaunchKernelGGL(k_pipe_init<2>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
+  else hipLaunchKernelGGL(k_pipe_init<1>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
+}
+void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, hipStream_t s) {
+  const size_t lds = ((size_t)(SPMV_LDS_STRIDE + 6) * g.block + 8) * sizeof(double);
+  const dim3 grid(mode ? 1 : g.n_wg);
+#define PGO_PIPE(PK) do { if (g.cluster == 2) hipLaunchKernelGGL((k_pipe_cg<PK, 2>), grid, dim3(g.block), lds, s, g, p, seq, mode); \
+                          else hipLaunchKernelGGL((k_pipe_cg<PK, 1>), grid, dim3(g.block), lds, s, g, p, seq, mode); } while (0)
+  if (g.blk_packed) PGO_PIPE(true); else PGO_PIPE(false);
+#undef PGO_PIPE
+  if (mode == 0) hipLaunchKernelGGL(k_pipe_fold, dim3(1), dim3(256), 0, s, g, seq);
 }
 void launch_lm_budget(const DeviceGraph& g, int decisions, hipStream_t s) { hipLaunchKernelGGL(k_lm_budget, dim3(1), dim3(1), 0, s, g, decisions); }
 void launch_lm_publish(const DeviceGraph& g, hipStream_t s) { hipLaunchKernelGGL(k_lm_publish, dim3(1), dim3(1), 0, s, g); }

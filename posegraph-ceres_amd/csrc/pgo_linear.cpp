@@ -25,10 +25,30 @@ int wait_handoff(pgo_problem* P) {
 // The step tail (model cost change, delta, candidate, candidate cost, scalar fold).  `gate`: the kernels run only once
 // the device-side CG state says "stopped", so the tail can ride behind every CG batch (no host round trip between the
 // last CG iteration and the tail); the scalar fold always hands off to the host.
+// Several ranks, truncated CG: the owner-only pipelined form (pgo_kernels.h DeviceGraph::pipe_buf) unless PGO_SHARD_PIPE=0
+bool pipe_mode(const pgo_problem* P, const pgo::CgParams& prm) {
+  const char* e = getenv("PGO_SHARD_PIPE");       // (read per call: the tests run both forms in one process; every rank sees the same environment)
+  const bool off = e && e[0] == '0';
+  return !off && !P->use_graph && pgo::pipe_supported(P->g, prm, P->g.cluster);
+}
+
 int enqueue_tail(pgo_problem* P, const pgo::CgParams* finish_prm) {
   hipStream_t s = P->stream;
   const pgo::CgParams none{0.0, -1.0, 0, 0};
   const int gate = finish_prm ? 1 : 0;
+  if (finish_prm && pipe_mode(P, *finish_prm)) {
+    // owner-only CG: the batch's last launch applied the stop test; x of every row is gathered first (cg_x is laid out like an
+    // exchange buffer: rank r owns [r * rows_per * 6, ...)), then the tail of the sharded path as below, gated on the CG having stopped
+    int rc = exchange(P, P->g.cg_x, (size_t)6 * P->g.rows_per);
+    if (rc) return rc;
+    pgo::launch_spmv_tail(P->g, none, s, 2, 0);
+    rc = exchange(P, P->g.cg_q, (size_t)P->g.seg);
+    if (rc) return rc;
+    pgo::launch_model_delta_and_retract(P->g, s, 1);
+    pgo::launch_cost(P->g, P->g.pose_c, 0, s, 1);
+    pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, s, 1);
+    return PGO_OK;
+  }
   if (P->g.world == 1) {
     // two launches: q = A x + candidate poses (diagonal lanes), then model change / norms / candidate cost / fold
     pgo::launch_spmv_tail(P->g, finish_prm ? *finish_prm : none, s, gate, 1);
@@ -57,6 +77,17 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool wi
   // refresh the test would never fire (measured: 27x the iterations on sphere x10), so that mode keeps the recurrence.
   const int period = prm.q_tolerance < 0.0 ? 0 : P->opt.cg_residual_reset_period;
   auto refresh_at = [&](int i) { return period > 0 && ((start_it + i) % period) == 0; };
+  if (pipe_mode(P, prm)) {
+    // owner-only CG: one launch and one all-gather per iteration (launch seq = iteration index + 1, pipe_begin() ran seq 0)
+    for (int i = 0; i < batch; ++i) {
+      const int seq = start_it + i;
+      pgo::launch_pipe_cg(P->g, prm, seq, 0, s);
+      int rc = exchange(P, P->g.pipe_buf[(seq & 1) ^ 1], (size_t)P->g.pipe_seg);
+      if (rc) return rc;
+    }
+    pgo::launch_pipe_cg(P->g, prm, start_it + batch, with_tail ? 2 : 1, s);    // the stop test of the last iteration; without a tail also the hand-over
+    return with_tail ? enqueue_tail(P, &prm) : PGO_OK;
+  }
   if (P->use_graph) {
     if (memcmp(&P->cg_graph_params, &prm, sizeof prm) != 0) { P->drop_graph(); P->cg_graph_params = prm; }
     // the captured kernels hold the DeviceGraph by value; the tail touches the pose ping-pong, so the key carries its parity
@@ -121,9 +152,20 @@ int pick_batch(const pgo::CgParams& prm, int user_batch, int round, int enqueued
   return (batch + 1) & ~1;  // even: every batch starts at an odd iteration (kernels take the parity at launch)
 }
 
+// CG start: r0 = b, z0 / u0 = M^-1 r0 (and, owner-only form, the first product w0 = A u0 with its two all-gathers)
+int pcg_begin(pgo_problem* P, const pgo::CgParams& prm) {
+  hipStream_t s = P->stream;
+  if (!pipe_mode(P, prm)) { pgo::launch_pcg_init(P->g, s); return PGO_OK; }
+  pgo::launch_pipe_init(P->g, s);
+  int rc = exchange(P, P->g.pipe_buf[0], (size_t)P->g.pipe_seg);
+  if (rc) return rc;
+  pgo::launch_pipe_cg(P->g, prm, 0, 0, s);
+  return exchange(P, P->g.pipe_buf[1], (size_t)P->g.pipe_seg);
+}
+
 int run_pcg(pgo_problem* P, const pgo::CgParams& prm, int batch, int* iterations, int* status) {
   hipStream_t s = P->stream;
-  pgo::launch_pcg_init(P->g, s);
+  { int rc0 = pcg_begin(P, prm); if (rc0) return rc0; }
   for (int round = 0, enqueued = 0;; ++round) {
     arm_handoff(P);
     const int nb = pick_batch(prm, batch, round, enqueued, 0);

@@ -281,7 +281,8 @@ int lm_advance(pgo_problem* P) {
     // as soon as the CG has stopped
     pgo::CgParams run_prm = prm;
     if (hybrid) run_prm.max_iterations = cg_budget;
-    pgo::launch_pcg_init(P->g, s);
+    rc = pcg_begin(P, run_prm);
+    if (rc) return rc;
     for (int round = 0, enqueued = 0;; ++round) {
       const int nb = pick_batch(run_prm, o.cg_batch, round, enqueued, P->last_cg_iterations);
       rc = launch_cg_batch(P, run_prm, nb, true, enqueued + 1);
@@ -345,6 +346,7 @@ int lm_advance(pgo_problem* P) {
   }
   HIP_TRY(hipGetLastError());
   const pgo::LmScalars dsc = *P->scal;
+  if (getenv("PGO_VERBOSE") && dsc.cg_status != 0) std::fprintf(stderr, "[pgo] rank %d iteration %d: CG ended with status %d after %d iterations\n", P->g.rank, L.cur.iteration + 1, dsc.cg_status, dsc.cg_iterations);
   P->last_cg_iterations = dsc.cg_iterations;
   L.t_linear += seconds_since(t_lin);
   const StepScalars sc{dsc.cand_cost, dsc.model_change, dsc.step_norm_sq, dsc.x_norm_sq, dsc.gradient_max,

@@ -68,7 +68,7 @@ int linearize_all(pgo_problem* P) {
 // the in-cluster off-diagonal blocks, which only the owner holds, so their inverses are exchanged.
 int damping_all(pgo_problem* P, double radius, double min_diag, double max_diag, int mode) {
   pgo::launch_damping(P->g, radius, min_diag, max_diag, mode, P->stream);
-  if (P->g.cluster > 1) return exchange(P, P->g.Minv, (size_t)36 * P->g.cluster * P->g.rows_per);
+  if (P->g.cluster > 1 && !pipe_mode(P, cg_params_for(P->opt))) return exchange(P, P->g.Minv, (size_t)36 * P->g.cluster * P->g.rows_per);   // (the owner-only CG applies its own blocks only)
   return PGO_OK;
 }
 
@@ -141,6 +141,10 @@ int prepare(pgo_problem* P) {
   // rows -> workgroups (greedy packing of `block` slots; a row with more incidences gets its own multi-chunk group)
   std::vector<int> wg_row_begin, wg_slot_begin, row_slot_begin(N, 0), row_slot_cnt(N, 0);
   long long slot = 0;
+  // Several ranks: a work-group boundary never separates the poses 2i and 2i + 1 (the owner-only CG applies the 12 x 12 Jacobi
+  // blocks inside the work-group that owns their rows: k_pipe_cg).  One rank keeps the tighter packing.
+  const bool keep_pairs = world > 1;
+  bool pairs_whole = keep_pairs;
   auto pack = [&](int lo, int hi, bool record) -> int {
     long long sl = 0;
     int cur = 0, n = 0;
@@ -156,11 +160,18 @@ int prepare(pgo_problem* P) {
       if (c > B) {
         if (cur > 0) close_wg(v);
         if (record) { row_slot_begin[v] = (int)sl; row_slot_cnt[v] = c; }
+        pairs_whole = false;        // (whatever rank's rows: every rank must take the same decision about the owner-only CG)
         sl += c;
         close_wg(v + 1);
         continue;
       }
-      if (cur + c > B) close_wg(v);
+      int need = c;
+      if (keep_pairs && ((v - lo) & 1) == 0 && v + 1 < hi) {
+        const int c1 = 1 + deg[v + 1];
+        if (c + c1 <= B) need = c + c1;
+        else pairs_whole = false;
+      }
+      if (cur + need > B) close_wg(v);
       if (record) { row_slot_begin[v] = (int)sl; row_slot_cnt[v] = c; }
       sl += c;
       cur += c;
@@ -303,9 +314,17 @@ int prepare(pgo_problem* P) {
   HIP_TRY(P->d_Minv.zero(s));
   DevBuf<double>* vecs[] = {&P->d_grad, &P->d_scale, &P->d_d2, &P->d_diagc, &P->d_cg_b, &P->d_cg_x, &P->d_cg_r,
                             &P->d_cg_z, &P->d_cg_p0, &P->d_cg_p1, &P->d_delta};
+  DevBuf<double>* pipe_vecs[] = {&P->d_cg_u, &P->d_cg_w, &P->d_cg_s, &P->d_cg_qq};
   for (DevBuf<double>* b : vecs) { HIP_TRY(b->alloc(m)); HIP_TRY(b->zero(s)); }
   HIP_TRY(P->d_cg_q.alloc((size_t)world * seg));   // exchange buffer: q segments + p'q partials (unused partial slots stay 0)
   HIP_TRY(P->d_cg_q.zero(s));
+  const int pipe_seg = rows_per * 6 + 4;      // m of the owned rows, then this rank's (r,u), (w,u), x'(b + r)
+  if (world > 1) {     // owner-only CG (pgo_kernels.h DeviceGraph::pipe_buf)
+    for (DevBuf<double>* b : pipe_vecs) { HIP_TRY(b->alloc(m)); HIP_TRY(b->zero(s)); }
+    HIP_TRY(P->d_pipe_a.alloc((size_t)world * pipe_seg)); HIP_TRY(P->d_pipe_a.zero(s));
+    HIP_TRY(P->d_pipe_b.alloc((size_t)world * pipe_seg)); HIP_TRY(P->d_pipe_b.zero(s));
+    HIP_TRY(P->d_pipe_x.alloc((size_t)world * rows_per * 6)); HIP_TRY(P->d_pipe_x.zero(s));
+  }
   const int n_vec_wg = std::max(1, std::min((int)(((size_t)6 * N + pgo::vec_block() - 1) / pgo::vec_block()), 256));
   const int n_edge_wg = std::min(std::max(1, (E + pgo::edge_block() - 1) / pgo::edge_block()), pgo::max_edge_wg());   // k_cost and the step tail stride beyond that
   const int n_pose_wg = (N + pgo::pose_block() - 1) / pgo::pose_block();
@@ -355,6 +374,9 @@ int prepare(pgo_problem* P) {
   g.cg_z = P->d_cg_z.p; g.cg_q = P->d_cg_q.p; g.cg_p0 = P->d_cg_p0.p; g.cg_p1 = P->d_cg_p1.p;
   g.delta = P->d_delta.p; g.part_rz = P->d_part_rz.p; g.part_q = P->d_part_q.p;
   g.part_rr = P->d_part_rr.p; g.part_bb = P->d_part_bb.p; g.part_misc = P->d_part_misc.p;
+  g.cg_u = P->d_cg_u.p; g.cg_w = P->d_cg_w.p; g.cg_s = P->d_cg_s.p; g.cg_qq = P->d_cg_qq.p;
+  g.pipe_buf[0] = P->d_pipe_a.p; g.pipe_buf[1] = P->d_pipe_b.p; g.pipe_xbuf = P->d_pipe_x.p; g.pipe_seg = pipe_seg;
+  g.pairs_whole = pairs_whole ? 1 : 0;
   g.n_part = n_part; g.n_vec_wg = n_vec_wg; g.n_edge_wg = n_edge_wg; g.n_pose_wg = n_pose_wg;
   g.cg = P->d_cg.p; g.flags = P->d_flags.p;
   void* dscal = nullptr;

@@ -55,6 +55,30 @@ def test_loopback_ranks_match_single_rank(gpu, ds, world, cluster):
     assert np.array_equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("cluster", [1, 2])
+def test_owner_only_cg_and_replicated_cg_agree(gpu, ds, cluster, monkeypatch):
+    """Several ranks run the truncated CG in its owner-only pipelined form (k_pipe_cg: one launch and one all-gather per iteration,
+    every rank updates its own rows) unless PGO_SHARD_PIPE=0 keeps the standard form with the vector update
+    replicated on every rank.  Same CG iteration counts in every LM iteration — runs of 100+ iterations included —, same decisions,
+    costs to 1e-8, and both equal to one rank."""
+    g = ds.manhattan_se3(3001, 14000, seed=77, loop_radius=3.0)
+    opt = dict(max_num_iterations=8, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=cluster)
+    prob, poses = gpu.problem_from_graph(g)
+    ref = gpu.solve(gpu.SolverOptions(**opt), prob)
+    res = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("PGO_SHARD_PIPE", form)
+        res[form] = _solve_sharded(gpu, g, 4, opt)
+    for form, out in res.items():
+        for s, p in out:
+            assert list(s.iterations["step_is_successful"]) == list(ref.iterations["step_is_successful"]), form
+            assert list(s.iterations["linear_solver_iterations"]) == list(ref.iterations["linear_solver_iterations"]), form
+            assert np.allclose(s.iterations["cost"], ref.iterations["cost"], rtol=1e-8), form
+            assert np.abs(p - poses).max() < 1e-6, form
+        assert all(np.array_equal(out[0][1], o[1]) for o in out)
+    assert max(ref.iterations["linear_solver_iterations"]) > 20
+
+
 def test_loopback_exact_request_falls_back_to_tight_pcg(gpu, ds, O):
     g = ds.manhattan_se3(300, 1000, seed=4)
     opt = dict(max_num_iterations=15, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
