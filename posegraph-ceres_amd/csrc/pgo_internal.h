@@ -448,7 +448,7 @@ struct pgo_problem {
 const char* last_error_string();
 int ensure_device(pgo_problem* P);
 int exchange(pgo_problem* P, double* buf, size_t seg_doubles);
-int linearize_all(pgo_problem* P);
+int linearize_all(pgo_problem* P, bool diag_only = false);
 int damping_all(pgo_problem* P, double radius, double min_diag, double max_diag, int mode);
 int cg_iteration(pgo_problem* P, const pgo::DeviceGraph& g, const pgo::CgParams& prm, int odd, bool refresh);
 int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd, bool refresh);

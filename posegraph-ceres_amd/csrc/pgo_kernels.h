@@ -282,6 +282,7 @@ bool uni_supported(const DeviceGraph& g);
 // iteration i; mode 1 / 2: only the stop test the launch `seq` would apply and the CG state for the host, 1: with the hand-over).
 // x needs no buffer of its own: cg_x is laid out like an exchange buffer of rows_per * 6 doubles per rank.
 bool pipe_supported(const DeviceGraph& g, const CgParams& p, int cluster);
+void launch_hdiag6(const DeviceGraph& g, double* buf, int phase, hipStream_t s);   // diagonals of the diagonal blocks: owned rows into buf (0) / other rows out of it (1)
 void launch_pipe_init(const DeviceGraph& g, hipStream_t s);
 void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, hipStream_t s);
 void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s);

@@ -2340,6 +2340,22 @@ __global__ __launch_bounds__(256) void k_pipe_fold(DeviceGraph g, int seq) {
   }
 }
 
+// Several ranks, owner-only CG: of the other ranks' diagonal blocks only the six diagonal entries are needed anywhere (column
+// scaling, LM damping, the model change of the step tail), so those travel — 6 doubles per pose instead of 36.  phase 0: the
+// owned rows' diagonals into the exchange buffer (laid out like cg_x); phase 1: the other rows' diagonals out of it.
+__global__ void k_hdiag6(DeviceGraph g, double* buf, int phase) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 6 * g.N) return;
+  const int v = idx / 6, i = idx - 6 * v;
+  const bool own = v >= g.row_lo && v < g.row_hi;
+  if (phase == 0) { if (own) buf[idx] = g.Hdiag[36 * (size_t)v + 7 * i]; }
+  else if (!own) {      // (the rest of the row is cleared: an earlier solve in the standard form left the owner's entries of that time)
+    const double d = buf[idx];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) g.Hdiag[36 * (size_t)v + 6 * i + j] = j == i ? d : 0.0;
+  }
+}
+
 // (Re)opens the universal stream for `decisions` more LM iterations; behind LM_HALT_BUDGET the head launch that paused it is due again.
 __global__ void k_lm_budget(DeviceGraph g, int decisions) {
   LmDev& D = *g.lm;
@@ -2596,6 +2612,9 @@ void launch_uni_v(const DeviceGraph& g, const CgParams& p, double min_diag, doub
   else if (g.cluster == 4) PGO_UNI_V(4);
   else PGO_UNI_V(1);
 #undef PGO_UNI_V
+}
+void launch_hdiag6(const DeviceGraph& g, double* buf, int phase, hipStream_t s) {
+  hipLaunchKernelGGL(k_hdiag6, dim3(cdiv(6 * g.N, 256)), dim3(256), 0, s, g, buf, phase);
 }
 bool pipe_supported(const DeviceGraph& g, const CgParams& p, int cluster) {
   return g.world > 1 && g.pairs_whole && g.pipe_buf[0] && (cluster == 1 || cluster == 2) && p.q_tolerance >= 0.0 && p.r_tolerance < 0.0;

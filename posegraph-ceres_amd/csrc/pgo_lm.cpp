@@ -8,18 +8,23 @@
 int evaluate_gradient_and_jacobian(pgo_problem* P, bool first) {
   const auto t0 = Clock::now();
   hipStream_t s = P->stream;
+  // several ranks, owner-only CG ahead (whatever block size the preconditioner ends up with: the standard form exchanges the
+  // inverses its owners build): only the diagonals of the diagonal blocks travel
+  const char* pe = getenv("PGO_SHARD_PIPE");
+  const bool diag_only = P->g.world > 1 && !(pe && pe[0] == '0') && !P->use_graph &&
+                         pgo::pipe_supported(P->g, cg_params_for(P->opt), P->opt.pcg_cluster_poses == 2 ? 2 : 1) && P->opt.pcg_cluster_poses != 4;
   if (first) {
     int rc = fill_scale_one(P);
     if (rc) return rc;
-    rc = linearize_all(P);
+    rc = linearize_all(P, diag_only);
     if (rc) return rc;
     if (P->opt.jacobi_scaling) {
       pgo::launch_scale_from_diag(P->g, s);
-      rc = linearize_all(P);
+      rc = linearize_all(P, diag_only);
       if (rc) return rc;
     }
   } else {
-    int rc = linearize_all(P);
+    int rc = linearize_all(P, diag_only);
     if (rc) return rc;
   }
   pgo::launch_gradient_norm(P->g, s);

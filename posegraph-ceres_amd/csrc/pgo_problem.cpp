@@ -57,10 +57,20 @@ int exchange(pgo_problem* P, double* buf, size_t seg_doubles) {
 }
 
 // linearise the owned rows, then make J'J diagonal blocks and J'r of ALL rows available on every rank
-int linearize_all(pgo_problem* P) {
+// diag_only (several ranks, the solve will run the owner-only CG): nobody reads another rank's off-diagonal entries of the
+// diagonal blocks then — 6 doubles per pose travel instead of 36 (28.8 -> 4.8 MB per accepted step at 100 k poses)
+int linearize_all(pgo_problem* P, bool diag_only) {
   pgo::launch_linearize(P->g, P->stream);
-  int rc = exchange(P, P->g.Hdiag, (size_t)36 * P->g.rows_per);
-  if (rc) return rc;
+  int rc;
+  if (diag_only && P->comm && P->comm->world > 1 && P->d_pipe_x.p) {
+    pgo::launch_hdiag6(P->g, P->d_pipe_x.p, 0, P->stream);
+    rc = exchange(P, P->d_pipe_x.p, (size_t)6 * P->g.rows_per);
+    if (rc) return rc;
+    pgo::launch_hdiag6(P->g, P->d_pipe_x.p, 1, P->stream);
+  } else {
+    rc = exchange(P, P->g.Hdiag, (size_t)36 * P->g.rows_per);
+    if (rc) return rc;
+  }
   return exchange(P, P->g.grad, (size_t)6 * P->g.rows_per);
 }
 
