@@ -516,7 +516,7 @@ def main():
         total_edges = E if sharded else E * world
         out = record(total_edges * args.steps / elapsed, elapsed,
                      ("single GPU" if world == 1 and not sharded else
-                      "one graph, pose rows sharded over %d ranks (one process per GPU), 1 RCCL all-gather over xGMI per CG iteration" % world if sharded else
+                      "one graph, pose rows sharded over %d ranks (one process per GPU), pipelined CG: every rank updates its own rows, 1 RCCL all-gather over xGMI per CG iteration" % world if sharded else
                       "replicas: 1 independent graph per GPU, no data-path collective"),
                      N if sharded or world == 1 else N * world, total_edges,
                      workload=("BASELINE configs[3]: synthetic Manhattan SE3 graph, %d poses / %d odom+loop edges in TOTAL (seed %d), row-sharded over "
