@@ -82,3 +82,40 @@ def test_point_api_errors(gpu, ds):
         p.add_point_observations([3], [4], [[0.0, 0.0, 0.0]])           # 4 is a pose, not a point
     assert p.add_points(points) == 20                                      # same memory again: the same blocks
     assert p.num_poses == 50
+
+
+def test_pose_landmark_pcg_sharded_over_loopback_ranks(gpu, ds):
+    """The same pose / landmark problem with its rows (poses first, then the points) sharded over three loopback ranks: the
+    owner-only CG of the sharded path takes the single-rank decisions with the single-rank CG counts, and every
+    rank ends with the same poses and points."""
+    import threading
+    pl = ds.pose_landmark_toy(n_poses=120, n_points=900, seed=20260933)
+    opt = dict(max_num_iterations=20, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2)
+    p0, poses0, points0 = _build(gpu, pl)
+    ref = gpu.solve(gpu.SolverOptions(**opt), p0)
+    world = 3
+    group = gpu.loopback_create(world)
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            p, poses, points = _build(gpu, pl)
+            p.comm_init_loopback(group, rank)
+            out[rank] = (gpu.solve(gpu.SolverOptions(**opt), p), poses, points)
+        except Exception as e:   # a failing rank would leave the others waiting: surface it
+            errs.append(e)
+
+    ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errs, errs
+    assert all(o is not None for o in out)
+    gpu.loopback_destroy(group)
+    for s, poses, points in out:
+        assert list(s.iterations["step_is_successful"]) == list(ref.iterations["step_is_successful"])
+        assert list(s.iterations["linear_solver_iterations"]) == list(ref.iterations["linear_solver_iterations"])
+        assert np.allclose(s.iterations["cost"], ref.iterations["cost"], rtol=1e-8)
+        assert np.abs(poses - poses0).max() < 1e-6 and np.abs(points - points0).max() < 1e-6
+        assert np.array_equal(poses, out[0][1]) and np.array_equal(points, out[0][2])
