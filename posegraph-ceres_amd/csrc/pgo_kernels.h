@@ -186,10 +186,10 @@ struct DeviceGraph {
   // w = A u, m = M^-1 w, n = A m and recurrences for z (cg_z), qq, s, p (cg_p0), x, r, u, w — has ONE global reduction per
   // iteration, so every rank updates the vectors of ITS rows only and the single all-gather per iteration carries the m
   // segments plus three sums per rank.  pipe_buf[0 / 1]: exchange buffers [world][pipe_seg] (rows_per * 6
-  // doubles of m, then the rank's three sums), read / written by launch parity; pipe_xbuf: [world][rows_per * 6] for x at the end.
+  // doubles of m, then the rank's three sums), read / written by launch parity (x is gathered in place at the end: cg_x is
+  // laid out like an exchange buffer of rows_per * 6 doubles per rank).
   double* cg_u; double* cg_w; double* cg_s; double* cg_qq;
   double* pipe_buf[2];
-  double* pipe_xbuf;
   int pipe_seg;
   int pairs_whole;    // the row partition keeps poses 2i, 2i + 1 in one single-chunk work-group (several ranks: prepare() sees to it)
   // partial sums

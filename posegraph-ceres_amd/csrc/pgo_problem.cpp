@@ -333,7 +333,7 @@ int prepare(pgo_problem* P) {
     for (DevBuf<double>* b : pipe_vecs) { HIP_TRY(b->alloc(m)); HIP_TRY(b->zero(s)); }
     HIP_TRY(P->d_pipe_a.alloc((size_t)world * pipe_seg)); HIP_TRY(P->d_pipe_a.zero(s));
     HIP_TRY(P->d_pipe_b.alloc((size_t)world * pipe_seg)); HIP_TRY(P->d_pipe_b.zero(s));
-    HIP_TRY(P->d_pipe_x.alloc((size_t)world * rows_per * 6)); HIP_TRY(P->d_pipe_x.zero(s));
+    HIP_TRY(P->d_pipe_x.alloc((size_t)world * rows_per * 6)); HIP_TRY(P->d_pipe_x.zero(s));    // exchange buffer of the diagonal blocks' diagonals (linearize_all)
   }
   const int n_vec_wg = std::max(1, std::min((int)(((size_t)6 * N + pgo::vec_block() - 1) / pgo::vec_block()), 256));
   const int n_edge_wg = std::min(std::max(1, (E + pgo::edge_block() - 1) / pgo::edge_block()), pgo::max_edge_wg());   // k_cost and the step tail stride beyond that
@@ -385,7 +385,7 @@ int prepare(pgo_problem* P) {
   g.delta = P->d_delta.p; g.part_rz = P->d_part_rz.p; g.part_q = P->d_part_q.p;
   g.part_rr = P->d_part_rr.p; g.part_bb = P->d_part_bb.p; g.part_misc = P->d_part_misc.p;
   g.cg_u = P->d_cg_u.p; g.cg_w = P->d_cg_w.p; g.cg_s = P->d_cg_s.p; g.cg_qq = P->d_cg_qq.p;
-  g.pipe_buf[0] = P->d_pipe_a.p; g.pipe_buf[1] = P->d_pipe_b.p; g.pipe_xbuf = P->d_pipe_x.p; g.pipe_seg = pipe_seg;
+  g.pipe_buf[0] = P->d_pipe_a.p; g.pipe_buf[1] = P->d_pipe_b.p; g.pipe_seg = pipe_seg;
   g.pairs_whole = pairs_whole ? 1 : 0;
   g.n_part = n_part; g.n_vec_wg = n_vec_wg; g.n_edge_wg = n_edge_wg; g.n_pose_wg = n_pose_wg;
   g.cg = P->d_cg.p; g.flags = P->d_flags.p;
