@@ -489,6 +489,18 @@ def main():
                                                      "the elimination tree in parallel, the top of the tree sequential (same bits as one thread)" % (nthr, it3),
                                            "lm_iters_per_sec": round(it3 / dt3, 4), "seconds": round(dt3, 3),
                                            "speedup_vs_1_core": round((it3 / dt3) / (iters / dt), 3)}
+        # ... the same-policy solve (cluster-Jacobi PCG, what the GPU run does) on all cores: Jacobian evaluation, the block SpMV (per
+        # row, contributions in the one-thread order) and the Jacobi blocks in parallel, same bits as one thread
+        nthr5 = min(ncore, 32)       # (measured on the GPU box's host: 1.11 s on one thread, 0.55 / 0.47 / 0.65 s on 8 / 32 / 64 — the pool's wake-ups and the serial vector work bound it)
+        t5 = time.perf_counter()
+        _, o5, _ = O.solve(og, O.default_options(max_num_iterations=args.steps, linear_solver=1, function_tolerance=0.0, parameter_tolerance=0.0,
+                                                 gradient_tolerance=0.0, pcg_cluster=args.cluster, num_threads=nthr5))
+        dt5 = time.perf_counter() - t5
+        it5 = max(1, o5.num_iterations - 1)
+        extra["cpu_same_policy_all_cores"] = {"value": round(E * it5 / dt5, 1), "unit": "edge-LM-iterations/s", "cores": nthr5,
+                                              "sample": "ONE solve on %d threads, %d LM iterations, cluster-Jacobi PCG eta=0.1" % (nthr5, it5),
+                                              "final_cost": o5.final_cost, "cg_iterations": o5.num_linear_iterations,
+                                              "speedup_vs_1_core": round((it5 / dt5) / (it2 / dt2), 3)}
         # ... and throughput: one copy of the sample per core, solved concurrently
         import threading
         k_all = max(2, k // 6)

@@ -957,10 +957,48 @@ void chol_dense_solve(const std::vector<double>& L, int n, const double* b, doub
   for (int i = n - 1; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < n; ++k) t -= L[(size_t)k * n + i] * x[k]; x[i] = t / L[(size_t)i * n + i]; }
 }
 
+// Threaded form of sym_matvec: per row the contributions in the order the sequential loop over (column, entry) delivers them, so
+// a row summed by any thread has the bits of the one-thread product.
+struct RowEvents {
+  struct Ev { int p, col; bool transposed; };
+  std::vector<std::vector<Ev>> rows;
+  explicit RowEvents(const BlockSym& H) : rows(H.n) {
+    for (int j = 0; j < H.n; ++j)
+      for (int p = H.colptr[j]; p < H.colptr[j + 1]; ++p) {
+        const int i = H.rowidx[p];
+        rows[i].push_back(Ev{p, j, false});
+        if (i != j) rows[j].push_back(Ev{p, i, true});
+      }
+  }
+  void matvec(const BlockSym& H, const double* d2, const double* x, double* y, Pool& pool) const {
+    const int n = H.n, chunks = pool.width() * 4;
+    pool.run(chunks, [&](int c) {
+      const int k0 = (int)((long long)n * c / chunks), k1 = (int)((long long)n * (c + 1) / chunks);
+      for (int k = k0; k < k1; ++k) {
+        double* yk = y + 6 * (size_t)k;
+        for (int r = 0; r < 6; ++r) yk[r] = d2 ? d2[6 * (size_t)k + r] * x[6 * (size_t)k + r] : 0.0;
+        for (const Ev& e : rows[k]) {
+          const double* B = H.val[e.p].data();
+          const double* xc = x + 6 * (size_t)e.col;
+          if (!e.transposed) {
+            for (int r = 0; r < 6; ++r) { double s2 = 0; for (int cc = 0; cc < 6; ++cc) s2 += B[6 * r + cc] * xc[cc]; yk[r] += s2; }
+          } else {
+            for (int cc = 0; cc < 6; ++cc) { double s2 = 0; for (int r = 0; r < 6; ++r) s2 += B[6 * r + cc] * xc[r]; yk[cc] += s2; }
+          }
+        }
+      }
+    });
+  }
+};
+
 int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, double q_tol,
-              int max_it, int min_it, int residual_reset_period, bool* ok, double* final_rnorm, int cluster = 1) {
+              int max_it, int min_it, int residual_reset_period, bool* ok, double* final_rnorm, int cluster = 1, Pool* pool = nullptr) {
   const int n = H.n;
   const size_t m = (size_t)6 * n;
+  if (pool && pool->width() <= 1) pool = nullptr;
+  std::unique_ptr<RowEvents> rows;
+  if (pool) rows.reset(new RowEvents(H));
+  auto matvec = [&](const double* in, double* outv) { if (pool) rows->matvec(H, d2, in, outv, *pool); else sym_matvec(H, d2, in, outv); };
   // block-Jacobi preconditioner; cluster > 1 groups `cluster` consecutive poses (a piece of the odometry
   // chain) into one dense diagonal block of H + D^2 (the product's cluster-Jacobi option)
   if (cluster < 1) cluster = 1;
@@ -985,10 +1023,13 @@ int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, d
     if (!chol_dense(A, dim)) { *ok = false; return 0; }
   }
   auto apply_M = [&](const double* rin, double* zout) {
-    for (int c = 0; c < ncl; ++c) {
+    auto one = [&](int c) {
       const int v0 = c * cluster, v1 = std::min(n, v0 + cluster);
       chol_dense_solve(Mfac[c], 6 * (v1 - v0), rin + 6 * (size_t)v0, zout + 6 * (size_t)v0);
-    }
+    };
+    if (!pool) { for (int c = 0; c < ncl; ++c) one(c); return; }
+    const int chunks = pool->width() * 4;
+    pool->run(chunks, [&](int ch) { for (int c = (int)((long long)ncl * ch / chunks); c < (int)((long long)ncl * (ch + 1) / chunks); ++c) one(c); });
   };
   std::vector<double> r(b, b + m), z(m), p(m, 0.0), q(m), tmp(m);
   std::fill(x, x + m, 0.0);
@@ -1009,14 +1050,14 @@ int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, d
       if (beta == 0.0 || !std::isfinite(beta)) { *ok = false; break; }
       for (size_t i = 0; i < m; ++i) p[i] = z[i] + beta * p[i];
     }
-    sym_matvec(H, d2, p.data(), q.data());
+    matvec(p.data(), q.data());
     const double pq = dot(p.data(), q.data());
     if (pq <= 0.0 || !std::isfinite(pq)) break;  // NO_CONVERGENCE: keep current x
     const double alpha = rho / pq;
     if (!std::isfinite(alpha)) { *ok = false; break; }
     for (size_t i = 0; i < m; ++i) x[i] += alpha * p[i];
     if (residual_reset_period > 0 && it % residual_reset_period == 0) {
-      sym_matvec(H, d2, x, tmp.data());
+      matvec(x, tmp.data());
       for (size_t i = 0; i < m; ++i) r[i] = b[i] - tmp[i];
     } else {
       for (size_t i = 0; i < m; ++i) r[i] -= alpha * q[i];
@@ -1340,7 +1381,7 @@ int oracle_solve(int N, int E, double* poses, const uint8_t* cmask, const int* i
       sum->factor_flops = chol.flops;
     } else {
       lin_it = pcg_solve(H, d2.data(), gs.data(), step.data(), opt->eta, opt->max_linear_solver_iterations,
-                         opt->min_linear_solver_iterations, opt->residual_reset_period, &lin_ok, nullptr, opt->pcg_cluster);
+                         opt->min_linear_solver_iterations, opt->residual_reset_period, &lin_ok, nullptr, opt->pcg_cluster, pool.get());
       sum->num_linear_iterations += lin_it;
     }
     if (lin_ok) for (size_t i = 0; i < m; ++i) { if (!std::isfinite(step[i])) { lin_ok = false; break; } }

@@ -19,3 +19,4 @@ def test_threaded_oracle_equals_sequential_bit_for_bit(O, ds, name):
     pc1, sc1, tc1 = O.solve(og, O.default_options(max_num_iterations=8, linear_solver=1, pcg_cluster=2, num_threads=1))
     pc, sc, tc = O.solve(og, O.default_options(max_num_iterations=8, linear_solver=1, pcg_cluster=2, num_threads=6))
     assert np.array_equal(tc, tc1) and np.array_equal(pc, pc1)
+    assert sc.num_linear_iterations == sc1.num_linear_iterations > 0      # (the PCG's block SpMV and Jacobi blocks run on the pool as well)
