@@ -87,6 +87,7 @@ int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const do
   if (!P || !options || !d2 || !b || !x) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_linear_solve");
   int rc = prepare(P);
   if (rc) return rc;
+  struct StandardCg { pgo_problem* p; explicit StandardCg(pgo_problem* q) : p(q) { p->force_standard_cg = true; } ~StandardCg() { p->force_standard_cg = false; } } standard_cg(P);
   hipStream_t s = P->stream;
   P->g.loss_kind = P->loss_kind; P->g.loss_a = P->loss_a;
   P->g.pose_x = P->d_pose_x.p; P->g.pose_c = P->d_pose_c.p;

@@ -337,6 +337,7 @@ struct pgo_problem {
       d_scale, d_d2, d_diagc, d_cg_b, d_cg_x, d_cg_r, d_cg_z, d_cg_q, d_cg_p0, d_cg_p1, d_delta, d_part_rz, d_part_q,
       d_part_rr, d_part_bb, d_part_misc, d_tmp_a, d_tmp_b, d_tmp_c, d_cg_u, d_cg_w, d_cg_s, d_cg_qq, d_pipe_a, d_pipe_b, d_pipe_x;
   DevBuf<pgo::CgState> d_cg;
+  bool force_standard_cg = false;   // pgo_linear_solve (one linear system, every rank reads the whole x): the replicated standard CG even on several ranks
   // spare set of the linearisation (blocks, diagonal blocks, gradient): the candidate point is linearised into it right behind
   // the step tail, before the host has decided; an accepted step swaps the sets (one rank, eager enqueue)
   DevBuf<double> d_bsr2, d_Hdiag2, d_grad2;

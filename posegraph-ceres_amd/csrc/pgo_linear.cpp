@@ -29,7 +29,7 @@ int wait_handoff(pgo_problem* P) {
 bool pipe_mode(const pgo_problem* P, const pgo::CgParams& prm) {
   const char* e = getenv("PGO_SHARD_PIPE");       // (read per call: the tests run both forms in one process; every rank sees the same environment)
   const bool off = e && e[0] == '0';
-  return !off && !P->use_graph && pgo::pipe_supported(P->g, prm, P->g.cluster);
+  return !off && !P->use_graph && !P->force_standard_cg && pgo::pipe_supported(P->g, prm, P->g.cluster);
 }
 
 int enqueue_tail(pgo_problem* P, const pgo::CgParams* finish_prm) {

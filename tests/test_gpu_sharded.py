@@ -79,6 +79,40 @@ def test_owner_only_cg_and_replicated_cg_agree(gpu, ds, cluster, monkeypatch):
     assert max(ref.iterations["linear_solver_iterations"]) > 20
 
 
+def test_linear_solve_on_loopback_ranks_returns_the_whole_solution(gpu, ds):
+    """pgo_linear_solve hands every rank the whole x: it keeps the standard CG (vector update on every rank) whatever form the
+    Levenberg-Marquardt loop of the same problem takes, and equals the single-rank solve."""
+    g = ds.manhattan_se3(901, 3300, seed=12)
+    opt = gpu.SolverOptions(linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, eta=1e-3, max_linear_solver_iterations=300)
+    rng = np.random.default_rng(3)
+    d2 = np.full(6 * g.N, 1e2)       # (well conditioned: the truncated CG stops by its Q-tolerance long before the iteration limit)
+    b = rng.normal(size=6 * g.N)
+    prob, _ = gpu.problem_from_graph(g)
+    x1, it1 = prob.linear_solve(d2, b, opt)
+    world = 3
+    group = gpu.loopback_create(world)
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            p, _ = gpu.problem_from_graph(g)
+            p.comm_init_loopback(group, rank)
+            out[rank] = p.linear_solve(d2, b, opt)
+        except Exception as e:  # a failing rank would leave the others waiting: surface it
+            errs.append(e)
+
+    ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert not errs, errs
+    gpu.loopback_destroy(group)
+    for x, it in out:
+        assert it == it1 < 300 and np.allclose(x, x1, rtol=1e-7, atol=1e-9 * np.abs(x1).max())
+        assert np.array_equal(x, out[0][0])
+
+
 def test_loopback_exact_request_falls_back_to_tight_pcg(gpu, ds, O):
     g = ds.manhattan_se3(300, 1000, seed=4)
     opt = dict(max_num_iterations=15, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
