@@ -21,6 +21,14 @@ for c in c2 c5; do
 done
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/front_mfma -o m -- python tools/front_prof.py c5 3 > $OUT/front_mfma.log 2>&1
 python tools/rocprof_mfma.py $OUT/front_mfma/m_results.db $OUT/${TAG}_front_c5_mfma_pmc.json > $OUT/front_mfma_summary.log 2>&1
+# 5. the sharded path on eight loopback ranks (C4), both CG forms; the one-rank all-gather timing; the FP64 MFMA clock measurement
+for m in 1 0; do
+  PGO_SHARD_PIPE=$m rocprofv3 --kernel-trace -d $OUT/sh$m -o t -- python tools/shard_pipe_check.py 100000 1000000 8 6 > $OUT/shard_log$m.txt 2>&1
+  python tools/rocprof_summary.py $OUT/sh$m/t_results.db $OUT/${TAG}_c4_8way_loopback_pipe${m}_kernel_stats.csv > /dev/null
+  rm -rf $OUT/sh$m
+done
+python tools/exchange_latency.py 2>/dev/null | grep "^{" > $OUT/exchange_world1_raw.json
+[ -x tools/bench/mfma_clock ] && tools/bench/mfma_clock > $OUT/${TAG}_mfma_clock.txt 2>&1
 cp $OUT/${TAG}_pmc.json profiles/ 2>/dev/null   # on this box only: the final bench run quotes the traffic measured above, on these very sources
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -n 3 $OUT/pmc.log $OUT/front_mfma_summary.log $OUT/front_c2.log $OUT/front_c5.log
