@@ -10,12 +10,18 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def test_kitti00_candidates_match_cpu_generator(pkg, ds):
+def test_kitti00_candidates_match_the_reference_file(pkg, ds):
+    """The GPU search against the ids of the reference's own config/Edge_Candidates_index.txt (stored in kitti00.npz
+    as keys / offsets / flat ids + the sha256 of the file text): bit-exact, and the formatted text hashes to the file."""
+    import hashlib
     k = np.load(os.path.join(GOLD, "kitti00.npz"))
     xyz = k["origin"][:, :3]
-    ref = ds.generate_candidates(xyz, 6.0, 100)
     got = pkg.generate_candidates(xyz, 6.0, 100)
-    assert got == ref
+    assert sorted(kk for kk in got if got[kk]) == [int(x) for x in k["cand_keys"]]
+    for i, kk in enumerate(k["cand_keys"]):
+        assert got[int(kk)] == k["cand_flat"][k["cand_offsets"][i]:k["cand_offsets"][i + 1]].tolist(), "line %d" % kk
+    assert hashlib.sha256(ds.format_candidates(got).encode()).hexdigest() == str(k["cand_sha256"])
+    assert got == ds.generate_candidates(xyz, 6.0, 100)       # and the CPU generator agrees
     assert sum(len(v) - 1 for v in got.values()) > 10000     # KITTI 00 revisits: the lists are not trivial
 
 

@@ -1,0 +1,75 @@
+"""-m gpu: the HIP path on the reference's own replayable before/after pair (result_before.g2o -> result_after.g2o,
+test/pose_graph_try1.cpp:137-148) and on the reference-held input graph `111`.  What the pair can and cannot pin, and
+the tolerances, are stated in tests/test_g2o_pair.py (the CPU/oracle half of the same check)."""
+import os
+
+import numpy as np
+import pytest
+
+from test_g2o_pair import COS_MIN, HALF_ROT, MAX_TOL_M, MEAN_TOL_M, displacement_stats, rounding_bound, unit
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def pair():
+    k = np.load(os.path.join(G, "g2o_pair.npz"))
+    return dict(before=unit(k["before"]), after=unit(k["after"]), raw_before=k["before"], raw_after=k["after"],
+                ia=k["ia"], ib=k["ib"], meas=unit(k["meas"]), L=np.tile(HALF_ROT, (len(k["ia"]), 1)))
+
+
+@pytest.mark.parametrize("state", ["before", "after"])
+def test_gpu_residuals_at_both_reference_states(gpu, ds, pair, state):
+    """Every edge of the reference's file, at the reference's own before and after vertices: residual inside the print
+    rounding of the endpoints (frame, direction, sign, quaternion order of a3 pinned edge by edge on the device)."""
+    g = ds.PoseGraphData(pair[state], pair["ia"], pair["ib"], pair["meas"], pair["L"])
+    prob, _ = gpu.problem_from_graph(g)
+    cost, r, ja, jb, grad = prob.evaluate()
+    bound = rounding_bound(pair["raw_" + state][:, :3], pair["ia"], pair["ib"]) + 2e-6
+    assert (np.linalg.norm(r[:, :3], axis=1) <= bound).all()
+    assert np.abs(r[:, 3:]).max() <= 2e-5 and cost < 6e-4
+    swapped = ds.PoseGraphData(pair[state], pair["ib"], pair["ia"], pair["meas"], pair["L"])
+    prob2, _ = gpu.problem_from_graph(swapped)
+    assert prob2.evaluate()[0] > 1e3
+
+
+@pytest.mark.parametrize("solver", ["SPARSE_NORMAL_CHOLESKY", "BLOCK_JACOBI_PCG"])
+def test_gpu_solve_reproduces_the_reference_after(gpu, ds, O, pair, solver):
+    g = ds.PoseGraphData(pair["before"], pair["ia"], pair["ib"], pair["meas"], pair["L"])
+    prob, poses = gpu.problem_from_graph(g)
+    tight = dict(max_num_iterations=200, function_tolerance=1e-16, parameter_tolerance=1e-14, gradient_tolerance=1e-16)
+    if solver == "BLOCK_JACOBI_PCG":
+        tight.update(max_linear_solver_iterations=5000, eta=1e-8)
+    s = gpu.solve(gpu.SolverOptions(linear_solver_type=getattr(gpu, solver), **tight), prob)
+    assert s.is_solution_usable() and s.final_cost < 1e-7
+    assert np.array_equal(poses[0], pair["before"][0])                  # FIX 0: bit-untouched
+    mean, mx, cos = displacement_stats(poses, pair["before"], pair["after"])
+    print("%s: GPU optimum vs reference after: mean %.2f mm max %.2f mm cosine %.3f (cost %.3e, %d its)" % (
+        solver, 1e3 * mean, 1e3 * mx, cos, s.final_cost, s.num_iterations))
+    assert mean <= MEAN_TOL_M and mx <= MAX_TOL_M and cos >= COS_MIN, (mean, mx, cos)
+    ang = 2 * np.arccos(np.clip(np.abs((poses[:, 3:] * pair["after"][:, 3:]).sum(1)), 0, 1))
+    assert ang.max() <= 3e-5
+    # and the GPU optimum is the oracle's optimum far below the file's print precision
+    opt = O.default_options(max_num_iterations=200, function_tolerance=1e-16, parameter_tolerance=1e-14, gradient_tolerance=1e-16)
+    mine, osum, _ = O.solve(O.Graph(pair["before"], pair["ia"], pair["ib"], pair["meas"], pair["L"]), opt)
+    assert np.abs(poses[:, :3] - mine[:, :3]).max() < (1e-7 if solver == "SPARSE_NORMAL_CHOLESKY" else 2e-5)
+
+
+def test_gpu_reference_input_111_matches_oracle(gpu, ds, O):
+    """`111` (2761 vertices / 8900 edges, real loop measurements, Huber active on > 1000 edges): the reference's options,
+    exact steps, GPU against oracle — same decisions, same costs, same poses."""
+    k = np.load(os.path.join(G, "g2o_111.npz"))
+    L = np.tile(HALF_ROT, (8900, 1))
+    g = ds.PoseGraphData(unit(k["poses"]), k["ia"], k["ib"], unit(k["meas"]), L)
+    prob, poses = gpu.problem_from_graph(g)
+    # (to its own stop the oracle takes 344 iterations / 20 s; 60 iterations cover the Huber-dominated descent)
+    s = gpu.solve(gpu.SolverOptions(max_num_iterations=60, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY), prob)
+    op, osum, otr = O.solve(O.Graph(g.poses, g.ia, g.ib, g.meas, L), O.default_options(max_num_iterations=60))
+    assert s.initial_cost == pytest.approx(osum.initial_cost, rel=1e-12)
+    n = min(len(otr), len(s.iterations), 40)
+    assert n >= 20
+    assert list(s.iterations["step_is_successful"][:n]) == [int(x) for x in otr[:n, 8]]
+    assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-6)
+    assert s.final_cost == pytest.approx(osum.final_cost, rel=1e-3)
+    assert s.final_cost < 0.02 * s.initial_cost
