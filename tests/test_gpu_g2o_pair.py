@@ -34,26 +34,25 @@ def test_gpu_residuals_at_both_reference_states(gpu, ds, pair, state):
     assert prob2.evaluate()[0] > 1e3
 
 
-@pytest.mark.parametrize("solver", ["SPARSE_NORMAL_CHOLESKY", "BLOCK_JACOBI_PCG"])
-def test_gpu_solve_reproduces_the_reference_after(gpu, ds, O, pair, solver):
+def test_gpu_solve_reproduces_the_reference_after(gpu, ds, O, pair):
+    """The reference's linear solver (exact steps; finial.cpp:534-536 / g2o's Cholesky) from *before* to tight convergence."""
     g = ds.PoseGraphData(pair["before"], pair["ia"], pair["ib"], pair["meas"], pair["L"])
     prob, poses = gpu.problem_from_graph(g)
     tight = dict(max_num_iterations=200, function_tolerance=1e-16, parameter_tolerance=1e-14, gradient_tolerance=1e-16)
-    if solver == "BLOCK_JACOBI_PCG":
-        tight.update(max_linear_solver_iterations=5000, eta=1e-8)
-    s = gpu.solve(gpu.SolverOptions(linear_solver_type=getattr(gpu, solver), **tight), prob)
-    assert s.is_solution_usable() and s.final_cost < 1e-7
+    s = gpu.solve(gpu.SolverOptions(linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY, **tight), prob)
+    assert s.is_solution_usable() and s.final_cost < 1e-7 and s.linear_solver_used == 0
     assert np.array_equal(poses[0], pair["before"][0])                  # FIX 0: bit-untouched
     mean, mx, cos = displacement_stats(poses, pair["before"], pair["after"])
-    print("%s: GPU optimum vs reference after: mean %.2f mm max %.2f mm cosine %.3f (cost %.3e, %d its)" % (
-        solver, 1e3 * mean, 1e3 * mx, cos, s.final_cost, s.num_iterations))
+    print("GPU optimum vs reference after: mean %.2f mm max %.2f mm cosine %.3f (cost %.3e, %d its)" % (
+        1e3 * mean, 1e3 * mx, cos, s.final_cost, s.num_iterations))
     assert mean <= MEAN_TOL_M and mx <= MAX_TOL_M and cos >= COS_MIN, (mean, mx, cos)
     ang = 2 * np.arccos(np.clip(np.abs((poses[:, 3:] * pair["after"][:, 3:]).sum(1)), 0, 1))
     assert ang.max() <= 3e-5
     # and the GPU optimum is the oracle's optimum far below the file's print precision
-    opt = O.default_options(max_num_iterations=200, function_tolerance=1e-16, parameter_tolerance=1e-14, gradient_tolerance=1e-16)
+    opt = O.default_options(**tight)
     mine, osum, _ = O.solve(O.Graph(pair["before"], pair["ia"], pair["ib"], pair["meas"], pair["L"]), opt)
-    assert np.abs(poses[:, :3] - mine[:, :3]).max() < (1e-7 if solver == "SPARSE_NORMAL_CHOLESKY" else 2e-5)
+    assert np.abs(poses[:, :3] - mine[:, :3]).max() < 1e-7
+    assert s.final_cost == pytest.approx(osum.final_cost, rel=1e-6)
 
 
 def test_gpu_reference_input_111_matches_oracle(gpu, ds, O):
