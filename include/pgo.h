@@ -133,7 +133,9 @@ typedef struct pgo_solver_summary {
   int num_parameter_blocks_reduced;     /* FullReport's Reduced column: constant blocks removed */
   int num_parameters_reduced;
   int num_effective_parameters_reduced;
-  int reserved1;
+  int cg_form;                  /* CG of the PCG solves: 0 one rank (universal stream / batches), 1 several ranks, replicated standard CG
+                                   (every rank updates every row, q all-gathered per iteration), 2 several ranks, owner-only pipelined CG
+                                   (every rank updates its own rows, one all-gather per iteration) */
 } pgo_solver_summary;
 
 /* One row per iteration, the numbers Summary::FullReport() tabulates with

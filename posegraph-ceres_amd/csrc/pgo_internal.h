@@ -337,11 +337,13 @@ struct pgo_problem {
       d_scale, d_d2, d_diagc, d_cg_b, d_cg_x, d_cg_r, d_cg_z, d_cg_q, d_cg_p0, d_cg_p1, d_delta, d_part_rz, d_part_q,
       d_part_rr, d_part_bb, d_part_misc, d_tmp_a, d_tmp_b, d_tmp_c, d_cg_u, d_cg_w, d_cg_s, d_cg_qq, d_pipe_a, d_pipe_b, d_pipe_x;
   DevBuf<pgo::CgState> d_cg;
+  DevBuf<long long> d_oplog;        // PGO_UNI_OPLOG=<file>: per-launch operation log of k_uni_s (DeviceGraph::oplog), appended to the file at pgo_solver_end
   bool force_standard_cg = false;   // pgo_linear_solve (one linear system, every rank reads the whole x): the replicated standard CG even on several ranks
   // spare set of the linearisation (blocks, diagonal blocks, gradient): the candidate point is linearised into it right behind
   // the step tail, before the host has decided; an accepted step swaps the sets (one rank, eager enqueue)
   DevBuf<double> d_bsr2, d_Hdiag2, d_grad2;
   bool spec_ready = false;
+  int lin_diag_only = -1;           // several ranks: what the last linearisation exchanged of the other ranks' diagonal blocks (1: only their diagonals — valid for the owner-only CG alone); checked against the CG form at every CG start
   pgo::LmScalars* scal = nullptr;  // pinned, device visible
   size_t scal_cap = 0;
   // device-resident LM (pgo_kernels.h LmDev): the trust-region decisions are taken on the device and the host enqueues the

@@ -207,6 +207,10 @@ struct DeviceGraph {
   LmScalars* scal;    // device-visible pinned host memory
   int* flags;         // [4] device flags: [0] linearize saw non-finite
   int debug;          // development ablation switches (0 in production)
+  // profiling aid (PGO_UNI_OPLOG=<file>, null otherwise): every k_uni_s launch appends (operation it performed, s_memrealtime) so
+  // that tools/rocprof_summary.py can bucket the dispatches of that one kernel symbol by what they did.  [0] = entries so far.
+  long long* oplog;
+  int oplog_cap;
   // one process per GPU: contiguous row ownership (all rows when world == 1)
   int world, rank, rows_per, row_lo, row_hi, pq_cap, seg;
   int cluster;        // poses per Jacobi block of the preconditioner: 1 (6x6), 2 (12x12) or 4 (24x24)

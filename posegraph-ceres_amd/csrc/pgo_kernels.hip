@@ -1371,7 +1371,9 @@ __device__ __forceinline__ void lm_pre_step_checks(LmDev& D, bool successful) {
 __device__ __forceinline__ void lm_cg_unfinished(const DeviceGraph& g) {
   LmDev& D = *g.lm;
   const int completed = g.cg->cnt_b;
-  if (D.cg_period <= 0 || completed % D.cg_period == 0) {
+  // (and an EVEN number of iterations: a continuation sequence is enqueued as iterations 1, 2, ... and the ping-pong buffer of p
+  // is chosen by that launch-time parity, so the absolute iteration completed + 1 has to be odd as well)
+  if ((completed & 1) == 0 && (D.cg_period <= 0 || completed % D.cg_period == 0)) {
     D.phase = LM_PHASE_CONT;
   } else {
     D.halt = LM_HALT_CG_STALL;
@@ -1605,6 +1607,14 @@ __global__ void k_lm_resume(DeviceGraph g, int cg_goes_on) {
 constexpr int UNI_V_BLOCK = 512;   // vector-shaped launches: 6 waves of vector update (VEC_BLOCK rows), 4 waves of step tail / accept-finish
                                    // (EDGE_BLOCK / POSE_BLOCK), up to 8 waves of cluster inverses for the 64 poses of a row chunk
 
+// profiling aid, see DeviceGraph::oplog (one entry per launch, written by work-group 0)
+__device__ __forceinline__ void uni_oplog(const DeviceGraph& g, int what) {
+  if (g.oplog && blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long i = g.oplog[0];
+    if (i + 1 < g.oplog_cap) { g.oplog[1 + i] = ((long long)__builtin_amdgcn_s_memrealtime() << 3) | (long long)what; g.oplog[0] = i + 1; }
+  }
+}
+
 template <bool PACKED, int INFO>
 __global__ __launch_bounds__(256) void k_uni_s(DeviceGraph g, CgParams prm, int period) {
   constexpr int NPAIR = PACKED ? BLK_PAIRS_PACKED : BLK_PAIRS_FULL;
@@ -1646,8 +1656,9 @@ __global__ __launch_bounds__(256) void k_uni_s(DeviceGraph g, CgParams prm, int 
       se[0] += g.part_rz[g.n_part + i]; se[2] += g.part_q[g.n_part + i];
     }
   }
-  if (op <= UNI_NOP) return;
+  if (op <= UNI_NOP) { uni_oplog(g, 0); return; }
   if (op == UNI_S_LINEARIZE) {
+    uni_oplog(g, UNI_S_LINEARIZE);
     DeviceGraph gl = g;
     gl.pose_x = g.pose_c;          // the accepted candidate; the accept-finish part of the next head launch copies it over
     linearize_body<INFO>(gl, lds);
@@ -1697,6 +1708,7 @@ __global__ __launch_bounds__(256) void k_uni_s(DeviceGraph g, CgParams prm, int 
     }
   }
   const bool cg_step = op == UNI_S_CG && !tail;
+  uni_oplog(g, cg_step ? UNI_S_CG : tail ? 4 : op);     // 1 CG product, 2 refresh product, 4 tail product (A x of the step tail)
   const double* p_old = odd ? g.cg_p0 : g.cg_p1;
   double* p_new = odd ? g.cg_p1 : g.cg_p0;
   // gathers of the first chunk

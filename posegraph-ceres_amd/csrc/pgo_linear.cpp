@@ -155,6 +155,11 @@ int pick_batch(const pgo::CgParams& prm, int user_batch, int round, int enqueued
 // CG start: r0 = b, z0 / u0 = M^-1 r0 (and, owner-only form, the first product w0 = A u0 with its two all-gathers)
 int pcg_begin(pgo_problem* P, const pgo::CgParams& prm) {
   hipStream_t s = P->stream;
+  // the linearisation decided how much of the other ranks' diagonal blocks to fetch from a predicate of its own (the cluster
+  // size is chosen after the first linearisation): the replicated standard CG on diagonal-only blocks would build different
+  // preconditioners on different ranks and diverge silently — refuse instead
+  if (P->g.world > 1 && P->lin_diag_only == 1 && !pipe_mode(P, prm))
+    return set_error(PGO_ERR_INVALID_ARGUMENT, "internal: the linearisation exchanged only the diagonals of the other ranks' blocks but the replicated CG is about to run");
   if (!pipe_mode(P, prm)) { pgo::launch_pcg_init(P->g, s); return PGO_OK; }
   pgo::launch_pipe_init(P->g, s);
   int rc = exchange(P, P->g.pipe_buf[0], (size_t)P->g.pipe_seg);

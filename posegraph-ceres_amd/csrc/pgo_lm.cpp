@@ -13,6 +13,7 @@ int evaluate_gradient_and_jacobian(pgo_problem* P, bool first) {
   const char* pe = getenv("PGO_SHARD_PIPE");
   const bool diag_only = P->g.world > 1 && !(pe && pe[0] == '0') && !P->use_graph &&
                          pgo::pipe_supported(P->g, cg_params_for(P->opt), P->opt.pcg_cluster_poses == 2 ? 2 : 1) && P->opt.pcg_cluster_poses != 4;
+  P->lin_diag_only = diag_only ? 1 : 0;
   if (first) {
     int rc = fill_scale_one(P);
     if (rc) return rc;
@@ -467,8 +468,9 @@ int pipe_pick_batch(const pgo_problem* P, const pgo::CgParams& prm, int period, 
     if (pred <= 7 && cont_streak == 0) nb = pred + 2;
     else {
       const int want = std::max(pred + pred / 4 + 1, 8) << std::min(cont_streak, 3);
-      nb = period > 0 ? (want + period - 1) / period * period : want;
-      nb = std::min(nb, period > 0 ? std::max(period, 60 / period * period) : 64);
+      const int per2 = (period & 1) ? 2 * period : period;     // sequences end on EVEN multiples of the period (lm_cg_unfinished)
+      nb = period > 0 ? (want + per2 - 1) / per2 * per2 : want;
+      nb = std::min(nb, period > 0 ? std::max(per2, 60 / per2 * per2) : 64);
     }
   }
   nb = std::max(1, std::min(nb, prm.max_iterations));
@@ -549,7 +551,9 @@ int lm_run_universal(pgo_problem* P, int budget, int* ran) {
     if (rc0) return rc0;
     P->pipe_dirty = false;
   }
-  static const int hi = getenv("PGO_UNI_AHEAD") ? std::max(2, atoi(getenv("PGO_UNI_AHEAD"))) : 12;
+  // (an LM iteration is at least two pairs, records are pulled once per turn of the loop below: at most hi / 2 decisions between
+  // two pulls, which has to stay below the LM_RING - 2 record slots in flight)
+  static const int hi = getenv("PGO_UNI_AHEAD") ? std::min(2 * (pgo::LM_RING - 4), std::max(2, atoi(getenv("PGO_UNI_AHEAD")))) : 12;
   const int lo = std::max(1, hi / 3);
   const pgo::CgParams prm = cg_params_for(o);
   const int period = prm.q_tolerance < 0.0 ? 0 : o.cg_residual_reset_period;
@@ -611,7 +615,8 @@ int lm_run_pipelined(pgo_problem* P, int budget, int* ran) {
     if (rc0) return rc0;
     P->pipe_dirty = false;
   }
-  static const int lookahead = getenv("PGO_PIPELINE_AHEAD") ? std::max(0, atoi(getenv("PGO_PIPELINE_AHEAD"))) : 1;
+  // (one decision per sequence at most; the iteration records of the sequences in flight share the LM_RING pinned slots)
+  static const int lookahead = getenv("PGO_PIPELINE_AHEAD") ? std::min((int)pgo::LM_RING - 4, std::max(0, atoi(getenv("PGO_PIPELINE_AHEAD")))) : 1;
   const bool direct = o.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY && P->direct_usable;
   const pgo::CgParams prm = cg_params_for(o);
   const int period = prm.q_tolerance < 0.0 ? 0 : o.cg_residual_reset_period;
@@ -651,7 +656,9 @@ int lm_run_pipelined(pgo_problem* P, int budget, int* ran) {
         // sequences line up again), then the tail
         const int completed = P->scal->cg_iterations;
         int nb = pipe_pick_batch(P, prm, period, std::max(P->pipe_last_nb, 8), 1);
-        if (period > 0) nb = ((completed + nb + period - 1) / period) * period - completed;
+        // (an even multiple: the sequences behind this one are enqueued as iterations 1, 2, ... and rely on that parity)
+        if (period > 0) { const int per2 = (period & 1) ? 2 * period : period; nb = ((completed + nb + per2 - 1) / per2) * per2 - completed; }
+        else if ((completed + nb) & 1) ++nb;
         pgo::launch_lm_resume(gp, 1, P->stream);
         rc = enqueue_sequence(P, gp, gl, prm, false, nb, completed + 1, false);
         if (rc) break;
@@ -674,7 +681,17 @@ int lm_run_pipelined(pgo_problem* P, int budget, int* ran) {
       continue;
     }
     __builtin_ia32_pause();
-    if ((++idle_spins & 0xfff) == 0 && seconds_since(t_idle) > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(100));   // long iterations (sphere x10: 34 ms): no need to burn the core
+    if ((++idle_spins & 0xfff) == 0 && seconds_since(t_idle) > 0.002) {
+      std::this_thread::sleep_for(std::chrono::microseconds(100));   // long iterations (sphere x10: 34 ms): no need to burn the core
+      if (seconds_since(t_idle) > 20.0) {                            // watchdog: nothing enqueued for 20 s and still sequences in flight
+        HIP_TRY(hipStreamSynchronize(P->stream));
+        if (__atomic_load_n(&P->scal->seq_done, __ATOMIC_ACQUIRE) == sdone && __atomic_load_n(&P->scal->halt, __ATOMIC_ACQUIRE) == 0 && in_flight > 0) {
+          rc = set_error(PGO_ERR_HIP, "the enqueued LM sequences made no progress (%d of %d through)", sdone, P->pipe_seq);
+          break;
+        }
+        t_idle = Clock::now();
+      }
+    }
   }
   if (rc == PGO_OK) rc = pipe_drain(P);
   if (rc) return rc;
@@ -716,8 +733,20 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
                  L.hybrid_direct, L.hybrid_pcg_ok, L.hybrid_pcg_over);
   int rc = download_poses(P, P->g.pose_x);
   if (rc) return rc;
+  if (P->g.oplog) {      // profiling aid (PGO_UNI_OPLOG): "<s_memrealtime tick> <operation>" per k_uni_s launch of this session
+    long long n = 0;
+    HIP_TRY(hipMemcpy(&n, P->g.oplog, sizeof n, hipMemcpyDeviceToHost));
+    std::vector<long long> h((size_t)n);
+    if (n) HIP_TRY(hipMemcpy(h.data(), P->g.oplog + 1, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(P->g.oplog, 0, sizeof(long long)));
+    if (FILE* f = std::fopen(getenv("PGO_UNI_OPLOG"), "a")) {
+      for (long long v : h) std::fprintf(f, "%lld %d\n", v >> 3, (int)(v & 7));
+      std::fclose(f);
+    }
+  }
   if (summary) {
     memset(summary, 0, sizeof *summary);
+    summary->cg_form = P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : 0;
     summary->termination_type = L.termination;
     summary->reason = L.reason;
     summary->num_successful_steps = L.num_successful;

@@ -389,6 +389,13 @@ int prepare(pgo_problem* P) {
   g.pairs_whole = pairs_whole ? 1 : 0;
   g.n_part = n_part; g.n_vec_wg = n_vec_wg; g.n_edge_wg = n_edge_wg; g.n_pose_wg = n_pose_wg;
   g.cg = P->d_cg.p; g.flags = P->d_flags.p;
+  g.oplog = nullptr; g.oplog_cap = 0;
+  if (getenv("PGO_UNI_OPLOG")) {
+    const size_t cap = (size_t)1 << 21;
+    HIP_TRY(P->d_oplog.alloc(cap));
+    HIP_TRY(hipMemsetAsync(P->d_oplog.p, 0, sizeof(long long), s));
+    g.oplog = P->d_oplog.p; g.oplog_cap = (int)cap;
+  }
   void* dscal = nullptr;
   HIP_TRY(hipHostGetDevicePointer(&dscal, P->scal, 0));
   g.scal = reinterpret_cast<pgo::LmScalars*>(dscal);

@@ -148,3 +148,19 @@ def test_stepping_in_pieces_equals_one_solve(gpu, ds, driver):
     last6 = s3.iterations[-6:]
     for f in ("cost", "step_is_successful", "linear_solver_iterations", "trust_region_radius"):
         assert np.array_equal(last6[f], whole.iterations[f][1:7]), f
+
+
+@pytest.mark.parametrize("period", [5, 3, 7])
+def test_allotted_sequences_with_an_odd_refresh_period(gpu, ds, period):
+    """a continuation sequence is enqueued as CG iterations 1, 2, ... and picks the ping-pong buffer of p
+    from that launch-time parity, so it may only take over after an EVEN number of completed iterations.  With an odd
+    cg_residual_reset_period the host-enqueued continuation used to end on an odd multiple of the period (period 5: 8 -> 35)
+    and the sequence behind it multiplied the wrong p.  Chain-like graph, 6x6 blocks: the early CG runs take > 40 iterations.
+    The allotted-sequence driver must reproduce the host-in-the-loop driver bit for bit."""
+    g = ds.manhattan_se3(1500, 1700, seed=23)
+    opt = dict(max_num_iterations=25, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=1,
+               cg_residual_reset_period=period)
+    b, pb = _solve(gpu, g, "host", **opt)
+    assert b.iterations["linear_solver_iterations"].max() > 40
+    a, pa = _solve(gpu, g, "seq", **opt)
+    _same(a, b, pa, pb)

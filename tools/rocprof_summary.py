@@ -1,18 +1,38 @@
 """Turns a rocprofv3 rocpd database (kernel trace) into the per-kernel summary kept under profiles/.
-usage: python tools/rocprof_summary.py gpurun_out/prof_r1/bench_results.db profiles/r01_bench_kernel_stats.csv"""
+usage: python tools/rocprof_summary.py <results.db> <out.csv> [<oplog.txt>]
+
+The universal stream runs ONE kernel symbol, k_uni_s, for four different jobs (CG product, tail product, refresh product,
+linearisation), chosen on the device at run time, so rocprofv3's per-symbol statistics mix them.  With PGO_UNI_OPLOG=<file> the
+library logs what every k_uni_s launch did ("<device tick> <op>" per launch, in launch order per problem); given that file, the
+dispatches of k_uni_s (ordered by start time) are matched one to one with the log entries (ordered by tick) and reported as
+separate rows  k_uni_s[cg] / [tail] / [refresh] / [linearize] / [nop]  next to the un-split row.  The counts must agree, or the
+split is refused."""
 import sqlite3
 import statistics
 import sys
 
+OPS = {0: "nop", 1: "cg", 2: "refresh", 3: "linearize", 4: "tail"}
 
-def main(db, out):
+
+def main(db, out, oplog=None):
     c = sqlite3.connect(db)
-    rows = c.execute("select name, duration, grid_x, workgroup_x, vgpr_count, sgpr_count, lds_size from kernels").fetchall()
+    rows = c.execute("select name, duration, grid_x, workgroup_x, vgpr_count, sgpr_count, lds_size, start from kernels order by start").fetchall()
     d = {}
-    for n, du, gx, wx, vg, sg, lds in rows:
+    for n, du, gx, wx, vg, sg, lds, st in rows:
         d.setdefault(n, []).append((du, gx, wx, vg, sg, lds))
-    total = sum(du for v in d.values() for du, *_ in v)
+    note = ""
+    if oplog:
+        log = sorted(tuple(int(x) for x in line.split()) for line in open(oplog) if line.strip())
+        uni = [(n, r) for n, *r in rows if n.startswith("k_uni_s") or "k_uni_s<" in n]
+        if len(log) != len(uni):
+            note = "# k_uni_s split REFUSED: %d dispatches in the trace, %d entries in the operation log\n" % (len(uni), len(log))
+        else:
+            for (n, r), (_, op) in zip(uni, log):
+                d.setdefault("%s[%s]" % (n, OPS.get(op, str(op))), []).append(tuple(r[:6]))
+            note = "# k_uni_s[...] rows: the %d dispatches of k_uni_s split by the operation each launch performed (PGO_UNI_OPLOG); they are also counted in the un-split k_uni_s row (pct of the split rows is relative to the same total)\n" % len(uni)
+    total = sum(du for n, v in d.items() if "[" not in n for du, *_ in v)
     with open(out, "w") as f:
+        f.write(note)
         f.write("kernel,calls,total_us,avg_us,median_us,min_us,max_us,pct,grid_x,workgroup_x,vgpr,sgpr,lds_bytes\n")
         for n, v in sorted(d.items(), key=lambda kv: -sum(x[0] for x in kv[1])):
             du = [x[0] / 1e3 for x in v]
@@ -23,4 +43,4 @@ def main(db, out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
