@@ -125,7 +125,14 @@ int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const do
     if (P->scal->linearize_bad) status = 2;
   } else {
     P->opt.cg_residual_reset_period = options->cg_residual_reset_period;   // launch_cg_batch reads the refresh period from P->opt
+    P->sym_active = false;
+    if (sym_wanted(P)) {               // large graph on one rank (or PGO_SYM=1): the CG products read the symmetric tile form
+      rc = sym_prepare(P);
+      if (rc) return rc;
+      P->sym_active = P->sym_ready;
+    }
     rc = run_pcg(P, cg_params_for(*options), options->cg_batch, &it, &status);
+    P->sym_active = false;
   }
   if (rc) return rc;
   HIP_TRY(staged_d2h(x, P->g.cg_x, m * sizeof(double), s));
@@ -167,11 +174,17 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
   }
   // "pcg_spmv" repeats the SpMV kernel of CG iteration 1 (the update kernel never runs, so the
   // iteration counter stays put); "pcg_update" likewise repeats the update of iteration 1.
-  if (k == "pcg_spmv" || k == "pcg_update" || k == "pcg_iteration") {
+  if (k == "sym_spmv" || k == "sym_repack" || k == "sym_plain") {
+    int rcs = sym_prepare(P);
+    if (rcs) return rcs;
+    if (!P->sym_ready) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): the graph does not fit the symmetric tile form", kernel);
+  }
+  if (k == "pcg_spmv" || k == "pcg_update" || k == "pcg_iteration" || k == "sym_spmv") {
     pgo::launch_damping(P->g, P->lm.radius, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, 0, s);
     pgo::launch_pcg_init(P->g, s);
   }
   if (k == "pcg_update") pgo::launch_pcg_spmv_only(P->g, prm, 1, s);
+  if (k == "sym_spmv" || k == "sym_plain") pgo::launch_sym_repack(P->g, P->sym, s);
   const bool wants_factor = k == "direct" || k == "front_factor" || k == "front_solve";
   if (wants_factor) {
     if (!P->direct_usable) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): no GPU factorisation prepared for this problem", kernel);
@@ -194,6 +207,9 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     else if (k == "spmv") pgo::launch_spmv_plain(P->g, s);
     else if (k == "pcg_spmv") pgo::launch_pcg_spmv_only(P->g, prm, 1, s);
     else if (k == "pcg_update") pgo::launch_pcg_update_only(P->g, 1, s);
+    else if (k == "sym_spmv") pgo::launch_spmv_sym(P->g, P->sym, prm, 1, 0, s);
+    else if (k == "sym_plain") pgo::launch_spmv_sym(P->g, P->sym, prm, 1, 1, s);
+    else if (k == "sym_repack") pgo::launch_sym_repack(P->g, P->sym, s);
     else if (k == "pcg_iteration") pgo::launch_pcg_iteration(P->g, prm, 1, s);
     else if (k == "empty") pgo::launch_debug(P->g, 0, s);
     else if (k == "touch") pgo::launch_debug(P->g, 1, s);

@@ -6,6 +6,7 @@
 #pragma once
 #include "../../include/pgo.h"
 #include "pgo_kernels.h"
+#include "pgo_sym.h"
 #include "pgo_lm_rules.h"
 #include "pgo_direct.h"
 #include "pgo_front.h"
@@ -407,6 +408,16 @@ struct pgo_problem {
   DevBuf<pgo::FrontDesc> df_fronts;
   DevBuf<pgo::FrontJob> df_jobs;
   DevBuf<double> df_Fval, df_Winv, df_x;
+  // symmetric tile form of the normal equations (pgo_sym.h): every interior off-diagonal block stored and read once by the CG
+  // products of large graphs on one rank (built at the start of such a solve; the incidence-slot arrays stay the system of record)
+  pgo::SymGraph sym{};
+  bool sym_built = false, sym_ready = false, sym_active = false;
+  double sym_interior_fraction = 0.0;
+  long long sym_stored_slots = 0;
+  DevBuf<pgo::SymTile> sy_tile;
+  DevBuf<int> sy_xlist, sy_chunk_base, sy_chunk_n, sy_src;
+  DevBuf<uint32_t> sy_meta, sy_rinfo;
+  DevBuf<double> sy_val;
   // cluster-Jacobi preconditioner topology (built when the option asks for clusters of 2 or 4 poses)
   DevBuf<int> d_cl_ptr, d_cl_slot;
   DevBuf<uint8_t> d_cl_rc;
@@ -456,6 +467,8 @@ int damping_all(pgo_problem* P, double radius, double min_diag, double max_diag,
 int cg_iteration(pgo_problem* P, const pgo::DeviceGraph& g, const pgo::CgParams& prm, int odd, bool refresh);
 int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd, bool refresh);
 int prepare(pgo_problem* P);
+bool sym_wanted(const pgo_problem* P);     // pgo_sym.cpp
+int sym_prepare(pgo_problem* P);
 int upload_poses(pgo_problem* P, double* dst);
 int download_poses(pgo_problem* P, const double* src);
 int fill_scale_one(pgo_problem* P);

@@ -160,7 +160,11 @@ int pcg_begin(pgo_problem* P, const pgo::CgParams& prm) {
   // preconditioners on different ranks and diverge silently — refuse instead
   if (P->g.world > 1 && P->lin_diag_only == 1 && !pipe_mode(P, prm))
     return set_error(PGO_ERR_INVALID_ARGUMENT, "internal: the linearisation exchanged only the diagonals of the other ranks' blocks but the replicated CG is about to run");
-  if (!pipe_mode(P, prm)) { pgo::launch_pcg_init(P->g, s); return PGO_OK; }
+  if (!pipe_mode(P, prm)) {
+    if (P->sym_active) pgo::launch_sym_repack(P->g, P->sym, s);    // the blocks of this linearisation + damping into the symmetric tile form
+    pgo::launch_pcg_init(P->g, s);
+    return PGO_OK;
+  }
   pgo::launch_pipe_init(P->g, s);
   int rc = exchange(P, P->g.pipe_buf[0], (size_t)P->g.pipe_seg);
   if (rc) return rc;

@@ -98,6 +98,13 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   P->pipelined = pipeline_wanted(P);
   P->universal = universal_wanted(P);
   P->pipe_dirty = true;
+  // symmetric tile form for the CG products: host-driven PCG of a large graph on one rank (pgo_sym.h)
+  P->sym_active = false;
+  if (P->opt.linear_solver_type == PGO_BLOCK_JACOBI_PCG && !P->universal && !P->pipelined && sym_wanted(P)) {
+    rc = sym_prepare(P);
+    if (rc) return rc;
+    P->sym_active = P->sym_ready;
+  }
   L.t_total += seconds_since(t0);
   if (!std::isfinite(L.x_cost)) {
     L.terminated = true; L.termination = PGO_FAILURE; L.reason = 7;

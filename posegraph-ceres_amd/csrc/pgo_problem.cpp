@@ -86,7 +86,8 @@ int damping_all(pgo_problem* P, double radius, double min_diag, double max_diag,
 // `refresh`: this is a residual_reset_period-th iteration — r is recomputed as b - A x (Ceres conjugate_gradients_solver.cc)
 // instead of updated: x-only update, A x into the exchange buffer, then r / z / partial sums.
 int cg_iteration(pgo_problem* P, const pgo::DeviceGraph& g, const pgo::CgParams& prm, int odd, bool refresh) {
-  pgo::launch_pcg_spmv_only(g, prm, odd, P->stream);
+  if (P->sym_active) pgo::launch_spmv_sym(g, P->sym, prm, odd, 0, P->stream);    // one rank, large graph: every interior block read once
+  else pgo::launch_pcg_spmv_only(g, prm, odd, P->stream);
   int rc = exchange(P, g.cg_q, (size_t)g.seg);
   if (rc) return rc;
   if (!refresh) {
@@ -228,6 +229,7 @@ int prepare(pgo_problem* P) {
   lap("rows -> workgroups, slots");
   P->h_slot_row = slot_row; P->h_slot_col = slot_col; P->h_slot_side = slot_side; P->h_row_slot_begin = row_slot_begin;
   P->direct_analyzed = false; P->direct_usable = false; P->front_usable = false; P->sfront_usable = false; P->cluster_built = 0; P->g.cluster = 1;
+  P->sym_built = false; P->sym_ready = false; P->sym_active = false;
   if (P->want_direct && !(getenv("PGO_NO_ANALYSIS_THREAD") && getenv("PGO_NO_ANALYSIS_THREAD")[0] == '1')) {
     // an exact request: its host analysis (ordering, symbolic factorisation, schedule) needs nothing but the slot topology
     const long long budget = front_memory_budget();

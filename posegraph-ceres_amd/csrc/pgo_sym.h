@@ -1,0 +1,63 @@
+// pgo_sym.h — "store every off-diagonal block once": the symmetric tile form of the block-sparse normal equations
+// (SURVEY.md §8d accounts K3 as (N + E) * 288 B per product: every off-diagonal 6x6 block counted ONCE; the incidence-slot BSR
+// of pgo_kernels.h stores and reads H_ab and H_ba = H_ab^T, 1.8x that traffic at 100 k poses / 1 M edges).
+//
+// Rows are partitioned into TILES of up to 256 poses with graph locality (natural order + greedy refinement, pgo_sym.cpp), one
+// work-group of 256 lanes per tile:
+//   * an edge whose two poses lie in the same tile (INTERIOR, 77 % of the edges of BASELINE config 4) keeps ONE block, H_ab in
+//     the begin-side orientation; the lane that loads it multiplies  u = H_ab x_b  for row a and  v = H_ab^T x_a  for row b;
+//   * a CUT edge keeps its two blocks, one in each tile (exactly the incidence-slot form);
+//   * x of the tile's rows and of its GHOST columns (the far ends of its cut edges) is staged in LDS once per product.
+// The stored slots of a tile are laid out row after row and processed in CHUNKS of 256 consecutive slots, one slot per lane (every
+// lane of a chunk but the last loads a block: the stream is as dense as the incidence-slot kernel's).  Products go to LDS — u at
+// the lane's own position, v at a position the producer knows, so that the entries of one destination row are contiguous — and
+// lane r, which keeps the sum of the tile's r-th row in registers across the chunks, adds its two ranges in a fixed order: bitwise
+// reproducible, no FP64 atomics, no index lookups inside the loop.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pgo_kernels.h"
+
+namespace pgo {
+
+enum { SYM_LANES = 256, SYM_X_MAX = 4095 };
+
+struct SymTile {
+  int chunk0;     // first entry of this tile in the chunk tables
+  int nchunks;
+  int x0;         // first entry of this tile in xlist
+  int nx;         // rows + ghosts staged in LDS
+  int nrows;      // the first nrows entries of the tile's xlist are its own rows (row r <-> lane r)
+  int base0, n0;  // chunk_base / chunk_n of the tile's first two chunks: their block loads start as soon as the descriptor is in
+  int base1, n1;
+  int pad[3];
+};
+
+// per stored slot (index = chunk_base[chunk] + lane):
+//   meta = xcol | side << 12 | interior << 14 | vpos << 15 | xrow << 23
+//   xcol: LDS index of the column's x (rows first, then ghosts); xrow: LDS index (= local row) of the slot's own row;
+//   vpos: where an interior slot's v goes in the chunk's v buffer
+// per (chunk, lane r):  rinfo = ub | uc << 8 | vb << 17 | vc << 25 — the u entries [ub, ub + uc) and the v entries [vb, vb + vc) of
+//   the chunk that belong to the tile's r-th row (uc <= 256, vc <= 127: a graph that needs more keeps the incidence-slot kernels)
+struct SymGraph {
+  int n_tiles, n_chunks, n_slots;     // n_slots: stored slots incl. alignment padding (multiple of 64)
+  int x_cap;                          // max over tiles of rows + ghosts (LDS sizing)
+  const SymTile* tile;                // [n_tiles]
+  const int* xlist;                   // pose id per staged x entry
+  const int* chunk_base;              // [n_chunks] first stored slot of the chunk (multiple of 64)
+  const int* chunk_n;                 // [n_chunks] active lanes
+  const uint32_t* meta;               // [n_slots]
+  const uint32_t* rinfo;              // [n_chunks * SYM_LANES]
+  const int* src_slot;                // [n_slots] slot of the incidence-slot BSR that holds the same block (-1: padding)
+  double* val;                        // [n_slots * 36] blocks, bsr_index() layout
+};
+
+// q = A p of a CG iteration (MODE 0: prologue, x = z + beta p, p_new, p'q partials — exactly k_spmv<0>'s contract) or plain
+// q = A cg_x (MODE 1) from the symmetric tile form
+void launch_spmv_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p, int odd, int mode, hipStream_t s);
+// copies the blocks of the incidence-slot BSR (g.bsr_val) into the symmetric tile form (after a linearisation / damping)
+void launch_sym_repack(const DeviceGraph& g, const SymGraph& sg, hipStream_t s);
+size_t sym_lds_bytes(const SymGraph& sg);
+
+}  // namespace pgo

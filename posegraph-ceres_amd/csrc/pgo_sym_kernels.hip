@@ -1,0 +1,354 @@
+// pgo_sym_kernels.hip — block SpMV from the symmetric tile form (pgo_sym.h): every interior off-diagonal block is read once and
+// used for both of its rows.  gfx950, FP64, HBM-bound: the only streams are the blocks (14 or 18 x 16 B per lane, 1 KiB per wave
+// instruction, prefetched one chunk ahead) and 4 + 2 bytes of indices per slot; the vectors live in LDS.
+#include "pgo_sym.h"
+#include "pgo_wave.h"
+
+namespace pgo {
+
+namespace {
+
+constexpr int VSTRIDE = 7;     // doubles per 6-vector in the LDS exchange buffers (odd: conflict-free 8-byte accesses)
+
+// y = H x for a slot of side BEGIN / END / DIAG (packed: TL = el[0..8], BR = el[9..17], Q = el[18..26] — bottom-left for BEGIN and
+// DIAG, top-right for END; the expressions are k_spmv's, so a cut slot rounds exactly as there)
+template <bool PACKED, int NPAIR>
+__device__ __forceinline__ void blk_mul(const double2 (&blk)[NPAIR], int side, const double (&x)[6], double (&y)[6]) {
+  if (PACKED) {
+    double el[28];
+#pragma unroll
+    for (int k = 0; k < BLK_PAIRS_PACKED; ++k) { el[2 * k] = blk[k].x; el[2 * k + 1] = blk[k].y; }
+    const bool is_end = side == SIDE_END, is_diag = side == SIDE_DIAG;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double a3 = is_end ? el[18 + 3 * i] : is_diag ? el[18 + i] : 0.0;
+      const double a4 = is_end ? el[18 + 3 * i + 1] : is_diag ? el[21 + i] : 0.0;
+      const double a5 = is_end ? el[18 + 3 * i + 2] : is_diag ? el[24 + i] : 0.0;
+      y[i] = el[3 * i] * x[0] + el[3 * i + 1] * x[1] + el[3 * i + 2] * x[2] + a3 * x[3] + a4 * x[4] + a5 * x[5];
+      const double b0 = is_end ? 0.0 : el[18 + 3 * i], b1 = is_end ? 0.0 : el[18 + 3 * i + 1], b2 = is_end ? 0.0 : el[18 + 3 * i + 2];
+      y[3 + i] = b0 * x[0] + b1 * x[1] + b2 * x[2] + el[9 + 3 * i] * x[3] + el[9 + 3 * i + 1] * x[4] + el[9 + 3 * i + 2] * x[5];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      y[i] = blk[3 * i].x * x[0] + blk[3 * i].y * x[1] + blk[3 * i + 1].x * x[2] + blk[3 * i + 1].y * x[3] +
+             blk[3 * i + 2].x * x[4] + blk[3 * i + 2].y * x[5];
+  }
+}
+// v = H^T x for an interior slot (always stored in the BEGIN orientation: packed H = [[TL, 0], [Q, BR]])
+template <bool PACKED, int NPAIR>
+__device__ __forceinline__ void blk_mul_t(const double2 (&blk)[NPAIR], const double (&x)[6], double (&v)[6]) {
+  if (PACKED) {
+    double el[28];
+#pragma unroll
+    for (int k = 0; k < BLK_PAIRS_PACKED; ++k) { el[2 * k] = blk[k].x; el[2 * k + 1] = blk[k].y; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      v[j] = el[j] * x[0] + el[3 + j] * x[1] + el[6 + j] * x[2] + el[18 + j] * x[3] + el[21 + j] * x[4] + el[24 + j] * x[5];
+      v[3 + j] = el[9 + j] * x[3] + el[12 + j] * x[4] + el[15 + j] * x[5];
+    }
+  } else {
+    double el[36];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) { el[2 * k] = blk[k].x; el[2 * k + 1] = blk[k].y; }
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      v[j] = el[j] * x[0] + el[6 + j] * x[1] + el[12 + j] * x[2] + el[18 + j] * x[3] + el[24 + j] * x[4] + el[30 + j] * x[5];
+  }
+}
+
+// Segmented inclusive scan of six doubles over the wave; segments = runs of equal `row` (contiguous by construction).  Inside the
+// 16-lane DPP rows: row_shr 1 / 2 / 4 / 8 (pure VALU, no LDS); then the three carries across the 16-lane rows, one after the other,
+// through v_readlane (a lane takes the carry iff its run reaches back to its row-of-16's first lane AND that lane continues the
+// previous row-of-16's last run).  A fixed tree: the same bits on every run.
+template <int D>
+__device__ __forceinline__ double dpp_row_shr_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + D, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + D, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int D>
+__device__ __forceinline__ void seg_scan_step(double (&u)[6], int row, int lane) {
+  const int rd = __builtin_amdgcn_update_dpp(0, row, 0x110 + D, 0xf, 0xf, true);
+  const bool same = (lane & 15) >= D && rd == row;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double t = dpp_row_shr_f64<D>(u[k]);
+    u[k] += same ? t : 0.0;
+  }
+}
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+__device__ __forceinline__ void seg_scan6(double (&u)[6], int row, int lane) {
+  seg_scan_step<1>(u, row, lane);
+  seg_scan_step<2>(u, row, lane);
+  seg_scan_step<4>(u, row, lane);
+  seg_scan_step<8>(u, row, lane);
+#pragma unroll
+  for (int b = 1; b < 4; ++b) {
+    const int r_prev = __builtin_amdgcn_readlane(row, 16 * b - 1), r_first = __builtin_amdgcn_readlane(row, 16 * b);
+    const bool take = (lane >> 4) == b && r_prev == r_first && row == r_first;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double carry = readlane_f64(u[k], 16 * b - 1);
+      u[k] += take ? carry : 0.0;
+    }
+  }
+}
+
+// One work-group per tile.  MODE 0: the SpMV of a CG iteration with k_spmv<0>'s contract (stop test of the previous iteration and
+// beta from the partial rows, x = z + beta p_old, p_new written for the tile's rows, q = A x into cg_q, partial p'q, CG state
+// published by work-group 0).  MODE 1: q = A cg_x.
+template <int MODE, bool PACKED>
+__global__ __launch_bounds__(SYM_LANES) void k_spmv_sym(DeviceGraph g, SymGraph sg, CgParams prm, int odd) {
+  constexpr int NPAIR = PACKED ? BLK_PAIRS_PACKED : BLK_PAIRS_FULL;
+  extern __shared__ double lds[];          // xs[6 * x_cap] | ubuf[SYM_LANES * VSTRIDE] | vbuf[SYM_LANES * VSTRIDE]
+  __shared__ double scratch[32];
+  const int tid = threadIdx.x, tile = blockIdx.x, lane = threadIdx.x & 63;
+  double* xs = lds;
+  double* ubuf = lds + (size_t)sg.x_cap * 6;
+  double* vbuf = ubuf + SYM_LANES * VSTRIDE;
+
+  // ---- loads that depend on nothing: the tile and its first two chunks (the chunk loop keeps two chunks of blocks in flight) ----
+  const SymTile T = sg.tile[tile];
+  const int nch = T.nchunks;
+  struct Chunk { double2 b[NPAIR]; uint32_t meta, rin; int n; };
+  auto load_blocks = [&](Chunk& C, int ci, int base, int n) {
+    C.n = n;
+    C.rin = sg.rinfo[(size_t)ci * SYM_LANES + tid];
+    C.meta = 0;
+    if (tid < n) {
+      const int t = base + tid;
+      C.meta = sg.meta[t];
+      const double2* bp = reinterpret_cast<const double2*>(sg.val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+#pragma unroll
+      for (int k = 0; k < NPAIR; ++k) C.b[k] = bp[(size_t)k * 64];
+    }
+  };
+  auto load_chunk = [&](Chunk& C, int c) { const int ci = T.chunk0 + c; load_blocks(C, ci, sg.chunk_base[ci], sg.chunk_n[ci]); };
+  Chunk CA, CB, CC;
+  load_blocks(CA, T.chunk0, T.base0, T.n0);
+  if (nch > 1) load_blocks(CB, T.chunk0 + 1, T.base1, T.n1);
+  // x staging, first half (independent of beta): z (MODE 1: x itself) of every staged column into xs, p_old into the exchange
+  // buffers' space as far as it reaches (597 columns; they are not needed before the chunk loop) — so that these gathers are in
+  // flight together with the first blocks and the partial rows of the prologue
+  double* ps = ubuf;
+  constexpr int PS_CAP = 2 * SYM_LANES * VSTRIDE / 6;
+  const double* p_old = odd ? g.cg_p0 : g.cg_p1;
+  for (int i = tid; i < T.nx * 3; i += SYM_LANES) {
+    const int e = i / 3, k = i - 3 * e;
+    const int pose = sg.xlist[T.x0 + e];
+    const double2 z = reinterpret_cast<const double2*>((MODE == 0 ? g.cg_z : g.cg_x) + 6 * (size_t)pose)[k];
+    xs[6 * e + 2 * k] = z.x;
+    xs[6 * e + 2 * k + 1] = z.y;
+    if (MODE == 0 && e < PS_CAP) {
+      const double2 p = reinterpret_cast<const double2*>(p_old + 6 * (size_t)pose)[k];
+      ps[6 * e + 2 * k] = p.x;
+      ps[6 * e + 2 * k + 1] = p.y;
+    }
+  }
+
+  // ---- CG prologue (k_spmv<0>): every work-group re-derives rho, beta and the stop test from the same partial rows ----
+  double beta = 0.0, rho_pub = 0.0, q_pub = 0.0;
+  int it = 1;
+  if (MODE == 0) {
+    const int done = g.cg->done, cnt_b = g.cg->cnt_b;
+    const double* rz_cur = g.part_rz + (size_t)(odd ? 0 : g.n_part);
+    const double* q_cur = g.part_q + (size_t)(odd ? 0 : g.n_part);
+    const double* rr_cur = g.part_rr + (size_t)(odd ? 0 : g.n_part);
+    const double hist_rho = g.cg->rho_hist[odd ? 0 : 1], hist_q = g.cg->q_hist[odd ? 0 : 1];
+    const bool need_rr = prm.r_tolerance >= 0.0;
+    double sums[6] = {0, 0, 0, 0, 0, 0};
+    if (need_rr) {
+      for (int i = tid; i < g.n_vec_wg; i += SYM_LANES) { sums[0] += rz_cur[i]; sums[2] += q_cur[i]; sums[4] += rr_cur[i]; sums[5] += g.part_bb[i]; }
+    } else {
+      for (int i = tid & 63; i < g.n_vec_wg; i += 64) { sums[0] += rz_cur[i]; sums[2] += q_cur[i]; }
+    }
+    if (done) return;
+    it = cnt_b + 1;
+    double rr = 0.0, bb = 0.0;
+    if (need_rr) { block_sum<6>(sums, scratch); rr = sums[4]; bb = sums[5]; }
+    else { sums[0] = wave_sum(sums[0]); sums[2] = wave_sum(sums[2]); }
+    const double rho = sums[0], Q1 = -sums[2];
+    rho_pub = rho;
+    q_pub = Q1;
+    int stop = 0, status = 0;
+    if (it > 1) {
+      const int done_it = it - 1;
+      const double zeta = done_it * (Q1 - hist_q) / Q1;
+      if (zeta < prm.q_tolerance && done_it >= prm.min_iterations) stop = 1;
+      if (need_rr && sqrt(rr) <= prm.r_tolerance * sqrt(bb) && done_it >= prm.min_iterations) stop = 1;
+      if (done_it >= prm.max_iterations) stop = 1;
+    }
+    if (!stop && (rho == 0.0 || !isfinite(rho))) { stop = 1; status = (rho == 0.0) ? 0 : 2; }
+    if (!stop && it > 1) {
+      beta = rho / hist_rho;
+      if (beta == 0.0 || !isfinite(beta)) { stop = 1; status = 2; }
+    }
+    if (stop) {
+      if (tile == 0 && tid == 0) { g.cg->iters = it - 1; g.cg->status = status; g.cg->done = 1; }
+      return;
+    }
+  }
+
+  // ---- x staging, second half: x = z + beta p_old (every lane combines the entries it staged itself: no barrier in between),
+  // which is also p_new of the tile's rows ----
+  if (MODE == 0) {
+    double* p_new = odd ? g.cg_p1 : g.cg_p0;
+    for (int i = tid; i < T.nx * 3; i += SYM_LANES) {
+      const int e = i / 3, k = i - 3 * e;
+      double2 p;
+      if (e < PS_CAP) p = double2{ps[6 * e + 2 * k], ps[6 * e + 2 * k + 1]};
+      else p = reinterpret_cast<const double2*>(p_old + 6 * (size_t)sg.xlist[T.x0 + e])[k];
+      const double2 v{xs[6 * e + 2 * k] + beta * p.x, xs[6 * e + 2 * k + 1] + beta * p.y};
+      xs[6 * e + 2 * k] = v.x;
+      xs[6 * e + 2 * k + 1] = v.y;
+      if (e < T.nrows) reinterpret_cast<double2*>(p_new + 6 * (size_t)sg.xlist[T.x0 + e])[k] = v;
+    }
+  }
+  __syncthreads();
+
+  double y[6] = {0, 0, 0, 0, 0, 0};       // row `tid` of the tile
+  auto process = [&](const Chunk& C) {
+    // u = H x of this lane's slot (0 for the idle lanes of a tile's last chunk), v = H^T x_row of an interior slot
+    double u[6] = {0, 0, 0, 0, 0, 0};
+    int row = -1 - lane;                     // idle lanes: a row id nobody shares
+    if (tid < C.n) {
+      const int xcol = (int)(C.meta & 0xFFFu), side = (int)((C.meta >> 12) & 3u);
+      row = (int)((C.meta >> 23) & 0xFFu);
+      double x[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) x[k] = xs[6 * xcol + k];
+      blk_mul<PACKED, NPAIR>(C.b, side, x, u);
+      if (C.meta & (1u << 14)) {
+        const int vpos = (int)((C.meta >> 15) & 0xFFu);
+        double xr[6], v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xr[k] = xs[6 * row + k];
+        blk_mul_t<PACKED, NPAIR>(C.b, xr, v);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vbuf[vpos * VSTRIDE + k] = v[k];
+      }
+    }
+    // The slots of a row sit in consecutive lanes: segmented inclusive scan inside the wave (fixed tree, deterministic), so that
+    // the LAST lane of every (row, wave) run holds the run's sum and only those lanes go through LDS — the row's lane then adds
+    // one entry per wave its slots span instead of one per slot.
+    if (!(g.debug & 512)) seg_scan6(u, row, lane);
+    {
+      const int rn = __shfl_down(row, 1, 64);
+      if (tid < C.n && (lane == 63 || rn != row)) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ubuf[tid * VSTRIDE + k] = u[k];
+      }
+    }
+    __syncthreads();
+    {
+      const int ub = (int)(C.rin & 0xFFu), uc = (int)((C.rin >> 8) & 0x1FFu), vb = (int)((C.rin >> 17) & 0xFFu), vc = (int)(C.rin >> 25);
+      if (uc > 0) {
+        const int last = ub + uc - 1;
+        for (int w = ub >> 6; w <= (last >> 6); ++w) {
+          const int tail = min(w * 64 + 63, last);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) y[k] += ubuf[tail * VSTRIDE + k];
+        }
+      }
+      for (int j = 0; j < vc; ++j) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) y[k] += vbuf[(vb + j) * VSTRIDE + k];
+      }
+    }
+    __syncthreads();
+  };
+  const int nrun = (g.debug & 256) ? 0 : nch;     // (development ablation)
+  for (int c = 0; c < nrun; c += 3) {
+    if (c + 2 < nch) load_chunk(CC, c + 2);
+    process(CA);
+    if (c + 1 < nch) {
+      if (c + 3 < nch) load_chunk(CA, c + 3);
+      process(CB);
+    }
+    if (c + 2 < nch) {
+      if (c + 4 < nch) load_chunk(CB, c + 4);
+      process(CC);
+    }
+  }
+
+  double pq[1] = {0.0};
+  if (tid < T.nrows) {
+    const int pose = sg.xlist[T.x0 + tid];
+    double2* q = reinterpret_cast<double2*>(g.cg_q + 6 * (size_t)pose);      // one rank: q_index(row, k) = 6 row + k
+    q[0] = double2{y[0], y[1]};
+    q[1] = double2{y[2], y[3]};
+    q[2] = double2{y[4], y[5]};
+    if (MODE == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pq[0] += y[k] * xs[6 * tid + k];
+    }
+  }
+  if (MODE == 0) {
+    block_sum<1>(pq, scratch);
+    if (tid == 0) {
+      double* pqp = g.cg_q + (size_t)g.rows_per * 6;
+      pqp[tile] = pq[0];
+      for (int i = tile + sg.n_tiles; i < g.pq_cap; i += sg.n_tiles) pqp[i] = 0.0;   // the update kernel folds pq_cap partials
+      if (tile == 0) {
+        g.cg->cnt_a = it; g.cg->beta = beta; g.cg->rho = rho_pub;
+        g.cg->rho_hist[odd ? 1 : 0] = rho_pub;
+        g.cg->q_hist[odd ? 1 : 0] = q_pub;
+      }
+    }
+  }
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_sym_repack(DeviceGraph g, SymGraph sg) {
+  constexpr int NPAIR = PACKED ? BLK_PAIRS_PACKED : BLK_PAIRS_FULL;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= sg.n_slots) return;
+  const int src = sg.src_slot[t];
+  if (src < 0) return;
+  const double2* sp = reinterpret_cast<const double2*>(g.bsr_val + (size_t)(src >> 6) * TILE_DOUBLES + (size_t)(src & 63) * 2);
+  double2* dp = reinterpret_cast<double2*>(sg.val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+  double2 b[NPAIR];
+#pragma unroll
+  for (int k = 0; k < NPAIR; ++k) b[k] = sp[(size_t)k * 64];
+#pragma unroll
+  for (int k = 0; k < NPAIR; ++k) dp[(size_t)k * 64] = b[k];
+}
+
+}  // namespace
+
+size_t sym_lds_bytes(const SymGraph& sg) {
+  return ((size_t)sg.x_cap * 6 + 2 * SYM_LANES * VSTRIDE) * sizeof(double);
+}
+
+void launch_spmv_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p, int odd, int mode, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {     // more than the default 64 KiB of dynamic LDS for tiles with many ghost columns (gfx950: 160 KiB per CU)
+    const int cap = 160 * 1024 - 512;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_sym<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_sym<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_sym<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_sym<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    attr_set = true;
+  }
+  const size_t lds = sym_lds_bytes(sg);
+  const dim3 grid(sg.n_tiles), block(SYM_LANES);
+  if (mode == 0) {
+    if (g.blk_packed) hipLaunchKernelGGL((k_spmv_sym<0, true>), grid, block, lds, s, g, sg, p, odd);
+    else hipLaunchKernelGGL((k_spmv_sym<0, false>), grid, block, lds, s, g, sg, p, odd);
+  } else {
+    if (g.blk_packed) hipLaunchKernelGGL((k_spmv_sym<1, true>), grid, block, lds, s, g, sg, p, odd);
+    else hipLaunchKernelGGL((k_spmv_sym<1, false>), grid, block, lds, s, g, sg, p, odd);
+  }
+}
+
+void launch_sym_repack(const DeviceGraph& g, const SymGraph& sg, hipStream_t s) {
+  const dim3 grid((sg.n_slots + 255) / 256), block(256);
+  if (g.blk_packed) hipLaunchKernelGGL(k_sym_repack<true>, grid, block, 0, s, g, sg);
+  else hipLaunchKernelGGL(k_sym_repack<false>, grid, block, 0, s, g, sg);
+}
+
+}  // namespace pgo
