@@ -415,7 +415,8 @@ struct pgo_problem {
   double sym_interior_fraction = 0.0;
   long long sym_stored_slots = 0;
   DevBuf<pgo::SymTile> sy_tile;
-  DevBuf<int> sy_xlist, sy_chunk_base, sy_chunk_n, sy_src;
+  DevBuf<int> sy_xlist, sy_chunk_base, sy_chunk_n, sy_src, sy_diag;
+  bool sym_stale = true;            // the off-diagonal blocks were rewritten since the last repack (else only the damped diagonal slots are copied)
   DevBuf<uint32_t> sy_meta, sy_rinfo;
   DevBuf<double> sy_val;
   // cluster-Jacobi preconditioner topology (built when the option asks for clusters of 2 or 4 poses)

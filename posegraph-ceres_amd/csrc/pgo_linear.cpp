@@ -161,7 +161,10 @@ int pcg_begin(pgo_problem* P, const pgo::CgParams& prm) {
   if (P->g.world > 1 && P->lin_diag_only == 1 && !pipe_mode(P, prm))
     return set_error(PGO_ERR_INVALID_ARGUMENT, "internal: the linearisation exchanged only the diagonals of the other ranks' blocks but the replicated CG is about to run");
   if (!pipe_mode(P, prm)) {
-    if (P->sym_active) pgo::launch_sym_repack(P->g, P->sym, s);    // the blocks of this linearisation + damping into the symmetric tile form
+    if (P->sym_active) {     // the blocks of this linearisation + damping into the symmetric tile form (a rejected step: the damped diagonal slots only)
+      pgo::launch_sym_repack(P->g, P->sym, s, P->sym_stale ? 0 : 1);
+      P->sym_stale = false;
+    }
     pgo::launch_pcg_init(P->g, s);
     return PGO_OK;
   }

@@ -368,6 +368,7 @@ int lm_advance(pgo_problem* P) {
   if (action == STEP_ACCEPT) {
     // HandleSuccessfulStep (device half): x <- candidate, re-linearise
     std::swap(P->g.pose_x, P->g.pose_c);
+    P->sym_stale = true;
     if (spec_in_flight) {   // the candidate was linearised behind the tail: its set becomes the current one
       const SpareSet sp = spare_set(P);
       P->g.bsr_val = sp.bsr; P->g.Hdiag = sp.Hdiag; P->g.grad = sp.grad;

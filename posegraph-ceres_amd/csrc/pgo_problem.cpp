@@ -61,6 +61,7 @@ int exchange(pgo_problem* P, double* buf, size_t seg_doubles) {
 // diagonal blocks then — 6 doubles per pose travel instead of 36 (28.8 -> 4.8 MB per accepted step at 100 k poses)
 int linearize_all(pgo_problem* P, bool diag_only) {
   pgo::launch_linearize(P->g, P->stream);
+  P->sym_stale = true;
   int rc;
   if (diag_only && P->comm && P->comm->world > 1 && P->d_pipe_x.p) {
     pgo::launch_hdiag6(P->g, P->d_pipe_x.p, 0, P->stream);

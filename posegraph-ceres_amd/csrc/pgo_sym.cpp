@@ -117,7 +117,7 @@ int sym_prepare(pgo_problem* P) {
     for (int e = 0; e < E; ++e) { inc[f[P->ia[e]]++] = 2 * e; inc[f[P->ib[e]]++] = 2 * e + 1; } }
 
   std::vector<pgo::SymTile> tiles(T);
-  std::vector<int> xlist, chunk_base, chunk_n, src_slot;
+  std::vector<int> xlist, chunk_base, chunk_n, src_slot, diag_slot(N, 0);
   std::vector<uint32_t> meta, rinfo;
   std::vector<int> local(N, -1);             // pose -> LDS index inside the tile being built
   int x_cap = 0;
@@ -189,6 +189,7 @@ int sym_prepare(pgo_problem* P) {
         const Slot& sl = slots[lo + l];
         src_slot[base + l] = sl.src;
         meta[base + l] = sl.m;
+        if (((sl.m >> 12) & 3u) == (uint32_t)pgo::SIDE_DIAG) diag_slot[rows[sl.row]] = base + l;
         uint32_t& w = rinfo[ri0 + sl.row];           // u range of the slot's row: [ub, ub + uc)
         if (((w >> 8) & 0x1FFu) == 0) w = (w & ~0xFFu) | (uint32_t)l;
         w += 1u << 8;
@@ -220,14 +221,16 @@ int sym_prepare(pgo_problem* P) {
   HIP_TRY(P->sy_meta.upload(meta, s));
   HIP_TRY(P->sy_rinfo.upload(rinfo, s));
   HIP_TRY(P->sy_src.upload(src_slot, s));
+  HIP_TRY(P->sy_diag.upload(diag_slot, s));
   HIP_TRY(P->sy_val.alloc((size_t)n_slots * 36));
   HIP_TRY(P->sy_val.zero(s));
   pgo::SymGraph& sg = P->sym;
   sg.n_tiles = T; sg.n_chunks = (int)chunk_base.size(); sg.n_slots = n_slots; sg.x_cap = x_cap;
   sg.tile = P->sy_tile.p; sg.xlist = P->sy_xlist.p; sg.chunk_base = P->sy_chunk_base.p; sg.chunk_n = P->sy_chunk_n.p;
-  sg.meta = P->sy_meta.p; sg.rinfo = P->sy_rinfo.p; sg.src_slot = P->sy_src.p; sg.val = P->sy_val.p;
+  sg.meta = P->sy_meta.p; sg.rinfo = P->sy_rinfo.p; sg.src_slot = P->sy_src.p; sg.diag_slot = P->sy_diag.p; sg.val = P->sy_val.p;
   HIP_TRY(hipStreamSynchronize(s));
   P->sym_ready = true;
+  P->sym_stale = true;
   P->sym_interior_fraction = E ? (double)interior_edges / E : 0.0;
   P->sym_stored_slots = stored;
   if (getenv("PGO_VERBOSE"))

@@ -50,6 +50,7 @@ struct SymGraph {
   const uint32_t* meta;               // [n_slots]
   const uint32_t* rinfo;              // [n_chunks * SYM_LANES]
   const int* src_slot;                // [n_slots] slot of the incidence-slot BSR that holds the same block (-1: padding)
+  const int* diag_slot;               // [N] stored slot of every row's diagonal block
   double* val;                        // [n_slots * 36] blocks, bsr_index() layout
 };
 
@@ -57,7 +58,8 @@ struct SymGraph {
 // q = A cg_x (MODE 1) from the symmetric tile form
 void launch_spmv_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p, int odd, int mode, hipStream_t s);
 // copies the blocks of the incidence-slot BSR (g.bsr_val) into the symmetric tile form (after a linearisation / damping)
-void launch_sym_repack(const DeviceGraph& g, const SymGraph& sg, hipStream_t s);
+// diag_only: a rejected LM step changed nothing but the damping, i.e. the diagonal slots
+void launch_sym_repack(const DeviceGraph& g, const SymGraph& sg, hipStream_t s, int diag_only = 0);
 size_t sym_lds_bytes(const SymGraph& sg);
 
 }  // namespace pgo

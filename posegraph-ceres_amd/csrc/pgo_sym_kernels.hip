@@ -318,6 +318,18 @@ __global__ __launch_bounds__(256) void k_sym_repack(DeviceGraph g, SymGraph sg) 
   for (int k = 0; k < NPAIR; ++k) dp[(size_t)k * 64] = b[k];
 }
 
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_sym_repack_diag(DeviceGraph g, SymGraph sg) {
+  constexpr int NPAIR = PACKED ? BLK_PAIRS_PACKED : BLK_PAIRS_FULL;
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= g.N) return;
+  const int src = g.row_slot_begin[v], t = sg.diag_slot[v];
+  const double2* sp = reinterpret_cast<const double2*>(g.bsr_val + (size_t)(src >> 6) * TILE_DOUBLES + (size_t)(src & 63) * 2);
+  double2* dp = reinterpret_cast<double2*>(sg.val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+#pragma unroll
+  for (int k = 0; k < NPAIR; ++k) dp[(size_t)k * 64] = sp[(size_t)k * 64];
+}
+
 }  // namespace
 
 size_t sym_lds_bytes(const SymGraph& sg) {
@@ -345,7 +357,13 @@ void launch_spmv_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p
   }
 }
 
-void launch_sym_repack(const DeviceGraph& g, const SymGraph& sg, hipStream_t s) {
+void launch_sym_repack(const DeviceGraph& g, const SymGraph& sg, hipStream_t s, int diag_only) {
+  if (diag_only) {
+    const dim3 grid((g.N + 255) / 256), block(256);
+    if (g.blk_packed) hipLaunchKernelGGL(k_sym_repack_diag<true>, grid, block, 0, s, g, sg);
+    else hipLaunchKernelGGL(k_sym_repack_diag<false>, grid, block, 0, s, g, sg);
+    return;
+  }
   const dim3 grid((sg.n_slots + 255) / 256), block(256);
   if (g.blk_packed) hipLaunchKernelGGL(k_sym_repack<true>, grid, block, 0, s, g, sg);
   else hipLaunchKernelGGL(k_sym_repack<false>, grid, block, 0, s, g, sg);
