@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--cluster", type=int, default=2, help="poses per Jacobi block of the PCG preconditioner (1, 2 or 4)")
     ap.add_argument("--prewarm", type=float, default=0.75, help="seconds of untimed LM steps before the timed region (device clocks)")
     ap.add_argument("--repeats", type=int, default=5, help="the timed region (exactly K steps each) is repeated; the median is the headline")
+    ap.add_argument("--no-quality", action="store_true", help="skip the solution-quality block (C2 solved to convergence by the exact path and by PCG with tight forcing terms)")
     ap.add_argument("--no-exact-blocks", action="store_true", help="skip the exact-solver blocks (KITTI-00 replay / dense, C2 and C5 factorisation)")
     args = ap.parse_args()
 
@@ -364,6 +365,40 @@ def main():
         extra["jacobi_6x6_blocks"] = {"value": round(E * args.steps / dt6, 1), "unit": "edge-LM-iterations/s",
                                       "ms_per_step": round(dt6 / args.steps * 1e3, 4), "final_cost": s6.final_cost,
                                       "cg_iterations": s6.num_linear_solver_iterations}
+
+    # ---- solution quality of the PCG policy against the exact-step path (the reference solves exactly: finial.cpp:534-536) ----
+    # The timed steps above use Ceres' default forcing term eta = 0.1 (cheap truncated steps).  Run to ITS OWN stop that policy ends
+    # 11 % above the cost the exact path reaches on this graph (a different basin, > 100 m away); with a tight forcing term the
+    # same PCG path ends at the exact path's cost, sooner than the factorisation gets there.  Whole solves through pgo_solve.
+    if rank == 0 and world == 1 and not sharded and not args.no_quality and (args.poses, args.edges) == (N_POSES, N_EDGES):
+        def _whole(**kw):
+            pq, poses_q = pkg.problem_from_graph(g)
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            sq = pkg.solve(pkg.SolverOptions(**kw), pq)
+            return sq, poses_q, time.perf_counter() - tq
+
+        def _time_to(sq, target):
+            c = sq.iterations["cost"]
+            hit = np.nonzero(c <= target)[0]
+            return None if len(hit) == 0 else round(sq.total_time_in_seconds * hit[0] / max(1, len(c) - 1), 4)
+
+        s_ex, p_ex, w_ex = _whole(max_num_iterations=1000, linear_solver_type=pkg.SPARSE_NORMAL_CHOLESKY)
+        target = s_ex.final_cost * (1.0 + 1e-3)
+        q = {"graph": "the timed graph (C2), from dead reckoning, every path to its own stop (function tolerance 1e-6)",
+             "final_cost_exact": s_ex.final_cost, "exact_lm_iterations": s_ex.num_iterations, "exact_wall_seconds": round(w_ex, 4),
+             "target": "exact final cost x (1 + 1e-3)", "exact_seconds_to_target": _time_to(s_ex, target), "pcg": {}}
+        for eta in (0.1, 1e-4, 1e-5):
+            s_pc, p_pc, w_pc = _whole(max_num_iterations=3000, linear_solver_type=pkg.BLOCK_JACOBI_PCG, pcg_cluster_poses=args.cluster,
+                                      eta=eta, max_linear_solver_iterations=3000)
+            q["pcg"]["eta_%g" % eta] = {
+                "final_cost_at_own_stop": s_pc.final_cost, "relative_to_exact": round(s_pc.final_cost / s_ex.final_cost - 1.0, 6),
+                "lm_iterations": s_pc.num_iterations, "cg_iterations": s_pc.num_linear_solver_iterations, "wall_seconds": round(w_pc, 4),
+                "seconds_to_target": _time_to(s_pc, target),
+                "max_translation_distance_to_exact_solution_m": round(float(np.linalg.norm(p_pc[:, :3] - p_ex[:, :3], axis=1).max()), 3)}
+        q["note"] = ("eta = 0.1 is Ceres' default and what the headline steps use; the exact path's own final cost moves by 3e-3 between "
+                     "the GPU and the oracle on this graph (tests/test_gpu_front.py), so distances between equal-cost solutions are not errors")
+        extra["c2_solution_quality"] = q
 
     # ---- kernel rooflines at C4 size (at <= 25 k poses the kernels are latency-bound, "quote HBM fraction
     # only for C4"): same kernels, 100 k poses / 1 M edges on this one GPU, outside the timed region ----
