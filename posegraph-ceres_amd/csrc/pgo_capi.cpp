@@ -125,7 +125,7 @@ int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const do
     if (P->scal->linearize_bad) status = 2;
   } else {
     P->opt.cg_residual_reset_period = options->cg_residual_reset_period;   // launch_cg_batch reads the refresh period from P->opt
-    P->sym_active = false;
+    P->sym_active = false; P->sym_storage = false;
     if (sym_wanted(P)) {               // large graph on one rank (or PGO_SYM=1): the CG products read the symmetric tile form
       rc = sym_prepare(P);
       if (rc) return rc;
@@ -174,10 +174,10 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
   }
   // "pcg_spmv" repeats the SpMV kernel of CG iteration 1 (the update kernel never runs, so the
   // iteration counter stays put); "pcg_update" likewise repeats the update of iteration 1.
-  if (k == "sym_spmv" || k == "sym_repack" || k == "sym_plain") {
+  if (k == "sym_spmv" || k == "sym_repack" || k == "sym_plain" || k == "sym_linearize") {
     int rcs = sym_prepare(P);
     if (rcs) return rcs;
-    if (!P->sym_ready) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): the graph does not fit the symmetric tile form", kernel);
+    if (!P->sym_ready || (k == "sym_linearize" && !P->sym_lin_fits)) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): the graph does not fit the symmetric tile form", kernel);
   }
   if (k == "pcg_spmv" || k == "pcg_update" || k == "pcg_iteration" || k == "sym_spmv") {
     pgo::launch_damping(P->g, P->lm.radius, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, 0, s);
@@ -210,6 +210,7 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     else if (k == "sym_spmv") pgo::launch_spmv_sym(P->g, P->sym, prm, 1, 0, s);
     else if (k == "sym_plain") pgo::launch_spmv_sym(P->g, P->sym, prm, 1, 1, s);
     else if (k == "sym_repack") pgo::launch_sym_repack(P->g, P->sym, s);
+    else if (k == "sym_linearize") pgo::launch_linearize_sym(P->g, P->sym, s);
     else if (k == "pcg_iteration") pgo::launch_pcg_iteration(P->g, prm, 1, s);
     else if (k == "empty") pgo::launch_debug(P->g, 0, s);
     else if (k == "touch") pgo::launch_debug(P->g, 1, s);

@@ -51,7 +51,8 @@ int enqueue_tail(pgo_problem* P, const pgo::CgParams* finish_prm) {
   }
   if (P->g.world == 1) {
     // two launches: q = A x + candidate poses (diagonal lanes), then model change / norms / candidate cost / fold
-    pgo::launch_spmv_tail(P->g, finish_prm ? *finish_prm : none, s, gate, 1);
+    if (P->sym_storage) pgo::launch_spmv_sym(P->g, P->sym, finish_prm ? *finish_prm : none, 1 | (gate ? 2 : 0) | 4, 1, s);
+    else pgo::launch_spmv_tail(P->g, finish_prm ? *finish_prm : none, s, gate, 1);
     pgo::launch_step_tail(P->g, s, gate);
     return PGO_OK;
   }
@@ -161,7 +162,7 @@ int pcg_begin(pgo_problem* P, const pgo::CgParams& prm) {
   if (P->g.world > 1 && P->lin_diag_only == 1 && !pipe_mode(P, prm))
     return set_error(PGO_ERR_INVALID_ARGUMENT, "internal: the linearisation exchanged only the diagonals of the other ranks' blocks but the replicated CG is about to run");
   if (!pipe_mode(P, prm)) {
-    if (P->sym_active) {     // the blocks of this linearisation + damping into the symmetric tile form (a rejected step: the damped diagonal slots only)
+    if (P->sym_active && !P->sym_storage) {     // the blocks of this linearisation + damping into the symmetric tile form (a rejected step: the damped diagonal slots only)
       pgo::launch_sym_repack(P->g, P->sym, s, P->sym_stale ? 0 : 1);
       P->sym_stale = false;
     }
@@ -221,6 +222,7 @@ int prepare_clusters(pgo_problem* P, int CL) {
     }
     HIP_TRY(P->d_cl_ptr.store(ptr, P->stream));
     HIP_TRY(P->d_cl_slot.store(slots, P->stream));
+    P->h_cl_slot = slots;
     HIP_TRY(P->d_cl_rc.store(rcs, P->stream));
     const size_t need = (size_t)P->g.world * P->g.rows_per * 36 * CL;   // every rank's clusters, padded
     if (P->d_Minv.n < need) { HIP_TRY(P->d_Minv.alloc(need)); HIP_TRY(P->d_Minv.zero(P->stream)); }

@@ -99,11 +99,13 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   P->universal = universal_wanted(P);
   P->pipe_dirty = true;
   // symmetric tile form for the CG products: host-driven PCG of a large graph on one rank (pgo_sym.h)
-  P->sym_active = false;
+  P->sym_active = false; P->sym_storage = false;
   if (P->opt.linear_solver_type == PGO_BLOCK_JACOBI_PCG && !P->universal && !P->pipelined && sym_wanted(P)) {
     rc = sym_prepare(P);
     if (rc) return rc;
     P->sym_active = P->sym_ready;
+    const char* rp = getenv("PGO_SYM_REPACK");        // (A/B: keep the incidence-slot linearisation and copy its blocks per LM iteration)
+    if (P->sym_active && P->sym_lin_fits && !(rp && rp[0] == '1')) { rc = sym_enter_storage(P); if (rc) return rc; }
   }
   L.t_total += seconds_since(t0);
   if (!std::isfinite(L.x_cost)) {
@@ -145,7 +147,7 @@ int ensure_spec_buffers(pgo_problem* P) {
 }
 bool speculation_on(const pgo_problem* P) {
   static const bool off = getenv("PGO_NO_SPECULATION") && getenv("PGO_NO_SPECULATION")[0] == '1';
-  return !off && P->g.world == 1 && !P->use_graph && !(P->comm && P->comm->world > 1);
+  return !off && P->g.world == 1 && !P->use_graph && !(P->comm && P->comm->world > 1) && !P->sym_storage;   // (the symmetric form has one set of blocks)
 }
 struct SpareSet { double *bsr, *Hdiag, *grad; };
 inline SpareSet spare_set(pgo_problem* P) {
@@ -721,6 +723,7 @@ int lm_run_pipelined(pgo_problem* P, int budget, int* ran) {
 int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* records, int capacity) {
   LmState& L = P->lm;
   if (!L.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_end without pgo_solver_begin");
+  struct SymOff { pgo_problem* p; ~SymOff() { p->sym_active = false; p->sym_storage = false; } } sym_off{P};   // the session's storage choice ends with it
   if (L.gmax_deferred) {
     pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, P->stream);
     HIP_TRY(hipStreamSynchronize(P->stream));

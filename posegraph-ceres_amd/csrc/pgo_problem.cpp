@@ -60,6 +60,7 @@ int exchange(pgo_problem* P, double* buf, size_t seg_doubles) {
 // diag_only (several ranks, the solve will run the owner-only CG): nobody reads another rank's off-diagonal entries of the
 // diagonal blocks then — 6 doubles per pose travel instead of 36 (28.8 -> 4.8 MB per accepted step at 100 k poses)
 int linearize_all(pgo_problem* P, bool diag_only) {
+  if (P->sym_storage) { pgo::launch_linearize_sym(P->g, P->sym, P->stream); return PGO_OK; }    // (one rank: nothing to exchange)
   pgo::launch_linearize(P->g, P->stream);
   P->sym_stale = true;
   int rc;
@@ -78,6 +79,7 @@ int linearize_all(pgo_problem* P, bool diag_only) {
 // LM damping + preconditioner.  6x6 blocks are rebuilt on every rank from the gathered diagonal; cluster blocks need
 // the in-cluster off-diagonal blocks, which only the owner holds, so their inverses are exchanged.
 int damping_all(pgo_problem* P, double radius, double min_diag, double max_diag, int mode) {
+  if (P->sym_storage) { pgo::launch_damping(sym_view(P), radius, min_diag, max_diag, mode, P->stream); return PGO_OK; }
   pgo::launch_damping(P->g, radius, min_diag, max_diag, mode, P->stream);
   if (P->g.cluster > 1 && !pipe_mode(P, cg_params_for(P->opt))) return exchange(P, P->g.Minv, (size_t)36 * P->g.cluster * P->g.rows_per);   // (the owner-only CG applies its own blocks only)
   return PGO_OK;
@@ -96,7 +98,8 @@ int cg_iteration(pgo_problem* P, const pgo::DeviceGraph& g, const pgo::CgParams&
     return PGO_OK;
   }
   if (g.world == 1) {   // x = x_old + alpha p formed on the fly by the SpMV, one combined vector launch
-    pgo::launch_spmv_refresh(g, P->stream, 1, odd);
+    if (P->sym_storage) pgo::launch_spmv_sym(g, P->sym, prm, 1 | 8 | 16 | (odd ? 32 : 0), 1, P->stream);
+    else pgo::launch_spmv_refresh(g, P->stream, 1, odd);
     pgo::launch_pcg_update_only(g, odd, P->stream, 3);
     return PGO_OK;
   }
@@ -230,7 +233,7 @@ int prepare(pgo_problem* P) {
   lap("rows -> workgroups, slots");
   P->h_slot_row = slot_row; P->h_slot_col = slot_col; P->h_slot_side = slot_side; P->h_row_slot_begin = row_slot_begin;
   P->direct_analyzed = false; P->direct_usable = false; P->front_usable = false; P->sfront_usable = false; P->cluster_built = 0; P->g.cluster = 1;
-  P->sym_built = false; P->sym_ready = false; P->sym_active = false;
+  P->sym_built = false; P->sym_ready = false; P->sym_active = false; P->sym_storage = false;
   if (P->want_direct && !(getenv("PGO_NO_ANALYSIS_THREAD") && getenv("PGO_NO_ANALYSIS_THREAD")[0] == '1')) {
     // an exact request: its host analysis (ordering, symbolic factorisation, schedule) needs nothing but the slot topology
     const long long budget = front_memory_budget();

@@ -118,11 +118,13 @@ int sym_prepare(pgo_problem* P) {
 
   std::vector<pgo::SymTile> tiles(T);
   std::vector<int> xlist, chunk_base, chunk_n, src_slot, diag_slot(N, 0);
-  std::vector<uint32_t> meta, rinfo;
+  std::vector<uint32_t> meta, rinfo, meta2, rinfo2;
+  std::vector<int> slot_edge;                // edge of every stored slot (-1: diagonal / padding)
+  int e_cap = 1;
   std::vector<int> local(N, -1);             // pose -> LDS index inside the tile being built
   int x_cap = 0;
   long long interior_edges = 0, stored = 0;
-  struct Slot { int src; uint32_t m; int row, dst_row; };   // m without vpos; dst_row: local row an interior slot's v goes to (-1 none)
+  struct Slot { int src; uint32_t m; int row, dst_row, edge; };   // m without vpos; dst_row: local row an interior slot's v goes to (-1 none)
   std::vector<Slot> slots;
   for (int t = 0; t < T; ++t) {
     const std::vector<int>& rows = trow[t];
@@ -151,7 +153,7 @@ int sym_prepare(pgo_problem* P) {
     slots.clear();
     for (int i = 0; i < nr; ++i) {
       const int v = rows[i];
-      slots.push_back(Slot{P->h_row_slot_begin[v], (uint32_t)i | ((uint32_t)pgo::SIDE_DIAG << 12) | ((uint32_t)i << 23), i, -1});
+      slots.push_back(Slot{P->h_row_slot_begin[v], (uint32_t)i | ((uint32_t)pgo::SIDE_DIAG << 12) | ((uint32_t)i << 23), i, -1, -1});
       for (int j = inc_ptr[v]; j < inc_ptr[v + 1]; ++j) {
         const int e = inc[j] >> 1, end_side = inc[j] & 1;
         const int o = end_side ? P->ia[e] : P->ib[e];
@@ -160,7 +162,7 @@ int sym_prepare(pgo_problem* P) {
         if (interior) ++interior_edges;
         slots.push_back(Slot{end_side ? end_slot[e] : beg_slot[e],
                              (uint32_t)local[o] | ((uint32_t)(end_side ? pgo::SIDE_END : pgo::SIDE_BEGIN) << 12) | (interior ? (1u << 14) : 0u) | ((uint32_t)i << 23),
-                             i, interior ? local[o] : -1});
+                             i, interior ? local[o] : -1, e});
       }
     }
     const int total = (int)slots.size();
@@ -181,13 +183,16 @@ int sym_prepare(pgo_problem* P) {
       if (c == 1) { TT.base1 = base; TT.n1 = n; }
       const size_t padded = (size_t)(n + 63) / 64 * 64;
       meta.resize(base + padded, 0u);
+      meta2.resize(base + padded, 0xFFFFFFFFu);
       src_slot.resize(base + padded, -1);
+      slot_edge.resize(base + padded, -1);
       const size_t ri0 = rinfo.size();
       rinfo.resize(ri0 + pgo::SYM_LANES, 0u);
       vs.clear();
       for (int l = 0; l < n; ++l) {
         const Slot& sl = slots[lo + l];
         src_slot[base + l] = sl.src;
+        slot_edge[base + l] = sl.edge;
         meta[base + l] = sl.m;
         if (((sl.m >> 12) & 3u) == (uint32_t)pgo::SIDE_DIAG) diag_slot[rows[sl.row]] = base + l;
         uint32_t& w = rinfo[ri0 + sl.row];           // u range of the slot's row: [ub, ub + uc)
@@ -203,6 +208,33 @@ int sym_prepare(pgo_problem* P) {
         if ((w >> 25) == 127) return unfit("has a row that receives more than 127 mirrored products in one chunk");
         w += 1u << 25;
       }
+      // exchange entries of the linearisation (k_linearize_sym): per destination row, ascending: the tails of its (row, wave) runs,
+      // then the mirrored contributions it receives — contiguous, so the row's lane adds one range
+      {
+        const size_t r20 = rinfo2.size();
+        rinfo2.resize(r20 + pgo::SYM_LANES, 0u);
+        int pos = 0;
+        size_t kv = 0;
+        for (int r = 0; r < nr; ++r) {
+          const uint32_t w = rinfo[ri0 + r];
+          const int ub = (int)(w & 0xFFu), uc = (int)((w >> 8) & 0x1FFu);
+          const int e0 = pos;
+          if (uc > 0) {
+            const int last = ub + uc - 1;
+            for (int wv = ub >> 6; wv <= (last >> 6); ++wv) {
+              const int tail = std::min(wv * 64 + 63, last);
+              meta2[base + tail] = (meta2[base + tail] & 0xFFFF0000u) | (uint32_t)pos++;
+            }
+          }
+          while (kv < vs.size() && vs[kv].first == r) {
+            const int l = vs[kv].second;
+            meta2[base + l] = (meta2[base + l] & 0x0000FFFFu) | ((uint32_t)pos++ << 16);
+            ++kv;
+          }
+          rinfo2[r20 + r] = (uint32_t)e0 | ((uint32_t)(pos - e0) << 16);
+        }
+        e_cap = std::max(e_cap, pos);
+      }
     }
     for (int v : rows) local[v] = -1;
     for (int gpose : ghosts) local[gpose] = -1;
@@ -213,6 +245,7 @@ int sym_prepare(pgo_problem* P) {
     return PGO_OK;
   }
   if (pgo::sym_lds_bytes(pgo::SymGraph{T, (int)chunk_base.size(), n_slots, x_cap}) > 160 * 1024 - 1024) return PGO_OK;
+  P->sym_lin_fits = ((size_t)x_cap * 8 + (size_t)27 * e_cap) * sizeof(double) + (size_t)x_cap * sizeof(int) <= 160 * 1024 - 1024;
 
   HIP_TRY(P->sy_tile.upload(tiles, s));
   HIP_TRY(P->sy_xlist.upload(xlist, s));
@@ -222,13 +255,43 @@ int sym_prepare(pgo_problem* P) {
   HIP_TRY(P->sy_rinfo.upload(rinfo, s));
   HIP_TRY(P->sy_src.upload(src_slot, s));
   HIP_TRY(P->sy_diag.upload(diag_slot, s));
+  // the linearisation's inputs in stored-slot order (component major, as the row kernels keep them in incidence-slot order)
+  {
+    HostArray lm, lw;
+    lm.resize((size_t)7 * n_slots);
+    if (P->has_info) lw.resize((size_t)21 * n_slots);
+    parallel_for(n_slots, [&](int lo, int hi) {
+      for (int t = lo; t < hi; ++t) {
+        const int e = slot_edge[t];
+        for (int c = 0; c < 7; ++c) lm[(size_t)c * n_slots + t] = e < 0 ? (c == 6 ? 1.0 : 0.0) : P->meas[(size_t)7 * e + c];
+        if (!P->has_info) continue;
+        if (e < 0) { for (int k = 0; k < 21; ++k) lw[(size_t)k * n_slots + t] = 0.0; continue; }
+        const double* L = &P->sqrt_info[(size_t)36 * e];
+        int k = 0;
+        for (int i = 0; i < 6; ++i)
+          for (int j = i; j < 6; ++j) {
+            double w = 0;
+            for (int r = 0; r < 6; ++r) w += L[6 * r + i] * L[6 * r + j];      // W = L^T L, as prepare() forms it
+            lw[(size_t)k * n_slots + t] = w;
+            ++k;
+          }
+      }
+    });
+    HIP_TRY(P->sy_lin_meas.upload(lm.data(), lm.n, s));
+    HIP_TRY(P->sy_lin_W.upload(lw.data(), lw.n, s));
+  }
+  HIP_TRY(P->sy_meta2.upload(meta2, s));
+  HIP_TRY(P->sy_rinfo2.upload(rinfo2, s));
   HIP_TRY(P->sy_val.alloc((size_t)n_slots * 36));
   HIP_TRY(P->sy_val.zero(s));
   pgo::SymGraph& sg = P->sym;
   sg.n_tiles = T; sg.n_chunks = (int)chunk_base.size(); sg.n_slots = n_slots; sg.x_cap = x_cap;
   sg.tile = P->sy_tile.p; sg.xlist = P->sy_xlist.p; sg.chunk_base = P->sy_chunk_base.p; sg.chunk_n = P->sy_chunk_n.p;
-  sg.meta = P->sy_meta.p; sg.rinfo = P->sy_rinfo.p; sg.src_slot = P->sy_src.p; sg.diag_slot = P->sy_diag.p; sg.val = P->sy_val.p;
+  sg.meta = P->sy_meta.p; sg.rinfo = P->sy_rinfo.p; sg.src_slot = P->sy_src.p; sg.diag_slot = P->sy_diag.p;
+  sg.lin_meas = P->sy_lin_meas.p; sg.lin_W = P->sy_lin_W.p; sg.meta2 = P->sy_meta2.p; sg.rinfo2 = P->sy_rinfo2.p; sg.e_cap = e_cap; sg.val = P->sy_val.p;
   HIP_TRY(hipStreamSynchronize(s));
+  P->h_sym_of_old.assign(P->g.n_slots, -1);
+  for (int t = 0; t < n_slots; ++t) if (src_slot[t] >= 0) P->h_sym_of_old[src_slot[t]] = t;
   P->sym_ready = true;
   P->sym_stale = true;
   P->sym_interior_fraction = E ? (double)interior_edges / E : 0.0;
@@ -236,5 +299,30 @@ int sym_prepare(pgo_problem* P) {
   if (getenv("PGO_VERBOSE"))
     std::fprintf(stderr, "[pgo] sym: %d tiles (<= %d rows), %.1f %% interior edges, %lld stored blocks (%.2f of N + 2E), %d chunks, x_cap %d, %.1f ms\n",
                  T, row_cap, 100.0 * P->sym_interior_fraction, stored, (double)stored / (N + 2.0 * E), sg.n_chunks, x_cap, 1e3 * seconds_since(t0));
+  return PGO_OK;
+}
+
+pgo::DeviceGraph sym_view(const pgo_problem* P) {
+  pgo::DeviceGraph gs = P->g;
+  gs.bsr_val = P->sym.val;
+  gs.row_slot_begin = P->sy_diag.p;
+  if (P->g.cluster > 1) gs.cl_slot = P->sy_cl_slot.p;
+  return gs;
+}
+
+// The symmetric form becomes the only storage of this LM session: the blocks of the linearisation that just ran (incidence-slot
+// kernels, iteration zero) are copied once, the cluster lists are re-indexed; from here on k_linearize_sym writes the form itself.
+int sym_enter_storage(pgo_problem* P) {
+  if (P->g.cluster > 1) {
+    std::vector<int> cl(P->h_cl_slot.size());
+    for (size_t i = 0; i < cl.size(); ++i) {
+      cl[i] = P->h_sym_of_old[P->h_cl_slot[i]];
+      if (cl[i] < 0) return set_error(PGO_ERR_UNSUPPORTED, "internal: a cluster block has no slot in the symmetric tile form");
+    }
+    HIP_TRY(P->sy_cl_slot.upload(cl, P->stream));
+  }
+  pgo::launch_sym_repack(P->g, P->sym, P->stream, 0);
+  P->sym_stale = false;
+  P->sym_storage = true;
   return PGO_OK;
 }

@@ -3,6 +3,7 @@
 // instruction, prefetched one chunk ahead) and 4 + 2 bytes of indices per slot; the vectors live in LDS.
 #include "pgo_sym.h"
 #include "pgo_wave.h"
+#include "pgo_lin.h"
 
 namespace pgo {
 
@@ -68,12 +69,12 @@ __device__ __forceinline__ double dpp_row_shr_f64(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + D, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-template <int D>
-__device__ __forceinline__ void seg_scan_step(double (&u)[6], int row, int lane) {
+template <int D, int NV>
+__device__ __forceinline__ void seg_scan_step(double (&u)[NV], int row, int lane) {
   const int rd = __builtin_amdgcn_update_dpp(0, row, 0x110 + D, 0xf, 0xf, true);
   const bool same = (lane & 15) >= D && rd == row;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < NV; ++k) {
     const double t = dpp_row_shr_f64<D>(u[k]);
     u[k] += same ? t : 0.0;
   }
@@ -81,17 +82,18 @@ __device__ __forceinline__ void seg_scan_step(double (&u)[6], int row, int lane)
 __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
-__device__ __forceinline__ void seg_scan6(double (&u)[6], int row, int lane) {
-  seg_scan_step<1>(u, row, lane);
-  seg_scan_step<2>(u, row, lane);
-  seg_scan_step<4>(u, row, lane);
-  seg_scan_step<8>(u, row, lane);
+template <int NV>
+__device__ __forceinline__ void seg_scan(double (&u)[NV], int row, int lane) {
+  seg_scan_step<1, NV>(u, row, lane);
+  seg_scan_step<2, NV>(u, row, lane);
+  seg_scan_step<4, NV>(u, row, lane);
+  seg_scan_step<8, NV>(u, row, lane);
 #pragma unroll
   for (int b = 1; b < 4; ++b) {
     const int r_prev = __builtin_amdgcn_readlane(row, 16 * b - 1), r_first = __builtin_amdgcn_readlane(row, 16 * b);
     const bool take = (lane >> 4) == b && r_prev == r_first && row == r_first;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < NV; ++k) {
       const double carry = readlane_f64(u[k], 16 * b - 1);
       u[k] += take ? carry : 0.0;
     }
@@ -110,6 +112,48 @@ __global__ __launch_bounds__(SYM_LANES) void k_spmv_sym(DeviceGraph g, SymGraph 
   double* xs = lds;
   double* ubuf = lds + (size_t)sg.x_cap * 6;
   double* vbuf = ubuf + SYM_LANES * VSTRIDE;
+
+  // MODE 1, `odd` carries k_spmv<1>'s flags: 2 = step tail behind a CG batch (CG bookkeeping first, A x only once the CG has
+  // stopped), 4 = the row lanes also write delta = -S x and the candidate Plus(x, delta), 8 = A x of a residual refresh (nothing
+  // once the CG has stopped), 16 = ... of x_old + alpha p formed on the fly (32: parity of p)
+  if (MODE == 1) {
+    if ((odd & 8) && g.cg->done) return;
+    if (!(odd & 8) && lm_halted(g)) return;
+    if (odd & 2) {
+      int done = g.cg->done;
+      const int iters0 = g.cg->iters, status = g.cg->status;
+      const int itd = done ? iters0 : g.cg->cnt_b;
+      double fs[4];
+      fs[0] = partial_sum(g.part_q + (size_t)(itd & 1) * g.n_part, g.n_vec_wg);
+      fs[1] = partial_sum(g.part_q + (size_t)((itd + 1) & 1) * g.n_part, g.n_vec_wg);
+      fs[2] = partial_sum(g.part_rr + (size_t)(itd & 1) * g.n_part, g.n_vec_wg);
+      fs[3] = partial_sum(g.part_bb, g.n_vec_wg);
+      block_sum<4>(fs, scratch);
+      const int was_done = done;
+      if (!done && itd >= 1) {
+        const double Q1 = -fs[0], Q0 = -fs[1];
+        const double zeta = itd * (Q1 - Q0) / Q1;
+        if ((zeta < prm.q_tolerance && itd >= prm.min_iterations) || itd >= prm.max_iterations) done = 1;
+        if (prm.r_tolerance >= 0.0 && sqrt(fs[2]) <= prm.r_tolerance * sqrt(fs[3]) && itd >= prm.min_iterations) done = 1;
+      }
+      if (tile == 0 && tid == 0) {
+        if (done && !was_done) { g.cg->iters = itd; __threadfence(); g.cg->done = 1; }
+        g.scal->cg_iterations = itd;
+        g.scal->cg_status = done ? status : -1;
+        g.scal->cg_residual_sq = fs[2];
+      }
+      if (!done) return;
+    }
+  }
+  double alpha_fly = 0.0;
+  if (MODE == 1 && (odd & 16)) {
+    double pqs[1] = {0.0};
+    const double* pqp = g.cg_q + (size_t)g.rows_per * 6;
+    for (int i = tid; i < g.pq_cap; i += SYM_LANES) pqs[0] += pqp[i];
+    block_sum<1>(pqs, scratch);
+    if (!(pqs[0] > 0.0) || !isfinite(pqs[0])) return;     // indefinite: the update kernel stops the CG
+    alpha_fly = g.cg->rho / pqs[0];
+  }
 
   // ---- loads that depend on nothing: the tile and its first two chunks (the chunk loop keeps two chunks of blocks in flight) ----
   const SymTile T = sg.tile[tile];
@@ -140,7 +184,11 @@ __global__ __launch_bounds__(SYM_LANES) void k_spmv_sym(DeviceGraph g, SymGraph 
   for (int i = tid; i < T.nx * 3; i += SYM_LANES) {
     const int e = i / 3, k = i - 3 * e;
     const int pose = sg.xlist[T.x0 + e];
-    const double2 z = reinterpret_cast<const double2*>((MODE == 0 ? g.cg_z : g.cg_x) + 6 * (size_t)pose)[k];
+    double2 z = reinterpret_cast<const double2*>((MODE == 0 ? g.cg_z : g.cg_x) + 6 * (size_t)pose)[k];
+    if (MODE == 1 && (odd & 16)) {
+      const double2 pc = reinterpret_cast<const double2*>(((odd & 32) ? g.cg_p1 : g.cg_p0) + 6 * (size_t)pose)[k];
+      z = double2{z.x + alpha_fly * pc.x, z.y + alpha_fly * pc.y};
+    }
     xs[6 * e + 2 * k] = z.x;
     xs[6 * e + 2 * k + 1] = z.y;
     if (MODE == 0 && e < PS_CAP) {
@@ -235,7 +283,7 @@ __global__ __launch_bounds__(SYM_LANES) void k_spmv_sym(DeviceGraph g, SymGraph 
     // The slots of a row sit in consecutive lanes: segmented inclusive scan inside the wave (fixed tree, deterministic), so that
     // the LAST lane of every (row, wave) run holds the run's sum and only those lanes go through LDS — the row's lane then adds
     // one entry per wave its slots span instead of one per slot.
-    if (!(g.debug & 512)) seg_scan6(u, row, lane);
+    if (!(g.debug & 512)) seg_scan<6>(u, row, lane);
     {
       const int rn = __shfl_down(row, 1, 64);
       if (tid < C.n && (lane == 63 || rn != row)) {
@@ -282,6 +330,30 @@ __global__ __launch_bounds__(SYM_LANES) void k_spmv_sym(DeviceGraph g, SymGraph 
     q[0] = double2{y[0], y[1]};
     q[1] = double2{y[2], y[3]};
     q[2] = double2{y[4], y[5]};
+    if (MODE == 1 && (odd & 4)) {
+      // step tail: delta = -S x and the candidate Plus(x, delta) of this row (k_retract's job)
+      const double2* ps2 = reinterpret_cast<const double2*>(g.pose_x + (size_t)POSE_STRIDE * pose);
+      const double2 a = ps2[0], b = ps2[1], c2 = ps2[2], d2 = ps2[3];
+      const V3 Pp{a.x, a.y, b.x};
+      const Q4 Pq{b.y, c2.x, c2.y, d2.x};
+      const uint8_t m = g.cmask[pose];
+      double d[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const bool cst = (i < 3) ? (m & 1) : (m & 2);
+        d[i] = cst ? 0.0 : -g.scale[6 * (size_t)pose + i] * xs[6 * tid + i];
+        g.delta[6 * (size_t)pose + i] = d[i];
+      }
+      V3 pc = Pp;
+      Q4 qc = Pq;
+      if (!(m & 1)) pc = V3{Pp.x + d[0], Pp.y + d[1], Pp.z + d[2]};
+      if (!(m & 2)) qc = quat_plus(Pq, V3{d[3], d[4], d[5]});
+      double2* o = reinterpret_cast<double2*>(g.pose_c + (size_t)POSE_STRIDE * pose);
+      o[0] = double2{pc.x, pc.y};
+      o[1] = double2{pc.z, qc.x};
+      o[2] = double2{qc.y, qc.z};
+      o[3] = double2{qc.w, 0.0};
+    }
     if (MODE == 0) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) pq[0] += y[k] * xs[6 * tid + k];
@@ -299,6 +371,112 @@ __global__ __launch_bounds__(SYM_LANES) void k_spmv_sym(DeviceGraph g, SymGraph 
         g.cg->q_hist[odd ? 1 : 0] = q_pub;
       }
     }
+  }
+}
+
+// Linearisation into the symmetric tile form.  One work-group per tile, one stored slot per lane and chunk (the SpMV's layout):
+// the lane evaluates its incidence with lin_slot() — the very expressions of k_linearize — from the poses staged in LDS, writes
+// its off-diagonal block, and contributes 27 numbers (21 of the diagonal block, 6 of the gradient) to its row; an INTERIOR slot
+// evaluates the mirrored incidence as well (same geometry: the compiler shares it) and sends those 27 numbers to the other row.
+// Row sums: segmented scan of the own contributions inside the wave, then run tails and mirrored contributions meet in an LDS
+// exchange buffer at positions the host laid out per destination row; lane r keeps row r's 27 sums in registers across the chunks.
+constexpr int LIN_NV = 27;
+template <int INFO>
+__global__ __launch_bounds__(SYM_LANES) void k_linearize_sym(DeviceGraph g, SymGraph sg, int gate) {
+  extern __shared__ double lds[];          // poses[8 * x_cap] | exch[LIN_NV * e_cap] | ids[x_cap]
+  if (gate == 1 && !g.cg->done) return;
+  if (gate == 2 && (g.lm->halt || !g.lm->accepted)) return;
+  const int tid = threadIdx.x, tile = blockIdx.x, lane = threadIdx.x & 63;
+  double* poses = lds;
+  double* exch = lds + (size_t)sg.x_cap * 8;
+  int* ids = reinterpret_cast<int*>(exch + (size_t)LIN_NV * sg.e_cap);
+  const SymTile T = sg.tile[tile];
+  for (int i = tid; i < T.nx * 4; i += SYM_LANES) {
+    const int e = i >> 2, k = i & 3;
+    const int pose = sg.xlist[T.x0 + e];
+    const double2 v = reinterpret_cast<const double2*>(g.pose_x + (size_t)POSE_STRIDE * pose)[k];
+    poses[8 * e + 2 * k] = v.x;
+    poses[8 * e + 2 * k + 1] = v.y;
+    if (k == 0) ids[e] = pose;
+  }
+  __syncthreads();
+  const size_t ns = (size_t)sg.n_slots;
+  double acc[LIN_NV];
+#pragma unroll
+  for (int k = 0; k < LIN_NV; ++k) acc[k] = 0.0;
+  auto pose_at = [&](int e) { const double* p = poses + 8 * e; return PoseRec{V3{p[0], p[1], p[2]}, Q4{p[3], p[4], p[5], p[6]}}; };
+  for (int c = 0; c < T.nchunks; ++c) {
+    const int ci = T.chunk0 + c;
+    const int n = sg.chunk_n[ci], t = sg.chunk_base[ci] + tid;
+    const uint32_t rin = sg.rinfo2[(size_t)ci * SYM_LANES + tid];
+    double v[LIN_NV];
+#pragma unroll
+    for (int k = 0; k < LIN_NV; ++k) v[k] = 0.0;
+    int row = -1 - lane;
+    uint32_t m2 = 0xFFFFFFFFu;
+    if (tid < n) {
+      const uint32_t meta = sg.meta[t];
+      m2 = sg.meta2[t];
+      const int xcol = (int)(meta & 0xFFFu), side = (int)((meta >> 12) & 3u);
+      row = (int)((meta >> 23) & 0xFFu);
+      if (side != SIDE_DIAG) {
+        const int ea = side == SIDE_BEGIN ? row : xcol, eb = side == SIDE_BEGIN ? xcol : row;
+        const PoseRec A = pose_at(ea), Bp = pose_at(eb);
+        const V3 mp{sg.lin_meas[t], sg.lin_meas[ns + t], sg.lin_meas[2 * ns + t]};
+        const Q4 mq{sg.lin_meas[3 * ns + t], sg.lin_meas[4 * ns + t], sg.lin_meas[5 * ns + t], sg.lin_meas[6 * ns + t]};
+        double wv[36];
+        lin_slot<INFO>(g, side, ids[row], ids[xcol], A, Bp, mp, mq, sg.lin_W, ns, (size_t)t, wv, v);
+        double2* out = reinterpret_cast<double2*>(sg.val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+#pragma unroll
+        for (int kk = 0; kk < (INFO != 1 ? (int)BLK_PAIRS_PACKED : (int)BLK_PAIRS_FULL); ++kk) out[(size_t)kk * 64] = double2{wv[2 * kk], wv[2 * kk + 1]};
+        if (meta & (1u << 14)) {       // interior: the END-side incidence of the same edge, for the other row
+          double wm[36], vm[LIN_NV];
+          lin_slot<INFO>(g, SIDE_END, ids[xcol], ids[row], A, Bp, mp, mq, sg.lin_W, ns, (size_t)t, wm, vm);
+          const int vp = (int)(m2 >> 16);
+#pragma unroll
+          for (int k = 0; k < LIN_NV; ++k) exch[(size_t)vp * LIN_NV + k] = vm[k];
+        }
+      }
+    }
+    seg_scan<LIN_NV>(v, row, lane);
+    {
+      const int rn = __shfl_down(row, 1, 64);
+      if (tid < n && (lane == 63 || rn != row)) {
+        const int tp = (int)(m2 & 0xFFFFu);
+#pragma unroll
+        for (int k = 0; k < LIN_NV; ++k) exch[(size_t)tp * LIN_NV + k] = v[k];
+      }
+    }
+    __syncthreads();
+    {
+      const int eb = (int)(rin & 0xFFFFu), ec = (int)(rin >> 16);
+      for (int j = 0; j < ec; ++j) {
+#pragma unroll
+        for (int k = 0; k < LIN_NV; ++k) acc[k] += exch[(size_t)(eb + j) * LIN_NV + k];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < T.nrows) {
+    const int pose = ids[tid];
+    const uint8_t cm = g.cmask[pose];
+    double H[36];
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) {
+        double sv = acc[k++];
+        if (i == j && ((i < 3) ? (cm & 1) : (cm & 2))) sv = 1.0;     // unit diagonal keeps the constant dims decoupled and the block SPD
+        H[6 * i + j] = sv;
+        H[6 * j + i] = sv;
+      }
+    double2* hd = reinterpret_cast<double2*>(g.Hdiag + 36 * (size_t)pose);
+#pragma unroll
+    for (int q = 0; q < 18; ++q) hd[q] = double2{H[2 * q], H[2 * q + 1]};
+    double2* gd = reinterpret_cast<double2*>(g.grad + 6 * (size_t)pose);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) gd[q] = double2{acc[21 + 2 * q], acc[21 + 2 * q + 1]};
   }
 }
 
@@ -355,6 +533,24 @@ void launch_spmv_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p
     if (g.blk_packed) hipLaunchKernelGGL((k_spmv_sym<1, true>), grid, block, lds, s, g, sg, p, odd);
     else hipLaunchKernelGGL((k_spmv_sym<1, false>), grid, block, lds, s, g, sg, p, odd);
   }
+}
+
+void launch_linearize_sym(const DeviceGraph& g, const SymGraph& sg, hipStream_t s, int gate) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    const int cap = 160 * 1024 - 512;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize_sym<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize_sym<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize_sym<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize_sym<3>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    attr_set = true;
+  }
+  const size_t lds = ((size_t)sg.x_cap * 8 + (size_t)LIN_NV * sg.e_cap) * sizeof(double) + (size_t)sg.x_cap * sizeof(int);
+  const dim3 grid(sg.n_tiles), block(SYM_LANES);
+  if (g.info_mode == 3) hipLaunchKernelGGL(k_linearize_sym<3>, grid, block, lds, s, g, sg, gate);
+  else if (g.info_mode == 2) hipLaunchKernelGGL(k_linearize_sym<2>, grid, block, lds, s, g, sg, gate);
+  else if (g.info_mode) hipLaunchKernelGGL(k_linearize_sym<1>, grid, block, lds, s, g, sg, gate);
+  else hipLaunchKernelGGL(k_linearize_sym<0>, grid, block, lds, s, g, sg, gate);
 }
 
 void launch_sym_repack(const DeviceGraph& g, const SymGraph& sg, hipStream_t s, int diag_only) {

@@ -93,16 +93,24 @@ def test_general_information_full_blocks(gpu, ds):
     assert e1 <= max(3.0 * e0, 1e-9 * np.abs(xs).max()), (e0, e1)
 
 
-def test_lm_solve_same_answer(gpu, ds, O):
+@pytest.mark.parametrize("repack", [False, True])
+def test_lm_solve_same_answer(gpu, ds, O, repack):
     """A whole LM solve (truncated PCG, Huber) with the CG products from the symmetric form: same iterations, same costs as the
     incidence-slot kernels, and the oracle's answer."""
     g = ds.manhattan_se3(4000, 16000, seed=21)
     opt = dict(max_num_iterations=12, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2)
     runs = []
+    # repack: the incidence-slot linearisation stays and its blocks are copied once per LM iteration (PGO_SYM_REPACK=1); otherwise the
+    # symmetric form is the session's only storage: k_linearize_sym writes it, damping / cluster preconditioner / tail and refresh
+    # products read and write it
+    os.environ.pop("PGO_SYM_REPACK", None)
     for on in (False, True):
+        if on and repack:
+            os.environ["PGO_SYM_REPACK"] = "1"
         with _Sym(on):
             prob, poses = gpu.problem_from_graph(g)
             runs.append((gpu.solve(gpu.SolverOptions(**opt), prob), poses))
+        os.environ.pop("PGO_SYM_REPACK", None)
     (a, pa), (b, pb) = runs
     assert len(a.iterations) == len(b.iterations)
     assert list(a.iterations["step_is_successful"]) == list(b.iterations["step_is_successful"])
@@ -110,3 +118,22 @@ def test_lm_solve_same_answer(gpu, ds, O):
     assert np.abs(pa - pb).max() < 1e-6
     op, osum, otr = O.solve(O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info), O.default_options(max_num_iterations=12, linear_solver=1, pcg_cluster=2))
     assert b.final_cost == pytest.approx(osum.final_cost, rel=1e-6)
+
+
+@pytest.mark.parametrize("name", ["identity", "fat_rows", "sphere"])
+def test_lm_solve_symmetric_storage_other_graphs(gpu, ds, name):
+    """Identity information (INFO 0), rows with many incidences (several chunks per tile, runs across wave boundaries), a mesh:
+    whole LM solves with the symmetric form as the only storage against the incidence-slot kernels."""
+    g = _graphs(ds)[name]
+    opt = dict(max_num_iterations=10, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=1 if name == "sphere" else 2)
+    runs = []
+    for on in (False, True):
+        with _Sym(on, 32):
+            prob, poses = gpu.problem_from_graph(g)
+            runs.append((gpu.solve(gpu.SolverOptions(**opt), prob), poses))
+    (a, pa), (b, pb) = runs
+    n = min(len(a.iterations), len(b.iterations))
+    assert n >= 5 and list(a.iterations["step_is_successful"][:n]) == list(b.iterations["step_is_successful"][:n])
+    assert np.allclose(a.iterations["cost"][:4], b.iterations["cost"][:4], rtol=1e-8)
+    # (truncated PCG on an ill-conditioned mesh amplifies the last-bit differences of the products: 1e-9 at iteration 3, 2e-4 at 5)
+    assert np.allclose(a.iterations["cost"][:n], b.iterations["cost"][:n], rtol=5e-3)

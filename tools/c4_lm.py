@@ -13,8 +13,9 @@ gpu = pgo_loader.load()
 ds = pgo_loader.datasets()
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 g = ds.manhattan_se3(100000, 1000000, seed=20260930, loop_radius=3.0)
-for sym in ("0", "1", "0", "1"):
+for sym, rp in (("0", "0"), ("1", "1"), ("1", "0"), ("0", "0"), ("1", "1"), ("1", "0")):
     os.environ["PGO_SYM"] = sym
+    os.environ["PGO_SYM_REPACK"] = rp
     prob, poses = gpu.problem_from_graph(g)
     opt = gpu.SolverOptions(max_num_iterations=2 ** 30, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, eta=0.1,
                             function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
@@ -24,5 +25,5 @@ for sym in ("0", "1", "0", "1"):
     ran, _ = prob.solver_step(steps)
     dt = time.perf_counter() - t0
     s = prob.solver_end()
-    print("PGO_SYM=%s: %.3f ms per LM iteration (%d iterations), %d CG iterations in the session, final cost %.9e" % (
-        sym, 1e3 * dt / max(1, ran), ran, s.num_linear_solver_iterations, s.final_cost), flush=True)
+    print("PGO_SYM=%s PGO_SYM_REPACK=%s: %.3f ms per LM iteration (%d iterations), %d CG iterations in the session, final cost %.9e" % (
+        sym, rp, 1e3 * dt / max(1, ran), ran, s.num_linear_solver_iterations, s.final_cost), flush=True)
