@@ -19,7 +19,6 @@
 #include "pgo_lm_rules.h"
 #include "pgo_math.h"
 #include "pgo_wave.h"
-#include "pgo_lin.h"
 
 namespace pgo {
 
@@ -42,6 +41,61 @@ __device__ __forceinline__ size_t q_index_flat(const DeviceGraph& g, int idx) { 
   if (g.world == 1) return (size_t)idx;
   const int row = idx / 6;
   return q_index(g, row, idx - 6 * row);
+}
+
+struct PoseRec { V3 p; Q4 q; };
+__device__ __forceinline__ PoseRec load_pose(const double* poses, int v) {
+  const double2* s = reinterpret_cast<const double2*>(poses + (size_t)POSE_STRIDE * v);
+  const double2 a = s[0], b = s[1], c = s[2], d = s[3];
+  return PoseRec{V3{a.x, a.y, b.x}, Q4{b.y, c.x, c.y, d.x}};
+}
+
+__device__ __forceinline__ int upper_index(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+
+struct WBlocks { M3 pp, pr, rr; };
+__device__ __forceinline__ WBlocks load_W(const double* W, size_t stride, size_t idx) {
+  double u[21];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) u[k] = W[(size_t)k * stride + idx];
+  WBlocks w;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      w.pp.m[3 * i + j] = (i <= j) ? u[upper_index(i, j)] : u[upper_index(j, i)];
+      w.pr.m[3 * i + j] = u[upper_index(i, 3 + j)];
+      w.rr.m[3 * i + j] = (i <= j) ? u[upper_index(3 + i, 3 + j)] : u[upper_index(3 + j, 3 + i)];
+    }
+  return w;
+}
+
+__device__ __forceinline__ WBlocks load_W_blockdiag(const double* W, size_t stride, size_t idx) {
+  WBlocks w;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i; j < 3; ++j) {
+      const double a = W[(size_t)upper_index(i, j) * stride + idx], b = W[(size_t)upper_index(3 + i, 3 + j) * stride + idx];
+      w.pp.m[3 * i + j] = a; w.pp.m[3 * j + i] = a;
+      w.rr.m[3 * i + j] = b; w.rr.m[3 * j + i] = b;
+    }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w.pr.m[k] = 0.0;
+  return w;
+}
+
+// diagonal information (W = diag(w), C2 / C4's diag(1/sigma^2)): six of the 21 planes are read; the entries set to 0.0 here are the
+// exact zeros load_W_blockdiag would have fetched, so the arithmetic behind it is the same to the bit
+__device__ __forceinline__ WBlocks load_W_diag(const double* W, size_t stride, size_t idx) {
+  WBlocks w;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { w.pp.m[k] = 0.0; w.pr.m[k] = 0.0; w.rr.m[k] = 0.0; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    w.pp.m[4 * i] = W[(size_t)upper_index(i, i) * stride + idx];
+    w.rr.m[4 * i] = W[(size_t)upper_index(3 + i, 3 + i) * stride + idx];
+  }
+  return w;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -88,16 +142,125 @@ __device__ __forceinline__ void linearize_body(const DeviceGraph& g, double* lds
       const size_t ns = (size_t)g.n_slots;
       const V3 mp{g.smeas[t], g.smeas[ns + t], g.smeas[2 * ns + t]};
       const Q4 mq{g.smeas[3 * ns + t], g.smeas[4 * ns + t], g.smeas[5 * ns + t], g.smeas[6 * ns + t]};
-      double wv[36];
-      lin_slot<INFO>(g, side, row, col, A, Bp, mp, mq, g.sW, ns, (size_t)t, wv, v);
+      const EdgeGeom eg = edge_geometry(A.p, A.q, Bp.p, Bp.q, mp, mq);
+      const V3 ep{eg.e[0], eg.e[1], eg.e[2]}, er{eg.e[3], eg.e[4], eg.e[5]};
+
+      V3 wep, wer;
+      M3 C1, C2, RU, GP, MQ, GU;
+      if (INFO >= 2) {
+        // block-diagonal information (W_pr = 0): only W_pp and W_rr are read (12 of 21 entries; 6 when W is diagonal, INFO 3);
+        // every term that carries W_pr in the general branch below is exactly zero there, so both branches give the same numbers
+        const WBlocks W = INFO == 3 ? load_W_diag(g.sW, ns, (size_t)t) : load_W_blockdiag(g.sW, ns, (size_t)t);
+        wep = mulv(W.pp, ep);
+        wer = mulv(W.rr, er);
+        const M3 X = mul(W.pp, eg.Rt), Qm = mul(W.rr, eg.M), U = mul(W.pp, eg.G);
+        C1 = mulT(eg.Rt, X); RU = mulT(eg.Rt, U); MQ = mulT(eg.M, Qm); GU = mulT(eg.G, U);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { C2.m[k] = 0.0; GP.m[k] = 0.0; }
+      } else if (INFO) {
+        const WBlocks W = load_W(g.sW, ns, (size_t)t);
+        const V3 a1 = mulv(W.pp, ep), a2 = mulv(W.pr, er), b1 = mulTv(W.pr, ep), b2 = mulv(W.rr, er);
+        wep = V3{a1.x + a2.x, a1.y + a2.y, a1.z + a2.z};
+        wer = V3{b1.x + b2.x, b1.y + b2.y, b1.z + b2.z};
+        const M3 X = mul(W.pp, eg.Rt), P = mul(W.pr, eg.M), Qm = mul(W.rr, eg.M), U = mul(W.pp, eg.G);
+        C1 = mulT(eg.Rt, X); C2 = mulT(eg.Rt, P); RU = mulT(eg.Rt, U);
+        GP = mulT(eg.G, P); MQ = mulT(eg.M, Qm); GU = mulT(eg.G, U);
+      } else {
+        wep = ep; wer = er;
+        C1 = mulT(eg.Rt, eg.Rt); RU = mulT(eg.Rt, eg.G); MQ = mulT(eg.M, eg.M); GU = mulT(eg.G, eg.G);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { C2.m[k] = 0.0; GP.m[k] = 0.0; }
+      }
+      const double s = dot(ep, wep) + dot(er, wer);
+      double rho0, rho1;
+      loss_eval(g.loss_kind, g.loss_a, s, &rho0, &rho1);
+
+      // 6x6 results for this row: off-diagonal block, own diagonal contribution, own gradient
+      double off[36], dg[36], gv[6];
+      const M3 RU2C2 = axpby(1.0, RU, 2.0, C2);          // Rt^T (U + 2P)
+      const M3 GP4MQ = axpby(2.0, GP, 4.0, MQ);          // 2 G^T P + 4 M^T Qm
+      const V3 rtw = mulTv(eg.Rt, wep), gtw = mulTv(eg.G, wep), mtw = mulTv(eg.M, wer);
+      if (side == SIDE_BEGIN) {
+        // H_ab = [ -C1 , 2C2 ; (RU+2C2)^T , -(2GP+4MQ) ]    H_aa = [ C1 , -(RU+2C2) ; sym , GU + 2(GP+GP^T) + 4MQ ]
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            off[6 * i + j] = -C1.m[3 * i + j];
+            off[6 * i + 3 + j] = 2.0 * C2.m[3 * i + j];
+            off[6 * (3 + i) + j] = RU2C2.m[3 * j + i];
+            off[6 * (3 + i) + 3 + j] = -GP4MQ.m[3 * i + j];
+            dg[6 * i + j] = C1.m[3 * i + j];
+            dg[6 * i + 3 + j] = -RU2C2.m[3 * i + j];
+            dg[6 * (3 + i) + j] = -RU2C2.m[3 * j + i];
+            dg[6 * (3 + i) + 3 + j] = GU.m[3 * i + j] + 2.0 * (GP.m[3 * i + j] + GP.m[3 * j + i]) + 4.0 * MQ.m[3 * i + j];
+          }
+        gv[0] = -rtw.x; gv[1] = -rtw.y; gv[2] = -rtw.z;
+        gv[3] = gtw.x + 2.0 * mtw.x; gv[4] = gtw.y + 2.0 * mtw.y; gv[5] = gtw.z + 2.0 * mtw.z;
+      } else {
+        // H_ba = H_ab^T                                      H_bb = [ C1 , -2C2 ; -2C2^T , 4MQ ]
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            off[6 * i + j] = -C1.m[3 * j + i];
+            off[6 * i + 3 + j] = RU2C2.m[3 * i + j];
+            off[6 * (3 + i) + j] = 2.0 * C2.m[3 * j + i];
+            off[6 * (3 + i) + 3 + j] = -GP4MQ.m[3 * j + i];
+            dg[6 * i + j] = C1.m[3 * i + j];
+            dg[6 * i + 3 + j] = -2.0 * C2.m[3 * i + j];
+            dg[6 * (3 + i) + j] = -2.0 * C2.m[3 * j + i];
+            dg[6 * (3 + i) + 3 + j] = 4.0 * MQ.m[3 * i + j];
+          }
+        gv[0] = rtw.x; gv[1] = rtw.y; gv[2] = rtw.z;
+        gv[3] = -2.0 * mtw.x; gv[4] = -2.0 * mtw.y; gv[5] = -2.0 * mtw.z;
+      }
+      // constant parameter blocks drop out of the program; Jacobi column scaling S
+      const uint8_t m_own = g.cmask[row], m_oth = g.cmask[col];
+      double so[6], st[6], mo[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const bool co = (i < 3) ? (m_own & 1) : (m_own & 2);
+        const bool ct = (i < 3) ? (m_oth & 1) : (m_oth & 2);
+        mo[i] = co ? 0.0 : 1.0;
+        so[i] = co ? 0.0 : g.scale[6 * (size_t)row + i];
+        st[i] = ct ? 0.0 : g.scale[6 * (size_t)col + i];
+      }
       double2* out = reinterpret_cast<double2*>(g.bsr_val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
       if (INFO != 1) {
+        // packed slot: positions 0..8 top-left, 9..17 bottom-right, 18..26 the stored off-diagonal quadrant (bottom-left of
+        // H_ab for the BEGIN slot, top-right of H_ba for the END slot), 27 unused.  Same products as the full layout.
+        double wv[28];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          const int i = q / 3, j = q % 3;
+          const int ktl = 6 * i + j, kbr = 6 * (3 + i) + 3 + j, kbl = 6 * (3 + i) + j, ktr = 6 * i + 3 + j;
+          wv[q] = rho1 * so[ktl / 6] * st[ktl % 6] * off[ktl];
+          wv[9 + q] = rho1 * so[kbr / 6] * st[kbr % 6] * off[kbr];
+          const double vbl = rho1 * so[kbl / 6] * st[kbl % 6] * off[kbl];
+          const double vtr = rho1 * so[ktr / 6] * st[ktr % 6] * off[ktr];
+          wv[18 + q] = side == SIDE_BEGIN ? vbl : vtr;
+        }
+        wv[27] = 0.0;
 #pragma unroll
         for (int kk = 0; kk < BLK_PAIRS_PACKED; ++kk) out[(size_t)kk * 64] = double2{wv[2 * kk], wv[2 * kk + 1]};
       } else {
 #pragma unroll
-        for (int kk = 0; kk < 18; ++kk) out[(size_t)kk * 64] = double2{wv[2 * kk], wv[2 * kk + 1]};
+        for (int kk = 0; kk < 18; ++kk) {
+          const int k0 = 2 * kk, k1 = 2 * kk + 1;
+          double2 w;
+          w.x = rho1 * so[k0 / 6] * st[k0 % 6] * off[k0];
+          w.y = rho1 * so[k1 / 6] * st[k1 % 6] * off[k1];
+          out[(size_t)kk * 64] = w;
+        }
       }
+      int k = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) v[k++] = rho1 * so[i] * so[j] * dg[6 * i + j];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v[21 + i] = rho1 * mo[i] * gv[i];
     }
 
     // per-row sums of the 27 values through LDS, in PASSES rounds of NVP values (stride NVS doubles per lane: odd, so the 8-byte

@@ -1,6 +1,9 @@
-// pgo_lin.h — one incidence of the linearisation (residual, closed-form Jacobians, Huber corrector, J'J / J'r pieces), shared by the
-// row-partitioned kernel of pgo_kernels.hip (k_linearize / k_uni_s) and the symmetric-tile kernel of pgo_sym_kernels.hip: the very
-// same expressions, so both produce the same numbers for the same incidence.
+// pgo_lin.h — one incidence of the linearisation (residual, closed-form Jacobians, Huber corrector, J'J / J'r pieces) for the
+// symmetric-tile kernel of pgo_sym_kernels.hip.  The expressions are those of linearize_body() in pgo_kernels.hip, statement by
+// statement; that kernel keeps its own inline copy on purpose: hipcc contracts a*b + c*d into FMAs differently depending on the
+// surrounding code, a shared function moved the last bit of a few products, and the row kernel's results are pinned bit for bit
+// (CG iteration counts equal to the oracle's over whole solves, tests/test_gpu_landmarks.py, test_gpu_parity.py).  The symmetric
+// form is held to the row kernels to rounding (tests/test_gpu_sym.py).
 // Reference behaviour: PLUS/include/PoseGraph3dError.h:21-54 (residual), SURVEY.md Appendix A.3-A.5 (closed-form blocks).
 #pragma once
 #include "pgo_kernels.h"
