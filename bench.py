@@ -183,6 +183,32 @@ def main():
         watchdog = threading.Timer(SHARDED_LIMIT_S, give_up)
         watchdog.daemon = True
 
+    # ---- N > 1, BASELINE configs[4] ("sphere x10, 8 x MI355X, Schur path"): the exact solver does not shard ("replicas
+    # only"), so the node serves one independent sphere graph per GPU, every LM step an MFMA multifrontal factorisation ----
+    c5_extra = None
+    if sharded and not args.no_exact_blocks:
+        try:
+            g5 = ds.sphere_layers(n_spheres=10, rings=50, per_ring=50, n_edges=250000, seed=20260931 + rank)
+            p5, _ = pkg.problem_from_graph(g5)
+            p5.solver_begin(pkg.SolverOptions(max_num_iterations=2 ** 30, linear_solver_type=pkg.SPARSE_NORMAL_CHOLESKY, function_tolerance=0.0,
+                                              parameter_tolerance=0.0, gradient_tolerance=0.0))
+            run_steps(p5, 2)
+            k5 = 5
+            barrier()
+            t0 = time.perf_counter()
+            run_steps(p5, k5)
+            torch.cuda.synchronize()
+            t5 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+            s5 = p5.solver_end()
+            c5_extra = {"workload": "BASELINE configs[4]: sphere x10 (25 k poses / 250 k edges), one independent graph per GPU, exact LM steps "
+                                    "(supernodal multifrontal Cholesky, FP64 MFMA fronts); replicas, no data-path collective",
+                        "lm_iters_per_sec_all_gpus": round(world * k5 / float(t5.item()), 2), "ms_per_step": round(1e3 * float(t5.item()) / k5, 3),
+                        "steps": k5, "n_gpus": world, "factor_gflop_per_step": round(s5.factor_flops / 1e9, 1), "linear_solver_used": s5.linear_solver_used}
+            del p5, g5
+        except Exception as exc:   # noqa: BLE001
+            c5_extra = {"error": str(exc)[:200]}
+
     c4_headline = sharded and (args.poses, args.edges) == (N_POSES, N_EDGES)      # N > 1: BASELINE configs[3], strong scaling
     weak_extra = one_gpu_extra = None
     if sharded:
@@ -248,6 +274,16 @@ def main():
         extra["independent_replicas"] = replica_extra
     if weak_extra is not None:
         extra["weak_scaling_c2_per_gpu"] = weak_extra
+    if c5_extra is not None:
+        extra["c5_exact_replicas"] = c5_extra
+    if sharded:
+        # the per-iteration collective of the sharded CG, timed by itself with HIP events on the solver stream (every rank takes
+        # part; world 1 forced through this path: RCCL returns without a launch) — so that a scaling run explains itself
+        try:
+            t_ex = prob.time_kernel("exchange", 200)
+            extra["exchange_us_per_cg_iteration"] = round(1e3 * t_ex, 2)
+        except Exception as exc:   # noqa: BLE001
+            extra["exchange_us_per_cg_iteration"] = "unavailable: %s" % (str(exc)[:120],)
     if one_gpu_extra is not None:
         extra["one_gpu_same_workload"] = one_gpu_extra
         extra["speedup_vs_one_gpu_same_workload"] = round(elapsed and (one_gpu_extra["ms_per_step"] / (1e3 * elapsed / args.steps)), 3)
