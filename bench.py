@@ -446,9 +446,18 @@ def main():
                                pcg_cluster_poses=args.cluster)
         p4.solver_begin(o4)
         p4.solver_step(2)
+        torch.cuda.synchronize()
+        t40 = time.perf_counter()
+        ran4, _ = p4.solver_step(10)
+        torch.cuda.synchronize()
+        c4_ms = 1e3 * (time.perf_counter() - t40) / max(1, ran4)
         N4, E4 = g4.N, g4.E
         blocks = {}
+        # (above 600 k BSR slots a PCG session on one rank keeps the normal equations in the symmetric tile form, csrc/pgo_sym.h: the
+        # *_sym kernels are the ones its LM loop runs; the incidence-slot kernels are what several ranks and smaller graphs run)
         for key, kern, nbytes, reps4 in (("k_evaluate_edges", "evaluate", 976 * E4 + 56 * N4, 30),
+                                         ("k_spmv_sym<0> (CG product, every interior block read once)", "sym_spmv", (N4 + E4) * 288 + 2 * N4 * 48, 100),
+                                         ("k_linearize_sym", "sym_linearize", 640 * E4 + 392 * N4, 50),
                                          ("k_linearize", "linearize", 640 * E4 + 392 * N4, 50),
                                          ("k_spmv<0>", "pcg_spmv", (N4 + E4) * 288 + 2 * N4 * 48, 100)):
             t4 = p4.time_kernel(kern, reps4)
@@ -457,7 +466,8 @@ def main():
                            "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
         blocks["k_evaluate_edges"]["edge_jacobians_per_sec"] = round(E4 / (blocks["k_evaluate_edges"]["avg_launch_us"] * 1e-6), 1)
         p4.solver_end()
-        extra["rooflines_at_c4_size"] = {"poses": N4, "edges": E4, "bound": "hbm", "peak": HBM_PEAK_GBS, "kernels": blocks}
+        extra["rooflines_at_c4_size"] = {"poses": N4, "edges": E4, "bound": "hbm", "peak": HBM_PEAK_GBS, "kernels": blocks,
+                                         "lm_iteration_ms_one_gpu": round(c4_ms, 4), "lm_iterations_timed": ran4}
 
     # ---- exact requests (the reference's own linear solver setting, SPARSE_NORMAL_CHOLESKY) through pgo_solve: host buffers in
     # and out, setup included — BASELINE.json's metric is quoted on "KITTI-00-scale" graphs ----
