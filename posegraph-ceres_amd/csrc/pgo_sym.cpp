@@ -170,7 +170,7 @@ int sym_prepare(pgo_problem* P) {
     const int L = (total + pgo::SYM_LANES - 1) / pgo::SYM_LANES;
     pgo::SymTile& TT = tiles[t];
     TT.chunk0 = (int)chunk_base.size(); TT.nchunks = L; TT.x0 = (int)xlist.size(); TT.nx = nx; TT.nrows = nr;
-    TT.pad[0] = TT.pad[1] = TT.pad[2] = 0; TT.base0 = TT.n0 = TT.base1 = TT.n1 = 0;
+    TT.pad[0] = TT.pad[1] = 0; TT.total = total; TT.base0 = TT.n0 = TT.base1 = TT.n1 = 0;
     for (int v : rows) xlist.push_back(v);
     for (int gpose : ghosts) xlist.push_back(gpose);
     std::vector<std::pair<int, int>> vs;          // (destination row, producing lane) of the chunk's v entries
@@ -245,7 +245,7 @@ int sym_prepare(pgo_problem* P) {
     return PGO_OK;
   }
   if (pgo::sym_lds_bytes(pgo::SymGraph{T, (int)chunk_base.size(), n_slots, x_cap}) > 160 * 1024 - 1024) return PGO_OK;
-  P->sym_lin_fits = ((size_t)x_cap * 8 + (size_t)27 * e_cap) * sizeof(double) + (size_t)x_cap * sizeof(int) <= 160 * 1024 - 1024;
+  { pgo::SymGraph probe{}; probe.x_cap = x_cap; probe.e_cap = e_cap; P->sym_lin_fits = pgo::sym_lin_lds_bytes(probe) <= 160 * 1024 - 1024; }
 
   HIP_TRY(P->sy_tile.upload(tiles, s));
   HIP_TRY(P->sy_xlist.upload(xlist, s));
@@ -297,8 +297,8 @@ int sym_prepare(pgo_problem* P) {
   P->sym_interior_fraction = E ? (double)interior_edges / E : 0.0;
   P->sym_stored_slots = stored;
   if (getenv("PGO_VERBOSE"))
-    std::fprintf(stderr, "[pgo] sym: %d tiles (<= %d rows), %.1f %% interior edges, %lld stored blocks (%.2f of N + 2E), %d chunks, x_cap %d, %.1f ms\n",
-                 T, row_cap, 100.0 * P->sym_interior_fraction, stored, (double)stored / (N + 2.0 * E), sg.n_chunks, x_cap, 1e3 * seconds_since(t0));
+    std::fprintf(stderr, "[pgo] sym: %d tiles (<= %d rows), %.1f %% interior edges, %lld stored blocks (%.2f of N + 2E), %d chunks, x_cap %d, e_cap %d, %.1f ms\n",
+                 T, row_cap, 100.0 * P->sym_interior_fraction, stored, (double)stored / (N + 2.0 * E), sg.n_chunks, x_cap, e_cap, 1e3 * seconds_since(t0));
   return PGO_OK;
 }
 

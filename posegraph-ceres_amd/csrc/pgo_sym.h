@@ -31,7 +31,8 @@ struct SymTile {
   int nrows;      // the first nrows entries of the tile's xlist are its own rows (row r <-> lane r)
   int base0, n0;  // chunk_base / chunk_n of the tile's first two chunks: their block loads start as soon as the descriptor is in
   int base1, n1;
-  int pad[3];
+  int total;      // stored slots of the tile: chunk c holds min(256, total - 256 c) of them, starting at base0 + 256 c
+  int pad[2];
 };
 
 // per stored slot (index = chunk_base[chunk] + lane):
@@ -67,6 +68,7 @@ void launch_spmv_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p
 // diag_only: a rejected LM step changed nothing but the damping, i.e. the diagonal slots
 void launch_sym_repack(const DeviceGraph& g, const SymGraph& sg, hipStream_t s, int diag_only = 0);
 size_t sym_lds_bytes(const SymGraph& sg);
+size_t sym_lin_lds_bytes(const SymGraph& sg);     // LDS of k_linearize_sym (staged poses + row sums + exchange buffer)
 // residual + Jacobians + J'J / J'r of every stored slot written into the symmetric tile form (off-diagonal blocks -> sg.val, diagonal
 // blocks -> g.Hdiag, gradient -> g.grad): an interior edge is evaluated once for both of its rows.  gate: as launch_linearize
 void launch_linearize_sym(const DeviceGraph& g, const SymGraph& sg, hipStream_t s, int gate = 0);
