@@ -1,4 +1,4 @@
-"""What rocprofv3 wraps for the C4-size evidence (profiles/r03_c4_*): BASELINE configs[3]'s graph (100 k poses / 1 M edges) on one
+"""What rocprofv3 wraps for the C4-size evidence (profiles/rNN_c4_*): BASELINE configs[3]'s graph (100 k poses / 1 M edges) on one
 GPU, `steps` LM iterations of the bench's PCG policy through the host-driven loop (graphs this large keep it), then the isolated
 kernels (pgo_time_kernel: 30 launches each of linearize / pcg_spmv / evaluate) so that every kernel of SURVEY 8d appears in the trace."""
 import os
@@ -17,7 +17,9 @@ opt = gpu.SolverOptions(max_num_iterations=2 ** 30, linear_solver_type=gpu.BLOCK
                         function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
 prob.solver_begin(opt)
 ran, done = prob.solver_step(steps)
-for k in ("linearize", "pcg_spmv", "evaluate"):
+# (a PCG session of this size keeps the normal equations in the symmetric tile form: its LM loop runs the *_sym kernels; the
+# incidence-slot kernels are timed next to them for the comparison)
+for k in ("sym_spmv", "sym_linearize", "linearize", "pcg_spmv", "evaluate"):
     prob.time_kernel(k, 30)
 s = prob.solver_end()
 print("C4 %d poses / %d edges: %d LM iterations, %d CG iterations, cost %.6e -> %.6e" % (

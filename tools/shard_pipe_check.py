@@ -40,13 +40,17 @@ def solve_sharded(g, world, opt_kw):
 n, e, world, its = (int(a) for a in (sys.argv[1:5] + ["20000", "150000", "8", "6"][len(sys.argv) - 1:]))
 g = ds.manhattan_se3(n, e, seed=20260930, loop_radius=3.0)
 opt = dict(max_num_iterations=its, linear_solver_type=pkg.BLOCK_JACOBI_PCG, pcg_cluster_poses=int(os.environ.get("CL", "2")))
-prob, poses = pkg.problem_from_graph(g)
-ref = pkg.solve(pkg.SolverOptions(**opt), prob)
-print("one rank   cg", list(ref.iterations["linear_solver_iterations"]), "cost %.9e" % ref.final_cost)
+# PGO_SHARD_TRACE_ONLY=1 (profiling): the sharded solve alone — no one-rank reference solve in the same kernel trace
+trace_only = os.environ.get("PGO_SHARD_TRACE_ONLY", "0") == "1"
+if not trace_only:
+    prob, poses = pkg.problem_from_graph(g)
+    ref = pkg.solve(pkg.SolverOptions(**opt), prob)
+    print("one rank   cg", list(ref.iterations["linear_solver_iterations"]), "cost %.9e" % ref.final_cost)
 for pipe in ("1", "0"):
-    os.environ["PGO_SHARD_PIPE"] = pipe      # (read once per process: only the first value counts -- run twice for both)
+    pipe = os.environ.get("PGO_SHARD_PIPE", pipe)      # (read once per process: only the first value counts -- run twice for both)
+    os.environ["PGO_SHARD_PIPE"] = pipe
     out = solve_sharded(g, world, opt)
     s, p = out[0]
     print("pipe=%s w=%d cg" % (pipe, world), list(s.iterations["linear_solver_iterations"]), "cost %.9e" % s.final_cost,
-          "max |dp| %.2e" % np.abs(p - poses).max(), "ranks identical", all(np.array_equal(out[0][1], o[1]) for o in out))
+          "" if trace_only else "max |dp| %.2e" % np.abs(p - poses).max(), "ranks identical", all(np.array_equal(out[0][1], o[1]) for o in out))
     break
