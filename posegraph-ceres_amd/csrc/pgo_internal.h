@@ -418,7 +418,6 @@ struct pgo_problem {
   DevBuf<int> sy_xlist, sy_chunk_base, sy_chunk_n, sy_src, sy_diag;
   bool sym_stale = true;            // the off-diagonal blocks were rewritten since the last repack (else only the damped diagonal slots are copied)
   DevBuf<uint32_t> sy_meta, sy_rinfo, sy_meta2, sy_rinfo2;
-  DevBuf<double> sy_lin_meas, sy_lin_W;
   bool sym_storage = false;         // this LM session keeps the normal equations in the symmetric tile form ONLY: linearisation, damping, the cluster
                                     // preconditioner and every product work on it (the incidence-slot blocks are not maintained)
   std::vector<int> h_cl_slot, h_sym_of_old;

@@ -100,7 +100,11 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   P->pipe_dirty = true;
   // symmetric tile form for the CG products: host-driven PCG of a large graph on one rank (pgo_sym.h)
   P->sym_active = false; P->sym_storage = false;
-  if (P->opt.linear_solver_type == PGO_BLOCK_JACOBI_PCG && !P->universal && !P->pipelined && sym_wanted(P)) {
+  // ... when the solve can run long enough to repay the form's construction (44 ms of host time at 100 k / 1 M against 0.7 ms saved
+  // per LM iteration of ~13 CG iterations: 64 iterations, or a tight forcing term whose CG runs are long); PGO_SYM=1 forces it
+  const char* sym_env = getenv("PGO_SYM");
+  const bool sym_pays = (sym_env && sym_env[0] == '1') || P->sym_ready || P->opt.max_num_iterations >= 64 || P->opt.eta <= 0.02;
+  if (P->opt.linear_solver_type == PGO_BLOCK_JACOBI_PCG && !P->universal && !P->pipelined && sym_pays && sym_wanted(P)) {
     rc = sym_prepare(P);
     if (rc) return rc;
     P->sym_active = P->sym_ready;

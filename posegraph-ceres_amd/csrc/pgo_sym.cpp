@@ -67,6 +67,11 @@ int sym_prepare(pgo_problem* P) {
   P->sym_built = true;
   P->sym_ready = false;
   const auto t0 = Clock::now();
+  const bool verbose = getenv("PGO_VERBOSE") != nullptr;
+  auto lap = [&, tl = Clock::now()](const char* what) mutable {
+    if (verbose) std::fprintf(stderr, "[pgo] sym_prepare: %-24s %.2f ms\n", what, 1e3 * seconds_since(tl));
+    tl = Clock::now();
+  };
   const int N = (int)P->pp.size(), E = (int)P->ia.size();
   hipStream_t s = P->stream;
   // adjacency (both directions)
@@ -85,7 +90,9 @@ int sym_prepare(pgo_problem* P) {
   if (getenv("PGO_SYM_TILES")) w_cap = std::max<long long>(64, (long long)((N + 2.0 * E) / (0.85 * atof(getenv("PGO_SYM_TILES")))));
   std::vector<int> part;
   int T0 = 0;
+  lap("adjacency");
   partition_rows(N, adj_ptr, adj, row_cap, w_cap, part, T0);
+  lap("partition");
   // compact tile ids, rows per tile ascending
   std::vector<int> tile_of(T0, -1);
   int T = 0;
@@ -116,129 +123,167 @@ int sym_prepare(pgo_problem* P) {
   { std::vector<int> f(inc_ptr.begin(), inc_ptr.end() - 1);
     for (int e = 0; e < E; ++e) { inc[f[P->ia[e]]++] = 2 * e; inc[f[P->ib[e]]++] = 2 * e + 1; } }
 
-  std::vector<pgo::SymTile> tiles(T);
-  std::vector<int> xlist, chunk_base, chunk_n, src_slot, diag_slot(N, 0);
-  std::vector<uint32_t> meta, rinfo, meta2, rinfo2;
-  std::vector<int> slot_edge;                // edge of every stored slot (-1: diagonal / padding)
-  int e_cap = 1;
-  std::vector<int> local(N, -1);             // pose -> LDS index inside the tile being built
-  int x_cap = 0;
-  long long interior_edges = 0, stored = 0;
-  struct Slot { int src; uint32_t m; int row, dst_row, edge; };   // m without vpos; dst_row: local row an interior slot's v goes to (-1 none)
-  std::vector<Slot> slots;
-  for (int t = 0; t < T; ++t) {
-    const std::vector<int>& rows = trow[t];
-    const int nr = (int)rows.size();
-    for (int i = 0; i < nr; ++i) local[rows[i]] = i;
-    // ghosts: far ends of cut edges, ascending pose id
+  // ---- per-tile layout, tiles in parallel (every index below is relative to the tile; offsets are added afterwards) ----
+  struct TileOut {
+    std::vector<int> xlist, chunk_n, src;        // src: per stored slot incl. chunk padding
+    std::vector<uint32_t> meta, meta2, rinfo, rinfo2;
+    std::vector<int> diag_local;                 // per row: stored slot of its diagonal block
+    int nr = 0, nx = 0, total = 0, L = 0, e_cap = 1;
+    long long interior = 0;
+    const char* unfit = nullptr;
+  };
+  std::vector<TileOut> outs(T);
+  struct Slot { int src; uint32_t m; int row, dst_row; };   // m without vpos; dst_row: local row an interior slot's v goes to (-1 none)
+  const int nthreads = std::max(1, std::min(pgo::HostPool::get().width(), std::min(16, T / 8 + 1)));
+  pgo::HostPool::get().run(nthreads, [&](int th) {
+    std::vector<int> local(N, -1);             // pose -> LDS index inside the tile being built
+    std::vector<Slot> slots;
     std::vector<int> ghosts;
-    for (int v : rows)
-      for (int j = inc_ptr[v]; j < inc_ptr[v + 1]; ++j) {
-        const int e = inc[j] >> 1, o = (inc[j] & 1) ? P->ia[e] : P->ib[e];
-        if (part[o] != t) ghosts.push_back(o);
+    std::vector<std::pair<int, int>> vs;       // (destination row, producing lane) of a chunk's v entries
+    for (int t = th; t < T; t += nthreads) {
+      TileOut& O = outs[t];
+      const std::vector<int>& rows = trow[t];
+      const int nr = (int)rows.size();
+      O.nr = nr;
+      for (int i = 0; i < nr; ++i) local[rows[i]] = i;
+      // ghosts: far ends of cut edges, ascending pose id
+      ghosts.clear();
+      for (int v : rows)
+        for (int j = inc_ptr[v]; j < inc_ptr[v + 1]; ++j) {
+          const int e = inc[j] >> 1, o = (inc[j] & 1) ? P->ia[e] : P->ib[e];
+          if (part[o] != t) ghosts.push_back(o);
+        }
+      std::sort(ghosts.begin(), ghosts.end());
+      ghosts.erase(std::unique(ghosts.begin(), ghosts.end()), ghosts.end());
+      const int nx = nr + (int)ghosts.size();
+      O.nx = nx;
+      auto reset_local = [&] { for (int v : rows) local[v] = -1; for (int gp : ghosts) local[gp] = -1; };
+      if (nx > pgo::SYM_X_MAX) { O.unfit = "stages too many columns"; reset_local(); continue; }
+      for (size_t gi = 0; gi < ghosts.size(); ++gi) local[ghosts[gi]] = nr + (int)gi;
+      O.xlist.assign(rows.begin(), rows.end());
+      O.xlist.insert(O.xlist.end(), ghosts.begin(), ghosts.end());
+      // stored slots, row after row: the diagonal, then the row's incidences in edge order (interior edges once, by the begin side)
+      slots.clear();
+      for (int i = 0; i < nr; ++i) {
+        const int v = rows[i];
+        slots.push_back(Slot{P->h_row_slot_begin[v], (uint32_t)i | ((uint32_t)pgo::SIDE_DIAG << 12) | ((uint32_t)i << 23), i, -1});
+        for (int j = inc_ptr[v]; j < inc_ptr[v + 1]; ++j) {
+          const int e = inc[j] >> 1, end_side = inc[j] & 1;
+          const int o = end_side ? P->ia[e] : P->ib[e];
+          const bool interior = part[o] == t;
+          if (interior && end_side) continue;
+          if (interior) ++O.interior;
+          slots.push_back(Slot{end_side ? end_slot[e] : beg_slot[e],
+                               (uint32_t)local[o] | ((uint32_t)(end_side ? pgo::SIDE_END : pgo::SIDE_BEGIN) << 12) | (interior ? (1u << 14) : 0u) | ((uint32_t)i << 23),
+                               i, interior ? local[o] : -1});
+        }
       }
-    std::sort(ghosts.begin(), ghosts.end());
-    ghosts.erase(std::unique(ghosts.begin(), ghosts.end()), ghosts.end());
-    const int nx = nr + (int)ghosts.size();
-    auto unfit = [&](const char* why) {
-      for (int v : rows) local[v] = -1;
-      for (int gpose : ghosts) local[gpose] = -1;
-      if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] sym: tile %d %s: the incidence-slot kernels stay\n", t, why);
-      return PGO_OK;
-    };
-    if (nx > pgo::SYM_X_MAX) return unfit("stages too many columns");
-    for (size_t gi = 0; gi < ghosts.size(); ++gi) local[ghosts[gi]] = nr + (int)gi;
-    x_cap = std::max(x_cap, nx);
-    // stored slots, row after row: the diagonal, then the row's incidences in edge order (interior edges once, by the begin side)
-    slots.clear();
-    for (int i = 0; i < nr; ++i) {
-      const int v = rows[i];
-      slots.push_back(Slot{P->h_row_slot_begin[v], (uint32_t)i | ((uint32_t)pgo::SIDE_DIAG << 12) | ((uint32_t)i << 23), i, -1, -1});
-      for (int j = inc_ptr[v]; j < inc_ptr[v + 1]; ++j) {
-        const int e = inc[j] >> 1, end_side = inc[j] & 1;
-        const int o = end_side ? P->ia[e] : P->ib[e];
-        const bool interior = part[o] == t;
-        if (interior && end_side) continue;
-        if (interior) ++interior_edges;
-        slots.push_back(Slot{end_side ? end_slot[e] : beg_slot[e],
-                             (uint32_t)local[o] | ((uint32_t)(end_side ? pgo::SIDE_END : pgo::SIDE_BEGIN) << 12) | (interior ? (1u << 14) : 0u) | ((uint32_t)i << 23),
-                             i, interior ? local[o] : -1, e});
-      }
-    }
-    const int total = (int)slots.size();
-    stored += total;
-    const int L = (total + pgo::SYM_LANES - 1) / pgo::SYM_LANES;
-    pgo::SymTile& TT = tiles[t];
-    TT.chunk0 = (int)chunk_base.size(); TT.nchunks = L; TT.x0 = (int)xlist.size(); TT.nx = nx; TT.nrows = nr;
-    TT.pad[0] = TT.pad[1] = 0; TT.total = total; TT.base0 = TT.n0 = TT.base1 = TT.n1 = 0;
-    for (int v : rows) xlist.push_back(v);
-    for (int gpose : ghosts) xlist.push_back(gpose);
-    std::vector<std::pair<int, int>> vs;          // (destination row, producing lane) of the chunk's v entries
-    for (int c = 0; c < L; ++c) {
-      const int lo = c * pgo::SYM_LANES, n = std::min((int)pgo::SYM_LANES, total - lo);
-      const int base = (int)meta.size();            // multiple of 64 by construction
-      chunk_base.push_back(base);
-      chunk_n.push_back(n);
-      if (c == 0) { TT.base0 = base; TT.n0 = n; }
-      if (c == 1) { TT.base1 = base; TT.n1 = n; }
-      const size_t padded = (size_t)(n + 63) / 64 * 64;
-      meta.resize(base + padded, 0u);
-      meta2.resize(base + padded, 0xFFFFFFFFu);
-      src_slot.resize(base + padded, -1);
-      slot_edge.resize(base + padded, -1);
-      const size_t ri0 = rinfo.size();
-      rinfo.resize(ri0 + pgo::SYM_LANES, 0u);
-      vs.clear();
-      for (int l = 0; l < n; ++l) {
-        const Slot& sl = slots[lo + l];
-        src_slot[base + l] = sl.src;
-        slot_edge[base + l] = sl.edge;
-        meta[base + l] = sl.m;
-        if (((sl.m >> 12) & 3u) == (uint32_t)pgo::SIDE_DIAG) diag_slot[rows[sl.row]] = base + l;
-        uint32_t& w = rinfo[ri0 + sl.row];           // u range of the slot's row: [ub, ub + uc)
-        if (((w >> 8) & 0x1FFu) == 0) w = (w & ~0xFFu) | (uint32_t)l;
-        w += 1u << 8;
-        if (sl.dst_row >= 0) vs.push_back({sl.dst_row, l});
-      }
-      std::sort(vs.begin(), vs.end());
-      for (size_t k = 0; k < vs.size(); ++k) {
-        meta[base + vs[k].second] |= (uint32_t)k << 15;
-        uint32_t& w = rinfo[ri0 + vs[k].first];
-        if ((w >> 25) == 0) w = (w & ~(0xFFu << 17)) | ((uint32_t)k << 17);
-        if ((w >> 25) == 127) return unfit("has a row that receives more than 127 mirrored products in one chunk");
-        w += 1u << 25;
-      }
-      // exchange entries of the linearisation (k_linearize_sym): per destination row, ascending: the tails of its (row, wave) runs,
-      // then the mirrored contributions it receives — contiguous, so the row's lane adds one range
-      {
-        const size_t r20 = rinfo2.size();
-        rinfo2.resize(r20 + pgo::SYM_LANES, 0u);
+      const int total = (int)slots.size();
+      O.total = total;
+      const int L = (total + pgo::SYM_LANES - 1) / pgo::SYM_LANES;
+      O.L = L;
+      O.diag_local.assign(nr, 0);
+      O.chunk_n.resize(L);
+      O.rinfo.assign((size_t)L * pgo::SYM_LANES, 0u);
+      O.rinfo2.assign((size_t)L * pgo::SYM_LANES, 0u);
+      const int padded_total = (L - 1) * pgo::SYM_LANES + (total - (L - 1) * pgo::SYM_LANES + 63) / 64 * 64;
+      O.meta.assign(padded_total, 0u);
+      O.meta2.assign(padded_total, 0xFFFFFFFFu);
+      O.src.assign(padded_total, -1);
+      for (int c = 0; c < L && !O.unfit; ++c) {
+        const int lo = c * pgo::SYM_LANES, n = std::min((int)pgo::SYM_LANES, total - lo);
+        const int base = lo;                           // relative to the tile (full chunks are 256 = 4 x 64 slots)
+        O.chunk_n[c] = n;
+        uint32_t* ri = &O.rinfo[(size_t)c * pgo::SYM_LANES];
+        vs.clear();
+        for (int l = 0; l < n; ++l) {
+          const Slot& sl = slots[lo + l];
+          O.src[base + l] = sl.src;
+          O.meta[base + l] = sl.m;
+          if (((sl.m >> 12) & 3u) == (uint32_t)pgo::SIDE_DIAG) O.diag_local[sl.row] = base + l;
+          uint32_t& w = ri[sl.row];                    // u range of the slot's row: [ub, ub + uc)
+          if (((w >> 8) & 0x1FFu) == 0) w = (w & ~0xFFu) | (uint32_t)l;
+          w += 1u << 8;
+          if (sl.dst_row >= 0) vs.push_back({sl.dst_row, l});
+        }
+        std::sort(vs.begin(), vs.end());
+        for (size_t k = 0; k < vs.size(); ++k) {
+          O.meta[base + vs[k].second] |= (uint32_t)k << 15;
+          uint32_t& w = ri[vs[k].first];
+          if ((w >> 25) == 0) w = (w & ~(0xFFu << 17)) | ((uint32_t)k << 17);
+          if ((w >> 25) == 127) { O.unfit = "has a row that receives more than 127 mirrored products in one chunk"; break; }
+          w += 1u << 25;
+        }
+        if (O.unfit) break;
+        // exchange entries of the linearisation (k_linearize_sym): per destination row, ascending: the tails of its (row, wave)
+        // runs, then the mirrored contributions it receives — contiguous, so the row's lanes add one range
+        uint32_t* r2 = &O.rinfo2[(size_t)c * pgo::SYM_LANES];
         int pos = 0;
         size_t kv = 0;
         for (int r = 0; r < nr; ++r) {
-          const uint32_t w = rinfo[ri0 + r];
+          const uint32_t w = ri[r];
           const int ub = (int)(w & 0xFFu), uc = (int)((w >> 8) & 0x1FFu);
           const int e0 = pos;
           if (uc > 0) {
             const int last = ub + uc - 1;
             for (int wv = ub >> 6; wv <= (last >> 6); ++wv) {
               const int tail = std::min(wv * 64 + 63, last);
-              meta2[base + tail] = (meta2[base + tail] & 0xFFFF0000u) | (uint32_t)pos++;
+              O.meta2[base + tail] = (O.meta2[base + tail] & 0xFFFF0000u) | (uint32_t)pos++;
             }
           }
           while (kv < vs.size() && vs[kv].first == r) {
             const int l = vs[kv].second;
-            meta2[base + l] = (meta2[base + l] & 0x0000FFFFu) | ((uint32_t)pos++ << 16);
+            O.meta2[base + l] = (O.meta2[base + l] & 0x0000FFFFu) | ((uint32_t)pos++ << 16);
             ++kv;
           }
-          rinfo2[r20 + r] = (uint32_t)e0 | ((uint32_t)(pos - e0) << 16);
+          r2[r] = (uint32_t)e0 | ((uint32_t)(pos - e0) << 16);
         }
-        e_cap = std::max(e_cap, pos);
+        O.e_cap = std::max(O.e_cap, pos);
       }
+      reset_local();
     }
-    for (int v : rows) local[v] = -1;
-    for (int gpose : ghosts) local[gpose] = -1;
+  });
+  // ---- offsets and the global arrays ----
+  std::vector<pgo::SymTile> tiles(T);
+  std::vector<int> xlist, chunk_base, chunk_n, src_slot, diag_slot(N, 0);
+  std::vector<uint32_t> meta, rinfo, meta2, rinfo2;
+  int e_cap = 1, x_cap = 0;
+  long long interior_edges = 0, stored = 0;
+  {
+    size_t nxs = 0, nsl = 0, nch = 0;
+    for (int t = 0; t < T; ++t) {
+      const TileOut& O = outs[t];
+      if (O.unfit) {
+        if (verbose) std::fprintf(stderr, "[pgo] sym: tile %d %s: the incidence-slot kernels stay\n", t, O.unfit);
+        return PGO_OK;
+      }
+      pgo::SymTile& TT = tiles[t];
+      TT.chunk0 = (int)nch; TT.nchunks = O.L; TT.x0 = (int)nxs; TT.nx = O.nx; TT.nrows = O.nr; TT.total = O.total;
+      TT.base0 = (int)nsl; TT.n0 = O.L > 0 ? O.chunk_n[0] : 0;
+      TT.base1 = (int)nsl + pgo::SYM_LANES; TT.n1 = O.L > 1 ? O.chunk_n[1] : 0;
+      TT.pad[0] = TT.pad[1] = 0;
+      nxs += O.xlist.size(); nsl += O.meta.size(); nch += O.L;
+      x_cap = std::max(x_cap, O.nx); e_cap = std::max(e_cap, O.e_cap);
+      interior_edges += O.interior; stored += O.total;
+    }
+    xlist.resize(nxs); meta.resize(nsl); meta2.resize(nsl); src_slot.resize(nsl);
+    chunk_base.resize(nch); chunk_n.resize(nch); rinfo.resize(nch * pgo::SYM_LANES); rinfo2.resize(nch * pgo::SYM_LANES);
+    pgo::HostPool::get().run(nthreads, [&](int th) {
+      for (int t = th; t < T; t += nthreads) {
+        const TileOut& O = outs[t];
+        const pgo::SymTile& TT = tiles[t];
+        std::copy(O.xlist.begin(), O.xlist.end(), xlist.begin() + TT.x0);
+        std::copy(O.meta.begin(), O.meta.end(), meta.begin() + TT.base0);
+        std::copy(O.meta2.begin(), O.meta2.end(), meta2.begin() + TT.base0);
+        std::copy(O.src.begin(), O.src.end(), src_slot.begin() + TT.base0);
+        std::copy(O.rinfo.begin(), O.rinfo.end(), rinfo.begin() + (size_t)TT.chunk0 * pgo::SYM_LANES);
+        std::copy(O.rinfo2.begin(), O.rinfo2.end(), rinfo2.begin() + (size_t)TT.chunk0 * pgo::SYM_LANES);
+        for (int c = 0; c < O.L; ++c) { chunk_base[TT.chunk0 + c] = TT.base0 + c * pgo::SYM_LANES; chunk_n[TT.chunk0 + c] = O.chunk_n[c]; }
+        for (int i = 0; i < O.nr; ++i) diag_slot[trow[t][i]] = TT.base0 + O.diag_local[i];
+      }
+    });
   }
+  lap("tile layout");
   const int n_slots = (int)meta.size();
   if (T > P->g.pq_cap) {       // the p'q partials of the tiles ride in the slots of the row partition's work-groups
     if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] sym: %d tiles > %d partial-sum slots: the incidence-slot kernels stay\n", T, P->g.pq_cap);
@@ -255,31 +300,6 @@ int sym_prepare(pgo_problem* P) {
   HIP_TRY(P->sy_rinfo.upload(rinfo, s));
   HIP_TRY(P->sy_src.upload(src_slot, s));
   HIP_TRY(P->sy_diag.upload(diag_slot, s));
-  // the linearisation's inputs in stored-slot order (component major, as the row kernels keep them in incidence-slot order)
-  {
-    HostArray lm, lw;
-    lm.resize((size_t)7 * n_slots);
-    if (P->has_info) lw.resize((size_t)21 * n_slots);
-    parallel_for(n_slots, [&](int lo, int hi) {
-      for (int t = lo; t < hi; ++t) {
-        const int e = slot_edge[t];
-        for (int c = 0; c < 7; ++c) lm[(size_t)c * n_slots + t] = e < 0 ? (c == 6 ? 1.0 : 0.0) : P->meas[(size_t)7 * e + c];
-        if (!P->has_info) continue;
-        if (e < 0) { for (int k = 0; k < 21; ++k) lw[(size_t)k * n_slots + t] = 0.0; continue; }
-        const double* L = &P->sqrt_info[(size_t)36 * e];
-        int k = 0;
-        for (int i = 0; i < 6; ++i)
-          for (int j = i; j < 6; ++j) {
-            double w = 0;
-            for (int r = 0; r < 6; ++r) w += L[6 * r + i] * L[6 * r + j];      // W = L^T L, as prepare() forms it
-            lw[(size_t)k * n_slots + t] = w;
-            ++k;
-          }
-      }
-    });
-    HIP_TRY(P->sy_lin_meas.upload(lm.data(), lm.n, s));
-    HIP_TRY(P->sy_lin_W.upload(lw.data(), lw.n, s));
-  }
   HIP_TRY(P->sy_meta2.upload(meta2, s));
   HIP_TRY(P->sy_rinfo2.upload(rinfo2, s));
   HIP_TRY(P->sy_val.alloc((size_t)n_slots * 36));
@@ -288,8 +308,9 @@ int sym_prepare(pgo_problem* P) {
   sg.n_tiles = T; sg.n_chunks = (int)chunk_base.size(); sg.n_slots = n_slots; sg.x_cap = x_cap;
   sg.tile = P->sy_tile.p; sg.xlist = P->sy_xlist.p; sg.chunk_base = P->sy_chunk_base.p; sg.chunk_n = P->sy_chunk_n.p;
   sg.meta = P->sy_meta.p; sg.rinfo = P->sy_rinfo.p; sg.src_slot = P->sy_src.p; sg.diag_slot = P->sy_diag.p;
-  sg.lin_meas = P->sy_lin_meas.p; sg.lin_W = P->sy_lin_W.p; sg.meta2 = P->sy_meta2.p; sg.rinfo2 = P->sy_rinfo2.p; sg.e_cap = e_cap; sg.val = P->sy_val.p;
+  sg.meta2 = P->sy_meta2.p; sg.rinfo2 = P->sy_rinfo2.p; sg.e_cap = e_cap; sg.val = P->sy_val.p;
   HIP_TRY(hipStreamSynchronize(s));
+  lap("index uploads + sync");
   P->h_sym_of_old.assign(P->g.n_slots, -1);
   for (int t = 0; t < n_slots; ++t) if (src_slot[t] >= 0) P->h_sym_of_old[src_slot[t]] = t;
   P->sym_ready = true;

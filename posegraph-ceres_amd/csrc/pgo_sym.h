@@ -54,8 +54,8 @@ struct SymGraph {
   const int* diag_slot;               // [N] stored slot of every row's diagonal block
   double* val;                        // [n_slots * 36] blocks, bsr_index() layout
   // ---- linearisation straight into this form (k_linearize_sym) ----
-  const double* lin_meas;             // [7][n_slots] measurement of the slot's edge, component major
-  const double* lin_W;                // [21][n_slots] upper triangle of L^T L (null: identity information)
+  // (measurement and information of a slot's edge are read from the incidence-slot arrays g.smeas / g.sW at src_slot: the stored
+  // slots of a tile map to ascending incidence slots, so the gathers are nearly contiguous — no second copy, nothing to upload)
   const uint32_t* meta2;              // [n_slots] tail_pos | vpos2 << 16: where the (row, wave) run sum / the mirrored 27 values go in the chunk's exchange buffer (0xFFFF: none)
   const uint32_t* rinfo2;             // [n_chunks * SYM_LANES] ebeg | ecnt << 16: the exchange entries of the tile's r-th row in the chunk
   int e_cap;                          // max exchange entries of a chunk

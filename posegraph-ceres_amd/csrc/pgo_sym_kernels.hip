@@ -408,14 +408,15 @@ __global__ __launch_bounds__(2 * SYM_LANES) void k_linearize_sym(DeviceGraph g, 
   }
   for (int i = tid; i < LIN_NV * SYM_LANES; i += 2 * SYM_LANES) accl[i] = 0.0;
   __syncthreads();
-  const size_t ns = (size_t)sg.n_slots;
+  const size_t ns = (size_t)g.n_slots;       // measurement / information: the incidence-slot arrays, gathered at src_slot
   auto pose_at = [&](int e) { const double* p = poses + LIN_POSE * e; return PoseRec{V3{p[0], p[1], p[2]}, Q4{p[3], p[4], p[5], p[6]}}; };
   for (int c = 0; c < T.nchunks; ++c) {
     const int ci = T.chunk0 + c;
     const int n = min((int)SYM_LANES, T.total - SYM_LANES * c), t = T.base0 + SYM_LANES * c + l;     // (no table look-up ahead of the slot loads)
     const uint32_t rin = sg.rinfo2[(size_t)ci * SYM_LANES + l];
     uint32_t meta = 0, m2 = 0xFFFFFFFFu;
-    if (l < n) { meta = sg.meta[t]; m2 = sg.meta2[t]; }
+    int src = 0;
+    if (l < n) { meta = sg.meta[t]; m2 = sg.meta2[t]; src = sg.src_slot[t]; }
     const int xcol = (int)(meta & 0xFFFu), side = (int)((meta >> 12) & 3u);
     const int srow = (int)((meta >> 23) & 0xFFu);
     const bool edge_slot = l < n && side != SIDE_DIAG;
@@ -427,10 +428,11 @@ __global__ __launch_bounds__(2 * SYM_LANES) void k_linearize_sym(DeviceGraph g, 
       if (edge_slot && !(g.debug & 4096)) {
         const int ea = side == SIDE_BEGIN ? srow : xcol, eb = side == SIDE_BEGIN ? xcol : srow;
         const PoseRec A = pose_at(ea), Bp = pose_at(eb);
-        const V3 mp{sg.lin_meas[t], sg.lin_meas[ns + t], sg.lin_meas[2 * ns + t]};
-        const Q4 mq{sg.lin_meas[3 * ns + t], sg.lin_meas[4 * ns + t], sg.lin_meas[5 * ns + t], sg.lin_meas[6 * ns + t]};
+        const size_t so = (size_t)src;
+        const V3 mp{g.smeas[so], g.smeas[ns + so], g.smeas[2 * ns + so]};
+        const Q4 mq{g.smeas[3 * ns + so], g.smeas[4 * ns + so], g.smeas[5 * ns + so], g.smeas[6 * ns + so]};
         double wv[36];
-        lin_slot<INFO>(g, side, ids[srow], ids[xcol], A, Bp, mp, mq, sg.lin_W, ns, (size_t)t, wv, v);
+        lin_slot<INFO>(g, side, ids[srow], ids[xcol], A, Bp, mp, mq, g.sW, ns, so, wv, v);
         double2* out = reinterpret_cast<double2*>(sg.val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
 #pragma unroll
         for (int kk = 0; kk < (INFO != 1 ? (int)BLK_PAIRS_PACKED : (int)BLK_PAIRS_FULL); ++kk) out[(size_t)kk * 64] = double2{wv[2 * kk], wv[2 * kk + 1]};
@@ -445,10 +447,11 @@ __global__ __launch_bounds__(2 * SYM_LANES) void k_linearize_sym(DeviceGraph g, 
     } else if (edge_slot && (meta & (1u << 14)) && !(g.debug & 8192)) {
       // interior (stored in the BEGIN orientation): the END-side incidence of the same edge, for the other row
       const PoseRec A = pose_at(srow), Bp = pose_at(xcol);
-      const V3 mp{sg.lin_meas[t], sg.lin_meas[ns + t], sg.lin_meas[2 * ns + t]};
-      const Q4 mq{sg.lin_meas[3 * ns + t], sg.lin_meas[4 * ns + t], sg.lin_meas[5 * ns + t], sg.lin_meas[6 * ns + t]};
+      const size_t so = (size_t)src;
+      const V3 mp{g.smeas[so], g.smeas[ns + so], g.smeas[2 * ns + so]};
+      const Q4 mq{g.smeas[3 * ns + so], g.smeas[4 * ns + so], g.smeas[5 * ns + so], g.smeas[6 * ns + so]};
       double wm[36], vm[LIN_NV];
-      lin_slot<INFO>(g, SIDE_END, ids[xcol], ids[srow], A, Bp, mp, mq, sg.lin_W, ns, (size_t)t, wm, vm);
+      lin_slot<INFO>(g, SIDE_END, ids[xcol], ids[srow], A, Bp, mp, mq, g.sW, ns, so, wm, vm);
       const int vp = (int)(m2 >> 16);
 #pragma unroll
       for (int k = 0; k < LIN_NV; ++k) exch[(size_t)vp * LIN_NV + k] = vm[k];
