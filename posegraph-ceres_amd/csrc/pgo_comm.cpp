@@ -49,6 +49,17 @@ struct LoopbackComm : Comm {
     if (ev_ready) (void)hipEventDestroy(ev_ready);
     if (ev_done) (void)hipEventDestroy(ev_done);
   }
+  // all virtual ranks live in one process on one GPU: a peer's device pointer is simply valid here
+  int peer_table(void* const mine[3], void** out, const char** what) override {
+    { std::lock_guard<std::mutex> lk(g->mu);
+      if (g->peer_ptrs.size() != (size_t)3 * world) g->peer_ptrs.assign((size_t)3 * world, nullptr);
+      for (int k = 0; k < 3; ++k) g->peer_ptrs[3 * rank + k] = mine[k]; }
+    if (!g->barrier()) { *what = "a peer rank failed"; return -1; }
+    { std::lock_guard<std::mutex> lk(g->mu);
+      for (int i = 0; i < 3 * world; ++i) out[i] = g->peer_ptrs[i]; }
+    if (!g->barrier()) { *what = "a peer rank failed"; return -1; }     // everybody has read the table before anybody publishes again
+    return 0;
+  }
   int all_gather(double* buf, size_t seg, hipStream_t s, const char** what) override {
     hipError_t e;
     if (!ev_ready && (e = hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming)) != hipSuccess) return fail(what, "hipEventCreate", e);

@@ -20,6 +20,10 @@ struct Comm {
   // returns hipSuccess-like 0 or a negative value; `what` receives a static description on failure
   virtual int all_gather(double* buf, size_t seg_doubles, hipStream_t s, const char** what) = 0;
   virtual bool capturable() const = 0;
+  // Device-initiated exchange (pgo_kernels.h DeviceGraph::peer_tab): every rank publishes three device pointers (its two exchange
+  // buffers and its flag array) and receives everybody's, `out[3 * rank + k]`; a collective call.  Returns 0, or -1 when the
+  // transport cannot give kernels access to peer memory (then the all-gather above stays in use).
+  virtual int peer_table(void* const mine[3], void** out, const char** what) { (void)mine; (void)out; *what = "not supported by this transport"; return -1; }
 };
 
 struct LoopbackGroup {
@@ -30,6 +34,7 @@ struct LoopbackGroup {
   int arrived = 0;
   long long generation = 0;
   std::vector<double*> bufs;
+  std::vector<void*> peer_ptrs;      // 3 per rank (peer_table)
   std::vector<hipEvent_t> ready, done, garbage;
   ~LoopbackGroup() { for (hipEvent_t e : garbage) (void)hipEventDestroy(e); }
   bool aborted = false;

@@ -339,6 +339,12 @@ struct pgo_problem {
       d_part_rr, d_part_bb, d_part_misc, d_tmp_a, d_tmp_b, d_tmp_c, d_cg_u, d_cg_w, d_cg_s, d_cg_qq, d_pipe_a, d_pipe_b, d_pipe_x;
   DevBuf<pgo::CgState> d_cg;
   DevBuf<long long> d_oplog;        // PGO_UNI_OPLOG=<file>: per-launch operation log of k_uni_s (DeviceGraph::oplog), appended to the file at pgo_solver_end
+  // device-initiated exchange of the owner-only CG (DeviceGraph::peer_tab): the table of every rank's buffers, this rank's flags, the
+  // global number of the last producing launch (the same on every rank: the launch sequences are replicated)
+  DevBuf<void*> d_peer_tab;
+  DevBuf<unsigned long long> d_peer_flags;
+  unsigned long long peer_gseq = 0;
+  bool peer_dirty = false;
   bool force_standard_cg = false;   // pgo_linear_solve (one linear system, every rank reads the whole x): the replicated standard CG even on several ranks
   // spare set of the linearisation (blocks, diagonal blocks, gradient): the candidate point is linearised into it right behind
   // the step tail, before the host has decided; an accepted step swaps the sets (one rank, eager enqueue)
@@ -473,6 +479,7 @@ int damping_all(pgo_problem* P, double radius, double min_diag, double max_diag,
 int cg_iteration(pgo_problem* P, const pgo::DeviceGraph& g, const pgo::CgParams& prm, int odd, bool refresh);
 int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd, bool refresh);
 int prepare(pgo_problem* P);
+int peer_direct_setup(pgo_problem* P);
 bool sym_wanted(const pgo_problem* P);     // pgo_sym.cpp
 pgo::DeviceGraph sym_view(const pgo_problem* P);   // P->g with the block storage, the diagonal slots and the cluster lists of the symmetric form
 int sym_enter_storage(pgo_problem* P);

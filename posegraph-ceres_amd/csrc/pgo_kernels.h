@@ -191,6 +191,13 @@ struct DeviceGraph {
   double* cg_u; double* cg_w; double* cg_s; double* cg_qq;
   double* pipe_buf[2];
   int pipe_seg;
+  // Device-initiated exchange of the owner-only CG (null: the host enqueues an all-gather between the launches).  peer_tab[3 r + k]:
+  // rank r's pipe_buf[0], pipe_buf[1], peer_flags.  A producing launch stores its segment into EVERY rank's buffer; its one-work-group
+  // tail (k_pipe_fold / k_peer_signal) adds the rank's sums, then — release at system scope — writes the launch's global sequence
+  // number into peer_flags[this rank] of every rank and waits until its own flag array shows that number from everybody: the next
+  // launch finds every segment in place and nobody still reading the buffer it will overwrite.  No host, no collective launch.
+  void* const* peer_tab;
+  unsigned long long* peer_flags;     // [world] this rank's flag array (device)
   int pairs_whole;    // the row partition keeps poses 2i, 2i + 1 in one single-chunk work-group (several ranks: prepare() sees to it)
   // partial sums
   double* part_rz;    // [2][n_part]
@@ -288,7 +295,8 @@ bool uni_supported(const DeviceGraph& g);
 bool pipe_supported(const DeviceGraph& g, const CgParams& p, int cluster);
 void launch_hdiag6(const DeviceGraph& g, double* buf, int phase, hipStream_t s);   // diagonals of the diagonal blocks: owned rows into buf (0) / other rows out of it (1)
 void launch_pipe_init(const DeviceGraph& g, hipStream_t s);
-void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, hipStream_t s);
+void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, hipStream_t s, unsigned long long gseq = 0);   // gseq: device-initiated exchange, global number of this producing launch
+void launch_peer_signal(const DeviceGraph& g, unsigned long long gseq, hipStream_t s);   // ... behind k_pipe_init
 void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s);
 void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s, int mode = 0);   // mode: see k_pcg_update
 void launch_spmv_refresh(const DeviceGraph& g, hipStream_t s, int on_the_fly = 0, int it_odd = 0);

@@ -2072,7 +2072,9 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_pipe_init(DeviceGraph g) {
 #pragma unroll
       for (int k = 0; k < DIM; ++k) u += Mi[k] * rv[k];
       g.cg_u[idx] = u;
-      g.pipe_buf[0][pipe_index(g, row, idx - 6 * row)] = u;
+      const size_t pi = pipe_index(g, row, idx - 6 * row);
+      if (g.peer_tab) { for (int rk = 0; rk < g.world; ++rk) static_cast<double*>(g.peer_tab[3 * rk])[pi] = u; }
+      else g.pipe_buf[0][pi] = u;
     }
     __syncthreads();
   }
@@ -2264,7 +2266,9 @@ __global__ __launch_bounds__(256) void k_pipe_cg(DeviceGraph g, CgParams prm, in
     double mn = 0.0;
 #pragma unroll
     for (int k = 0; k < DIM / 2; ++k) mn += mi[k].x * wv[2 * k] + mi[k].y * wv[2 * k + 1];
-    wr[pipe_index(g, r0 + idx / 6, idx % 6)] = mn;
+    const size_t pi = pipe_index(g, r0 + idx / 6, idx % 6);
+    if (g.peer_tab) { for (int rk = 0; rk < g.world; ++rk) static_cast<double*>(g.peer_tab[3 * rk + ws])[pi] = mn; }
+    else wr[pi] = mn;
   }
   // this rank's three sums: per work-group partials here, folded by k_pipe_fold (one work-group, behind this launch) — the exchange
   // carries three numbers per rank.  (A ticket for the last work-group to fold them cost more than the launch: > 1000
@@ -2272,17 +2276,42 @@ __global__ __launch_bounds__(256) void k_pipe_cg(DeviceGraph g, CgParams prm, in
   block_sum_w<3>(acc, scratch, B / 64);
   if (tid == 0) { g.part_rz[wg] = acc[0]; g.part_q[wg] = acc[1]; g.part_rr[wg] = acc[2]; }
 }
-__global__ __launch_bounds__(256) void k_pipe_fold(DeviceGraph g, int seq) {
+// device-initiated exchange: "this rank's launch gseq has stored everything" to every rank, then wait for everybody's (one lane)
+__device__ __forceinline__ void peer_signal_and_wait(const DeviceGraph& g, unsigned long long gseq) {
+  __threadfence_system();
+  for (int rk = 0; rk < g.world; ++rk)
+    __hip_atomic_store(static_cast<unsigned long long*>(g.peer_tab[3 * rk + 2]) + g.rank, gseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // (a peer that never signals — e.g. virtual ranks whose streams share one hardware queue, so that this spinning launch blocks the
+  // very kernel it waits for — must not hang the device: after 2 s of the 100 MHz clock the CG is stopped with the "broke down"
+  // status, which the LM loop reports as a linear-solver failure)
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int rk = 0; rk < g.world; ++rk)
+    while (__hip_atomic_load(g.peer_flags + rk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < gseq) {
+      __builtin_amdgcn_s_sleep(2);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { g.cg->status = 2; g.cg->done = 1; atomicOr(&g.flags[3], 1); return; }
+    }
+}
+__global__ __launch_bounds__(256) void k_pipe_fold(DeviceGraph g, int seq, unsigned long long gseq) {
   __shared__ double scratch[16];
-  if (g.cg->done) return;
+  if (g.cg->done) return;       // (the same decision on every rank: nobody waits for this launch's number)
   double t3[3] = {0.0, 0.0, 0.0};
   for (int i = threadIdx.x; i < g.n_wg; i += 256) { t3[0] += g.part_rz[i]; t3[1] += g.part_q[i]; t3[2] += g.part_rr[i]; }
   block_sum<3>(t3, scratch);
   if (threadIdx.x == 0) {
-    double* pp = g.pipe_buf[(seq & 1) ^ 1] + (size_t)g.rank * g.pipe_seg + (size_t)g.rows_per * 6;
-    pp[0] = t3[0]; pp[1] = t3[1]; pp[2] = t3[2];
+    const size_t off = (size_t)g.rank * g.pipe_seg + (size_t)g.rows_per * 6;
+    if (g.peer_tab) {
+      for (int rk = 0; rk < g.world; ++rk) {
+        double* pp = static_cast<double*>(g.peer_tab[3 * rk + ((seq & 1) ^ 1)]) + off;
+        pp[0] = t3[0]; pp[1] = t3[1]; pp[2] = t3[2];
+      }
+      peer_signal_and_wait(g, gseq);
+    } else {
+      double* pp = g.pipe_buf[(seq & 1) ^ 1] + off;
+      pp[0] = t3[0]; pp[1] = t3[1]; pp[2] = t3[2];
+    }
   }
 }
+__global__ void k_peer_signal(DeviceGraph g, unsigned long long gseq) { peer_signal_and_wait(g, gseq); }
 
 // Several ranks, owner-only CG: of the other ranks' diagonal blocks only the six diagonal entries are needed anywhere (column
 // scaling, LM damping, the model change of the step tail), so those travel — 6 doubles per pose instead of 36.  phase 0: the
@@ -2567,14 +2596,15 @@ void launch_pipe_init(const DeviceGraph& g, hipStream_t s) {
   if (g.cluster == 2) hipLaunchKernelGGL(k_pipe_init<2>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
   else hipLaunchKernelGGL(k_pipe_init<1>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
 }
-void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, hipStream_t s) {
+void launch_peer_signal(const DeviceGraph& g, unsigned long long gseq, hipStream_t s) { hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(1), 0, s, g, gseq); }
+void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, hipStream_t s, unsigned long long gseq) {
   const size_t lds = ((size_t)(SPMV_LDS_STRIDE + 6) * g.block + 8) * sizeof(double);
   const dim3 grid(mode ? 1 : g.n_wg);
 #define PGO_PIPE(PK) do { if (g.cluster == 2) hipLaunchKernelGGL((k_pipe_cg<PK, 2>), grid, dim3(g.block), lds, s, g, p, seq, mode); \
                           else hipLaunchKernelGGL((k_pipe_cg<PK, 1>), grid, dim3(g.block), lds, s, g, p, seq, mode); } while (0)
   if (g.blk_packed) PGO_PIPE(true); else PGO_PIPE(false);
 #undef PGO_PIPE
-  if (mode == 0) hipLaunchKernelGGL(k_pipe_fold, dim3(1), dim3(256), 0, s, g, seq);
+  if (mode == 0) hipLaunchKernelGGL(k_pipe_fold, dim3(1), dim3(256), 0, s, g, seq, gseq);
 }
 void launch_lm_budget(const DeviceGraph& g, int decisions, hipStream_t s) { hipLaunchKernelGGL(k_lm_budget, dim3(1), dim3(1), 0, s, g, decisions); }
 void launch_lm_publish(const DeviceGraph& g, hipStream_t s) { hipLaunchKernelGGL(k_lm_publish, dim3(1), dim3(1), 0, s, g); }

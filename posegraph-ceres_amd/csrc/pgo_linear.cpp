@@ -82,6 +82,7 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool wi
     // owner-only CG: one launch and one all-gather per iteration (launch seq = iteration index + 1, pipe_begin() ran seq 0)
     for (int i = 0; i < batch; ++i) {
       const int seq = start_it + i;
+      if (P->g.peer_tab) { pgo::launch_pipe_cg(P->g, prm, seq, 0, s, ++P->peer_gseq); continue; }
       pgo::launch_pipe_cg(P->g, prm, seq, 0, s);
       int rc = exchange(P, P->g.pipe_buf[(seq & 1) ^ 1], (size_t)P->g.pipe_seg);
       if (rc) return rc;
@@ -170,6 +171,11 @@ int pcg_begin(pgo_problem* P, const pgo::CgParams& prm) {
     return PGO_OK;
   }
   pgo::launch_pipe_init(P->g, s);
+  if (P->g.peer_tab) {       // device-initiated exchange: the kernels store into every rank's buffer and signal each other
+    pgo::launch_peer_signal(P->g, ++P->peer_gseq, s);
+    pgo::launch_pipe_cg(P->g, prm, 0, 0, s, ++P->peer_gseq);
+    return PGO_OK;
+  }
   int rc = exchange(P, P->g.pipe_buf[0], (size_t)P->g.pipe_seg);
   if (rc) return rc;
   pgo::launch_pipe_cg(P->g, prm, 0, 0, s);

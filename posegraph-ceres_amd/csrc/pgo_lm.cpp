@@ -40,6 +40,10 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   int rc = prepare(P);
   P->want_direct = false;
   if (rc) return rc;
+  rc = peer_direct_setup(P);
+  if (rc) return rc;
+  if (getenv("PGO_VERBOSE") && P->g.world > 1)
+    std::fprintf(stderr, "[pgo] rank %d of %d: pairs_whole %d, exchange %s\n", P->g.rank, P->g.world, P->g.pairs_whole, P->g.peer_tab ? "by the kernels (peer table)" : "all-gather");
   P->opt = *options;
   LmState& L = P->lm;
   const double t_setup = L.t_setup;

@@ -113,7 +113,7 @@ int cg_iteration(pgo_problem* P, const pgo::DeviceGraph& g, const pgo::CgParams&
 int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd, bool refresh) { return cg_iteration(P, P->g, prm, odd, refresh); }
 
 int choose_block(long long total_slots) {
-  static const int env_block = getenv("PGO_BLOCK") ? atoi(getenv("PGO_BLOCK")) : 0;   // tuning experiments: 64, 128 or 256
+  const int env_block = getenv("PGO_BLOCK") ? atoi(getenv("PGO_BLOCK")) : 0;   // tuning experiments / tests: 64, 128 or 256 (read per call)
   if (env_block == 64 || env_block == 128 || env_block == 256) return env_block;
   if (total_slots >= 256LL * 512) return 256;
   if (total_slots >= 128LL * 384) return 128;
@@ -392,6 +392,8 @@ int prepare(pgo_problem* P) {
   g.part_rr = P->d_part_rr.p; g.part_bb = P->d_part_bb.p; g.part_misc = P->d_part_misc.p;
   g.cg_u = P->d_cg_u.p; g.cg_w = P->d_cg_w.p; g.cg_s = P->d_cg_s.p; g.cg_qq = P->d_cg_qq.p;
   g.pipe_buf[0] = P->d_pipe_a.p; g.pipe_buf[1] = P->d_pipe_b.p; g.pipe_seg = pipe_seg;
+  g.peer_tab = nullptr; g.peer_flags = nullptr;
+  P->peer_dirty = true;       // (the table is exchanged by peer_direct_setup(), outside this function's upload scope: it is a collective call)
   g.pairs_whole = pairs_whole ? 1 : 0;
   g.n_part = n_part; g.n_vec_wg = n_vec_wg; g.n_edge_wg = n_edge_wg; g.n_pose_wg = n_pose_wg;
   g.cg = P->d_cg.p; g.flags = P->d_flags.p;
@@ -409,6 +411,40 @@ int prepare(pgo_problem* P) {
   lap("device buffers");
   P->topo_dirty = false;
   P->lm.t_setup = seconds_since(t0);
+  return PGO_OK;
+}
+
+// Device-initiated exchange where the transport can hand kernels the peers' buffers (the loopback transport; over RCCL the buffers
+// would have to be fine-grained IPC allocations: not built, the all-gather stays).  A COLLECTIVE call: every rank makes it after
+// its prepare() (never inside it: prepare() holds the process-wide staging buffers while it uploads, and a rank waiting for its
+// peers there would keep them from ever arriving).
+int peer_direct_setup(pgo_problem* P) {
+  if (!P->peer_dirty) return PGO_OK;
+  P->peer_dirty = false;
+  pgo::DeviceGraph& g = P->g;
+  const int world = g.world;
+  hipStream_t s = P->stream;
+  g.peer_tab = nullptr; g.peer_flags = nullptr;
+  if (world > 1 && P->comm && P->d_pipe_a.p) {
+    // Opt-in (PGO_PEER_DIRECT=1): virtual ranks are streams of ONE device, and streams that share a hardware queue (ROCm hands out
+    // GPU_MAX_HW_QUEUES = 4 per process by default) can put a waiting launch in front of the kernel it waits for — that only ends
+    // by the wait's time-out.  On real ranks (one device each) the question does not arise.  Every rank reads the same environment.
+    const char* pd = getenv("PGO_PEER_DIRECT");
+    if (pd && pd[0] == '1') {
+      HIP_TRY(P->d_peer_flags.alloc((size_t)world));
+      HIP_TRY(P->d_peer_flags.zero(s));
+      HIP_TRY(hipStreamSynchronize(s));
+      void* mine[3] = {P->d_pipe_a.p, P->d_pipe_b.p, P->d_peer_flags.p};
+      std::vector<void*> tab((size_t)3 * world, nullptr);
+      const char* what = "";
+      if (P->comm->peer_table(mine, tab.data(), &what) == 0) {
+        HIP_TRY(P->d_peer_tab.upload(tab, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        g.peer_tab = P->d_peer_tab.p; g.peer_flags = P->d_peer_flags.p;
+        P->peer_gseq = 0;
+      }
+    }
+  }
   return PGO_OK;
 }
 

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# Virtual ranks (tests/test_gpu_sharded.py) are streams of one device; the device-initiated exchange makes a launch of one rank wait
+# for a kernel of another, which must not sit behind it in the same hardware queue.  ROCm maps streams onto GPU_MAX_HW_QUEUES (4 by
+# default) queues per process: give every virtual rank's stream its own.  Read by the HIP runtime when it initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

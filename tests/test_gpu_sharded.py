@@ -66,11 +66,13 @@ def test_owner_only_cg_and_replicated_cg_agree(gpu, ds, cluster, monkeypatch):
     prob, poses = gpu.problem_from_graph(g)
     ref = gpu.solve(gpu.SolverOptions(**opt), prob)
     res = {}
+    monkeypatch.setenv("PGO_BLOCK", "256")      # (work-groups of 256 slots: every pose pair 2i, 2i+1 fits one — what the owner-only form needs)
     for form in ("1", "0"):
         monkeypatch.setenv("PGO_SHARD_PIPE", form)
         res[form] = _solve_sharded(gpu, g, 4, opt)
     for form, out in res.items():
         for s, p in out:
+            assert s.cg_form == (2 if form == "1" else 1)      # the form that really ran (Summary::cg_form)
             assert list(s.iterations["step_is_successful"]) == list(ref.iterations["step_is_successful"]), form
             assert list(s.iterations["linear_solver_iterations"]) == list(ref.iterations["linear_solver_iterations"]), form
             assert np.allclose(s.iterations["cost"], ref.iterations["cost"], rtol=1e-8), form
@@ -146,3 +148,24 @@ print("RCCL_OK", s.final_cost)
     env = dict(os.environ, PGO_FORCE_EXCHANGE="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert "RCCL_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_device_initiated_exchange_equals_the_all_gather(gpu, ds, world, monkeypatch):
+    """The owner-only CG with the exchange done by the kernels themselves (every producing launch stores its segment into every
+    rank's buffer; its one-work-group tail signals a per-rank flag and waits for everybody's: DeviceGraph::peer_tab) against the
+    host-enqueued all-gather between the launches: same kernels, same arithmetic, only the transport differs — bit-identical
+    iteration records and poses.  (Loopback ranks: peers' device pointers are valid in this process; the RCCL transport keeps
+    the all-gather.)"""
+    g = ds.manhattan_se3(3001, 14000, seed=77, loop_radius=3.0)
+    opt = dict(max_num_iterations=8, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2)
+    monkeypatch.setenv("PGO_BLOCK", "256")
+    monkeypatch.setenv("PGO_PEER_DIRECT", "0")
+    ref = _solve_sharded(gpu, g, world, opt)
+    monkeypatch.setenv("PGO_PEER_DIRECT", "1")
+    out = _solve_sharded(gpu, g, world, opt)
+    for (s, p), (s0, p0) in zip(out, ref):
+        assert s.termination_type != gpu.FAILURE and s.cg_form == 2
+        for f in ("step_is_successful", "linear_solver_iterations", "cost", "trust_region_radius"):
+            assert np.array_equal(s.iterations[f], s0.iterations[f]), f
+        assert np.array_equal(p, p0)

@@ -52,5 +52,8 @@ for pipe in ("1", "0"):
     out = solve_sharded(g, world, opt)
     s, p = out[0]
     print("pipe=%s w=%d cg" % (pipe, world), list(s.iterations["linear_solver_iterations"]), "cost %.9e" % s.final_cost,
-          "" if trace_only else "max |dp| %.2e" % np.abs(p - poses).max(), "ranks identical", all(np.array_equal(out[0][1], o[1]) for o in out))
+          "" if trace_only else "max |dp| %.2e" % np.abs(p - poses).max(), "ranks identical", all(np.array_equal(out[0][1], o[1]) for o in out),
+          "| cg_form %d, %.3f ms per LM iteration (solver clock, rank 0), exchange %s" % (
+              s.cg_form, 1e3 * s.total_time_in_seconds / max(1, s.num_iterations - 1),
+              "by the kernels" if os.environ.get("PGO_PEER_DIRECT", "0") == "1" else "host-enqueued all-gather (loopback copies)"))
     break
