@@ -31,6 +31,10 @@ for m in 1 0; do
   python tools/rocprof_summary.py $OUT/sh$m/t_results.db $OUT/${TAG}_c4_8way_loopback_pipe${m}_kernel_stats.csv > /dev/null
   rm -rf $OUT/sh$m
 done
+# ... and with the exchange done by the kernels themselves (DeviceGraph::peer_tab; every virtual rank's stream on its own hardware queue)
+GPU_MAX_HW_QUEUES=16 PGO_PEER_DIRECT=1 PGO_SHARD_TRACE_ONLY=1 PGO_SHARD_PIPE=1 rocprofv3 --kernel-trace -d $OUT/shd -o t -- python tools/shard_pipe_check.py 100000 1000000 8 6 > $OUT/shard_log_direct.txt 2>&1
+python tools/rocprof_summary.py $OUT/shd/t_results.db $OUT/${TAG}_c4_8way_loopback_direct_kernel_stats.csv > /dev/null
+rm -rf $OUT/shd
 python tools/exchange_latency.py 2>/dev/null | grep "^{" > $OUT/exchange_world1_raw.json
 [ -x tools/bench/mfma_clock ] && tools/bench/mfma_clock > $OUT/${TAG}_mfma_clock.txt 2>&1
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/front_c2 $OUT/front_c5 $OUT/front_mfma
