@@ -302,11 +302,10 @@ def main():
         b_eval = 976 * E + 56 * N
         # in-situ duration of the dominant kernel: one CG iteration (SpMV + vector update) timed inside the enqueued stream the
         # solver really runs (HIP events around 200 iterations on the solver stream), split between its two kernels in
-        # proportion of their isolated durations; the isolated back-to-back duration (MALL-warm) is kept next to it.  rocprofv3
-        # slows this stream of ~7 us kernels down by ~19 % (the same HIP-event pair time: 13.3 us plain, 15.7 us under
-        # --kernel-trace), so the cross-check with profiles/ is made where it is meaningful: `rocprof_check` below quotes the
-        # committed per-dispatch statistics of the CG-mode launches (tools/rocprof_summary.py splits k_uni_s by operation) next
-        # to what THIS measurement printed when the same command ran under the profiler, and the fraction the CSV average gives
+        # proportion of their isolated durations; the isolated back-to-back duration (MALL-warm) is kept next to it.
+        # `rocprof_check` below quotes the committed per-dispatch statistics of the CG-mode launches (tools/rocprof_summary.py
+        # splits k_uni_s by operation) and the fraction the CSV average gives, so that the line carries the figure a reader
+        # re-derives from profiles/ next to the live one (the profiler slows this stream of ~7 us kernels: DESIGN.md section 7)
         # (one rank, PCG, graphs of this size: the timed region runs the universal stream — k_uni_s in its CG mode is the SpMV — so the
         # in-situ figure is a (k_uni_v, k_uni_s) pair of that stream; otherwise a captured batch of the k_spmv / k_pcg_update kernels)
         uni = False
@@ -365,8 +364,10 @@ def main():
                         "this_measurement_under_rocprof_us": ub["roofline"]["avg_launch_us"],
                         "cg_iteration_us_under_rocprof": ub["roofline"]["cg_iteration_us_in_situ"],
                         "same_kernel_sources": ub.get("kernel_source_sha256_16") == sha,
-                        "note": "rocprofv3 --kernel-trace of this command; the HIP-event figure printed by the run under the profiler "
-                                "(profiles/%s) is the one to compare with rocprof_avg_us; `frac` above is the unprofiled run" % under[-1]}
+                        "note": "rocprofv3 --kernel-trace of this command with k_uni_s split by operation (tools/rocprof_summary.py); "
+                                "frac_from_rocprof_avg is exactly what the committed CSV gives, `frac` above is this run's live HIP-event "
+                                "figure (unprofiled; the profiler slows this stream of ~7 us kernels by 19-97 %% depending on the run: "
+                                "profiles/%s is the line the profiled run printed)" % under[-1]}
         except Exception as ex:  # noqa: BLE001
             extra["rocprof_check_error"] = str(ex)
         ach_lin = b_lin / (t_lin * 1e-3) / 1e9

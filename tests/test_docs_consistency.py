@@ -28,3 +28,38 @@ def test_readme_quotes_the_committed_bench_line():
     d = json.load(open(latest))
     readme = open(os.path.join(ROOT, "README.md")).read()
     assert ("%.3f" % d["ms_per_step"]) in readme, "README.md does not quote ms_per_step %.3f of %s" % (d["ms_per_step"], os.path.basename(latest))
+
+
+def _csv_rows(path):
+    import csv
+    return [r for r in csv.reader(l for l in open(path) if not l.startswith("#"))][1:]
+
+
+def test_design_quotes_the_committed_rocprof_figures():
+    """r03 verdict: DESIGN.md quoted a rocprof median that the committed CSV did not contain.  The figures DESIGN.md sections 4 / 7 quote
+    for the dominant kernels are read back from the latest committed profiles."""
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    bench_csv = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))[-1]
+    cg = [r for r in _csv_rows(bench_csv) if r[0].endswith("[cg]")]
+    assert cg, "%s has no k_uni_s[cg] row (run tools/profile_round.sh: PGO_UNI_OPLOG split)" % os.path.basename(bench_csv)
+    assert ("%.2f" % float(cg[0][3])) in design and os.path.basename(bench_csv) in design      # average us of the CG-mode launches
+    assert ("%d" % int(cg[0][1])).replace("", "") in design.replace(" ", "").replace(" ", "")  # ... over that many dispatches
+    c4_csv = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c4_kernel_stats.csv")))[-1]
+    sym = [r for r in _csv_rows(c4_csv) if "k_spmv_sym<0" in r[0]]
+    assert sym and ("%.1f" % float(sym[0][4])) in design                                          # median us of the symmetric-form product
+    pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c4_pmc.json")))[-1]))
+    assert ("%.1f" % (pmc["kernels"]["k_spmv_sym<0>"]["hbm_bytes_per_launch_corrected"] / 1e6)) in design
+
+
+def test_bench_line_carries_the_fraction_the_csv_gives():
+    """roofline.rocprof_check.frac_from_rocprof_avg of the committed bench line = 15.36 MB / (the CSV's k_uni_s[cg] average) / 8 TB/s."""
+    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))[-1]
+    d = json.load(open(latest))
+    chk = d["roofline"].get("rocprof_check")
+    if chk is None:
+        import pytest
+        pytest.skip("the committed bench line predates rocprof_check")
+    rows = [r for r in _csv_rows(os.path.join(ROOT, chk["csv"])) if r[0].endswith("[cg]")]
+    avg = float(rows[0][3])
+    assert abs(chk["rocprof_avg_us"] - avg) < 1e-9
+    assert abs(chk["frac_from_rocprof_avg"] - d["roofline"]["algorithmic_bytes_per_launch"] / (avg * 1e-6) / 1e9 / d["roofline"]["peak"]) < 1e-3
