@@ -410,13 +410,23 @@ __global__ __launch_bounds__(2 * SYM_LANES) void k_linearize_sym(DeviceGraph g, 
   __syncthreads();
   const size_t ns = (size_t)g.n_slots;       // measurement / information: the incidence-slot arrays, gathered at src_slot
   auto pose_at = [&](int e) { const double* p = poses + LIN_POSE * e; return PoseRec{V3{p[0], p[1], p[2]}, Q4{p[3], p[4], p[5], p[6]}}; };
-  for (int c = 0; c < T.nchunks; ++c) {
-    const int ci = T.chunk0 + c;
+  // the index words of a chunk (4 registers) are requested one chunk ahead: the measurement / information gathers, which need
+  // src_slot, then start with the chunk instead of behind a dependent load
+  struct Idx { uint32_t rin, meta, m2; int src; };
+  auto load_idx = [&](Idx& I, int c) {
     const int n = min((int)SYM_LANES, T.total - SYM_LANES * c), t = T.base0 + SYM_LANES * c + l;     // (no table look-up ahead of the slot loads)
-    const uint32_t rin = sg.rinfo2[(size_t)ci * SYM_LANES + l];
-    uint32_t meta = 0, m2 = 0xFFFFFFFFu;
-    int src = 0;
-    if (l < n) { meta = sg.meta[t]; m2 = sg.meta2[t]; src = sg.src_slot[t]; }
+    I.rin = sg.rinfo2[(size_t)(T.chunk0 + c) * SYM_LANES + l];
+    I.meta = 0; I.m2 = 0xFFFFFFFFu; I.src = 0;
+    if (l < n) { I.meta = sg.meta[t]; I.m2 = sg.meta2[t]; I.src = sg.src_slot[t]; }
+  };
+  Idx cur, nxt;
+  load_idx(cur, 0);
+  nxt = cur;
+  for (int c = 0; c < T.nchunks; ++c) {
+    if (c + 1 < T.nchunks) load_idx(nxt, c + 1);
+    const int n = min((int)SYM_LANES, T.total - SYM_LANES * c), t = T.base0 + SYM_LANES * c + l;
+    const uint32_t rin = cur.rin, meta = cur.meta, m2 = cur.m2;
+    const int src = cur.src;
     const int xcol = (int)(meta & 0xFFFu), side = (int)((meta >> 12) & 3u);
     const int srow = (int)((meta >> 23) & 0xFFu);
     const bool edge_slot = l < n && side != SIDE_DIAG;
@@ -475,6 +485,7 @@ __global__ __launch_bounds__(2 * SYM_LANES) void k_linearize_sym(DeviceGraph g, 
       }
     }
     __syncthreads();
+    cur = nxt;
   }
   if (tid < T.nrows) {
     const int pose = ids[tid];
