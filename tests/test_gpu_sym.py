@@ -137,3 +137,14 @@ def test_lm_solve_symmetric_storage_other_graphs(gpu, ds, name):
     assert np.allclose(a.iterations["cost"][:4], b.iterations["cost"][:4], rtol=1e-8)
     # (truncated PCG on an ill-conditioned mesh amplifies the last-bit differences of the products: 1e-9 at iteration 3, 2e-4 at 5)
     assert np.allclose(a.iterations["cost"][:n], b.iterations["cost"][:n], rtol=5e-3)
+
+
+def test_fuzz_sweep_of_the_symmetric_form():
+    """tools/fuzz_sym.py: 120 random graphs (lattice walks, random chords, hubs with hundreds of incidences, duplicate edges, all three
+    information kinds, constant blocks, five losses, tile caps from 8 to 256 rows, both storage modes) — the symmetric form against the
+    incidence-slot kernels and against itself.  A separate process: the sweep sets driver switches in its environment."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_sym.py"), "120", "100"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
