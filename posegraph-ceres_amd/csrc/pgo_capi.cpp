@@ -174,7 +174,7 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
   }
   // "pcg_spmv" repeats the SpMV kernel of CG iteration 1 (the update kernel never runs, so the
   // iteration counter stays put); "pcg_update" likewise repeats the update of iteration 1.
-  if (k == "sym_spmv" || k == "sym_repack" || k == "sym_plain" || k == "sym_linearize") {
+  if (k == "sym_spmv" || k == "sym_repack" || k == "sym_plain" || k == "sym_linearize" || k == "sym_linearize_rows") {
     int rcs = sym_prepare(P);
     if (rcs) return rcs;
     if (!P->sym_ready || (k == "sym_linearize" && !P->sym_lin_fits)) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): the graph does not fit the symmetric tile form", kernel);
@@ -211,6 +211,7 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     else if (k == "sym_plain") pgo::launch_spmv_sym(P->g, P->sym, prm, 1, 1, s);
     else if (k == "sym_repack") pgo::launch_sym_repack(P->g, P->sym, s);
     else if (k == "sym_linearize") pgo::launch_linearize_sym(P->g, P->sym, s);
+    else if (k == "sym_linearize_rows") { pgo::DeviceGraph gs = P->g; gs.sym_dst = P->sy_dst.p; gs.sym_val = P->sym.val; pgo::launch_linearize_symout(gs, s); }
     else if (k == "pcg_iteration") pgo::launch_pcg_iteration(P->g, prm, 1, s);
     else if (k == "empty") pgo::launch_debug(P->g, 0, s);
     else if (k == "touch") pgo::launch_debug(P->g, 1, s);

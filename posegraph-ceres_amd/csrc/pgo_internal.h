@@ -427,7 +427,7 @@ struct pgo_problem {
   bool sym_storage = false;         // this LM session keeps the normal equations in the symmetric tile form ONLY: linearisation, damping, the cluster
                                     // preconditioner and every product work on it (the incidence-slot blocks are not maintained)
   std::vector<int> h_cl_slot, h_sym_of_old;
-  DevBuf<int> sy_cl_slot;
+  DevBuf<int> sy_cl_slot, sy_dst;
   bool sym_lin_fits = false;        // k_linearize_sym's LDS (poses + exchange buffer) fits: the linearisation writes the symmetric form itself
   DevBuf<double> sy_val;
   // cluster-Jacobi preconditioner topology (built when the option asks for clusters of 2 or 4 poses)

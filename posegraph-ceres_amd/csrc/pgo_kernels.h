@@ -218,6 +218,10 @@ struct DeviceGraph {
   // that tools/rocprof_summary.py can bucket the dispatches of that one kernel symbol by what they did.  [0] = entries so far.
   long long* oplog;
   int oplog_cap;
+  // linearisation into the symmetric tile form by the row kernel (k_linearize_symout): stored slot of every incidence slot (-1: the
+  // mirrored incidence of an interior edge, not stored) and the form's block array
+  const int* sym_dst;
+  double* sym_val;
   // one process per GPU: contiguous row ownership (all rows when world == 1)
   int world, rank, rows_per, row_lo, row_hi, pq_cap, seg;
   int cluster;        // poses per Jacobi block of the preconditioner: 1 (6x6), 2 (12x12) or 4 (24x24)
@@ -262,6 +266,7 @@ __device__ __forceinline__ bool lm_halted(const DeviceGraph& g) { return g.lm &&
 
 // launches (all asynchronous on `s`)
 void launch_linearize(const DeviceGraph& g, hipStream_t s, int gate = 0);   // gate 1: run only once the CG has stopped (speculative launch behind a step tail); 2: device-resident LM, behind an accepted step
+void launch_linearize_symout(const DeviceGraph& g, hipStream_t s, int gate = 0);   // ... with the off-diagonal blocks written into the symmetric tile form (g.sym_dst / g.sym_val)
 void launch_scale_from_diag(const DeviceGraph& g, hipStream_t s);
 void launch_damping(const DeviceGraph& g, double radius, double min_diag, double max_diag, int mode, hipStream_t s);
 void launch_cost(const DeviceGraph& g, const double* poses, int part_row, hipStream_t s, int gate = 0);

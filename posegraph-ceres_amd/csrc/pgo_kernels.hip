@@ -105,7 +105,10 @@ __device__ __forceinline__ WBlocks load_W_diag(const double* W, size_t stride, s
 // gate: a speculative launch behind the step tail of a CG batch (the linearisation of the candidate point into the spare buffers)
 // runs only once the CG has stopped, like the tail itself.
 // (the body is shared with the universal slot kernel k_uni_s further down)
-template <int INFO, int PASSES = 1>
+// SYMOUT: the off-diagonal blocks go to the symmetric tile form (pgo_sym.h) instead — slot t's block to stored slot g.sym_dst[t], the
+// mirrored incidence of an interior edge (sym_dst < 0) writes none; diagonal blocks and gradient as always (compile-time: the
+// other instantiations are the code they were)
+template <int INFO, int PASSES = 1, bool SYMOUT = false>
 __device__ __forceinline__ void linearize_body(const DeviceGraph& g, double* lds) {
   constexpr int NVP = (NV_LIN + PASSES - 1) / PASSES;   // values per round
   constexpr int NVS = NVP | 1;                          // LDS stride per lane (odd)
@@ -227,6 +230,13 @@ __device__ __forceinline__ void linearize_body(const DeviceGraph& g, double* lds
         st[i] = ct ? 0.0 : g.scale[6 * (size_t)col + i];
       }
       double2* out = reinterpret_cast<double2*>(g.bsr_val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+      bool st_blk = true;
+      if (SYMOUT) {
+        const int dst = g.sym_dst[t];
+        st_blk = dst >= 0;
+        const int d0 = st_blk ? dst : 0;
+        out = reinterpret_cast<double2*>(g.sym_val + (size_t)(d0 >> 6) * TILE_DOUBLES + (size_t)(d0 & 63) * 2);
+      }
       if (INFO != 1) {
         // packed slot: positions 0..8 top-left, 9..17 bottom-right, 18..26 the stored off-diagonal quadrant (bottom-left of
         // H_ab for the BEGIN slot, top-right of H_ba for the END slot), 27 unused.  Same products as the full layout.
@@ -243,7 +253,7 @@ __device__ __forceinline__ void linearize_body(const DeviceGraph& g, double* lds
         }
         wv[27] = 0.0;
 #pragma unroll
-        for (int kk = 0; kk < BLK_PAIRS_PACKED; ++kk) out[(size_t)kk * 64] = double2{wv[2 * kk], wv[2 * kk + 1]};
+        for (int kk = 0; kk < BLK_PAIRS_PACKED; ++kk) if (!SYMOUT || st_blk) out[(size_t)kk * 64] = double2{wv[2 * kk], wv[2 * kk + 1]};
       } else {
 #pragma unroll
         for (int kk = 0; kk < 18; ++kk) {
@@ -251,7 +261,7 @@ __device__ __forceinline__ void linearize_body(const DeviceGraph& g, double* lds
           double2 w;
           w.x = rho1 * so[k0 / 6] * st[k0 % 6] * off[k0];
           w.y = rho1 * so[k1 / 6] * st[k1 % 6] * off[k1];
-          out[(size_t)kk * 64] = w;
+          if (!SYMOUT || st_blk) out[(size_t)kk * 64] = w;
         }
       }
       int k = 0;
@@ -341,6 +351,14 @@ __global__ __launch_bounds__(256) void k_linearize(DeviceGraph g, int gate) {
   if (gate == 1 && !g.cg->done) return;
   if (gate == 2 && (g.lm->halt || !g.lm->accepted)) return;   // device-resident LM: behind an accepted step only (g.pose_x is the candidate)
   linearize_body<INFO>(g, lds);
+}
+
+template <int INFO>
+__global__ __launch_bounds__(256) void k_linearize_symout(DeviceGraph g, int gate) {
+  extern __shared__ double lds[];
+  if (gate == 1 && !g.cg->done) return;
+  if (gate == 2 && (g.lm->halt || !g.lm->accepted)) return;
+  linearize_body<INFO, 1, true>(g, lds);
 }
 
 // Jacobi scaling, computed once at iteration 0 from the unscaled diag(J^T J):  S = 1 / (1 + sqrt(d)).
@@ -2475,6 +2493,13 @@ void launch_linearize(const DeviceGraph& g, hipStream_t s, int gate) {
   else if (g.info_mode == 2) hipLaunchKernelGGL(k_linearize<2>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
   else if (g.info_mode) hipLaunchKernelGGL(k_linearize<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
   else hipLaunchKernelGGL(k_linearize<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
+}
+void launch_linearize_symout(const DeviceGraph& g, hipStream_t s, int gate) {
+  const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);
+  if (g.info_mode == 3) hipLaunchKernelGGL(k_linearize_symout<3>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
+  else if (g.info_mode == 2) hipLaunchKernelGGL(k_linearize_symout<2>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
+  else if (g.info_mode) hipLaunchKernelGGL(k_linearize_symout<1>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
+  else hipLaunchKernelGGL(k_linearize_symout<0>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
 }
 void launch_scale_from_diag(const DeviceGraph& g, hipStream_t s) {
   hipLaunchKernelGGL(k_scale_from_diag, dim3(cdiv(6 * g.N, 256)), dim3(256), 0, s, g);

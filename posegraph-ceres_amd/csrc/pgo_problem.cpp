@@ -60,7 +60,16 @@ int exchange(pgo_problem* P, double* buf, size_t seg_doubles) {
 // diag_only (several ranks, the solve will run the owner-only CG): nobody reads another rank's off-diagonal entries of the
 // diagonal blocks then — 6 doubles per pose travel instead of 36 (28.8 -> 4.8 MB per accepted step at 100 k poses)
 int linearize_all(pgo_problem* P, bool diag_only) {
-  if (P->sym_storage) { pgo::launch_linearize_sym(P->g, P->sym, P->stream); return PGO_OK; }    // (one rank: nothing to exchange)
+  if (P->sym_storage) {        // (one rank: nothing to exchange)
+    // two kernels write the form: the row kernel with redirected block stores (every incidence evaluated by its own lane, as on the
+    // incidence-slot BSR) and the tile kernel (an interior edge evaluated once for both rows); PGO_SYM_LIN=tile picks the latter
+    const char* sl = getenv("PGO_SYM_LIN");
+    if (sl && sl[0] == 't') { pgo::launch_linearize_sym(P->g, P->sym, P->stream); return PGO_OK; }
+    pgo::DeviceGraph gs = P->g;
+    gs.sym_dst = P->sy_dst.p; gs.sym_val = P->sym.val;
+    pgo::launch_linearize_symout(gs, P->stream);
+    return PGO_OK;
+  }
   pgo::launch_linearize(P->g, P->stream);
   P->sym_stale = true;
   int rc;
@@ -398,6 +407,7 @@ int prepare(pgo_problem* P) {
   g.n_part = n_part; g.n_vec_wg = n_vec_wg; g.n_edge_wg = n_edge_wg; g.n_pose_wg = n_pose_wg;
   g.cg = P->d_cg.p; g.flags = P->d_flags.p;
   g.oplog = nullptr; g.oplog_cap = 0;
+  g.sym_dst = nullptr; g.sym_val = nullptr;
   if (getenv("PGO_UNI_OPLOG")) {
     const size_t cap = (size_t)1 << 21;
     HIP_TRY(P->d_oplog.alloc(cap));

@@ -313,6 +313,12 @@ int sym_prepare(pgo_problem* P) {
   lap("index uploads + sync");
   P->h_sym_of_old.assign(P->g.n_slots, -1);
   for (int t = 0; t < n_slots; ++t) if (src_slot[t] >= 0) P->h_sym_of_old[src_slot[t]] = t;
+  {   // for the row kernel that linearises into this form (k_linearize_symout): diagonal slots are written by the damping, not by it
+    std::vector<int> dst(P->h_sym_of_old);
+    for (int v = 0; v < N; ++v) dst[P->h_row_slot_begin[v]] = -1;
+    HIP_TRY(P->sy_dst.upload(dst, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
   P->sym_ready = true;
   P->sym_stale = true;
   P->sym_interior_fraction = E ? (double)interior_edges / E : 0.0;

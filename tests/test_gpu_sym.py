@@ -120,10 +120,14 @@ def test_lm_solve_same_answer(gpu, ds, O, repack):
     assert b.final_cost == pytest.approx(osum.final_cost, rel=1e-6)
 
 
+@pytest.mark.parametrize("lin", ["rows", "tile"])
 @pytest.mark.parametrize("name", ["identity", "fat_rows", "sphere"])
-def test_lm_solve_symmetric_storage_other_graphs(gpu, ds, name):
+def test_lm_solve_symmetric_storage_other_graphs(gpu, ds, name, lin, monkeypatch):
     """Identity information (INFO 0), rows with many incidences (several chunks per tile, runs across wave boundaries), a mesh:
     whole LM solves with the symmetric form as the only storage against the incidence-slot kernels."""
+    # lin: which kernel writes the form — the row kernel with redirected block stores (k_linearize_symout, the default) or the tile
+    # kernel that evaluates an interior edge once for both rows (k_linearize_sym, PGO_SYM_LIN=tile)
+    monkeypatch.setenv("PGO_SYM_LIN", lin)
     g = _graphs(ds)[name]
     opt = dict(max_num_iterations=10, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=1 if name == "sphere" else 2)
     runs = []
