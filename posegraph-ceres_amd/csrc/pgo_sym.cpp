@@ -1,5 +1,6 @@
-// pgo_sym.cpp — host side of the symmetric tile form (pgo_sym.h): row tiles with graph locality, the sliced layout of the
-// stored slots and every index the kernel needs.  One-off per topology (one rank; built when a PCG solve of a large graph starts).
+// pgo_sym.cpp — host side of the symmetric tile form (pgo_sym.h): row tiles with graph locality, the row-after-row layout of the
+// stored slots in chunks of 256, and every index the kernels need.  One-off per topology (one rank; built when a PCG solve of a
+// large graph starts and can repay it: 44 ms at 100 k poses / 1 M edges).
 #include <algorithm>
 #include <numeric>
 
@@ -9,7 +10,7 @@ namespace {
 
 // Tiles: the natural order cut into runs of <= 0.85 * (row cap, weight cap), then greedy refinement — a pose moves to the tile
 // that holds most of its neighbours while the caps allow (pose-graph ids follow the trajectory, so the runs are already local;
-// the refinement pulls the loop-closure partners together: BASELINE config 4 goes from 56 % to 77 % interior edges).
+// the refinement pulls the loop-closure partners together: BASELINE config 4 goes from 56 % to 72-78 % interior edges).
 void partition_rows(int N, const std::vector<int>& adj_ptr, const std::vector<int>& adj, int row_cap, long long w_cap, std::vector<int>& part, int& T) {
   part.assign(N, 0);
   const int r0 = std::max(1, (int)(0.85 * row_cap));
