@@ -174,7 +174,7 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
   }
   // "pcg_spmv" repeats the SpMV kernel of CG iteration 1 (the update kernel never runs, so the
   // iteration counter stays put); "pcg_update" likewise repeats the update of iteration 1.
-  if (k == "sym_spmv" || k == "sym_repack" || k == "sym_plain" || k == "sym_linearize" || k == "sym_linearize_rows") {
+  if (k == "sym_spmv" || k == "sym_repack" || k == "sym_plain" || k == "sym_linearize" || k == "sym_linearize_rows" || k == "sym_linearize_lean" || k == "sym_lean_check") {
     int rcs = sym_prepare(P);
     if (rcs) return rcs;
     if (!P->sym_ready || (k == "sym_linearize" && !P->sym_lin_fits)) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): the graph does not fit the symmetric tile form", kernel);
@@ -212,6 +212,7 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     else if (k == "sym_repack") pgo::launch_sym_repack(P->g, P->sym, s);
     else if (k == "sym_linearize") pgo::launch_linearize_sym(P->g, P->sym, s);
     else if (k == "sym_linearize_rows") { pgo::DeviceGraph gs = P->g; gs.sym_dst = P->sy_dst.p; gs.sym_val = P->sym.val; pgo::launch_linearize_symout(gs, s); }
+    else if (k == "sym_linearize_lean") { pgo::DeviceGraph gs = P->g; gs.sym_dst = P->sy_dst.p; gs.sym_val = P->sym.val; pgo::launch_linearize_lean(gs, s); }
     else if (k == "pcg_iteration") pgo::launch_pcg_iteration(P->g, prm, 1, s);
     else if (k == "empty") pgo::launch_debug(P->g, 0, s);
     else if (k == "touch") pgo::launch_debug(P->g, 1, s);
@@ -274,6 +275,56 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     (void)hipEventDestroy(b);
     P->drop_graph();
     *avg_ms = total / repeats / batch;
+    return PGO_OK;
+  }
+  if (k == "sym_lean_check") {
+    // not a timing: k_linearize_symout and k_linearize_lean (pgo_lean_kernels.hip) write the symmetric form, the diagonal blocks and
+    // the gradient of the current point one after the other (the form pre-set to a sentinel before the second, so a block it does
+    // not write shows); *avg_ms receives the largest difference relative to the largest entry of its group (blocks / diagonal / gradient)
+    pgo::DeviceGraph gs = P->g;
+    gs.sym_dst = P->sy_dst.p; gs.sym_val = P->sym.val;
+    const size_t nv = P->sy_val.n, nh = (size_t)36 * P->g.N, ng = (size_t)6 * P->g.N;
+    std::vector<double> v0(nv), v1(nv), h0(nh), h1(nh), g0(ng), g1(ng);
+    pgo::launch_linearize_symout(gs, s);
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(v0.data(), P->sym.val, nv * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h0.data(), P->g.Hdiag, nh * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(g0.data(), P->g.grad, ng * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> sentinel(nv, 1.0e300);
+    HIP_TRY(hipMemcpy(P->sym.val, sentinel.data(), nv * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(P->g.Hdiag, 0x7f, nh * sizeof(double), s));      // (on the solver's stream: it does not wait for the null stream)
+    HIP_TRY(hipMemsetAsync(P->g.grad, 0x7f, ng * sizeof(double), s));
+    pgo::launch_linearize_lean(gs, s);
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(v1.data(), P->sym.val, nv * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h1.data(), P->g.Hdiag, nh * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(g1.data(), P->g.grad, ng * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(P->sym.val, v0.data(), nv * sizeof(double), hipMemcpyHostToDevice));       // the session goes on with the first kernel's result
+    HIP_TRY(hipMemcpy(P->g.Hdiag, h0.data(), nh * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P->g.grad, g0.data(), ng * sizeof(double), hipMemcpyHostToDevice));
+    auto rel = [](const std::vector<double>& a, const std::vector<double>& b, bool written_only) {
+      double m = 0, e = 0;
+      for (size_t i = 0; i < a.size(); ++i) {
+        if (written_only && b[i] == 1.0e300) continue;      // (places of the form nobody linearises into: diagonal slots, padding)
+        m = std::max(m, std::fabs(a[i]));
+        const double d = std::fabs(a[i] - b[i]);
+        e = std::max(e, d == d ? d : 1.0e300);
+      }
+      return m > 0 ? e / m : e;
+    };
+    // a place the first kernel wrote and the second did not shows as 1e300 against a block entry: count those separately
+    size_t unwritten = 0;
+    { std::vector<double> vs(nv);
+      HIP_TRY(hipMemcpy(P->sym.val, sentinel.data(), nv * sizeof(double), hipMemcpyHostToDevice));
+      pgo::launch_linearize_symout(gs, s);
+      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipMemcpy(vs.data(), P->sym.val, nv * sizeof(double), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < nv; ++i) unwritten += (vs[i] == 1.0e300) != (v1[i] == 1.0e300);
+      HIP_TRY(hipMemcpy(P->sym.val, v0.data(), nv * sizeof(double), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(P->g.Hdiag, h0.data(), nh * sizeof(double), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(P->g.grad, g0.data(), ng * sizeof(double), hipMemcpyHostToDevice)); }
+    const double worst = std::max(rel(v0, v1, true), std::max(rel(h0, h1, false), rel(g0, g1, false)));
+    *avg_ms = unwritten ? 1.0e300 : worst;
     return PGO_OK;
   }
   hipEvent_t e0, e1;

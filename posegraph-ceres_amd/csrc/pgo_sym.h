@@ -72,5 +72,8 @@ size_t sym_lin_lds_bytes(const SymGraph& sg);     // LDS of k_linearize_sym (sta
 // residual + Jacobians + J'J / J'r of every stored slot written into the symmetric tile form (off-diagonal blocks -> sg.val, diagonal
 // blocks -> g.Hdiag, gradient -> g.grad): an interior edge is evaluated once for both of its rows.  gate: as launch_linearize
 void launch_linearize_sym(const DeviceGraph& g, const SymGraph& sg, hipStream_t s, int gate = 0);
+// pgo_lean_kernels.hip: the row kernel writing the form (g.sym_dst / g.sym_val set) with the lean per-incidence algebra of pgo_lin_lean.h
+void launch_linearize_lean(const DeviceGraph& g, hipStream_t s, int gate = 0);      // (falls back to launch_linearize_symout when it does not fit)
+bool linearize_lean_fits(const DeviceGraph& g);
 
 }  // namespace pgo

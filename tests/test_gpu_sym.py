@@ -120,13 +120,14 @@ def test_lm_solve_same_answer(gpu, ds, O, repack):
     assert b.final_cost == pytest.approx(osum.final_cost, rel=1e-6)
 
 
-@pytest.mark.parametrize("lin", ["rows", "tile"])
+@pytest.mark.parametrize("lin", ["lean", "rows", "tile"])
 @pytest.mark.parametrize("name", ["identity", "fat_rows", "sphere"])
 def test_lm_solve_symmetric_storage_other_graphs(gpu, ds, name, lin, monkeypatch):
     """Identity information (INFO 0), rows with many incidences (several chunks per tile, runs across wave boundaries), a mesh:
     whole LM solves with the symmetric form as the only storage against the incidence-slot kernels."""
-    # lin: which kernel writes the form — the row kernel with redirected block stores (k_linearize_symout, the default) or the tile
-    # kernel that evaluates an interior edge once for both rows (k_linearize_sym, PGO_SYM_LIN=tile)
+    # lin: which kernel writes the form — the row kernel with the lean per-incidence algebra (k_linearize_lean, the default), the row
+    # kernel with the general body and redirected block stores (k_linearize_symout, PGO_SYM_LIN=rows) or the tile kernel that evaluates
+    # an interior edge once for both rows (k_linearize_sym, PGO_SYM_LIN=tile)
     monkeypatch.setenv("PGO_SYM_LIN", lin)
     g = _graphs(ds)[name]
     opt = dict(max_num_iterations=10, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=1 if name == "sphere" else 2)
@@ -141,6 +142,38 @@ def test_lm_solve_symmetric_storage_other_graphs(gpu, ds, name, lin, monkeypatch
     assert np.allclose(a.iterations["cost"][:4], b.iterations["cost"][:4], rtol=1e-8)
     # (truncated PCG on an ill-conditioned mesh amplifies the last-bit differences of the products: 1e-9 at iteration 3, 2e-4 at 5)
     assert np.allclose(a.iterations["cost"][:n], b.iterations["cost"][:n], rtol=5e-3)
+
+
+def _block_diagonal_information(ds, seed=8):
+    g = ds.manhattan_se3(2500, 9000, seed=seed)
+    rng = np.random.default_rng(4)
+    L = np.zeros((len(g.ia), 6, 6))          # W_pp, W_rr full 3 x 3, no position / rotation coupling (INFO 2)
+    for blk in (slice(0, 3), slice(3, 6)):
+        L[:, blk, blk] = rng.normal(size=(len(g.ia), 3, 3)) * 0.3 + 3.0 * np.eye(3)
+    g.sqrt_info = L
+    return g
+
+
+@pytest.mark.parametrize("name", ["manhattan", "identity", "fat_rows", "sphere", "chain", "block_diagonal", "soft_l_one", "no_loss"])
+def test_lean_linearisation_equals_the_general_one(gpu, ds, name):
+    """k_linearize_lean (csrc/pgo_lean_kernels.hip: hand-reduced algebra, pair sums on the DPP crossbar) against k_linearize_symout
+    (the general body) at the same point: every block written into the form, every diagonal block, the gradient — largest
+    difference relative to the largest entry of its group below 1e-12; both write exactly the same places of the form."""
+    kw = {}
+    if name == "block_diagonal":
+        g = _block_diagonal_information(ds)
+    elif name in ("soft_l_one", "no_loss"):
+        g = ds.manhattan_se3(2000, 8000, seed=17)
+        kw = dict(loss=gpu.SOFT_L_ONE if name == "soft_l_one" else gpu.TRIVIAL, loss_a=0.7)
+    else:
+        g = _graphs(ds)[name]
+    with _Sym(True, 32):
+        prob, _ = gpu.problem_from_graph(g, **kw)
+        prob.solver_begin(gpu.SolverOptions(max_num_iterations=50, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2))
+        prob.solver_step(2)          # (a point with Huber-active edges and Jacobi scales in place)
+        worst = prob.time_kernel("sym_lean_check", 1)
+        prob.solver_end()
+    assert worst < 1e-12, worst
 
 
 def test_fuzz_sweep_of_the_symmetric_form():
