@@ -43,7 +43,15 @@ struct LeanSink {
     if (store) {
 #pragma unroll
       for (int kk = 0; kk < BLK_PAIRS_PACKED; ++kk)
-        if (kk >= k0 && kk < k1) *reinterpret_cast<double2*>(reinterpret_cast<char*>(val) + (off + 1024u * kk)) = double2{wv[2 * kk], wv[2 * kk + 1]};
+        if (kk >= k0 && kk < k1) {
+          double* q = reinterpret_cast<double*>(reinterpret_cast<char*>(val) + (off + 1024u * kk));
+          // nontemporal: 310 MB written once and next read from HBM by the CG product anyway (measured 179 -> 163 us against plain
+          // stores; nontemporal LOADS of the streamed inputs change nothing)
+          typedef double v2d __attribute__((ext_vector_type(2)));
+          v2d x;
+          x.x = wv[2 * kk]; x.y = wv[2 * kk + 1];
+          __builtin_nontemporal_store(x, reinterpret_cast<v2d*>(q));
+        }
     }
   }
 };
@@ -66,7 +74,6 @@ struct LeanData {
 // (a 64-bit address per plane and lane costs the kernel 30 registers it does not have)
 template <class T>
 __device__ __forceinline__ T ld_at(const void* base, unsigned byte_off) { return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off); }
-
 __device__ __forceinline__ LeanIdx lean_load_idx(const DeviceGraph& g, int t) {
   LeanIdx l;
   l.side = ld_at<uint8_t>(g.slot_side, (unsigned)t);
