@@ -458,7 +458,8 @@ def main():
         # *_sym kernels are the ones its LM loop runs; the incidence-slot kernels are what several ranks and smaller graphs run)
         for key, kern, nbytes, reps4 in (("k_evaluate_edges", "evaluate", 976 * E4 + 56 * N4, 30),
                                          ("k_spmv_sym<0> (CG product, every interior block read once)", "sym_spmv", (N4 + E4) * 288 + 2 * N4 * 48, 100),
-                                         ("k_linearize_symout (the row kernel writing the symmetric form: what the session's LM loop runs)", "sym_linearize_rows", 640 * E4 + 392 * N4, 50),
+                                         ("k_linearize_lean (the row kernel with the hand-reduced algebra writing the symmetric form: what the session's LM loop runs)", "sym_linearize_lean", 640 * E4 + 392 * N4, 50),
+                                         ("k_linearize_symout (the general body writing the symmetric form, PGO_SYM_LIN=rows)", "sym_linearize_rows", 640 * E4 + 392 * N4, 50),
                                          ("k_linearize_sym (tile kernel, PGO_SYM_LIN=tile)", "sym_linearize", 640 * E4 + 392 * N4, 50),
                                          ("k_linearize", "linearize", 640 * E4 + 392 * N4, 50),
                                          ("k_spmv<0>", "pcg_spmv", (N4 + E4) * 288 + 2 * N4 * 48, 100)):

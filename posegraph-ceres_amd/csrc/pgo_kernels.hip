@@ -1822,9 +1822,13 @@ __global__ __launch_bounds__(UNI_V_BLOCK) void k_uni_v(DeviceGraph g, CgParams p
   if (live) {
     x0 = g.cg_x[idx]; r0 = g.cg_r[idx]; q0 = g.cg_q[idx]; b0 = g.cg_b[idx];
     p0v = g.cg_p0[idx]; p1v = g.cg_p1[idx];
-    const double2* Mi = reinterpret_cast<const double2*>(g.Minv + (size_t)idx * DIM);
+    // (four-pose clusters: 24 doubles per row requested here do not stay in registers across the operation switch — the compiler
+    // parked each of them in scratch behind a wait for its load, 8 us at the top of every launch; they are requested in the update)
+    if (CL != 4) {
+      const double2* Mi = reinterpret_cast<const double2*>(g.Minv + (size_t)idx * DIM);
 #pragma unroll
-    for (int k = 0; k < DIM / 2; ++k) mi[k] = Mi[k];
+      for (int k = 0; k < DIM / 2; ++k) mi[k] = Mi[k];
+    }
   }
   const int op = g.cg->op_v;
   const int it = g.cg->cnt_a;
@@ -1871,6 +1875,10 @@ __global__ __launch_bounds__(UNI_V_BLOCK) void k_uni_v(DeviceGraph g, CgParams p
 #pragma unroll
           for (int k = 0; k < DIM / 2; ++k) mi[k] = Mi[k];
         }
+      } else if (CL == 4 && live) {
+        const double2* Mi = reinterpret_cast<const double2*>(g.Minv + (size_t)idx * DIM);
+#pragma unroll
+        for (int k = 0; k < DIM / 2; ++k) mi[k] = Mi[k];
       }
       double x = 0.0, r = 0.0;
       if (live) {
