@@ -49,6 +49,10 @@ def test_design_quotes_the_committed_rocprof_figures():
     assert sym and ("%.1f" % float(sym[0][4])) in design                                          # median us of the symmetric-form product
     pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c4_pmc.json")))[-1]))
     assert ("%.1f" % (pmc["kernels"]["k_spmv_sym<0>"]["hbm_bytes_per_launch_corrected"] / 1e6)) in design
+    lean = [r for r in _csv_rows(c4_csv) if "k_linearize_lean<3" in r[0]]
+    assert lean and ("%.1f" % float(lean[0][4])) in design                                        # median us of the lean linearisation
+    assert ("%.1f" % (pmc["kernels"]["k_linearize_lean<3>"]["hbm_bytes_per_launch_corrected"] / 1e6)) in design
+    assert float(lean[0][4]) <= 170.0         # r03 verdict item 4: rocprof median <= 170 us at 100 k poses / 1 M edges
 
 
 def test_bench_line_carries_the_fraction_the_csv_gives():
