@@ -587,7 +587,11 @@ __device__ __forceinline__ void store_rows_coalesced(double* lds_w, double* out,
   const int n2 = count * W / 2;
   for (int i = lane; i < n2; i += 64) {
     const int d0 = 2 * i, el = d0 / W, kk = d0 - el * W;
-    dst[i] = double2{lds_w[el * 37 + kk], lds_w[el * 37 + kk + 1]};
+    // nontemporal: 600+ bytes per edge written once, read next by the host or a later launch from HBM anyway (C4: 188 -> ... us)
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d x;
+    x.x = lds_w[el * 37 + kk]; x.y = lds_w[el * 37 + kk + 1];
+    __builtin_nontemporal_store(x, reinterpret_cast<v2d*>(dst + i));
   }
   __syncthreads();
 }
