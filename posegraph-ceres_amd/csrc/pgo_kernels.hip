@@ -108,6 +108,12 @@ __device__ __forceinline__ WBlocks load_W_diag(const double* W, size_t stride, s
 // SYMOUT: the off-diagonal blocks go to the symmetric tile form (pgo_sym.h) instead — slot t's block to stored slot g.sym_dst[t], the
 // mirrored incidence of an interior edge (sym_dst < 0) writes none; diagonal blocks and gradient as always (compile-time: the
 // other instantiations are the code they were)
+__device__ __forceinline__ void store_pair_nt(double2* p, double a, double b) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  v2d x;
+  x.x = a; x.y = b;
+  __builtin_nontemporal_store(x, reinterpret_cast<v2d*>(p));
+}
 template <int INFO, int PASSES = 1, bool SYMOUT = false>
 __device__ __forceinline__ void linearize_body(const DeviceGraph& g, double* lds) {
   constexpr int NVP = (NV_LIN + PASSES - 1) / PASSES;   // values per round
@@ -253,7 +259,13 @@ __device__ __forceinline__ void linearize_body(const DeviceGraph& g, double* lds
         }
         wv[27] = 0.0;
 #pragma unroll
-        for (int kk = 0; kk < BLK_PAIRS_PACKED; ++kk) if (!SYMOUT || st_blk) out[(size_t)kk * 64] = double2{wv[2 * kk], wv[2 * kk + 1]};
+        for (int kk = 0; kk < BLK_PAIRS_PACKED; ++kk) {
+          if (SYMOUT) {      // (a symmetric-form session is large: the blocks are written once and next read from HBM — nontemporal)
+            if (st_blk) store_pair_nt(out + (size_t)kk * 64, wv[2 * kk], wv[2 * kk + 1]);
+          } else {
+            out[(size_t)kk * 64] = double2{wv[2 * kk], wv[2 * kk + 1]};
+          }
+        }
       } else {
 #pragma unroll
         for (int kk = 0; kk < 18; ++kk) {
@@ -261,7 +273,8 @@ __device__ __forceinline__ void linearize_body(const DeviceGraph& g, double* lds
           double2 w;
           w.x = rho1 * so[k0 / 6] * st[k0 % 6] * off[k0];
           w.y = rho1 * so[k1 / 6] * st[k1 % 6] * off[k1];
-          if (!SYMOUT || st_blk) out[(size_t)kk * 64] = w;
+          if (SYMOUT) { if (st_blk) store_pair_nt(out + (size_t)kk * 64, w.x, w.y); }
+          else out[(size_t)kk * 64] = w;
         }
       }
       int k = 0;
