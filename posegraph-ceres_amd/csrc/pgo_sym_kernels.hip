@@ -171,7 +171,9 @@ __global__ __launch_bounds__(SYM_LANES) void k_spmv_sym(DeviceGraph g, SymGraph 
       for (int k = 0; k < NPAIR; ++k) C.b[k] = bp[(size_t)k * 64];
     }
   };
-  auto load_chunk = [&](Chunk& C, int c) { const int ci = T.chunk0 + c; load_blocks(C, ci, sg.chunk_base[ci], sg.chunk_n[ci]); };
+  // (a tile's chunks are consecutive: base and size follow from the tile record.  A look-up in the chunk table is a uniform load,
+  // which the compiler issues as a vector load and waits for with vmcnt(0) — a wait for every block in flight: 81.8 -> 78.4 us)
+  auto load_chunk = [&](Chunk& C, int c) { load_blocks(C, T.chunk0 + c, T.base0 + SYM_LANES * c, min((int)SYM_LANES, T.total - SYM_LANES * c)); };
   Chunk CA, CB, CC;
   load_blocks(CA, T.chunk0, T.base0, T.n0);
   if (nch > 1) load_blocks(CB, T.chunk0 + 1, T.base1, T.n1);
