@@ -14,6 +14,12 @@ REF = /root/reference/src/POSE_GRAPH
                                     residuals (2761 vertices, 8900 edges; Huber active on most loop edges); there is
                                     no "after" for it, it is used as an input for GPU-vs-oracle parity only.
 
+  * result/result_before.g2o -> result/result_after.g2o (ONE DIRECTORY UP; same vertices and edge ids as the pair
+                                    above, different edge measurements): the far sharper pair.  At *before* the cost
+                                    is 5359 with 4056 of the 4695 edges in Huber's linear region; *after* lies 480 m
+                                    (mean) / 931 m (max) away at cost 2.99939 with every edge carrying residual.
+                                    Stored as g2o_pair_strong.npz; tests/test_g2o_strong_pair.py states what it pins.
+
 Both files print 6 significant digits.  g2o's EdgeSE3 error is toVectorMQT(Z^-1 Xi^-1 Xj) = [t ; vec q] of the
 error transform, so with identity information chi2 = |dt|^2 + |vec dq|^2; this repo's residual
 (PoseGraph3dError.h:32-51) has the rotation part 2 vec(dq), hence sqrt-information L = diag(1,1,1,.5,.5,.5)
@@ -45,6 +51,18 @@ def main():
     d = np.linalg.norm(ga.poses[:, :3] - gb.poses[:, :3], axis=1)
     print("g2o pair: %d vertices, %d edges (%d loop), moved mean %.2f mm max %.2f mm" % (
         gb.N, gb.E, int((np.abs(gb.ia - gb.ib) > 1).sum()), 1e3 * d.mean(), 1e3 * d.max()))
+
+    up = os.path.dirname(REF)
+    sb = ds.read_g2o(os.path.join(up, "result_before.g2o"))
+    sa = ds.read_g2o(os.path.join(up, "result_after.g2o"))
+    assert sb.N == sa.N == 4541 and sb.E == sa.E == 4695 and sb.fixed == sa.fixed == [0]
+    assert np.array_equal(sb.ia, sa.ia) and np.array_equal(sb.ib, sa.ib) and np.array_equal(sb.meas, sa.meas)
+    assert np.array_equal(sb.ia, gb.ia) and np.array_equal(sb.ib, gb.ib) and not np.array_equal(sb.meas, gb.meas)
+    assert sb.sqrt_info is None and sa.sqrt_info is None
+    np.savez_compressed(os.path.join(HERE, "g2o_pair_strong.npz"), before=sb.poses, after=sa.poses, ia=sb.ia, ib=sb.ib,
+                        meas=sb.meas, fixed=np.array(sb.fixed, dtype=np.int32))
+    d = np.linalg.norm(sa.poses[:, :3] - sb.poses[:, :3], axis=1)
+    print("strong pair: %d vertices, %d edges, moved mean %.1f m max %.1f m" % (sb.N, sb.E, d.mean(), d.max()))
 
     g = ds.read_g2o(os.path.join(REF, "111"))
     assert g.sqrt_info is None and g.fixed == [0]
