@@ -19,6 +19,10 @@ vertices move 3.3 mm, Huber never active):
   * controls on the same data: identity L (Ceres' functor without the 1/2) walks 12.9 m (mean) away from *after*, rotation
     weight x0.25 walks 17.9 m; a swapped edge direction or w-first quaternions raise the cost at *after* from 3.0 to
     5360 / 2347.
+How sharply the stationary point itself is defined: the graph is a 4541-vertex chain with few closures, its softest modes
+have curvature ~1e-7, so FP64 rounding of the cost (3e-16) leaves the minimiser undetermined by ~0.1-0.5 mm: a 1e-9 m
+perturbation of the start moves the tightly converged end point by 0.11 mm at a cost equal to 15 digits (asserted below).
+Two correct FP64 implementations (oracle, HIP path) therefore agree on the end point to ~0.5 mm and on its cost to 1e-12.
 What it does NOT give: a replayable path.  From *before* the oracle's LM (Ceres 1.13 rules) descends into a different,
 LOWER minimum (cost 0.548 after 300 iterations, still creeping; ~370 m from *after*): g2o's LM (other damping rule, initial
 guess re-propagated by computeInitialGuess, :141-142) chose another basin of this non-convex problem.  The stationary point
@@ -109,6 +113,20 @@ def test_reference_after_is_a_stationary_point_of_this_cost(O, sp):
     assert mean <= STAT_MEAN_M and mx <= STAT_MAX_M, (mean, mx)
     assert s.final_cost == pytest.approx(2.99881, abs=2e-5)
     assert np.array_equal(p[0], sp["after"][0])
+
+
+def test_the_stationary_point_is_defined_to_tenths_of_a_millimetre_in_fp64(O, sp):
+    """Why GPU-vs-oracle end points are compared at 1e-3 m and their costs at 1e-12 (tests/test_gpu_g2o_strong_pair.py)."""
+    opt = O.default_options(**TIGHT)
+    p0, s0, _ = O.solve(O.Graph(sp["after"], sp["ia"], sp["ib"], sp["meas"], sp["L"]), opt)
+    nudged = sp["after"].copy()
+    nudged[1:, :3] += 1e-9 * np.random.default_rng(1).standard_normal((4540, 3))
+    p1, s1, _ = O.solve(O.Graph(nudged, sp["ia"], sp["ib"], sp["meas"], sp["L"]), opt)
+    assert s1.final_cost == pytest.approx(s0.final_cost, rel=1e-13)
+    d = np.abs(p1[:, :3] - p0[:, :3]).max()
+    assert 1e-5 < d < 1e-3, d
+    p2, s2, _ = O.solve(O.Graph(p0, sp["ia"], sp["ib"], sp["meas"], sp["L"]), opt)   # restarting at the end point: nothing moves
+    assert np.abs(p2[:, :3] - p0[:, :3]).max() < 1e-9
 
 
 def test_wrong_weighting_or_conventions_leave_the_reference_after(O, sp):
