@@ -84,7 +84,11 @@ typedef struct pgo_solver_options {
   int cg_residual_reset_period;           /* 10: every so many CG iterations r is recomputed as b - A x instead of updated
                                              (Ceres conjugate_gradients_solver.cc, LinearSolver::Options::residual_reset_period);
                                              0 = never */
-  int reserved0;
+  int pcg_form;                           /* recurrences of the truncated PCG on one GPU: 0 = the library chooses (the one-launch
+                                             pipelined form where it applies), 1 = standard CG (Ceres' ConjugateGradientsSolver
+                                             statement by statement: two dependent launches per iteration, residual refresh),
+                                             2 = pipelined CG (Ghysels-Vanroose: same iterates in exact arithmetic, one launch per
+                                             iteration); Summary::cg_form says which ran */
   double function_tolerance;              /* 1e-6 */
   double gradient_tolerance;              /* 1e-10 */
   double parameter_tolerance;             /* 1e-8 */
@@ -133,9 +137,10 @@ typedef struct pgo_solver_summary {
   int num_parameter_blocks_reduced;     /* FullReport's Reduced column: constant blocks removed */
   int num_parameters_reduced;
   int num_effective_parameters_reduced;
-  int cg_form;                  /* CG of the PCG solves: 0 one rank (universal stream / batches), 1 several ranks, replicated standard CG
-                                   (every rank updates every row, q all-gathered per iteration), 2 several ranks, owner-only pipelined CG
-                                   (every rank updates its own rows, one all-gather per iteration) */
+  int cg_form;                  /* CG of the PCG solves: 0 one rank, standard CG (two-kernel universal stream / batches), 1 several ranks,
+                                   replicated standard CG (every rank updates every row, q all-gathered per iteration), 2 several ranks,
+                                   owner-only pipelined CG (every rank updates its own rows, one all-gather per iteration), 3 one rank,
+                                   pipelined CG in the fused universal stream (one launch per CG iteration) */
 } pgo_solver_summary;
 
 /* One row per iteration, the numbers Summary::FullReport() tabulates with
@@ -261,6 +266,16 @@ PGO_API int pgo_solver_step(pgo_problem* problem, int n, int* executed, int* don
 PGO_API int pgo_solver_reset(pgo_problem* problem);
 PGO_API int pgo_solver_end(pgo_problem* problem, pgo_solver_summary* summary, pgo_iteration_record* records,
                    int records_capacity);
+/* ---- launch trace of a stepping session (profiling aid; PCG on one GPU in the fused universal stream, Summary::cg_form 3) ----
+ * pgo_solver_trace_start (between pgo_solver_begin / pgo_solver_reset and the pgo_solver_step calls to be traced): from now on
+ * every launch of the stream records what it did and when (device clock, 100 MHz ticks), up to max_launches launches; 0 stops
+ * recording.  pgo_solver_trace_read (the stream is idle between pgo_solver_step calls): records[i] = {operation, start tick of
+ * work-group 0, end tick of the last work-group to finish} of launch i since the trace started; operation: 0 nothing (stream
+ * stopped or paused), 1 head (accept-finish, damping, Jacobi blocks, CG start), 2 first product, 3 CG iteration (or, once the CG
+ * has stopped, the step tail's A x), 4 step tail + decision, 5 linearisation.  host[0] = launches the host enqueued, host[1] =
+ * seconds it spent inside the launch calls since the trace started.  Returns the number of records or a negative status. */
+PGO_API int pgo_solver_trace_start(pgo_problem* problem, int max_launches);
+PGO_API int pgo_solver_trace_read(pgo_problem* problem, long long* records, int capacity, double host[2]);
 /* repeats one kernel of the path `repeats` times on the solver stream between two HIP events and
  * returns the average milliseconds per launch.  kernel: "linearize", "spmv", "cost", "evaluate",
  * "pcg_update". */

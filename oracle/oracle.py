@@ -28,7 +28,7 @@ class Options(C.Structure):
         ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
         ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
         ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double), ("eta", C.c_double),
-        ("pcg_cluster", C.c_int), ("num_threads", C.c_int),
+        ("pcg_cluster", C.c_int), ("num_threads", C.c_int), ("pcg_form", C.c_int), ("reserved", C.c_int),
     ]
 
 

@@ -991,8 +991,14 @@ struct RowEvents {
   }
 };
 
+// form 0: Ceres' ConjugateGradientsSolver statement by statement.  form 1: the same Krylov iterates through the pipelined
+// recurrences of Ghysels & Vanroose (2014) — u = M^-1 r, w = A u, m = M^-1 w, n = A m; z = n + beta z, qq = m + beta qq,
+// s = w + beta s, p = u + beta p; x += alpha p, r -= alpha s, u -= alpha qq, w -= alpha z — with ONE set of inner products
+// (gamma = (r,u), delta = (w,u), Q = -x'(b + r)) per iteration, the form the product's one-launch CG iteration computes
+// (posegraph-ceres_amd/csrc/pgo_uni_fused.h); same stop rules on the same quantities, no residual refresh.
 int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, double q_tol,
-              int max_it, int min_it, int residual_reset_period, bool* ok, double* final_rnorm, int cluster = 1, Pool* pool = nullptr) {
+              int max_it, int min_it, int residual_reset_period, bool* ok, double* final_rnorm, int cluster = 1, Pool* pool = nullptr,
+              int form = 0) {
   const int n = H.n;
   const size_t m = (size_t)6 * n;
   if (pool && pool->width() <= 1) pool = nullptr;
@@ -1035,6 +1041,45 @@ int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, d
   std::fill(x, x + m, 0.0);
   double rho = 1.0;
   auto dot = [&](const double* a_, const double* b_) { double s = 0; for (size_t i = 0; i < m; ++i) s += a_[i] * b_[i]; return s; };
+  if (form == 1) {
+    std::vector<double> u(m), w(m), mv(m), nv(m), zz(m, 0.0), qq(m, 0.0), sv(m, 0.0);
+    apply_M(r.data(), u.data());
+    matvec(u.data(), w.data());
+    *ok = true;
+    double gamma_prev = 0.0, alpha_prev = 0.0, q_prev = 0.0;
+    int cnt = 0;
+    for (;;) {
+      apply_M(w.data(), mv.data());
+      const double gamma = dot(r.data(), u.data()), delta = dot(w.data(), u.data());
+      double sQ = 0;
+      for (size_t i = 0; i < m; ++i) sQ += x[i] * (b[i] + r[i]);
+      const double Q1 = -1.0 * sQ;
+      if (cnt > 0) {
+        const double zeta = cnt * (Q1 - q_prev) / Q1;
+        if (zeta < q_tol && cnt >= min_it) break;
+        if (cnt >= max_it) break;
+      }
+      if (gamma == 0.0 || !std::isfinite(gamma)) { *ok = (gamma == 0.0); break; }
+      double beta = 0.0;
+      if (cnt > 0) {
+        beta = gamma / gamma_prev;
+        if (beta == 0.0 || !std::isfinite(beta)) { *ok = false; break; }
+      }
+      const double den = cnt > 0 ? delta - beta * gamma / alpha_prev : delta;
+      if (!(den > 0.0) || !std::isfinite(den)) break;     // "matrix is indefinite": x of the previous iteration stands
+      const double alpha = gamma / den;
+      matvec(mv.data(), nv.data());
+      for (size_t i = 0; i < m; ++i) {
+        const double zn = nv[i] + beta * zz[i], qn = mv[i] + beta * qq[i], sn = w[i] + beta * sv[i], pn = u[i] + beta * p[i];
+        zz[i] = zn; qq[i] = qn; sv[i] = sn; p[i] = pn;
+        x[i] += alpha * pn; r[i] -= alpha * sn; u[i] -= alpha * qn; w[i] -= alpha * zn;
+      }
+      gamma_prev = gamma; alpha_prev = alpha; q_prev = Q1;
+      ++cnt;
+    }
+    if (final_rnorm) *final_rnorm = std::sqrt(dot(r.data(), r.data()));
+    return cnt;
+  }
   double Q0;
   { double s = 0; for (size_t i = 0; i < m; ++i) s += x[i] * (b[i] + r[i]); Q0 = -1.0 * s; }
   *ok = true;
@@ -1104,6 +1149,8 @@ struct oracle_options {
   int pcg_cluster;                     // poses per Jacobi block of the PCG preconditioner (1 = 6x6 blocks, Ceres JACOBI-like)
   int num_threads;   /* 0 / 1: sequential (the reference sets num_threads = 1); > 1: Jacobian evaluation, cost evaluation and the
                         numeric Cholesky on that many threads — same results to the bit */
+  int pcg_form;      /* 0: Ceres' CG statement by statement; 1: the pipelined recurrences (pcg_solve above) */
+  int reserved;
 };
 
 struct oracle_summary {
@@ -1149,6 +1196,8 @@ void oracle_default_options(oracle_options* o) {
   o->eta = 0.1;
   o->pcg_cluster = 1;
   o->num_threads = 0;
+  o->pcg_form = 0;
+  o->reserved = 0;
 }
 
 void oracle_edge_eval_autodiff(const double* pa, const double* qa, const double* pb, const double* qb,
@@ -1237,7 +1286,10 @@ int oracle_linear_solve(int N, int E, const double* poses, const uint8_t* cmask,
     return 0;
   }
   bool ok;
-  int it = pcg_solve(H, d2, b, x, q_tol, max_it, 0, 10, &ok, nullptr, linear_solver >= 100 ? linear_solver - 100 : 1);
+  // linear_solver: 1 = 6x6 Jacobi blocks, 100 + c = clusters of c poses; + 1000 = the pipelined recurrences
+  const int form = linear_solver >= 1000 ? 1 : 0;
+  if (form) linear_solver -= 1000;
+  int it = pcg_solve(H, d2, b, x, q_tol, max_it, 0, 10, &ok, nullptr, linear_solver >= 100 ? linear_solver - 100 : 1, nullptr, form);
   return ok ? it : -1;
 }
 
@@ -1381,7 +1433,7 @@ int oracle_solve(int N, int E, double* poses, const uint8_t* cmask, const int* i
       sum->factor_flops = chol.flops;
     } else {
       lin_it = pcg_solve(H, d2.data(), gs.data(), step.data(), opt->eta, opt->max_linear_solver_iterations,
-                         opt->min_linear_solver_iterations, opt->residual_reset_period, &lin_ok, nullptr, opt->pcg_cluster, pool.get());
+                         opt->min_linear_solver_iterations, opt->residual_reset_period, &lin_ok, nullptr, opt->pcg_cluster, pool.get(), opt->pcg_form);
       sum->num_linear_iterations += lin_it;
     }
     if (lin_ok) for (size_t i = 0; i < m; ++i) { if (!std::isfinite(step[i])) { lin_ok = false; break; } }

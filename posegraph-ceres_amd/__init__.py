@@ -40,7 +40,7 @@ C_ABI_SYMBOLS = [
     "pgo_problem_set_parameter_block_constant", "pgo_problem_num_poses", "pgo_problem_num_edges",
     "pgo_solver_options_init", "pgo_solve", "pgo_summary_is_solution_usable", "pgo_summary_full_report",
     "pgo_evaluate", "pgo_normal_equations", "pgo_linear_solve", "pgo_plus", "pgo_solver_begin",
-    "pgo_solver_step", "pgo_solver_reset", "pgo_solver_end", "pgo_time_kernel", "pgo_shard_range",
+    "pgo_solver_step", "pgo_solver_reset", "pgo_solver_end", "pgo_time_kernel", "pgo_solver_trace_start", "pgo_solver_trace_read", "pgo_shard_range",
     "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_debug_comm_stress", "pgo_debug_lm_decide", "pgo_loopback_create", "pgo_loopback_destroy", "pgo_comm_init_loopback",
     "pgo_generate_candidates", "pgo_reproj_options_init", "pgo_reproj_solve_batch",
     "pgo_row_shard_range", "pgo_read_trajectory", "pgo_build_odometry_edges", "pgo_edge_rules_init", "pgo_build_edges",
@@ -59,7 +59,7 @@ class _COptions(C.Structure):
         ("max_num_iterations", C.c_int), ("linear_solver_type", C.c_int), ("jacobi_scaling", C.c_int),
         ("max_linear_solver_iterations", C.c_int), ("min_linear_solver_iterations", C.c_int),
         ("max_num_consecutive_invalid_steps", C.c_int), ("cg_batch", C.c_int), ("pcg_cluster_poses", C.c_int),
-        ("cg_residual_reset_period", C.c_int), ("reserved0", C.c_int),
+        ("cg_residual_reset_period", C.c_int), ("pcg_form", C.c_int),
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
         ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
         ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
@@ -496,6 +496,19 @@ class Problem:
 
     def comm_init_loopback(self, group, rank):
         _check(lib().pgo_comm_init_loopback(self._h, C.c_void_p(group), C.c_int(rank)))
+
+    def trace_start(self, max_launches=20000):
+        """Launch trace of the fused universal stream (include/pgo.h pgo_solver_trace_start); 0 stops recording."""
+        _check(lib().pgo_solver_trace_start(self._h, C.c_int(max_launches)))
+
+    def trace_read(self, capacity=20000):
+        """-> (records [n][3] int64: operation, start tick, end tick (100 MHz device clock); host launches; host enqueue seconds)"""
+        rec = np.zeros((capacity, 3), dtype=np.int64)
+        host = (C.c_double * 2)()
+        n = lib().pgo_solver_trace_read(self._h, rec.ctypes.data_as(C.POINTER(C.c_longlong)), C.c_int(capacity), host)
+        if n < 0:
+            _check(n)
+        return rec[:n].copy(), int(host[0]), float(host[1])
 
     def time_kernel(self, name, repeats=100):
         ms = C.c_double(0)

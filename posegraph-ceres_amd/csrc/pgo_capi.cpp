@@ -160,6 +160,47 @@ int pgo_plus(pgo_problem* P, const double* delta) {
   return download_poses(P, P->g.pose_c);
 }
 
+static const int TRACE_WORDS = 66;     // pgo_uni_fused.h UNI_F_TRACE_WORDS
+int pgo_solver_trace_start(pgo_problem* P, int max_launches) {
+  if (!P || max_launches < 0) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_solver_trace_start");
+  if (!P->lm.active || !P->stream_ready) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_trace_start needs a stepping session (call pgo_solver_begin first)");
+  if (!P->uni_fused) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_trace_start: this session does not run the fused universal stream");
+  HIP_TRY(hipStreamSynchronize(P->stream));
+  if (max_launches == 0) { P->g.oplog = nullptr; P->g.oplog_cap = 0; return PGO_OK; }
+  // the launch index the kernels record under restarts whenever the device state is uploaded afresh; make that happen now
+  P->pipe_dirty = true;
+  const size_t cap = 1 + (size_t)TRACE_WORDS * max_launches;
+  HIP_TRY(P->d_oplog.alloc(cap));
+  HIP_TRY(hipMemsetAsync(P->d_oplog.p, 0, cap * sizeof(long long), P->stream));
+  HIP_TRY(hipStreamSynchronize(P->stream));
+  P->g.oplog = P->d_oplog.p; P->g.oplog_cap = (int)cap;
+  P->uni_host_launches = 0; P->uni_host_enqueue_s = 0.0;
+  return PGO_OK;
+}
+
+int pgo_solver_trace_read(pgo_problem* P, long long* records, int capacity, double host[2]) {
+  if (!P || !records || capacity < 0) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_solver_trace_read");
+  if (!P->g.oplog || !P->uni_fused) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_trace_read: no trace is being recorded (pgo_solver_trace_start)");
+  HIP_TRY(hipStreamSynchronize(P->stream));
+  const int n = std::min(std::min(P->uni_enq, (P->g.oplog_cap - 1) / TRACE_WORDS), capacity);
+  std::vector<long long> h((size_t)TRACE_WORDS * std::max(n, 1));
+  if (n) HIP_TRY(hipMemcpy(h.data(), P->g.oplog + 1, (size_t)TRACE_WORDS * n * sizeof(long long), hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i) {
+    const long long* w = h.data() + (size_t)TRACE_WORDS * i;
+    long long end = 0;
+    for (int x = 0; x < TRACE_WORDS - 2; ++x) end = std::max(end, w[2 + x]);
+    if (getenv("PGO_TRACE_PHASES") && (w[0] & 7) == 4 && i < 120)
+      std::fprintf(stderr, "[pgo] launch %d TAIL, deciding work-group (ticks from ITS top): loops done %lld, last arrival known %lld, folded %lld, decided %lld\n", i, w[1] & 0xffff, (w[1] >> 16) & 0xffff, (w[1] >> 32) & 0xffff, (w[1] >> 48) & 0xffff);
+    if (getenv("PGO_TRACE_PHASES") && (w[0] & 7) == 3 && i > 40 && i < 46)
+      std::fprintf(stderr, "[pgo] launch %d work-group 0: product done %lld, fold %lld, rows %lld, end %lld ticks (10 ns)\n", i, w[1] & 0xffff, (w[1] >> 16) & 0xffff, (w[1] >> 32) & 0xffff, (w[1] >> 48) & 0xffff);
+    records[3 * (size_t)i] = w[0] & 7;
+    records[3 * (size_t)i + 1] = w[0] >> 3;
+    records[3 * (size_t)i + 2] = end;
+  }
+  if (host) { host[0] = (double)P->uni_host_launches; host[1] = P->uni_host_enqueue_s; }
+  return n;
+}
+
 int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg_ms) {
   if (!P || !kernel || repeats <= 0 || !avg_ms) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_time_kernel");
   if (P->topo_dirty || !P->stream_ready) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel needs a prepared problem (call pgo_solver_begin first)");
@@ -233,11 +274,21 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     HIP_TRY(hipEventCreate(&b));
     double total = 0;
     for (int r = 0; r < repeats + 1; ++r) {
-      pgo::launch_lm_budget(gp, -1, s);
-      pgo::launch_uni_v(gp, np, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, s);    // head: damping, preconditioner, CG start
-      pgo::launch_uni_s(gp, np, 0, s);
-      HIP_TRY(hipEventRecord(a, s));
-      for (int i = 0; i < pairs; ++i) { pgo::launch_uni_v(gp, np, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, s); pgo::launch_uni_s(gp, np, 0, s); }
+      if (P->uni_fused) {
+        // fused form: head, first product, then 200 CG launches (one launch is one CG iteration)
+        int L = 0;
+        pgo::launch_lm_budget(gp, -1, s, L);
+        pgo::launch_uni_f(gp, np, L++, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, s);
+        pgo::launch_uni_f(gp, np, L++, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, s);
+        HIP_TRY(hipEventRecord(a, s));
+        for (int i = 0; i < pairs; ++i) pgo::launch_uni_f(gp, np, L++, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, s);
+      } else {
+        pgo::launch_lm_budget(gp, -1, s);
+        pgo::launch_uni_v(gp, np, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, s);    // head: damping, preconditioner, CG start
+        pgo::launch_uni_s(gp, np, 0, s);
+        HIP_TRY(hipEventRecord(a, s));
+        for (int i = 0; i < pairs; ++i) { pgo::launch_uni_v(gp, np, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, s); pgo::launch_uni_s(gp, np, 0, s); }
+      }
       HIP_TRY(hipEventRecord(b, s));
       HIP_TRY(hipEventSynchronize(b));
       float ms = 0.f;

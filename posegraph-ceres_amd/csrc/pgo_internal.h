@@ -336,7 +336,7 @@ struct pgo_problem {
   DevBuf<uint8_t> d_slot_side, d_cmask;
   DevBuf<double> d_smeas, d_sW, d_emeas, d_eW, d_eL, d_pose_x, d_pose_c, d_pose_0, d_bsr, d_Hdiag, d_Minv, d_grad,
       d_scale, d_d2, d_diagc, d_cg_b, d_cg_x, d_cg_r, d_cg_z, d_cg_q, d_cg_p0, d_cg_p1, d_delta, d_part_rz, d_part_q,
-      d_part_rr, d_part_bb, d_part_misc, d_tmp_a, d_tmp_b, d_tmp_c, d_cg_u, d_cg_w, d_cg_s, d_cg_qq, d_pipe_a, d_pipe_b, d_pipe_x;
+      d_part_rr, d_part_bb, d_part_misc, d_tmp_a, d_tmp_b, d_tmp_c, d_cg_u, d_cg_w, d_cg_s, d_cg_qq, d_pipe_a, d_pipe_b, d_pipe_x, d_part_f;
   DevBuf<pgo::CgState> d_cg;
   DevBuf<long long> d_oplog;        // PGO_UNI_OPLOG=<file>: per-launch operation log of k_uni_s (DeviceGraph::oplog), appended to the file at pgo_solver_end
   // device-initiated exchange of the owner-only CG (DeviceGraph::peer_tab): the table of every rank's buffers, this rank's flags, the
@@ -362,7 +362,11 @@ struct pgo_problem {
   int pipe_pulled = 0;             // next iteration record to copy from the pinned ring into LmState::records
   bool pipe_dirty = true;          // LmState was (re)initialised by the host: upload it before the next sequence
   bool universal = false;          // PCG on one rank: the universal stream (pgo_kernels.h UniOp) instead of allotted sequences
-  int uni_enq = 0;                 // vector-shaped launches of the stream enqueued since the last upload
+  int uni_enq = 0;                 // vector-shaped launches (fused form: launches) of the stream enqueued since the last upload
+  bool uni_fused = false;          // ... in its fused form (k_uni_f: one kernel symbol, one launch per CG iteration, pipelined recurrences)
+  // what the host spent enqueueing the stream (pgo_solver_trace): launches and seconds inside the launch calls, since pgo_solver_begin
+  long long uni_host_launches = 0;
+  double uni_host_enqueue_s = 0.0;
   double pipe_t_linear0 = 0, pipe_t_jacobian0 = 0;   // LmState times when the device clocks were last zeroed
   // captured CG batches, keyed by the number of iterations in the batch
   struct CapturedBatch { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };

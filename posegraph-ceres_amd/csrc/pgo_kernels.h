@@ -134,7 +134,13 @@ struct CgState {
   double q_hist[2];    //   (written during the previous launch), so it re-reduces two partial rows instead of four
   // owner-only CG of the sharded path (k_pipe_cg below): launch `seq` reads pipe[seq & 1] and writes the other slot
   struct Pipe { int cnt, pad; double gamma_prev, alpha_prev, q_prev; } pipe[2];
+  // universal stream, fused form (k_uni_f, r05): ONE kernel per launch, the whole stream state double-buffered by launch parity —
+  // launch L reads f[L & 1] (written during launch L - 1 by one lane) and one lane writes f[(L & 1) ^ 1]: no word is read and
+  // written by the same launch.  op: FusedOp; cnt: CG iterations completed; the scalars of the pipelined recurrences as in Pipe.
+  struct Fused { int op, cnt; double gamma_prev, alpha_prev, q_prev; } f[2];
 };
+// what a launch of the fused universal stream does (CgState::Fused::op)
+enum FusedOp { F_EXIT = -1, F_IDLE = 0, F_HEAD = 1, F_W0 = 2, F_CG = 3, F_TAIL = 4, F_LIN = 5 };
 
 struct DeviceGraph {
   int N, E;
@@ -205,6 +211,7 @@ struct DeviceGraph {
   double* part_rr;    // [2][n_part]  |r|^2
   double* part_bb;    // [n_part]     |b|^2 (written by pcg_init)
   double* part_misc;  // [8][n_part] scratch partials for LM scalars
+  double* part_f;     // [2][n_part][4] fused universal stream: per work-group (r,u), (w,u), x'(b + r) by launch parity (k_uni_f)
   int n_part;         // capacity of one partial row (>= max grid of any reducing kernel)
   int n_vec_wg;       // grid of the element-wise kernels (6N lanes)
   int n_edge_wg;      // grid of edge-parallel kernels
@@ -212,10 +219,12 @@ struct DeviceGraph {
   CgState* cg;        // device
   LmDev* lm;          // device-resident LM state; null: the host decides and passes radius / mode by value (several ranks, batched solve, tests)
   LmScalars* scal;    // device-visible pinned host memory
-  int* flags;         // [4] device flags: [0] linearize saw non-finite
+  int* flags;         // [16] device flags: [0] linearize saw non-finite; [4..12] two-level ticket of the fused universal stream
   int debug;          // development ablation switches (0 in production)
   // profiling aid (PGO_UNI_OPLOG=<file>, null otherwise): every k_uni_s launch appends (operation it performed, s_memrealtime) so
   // that tools/rocprof_summary.py can bucket the dispatches of that one kernel symbol by what they did.  [0] = entries so far.
+  // Fused stream (pgo_solver_trace_*): launch L owns the 66 words at 1 + 66 L: [0] (start tick << 3 | operation) by work-group 0,
+  // [2 + s] the latest end tick among the work-groups with index % 64 == s (atomic max).
   long long* oplog;
   int oplog_cap;
   // linearisation into the symmetric tile form by the row kernel (k_linearize_symout): stored slot of every incidence slot (-1: the
@@ -291,7 +300,11 @@ void launch_lm_resume(const DeviceGraph& g, int cg_goes_on, hipStream_t s);
 // `decisions` more LM iterations; the publish kernel sets LmScalars::seq behind everything enqueued so far
 void launch_uni_s(const DeviceGraph& g, const CgParams& p, int period, hipStream_t s);
 void launch_uni_v(const DeviceGraph& g, const CgParams& p, double min_diag, double max_diag, hipStream_t s);
-void launch_lm_budget(const DeviceGraph& g, int decisions, hipStream_t s);
+// fused form: one kernel symbol; `launch` = index of this launch in the stream (its parity selects the state
+// slot, the partial-sum rows and the exchange buffer it reads; the device reports launch + 1 as LmScalars::slots_done)
+void launch_uni_f(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s);
+bool uni_f_supported(const DeviceGraph& g, const CgParams& p, int cluster);
+void launch_lm_budget(const DeviceGraph& g, int decisions, hipStream_t s, int next_launch = 0);
 void launch_lm_publish(const DeviceGraph& g, hipStream_t s);
 bool uni_supported(const DeviceGraph& g);
 // owner-only pipelined CG of the sharded path: r0 / u0 of the owned rows; one launch per product (seq 0: w0 = A u0, seq i + 1:

@@ -2373,7 +2373,8 @@ __global__ void k_hdiag6(DeviceGraph g, double* buf, int phase) {
 }
 
 // (Re)opens the universal stream for `decisions` more LM iterations; behind LM_HALT_BUDGET the head launch that paused it is due again.
-__global__ void k_lm_budget(DeviceGraph g, int decisions) {
+// next_launch: index of the first launch behind this kernel (fused form: its parity names the state slot that launch reads)
+__global__ void k_lm_budget(DeviceGraph g, int decisions, int next_launch) {
   LmDev& D = *g.lm;
   D.t_mark = (long long)__builtin_amdgcn_s_memrealtime();
   D.decision_limit = decisions < 0 ? 0x7fffffff : D.lm_done + decisions;
@@ -2382,6 +2383,9 @@ __global__ void k_lm_budget(DeviceGraph g, int decisions) {
     D.halt = LM_RUN;
     g.cg->op_s = UNI_NOP;
     g.cg->op_v = UNI_V_HEAD;
+    CgState::Fused n{};
+    n.op = F_HEAD;
+    g.cg->f[next_launch & 1] = n;
     g.scal->halt = 0;
   }
 }
@@ -2504,6 +2508,8 @@ __global__ void k_copy_delta(DeviceGraph g, const double* step) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < 6 * g.N) g.delta[idx] = step[idx];
 }
+
+#include "pgo_uni_fused.h"
 
 }  // namespace
 
@@ -2656,7 +2662,29 @@ void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, 
 #undef PGO_PIPE
   if (mode == 0) hipLaunchKernelGGL(k_pipe_fold, dim3(1), dim3(256), 0, s, g, seq, gseq);
 }
-void launch_lm_budget(const DeviceGraph& g, int decisions, hipStream_t s) { hipLaunchKernelGGL(k_lm_budget, dim3(1), dim3(1), 0, s, g, decisions); }
+void launch_lm_budget(const DeviceGraph& g, int decisions, hipStream_t s, int next_launch) {
+  hipLaunchKernelGGL(k_lm_budget, dim3(1), dim3(1), 0, s, g, decisions, next_launch);
+}
+// The fused stream serves the truncated CG (Q-tolerance stop, no residual test) with 6x6 or 12x12 Jacobi blocks on a row
+// partition whose work-groups hold whole pose pairs and no row fatter than a work-group (prepare(): pairs_whole).
+bool uni_f_supported(const DeviceGraph& g, const CgParams& p, int cluster) {
+  return g.world == 1 && g.block <= 256 && g.pairs_whole && g.n_wg <= UNI_F_FOLD * g.block && g.pipe_buf[0] && g.cg_u && g.part_f &&
+         (cluster == 1 || cluster == 2) &&
+         p.q_tolerance >= 0.0 && p.r_tolerance < 0.0;
+}
+void launch_uni_f(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s) {
+  const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);
+#define PGO_UNI_F2(PK, INF, CLV) hipLaunchKernelGGL((k_uni_f<PK, INF, CLV>), dim3(g.n_wg), dim3(g.block), lds, s, g, p, launch, min_diag, max_diag)
+#define PGO_UNI_F(PK, INF) do { if (g.cluster == 2) PGO_UNI_F2(PK, INF, 2); else PGO_UNI_F2(PK, INF, 1); } while (0)
+  if (g.blk_packed) {
+    if (g.info_mode == 3) PGO_UNI_F(true, 3);
+    else if (g.info_mode == 2) PGO_UNI_F(true, 2);
+    else PGO_UNI_F(true, 0);
+  } else if (g.info_mode == 0) PGO_UNI_F(false, 0);
+  else PGO_UNI_F(false, 1);
+#undef PGO_UNI_F
+#undef PGO_UNI_F2
+}
 void launch_lm_publish(const DeviceGraph& g, hipStream_t s) { hipLaunchKernelGGL(k_lm_publish, dim3(1), dim3(1), 0, s, g); }
 void launch_finalize_scalars(const DeviceGraph& g, int n_cost_part, hipStream_t s, int gate) {
   hipLaunchKernelGGL(k_finalize_scalars, dim3(1), dim3(256), 0, s, g, n_cost_part, gate);

@@ -101,6 +101,10 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   L.active = true;
   P->pipelined = pipeline_wanted(P);
   P->universal = universal_wanted(P);
+  // ... in its fused form (one launch per CG iteration, pipelined recurrences) unless the caller asks for the standard CG or the
+  // request is one the fused kernel does not serve (pgo_kernels.hip uni_f_supported)
+  P->uni_fused = P->universal && P->opt.pcg_form != 1 && pgo::uni_f_supported(P->g, cg_params_for(P->opt), P->g.cluster);
+  P->uni_host_launches = 0; P->uni_host_enqueue_s = 0.0;
   P->pipe_dirty = true;
   // symmetric tile form for the CG products: host-driven PCG of a large graph on one rank (pgo_sym.h)
   P->sym_active = false; P->sym_storage = false;
@@ -571,7 +575,9 @@ int lm_run_universal(pgo_problem* P, int budget, int* ran) {
   }
   // (an LM iteration is at least two pairs, records are pulled once per turn of the loop below: at most hi / 2 decisions between
   // two pulls, which has to stay below the LM_RING - 2 record slots in flight)
-  static const int hi = getenv("PGO_UNI_AHEAD") ? std::min(2 * (pgo::LM_RING - 4), std::max(2, atoi(getenv("PGO_UNI_AHEAD")))) : 12;
+  // (fused form: the unit is one launch, an LM iteration is at least four)
+  const bool fused = P->uni_fused;
+  const int hi = fused ? 24 : 12;
   const int lo = std::max(1, hi / 3);
   const pgo::CgParams prm = cg_params_for(o);
   const int period = prm.q_tolerance < 0.0 ? 0 : o.cg_residual_reset_period;
@@ -579,18 +585,24 @@ int lm_run_universal(pgo_problem* P, int budget, int* ran) {
   gp.lm = P->d_lm.p;
   const int d0 = __atomic_load_n(&P->scal->lm_done, __ATOMIC_ACQUIRE);
   P->scal->halt = 0;
-  pgo::launch_lm_budget(gp, budget, s);
+  pgo::launch_lm_budget(gp, budget, s, P->uni_enq);
   unsigned idle_spins = 0;
   auto t_idle = Clock::now();
   for (;;) {
     if (__atomic_load_n(&P->scal->halt, __ATOMIC_ACQUIRE)) break;
     const int pending = P->uni_enq - __atomic_load_n(&P->scal->slots_done, __ATOMIC_ACQUIRE);
     if (pending <= hi - lo) {
+      const auto t_enq = Clock::now();
       for (int i = 0; i < lo; ++i) {
-        pgo::launch_uni_v(gp, prm, o.min_lm_diagonal, o.max_lm_diagonal, s);
-        pgo::launch_uni_s(gp, prm, period, s);
+        if (fused) pgo::launch_uni_f(gp, prm, P->uni_enq, o.min_lm_diagonal, o.max_lm_diagonal, s);
+        else {
+          pgo::launch_uni_v(gp, prm, o.min_lm_diagonal, o.max_lm_diagonal, s);
+          pgo::launch_uni_s(gp, prm, period, s);
+        }
         ++P->uni_enq;
       }
+      P->uni_host_enqueue_s += seconds_since(t_enq);
+      P->uni_host_launches += fused ? lo : 2 * lo;
       lm_pull_records(P, false);
       idle_spins = 0; t_idle = Clock::now();
       continue;
@@ -765,7 +777,7 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
   }
   if (summary) {
     memset(summary, 0, sizeof *summary);
-    summary->cg_form = P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : 0;
+    summary->cg_form = P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : (P->uni_fused ? 3 : 0);
     summary->termination_type = L.termination;
     summary->reason = L.reason;
     summary->num_successful_steps = L.num_successful;

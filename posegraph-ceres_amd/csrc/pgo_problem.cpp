@@ -167,9 +167,9 @@ int prepare(pgo_problem* P) {
   // rows -> workgroups (greedy packing of `block` slots; a row with more incidences gets its own multi-chunk group)
   std::vector<int> wg_row_begin, wg_slot_begin, row_slot_begin(N, 0), row_slot_cnt(N, 0);
   long long slot = 0;
-  // Several ranks: a work-group boundary never separates the poses 2i and 2i + 1 (the owner-only CG applies the 12 x 12 Jacobi
-  // blocks inside the work-group that owns their rows: k_pipe_cg).  One rank keeps the tighter packing.
-  const bool keep_pairs = world > 1;
+  // A work-group boundary never separates the poses 2i and 2i + 1: the one-launch CG iteration (several ranks: k_pipe_cg; one rank:
+  // the fused universal stream k_uni_f) applies the 12 x 12 Jacobi blocks inside the work-group that owns their rows.
+  const bool keep_pairs = true;
   bool pairs_whole = keep_pairs;
   auto pack = [&](int lo, int hi, bool record) -> int {
     long long sl = 0;
@@ -346,7 +346,7 @@ int prepare(pgo_problem* P) {
   HIP_TRY(P->d_cg_q.alloc((size_t)world * seg));   // exchange buffer: q segments + p'q partials (unused partial slots stay 0)
   HIP_TRY(P->d_cg_q.zero(s));
   const int pipe_seg = rows_per * 6 + 4;      // m of the owned rows, then this rank's (r,u), (w,u), x'(b + r)
-  if (world > 1) {     // owner-only CG (pgo_kernels.h DeviceGraph::pipe_buf)
+  {                    // one-launch CG iterations (pgo_kernels.h DeviceGraph::pipe_buf): owner-only CG of several ranks, fused stream of one
     for (DevBuf<double>* b : pipe_vecs) { HIP_TRY(b->alloc(m)); HIP_TRY(b->zero(s)); }
     HIP_TRY(P->d_pipe_a.alloc((size_t)world * pipe_seg)); HIP_TRY(P->d_pipe_a.zero(s));
     HIP_TRY(P->d_pipe_b.alloc((size_t)world * pipe_seg)); HIP_TRY(P->d_pipe_b.zero(s));
@@ -368,9 +368,11 @@ int prepare(pgo_problem* P) {
   HIP_TRY(P->d_part_bb.zero(s));
   HIP_TRY(P->d_part_misc.alloc((size_t)8 * n_part));
   HIP_TRY(P->d_part_misc.zero(s));
+  HIP_TRY(P->d_part_f.alloc((size_t)2 * 4 * n_part));     // fused stream: [launch parity][work-group][gamma, delta, Q, -]
+  HIP_TRY(P->d_part_f.zero(s));
   HIP_TRY(P->d_cg.alloc(1));
   HIP_TRY(P->d_cg.zero(s));
-  HIP_TRY(P->d_flags.alloc(4));
+  HIP_TRY(P->d_flags.alloc(16));     // [0..3] as pgo_kernels.h says, [4..12] the two-level ticket of the fused stream (k_uni_f)
   HIP_TRY(P->d_flags.zero(s));
 
   pgo::DeviceGraph& g = P->g;
@@ -400,7 +402,7 @@ int prepare(pgo_problem* P) {
   g.diag_clamped = P->d_diagc.p; g.cg_b = P->d_cg_b.p; g.cg_x = P->d_cg_x.p; g.cg_r = P->d_cg_r.p;
   g.cg_z = P->d_cg_z.p; g.cg_q = P->d_cg_q.p; g.cg_p0 = P->d_cg_p0.p; g.cg_p1 = P->d_cg_p1.p;
   g.delta = P->d_delta.p; g.part_rz = P->d_part_rz.p; g.part_q = P->d_part_q.p;
-  g.part_rr = P->d_part_rr.p; g.part_bb = P->d_part_bb.p; g.part_misc = P->d_part_misc.p;
+  g.part_rr = P->d_part_rr.p; g.part_bb = P->d_part_bb.p; g.part_misc = P->d_part_misc.p; g.part_f = P->d_part_f.p;
   g.cg_u = P->d_cg_u.p; g.cg_w = P->d_cg_w.p; g.cg_s = P->d_cg_s.p; g.cg_qq = P->d_cg_qq.p;
   g.pipe_buf[0] = P->d_pipe_a.p; g.pipe_buf[1] = P->d_pipe_b.p; g.pipe_seg = pipe_seg;
   g.peer_tab = nullptr; g.peer_flags = nullptr;
@@ -675,7 +677,7 @@ void pgo_solver_options_init(pgo_solver_options* o) {
   o->cg_batch = 0;
   o->pcg_cluster_poses = 1;
   o->cg_residual_reset_period = 10;   // LinearSolver::Options::residual_reset_period of Ceres 1.13
-  o->reserved0 = 0;
+  o->pcg_form = 0;
   o->function_tolerance = 1e-6;
   o->gradient_tolerance = 1e-10;
   o->parameter_tolerance = 1e-8;

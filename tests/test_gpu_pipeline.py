@@ -37,6 +37,7 @@ class _Env:
 
 
 def _solve(gpu, g, driver, **opt):
+    opt.setdefault("pcg_form", 1)      # the three drivers run the same kernels only with Ceres' CG recurrences (the fused stream's own tests: test_gpu_fused.py)
     with _Env(driver):
         prob, poses = gpu.problem_from_graph(g)
         s = gpu.solve(gpu.SolverOptions(**opt), prob)
