@@ -85,7 +85,7 @@ typedef struct pgo_solver_options {
                                              (Ceres conjugate_gradients_solver.cc, LinearSolver::Options::residual_reset_period);
                                              0 = never */
   int pcg_form;                           /* recurrences of the truncated PCG on one GPU: 0 = the library chooses (the one-launch
-                                             pipelined form where it applies), 1 = standard CG (Ceres' ConjugateGradientsSolver
+                                             pipelined form where it applies and eta >= 0.01), 1 = standard CG (Ceres' ConjugateGradientsSolver
                                              statement by statement: two dependent launches per iteration, residual refresh),
                                              2 = pipelined CG (Ghysels-Vanroose: same iterates in exact arithmetic, one launch per
                                              iteration); Summary::cg_form says which ran */

@@ -220,12 +220,17 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     if (rcs) return rcs;
     if (!P->sym_ready || (k == "sym_linearize" && !P->sym_lin_fits)) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): the graph does not fit the symmetric tile form", kernel);
   }
+  // (a session that keeps the symmetric form as its ONLY storage has no current incidence-slot blocks to repack from: damping goes
+  // through the form's view, a repack would overwrite the live form with the blocks of iteration zero)
+  if (k == "sym_repack" && P->sym_storage)
+    return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('sym_repack'): this session stores the normal equations in the symmetric form only; there is nothing to repack");
   if (k == "pcg_spmv" || k == "pcg_update" || k == "pcg_iteration" || k == "sym_spmv") {
-    pgo::launch_damping(P->g, P->lm.radius, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, 0, s);
+    if (P->sym_storage) pgo::launch_damping(sym_view(P), P->lm.radius, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, 0, s);
+    else pgo::launch_damping(P->g, P->lm.radius, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, 0, s);
     pgo::launch_pcg_init(P->g, s);
   }
   if (k == "pcg_update") pgo::launch_pcg_spmv_only(P->g, prm, 1, s);
-  if (k == "sym_spmv" || k == "sym_plain") pgo::launch_sym_repack(P->g, P->sym, s);
+  if ((k == "sym_spmv" || k == "sym_plain") && !P->sym_storage) pgo::launch_sym_repack(P->g, P->sym, s);
   const bool wants_factor = k == "direct" || k == "front_factor" || k == "front_solve";
   if (wants_factor) {
     if (!P->direct_usable) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): no GPU factorisation prepared for this problem", kernel);

@@ -291,7 +291,7 @@ struct LmState {
   double radius = 1e4, decrease_factor = 2.0;
   bool reuse_diagonal = false;
   bool gmax_deferred = false;  // gradient norm of the accepted point is read at the next host sync
-  double x_cost = 0, x_norm = 0, gmax = 0, initial_cost = 0;
+  double x_cost = 0, x_norm = 0, gmax = 0, initial_cost = 0, initial_x_norm = 0;
   int num_successful = 0, num_unsuccessful = 0, num_consecutive_invalid = 0, num_linear_iterations = 0;
   pgo_iteration_record cur{};
   std::vector<pgo_iteration_record> records;

@@ -2331,7 +2331,7 @@ __device__ __forceinline__ void peer_signal_and_wait(const DeviceGraph& g, unsig
   for (int rk = 0; rk < g.world; ++rk)
     while (__hip_atomic_load(g.peer_flags + rk, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < gseq) {
       __builtin_amdgcn_s_sleep(2);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { g.cg->status = 2; g.cg->done = 1; atomicOr(&g.flags[3], 1); return; }
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { g.cg->status = 2; g.cg->done = 1; return; }   // (status / done report it; flags[3] is the ticket counter of the step tail, not a status word)
     }
 }
 __global__ __launch_bounds__(256) void k_pipe_fold(DeviceGraph g, int seq, unsigned long long gseq) {

@@ -13,7 +13,6 @@ int evaluate_gradient_and_jacobian(pgo_problem* P, bool first) {
   const char* pe = getenv("PGO_SHARD_PIPE");
   const bool diag_only = P->g.world > 1 && !(pe && pe[0] == '0') && !P->use_graph &&
                          pgo::pipe_supported(P->g, cg_params_for(P->opt), P->opt.pcg_cluster_poses == 2 ? 2 : 1) && P->opt.pcg_cluster_poses != 4;
-  P->lin_diag_only = diag_only ? 1 : 0;
   if (first) {
     int rc = fill_scale_one(P);
     if (rc) return rc;
@@ -88,6 +87,7 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   L.x_cost = P->scal->cand_cost;
   L.initial_cost = L.x_cost;
   L.x_norm = std::sqrt(P->scal->x_norm_sq);
+  L.initial_x_norm = L.x_norm;
   L.gmax = P->scal->gradient_max;
   L.radius = P->opt.initial_trust_region_radius;
   L.decrease_factor = 2.0;
@@ -98,12 +98,15 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   L.cur.cost = L.x_cost;
   L.cur.gradient_max_norm = L.gmax;
   L.pending_record = true;
-  L.active = true;
   P->pipelined = pipeline_wanted(P);
   P->universal = universal_wanted(P);
   // ... in its fused form (one launch per CG iteration, pipelined recurrences) unless the caller asks for the standard CG or the
   // request is one the fused kernel does not serve (pgo_kernels.hip uni_f_supported)
-  P->uni_fused = P->universal && P->opt.pcg_form != 1 && pgo::uni_f_supported(P->g, cg_params_for(P->opt), P->g.cluster);
+  // (its recurrences carry no residual refresh: left to itself the library takes them for forcing terms eta >= 0.01 — CG runs of
+  // tens of iterations — and keeps Ceres' refreshed CG for tighter ones, whose runs of hundreds of iterations are where a
+  // pipelined CG loses attainable accuracy; pcg_form 2 asks for them regardless)
+  const bool fused_asked = P->opt.pcg_form == 2 || (P->opt.pcg_form == 0 && P->opt.eta >= 1e-2);
+  P->uni_fused = P->universal && fused_asked && pgo::uni_f_supported(P->g, cg_params_for(P->opt), P->g.cluster);
   P->uni_host_launches = 0; P->uni_host_enqueue_s = 0.0;
   P->pipe_dirty = true;
   // symmetric tile form for the CG products: host-driven PCG of a large graph on one rank (pgo_sym.h)
@@ -117,8 +120,12 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
     if (rc) return rc;
     P->sym_active = P->sym_ready;
     const char* rp = getenv("PGO_SYM_REPACK");        // (A/B: keep the incidence-slot linearisation and copy its blocks per LM iteration)
-    if (P->sym_active && P->sym_lin_fits && !(rp && rp[0] == '1')) { rc = sym_enter_storage(P); if (rc) return rc; }
+    // (storage mode needs the tile kernel's LDS budget only when that kernel writes the form: PGO_SYM_LIN=tile)
+    const char* sl = getenv("PGO_SYM_LIN");
+    const bool tile_lin = sl && sl[0] == 't';
+    if (P->sym_active && (P->sym_lin_fits || !tile_lin) && !(rp && rp[0] == '1')) { rc = sym_enter_storage(P); if (rc) return rc; }
   }
+  L.active = true;            // (only a session that got this far is one: an error above leaves the problem as it was)
   L.t_total += seconds_since(t0);
   if (!std::isfinite(L.x_cost)) {
     L.terminated = true; L.termination = PGO_FAILURE; L.reason = 7;
@@ -770,7 +777,8 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
     std::vector<long long> h((size_t)n);
     if (n) HIP_TRY(hipMemcpy(h.data(), P->g.oplog + 1, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(P->g.oplog, 0, sizeof(long long)));
-    if (FILE* f = std::fopen(getenv("PGO_UNI_OPLOG"), "a")) {
+    const char* path = getenv("PGO_UNI_OPLOG");       // (may have been unset since prepare() read it)
+    if (FILE* f = path ? std::fopen(path, "a") : nullptr) {
       for (long long v : h) std::fprintf(f, "%lld %d\n", v >> 3, (int)(v & 7));
       std::fclose(f);
     }
@@ -863,7 +871,10 @@ int pgo_solver_reset(pgo_problem* P) {
   pgo::launch_cost(P->g, P->g.pose_x, 0, P->stream);
   pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, P->stream);
   HIP_TRY(hipStreamSynchronize(P->stream));
+  // the session restarts as pgo_solver_begin left it: state, counters and the iteration records (the steps taken so far leave no
+  // trace — what pgo_solver_end reports is the solve from here on)
   L.x_cost = P->scal->cand_cost;
+  L.x_norm = L.initial_x_norm;
   L.gmax = P->scal->gradient_max;
   L.radius = P->opt.initial_trust_region_radius;
   L.decrease_factor = 2.0;
@@ -871,13 +882,17 @@ int pgo_solver_reset(pgo_problem* P) {
   L.terminated = false;
   L.gmax_deferred = false;
   L.num_consecutive_invalid = 0;
+  L.num_successful = L.num_unsuccessful = L.num_linear_iterations = 0;
+  L.num_trial_steps = 0;
+  L.n_factorizations = 0;
+  L.records.clear();
   pgo_iteration_record r{};
   r.iteration = 0;  // the iteration budget restarts with the state
   r.step_is_successful = 1;
   r.cost = L.x_cost;
   r.gradient_max_norm = L.gmax;
   L.cur = r;
-  L.pending_record = false;
+  L.pending_record = true;
   P->pipe_dirty = true;
   return PGO_OK;
 }

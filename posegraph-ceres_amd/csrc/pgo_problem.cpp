@@ -75,7 +75,10 @@ int linearize_all(pgo_problem* P, bool diag_only) {
   pgo::launch_linearize(P->g, P->stream);
   P->sym_stale = true;
   int rc;
-  if (diag_only && P->comm && P->comm->world > 1 && P->d_pipe_x.p) {
+  // what THIS linearisation exchanges is what the CG start checks against its form (pcg_begin): recorded here, from the branch
+  // actually taken, so that callers which linearise by themselves (pgo_linear_solve: a full exchange) are covered too
+  P->lin_diag_only = (diag_only && P->comm && P->comm->world > 1 && P->d_pipe_x.p) ? 1 : 0;
+  if (P->lin_diag_only) {
     pgo::launch_hdiag6(P->g, P->d_pipe_x.p, 0, P->stream);
     rc = exchange(P, P->d_pipe_x.p, (size_t)6 * P->g.rows_per);
     if (rc) return rc;

@@ -564,12 +564,14 @@ def test_traces_to_convergence_match_oracle(gpu, O, ds, name, exact):
     ls, cl = (gpu.SPARSE_NORMAL_CHOLESKY, 1) if exact else (gpu.BLOCK_JACOBI_PCG, 2)
     s = gpu.solve(gpu.SolverOptions(max_num_iterations=300, linear_solver_type=ls, pcg_cluster_poses=cl), prob)
     og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
-    oposes, osum, otr = O.solve(og, O.default_options(max_num_iterations=300, linear_solver=0 if exact else 1, pcg_cluster=cl))
+    # (the oracle runs the CG recurrences the GPU session ran: Summary::cg_form 3 = the pipelined ones of the fused stream)
+    oposes, osum, otr = O.solve(og, O.default_options(max_num_iterations=300, linear_solver=0 if exact else 1, pcg_cluster=cl,
+                                                      pcg_form=1 if s.cg_form == 3 else 0))
     assert len(s.iterations) == len(otr) and 15 < len(otr) < 300
     assert list(s.iterations["step_is_successful"]) == [int(v) for v in otr[:, 8]]
     assert np.allclose(s.iterations["cost"], otr[:, 1], rtol=1e-8)
     assert s.termination_type == gpu.CONVERGENCE and s.termination_type == osum.termination_type
-    assert s.final_cost == pytest.approx(osum.final_cost, rel=1e-9)
+    assert s.final_cost == pytest.approx(osum.final_cost, rel=1e-8 if s.cg_form == 3 else 1e-9)     # (pipelined recurrences: 3e-9 measured)
     assert np.abs(poses - oposes).max() <= (1e-7 if exact else 1e-5)
     if not exact:
         assert s.num_linear_solver_iterations == osum.num_linear_iterations

@@ -115,6 +115,39 @@ def test_linear_solve_on_loopback_ranks_returns_the_whole_solution(gpu, ds):
         assert np.array_equal(x, out[0][0])
 
 
+def test_linear_solve_behind_an_owner_only_solve_on_the_same_problems(gpu, ds, monkeypatch):
+    """r04 advisor: an LM session in the owner-only CG leaves `the last linearisation exchanged only diagonals` behind; pgo_linear_solve
+    linearises by itself (full exchange) and runs the replicated standard CG — it must not trip over the stale flag."""
+    monkeypatch.setenv("PGO_BLOCK", "256")
+    g = ds.manhattan_se3(901, 3300, seed=12)
+    lm_opt = gpu.SolverOptions(max_num_iterations=4, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2)
+    ls_opt = gpu.SolverOptions(linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, eta=1e-3, max_linear_solver_iterations=300)
+    rng = np.random.default_rng(3)
+    d2, b = np.full(6 * g.N, 1e2), rng.normal(size=6 * g.N)
+    world = 2
+    group = gpu.loopback_create(world)
+    out, forms, errs = [None] * world, [None] * world, []
+
+    def run(rank):
+        try:
+            p, _ = gpu.problem_from_graph(g)
+            p.comm_init_loopback(group, rank)
+            forms[rank] = gpu.solve(lm_opt, p).cg_form
+            out[rank] = p.linear_solve(d2, b, ls_opt)
+        except Exception as e:
+            errs.append(e)
+
+    ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert not errs, errs
+    gpu.loopback_destroy(group)
+    assert forms == [2, 2]                                   # the LM session really ran the owner-only form
+    assert out[0][1] == out[1][1] and np.array_equal(out[0][0], out[1][0])
+
+
 def test_loopback_exact_request_falls_back_to_tight_pcg(gpu, ds, O):
     g = ds.manhattan_se3(300, 1000, seed=4)
     opt = dict(max_num_iterations=15, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
