@@ -270,7 +270,10 @@ PGO_API int pgo_solver_end(pgo_problem* problem, pgo_solver_summary* summary, pg
  * pgo_solver_trace_start (between pgo_solver_begin / pgo_solver_reset and the pgo_solver_step calls to be traced): from now on
  * every launch of the stream records what it did and when (device clock, 100 MHz ticks), up to max_launches launches; 0 stops
  * recording.  pgo_solver_trace_read (the stream is idle between pgo_solver_step calls): records[i] = {operation, start tick of
- * work-group 0, end tick of the last work-group to finish} of launch i since the trace started; operation: 0 nothing (stream
+ * work-group 0, end tick of the last work-group to finish, phase stamps} of launch i since the trace started (4 words per
+ * launch; phase stamps: four 16-bit tick counts from the top of ONE work-group — a CG launch: work-group 0's product done /
+ * sums folded / rows updated / end; a step tail: the deciding work-group's loops done / last arrival known / partials folded /
+ * decided); operation: 0 nothing (stream
  * stopped or paused), 1 head (accept-finish, damping, Jacobi blocks, CG start), 2 first product, 3 CG iteration (or, once the CG
  * has stopped, the step tail's A x), 4 step tail + decision, 5 linearisation.  host[0] = launches the host enqueued, host[1] =
  * seconds it spent inside the launch calls since the trace started.  Returns the number of records or a negative status. */

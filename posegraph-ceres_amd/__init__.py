@@ -502,8 +502,8 @@ class Problem:
         _check(lib().pgo_solver_trace_start(self._h, C.c_int(max_launches)))
 
     def trace_read(self, capacity=20000):
-        """-> (records [n][3] int64: operation, start tick, end tick (100 MHz device clock); host launches; host enqueue seconds)"""
-        rec = np.zeros((capacity, 3), dtype=np.int64)
+        """-> (records [n][4] int64: operation, start tick, end tick (100 MHz device clock), phase stamps; host launches; host enqueue seconds)"""
+        rec = np.zeros((capacity, 4), dtype=np.int64)
         host = (C.c_double * 2)()
         n = lib().pgo_solver_trace_read(self._h, rec.ctypes.data_as(C.POINTER(C.c_longlong)), C.c_int(capacity), host)
         if n < 0:

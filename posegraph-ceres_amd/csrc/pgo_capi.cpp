@@ -189,13 +189,10 @@ int pgo_solver_trace_read(pgo_problem* P, long long* records, int capacity, doub
     const long long* w = h.data() + (size_t)TRACE_WORDS * i;
     long long end = 0;
     for (int x = 0; x < TRACE_WORDS - 2; ++x) end = std::max(end, w[2 + x]);
-    if (getenv("PGO_TRACE_PHASES") && (w[0] & 7) == 4 && i < 120)
-      std::fprintf(stderr, "[pgo] launch %d TAIL, deciding work-group (ticks from ITS top): loops done %lld, last arrival known %lld, folded %lld, decided %lld\n", i, w[1] & 0xffff, (w[1] >> 16) & 0xffff, (w[1] >> 32) & 0xffff, (w[1] >> 48) & 0xffff);
-    if (getenv("PGO_TRACE_PHASES") && (w[0] & 7) == 3 && i > 40 && i < 46)
-      std::fprintf(stderr, "[pgo] launch %d work-group 0: product done %lld, fold %lld, rows %lld, end %lld ticks (10 ns)\n", i, w[1] & 0xffff, (w[1] >> 16) & 0xffff, (w[1] >> 32) & 0xffff, (w[1] >> 48) & 0xffff);
-    records[3 * (size_t)i] = w[0] & 7;
-    records[3 * (size_t)i + 1] = w[0] >> 3;
-    records[3 * (size_t)i + 2] = end;
+    records[4 * (size_t)i] = w[0] & 7;
+    records[4 * (size_t)i + 1] = w[0] >> 3;
+    records[4 * (size_t)i + 2] = end;
+    records[4 * (size_t)i + 3] = w[1];
   }
   if (host) { host[0] = (double)P->uni_host_launches; host[1] = P->uni_host_enqueue_s; }
   return n;

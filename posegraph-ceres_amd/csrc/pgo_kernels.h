@@ -137,7 +137,7 @@ struct CgState {
   // universal stream, fused form (k_uni_f, r05): ONE kernel per launch, the whole stream state double-buffered by launch parity —
   // launch L reads f[L & 1] (written during launch L - 1 by one lane) and one lane writes f[(L & 1) ^ 1]: no word is read and
   // written by the same launch.  op: FusedOp; cnt: CG iterations completed; the scalars of the pipelined recurrences as in Pipe.
-  struct Fused { int op, cnt; double gamma_prev, alpha_prev, q_prev; } f[2];
+  struct Fused { int op, cnt, mirror, pad; double gamma_prev, alpha_prev, q_prev; } f[2];   // mirror: this launch publishes LmDev to the host
 };
 // what a launch of the fused universal stream does (CgState::Fused::op)
 enum FusedOp { F_EXIT = -1, F_IDLE = 0, F_HEAD = 1, F_W0 = 2, F_CG = 3, F_TAIL = 4, F_LIN = 5 };

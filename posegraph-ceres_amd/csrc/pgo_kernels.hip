@@ -1390,7 +1390,7 @@ __device__ __forceinline__ void lm_device_decide(const DeviceGraph& g, double ca
       if (D.lm_done >= D.decision_limit) D.pause = 1;   // pgo_solver_step(n): the head launch only finishes the accepted step, then the stream pauses
     }
   }
-  lm_mirror(g);
+  if (!(direct & 8)) lm_mirror(g);      // (8: the caller publishes the state later — the fused stream, from its next launch)
 }
 
 // Fused step tail (one launch instead of k_model_delta + k_cost + k_finalize_scalars; every kernel boundary costs ~4 us

@@ -129,7 +129,9 @@ int cg_iteration(pgo_problem* P, const pgo::CgParams& prm, int odd, bool refresh
 int choose_block(long long total_slots) {
   const int env_block = getenv("PGO_BLOCK") ? atoi(getenv("PGO_BLOCK")) : 0;   // tuning experiments / tests: 64, 128 or 256 (read per call)
   if (env_block == 64 || env_block == 128 || env_block == 256) return env_block;
-  if (total_slots >= 256LL * 512) return 256;
+  // (r05, re-measured on this round's boxes at BASELINE configs[1], 90 k slots: 256-slot work-groups 0.226 / 0.220 ms per LM
+  // iteration (two-kernel / fused stream) against 0.238 / 0.227 with 128 — half the work-groups to dispatch, half the partial sums)
+  if (total_slots >= 256LL * 320) return 256;
   if (total_slots >= 128LL * 384) return 128;
   return 64;
 }

@@ -85,7 +85,7 @@ __device__ __forceinline__ void uni_f_trace_end(const DeviceGraph& g, int launch
 
 template <bool PACKED, int INFO, int CL>
 __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams& prm, int launch, double min_diag, double max_diag,
-                                           double* lds, double* scratch, int* is_last_p) {
+                                           double* lds, double* scratch, int* is_last_p, int* publish) {
   constexpr int NPAIR = PACKED ? BLK_PAIRS_PACKED : BLK_PAIRS_FULL;
   constexpr int DIM = 6 * CL;
   const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
@@ -117,19 +117,15 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
   }
   // the previous launch's partial sums, one entry {(r,u), (w,u), x'(b + r), -} per work-group: every lane takes the entries
   // tid, tid + B, ... — all requested at once (clamped index, zero weight: no load sits behind a branch)
-  double f3[3] = {0.0, 0.0, 0.0};
+  // (only requested here: they are added up inside the CG branch, behind the product — a launch that turns out to do something else
+  // must not wait for them, nor for the blocks in front of them)
+  double2 e0[UNI_F_FOLD], e1[UNI_F_FOLD];
   {
     const double2* pf = reinterpret_cast<const double2*>(g.part_f + (size_t)rp * 4 * g.n_part);
-    double2 e0[UNI_F_FOLD], e1[UNI_F_FOLD];
 #pragma unroll
     for (int k = 0; k < UNI_F_FOLD; ++k) {
       const int i = min(tid + k * B, g.n_wg - 1);
       e0[k] = pf[2 * (size_t)i]; e1[k] = pf[2 * (size_t)i + 1];
-    }
-#pragma unroll
-    for (int k = 0; k < UNI_F_FOLD; ++k) {
-      const double wgt = tid + k * B < g.n_wg ? 1.0 : 0.0;
-      f3[0] += wgt * e0[k].x; f3[1] += wgt * e0[k].y; f3[2] += wgt * e1[k].x;
     }
   }
   const int nown = nrows * 6;
@@ -153,8 +149,12 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
   if (wg == 0 && tid == 0) __hip_atomic_store(&g.scal->slots_done, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int op = st.op;
   uni_f_trace_begin(g, launch, op < 0 ? 0 : op, t_top);
+  // the decisions of earlier launches go to the host from work-group 0 of a launch that does not touch the LM state, once its own
+  // work is done (k_uni_f below: the deciding work-group would have held up the end of its launch for the 4 us the pinned-memory
+  // stores and their fence take; up here the fence would sit in front of every launch's work)
+  *publish = st.mirror && op != F_HEAD && op != F_TAIL;
   if (op <= F_IDLE) {          // stopped (terminated, paused) or not opened yet: the state stands
-    if (wg == 0 && tid == 0) g.cg->f[wp] = st;
+    if (wg == 0 && tid == 0) { CgState::Fused n = st; n.mirror = 0; g.cg->f[wp] = n; }
     return;
   }
 
@@ -162,7 +162,7 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
     DeviceGraph gl = g;
     gl.pose_x = g.pose_c;          // the accepted candidate; the accept-finish part of the next HEAD copies it over
     linearize_body<INFO>(gl, lds);
-    if (wg == 0 && tid == 0) { CgState::Fused n = st; n.op = F_HEAD; g.cg->f[wp] = n; }
+    if (wg == 0 && tid == 0) { CgState::Fused n{}; n.op = F_HEAD; g.cg->f[wp] = n; }
     return;
   }
 
@@ -267,9 +267,9 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
       if (D.halt) n.op = F_EXIT;
       else if (pause) { D.halt = LM_HALT_BUDGET; n.op = F_EXIT; }
       else n.op = F_W0;
+      n.mirror = 1;            // the next launch publishes the state to the host (lane 0 of its work-group 0, beside its work)
       g.cg->f[wp] = n;
       g.cg->done = 0; g.cg->iters = 0; g.cg->status = 0;
-      lm_mirror(g);
     }
     return;
   }
@@ -313,9 +313,20 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
     __threadfence();
     const long long t_last = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
     double s4[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = tid; i < nT; i += B) {   // other work-groups' partials: read at device scope (not from this CU's L1)
+    {   // other work-groups' partials, read at device scope (not from this CU's L1), all requested at once
+      double v[UNI_F_FOLD][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) s4[k] += __hip_atomic_load(&g.part_misc[(size_t)k * g.n_part + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int kk = 0; kk < UNI_F_FOLD; ++kk) {
+        const int i = min(tid + kk * B, nT - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[kk][k] = __hip_atomic_load(&g.part_misc[(size_t)k * g.n_part + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int kk = 0; kk < UNI_F_FOLD; ++kk) {
+        const double wgt = tid + kk * B < nT ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s4[k] += wgt * v[kk][k];
+      }
     }
     block_sum<4>(s4, scratch);
     if (tid == 0) {
@@ -328,10 +339,11 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
       g.scal->linearize_bad = bad;
       g.flags[1] = 0;
       g.flags[2] = 0;
-      lm_device_decide(g, s4[0], s4[1], s4[2], s4[3], bad, 2);    // accept / reject / stop, on the spot (pgo_lm_rules.h)
+      lm_device_decide(g, s4[0], s4[1], s4[2], s4[3], bad, 2 | 8);    // accept / reject / stop, on the spot (pgo_lm_rules.h); 8: no mirror here
       LmDev& D = *g.lm;
       CgState::Fused n{};
       n.op = D.halt ? F_EXIT : D.accepted ? F_LIN : F_HEAD;
+      n.mirror = 1;            // the next launch publishes the decision to the host
       g.cg->f[wp] = n;
       if (g.oplog && 1 + UNI_F_TRACE_WORDS * ((long long)launch + 1) <= g.oplog_cap) {   // phase stamps of the deciding work-group
         const long long t_end = (long long)__builtin_amdgcn_s_memrealtime();
@@ -355,6 +367,12 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
 #pragma unroll
   for (int k = 0; k < 6; ++k) lds[tid * SPMV_LDS_STRIDE + k] = y[k];
   const long long t_mul = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+  double f3[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < UNI_F_FOLD; ++k) {
+    const double wgt = tid + k * B < g.n_wg ? 1.0 : 0.0;
+    f3[0] += wgt * e0[k].x; f3[1] += wgt * e0[k].y; f3[2] += wgt * e1[k].x;
+  }
   block_sum<3>(f3, scratch);     // every work-group folds the same entries in the same order: same bits everywhere (its barriers
                                  // also publish the slot results)
   int stop = 0, status = 0;
@@ -500,6 +518,8 @@ __global__ __launch_bounds__(256, 2) void k_uni_f(DeviceGraph g, CgParams prm, i
   extern __shared__ double lds[];  // NV_LIN * block (the linearisation); the CG uses (SPMV_LDS_STRIDE + 6) * block + 6 of it
   __shared__ double scratch[32];
   __shared__ int is_last;
-  uni_f_body<PACKED, INFO, CL>(g, prm, launch, min_diag, max_diag, lds, scratch, &is_last);
+  int publish = 0;
+  uni_f_body<PACKED, INFO, CL>(g, prm, launch, min_diag, max_diag, lds, scratch, &is_last, &publish);
+  if (publish && blockIdx.x == 0 && threadIdx.x == 0) lm_mirror(g);
   uni_f_trace_end(g, launch);
 }

@@ -22,6 +22,9 @@ prob.solver_end()
 names = {0: "idle", 1: "head", 2: "w0", 3: "cg", 4: "tail", 5: "lin"}
 live = rec[:, 0] > 0
 last = np.nonzero(live)[0].max()
+idle = rec[last + 1:]
+if len(idle) > 2:
+    print("  idle  %4d launches behind the pause: top-to-last-end %.2f us, period %.2f us" % (len(idle), ((idle[:, 2] - idle[:, 1]) / 100.0).mean(), (np.diff(idle[:, 1]) / 100.0).mean()))
 rec = rec[: last + 1]
 dur = (rec[:, 2] - rec[:, 1]) / 100.0
 period = np.diff(rec[:, 1]) / 100.0
@@ -33,3 +36,10 @@ for op in range(6):
         print("  %-5s %4d launches: top-to-last-end %.2f us (median %.2f), gap behind it %.2f us (median %.2f), period %.2f us; per LM step %.1f us" % (
             names[op], m.sum(), dur[:-1][m].mean(), np.median(dur[:-1][m]), gap[m].mean(), np.median(gap[m]), period[m].mean(), period[m].sum() / ran))
 print("  host: %d launches enqueued, %.2f us per launch" % (hl, 1e6 * hs / max(hl, 1)))
+
+def phases(w):
+    return [int((w >> (16 * k)) & 0xffff) / 100.0 for k in range(4)]
+for op, label in ((3, "cg  (wg 0: product, fold, rows, end)"), (4, "tail (deciding wg: loops, last known, folded, decided)")):
+    rows = np.array([phases(int(w)) for w in rec[rec[:, 0] == op][5:, 3]])
+    if len(rows):
+        print("  phases %s: median us %s" % (label, np.round(np.median(rows, axis=0), 2)))
