@@ -166,21 +166,21 @@ int pgo_solver_trace_start(pgo_problem* P, int max_launches) {
   if (!P->lm.active || !P->stream_ready) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_trace_start needs a stepping session (call pgo_solver_begin first)");
   if (!P->uni_fused) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_trace_start: this session does not run the fused universal stream");
   HIP_TRY(hipStreamSynchronize(P->stream));
-  if (max_launches == 0) { P->g.oplog = nullptr; P->g.oplog_cap = 0; return PGO_OK; }
+  if (max_launches == 0) { P->g.oplog = nullptr; P->g.oplog_cap = 0; P->g.oplog_indexed = 0; return PGO_OK; }
   // the launch index the kernels record under restarts whenever the device state is uploaded afresh; make that happen now
   P->pipe_dirty = true;
   const size_t cap = 1 + (size_t)TRACE_WORDS * max_launches;
   HIP_TRY(P->d_oplog.alloc(cap));
   HIP_TRY(hipMemsetAsync(P->d_oplog.p, 0, cap * sizeof(long long), P->stream));
   HIP_TRY(hipStreamSynchronize(P->stream));
-  P->g.oplog = P->d_oplog.p; P->g.oplog_cap = (int)cap;
+  P->g.oplog = P->d_oplog.p; P->g.oplog_cap = (int)cap; P->g.oplog_indexed = 1;
   P->uni_host_launches = 0; P->uni_host_enqueue_s = 0.0;
   return PGO_OK;
 }
 
 int pgo_solver_trace_read(pgo_problem* P, long long* records, int capacity, double host[2]) {
   if (!P || !records || capacity < 0) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_solver_trace_read");
-  if (!P->g.oplog || !P->uni_fused) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_trace_read: no trace is being recorded (pgo_solver_trace_start)");
+  if (!P->g.oplog || !P->g.oplog_indexed || !P->uni_fused) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_trace_read: no trace is being recorded (pgo_solver_trace_start)");
   HIP_TRY(hipStreamSynchronize(P->stream));
   const int n = std::min(std::min(P->uni_enq, (P->g.oplog_cap - 1) / TRACE_WORDS), capacity);
   std::vector<long long> h((size_t)TRACE_WORDS * std::max(n, 1));

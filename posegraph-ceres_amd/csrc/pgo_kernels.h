@@ -227,6 +227,7 @@ struct DeviceGraph {
   // [2 + s] the latest end tick among the work-groups with index % 64 == s (atomic max).
   long long* oplog;
   int oplog_cap;
+  int oplog_indexed;  // 1: the fused stream's per-launch records (pgo_solver_trace_*); 0: appended (tick, operation) entries (PGO_UNI_OPLOG)
   // linearisation into the symmetric tile form by the row kernel (k_linearize_symout): stored slot of every incidence slot (-1: the
   // mirrored incidence of an interior edge, not stored) and the form's block array
   const int* sym_dst;

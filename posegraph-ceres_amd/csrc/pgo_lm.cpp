@@ -771,7 +771,7 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
                  L.hybrid_direct, L.hybrid_pcg_ok, L.hybrid_pcg_over);
   int rc = download_poses(P, P->g.pose_x);
   if (rc) return rc;
-  if (P->g.oplog) {      // profiling aid (PGO_UNI_OPLOG): "<s_memrealtime tick> <operation>" per k_uni_s launch of this session
+  if (P->g.oplog && !P->g.oplog_indexed) {      // profiling aid (PGO_UNI_OPLOG): "<s_memrealtime tick> <operation>" per k_uni_s launch of this session
     long long n = 0;
     HIP_TRY(hipMemcpy(&n, P->g.oplog, sizeof n, hipMemcpyDeviceToHost));
     std::vector<long long> h((size_t)n);
@@ -779,7 +779,7 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
     HIP_TRY(hipMemset(P->g.oplog, 0, sizeof(long long)));
     const char* path = getenv("PGO_UNI_OPLOG");       // (may have been unset since prepare() read it)
     if (FILE* f = path ? std::fopen(path, "a") : nullptr) {
-      for (long long v : h) std::fprintf(f, "%lld %d\n", v >> 3, (int)(v & 7));
+      for (long long v : h) std::fprintf(f, "%lld %d\n", v >> 3, (int)(v & 7) + (P->uni_fused ? 16 : 0));    // (16 +: operations of k_uni_f)
       std::fclose(f);
     }
   }

@@ -415,7 +415,7 @@ int prepare(pgo_problem* P) {
   g.pairs_whole = pairs_whole ? 1 : 0;
   g.n_part = n_part; g.n_vec_wg = n_vec_wg; g.n_edge_wg = n_edge_wg; g.n_pose_wg = n_pose_wg;
   g.cg = P->d_cg.p; g.flags = P->d_flags.p;
-  g.oplog = nullptr; g.oplog_cap = 0;
+  g.oplog = nullptr; g.oplog_cap = 0; g.oplog_indexed = 0;
   g.sym_dst = nullptr; g.sym_val = nullptr;
   if (getenv("PGO_UNI_OPLOG")) {
     const size_t cap = (size_t)1 << 21;

@@ -73,12 +73,20 @@ __device__ __forceinline__ bool uni_f_last_arrival(const DeviceGraph& g, int wg,
 // of work-group 0 << 3 | operation), [2 + s] the latest end tick among the work-groups with index % 64 == s (one atomic per
 // work-group, 64 addresses: a dozen per address at BASELINE configs[1])
 constexpr int UNI_F_TRACE_WORDS = 66;
+__device__ __forceinline__ bool uni_f_traced(const DeviceGraph& g, int launch) {
+  return g.oplog && g.oplog_indexed && 1 + UNI_F_TRACE_WORDS * ((long long)launch + 1) <= g.oplog_cap;
+}
 __device__ __forceinline__ void uni_f_trace_begin(const DeviceGraph& g, int launch, int what, long long t_top) {
-  if (g.oplog && blockIdx.x == 0 && threadIdx.x == 0 && 1 + UNI_F_TRACE_WORDS * ((long long)launch + 1) <= g.oplog_cap)
+  if (!g.oplog || blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (!g.oplog_indexed) {      // PGO_UNI_OPLOG: one appended entry per launch (tools/rocprof_summary.py buckets the dispatches of this one symbol with it)
+    const long long i = g.oplog[0];
+    if (i + 1 < g.oplog_cap) { g.oplog[1 + i] = (t_top << 3) | (long long)(what & 7); g.oplog[0] = i + 1; }
+  } else if (uni_f_traced(g, launch)) {
     g.oplog[1 + UNI_F_TRACE_WORDS * (size_t)launch] = (t_top << 3) | (long long)(what & 7);
+  }
 }
 __device__ __forceinline__ void uni_f_trace_end(const DeviceGraph& g, int launch) {
-  if (g.oplog && threadIdx.x == 0 && 1 + UNI_F_TRACE_WORDS * ((long long)launch + 1) <= g.oplog_cap)
+  if (threadIdx.x == 0 && uni_f_traced(g, launch))
     atomicMax(reinterpret_cast<unsigned long long*>(g.oplog + 1 + UNI_F_TRACE_WORDS * (size_t)launch + 2 + (blockIdx.x & 63)),
               (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
@@ -93,7 +101,7 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
   const double* rd = g.pipe_buf[rp];
   double* wr = g.pipe_buf[wp];
   const int m = 6 * g.N;
-  const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+  const long long t_top = uni_f_traced(g, launch) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   // ---- requested before the state is known: what a CG launch needs (work-groups of this form hold exactly B slots: no look-up) ----
   const CgState::Fused st = g.cg->f[rp];
   const int s_begin = wg * B;
@@ -301,7 +309,7 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
       }
     }
     for (int e = (nT - 1 - wg) * B + tid; e < g.E; e += nT * B) acc[0] += edge_cost<INFO>(g, g.pose_c, e);   // (edges from the top, poses from the bottom)
-    const long long t_loops = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    const long long t_loops = uni_f_traced(g, launch) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
     block_sum<4>(acc, scratch);
     if (tid == 0) {
 #pragma unroll
@@ -311,7 +319,7 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
     __syncthreads();
     if (!is_last) return;
     __threadfence();
-    const long long t_last = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    const long long t_last = uni_f_traced(g, launch) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
     double s4[4] = {0.0, 0.0, 0.0, 0.0};
     {   // other work-groups' partials, read at device scope (not from this CU's L1), all requested at once
       double v[UNI_F_FOLD][4];
@@ -330,7 +338,7 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
     }
     block_sum<4>(s4, scratch);
     if (tid == 0) {
-      const long long t_folded = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+      const long long t_folded = uni_f_traced(g, launch) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
       g.scal->cand_cost = s4[0];
       g.scal->model_change = s4[1];
       g.scal->step_norm_sq = s4[2];
@@ -345,7 +353,7 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
       n.op = D.halt ? F_EXIT : D.accepted ? F_LIN : F_HEAD;
       n.mirror = 1;            // the next launch publishes the decision to the host
       g.cg->f[wp] = n;
-      if (g.oplog && 1 + UNI_F_TRACE_WORDS * ((long long)launch + 1) <= g.oplog_cap) {   // phase stamps of the deciding work-group
+      if (uni_f_traced(g, launch)) {   // phase stamps of the deciding work-group
         const long long t_end = (long long)__builtin_amdgcn_s_memrealtime();
         g.oplog[1 + UNI_F_TRACE_WORDS * (size_t)launch + 1] = ((t_loops - t_top) & 0xffff) | (((t_last - t_top) & 0xffff) << 16) |
                                                               (((t_folded - t_top) & 0xffff) << 32) | (((t_end - t_top) & 0xffff) << 48);
@@ -366,13 +374,13 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
   }
 #pragma unroll
   for (int k = 0; k < 6; ++k) lds[tid * SPMV_LDS_STRIDE + k] = y[k];
-  const long long t_mul = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   double f3[3] = {0.0, 0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < UNI_F_FOLD; ++k) {
     const double wgt = tid + k * B < g.n_wg ? 1.0 : 0.0;
     f3[0] += wgt * e0[k].x; f3[1] += wgt * e0[k].y; f3[2] += wgt * e1[k].x;
   }
+  const long long t_mul = uni_f_traced(g, launch) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   block_sum<3>(f3, scratch);     // every work-group folds the same entries in the same order: same bits everywhere (its barriers
                                  // also publish the slot results)
   int stop = 0, status = 0;
@@ -441,7 +449,7 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
     for (int k = 0; k < 6; ++k) lds[tid * SPMV_LDS_STRIDE + k] = y[k];
     __syncthreads();
   }
-  const long long t_fold = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+  const long long t_fold = uni_f_traced(g, launch) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   double* lds_w = lds + (size_t)SPMV_LDS_STRIDE * B;
   // ---- the owned rows: lane idx owns component idx % 6 of row r0 + idx / 6 ----
   double acc[3] = {0.0, 0.0, 0.0};
@@ -484,7 +492,7 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
     lds_w[idx] = wn;
   }
   if (stop) return;
-  const long long t_rows = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+  const long long t_rows = uni_f_traced(g, launch) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   if (tid < 6) lds_w[nown + tid] = 0.0;       // the missing half of a last odd pair
   __syncthreads();
   for (int idx = tid; idx < nown; idx += B) {
@@ -505,7 +513,7 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
     double2* pf = reinterpret_cast<double2*>(g.part_f + ((size_t)wp * g.n_part + wg) * 4);
     pf[0] = double2{acc[0], acc[1]};
     pf[1] = double2{acc[2], 0.0};
-    if (g.oplog && wg == 0 && 1 + UNI_F_TRACE_WORDS * ((long long)launch + 1) <= g.oplog_cap) {   // phase stamps of work-group 0 (ticks from its top)
+    if (wg == 0 && uni_f_traced(g, launch)) {   // phase stamps of work-group 0 (ticks from its top)
       const long long t_end = (long long)__builtin_amdgcn_s_memrealtime();
       g.oplog[1 + UNI_F_TRACE_WORDS * (size_t)launch + 1] = ((t_mul - t_top) & 0xffff) | (((t_fold - t_top) & 0xffff) << 16) |
                                                             (((t_rows - t_top) & 0xffff) << 32) | (((t_end - t_top) & 0xffff) << 48);

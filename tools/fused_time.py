@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import pgo_loader
 gpu = pgo_loader.load(); ds = pgo_loader.datasets()
+if os.environ.get("PGO_AB_LIB"): gpu.LIB_PATH = os.environ["PGO_AB_LIB"]      # development: time another build of the library
 c2 = ds.manhattan_se3(10000, 40000)
 blocks = [int(a) for a in sys.argv[1:]] or [128, 256]
 for B in blocks:

@@ -12,6 +12,8 @@ import statistics
 import sys
 
 OPS = {0: "nop", 1: "cg", 2: "refresh", 3: "linearize", 4: "tail"}
+# the fused stream (r05: k_uni_f, one kernel symbol for everything; its log entries carry 16 + operation)
+OPS_F = {16: "idle", 17: "head", 18: "w0", 19: "cg", 20: "tail", 21: "linearize"}
 
 
 def main(db, out, oplog=None):
@@ -22,14 +24,17 @@ def main(db, out, oplog=None):
         d.setdefault(n, []).append((du, gx, wx, vg, sg, lds))
     note = ""
     if oplog:
-        log = sorted(tuple(int(x) for x in line.split()) for line in open(oplog) if line.strip())
-        uni = [(n, r) for n, *r in rows if n.startswith("k_uni_s") or "k_uni_s<" in n]
-        if len(log) != len(uni):
-            note = "# k_uni_s split REFUSED: %d dispatches in the trace, %d entries in the operation log\n" % (len(uni), len(log))
-        else:
+        entries = sorted(tuple(int(x) for x in line.split()) for line in open(oplog) if line.strip())
+        for sym, names, log in (("k_uni_s", OPS, [e for e in entries if e[1] < 16]), ("k_uni_f", OPS_F, [e for e in entries if e[1] >= 16])):
+            uni = [(n, r) for n, *r in rows if sym in n]
+            if not uni and not log:
+                continue
+            if len(log) != len(uni):
+                note += "# %s split REFUSED: %d dispatches in the trace, %d entries in the operation log\n" % (sym, len(uni), len(log))
+                continue
             for (n, r), (_, op) in zip(uni, log):
-                d.setdefault("%s[%s]" % (n, OPS.get(op, str(op))), []).append(tuple(r[:6]))
-            note = "# k_uni_s[...] rows: the %d dispatches of k_uni_s split by the operation each launch performed (PGO_UNI_OPLOG); they are also counted in the un-split k_uni_s row (pct of the split rows is relative to the same total)\n" % len(uni)
+                d.setdefault("%s[%s]" % (n, names.get(op, str(op))), []).append(tuple(r[:6]))
+            note += "# %s[...] rows: the %d dispatches of %s split by the operation each launch performed (PGO_UNI_OPLOG); they are also counted in the un-split row (pct of the split rows is relative to the same total)\n" % (sym, len(uni), sym)
     total = sum(du for n, v in d.items() if "[" not in n for du, *_ in v)
     with open(out, "w") as f:
         f.write(note)
