@@ -65,6 +65,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PGO_BENCH_ONE_GPU=1: every rank on device 0, control plane over gloo, data path over the IPC transport (one process per rank,
+    # exchange buffers mapped through hipIpc handles, the CG's exchange done by the kernels: include/pgo.h pgo_comm_init_ipc) — how
+    # the N > 1 orchestration of this script is executed on a one-GPU box.  PGO_BENCH_TRANSPORT=ipc selects that data path with one
+    # GPU per rank as well (default there: RCCL).
+    one_gpu = os.environ.get("PGO_BENCH_ONE_GPU", "0") == "1"
+    transport = "ipc" if one_gpu else os.environ.get("PGO_BENCH_TRANSPORT", "rccl")
+    if one_gpu:
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
@@ -76,7 +84,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")     # (the launcher sets both; the forced one-GPU run of this path has neither)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if one_gpu else "cuda"
 
     import pgo_loader
     pkg = pgo_loader.load()
@@ -133,7 +145,7 @@ def main():
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
             if use_dist:
-                t = torch.tensor([el], dtype=torch.float64, device="cuda")
+                t = torch.tensor([el], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 el = float(t.item())
                 dist.barrier()
@@ -198,7 +210,7 @@ def main():
             t0 = time.perf_counter()
             run_steps(p5, k5)
             torch.cuda.synchronize()
-            t5 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            t5 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t5, op=dist.ReduceOp.MAX)
             s5 = p5.solver_end()
             c5_extra = {"workload": "BASELINE configs[4]: sphere x10 (25 k poses / 250 k edges), one independent graph per GPU, exact LM steps "
@@ -216,9 +228,13 @@ def main():
         try:
             def sharded_run(graph):
                 pr, _ = pkg.problem_from_graph(graph)
-                box = [pkg.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                pr.comm_init(box[0], rank, world)
+                if transport == "ipc":
+                    sharded_run.n = getattr(sharded_run, "n", 0) + 1
+                    pr.comm_init_ipc("/pgo_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), sharded_run.n), rank, world)
+                else:
+                    box = [pkg.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    pr.comm_init(box[0], rank, world)
                 pr.solver_begin(opt)
                 return (pr,) + timed_region(pr)
 
@@ -715,13 +731,18 @@ def main():
         out = record(total_edges * args.steps / elapsed, elapsed,
                      ("single GPU" if world == 1 and not sharded else
                       ("one graph, pose rows sharded over %d ranks (one process per GPU), " % world + (
-                          "pipelined CG: every rank updates its own rows, 1 RCCL all-gather over xGMI per CG iteration" if summary.cg_form == 2 else
+                          ("pipelined CG: every rank updates its own rows, the kernels exchange their segments themselves (stores into every rank's "
+                           "IPC-mapped buffer + flags, no host-enqueued collective per CG iteration)" if summary.cg_exchange == 2 else
+                           "pipelined CG: every rank updates its own rows, 1 RCCL all-gather over xGMI per CG iteration") if summary.cg_form == 2 else
                           "replicated standard CG: every rank updates every row, q all-gathered over xGMI per CG iteration (the owner-only form was not usable: PGO_SHARD_PIPE=0, captured graphs or 4-pose clusters)")) if sharded else
                       "replicas: 1 independent graph per GPU, no data-path collective"),
                      N if sharded or world == 1 else N * world, total_edges,
                      workload=("BASELINE configs[3]: synthetic Manhattan SE3 graph, %d poses / %d odom+loop edges in TOTAL (seed %d), row-sharded over "
                                "%d GPUs, block-Jacobi PCG (eta=0.1, <=500 it), Huber(1.0), LM from dead reckoning" % (N, E, C4_SEED, world)) if c4_headline else None,
                      scaling="strong" if c4_headline else "weak", seed=C4_SEED if c4_headline else SEED)
+        if one_gpu and world > 1:
+            out["one_gpu_dry_run"] = ("PGO_BENCH_ONE_GPU=1: all %d ranks share ONE GPU (gloo control plane, IPC data path): this line shows that the "
+                                      "N > 1 orchestration runs end to end, its numbers are NOT a scaling measurement" % world)
         out.update({
             "lm_iters_per_sec": round(args.steps * (1 if sharded else world) / elapsed, 2),
             "cg_iterations_in_solver_state": summary.num_linear_solver_iterations,

@@ -28,7 +28,7 @@ extern "C" {
  * *_reduced fields in r02).  pgo_solve / pgo_solver_end / pgo_solve_batch write sizeof(pgo_solver_summary) bytes: a caller must
  * check pgo_version() == PGO_VERSION of the header it was compiled against before handing structs over (the facade's
  * ceres::Solve does, include/ceres/solver.h). */
-#define PGO_VERSION 101
+#define PGO_VERSION 102
 
 /* The library is built with -fvisibility=hidden: these entry points are all it exports. */
 #if defined(__GNUC__)
@@ -141,6 +141,9 @@ typedef struct pgo_solver_summary {
                                    replicated standard CG (every rank updates every row, q all-gathered per iteration), 2 several ranks,
                                    owner-only pipelined CG (every rank updates its own rows, one all-gather per iteration), 3 one rank,
                                    pipelined CG in the fused universal stream (one launch per CG iteration) */
+  int cg_exchange;              /* how the ranks' CG exchanged their segments: 0 nothing to exchange (one rank), 1 a host-enqueued collective
+                                   per CG iteration (RCCL all-gather, loopback copies), 2 by the kernels themselves (peer table: stores
+                                   into every rank's buffer + flags; the IPC transport's normal mode) */
 } pgo_solver_summary;
 
 /* One row per iteration, the numbers Summary::FullReport() tabulates with
@@ -382,6 +385,12 @@ PGO_API int pgo_comm_get_unique_id(unsigned char id[128]);
  * accepted LM step (J'J diagonal blocks, J'r) and one per LM iteration for cluster preconditioners.  All ranks take
  * identical decisions from identical scalars, so no other coordination is needed. */
 PGO_API int pgo_comm_init(pgo_problem* problem, const unsigned char id[128], int rank, int world);
+/* The same ownership over a transport of PROCESSES that map each other's exchange buffers through hipIpc memory handles (one
+ * process per rank; the ranks' devices must be IPC-capable peers — the GPUs of one node, or one GPU shared by several processes):
+ * the kernels of the owner-only CG then store into every rank's buffer and flag array themselves (no host-enqueued collective per
+ * CG iteration); the few exchanges per LM iteration outside the CG go through an IPC-mapped staging buffer.  `name`: a POSIX
+ * shared-memory name ("/...") unique to the group; rank 0 creates it, every rank calls this collectively. */
+PGO_API int pgo_comm_init_ipc(pgo_problem* problem, const char* name, int rank, int world);
 /* Test transport: `world` virtual ranks = problems driven by host threads of ONE process on one GPU, segments exchanged
  * by device-to-device copies.  Lets the sharded path be validated on a single-GPU machine. */
 /* development / test hook (tests/test_lm_rules_cpu.py): one application of the trust-region rules the device and the host driver share

@@ -41,7 +41,7 @@ C_ABI_SYMBOLS = [
     "pgo_solver_options_init", "pgo_solve", "pgo_summary_is_solution_usable", "pgo_summary_full_report",
     "pgo_evaluate", "pgo_normal_equations", "pgo_linear_solve", "pgo_plus", "pgo_solver_begin",
     "pgo_solver_step", "pgo_solver_reset", "pgo_solver_end", "pgo_time_kernel", "pgo_solver_trace_start", "pgo_solver_trace_read", "pgo_shard_range",
-    "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_debug_comm_stress", "pgo_debug_lm_decide", "pgo_loopback_create", "pgo_loopback_destroy", "pgo_comm_init_loopback",
+    "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_init_ipc", "pgo_debug_comm_stress", "pgo_debug_lm_decide", "pgo_loopback_create", "pgo_loopback_destroy", "pgo_comm_init_loopback",
     "pgo_generate_candidates", "pgo_reproj_options_init", "pgo_reproj_solve_batch",
     "pgo_row_shard_range", "pgo_read_trajectory", "pgo_build_odometry_edges", "pgo_edge_rules_init", "pgo_build_edges",
     "pgo_solve_batch", "pgo_release_device_memory",
@@ -80,7 +80,7 @@ class _CSummary(C.Structure):
         ("final_trust_region_radius", C.c_double), ("message", C.c_char * 256),
         ("factor_kind", C.c_int), ("factor_max_front", C.c_int), ("factor_flops", C.c_double),
         ("num_parameter_blocks_reduced", C.c_int), ("num_parameters_reduced", C.c_int), ("num_effective_parameters_reduced", C.c_int),
-        ("cg_form", C.c_int),
+        ("cg_form", C.c_int), ("cg_exchange", C.c_int),
     ]
 
 
@@ -493,6 +493,10 @@ class Problem:
     def comm_init(self, unique_id, rank, world):
         buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
         _check(lib().pgo_comm_init(self._h, buf, C.c_int(rank), C.c_int(world)))
+
+    def comm_init_ipc(self, name, rank, world):
+        """One process per rank, exchange buffers mapped through hipIpc handles (include/pgo.h pgo_comm_init_ipc)."""
+        _check(lib().pgo_comm_init_ipc(self._h, name.encode(), C.c_int(rank), C.c_int(world)))
 
     def comm_init_loopback(self, group, rank):
         _check(lib().pgo_comm_init_loopback(self._h, C.c_void_p(group), C.c_int(rank)))

@@ -478,6 +478,16 @@ int pgo_comm_init(pgo_problem* P, const unsigned char id[128], int rank, int wor
   return attach_comm(P, c);
 }
 
+int pgo_comm_init_ipc(pgo_problem* P, const char* name, int rank, int world) {
+  if (!P || !name || name[0] != '/' || world < 1 || rank < 0 || rank >= world) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_comm_init_ipc (name: a POSIX shared-memory name, \"/...\")");
+  int rc = ensure_device(P);
+  if (rc) return rc;
+  const char* what = "";
+  pgo::Comm* c = pgo::make_ipc_comm(name, rank, world, &what);
+  if (!c) return set_error(PGO_ERR_HIP, "the IPC group could not be formed: %s", what);
+  return attach_comm(P, c);
+}
+
 // development hook (not part of include/pgo.h): stress the attached transport, returns mismatching words
 int pgo_debug_comm_stress(pgo_problem* P, int iters, int seg_doubles) {
   if (!P || !P->comm) return -1;

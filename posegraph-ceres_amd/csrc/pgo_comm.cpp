@@ -3,9 +3,18 @@
 
 #include <rccl/rccl.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <thread>
 
 namespace pgo {
 
@@ -93,7 +102,149 @@ struct RcclComm : Comm {
   }
 };
 
+// ---- one process per rank, peer memory through hipIpc handles ------------------------------------------------------------
+constexpr int IPC_MAX_WORLD = 16;
+constexpr int IPC_MAGIC = 0x50474f35;
+struct IpcShared {                      // lives in POSIX shared memory; rank 0 initialises it and sets `magic` last
+  std::atomic<int> magic;
+  std::atomic<int> arrived;
+  std::atomic<long long> generation;
+  std::atomic<int> aborted;
+  int world;
+  unsigned long long stage_bytes;
+  hipIpcMemHandle_t stage[IPC_MAX_WORLD];
+  hipIpcMemHandle_t peer[IPC_MAX_WORLD][3];
+};
+
+struct IpcComm : Comm {
+  std::string name;
+  IpcShared* sh = nullptr;
+  double* stage = nullptr;                        // this rank's staging buffer (device), mapped by every peer
+  double* peer_stage[IPC_MAX_WORLD] = {};
+  void* opened[IPC_MAX_WORLD][3] = {};
+  hipIpcMemHandle_t opened_h[IPC_MAX_WORLD][3] = {};
+  static constexpr size_t STAGE_BYTES = (size_t)64 << 20;
+  bool capturable() const override { return false; }
+  bool peer_direct_default() const override { return true; }
+  ~IpcComm() override {
+    for (int p = 0; p < world; ++p) {
+      if (peer_stage[p] && p != rank) (void)hipIpcCloseMemHandle(peer_stage[p]);
+      for (int k = 0; k < 3; ++k) if (opened[p][k]) (void)hipIpcCloseMemHandle(opened[p][k]);
+    }
+    if (stage) (void)hipFree(stage);
+    if (sh) munmap(sh, sizeof(IpcShared));
+    if (rank == 0 && !name.empty()) shm_unlink(name.c_str());
+  }
+  int fail(const char** what, const char* where, hipError_t e) {
+    static thread_local char msg[256];
+    snprintf(msg, sizeof msg, "%s: %s", where, e == hipSuccess ? "failed" : hipGetErrorString(e));
+    *what = msg;
+    if (sh) sh->aborted.store(1);
+    return -1;
+  }
+  // sense-reversing barrier over the shared block; gives up (and aborts the group) after 60 s
+  bool barrier() {
+    if (sh->aborted.load()) return false;
+    const long long gen = sh->generation.load();
+    if (sh->arrived.fetch_add(1) + 1 == world) {
+      sh->arrived.store(0);
+      sh->generation.fetch_add(1);
+      return true;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1; sh->generation.load() == gen; ++spins) {
+      if (sh->aborted.load()) return false;
+      if ((spins & 0xff) == 0) {
+        std::this_thread::yield();
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) { sh->aborted.store(1); return false; }
+      }
+    }
+    return true;
+  }
+  int init(const char** what) {
+    const int fd = rank == 0 ? shm_open(name.c_str(), O_CREAT | O_RDWR | O_TRUNC, 0600) : -1;
+    int f = fd;
+    if (rank == 0) {
+      if (f < 0 || ftruncate(f, sizeof(IpcShared)) != 0) { *what = "shm_open / ftruncate failed"; return -1; }
+    } else {
+      const auto t0 = std::chrono::steady_clock::now();
+      while ((f = shm_open(name.c_str(), O_RDWR, 0600)) < 0) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) { *what = "the group's shared-memory block did not appear"; return -1; }
+      }
+      struct stat st;
+      while (fstat(f, &st) == 0 && (size_t)st.st_size < sizeof(IpcShared)) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    sh = static_cast<IpcShared*>(mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, f, 0));
+    close(f);
+    if (sh == MAP_FAILED) { sh = nullptr; *what = "mmap of the shared block failed"; return -1; }
+    if (rank == 0) {
+      sh->arrived.store(0); sh->generation.store(0); sh->aborted.store(0);
+      sh->world = world; sh->stage_bytes = STAGE_BYTES;
+      sh->magic.store(IPC_MAGIC);
+    } else {
+      const auto t0 = std::chrono::steady_clock::now();
+      while (sh->magic.load() != IPC_MAGIC) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) { *what = "rank 0 never initialised the shared block"; return -1; }
+      }
+      if (sh->world != world) { *what = "the group was created for another world size"; return -1; }
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&stage), STAGE_BYTES);
+    if (e != hipSuccess) return fail(what, "hipMalloc (staging buffer)", e);
+    if ((e = hipIpcGetMemHandle(&sh->stage[rank], stage)) != hipSuccess) return fail(what, "hipIpcGetMemHandle (staging buffer)", e);
+    if (!barrier()) { *what = "a peer rank failed while the group formed"; return -1; }
+    for (int p = 0; p < world; ++p) {
+      if (p == rank) { peer_stage[p] = stage; continue; }
+      void* q = nullptr;
+      if ((e = hipIpcOpenMemHandle(&q, sh->stage[p], hipIpcMemLazyEnablePeerAccess)) != hipSuccess) return fail(what, "hipIpcOpenMemHandle (staging buffer)", e);
+      peer_stage[p] = static_cast<double*>(q);
+    }
+    if (!barrier()) { *what = "a peer rank failed while the group formed"; return -1; }
+    return 0;
+  }
+  int all_gather(double* buf, size_t seg, hipStream_t s, const char** what) override {
+    if (seg * sizeof(double) > STAGE_BYTES) { *what = "segment larger than the IPC staging buffer (64 MiB)"; sh->aborted.store(1); return -1; }
+    hipError_t e;
+    if ((e = hipMemcpyAsync(stage, buf + (size_t)rank * seg, seg * sizeof(double), hipMemcpyDeviceToDevice, s)) != hipSuccess) return fail(what, "ipc stage copy", e);
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return fail(what, "hipStreamSynchronize", e);
+    if (!barrier()) { *what = "a peer rank failed"; return -1; }              // every segment is in its owner's staging buffer
+    for (int p = 0; p < world; ++p)
+      if (p != rank && (e = hipMemcpyAsync(buf + (size_t)p * seg, peer_stage[p], seg * sizeof(double), hipMemcpyDeviceToDevice, s)) != hipSuccess)
+        return fail(what, "ipc peer copy", e);
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return fail(what, "hipStreamSynchronize", e);
+    if (!barrier()) { *what = "a peer rank failed"; return -1; }              // nobody refills a staging buffer a peer is still reading
+    return 0;
+  }
+  int peer_table(void* const mine[3], void** out, const char** what) override {
+    hipError_t e;
+    for (int k = 0; k < 3; ++k)
+      if ((e = hipIpcGetMemHandle(&sh->peer[rank][k], mine[k])) != hipSuccess) return fail(what, "hipIpcGetMemHandle (exchange buffer)", e);
+    if (!barrier()) { *what = "a peer rank failed"; return -1; }
+    for (int p = 0; p < world; ++p)
+      for (int k = 0; k < 3; ++k) {
+        if (p == rank) { out[3 * p + k] = mine[k]; continue; }
+        if (opened[p][k] && memcmp(&opened_h[p][k], &sh->peer[p][k], sizeof(hipIpcMemHandle_t)) == 0) { out[3 * p + k] = opened[p][k]; continue; }
+        if (opened[p][k]) { (void)hipIpcCloseMemHandle(opened[p][k]); opened[p][k] = nullptr; }
+        void* q = nullptr;
+        if ((e = hipIpcOpenMemHandle(&q, sh->peer[p][k], hipIpcMemLazyEnablePeerAccess)) != hipSuccess) return fail(what, "hipIpcOpenMemHandle (exchange buffer)", e);
+        opened[p][k] = q; opened_h[p][k] = sh->peer[p][k];
+        out[3 * p + k] = q;
+      }
+    if (!barrier()) { *what = "a peer rank failed"; return -1; }              // everybody has mapped the table before anybody publishes again
+    return 0;
+  }
+};
+
 }  // namespace
+
+Comm* make_ipc_comm(const char* name, int rank, int world, const char** what) {
+  if (world < 1 || world > IPC_MAX_WORLD) { *what = "world size out of range (1..16)"; return nullptr; }
+  IpcComm* c = new IpcComm();
+  c->name = name; c->rank = rank; c->world = world;
+  if (c->init(what) != 0) { delete c; return nullptr; }
+  return c;
+}
 
 Comm* make_loopback_comm(LoopbackGroup* group, int rank) { return new LoopbackComm(group, rank); }
 

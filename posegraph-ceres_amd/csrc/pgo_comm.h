@@ -4,6 +4,12 @@
 //   * LoopbackComm : several "virtual ranks" = pgo_problem instances driven by host threads of ONE process on one
 //                    GPU; segments are exchanged with device-to-device copies ordered by events.  It exists so that
 //                    the sharding logic can be tested on a single-GPU box; it is not capturable into a hipGraph.
+//   * IpcComm (r05): one PROCESS per rank, the ranks' exchange buffers mapped into each other through hipIpc memory handles —
+//                    what lets the kernels of the owner-only CG store into every rank's buffer and flag array themselves
+//                    (peer_table, DeviceGraph::peer_tab) across process boundaries: several GPUs of one node, or (tests) several
+//                    processes on ONE GPU.  Control plane: a POSIX shared-memory block (handles, a barrier).  Its all-gather —
+//                    used by the few exchanges per LM iteration outside the CG — goes through an IPC-mapped staging buffer
+//                    with two host barriers: correct, not fast, not capturable.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -24,6 +30,8 @@ struct Comm {
   // buffers and its flag array) and receives everybody's, `out[3 * rank + k]`; a collective call.  Returns 0, or -1 when the
   // transport cannot give kernels access to peer memory (then the all-gather above stays in use).
   virtual int peer_table(void* const mine[3], void** out, const char** what) { (void)mine; (void)out; *what = "not supported by this transport"; return -1; }
+  // whether the device-initiated exchange is this transport's normal mode (PGO_PEER_DIRECT=0 / 1 overrides either way)
+  virtual bool peer_direct_default() const { return false; }
 };
 
 struct LoopbackGroup {
@@ -44,6 +52,8 @@ struct LoopbackGroup {
 
 Comm* make_loopback_comm(LoopbackGroup* group, int rank);
 // RCCL: id is the 128-byte ncclUniqueId created by rccl_unique_id() on rank 0
+// IPC: `name` = POSIX shared-memory object every rank of the group opens (rank 0 creates it), e.g. "/pgo_ipc_<pid>"
+Comm* make_ipc_comm(const char* name, int rank, int world, const char** what);
 int rccl_unique_id(unsigned char id[128], const char** what);
 Comm* make_rccl_comm(const unsigned char id[128], int rank, int world, const char** what);
 

@@ -785,6 +785,7 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
   }
   if (summary) {
     memset(summary, 0, sizeof *summary);
+    summary->cg_exchange = P->g.world > 1 ? (P->g.peer_tab && pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : 0;
     summary->cg_form = P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : (P->uni_fused ? 3 : 0);
     summary->termination_type = L.termination;
     summary->reason = L.reason;

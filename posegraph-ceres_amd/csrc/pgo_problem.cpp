@@ -448,8 +448,9 @@ int peer_direct_setup(pgo_problem* P) {
     // Opt-in (PGO_PEER_DIRECT=1): virtual ranks are streams of ONE device, and streams that share a hardware queue (ROCm hands out
     // GPU_MAX_HW_QUEUES = 4 per process by default) can put a waiting launch in front of the kernel it waits for — that only ends
     // by the wait's time-out.  On real ranks (one device each) the question does not arise.  Every rank reads the same environment.
+    // A transport made of processes (IpcComm) has it on by default; PGO_PEER_DIRECT=0 / 1 overrides either way.
     const char* pd = getenv("PGO_PEER_DIRECT");
-    if (pd && pd[0] == '1') {
+    if (pd ? pd[0] == '1' : P->comm->peer_direct_default()) {
       HIP_TRY(P->d_peer_flags.alloc((size_t)world));
       HIP_TRY(P->d_peer_flags.zero(s));
       HIP_TRY(hipStreamSynchronize(s));
