@@ -5,7 +5,7 @@
 #   2. FETCH_SIZE / WRITE_SIZE passes of the same command -> HBM bytes per launch (tools/rocprof_pmc.py)
 #   3. kernel trace of the multifrontal factorisation on C2 and C5
 #   4. FP64 MFMA counters of the multifrontal factorisation on C5
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
