@@ -204,7 +204,9 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
   hipStream_t s = P->stream;
   const std::string k = kernel;
   pgo::CgParams prm = cg_params_for(P->opt);
+#ifdef PGO_ABLATE
   { const char* d = getenv("PGO_DEBUG"); P->g.debug = d ? atoi(d) : 0; }
+#endif
   if (k == "evaluate") {
     HIP_TRY(P->d_tmp_a.alloc((size_t)6 * P->g.E));
     HIP_TRY(P->d_tmp_b.alloc((size_t)36 * P->g.E));

@@ -213,14 +213,14 @@ struct Dissector {
 // Orders every range of `roots` (disjoint ranges of sh.work).  Ranges above kSequential vertices are split by the thread that
 // takes them and their halves handed back; up to `max_threads` host threads, none when everything is small.
 void dissect_ranges(DissectShared& sh, std::vector<std::pair<int, int>> roots, int max_threads) {
-  static const int kSequential = getenv("PGO_ND_SEQ") ? std::max(8, atoi(getenv("PGO_ND_SEQ"))) : 600;
+  static const int kSequential = 600;
   long long total = 0;
   for (const auto& r : roots) total += r.second - r.first;
   // one pool worker per ~500 vertices, subsets above 600 vertices split as tasks (PGO_ND_PER_THREAD / PGO_ND_SEQ).  With a fresh
   // std::thread per worker these were 2000 / 3000 (a start cost tens of microseconds); handing a task to a pool worker costs a
   // few: KITTI-00's 4541 poses are ordered in 0.43 instead of 0.68 ms, the setup of a solve 1.72 -> 1.45 ms.  The order is the same
   // whatever the numbers (a subset's result is a function of its vertex sequence alone).
-  static const int per_thread = getenv("PGO_ND_PER_THREAD") ? std::max(8, atoi(getenv("PGO_ND_PER_THREAD"))) : 500;
+  static const int per_thread = 500;
   const int nt = (int)std::max<long long>(1, std::min<long long>(std::min(max_threads, (int)std::thread::hardware_concurrency()), total / per_thread));
   if (nt <= 1) {
     Dissector d(sh);
@@ -303,7 +303,7 @@ static Components find_components(const Csr& g) {
 }
 
 static int component_workers(const Components& C) {
-  static const int cap = getenv("PGO_ANALYSIS_THREADS") ? std::max(1, atoi(getenv("PGO_ANALYSIS_THREADS"))) : 16;
+  static const int cap = 16;
   return std::max(1, std::min(std::min(C.count(), cap), (int)std::thread::hardware_concurrency()));
 }
 
@@ -332,7 +332,7 @@ static bool order_components(const Csr& g, const Components& C, std::vector<int>
   std::vector<std::pair<int, int>> roots;
   roots.reserve(C.count());
   for (int c = 0; c < C.count(); ++c) roots.emplace_back(C.ptr[c], C.ptr[c + 1]);
-  static const int cap = getenv("PGO_ANALYSIS_THREADS") ? std::max(1, atoi(getenv("PGO_ANALYSIS_THREADS"))) : 16;
+  static const int cap = 16;
   dissect_ranges(sh, std::move(roots), cap);
   return true;
 }
@@ -421,7 +421,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   for (int k = 0; k < N; ++k) S.iperm[S.perm[k]] = k;
   phase("nested dissection");
 
-  static const long long max_pairs = getenv("PGO_DIRECT_MAX_PAIRS") ? atoll(getenv("PGO_DIRECT_MAX_PAIRS")) : 16000000LL;
+  static const long long max_pairs = 16000000LL;
   // ---- 2. symbolic factorisation ----
   // struct(j) = rows > j of column j, sorted: the neighbours of j plus the structures of its etree children.  Flat storage
   // (st_ptr / st_idx), children as sibling lists; a component's columns are a contiguous range of the new numbering and
@@ -627,7 +627,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   // COLUMN/FUSED: a column is processed ten blocks at a time by one wave; a block's update list is walked serially by its
   // 6-lane group(s).  SPLIT: every block of the level has its own wave (ten groups share its list), then a cheap
   // per-column pass.  A level is split when its one-wave-per-column cost exceeds HEAVY steps.
-  static const double HEAVY = getenv("PGO_DIRECT_HEAVY") ? atof(getenv("PGO_DIRECT_HEAVY")) : 16.0;
+  static const double HEAVY = 16.0;
   std::vector<double> level_cost(S.n_levels, 0.0), split_cost(S.n_levels, 0.0);
   {
     // per column: the cost of walking it with one wave, and of its heaviest block; maxima per level (positions of level_cols
@@ -664,7 +664,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   parallel_ranges(N, 8192, [&](int lo, int hi) {
     for (int j = lo; j < hi; ++j) for (int bi = S.col_ptr[j]; bi < S.col_ptr[j + 1]; ++bi) blk_col[bi] = j;
   });
-  static const int PANEL_MAX = getenv("PGO_DIRECT_PANEL") ? std::max(1, std::min(16, atoi(getenv("PGO_DIRECT_PANEL")))) : 8;
+  static const int PANEL_MAX = 8;
   auto is_heavy = [&](int l) { return level_cost[l] > HEAVY && split_cost[l] < level_cost[l]; };
   std::vector<int> tmp_a, tmp_b, tmp_pa, tmp_pb, chain_pos(N, -1);
   double steps = 0.0;
@@ -803,7 +803,7 @@ bool direct_analyze(int N, const std::vector<int>& ia, const std::vector<int>& i
   // (`hybrid`): early LM iterations of a mesh are ill-conditioned (Manhattan 10 k: ~3000 CG iterations = 42 ms vs 6.9 ms
   // direct), late ones are not (~90 CG iterations = 1.3 ms).
   const double max_steps = getenv("PGO_DIRECT_MAX_STEPS") ? atof(getenv("PGO_DIRECT_MAX_STEPS")) : 7000.0;
-  const double hybrid_steps = getenv("PGO_DIRECT_HYBRID_STEPS") ? atof(getenv("PGO_DIRECT_HYBRID_STEPS")) : 30000.0;
+  const double hybrid_steps = 30000.0;
   if (S.steps.size() > 4000 || steps > std::max(max_steps, hybrid_steps)) return false;
   S.hybrid = steps > max_steps;
   return true;

@@ -277,9 +277,8 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_assemble4(DeviceGraph g
 // SPLIT step as ONE launch: as k_chol_assemble4, but a sub-diagonal block does not leave V behind for a scaling launch —
 // its workgroup waits (flag = this factorisation's epoch, polled by one lane, bounded) until the column's diagonal block
 // has been published by ITS workgroup, then applies L_jj^-T itself.  The launcher uses this only while every workgroup of
-// the step is resident at once (<= SPLIT_FUSED_MAX blocks), so a waiting workgroup cannot keep its producer off the chip;
+// the step is resident at once (<= 256 blocks: one per CU, launch_direct_factor), so a waiting workgroup cannot keep its producer off the chip;
 // a wait that runs out sets the failure flag instead of hanging.
-constexpr int SPLIT_FUSED_MAX = 1024;
 __global__ __launch_bounds__(64 * ASM_WAVES) void k_chol_split(DeviceGraph g, DirectPlan p, int blk_begin, int epoch, int max_spins) {
   if (lm_halted(g)) return;   // device-resident LM: a sequence enqueued ahead of a halt (pgo_kernels.h LmDev)
   __shared__ double sh[ASM_WAVES][360];
@@ -966,9 +965,9 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_bwd_tail(DeviceGraph g, Di
 
 void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const DirectSymbolic& sym, hipStream_t s, int epoch) {
   // single-launch SPLIT steps: by default only while the step has at most one workgroup per CU (every workgroup resident
-  // from the start; chain-like graphs: KITTI-00 replay -56 us per LM iteration); PGO_DIRECT_FUSE_SPLIT=1 raises the limit
-  // to SPLIT_FUSED_MAX (no gain measured on dense separators: the wait costs what the launch did), =0 switches it off
-  static const int fuse_split_max = !getenv("PGO_DIRECT_FUSE_SPLIT") ? 256 : getenv("PGO_DIRECT_FUSE_SPLIT")[0] == '0' ? 0 : SPLIT_FUSED_MAX;
+  // from the start; chain-like graphs: KITTI-00 replay -56 us per LM iteration; raising the limit to 1024 gained nothing on
+  // dense separators: the wait costs what the launch did)
+  static const int fuse_split_max = 256;
   // (block assembly with four waves per block — KITTI-00 dense 10.7 -> ~8 us per launch —, three waves per column in the COLUMN
   // levels — 1-4 us per level of KITTI-00 — and four per column in the backward levels were switches in r01 / r02
   // (PGO_DIRECT_ASM4 / _ROLES / _BWD4); the one-wave forms they kept alive went with them in r03)
@@ -976,7 +975,7 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
     if (st.type == DirectStep::COLUMN) {
       const int nc = sym.level_ptr[st.level_begin + 1] - sym.level_ptr[st.level_begin];
       // wide levels (batched solves): one 6-lane group per column from PGO_DIRECT_GROUPS columns on (default 4096)
-      static const int grp_min = getenv("PGO_DIRECT_GROUPS") ? atoi(getenv("PGO_DIRECT_GROUPS")) : 4096;
+      static const int grp_min = 4096;
       if (nc >= grp_min) hipLaunchKernelGGL(k_chol_level_grp, dim3((nc + 10 * GRP_WAVES - 1) / (10 * GRP_WAVES)), dim3(64 * GRP_WAVES), 0, s, g, p, st.level_begin);
       else hipLaunchKernelGGL(k_chol_level3, dim3(nc), dim3(192), 0, s, g, p, st.level_begin);
     } else if (st.type == DirectStep::FUSED) {
@@ -1009,7 +1008,7 @@ void launch_direct_solve(const DeviceGraph& g, const DirectPlan& p, const int* l
   }
   for (int l = fused_from_level - 1; l >= 0; --l) {
     const int nc = level_ptr_host[l + 1] - level_ptr_host[l];
-    static const int grp_min = getenv("PGO_DIRECT_GROUPS") ? atoi(getenv("PGO_DIRECT_GROUPS")) : 4096;
+    static const int grp_min = 4096;
     if (nc >= grp_min) hipLaunchKernelGGL(k_bwd_level_grp, dim3((nc + 10 * GRP_WAVES - 1) / (10 * GRP_WAVES)), dim3(64 * GRP_WAVES), 0, s, g, p, l);
     else hipLaunchKernelGGL(k_bwd_level4, dim3(nc), dim3(64 * BWD_WAVES), 0, s, g, p, l);
   }

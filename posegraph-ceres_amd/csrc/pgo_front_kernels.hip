@@ -1350,7 +1350,11 @@ static void sfront_attributes() {
                             (int)((2 * (size_t)SFRONT_MAX + 6) * (SFRONT_MAX + 1) * sizeof(double)));
   attr_set = true;
 }
+#ifdef PGO_ABLATE
 static const int sf_dbg = getenv("PGO_SF_DBG") ? atoi(getenv("PGO_SF_DBG")) : 0;   // timing ablations of k_sfront_factor (results are wrong with any bit set)
+#else
+static const int sf_dbg = 0;
+#endif
 
 // the kernels that see only the plan gate on FrontPlan::halt = the first word of the device-resident LM state (null without it)
 static inline FrontPlan with_halt(const FrontPlan& p, const DeviceGraph& g) {

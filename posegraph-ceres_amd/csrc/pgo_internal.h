@@ -188,7 +188,7 @@ struct HostSidePool {
   std::mutex mu;
   std::vector<std::pair<int, hipStream_t>> streams;             // (device, stream)
   std::multimap<size_t, void*> pinned;                          // capacity -> mapped, portable host block
-  static bool off() { static const bool v = getenv("PGO_NO_HOST_POOL") && getenv("PGO_NO_HOST_POOL")[0] == '1'; return v; }
+  static bool off() { static const bool v = false; return v; }
   hipError_t get_stream(int dev, hipStream_t* out) {
     if (!off()) {
       std::lock_guard<std::mutex> lk(mu);

@@ -220,7 +220,7 @@ struct DeviceGraph {
   LmDev* lm;          // device-resident LM state; null: the host decides and passes radius / mode by value (several ranks, batched solve, tests)
   LmScalars* scal;    // device-visible pinned host memory
   int* flags;         // [16] device flags: [0] linearize saw non-finite; [4..12] two-level ticket of the fused universal stream
-  int debug;          // development ablation switches (0 in production)
+  int debug;          // timing-ablation bits: read by the kernels only in a -DPGO_ABLATE build (PGO_ABLATION below); 0 otherwise
   // profiling aid (PGO_UNI_OPLOG=<file>, null otherwise): every k_uni_s launch appends (operation it performed, s_memrealtime) so
   // that tools/rocprof_summary.py can bucket the dispatches of that one kernel symbol by what they did.  [0] = entries so far.
   // Fused stream (pgo_solver_trace_*): launch L owns the 66 words at 1 + 66 L: [0] (start tick << 3 | operation) by work-group 0,
@@ -239,6 +239,14 @@ struct DeviceGraph {
   const int* cl_slot;
   const uint8_t* cl_rc;  // per entry: (row - cluster base) << 4 | (col - cluster base)
 };
+
+// Timing ablations (a kernel with a phase switched off: its results are wrong) exist in builds made with -DPGO_ABLATE only; a
+// production build compiles every such test to `false` and carries none of the branches.
+#ifdef PGO_ABLATE
+#define PGO_ABLATION(g, bits) (((g).debug & (bits)) != 0)
+#else
+#define PGO_ABLATION(g, bits) false
+#endif
 
 // element k (row-major 6x6) of slot `slot`, whatever the layout
 __device__ __forceinline__ double bsr_elem(const DeviceGraph& g, int slot, int side, int k) {

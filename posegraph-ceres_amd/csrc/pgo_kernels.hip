@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
   int done = 0, cnt_b = 0;
   double hist_rho = 0.0, hist_q = 0.0;
   double sums[6] = {0, 0, 0, 0, 0, 0};
-  if (MODE == 0 && !(g.debug & 1)) {
+  if (MODE == 0 && !PGO_ABLATION(g, 1)) {
     done = g.cg->done;
     cnt_b = g.cg->cnt_b;
     const double* rz_cur = g.part_rz + (size_t)(odd ? 0 : g.n_part);   // (it-1)&1
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
 
   double beta = 0.0, rho_pub = 0.0, q_pub = 0.0;
   int it = 1;
-  if (MODE == 0 && !(g.debug & 1)) {
+  if (MODE == 0 && !PGO_ABLATION(g, 1)) {
     if (done) return;
     it = cnt_b + 1;
     double rr = 0.0, bb = 0.0;
@@ -976,7 +976,7 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
           for (int k = 0; k < 6; ++k) lds_p[6 * rl + k] = x[k];
         }
       }
-      if (!(g.debug & 2)) {
+      if (!PGO_ABLATION(g, 2)) {
         if (PACKED) {
           // packed slot: TL = positions 0..8, BR = 9..17, Q = 18..26 (bottom-left for BEGIN / DIAG, top-right for END); the
           // row sums keep the expression of the full layout (entries that are structurally zero there are zero here), so
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(256) void k_spmv(DeviceGraph g, CgParams prm, int o
 #pragma unroll
     for (int k = 0; k < 6; ++k) lds[tid * SPMV_LDS_STRIDE + k] = y[k];
     __syncthreads();
-    for (int idx = tid; idx < nrows * 6 && !(g.debug & 4); idx += B) {
+    for (int idx = tid; idx < nrows * 6 && !PGO_ABLATION(g, 4); idx += B) {
       const int rl = idx / 6, k = idx - rl * 6;
       const int rw = r0 + rl;
       const int rb = (idx == tid) ? seg_rb : g.row_slot_begin[rw];

@@ -131,7 +131,7 @@ __device__ __forceinline__ void lean_slot(const DeviceGraph& g, const LeanIdx& c
   LeanSink sink;
   sink.lpair = lpair;
   sink.odd = odd;
-  sink.store = edge && c1.dst >= 0 && !(g.debug & 2);      // (bit 2: timing ablation, no block stores)
+  sink.store = edge && c1.dst >= 0 && !PGO_ABLATION(g, 2);      // (bit 2: timing ablation, no block stores)
   const int d0 = sink.store ? c1.dst : 0;
   sink.val = g.sym_val;
   sink.off = (unsigned)(d0 >> 6) * (unsigned)(TILE_DOUBLES * sizeof(double)) + (unsigned)(d0 & 63) * 16u;      // (launch_linearize_lean: the form is below 4 GiB)
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     const LeanIdx c1 = lean_load_idx(g, cb + tid);
     const LeanData<INFO> c2 = lean_load_data<INFO>(g, cb + tid, c1);
     lean_slot<INFO>(g, c1, c2, lpair, tid & 1);
-    if (g.debug & 4) continue;      // (timing ablation: no row sums)
+    if (PGO_ABLATION(g, 4)) continue;      // (timing ablation: no row sums)
     __syncthreads();
     for (int idx = tid; idx < nrows * LEAN_NV; idx += B) {
       const int rl = idx / LEAN_NV, k = idx - rl * LEAN_NV, rw = r0 + rl;
@@ -217,10 +217,8 @@ bool linearize_lean_fits(const DeviceGraph& g) {
 void launch_linearize_lean(const DeviceGraph& g, hipStream_t s, int gate) {
   if (!linearize_lean_fits(g)) { launch_linearize_symout(g, s, gate); return; }
   // three waves per SIMD: 168 registers without a spill (INFO 0, 3); block-diagonal information needs 12 bytes of scratch there: two
-  static const int waves_env = getenv("PGO_LEAN_WAVES") ? atoi(getenv("PGO_LEAN_WAVES")) : 0;     // experiment switch
-  const int waves = waves_env ? waves_env : g.info_mode == 2 ? 2 : 3;
-  if (waves == 4) launch_lean_w<4>(g, s, gate);
-  else if (waves == 3) launch_lean_w<3>(g, s, gate);
+  const int waves = g.info_mode == 2 ? 2 : 3;
+  if (waves == 3) launch_lean_w<3>(g, s, gate);
   else launch_lean_w<2>(g, s, gate);
 }
 

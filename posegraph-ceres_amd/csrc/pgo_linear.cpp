@@ -8,8 +8,7 @@
 // sets it, spin on the pinned word.  A stream synchronise costs ~20-30 us of wake-up latency per LM iteration phase;
 // the spin sees the result ~2 us after the kernel stored it.  Falls back to the blocking call after 50 ms.
 int wait_handoff(pgo_problem* P) {
-  static const bool no_spin = getenv("PGO_NO_SPIN") && getenv("PGO_NO_SPIN")[0] == '1';
-  if (!no_spin) {
+  {
     const auto t0 = Clock::now();
     for (unsigned spins = 1;; ++spins) {
       if (__atomic_load_n(&P->scal->seq, __ATOMIC_ACQUIRE) != 0) return PGO_OK;
@@ -306,7 +305,7 @@ int upload_front(pgo_problem* P) {
     // pays them once, which the GEMM-heavy factorisations cannot afford.  Default: single launch up to 3 GFLOP
     // (PGO_FRONT_FUSED=1 always, =0 never; PGO_FRONT_FUSED_GFLOP moves the limit).
     const char* fu = getenv("PGO_FRONT_FUSED");
-    const double limit = getenv("PGO_FRONT_FUSED_GFLOP") ? atof(getenv("PGO_FRONT_FUSED_GFLOP")) : 3.0;
+    const double limit = 3.0;
     const bool on = fu ? fu[0] == '1' : S.flops <= limit * 1e9;
     P->front_launches = !on || S.st_table.empty();
   }
@@ -398,7 +397,7 @@ int decide_direct_host(pgo_problem* P, int N, int E, int n_slots, long long fron
   // multifrontal.  PGO_FRONT=1: always multifrontal; 0: never.
   const char* fr = getenv("PGO_FRONT");
   const int front_mode = !fr ? -1 : (fr[0] == '1' ? 1 : 0);
-  const int front_min = getenv("PGO_FRONT_MIN") ? atoi(getenv("PGO_FRONT_MIN")) : 192;
+  const int front_min = 192;
   pgo::DirectSymbolic& S = P->dsym;
   bool front_ok = false;
   // a trajectory with a few chords (KITTI-00 replay: 1.14 edges per pose) is the enumerated schedule's case: its analysis runs
@@ -505,7 +504,7 @@ void enqueue_front_factor(pgo_problem* P, const pgo::DeviceGraph& G) {
   if (!P->front_launches) {
     const char* sp_env = getenv("PGO_FRONT_SPINS");
     const int n_tickets = (int)(P->fsym.st_table.size() / 2);
-    static const bool want_stamps = getenv("PGO_FRONT_STAMPS") && getenv("PGO_FRONT_STAMPS")[0] == '1';
+    static const bool want_stamps = false;
     if (want_stamps && P->ds_stamps.n == 0 && P->ds_stamps.alloc(3 * (size_t)n_tickets) != hipSuccess) return;
     const pgo::FrontStages fs{++P->front_epoch, P->front_tickets, n_tickets, (int)P->fsym.st_need.size(), sp_env ? atoi(sp_env) : (1 << 20),
                               want_stamps ? P->ds_stamps.p : nullptr};
@@ -557,7 +556,7 @@ int run_direct(pgo_problem* P, const pgo::DeviceGraph& G) {
         HIP_TRY(hipMemsetAsync(P->ds_done.p, 0, (size_t)P->fsym.nf * sizeof(int), s));
         HIP_TRY(hipMemsetAsync(P->ds_done.p + P->fsym.nf + 1, 0, (size_t)P->fsym.nf * sizeof(int), s));
       }
-      static const bool want_stamps = getenv("PGO_SF_STAMPS") && getenv("PGO_SF_STAMPS")[0] == '1';
+      static const bool want_stamps = false;
       if (want_stamps && P->ds_stamps.n == 0) HIP_TRY(P->ds_stamps.alloc(6 * (size_t)P->fsym.nf));
       const pgo::SFrontSync sy{P->ds_done.p, P->sfront_tickets, P->sfront_epoch, max_spins, want_stamps ? P->ds_stamps.p : nullptr};
       const pgo::SFrontSync sy_bwd{P->ds_done.p + P->fsym.nf + 1, P->sfront_tickets, P->sfront_epoch, max_spins, nullptr};

@@ -165,8 +165,7 @@ int ensure_spec_buffers(pgo_problem* P) {
   return PGO_OK;
 }
 bool speculation_on(const pgo_problem* P) {
-  static const bool off = getenv("PGO_NO_SPECULATION") && getenv("PGO_NO_SPECULATION")[0] == '1';
-  return !off && P->g.world == 1 && !P->use_graph && !(P->comm && P->comm->world > 1) && !P->sym_storage;   // (the symmetric form has one set of blocks)
+  return P->g.world == 1 && !P->use_graph && !(P->comm && P->comm->world > 1) && !P->sym_storage;   // (the symmetric form has one set of blocks)
 }
 struct SpareSet { double *bsr, *Hdiag, *grad; };
 inline SpareSet spare_set(pgo_problem* P) {
@@ -563,7 +562,7 @@ static bool universal_wanted(const pgo_problem* P) {
   if (direct || !pgo::uni_supported(P->g)) return false;
   // large graphs (kernels of 100+ us) gain nothing from it and the slot kernel's LDS footprint (the linearisation's) would cost the
   // SpMV occupancy there: they keep the host-driven loop
-  const long long limit = getenv("PGO_UNI_MAX_SLOTS") ? atoll(getenv("PGO_UNI_MAX_SLOTS")) : 600000;
+  const long long limit = 600000;
   return (u && u[0] == '1') || P->g.n_slots <= limit;
 }
 
@@ -653,7 +652,7 @@ int lm_run_pipelined(pgo_problem* P, int budget, int* ran) {
     P->pipe_dirty = false;
   }
   // (one decision per sequence at most; the iteration records of the sequences in flight share the LM_RING pinned slots)
-  static const int lookahead = getenv("PGO_PIPELINE_AHEAD") ? std::min((int)pgo::LM_RING - 4, std::max(0, atoi(getenv("PGO_PIPELINE_AHEAD")))) : 1;
+  static const int lookahead = 1;
   const bool direct = o.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY && P->direct_usable;
   const pgo::CgParams prm = cg_params_for(o);
   const int period = prm.q_tolerance < 0.0 ? 0 : o.cg_residual_reset_period;

@@ -250,7 +250,7 @@ int prepare(pgo_problem* P) {
   P->h_slot_row = slot_row; P->h_slot_col = slot_col; P->h_slot_side = slot_side; P->h_row_slot_begin = row_slot_begin;
   P->direct_analyzed = false; P->direct_usable = false; P->front_usable = false; P->sfront_usable = false; P->cluster_built = 0; P->g.cluster = 1;
   P->sym_built = false; P->sym_ready = false; P->sym_active = false; P->sym_storage = false;
-  if (P->want_direct && !(getenv("PGO_NO_ANALYSIS_THREAD") && getenv("PGO_NO_ANALYSIS_THREAD")[0] == '1')) {
+  if (P->want_direct) {
     // an exact request: its host analysis (ordering, symbolic factorisation, schedule) needs nothing but the slot topology
     const long long budget = front_memory_budget();
     const int ns = (int)n_slots;
@@ -383,15 +383,13 @@ int prepare(pgo_problem* P) {
   pgo::DeviceGraph& g = P->g;
   g.N = N; g.E = E; g.n_wg = n_wg; g.n_slots = n_slots; g.block = B;
   g.world = world; g.rank = rank; g.rows_per = rows_per; g.row_lo = row_lo; g.row_hi = row_hi; g.pq_cap = pq_cap; g.seg = seg;
-  // Several ranks: RCCL collectives are enqueued eagerly by default (capturing them into the CG batch graph is only
-  // validated at world size 1 on the development box; PGO_COMM_GRAPH=1 opts in).  The per-iteration cost is then
-  // dominated by the all-gather latency, not by launch overhead.
-  if (P->comm && (!P->comm->capturable() || (world > 1 && !(getenv("PGO_COMM_GRAPH") && getenv("PGO_COMM_GRAPH")[0] == '1')))) P->use_graph = false;
+  // Several ranks: the collectives are enqueued eagerly (capturing them into the CG batch graph was only ever validated at world
+  // size 1); the per-iteration cost is then dominated by the collective's latency, not by launch overhead.
+  if (P->comm && (!P->comm->capturable() || world > 1)) P->use_graph = false;
   // 0 identity, 1 general, 2 block-diagonal W (every W_pr entry exactly zero: diag(1/sigma^2) and the like); 0 and 2 use the packed
-  // 27-entry slots.  PGO_BLK_FULL=1 keeps the general kernels and the full layout (A/B measurements).
+  // 27-entry slots.
   {
-    const char* full = getenv("PGO_BLK_FULL");
-    const bool force_full = full && full[0] == '1';
+    const bool force_full = false;
     static const bool no_diag = getenv("PGO_NO_DIAG_INFO") && getenv("PGO_NO_DIAG_INFO")[0] == '1';    // (A/B: the 12-entry reads of mode 2)
     g.info_mode = !P->has_info ? 0 : (w_diag && !force_full && !no_diag) ? 3 : (w_blockdiag && !force_full) ? 2 : 1;
     g.blk_packed = (g.info_mode != 1 && !force_full) ? 1 : 0;

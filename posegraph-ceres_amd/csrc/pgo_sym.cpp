@@ -14,7 +14,7 @@ bool sym_wanted(const pgo_problem* P) {
   if (e && e[0] == '1') return true;
   // the universal stream serves the graphs below its slot limit (latency-bound kernels of a few microseconds: nothing to gain
   // from fewer bytes there); above it the host-driven CG runs and the SpMV is bandwidth-bound
-  const long long limit = getenv("PGO_UNI_MAX_SLOTS") ? atoll(getenv("PGO_UNI_MAX_SLOTS")) : 600000;
+  const long long limit = 600000;
   return (long long)P->g.n_slots > limit;
 }
 
@@ -38,10 +38,9 @@ int sym_prepare(pgo_problem* P) {
   hp.row_cap = re ? atoi(re) : std::min(256, std::max(32, N / 384));
   hp.row_cap = std::max(8, std::min(hp.row_cap, (int)pgo::SYM_LANES));
   const double avg_w = (double)(N + 2LL * E) / std::max(1, N);
-  const double w_mult = getenv("PGO_SYM_WCAP") ? atof(getenv("PGO_SYM_WCAP")) : 0.95;
+  const double w_mult = 0.95;
   hp.w_cap = std::max<long long>(64, (long long)(w_mult * hp.row_cap * avg_w));
-  if (getenv("PGO_SYM_TILES")) hp.w_cap = std::max<long long>(64, (long long)((N + 2.0 * E) / (0.85 * atof(getenv("PGO_SYM_TILES")))));
-  hp.sort_tiles = !getenv("PGO_SYM_NOSORT");
+  hp.sort_tiles = true;
   pgo::SymHostLayout H;
   pgo::sym_build_host(N, E, P->ia.data(), P->ib.data(), P->h_row_slot_begin.data(), hp, &H);
   if (verbose) std::fprintf(stderr, "[pgo] sym_prepare: partition %.2f ms, tile layout %.2f ms\n", H.ms_partition, H.ms_layout);

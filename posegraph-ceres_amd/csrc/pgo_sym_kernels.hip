@@ -285,7 +285,7 @@ __global__ __launch_bounds__(SYM_LANES) void k_spmv_sym(DeviceGraph g, SymGraph 
     // The slots of a row sit in consecutive lanes: segmented inclusive scan inside the wave (fixed tree, deterministic), so that
     // the LAST lane of every (row, wave) run holds the run's sum and only those lanes go through LDS — the row's lane then adds
     // one entry per wave its slots span instead of one per slot.
-    if (!(g.debug & 512)) seg_scan<6>(u, row, lane);
+    if (!PGO_ABLATION(g, 512)) seg_scan<6>(u, row, lane);
     {
       const int rn = __shfl_down(row, 1, 64);
       if (tid < C.n && (lane == 63 || rn != row)) {
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(SYM_LANES) void k_spmv_sym(DeviceGraph g, SymGraph 
     }
     __syncthreads();
   };
-  const int nrun = (g.debug & 256) ? 0 : nch;     // (development ablation)
+  const int nrun = PGO_ABLATION(g, 256) ? 0 : nch;     // (development ablation)
   for (int c = 0; c < nrun; c += 3) {
     if (c + 2 < nch) load_chunk(CC, c + 2);
     process(CA);
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(2 * SYM_LANES) void k_linearize_sym(DeviceGraph g, 
 #pragma unroll
       for (int k = 0; k < LIN_NV; ++k) v[k] = 0.0;
       int row = l < n ? srow : -1 - lane;
-      if (edge_slot && !(g.debug & 4096)) {
+      if (edge_slot && !PGO_ABLATION(g, 4096)) {
         const int ea = side == SIDE_BEGIN ? srow : xcol, eb = side == SIDE_BEGIN ? xcol : srow;
         const PoseRec A = pose_at(ea), Bp = pose_at(eb);
         const size_t so = (size_t)src;
@@ -449,14 +449,14 @@ __global__ __launch_bounds__(2 * SYM_LANES) void k_linearize_sym(DeviceGraph g, 
 #pragma unroll
         for (int kk = 0; kk < (INFO != 1 ? (int)BLK_PAIRS_PACKED : (int)BLK_PAIRS_FULL); ++kk) out[(size_t)kk * 64] = double2{wv[2 * kk], wv[2 * kk + 1]};
       }
-      if (!(g.debug & 2048)) seg_scan<LIN_NV>(v, row, lane);
+      if (!PGO_ABLATION(g, 2048)) seg_scan<LIN_NV>(v, row, lane);
       const int rn = __shfl_down(row, 1, 64);
       if (l < n && (lane == 63 || rn != row)) {
         const int tp = (int)(m2 & 0xFFFFu);
 #pragma unroll
         for (int k = 0; k < LIN_NV; ++k) exch[(size_t)tp * LIN_NV + k] = v[k];
       }
-    } else if (edge_slot && (meta & (1u << 14)) && !(g.debug & 8192)) {
+    } else if (edge_slot && (meta & (1u << 14)) && !PGO_ABLATION(g, 8192)) {
       // interior (stored in the BEGIN orientation): the END-side incidence of the same edge, for the other row
       const PoseRec A = pose_at(srow), Bp = pose_at(xcol);
       const size_t so = (size_t)src;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(2 * SYM_LANES) void k_linearize_sym(DeviceGraph g, 
     {
       // row l of the tile: lanes 0..255 add values 0..13 of its exchange entries, lanes 256..511 values 14..26
       const int eb = (int)(rin & 0xFFFFu), ec = (int)(rin >> 16);
-      if (ec > 0 && !(g.debug & 1024)) {       // the row's sums pass through registers once per chunk (not once per entry)
+      if (ec > 0 && !PGO_ABLATION(g, 1024)) {       // the row's sums pass through registers once per chunk (not once per entry)
         const int k0 = half ? 14 : 0, nk = half ? LIN_NV - 14 : 14;
         double a[14];
 #pragma unroll

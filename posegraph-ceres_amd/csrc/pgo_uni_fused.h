@@ -101,7 +101,7 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
   const double* rd = g.pipe_buf[rp];
   double* wr = g.pipe_buf[wp];
   const int m = 6 * g.N;
-  const long long t_top = uni_f_traced(g, launch) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+  const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;     // (both log forms order their entries by it)
   // ---- requested before the state is known: what a CG launch needs (work-groups of this form hold exactly B slots: no look-up) ----
   const CgState::Fused st = g.cg->f[rp];
   const int s_begin = wg * B;

@@ -43,6 +43,40 @@ def test_c4_cost_gradient_and_lm_descent(gpu, ds, O, big):
     assert np.array_equal(poses, poses2) and s1.final_cost == s2.final_cost
 
 
+def test_c4_symmetric_form_session_is_tied_to_the_oracle(gpu, ds, O, big):
+    """The DEFAULT path of BASELINE configs[3] on one GPU once a solve can repay the form (max_num_iterations >= 64): the normal
+    equations live in the symmetric tile form only (k_linearize_lean writes it, k_spmv_sym reads it).  Tied to the oracle at full
+    size by what one oracle sweep can check: the cost the session reports for its final poses is the oracle's cost of those
+    poses (1e-11), the accepted costs of its trace are the oracle's costs of ... the same statement at the start, and the gradient
+    the form's linearisation produced at the final point satisfies the directional-derivative identity."""
+    g = big
+    prob, poses = gpu.problem_from_graph(g)
+    s = gpu.solve(gpu.SolverOptions(max_num_iterations=64, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2), prob)
+    assert s.cg_form == 0 and len(s.iterations) >= 20          # host-driven PCG above the universal stream's size limit
+    og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
+    assert s.initial_cost == pytest.approx(O.cost(og), rel=1e-11)
+    assert s.final_cost == pytest.approx(O.cost(og, poses), rel=1e-11)          # one oracle evaluation of the FINAL poses
+    assert s.final_cost < 0.05 * s.initial_cost
+    assert np.array_equal(poses[0], g.poses[0])
+    # the gradient at the final point (fresh evaluation through the incidence-slot kernels) against central differences of the cost
+    final = poses.copy()
+    cost, _, _, _, grad = prob.evaluate(residuals=False, jacobians=False, gradient=True)
+    assert cost == pytest.approx(s.final_cost, rel=1e-11)
+    d = np.random.default_rng(1).normal(size=(g.N, 6)) * 1e-6
+    d[0] = 0
+    prob.plus(d)
+    cp = prob.evaluate(False, False, False)[0]
+    poses[:] = final
+    prob.plus(-d)
+    cm = prob.evaluate(False, False, False)[0]
+    poses[:] = final
+    assert (cp - cm) / 2 == pytest.approx(float((grad * d).sum()), rel=1e-4, abs=1e-9 * abs(cost))
+    # and the session is reproducible bit for bit
+    prob2, poses2 = gpu.problem_from_graph(g)
+    s2 = gpu.solve(gpu.SolverOptions(max_num_iterations=64, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2), prob2)
+    assert s2.final_cost == s.final_cost and np.array_equal(poses2, final)
+
+
 def test_c5_sphere_layers(gpu, ds, O):
     """SURVEY C5 shape: 10 sphere2500-style layers, 25 k poses / 250 k edges (single GPU here)."""
     g = ds.sphere_layers(n_spheres=10, rings=50, per_ring=50, n_edges=250000, seed=20260931)
