@@ -88,7 +88,9 @@ typedef struct pgo_solver_options {
                                              pipelined form where it applies and eta >= 0.01), 1 = standard CG (Ceres' ConjugateGradientsSolver
                                              statement by statement: two dependent launches per iteration, residual refresh),
                                              2 = pipelined CG (Ghysels-Vanroose: same iterates in exact arithmetic, one launch per
-                                             iteration); Summary::cg_form says which ran */
+                                             iteration), 3 = the same recurrences with the whole CG of an LM iteration in ONE launch (blocks and
+                                             vectors resident in registers, a grid barrier per iteration; one such session per device at a
+                                             time, the fused form otherwise); Summary::cg_form says which ran */
   double function_tolerance;              /* 1e-6 */
   double gradient_tolerance;              /* 1e-10 */
   double parameter_tolerance;             /* 1e-8 */
@@ -140,7 +142,8 @@ typedef struct pgo_solver_summary {
   int cg_form;                  /* CG of the PCG solves: 0 one rank, standard CG (two-kernel universal stream / batches), 1 several ranks,
                                    replicated standard CG (every rank updates every row, q all-gathered per iteration), 2 several ranks,
                                    owner-only pipelined CG (every rank updates its own rows, one all-gather per iteration), 3 one rank,
-                                   pipelined CG in the fused universal stream (one launch per CG iteration) */
+                                   pipelined CG in the fused universal stream (one launch per CG iteration), 4 one rank, the same CG resident in one
+                                   launch per LM iteration (grid barrier per CG iteration) */
   int cg_exchange;              /* how the ranks' CG exchanged their segments: 0 nothing to exchange (one rank), 1 a host-enqueued collective
                                    per CG iteration (RCCL all-gather, loopback copies), 2 by the kernels themselves (peer table: stores
                                    into every rank's buffer + flags; the IPC transport's normal mode) */

@@ -278,7 +278,14 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     HIP_TRY(hipEventCreate(&b));
     double total = 0;
     for (int r = 0; r < repeats + 1; ++r) {
-      if (P->uni_fused) {
+      if (P->uni_resident) {
+        // resident form: head, then ONE launch that runs exactly `pairs` CG iterations (stopping tests off, iteration limit = pairs)
+        pgo::CgParams nr{-1.0, -1.0, pairs, 0};
+        pgo::launch_lm_budget(gp, -1, s, 0);
+        pgo::launch_uni_r(gp, nr, 0, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, s);
+        HIP_TRY(hipEventRecord(a, s));
+        pgo::launch_uni_r(gp, nr, 1, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, s);
+      } else if (P->uni_fused) {
         // fused form: head, first product, then 200 CG launches (one launch is one CG iteration)
         int L = 0;
         pgo::launch_lm_budget(gp, -1, s, L);

@@ -363,6 +363,9 @@ struct pgo_problem {
   bool pipe_dirty = true;          // LmState was (re)initialised by the host: upload it before the next sequence
   bool universal = false;          // PCG on one rank: the universal stream (pgo_kernels.h UniOp) instead of allotted sequences
   int uni_enq = 0;                 // vector-shaped launches (fused form: launches) of the stream enqueued since the last upload
+  bool uni_resident = false;       // ... in its resident form (pgo_uni_resident.h: four kernels in a fixed cycle, the whole CG of an LM iteration one launch with a
+                                   //     grid barrier per iteration); uni_fused is set as well (same state words, same launch trace)
+  bool resident_slot = false;      // this problem holds its device's one resident-session slot (pgo_lm.cpp)
   bool uni_fused = false;          // ... in its fused form (k_uni_f: one kernel symbol, one launch per CG iteration, pipelined recurrences)
   // what the host spent enqueueing the stream (pgo_solver_trace): launches and seconds inside the launch calls, since pgo_solver_begin
   long long uni_host_launches = 0;
@@ -532,6 +535,7 @@ int lm_advance(pgo_problem* P);
 int lm_upload_state(pgo_problem* P);
 int lm_run_pipelined(pgo_problem* P, int budget, int* ran);
 int lm_run_universal(pgo_problem* P, int budget, int* ran);
+void resident_slot_release(pgo_problem* P);     // the device's one resident-CG session slot (pgo_lm.cpp)
 int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* records, int capacity);
 
 // ---- pgo_batch.cpp ----

@@ -204,6 +204,7 @@ struct DeviceGraph {
   // launch finds every segment in place and nobody still reading the buffer it will overwrite.  No host, no collective launch.
   void* const* peer_tab;
   unsigned long long* peer_flags;     // [world] this rank's flag array (device)
+  int rows_fit;       // every work-group owns at most block / 6 rows: a row lane per vector component (the resident CG keeps them in registers)
   int pairs_whole;    // the row partition keeps poses 2i, 2i + 1 in one single-chunk work-group (several ranks: prepare() sees to it)
   // partial sums
   double* part_rz;    // [2][n_part]
@@ -313,6 +314,9 @@ void launch_uni_v(const DeviceGraph& g, const CgParams& p, double min_diag, doub
 // slot, the partial-sum rows and the exchange buffer it reads; the device reports launch + 1 as LmScalars::slots_done)
 void launch_uni_f(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s);
 bool uni_f_supported(const DeviceGraph& g, const CgParams& p, int cluster);
+// resident form (pgo_uni_resident.h): four kernel symbols in a fixed cycle, launch L plays role L % 4 (HEAD, whole CG, TAIL, LIN)
+void launch_uni_r(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s);
+bool uni_r_supported(const DeviceGraph& g, const CgParams& p, int cluster);
 void launch_lm_budget(const DeviceGraph& g, int decisions, hipStream_t s, int next_launch = 0);
 void launch_lm_publish(const DeviceGraph& g, hipStream_t s);
 bool uni_supported(const DeviceGraph& g);

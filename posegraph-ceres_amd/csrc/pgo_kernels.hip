@@ -2510,6 +2510,7 @@ __global__ void k_copy_delta(DeviceGraph g, const double* step) {
 }
 
 #include "pgo_uni_fused.h"
+#include "pgo_uni_resident.h"
 
 }  // namespace
 
@@ -2671,6 +2672,35 @@ bool uni_f_supported(const DeviceGraph& g, const CgParams& p, int cluster) {
   return g.world == 1 && g.block <= 256 && g.pairs_whole && g.n_wg <= UNI_F_FOLD * g.block && g.pipe_buf[0] && g.cg_u && g.part_f &&
          (cluster == 1 || cluster == 2) &&
          p.q_tolerance >= 0.0 && p.r_tolerance < 0.0;
+}
+// The resident stream needs what the fused one needs, every row lane in one pass (rows_fit) and a grid that is resident at once at two
+// waves per SIMD (the grid barrier of k_res_cg): 8 waves per CU, 256 CUs.
+bool uni_r_supported(const DeviceGraph& g, const CgParams& p, int cluster) {
+  return uni_f_supported(g, p, cluster) && g.rows_fit && g.block >= 64 && (long long)g.n_wg * (g.block / 64) <= 8LL * 256;
+}
+void launch_uni_r(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s) {
+  const int role = launch & 3;
+  const dim3 grid(g.n_wg), blk(g.block);
+  if (role == 0 || role == 2) {
+    const int op = role == 0 ? F_HEAD : F_TAIL;
+    const size_t lds = (size_t)g.block * sizeof(double);
+#define PGO_RES_V(INF) do { if (g.cluster == 2) hipLaunchKernelGGL((k_res_v<INF, 2>), grid, blk, lds, s, g, launch, op, min_diag, max_diag); \
+                            else hipLaunchKernelGGL((k_res_v<INF, 1>), grid, blk, lds, s, g, launch, op, min_diag, max_diag); } while (0)
+    if (g.info_mode == 3) PGO_RES_V(3); else if (g.info_mode == 2) PGO_RES_V(2); else if (g.info_mode == 1) PGO_RES_V(1); else PGO_RES_V(0);
+#undef PGO_RES_V
+  } else if (role == 1) {
+    const size_t lds = ((size_t)(SPMV_LDS_STRIDE + 6) * g.block + 8) * sizeof(double);
+#define PGO_RES_CG(PK) do { if (g.cluster == 2) hipLaunchKernelGGL((k_res_cg<PK, 2>), grid, blk, lds, s, g, p, launch); \
+                            else hipLaunchKernelGGL((k_res_cg<PK, 1>), grid, blk, lds, s, g, p, launch); } while (0)
+    if (g.blk_packed) PGO_RES_CG(true); else PGO_RES_CG(false);
+#undef PGO_RES_CG
+  } else {
+    const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);
+    if (g.info_mode == 3) hipLaunchKernelGGL(k_res_lin<3>, grid, blk, lds, s, g, launch);
+    else if (g.info_mode == 2) hipLaunchKernelGGL(k_res_lin<2>, grid, blk, lds, s, g, launch);
+    else if (g.info_mode) hipLaunchKernelGGL(k_res_lin<1>, grid, blk, lds, s, g, launch);
+    else hipLaunchKernelGGL(k_res_lin<0>, grid, blk, lds, s, g, launch);
+  }
 }
 void launch_uni_f(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s) {
   const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);

@@ -34,6 +34,23 @@ int evaluate_gradient_and_jacobian(pgo_problem* P, bool first) {
 
 static bool pipeline_wanted(const pgo_problem* P);
 static bool universal_wanted(const pgo_problem* P);
+
+// The resident CG (pgo_uni_resident.h) meets at a grid barrier: every work-group of its launch has to be on the chip at once, which
+// two such launches sharing a device cannot both count on.  ONE session per device holds the right to run it; the others take the fused
+// stream (whose launches need no co-residency and simply share the chip with it).
+static std::atomic<int> g_resident_busy[64];
+static bool resident_slot_acquire(pgo_problem* P) {
+  if (P->resident_slot) return true;
+  int expected = 0;
+  if (P->device < 0 || P->device >= 64 || !g_resident_busy[P->device].compare_exchange_strong(expected, 1)) return false;
+  P->resident_slot = true;
+  return true;
+}
+void resident_slot_release(pgo_problem* P) {
+  if (!P->resident_slot) return;
+  g_resident_busy[P->device].store(0);
+  P->resident_slot = false;
+}
 int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   P->want_direct = options->linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY;
   int rc = prepare(P);
@@ -107,6 +124,14 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   // pipelined CG loses attainable accuracy; pcg_form 2 asks for them regardless)
   const bool fused_asked = P->opt.pcg_form == 2 || (P->opt.pcg_form == 0 && P->opt.eta >= 1e-2);
   P->uni_fused = P->universal && fused_asked && pgo::uni_f_supported(P->g, cg_params_for(P->opt), P->g.cluster);
+  // ... or in its resident form (the whole CG one launch, blocks and vectors in registers, a grid barrier per iteration): the library's
+  // choice where the grid fits the chip and this session gets the device's one resident slot; pcg_form 3 asks for it (and gets the fused
+  // form where it cannot be had), pcg_form 2 keeps the fused form
+  const bool res_asked = P->opt.pcg_form == 3 || (P->opt.pcg_form == 0 && P->opt.eta >= 1e-2);
+  P->uni_resident = P->universal && res_asked && pgo::uni_r_supported(P->g, cg_params_for(P->opt), P->g.cluster) && resident_slot_acquire(P);
+  if (!P->uni_resident) resident_slot_release(P);
+  if (P->opt.pcg_form == 3 && !P->uni_resident) P->uni_fused = P->universal && pgo::uni_f_supported(P->g, cg_params_for(P->opt), P->g.cluster);
+  if (P->uni_resident) P->uni_fused = true;
   P->uni_host_launches = 0; P->uni_host_enqueue_s = 0.0;
   P->pipe_dirty = true;
   // symmetric tile form for the CG products: host-driven PCG of a large graph on one rank (pgo_sym.h)
@@ -600,7 +625,8 @@ int lm_run_universal(pgo_problem* P, int budget, int* ran) {
     if (pending <= hi - lo) {
       const auto t_enq = Clock::now();
       for (int i = 0; i < lo; ++i) {
-        if (fused) pgo::launch_uni_f(gp, prm, P->uni_enq, o.min_lm_diagonal, o.max_lm_diagonal, s);
+        if (P->uni_resident) pgo::launch_uni_r(gp, prm, P->uni_enq, o.min_lm_diagonal, o.max_lm_diagonal, s);
+        else if (fused) pgo::launch_uni_f(gp, prm, P->uni_enq, o.min_lm_diagonal, o.max_lm_diagonal, s);
         else {
           pgo::launch_uni_v(gp, prm, o.min_lm_diagonal, o.max_lm_diagonal, s);
           pgo::launch_uni_s(gp, prm, period, s);
@@ -768,6 +794,7 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
   if (P->dsym.hybrid && P->direct_usable && getenv("PGO_VERBOSE"))
     std::fprintf(stderr, "[pgo] exact request, per-iteration choice: %d factorisations, %d PCG solves within budget, %d over budget (redone)\n",
                  L.hybrid_direct, L.hybrid_pcg_ok, L.hybrid_pcg_over);
+  resident_slot_release(P);
   int rc = download_poses(P, P->g.pose_x);
   if (rc) return rc;
   if (P->g.oplog && !P->g.oplog_indexed) {      // profiling aid (PGO_UNI_OPLOG): "<s_memrealtime tick> <operation>" per k_uni_s launch of this session
@@ -778,14 +805,14 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
     HIP_TRY(hipMemset(P->g.oplog, 0, sizeof(long long)));
     const char* path = getenv("PGO_UNI_OPLOG");       // (may have been unset since prepare() read it)
     if (FILE* f = path ? std::fopen(path, "a") : nullptr) {
-      for (long long v : h) std::fprintf(f, "%lld %d\n", v >> 3, (int)(v & 7) + (P->uni_fused ? 16 : 0));    // (16 +: operations of k_uni_f)
+      for (long long v : h) std::fprintf(f, "%lld %d\n", v >> 3, (int)(v & 7) + (P->uni_resident ? 32 : P->uni_fused ? 16 : 0));    // (16 +: operations of k_uni_f; 32 +: of the resident stream's kernels, symbols of their own)
       std::fclose(f);
     }
   }
   if (summary) {
     memset(summary, 0, sizeof *summary);
     summary->cg_exchange = P->g.world > 1 ? (P->g.peer_tab && pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : 0;
-    summary->cg_form = P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : (P->uni_fused ? 3 : 0);
+    summary->cg_form = P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : (P->uni_resident ? 4 : P->uni_fused ? 3 : 0);
     summary->termination_type = L.termination;
     summary->reason = L.reason;
     summary->num_successful_steps = L.num_successful;

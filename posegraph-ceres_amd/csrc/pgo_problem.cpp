@@ -176,15 +176,19 @@ int prepare(pgo_problem* P) {
   // the fused universal stream k_uni_f) applies the 12 x 12 Jacobi blocks inside the work-group that owns their rows.
   const bool keep_pairs = true;
   bool pairs_whole = keep_pairs;
+  // rows per work-group: at most block / 6 where that costs little (the resident CG, pgo_uni_resident.h, keeps a row lane per vector
+  // component in registers: one pass), unlimited on graphs of low degree (a chain would pay ~2x the work-groups for it)
+  int row_cap = 0;
   auto pack = [&](int lo, int hi, bool record) -> int {
     long long sl = 0;
-    int cur = 0, n = 0;
+    int cur = 0, n = 0, rows = 0;
     if (record) { wg_row_begin.assign(1, lo); wg_slot_begin.assign(1, 0); }
     auto close_wg = [&](int next_row) {
       sl = (sl + B - 1) / B * B;
       ++n;
       if (record) { wg_row_begin.push_back(next_row); wg_slot_begin.push_back((int)sl); }
       cur = 0;
+      rows = 0;
     };
     for (int v = lo; v < hi; ++v) {
       const int c = 1 + deg[v];
@@ -202,16 +206,24 @@ int prepare(pgo_problem* P) {
         if (c + c1 <= B) need = c + c1;
         else pairs_whole = false;
       }
-      if (cur + need > B) close_wg(v);
+      if (cur + need > B || (row_cap > 0 && ((v - lo) & 1) == 0 && rows + 2 > row_cap && cur > 0)) close_wg(v);
       if (record) { row_slot_begin[v] = (int)sl; row_slot_cnt[v] = c; }
       sl += c;
       cur += c;
+      ++rows;
     }
     if (cur > 0) close_wg(hi);
     if (n == 0) { sl += B; close_wg(hi); }   // a rank without rows still launches one (empty) workgroup
     if (record) slot = sl;
     return n;
   };
+  if (world == 1) {
+    const bool pw = pairs_whole;
+    const int n_free = pack(row_lo, row_hi, false);
+    row_cap = (B / 6) & ~1;
+    if (pack(row_lo, row_hi, false) > n_free + n_free / 10) row_cap = 0;
+    pairs_whole = pw;
+  }
   int pq_cap = 1;
   for (int r = 0; r < world; ++r) pq_cap = std::max(pq_cap, pack(std::min(N, r * rows_per), std::min(N, (r + 1) * rows_per), false));
   const int n_wg = pack(row_lo, row_hi, true);
@@ -377,7 +389,7 @@ int prepare(pgo_problem* P) {
   HIP_TRY(P->d_part_f.zero(s));
   HIP_TRY(P->d_cg.alloc(1));
   HIP_TRY(P->d_cg.zero(s));
-  HIP_TRY(P->d_flags.alloc(16));     // [0..3] as pgo_kernels.h says, [4..12] the two-level ticket of the fused stream (k_uni_f)
+  HIP_TRY(P->d_flags.alloc(704));     // [0..3] as pgo_kernels.h says, [4..12] the two-level ticket of the fused stream (k_uni_f), [64..703] the grid barrier of the resident CG (k_res_cg: a 128-byte line per word)
   HIP_TRY(P->d_flags.zero(s));
 
   pgo::DeviceGraph& g = P->g;
@@ -411,6 +423,11 @@ int prepare(pgo_problem* P) {
   g.peer_tab = nullptr; g.peer_flags = nullptr;
   P->peer_dirty = true;       // (the table is exchanged by peer_direct_setup(), outside this function's upload scope: it is a collective call)
   g.pairs_whole = pairs_whole ? 1 : 0;
+  {
+    int most = 0;
+    for (int w = 0; w < n_wg; ++w) most = std::max(most, wg_row_begin[w + 1] - wg_row_begin[w]);
+    g.rows_fit = 6 * most <= B ? 1 : 0;
+  }
   g.n_part = n_part; g.n_vec_wg = n_vec_wg; g.n_edge_wg = n_edge_wg; g.n_pose_wg = n_pose_wg;
   g.cg = P->d_cg.p; g.flags = P->d_flags.p;
   g.oplog = nullptr; g.oplog_cap = 0; g.oplog_indexed = 0;
@@ -523,7 +540,7 @@ pgo_problem* pgo_problem_create(void) {
   if (p) p->device = g_default_device;
   return p;
 }
-void pgo_problem_destroy(pgo_problem* problem) { delete problem; }
+void pgo_problem_destroy(pgo_problem* problem) { if (problem) resident_slot_release(problem); delete problem; }
 
 int pgo_problem_add_pose(pgo_problem* P, double* p, double* q) {
   if (!P || !p || !q) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_problem_add_pose");

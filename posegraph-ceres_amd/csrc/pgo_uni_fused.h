@@ -176,189 +176,18 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
 
   const int nT = g.n_wg;       // every work-group takes part in the vector-shaped operations
   int& is_last = *is_last_p;
-
   if (op == F_HEAD) {
-    // ---- accept-finish of the step just accepted, then damping / Jacobi blocks and the CG start of the next pass ----
-    if (wg >= nT) return;
-    LmDev& D = *g.lm;
-    const int accepted = D.accepted, pause = D.pause;
-    double gmx = 0.0;
-    if (accepted) {
-      for (int v = (nT - 1 - wg) * B + tid; v < g.N; v += nT * B) {      // (from the top: the chunks below start at work-group 0)
-        const PoseRec P = load_pose(g.pose_c, v);
-        const double2* src = reinterpret_cast<const double2*>(g.pose_c + (size_t)POSE_STRIDE * v);
-        double2* dst = reinterpret_cast<double2*>(g.pose_x + (size_t)POSE_STRIDE * v);
-        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
-        const uint8_t cm = g.cmask[v];
-        const double* gr = g.grad + 6 * (size_t)v;
-        if (!(cm & 1)) gmx = fmax(gmx, fmax(fabs(gr[0]), fmax(fabs(gr[1]), fabs(gr[2]))));
-        if (!(cm & 2)) {
-          const Q4 q = quat_plus(P.q, V3{-gr[3], -gr[4], -gr[5]});
-          gmx = fmax(gmx, fmax(fmax(fabs(P.q.x - q.x), fabs(P.q.y - q.y)), fmax(fabs(P.q.z - q.z), fabs(P.q.w - q.w))));
-        }
-      }
-    }
-    gmx = wave_max(gmx);
-    if ((tid & 63) == 0) scratch[tid >> 6] = gmx;
-    __syncthreads();
-    if (tid == 0 && accepted) {
-      double tm = 0.0;
-      for (int w = 0; w < (B + 63) / 64; ++w) tm = fmax(tm, scratch[w]);
-      __hip_atomic_store(&g.part_misc[4 * (size_t)g.n_part + wg], tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!pause) {
-      const double radius = D.core.radius;
-      const int mode = D.core.reuse_diagonal ? 1 : 0;
-      constexpr int CPW = CL == 1 ? 1 : 64 / DIM;                 // Jacobi blocks per wave (cluster_precond_wave)
-      const int PC = CL == 1 ? B / 6 : (B / 64) * CPW * CL;       // poses per chunk: whole Jacobi blocks, 6 PC rows <= B lanes
-      const int n_chunks = (g.N + PC - 1) / PC;
-      for (int ch = wg; ch < n_chunks; ch += nT) {
-        const int pose0 = ch * PC;
-        if constexpr (CL == 1) {
-          if (tid < PC && pose0 + tid < g.N) damping_pose(g, pose0 + tid, radius, min_diag, max_diag, mode);
-        } else {
-          const int wave = tid >> 6, lane = tid & 63;
-          const int n_cl = (g.N + CL - 1) / CL;
-          cluster_precond_wave<CL>(g, radius, min_diag, max_diag, mode, pose0 / CL + wave * CPW, min(n_cl, pose0 / CL + (wave + 1) * CPW), lane);
-        }
-        __syncthreads();      // the inverses were written by other lanes of this work-group
-        const int ridx = 6 * pose0 + tid;
-        const bool rlive = tid < 6 * PC && ridx < m;
-        double b = 0.0;
-        if (rlive) {
-          b = g.scale[ridx] * g.grad[ridx];
-          g.cg_b[ridx] = b;
-          g.cg_x[ridx] = 0.0;
-          g.cg_r[ridx] = b;
-        }
-        lds[tid] = b;
-        __syncthreads();
-        if (rlive) {
-          const double* Mi = g.Minv + (size_t)ridx * DIM;
-          const double* rv = lds + DIM * (tid / DIM);
-          double u = 0.0;
-#pragma unroll
-          for (int k = 0; k < DIM; ++k) u += Mi[k] * rv[k];
-          g.cg_u[ridx] = u;
-          wr[ridx] = u;
-        }
-        __syncthreads();
-      }
-    }
-    // the last work-group to finish: gradient norm of the accepted point, the opening tests of the next pass, the next operation
-    if (tid == 0) is_last = uni_f_last_arrival(g, wg, nT);
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    double mm = 0.0;
-    if (accepted)
-      for (int i = tid; i < nT; i += B)
-        mm = fmax(mm, __hip_atomic_load(&g.part_misc[4 * (size_t)g.n_part + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    mm = wave_max(mm);
-    if ((tid & 63) == 0) scratch[tid >> 6] = mm;
-    __syncthreads();
-    if (tid == 0) {
-      const long long now = (long long)__builtin_amdgcn_s_memrealtime();
-      if (accepted) {
-        double tm = 0.0;
-        for (int w = 0; w < (B + 63) / 64; ++w) tm = fmax(tm, scratch[w]);
-        D.core.gmax = tm;
-        g.scal->ring[D.core.iteration % LM_RING].gradient_max_norm = tm;
-        g.scal->gradient_max = tm;
-        D.accepted = 0;
-        lm_pre_step_checks(D, true);
-        D.ticks_jacobian += now - D.t_mark;    // (the damping / CG start share of this launch is booked here too: one clock per launch)
-        D.t_mark = now;
-      }
-      CgState::Fused n{};
-      if (D.halt) n.op = F_EXIT;
-      else if (pause) { D.halt = LM_HALT_BUDGET; n.op = F_EXIT; }
-      else n.op = F_W0;
-      n.mirror = 1;            // the next launch publishes the state to the host (lane 0 of its work-group 0, beside its work)
-      g.cg->f[wp] = n;
-      g.cg->done = 0; g.cg->iters = 0; g.cg->status = 0;
-    }
+#define PGO_UNI_HEAD_BLOCK
+#define PGO_UNI_HEAD_NEXT F_W0
+#include "pgo_uni_head_tail.inc"
+#undef PGO_UNI_HEAD_NEXT
+#undef PGO_UNI_HEAD_BLOCK
     return;
   }
-
   if (op == F_TAIL) {
-    // ---- step tail: candidate cost (edges), model change and norms (poses), then the DECISION by the last work-group ----
-    if (wg >= nT) return;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};   // candidate cost, model change, |step|^2, |x|^2
-    for (int v = wg * B + tid; v < g.N; v += nT * B) {
-      const PoseRec P = load_pose(g.pose_x, v), C = load_pose(g.pose_c, v);
-      const uint8_t cm = g.cmask[v];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const size_t idx = 6 * (size_t)v + i;
-        const double x = g.cg_x[idx];
-        const double hx = g.cg_q[idx] - g.d2[idx] * x;
-        const bool c = (i < 3) ? (cm & 1) : (cm & 2);
-        acc[1] += c ? 0.0 : (x * g.cg_b[idx] - 0.5 * x * hx);
-      }
-      if (!(cm & 1)) {
-        const double dx = P.p.x - C.p.x, dy = P.p.y - C.p.y, dz = P.p.z - C.p.z;
-        acc[2] += dx * dx + dy * dy + dz * dz;
-        acc[3] += P.p.x * P.p.x + P.p.y * P.p.y + P.p.z * P.p.z;
-      }
-      if (!(cm & 2)) {
-        const double dx = P.q.x - C.q.x, dy = P.q.y - C.q.y, dz = P.q.z - C.q.z, dw = P.q.w - C.q.w;
-        acc[2] += dx * dx + dy * dy + dz * dz + dw * dw;
-        acc[3] += P.q.x * P.q.x + P.q.y * P.q.y + P.q.z * P.q.z + P.q.w * P.q.w;
-      }
-    }
-    for (int e = (nT - 1 - wg) * B + tid; e < g.E; e += nT * B) acc[0] += edge_cost<INFO>(g, g.pose_c, e);   // (edges from the top, poses from the bottom)
-    const long long t_loops = uni_f_traced(g, launch) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-    block_sum<4>(acc, scratch);
-    if (tid == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) __hip_atomic_store(&g.part_misc[(size_t)k * g.n_part + wg], acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      is_last = uni_f_last_arrival(g, wg, nT);
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    const long long t_last = uni_f_traced(g, launch) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-    double s4[4] = {0.0, 0.0, 0.0, 0.0};
-    {   // other work-groups' partials, read at device scope (not from this CU's L1), all requested at once
-      double v[UNI_F_FOLD][4];
-#pragma unroll
-      for (int kk = 0; kk < UNI_F_FOLD; ++kk) {
-        const int i = min(tid + kk * B, nT - 1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[kk][k] = __hip_atomic_load(&g.part_misc[(size_t)k * g.n_part + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-#pragma unroll
-      for (int kk = 0; kk < UNI_F_FOLD; ++kk) {
-        const double wgt = tid + kk * B < nT ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s4[k] += wgt * v[kk][k];
-      }
-    }
-    block_sum<4>(s4, scratch);
-    if (tid == 0) {
-      const long long t_folded = uni_f_traced(g, launch) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-      g.scal->cand_cost = s4[0];
-      g.scal->model_change = s4[1];
-      g.scal->step_norm_sq = s4[2];
-      g.scal->x_norm_sq = s4[3];
-      const int bad = g.flags[1] | (g.flags[2] << 1);
-      g.scal->linearize_bad = bad;
-      g.flags[1] = 0;
-      g.flags[2] = 0;
-      lm_device_decide(g, s4[0], s4[1], s4[2], s4[3], bad, 2 | 8);    // accept / reject / stop, on the spot (pgo_lm_rules.h); 8: no mirror here
-      LmDev& D = *g.lm;
-      CgState::Fused n{};
-      n.op = D.halt ? F_EXIT : D.accepted ? F_LIN : F_HEAD;
-      n.mirror = 1;            // the next launch publishes the decision to the host
-      g.cg->f[wp] = n;
-      if (uni_f_traced(g, launch)) {   // phase stamps of the deciding work-group
-        const long long t_end = (long long)__builtin_amdgcn_s_memrealtime();
-        g.oplog[1 + UNI_F_TRACE_WORDS * (size_t)launch + 1] = ((t_loops - t_top) & 0xffff) | (((t_last - t_top) & 0xffff) << 16) |
-                                                              (((t_folded - t_top) & 0xffff) << 32) | (((t_end - t_top) & 0xffff) << 48);
-      }
-    }
+#define PGO_UNI_TAIL_BLOCK
+#include "pgo_uni_head_tail.inc"
+#undef PGO_UNI_TAIL_BLOCK
     return;
   }
 

@@ -1,0 +1,335 @@
+// pgo_uni_resident.h — the universal stream in its RESIDENT form (r05): the whole truncated CG of an LM iteration is ONE launch whose
+// work-groups keep their 6x6 blocks, their Jacobi blocks and the eight vectors of their rows in REGISTERS from the first product to the
+// last, and meet at a grid barrier once per iteration.  Included by pgo_kernels.hip behind pgo_uni_fused.h (same namespace, same helpers).
+//
+// Why: in the fused stream (pgo_uni_fused.h) a CG iteration is one launch of ~10 us + 2.3 us of kernel boundary that re-requests 44 MB
+// (blocks, vectors, Jacobi blocks) the previous launch already had — at BASELINE configs[1] the whole working set is 26 MB and a launch is
+// a chain of dependent round trips, not a stream.  What has to cross work-groups per iteration is 480 KB: the vector m = M^-1 w every
+// product gathers by column, and three partial sums per work-group.  So: load the blocks once, then per iteration
+//     gather m (6 doubles per slot)  ->  n = A m (LDS row sums)  ->  the pipelined recurrences on the row lanes' registers  ->
+//     m_new = M^-1 w from LDS  ->  publish m_new + {(r,u), (w,u), x'(b + r)}  ->  GRID BARRIER  ->  fold the partial sums, stop / alpha / beta.
+// Same recurrences, same fold order, same stop rules as k_uni_f: the iterates are the fused stream's bit for bit (tests/test_gpu_resident.py).
+//
+// Cross-work-group data (m, the partial sums, x at the end) moves through 8-byte device-scope atomics on both sides — write-through
+// stores, L1-bypassing loads — so no cache write-back or invalidate is needed around the barrier (a release + acquire fence pair is
+// 3.4 us; MI355X_MICROARCH.md, hand-off forms); the barrier itself is a two-level arrival counter (8 classes + 1) and a generation word
+// every work-group's lane 0 polls with relaxed loads.  A work-group that waits longer than ~2 s (a grid that is not fully resident — two
+// such launches sharing the device — would wait forever) sets the abort word: everybody leaves, the CG reports "broke down" and the LM
+// loop treats it as a failed linear solve instead of hanging the device.  The host admits ONE resident session per device at a time
+// (pgo_lm.cpp) and only grids that fit the chip at two waves per SIMD.
+//
+// The stream: four kernel symbols in a fixed cycle, launch L plays role L % 4 —
+//     k_res_v (HEAD) | k_res_cg (the whole CG + the step tail's A x) | k_res_v (TAIL + decision) | k_res_lin (behind an accepted step)
+// — each acting only if the state word says its operation is next (a rejected step leaves the LIN launch idle), state double-buffered
+// by launch parity exactly as in the fused stream; the host enqueues whole cycles ahead of the device's launch counter.
+
+// barrier words in g.flags (zeroed whenever the device state is uploaded), each on a 128-byte line of its own (32 ints): arrivals of
+// class c (work-group index % 8) at RES_CLS + 32 c, classes complete at RES_TOP, generation = barriers completed as seen by class c at
+// RES_GEN + 32 c, abort at RES_ABORT.  Lines of their own: with the generation word next to the counters, 392 polling lanes kept the
+// arrival atomics of the slower work-groups queued behind their loads — 15 us per barrier.  The counters only ever grow (barrier
+// number b is complete when a class has seen in_class * b arrivals and the top word 8 * b): nothing is reset between two barriers.
+constexpr int RES_CLS = 64, RES_TOP = 320, RES_GEN = 352, RES_ABORT = 640, RES_FLAG_WORDS = 704;
+
+// One lane per work-group calls it (after __syncthreads()); returns false if the barrier was aborted.  `gen` = the generation this
+// work-group has seen complete; every arrival targets gen + 1.
+__device__ __forceinline__ bool res_grid_barrier(const DeviceGraph& g, int wg, int n_wg, int& gen) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this work-group's write-through stores have left
+  const int target = gen + 1;
+  const int cls = wg & 7;
+  const int in_class = (n_wg - cls + 7) >> 3;
+  if (atomicAdd(&g.flags[RES_CLS + 32 * cls], 1) + 1 == in_class * target) {
+    if (atomicAdd(&g.flags[RES_TOP], 1) + 1 == min(n_wg, 8) * target) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) __hip_atomic_store(&g.flags[RES_GEN + 32 * c], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned spins = 0;
+  while (__hip_atomic_load(&g.flags[RES_GEN + 32 * cls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0) {
+    __builtin_amdgcn_s_sleep(2);
+    if ((++spins & 0x3ff) == 0) {
+      if (__hip_atomic_load(&g.flags[RES_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { __hip_atomic_store(&g.flags[RES_ABORT], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    }
+  }
+  gen = target;
+  return true;
+}
+
+__device__ __forceinline__ double res_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void res_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// what every kernel of the cycle does when its operation is not the next one (or the stream is stopped): hand the state on
+__device__ __forceinline__ void res_pass_on(const DeviceGraph& g, const CgState::Fused& st, int wp) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (st.mirror) lm_mirror(g);          // (nothing touches the LM state in an idle launch)
+    CgState::Fused n = st;
+    n.mirror = 0;
+    g.cg->f[wp] = n;
+  }
+}
+
+// ---- roles 0 and 2: HEAD and TAIL (the fused stream's operations, without its speculative requests) ----
+template <int INFO, int CL>
+__global__ __launch_bounds__(256) void k_res_v(DeviceGraph g, int launch, int role_op, double min_diag, double max_diag) {
+  extern __shared__ double lds[];
+  __shared__ double scratch[32];
+  __shared__ int is_last_s;
+  constexpr int DIM = 6 * CL;
+  const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
+  const int m = 6 * g.N, nT = g.n_wg;
+  const int rp = launch & 1, wp = rp ^ 1;
+  double* wr = g.pipe_buf[wp];
+  int& is_last = is_last_s;
+  const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+  const CgState::Fused st = g.cg->f[rp];
+  if (wg == 0 && tid == 0) __hip_atomic_store(&g.scal->slots_done, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const bool mine = st.op == role_op;
+  uni_f_trace_begin(g, launch, mine ? role_op : 0, t_top);
+  if (!mine) { res_pass_on(g, st, wp); uni_f_trace_end(g, launch); return; }
+  if (role_op == F_HEAD) {
+    [&]() {          // (the pasted block leaves by `return`)
+#define PGO_UNI_HEAD_BLOCK
+#define PGO_UNI_HEAD_NEXT F_CG
+#include "pgo_uni_head_tail.inc"
+#undef PGO_UNI_HEAD_NEXT
+#undef PGO_UNI_HEAD_BLOCK
+    }();
+  } else {
+    [&]() {
+#define PGO_UNI_TAIL_BLOCK
+#include "pgo_uni_head_tail.inc"
+#undef PGO_UNI_TAIL_BLOCK
+    }();
+  }
+  uni_f_trace_end(g, launch);
+}
+
+// ---- role 3: the linearisation of an accepted candidate ----
+template <int INFO>
+__global__ __launch_bounds__(256) void k_res_lin(DeviceGraph g, int launch) {
+  extern __shared__ double lds[];  // NV_LIN * block
+  const int rp = launch & 1, wp = rp ^ 1;
+  const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+  const CgState::Fused st = g.cg->f[rp];
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&g.scal->slots_done, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const bool mine = st.op == F_LIN;
+  uni_f_trace_begin(g, launch, mine ? F_LIN : 0, t_top);
+  if (!mine) res_pass_on(g, st, wp);
+  else {
+    DeviceGraph gl = g;
+    gl.pose_x = g.pose_c;          // the accepted candidate; the accept-finish part of the next HEAD copies it over
+    linearize_body<INFO>(gl, lds);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (st.mirror) lm_mirror(g);
+      CgState::Fused n{};
+      n.op = F_HEAD;
+      g.cg->f[wp] = n;
+    }
+  }
+  uni_f_trace_end(g, launch);
+}
+
+// ---- role 1: the whole CG ----
+template <bool PACKED, int CL>
+__global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, int launch) {
+  constexpr int NPAIR = PACKED ? BLK_PAIRS_PACKED : BLK_PAIRS_FULL;
+  constexpr int DIM = 6 * CL;
+  extern __shared__ double lds[];  // SPMV_LDS_STRIDE * block (slot results) + 6 * block + 6 (w of the owned rows)
+  __shared__ double scratch[32];
+  __shared__ int sh_ok;
+  const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
+  const int rp = launch & 1, wp = rp ^ 1;
+  const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+  const CgState::Fused st = g.cg->f[rp];
+  if (wg == 0 && tid == 0) __hip_atomic_store(&g.scal->slots_done, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const bool mine = st.op == F_CG;
+  uni_f_trace_begin(g, launch, mine ? F_CG : 0, t_top);
+  if (!mine) { res_pass_on(g, st, wp); uni_f_trace_end(g, launch); return; }
+
+  // ---- what stays in registers for the whole CG: the slot's block, the row lane's vectors and its Jacobi-block row ----
+  const int s_begin = wg * B;
+  const int r0 = g.wg_row_begin[wg], nrows = g.wg_row_begin[wg + 1] - r0;
+  const int t = s_begin + tid;
+  const int col = g.slot_col[t];
+  const int row = g.slot_row[t];
+  const uint8_t side = g.slot_side[t];
+  double2 blk[NPAIR];
+  {
+    const double2* bp = reinterpret_cast<const double2*>(g.bsr_val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) blk[k] = bp[(size_t)k * 64];
+  }
+  const int nown = nrows * 6;                        // <= B (res_supported)
+  const bool own = tid < nown;
+  const size_t gi = 6 * (size_t)r0 + tid;
+  int sb = 0, sE = 0;
+  double vr = 0, vu = 0, vw = 0, vz = 0, vq = 0, vs = 0, vp = 0, vx = 0, vb = 0;
+  double2 mi[DIM / 2];
+#pragma unroll
+  for (int k = 0; k < DIM / 2; ++k) mi[k] = double2{0, 0};
+  if (own) {
+    sb = g.row_slot_begin[r0 + tid / 6] - s_begin;
+    sE = sb + g.row_slot_cnt[r0 + tid / 6];
+    vb = g.cg_b[gi]; vr = vb; vu = g.cg_u[gi];
+    const double2* Mi = reinterpret_cast<const double2*>(g.Minv + gi * DIM);
+#pragma unroll
+    for (int k = 0; k < DIM / 2; ++k) mi[k] = Mi[k];
+  }
+  const int kc = tid % 6;
+  double* lds_w = lds + (size_t)SPMV_LDS_STRIDE * B;
+  int cur = rp;                                      // exchange buffer / partial-sum row this iteration READS (HEAD wrote u0 into pipe_buf[rp])
+  int gen = 0;
+  if (tid == 0) gen = __hip_atomic_load(&g.flags[RES_GEN + 32 * (wg & 7)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (nobody moves it before everybody has arrived once)
+  int cnt = 0, stop = 0, status = 0;
+  double alpha = 0.0, beta = 0.0, gamma_prev = 0.0, alpha_prev = 0.0, q_prev = 0.0;
+  bool ok = true;
+  const bool traced = wg == 0 && tid == 0 && uni_f_traced(g, launch);
+  long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;      // (trace: ticks work-group 0 spent up to the publish / in the barrier / in the fold, summed over the iterations)
+  for (int it = 0;; ++it) {
+    // ---- n = A m over this work-group's slots (it == 0: w0 = A u0) ----
+    const long long tp0 = traced ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    double y[6] = {0, 0, 0, 0, 0, 0};
+    double mine_m = 0.0;
+    if (own && it > 0) mine_m = res_ld(g.pipe_buf[cur] + gi);
+    if (col >= 0) {
+      const double* ms = g.pipe_buf[cur] + 6 * (size_t)col;
+      double x[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) x[k] = res_ld(ms + k);
+      slot_block_times<PACKED, NPAIR>(blk, side, x, y);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) lds[tid * SPMV_LDS_STRIDE + k] = y[k];
+    __syncthreads();
+    double acc[3] = {0.0, 0.0, 0.0};
+    if (own) {
+      double s0 = 0.0, s1 = 0.0;
+      int j = sb;
+      for (; j + 1 < sE; j += 2) { s0 += lds[j * SPMV_LDS_STRIDE + kc]; s1 += lds[(j + 1) * SPMV_LDS_STRIDE + kc]; }
+      if (j < sE) s0 += lds[j * SPMV_LDS_STRIDE + kc];
+      const double sm = s0 + s1;
+      if (it == 0) {
+        vw = sm;
+      } else {
+        const double zn = sm + beta * vz, qn = mine_m + beta * vq, sn = vw + beta * vs, pn = vu + beta * vp;
+        vx = vx + alpha * pn;
+        vr = vr - alpha * sn;
+        vu = vu - alpha * qn;
+        vw = vw - alpha * zn;
+        vz = zn; vq = qn; vs = sn; vp = pn;
+        acc[2] = vx * (vb + vr);
+      }
+      acc[0] = vr * vu;
+      acc[1] = vw * vu;
+      lds_w[tid] = vw;
+    }
+    if (tid < 6) lds_w[nown + tid] = 0.0;       // the missing half of a last odd pair
+    __syncthreads();
+    if (own) {
+      const double* wv = lds_w + DIM * (tid / DIM);
+      double mn = 0.0;
+#pragma unroll
+      for (int k = 0; k < DIM / 2; ++k) mn += mi[k].x * wv[2 * k] + mi[k].y * wv[2 * k + 1];
+      res_st(g.pipe_buf[cur ^ 1] + gi, mn);
+    }
+    block_sum<3>(acc, scratch);
+    if (tid == 0) {
+      double* pf = g.part_f + ((size_t)(cur ^ 1) * g.n_part + wg) * 4;
+      res_st(pf, acc[0]); res_st(pf + 1, acc[1]); res_st(pf + 2, acc[2]);
+      const long long tp1 = traced ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+      sh_ok = res_grid_barrier(g, wg, g.n_wg, gen) ? 1 : 0;
+      if (traced) { const long long tp2 = (long long)__builtin_amdgcn_s_memrealtime(); ph0 += tp1 - tp0; ph1 += tp2 - tp1; ph3 = tp2; }
+    }
+    __syncthreads();
+    if (!sh_ok) { ok = false; break; }
+    cur ^= 1;
+    // ---- fold the partial sums (every work-group alike, the fused stream's order), then its stop test / alpha / beta ----
+    double f3[3] = {0.0, 0.0, 0.0};
+    {
+      const double* pf = g.part_f + (size_t)cur * 4 * g.n_part;
+      for (int k = 0; k * B < g.n_wg; ++k) {          // (the fused stream's order: entry tid + k B in turn k; it adds 0 x entry for the lanes past the end)
+        const int i = min(tid + k * B, g.n_wg - 1);
+        const double wgt = tid + k * B < g.n_wg ? 1.0 : 0.0;
+        const double a0 = res_ld(pf + 4 * (size_t)i), a1 = res_ld(pf + 4 * (size_t)i + 1), a2 = res_ld(pf + 4 * (size_t)i + 2);
+        f3[0] += wgt * a0; f3[1] += wgt * a1; f3[2] += wgt * a2;
+      }
+    }
+    block_sum<3>(f3, scratch);
+    if (traced) ph2 += (long long)__builtin_amdgcn_s_memrealtime() - ph3;
+    const double gamma = f3[0], delta = f3[1], Q1 = -f3[2];
+    if (cnt > 0) {
+      const double zeta = cnt * (Q1 - q_prev) / Q1;
+      if (zeta < prm.q_tolerance && cnt >= prm.min_iterations) stop = 1;
+      if (cnt >= prm.max_iterations) stop = 1;
+    }
+    if (!stop && (gamma == 0.0 || !isfinite(gamma))) { stop = 1; status = (gamma == 0.0) ? 0 : 2; }
+    if (!stop && cnt > 0) {
+      beta = gamma / gamma_prev;
+      if (beta == 0.0 || !isfinite(beta)) { stop = 1; status = 2; }
+    }
+    if (!stop) {
+      const double den = cnt > 0 ? delta - beta * gamma / alpha_prev : delta;
+      if (!(den > 0.0) || !isfinite(den)) { stop = 1; status = 1; }     // "matrix is indefinite": x of the previous iteration stands
+      else alpha = gamma / den;
+    }
+    if (stop) break;
+    gamma_prev = gamma; alpha_prev = alpha; q_prev = Q1;
+    cnt = it + 1;              // the update the next turn of the loop applies is iteration `cnt`
+  }
+  if (!ok) { status = 2; }
+  // ---- the CG has stopped after `cnt` iterations: x to everybody, then q = A x and the candidates for the step tail ----
+  if (own) res_st(g.cg_x + gi, vx);
+  __syncthreads();
+  if (ok) {
+    if (tid == 0) sh_ok = res_grid_barrier(g, wg, g.n_wg, gen) ? 1 : 0;
+    __syncthreads();
+    if (!sh_ok) { ok = false; status = 2; }
+  }
+  if (wg == 0 && tid == 0) {
+    if (st.mirror) lm_mirror(g);
+    g.cg->iters = cnt; g.cg->status = status; g.cg->done = 1;
+    CgState::Fused n{};
+    n.op = F_TAIL;
+    g.cg->f[wp] = n;
+    if (traced) g.oplog[1 + UNI_F_TRACE_WORDS * (size_t)launch + 1] = (ph0 & 0xffff) | ((ph1 & 0xffff) << 16) | ((ph2 & 0xffff) << 32) | ((long long)(cnt & 0xffff) << 48);
+  }
+  double y[6] = {0, 0, 0, 0, 0, 0};
+  if (col >= 0) {
+    double x[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = res_ld(g.cg_x + 6 * (size_t)col + k);
+    if (side == SIDE_DIAG) {
+      const PoseRec P = load_pose(g.pose_x, row);
+      const uint8_t cm = g.cmask[row];
+      double d[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const bool c = (i < 3) ? (cm & 1) : (cm & 2);
+        d[i] = c ? 0.0 : -g.scale[6 * (size_t)row + i] * x[i];
+        g.delta[6 * (size_t)row + i] = d[i];
+      }
+      V3 pc = P.p;
+      Q4 qc = P.q;
+      if (!(cm & 1)) pc = V3{P.p.x + d[0], P.p.y + d[1], P.p.z + d[2]};
+      if (!(cm & 2)) qc = quat_plus(P.q, V3{d[3], d[4], d[5]});
+      double2* o = reinterpret_cast<double2*>(g.pose_c + (size_t)POSE_STRIDE * row);
+      o[0] = double2{pc.x, pc.y};
+      o[1] = double2{pc.z, qc.x};
+      o[2] = double2{qc.y, qc.z};
+      o[3] = double2{qc.w, 0.0};
+    }
+    slot_block_times<PACKED, NPAIR>(blk, side, x, y);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) lds[tid * SPMV_LDS_STRIDE + k] = y[k];
+  __syncthreads();
+  if (own) {
+    double s0 = 0.0, s1 = 0.0;
+    int j = sb;
+    for (; j + 1 < sE; j += 2) { s0 += lds[j * SPMV_LDS_STRIDE + kc]; s1 += lds[(j + 1) * SPMV_LDS_STRIDE + kc]; }
+    if (j < sE) s0 += lds[j * SPMV_LDS_STRIDE + kc];
+    g.cg_q[gi] = s0 + s1;
+  }
+  uni_f_trace_end(g, launch);
+}

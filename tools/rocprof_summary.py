@@ -25,7 +25,7 @@ def main(db, out, oplog=None):
     note = ""
     if oplog:
         entries = sorted(tuple(int(x) for x in line.split()) for line in open(oplog) if line.strip())
-        for sym, names, log in (("k_uni_s", OPS, [e for e in entries if e[1] < 16]), ("k_uni_f", OPS_F, [e for e in entries if e[1] >= 16])):
+        for sym, names, log in (("k_uni_s", OPS, [e for e in entries if e[1] < 16]), ("k_uni_f", OPS_F, [e for e in entries if 16 <= e[1] < 32])):
             uni = [(n, r) for n, *r in rows if sym in n]
             if not uni and not log:
                 continue
