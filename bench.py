@@ -325,75 +325,88 @@ def main():
         # (one rank, PCG, graphs of this size: the timed region runs the universal stream — k_uni_s in its CG mode is the SpMV — so the
         # in-situ figure is a (k_uni_v, k_uni_s) pair of that stream; otherwise a captured batch of the k_spmv / k_pcg_update kernels)
         uni = False
-        fused = False
         t_iter = None
+        form = prob.cg_form() if (world == 1 and not sharded) else -1        # 0 two-kernel stream / batches, 3 fused stream, 4 resident stream
+        fused, resident = form == 3, form == 4
         if world == 1 and not sharded:
             try:
-                t_iter = prob.time_kernel("uni_cg", 5)
+                t_iter = prob.time_kernel("uni_cg", 5)       # one CG iteration in situ (HIP events on the solver stream; resident: one launch of 200 iterations / 200)
                 uni = True
             except Exception:  # noqa: BLE001 - the session does not use the universal stream
                 t_iter = prob.time_kernel("pcg_graph", 5)
-        # ---- where a timed LM step goes: launch trace of the fused universal stream (include/pgo.h pgo_solver_trace_*), the same K
+        # ---- where a timed LM step goes: launch trace of the one-launch universal streams (include/pgo.h pgo_solver_trace_*), the same K
         # steps from the same start once more with every launch recording its operation and device clock (s_memrealtime, 100 MHz) ----
         breakdown = None
-        if uni and not os.environ.get("PGO_UNI_OPLOG"):     # (the rocprof runs use the appended operation log instead: one buffer)
-            try:
-                prob.solver_reset()
-                prob.trace_start(400 * args.steps + 400)
-                fused = True
-            except pkg.PgoError:
-                fused = False
-            if fused:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                run_steps(prob, args.steps)
-                torch.cuda.synchronize()
-                wall_tr = time.perf_counter() - t0
-                rec, host_launches, host_s = prob.trace_read(400 * args.steps + 400)
-                prob.trace_start(0)
-                names = {1: "head (accept-finish, damping, Jacobi blocks, CG start)", 2: "first product w0 = A u0", 3: "cg (one launch per PCG iteration; the last one of a run multiplies A x for the step tail)",
-                         4: "step tail + decision", 5: "linearise (behind an accepted step)"}
-                live = np.nonzero(rec[:, 0] > 0)[0]
-                last = int(live.max())
-                body, drain = rec[: last + 1], rec[last + 1:]
-                dur = (body[:, 2] - body[:, 1]) / 100.0                       # top of work-group 0 -> end of the last work-group, us
-                gap = np.append((body[1:, 1] - body[:-1, 2]) / 100.0, 0.0)     # end of a launch -> top of the next one: boundary + stream idle
-                ops = {}
-                for op, label in names.items():
-                    m = body[:, 0] == op
-                    if m.any():
-                        ops[label] = {"launches_per_step": round(float(m.sum()) / args.steps, 2), "kernel_us": round(float(dur[m].mean()), 2),
-                                      "gap_behind_us": round(float(gap[m].mean()), 2),
-                                      "us_per_step": round(float((dur[m] + gap[m]).sum()) / args.steps, 1)}
-                span = (body[-1, 2] - body[0, 1]) / 100.0
-                drain_us = float((drain[-1, 2] - body[-1, 2]) / 100.0) if len(drain) else 0.0
-                cgm = body[:, 0] == 3
-                ph = np.array([[(int(w) >> (16 * k)) & 0xffff for k in range(4)] for w in body[cgm][:, 3]]) / 100.0
-                breakdown = {"what": "the timed region once more (same K steps, same start) with the launch trace on: device clock of every launch",
-                             "ms_per_step_traced": round(1e3 * wall_tr / args.steps, 4), "launches_per_step": round((last + 1) / args.steps, 2),
-                             "operations": ops, "sum_of_operations_us_per_step": round(sum(v["us_per_step"] for v in ops.values()), 1),
-                             "device_span_us_per_step": round(span / args.steps, 1),
-                             "stream_idle_gaps_us_per_step": round(float(gap.sum()) / args.steps, 1),
-                             "drain_behind_the_last_decision_us_per_step": round(drain_us / args.steps, 1),
-                             "launches_enqueued_behind_the_pause": int(len(drain)),
-                             "host_side_us_per_step_outside_the_device_span": round(1e6 * wall_tr / args.steps - span / args.steps, 1),
-                             "host_enqueue_us_per_launch": round(1e6 * host_s / max(1, host_launches), 2), "host_launches": host_launches,
-                             "cg_launch_phases_us_work_group_0": dict(zip(("product_done", "sums_folded", "rows_updated", "end"),
-                                                                          [round(float(x), 2) for x in np.median(ph, axis=0)])) if len(ph) else None,
-                             "note": "kernel_us = top of work-group 0 to the end of the last work-group; gap_behind_us = from there to the top of the next "
-                                     "launch (kernel boundary + whatever the stream idles); tracing costs 3-4 % (one atomic per work-group per launch)"}
-        # algorithmic bytes of ONE launch of the dominant kernel: fused stream = K3 + K4 in one launch (block product
-        # (N + E) 288 + 2 N 48, the ten vector streams 10 N 48, the Jacobi blocks N 36 CL 8); two-kernel stream = K3 (the slot kernel)
-        b_dom = b_spmv + ((10 * N * 48 + N * 36 * args.cluster * 8) if fused else 0)
-        t_dom = t_iter if fused else (t_iter * t_spmv / (t_spmv + t_upd) if t_iter else t_spmv)
+        cg_its_per_launch = cg_launch_us = None
+        if (fused or resident) and not os.environ.get("PGO_UNI_OPLOG"):     # (the rocprof runs use the appended operation log instead: one buffer)
+            prob.solver_reset()
+            prob.trace_start(400 * args.steps + 400)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(prob, args.steps)
+            torch.cuda.synchronize()
+            wall_tr = time.perf_counter() - t0
+            rec, host_launches, host_s = prob.trace_read(400 * args.steps + 400)
+            prob.trace_start(0)
+            names = {1: "head (accept-finish, damping, Jacobi blocks, CG start)", 2: "first product w0 = A u0",
+                     3: ("cg (ONE launch per LM iteration: first product, every PCG iteration with a grid barrier each, the step tail's A x)" if resident else
+                         "cg (one launch per PCG iteration; the last one of a run multiplies A x for the step tail)"),
+                     4: "step tail + decision", 5: "linearise (behind an accepted step)", 0: "idle launch of the cycle (the linearise slot behind a rejected step)"}
+            live = np.nonzero(rec[:, 0] > 0)[0]
+            last = int(live.max())
+            body, drain = rec[: last + 1], rec[last + 1:]
+            dur = (body[:, 2] - body[:, 1]) / 100.0                       # top of work-group 0 -> end of the last work-group, us
+            gap = np.append((body[1:, 1] - body[:-1, 2]) / 100.0, 0.0)     # end of a launch -> top of the next one: boundary + stream idle
+            ops = {}
+            for op, label in names.items():
+                m = body[:, 0] == op
+                if m.any():
+                    ops[label] = {"launches_per_step": round(float(m.sum()) / args.steps, 2), "kernel_us": round(float(dur[m].mean()), 2),
+                                  "gap_behind_us": round(float(gap[m].mean()), 2),
+                                  "us_per_step": round(float((dur[m] + gap[m]).sum()) / args.steps, 1)}
+            span = (body[-1, 2] - body[0, 1]) / 100.0
+            drain_us = float((drain[-1, 2] - body[-1, 2]) / 100.0) if len(drain) else 0.0
+            cgm = body[:, 0] == 3
+            ph = np.array([[(int(w) >> (16 * k)) & 0xffff for k in range(4)] for w in body[cgm][:, 3]], dtype=float)
+            breakdown = {"what": "the timed region once more (same K steps, same start) with the launch trace on: device clock of every launch",
+                         "ms_per_step_traced": round(1e3 * wall_tr / args.steps, 4), "launches_per_step": round((last + 1) / args.steps, 2),
+                         "operations": ops, "sum_of_operations_us_per_step": round(sum(v["us_per_step"] for v in ops.values()), 1),
+                         "device_span_us_per_step": round(span / args.steps, 1),
+                         "stream_idle_gaps_us_per_step": round(float(gap.sum()) / args.steps, 1),
+                         "drain_behind_the_last_decision_us_per_step": round(drain_us / args.steps, 1),
+                         "launches_enqueued_behind_the_pause": int(len(drain)),
+                         "host_side_us_per_step_outside_the_device_span": round(1e6 * wall_tr / args.steps - span / args.steps, 1),
+                         "host_enqueue_us_per_launch": round(1e6 * host_s / max(1, host_launches), 2), "host_launches": host_launches,
+                         "note": "kernel_us = top of work-group 0 to the end of the last work-group; gap_behind_us = from there to the top of the next "
+                                 "launch (kernel boundary + whatever the stream idles); tracing costs 3-4 % (one atomic per work-group per launch)"}
+            if resident and len(ph):
+                turns = ph[:, 3] + 1.0                           # turns of the CG loop = first product + iterations
+                cg_its_per_launch = float(ph[:, 3].mean())
+                cg_launch_us = float(dur[cgm].mean())
+                breakdown["cg_iterations_per_step"] = round(cg_its_per_launch, 2)
+                breakdown["cg_us_per_loop_turn"] = round(float(dur[cgm].sum() / (turns + 1.0).sum()), 2)     # turns + the step tail's product
+                breakdown["cg_loop_turn_us_work_group_0"] = {"product_recurrences_publish": round(float((ph[:, 0] / turns).mean()) / 100.0, 2),
+                                                             "grid_barrier": round(float((ph[:, 1] / turns).mean()) / 100.0, 2),
+                                                             "fold_and_stop_test": round(float((ph[:, 2] / turns).mean()) / 100.0, 2)}
+            elif len(ph):
+                breakdown["cg_launch_phases_us_work_group_0"] = dict(zip(("product_done", "sums_folded", "rows_updated", "end"),
+                                                                         [round(float(x), 2) for x in np.median(ph, axis=0) / 100.0]))
+        # algorithmic bytes of ONE CG iteration of the dominant kernel: one-launch forms = K3 + K4 (block product
+        # (N + E) 288 + 2 N 48, the ten vector streams 10 N 48, the Jacobi blocks N 36 CL 8); two-kernel stream = K3 (the slot kernel).
+        # The resident kernel runs `cg_its_per_launch` iterations per launch: bytes per launch = that many times the per-iteration figure
+        # (what it MOVES per iteration is 1.5 MB: the blocks and vectors stay in registers — `traffic` says so)
+        b_dom = b_spmv + ((10 * N * 48 + N * 36 * args.cluster * 8) if (fused or resident) else 0)
+        t_dom = t_iter if (fused or resident) else (t_iter * t_spmv / (t_spmv + t_upd) if t_iter else t_spmv)
         ach = b_dom / (t_dom * 1e-3) / 1e9
-        dom = "k_uni_f" if fused else ("k_uni_s" if uni else "k_spmv<0")
+        if resident and cg_its_per_launch and cg_launch_us:
+            ach = b_dom * cg_its_per_launch / (cg_launch_us * 1e-6) / 1e9       # whole launches: first product, barriers and the tail's product included
+        dom = "k_res_cg" if resident else "k_uni_f" if fused else ("k_uni_s" if uni else "k_spmv<0")
         # HBM bytes per launch: only from a PMC profile taken on THESE kernel sources (sha256 of the kernel sources recorded by
         # tools/rocprof_pmc.py); a profile of other sources is not quoted
         traffic = None
         import hashlib
         sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "posegraph-ceres_amd", "csrc", f), "rb").read()
-                                      for f in ("pgo_kernels.hip", "pgo_uni_fused.h"))).hexdigest()[:16]
+                                      for f in ("pgo_kernels.hip", "pgo_uni_fused.h", "pgo_uni_head_tail.inc", "pgo_uni_resident.h"))).hexdigest()[:16]
         extra["kernel_source_sha256_16"] = sha
         try:
             pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
@@ -406,25 +419,32 @@ def main():
                     extra["traffic_source"] = "none: profiles/%s was taken on other kernel sources (%s vs %s)" % (pmcs[-1], pm.get("kernel_source_sha256_16"), sha)
         except Exception:  # noqa: BLE001
             traffic = None
-        roofline = {"kernel": ("k_uni_f, CG operation (the fused universal stream: one launch = one PCG iteration — block product n = A m, the pipelined "
+        roofline = {"kernel": ("k_res_cg (the resident universal stream: the whole PCG of an LM iteration in ONE launch — blocks, Jacobi blocks and row vectors in "
+                               "registers, per iteration: gather m, block product, pipelined recurrences, publish, grid barrier, fold; FP64 6x6 BSR)" if resident else
+                               "k_uni_f, CG operation (the fused universal stream: one launch = one PCG iteration — block product n = A m, the pipelined "
                                "vector recurrences, the Jacobi blocks; FP64 6x6 BSR)" if fused else
                                "k_uni_s, CG mode (the universal stream's slot kernel: PCG block SpMV, FP64 6x6 BSR)" if uni else "k_spmv<0> (PCG block SpMV, FP64 6x6 BSR)"),
                     "rocprof_kernel_name": dom, "bound": "hbm",
-                    "regime": "launch/latency-bound at this size: the 26 MB working set lives in the 256 MiB Infinity Cache and a launch is a chain of "
-                              "dependent round trips (SURVEY 8d: quote HBM fractions at C4 size: `at_c4_size` below)",
+                    "regime": "launch/latency-bound at this size: the 26 MB working set lives in registers / the 256 MiB Infinity Cache and an iteration is a chain of "
+                              "dependent round trips and a grid barrier (SURVEY 8d: quote HBM fractions at C4 size: `at_c4_size` below)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "frac_live": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": b_dom, "avg_launch_us": round(t_dom * 1e3, 3),
-                    "avg_launch_us_is": "HIP events around 200 back-to-back launches on the solver stream (kernel + boundary)" if fused else
-                                        "HIP events around 200 (vector, slot) pairs, split in proportion of the isolated durations",
+                    "algorithmic_bytes_per_cg_iteration": b_dom,
+                    "algorithmic_bytes_per_launch": int(b_dom * cg_its_per_launch) if (resident and cg_its_per_launch) else b_dom,
+                    "cg_iterations_per_launch": round(cg_its_per_launch, 2) if (resident and cg_its_per_launch) else 1,
+                    "avg_launch_us": round(cg_launch_us, 3) if (resident and cg_launch_us) else round(t_dom * 1e3, 3),
+                    "avg_launch_us_is": ("device clock of the CG launches of the traced K steps (top of work-group 0 to the end of the last work-group)" if resident else
+                                         "HIP events around 200 back-to-back launches on the solver stream (kernel + boundary)" if fused else
+                                         "HIP events around 200 (vector, slot) pairs, split in proportion of the isolated durations"),
                     "cg_iteration_us_in_situ": round(t_iter * 1e3, 3) if t_iter else None}
-        if breakdown is not None:
+        if breakdown is not None and not resident:
             cg_row = next((v for k, v in breakdown["operations"].items() if k.startswith("cg")), None)
             if cg_row:
                 roofline["device_clock_kernel_us"] = cg_row["kernel_us"]
                 roofline["frac_from_device_clock"] = round(b_dom / (cg_row["kernel_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-        # `frac` is what the COMMITTED rocprofv3 statistics give (latest profiles/*_bench_kernel_stats.csv, the dominant kernel's CG
-        # dispatches split out by tools/rocprof_summary.py) whenever they were taken on these kernel sources; `frac_live` is this run's
+        # `frac` is what the COMMITTED rocprofv3 statistics give (latest profiles/*_bench_kernel_stats.csv: the dominant kernel's CG
+        # dispatches — split out by tools/rocprof_summary.py for the one-symbol streams, the k_res_cg row itself for the resident stream,
+        # whose launches run cg_iterations_per_launch iterations each) whenever they were taken on these kernel sources; `frac_live` is this run's
         try:
             import csv
             pdir = os.path.join(ROOT, "profiles")
@@ -432,28 +452,30 @@ def main():
             under = sorted(f for f in os.listdir(pdir) if f.endswith("_bench_under_rocprof.json"))
             if stats and under and (N, E) == (N_POSES, N_EDGES) and world == 1:
                 rows = [r for r in csv.reader(l for l in open(os.path.join(pdir, stats[-1])) if not l.startswith("#"))]
-                row = next((r for r in rows[1:] if dom in r[0] and ("[cg]" in r[0] or not uni)), None)
+                row = next((r for r in rows[1:] if dom in r[0] and (resident or "[cg]" in r[0] or not uni)), None)
                 ub = json.loads(open(os.path.join(pdir, under[-1])).read().strip().splitlines()[-1])
                 if row is not None:
                     avg_us, med_us = float(row[3]), float(row[4])
                     same = ub.get("kernel_source_sha256_16") == sha
+                    bytes_per_launch = roofline["algorithmic_bytes_per_launch"]
                     roofline["rocprof_check"] = {
                         "csv": "profiles/" + stats[-1], "row": row[0][-40:], "dispatches": int(row[1]),
                         "rocprof_avg_us": avg_us, "rocprof_median_us": med_us,
-                        "frac_from_rocprof_avg": round(b_dom / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                        "frac_from_rocprof_avg": round(bytes_per_launch / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         "cg_iteration_us_under_rocprof": ub["roofline"]["cg_iteration_us_in_situ"],
                         "same_kernel_sources": same,
-                        "note": "rocprofv3 --kernel-trace of this command, the one symbol split by operation (tools/rocprof_summary.py); rocprofv3 "
-                                "times the kernel alone, avg_launch_us above includes the boundary to the next launch"}
+                        "note": "rocprofv3 --kernel-trace of this command (tools/rocprof_summary.py); the profiled command runs other launches of the same symbol too "
+                                "(untimed warm-up, the 6x6-block run), so its average launch is not exactly the timed region's"}
                     if same:
                         roofline["frac"] = roofline["rocprof_check"]["frac_from_rocprof_avg"]
-                        roofline["achieved"] = round(b_dom / (avg_us * 1e-6) / 1e9, 1)
-                        roofline["frac_is"] = "algorithmic bytes / the committed rocprofv3 average of the CG dispatches (profiles/%s)" % stats[-1]
+                        roofline["achieved"] = round(bytes_per_launch / (avg_us * 1e-6) / 1e9, 1)
+                        roofline["frac_is"] = "algorithmic bytes per launch / the committed rocprofv3 average launch of the dominant kernel (profiles/%s)" % stats[-1]
         except Exception as ex:  # noqa: BLE001
             extra["rocprof_check_error"] = str(ex)
         if breakdown is not None:
             extra["lm_step_breakdown"] = breakdown
-        extra["stream"] = ("fused universal stream (k_uni_f: one kernel symbol, one launch per PCG iteration, pipelined recurrences)" if fused else
+        extra["stream"] = ("resident universal stream (HEAD | the whole PCG in one launch, grid barrier per iteration | TAIL | LIN: four kernels in a fixed cycle)" if resident else
+                           "fused universal stream (k_uni_f: one kernel symbol, one launch per PCG iteration, pipelined recurrences)" if fused else
                            "two-kernel universal stream (k_uni_v / k_uni_s, standard CG)" if uni else "host-driven batches")
         ach_lin = b_lin / (t_lin * 1e-3) / 1e9
         ach_eval = b_eval / (t_eval * 1e-3) / 1e9

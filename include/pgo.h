@@ -283,6 +283,8 @@ PGO_API int pgo_solver_end(pgo_problem* problem, pgo_solver_summary* summary, pg
  * stopped or paused), 1 head (accept-finish, damping, Jacobi blocks, CG start), 2 first product, 3 CG iteration (or, once the CG
  * has stopped, the step tail's A x), 4 step tail + decision, 5 linearisation.  host[0] = launches the host enqueued, host[1] =
  * seconds it spent inside the launch calls since the trace started.  Returns the number of records or a negative status. */
+/* which CG form the stepping session runs (the value Summary::cg_form will carry), or a negative status without a session */
+PGO_API int pgo_solver_cg_form(pgo_problem* problem);
 PGO_API int pgo_solver_trace_start(pgo_problem* problem, int max_launches);
 PGO_API int pgo_solver_trace_read(pgo_problem* problem, long long* records, int capacity, double host[2]);
 /* repeats one kernel of the path `repeats` times on the solver stream between two HIP events and

@@ -160,6 +160,11 @@ int pgo_plus(pgo_problem* P, const double* delta) {
   return download_poses(P, P->g.pose_c);
 }
 
+int pgo_solver_cg_form(pgo_problem* P) {
+  if (!P || !P->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_cg_form needs a stepping session (call pgo_solver_begin first)");
+  return P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : (P->uni_resident ? 4 : P->uni_fused ? 3 : 0);
+}
+
 static const int TRACE_WORDS = 66;     // pgo_uni_fused.h UNI_F_TRACE_WORDS
 int pgo_solver_trace_start(pgo_problem* P, int max_launches) {
   if (!P || max_launches < 0) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_solver_trace_start");
@@ -310,7 +315,13 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     (void)hipEventDestroy(b);
     P->uni_enq = 0;
     P->pipe_dirty = true;        // the device state (CG counters, operation words) is re-uploaded before the next LM step
-    *avg_ms = total / repeats / pairs;
+    int its = pairs;
+    if (P->uni_resident) {       // the one launch ran until its own breakdown test or the iteration limit: divide by what it did
+      pgo::CgState cs;
+      HIP_TRY(hipMemcpy(&cs, P->d_cg.p, sizeof cs, hipMemcpyDeviceToHost));
+      its = std::max(1, cs.iters);
+    }
+    *avg_ms = total / repeats / its;
     return PGO_OK;
   }
   if (k == "pcg_graph") {

@@ -79,7 +79,7 @@ def test_fused_and_two_kernel_streams_agree(gpu, ds, loss, monkeypatch):
 def test_requests_the_fused_stream_does_not_serve_keep_the_two_kernel_stream(gpu, ds, monkeypatch):
     monkeypatch.setenv("PGO_BLOCK", "256")
     g = ds.manhattan_se3(1000, 4000, seed=3)
-    assert _solve(gpu, g, 0, pcg_cluster_poses=2)[0].cg_form == 3            # the library's choice where it applies ...
+    assert _solve(gpu, g, 0, pcg_cluster_poses=2)[0].cg_form == 4            # the library's choice where it applies: a one-launch form (the resident one: tests/test_gpu_resident.py) ...
     assert _solve(gpu, g, 0, pcg_cluster_poses=2, eta=1e-3)[0].cg_form == 0  # ... which excludes tight forcing terms (long CG runs: Ceres' refreshed CG)
     assert _solve(gpu, g, 2, pcg_cluster_poses=2, eta=1e-3)[0].cg_form == 3  # unless asked for
     assert _solve(gpu, g, 1, pcg_cluster_poses=2)[0].cg_form == 0            # the caller asked for Ceres' recurrences

@@ -1,0 +1,128 @@
+"""-m gpu: the universal stream in its resident form (r05, csrc/pgo_uni_resident.h): the whole truncated CG of an LM iteration is ONE
+launch — blocks, Jacobi blocks and the row vectors stay in registers, the work-groups meet at a grid barrier once per iteration —
+inside a fixed cycle of four kernels (HEAD, CG, TAIL, LIN).  Same recurrences, fold order and stop rules as the fused stream
+(tests/test_gpu_fused.py); checked against the oracle's restatement of those recurrences, against the fused and the two-kernel
+streams, against itself (stepping, pauses, resets, repeatability), and for what happens when two sessions want the device's one
+resident slot."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ["iteration", "step_is_successful", "linear_solver_iterations", "cost", "cost_change", "gradient_max_norm",
+          "step_norm", "relative_decrease", "trust_region_radius"]
+
+
+def _solve(gpu, g, form, **kw):
+    prob, poses = gpu.problem_from_graph(g)
+    opt = dict(max_num_iterations=20, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_form=form)
+    opt.update(kw)
+    return gpu.solve(gpu.SolverOptions(**opt), prob), poses
+
+
+@pytest.mark.parametrize("info", ["diag", "identity"])
+@pytest.mark.parametrize("cluster", [1, 2])
+def test_resident_stream_matches_the_oracles_pipelined_cg(gpu, ds, O, info, cluster, monkeypatch):
+    monkeypatch.setenv("PGO_BLOCK", "256")
+    g = ds.manhattan_se3(1000, 4000, seed=3)
+    if info == "identity":
+        g = ds.PoseGraphData(g.poses, g.ia, g.ib, g.meas, None)
+    s, poses = _solve(gpu, g, 3, pcg_cluster_poses=cluster)
+    assert s.cg_form == 4                                     # the resident stream really ran
+    og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
+    op, osum, otr = O.solve(og, O.default_options(max_num_iterations=20, linear_solver=1, pcg_cluster=cluster, pcg_form=1))
+    assert len(s.iterations) == len(otr)
+    assert list(s.iterations["step_is_successful"]) == [int(x) for x in otr[:, 8]]
+    assert list(s.iterations["linear_solver_iterations"]) == [int(x) for x in otr[:, 7]]
+    assert np.allclose(s.iterations["cost"], otr[:, 1], rtol=1e-7)
+    assert s.final_cost == pytest.approx(osum.final_cost, rel=1e-7)
+    assert np.abs(poses - op).max() < 1e-5
+    assert max(s.iterations["linear_solver_iterations"]) > 20
+
+
+@pytest.mark.parametrize("loss", ["trivial", "huber"])
+def test_resident_fused_and_two_kernel_streams_agree(gpu, ds, loss, monkeypatch):
+    monkeypatch.setenv("PGO_BLOCK", "256")
+    g = ds.manhattan_se3(3001, 14000, seed=77, loop_radius=3.0)
+    res = {}
+    for form in (1, 2, 3):
+        prob, poses = gpu.problem_from_graph(g, loss={"trivial": gpu.TRIVIAL, "huber": gpu.HUBER}[loss], loss_a=1.0)
+        res[form] = (gpu.solve(gpu.SolverOptions(max_num_iterations=12, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2,
+                                                 pcg_form=form), prob), poses)
+    assert [res[f][0].cg_form for f in (1, 2, 3)] == [0, 3, 4]
+    for other in (1, 2):
+        a, b = res[other][0], res[3][0]
+        assert list(a.iterations["step_is_successful"]) == list(b.iterations["step_is_successful"])
+        assert list(a.iterations["linear_solver_iterations"]) == list(b.iterations["linear_solver_iterations"])
+        assert np.allclose(a.iterations["cost"], b.iterations["cost"], rtol=1e-8 if other == 1 else 1e-9)
+        assert np.abs(res[other][1] - res[3][1]).max() < 1e-6
+
+
+def test_resident_stepping_pauses_and_resets_equal_one_solve(gpu, ds, monkeypatch):
+    monkeypatch.setenv("PGO_BLOCK", "256")
+    g = ds.manhattan_se3(1500, 6000, seed=21)
+    opt = dict(max_num_iterations=40, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2)
+    ref, pref = _solve(gpu, g, 3, **opt)
+    assert ref.cg_form == 4
+    prob, poses = gpu.problem_from_graph(g)
+    prob.solver_begin(gpu.SolverOptions(pcg_form=3, **opt))
+    prob.solver_step(7)
+    prob.solver_reset()
+    done = False
+    for n in (1, 2, 1, 5, 3, 100):
+        if done:
+            break
+        ran, done = prob.solver_step(n)
+    s = prob.solver_end()
+    assert s.cg_form == 4 and done and len(s.iterations) == len(ref.iterations)
+    for f in FIELDS:
+        assert np.array_equal(s.iterations[f], ref.iterations[f]), f
+    assert s.final_cost == ref.final_cost and s.message == ref.message and np.array_equal(poses, pref)
+    again, pagain = _solve(gpu, g, 3, **opt)                              # run to run: the same bits
+    for f in FIELDS:
+        assert np.array_equal(again.iterations[f], ref.iterations[f]), f
+    assert np.array_equal(pagain, pref)
+
+
+def test_one_resident_session_per_device_the_next_one_takes_the_fused_stream(gpu, ds, monkeypatch):
+    """The resident CG needs its whole grid on the chip at once (grid barrier); two of them sharing a device cannot both count on that.
+    The second session that asks while the first holds the slot runs the fused stream — and both are right."""
+    monkeypatch.setenv("PGO_BLOCK", "256")
+    g = ds.manhattan_se3(1500, 6000, seed=21)
+    opt = gpu.SolverOptions(max_num_iterations=15, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_form=3)
+    a, pa = gpu.problem_from_graph(g)
+    b, pb = gpu.problem_from_graph(g)
+    a.solver_begin(opt)
+    b.solver_begin(opt)
+    for _ in range(5):                      # interleaved on their two streams
+        a.solver_step(3)
+        b.solver_step(3)
+    sa, sb = a.solver_end(), b.solver_end()
+    assert (sa.cg_form, sb.cg_form) == (4, 3)
+    assert list(sa.iterations["step_is_successful"]) == list(sb.iterations["step_is_successful"])
+    assert list(sa.iterations["linear_solver_iterations"]) == list(sb.iterations["linear_solver_iterations"])
+    assert np.allclose(sa.iterations["cost"], sb.iterations["cost"], rtol=1e-7)      # (rejected candidates behind long CG runs: 5e-9 measured)
+    c, pc = gpu.problem_from_graph(g)       # the slot is free again
+    assert gpu.solve(opt, c).cg_form == 4
+
+
+def test_resident_launch_trace_is_the_four_kernel_cycle(gpu, ds, monkeypatch):
+    monkeypatch.setenv("PGO_BLOCK", "256")
+    g = ds.manhattan_se3(1500, 6000, seed=21)
+    prob, poses = gpu.problem_from_graph(g)
+    prob.solver_begin(gpu.SolverOptions(max_num_iterations=100, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_form=3))
+    prob.trace_start(2000)
+    ran, done = prob.solver_step(10)
+    rec, host_launches, host_seconds = prob.trace_read()
+    s = prob.solver_end()
+    assert ran == 10 and s.cg_form == 4
+    ops = [int(o) for o in rec[:, 0]]
+    HEAD, CG, TAIL, LIN = 1, 3, 4, 5
+    for i, o in enumerate(ops):
+        assert o in (0, (HEAD, CG, TAIL, LIN)[i % 4]), (i, o)           # launch L plays role L % 4, or idles
+    assert ops.count(CG) == 10 and ops.count(TAIL) == 10 and ops.count(HEAD) == 11     # (the 11th head only finishes the last accepted step)
+    assert ops.count(LIN) == int(s.iterations["step_is_successful"][1:11].sum())
+    # phase word of a CG launch: the iteration count it ran is the record's
+    cg = rec[rec[:, 0] == CG]
+    assert [int((int(w) >> 48) & 0xffff) for w in cg[:, 3]] == [int(x) for x in s.iterations["linear_solver_iterations"][1:11]]
+    assert (rec[:, 2] >= rec[:, 1]).all() and host_launches >= len(ops)
