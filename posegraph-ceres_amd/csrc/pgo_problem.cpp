@@ -389,7 +389,7 @@ int prepare(pgo_problem* P) {
   HIP_TRY(P->d_part_f.zero(s));
   HIP_TRY(P->d_cg.alloc(1));
   HIP_TRY(P->d_cg.zero(s));
-  HIP_TRY(P->d_flags.alloc(704));     // [0..3] as pgo_kernels.h says, [4..12] the two-level ticket of the fused stream (k_uni_f), [64..703] the grid barrier of the resident CG (k_res_cg: a 128-byte line per word)
+  HIP_TRY(P->d_flags.alloc(2240));     // [0..3] as pgo_kernels.h says, [4..12] the two-level ticket of the fused stream (k_uni_f), [64..2239] the grid barrier of the resident CG (k_res_cg: a 128-byte line per word)
   HIP_TRY(P->d_flags.zero(s));
 
   pgo::DeviceGraph& g = P->g;

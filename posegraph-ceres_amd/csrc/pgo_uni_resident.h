@@ -13,7 +13,9 @@
 // Cross-work-group data (m, the partial sums, x at the end) moves through 8-byte device-scope atomics on both sides — write-through
 // stores, L1-bypassing loads — so no cache write-back or invalidate is needed around the barrier (a release + acquire fence pair is
 // 3.4 us; MI355X_MICROARCH.md, hand-off forms); the barrier itself is a two-level arrival counter (8 classes + 1) and a generation word
-// every work-group's lane 0 polls with relaxed loads.  A work-group that waits longer than ~2 s (a grid that is not fully resident — two
+// every work-group's lane 0 polls with relaxed loads (3.1 us; measured and dropped: no counters at all — every entry of the partial sums
+// tagged with the turn's number and the fold polling the tags: 392 work-groups polling 392 entries each cost 5.7 us per turn against
+// 3.1 + 1.8).  A work-group that waits longer than ~2 s (a grid that is not fully resident — two
 // such launches sharing the device — would wait forever) sets the abort word: everybody leaves, the CG reports "broke down" and the LM
 // loop treats it as a failed linear solve instead of hanging the device.  The host admits ONE resident session per device at a time
 // (pgo_lm.cpp) and only grids that fit the chip at two waves per SIMD.
@@ -28,24 +30,25 @@
 // RES_GEN + 32 c, abort at RES_ABORT.  Lines of their own: with the generation word next to the counters, 392 polling lanes kept the
 // arrival atomics of the slower work-groups queued behind their loads — 15 us per barrier.  The counters only ever grow (barrier
 // number b is complete when a class has seen in_class * b arrivals and the top word 8 * b): nothing is reset between two barriers.
-constexpr int RES_CLS = 64, RES_TOP = 320, RES_GEN = 352, RES_ABORT = 640, RES_FLAG_WORDS = 704;
+constexpr int RES_NCLS = 32;                          // arrival classes (work-group index % RES_NCLS): ~12 arrivals queue on a counter at C2, not 49
+constexpr int RES_CLS = 64, RES_GEN = RES_CLS + 32 * RES_NCLS, RES_ABORT = RES_GEN + 32 * RES_NCLS, RES_FLAG_WORDS = RES_ABORT + 32;
 
-// One lane per work-group calls it (after __syncthreads()); returns false if the barrier was aborted.  `gen` = the generation this
-// work-group has seen complete; every arrival targets gen + 1.
-__device__ __forceinline__ bool res_grid_barrier(const DeviceGraph& g, int wg, int n_wg, int& gen) {
+// Lanes 0..7 of a work-group call it together (after __syncthreads()); returns false if the barrier was aborted.  `gen` = the
+// generation this work-group has seen complete; every arrival targets gen + 1.  Lane 0 arrives at its class; the last arrival of a
+// class publishes the class's generation word; lane c polls the word of class c and the eight leave together when all have moved.
+__device__ __forceinline__ bool res_grid_barrier(const DeviceGraph& g, int wg, int n_wg, int& gen, int lane) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this work-group's write-through stores have left
   const int target = gen + 1;
-  const int cls = wg & 7;
-  const int in_class = (n_wg - cls + 7) >> 3;
-  if (atomicAdd(&g.flags[RES_CLS + 32 * cls], 1) + 1 == in_class * target) {
-    if (atomicAdd(&g.flags[RES_TOP], 1) + 1 == min(n_wg, 8) * target) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c) __hip_atomic_store(&g.flags[RES_GEN + 32 * c], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  if (lane == 0) {
+    const int cls = wg % RES_NCLS;
+    const int in_class = (n_wg - cls + RES_NCLS - 1) / RES_NCLS;
+    if (atomicAdd(&g.flags[RES_CLS + 32 * cls], 1) + 1 == in_class * target)
+      __hip_atomic_store(&g.flags[RES_GEN + 32 * cls], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  const int* word = &g.flags[RES_GEN + 32 * min(lane, min(n_wg, RES_NCLS) - 1)];
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   unsigned spins = 0;
-  while (__hip_atomic_load(&g.flags[RES_GEN + 32 * cls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0) {
+  while (__ballot(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0)) {
     __builtin_amdgcn_s_sleep(2);
     if ((++spins & 0x3ff) == 0) {
       if (__hip_atomic_load(&g.flags[RES_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
@@ -56,6 +59,14 @@ __device__ __forceinline__ bool res_grid_barrier(const DeviceGraph& g, int wg, i
   return true;
 }
 
+// 16 bytes per request, past the CU's L1 like res_ld (raw buffer load with sc1): what was written before a grid barrier and is read
+// behind it needs no single-copy atomicity, and the texture addresser works per request — the gather of a slot's six entries of m is
+// three requests instead of six, a partial-sum entry two instead of three.
+typedef unsigned int res_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t res_buf(const double* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, 0x7fffffff, 0x00020000); }
+__device__ __forceinline__ double2 res_ld2(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
 __device__ __forceinline__ double res_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void res_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -178,27 +189,31 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
   }
   const int kc = tid % 6;
   double* lds_w = lds + (size_t)SPMV_LDS_STRIDE * B;
+  const double* const pbuf0 = g.pipe_buf[0];        // (both in registers: an index that changes per turn would re-load the pointer from the kernel arguments — a round trip in front of every gather)
+  const double* const pbuf1 = g.pipe_buf[1];
   int cur = rp;                                      // exchange buffer / partial-sum row this iteration READS (HEAD wrote u0 into pipe_buf[rp])
   int gen = 0;
-  if (tid == 0) gen = __hip_atomic_load(&g.flags[RES_GEN + 32 * (wg & 7)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (nobody moves it before everybody has arrived once)
+  if (tid < RES_NCLS) gen = __hip_atomic_load(&g.flags[RES_GEN + 32 * (wg % RES_NCLS)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (nobody moves it before everybody has arrived once)
   int cnt = 0, stop = 0, status = 0;
   double alpha = 0.0, beta = 0.0, gamma_prev = 0.0, alpha_prev = 0.0, q_prev = 0.0;
   bool ok = true;
   const bool traced = wg == 0 && tid == 0 && uni_f_traced(g, launch);
   long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;      // (trace: ticks work-group 0 spent up to the publish / in the barrier / in the fold, summed over the iterations)
+  // The operand of a turn's product (the slot's six entries of m, and the row lane's own entry) is asked for as soon as the
+  // barrier of the turn before has been passed, TOGETHER with the partial sums of the fold: one round trip to L2, not two.
+  double x[6] = {0, 0, 0, 0, 0, 0};
+  double mine_m = 0.0;
+  const unsigned col_off = 48u * (unsigned)max(col, 0);
+  if (col >= 0) {
+    const __amdgpu_buffer_rsrc_t mb = res_buf(cur ? pbuf1 : pbuf0);
+    const double2 a = res_ld2(mb, col_off), b = res_ld2(mb, col_off + 16), c = res_ld2(mb, col_off + 32);
+    x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y; x[4] = c.x; x[5] = c.y;
+  }
   for (int it = 0;; ++it) {
     // ---- n = A m over this work-group's slots (it == 0: w0 = A u0) ----
     const long long tp0 = traced ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
     double y[6] = {0, 0, 0, 0, 0, 0};
-    double mine_m = 0.0;
-    if (own && it > 0) mine_m = res_ld(g.pipe_buf[cur] + gi);
-    if (col >= 0) {
-      const double* ms = g.pipe_buf[cur] + 6 * (size_t)col;
-      double x[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) x[k] = res_ld(ms + k);
-      slot_block_times<PACKED, NPAIR>(blk, side, x, y);
-    }
+    if (col >= 0) slot_block_times<PACKED, NPAIR>(blk, side, x, y);
 #pragma unroll
     for (int k = 0; k < 6; ++k) lds[tid * SPMV_LDS_STRIDE + k] = y[k];
     __syncthreads();
@@ -231,28 +246,39 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
       double mn = 0.0;
 #pragma unroll
       for (int k = 0; k < DIM / 2; ++k) mn += mi[k].x * wv[2 * k] + mi[k].y * wv[2 * k + 1];
-      res_st(g.pipe_buf[cur ^ 1] + gi, mn);
+      res_st(const_cast<double*>(cur ? pbuf0 : pbuf1) + gi, mn);
     }
     block_sum<3>(acc, scratch);
     if (tid == 0) {
       double* pf = g.part_f + ((size_t)(cur ^ 1) * g.n_part + wg) * 4;
       res_st(pf, acc[0]); res_st(pf + 1, acc[1]); res_st(pf + 2, acc[2]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY lane: its store of m (and lane 0's partial sums) has left — ONE wait for both, the acknowledgements overlap —
+    __syncthreads();                                       // ... before the arrival below says so
+    if (tid < RES_NCLS) {
       const long long tp1 = traced ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-      sh_ok = res_grid_barrier(g, wg, g.n_wg, gen) ? 1 : 0;
+      const bool passed = res_grid_barrier(g, wg, g.n_wg, gen, tid);
+      if (tid == 0) sh_ok = passed ? 1 : 0;
       if (traced) { const long long tp2 = (long long)__builtin_amdgcn_s_memrealtime(); ph0 += tp1 - tp0; ph1 += tp2 - tp1; ph3 = tp2; }
     }
     __syncthreads();
     if (!sh_ok) { ok = false; break; }
     cur ^= 1;
+    if (own) mine_m = res_ld((cur ? pbuf1 : pbuf0) + gi);
+    if (col >= 0) {
+      const __amdgpu_buffer_rsrc_t mb = res_buf(cur ? pbuf1 : pbuf0);
+      const double2 a = res_ld2(mb, col_off), b = res_ld2(mb, col_off + 16), c = res_ld2(mb, col_off + 32);
+      x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y; x[4] = c.x; x[5] = c.y;
+    }
     // ---- fold the partial sums (every work-group alike, the fused stream's order), then its stop test / alpha / beta ----
     double f3[3] = {0.0, 0.0, 0.0};
     {
-      const double* pf = g.part_f + (size_t)cur * 4 * g.n_part;
+      const __amdgpu_buffer_rsrc_t pf = res_buf(g.part_f + (size_t)cur * 4 * g.n_part);
       for (int k = 0; k * B < g.n_wg; ++k) {          // (the fused stream's order: entry tid + k B in turn k; it adds 0 x entry for the lanes past the end)
         const int i = min(tid + k * B, g.n_wg - 1);
         const double wgt = tid + k * B < g.n_wg ? 1.0 : 0.0;
-        const double a0 = res_ld(pf + 4 * (size_t)i), a1 = res_ld(pf + 4 * (size_t)i + 1), a2 = res_ld(pf + 4 * (size_t)i + 2);
-        f3[0] += wgt * a0; f3[1] += wgt * a1; f3[2] += wgt * a2;
+        const double2 a01 = res_ld2(pf, 32u * (unsigned)i), a2 = res_ld2(pf, 32u * (unsigned)i + 16);
+        f3[0] += wgt * a01.x; f3[1] += wgt * a01.y; f3[2] += wgt * a2.x;
       }
     }
     block_sum<3>(f3, scratch);
@@ -280,9 +306,13 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
   if (!ok) { status = 2; }
   // ---- the CG has stopped after `cnt` iterations: x to everybody, then q = A x and the candidates for the step tail ----
   if (own) res_st(g.cg_x + gi, vx);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (ok) {
-    if (tid == 0) sh_ok = res_grid_barrier(g, wg, g.n_wg, gen) ? 1 : 0;
+    if (tid < RES_NCLS) {
+      const bool passed = res_grid_barrier(g, wg, g.n_wg, gen, tid);
+      if (tid == 0) sh_ok = passed ? 1 : 0;
+    }
     __syncthreads();
     if (!sh_ok) { ok = false; status = 2; }
   }

@@ -4,10 +4,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import pgo_loader
 gpu = pgo_loader.load(); ds = pgo_loader.datasets()
+if os.environ.get("PGO_AB_LIB"): gpu.LIB_PATH = os.environ["PGO_AB_LIB"]      # development: trace another build of the library
 c2 = ds.manhattan_se3(10000, 40000)
 prob, poses = gpu.problem_from_graph(c2)
 prob.solver_begin(gpu.SolverOptions(max_num_iterations=1000, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_form=3))
-prob.solver_step(5); prob.solver_reset(); prob.solver_step(5)
+prob.solver_step(5)
+ts = []
+for rep in range(5):
+    prob.solver_reset(); prob.solver_step(5)
+    t = time.perf_counter(); ran, done = prob.solver_step(20); ts.append((time.perf_counter() - t) / max(ran, 1))
+print("untraced %.4f ms per LM step (median of 5 x 20 steps)" % (1e3 * float(np.median(ts))))
+prob.solver_reset(); prob.solver_step(5)
 prob.trace_start(4000)
 t = time.perf_counter(); ran, done = prob.solver_step(20); wall = time.perf_counter() - t
 rec, hl, hs = prob.trace_read()
