@@ -426,7 +426,9 @@ def main():
                                "k_uni_s, CG mode (the universal stream's slot kernel: PCG block SpMV, FP64 6x6 BSR)" if uni else "k_spmv<0> (PCG block SpMV, FP64 6x6 BSR)"),
                     "rocprof_kernel_name": dom, "bound": "hbm",
                     "regime": "launch/latency-bound at this size: the 26 MB working set lives in registers / the 256 MiB Infinity Cache and an iteration is a chain of "
-                              "dependent round trips and a grid barrier (SURVEY 8d: quote HBM fractions at C4 size: `at_c4_size` below)",
+                              "dependent round trips and a grid barrier (SURVEY 8d: quote HBM fractions at C4 size: `at_c4_size` below).  The algorithmic bytes are what "
+                              "an iteration has to touch (blocks, vectors, Jacobi blocks); the resident kernel holds them in registers, so `traffic` (what really "
+                              "crossed the HBM interface per launch) may be BELOW them: `achieved` is an equivalent rate, not a transfer rate",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "frac_live": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_cg_iteration": b_dom,
@@ -452,23 +454,31 @@ def main():
             under = sorted(f for f in os.listdir(pdir) if f.endswith("_bench_under_rocprof.json"))
             if stats and under and (N, E) == (N_POSES, N_EDGES) and world == 1:
                 rows = [r for r in csv.reader(l for l in open(os.path.join(pdir, stats[-1])) if not l.startswith("#"))]
-                row = next((r for r in rows[1:] if dom in r[0] and (resident or "[cg]" in r[0] or not uni)), None)
+                row = next((r for r in rows[1:] if dom in r[0] and ("[cg]" in r[0] or not uni)), None)
                 ub = json.loads(open(os.path.join(pdir, under[-1])).read().strip().splitlines()[-1])
                 if row is not None:
                     avg_us, med_us = float(row[3]), float(row[4])
                     same = ub.get("kernel_source_sha256_16") == sha
-                    bytes_per_launch = roofline["algorithmic_bytes_per_launch"]
+                    # (resident stream: a launch runs a whole CG — price the profiled launches with the iterations per launch of the profiled run)
+                    its_rp = ub["roofline"].get("cg_iterations_per_launch", 1) if resident else 1
+                    bytes_per_launch = int(b_dom * its_rp)
                     roofline["rocprof_check"] = {
                         "csv": "profiles/" + stats[-1], "row": row[0][-40:], "dispatches": int(row[1]),
                         "rocprof_avg_us": avg_us, "rocprof_median_us": med_us,
+                        "cg_iterations_per_launch_of_the_profiled_run": its_rp, "algorithmic_bytes_per_launch": bytes_per_launch,
                         "frac_from_rocprof_avg": round(bytes_per_launch / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         "cg_iteration_us_under_rocprof": ub["roofline"]["cg_iteration_us_in_situ"],
                         "same_kernel_sources": same,
-                        "note": "rocprofv3 --kernel-trace of this command (tools/rocprof_summary.py); the profiled command runs other launches of the same symbol too "
-                                "(untimed warm-up, the 6x6-block run), so its average launch is not exactly the timed region's"}
+                        "note": "rocprofv3 --kernel-trace of this command (tools/rocprof_summary.py splits the dispatches of a symbol by what each launch did); the profiled "
+                                "command runs other launches of the same symbol too (untimed warm-up), so its average launch is not exactly the timed region's"}
                     if same:
+                        roofline["live"] = {k: roofline[k] for k in ("achieved", "frac", "algorithmic_bytes_per_launch", "cg_iterations_per_launch", "avg_launch_us", "avg_launch_us_is")}
                         roofline["frac"] = roofline["rocprof_check"]["frac_from_rocprof_avg"]
                         roofline["achieved"] = round(bytes_per_launch / (avg_us * 1e-6) / 1e9, 1)
+                        roofline["algorithmic_bytes_per_launch"] = bytes_per_launch
+                        roofline["cg_iterations_per_launch"] = its_rp
+                        roofline["avg_launch_us"] = avg_us
+                        roofline["avg_launch_us_is"] = "rocprofv3 average of the dominant kernel's CG dispatches (profiles/%s); this run's own figures under `live`" % stats[-1]
                         roofline["frac_is"] = "algorithmic bytes per launch / the committed rocprofv3 average launch of the dominant kernel (profiles/%s)" % stats[-1]
         except Exception as ex:  # noqa: BLE001
             extra["rocprof_check_error"] = str(ex)

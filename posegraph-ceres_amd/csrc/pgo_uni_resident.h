@@ -8,14 +8,20 @@
 // product gathers by column, and three partial sums per work-group.  So: load the blocks once, then per iteration
 //     gather m (6 doubles per slot)  ->  n = A m (LDS row sums)  ->  the pipelined recurrences on the row lanes' registers  ->
 //     m_new = M^-1 w from LDS  ->  publish m_new + {(r,u), (w,u), x'(b + r)}  ->  GRID BARRIER  ->  fold the partial sums, stop / alpha / beta.
-// Same recurrences, same fold order, same stop rules as k_uni_f: the iterates are the fused stream's bit for bit (tests/test_gpu_resident.py).
+// Same recurrences, same fold order, same stop rules as k_uni_f: same decisions and CG counts, costs to ~1e-9 of the fused stream's (the
+// compiler contracts the two bodies' multiply-adds differently; tests/test_gpu_resident.py), and both are held to the oracle's pipelined CG.
 //
-// Cross-work-group data (m, the partial sums, x at the end) moves through 8-byte device-scope atomics on both sides — write-through
-// stores, L1-bypassing loads — so no cache write-back or invalidate is needed around the barrier (a release + acquire fence pair is
-// 3.4 us; MI355X_MICROARCH.md, hand-off forms); the barrier itself is a two-level arrival counter (8 classes + 1) and a generation word
-// every work-group's lane 0 polls with relaxed loads (3.1 us; measured and dropped: no counters at all — every entry of the partial sums
-// tagged with the turn's number and the fold polling the tags: 392 work-groups polling 392 entries each cost 5.7 us per turn against
-// 3.1 + 1.8).  A work-group that waits longer than ~2 s (a grid that is not fully resident — two
+// Cross-work-group data (m, the partial sums, x at the end) moves through write-through stores (8-byte device-scope atomics) and
+// L1-bypassing loads (sc1: 8-byte atomics, or 16-byte raw buffer loads where a lane wants neighbours — the texture addresser works per
+// request, 3 + 2 x 2 requests per lane and turn instead of 6 + 2 x 3 took 0.5 us off a turn), so no cache write-back or invalidate is
+// needed around the barrier (a release + acquire fence pair is 3.4 us; MI355X_MICROARCH.md, hand-off forms).  The barrier is one level of
+// arrival counters (RES_NCLS classes) whose last arrival publishes the class's generation word; lanes 0..RES_NCLS-1 of every work-group
+// poll one class word each with relaxed loads and leave together (2.6 us per turn as work-group 0 sees it, which includes waiting for the
+// slowest work-group).  Measured and dropped: a second counter level + one generation word per class written by the last arrival of all
+// (3.1 us); no counters at all — every entry of the partial sums tagged with the turn's number and the fold polling the tags (392
+// work-groups polling 392 entries each: 5.7 us per turn against 2.6 + 1.9).  What a turn costs is round trips to L2, so they are merged:
+// the operand of the next product is requested together with the fold's partial sums, and the acknowledgements of the m store and of
+// the partial-sum store are waited for once.  A work-group that waits longer than ~2 s (a grid that is not fully resident — two
 // such launches sharing the device — would wait forever) sets the abort word: everybody leaves, the CG reports "broke down" and the LM
 // loop treats it as a failed linear solve instead of hanging the device.  The host admits ONE resident session per device at a time
 // (pgo_lm.cpp) and only grids that fit the chip at two waves per SIMD.
@@ -26,16 +32,16 @@
 // by launch parity exactly as in the fused stream; the host enqueues whole cycles ahead of the device's launch counter.
 
 // barrier words in g.flags (zeroed whenever the device state is uploaded), each on a 128-byte line of its own (32 ints): arrivals of
-// class c (work-group index % 8) at RES_CLS + 32 c, classes complete at RES_TOP, generation = barriers completed as seen by class c at
-// RES_GEN + 32 c, abort at RES_ABORT.  Lines of their own: with the generation word next to the counters, 392 polling lanes kept the
-// arrival atomics of the slower work-groups queued behind their loads — 15 us per barrier.  The counters only ever grow (barrier
-// number b is complete when a class has seen in_class * b arrivals and the top word 8 * b): nothing is reset between two barriers.
+// class c (work-group index % RES_NCLS) at RES_CLS + 32 c, generation = barriers class c has completed at RES_GEN + 32 c, abort at
+// RES_ABORT.  Lines of their own: with a polled word next to the counters, 392 polling lanes kept the arrival atomics of the slower
+// work-groups queued behind their loads — 15 us per barrier.  The counters only ever grow (barrier number b is complete for a class
+// when it has seen in_class * b arrivals): nothing is reset between two barriers.
 constexpr int RES_NCLS = 32;                          // arrival classes (work-group index % RES_NCLS): ~12 arrivals queue on a counter at C2, not 49
 constexpr int RES_CLS = 64, RES_GEN = RES_CLS + 32 * RES_NCLS, RES_ABORT = RES_GEN + 32 * RES_NCLS, RES_FLAG_WORDS = RES_ABORT + 32;
 
-// Lanes 0..7 of a work-group call it together (after __syncthreads()); returns false if the barrier was aborted.  `gen` = the
+// Lanes 0..RES_NCLS-1 of a work-group call it together (after __syncthreads()); returns false if the barrier was aborted.  `gen` = the
 // generation this work-group has seen complete; every arrival targets gen + 1.  Lane 0 arrives at its class; the last arrival of a
-// class publishes the class's generation word; lane c polls the word of class c and the eight leave together when all have moved.
+// class publishes the class's generation word; lane c polls the word of class c and they leave together when all classes have moved.
 __device__ __forceinline__ bool res_grid_barrier(const DeviceGraph& g, int wg, int n_wg, int& gen, int lane) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this work-group's write-through stores have left
   const int target = gen + 1;
@@ -154,11 +160,8 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
   const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   const CgState::Fused st = g.cg->f[rp];
   if (wg == 0 && tid == 0) __hip_atomic_store(&g.scal->slots_done, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const bool mine = st.op == F_CG;
-  uni_f_trace_begin(g, launch, mine ? F_CG : 0, t_top);
-  if (!mine) { res_pass_on(g, st, wp); uni_f_trace_end(g, launch); return; }
-
-  // ---- what stays in registers for the whole CG: the slot's block, the row lane's vectors and its Jacobi-block row ----
+  // ---- what stays in registers for the whole CG: the slot's block, the row lane's vectors and its Jacobi-block row.  The slot's words
+  // and its block are asked for BEFORE the state word is looked at (an idle launch of this role — a stopped stream — reads them in vain) ----
   const int s_begin = wg * B;
   const int r0 = g.wg_row_begin[wg], nrows = g.wg_row_begin[wg + 1] - r0;
   const int t = s_begin + tid;
@@ -171,6 +174,9 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) blk[k] = bp[(size_t)k * 64];
   }
+  const bool mine = st.op == F_CG;
+  uni_f_trace_begin(g, launch, mine ? F_CG : 0, t_top);
+  if (!mine) { res_pass_on(g, st, wp); uni_f_trace_end(g, launch); return; }
   const int nown = nrows * 6;                        // <= B (res_supported)
   const bool own = tid < nown;
   const size_t gi = 6 * (size_t)r0 + tid;
@@ -247,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
 #pragma unroll
       for (int k = 0; k < DIM / 2; ++k) mn += mi[k].x * wv[2 * k] + mi[k].y * wv[2 * k + 1];
       res_st(const_cast<double*>(cur ? pbuf0 : pbuf1) + gi, mn);
+      res_st(g.cg_x + gi, vx);        // x of this turn too: if the fold behind the barrier says "stop", it is already everybody's to read
     }
     block_sum<3>(acc, scratch);
     if (tid == 0) {
@@ -304,18 +311,8 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
     cnt = it + 1;              // the update the next turn of the loop applies is iteration `cnt`
   }
   if (!ok) { status = 2; }
-  // ---- the CG has stopped after `cnt` iterations: x to everybody, then q = A x and the candidates for the step tail ----
-  if (own) res_st(g.cg_x + gi, vx);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (ok) {
-    if (tid < RES_NCLS) {
-      const bool passed = res_grid_barrier(g, wg, g.n_wg, gen, tid);
-      if (tid == 0) sh_ok = passed ? 1 : 0;
-    }
-    __syncthreads();
-    if (!sh_ok) { ok = false; status = 2; }
-  }
+  // ---- the CG has stopped after `cnt` iterations (every work-group alike, behind the same barrier: the x every row lane stored in front
+  // of it is the final one): q = A x and the candidates for the step tail ----
   if (wg == 0 && tid == 0) {
     if (st.mirror) lm_mirror(g);
     g.cg->iters = cnt; g.cg->status = status; g.cg->done = 1;
@@ -326,9 +323,11 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
   }
   double y[6] = {0, 0, 0, 0, 0, 0};
   if (col >= 0) {
-    double x[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) x[k] = res_ld(g.cg_x + 6 * (size_t)col + k);
+    {
+      const __amdgpu_buffer_rsrc_t xb = res_buf(g.cg_x);
+      const double2 a = res_ld2(xb, col_off), b = res_ld2(xb, col_off + 16), c = res_ld2(xb, col_off + 32);
+      x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y; x[4] = c.x; x[5] = c.y;
+    }
     if (side == SIDE_DIAG) {
       const PoseRec P = load_pose(g.pose_x, row);
       const uint8_t cm = g.cmask[row];

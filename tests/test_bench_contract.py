@@ -22,7 +22,10 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
+    if "k_res_cg" in r["kernel"]:       # the resident CG holds the matrix in registers: a launch of ~15 iterations moves LESS than their algorithmic bytes
+        assert r["traffic"] is None or 0 < r["traffic"] < r["algorithmic_bytes_per_launch"]
+    else:
+        assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
     # achieved = algorithmic bytes / the kernel's launch duration
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) / r["achieved"] < 2e-3
     c = d["cpu_baseline"]
@@ -66,10 +69,12 @@ def test_quoted_traffic_and_kernel_statistics_exist_in_the_committed_profiles():
     r = d["roofline"]
     if r["traffic"] is not None:
         pm = json.load(open(os.path.join(ROOT, "profiles", TAG + "_pmc.json")))
-        assert pm["kernels"]["k_uni_s" if "k_uni_s" in r["kernel"] else "k_spmv<0>"]["hbm_bytes_per_launch_corrected"] == r["traffic"]
+        key = r.get("rocprof_kernel_name") if r.get("rocprof_kernel_name") in pm["kernels"] else ("k_uni_s" if "k_uni_s" in r["kernel"] else "k_spmv<0>")
+        assert pm["kernels"][key]["hbm_bytes_per_launch_corrected"] == r["traffic"]
         assert pm["kernel_source_sha256_16"] in d["traffic_source"]
     rows = list(csv.DictReader(l for l in open(os.path.join(ROOT, "profiles", TAG + "_bench_kernel_stats.csv")) if not l.startswith("#")))
     spmv = [x for x in rows if r.get("rocprof_kernel_name", "k_spmv<0") in x["kernel"]]
+    spmv = [x for x in spmv if "[cg]" in x["kernel"]] or spmv         # (one-symbol / fixed-cycle streams: the launches that ran a CG)
     assert spmv and float(spmv[0]["pct"]) > 30.0                      # the roofline kernel IS the dominant kernel of the timed command
     # the in-situ duration of the bench line and the rocprofv3 average of the same command agree within the profiler's overhead
     # (k_uni_s: one launch in ~20 is the linearisation, ~17 us, and the drain launches are short: the MEDIAN launch is a CG SpMV)

@@ -14,6 +14,8 @@ import sys
 OPS = {0: "nop", 1: "cg", 2: "refresh", 3: "linearize", 4: "tail"}
 # the fused stream (r05: k_uni_f, one kernel symbol for everything; its log entries carry 16 + operation)
 OPS_F = {16: "idle", 17: "head", 18: "w0", 19: "cg", 20: "tail", 21: "linearize"}
+# the resident stream (r05: k_res_v / k_res_cg / k_res_lin in a fixed cycle, each launch acting only if its operation is next; 32 + operation)
+OPS_R = {32: "idle", 33: "head", 35: "cg", 36: "tail", 37: "linearize"}
 
 
 def main(db, out, oplog=None):
@@ -25,7 +27,8 @@ def main(db, out, oplog=None):
     note = ""
     if oplog:
         entries = sorted(tuple(int(x) for x in line.split()) for line in open(oplog) if line.strip())
-        for sym, names, log in (("k_uni_s", OPS, [e for e in entries if e[1] < 16]), ("k_uni_f", OPS_F, [e for e in entries if 16 <= e[1] < 32])):
+        for sym, names, log in (("k_uni_s", OPS, [e for e in entries if e[1] < 16]), ("k_uni_f", OPS_F, [e for e in entries if 16 <= e[1] < 32]),
+                                ("k_res_", OPS_R, [e for e in entries if 32 <= e[1] < 48])):
             uni = [(n, r) for n, *r in rows if sym in n]
             if not uni and not log:
                 continue
