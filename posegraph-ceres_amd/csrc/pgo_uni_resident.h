@@ -215,14 +215,56 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
     const double2 a = res_ld2(mb, col_off), b = res_ld2(mb, col_off + 16), c = res_ld2(mb, col_off + 32);
     x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y; x[4] = c.x; x[5] = c.y;
   }
+  // A turn of the loop: [fold of the turn before, stop test / alpha / beta] + product -> LDS row sums -> recurrences -> Jacobi block ->
+  // publish -> grid barrier -> requests.  The two block-wide sums of a turn (the fold's and the row lanes' partial sums) share the
+  // barriers the product and the Jacobi block need anyway (wave sums into `scratch`, summed in wave order behind the barrier:
+  // block_sum's arithmetic exactly, four __syncthreads per turn instead of eight).
+  double f3[3] = {0.0, 0.0, 0.0};
+  const int lane = tid & 63, wave = tid >> 6, nw = (B + 63) >> 6;
   for (int it = 0;; ++it) {
-    // ---- n = A m over this work-group's slots (it == 0: w0 = A u0) ----
     const long long tp0 = traced ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    if (traced && it > 0) ph2 += tp0 - ph3;
+    if (it > 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double sw = wave_sum(f3[k]);
+        if (lane == 0) scratch[wave * 3 + k] = sw;
+      }
+    }
+    // ---- n = A m over this work-group's slots (it == 0: w0 = A u0) ----
     double y[6] = {0, 0, 0, 0, 0, 0};
     if (col >= 0) slot_block_times<PACKED, NPAIR>(blk, side, x, y);
 #pragma unroll
     for (int k = 0; k < 6; ++k) lds[tid * SPMV_LDS_STRIDE + k] = y[k];
     __syncthreads();
+    if (it > 0) {
+      // ---- the fold of the turn before (every work-group alike, the fused stream's order), its stop test / alpha / beta ----
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double sw = 0.0;
+        for (int w = 0; w < nw; ++w) sw += scratch[w * 3 + k];
+        f3[k] = sw;
+      }
+      const double gamma = f3[0], delta = f3[1], Q1 = -f3[2];
+      if (cnt > 0) {
+        const double zeta = cnt * (Q1 - q_prev) / Q1;
+        if (zeta < prm.q_tolerance && cnt >= prm.min_iterations) stop = 1;
+        if (cnt >= prm.max_iterations) stop = 1;
+      }
+      if (!stop && (gamma == 0.0 || !isfinite(gamma))) { stop = 1; status = (gamma == 0.0) ? 0 : 2; }
+      if (!stop && cnt > 0) {
+        beta = gamma / gamma_prev;
+        if (beta == 0.0 || !isfinite(beta)) { stop = 1; status = 2; }
+      }
+      if (!stop) {
+        const double den = cnt > 0 ? delta - beta * gamma / alpha_prev : delta;
+        if (!(den > 0.0) || !isfinite(den)) { stop = 1; status = 1; }     // "matrix is indefinite": x of the previous iteration stands
+        else alpha = gamma / den;
+      }
+      if (stop) break;           // (the product above was in vain; x as published in front of the last barrier is final)
+      gamma_prev = gamma; alpha_prev = alpha; q_prev = Q1;
+      cnt = it;                  // the update this turn applies is iteration `cnt`
+    }
     double acc[3] = {0.0, 0.0, 0.0};
     if (own) {
       double s0 = 0.0, s1 = 0.0;
@@ -246,6 +288,11 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
       lds_w[tid] = vw;
     }
     if (tid < 6) lds_w[nown + tid] = 0.0;       // the missing half of a last odd pair
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double sw = wave_sum(acc[k]);
+      if (lane == 0) scratch[12 + wave * 3 + k] = sw;
+    }
     __syncthreads();
     if (own) {
       const double* wv = lds_w + DIM * (tid / DIM);
@@ -255,10 +302,14 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
       res_st(const_cast<double*>(cur ? pbuf0 : pbuf1) + gi, mn);
       res_st(g.cg_x + gi, vx);        // x of this turn too: if the fold behind the barrier says "stop", it is already everybody's to read
     }
-    block_sum<3>(acc, scratch);
     if (tid == 0) {
       double* pf = g.part_f + ((size_t)(cur ^ 1) * g.n_part + wg) * 4;
-      res_st(pf, acc[0]); res_st(pf + 1, acc[1]); res_st(pf + 2, acc[2]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double sw = 0.0;
+        for (int w = 0; w < nw; ++w) sw += scratch[12 + w * 3 + k];
+        res_st(pf + k, sw);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY lane: its store of m (and lane 0's partial sums) has left — ONE wait for both, the acknowledgements overlap —
     __syncthreads();                                       // ... before the arrival below says so
@@ -270,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
     }
     __syncthreads();
     if (!sh_ok) { ok = false; break; }
+    // ---- behind the barrier: everything the next turn reads from other work-groups, in one round trip ----
     cur ^= 1;
     if (own) mine_m = res_ld((cur ? pbuf1 : pbuf0) + gi);
     if (col >= 0) {
@@ -277,8 +329,7 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
       const double2 a = res_ld2(mb, col_off), b = res_ld2(mb, col_off + 16), c = res_ld2(mb, col_off + 32);
       x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y; x[4] = c.x; x[5] = c.y;
     }
-    // ---- fold the partial sums (every work-group alike, the fused stream's order), then its stop test / alpha / beta ----
-    double f3[3] = {0.0, 0.0, 0.0};
+    f3[0] = f3[1] = f3[2] = 0.0;
     {
       const __amdgpu_buffer_rsrc_t pf = res_buf(g.part_f + (size_t)cur * 4 * g.n_part);
       for (int k = 0; k * B < g.n_wg; ++k) {          // (the fused stream's order: entry tid + k B in turn k; it adds 0 x entry for the lanes past the end)
@@ -288,27 +339,6 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
         f3[0] += wgt * a01.x; f3[1] += wgt * a01.y; f3[2] += wgt * a2.x;
       }
     }
-    block_sum<3>(f3, scratch);
-    if (traced) ph2 += (long long)__builtin_amdgcn_s_memrealtime() - ph3;
-    const double gamma = f3[0], delta = f3[1], Q1 = -f3[2];
-    if (cnt > 0) {
-      const double zeta = cnt * (Q1 - q_prev) / Q1;
-      if (zeta < prm.q_tolerance && cnt >= prm.min_iterations) stop = 1;
-      if (cnt >= prm.max_iterations) stop = 1;
-    }
-    if (!stop && (gamma == 0.0 || !isfinite(gamma))) { stop = 1; status = (gamma == 0.0) ? 0 : 2; }
-    if (!stop && cnt > 0) {
-      beta = gamma / gamma_prev;
-      if (beta == 0.0 || !isfinite(beta)) { stop = 1; status = 2; }
-    }
-    if (!stop) {
-      const double den = cnt > 0 ? delta - beta * gamma / alpha_prev : delta;
-      if (!(den > 0.0) || !isfinite(den)) { stop = 1; status = 1; }     // "matrix is indefinite": x of the previous iteration stands
-      else alpha = gamma / den;
-    }
-    if (stop) break;
-    gamma_prev = gamma; alpha_prev = alpha; q_prev = Q1;
-    cnt = it + 1;              // the update the next turn of the loop applies is iteration `cnt`
   }
   if (!ok) { status = 2; }
   // ---- the CG has stopped after `cnt` iterations (every work-group alike, behind the same barrier: the x every row lane stored in front

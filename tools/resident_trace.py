@@ -29,5 +29,5 @@ for op, nm in names.items():
 cg = rec[rec[:, 0] == 3]
 ph = np.array([[(int(w) >> (16 * k)) & 0xffff for k in range(4)] for w in cg[:, 3]], dtype=float)
 its = ph[:, 3] + 2          # barriers per launch: w0 + iterations ... (cnt + 1 turns of the loop)
-print("  cg launches: mean CG iterations %.1f; per turn of the loop (work-group 0): work+publish %.2f us, barrier %.2f us, fold %.2f us" % (
+print("  cg launches: mean CG iterations %.1f; per turn of the loop (work-group 0): fold + product + recurrences + publish %.2f us, grid barrier %.2f us, requests behind it %.2f us" % (
     ph[:, 3].mean(), (ph[:, 0] / (ph[:, 3] + 1)).mean() / 100, (ph[:, 1] / (ph[:, 3] + 1)).mean() / 100, (ph[:, 2] / (ph[:, 3] + 1)).mean() / 100))
