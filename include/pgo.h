@@ -272,13 +272,16 @@ PGO_API int pgo_solver_step(pgo_problem* problem, int n, int* executed, int* don
 PGO_API int pgo_solver_reset(pgo_problem* problem);
 PGO_API int pgo_solver_end(pgo_problem* problem, pgo_solver_summary* summary, pgo_iteration_record* records,
                    int records_capacity);
-/* ---- launch trace of a stepping session (profiling aid; PCG on one GPU in the fused universal stream, Summary::cg_form 3) ----
+/* ---- launch trace of a stepping session (profiling aid; PCG on one GPU in the fused or the resident universal stream,
+ * Summary::cg_form 3 / 4) ----
  * pgo_solver_trace_start (between pgo_solver_begin / pgo_solver_reset and the pgo_solver_step calls to be traced): from now on
  * every launch of the stream records what it did and when (device clock, 100 MHz ticks), up to max_launches launches; 0 stops
  * recording.  pgo_solver_trace_read (the stream is idle between pgo_solver_step calls): records[i] = {operation, start tick of
  * work-group 0, end tick of the last work-group to finish, phase stamps} of launch i since the trace started (4 words per
  * launch; phase stamps: four 16-bit tick counts from the top of ONE work-group — a CG launch: work-group 0's product done /
- * sums folded / rows updated / end; a step tail: the deciding work-group's loops done / last arrival known / partials folded /
+ * sums folded / rows updated / end, in the resident stream (one launch = the whole CG): ticks summed over the turns of its loop
+ * spent up to the arrival at the grid barrier / inside the barrier / behind it until the next turn starts, and the CG iteration
+ * count of the launch; a step tail: the deciding work-group's loops done / last arrival known / partials folded /
  * decided); operation: 0 nothing (stream
  * stopped or paused), 1 head (accept-finish, damping, Jacobi blocks, CG start), 2 first product, 3 CG iteration (or, once the CG
  * has stopped, the step tail's A x), 4 step tail + decision, 5 linearisation.  host[0] = launches the host enqueued, host[1] =
