@@ -363,6 +363,7 @@ struct pgo_problem {
   bool pipe_dirty = true;          // LmState was (re)initialised by the host: upload it before the next sequence
   bool universal = false;          // PCG on one rank: the universal stream (pgo_kernels.h UniOp) instead of allotted sequences
   int uni_enq = 0;                 // vector-shaped launches (fused form: launches) of the stream enqueued since the last upload
+  int resident_aborts = 0;         // times a resident session gave up at a grid barrier and went on with the fused stream (0 or 1 per session)
   bool uni_resident = false;       // ... in its resident form (pgo_uni_resident.h: four kernels in a fixed cycle, the whole CG of an LM iteration one launch with a
                                    //     grid barrier per iteration); uni_fused is set as well (same state words, same launch trace)
   bool resident_slot = false;      // this problem holds its device's one resident-session slot (pgo_lm.cpp)

@@ -115,6 +115,7 @@ struct LmScalars {
   int halt;                // mirror of LmDev::halt
   int last_cg;             // CG iterations of the last decided iteration (batch-length prediction)
   int slots_done;          // universal stream: vector-shaped launches completed
+  int resident_abort;      // resident stream: its grid barrier gave up (pgo_uni_resident.h); the host carries on with the fused stream
   LmDev lm;                // mirror of the device state, complete whenever seq_done == the last enqueued sequence
   LmRecord ring[LM_RING];  // iteration records, slot = record index % LM_RING
 };
@@ -317,6 +318,7 @@ bool uni_f_supported(const DeviceGraph& g, const CgParams& p, int cluster);
 // resident form (pgo_uni_resident.h): four kernel symbols in a fixed cycle, launch L plays role L % 4 (HEAD, whole CG, TAIL, LIN)
 void launch_uni_r(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s);
 bool uni_r_supported(const DeviceGraph& g, const CgParams& p, int cluster);
+int uni_r_abort_word();       // index of the resident stream's abort word in DeviceGraph::flags
 void launch_lm_budget(const DeviceGraph& g, int decisions, hipStream_t s, int next_launch = 0);
 void launch_lm_publish(const DeviceGraph& g, hipStream_t s);
 bool uni_supported(const DeviceGraph& g);

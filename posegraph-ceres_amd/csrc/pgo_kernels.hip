@@ -2678,6 +2678,7 @@ bool uni_f_supported(const DeviceGraph& g, const CgParams& p, int cluster) {
 bool uni_r_supported(const DeviceGraph& g, const CgParams& p, int cluster) {
   return uni_f_supported(g, p, cluster) && g.rows_fit && g.block >= 64 && (long long)g.n_wg * (g.block / 64) <= 8LL * 256;
 }
+int uni_r_abort_word() { return RES_ABORT; }
 void launch_uni_r(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s) {
   const int role = launch & 3;
   const dim3 grid(g.n_wg), blk(g.block);

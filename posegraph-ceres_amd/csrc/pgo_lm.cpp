@@ -133,6 +133,7 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   if (P->opt.pcg_form == 3 && !P->uni_resident) P->uni_fused = P->universal && pgo::uni_f_supported(P->g, cg_params_for(P->opt), P->g.cluster);
   if (P->uni_resident) P->uni_fused = true;
   P->uni_host_launches = 0; P->uni_host_enqueue_s = 0.0;
+  P->resident_aborts = 0;
   P->pipe_dirty = true;
   // symmetric tile form for the CG products: host-driven PCG of a large graph on one rank (pgo_sym.h)
   P->sym_active = false; P->sym_storage = false;
@@ -473,6 +474,11 @@ int lm_upload_state(pgo_problem* P) {
     HIP_TRY(P->d_flags.zero(P->stream));
     P->uni_enq = 0;
     P->scal->slots_done = 0;
+    P->scal->resident_abort = 0;
+    // (diagnostic, tests/test_gpu_resident.py: the abort word set by hand — the cycle's kernels find the barrier "given up" before the
+    // first CG and the session has to carry on with the fused stream, as it would behind a real time-out)
+    if (P->uni_resident && getenv("PGO_RESIDENT_ABORT_TEST"))
+      HIP_TRY(hipMemsetAsync(P->d_flags.p + pgo::uni_r_abort_word(), 1, sizeof(int), P->stream));
   }
   P->scal->lm = D;
   P->scal->lm_done = 0; P->scal->halt = 0; P->scal->last_cg = D.last_cg;
@@ -621,6 +627,15 @@ int lm_run_universal(pgo_problem* P, int budget, int* ran) {
   auto t_idle = Clock::now();
   for (;;) {
     if (__atomic_load_n(&P->scal->halt, __ATOMIC_ACQUIRE)) break;
+    if (P->uni_resident && __atomic_load_n(&P->scal->resident_abort, __ATOMIC_ACQUIRE)) {
+      // a grid barrier of the resident CG gave up (its grid was not all on the chip: somebody else's kernels hold CUs).  The device put
+      // the LM iteration back to its HEAD and the cycle's kernels only pass the state on from here: the rest of the session runs the
+      // fused stream, whose one symbol does whatever the state names at any launch number.
+      P->uni_resident = false;
+      resident_slot_release(P);
+      ++P->resident_aborts;
+      if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] resident CG gave up at a grid barrier (launch %d): continuing with the fused stream\n", P->uni_enq);
+    }
     const int pending = P->uni_enq - __atomic_load_n(&P->scal->slots_done, __ATOMIC_ACQUIRE);
     if (pending <= hi - lo) {
       const auto t_enq = Clock::now();

@@ -22,8 +22,8 @@
 // work-groups polling 392 entries each: 5.7 us per turn against 2.6 + 1.9).  What a turn costs is round trips to L2, so they are merged:
 // the operand of the next product is requested together with the fold's partial sums, and the acknowledgements of the m store and of
 // the partial-sum store are waited for once.  A work-group that waits longer than ~2 s (a grid that is not fully resident — two
-// such launches sharing the device — would wait forever) sets the abort word: everybody leaves, the CG reports "broke down" and the LM
-// loop treats it as a failed linear solve instead of hanging the device.  The host admits ONE resident session per device at a time
+// such launches sharing the device — would wait forever) sets the abort word: everybody leaves, the LM iteration goes back to its HEAD,
+// the host is told (LmScalars::resident_abort) and carries on with the fused stream's launches instead of hanging the device.  The host admits ONE resident session per device at a time
 // (pgo_lm.cpp) and only grids that fit the chip at two waves per SIMD.
 //
 // The stream: four kernel symbols in a fixed cycle, launch L plays role L % 4 —
@@ -76,6 +76,13 @@ __device__ __forceinline__ double2 res_ld2(__amdgpu_buffer_rsrc_t r, unsigned by
 __device__ __forceinline__ double res_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void res_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// The abort word, read at the top of every launch of the cycle: once a grid barrier has given up, the kernels of the cycle only hand the
+// state on — the work-group that gave up has put the LM iteration back to its HEAD and told the host (LmScalars::resident_abort), which
+// carries on with the fused stream's launches (k_uni_f does whatever operation the state names, whatever the launch number).
+__device__ __forceinline__ bool res_aborted(const DeviceGraph& g) {
+  return __hip_atomic_load(&g.flags[RES_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
 // what every kernel of the cycle does when its operation is not the next one (or the stream is stopped): hand the state on
 __device__ __forceinline__ void res_pass_on(const DeviceGraph& g, const CgState::Fused& st, int wp) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -84,6 +91,17 @@ __device__ __forceinline__ void res_pass_on(const DeviceGraph& g, const CgState:
     n.mirror = 0;
     g.cg->f[wp] = n;
   }
+}
+// A launch of the cycle that finds the abort word set (or the CG launch whose barrier just gave up): the state is handed on — an LM
+// iteration that was in its CG goes back to its HEAD (idempotent: same damping, same CG start; the fused stream's CG wants its own
+// first product) — and the host is told.  One lane calls it.
+__device__ __forceinline__ void res_when_aborted(const DeviceGraph& g, const CgState::Fused& st, int wp) {
+  if (st.mirror) lm_mirror(g);
+  CgState::Fused n = st;
+  n.mirror = 0;
+  if (st.op == F_CG) { n = CgState::Fused{}; n.op = F_HEAD; }
+  g.cg->f[wp] = n;
+  __hip_atomic_store(&g.scal->resident_abort, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- roles 0 and 2: HEAD and TAIL (the fused stream's operations, without its speculative requests) ----
@@ -101,9 +119,15 @@ __global__ __launch_bounds__(256) void k_res_v(DeviceGraph g, int launch, int ro
   const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   const CgState::Fused st = g.cg->f[rp];
   if (wg == 0 && tid == 0) __hip_atomic_store(&g.scal->slots_done, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const bool mine = st.op == role_op;
+  const bool aborted = res_aborted(g);
+  const bool mine = st.op == role_op && !aborted;
   uni_f_trace_begin(g, launch, mine ? role_op : 0, t_top);
-  if (!mine) { res_pass_on(g, st, wp); uni_f_trace_end(g, launch); return; }
+  if (!mine) {
+    if (!aborted) res_pass_on(g, st, wp);
+    else if (wg == 0 && tid == 0) res_when_aborted(g, st, wp);
+    uni_f_trace_end(g, launch);
+    return;
+  }
   if (role_op == F_HEAD) {
     [&]() {          // (the pasted block leaves by `return`)
 #define PGO_UNI_HEAD_BLOCK
@@ -130,10 +154,13 @@ __global__ __launch_bounds__(256) void k_res_lin(DeviceGraph g, int launch) {
   const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   const CgState::Fused st = g.cg->f[rp];
   if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&g.scal->slots_done, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const bool mine = st.op == F_LIN;
+  const bool aborted = res_aborted(g);
+  const bool mine = st.op == F_LIN && !aborted;
   uni_f_trace_begin(g, launch, mine ? F_LIN : 0, t_top);
-  if (!mine) res_pass_on(g, st, wp);
-  else {
+  if (!mine) {
+    if (!aborted) res_pass_on(g, st, wp);
+    else if (blockIdx.x == 0 && threadIdx.x == 0) res_when_aborted(g, st, wp);
+  } else {
     DeviceGraph gl = g;
     gl.pose_x = g.pose_c;          // the accepted candidate; the accept-finish part of the next HEAD copies it over
     linearize_body<INFO>(gl, lds);
@@ -174,9 +201,15 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) blk[k] = bp[(size_t)k * 64];
   }
-  const bool mine = st.op == F_CG;
+  const bool aborted = res_aborted(g);
+  const bool mine = st.op == F_CG && !aborted;
   uni_f_trace_begin(g, launch, mine ? F_CG : 0, t_top);
-  if (!mine) { res_pass_on(g, st, wp); uni_f_trace_end(g, launch); return; }
+  if (!mine) {
+    if (!aborted) res_pass_on(g, st, wp);
+    else if (wg == 0 && tid == 0) res_when_aborted(g, st, wp);
+    uni_f_trace_end(g, launch);
+    return;
+  }
   const int nown = nrows * 6;                        // <= B (res_supported)
   const bool own = tid < nown;
   const size_t gi = 6 * (size_t)r0 + tid;
@@ -340,7 +373,11 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
       }
     }
   }
-  if (!ok) { status = 2; }
+  if (!ok) {          // a barrier gave up (every work-group leaves the same way, sooner or later: the abort word)
+    if (wg == 0 && tid == 0) res_when_aborted(g, st, wp);
+    uni_f_trace_end(g, launch);
+    return;
+  }
   // ---- the CG has stopped after `cnt` iterations (every work-group alike, behind the same barrier: the x every row lane stored in front
   // of it is the final one): q = A x and the candidates for the step tail ----
   if (wg == 0 && tid == 0) {

@@ -126,3 +126,90 @@ def test_resident_launch_trace_is_the_four_kernel_cycle(gpu, ds, monkeypatch):
     cg = rec[rec[:, 0] == CG]
     assert [int((int(w) >> 48) & 0xffff) for w in cg[:, 3]] == [int(x) for x in s.iterations["linear_solver_iterations"][1:11]]
     assert (rec[:, 2] >= rec[:, 1]).all() and host_launches >= len(ops)
+
+
+def test_a_barrier_that_gave_up_hands_the_session_to_the_fused_stream(gpu, ds, monkeypatch):
+    """The abort word of the resident CG's grid barrier (set by a work-group that waited ~2 s: a grid that is not all on the chip) must
+    not cost the solve anything but time: the LM iteration that was in its CG goes back to its HEAD and the session carries on in the
+    fused stream.  PGO_RESIDENT_ABORT_TEST sets the word by hand before the first launch; the time-out itself is exercised by
+    test_two_processes_with_resident_sessions_on_one_gpu_both_finish."""
+    monkeypatch.setenv("PGO_BLOCK", "256")
+    g = ds.manhattan_se3(1500, 6000, seed=21)
+    ref, pref = _solve(gpu, g, 2, pcg_cluster_poses=2)
+    monkeypatch.setenv("PGO_RESIDENT_ABORT_TEST", "1")
+    prob, poses = gpu.problem_from_graph(g)
+    prob.solver_begin(gpu.SolverOptions(max_num_iterations=20, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_form=3))
+    assert prob.cg_form() == 4                      # it starts as a resident session ...
+    ran, done = prob.solver_step(7)
+    assert ran == 7 and prob.cg_form() == 3         # ... and is a fused one after the first launches found the word
+    prob.solver_step(1000)
+    s = prob.solver_end()
+    assert s.cg_form == 3 and len(s.iterations) == len(ref.iterations)
+    for f in FIELDS:                                # nothing was lost or repeated: the fused stream's records, bit for bit
+        assert np.array_equal(s.iterations[f], ref.iterations[f]), f
+    assert np.array_equal(poses, pref)
+    monkeypatch.delenv("PGO_RESIDENT_ABORT_TEST")
+    c, pc = gpu.problem_from_graph(g)               # the device's resident slot was given back
+    assert gpu.solve(gpu.SolverOptions(max_num_iterations=5, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_form=3), c).cg_form == 4
+
+
+_TWO_PROC_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, os.environ["PGO_ROOT"])
+import numpy as np
+import pgo_loader
+pkg = pgo_loader.load(); ds = pgo_loader.datasets()
+g = ds.manhattan_se3(10000, 40000)
+prob, poses = pkg.problem_from_graph(g)
+prob.solver_begin(pkg.SolverOptions(max_num_iterations=1000, linear_solver_type=pkg.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_form=3))
+first = prob.cg_form()
+open(os.environ["PGO_OUT"] + ".ready", "w").write("1")
+while not os.path.exists(os.environ["PGO_GO"]): time.sleep(0.001)
+t0 = time.time()
+for rep in range(20):
+    prob.solver_reset()
+    ran, done = prob.solver_step(60)
+s = prob.solver_end()
+np.savez(os.environ["PGO_OUT"], cost=s.iterations["cost"], ok=s.iterations["step_is_successful"], cg=s.iterations["linear_solver_iterations"],
+         first=first, last=s.cg_form, seconds=time.time() - t0, term=s.termination_type)
+'''
+
+
+def test_two_processes_with_resident_sessions_on_one_gpu_both_finish(gpu, ds, tmp_path):
+    """Two PROCESSES know nothing of each other's resident slot: both launch the one-launch CG (392 work-groups each at this size, the chip
+    holds 512) on the same GPU at the same time, so neither grid need be all on the chip and a barrier may wait for work-groups that cannot
+    start.  Whatever happens — both get through, or the 2 s watchdog of one or both gives up and the session carries on in the fused stream
+    — both solves end with the records of an undisturbed one (decisions and CG counts; costs to the streams' 1e-7)."""
+    import os, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = ds.manhattan_se3(10000, 40000)
+    prob, poses = gpu.problem_from_graph(g)
+    prob.solver_begin(gpu.SolverOptions(max_num_iterations=1000, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_form=3))
+    prob.solver_step(60)
+    ref = prob.solver_end()
+    del prob
+    script = tmp_path / "worker.py"
+    script.write_text(_TWO_PROC_WORKER)
+    go = str(tmp_path / "go")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, PGO_ROOT=root, PGO_OUT=str(tmp_path / ("out%d" % r)), PGO_GO=go))
+             for r in range(2)]
+    t0 = time.time()
+    try:
+        while not all(os.path.exists(str(tmp_path / ("out%d.ready" % r))) for r in range(2)):
+            assert time.time() - t0 < 240 and all(p.poll() is None for p in procs)
+            time.sleep(0.01)
+        open(go, "w").write("1")
+        for p in procs:
+            p.wait(timeout=max(1, 300 - (time.time() - t0)))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert [p.returncode for p in procs] == [0, 0]
+    for r in range(2):
+        k = np.load(str(tmp_path / ("out%d.npz" % r)))
+        assert int(k["first"]) == 4 and int(k["last"]) in (3, 4)
+        assert list(k["ok"]) == list(ref.iterations["step_is_successful"])
+        assert list(k["cg"]) == list(ref.iterations["linear_solver_iterations"])
+        assert np.allclose(k["cost"], ref.iterations["cost"], rtol=1e-7)
+        print("process %d: cg_form %d -> %d, %.2f s for 20 x 60 LM iterations" % (r, int(k["first"]), int(k["last"]), float(k["seconds"])))
