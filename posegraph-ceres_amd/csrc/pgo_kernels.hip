@@ -433,9 +433,12 @@ __global__ void k_damping(DeviceGraph g, double radius, double min_diag, double 
 // Gauss-Jordan (SPD, no pivoting).  One wave per cluster.  Row r of the inverse is what lane r of the
 // vector kernels reads (contiguous 6 CL doubles).
 // One wave: the clusters [cl_first, cl_first + 64 / (6 CL)) of this rank, as far as they lie below cl_end.
-template <int CL>
+// CGSTART (the HEAD operation of the one-launch streams): the wave also starts the CG for its rows — b = S g, x0 = 0, r0 = b and
+// u0 = M^-1 b straight from the registers the inverse sits in (lane j holds row j of it), written to cg_b / cg_x / cg_r / cg_u and to
+// `u_out` (the exchange buffer the next launch gathers from): no store -> barrier -> reload of the Jacobi block in between.
+template <int CL, bool CGSTART = false>
 __device__ __forceinline__ void cluster_precond_wave(const DeviceGraph& g, double radius, double min_diag, double max_diag, int mode,
-                                                     int cl_first, int cl_end, int lane) {
+                                                     int cl_first, int cl_end, int lane, double* u_out = nullptr) {
   // mode >= 0: this kernel also does k_damping's job for its poses (D^2, clamped diagonal, damped diagonal BSR slot) —
   // one launch fewer per LM iteration; mode < 0: k_damping ran before (several ranks: D^2 is needed for ALL rows).
   //
@@ -455,6 +458,10 @@ __device__ __forceinline__ void cluster_precond_wave(const DeviceGraph& g, doubl
   double a[DIM];
 #pragma unroll
   for (int i = 0; i < DIM; ++i) a[i] = (i == j) ? 1.0 : 0.0;   // poses past the end: identity
+  double bj = 0.0;
+  if constexpr (CGSTART) {
+    if (live && v < g.N) bj = g.scale[6 * (size_t)v + jc] * g.grad[6 * (size_t)v + jc];     // (requested in front of everything the inverse waits for)
+  }
   if (live && v < g.N) {
     // own diagonal block: rows of pose lp, column jc
 #pragma unroll
@@ -529,11 +536,26 @@ __device__ __forceinline__ void cluster_precond_wave(const DeviceGraph& g, doubl
       for (int i = 0; i < DIM; ++i) a[i] = (i == k) ? ip : colk[i] * -ip;
     }
   }
+  // Lane j holds COLUMN j of the inverse; it is stored as ROW j (16-byte stores, a lane's row contiguous): the inverse of a symmetric
+  // matrix is symmetric up to rounding, and every reader — the vector kernels' row lanes, the CG start below — applies the same stored rows.
   if (live) {
     if (!ok && j == 0) atomicOr(&g.flags[1], 1);
-    double* out = g.Minv + (size_t)c * DIM * DIM;
+    double2* out = reinterpret_cast<double2*>(g.Minv + (size_t)c * DIM * DIM + (size_t)j * DIM);
 #pragma unroll
-    for (int i = 0; i < DIM; ++i) out[i * DIM + j] = a[i];
+    for (int i = 0; i < DIM / 2; ++i) out[i] = double2{a[2 * i], a[2 * i + 1]};
+  }
+  if constexpr (CGSTART) {
+    double u = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) u += a[i] * __shfl(bj, base + i);
+    if (live && v < g.N) {
+      const size_t ridx = 6 * (size_t)v + jc;
+      g.cg_b[ridx] = bj;
+      g.cg_x[ridx] = 0.0;
+      g.cg_r[ridx] = bj;
+      g.cg_u[ridx] = u;
+      u_out[ridx] = u;
+    }
   }
 }
 template <int CL>

@@ -84,23 +84,29 @@ __device__ __forceinline__ bool res_aborted(const DeviceGraph& g) {
 }
 
 // what every kernel of the cycle does when its operation is not the next one (or the stream is stopped): hand the state on
-__device__ __forceinline__ void res_pass_on(const DeviceGraph& g, const CgState::Fused& st, int wp) {
+// (The launches keep only the two words of the state they branch on, `st_op` and `st_mirror`, in registers, and state records are
+// written word by word: a record held as a local made the compiler park it in LDS, whose addressing reads the work-group size from
+// the dispatch packet — host memory, 10-25 us per launch.)
+__device__ __forceinline__ void res_put_state(const DeviceGraph& g, int wp, int op, int cnt, double gamma_prev, double alpha_prev, double q_prev) {
+  CgState::Fused* d = &g.cg->f[wp];
+  d->op = op; d->cnt = cnt; d->mirror = 0; d->pad = 0;
+  d->gamma_prev = gamma_prev; d->alpha_prev = alpha_prev; d->q_prev = q_prev;
+}
+__device__ __forceinline__ void res_pass_on(const DeviceGraph& g, int rp, int wp) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (st.mirror) lm_mirror(g);          // (nothing touches the LM state in an idle launch)
-    CgState::Fused n = st;
-    n.mirror = 0;
-    g.cg->f[wp] = n;
+    const CgState::Fused* s = &g.cg->f[rp];
+    if (s->mirror) lm_mirror(g);          // (nothing touches the LM state in an idle launch)
+    res_put_state(g, wp, s->op, s->cnt, s->gamma_prev, s->alpha_prev, s->q_prev);
   }
 }
 // A launch of the cycle that finds the abort word set (or the CG launch whose barrier just gave up): the state is handed on — an LM
 // iteration that was in its CG goes back to its HEAD (idempotent: same damping, same CG start; the fused stream's CG wants its own
 // first product) — and the host is told.  One lane calls it.
-__device__ __forceinline__ void res_when_aborted(const DeviceGraph& g, const CgState::Fused& st, int wp) {
-  if (st.mirror) lm_mirror(g);
-  CgState::Fused n = st;
-  n.mirror = 0;
-  if (st.op == F_CG) { n = CgState::Fused{}; n.op = F_HEAD; }
-  g.cg->f[wp] = n;
+__device__ __forceinline__ void res_when_aborted(const DeviceGraph& g, int rp, int wp) {
+  const CgState::Fused* s = &g.cg->f[rp];
+  if (s->mirror) lm_mirror(g);
+  if (s->op == F_CG) res_put_state(g, wp, F_HEAD, 0, 0.0, 0.0, 0.0);
+  else res_put_state(g, wp, s->op, s->cnt, s->gamma_prev, s->alpha_prev, s->q_prev);
   __hip_atomic_store(&g.scal->resident_abort, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -117,14 +123,14 @@ __global__ __launch_bounds__(256) void k_res_v(DeviceGraph g, int launch, int ro
   double* wr = g.pipe_buf[wp];
   int& is_last = is_last_s;
   const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-  const CgState::Fused st = g.cg->f[rp];
+  const int st_op = g.cg->f[rp].op;
   if (wg == 0 && tid == 0) __hip_atomic_store(&g.scal->slots_done, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const bool aborted = res_aborted(g);
-  const bool mine = st.op == role_op && !aborted;
+  const bool mine = st_op == role_op && !aborted;
   uni_f_trace_begin(g, launch, mine ? role_op : 0, t_top);
   if (!mine) {
-    if (!aborted) res_pass_on(g, st, wp);
-    else if (wg == 0 && tid == 0) res_when_aborted(g, st, wp);
+    if (!aborted) res_pass_on(g, rp, wp);
+    else if (wg == 0 && tid == 0) res_when_aborted(g, rp, wp);
     uni_f_trace_end(g, launch);
     return;
   }
@@ -152,23 +158,21 @@ __global__ __launch_bounds__(256) void k_res_lin(DeviceGraph g, int launch) {
   extern __shared__ double lds[];  // NV_LIN * block
   const int rp = launch & 1, wp = rp ^ 1;
   const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-  const CgState::Fused st = g.cg->f[rp];
+  const int st_op = g.cg->f[rp].op, st_mirror = g.cg->f[rp].mirror;
   if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&g.scal->slots_done, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const bool aborted = res_aborted(g);
-  const bool mine = st.op == F_LIN && !aborted;
+  const bool mine = st_op == F_LIN && !aborted;
   uni_f_trace_begin(g, launch, mine ? F_LIN : 0, t_top);
   if (!mine) {
-    if (!aborted) res_pass_on(g, st, wp);
-    else if (blockIdx.x == 0 && threadIdx.x == 0) res_when_aborted(g, st, wp);
+    if (!aborted) res_pass_on(g, rp, wp);
+    else if (blockIdx.x == 0 && threadIdx.x == 0) res_when_aborted(g, rp, wp);
   } else {
     DeviceGraph gl = g;
     gl.pose_x = g.pose_c;          // the accepted candidate; the accept-finish part of the next HEAD copies it over
     linearize_body<INFO>(gl, lds);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-      if (st.mirror) lm_mirror(g);
-      CgState::Fused n{};
-      n.op = F_HEAD;
-      g.cg->f[wp] = n;
+      if (st_mirror) lm_mirror(g);
+      res_put_state(g, wp, F_HEAD, 0, 0.0, 0.0, 0.0);
     }
   }
   uni_f_trace_end(g, launch);
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
   const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
   const int rp = launch & 1, wp = rp ^ 1;
   const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-  const CgState::Fused st = g.cg->f[rp];
+  const int st_op = g.cg->f[rp].op, st_mirror = g.cg->f[rp].mirror;
   if (wg == 0 && tid == 0) __hip_atomic_store(&g.scal->slots_done, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // ---- what stays in registers for the whole CG: the slot's block, the row lane's vectors and its Jacobi-block row.  The slot's words
   // and its block are asked for BEFORE the state word is looked at (an idle launch of this role — a stopped stream — reads them in vain) ----
@@ -202,11 +206,11 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
     for (int k = 0; k < NPAIR; ++k) blk[k] = bp[(size_t)k * 64];
   }
   const bool aborted = res_aborted(g);
-  const bool mine = st.op == F_CG && !aborted;
+  const bool mine = st_op == F_CG && !aborted;
   uni_f_trace_begin(g, launch, mine ? F_CG : 0, t_top);
   if (!mine) {
-    if (!aborted) res_pass_on(g, st, wp);
-    else if (wg == 0 && tid == 0) res_when_aborted(g, st, wp);
+    if (!aborted) res_pass_on(g, rp, wp);
+    else if (wg == 0 && tid == 0) res_when_aborted(g, rp, wp);
     uni_f_trace_end(g, launch);
     return;
   }
@@ -374,18 +378,16 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
     }
   }
   if (!ok) {          // a barrier gave up (every work-group leaves the same way, sooner or later: the abort word)
-    if (wg == 0 && tid == 0) res_when_aborted(g, st, wp);
+    if (wg == 0 && tid == 0) res_when_aborted(g, rp, wp);
     uni_f_trace_end(g, launch);
     return;
   }
   // ---- the CG has stopped after `cnt` iterations (every work-group alike, behind the same barrier: the x every row lane stored in front
   // of it is the final one): q = A x and the candidates for the step tail ----
   if (wg == 0 && tid == 0) {
-    if (st.mirror) lm_mirror(g);
+    if (st_mirror) lm_mirror(g);
     g.cg->iters = cnt; g.cg->status = status; g.cg->done = 1;
-    CgState::Fused n{};
-    n.op = F_TAIL;
-    g.cg->f[wp] = n;
+    res_put_state(g, wp, F_TAIL, 0, 0.0, 0.0, 0.0);
     if (traced) g.oplog[1 + UNI_F_TRACE_WORDS * (size_t)launch + 1] = (ph0 & 0xffff) | ((ph1 & 0xffff) << 16) | ((ph2 & 0xffff) << 32) | ((long long)(cnt & 0xffff) << 48);
   }
   double y[6] = {0, 0, 0, 0, 0, 0};

@@ -31,3 +31,10 @@ ph = np.array([[(int(w) >> (16 * k)) & 0xffff for k in range(4)] for w in cg[:, 
 its = ph[:, 3] + 2          # barriers per launch: w0 + iterations ... (cnt + 1 turns of the loop)
 print("  cg launches: mean CG iterations %.1f; per turn of the loop (work-group 0): fold + product + recurrences + publish %.2f us, grid barrier %.2f us, requests behind it %.2f us" % (
     ph[:, 3].mean(), (ph[:, 0] / (ph[:, 3] + 1)).mean() / 100, (ph[:, 1] / (ph[:, 3] + 1)).mean() / 100, (ph[:, 2] / (ph[:, 3] + 1)).mean() / 100))
+for op, nm, labels in ((1, "head", ("accept-finish done", "its chunk done (damping, Jacobi block, b, M^-1 b)", "known to be last", "end")),
+                       (4, "tail", ("loops done", "known to be last", "partials folded", "decided"))):
+    w = rec[rec[:, 0] == op][:, 3]
+    w = w[w != 0]
+    if len(w):
+        st = np.array([[(int(x) >> (16 * k)) & 0xffff for k in range(4)] for x in w], dtype=float) / 100.0
+        print("  %s, the last work-group to arrive (us from its top, median of %d): %s" % (nm, len(w), ", ".join("%s %.2f" % (l, v) for l, v in zip(labels, np.median(st, axis=0)))))
