@@ -2707,10 +2707,12 @@ void launch_uni_r(const DeviceGraph& g, const CgParams& p, int launch, double mi
   if (role == 0 || role == 2) {
     const int op = role == 0 ? F_HEAD : F_TAIL;
     const size_t lds = (size_t)g.block * sizeof(double);
-#define PGO_RES_V(INF) do { if (g.cluster == 2) hipLaunchKernelGGL((k_res_v<INF, 2>), grid, blk, lds, s, g, launch, op, min_diag, max_diag); \
-                            else hipLaunchKernelGGL((k_res_v<INF, 1>), grid, blk, lds, s, g, launch, op, min_diag, max_diag); } while (0)
+#define PGO_RES_V2(INF, C) do { if (op == F_HEAD) hipLaunchKernelGGL((k_res_v<INF, C, F_HEAD>), grid, blk, lds, s, g, launch, min_diag, max_diag); \
+                                else hipLaunchKernelGGL((k_res_v<INF, C, F_TAIL>), grid, blk, lds, s, g, launch, min_diag, max_diag); } while (0)
+#define PGO_RES_V(INF) do { if (g.cluster == 2) PGO_RES_V2(INF, 2); else PGO_RES_V2(INF, 1); } while (0)
     if (g.info_mode == 3) PGO_RES_V(3); else if (g.info_mode == 2) PGO_RES_V(2); else if (g.info_mode == 1) PGO_RES_V(1); else PGO_RES_V(0);
 #undef PGO_RES_V
+#undef PGO_RES_V2
   } else if (role == 1) {
     const size_t lds = ((size_t)(SPMV_LDS_STRIDE + 6) * g.block + 8) * sizeof(double);
 #define PGO_RES_CG(PK) do { if (g.cluster == 2) hipLaunchKernelGGL((k_res_cg<PK, 2>), grid, blk, lds, s, g, p, launch); \

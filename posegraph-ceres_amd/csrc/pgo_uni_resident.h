@@ -111,8 +111,10 @@ __device__ __forceinline__ void res_when_aborted(const DeviceGraph& g, int rp, i
 }
 
 // ---- roles 0 and 2: HEAD and TAIL (the fused stream's operations, without its speculative requests) ----
-template <int INFO, int CL>
-__global__ __launch_bounds__(256) void k_res_v(DeviceGraph g, int launch, int role_op, double min_diag, double max_diag) {
+// (the role is a template argument: HEAD — a 12x12 Gauss-Jordan in registers — and TAIL — the edge costs — get a register allocation each)
+template <int INFO, int CL, int ROLE>
+__global__ __launch_bounds__(256, 2) void k_res_v(DeviceGraph g, int launch, double min_diag, double max_diag) {
+  constexpr int role_op = ROLE;
   extern __shared__ double lds[];
   __shared__ double scratch[32];
   __shared__ int is_last_s;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void k_res_v(DeviceGraph g, int launch, int ro
     uni_f_trace_end(g, launch);
     return;
   }
-  if (role_op == F_HEAD) {
+  if constexpr (ROLE == F_HEAD) {
     [&]() {          // (the pasted block leaves by `return`)
 #define PGO_UNI_HEAD_BLOCK
 #define PGO_UNI_HEAD_NEXT F_CG
