@@ -19,6 +19,7 @@
 #include "pgo_lm_rules.h"
 #include "pgo_math.h"
 #include "pgo_wave.h"
+#include "pgo_lin_lean.h"
 
 namespace pgo {
 
@@ -2532,6 +2533,7 @@ __global__ void k_copy_delta(DeviceGraph g, const double* step) {
 }
 
 #include "pgo_uni_fused.h"
+#include "pgo_lean_body.h"
 #include "pgo_uni_resident.h"
 
 }  // namespace
@@ -2719,6 +2721,12 @@ void launch_uni_r(const DeviceGraph& g, const CgParams& p, int launch, double mi
                             else hipLaunchKernelGGL((k_res_cg<PK, 1>), grid, blk, lds, s, g, p, launch); } while (0)
     if (g.blk_packed) PGO_RES_CG(true); else PGO_RES_CG(false);
 #undef PGO_RES_CG
+  } else if (g.info_mode != 1 && g.blk_packed && (long long)g.n_slots < 14000000LL && (long long)g.N < 60000000LL) {
+    // (information without position / rotation coupling, packed slots, 32-bit byte offsets: what linearize_lean_fits asks for)
+    const size_t lds = (size_t)LEAN_NV * (g.block / 2) * sizeof(double);
+    if (g.info_mode == 3) hipLaunchKernelGGL(k_res_lin_lean<3>, grid, blk, lds, s, g, launch);
+    else if (g.info_mode == 2) hipLaunchKernelGGL(k_res_lin_lean<2>, grid, blk, lds, s, g, launch);
+    else hipLaunchKernelGGL(k_res_lin_lean<0>, grid, blk, lds, s, g, launch);
   } else {
     const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);
     if (g.info_mode == 3) hipLaunchKernelGGL(k_res_lin<3>, grid, blk, lds, s, g, launch);

@@ -180,6 +180,33 @@ __global__ __launch_bounds__(256) void k_res_lin(DeviceGraph g, int launch) {
   uni_f_trace_end(g, launch);
 }
 
+// ... with the lean algebra (pgo_lin_lean.h / pgo_lean_body.h: 0.68 of the FP64 instructions, half the LDS) where the information has no
+// position / rotation coupling — the blocks go to their own incidence slots of the BSR, the row sums to Hdiag / grad as always
+template <int INFO>
+__global__ __launch_bounds__(256, 2) void k_res_lin_lean(DeviceGraph g, int launch) {
+  extern __shared__ double lds[];  // LEAN_NV * block / 2
+  const int rp = launch & 1, wp = rp ^ 1;
+  const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+  const int st_op = g.cg->f[rp].op, st_mirror = g.cg->f[rp].mirror;
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&g.scal->slots_done, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const bool aborted = res_aborted(g);
+  const bool mine = st_op == F_LIN && !aborted;
+  uni_f_trace_begin(g, launch, mine ? F_LIN : 0, t_top);
+  if (!mine) {
+    if (!aborted) res_pass_on(g, rp, wp);
+    else if (blockIdx.x == 0 && threadIdx.x == 0) res_when_aborted(g, rp, wp);
+  } else {
+    DeviceGraph gl = g;
+    gl.pose_x = g.pose_c;          // the accepted candidate; the accept-finish part of the next HEAD copies it over
+    lean_linearize_body<INFO, true>(gl, lds);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (st_mirror) lm_mirror(g);
+      res_put_state(g, wp, F_HEAD, 0, 0.0, 0.0, 0.0);
+    }
+  }
+  uni_f_trace_end(g, launch);
+}
+
 // ---- role 1: the whole CG ----
 template <bool PACKED, int CL>
 __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, int launch) {

@@ -54,7 +54,7 @@ def test_resident_fused_and_two_kernel_streams_agree(gpu, ds, loss, monkeypatch)
         a, b = res[other][0], res[3][0]
         assert list(a.iterations["step_is_successful"]) == list(b.iterations["step_is_successful"])
         assert list(a.iterations["linear_solver_iterations"]) == list(b.iterations["linear_solver_iterations"])
-        assert np.allclose(a.iterations["cost"], b.iterations["cost"], rtol=1e-8 if other == 1 else 1e-9)
+        assert np.allclose(a.iterations["cost"], b.iterations["cost"], rtol=1e-8)      # (the resident stream linearises with the lean algebra where it can: 1e-12 per block, 1e-9 here after 12 iterations)
         assert np.abs(res[other][1] - res[3][1]).max() < 1e-6
 
 
