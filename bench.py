@@ -482,6 +482,12 @@ def main():
                         roofline["frac_is"] = "algorithmic bytes per launch / the committed rocprofv3 average launch of the dominant kernel (profiles/%s)" % stats[-1]
         except Exception as ex:  # noqa: BLE001
             extra["rocprof_check_error"] = str(ex)
+        if traffic and roofline.get("avg_launch_us"):
+            # what really crossed the HBM interface per launch (PMC) over the same launch duration: for the resident kernel this is the
+            # TRANSFER rate (its matrix sits in registers), `achieved` the equivalent rate of the algorithmic bytes
+            roofline["traffic_rate_gbs"] = round(traffic / (roofline["avg_launch_us"] * 1e-6) / 1e9, 1)
+            roofline["traffic_frac_of_peak"] = round(traffic / (roofline["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            roofline["traffic_over_algorithmic"] = round(traffic / roofline["algorithmic_bytes_per_launch"], 3)
         if breakdown is not None:
             extra["lm_step_breakdown"] = breakdown
         extra["stream"] = ("resident universal stream (HEAD | the whole PCG in one launch, grid barrier per iteration | TAIL | LIN: four kernels in a fixed cycle)" if resident else
