@@ -205,6 +205,7 @@ struct DeviceGraph {
   // launch finds every segment in place and nobody still reading the buffer it will overwrite.  No host, no collective launch.
   void* const* peer_tab;
   unsigned long long* peer_flags;     // [world] this rank's flag array (device)
+  int n_cu;           // compute units of the device (hipDeviceAttributeMultiprocessorCount: 256 on an MI355X in SPX mode, fewer in a partition): what a grid that has to sit on the chip at once is sized against
   int rows_fit;       // every work-group owns at most block / 6 rows: a row lane per vector component (the resident CG keeps them in registers)
   int pairs_whole;    // the row partition keeps poses 2i, 2i + 1 in one single-chunk work-group (several ranks: prepare() sees to it)
   // partial sums

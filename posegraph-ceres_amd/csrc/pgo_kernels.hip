@@ -2700,7 +2700,8 @@ bool uni_f_supported(const DeviceGraph& g, const CgParams& p, int cluster) {
 // The resident stream needs what the fused one needs, every row lane in one pass (rows_fit) and a grid that is resident at once at two
 // waves per SIMD (the grid barrier of k_res_cg): 8 waves per CU, 256 CUs.
 bool uni_r_supported(const DeviceGraph& g, const CgParams& p, int cluster) {
-  return uni_f_supported(g, p, cluster) && g.rows_fit && g.block >= 64 && (long long)g.n_wg * (g.block / 64) <= 8LL * 256;
+  // (k_res_cg runs two waves per SIMD — __launch_bounds__(256, 2), 214 registers — i.e. eight waves per compute unit, 27 KB of LDS per work-group)
+  return uni_f_supported(g, p, cluster) && g.rows_fit && g.block >= 64 && g.n_cu > 0 && (long long)g.n_wg * (g.block / 64) <= 8LL * g.n_cu;
 }
 int uni_r_abort_word() { return RES_ABORT; }
 void launch_uni_r(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s) {

@@ -427,6 +427,9 @@ int prepare(pgo_problem* P) {
     int most = 0;
     for (int w = 0; w < n_wg; ++w) most = std::max(most, wg_row_begin[w + 1] - wg_row_begin[w]);
     g.rows_fit = 6 * most <= B ? 1 : 0;
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, P->device) != hipSuccess) { (void)hipGetLastError(); n_cu = 0; }
+    g.n_cu = n_cu;
   }
   g.n_part = n_part; g.n_vec_wg = n_vec_wg; g.n_edge_wg = n_edge_wg; g.n_pose_wg = n_pose_wg;
   g.cg = P->d_cg.p; g.flags = P->d_flags.p;
