@@ -20,13 +20,23 @@ def _solve(gpu, g, form, **kw):
     return gpu.solve(gpu.SolverOptions(**opt), prob), poses
 
 
-@pytest.mark.parametrize("info", ["diag", "identity"])
+@pytest.mark.parametrize("info", ["diag", "identity", "block_diagonal", "full"])
 @pytest.mark.parametrize("cluster", [1, 2])
 def test_resident_stream_matches_the_oracles_pipelined_cg(gpu, ds, O, info, cluster, monkeypatch):
+    """All four kinds of information: diagonal / identity / block-diagonal take the packed 27-entry slots and the lean linearisation,
+    a full 6 x 6 square-root information (position / rotation coupling) the 36-entry slots and the general body."""
     monkeypatch.setenv("PGO_BLOCK", "256")
     g = ds.manhattan_se3(1000, 4000, seed=3)
     if info == "identity":
         g = ds.PoseGraphData(g.poses, g.ia, g.ib, g.meas, None)
+    elif info in ("block_diagonal", "full"):
+        rng = np.random.default_rng(12)
+        A = rng.normal(size=(g.E, 6, 6))
+        if info == "block_diagonal":
+            A[:, :3, 3:] = 0.0
+            A[:, 3:, :3] = 0.0
+        L = np.linalg.cholesky(A @ np.transpose(A, (0, 2, 1)) + 6.0 * np.eye(6)) * 0.6
+        g = ds.PoseGraphData(g.poses, g.ia, g.ib, g.meas, L.reshape(-1, 36))
     s, poses = _solve(gpu, g, 3, pcg_cluster_poses=cluster)
     assert s.cg_form == 4                                     # the resident stream really ran
     og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
