@@ -1007,8 +1007,50 @@ int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, d
   auto matvec = [&](const double* in, double* outv) { if (pool) rows->matvec(H, d2, in, outv, *pool); else sym_matvec(H, d2, in, outv); };
   // block-Jacobi preconditioner; cluster > 1 groups `cluster` consecutive poses (a piece of the odometry
   // chain) into one dense diagonal block of H + D^2 (the product's cluster-Jacobi option)
+  // cluster == -1: the odometry chain solved exactly (M = the block-tridiagonal part of H + D^2: every diagonal block,
+  // and the blocks (i+1, i) where an edge couples consecutive poses; SPD, since every dropped off-diagonal block leaves
+  // its edge's diagonal contributions behind).  Block LDL^T down the chain: S_i = A_ii - W_i S_{i-1} W_i^T with
+  // W_i = A_{i,i-1} S_{i-1}^-1 — the recurrence the product's chain preconditioner factorises by segments.
+  const bool chain = cluster == -1;
+  std::vector<Blk> chS, chW;        // Cholesky factor of S_i (lower, row-major 6x6), W_i (row-major)
+  std::vector<uint8_t> chHas;
+  if (chain) {
+    chS.resize(n); chW.resize(n); chHas.assign(n, 0);
+    for (int i = 0; i < n; ++i) {
+      double S[36];
+      for (int k = 0; k < 36; ++k) S[k] = H.val[H.colptr[i]][k];
+      for (int k = 0; k < 6; ++k) S[7 * k] += d2[6 * (size_t)i + k];
+      // symmetrise from the stored lower triangle convention (full 6x6 diagonal blocks are stored)
+      if (i > 0) {
+        const int j = i - 1;
+        int slot = -1;
+        if (H.colptr[j] + 1 < H.colptr[j + 1] && H.rowidx[H.colptr[j] + 1] == i) slot = H.colptr[j] + 1;
+        if (slot >= 0) {
+          chHas[i] = 1;
+          const double* A = H.val[slot].data();     // block (i, i-1), row-major
+          // W = A S_{i-1}^-1: solve S_{i-1} W^T = A^T column by column
+          double* W = chW[i].data();
+          for (int r = 0; r < 6; ++r) {
+            double rhs[6], sol[6];
+            for (int c = 0; c < 6; ++c) rhs[c] = A[6 * r + c];
+            chol6_solve(chS[j].data(), rhs, sol);
+            for (int c = 0; c < 6; ++c) W[6 * r + c] = sol[c];
+          }
+          for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) {
+              double acc = 0;
+              for (int k = 0; k < 6; ++k) acc += W[6 * r + k] * A[6 * c + k];
+              S[6 * r + c] -= acc;
+            }
+        }
+      }
+      for (int k = 0; k < 36; ++k) chS[i][k] = S[k];
+      if (!chol6(chS[i].data())) { *ok = false; return 0; }
+    }
+    cluster = 1;
+  }
   if (cluster < 1) cluster = 1;
-  const int ncl = (n + cluster - 1) / cluster;
+  const int ncl = chain ? 0 : (n + cluster - 1) / cluster;
   std::vector<std::vector<double>> Mfac(ncl);
   for (int c = 0; c < ncl; ++c) {
     const int v0 = c * cluster, v1 = std::min(n, v0 + cluster), dim = 6 * (v1 - v0);
@@ -1029,6 +1071,28 @@ int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, d
     if (!chol_dense(A, dim)) { *ok = false; return 0; }
   }
   auto apply_M = [&](const double* rin, double* zout) {
+    if (chain) {
+      std::vector<double> y(m);
+      for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < 6; ++k) y[6 * (size_t)i + k] = rin[6 * (size_t)i + k];
+        if (chHas[i])
+          for (int r = 0; r < 6; ++r) {
+            double acc = 0;
+            for (int k = 0; k < 6; ++k) acc += chW[i][6 * r + k] * y[6 * (size_t)(i - 1) + k];
+            y[6 * (size_t)i + r] -= acc;
+          }
+      }
+      for (int i = n - 1; i >= 0; --i) {
+        chol6_solve(chS[i].data(), &y[6 * (size_t)i], zout + 6 * (size_t)i);
+        if (i + 1 < n && chHas[i + 1])
+          for (int c = 0; c < 6; ++c) {
+            double acc = 0;
+            for (int k = 0; k < 6; ++k) acc += chW[i + 1][6 * k + c] * zout[6 * (size_t)(i + 1) + k];
+            zout[6 * (size_t)i + c] -= acc;
+          }
+      }
+      return;
+    }
     auto one = [&](int c) {
       const int v0 = c * cluster, v1 = std::min(n, v0 + cluster);
       chol_dense_solve(Mfac[c], 6 * (v1 - v0), rin + 6 * (size_t)v0, zout + 6 * (size_t)v0);

@@ -375,6 +375,24 @@ __global__ __launch_bounds__(256) void k_linearize_symout(DeviceGraph g, int gat
   linearize_body<INFO, 1, true>(g, lds);
 }
 
+// The lean per-incidence algebra (pgo_lin_lean.h: 0.68 of the FP64 instructions, half the LDS, 168 registers) is THE linearisation wherever
+// the information has no position / rotation coupling (INFO 0, 2, 3: packed 27-entry slots); the general body above stays for INFO 1.
+#include "pgo_lean_body.h"
+
+template <int INFO, int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_linearize_lean_bsr(DeviceGraph g, int gate) {
+  extern __shared__ double lds[];      // LEAN_NV doubles per lane PAIR
+  if (gate == 1 && !g.cg->done) return;
+  if (gate == 2 && (g.lm->halt || !g.lm->accepted)) return;
+  lean_linearize_body<INFO, true>(g, lds);
+}
+// the body a universal-stream kernel runs for its LIN operation (compile-time: one body per instantiation)
+template <int INFO>
+__device__ __forceinline__ void linearize_any(const DeviceGraph& g, double* lds) {
+  if constexpr (INFO == 1) linearize_body<1>(g, lds);
+  else lean_linearize_body<INFO, true>(g, lds);
+}
+
 // Jacobi scaling, computed once at iteration 0 from the unscaled diag(J^T J):  S = 1 / (1 + sqrt(d)).
 __global__ void k_scale_from_diag(DeviceGraph g) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1651,7 +1669,7 @@ __global__ __launch_bounds__(256) void k_uni_s(DeviceGraph g, CgParams prm, int 
     uni_oplog(g, UNI_S_LINEARIZE);
     DeviceGraph gl = g;
     gl.pose_x = g.pose_c;          // the accepted candidate; the accept-finish part of the next head launch copies it over
-    linearize_body<INFO>(gl, lds);
+    linearize_any<INFO>(gl, lds);
     return;
   }
   // ---- CG iteration `it`: the stop test of iteration it - 1 first (k_spmv<0>'s prologue), by every work-group alike ----
@@ -2533,7 +2551,6 @@ __global__ void k_copy_delta(DeviceGraph g, const double* step) {
 }
 
 #include "pgo_uni_fused.h"
-#include "pgo_lean_body.h"
 #include "pgo_uni_resident.h"
 
 }  // namespace
@@ -2543,7 +2560,25 @@ __global__ void k_copy_delta(DeviceGraph g, const double* step) {
 // ------------------------------------------------------------------------------------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+bool lean_bsr_fits(const DeviceGraph& g) {
+  // packed slots (no position / rotation coupling in the information) and 32-bit byte offsets: 21 information planes, the blocks and
+  // the pose array each below 4 GiB
+  return g.info_mode != 1 && g.blk_packed && (long long)g.n_slots < 14000000LL && (long long)g.N < 60000000LL;
+}
+template <int WAVES>
+static void launch_lean_bsr_w(const DeviceGraph& g, hipStream_t s, int gate) {
+  const size_t lds = (size_t)LEAN_NV * (g.block / 2) * sizeof(double);
+  const dim3 grid(g.n_wg), block(g.block);
+  if (g.info_mode == 3) hipLaunchKernelGGL((k_linearize_lean_bsr<3, WAVES>), grid, block, lds, s, g, gate);
+  else if (g.info_mode == 2) hipLaunchKernelGGL((k_linearize_lean_bsr<2, WAVES>), grid, block, lds, s, g, gate);
+  else hipLaunchKernelGGL((k_linearize_lean_bsr<0, WAVES>), grid, block, lds, s, g, gate);
+}
 void launch_linearize(const DeviceGraph& g, hipStream_t s, int gate) {
+  if (lean_bsr_fits(g)) {
+    // three waves per SIMD: 168 registers without a spill (INFO 0, 3); block-diagonal information needs 12 bytes of scratch there: two
+    if (g.info_mode == 2) launch_lean_bsr_w<2>(g, s, gate); else launch_lean_bsr_w<3>(g, s, gate);
+    return;
+  }
   const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);
   if (g.info_mode == 3) hipLaunchKernelGGL(k_linearize<3>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
   else if (g.info_mode == 2) hipLaunchKernelGGL(k_linearize<2>, dim3(g.n_wg), dim3(g.block), lds, s, g, gate);
@@ -2646,7 +2681,8 @@ void launch_lm_resume(const DeviceGraph& g, int cg_goes_on, hipStream_t s) {
   hipLaunchKernelGGL(k_lm_resume, dim3(1), dim3(1), 0, s, g, cg_goes_on);
 }
 static inline int uni_v_grid(const DeviceGraph& g) { return std::max(g.n_vec_wg, g.n_edge_wg + g.n_pose_wg); }
-bool uni_supported(const DeviceGraph& g) { return g.world == 1 && g.block <= 256; }
+// (the universal streams' LIN operation is the lean body wherever the slots are packed: 32-bit byte offsets, see lean_bsr_fits)
+bool uni_supported(const DeviceGraph& g) { return g.world == 1 && g.block <= 256 && (g.info_mode == 1 || lean_bsr_fits(g)); }
 void launch_uni_s(const DeviceGraph& g, const CgParams& p, int period, hipStream_t s) {
   const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);
 #define PGO_UNI_S(PK, INF) hipLaunchKernelGGL((k_uni_s<PK, INF>), dim3(g.n_wg), dim3(g.block), lds, s, g, p, period)

@@ -169,7 +169,7 @@ __device__ __forceinline__ void uni_f_body(const DeviceGraph& g, const CgParams&
   if (op == F_LIN) {
     DeviceGraph gl = g;
     gl.pose_x = g.pose_c;          // the accepted candidate; the accept-finish part of the next HEAD copies it over
-    linearize_body<INFO>(gl, lds);
+    linearize_any<INFO>(gl, lds);
     if (wg == 0 && tid == 0) { CgState::Fused n{}; n.op = F_HEAD; g.cg->f[wp] = n; }
     return;
   }

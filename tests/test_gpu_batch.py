@@ -49,7 +49,9 @@ def test_batch_follows_the_single_problem_traces(gpu, ds):
 
 
 def test_batch_of_identical_graphs_and_iteration_cap(gpu, ds):
-    """Eight copies of one graph give eight identical results; max_num_iterations is honoured per problem."""
+    """Eight copies of one graph give the same result eight times — to rounding: the linearisation sums a row's incidences in lane
+    pairs, so where the pairs fall depends on the parity of the row's first slot inside the union — ; max_num_iterations is
+    honoured per problem."""
     g = ds.manhattan_se3(500, 1200, seed=3)
     opt = gpu.SolverOptions(max_num_iterations=4, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
     prob, poses = gpu.problem_from_graph(g)
@@ -58,7 +60,7 @@ def test_batch_of_identical_graphs_and_iteration_cap(gpu, ds):
     sums = gpu.solve_batch(opt, [p for p, _ in pairs])
     for sb, (_, pb) in zip(sums, pairs):
         _compare(single, sb, poses, pb)
-        assert np.array_equal(pb, pairs[0][1])
+        assert np.abs(pb - pairs[0][1]).max() <= 1e-9
         assert sb.termination_type == gpu.NO_CONVERGENCE and len(sb.iterations) == 5
 
 
@@ -93,7 +95,7 @@ def test_small_front_plan_with_many_workgroups_in_flight_is_reproducible(gpu, ds
     """Regression (r02): 48 KITTI-00 graphs through the small-front plan = ~14 000 LDS fronts per level, several workgroups per
     CU, so the waves of one workgroup drift apart.  A pose step of k_sfront_factor used to write the factorised pivot block
     before every wave had read the unfactorised one: a few components of such a batch came out with 13-15 iterations and a cost
-    off in the 7th digit (and a single solve did so once in ~1000 runs).  The components must agree bit for bit and follow the single solve."""
+    off in the 7th digit (and a single solve did so once in ~1000 runs).  The components must agree (to 1e-12; bit for bit from run to run) and follow the single solve."""
     k = np.load(os.path.join(G, "kitti00.npz"))
     g = ds.PoseGraphData(k["origin"], k["ia"], k["ib"], k["meas"], None)
     opt = gpu.SolverOptions(max_num_iterations=1000, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
@@ -101,10 +103,16 @@ def test_small_front_plan_with_many_workgroups_in_flight_is_reproducible(gpu, ds
     prob, _ = gpu.problem_from_graph(g)
     single = gpu.solve(opt, prob)
     assert single.c.factor_kind == 3
+    runs = []
     for _ in range(2):
         pairs = [gpu.problem_from_graph(g) for _ in range(48)]
         sums = gpu.solve_batch(opt, [p for p, _ in pairs])
         assert all(s.c.factor_kind == 3 for s in sums)
         assert {len(s.iterations) for s in sums} == {len(single.iterations)}
-        assert len({s.final_cost for s in sums}) == 1                       # bit for bit among the components
+        # among the components: to the rounding of the linearisation's pair sums (a row's pairs fall by the parity of its first slot in
+        # the union: 1e-15 measured; the race moved the 7th digit)
+        costs = [s.final_cost for s in sums]
+        assert max(costs) - min(costs) <= 1e-12 * single.final_cost
         assert sums[0].final_cost == pytest.approx(single.final_cost, rel=1e-12)
+        runs.append(costs)
+    assert runs[0] == runs[1]                                               # and bit for bit from run to run
