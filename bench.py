@@ -496,7 +496,7 @@ def main():
         ach_lin = b_lin / (t_lin * 1e-3) / 1e9
         ach_eval = b_eval / (t_eval * 1e-3) / 1e9
         extra["roofline_jacobian_kernel"] = {
-            "kernel": "k_linearize (residual + analytic Jacobians + Huber + J'J/J'r, fused)", "bound": "hbm",
+            "kernel": "k_linearize_lean_bsr (residual + analytic Jacobians + Huber + J'J/J'r, fused; the lean per-incidence algebra)", "bound": "hbm",
             "achieved": round(ach_lin, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_lin / HBM_PEAK_GBS, 4),
             "algorithmic_bytes_per_launch": b_lin, "avg_launch_us": round(t_lin * 1e3, 3),
             "edge_jacobians_per_sec": round(E / (t_lin * 1e-3), 1)}
@@ -592,8 +592,7 @@ def main():
                                          ("k_spmv_sym<0> (CG product, every interior block read once)", "sym_spmv", (N4 + E4) * 288 + 2 * N4 * 48, 100),
                                          ("k_linearize_lean (the row kernel with the hand-reduced algebra writing the symmetric form: what the session's LM loop runs)", "sym_linearize_lean", 640 * E4 + 392 * N4, 50),
                                          ("k_linearize_symout (the general body writing the symmetric form, PGO_SYM_LIN=rows)", "sym_linearize_rows", 640 * E4 + 392 * N4, 50),
-                                         ("k_linearize_sym (tile kernel, PGO_SYM_LIN=tile)", "sym_linearize", 640 * E4 + 392 * N4, 50),
-                                         ("k_linearize", "linearize", 640 * E4 + 392 * N4, 50),
+                                         ("k_linearize_lean_bsr (the same algebra writing the incidence-slot blocks: sessions below 600 k slots and sharded ranks)", "linearize", 640 * E4 + 392 * N4, 50),
                                          ("k_spmv<0>", "pcg_spmv", (N4 + E4) * 288 + 2 * N4 * 48, 100)):
             t4 = p4.time_kernel(kern, reps4)
             gbs = nbytes / (t4 * 1e-3) / 1e9

@@ -1210,7 +1210,7 @@ struct oracle_options {
   double min_lm_diagonal;              // 1e-6
   double max_lm_diagonal;              // 1e32
   double eta;                          // 0.1
-  int pcg_cluster;                     // poses per Jacobi block of the PCG preconditioner (1 = 6x6 blocks, Ceres JACOBI-like)
+  int pcg_cluster;                     // poses per Jacobi block of the PCG preconditioner (1 = 6x6 blocks, Ceres JACOBI-like); -1: the odometry chain (block-tridiagonal part of H + D^2) solved exactly
   int num_threads;   /* 0 / 1: sequential (the reference sets num_threads = 1); > 1: Jacobian evaluation, cost evaluation and the
                         numeric Cholesky on that many threads — same results to the bit */
   int pcg_form;      /* 0: Ceres' CG statement by statement; 1: the pipelined recurrences (pcg_solve above) */
@@ -1350,10 +1350,11 @@ int oracle_linear_solve(int N, int E, const double* poses, const uint8_t* cmask,
     return 0;
   }
   bool ok;
-  // linear_solver: 1 = 6x6 Jacobi blocks, 100 + c = clusters of c poses; + 1000 = the pipelined recurrences
+  // linear_solver: 1 = 6x6 Jacobi blocks, 100 + c = clusters of c poses, 99 = the odometry chain solved exactly (pcg_cluster -1);
+  // + 1000 = the pipelined recurrences
   const int form = linear_solver >= 1000 ? 1 : 0;
   if (form) linear_solver -= 1000;
-  int it = pcg_solve(H, d2, b, x, q_tol, max_it, 0, 10, &ok, nullptr, linear_solver >= 100 ? linear_solver - 100 : 1, nullptr, form);
+  int it = pcg_solve(H, d2, b, x, q_tol, max_it, 0, 10, &ok, nullptr, linear_solver == 99 ? -1 : linear_solver >= 100 ? linear_solver - 100 : 1, nullptr, form);
   return ok ? it : -1;
 }
 

@@ -219,10 +219,10 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
   }
   // "pcg_spmv" repeats the SpMV kernel of CG iteration 1 (the update kernel never runs, so the
   // iteration counter stays put); "pcg_update" likewise repeats the update of iteration 1.
-  if (k == "sym_spmv" || k == "sym_repack" || k == "sym_plain" || k == "sym_linearize" || k == "sym_linearize_rows" || k == "sym_linearize_lean" || k == "sym_lean_check") {
+  if (k == "sym_spmv" || k == "sym_repack" || k == "sym_plain" || k == "sym_linearize_rows" || k == "sym_linearize_lean" || k == "sym_lean_check") {
     int rcs = sym_prepare(P);
     if (rcs) return rcs;
-    if (!P->sym_ready || (k == "sym_linearize" && !P->sym_lin_fits)) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): the graph does not fit the symmetric tile form", kernel);
+    if (!P->sym_ready) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('%s'): the graph does not fit the symmetric tile form", kernel);
   }
   // (a session that keeps the symmetric form as its ONLY storage has no current incidence-slot blocks to repack from: damping goes
   // through the form's view, a repack would overwrite the live form with the blocks of iteration zero)
@@ -260,7 +260,6 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     else if (k == "sym_spmv") pgo::launch_spmv_sym(P->g, P->sym, prm, 1, 0, s);
     else if (k == "sym_plain") pgo::launch_spmv_sym(P->g, P->sym, prm, 1, 1, s);
     else if (k == "sym_repack") pgo::launch_sym_repack(P->g, P->sym, s);
-    else if (k == "sym_linearize") pgo::launch_linearize_sym(P->g, P->sym, s);
     else if (k == "sym_linearize_rows") { pgo::DeviceGraph gs = P->g; gs.sym_dst = P->sy_dst.p; gs.sym_val = P->sym.val; pgo::launch_linearize_symout(gs, s); }
     else if (k == "sym_linearize_lean") { pgo::DeviceGraph gs = P->g; gs.sym_dst = P->sy_dst.p; gs.sym_val = P->sym.val; pgo::launch_linearize_lean(gs, s); }
     else if (k == "pcg_iteration") pgo::launch_pcg_iteration(P->g, prm, 1, s);

@@ -431,12 +431,11 @@ struct pgo_problem {
   DevBuf<pgo::SymTile> sy_tile;
   DevBuf<int> sy_xlist, sy_chunk_base, sy_chunk_n, sy_src, sy_diag;
   bool sym_stale = true;            // the off-diagonal blocks were rewritten since the last repack (else only the damped diagonal slots are copied)
-  DevBuf<uint32_t> sy_meta, sy_rinfo, sy_meta2, sy_rinfo2;
+  DevBuf<uint32_t> sy_meta, sy_rinfo;
   bool sym_storage = false;         // this LM session keeps the normal equations in the symmetric tile form ONLY: linearisation, damping, the cluster
                                     // preconditioner and every product work on it (the incidence-slot blocks are not maintained)
   std::vector<int> h_cl_slot, h_sym_of_old;
   DevBuf<int> sy_cl_slot, sy_dst;
-  bool sym_lin_fits = false;        // k_linearize_sym's LDS (poses + exchange buffer) fits: the linearisation writes the symmetric form itself
   DevBuf<double> sy_val;
   // cluster-Jacobi preconditioner topology (built when the option asks for clusters of 2 or 4 poses)
   DevBuf<int> d_cl_ptr, d_cl_slot;

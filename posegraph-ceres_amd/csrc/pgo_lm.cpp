@@ -146,10 +146,7 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
     if (rc) return rc;
     P->sym_active = P->sym_ready;
     const char* rp = getenv("PGO_SYM_REPACK");        // (A/B: keep the incidence-slot linearisation and copy its blocks per LM iteration)
-    // (storage mode needs the tile kernel's LDS budget only when that kernel writes the form: PGO_SYM_LIN=tile)
-    const char* sl = getenv("PGO_SYM_LIN");
-    const bool tile_lin = sl && sl[0] == 't';
-    if (P->sym_active && (P->sym_lin_fits || !tile_lin) && !(rp && rp[0] == '1')) { rc = sym_enter_storage(P); if (rc) return rc; }
+    if (P->sym_active && !(rp && rp[0] == '1')) { rc = sym_enter_storage(P); if (rc) return rc; }
   }
   L.active = true;            // (only a session that got this far is one: an error above leaves the problem as it was)
   L.t_total += seconds_since(t0);

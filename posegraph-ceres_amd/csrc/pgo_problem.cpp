@@ -61,11 +61,10 @@ int exchange(pgo_problem* P, double* buf, size_t seg_doubles) {
 // diagonal blocks then — 6 doubles per pose travel instead of 36 (28.8 -> 4.8 MB per accepted step at 100 k poses)
 int linearize_all(pgo_problem* P, bool diag_only) {
   if (P->sym_storage) {        // (one rank: nothing to exchange)
-    // three kernels write the form: the row kernel with the lean per-incidence algebra (k_linearize_lean, the default where it fits:
-    // information without position / rotation coupling), the row kernel with the general body and redirected block stores
-    // (k_linearize_symout, PGO_SYM_LIN=rows) and the tile kernel (an interior edge evaluated once for both rows, PGO_SYM_LIN=tile)
+    // two kernels write the form: the row kernel with the lean per-incidence algebra (k_linearize_lean, the default where it fits:
+    // information without position / rotation coupling) and the row kernel with the general body and redirected block stores
+    // (k_linearize_symout: information with the coupling; PGO_SYM_LIN=rows runs it everywhere — tests/test_gpu_sym.py holds one to the other)
     const char* sl = getenv("PGO_SYM_LIN");
-    if (sl && sl[0] == 't') { pgo::launch_linearize_sym(P->g, P->sym, P->stream); return PGO_OK; }
     pgo::DeviceGraph gs = P->g;
     gs.sym_dst = P->sy_dst.p; gs.sym_val = P->sym.val;
     if (sl && sl[0] == 'r') pgo::launch_linearize_symout(gs, P->stream);

@@ -48,11 +48,11 @@ int sym_prepare(pgo_problem* P) {
     if (verbose) std::fprintf(stderr, "[pgo] sym: tile %d %s: the incidence-slot kernels stay\n", H.unfit_tile, H.unfit);
     return PGO_OK;
   }
-  const int T = (int)H.tiles.size(), row_cap = hp.row_cap, x_cap = H.x_cap, e_cap = H.e_cap;
+  const int T = (int)H.tiles.size(), row_cap = hp.row_cap, x_cap = H.x_cap;
   const long long interior_edges = H.interior_edges, stored = H.stored;
   std::vector<pgo::SymTile>& tiles = H.tiles;
   std::vector<int>&xlist = H.xlist, &chunk_base = H.chunk_base, &chunk_n = H.chunk_n, &src_slot = H.src_slot, &diag_slot = H.diag_slot;
-  std::vector<uint32_t>&meta = H.meta, &rinfo = H.rinfo, &meta2 = H.meta2, &rinfo2 = H.rinfo2;
+  std::vector<uint32_t>&meta = H.meta, &rinfo = H.rinfo;
   lap("tile layout");
   const int n_slots = (int)meta.size();
   if (T > P->g.pq_cap) {       // the p'q partials of the tiles ride in the slots of the row partition's work-groups
@@ -60,7 +60,6 @@ int sym_prepare(pgo_problem* P) {
     return PGO_OK;
   }
   if (pgo::sym_lds_bytes(pgo::SymGraph{T, (int)chunk_base.size(), n_slots, x_cap}) > 160 * 1024 - 1024) return PGO_OK;
-  { pgo::SymGraph probe{}; probe.x_cap = x_cap; probe.e_cap = e_cap; P->sym_lin_fits = pgo::sym_lin_lds_bytes(probe) <= 160 * 1024 - 1024; }
 
   HIP_TRY(P->sy_tile.upload(tiles, s));
   HIP_TRY(P->sy_xlist.upload(xlist, s));
@@ -70,15 +69,13 @@ int sym_prepare(pgo_problem* P) {
   HIP_TRY(P->sy_rinfo.upload(rinfo, s));
   HIP_TRY(P->sy_src.upload(src_slot, s));
   HIP_TRY(P->sy_diag.upload(diag_slot, s));
-  HIP_TRY(P->sy_meta2.upload(meta2, s));
-  HIP_TRY(P->sy_rinfo2.upload(rinfo2, s));
   HIP_TRY(P->sy_val.alloc((size_t)n_slots * 36));
   HIP_TRY(P->sy_val.zero(s));
   pgo::SymGraph& sg = P->sym;
   sg.n_tiles = T; sg.n_chunks = (int)chunk_base.size(); sg.n_slots = n_slots; sg.x_cap = x_cap;
   sg.tile = P->sy_tile.p; sg.xlist = P->sy_xlist.p; sg.chunk_base = P->sy_chunk_base.p; sg.chunk_n = P->sy_chunk_n.p;
   sg.meta = P->sy_meta.p; sg.rinfo = P->sy_rinfo.p; sg.src_slot = P->sy_src.p; sg.diag_slot = P->sy_diag.p;
-  sg.meta2 = P->sy_meta2.p; sg.rinfo2 = P->sy_rinfo2.p; sg.e_cap = e_cap; sg.val = P->sy_val.p;
+  sg.val = P->sy_val.p;
   HIP_TRY(hipStreamSynchronize(s));
   lap("index uploads + sync");
   P->h_sym_of_old.assign(P->g.n_slots, -1);
@@ -94,8 +91,8 @@ int sym_prepare(pgo_problem* P) {
   P->sym_interior_fraction = E ? (double)interior_edges / E : 0.0;
   P->sym_stored_slots = stored;
   if (getenv("PGO_VERBOSE"))
-    std::fprintf(stderr, "[pgo] sym: %d tiles (<= %d rows), %.1f %% interior edges, %lld stored blocks (%.2f of N + 2E), %d chunks, x_cap %d, e_cap %d, %.1f ms\n",
-                 T, row_cap, 100.0 * P->sym_interior_fraction, stored, (double)stored / (N + 2.0 * E), sg.n_chunks, x_cap, e_cap, 1e3 * seconds_since(t0));
+    std::fprintf(stderr, "[pgo] sym: %d tiles (<= %d rows), %.1f %% interior edges, %lld stored blocks (%.2f of N + 2E), %d chunks, x_cap %d, %.1f ms\n",
+                 T, row_cap, 100.0 * P->sym_interior_fraction, stored, (double)stored / (N + 2.0 * E), sg.n_chunks, x_cap, 1e3 * seconds_since(t0));
   return PGO_OK;
 }
 
@@ -108,7 +105,7 @@ pgo::DeviceGraph sym_view(const pgo_problem* P) {
 }
 
 // The symmetric form becomes the only storage of this LM session: the blocks of the linearisation that just ran (incidence-slot
-// kernels, iteration zero) are copied once, the cluster lists are re-indexed; from here on k_linearize_sym writes the form itself.
+// kernels, iteration zero) are copied once, the cluster lists are re-indexed; from here on the linearisation writes the form itself.
 int sym_enter_storage(pgo_problem* P) {
   if (P->g.cluster > 1) {
     std::vector<int> cl(P->h_cl_slot.size());

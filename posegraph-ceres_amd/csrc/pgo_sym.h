@@ -53,12 +53,6 @@ struct SymGraph {
   const int* src_slot;                // [n_slots] slot of the incidence-slot BSR that holds the same block (-1: padding)
   const int* diag_slot;               // [N] stored slot of every row's diagonal block
   double* val;                        // [n_slots * 36] blocks, bsr_index() layout
-  // ---- linearisation straight into this form (k_linearize_sym) ----
-  // (measurement and information of a slot's edge are read from the incidence-slot arrays g.smeas / g.sW at src_slot: the stored
-  // slots of a tile map to ascending incidence slots, so the gathers are nearly contiguous — no second copy, nothing to upload)
-  const uint32_t* meta2;              // [n_slots] tail_pos | vpos2 << 16: where the (row, wave) run sum / the mirrored 27 values go in the chunk's exchange buffer (0xFFFF: none)
-  const uint32_t* rinfo2;             // [n_chunks * SYM_LANES] ebeg | ecnt << 16: the exchange entries of the tile's r-th row in the chunk
-  int e_cap;                          // max exchange entries of a chunk
 };
 
 // q = A p of a CG iteration (MODE 0: prologue, x = z + beta p, p_new, p'q partials — exactly k_spmv<0>'s contract) or plain
@@ -68,10 +62,6 @@ void launch_spmv_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p
 // diag_only: a rejected LM step changed nothing but the damping, i.e. the diagonal slots
 void launch_sym_repack(const DeviceGraph& g, const SymGraph& sg, hipStream_t s, int diag_only = 0);
 size_t sym_lds_bytes(const SymGraph& sg);
-size_t sym_lin_lds_bytes(const SymGraph& sg);     // LDS of k_linearize_sym (staged poses + row sums + exchange buffer)
-// residual + Jacobians + J'J / J'r of every stored slot written into the symmetric tile form (off-diagonal blocks -> sg.val, diagonal
-// blocks -> g.Hdiag, gradient -> g.grad): an interior edge is evaluated once for both of its rows.  gate: as launch_linearize
-void launch_linearize_sym(const DeviceGraph& g, const SymGraph& sg, hipStream_t s, int gate = 0);
 // pgo_lean_kernels.hip: the row kernel writing the form (g.sym_dst / g.sym_val set) with the lean per-incidence algebra of pgo_lin_lean.h
 void launch_linearize_lean(const DeviceGraph& g, hipStream_t s, int gate = 0);      // (falls back to launch_linearize_symout when it does not fit)
 bool linearize_lean_fits(const DeviceGraph& g);

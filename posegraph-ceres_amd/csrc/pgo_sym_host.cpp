@@ -100,9 +100,9 @@ void sym_build_host(int N, int E, const int* ia, const int* ib, const int* row_s
   // ---- per-tile layout, tiles in parallel (every index below is relative to the tile; offsets are added afterwards) ----
   struct TileOut {
     std::vector<int> xlist, chunk_n, src;        // src: per stored slot incl. chunk padding
-    std::vector<uint32_t> meta, meta2, rinfo, rinfo2;
+    std::vector<uint32_t> meta, rinfo;
     std::vector<int> diag_local;                 // per row: stored slot of its diagonal block
-    int nr = 0, nx = 0, total = 0, L = 0, e_cap = 1;
+    int nr = 0, nx = 0, total = 0, L = 0;
     long long interior = 0;
     const char* unfit = nullptr;
   };
@@ -159,10 +159,8 @@ void sym_build_host(int N, int E, const int* ia, const int* ib, const int* row_s
       O.diag_local.assign(nr, 0);
       O.chunk_n.resize(L);
       O.rinfo.assign((size_t)L * pgo::SYM_LANES, 0u);
-      O.rinfo2.assign((size_t)L * pgo::SYM_LANES, 0u);
       const int padded_total = (L - 1) * pgo::SYM_LANES + (total - (L - 1) * pgo::SYM_LANES + 63) / 64 * 64;
       O.meta.assign(padded_total, 0u);
-      O.meta2.assign(padded_total, 0xFFFFFFFFu);
       O.src.assign(padded_total, -1);
       for (int c = 0; c < L && !O.unfit; ++c) {
         const int lo = c * pgo::SYM_LANES, n = std::min((int)pgo::SYM_LANES, total - lo);
@@ -189,30 +187,6 @@ void sym_build_host(int N, int E, const int* ia, const int* ib, const int* row_s
           w += 1u << 25;
         }
         if (O.unfit) break;
-        // exchange entries of the linearisation (k_linearize_sym): per destination row, ascending: the tails of its (row, wave)
-        // runs, then the mirrored contributions it receives — contiguous, so the row's lanes add one range
-        uint32_t* r2 = &O.rinfo2[(size_t)c * pgo::SYM_LANES];
-        int pos = 0;
-        size_t kv = 0;
-        for (int r = 0; r < nr; ++r) {
-          const uint32_t w = ri[r];
-          const int ub = (int)(w & 0xFFu), uc = (int)((w >> 8) & 0x1FFu);
-          const int e0 = pos;
-          if (uc > 0) {
-            const int last = ub + uc - 1;
-            for (int wv = ub >> 6; wv <= (last >> 6); ++wv) {
-              const int tail = std::min(wv * 64 + 63, last);
-              O.meta2[base + tail] = (O.meta2[base + tail] & 0xFFFF0000u) | (uint32_t)pos++;
-            }
-          }
-          while (kv < vs.size() && vs[kv].first == r) {
-            const int l = vs[kv].second;
-            O.meta2[base + l] = (O.meta2[base + l] & 0x0000FFFFu) | ((uint32_t)pos++ << 16);
-            ++kv;
-          }
-          r2[r] = (uint32_t)e0 | ((uint32_t)(pos - e0) << 16);
-        }
-        O.e_cap = std::max(O.e_cap, pos);
       }
       reset_local();
     }
@@ -222,12 +196,11 @@ void sym_build_host(int N, int E, const int* ia, const int* ib, const int* row_s
   tiles.assign(T, pgo::SymTile{});
   std::vector<int>&xlist = out->xlist, &chunk_base = out->chunk_base, &chunk_n = out->chunk_n, &src_slot = out->src_slot, &diag_slot = out->diag_slot;
   diag_slot.assign(N, 0);
-  std::vector<uint32_t>&meta = out->meta, &rinfo = out->rinfo, &meta2 = out->meta2, &rinfo2 = out->rinfo2;
-  int& e_cap = out->e_cap;
+  std::vector<uint32_t>&meta = out->meta, &rinfo = out->rinfo;
   int& x_cap = out->x_cap;
   long long& interior_edges = out->interior_edges;
   long long& stored = out->stored;
-  e_cap = 1; x_cap = 0; interior_edges = 0; stored = 0;
+  x_cap = 0; interior_edges = 0; stored = 0;
   {
     size_t nxs = 0, nsl = 0, nch = 0;
     for (int t = 0; t < T; ++t) {
@@ -239,21 +212,19 @@ void sym_build_host(int N, int E, const int* ia, const int* ib, const int* row_s
       TT.base1 = (int)nsl + pgo::SYM_LANES; TT.n1 = O.L > 1 ? O.chunk_n[1] : 0;
       TT.pad[0] = TT.pad[1] = 0;
       nxs += O.xlist.size(); nsl += O.meta.size(); nch += O.L;
-      x_cap = std::max(x_cap, O.nx); e_cap = std::max(e_cap, O.e_cap);
+      x_cap = std::max(x_cap, O.nx);
       interior_edges += O.interior; stored += O.total;
     }
-    xlist.resize(nxs); meta.resize(nsl); meta2.resize(nsl); src_slot.resize(nsl);
-    chunk_base.resize(nch); chunk_n.resize(nch); rinfo.resize(nch * pgo::SYM_LANES); rinfo2.resize(nch * pgo::SYM_LANES);
+    xlist.resize(nxs); meta.resize(nsl); src_slot.resize(nsl);
+    chunk_base.resize(nch); chunk_n.resize(nch); rinfo.resize(nch * pgo::SYM_LANES);
     pgo::HostPool::get().run(nthreads, [&](int th) {
       for (int t = th; t < T; t += nthreads) {
         const TileOut& O = outs[t];
         const pgo::SymTile& TT = tiles[t];
         std::copy(O.xlist.begin(), O.xlist.end(), xlist.begin() + TT.x0);
         std::copy(O.meta.begin(), O.meta.end(), meta.begin() + TT.base0);
-        std::copy(O.meta2.begin(), O.meta2.end(), meta2.begin() + TT.base0);
         std::copy(O.src.begin(), O.src.end(), src_slot.begin() + TT.base0);
         std::copy(O.rinfo.begin(), O.rinfo.end(), rinfo.begin() + (size_t)TT.chunk0 * pgo::SYM_LANES);
-        std::copy(O.rinfo2.begin(), O.rinfo2.end(), rinfo2.begin() + (size_t)TT.chunk0 * pgo::SYM_LANES);
         for (int c = 0; c < O.L; ++c) { chunk_base[TT.chunk0 + c] = TT.base0 + c * pgo::SYM_LANES; chunk_n[TT.chunk0 + c] = O.chunk_n[c]; }
         for (int i = 0; i < O.nr; ++i) diag_slot[trow[t][i]] = TT.base0 + O.diag_local[i];
       }

@@ -15,8 +15,8 @@ struct SymHostParams {
 struct SymHostLayout {
   std::vector<SymTile> tiles;
   std::vector<int> xlist, chunk_base, chunk_n, src_slot, diag_slot;
-  std::vector<uint32_t> meta, rinfo, meta2, rinfo2;
-  int n_slots = 0, x_cap = 0, e_cap = 1;
+  std::vector<uint32_t> meta, rinfo;
+  int n_slots = 0, x_cap = 0;
   long long interior_edges = 0, stored = 0;
   const char* unfit = nullptr;    // why the graph does not fit the form (the caller keeps the incidence-slot kernels)
   int unfit_tile = -1;

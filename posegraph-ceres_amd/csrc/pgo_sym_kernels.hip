@@ -3,7 +3,6 @@
 // instruction, prefetched one chunk ahead) and 4 + 2 bytes of indices per slot; the vectors live in LDS.
 #include "pgo_sym.h"
 #include "pgo_wave.h"
-#include "pgo_lin.h"
 
 namespace pgo {
 
@@ -376,143 +375,6 @@ __global__ __launch_bounds__(SYM_LANES) void k_spmv_sym(DeviceGraph g, SymGraph 
   }
 }
 
-// Linearisation into the symmetric tile form.  One work-group per tile, one stored slot per lane and chunk (the SpMV's layout):
-// the lane evaluates its incidence with lin_slot() — the very expressions of k_linearize — from the poses staged in LDS, writes
-// its off-diagonal block, and contributes 27 numbers (21 of the diagonal block, 6 of the gradient) to its row; an INTERIOR slot
-// evaluates the mirrored incidence as well (same geometry: the compiler shares it) and sends those 27 numbers to the other row.
-// Row sums: segmented scan of the own contributions inside the wave, then run tails and mirrored contributions meet in an LDS
-// exchange buffer at positions the host laid out per destination row; lane r keeps row r's 27 sums in registers across the chunks.
-constexpr int LIN_NV = 27;
-constexpr int LIN_POSE = 7;       // doubles per staged pose
-// 512 lanes per tile: lanes 0..255 own one stored slot of the chunk each (block + own contribution), lanes 256..511 evaluate the
-// mirrored incidence of the same slot when it is interior — one lin_slot() per lane, so the kernel fits 256 registers and runs two
-// waves per SIMD (one 256-lane work-group holding both evaluations and the row sums needed 374 registers: one wave per SIMD, 299 us
-// at 100 k / 1 M).  The 27 sums of the tile's rows live in LDS; both halves of the work-group add the exchange entries to them.
-template <int INFO>
-__global__ __launch_bounds__(2 * SYM_LANES) void k_linearize_sym(DeviceGraph g, SymGraph sg, int gate) {
-  extern __shared__ double lds[];          // poses[LIN_POSE * x_cap] | acc[LIN_NV * SYM_LANES] | exch[LIN_NV * e_cap] | ids[x_cap]
-  if (gate == 1 && !g.cg->done) return;
-  if (gate == 2 && (g.lm->halt || !g.lm->accepted)) return;
-  const int tid = threadIdx.x, tile = blockIdx.x, lane = threadIdx.x & 63;
-  const int half = tid >> 8, l = tid & (SYM_LANES - 1);
-  double* poses = lds;
-  double* accl = lds + (size_t)sg.x_cap * LIN_POSE;
-  double* exch = accl + (size_t)LIN_NV * SYM_LANES;
-  int* ids = reinterpret_cast<int*>(exch + (size_t)LIN_NV * sg.e_cap);
-  const SymTile T = sg.tile[tile];
-  for (int i = tid; i < T.nx * 4; i += 2 * SYM_LANES) {
-    const int e = i >> 2, k = i & 3;
-    const int pose = sg.xlist[T.x0 + e];
-    const double2 v = reinterpret_cast<const double2*>(g.pose_x + (size_t)POSE_STRIDE * pose)[k];
-    poses[LIN_POSE * e + 2 * k] = v.x;
-    if (k < 3) poses[LIN_POSE * e + 2 * k + 1] = v.y;
-    if (k == 0) ids[e] = pose;
-  }
-  for (int i = tid; i < LIN_NV * SYM_LANES; i += 2 * SYM_LANES) accl[i] = 0.0;
-  __syncthreads();
-  const size_t ns = (size_t)g.n_slots;       // measurement / information: the incidence-slot arrays, gathered at src_slot
-  auto pose_at = [&](int e) { const double* p = poses + LIN_POSE * e; return PoseRec{V3{p[0], p[1], p[2]}, Q4{p[3], p[4], p[5], p[6]}}; };
-  // the index words of a chunk (4 registers) are requested one chunk ahead: the measurement / information gathers, which need
-  // src_slot, then start with the chunk instead of behind a dependent load
-  struct Idx { uint32_t rin, meta, m2; int src; };
-  auto load_idx = [&](Idx& I, int c) {
-    const int n = min((int)SYM_LANES, T.total - SYM_LANES * c), t = T.base0 + SYM_LANES * c + l;     // (no table look-up ahead of the slot loads)
-    I.rin = sg.rinfo2[(size_t)(T.chunk0 + c) * SYM_LANES + l];
-    I.meta = 0; I.m2 = 0xFFFFFFFFu; I.src = 0;
-    if (l < n) { I.meta = sg.meta[t]; I.m2 = sg.meta2[t]; I.src = sg.src_slot[t]; }
-  };
-  Idx cur, nxt;
-  load_idx(cur, 0);
-  nxt = cur;
-  for (int c = 0; c < T.nchunks; ++c) {
-    if (c + 1 < T.nchunks) load_idx(nxt, c + 1);
-    const int n = min((int)SYM_LANES, T.total - SYM_LANES * c), t = T.base0 + SYM_LANES * c + l;
-    const uint32_t rin = cur.rin, meta = cur.meta, m2 = cur.m2;
-    const int src = cur.src;
-    const int xcol = (int)(meta & 0xFFFu), side = (int)((meta >> 12) & 3u);
-    const int srow = (int)((meta >> 23) & 0xFFu);
-    const bool edge_slot = l < n && side != SIDE_DIAG;
-    if (half == 0) {
-      double v[LIN_NV];
-#pragma unroll
-      for (int k = 0; k < LIN_NV; ++k) v[k] = 0.0;
-      int row = l < n ? srow : -1 - lane;
-      if (edge_slot && !PGO_ABLATION(g, 4096)) {
-        const int ea = side == SIDE_BEGIN ? srow : xcol, eb = side == SIDE_BEGIN ? xcol : srow;
-        const PoseRec A = pose_at(ea), Bp = pose_at(eb);
-        const size_t so = (size_t)src;
-        const V3 mp{g.smeas[so], g.smeas[ns + so], g.smeas[2 * ns + so]};
-        const Q4 mq{g.smeas[3 * ns + so], g.smeas[4 * ns + so], g.smeas[5 * ns + so], g.smeas[6 * ns + so]};
-        double wv[36];
-        lin_slot<INFO>(g, side, ids[srow], ids[xcol], A, Bp, mp, mq, g.sW, ns, so, wv, v);
-        double2* out = reinterpret_cast<double2*>(sg.val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
-#pragma unroll
-        for (int kk = 0; kk < (INFO != 1 ? (int)BLK_PAIRS_PACKED : (int)BLK_PAIRS_FULL); ++kk) out[(size_t)kk * 64] = double2{wv[2 * kk], wv[2 * kk + 1]};
-      }
-      if (!PGO_ABLATION(g, 2048)) seg_scan<LIN_NV>(v, row, lane);
-      const int rn = __shfl_down(row, 1, 64);
-      if (l < n && (lane == 63 || rn != row)) {
-        const int tp = (int)(m2 & 0xFFFFu);
-#pragma unroll
-        for (int k = 0; k < LIN_NV; ++k) exch[(size_t)tp * LIN_NV + k] = v[k];
-      }
-    } else if (edge_slot && (meta & (1u << 14)) && !PGO_ABLATION(g, 8192)) {
-      // interior (stored in the BEGIN orientation): the END-side incidence of the same edge, for the other row
-      const PoseRec A = pose_at(srow), Bp = pose_at(xcol);
-      const size_t so = (size_t)src;
-      const V3 mp{g.smeas[so], g.smeas[ns + so], g.smeas[2 * ns + so]};
-      const Q4 mq{g.smeas[3 * ns + so], g.smeas[4 * ns + so], g.smeas[5 * ns + so], g.smeas[6 * ns + so]};
-      double wm[36], vm[LIN_NV];
-      lin_slot<INFO>(g, SIDE_END, ids[xcol], ids[srow], A, Bp, mp, mq, g.sW, ns, so, wm, vm);
-      const int vp = (int)(m2 >> 16);
-#pragma unroll
-      for (int k = 0; k < LIN_NV; ++k) exch[(size_t)vp * LIN_NV + k] = vm[k];
-    }
-    __syncthreads();
-    {
-      // row l of the tile: lanes 0..255 add values 0..13 of its exchange entries, lanes 256..511 values 14..26
-      const int eb = (int)(rin & 0xFFFFu), ec = (int)(rin >> 16);
-      if (ec > 0 && !PGO_ABLATION(g, 1024)) {       // the row's sums pass through registers once per chunk (not once per entry)
-        const int k0 = half ? 14 : 0, nk = half ? LIN_NV - 14 : 14;
-        double a[14];
-#pragma unroll
-        for (int k = 0; k < 14; ++k) a[k] = k < nk ? accl[(size_t)l * LIN_NV + k0 + k] : 0.0;
-        for (int j = 0; j < ec; ++j) {
-          const double* ep = exch + (size_t)(eb + j) * LIN_NV + k0;
-#pragma unroll
-          for (int k = 0; k < 14; ++k) if (k < nk) a[k] += ep[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 14; ++k) if (k < nk) accl[(size_t)l * LIN_NV + k0 + k] = a[k];
-      }
-    }
-    __syncthreads();
-    cur = nxt;
-  }
-  if (tid < T.nrows) {
-    const int pose = ids[tid];
-    const uint8_t cm = g.cmask[pose];
-    const double* acc = accl + (size_t)tid * LIN_NV;
-    double H[36];
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = i; j < 6; ++j) {
-        double sv = acc[k++];
-        if (i == j && ((i < 3) ? (cm & 1) : (cm & 2))) sv = 1.0;     // unit diagonal keeps the constant dims decoupled and the block SPD
-        H[6 * i + j] = sv;
-        H[6 * j + i] = sv;
-      }
-    double2* hd = reinterpret_cast<double2*>(g.Hdiag + 36 * (size_t)pose);
-#pragma unroll
-    for (int q = 0; q < 18; ++q) hd[q] = double2{H[2 * q], H[2 * q + 1]};
-    double2* gd = reinterpret_cast<double2*>(g.grad + 6 * (size_t)pose);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) gd[q] = double2{acc[21 + 2 * q], acc[21 + 2 * q + 1]};
-  }
-}
-
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_sym_repack(DeviceGraph g, SymGraph sg) {
   constexpr int NPAIR = PACKED ? BLK_PAIRS_PACKED : BLK_PAIRS_FULL;
@@ -543,9 +405,6 @@ __global__ __launch_bounds__(256) void k_sym_repack_diag(DeviceGraph g, SymGraph
 
 }  // namespace
 
-size_t sym_lin_lds_bytes(const SymGraph& sg) {
-  return ((size_t)sg.x_cap * LIN_POSE + (size_t)LIN_NV * SYM_LANES + (size_t)LIN_NV * sg.e_cap) * sizeof(double) + (size_t)sg.x_cap * sizeof(int);
-}
 size_t sym_lds_bytes(const SymGraph& sg) {
   return ((size_t)sg.x_cap * 6 + 2 * SYM_LANES * VSTRIDE) * sizeof(double);
 }
@@ -569,24 +428,6 @@ void launch_spmv_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p
     if (g.blk_packed) hipLaunchKernelGGL((k_spmv_sym<1, true>), grid, block, lds, s, g, sg, p, odd);
     else hipLaunchKernelGGL((k_spmv_sym<1, false>), grid, block, lds, s, g, sg, p, odd);
   }
-}
-
-void launch_linearize_sym(const DeviceGraph& g, const SymGraph& sg, hipStream_t s, int gate) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    const int cap = 160 * 1024 - 512;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize_sym<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize_sym<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize_sym<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_linearize_sym<3>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    attr_set = true;
-  }
-  const size_t lds = sym_lin_lds_bytes(sg);
-  const dim3 grid(sg.n_tiles), block(2 * SYM_LANES);
-  if (g.info_mode == 3) hipLaunchKernelGGL(k_linearize_sym<3>, grid, block, lds, s, g, sg, gate);
-  else if (g.info_mode == 2) hipLaunchKernelGGL(k_linearize_sym<2>, grid, block, lds, s, g, sg, gate);
-  else if (g.info_mode) hipLaunchKernelGGL(k_linearize_sym<1>, grid, block, lds, s, g, sg, gate);
-  else hipLaunchKernelGGL(k_linearize_sym<0>, grid, block, lds, s, g, sg, gate);
 }
 
 void launch_sym_repack(const DeviceGraph& g, const SymGraph& sg, hipStream_t s, int diag_only) {

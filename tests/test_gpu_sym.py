@@ -101,7 +101,7 @@ def test_lm_solve_same_answer(gpu, ds, O, repack):
     opt = dict(max_num_iterations=12, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2)
     runs = []
     # repack: the incidence-slot linearisation stays and its blocks are copied once per LM iteration (PGO_SYM_REPACK=1); otherwise the
-    # symmetric form is the session's only storage: k_linearize_sym writes it, damping / cluster preconditioner / tail and refresh
+    # symmetric form is the session's only storage: the linearisation writes it, damping / cluster preconditioner / tail and refresh
     # products read and write it
     os.environ.pop("PGO_SYM_REPACK", None)
     for on in (False, True):
@@ -120,14 +120,14 @@ def test_lm_solve_same_answer(gpu, ds, O, repack):
     assert b.final_cost == pytest.approx(osum.final_cost, rel=1e-6)
 
 
-@pytest.mark.parametrize("lin", ["lean", "rows", "tile"])
+@pytest.mark.parametrize("lin", ["lean", "rows"])
 @pytest.mark.parametrize("name", ["identity", "fat_rows", "sphere"])
 def test_lm_solve_symmetric_storage_other_graphs(gpu, ds, name, lin, monkeypatch):
     """Identity information (INFO 0), rows with many incidences (several chunks per tile, runs across wave boundaries), a mesh:
     whole LM solves with the symmetric form as the only storage against the incidence-slot kernels."""
-    # lin: which kernel writes the form — the row kernel with the lean per-incidence algebra (k_linearize_lean, the default), the row
-    # kernel with the general body and redirected block stores (k_linearize_symout, PGO_SYM_LIN=rows) or the tile kernel that evaluates
-    # an interior edge once for both rows (k_linearize_sym, PGO_SYM_LIN=tile)
+    # lin: which kernel writes the form — the row kernel with the lean per-incidence algebra (k_linearize_lean, the default) or the row
+    # kernel with the general body and redirected block stores (k_linearize_symout: information with position / rotation coupling;
+    # PGO_SYM_LIN=rows runs it on every graph)
     monkeypatch.setenv("PGO_SYM_LIN", lin)
     g = _graphs(ds)[name]
     opt = dict(max_num_iterations=10, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=1 if name == "sphere" else 2)

@@ -69,3 +69,68 @@ def test_lm_traces_of_the_two_forms_agree(O, ds):
     assert [int(x) for x in t0[:, 7]] == [int(x) for x in t1[:, 7]]            # CG iterations per LM iteration
     assert np.allclose(t0[:, 1], t1[:, 1], rtol=1e-5)       # (rejected candidates behind CG runs of hundreds of iterations: 6e-7 measured)
     assert np.abs(p0 - p1).max() < 1e-6
+
+
+def _numpy_chain_pcg(A, b, q_tol, max_it):
+    """Ceres' CG (form 0) with M = the block-tridiagonal part of A (6x6 blocks), dense numpy — independent of the C++ block-Thomas."""
+    n = len(b)
+    M = np.zeros_like(A)
+    for s in range(0, n, 6):
+        M[s:s + 6, s:s + 6] = A[s:s + 6, s:s + 6]
+        if s + 12 <= n:
+            M[s + 6:s + 12, s:s + 6] = A[s + 6:s + 12, s:s + 6]
+            M[s:s + 6, s + 6:s + 12] = A[s:s + 6, s + 6:s + 12]
+    Minv = np.linalg.inv(M)
+    x = np.zeros(n); r = b.copy(); p = np.zeros(n)
+    rho = 1.0
+    Q0 = -(x @ (b + r))
+    it = 1
+    while True:
+        z = Minv @ r
+        last, rho = rho, r @ z
+        p = z if it == 1 else z + (rho / last) * p
+        q = A @ p
+        alpha = rho / (p @ q)
+        x = x + alpha * p
+        r = b - A @ x if it % 10 == 0 else r - alpha * q
+        Q1 = -(x @ (b + r))
+        if it * (Q1 - Q0) / Q1 < q_tol or it >= max_it:
+            return x, it
+        Q0 = Q1
+        it += 1
+
+
+def test_chain_preconditioner_is_the_block_tridiagonal_part_solved_exactly(O, ds):
+    """pcg_cluster -1 (linear_solver 99): M = diagonal blocks + the blocks between consecutive poses of H + D^2, applied by a block
+    LDL^T down the chain.  Against a dense numpy statement of the same CG with M^-1 formed by np.linalg.inv: same iteration count, same
+    solution to rounding; and on a graph that IS a chain (no closures) M = A, so the CG stops at its first test with the exact solution."""
+    og, A, d2, b = _system(O, ds, 11, 1)
+    for q_tol in (0.1, 1e-3):
+        x, it = O.linear_solve(og, d2, b, linear_solver=99, q_tol=q_tol, max_it=400)
+        xn, itn = _numpy_chain_pcg(A, b, q_tol, 400)
+        assert it == itn and it < 400
+        assert np.abs(x - xn).max() <= 1e-9 * np.abs(xn).max()
+    _, it_jacobi = O.linear_solve(og, d2, b, linear_solver=1, q_tol=1e-3, max_it=400)
+    assert it < it_jacobi                                   # (41 against 77 on this mesh-like graph)
+    g = ds.manhattan_se3(200, 199, seed=4)                  # odometry only
+    assert np.array_equal(np.sort(np.abs(g.ia - g.ib)), np.ones(199, dtype=g.ia.dtype))
+    oc = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
+    d2c = np.full(6 * g.N, 0.3)
+    bc = np.random.default_rng(1).normal(size=6 * g.N)
+    xc, itc = O.linear_solve(oc, d2c, bc, linear_solver=99, q_tol=1e-6, max_it=50)
+    xe, _ = O.linear_solve(oc, d2c, bc, linear_solver=0)
+    assert itc <= 2 and np.abs(xc - xe).max() <= 1e-10 * np.abs(xe).max()
+
+
+def test_chain_preconditioner_on_the_kitti00_replay(O):
+    """What it buys where the graph is a trajectory with a few hundred closures (4541 poses, 639 loop edges): the LM solve with
+    truncated PCG (eta 0.1) takes 13 iterations like the exact steps and 1287 CG iterations in all — 2-pose Jacobi clusters: 21
+    iterations, 46 795 CG iterations — and ends at the exact path's cost to 1e-4."""
+    import os
+    k = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti00.npz"))
+    mk = lambda: O.Graph(k["origin"].copy(), k["ia"], k["ib"], k["meas"], None)
+    _, se, _ = O.solve(mk(), O.default_options(max_num_iterations=60, linear_solver=0))
+    _, sc, _ = O.solve(mk(), O.default_options(max_num_iterations=60, linear_solver=1, pcg_cluster=-1, max_linear_solver_iterations=3000))
+    assert sc.num_iterations == se.num_iterations == 13
+    assert sc.num_linear_iterations <= 3000
+    assert sc.final_cost == pytest.approx(se.final_cost, rel=2e-4)

@@ -1,6 +1,6 @@
-"""CPU: the host side of the symmetric tile form (csrc/pgo_sym_host.cpp: row partition, slot order, positions of the row ranges and
-of the exchange entries) checked without a GPU by tools/sym_check_cli, which builds the layout exactly as the library does and
-runs a scalar emulation of the two kernels that consume it against a plain sum over all incidences.  The same check run on
+"""CPU: the host side of the symmetric tile form (csrc/pgo_sym_host.cpp: row partition, slot order, positions of the row ranges)
+checked without a GPU by tools/sym_check_cli, which builds the layout exactly as the library does and
+runs a scalar emulation of the product kernel that consumes it against a plain sum over all incidences.  The same check run on
 layouts with ONE damaged entry must fail in every case — the checker checks."""
 import os
 import subprocess

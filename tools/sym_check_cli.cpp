@@ -1,9 +1,7 @@
 // tools/sym_check_cli.cpp — host-only check of the symmetric tile form's layout (csrc/pgo_sym_host.cpp): random graphs, the layout built
-// exactly as sym_prepare() builds it, and the two kernels that consume it EMULATED in scalar code on the host:
+// exactly as sym_prepare() builds it, and the kernel that consumes it EMULATED in scalar code on the host:
 //   * the product (k_spmv_sym): chunk by chunk, u = H x_col at the lane's position, v = H^T x_row at vpos, row r adds its ranges
 //     [ub, ub + uc) and [vb, vb + vc) — against a plain sum over all incidences;
-//   * the exchange layout of the tile linearisation (k_linearize_sym): every run tail and every mirrored contribution has a position,
-//     the positions of a row are one contiguous range, ranges of a chunk are disjoint and stay below e_cap.
 // plus the invariants the kernels rely on (one diagonal slot per row, an interior edge stored once in the begin orientation, a cut edge
 // twice, x indices in range, chunk bases multiples of 64).  Needs no GPU: tests/test_sym_host.py runs it in the CPU suite.
 // usage: sym_check_cli [cases] [first_seed] [damage 1..4: self-test, one damaged layout entry per case must be noticed]
@@ -66,7 +64,8 @@ static int check_case(unsigned seed) {
     if (pick == 1) L.meta[at] ^= 1u << 23;                               // another row
     else if (pick == 2) L.meta[at] ^= 1u;                                // another column
     else if (pick == 3) { size_t r = (size_t)(rng() % L.rinfo.size()); while (!L.rinfo[r]) r = (r + 1) % L.rinfo.size(); L.rinfo[r] += 1u << 8; }   // a longer u range
-    else if (pick == 4) { size_t r = at; while (L.meta2[r] >> 16 == 0xFFFF) r = (r + 1) % L.meta2.size(); L.meta2[r] += 1u << 16; }   // a mirror position moved
+    else if (pick == 4) { size_t r = at, tries = 0; while (!((L.meta[r] >> 14) & 1u) && tries++ < L.meta.size()) r = (r + 1) % L.meta.size();
+                          if (!((L.meta[r] >> 14) & 1u)) return 1; L.meta[r] ^= 1u << 15; }   // the position of a mirrored product moved
     else return 1;
   }
   int bad = 0;
@@ -123,30 +122,6 @@ static int check_case(unsigned seed) {
         for (int j = 0; j < vc; ++j) { if (!vused[vb + j]) fail("v range reads an unwritten position", r, vb + j); acc[r] += vbuf[vb + j]; }
       }
       for (int r = T.nrows; r < 256; ++r) if (L.rinfo[(size_t)ci * 256 + r]) fail("range for a lane that is no row", r);
-      // ---- exchange layout of the tile linearisation ----
-      std::vector<int> owner(L.e_cap + 1, -1);
-      for (int r = 0; r < T.nrows; ++r) {
-        const uint32_t w2 = L.rinfo2[(size_t)ci * 256 + r];
-        const int eb = w2 & 0xFFFF, ec = w2 >> 16;
-        if (eb + ec > L.e_cap) { fail("exchange range beyond e_cap", eb + ec, L.e_cap); continue; }
-        for (int j = 0; j < ec; ++j) { if (owner[eb + j] != -1) fail("exchange ranges overlap", r); owner[eb + j] = r; }
-      }
-      std::vector<int> writers(L.e_cap + 1, 0);
-      for (int l = 0; l < n; ++l) {
-        const uint32_t m = L.meta[base + l], m2 = L.meta2[base + l];
-        const int row = (m >> 23) & 0xFF, nxt_row = l + 1 < n ? (int)((L.meta[base + l + 1] >> 23) & 0xFF) : -1;
-        const bool tail = (l & 63) == 63 || l + 1 == n || nxt_row != row;
-        const int tp = m2 & 0xFFFF, vp = m2 >> 16;
-        if (tail != (tp != 0xFFFF)) fail("run tail without / with a position it should not have", l, tp);
-        if (tail && (tp > L.e_cap || owner[tp] != row)) fail("tail position not in its row's range", l, tp);
-        const bool inter = (m >> 14) & 1;
-        if (inter != (vp != 0xFFFF)) fail("mirrored contribution without / with a position", l, vp);
-        if (inter && (vp > L.e_cap || owner[vp] != (int)(m & 0xFFF))) fail("mirror position not in the destination row's range", l, vp);
-        if (tail && tp <= L.e_cap) ++writers[tp];
-        if (inter && vp <= L.e_cap) ++writers[vp];
-      }
-      for (int q = 0; q < L.e_cap; ++q)       // a position a row sums is written exactly once; nothing is written outside the ranges
-        if (writers[q] != (owner[q] != -1)) fail("exchange position written 0 or 2 times / outside a range", q, writers[q]);
     }
     for (int r = 0; r < T.nrows; ++r) y[L.xlist[T.x0 + r]] = acc[r];
   }
