@@ -117,7 +117,9 @@ __device__ __forceinline__ void lean_slot(const DeviceGraph& g, const LeanIdx& c
   sink.store = edge && c1.dst >= 0 && !PGO_ABLATION(g, 2);      // (bit 2: timing ablation, no block stores)
   const int d0 = sink.store ? c1.dst : 0;
   sink.val = TO_BSR ? g.bsr_val : g.sym_val;
-  sink.nt = !TO_BSR;        // (the form of a large graph is written once and next read from HBM; the BSR of a resident-stream session is read back within microseconds)
+  // (the form or the BSR of a large graph is written once and next read from HBM: nontemporal; the BSR of a universal-stream session —
+  // at most 600 k slots, pgo_lm.cpp universal_wanted — is read back within microseconds: plain stores)
+  sink.nt = !TO_BSR || g.n_slots > 600000;
   sink.off = (unsigned)(d0 >> 6) * (unsigned)(TILE_DOUBLES * sizeof(double)) + (unsigned)(d0 & 63) * 16u;      // (launch_linearize_lean: the form is below 4 GiB)
   lean_incidence<INFO>(begin, pa, qa, pb, qb, V3{c2.ms[0], c2.ms[1], c2.ms[2]}, Q4{c2.ms[3], c2.ms[4], c2.ms[5], c2.ms[6]}, c2.wp, c2.wr, so, st, mo,
                        g.loss_kind, g.loss_a, sink);

@@ -1,6 +1,7 @@
 // pgo_sym_kernels.hip — block SpMV from the symmetric tile form (pgo_sym.h): every interior off-diagonal block is read once and
 // used for both of its rows.  gfx950, FP64, HBM-bound: the only streams are the blocks (14 or 18 x 16 B per lane, 1 KiB per wave
 // instruction, prefetched one chunk ahead) and 4 + 2 bytes of indices per slot; the vectors live in LDS.
+#include "pgo_math.h"
 #include "pgo_sym.h"
 #include "pgo_wave.h"
 

@@ -51,7 +51,9 @@ def test_latest_round_extras_are_consistent():
         assert abs(k["speedup_vs_cpu_restatement_1_core"] - k["cpu_restatement_wall_ms"] / k["wall_ms_median_of_5"]) < 0.02
         assert k["speedup_vs_cpu_restatement_1_core"] >= 10.0            # north_star: >= 10x end to end on KITTI-00-scale graphs
     b = d["kitti00_batch16"]
-    assert b["final_cost_spread"] == 0.0 and abs(b["final_cost"] - d["kitti00_exact"]["final_cost"]) < 1e-9
+    # (copies of one graph inside a batch agree to the rounding of the linearisation's pair sums — where a row's lane pairs fall depends on
+    # the parity of its first slot inside the union: 2.4e-14 measured on a cost of 3.69 — and with the single solve)
+    assert b["final_cost_spread"] <= 1e-12 and abs(b["final_cost"] - d["kitti00_exact"]["final_cost"]) < 1e-9
     assert b["throughput_vs_one_at_a_time"] > 3.0
     m = d["multifrontal_exact_solver"]
     assert all(v["linear_solver_used"] == 0 for v in m.values()) and set(m) == {"c2_manhattan_10k_40k", "c5_sphere_x10_25k_250k"}

@@ -26,7 +26,7 @@ for name, g in cases:
     prob.solver_step(2)
     out = []
     for k, nbytes in (("linearize", 640 * E + 392 * N), ("pcg_spmv", (N + E) * 288 + 2 * N * 48), ("sym_spmv", (N + E) * 288 + 2 * N * 48),
-                      ("sym_repack", (N + E) * 288 * 2), ("sym_linearize_rows", 640 * E + 392 * N), ("sym_linearize_lean", 640 * E + 392 * N), ("evaluate", 976 * E + 56 * N)):
+                      ("sym_linearize_rows", 640 * E + 392 * N), ("sym_linearize_lean", 640 * E + 392 * N), ("evaluate", 976 * E + 56 * N)):
         reps = 50 if name == "c4" else 300
         t = min(prob.time_kernel(k, reps) for _ in range(3))
         out.append("%s %.1f us %.0f GB/s frac %.3f" % (k, t * 1e3, nbytes / (t * 1e-3) / 1e9, nbytes / (t * 1e-3) / 1e9 / 8000.0))
