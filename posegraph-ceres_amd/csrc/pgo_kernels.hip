@@ -2758,18 +2758,15 @@ void launch_uni_r(const DeviceGraph& g, const CgParams& p, int launch, double mi
                             else hipLaunchKernelGGL((k_res_cg<PK, 1>), grid, blk, lds, s, g, p, launch); } while (0)
     if (g.blk_packed) PGO_RES_CG(true); else PGO_RES_CG(false);
 #undef PGO_RES_CG
-  } else if (g.info_mode != 1 && g.blk_packed && (long long)g.n_slots < 14000000LL && (long long)g.N < 60000000LL) {
-    // (information without position / rotation coupling, packed slots, 32-bit byte offsets: what linearize_lean_fits asks for)
+  } else if (g.info_mode != 1) {
+    // (information without position / rotation coupling: packed slots; 32-bit byte offsets are what uni_supported() admitted the graph on)
     const size_t lds = (size_t)LEAN_NV * (g.block / 2) * sizeof(double);
     if (g.info_mode == 3) hipLaunchKernelGGL(k_res_lin_lean<3>, grid, blk, lds, s, g, launch);
     else if (g.info_mode == 2) hipLaunchKernelGGL(k_res_lin_lean<2>, grid, blk, lds, s, g, launch);
     else hipLaunchKernelGGL(k_res_lin_lean<0>, grid, blk, lds, s, g, launch);
   } else {
     const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);
-    if (g.info_mode == 3) hipLaunchKernelGGL(k_res_lin<3>, grid, blk, lds, s, g, launch);
-    else if (g.info_mode == 2) hipLaunchKernelGGL(k_res_lin<2>, grid, blk, lds, s, g, launch);
-    else if (g.info_mode) hipLaunchKernelGGL(k_res_lin<1>, grid, blk, lds, s, g, launch);
-    else hipLaunchKernelGGL(k_res_lin<0>, grid, blk, lds, s, g, launch);
+    hipLaunchKernelGGL(k_res_lin<1>, grid, blk, lds, s, g, launch);      // the general body: information with position / rotation coupling
   }
 }
 void launch_uni_f(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s) {
