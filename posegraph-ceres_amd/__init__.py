@@ -105,9 +105,17 @@ def build(force=False):
     src = os.path.join(_HERE, "csrc")
     deps = [os.path.join(src, f) for f in os.listdir(src) if os.path.isfile(os.path.join(src, f))]
     deps.append(os.path.join(_HERE, "..", "include", "pgo.h"))
-    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps)
-    if force or stale:
+    def stale():
+        return (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps)
+    if force or stale():
         subprocess.check_call(["make", "-j8", "-C", src] + (["-B"] if force else []))
+        # make can answer "up to date" while a source is newer than the library: a header named in the Makefile that no longer exists
+        # switches its pattern rules off without a word (r05: the library silently stopped rebuilding).  Rebuild everything once, and
+        # refuse to hand out a library older than its sources.
+        if stale():
+            subprocess.check_call(["make", "-j8", "-B", "-C", src])
+        if stale():
+            raise RuntimeError("%s is older than its sources after make -B: check the HDRS list of csrc/Makefile" % LIB_PATH)
     return LIB_PATH
 
 
