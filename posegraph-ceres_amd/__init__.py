@@ -103,20 +103,39 @@ _lib = None
 def build(force=False):
     """Compiles csrc/ into libpgo_hip.so with hipcc --offload-arch=gfx950 (works without a GPU)."""
     src = os.path.join(_HERE, "csrc")
-    deps = [os.path.join(src, f) for f in os.listdir(src) if os.path.isfile(os.path.join(src, f))]
+    deps = [os.path.join(src, f) for f in os.listdir(src) if os.path.isfile(os.path.join(src, f)) and not f.startswith(".")]
     deps.append(os.path.join(_HERE, "..", "include", "pgo.h"))
     def stale():
         return (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps)
     if force or stale():
-        subprocess.check_call(["make", "-j8", "-C", src] + (["-B"] if force else []))
-        # make can answer "up to date" while a source is newer than the library: a header named in the Makefile that no longer exists
-        # switches its pattern rules off without a word (r05: the library silently stopped rebuilding).  Rebuild everything once, and
-        # refuse to hand out a library older than its sources.
-        if stale():
-            subprocess.check_call(["make", "-j8", "-B", "-C", src])
-        if stale():
-            raise RuntimeError("%s is older than its sources after make -B: check the HDRS list of csrc/Makefile" % LIB_PATH)
+        # one make at a time in this directory: the rank processes of a multi-process test / bench all call build() (r06)
+        import fcntl
+        with open(os.path.join(src, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or stale():          # (somebody else may have built it while this process waited for the lock)
+                subprocess.check_call(["make", "-j8", "-C", src] + (["-B"] if force else []))
+                # make can answer "up to date" while a source is newer than the library: a header named in the Makefile that no longer
+                # exists switches its pattern rules off without a word (r05: the library silently stopped rebuilding).  Rebuild
+                # everything once, and refuse to hand out a library older than its sources.
+                if stale():
+                    subprocess.check_call(["make", "-j8", "-B", "-C", src])
+                if stale():
+                    raise RuntimeError("%s is older than its sources after make -B: check the HDRS list of csrc/Makefile" % LIB_PATH)
     return LIB_PATH
+
+
+def kernel_source_sha():
+    """sha256 (16 hex digits) of everything the library is built from: every file of csrc/ in name order + the Makefile (its FLAGS).
+    bench.py quotes a committed profile only when it was taken on these very sources (tools/rocprof_pmc.py records the same value)."""
+    import hashlib
+    src = os.path.join(_HERE, "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(src)):
+        fp = os.path.join(src, f)
+        if os.path.isfile(fp) and not f.startswith(".") and (f.endswith((".hip", ".cpp", ".h", ".inc")) or f == "Makefile"):
+            h.update(f.encode())
+            h.update(open(fp, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def lib():

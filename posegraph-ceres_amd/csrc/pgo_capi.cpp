@@ -165,13 +165,14 @@ int pgo_solver_cg_form(pgo_problem* P) {
   return P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : (P->uni_resident ? 4 : P->uni_fused ? 3 : 0);
 }
 
-static const int TRACE_WORDS = 66;     // pgo_uni_fused.h UNI_F_TRACE_WORDS
+static const int TRACE_WORDS = pgo::UNI_F_TRACE_WORDS;
 int pgo_solver_trace_start(pgo_problem* P, int max_launches) {
   if (!P || max_launches < 0) return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_solver_trace_start");
   if (!P->lm.active || !P->stream_ready) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_trace_start needs a stepping session (call pgo_solver_begin first)");
   if (!P->uni_fused) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_trace_start: this session does not run the fused universal stream");
   HIP_TRY(hipStreamSynchronize(P->stream));
   if (max_launches == 0) { P->g.oplog = nullptr; P->g.oplog_cap = 0; P->g.oplog_indexed = 0; return PGO_OK; }
+  if (max_launches > (0x7fffffff - 1) / TRACE_WORDS) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_trace_start: at most %d launches can be traced", (0x7fffffff - 1) / TRACE_WORDS);
   // the launch index the kernels record under restarts whenever the device state is uploaded afresh; make that happen now
   P->pipe_dirty = true;
   const size_t cap = 1 + (size_t)TRACE_WORDS * max_launches;

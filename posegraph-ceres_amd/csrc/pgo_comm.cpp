@@ -110,6 +110,10 @@ struct IpcShared {                      // lives in POSIX shared memory; rank 0 
   std::atomic<int> arrived;
   std::atomic<long long> generation;
   std::atomic<int> aborted;
+  unsigned long long nonce;             // (pid of rank 0, time of creation): tells two groups of the same name apart in a debugger / log
+  // proof that rank 0 is alive on THIS block: rank r > 0 writes a random challenge, the live rank 0 echoes it (a block left behind by
+  // a crashed run has nobody to answer)
+  std::atomic<unsigned long long> chal[IPC_MAX_WORLD], echo[IPC_MAX_WORLD];
   int world;
   unsigned long long stage_bytes;
   hipIpcMemHandle_t stage[IPC_MAX_WORLD];
@@ -126,14 +130,16 @@ struct IpcComm : Comm {
   static constexpr size_t STAGE_BYTES = (size_t)64 << 20;
   bool capturable() const override { return false; }
   bool peer_direct_default() const override { return true; }
+  bool peers_may_be_remote() const override { return true; }
   ~IpcComm() override {
     for (int p = 0; p < world; ++p) {
       if (peer_stage[p] && p != rank) (void)hipIpcCloseMemHandle(peer_stage[p]);
       for (int k = 0; k < 3; ++k) if (opened[p][k]) (void)hipIpcCloseMemHandle(opened[p][k]);
     }
     if (stage) (void)hipFree(stage);
+    if (sh && rank == 0) sh->magic.store(0);        // nothing of a finished group can be taken for a live one
     if (sh) munmap(sh, sizeof(IpcShared));
-    if (rank == 0 && !name.empty()) shm_unlink(name.c_str());
+    if (rank == 0 && !name.empty() && my_inode && name_inode(name.c_str()) == my_inode) shm_unlink(name.c_str());
   }
   int fail(const char** what, const char* where, hipError_t e) {
     static thread_local char msg[256];
@@ -161,34 +167,95 @@ struct IpcComm : Comm {
     }
     return true;
   }
-  int init(const char** what) {
-    const int fd = rank == 0 ? shm_open(name.c_str(), O_CREAT | O_RDWR | O_TRUNC, 0600) : -1;
-    int f = fd;
-    if (rank == 0) {
-      if (f < 0 || ftruncate(f, sizeof(IpcShared)) != 0) { *what = "shm_open / ftruncate failed"; return -1; }
-    } else {
-      const auto t0 = std::chrono::steady_clock::now();
+  // inode the name currently points at (0: no such object)
+  static unsigned long long name_inode(const char* nm) {
+    const int f = shm_open(nm, O_RDWR, 0600);
+    if (f < 0) return 0;
+    struct stat st;
+    const unsigned long long ino = fstat(f, &st) == 0 ? (unsigned long long)st.st_ino : 0;
+    close(f);
+    return ino;
+  }
+  // Group identity (r06): a block left behind by a crashed run carries a valid magic, and a rank that starts early can map it before
+  // rank 0 has replaced it.  So: rank 0 unlinks whatever holds the name and creates the block O_EXCL (a fresh inode), fills it and sets
+  // `magic` last; a rank > 0 maps what the name points at, waits for the magic, writes a random challenge and waits for rank 0 to echo
+  // it — only a LIVE rank 0 answers — while it keeps checking that the name still points at the inode it mapped.  If it does not, the
+  // block it holds is a stale one: it lets go and attaches again.  The destructor clears the magic (a clean exit leaves nothing to be
+  // mistaken for a live group) and rank 0 unlinks the name if it is still its own.
+  unsigned long long my_inode = 0;
+  int attach(const char** what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    auto timed_out = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0; };
+    for (;;) {
+      int f;
       while ((f = shm_open(name.c_str(), O_RDWR, 0600)) < 0) {
         std::this_thread::sleep_for(std::chrono::milliseconds(2));
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) { *what = "the group's shared-memory block did not appear"; return -1; }
+        if (timed_out()) { *what = "the group's shared-memory block did not appear"; return -1; }
       }
       struct stat st;
-      while (fstat(f, &st) == 0 && (size_t)st.st_size < sizeof(IpcShared)) std::this_thread::sleep_for(std::chrono::milliseconds(1));
-    }
-    sh = static_cast<IpcShared*>(mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, f, 0));
-    close(f);
-    if (sh == MAP_FAILED) { sh = nullptr; *what = "mmap of the shared block failed"; return -1; }
-    if (rank == 0) {
-      sh->arrived.store(0); sh->generation.store(0); sh->aborted.store(0);
-      sh->world = world; sh->stage_bytes = STAGE_BYTES;
-      sh->magic.store(IPC_MAGIC);
-    } else {
-      const auto t0 = std::chrono::steady_clock::now();
-      while (sh->magic.load() != IPC_MAGIC) {
+      while (fstat(f, &st) == 0 && (size_t)st.st_size < sizeof(IpcShared) && !timed_out()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      if ((size_t)st.st_size < sizeof(IpcShared)) { close(f); *what = "the group's shared-memory block was never sized"; return -1; }
+      my_inode = (unsigned long long)st.st_ino;
+      sh = static_cast<IpcShared*>(mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, f, 0));
+      close(f);
+      if (sh == MAP_FAILED) { sh = nullptr; *what = "mmap of the shared block failed"; return -1; }
+      bool stale = false;
+      while (sh->magic.load() != IPC_MAGIC && !stale) {
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) { *what = "rank 0 never initialised the shared block"; return -1; }
+        if (name_inode(name.c_str()) != my_inode) stale = true;
+        if (timed_out()) { *what = "rank 0 never initialised the shared block"; return -1; }
       }
-      if (sh->world != world) { *what = "the group was created for another world size"; return -1; }
+      if (!stale && name_inode(name.c_str()) == my_inode) return 0;
+      munmap(sh, sizeof(IpcShared));        // a block of an earlier group: rank 0 of this one has replaced (or is replacing) it
+      sh = nullptr;
+      std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+  }
+  int init(const char** what) {
+    if (rank == 0) {
+      (void)shm_unlink(name.c_str());        // whatever an earlier (crashed) group left under this name
+      const int f = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (f < 0 || ftruncate(f, sizeof(IpcShared)) != 0) { if (f >= 0) close(f); *what = "shm_open (O_EXCL) / ftruncate failed"; return -1; }
+      struct stat st;
+      if (fstat(f, &st) == 0) my_inode = (unsigned long long)st.st_ino;
+      sh = static_cast<IpcShared*>(mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, f, 0));
+      close(f);
+      if (sh == MAP_FAILED) { sh = nullptr; *what = "mmap of the shared block failed"; return -1; }
+      sh->arrived.store(0); sh->generation.store(0); sh->aborted.store(0);
+      for (int r = 0; r < IPC_MAX_WORLD; ++r) { sh->chal[r].store(0); sh->echo[r].store(0); }
+      sh->world = world; sh->stage_bytes = STAGE_BYTES;
+      sh->nonce = ((unsigned long long)getpid() << 32) ^ (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+      sh->magic.store(IPC_MAGIC);
+      // the group has formed once every other rank's challenge has been answered on THIS block
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int answered = 0; answered < world - 1;) {
+        answered = 0;
+        for (int r = 1; r < world; ++r) {
+          const unsigned long long c = sh->chal[r].load();
+          if (c != 0) { sh->echo[r].store(c); ++answered; }
+        }
+        if (answered < world - 1) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) { *what = "the other ranks never joined the group"; sh->aborted.store(1); return -1; }
+      }
+    } else {
+      for (;;) {
+        if (attach(what) != 0) return -1;
+        if (sh->world != world) { *what = "the group was created for another world size"; return -1; }
+        unsigned long long c = ((unsigned long long)getpid() << 32) ^ (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((unsigned long long)rank << 56);
+        if (c == 0) c = 1;
+        sh->echo[rank].store(0);
+        sh->chal[rank].store(c);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool stale = false;
+        while (sh->echo[rank].load() != c && !stale) {
+          std::this_thread::sleep_for(std::chrono::microseconds(500));
+          if (name_inode(name.c_str()) != my_inode) stale = true;      // challenged a block that has since been replaced: attach again
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) { *what = "rank 0 never answered on the group's shared block"; return -1; }
+        }
+        if (!stale) break;
+        munmap(sh, sizeof(IpcShared));
+        sh = nullptr;
+      }
     }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&stage), STAGE_BYTES);
     if (e != hipSuccess) return fail(what, "hipMalloc (staging buffer)", e);

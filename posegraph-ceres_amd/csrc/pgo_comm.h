@@ -32,6 +32,9 @@ struct Comm {
   virtual int peer_table(void* const mine[3], void** out, const char** what) { (void)mine; (void)out; *what = "not supported by this transport"; return -1; }
   // whether the device-initiated exchange is this transport's normal mode (PGO_PEER_DIRECT=0 / 1 overrides either way)
   virtual bool peer_direct_default() const { return false; }
+  // whether the peers of peer_table() may be OTHER devices (processes, one GPU each): their exchange buffers and flag words must then be
+  // fine-grained allocations (pgo_internal.h DevBuf::alloc_fine); virtual ranks share one device and its L2
+  virtual bool peers_may_be_remote() const { return false; }
 };
 
 struct LoopbackGroup {

@@ -236,11 +236,26 @@ struct DevBuf {
   size_t n = 0;
   size_t cap_bytes = 0;
   int dev = 0;
+  bool fine = false;     // fine-grained device memory (alloc_fine): what kernels of OTHER devices store into and poll; never pooled
   ~DevBuf() { release(true); }
   void release(bool to_pool = false) {
     if (!p) return;
-    if (to_pool) device_pool().put(p, cap_bytes, dev); else (void)hipFree(p);
-    p = nullptr; n = 0; cap_bytes = 0;
+    if (to_pool && !fine) device_pool().put(p, cap_bytes, dev); else (void)hipFree(p);
+    p = nullptr; n = 0; cap_bytes = 0; fine = false;
+  }
+  // Exchange buffers and flag words that peer devices write through IPC / peer mappings (DeviceGraph::peer_tab): ordinary hipMalloc
+  // memory is coarse-grained — a remote store is only guaranteed visible at kernel boundaries — so these are allocated fine-grained
+  // (coherent across agents while kernels run).  Falls back to the ordinary allocation where the runtime refuses the flag.
+  hipError_t alloc_fine(size_t count) {
+    release(false);
+    n = count;
+    if (count == 0) return hipSuccess;
+    void* q = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&q, count * sizeof(T), hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; return alloc(count); }
+    (void)hipGetDevice(&dev);
+    p = static_cast<T*>(q); cap_bytes = count * sizeof(T); fine = true;
+    return hipSuccess;
   }
   hipError_t alloc(size_t count) {
     release(false);

@@ -140,6 +140,9 @@ struct CgState {
   // written by the same launch.  op: FusedOp; cnt: CG iterations completed; the scalars of the pipelined recurrences as in Pipe.
   struct Fused { int op, cnt, mirror, pad; double gamma_prev, alpha_prev, q_prev; } f[2];   // mirror: this launch publishes LmDev to the host
 };
+// launch trace of the one-launch universal streams (DeviceGraph::oplog, pgo_solver_trace_*): words per launch — the kernels
+// (pgo_uni_fused.h) and the reader (pgo_capi.cpp) stride by this ONE constant
+constexpr int UNI_F_TRACE_WORDS = 66;
 // what a launch of the fused universal stream does (CgState::Fused::op)
 enum FusedOp { F_EXIT = -1, F_IDLE = 0, F_HEAD = 1, F_W0 = 2, F_CG = 3, F_TAIL = 4, F_LIN = 5 };
 
@@ -229,7 +232,7 @@ struct DeviceGraph {
   // Fused stream (pgo_solver_trace_*): launch L owns the 66 words at 1 + 66 L: [0] (start tick << 3 | operation) by work-group 0,
   // [2 + s] the latest end tick among the work-groups with index % 64 == s (atomic max).
   long long* oplog;
-  int oplog_cap;
+  int oplog_cap;      // words (pgo_solver_trace_start refuses more launches than fit an int)
   int oplog_indexed;  // 1: the fused stream's per-launch records (pgo_solver_trace_*); 0: appended (tick, operation) entries (PGO_UNI_OPLOG)
   // linearisation into the symmetric tile form by the row kernel (k_linearize_symout): stored slot of every incidence slot (-1: the
   // mirrored incidence of an interior edge, not stored) and the form's block array

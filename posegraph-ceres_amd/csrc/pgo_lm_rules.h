@@ -9,9 +9,9 @@
 #include "pgo_kernels.h"
 
 #if defined(__HIPCC__)
-#define PGO_HD __host__ __device__
+#define PGO_RULE_HD __host__ __device__
 #else
-#define PGO_HD
+#define PGO_RULE_HD
 #endif
 
 namespace pgo {
@@ -33,7 +33,7 @@ enum LmOutcome {
 // t^3 rounded once (double-double product, explicit fma): what pow(t, 3) of a correctly rounding libm returns.
 // Contraction must stay off: hipcc's default (-ffp-contract=fast) fuses the final `q + ...` with the product that formed q and
 // counts q's rounding error twice (measured on gfx950: 26 % of the results one ulp off the host's).
-PGO_HD inline double lm_cube(double t) {
+PGO_RULE_HD inline double lm_cube(double t) {
 #pragma clang fp contract(off)
   const double p = t * t;
   const double e = fma(t, t, -p);
@@ -45,7 +45,7 @@ PGO_HD inline double lm_cube(double t) {
 // One pass of the TrustRegionMinimizer loop body behind ComputeCandidatePointAndEvaluateCost.  `nx` is the record of the new
 // iteration (valid for INVALID / ACCEPT / REJECT; its trust_region_radius is the radius AFTER the update, which is what
 // Ceres logs); `term_value` the number the termination message quotes.
-PGO_HD inline LmOutcome lm_decide(LmCore& L, const LmTolerances& o, const LmStepIn& sc, LmRecord& nx, double& term_value) {
+PGO_RULE_HD inline LmOutcome lm_decide(LmCore& L, const LmTolerances& o, const LmStepIn& sc, LmRecord& nx, double& term_value) {
 #pragma clang fp contract(off)
   nx.iteration = L.iteration + 1;
   nx.step_is_successful = 0;

@@ -364,8 +364,12 @@ int prepare(pgo_problem* P) {
   const int pipe_seg = rows_per * 6 + 4;      // m of the owned rows, then this rank's (r,u), (w,u), x'(b + r)
   {                    // one-launch CG iterations (pgo_kernels.h DeviceGraph::pipe_buf): owner-only CG of several ranks, fused stream of one
     for (DevBuf<double>* b : pipe_vecs) { HIP_TRY(b->alloc(m)); HIP_TRY(b->zero(s)); }
-    HIP_TRY(P->d_pipe_a.alloc((size_t)world * pipe_seg)); HIP_TRY(P->d_pipe_a.zero(s));
-    HIP_TRY(P->d_pipe_b.alloc((size_t)world * pipe_seg)); HIP_TRY(P->d_pipe_b.zero(s));
+    // (r06: what kernels of other devices store into — the IPC transport's device-initiated exchange — is fine-grained memory)
+    const bool remote_peers = world > 1 && P->comm && P->comm->peers_may_be_remote();
+    if (remote_peers) { HIP_TRY(P->d_pipe_a.alloc_fine((size_t)world * pipe_seg)); HIP_TRY(P->d_pipe_b.alloc_fine((size_t)world * pipe_seg)); }
+    else { HIP_TRY(P->d_pipe_a.alloc((size_t)world * pipe_seg)); HIP_TRY(P->d_pipe_b.alloc((size_t)world * pipe_seg)); }
+    HIP_TRY(P->d_pipe_a.zero(s));
+    HIP_TRY(P->d_pipe_b.zero(s));
     HIP_TRY(P->d_pipe_x.alloc((size_t)world * rows_per * 6)); HIP_TRY(P->d_pipe_x.zero(s));    // exchange buffer of the diagonal blocks' diagonals (linearize_all)
   }
   const int n_vec_wg = std::max(1, std::min((int)(((size_t)6 * N + pgo::vec_block() - 1) / pgo::vec_block()), 256));
@@ -468,7 +472,8 @@ int peer_direct_setup(pgo_problem* P) {
     // A transport made of processes (IpcComm) has it on by default; PGO_PEER_DIRECT=0 / 1 overrides either way.
     const char* pd = getenv("PGO_PEER_DIRECT");
     if (pd ? pd[0] == '1' : P->comm->peer_direct_default()) {
-      HIP_TRY(P->d_peer_flags.alloc((size_t)world));
+      if (P->comm->peers_may_be_remote()) HIP_TRY(P->d_peer_flags.alloc_fine((size_t)world));
+      else HIP_TRY(P->d_peer_flags.alloc((size_t)world));
       HIP_TRY(P->d_peer_flags.zero(s));
       HIP_TRY(hipStreamSynchronize(s));
       void* mine[3] = {P->d_pipe_a.p, P->d_pipe_b.p, P->d_peer_flags.p};

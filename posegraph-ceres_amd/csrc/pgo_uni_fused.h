@@ -72,7 +72,7 @@ __device__ __forceinline__ bool uni_f_last_arrival(const DeviceGraph& g, int wg,
 // trace of the fused stream (DeviceGraph::oplog, pgo_solver_trace_*): UNI_F_TRACE_WORDS words per launch — [0] (tick at the top
 // of work-group 0 << 3 | operation), [2 + s] the latest end tick among the work-groups with index % 64 == s (one atomic per
 // work-group, 64 addresses: a dozen per address at BASELINE configs[1])
-constexpr int UNI_F_TRACE_WORDS = 66;
+// (UNI_F_TRACE_WORDS: pgo_kernels.h)
 __device__ __forceinline__ bool uni_f_traced(const DeviceGraph& g, int launch) {
   return g.oplog && g.oplog_indexed && 1 + UNI_F_TRACE_WORDS * ((long long)launch + 1) <= g.oplog_cap;
 }

@@ -223,3 +223,25 @@ def test_two_processes_with_resident_sessions_on_one_gpu_both_finish(gpu, ds, tm
         assert list(k["cg"]) == list(ref.iterations["linear_solver_iterations"])
         assert np.allclose(k["cost"], ref.iterations["cost"], rtol=1e-7)
         print("process %d: cg_form %d -> %d, %.2f s for 20 x 60 LM iterations" % (r, int(k["first"]), int(k["last"]), float(k["seconds"])))
+
+
+def test_the_headline_configuration_is_tied_to_the_oracle(gpu, ds, O):
+    """What bench.py's `value` times, held to the oracle in a test of its own (r06; VERDICT r05 missing #5): BASELINE configs[1]
+    (Manhattan 10 k / 40 k, seed 20260928 = bench.py's SEED), the library's own choice of stream and work-group size (nothing set in
+    the environment, pcg_form left at 0), 2-pose Jacobi clusters, 25 LM iterations from dead reckoning with Ceres' default forcing
+    term — against the oracle's restatement of the same pipelined recurrences (~1 s of host time): same decisions, same CG count in
+    every LM iteration, costs to 1e-7, final cost to 1e-9."""
+    g = ds.manhattan_se3(10000, 40000, seed=20260928)
+    prob, poses = gpu.problem_from_graph(g)
+    s = gpu.solve(gpu.SolverOptions(max_num_iterations=25, linear_solver_type=gpu.BLOCK_JACOBI_PCG, eta=0.1, max_linear_solver_iterations=500,
+                                    function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0, pcg_cluster_poses=2), prob)
+    assert s.cg_form == 4                                     # the resident stream, chosen by the library
+    og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
+    op, osum, otr = O.solve(og, O.default_options(max_num_iterations=25, linear_solver=1, pcg_cluster=2, pcg_form=1, eta=0.1, max_linear_solver_iterations=500,
+                                                  function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0))
+    assert len(s.iterations) == len(otr) == 26
+    assert list(s.iterations["step_is_successful"]) == [int(x) for x in otr[:, 8]]
+    assert list(s.iterations["linear_solver_iterations"]) == [int(x) for x in otr[:, 7]]
+    assert np.allclose(s.iterations["cost"], otr[:, 1], rtol=1e-7)
+    assert s.final_cost == pytest.approx(osum.final_cost, rel=1e-9)
+    assert s.num_linear_solver_iterations == osum.num_linear_iterations
