@@ -616,6 +616,8 @@ def main():
         # (above 600 k BSR slots a PCG session on one rank keeps the normal equations in the symmetric tile form, csrc/pgo_sym.h: the
         # *_sym kernels are the ones its LM loop runs; the incidence-slot kernels are what several ranks and smaller graphs run)
         for key, kern, nbytes, reps4 in (("k_evaluate_edges", "evaluate", 976 * E4 + 56 * N4, 30),
+                                         ("k_pipe_cg_sym (r06: ONE launch per CG iteration of this session — product from the symmetric form, the eight vector recurrences, the Jacobi blocks; + its one-work-group fold)",
+                                          "sym_pipe_cg", (N4 + E4) * 288 + 2 * N4 * 48 + 10 * N4 * 48 + N4 * 36 * args.cluster * 8, 96),
                                          ("k_spmv_sym<0> (CG product, every interior block read once)", "sym_spmv", (N4 + E4) * 288 + 2 * N4 * 48, 100),
                                          ("k_linearize_lean (the row kernel with the hand-reduced algebra writing the symmetric form: what the session's LM loop runs)", "sym_linearize_lean", 640 * E4 + 392 * N4, 50),
                                          ("k_linearize_symout (the general body writing the symmetric form, PGO_SYM_LIN=rows)", "sym_linearize_rows", 640 * E4 + 392 * N4, 50),

@@ -28,7 +28,7 @@ extern "C" {
  * *_reduced fields in r02).  pgo_solve / pgo_solver_end / pgo_solve_batch write sizeof(pgo_solver_summary) bytes: a caller must
  * check pgo_version() == PGO_VERSION of the header it was compiled against before handing structs over (the facade's
  * ceres::Solve does, include/ceres/solver.h). */
-#define PGO_VERSION 102
+#define PGO_VERSION 103
 
 /* The library is built with -fvisibility=hidden: these entry points are all it exports. */
 #if defined(__GNUC__)
@@ -140,13 +140,17 @@ typedef struct pgo_solver_summary {
   int num_parameters_reduced;
   int num_effective_parameters_reduced;
   int cg_form;                  /* CG of the PCG solves: 0 one rank, standard CG (two-kernel universal stream / batches), 1 several ranks,
-                                   replicated standard CG (every rank updates every row, q all-gathered per iteration), 2 several ranks,
-                                   owner-only pipelined CG (every rank updates its own rows, one all-gather per iteration), 3 one rank,
+                                   replicated standard CG (every rank updates every row, q all-gathered per iteration), 2 owner-only
+                                   pipelined CG, one launch per iteration (several ranks: every rank updates its own rows, one all-gather per
+                                   iteration; one rank: the same kernel on the symmetric tile form, graphs above the universal stream's size limit), 3 one rank,
                                    pipelined CG in the fused universal stream (one launch per CG iteration), 4 one rank, the same CG resident in one
                                    launch per LM iteration (grid barrier per CG iteration) */
   int cg_exchange;              /* how the ranks' CG exchanged their segments: 0 nothing to exchange (one rank), 1 a host-enqueued collective
                                    per CG iteration (RCCL all-gather, loopback copies), 2 by the kernels themselves (peer table: stores
                                    into every rank's buffer + flags; the IPC transport's normal mode) */
+  int sym_form;                 /* 1: the session kept the normal equations in the symmetric tile form (every interior off-diagonal block stored
+                                   and read once; graphs above 600 k incidence slots, on one rank or row-sharded over several), 0: incidence-slot blocks */
+  int reserved_summary;
 } pgo_solver_summary;
 
 /* One row per iteration, the numbers Summary::FullReport() tabulates with

@@ -80,7 +80,7 @@ class _CSummary(C.Structure):
         ("final_trust_region_radius", C.c_double), ("message", C.c_char * 256),
         ("factor_kind", C.c_int), ("factor_max_front", C.c_int), ("factor_flops", C.c_double),
         ("num_parameter_blocks_reduced", C.c_int), ("num_parameters_reduced", C.c_int), ("num_effective_parameters_reduced", C.c_int),
-        ("cg_form", C.c_int), ("cg_exchange", C.c_int),
+        ("cg_form", C.c_int), ("cg_exchange", C.c_int), ("sym_form", C.c_int), ("reserved_summary", C.c_int),
     ]
 
 

@@ -162,7 +162,7 @@ int pgo_plus(pgo_problem* P, const double* delta) {
 
 int pgo_solver_cg_form(pgo_problem* P) {
   if (!P || !P->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_cg_form needs a stepping session (call pgo_solver_begin first)");
-  return P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : (P->uni_resident ? 4 : P->uni_fused ? 3 : 0);
+  return P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : (P->uni_resident ? 4 : P->uni_fused ? 3 : pipe_mode(P, cg_params_for(P->opt)) ? 2 : 0);
 }
 
 static const int TRACE_WORDS = pgo::UNI_F_TRACE_WORDS;
@@ -322,6 +322,34 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
       its = std::max(1, cs.iters);
     }
     *avg_ms = total / repeats / its;
+    return PGO_OK;
+  }
+  if (k == "sym_pipe_cg") {
+    // one iteration of the pipelined CG on the symmetric tile form (k_pipe_cg_sym + its fold) in situ: groups of 16 consecutive
+    // iterations of a freshly started CG with the stopping tests off, HIP events on the solver stream around each group
+    if (!P->sym_storage || !pipe_mode(P, prm)) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('sym_pipe_cg'): this session does not run the pipelined CG on the symmetric form");
+    if (P->g.world > 1) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_time_kernel('sym_pipe_cg'): one rank only (no exchange is enqueued here)");
+    pgo::CgParams np{-1.0, -1.0, 1 << 30, 0};
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    pgo::launch_damping(sym_view(P), P->lm.radius, P->opt.min_lm_diagonal, P->opt.max_lm_diagonal, 0, s);
+    const int group = 16, groups = std::max(1, repeats / group);
+    double total = 0;
+    for (int r = 0; r < groups + 1; ++r) {
+      pgo::launch_pipe_init(P->g, s);
+      pgo::launch_pipe_cg_sym(sym_view(P), P->sym, np, 0, s);
+      HIP_TRY(hipEventRecord(a, s));
+      for (int i = 1; i <= group; ++i) pgo::launch_pipe_cg_sym(sym_view(P), P->sym, np, i, s);
+      HIP_TRY(hipEventRecord(b, s));
+      HIP_TRY(hipEventSynchronize(b));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, a, b));
+      if (r > 0) total += ms;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *avg_ms = total / groups / group;
     return PGO_OK;
   }
   if (k == "pcg_graph") {

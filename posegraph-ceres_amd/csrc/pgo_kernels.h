@@ -334,6 +334,7 @@ void launch_hdiag6(const DeviceGraph& g, double* buf, int phase, hipStream_t s);
 void launch_pipe_init(const DeviceGraph& g, hipStream_t s);
 void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, hipStream_t s, unsigned long long gseq = 0);   // gseq: device-initiated exchange, global number of this producing launch
 void launch_peer_signal(const DeviceGraph& g, unsigned long long gseq, hipStream_t s);   // ... behind k_pipe_init
+void launch_pipe_fold(const DeviceGraph& g, int seq, unsigned long long gseq, hipStream_t s);   // one work-group: the g.n_wg partial triples of the producing launch -> this rank's three sums in the exchange buffer(s) (+ signal / wait)
 void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s);
 void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s, int mode = 0);   // mode: see k_pcg_update
 void launch_spmv_refresh(const DeviceGraph& g, hipStream_t s, int on_the_fly = 0, int it_odd = 0);

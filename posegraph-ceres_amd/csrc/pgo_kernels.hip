@@ -2721,7 +2721,10 @@ void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, 
                           else hipLaunchKernelGGL((k_pipe_cg<PK, 1>), grid, dim3(g.block), lds, s, g, p, seq, mode); } while (0)
   if (g.blk_packed) PGO_PIPE(true); else PGO_PIPE(false);
 #undef PGO_PIPE
-  if (mode == 0) hipLaunchKernelGGL(k_pipe_fold, dim3(1), dim3(256), 0, s, g, seq, gseq);
+  if (mode == 0) launch_pipe_fold(g, seq, gseq, s);
+}
+void launch_pipe_fold(const DeviceGraph& g, int seq, unsigned long long gseq, hipStream_t s) {
+  hipLaunchKernelGGL(k_pipe_fold, dim3(1), dim3(256), 0, s, g, seq, gseq);
 }
 void launch_lm_budget(const DeviceGraph& g, int decisions, hipStream_t s, int next_launch) {
   hipLaunchKernelGGL(k_lm_budget, dim3(1), dim3(1), 0, s, g, decisions, next_launch);

@@ -28,7 +28,19 @@ int wait_handoff(pgo_problem* P) {
 bool pipe_mode(const pgo_problem* P, const pgo::CgParams& prm) {
   const char* e = getenv("PGO_SHARD_PIPE");       // (read per call: the tests run both forms in one process; every rank sees the same environment)
   const bool off = e && e[0] == '0';
-  return !off && !P->use_graph && !P->force_standard_cg && pgo::pipe_supported(P->g, prm, P->g.cluster);
+  if (off || P->use_graph || P->force_standard_cg) return false;
+  if (P->g.world > 1) return pgo::pipe_supported(P->g, prm, P->g.cluster);
+  // One rank (r06): a session that keeps the normal equations in the symmetric tile form — the graphs above the universal stream's size
+  // limit — runs the same one-launch CG iteration on it (k_pipe_cg_sym) where the library would take the pipelined recurrences anyway
+  // (truncated CG with a forcing term >= 0.01, or pcg_form 2); pcg_form 1 and tighter forcing terms keep Ceres' refreshed CG (k_spmv_sym<0> + k_pcg_update)
+  const bool asked = P->opt.pcg_form == 2 || (P->opt.pcg_form == 0 && P->opt.eta >= 1e-2);
+  return P->sym_storage && asked && !P->universal && !P->pipelined && (P->g.cluster == 1 || P->g.cluster == 2) && prm.q_tolerance >= 0.0 && prm.r_tolerance < 0.0 &&
+         P->g.pipe_buf[0] != nullptr;
+}
+// one product launch of the owner-only CG (+ its fold): from the symmetric tile form where the session keeps its blocks there
+static void pipe_cg_launch(pgo_problem* P, const pgo::CgParams& prm, int seq, unsigned long long gseq = 0) {
+  if (P->sym_storage) pgo::launch_pipe_cg_sym(sym_view(P), P->sym, prm, seq, P->stream, gseq);
+  else pgo::launch_pipe_cg(P->g, prm, seq, 0, P->stream, gseq);
 }
 
 int enqueue_tail(pgo_problem* P, const pgo::CgParams* finish_prm) {
@@ -38,9 +50,15 @@ int enqueue_tail(pgo_problem* P, const pgo::CgParams* finish_prm) {
   if (finish_prm && pipe_mode(P, *finish_prm)) {
     // owner-only CG: the batch's last launch applied the stop test; x of every row is gathered first (cg_x is laid out like an
     // exchange buffer: rank r owns [r * rows_per * 6, ...)), then the tail of the sharded path as below, gated on the CG having stopped
+    if (P->g.world == 1) {        // (one rank, symmetric form: the two-launch tail of the one-rank path, gated on the CG state k_pipe_cg_sym keeps)
+      pgo::launch_spmv_sym(P->g, P->sym, none, 1 | 64 | 4, 1, s);
+      pgo::launch_step_tail(P->g, s, 1);
+      return PGO_OK;
+    }
     int rc = exchange(P, P->g.cg_x, (size_t)6 * P->g.rows_per);
     if (rc) return rc;
-    pgo::launch_spmv_tail(P->g, none, s, 2, 0);
+    if (P->sym_storage) pgo::launch_spmv_sym(P->g, P->sym, none, 1 | 64, 1, s);
+    else pgo::launch_spmv_tail(P->g, none, s, 2, 0);
     rc = exchange(P, P->g.cg_q, (size_t)P->g.seg);
     if (rc) return rc;
     pgo::launch_model_delta_and_retract(P->g, s, 1);
@@ -81,8 +99,8 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool wi
     // owner-only CG: one launch and one all-gather per iteration (launch seq = iteration index + 1, pipe_begin() ran seq 0)
     for (int i = 0; i < batch; ++i) {
       const int seq = start_it + i;
-      if (P->g.peer_tab) { pgo::launch_pipe_cg(P->g, prm, seq, 0, s, ++P->peer_gseq); continue; }
-      pgo::launch_pipe_cg(P->g, prm, seq, 0, s);
+      if (P->g.peer_tab) { pipe_cg_launch(P, prm, seq, ++P->peer_gseq); continue; }
+      pipe_cg_launch(P, prm, seq);
       int rc = exchange(P, P->g.pipe_buf[(seq & 1) ^ 1], (size_t)P->g.pipe_seg);
       if (rc) return rc;
     }
@@ -172,12 +190,12 @@ int pcg_begin(pgo_problem* P, const pgo::CgParams& prm) {
   pgo::launch_pipe_init(P->g, s);
   if (P->g.peer_tab) {       // device-initiated exchange: the kernels store into every rank's buffer and signal each other
     pgo::launch_peer_signal(P->g, ++P->peer_gseq, s);
-    pgo::launch_pipe_cg(P->g, prm, 0, 0, s, ++P->peer_gseq);
+    pipe_cg_launch(P, prm, 0, ++P->peer_gseq);
     return PGO_OK;
   }
   int rc = exchange(P, P->g.pipe_buf[0], (size_t)P->g.pipe_seg);
   if (rc) return rc;
-  pgo::launch_pipe_cg(P->g, prm, 0, 0, s);
+  pipe_cg_launch(P, prm, 0);
   return exchange(P, P->g.pipe_buf[1], (size_t)P->g.pipe_seg);
 }
 

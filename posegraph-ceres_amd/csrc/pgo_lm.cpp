@@ -139,9 +139,9 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   P->sym_active = false; P->sym_storage = false;
   // ... when the solve can run long enough to repay the form's construction (44 ms of host time at 100 k / 1 M against 0.7 ms saved
   // per LM iteration of ~13 CG iterations: 64 iterations, or a tight forcing term whose CG runs are long); PGO_SYM=1 forces it
-  const char* sym_env = getenv("PGO_SYM");
-  const bool sym_pays = (sym_env && sym_env[0] == '1') || P->sym_ready || P->opt.max_num_iterations >= 64 || P->opt.eta <= 0.02;
-  if (P->opt.linear_solver_type == PGO_BLOCK_JACOBI_PCG && !P->universal && !P->pipelined && sym_pays && sym_wanted(P)) {
+  // (r06: unconditionally — the form's construction, 44 ms of host time at 100 k / 1 M on 16 threads, is less than the rest of the
+  // set-up it sits in, and the first session is as likely to be the long one as any)
+  if (P->opt.linear_solver_type == PGO_BLOCK_JACOBI_PCG && !P->universal && !P->pipelined && sym_wanted(P)) {
     rc = sym_prepare(P);
     if (rc) return rc;
     P->sym_active = P->sym_ready;
@@ -824,7 +824,8 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
   if (summary) {
     memset(summary, 0, sizeof *summary);
     summary->cg_exchange = P->g.world > 1 ? (P->g.peer_tab && pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : 0;
-    summary->cg_form = P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : (P->uni_resident ? 4 : P->uni_fused ? 3 : 0);
+    summary->cg_form = P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : (P->uni_resident ? 4 : P->uni_fused ? 3 : pipe_mode(P, cg_params_for(P->opt)) ? 2 : 0);
+    summary->sym_form = P->sym_storage ? 1 : 0;
     summary->termination_type = L.termination;
     summary->reason = L.reason;
     summary->num_successful_steps = L.num_successful;

@@ -60,7 +60,7 @@ int exchange(pgo_problem* P, double* buf, size_t seg_doubles) {
 // diag_only (several ranks, the solve will run the owner-only CG): nobody reads another rank's off-diagonal entries of the
 // diagonal blocks then — 6 doubles per pose travel instead of 36 (28.8 -> 4.8 MB per accepted step at 100 k poses)
 int linearize_all(pgo_problem* P, bool diag_only) {
-  if (P->sym_storage) {        // (one rank: nothing to exchange)
+  if (P->sym_storage) {
     // two kernels write the form: the row kernel with the lean per-incidence algebra (k_linearize_lean, the default where it fits:
     // information without position / rotation coupling) and the row kernel with the general body and redirected block stores
     // (k_linearize_symout: information with the coupling; PGO_SYM_LIN=rows runs it everywhere — tests/test_gpu_sym.py holds one to the other)
@@ -69,10 +69,11 @@ int linearize_all(pgo_problem* P, bool diag_only) {
     gs.sym_dst = P->sy_dst.p; gs.sym_val = P->sym.val;
     if (sl && sl[0] == 'r') pgo::launch_linearize_symout(gs, P->stream);
     else pgo::launch_linearize_lean(gs, P->stream);
-    return PGO_OK;
+    if (P->g.world == 1) return PGO_OK;        // (one rank: nothing to exchange; several: the diagonal blocks' diagonals and the gradient, as below)
+  } else {
+    pgo::launch_linearize(P->g, P->stream);
+    P->sym_stale = true;
   }
-  pgo::launch_linearize(P->g, P->stream);
-  P->sym_stale = true;
   int rc;
   // what THIS linearisation exchanges is what the CG start checks against its form (pcg_begin): recorded here, from the branch
   // actually taken, so that callers which linearise by themselves (pgo_linear_solve: a full exchange) are covered too

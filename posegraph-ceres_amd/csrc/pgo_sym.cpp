@@ -10,12 +10,17 @@
 bool sym_wanted(const pgo_problem* P) {
   const char* e = getenv("PGO_SYM");
   if (e && e[0] == '0') return false;
-  if (P->g.world != 1 || (P->comm && P->comm->world > 1) || P->use_graph) return false;
+  if (P->use_graph) return false;
+  // several ranks (r06): every rank keeps the form of ITS rows; the only CG that multiplies with it there is the owner-only pipelined
+  // one (k_pipe_cg_sym), so the request has to be one that form serves
+  if (P->g.world > 1 && !pgo::pipe_supported(P->g, cg_params_for(P->opt), P->g.cluster)) return false;
+  if (P->g.world > 1) { const char* pe = getenv("PGO_SHARD_PIPE"); if ((pe && pe[0] == '0') || P->force_standard_cg) return false; }
   if (e && e[0] == '1') return true;
   // the universal stream serves the graphs below its slot limit (latency-bound kernels of a few microseconds: nothing to gain
-  // from fewer bytes there); above it the host-driven CG runs and the SpMV is bandwidth-bound
+  // from fewer bytes there); above it the host-driven CG runs and the SpMV is bandwidth-bound.  The limit is on the WHOLE graph
+  // (N + 2 E incidence slots), whatever share of it this rank holds.
   const long long limit = 600000;
-  return (long long)P->g.n_slots > limit;
+  return (long long)P->pp.size() + 2LL * (long long)P->ia.size() > limit;
 }
 
 // Builds P->sym (device arrays + pgo::SymGraph).  Returns PGO_OK with P->sym_ready false when the graph does not fit the form
@@ -35,12 +40,19 @@ int sym_prepare(pgo_problem* P) {
   // tile caps: up to 256 rows; enough tiles to fill the chip on small graphs; the weight cap keeps the tiles' stored slots alike
   pgo::SymHostParams hp;
   const char* re = getenv("PGO_SYM_ROWS");
-  hp.row_cap = re ? atoi(re) : std::min(256, std::max(32, N / 384));
+  const int N_own = std::max(1, P->g.row_hi - P->g.row_lo);
+  hp.row_cap = re ? atoi(re) : std::min(256, std::max(32, N_own / 384));
   hp.row_cap = std::max(8, std::min(hp.row_cap, (int)pgo::SYM_LANES));
-  const double avg_w = (double)(N + 2LL * E) / std::max(1, N);
+  // (several ranks: this rank's rows and their incidences)
+  long long own_slots = P->g.row_hi - P->g.row_lo;
+  if (P->g.world > 1) { for (int e = 0; e < E; ++e) own_slots += (P->ia[e] >= P->g.row_lo && P->ia[e] < P->g.row_hi) + (P->ib[e] >= P->g.row_lo && P->ib[e] < P->g.row_hi); }
+  const double avg_w = P->g.world > 1 ? std::max(1.0, (double)own_slots / N_own) : (double)(N + 2LL * E) / std::max(1, N);
   const double w_mult = 0.95;
   hp.w_cap = std::max<long long>(64, (long long)(w_mult * hp.row_cap * avg_w));
   hp.sort_tiles = true;
+  // whole 2-pose clusters per tile, always: what the one-launch CG iteration on the form needs for 12 x 12 Jacobi blocks is also fine
+  // for 6 x 6 ones, and the form is built once per topology whatever preconditioner later sessions ask for
+  hp.row_lo = P->g.row_lo; hp.row_hi = P->g.row_hi; hp.unit = 2;
   pgo::SymHostLayout H;
   pgo::sym_build_host(N, E, P->ia.data(), P->ib.data(), P->h_row_slot_begin.data(), hp, &H);
   if (verbose) std::fprintf(stderr, "[pgo] sym_prepare: partition %.2f ms, tile layout %.2f ms\n", H.ms_partition, H.ms_layout);

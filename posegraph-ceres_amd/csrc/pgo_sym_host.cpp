@@ -13,89 +13,104 @@ namespace {
 // Tiles: the natural order cut into runs of <= 0.85 * (row cap, weight cap), then greedy refinement — a pose moves to the tile
 // that holds most of its neighbours while the caps allow (pose-graph ids follow the trajectory, so the runs are already local;
 // the refinement pulls the loop-closure partners together: BASELINE config 4 goes from 56 % to 72-78 % interior edges).
-void partition_rows(int N, const std::vector<int>& adj_ptr, const std::vector<int>& adj, int row_cap, long long w_cap, std::vector<int>& part, int& T) {
-  part.assign(N, 0);
-  const int r0 = std::max(1, (int)(0.85 * row_cap));
+void partition_rows(int N, int lo, int hi, int unit, const std::vector<int>& adj_ptr, const std::vector<int>& adj, int row_cap, long long w_cap, std::vector<int>& part, int& T) {
+  // part[v] = -1 outside [lo, hi).  The items that move are UNITS: `unit` consecutive poses starting at lo + unit * k.
+  part.assign(N, -1);
+  const int nu = (hi - lo + unit - 1) / unit;
+  auto u_lo = [&](int k) { return lo + unit * k; };
+  auto u_hi = [&](int k) { return std::min(hi, lo + unit * (k + 1)); };
+  auto u_w = [&](int k) { long long w = 0; for (int v = u_lo(k); v < u_hi(k); ++v) w += 1 + adj_ptr[v + 1] - adj_ptr[v]; return w; };
+  const int r0 = std::max(unit, (int)(0.85 * row_cap));
   const long long w0 = std::max<long long>(1, (long long)(0.85 * w_cap));
   int t = 0, r = 0;
   long long w = 0;
-  for (int v = 0; v < N; ++v) {
-    const int wv = 1 + adj_ptr[v + 1] - adj_ptr[v];
-    if (r > 0 && (r >= r0 || w + wv > w0)) { ++t; r = 0; w = 0; }
-    part[v] = t; ++r; w += wv;
+  for (int k = 0; k < nu; ++k) {
+    const long long wv = u_w(k);
+    const int nr = u_hi(k) - u_lo(k);
+    if (r > 0 && (r + nr > r0 || w + wv > w0)) { ++t; r = 0; w = 0; }
+    for (int v = u_lo(k); v < u_hi(k); ++v) part[v] = t;
+    r += nr; w += wv;
   }
-  T = t + 1;
+  T = nu > 0 ? t + 1 : 0;
   std::vector<int> rows(T, 0);
   std::vector<long long> wt(T, 0);
-  for (int v = 0; v < N; ++v) { ++rows[part[v]]; wt[part[v]] += 1 + adj_ptr[v + 1] - adj_ptr[v]; }
+  for (int v = lo; v < hi; ++v) { ++rows[part[v]]; wt[part[v]] += 1 + adj_ptr[v + 1] - adj_ptr[v]; }
   std::vector<int> cnt(T, 0), touched;
   for (int pass = 0; pass < 6; ++pass) {
     int moved = 0;
-    for (int v = 0; v < N; ++v) {
-      const int cur = part[v];
+    for (int k = 0; k < nu; ++k) {
+      const int cur = part[u_lo(k)];
       touched.clear();
-      for (int j = adj_ptr[v]; j < adj_ptr[v + 1]; ++j) {
-        const int tv = part[adj[j]];
-        if (cnt[tv]++ == 0) touched.push_back(tv);
-      }
+      for (int v = u_lo(k); v < u_hi(k); ++v)
+        for (int j = adj_ptr[v]; j < adj_ptr[v + 1]; ++j) {
+          const int tv = part[adj[j]];
+          if (tv < 0) continue;                      // another rank's row
+          if (cnt[tv]++ == 0) touched.push_back(tv);
+        }
       int best = cur, best_c = cnt[cur];
       for (int tv : touched) if (cnt[tv] > best_c || (cnt[tv] == best_c && tv < best && best != cur)) { best = tv; best_c = cnt[tv]; }
       for (int tv : touched) cnt[tv] = 0;
-      const int wv = 1 + adj_ptr[v + 1] - adj_ptr[v];
-      if (best != cur && rows[best] < row_cap && wt[best] + wv <= w_cap && rows[cur] > 1) {
-        --rows[cur]; ++rows[best]; wt[cur] -= wv; wt[best] += wv; part[v] = best; ++moved;
+      const long long wv = u_w(k);
+      const int nr = u_hi(k) - u_lo(k);
+      if (best != cur && rows[best] + nr <= row_cap && wt[best] + wv <= w_cap && rows[cur] > nr) {
+        rows[cur] -= nr; rows[best] += nr; wt[cur] -= wv; wt[best] += wv;
+        for (int v = u_lo(k); v < u_hi(k); ++v) part[v] = best;
+        ++moved;
       }
     }
-    if (moved < N / 500) break;
+    if (moved < nu / 500) break;
   }
 }
 
 }  // namespace
 
 void sym_build_host(int N, int E, const int* ia, const int* ib, const int* row_slot_begin, const SymHostParams& prm, SymHostLayout* out) {
-  // adjacency (both directions)
+  const int lo = std::max(0, prm.row_lo), hi = prm.row_hi < 0 ? N : std::min(N, prm.row_hi);
+  const int unit = std::max(1, prm.unit);
+  auto owned = [&](int v) { return v >= lo && v < hi; };
+  // adjacency of the owned rows (both directions; the neighbours may be anybody's)
   std::vector<int> adj_ptr(N + 1, 0);
-  for (int e = 0; e < E; ++e) { ++adj_ptr[ia[e] + 1]; ++adj_ptr[ib[e] + 1]; }
+  for (int e = 0; e < E; ++e) { if (owned(ia[e])) ++adj_ptr[ia[e] + 1]; if (owned(ib[e])) ++adj_ptr[ib[e] + 1]; }
   for (int v = 0; v < N; ++v) adj_ptr[v + 1] += adj_ptr[v];
   std::vector<int> adj(adj_ptr[N]), fillp(adj_ptr.begin(), adj_ptr.end() - 1);
-  for (int e = 0; e < E; ++e) { adj[fillp[ia[e]]++] = ib[e]; adj[fillp[ib[e]]++] = ia[e]; }
+  for (int e = 0; e < E; ++e) { if (owned(ia[e])) adj[fillp[ia[e]]++] = ib[e]; if (owned(ib[e])) adj[fillp[ib[e]]++] = ia[e]; }
   const int row_cap = prm.row_cap;
   const long long w_cap = prm.w_cap;
   std::vector<int> part;
   int T0 = 0;
   const auto t_part = std::chrono::steady_clock::now();
-  partition_rows(N, adj_ptr, adj, row_cap, w_cap, part, T0);
+  partition_rows(N, lo, hi, unit, adj_ptr, adj, row_cap, w_cap, part, T0);
   out->ms_partition = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_part).count();
   const auto t_lay = std::chrono::steady_clock::now();
   // compact tile ids, rows per tile ascending
   std::vector<int> tile_of(T0, -1);
   int T = 0;
-  for (int v = 0; v < N; ++v) if (tile_of[part[v]] < 0) tile_of[part[v]] = T++;
-  for (int v = 0; v < N; ++v) part[v] = tile_of[part[v]];
+  for (int v = lo; v < hi; ++v) if (tile_of[part[v]] < 0) tile_of[part[v]] = T++;
+  for (int v = lo; v < hi; ++v) part[v] = tile_of[part[v]];
   if (prm.sort_tiles) {
     // largest tiles first: work-groups are handed out in index order, so the small tiles fill the tail of the launch
     std::vector<long long> wt(T, 0);
-    for (int v = 0; v < N; ++v) wt[part[v]] += 1 + adj_ptr[v + 1] - adj_ptr[v];
+    for (int v = lo; v < hi; ++v) wt[part[v]] += 1 + adj_ptr[v + 1] - adj_ptr[v];
     std::vector<int> order(T), rank_of(T);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wt[a] > wt[b]; });
     for (int k = 0; k < T; ++k) rank_of[order[k]] = k;
-    for (int v = 0; v < N; ++v) part[v] = rank_of[part[v]];
+    for (int v = lo; v < hi; ++v) part[v] = rank_of[part[v]];
   }
   std::vector<std::vector<int>> trow(T);
-  for (int v = 0; v < N; ++v) trow[part[v]].push_back(v);
+  for (int v = lo; v < hi; ++v) trow[part[v]].push_back(v);      // (ascending pose ids: the poses of a unit sit in consecutive lanes, the unit's first one in a lane that is a multiple of `unit` when every unit of the tile is whole)
 
   // old slots of every edge (prepare(): the row's diagonal first, then its incidences in edge order)
-  std::vector<int> fill(N), beg_slot(E), end_slot(E);
-  for (int v = 0; v < N; ++v) fill[v] = row_slot_begin[v] + 1;
-  for (int e = 0; e < E; ++e) { beg_slot[e] = fill[ia[e]]++; end_slot[e] = fill[ib[e]]++; }
-  // incidences per row: (edge, side)
+  std::vector<int> fill(N, 0), beg_slot(E, -1), end_slot(E, -1);
+  for (int v = lo; v < hi; ++v) fill[v] = row_slot_begin[v] + 1;
+  for (int e = 0; e < E; ++e) { if (owned(ia[e])) beg_slot[e] = fill[ia[e]]++; if (owned(ib[e])) end_slot[e] = fill[ib[e]]++; }
+  // incidences per owned row: (edge, side)
   std::vector<int> inc_ptr(N + 1, 0);
-  for (int e = 0; e < E; ++e) { ++inc_ptr[ia[e] + 1]; ++inc_ptr[ib[e] + 1]; }
+  for (int e = 0; e < E; ++e) { if (owned(ia[e])) ++inc_ptr[ia[e] + 1]; if (owned(ib[e])) ++inc_ptr[ib[e] + 1]; }
   for (int v = 0; v < N; ++v) inc_ptr[v + 1] += inc_ptr[v];
   std::vector<int> inc(inc_ptr[N]);
   { std::vector<int> f(inc_ptr.begin(), inc_ptr.end() - 1);
-    for (int e = 0; e < E; ++e) { inc[f[ia[e]]++] = 2 * e; inc[f[ib[e]]++] = 2 * e + 1; } }
+    for (int e = 0; e < E; ++e) { if (owned(ia[e])) inc[f[ia[e]]++] = 2 * e; if (owned(ib[e])) inc[f[ib[e]]++] = 2 * e + 1; } }
 
   // ---- per-tile layout, tiles in parallel (every index below is relative to the tile; offsets are added afterwards) ----
   struct TileOut {

@@ -11,6 +11,12 @@ struct SymHostParams {
   int row_cap = 256;          // poses per tile (<= SYM_LANES)
   long long w_cap = 1 << 30;  // incidences (1 + degree, summed over the rows) per tile
   bool sort_tiles = true;     // largest tiles first
+  // r06 — the form of ONE RANK's rows (several ranks: every rank builds the form of the rows it owns; the far end of an edge that leaves
+  // the range is a ghost column like the far end of any cut edge, an edge with neither end in the range is not the rank's business) and
+  // tiles made of whole preconditioner clusters (the one-launch CG iteration on the form, k_pipe_cg_sym, applies a row's Jacobi block
+  // inside the tile that owns the row: poses unit*c .. unit*c + unit - 1 move together and sit in consecutive lanes)
+  int row_lo = 0, row_hi = -1;   // owned rows [row_lo, row_hi); row_hi < 0: all of them
+  int unit = 1;                  // poses per indivisible group (1, 2 or 4; row_lo is a multiple of it)
 };
 struct SymHostLayout {
   std::vector<SymTile> tiles;

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(SYM_LANES) void k_spmv_sym(DeviceGraph g, SymGraph 
   // stopped), 4 = the row lanes also write delta = -S x and the candidate Plus(x, delta), 8 = A x of a residual refresh (nothing
   // once the CG has stopped), 16 = ... of x_old + alpha p formed on the fly (32: parity of p)
   if (MODE == 1) {
+    if ((odd & 64) && !g.cg->done) return;     // step tail behind a batch of the owner-only CG (k_pipe_cg_sym applied the stop test): only once the CG has stopped
     if ((odd & 8) && g.cg->done) return;
     if (!(odd & 8) && lm_halted(g)) return;
     if (odd & 2) {
@@ -328,10 +329,17 @@ __global__ __launch_bounds__(SYM_LANES) void k_spmv_sym(DeviceGraph g, SymGraph 
   double pq[1] = {0.0};
   if (tid < T.nrows) {
     const int pose = sg.xlist[T.x0 + tid];
-    double2* q = reinterpret_cast<double2*>(g.cg_q + 6 * (size_t)pose);      // one rank: q_index(row, k) = 6 row + k
-    q[0] = double2{y[0], y[1]};
-    q[1] = double2{y[2], y[3]};
-    q[2] = double2{y[4], y[5]};
+    if (g.world == 1) {
+      double2* q = reinterpret_cast<double2*>(g.cg_q + 6 * (size_t)pose);      // one rank: q_index(row, k) = 6 row + k
+      q[0] = double2{y[0], y[1]};
+      q[1] = double2{y[2], y[3]};
+      q[2] = double2{y[4], y[5]};
+    } else {                // several ranks: the owner's segment of the exchange buffer (pgo_kernels.hip q_index; a segment need not start on 16 bytes)
+      const int rk = pose / g.rows_per;
+      double* q = g.cg_q + (size_t)rk * g.seg + (size_t)(pose - rk * g.rows_per) * 6;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) q[k] = y[k];
+    }
     if (MODE == 1 && (odd & 4)) {
       // step tail: delta = -S x and the candidate Plus(x, delta) of this row (k_retract's job)
       const double2* ps2 = reinterpret_cast<const double2*>(g.pose_x + (size_t)POSE_STRIDE * pose);
@@ -374,6 +382,284 @@ __global__ __launch_bounds__(SYM_LANES) void k_spmv_sym(DeviceGraph g, SymGraph 
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// r06 — the owner-only pipelined CG (pgo_kernels.hip k_pipe_cg: Ghysels & Vanroose, one global reduction per iteration) with its
+// product taken from the symmetric tile form: ONE launch per CG iteration does
+//     fold of every rank's three sums -> stop test, alpha, beta          (every work-group alike: same bits everywhere)
+//     m of the tile's rows and ghost columns from the exchange buffer -> LDS
+//     n = A m over the tile's stored slots (every interior block read once, used for both of its rows: k_spmv_sym's chunk loop)
+//     the eight vector recurrences of the tile's rows (lane r = row r, six components each)
+//     m_new = M^-1 w with the row's 6x6 / 12x12 Jacobi block (the cluster's w through LDS: tiles are made of whole clusters)
+//     m_new into the exchange buffer(s), three partial sums per tile (folded by k_pipe_fold behind this launch)
+// It serves the sharded ranks (each rank holds the form of ITS rows: cut edges to other ranks are ghost columns) and, on one rank,
+// the graphs above the universal stream's size limit (BASELINE configs[3] on one GPU), where it replaces k_spmv_sym<0> +
+// k_pcg_update + k_cluster_precond's reloads: one launch and one pass over the vectors per iteration instead of two.
+// Launch `seq` reads pipe_buf[seq & 1] / CgState::pipe[seq & 1] and writes the other ones; seq 0: w0 = A u0.  The single-work-group
+// "stop test only" launches at the end of a batch are k_pipe_cg's (mode 1 / 2): same state words, same sums.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t sym_pipe_index(const DeviceGraph& g, int row) {
+  if (g.world == 1) return (size_t)row * 6;
+  const int rk = row / g.rows_per;
+  return (size_t)rk * g.pipe_seg + (size_t)(row - rk * g.rows_per) * 6;
+}
+
+template <bool PACKED, int CL>
+__global__ __launch_bounds__(SYM_LANES) void k_pipe_cg_sym(DeviceGraph g, SymGraph sg, CgParams prm, int seq) {
+  constexpr int NPAIR = PACKED ? BLK_PAIRS_PACKED : BLK_PAIRS_FULL;
+  constexpr int DIM = 6 * CL;
+  extern __shared__ double lds[];          // xs[6 * x_cap] | ubuf[SYM_LANES * VSTRIDE] | vbuf[SYM_LANES * VSTRIDE]
+  __shared__ double scratch[32];
+  const int tid = threadIdx.x, tile = blockIdx.x, lane = threadIdx.x & 63;
+  double* xs = lds;
+  double* ubuf = lds + (size_t)sg.x_cap * 6;
+  double* vbuf = ubuf + SYM_LANES * VSTRIDE;
+  const int rs = seq & 1, ws = rs ^ 1;
+  const double* rd = g.pipe_buf[rs];
+  double* wr = g.pipe_buf[ws];
+
+  // ---- loads that depend on nothing: the tile, its first two chunks, the CG state, every rank's three sums ----
+  const SymTile T = sg.tile[tile];
+  const int nch = T.nchunks;
+  struct Chunk { double2 b[NPAIR]; uint32_t meta, rin; int n; };
+  auto load_blocks = [&](Chunk& C, int ci, int base, int n) {
+    C.n = n;
+    C.rin = sg.rinfo[(size_t)ci * SYM_LANES + tid];
+    C.meta = 0;
+    if (tid < n) {
+      const int t = base + tid;
+      C.meta = sg.meta[t];
+      const double2* bp = reinterpret_cast<const double2*>(sg.val + (size_t)(t >> 6) * TILE_DOUBLES + (size_t)(t & 63) * 2);
+#pragma unroll
+      for (int k = 0; k < NPAIR; ++k) C.b[k] = bp[(size_t)k * 64];
+    }
+  };
+  auto load_chunk = [&](Chunk& C, int c) { load_blocks(C, T.chunk0 + c, T.base0 + SYM_LANES * c, min((int)SYM_LANES, T.total - SYM_LANES * c)); };
+  Chunk CA, CB, CC;
+  load_blocks(CA, T.chunk0, T.base0, T.n0);
+  if (nch > 1) load_blocks(CB, T.chunk0 + 1, T.base1, T.n1);
+  const int done0 = g.cg->done;
+  const CgState::Pipe st = g.cg->pipe[rs];
+  double f_gamma = 0, f_delta = 0, f_q = 0;     // every rank's three sums, added in rank order by every lane alike: same bits everywhere
+  for (int rk = 0; rk < g.world; ++rk) {
+    const double* pp = rd + (size_t)rk * g.pipe_seg + (size_t)g.rows_per * 6;
+    f_gamma += pp[0]; f_delta += pp[1]; f_q += pp[2];
+  }
+  // m of every staged column (the tile's rows first, then its ghosts — other tiles' rows, other ranks' rows)
+  for (int i = tid; i < T.nx * 3; i += SYM_LANES) {
+    const int e = i / 3, k = i - 3 * e;
+    const int pose = sg.xlist[T.x0 + e];
+    const double2 z = reinterpret_cast<const double2*>(rd + sym_pipe_index(g, pose))[k];
+    xs[6 * e + 2 * k] = z.x;
+    xs[6 * e + 2 * k + 1] = z.y;
+  }
+  const bool w0 = seq == 0;
+  int stop = 0, status = 0;
+  double alpha = 0.0, beta = 0.0, gamma = 0.0, Q1 = 0.0;
+  const int cnt = st.cnt;
+  if (!done0 && !w0) {          // (k_pipe_cg's statements: the two kernels take the same decisions from the same numbers)
+    gamma = f_gamma;
+    const double delta = f_delta;
+    Q1 = -f_q;
+    if (cnt > 0) {
+      const double zeta = cnt * (Q1 - st.q_prev) / Q1;
+      if (zeta < prm.q_tolerance && cnt >= prm.min_iterations) stop = 1;
+      if (cnt >= prm.max_iterations) stop = 1;
+    }
+    if (!stop && (gamma == 0.0 || !isfinite(gamma))) { stop = 1; status = (gamma == 0.0) ? 0 : 2; }
+    if (!stop && cnt > 0) {
+      beta = gamma / st.gamma_prev;
+      if (beta == 0.0 || !isfinite(beta)) { stop = 1; status = 2; }
+    }
+    if (!stop) {
+      const double den = cnt > 0 ? delta - beta * gamma / st.alpha_prev : delta;
+      if (!(den > 0.0) || !isfinite(den)) { stop = 1; status = 1; }     // "matrix is indefinite": x of the previous iteration stands
+      else alpha = gamma / den;
+    }
+  }
+  if (done0) return;
+  if (stop) {
+    if (tile == 0 && tid == 0) { g.cg->iters = cnt; g.cg->status = status; __threadfence(); g.cg->done = 1; }
+    return;
+  }
+  if (tile == 0 && tid == 0) {
+    CgState::Pipe n;
+    n.pad = 0;
+    if (w0) { n.cnt = 0; n.gamma_prev = 0.0; n.alpha_prev = 0.0; n.q_prev = 0.0; }
+    else { n.cnt = cnt + 1; n.gamma_prev = gamma; n.alpha_prev = alpha; n.q_prev = Q1; }
+    g.cg->pipe[ws] = n;
+  }
+  __syncthreads();
+
+  // ---- n = A m: k_spmv_sym's chunk loop (lane r keeps the sum of the tile's r-th row) ----
+  double y[6] = {0, 0, 0, 0, 0, 0};
+  auto process = [&](const Chunk& C) {
+    double u[6] = {0, 0, 0, 0, 0, 0};
+    int row = -1 - lane;                     // idle lanes: a row id nobody shares
+    if (tid < C.n) {
+      const int xcol = (int)(C.meta & 0xFFFu), side = (int)((C.meta >> 12) & 3u);
+      row = (int)((C.meta >> 23) & 0xFFu);
+      double x[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) x[k] = xs[6 * xcol + k];
+      blk_mul<PACKED, NPAIR>(C.b, side, x, u);
+      if (C.meta & (1u << 14)) {
+        const int vpos = (int)((C.meta >> 15) & 0xFFu);
+        double xr[6], v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xr[k] = xs[6 * row + k];
+        blk_mul_t<PACKED, NPAIR>(C.b, xr, v);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vbuf[vpos * VSTRIDE + k] = v[k];
+      }
+    }
+    seg_scan<6>(u, row, lane);
+    {
+      const int rn = __shfl_down(row, 1, 64);
+      if (tid < C.n && (lane == 63 || rn != row)) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ubuf[tid * VSTRIDE + k] = u[k];
+      }
+    }
+    __syncthreads();
+    {
+      const int ub = (int)(C.rin & 0xFFu), uc = (int)((C.rin >> 8) & 0x1FFu), vb = (int)((C.rin >> 17) & 0xFFu), vc = (int)(C.rin >> 25);
+      if (uc > 0) {
+        const int last = ub + uc - 1;
+        for (int w = ub >> 6; w <= (last >> 6); ++w) {
+          const int tail = min(w * 64 + 63, last);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) y[k] += ubuf[tail * VSTRIDE + k];
+        }
+      }
+      for (int j = 0; j < vc; ++j) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) y[k] += vbuf[(vb + j) * VSTRIDE + k];
+      }
+    }
+    __syncthreads();
+  };
+  // the row lane's vectors are requested while the last chunks are multiplied (they depend on nothing the loop produces)
+  const bool own = tid < T.nrows;
+  const int pose = own ? sg.xlist[T.x0 + tid] : 0;
+  const size_t gj = 6 * (size_t)pose;
+  double2 vr[3], vu[3], vw[3], vz[3], vq[3], vs[3], vp[3], vx[3], vb[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { vr[k] = vu[k] = vw[k] = vz[k] = vq[k] = vs[k] = vp[k] = vx[k] = vb[k] = double2{0.0, 0.0}; }
+  auto load_vectors = [&]() {
+    if (!own) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      vr[k] = reinterpret_cast<const double2*>(g.cg_r + gj)[k];
+      vu[k] = reinterpret_cast<const double2*>(g.cg_u + gj)[k];
+      if (!w0) {
+        vw[k] = reinterpret_cast<const double2*>(g.cg_w + gj)[k];
+        vz[k] = reinterpret_cast<const double2*>(g.cg_z + gj)[k];
+        vq[k] = reinterpret_cast<const double2*>(g.cg_qq + gj)[k];
+        vs[k] = reinterpret_cast<const double2*>(g.cg_s + gj)[k];
+        vp[k] = reinterpret_cast<const double2*>(g.cg_p0 + gj)[k];
+        vx[k] = reinterpret_cast<const double2*>(g.cg_x + gj)[k];
+        vb[k] = reinterpret_cast<const double2*>(g.cg_b + gj)[k];
+      }
+    }
+  };
+  double pm[6] = {0, 0, 0, 0, 0, 0};        // the row's own entries of m (the recurrence of qq needs them), read before xs is reused
+  if (own) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pm[k] = xs[6 * tid + k];
+  }
+  for (int c = 0; c < nch; c += 3) {
+    if (c + 2 < nch) load_chunk(CC, c + 2);
+    process(CA);
+    if (c + 1 < nch) {
+      if (c + 3 < nch) load_chunk(CA, c + 3);
+      process(CB);
+    }
+    if (c + 2 < nch) {
+      if (c + 4 < nch) load_chunk(CB, c + 4);
+      process(CC);
+    }
+  }
+  load_vectors();
+
+  // ---- the recurrences of the tile's rows (k_pipe_cg's statements per component) ----
+  double acc[3] = {0.0, 0.0, 0.0};
+  double wn[6] = {0, 0, 0, 0, 0, 0};
+  if (own) {
+    double r6[6], u6[6], w6[6], z6[6], q6[6], s6[6], p6[6], x6[6], b6[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      r6[2 * k] = vr[k].x; r6[2 * k + 1] = vr[k].y; u6[2 * k] = vu[k].x; u6[2 * k + 1] = vu[k].y;
+      w6[2 * k] = vw[k].x; w6[2 * k + 1] = vw[k].y; z6[2 * k] = vz[k].x; z6[2 * k + 1] = vz[k].y;
+      q6[2 * k] = vq[k].x; q6[2 * k + 1] = vq[k].y; s6[2 * k] = vs[k].x; s6[2 * k + 1] = vs[k].y;
+      p6[2 * k] = vp[k].x; p6[2 * k + 1] = vp[k].y; x6[2 * k] = vx[k].x; x6[2 * k + 1] = vx[k].y;
+      b6[2 * k] = vb[k].x; b6[2 * k + 1] = vb[k].y;
+    }
+    double zn[6], qn[6], sn[6], pn[6], xn[6], rn[6], un[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double sm = y[k];
+      rn[k] = r6[k]; un[k] = u6[k];
+      if (w0) {
+        wn[k] = sm;
+        zn[k] = 0.0; qn[k] = 0.0; sn[k] = 0.0; pn[k] = 0.0; xn[k] = 0.0;
+      } else {
+        zn[k] = sm + beta * z6[k]; qn[k] = pm[k] + beta * q6[k]; sn[k] = w6[k] + beta * s6[k]; pn[k] = u6[k] + beta * p6[k];
+        xn[k] = x6[k] + alpha * pn[k];
+        rn[k] = r6[k] - alpha * sn[k];
+        un[k] = u6[k] - alpha * qn[k];
+        wn[k] = w6[k] - alpha * zn[k];
+        acc[2] += xn[k] * (b6[k] + rn[k]);
+      }
+      acc[0] += rn[k] * un[k];
+      acc[1] += wn[k] * un[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      reinterpret_cast<double2*>(g.cg_w + gj)[k] = double2{wn[2 * k], wn[2 * k + 1]};
+      reinterpret_cast<double2*>(g.cg_z + gj)[k] = double2{zn[2 * k], zn[2 * k + 1]};
+      reinterpret_cast<double2*>(g.cg_qq + gj)[k] = double2{qn[2 * k], qn[2 * k + 1]};
+      reinterpret_cast<double2*>(g.cg_s + gj)[k] = double2{sn[2 * k], sn[2 * k + 1]};
+      reinterpret_cast<double2*>(g.cg_p0 + gj)[k] = double2{pn[2 * k], pn[2 * k + 1]};
+      if (!w0) {
+        reinterpret_cast<double2*>(g.cg_x + gj)[k] = double2{xn[2 * k], xn[2 * k + 1]};
+        reinterpret_cast<double2*>(g.cg_r + gj)[k] = double2{rn[2 * k], rn[2 * k + 1]};
+        reinterpret_cast<double2*>(g.cg_u + gj)[k] = double2{un[2 * k], un[2 * k + 1]};
+      }
+    }
+  }
+  // ---- m_new = M^-1 w: the cluster's w through LDS (a tile is made of whole clusters in consecutive lanes: pgo_sym_host.h `unit`) ----
+  double* wl = ubuf;                         // (free: the chunk loop ended with a barrier)
+  if (tid < T.nrows + CL) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wl[6 * tid + k] = own ? wn[k] : 0.0;      // (the lanes behind the last row: the missing poses of a last, partial cluster)
+  }
+  __syncthreads();
+  if (own) {
+    const double* wv = wl + DIM * (tid / CL);
+    double mn[6];
+#pragma unroll
+    for (int c6 = 0; c6 < 6; ++c6) {
+      const double2* Mi = reinterpret_cast<const double2*>(g.Minv + (gj + c6) * DIM);
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < DIM / 2; ++k) { const double2 mk = Mi[k]; a += mk.x * wv[2 * k] + mk.y * wv[2 * k + 1]; }
+      mn[c6] = a;
+    }
+    const size_t pi = sym_pipe_index(g, pose);
+    if (g.peer_tab) {
+      for (int rk = 0; rk < g.world; ++rk) {
+        double2* o = reinterpret_cast<double2*>(static_cast<double*>(g.peer_tab[3 * rk + ws]) + pi);
+        o[0] = double2{mn[0], mn[1]}; o[1] = double2{mn[2], mn[3]}; o[2] = double2{mn[4], mn[5]};
+      }
+    } else {
+      double2* o = reinterpret_cast<double2*>(wr + pi);
+      o[0] = double2{mn[0], mn[1]}; o[1] = double2{mn[2], mn[3]}; o[2] = double2{mn[4], mn[5]};
+    }
+  }
+  block_sum<3>(acc, scratch);
+  if (tid == 0) { g.part_rz[tile] = acc[0]; g.part_q[tile] = acc[1]; g.part_rr[tile] = acc[2]; }
 }
 
 template <bool PACKED>
@@ -429,6 +715,27 @@ void launch_spmv_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p
     if (g.blk_packed) hipLaunchKernelGGL((k_spmv_sym<1, true>), grid, block, lds, s, g, sg, p, odd);
     else hipLaunchKernelGGL((k_spmv_sym<1, false>), grid, block, lds, s, g, sg, p, odd);
   }
+}
+
+void launch_pipe_cg_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p, int seq, hipStream_t s, unsigned long long gseq) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    const int cap = 160 * 1024 - 512;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_cg_sym<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_cg_sym<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_cg_sym<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_cg_sym<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    attr_set = true;
+  }
+  const size_t lds = sym_lds_bytes(sg);
+  const dim3 grid(sg.n_tiles), block(SYM_LANES);
+#define PGO_PIPE_SYM(PK) do { if (g.cluster == 2) hipLaunchKernelGGL((k_pipe_cg_sym<PK, 2>), grid, block, lds, s, g, sg, p, seq); \
+                              else hipLaunchKernelGGL((k_pipe_cg_sym<PK, 1>), grid, block, lds, s, g, sg, p, seq); } while (0)
+  if (g.blk_packed) PGO_PIPE_SYM(true); else PGO_PIPE_SYM(false);
+#undef PGO_PIPE_SYM
+  DeviceGraph gf = g;
+  gf.n_wg = sg.n_tiles;         // the fold adds one entry per work-group of the producing launch
+  launch_pipe_fold(gf, seq, gseq, s);
 }
 
 void launch_sym_repack(const DeviceGraph& g, const SymGraph& sg, hipStream_t s, int diag_only) {

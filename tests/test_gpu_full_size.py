@@ -52,7 +52,7 @@ def test_c4_symmetric_form_session_is_tied_to_the_oracle(gpu, ds, O, big):
     g = big
     prob, poses = gpu.problem_from_graph(g)
     s = gpu.solve(gpu.SolverOptions(max_num_iterations=64, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2), prob)
-    assert s.cg_form == 0 and len(s.iterations) >= 20          # host-driven PCG above the universal stream's size limit
+    assert s.cg_form == 2 and s.sym_form == 1 and len(s.iterations) >= 20          # above the universal stream's size limit: the one-launch pipelined CG iteration on the form (r06: k_pipe_cg_sym)
     og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
     assert s.initial_cost == pytest.approx(O.cost(og), rel=1e-11)
     assert s.final_cost == pytest.approx(O.cost(og, poses), rel=1e-11)          # one oracle evaluation of the FINAL poses
@@ -157,7 +157,9 @@ def test_c4_sharded_eight_ways_matches_one_rank(gpu, ds, big):
     assert not errs, errs
     assert all(o is not None for o in out), "a virtual rank did not finish"
     gpu.loopback_destroy(group)
+    assert ref.sym_form == 1 and ref.cg_form == 2
     for s, x in out:
+        assert s.sym_form == 1 and s.cg_form == 2           # (r06) every rank keeps the symmetric form of its rows: k_pipe_cg_sym, k_linearize_lean
         assert list(s.iterations["step_is_successful"]) == list(ref.iterations["step_is_successful"])
         assert list(s.iterations["linear_solver_iterations"]) == list(ref.iterations["linear_solver_iterations"])
         assert np.allclose(s.iterations["cost"], ref.iterations["cost"], rtol=1e-9)

@@ -98,7 +98,7 @@ def test_lm_solve_same_answer(gpu, ds, O, repack):
     """A whole LM solve (truncated PCG, Huber) with the CG products from the symmetric form: same iterations, same costs as the
     incidence-slot kernels, and the oracle's answer."""
     g = ds.manhattan_se3(4000, 16000, seed=21)
-    opt = dict(max_num_iterations=12, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2)
+    opt = dict(max_num_iterations=12, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_form=1)     # (pcg_form 1: Ceres' refreshed CG, k_spmv_sym<0>; the pipelined CG on the form is tests/test_gpu_sym_pipe.py)
     runs = []
     # repack: the incidence-slot linearisation stays and its blocks are copied once per LM iteration (PGO_SYM_REPACK=1); otherwise the
     # symmetric form is the session's only storage: the linearisation writes it, damping / cluster preconditioner / tail and refresh
@@ -130,7 +130,7 @@ def test_lm_solve_symmetric_storage_other_graphs(gpu, ds, name, lin, monkeypatch
     # PGO_SYM_LIN=rows runs it on every graph)
     monkeypatch.setenv("PGO_SYM_LIN", lin)
     g = _graphs(ds)[name]
-    opt = dict(max_num_iterations=10, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=1 if name == "sphere" else 2)
+    opt = dict(max_num_iterations=10, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=1 if name == "sphere" else 2, pcg_form=1)
     runs = []
     for on in (False, True):
         with _Sym(on, 32):

@@ -29,6 +29,16 @@ def test_layouts_of_random_graphs_reproduce_the_plain_product(cli):
     assert int(words[words.index("tiles,") - 1]) > 10000 and int(words[words.index("interior") - 1]) > 100000, out   # not vacuous
 
 
+def test_the_form_of_one_ranks_rows(cli):
+    """r06: every rank of a row-sharded solve keeps the form of ITS rows (csrc/pgo_sym_host.h row_lo / row_hi), tiles made of whole
+    2-pose clusters in consecutive lanes: the owned rows' product, one stored block per owned end of an edge (one in all when interior),
+    nobody else's row in a tile, no split unit."""
+    code, out = _run(cli, 400, 9000, 0, 1)
+    assert code == 0, out
+    words = out.split()
+    assert int(words[words.index("tiles,") - 1]) > 2000 and int(words[words.index("interior") - 1]) > 20000, out
+
+
 @pytest.mark.parametrize("damage", [1, 2, 3, 4])
 def test_one_damaged_entry_is_noticed(cli, damage):
     code, out = _run(cli, 150, 5000, damage)

@@ -19,7 +19,7 @@ prob.solver_begin(opt)
 ran, done = prob.solver_step(steps)
 # (a PCG session of this size keeps the normal equations in the symmetric tile form: its LM loop runs the *_sym kernels; the
 # incidence-slot kernels are timed next to them for the comparison)
-for k in ("sym_spmv", "sym_linearize_lean", "sym_linearize_rows", "linearize", "pcg_spmv", "evaluate"):
+for k in ("sym_pipe_cg", "sym_spmv", "sym_linearize_lean", "sym_linearize_rows", "linearize", "pcg_spmv", "evaluate"):
     prob.time_kernel(k, 30)
 s = prob.solver_end()
 print("C4 %d poses / %d edges: %d LM iterations, %d CG iterations, cost %.6e -> %.6e" % (

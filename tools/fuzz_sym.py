@@ -59,17 +59,18 @@ def random_case(seed):
     cmask[0] = 3
     for v in rng.integers(0, g.N, int(rng.integers(0, 3))):
         cmask[v] = rng.integers(1, 4)
-    return g, cmask, int(rng.integers(0, 5)), float(rng.uniform(0.3, 3.0)), int(rng.choice([1, 2, 4])), int(rng.choice([8, 16, 33, 64, 256])), bool(rng.integers(0, 2))
+    return (g, cmask, int(rng.integers(0, 5)), float(rng.uniform(0.3, 3.0)), int(rng.choice([1, 2, 4])), int(rng.choice([8, 16, 33, 64, 256])), bool(rng.integers(0, 2)),
+            int(rng.choice([1, 0])))       # pcg_form: 1 = Ceres' refreshed CG on the form (k_spmv_sym<0>), 0 = the library's choice (r06: the one-launch pipelined iteration, k_pipe_cg_sym, where the form is the session's storage)
 
 
-def solve(g, cmask, loss, loss_a, cluster, sym, rows, repack):
+def solve(g, cmask, loss, loss_a, cluster, sym, rows, repack, form):
     os.environ["PGO_SYM"] = "1" if sym else "0"
     os.environ["PGO_SYM_ROWS"] = str(rows)
     os.environ["PGO_SYM_REPACK"] = "1" if repack else "0"
     prob, poses = pkg.problem_from_graph(g, loss=loss, loss_a=loss_a, constant_first=False)
     for v in np.nonzero(cmask)[0]:
         prob.set_pose_constant(int(v), int(cmask[v]))
-    s = pkg.solve(pkg.SolverOptions(max_num_iterations=8, linear_solver_type=pkg.BLOCK_JACOBI_PCG, pcg_cluster_poses=cluster), prob)
+    s = pkg.solve(pkg.SolverOptions(max_num_iterations=8, linear_solver_type=pkg.BLOCK_JACOBI_PCG, pcg_cluster_poses=cluster, pcg_form=form), prob)
     return s, poses
 
 
@@ -77,11 +78,11 @@ def main(n_cases=100, first=0):
     bad = 0
     t0 = time.time()
     for seed in range(first, first + n_cases):
-        g, cmask, loss, loss_a, cluster, rows, repack = random_case(seed)
+        g, cmask, loss, loss_a, cluster, rows, repack, form = random_case(seed)
         try:
-            a, pa = solve(g, cmask, loss, loss_a, cluster, False, rows, False)
-            b, pb = solve(g, cmask, loss, loss_a, cluster, True, rows, repack)
-            c, pc = solve(g, cmask, loss, loss_a, cluster, True, rows, repack)
+            a, pa = solve(g, cmask, loss, loss_a, cluster, False, rows, False, form)
+            b, pb = solve(g, cmask, loss, loss_a, cluster, True, rows, repack, form)
+            c, pc = solve(g, cmask, loss, loss_a, cluster, True, rows, repack, form)
         except Exception as exc:   # noqa: BLE001
             print("seed", seed, "EXCEPTION", exc, flush=True)
             bad += 1
@@ -99,7 +100,7 @@ def main(n_cases=100, first=0):
             why.append("constant pose moved / non-finite")
         if why:
             bad += 1
-            print("seed", seed, "N", g.N, "E", g.E, "rows", rows, "repack", repack, "cluster", cluster, "loss", loss, ":", "; ".join(why), flush=True)
+            print("seed", seed, "N", g.N, "E", g.E, "rows", rows, "repack", repack, "cluster", cluster, "loss", loss, "form", form, "cg_form", b.cg_form, ":", "; ".join(why), flush=True)
     print("%d cases, %d bad, %.1f s" % (n_cases, bad, time.time() - t0), flush=True)
     return bad
 

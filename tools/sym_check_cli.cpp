@@ -4,7 +4,11 @@
 //     [ub, ub + uc) and [vb, vb + vc) — against a plain sum over all incidences;
 // plus the invariants the kernels rely on (one diagonal slot per row, an interior edge stored once in the begin orientation, a cut edge
 // twice, x indices in range, chunk bases multiples of 64).  Needs no GPU: tests/test_sym_host.py runs it in the CPU suite.
-// usage: sym_check_cli [cases] [first_seed] [damage 1..4: self-test, one damaged layout entry per case must be noticed]
+// r06: with a fourth argument `1` every case builds the form of ONE RANK's rows — a random owned range [lo, hi), lo even, tiles made of
+// whole 2-pose units (SymHostParams::row_lo / row_hi / unit) — and checks, besides the product of the owned rows, that no other row sits
+// in a tile, that an edge is stored once per owned end (once in all when interior), and that the poses of a unit occupy consecutive
+// lanes starting at an even one (what k_pipe_cg_sym's Jacobi-block step relies on).
+// usage: sym_check_cli [cases] [first_seed] [damage 1..4: self-test, one damaged layout entry per case must be noticed] [ranks 0 / 1]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +22,7 @@ using pgo::SymTile;
 
 static long long g_unfit = 0, g_tiles = 0, g_interior = 0, g_stored = 0;
 static int g_mutate = 0;      // self-test: damage one entry of the layout and expect the checks to notice
+static int g_ranks = 0;       // 1: the form of one rank's rows (owned range + 2-pose units)
 
 static int check_case(unsigned seed) {
   std::mt19937_64 rng(seed);
@@ -35,25 +40,30 @@ static int check_case(unsigned seed) {
     if (a != b) { ia.push_back(a); ib.push_back(b); }
   }
   const int E = (int)ia.size();
-  // incidence-slot numbering as prepare() lays it out: the row's diagonal, then its incidences in edge order
+  int lo = 0, hi = N;
+  const int unit = g_ranks ? 2 : 1;
+  if (g_ranks) { const int world = 2 + U(7), rk = U(world), per = ((N + world - 1) / world + 3) / 4 * 4; lo = std::min(N, rk * per); hi = std::min(N, lo + per); if (lo >= hi) { lo = 0; hi = std::min(N, per); } }
+  auto owned = [&](int v) { return v >= lo && v < hi; };
+  // incidence-slot numbering as prepare() lays it out: the (owned) row's diagonal, then its incidences in edge order
   std::vector<int> deg(N, 0), rsb(N, 0);
   for (int e = 0; e < E; ++e) { ++deg[ia[e]]; ++deg[ib[e]]; }
   int n_old = 0;
-  for (int v = 0; v < N; ++v) { rsb[v] = n_old; n_old += 1 + deg[v]; }
-  std::vector<int> fill(N), beg(E), end(E);
-  for (int v = 0; v < N; ++v) fill[v] = rsb[v] + 1;
-  for (int e = 0; e < E; ++e) { beg[e] = fill[ia[e]]++; end[e] = fill[ib[e]]++; }
+  for (int v = lo; v < hi; ++v) { rsb[v] = n_old; n_old += 1 + deg[v]; }
+  std::vector<int> fill(N, 0), beg(E, -1), end(E, -1);
+  for (int v = lo; v < hi; ++v) fill[v] = rsb[v] + 1;
+  for (int e = 0; e < E; ++e) { if (owned(ia[e])) beg[e] = fill[ia[e]]++; if (owned(ib[e])) end[e] = fill[ib[e]]++; }
   // a scalar per slot stands for its 6x6 block: H_ab = h[e], H_ba = its "transpose" (same scalar), diagonal d[v]
   std::vector<double> h_old(n_old, 0.0), x(N), y_ref(N, 0.0);
   std::uniform_real_distribution<double> ud(-1.0, 1.0);
-  for (int v = 0; v < N; ++v) { x[v] = ud(rng); h_old[rsb[v]] = 2.0 + ud(rng); y_ref[v] = h_old[rsb[v]] * x[v]; }
-  for (int e = 0; e < E; ++e) { const double w = ud(rng); h_old[beg[e]] = w; h_old[end[e]] = w; y_ref[ia[e]] += w * x[ib[e]]; y_ref[ib[e]] += w * x[ia[e]]; }
+  for (int v = 0; v < N; ++v) { x[v] = ud(rng); const double d = 2.0 + ud(rng); if (owned(v)) h_old[rsb[v]] = d; y_ref[v] = d * x[v]; }
+  for (int e = 0; e < E; ++e) { const double w = ud(rng); if (beg[e] >= 0) h_old[beg[e]] = w; if (end[e] >= 0) h_old[end[e]] = w; y_ref[ia[e]] += w * x[ib[e]]; y_ref[ib[e]] += w * x[ia[e]]; }
 
   pgo::SymHostParams hp;
   const int caps[] = {8, 16, 33, 64, 256};
   hp.row_cap = caps[U(5)];
   hp.w_cap = std::max<long long>(64, (long long)((0.6 + 0.1 * U(8)) * hp.row_cap * (double)(N + 2LL * E) / N));
   hp.sort_tiles = U(2) != 0;
+  if (g_ranks) { hp.row_lo = lo; hp.row_hi = hi; hp.unit = unit; }
   pgo::SymHostLayout L;
   pgo::sym_build_host(N, E, ia.data(), ib.data(), rsb.data(), hp, &L);
   if (L.unfit) { ++g_unfit; return g_mutate ? 1 : 0; }       // a declared "does not fit" is a valid outcome (the incidence-slot kernels stay)
@@ -87,7 +97,15 @@ static int check_case(unsigned seed) {
     if (total != T.total) fail("chunk sizes do not add up", total, T.total);
     stored += T.total;
   }
-  for (int v = 0; v < N; ++v) if (row_tile[v] < 0) fail("row in no tile", v);
+  for (int v = 0; v < N; ++v) { if (owned(v) && row_tile[v] < 0) fail("row in no tile", v); if (!owned(v) && row_tile[v] >= 0) fail("another rank's row in a tile", v); }
+  if (unit > 1)
+    for (size_t t = 0; t < L.tiles.size(); ++t) {
+      const SymTile& T = L.tiles[t];
+      for (int i = 0; i < T.nrows; ++i) {
+        const int v = L.xlist[T.x0 + i];
+        if ((v - lo) % unit == 0) { if (i % unit) fail("a unit starts at an odd lane", v, i); if (v + 1 < hi && (i + 1 >= T.nrows || L.xlist[T.x0 + i + 1] != v + 1)) fail("a unit is split", v); }
+      }
+    }
   // ---- the product, emulated ----
   std::vector<double> y(N, 0.0);
   for (size_t t = 0; t < L.tiles.size(); ++t) {
@@ -126,13 +144,15 @@ static int check_case(unsigned seed) {
     for (int r = 0; r < T.nrows; ++r) y[L.xlist[T.x0 + r]] = acc[r];
   }
   double worst = 0;
-  for (int v = 0; v < N; ++v) worst = std::max(worst, std::fabs(y[v] - y_ref[v]) / (1.0 + std::fabs(y_ref[v])));
+  for (int v = lo; v < hi; ++v) worst = std::max(worst, std::fabs(y[v] - y_ref[v]) / (1.0 + std::fabs(y_ref[v])));
   if (worst > 1e-12) fail("emulated product differs from the plain sum", (long long)(worst * 1e15));
   // an interior edge once, a cut edge twice, every diagonal once
-  if (stored != L.stored || interior != L.interior_edges || stored != (long long)N + 2LL * E - interior) fail("stored-slot count", stored, (long long)N + 2LL * E - interior);
+  if (stored != L.stored || interior != L.interior_edges || stored != (long long)n_old - interior) fail("stored-slot count", stored, (long long)n_old - interior);
   for (int e = 0; e < E; ++e) {
-    const int sb = seen_old[beg[e]], se = seen_old[end[e]];
-    if (!(sb == 1 && (se == 0 || se == 1)) || (se == 0) != (row_tile[ia[e]] == row_tile[ib[e]])) fail("edge storage", e, sb * 10 + se);
+    const bool oa = owned(ia[e]), ob = owned(ib[e]);
+    const int sb = oa ? seen_old[beg[e]] : -1, se = ob ? seen_old[end[e]] : -1;
+    if (oa && ob) { if (!(sb == 1 && (se == 0 || se == 1)) || (se == 0) != (row_tile[ia[e]] == row_tile[ib[e]])) fail("edge storage", e, sb * 10 + se); }
+    else if ((oa && sb != 1) || (ob && se != 1)) fail("edge with one owned end", e, sb * 10 + se);
   }
   return bad;
 }
@@ -141,6 +161,7 @@ int main(int argc, char** argv) {
   const int cases = argc > 1 ? atoi(argv[1]) : 200;
   const unsigned first = argc > 2 ? (unsigned)atoi(argv[2]) : 0u;
   g_mutate = argc > 3 ? atoi(argv[3]) : 0;
+  g_ranks = argc > 4 ? atoi(argv[4]) : 0;
   int bad = 0;
   if (g_mutate) std::fclose(stderr);
   for (int k = 0; k < cases; ++k) bad += check_case(first + k) != 0;
