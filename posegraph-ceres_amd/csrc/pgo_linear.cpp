@@ -38,8 +38,8 @@ bool pipe_mode(const pgo_problem* P, const pgo::CgParams& prm) {
          P->g.pipe_buf[0] != nullptr;
 }
 // one product launch of the owner-only CG (+ its fold): from the symmetric tile form where the session keeps its blocks there
-static void pipe_cg_launch(pgo_problem* P, const pgo::CgParams& prm, int seq, unsigned long long gseq = 0) {
-  if (P->sym_storage) pgo::launch_pipe_cg_sym(sym_view(P), P->sym, prm, seq, P->stream, gseq);
+static void pipe_cg_launch(pgo_problem* P, const pgo::CgParams& prm, int seq, unsigned long long gseq = 0, bool last_of_batch = false) {
+  if (P->sym_storage) pgo::launch_pipe_cg_sym(sym_view(P), P->sym, prm, seq, P->stream, gseq, last_of_batch);
   else pgo::launch_pipe_cg(P->g, prm, seq, 0, P->stream, gseq);
 }
 
@@ -100,7 +100,7 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool wi
     for (int i = 0; i < batch; ++i) {
       const int seq = start_it + i;
       if (P->g.peer_tab) { pipe_cg_launch(P, prm, seq, ++P->peer_gseq); continue; }
-      pipe_cg_launch(P, prm, seq);
+      pipe_cg_launch(P, prm, seq, 0, i == batch - 1);
       int rc = exchange(P, P->g.pipe_buf[(seq & 1) ^ 1], (size_t)P->g.pipe_seg);
       if (rc) return rc;
     }

@@ -226,6 +226,9 @@ int prepare(pgo_problem* P) {
   }
   int pq_cap = 1;
   for (int r = 0; r < world; ++r) pq_cap = std::max(pq_cap, pack(std::min(N, r * rows_per), std::min(N, (r + 1) * rows_per), false));
+  // (one rank: room for one p'q partial per tile of the symmetric form as well — tiles of >= 32 rows, filled to ~0.8 by the row and
+  // weight caps of pgo_sym.cpp: N / 26 of them; several ranks: the same room in the partial-sum rows, below)
+  if (world == 1) pq_cap = std::max(pq_cap, N / 16 + 8);
   const int n_wg = pack(row_lo, row_hi, true);
   if (slot > 0x7fffffffLL - 1024) return set_error(PGO_ERR_UNSUPPORTED, "graph too large for 32-bit slot indices");
   const int n_slots = (int)slot;
@@ -376,7 +379,7 @@ int prepare(pgo_problem* P) {
   const int n_vec_wg = std::max(1, std::min((int)(((size_t)6 * N + pgo::vec_block() - 1) / pgo::vec_block()), 256));
   const int n_edge_wg = std::min(std::max(1, (E + pgo::edge_block() - 1) / pgo::edge_block()), pgo::max_edge_wg());   // k_cost and the step tail stride beyond that
   const int n_pose_wg = (N + pgo::pose_block() - 1) / pgo::pose_block();
-  const int n_part = std::max(std::max(n_wg, n_vec_wg), n_edge_wg + n_pose_wg);   // the fused step tail runs n_edge_wg + n_pose_wg workgroups
+  const int n_part = std::max(std::max(std::max(n_wg, n_vec_wg), n_edge_wg + n_pose_wg), std::max(pq_cap, rows_per / 16 + 8));   // the fused step tail runs n_edge_wg + n_pose_wg workgroups; one entry per tile of the symmetric form
   // (blocks may come from the pool with a previous problem's contents: everything that is not fully written before it is read
   // is cleared here)
   HIP_TRY(P->d_part_rz.alloc((size_t)2 * n_part));

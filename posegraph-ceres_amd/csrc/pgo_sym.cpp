@@ -67,8 +67,11 @@ int sym_prepare(pgo_problem* P) {
   std::vector<uint32_t>&meta = H.meta, &rinfo = H.rinfo;
   lap("tile layout");
   const int n_slots = (int)meta.size();
-  if (T > P->g.pq_cap) {       // the p'q partials of the tiles ride in the slots of the row partition's work-groups
-    if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] sym: %d tiles > %d partial-sum slots: the incidence-slot kernels stay\n", T, P->g.pq_cap);
+  // one rank: the p'q partials of the tiles (k_spmv_sym<0>, Ceres' CG) ride in the slots of the row partition's work-groups; several
+  // ranks run the pipelined CG only (k_pipe_cg_sym), whose three partial sums per tile go to the partial-sum rows (n_part entries)
+  const int part_cap = P->g.world > 1 ? P->g.n_part : std::min(P->g.pq_cap, P->g.n_part);
+  if (T > part_cap) {
+    if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] sym: %d tiles > %d partial-sum slots: the incidence-slot kernels stay\n", T, part_cap);
     return PGO_OK;
   }
   if (pgo::sym_lds_bytes(pgo::SymGraph{T, (int)chunk_base.size(), n_slots, x_cap}) > 160 * 1024 - 1024) return PGO_OK;

@@ -64,7 +64,8 @@ void launch_sym_repack(const DeviceGraph& g, const SymGraph& sg, hipStream_t s, 
 size_t sym_lds_bytes(const SymGraph& sg);
 // r06: one iteration of the owner-only pipelined CG (k_pipe_cg's contract: launch `seq` reads pipe_buf[seq & 1], seq 0 = w0 = A u0) with
 // the product from the symmetric tile form, followed by k_pipe_fold; the tiles must be made of whole preconditioner clusters
-void launch_pipe_cg_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p, int seq, hipStream_t s, unsigned long long gseq = 0);
+// fold (one rank only; several ranks always fold): also run k_pipe_fold behind the launch — wanted in front of a "stop test only" launch
+void launch_pipe_cg_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p, int seq, hipStream_t s, unsigned long long gseq = 0, bool fold = false);
 // pgo_lean_kernels.hip: the row kernel writing the form (g.sym_dst / g.sym_val set) with the lean per-incidence algebra of pgo_lin_lean.h
 void launch_linearize_lean(const DeviceGraph& g, hipStream_t s, int gate = 0);      // (falls back to launch_linearize_symout when it does not fit)
 bool linearize_lean_fits(const DeviceGraph& g);

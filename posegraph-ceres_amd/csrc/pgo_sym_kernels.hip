@@ -419,8 +419,27 @@ __global__ __launch_bounds__(SYM_LANES) void k_pipe_cg_sym(DeviceGraph g, SymGra
   const double* rd = g.pipe_buf[rs];
   double* wr = g.pipe_buf[ws];
 
-  // ---- loads that depend on nothing: the tile, its first two chunks, the CG state, every rank's three sums ----
+  // ---- loads that depend on nothing.  What the stop test needs — the CG state and the sums — is requested FIRST, so that a launch
+  // enqueued past the CG's end leaves without waiting for blocks; then the tile's first two chunks ----
   const SymTile T = sg.tile[tile];
+  const int done0 = g.cg->done;
+  const CgState::Pipe st = g.cg->pipe[rs];
+  const bool w0 = seq == 0;
+  double f3[3] = {0.0, 0.0, 0.0};
+  if (g.world == 1) {
+    // one rank: every work-group folds the per-tile partial triples the launch before left (row `rs` of the partial-sum arrays; this
+    // launch writes row `ws`) — k_pipe_fold's loop and block sum, the same bits — instead of a one-work-group launch in between
+    if (!w0) {
+      const double* a0 = g.part_rz + (size_t)rs * g.n_part, *a1 = g.part_q + (size_t)rs * g.n_part, *a2 = g.part_rr + (size_t)rs * g.n_part;
+      for (int i = tid; i < sg.n_tiles; i += SYM_LANES) { f3[0] += a0[i]; f3[1] += a1[i]; f3[2] += a2[i]; }
+    }
+  } else {
+    // every rank's three sums, added in rank order by every lane alike: same bits everywhere
+    for (int rk = 0; rk < g.world; ++rk) {
+      const double* pp = rd + (size_t)rk * g.pipe_seg + (size_t)g.rows_per * 6;
+      f3[0] += pp[0]; f3[1] += pp[1]; f3[2] += pp[2];
+    }
+  }
   const int nch = T.nchunks;
   struct Chunk { double2 b[NPAIR]; uint32_t meta, rin; int n; };
   auto load_blocks = [&](Chunk& C, int ci, int base, int n) {
@@ -439,22 +458,8 @@ __global__ __launch_bounds__(SYM_LANES) void k_pipe_cg_sym(DeviceGraph g, SymGra
   Chunk CA, CB, CC;
   load_blocks(CA, T.chunk0, T.base0, T.n0);
   if (nch > 1) load_blocks(CB, T.chunk0 + 1, T.base1, T.n1);
-  const int done0 = g.cg->done;
-  const CgState::Pipe st = g.cg->pipe[rs];
-  double f_gamma = 0, f_delta = 0, f_q = 0;     // every rank's three sums, added in rank order by every lane alike: same bits everywhere
-  for (int rk = 0; rk < g.world; ++rk) {
-    const double* pp = rd + (size_t)rk * g.pipe_seg + (size_t)g.rows_per * 6;
-    f_gamma += pp[0]; f_delta += pp[1]; f_q += pp[2];
-  }
-  // m of every staged column (the tile's rows first, then its ghosts — other tiles' rows, other ranks' rows)
-  for (int i = tid; i < T.nx * 3; i += SYM_LANES) {
-    const int e = i / 3, k = i - 3 * e;
-    const int pose = sg.xlist[T.x0 + e];
-    const double2 z = reinterpret_cast<const double2*>(rd + sym_pipe_index(g, pose))[k];
-    xs[6 * e + 2 * k] = z.x;
-    xs[6 * e + 2 * k + 1] = z.y;
-  }
-  const bool w0 = seq == 0;
+  if (g.world == 1 && !w0) block_sum<3>(f3, scratch);
+  const double f_gamma = f3[0], f_delta = f3[1], f_q = f3[2];
   int stop = 0, status = 0;
   double alpha = 0.0, beta = 0.0, gamma = 0.0, Q1 = 0.0;
   const int cnt = st.cnt;
@@ -489,6 +494,14 @@ __global__ __launch_bounds__(SYM_LANES) void k_pipe_cg_sym(DeviceGraph g, SymGra
     if (w0) { n.cnt = 0; n.gamma_prev = 0.0; n.alpha_prev = 0.0; n.q_prev = 0.0; }
     else { n.cnt = cnt + 1; n.gamma_prev = gamma; n.alpha_prev = alpha; n.q_prev = Q1; }
     g.cg->pipe[ws] = n;
+  }
+  // m of every staged column (the tile's rows first, then its ghosts — other tiles' rows, other ranks' rows)
+  for (int i = tid; i < T.nx * 3; i += SYM_LANES) {
+    const int e = i / 3, k = i - 3 * e;
+    const int pose = sg.xlist[T.x0 + e];
+    const double2 z = reinterpret_cast<const double2*>(rd + sym_pipe_index(g, pose))[k];
+    xs[6 * e + 2 * k] = z.x;
+    xs[6 * e + 2 * k + 1] = z.y;
   }
   __syncthreads();
 
@@ -659,7 +672,10 @@ __global__ __launch_bounds__(SYM_LANES) void k_pipe_cg_sym(DeviceGraph g, SymGra
     }
   }
   block_sum<3>(acc, scratch);
-  if (tid == 0) { g.part_rz[tile] = acc[0]; g.part_q[tile] = acc[1]; g.part_rr[tile] = acc[2]; }
+  if (tid == 0) {       // one rank: row `ws` (the next launch folds it itself); several: row 0, folded by k_pipe_fold behind this launch
+    const size_t at = (g.world == 1 ? (size_t)ws * g.n_part : 0) + tile;
+    g.part_rz[at] = acc[0]; g.part_q[at] = acc[1]; g.part_rr[at] = acc[2];
+  }
 }
 
 template <bool PACKED>
@@ -717,7 +733,7 @@ void launch_spmv_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p
   }
 }
 
-void launch_pipe_cg_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p, int seq, hipStream_t s, unsigned long long gseq) {
+void launch_pipe_cg_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p, int seq, hipStream_t s, unsigned long long gseq, bool fold) {
   static bool attr_set = false;
   if (!attr_set) {
     const int cap = 160 * 1024 - 512;
@@ -733,8 +749,12 @@ void launch_pipe_cg_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams
                               else hipLaunchKernelGGL((k_pipe_cg_sym<PK, 1>), grid, block, lds, s, g, sg, p, seq); } while (0)
   if (g.blk_packed) PGO_PIPE_SYM(true); else PGO_PIPE_SYM(false);
 #undef PGO_PIPE_SYM
+  // several ranks: the rank's three sums go into the exchange buffer(s) behind every launch.  One rank: the next launch folds the
+  // partial triples itself; only the "stop test only" launch at the end of a batch (k_pipe_cg's, one work-group) wants them folded
+  if (g.world == 1 && !fold) return;
   DeviceGraph gf = g;
   gf.n_wg = sg.n_tiles;         // the fold adds one entry per work-group of the producing launch
+  if (g.world == 1) { const size_t off = (size_t)((seq & 1) ^ 1) * g.n_part; gf.part_rz += off; gf.part_q += off; gf.part_rr += off; }
   launch_pipe_fold(gf, seq, gseq, s);
 }
 
