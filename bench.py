@@ -379,10 +379,13 @@ def main():
             wall_tr = time.perf_counter() - t0
             rec, host_launches, host_s = prob.trace_read(400 * args.steps + 400)
             prob.trace_start(0)
-            names = {1: "head (accept-finish, damping, Jacobi blocks, CG start)", 2: "first product w0 = A u0",
-                     3: ("cg (ONE launch per LM iteration: first product, every PCG iteration with a grid barrier each, the step tail's A x)" if resident else
+            names = {1: ("head alone, behind a rejected step (damping, Jacobi blocks, CG start: every work-group on its own rows)" if resident else
+                         "head (accept-finish, damping, Jacobi blocks, CG start)"), 2: "first product w0 = A u0",
+                     3: ("cg + step tail + decision (ONE launch per LM iteration: first product, every PCG iteration with a grid barrier each, A x, "
+                         "candidate cost and model change from what the lanes hold, the decision by the last work-group to arrive)" if resident else
                          "cg (one launch per PCG iteration; the last one of a run multiplies A x for the step tail)"),
-                     4: "step tail + decision", 5: "linearise (behind an accepted step)", 0: "idle launch of the cycle (the linearise slot behind a rejected step)"}
+                     4: "step tail + decision", 5: ("linearise + head in one launch (behind an accepted step: accept-finish, damping, Jacobi blocks, CG start of the rows just linearised)" if resident else
+                                                    "linearise (behind an accepted step)"), 0: "idle launch of the cycle"}
             live = np.nonzero(rec[:, 0] > 0)[0]
             last = int(live.max())
             body, drain = rec[: last + 1], rec[last + 1:]
@@ -517,7 +520,7 @@ def main():
             roofline["frac_physical"] = roofline["traffic_frac_of_peak"]
         if breakdown is not None:
             extra["lm_step_breakdown"] = breakdown
-        extra["stream"] = ("resident universal stream (HEAD | the whole PCG in one launch, grid barrier per iteration | TAIL | LIN: four kernels in a fixed cycle)" if resident else
+        extra["stream"] = ("resident universal stream (r06: two launches per LM iteration — [linearise + head on the work-group's own rows] | [the whole PCG with a grid barrier per iteration + step tail + decision])" if resident else
                            "fused universal stream (k_uni_f: one kernel symbol, one launch per PCG iteration, pipelined recurrences)" if fused else
                            "two-kernel universal stream (k_uni_v / k_uni_s, standard CG)" if uni else "host-driven batches")
         ach_lin = b_lin / (t_lin * 1e-3) / 1e9

@@ -1399,8 +1399,10 @@ __device__ __forceinline__ void lm_cg_unfinished(const DeviceGraph& g) {
   D.accepted = 0;
   lm_mirror(g);
 }
+// cg_iters / cg_status >= 0: the caller knows how the CG ended (the resident stream decides in the launch that ran the CG: the CG state
+// words may sit, stale, in the deciding compute unit's L1); otherwise they are read from the CG state
 __device__ __forceinline__ void lm_device_decide(const DeviceGraph& g, double cand_cost, double model_change, double step_norm_sq,
-                                                 double x_norm_sq, int bad, int direct) {
+                                                 double x_norm_sq, int bad, int direct, int cg_iters = -1, int cg_status = -1) {
   LmDev& D = *g.lm;
   const long long now = (long long)__builtin_amdgcn_s_memrealtime();
   D.ticks_linear += now - D.t_mark;
@@ -1412,7 +1414,8 @@ __device__ __forceinline__ void lm_device_decide(const DeviceGraph& g, double ca
     lm_mirror(g);
     return;
   }
-  const LmStepIn in{cand_cost, model_change, step_norm_sq, x_norm_sq, (direct & 1) ? 0 : g.cg->iters, (direct & 1) ? 0 : g.cg->status, bad, 0};
+  const LmStepIn in{cand_cost, model_change, step_norm_sq, x_norm_sq, (direct & 1) ? 0 : cg_iters >= 0 ? cg_iters : g.cg->iters,
+                    (direct & 1) ? 0 : cg_iters >= 0 ? cg_status : g.cg->status, bad, 0};
   LmRecord nx;
   double tv = 0.0;
   const LmOutcome out = lm_decide(D.core, D.tol, in, nx, tv);
@@ -2764,32 +2767,24 @@ bool uni_r_supported(const DeviceGraph& g, const CgParams& p, int cluster) {
 }
 int uni_r_abort_word() { return RES_ABORT; }
 void launch_uni_r(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s) {
-  const int role = launch & 3;
+  // r06: a cycle of TWO — [LIN (behind an accepted step) + HEAD, every work-group on its own rows] | [the whole CG + the step tail + the
+  // decision] — where r05 ran four launches per LM iteration (HEAD | CG | TAIL | LIN)
+  const int role = launch & 1;
   const dim3 grid(g.n_wg), blk(g.block);
-  if (role == 0 || role == 2) {
-    const int op = role == 0 ? F_HEAD : F_TAIL;
-    const size_t lds = (size_t)g.block * sizeof(double);
-#define PGO_RES_V2(INF, C) do { if (op == F_HEAD) hipLaunchKernelGGL((k_res_v<INF, C, F_HEAD>), grid, blk, lds, s, g, launch, min_diag, max_diag); \
-                                else hipLaunchKernelGGL((k_res_v<INF, C, F_TAIL>), grid, blk, lds, s, g, launch, min_diag, max_diag); } while (0)
-#define PGO_RES_V(INF) do { if (g.cluster == 2) PGO_RES_V2(INF, 2); else PGO_RES_V2(INF, 1); } while (0)
-    if (g.info_mode == 3) PGO_RES_V(3); else if (g.info_mode == 2) PGO_RES_V(2); else if (g.info_mode == 1) PGO_RES_V(1); else PGO_RES_V(0);
-#undef PGO_RES_V
-#undef PGO_RES_V2
-  } else if (role == 1) {
-    const size_t lds = ((size_t)(SPMV_LDS_STRIDE + 6) * g.block + 8) * sizeof(double);
-#define PGO_RES_CG(PK) do { if (g.cluster == 2) hipLaunchKernelGGL((k_res_cg<PK, 2>), grid, blk, lds, s, g, p, launch); \
-                            else hipLaunchKernelGGL((k_res_cg<PK, 1>), grid, blk, lds, s, g, p, launch); } while (0)
-    if (g.blk_packed) PGO_RES_CG(true); else PGO_RES_CG(false);
-#undef PGO_RES_CG
-  } else if (g.info_mode != 1) {
-    // (information without position / rotation coupling: packed slots; 32-bit byte offsets are what uni_supported() admitted the graph on)
-    const size_t lds = (size_t)LEAN_NV * (g.block / 2) * sizeof(double);
-    if (g.info_mode == 3) hipLaunchKernelGGL(k_res_lin_lean<3>, grid, blk, lds, s, g, launch);
-    else if (g.info_mode == 2) hipLaunchKernelGGL(k_res_lin_lean<2>, grid, blk, lds, s, g, launch);
-    else hipLaunchKernelGGL(k_res_lin_lean<0>, grid, blk, lds, s, g, launch);
+  if (role == 0) {
+    const bool lean = g.info_mode != 1;      // (information without position / rotation coupling: packed slots, the lean algebra)
+    const size_t lds = std::max((size_t)g.block, lean ? (size_t)LEAN_NV * (g.block / 2) : (size_t)NV_LIN * g.block) * sizeof(double);
+#define PGO_RES_LH(INF, LN) do { if (g.cluster == 2) hipLaunchKernelGGL((k_res_lh<INF, 2, LN>), grid, blk, lds, s, g, launch, min_diag, max_diag); \
+                                 else hipLaunchKernelGGL((k_res_lh<INF, 1, LN>), grid, blk, lds, s, g, launch, min_diag, max_diag); } while (0)
+    if (g.info_mode == 3) PGO_RES_LH(3, true); else if (g.info_mode == 2) PGO_RES_LH(2, true); else if (g.info_mode == 1) PGO_RES_LH(1, false); else PGO_RES_LH(0, true);
+#undef PGO_RES_LH
   } else {
-    const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);
-    hipLaunchKernelGGL(k_res_lin<1>, grid, blk, lds, s, g, launch);      // the general body: information with position / rotation coupling
+    const size_t lds = ((size_t)(SPMV_LDS_STRIDE + 6) * g.block + 8) * sizeof(double);
+#define PGO_RES_CG(PK, INF) do { if (g.cluster == 2) hipLaunchKernelGGL((k_res_cg<PK, 2, INF>), grid, blk, lds, s, g, p, launch); \
+                                 else hipLaunchKernelGGL((k_res_cg<PK, 1, INF>), grid, blk, lds, s, g, p, launch); } while (0)
+    // (packed 27-entry slots <=> information without position / rotation coupling: INFO 0, 2, 3)
+    if (g.info_mode == 3) PGO_RES_CG(true, 3); else if (g.info_mode == 2) PGO_RES_CG(true, 2); else if (g.info_mode == 1) PGO_RES_CG(false, 1); else PGO_RES_CG(true, 0);
+#undef PGO_RES_CG
   }
 }
 void launch_uni_f(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s) {

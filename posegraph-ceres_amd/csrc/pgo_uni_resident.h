@@ -26,10 +26,13 @@
 // the host is told (LmScalars::resident_abort) and carries on with the fused stream's launches instead of hanging the device.  The host admits ONE resident session per device at a time
 // (pgo_lm.cpp) and only grids that fit the chip at two waves per SIMD.
 //
-// The stream: four kernel symbols in a fixed cycle, launch L plays role L % 4 —
-//     k_res_v (HEAD) | k_res_cg (the whole CG + the step tail's A x) | k_res_v (TAIL + decision) | k_res_lin (behind an accepted step)
-// — each acting only if the state word says its operation is next (a rejected step leaves the LIN launch idle), state double-buffered
-// by launch parity exactly as in the fused stream; the host enqueues whole cycles ahead of the device's launch counter.
+// The stream (r06): TWO kernel symbols in a fixed cycle, launch L plays role L % 2 —
+//     k_res_lh (LIN behind an accepted step + HEAD, every work-group on its own rows) | k_res_cg (the whole CG + the step tail + the decision)
+// — each acting only if the state word says its operation is next, state double-buffered by launch parity exactly as in the fused
+// stream; the host enqueues whole cycles ahead of the device's launch counter.  (r05 ran four launches per LM iteration: HEAD | CG |
+// TAIL | LIN.  Measured on one box, C2, 20 / 25 steps: 0.1872 / 0.1676 ms per LM iteration with four, 0.1852 / 0.1663 with the tail
+// inside the CG launch, 0.1874 / 0.1666 with LIN + HEAD in one launch as well — the boundaries saved are paid back by Jacobi blocks
+// inverted on all 392 work-groups, two per compute unit on half the chip, instead of on 250: EXPERIMENTS.md r06.)
 
 // barrier words in g.flags (zeroed whenever the device state is uploaded), each on a 128-byte line of its own (32 ints): arrivals of
 // class c (work-group index % RES_NCLS) at RES_CLS + 32 c, generation = barriers class c has completed at RES_GEN + 32 c, abort at
@@ -110,105 +113,151 @@ __device__ __forceinline__ void res_when_aborted(const DeviceGraph& g, int rp, i
   __hip_atomic_store(&g.scal->resident_abort, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// ---- roles 0 and 2: HEAD and TAIL (the fused stream's operations, without its speculative requests) ----
-// (the role is a template argument: HEAD — a 12x12 Gauss-Jordan in registers — and TAIL — the edge costs — get a register allocation each)
-template <int INFO, int CL, int ROLE>
-__global__ __launch_bounds__(256, 2) void k_res_v(DeviceGraph g, int launch, double min_diag, double max_diag) {
-  constexpr int role_op = ROLE;
-  extern __shared__ double lds[];
+// ---- r06, role 0 of the TWO-launch cycle: LIN (behind an accepted step) and HEAD in one launch, every work-group on ITS OWN rows ----
+// HEAD as a launch of its own (r05: the fused stream's text, pgo_uni_head_tail.inc) handed Jacobi blocks out in chunks of 40 poses to the first 250
+// work-groups, whatever rows those own.  Everything HEAD reads of a row, though — its diagonal block and gradient, the blocks between
+// the two poses of its cluster, its scales — is written by the work-group that OWNS the row when it linearises, and a work-group holds
+// whole clusters (prepare(): pairs_whole).  So the work-group that has just linearised its rows goes straight on: candidate -> current
+// point and gradient norm of its rows, damping, its clusters' 12 x 12 inverses in registers (cluster_precond_wave), r0 = b, u0 = M^-1 b
+// into the exchange buffer — no kernel boundary, no idle LIN slot behind a rejected step (the launch then runs HEAD alone), 392 waves'
+// worth of Gauss-Jordan spread over all work-groups instead of 250.  Only the last work-group to arrive does the global part (gradient
+// max-norm, the opening tests of the pass, the next operation), as in HEAD.
+template <int INFO, int CL, bool LEAN>
+__global__ __launch_bounds__(256, 2) void k_res_lh(DeviceGraph g, int launch, double min_diag, double max_diag) {
+  extern __shared__ double lds[];  // the linearisation's row sums (LEAN_NV * block / 2 or NV_LIN * block doubles) / HEAD: block doubles
   __shared__ double scratch[32];
   __shared__ int is_last_s;
   constexpr int DIM = 6 * CL;
   const int B = blockDim.x, tid = threadIdx.x, wg = blockIdx.x;
-  const int m = 6 * g.N, nT = g.n_wg;
+  const int nT = g.n_wg;
   const int rp = launch & 1, wp = rp ^ 1;
   double* wr = g.pipe_buf[wp];
-  int& is_last = is_last_s;
   const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   const int st_op = g.cg->f[rp].op;
   if (wg == 0 && tid == 0) __hip_atomic_store(&g.scal->slots_done, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const bool aborted = res_aborted(g);
-  const bool mine = st_op == role_op && !aborted;
-  uni_f_trace_begin(g, launch, mine ? role_op : 0, t_top);
+  const bool mine = (st_op == F_LIN || st_op == F_HEAD) && !aborted;
+  uni_f_trace_begin(g, launch, mine ? st_op : 0, t_top);
   if (!mine) {
     if (!aborted) res_pass_on(g, rp, wp);
     else if (wg == 0 && tid == 0) res_when_aborted(g, rp, wp);
     uni_f_trace_end(g, launch);
     return;
   }
-  if constexpr (ROLE == F_HEAD) {
-    [&]() {          // (the pasted block leaves by `return`)
-#define PGO_UNI_HEAD_BLOCK
-#define PGO_UNI_HEAD_NEXT F_CG
-#include "pgo_uni_head_tail.inc"
-#undef PGO_UNI_HEAD_NEXT
-#undef PGO_UNI_HEAD_BLOCK
-    }();
-  } else {
-    [&]() {
-#define PGO_UNI_TAIL_BLOCK
-#include "pgo_uni_head_tail.inc"
-#undef PGO_UNI_TAIL_BLOCK
-    }();
-  }
-  uni_f_trace_end(g, launch);
-}
-
-// ---- role 3: the linearisation of an accepted candidate ----
-template <int INFO>
-__global__ __launch_bounds__(256) void k_res_lin(DeviceGraph g, int launch) {
-  extern __shared__ double lds[];  // NV_LIN * block
-  const int rp = launch & 1, wp = rp ^ 1;
-  const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-  const int st_op = g.cg->f[rp].op, st_mirror = g.cg->f[rp].mirror;
-  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&g.scal->slots_done, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const bool aborted = res_aborted(g);
-  const bool mine = st_op == F_LIN && !aborted;
-  uni_f_trace_begin(g, launch, mine ? F_LIN : 0, t_top);
-  if (!mine) {
-    if (!aborted) res_pass_on(g, rp, wp);
-    else if (blockIdx.x == 0 && threadIdx.x == 0) res_when_aborted(g, rp, wp);
-  } else {
+  if (st_op == F_LIN) {
     DeviceGraph gl = g;
-    gl.pose_x = g.pose_c;          // the accepted candidate; the accept-finish part of the next HEAD copies it over
-    linearize_body<INFO>(gl, lds);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      if (st_mirror) lm_mirror(g);
-      res_put_state(g, wp, F_HEAD, 0, 0.0, 0.0, 0.0);
+    gl.pose_x = g.pose_c;          // the accepted candidate; the accept-finish part below copies it over
+    if constexpr (LEAN) lean_linearize_body<INFO, true>(gl, lds);
+    else linearize_body<INFO>(gl, lds);
+    __syncthreads();               // this work-group's diagonal blocks, gradient and blocks are in place for its other waves
+  }
+  const long long t_lin = uni_f_traced(g, launch) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+  LmDev& D = *g.lm;
+  const int accepted = D.accepted, pause = D.pause;
+  const double radius = D.core.radius;
+  const int mode = D.core.reuse_diagonal ? 1 : 0;
+  const int r0 = g.wg_row_begin[wg], nrows = g.wg_row_begin[wg + 1] - r0;
+  // ---- accept-finish of the work-group's rows ----
+  double gmx = 0.0;
+  if (accepted && tid < nrows) {
+    const int v = r0 + tid;
+    const PoseRec P = load_pose(g.pose_c, v);
+    const double2* src = reinterpret_cast<const double2*>(g.pose_c + (size_t)POSE_STRIDE * v);
+    double2* dst = reinterpret_cast<double2*>(g.pose_x + (size_t)POSE_STRIDE * v);
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    const uint8_t cm = g.cmask[v];
+    const double* gr = g.grad + 6 * (size_t)v;
+    if (!(cm & 1)) gmx = fmax(gmx, fmax(fabs(gr[0]), fmax(fabs(gr[1]), fabs(gr[2]))));
+    if (!(cm & 2)) {
+      const Q4 q = quat_plus(P.q, V3{-gr[3], -gr[4], -gr[5]});
+      gmx = fmax(gmx, fmax(fmax(fabs(P.q.x - q.x), fabs(P.q.y - q.y)), fmax(fabs(P.q.z - q.z), fabs(P.q.w - q.w))));
     }
   }
-  uni_f_trace_end(g, launch);
-}
-
-// ... with the lean algebra (pgo_lin_lean.h / pgo_lean_body.h: 0.68 of the FP64 instructions, half the LDS) where the information has no
-// position / rotation coupling — the blocks go to their own incidence slots of the BSR, the row sums to Hdiag / grad as always
-template <int INFO>
-__global__ __launch_bounds__(256, 2) void k_res_lin_lean(DeviceGraph g, int launch) {
-  extern __shared__ double lds[];  // LEAN_NV * block / 2
-  const int rp = launch & 1, wp = rp ^ 1;
-  const long long t_top = g.oplog ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-  const int st_op = g.cg->f[rp].op, st_mirror = g.cg->f[rp].mirror;
-  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&g.scal->slots_done, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const bool aborted = res_aborted(g);
-  const bool mine = st_op == F_LIN && !aborted;
-  uni_f_trace_begin(g, launch, mine ? F_LIN : 0, t_top);
-  if (!mine) {
-    if (!aborted) res_pass_on(g, rp, wp);
-    else if (blockIdx.x == 0 && threadIdx.x == 0) res_when_aborted(g, rp, wp);
-  } else {
-    DeviceGraph gl = g;
-    gl.pose_x = g.pose_c;          // the accepted candidate; the accept-finish part of the next HEAD copies it over
-    lean_linearize_body<INFO, true>(gl, lds);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      if (st_mirror) lm_mirror(g);
-      res_put_state(g, wp, F_HEAD, 0, 0.0, 0.0, 0.0);
+  gmx = wave_max(gmx);
+  if ((tid & 63) == 0) scratch[tid >> 6] = gmx;
+  __syncthreads();
+  if (tid == 0 && accepted) {
+    double tm = 0.0;
+    for (int w = 0; w < (B + 63) / 64; ++w) tm = fmax(tm, scratch[w]);
+    __hip_atomic_store(&g.part_misc[4 * (size_t)g.n_part + wg], tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  // ---- damping, Jacobi blocks, CG start of the work-group's rows ----
+  if (!pause) {
+    if constexpr (CL == 1) {
+      if (tid < nrows) damping_pose(g, r0 + tid, radius, min_diag, max_diag, mode);
+      __syncthreads();      // the inverses were written by other lanes of this work-group
+      const int ridx = 6 * r0 + tid;
+      const bool rlive = tid < 6 * nrows;
+      double b = 0.0;
+      if (rlive) {
+        b = g.scale[ridx] * g.grad[ridx];
+        g.cg_b[ridx] = b;
+        g.cg_x[ridx] = 0.0;
+        g.cg_r[ridx] = b;
+      }
+      lds[tid] = b;
+      __syncthreads();
+      if (rlive) {
+        const double* Mi = g.Minv + (size_t)ridx * DIM;
+        const double* rv = lds + DIM * (tid / DIM);
+        double u = 0.0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) u += Mi[k] * rv[k];
+        g.cg_u[ridx] = u;
+        wr[ridx] = u;
+      }
+    } else {                // a wave inverts Jacobi blocks in registers and starts the CG of their rows from there (no barrier)
+      constexpr int CPW = 64 / DIM;
+      const int wave = tid >> 6, lane = tid & 63, nw = B >> 6;
+      const int c_first = r0 / CL, c_end = (r0 + nrows + CL - 1) / CL;       // (r0 is a multiple of CL: a work-group holds whole clusters)
+      for (int c0 = c_first + wave * CPW; c0 < c_end; c0 += nw * CPW)
+        cluster_precond_wave<CL, true>(g, radius, min_diag, max_diag, mode, c0, min(c_end, c0 + CPW), lane, wr);
+    }
+  }
+  // ---- the last work-group to finish: gradient norm of the accepted point, the opening tests of the next pass, the next operation ----
+  if (tid == 0) is_last_s = uni_f_last_arrival(g, wg, nT);
+  __syncthreads();
+  if (is_last_s) {
+    double mm = 0.0;
+    if (accepted)
+      for (int i = tid; i < nT; i += B)
+        mm = fmax(mm, __hip_atomic_load(&g.part_misc[4 * (size_t)g.n_part + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    mm = wave_max(mm);
+    if ((tid & 63) == 0) scratch[tid >> 6] = mm;
+    __syncthreads();
+    if (tid == 0) {
+      const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+      if (accepted) {
+        double tm = 0.0;
+        for (int w = 0; w < (B + 63) / 64; ++w) tm = fmax(tm, scratch[w]);
+        D.core.gmax = tm;
+        g.scal->ring[D.core.iteration % LM_RING].gradient_max_norm = tm;
+        g.scal->gradient_max = tm;
+        D.accepted = 0;
+        lm_pre_step_checks(D, true);
+        D.ticks_jacobian += now - D.t_mark;
+        D.t_mark = now;
+      }
+      int next_op = F_CG;
+      if (D.halt) next_op = F_EXIT;
+      else if (pause) { D.halt = LM_HALT_BUDGET; next_op = F_EXIT; }
+      CgState::Fused* d = &g.cg->f[wp];
+      d->op = next_op; d->cnt = 0; d->pad = 0;
+      d->mirror = 1;         // the next launch publishes the state to the host (lane 0 of its work-group 0, beside its work)
+      d->gamma_prev = 0.0; d->alpha_prev = 0.0; d->q_prev = 0.0;
+      g.cg->done = 0; g.cg->iters = 0; g.cg->status = 0;
+      if (uni_f_traced(g, launch)) {   // phase stamps of the LAST work-group to arrive: its linearisation done / end
+        const long long t_end = (long long)__builtin_amdgcn_s_memrealtime();
+        g.oplog[1 + UNI_F_TRACE_WORDS * (size_t)launch + 1] = ((t_lin - t_top) & 0xffff) | (((t_end - t_top) & 0xffff) << 48);
+      }
     }
   }
   uni_f_trace_end(g, launch);
 }
 
 // ---- role 1: the whole CG ----
-template <bool PACKED, int CL>
+template <bool PACKED, int CL, int INFO>
 __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, int launch) {
   constexpr int NPAIR = PACKED ? BLK_PAIRS_PACKED : BLK_PAIRS_FULL;
   constexpr int DIM = 6 * CL;
@@ -412,39 +461,105 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
     return;
   }
   // ---- the CG has stopped after `cnt` iterations (every work-group alike, behind the same barrier: the x every row lane stored in front
-  // of it is the final one): q = A x and the candidates for the step tail ----
+  // of it is the final one).  r06: the STEP TAIL runs here, in the same launch and without another grid barrier — q = A x from the blocks
+  // still in registers; the model change from the row lanes' own x, b, q; the candidate of a pose recomputed by every lane that needs it
+  // (Plus(x_v, -S_v x_v) from the gathered x of the slot's column and the work-group's own rows: the formula of the DIAG lane that writes
+  // pose_c); the candidate cost of an edge by its BEGIN-side slot lane from the slot-order measurement / information arrays (edge_cost's
+  // arithmetic per edge, summed per work-group); four partial sums per work-group, and the last work-group to arrive folds and DECIDES
+  // (the TAIL operation of pgo_uni_head_tail.inc from its ticket on).  What the TAIL launch of r05 cost — a kernel boundary, its state and
+  // argument round trips, two strided gather loops — is one round trip of loads here. ----
   if (wg == 0 && tid == 0) {
     if (st_mirror) lm_mirror(g);
-    g.cg->iters = cnt; g.cg->status = status; g.cg->done = 1;
-    res_put_state(g, wp, F_TAIL, 0, 0.0, 0.0, 0.0);
     if (traced) g.oplog[1 + UNI_F_TRACE_WORDS * (size_t)launch + 1] = (ph0 & 0xffff) | ((ph1 & 0xffff) << 16) | ((ph2 & 0xffff) << 32) | ((long long)(cnt & 0xffff) << 48);
   }
+  const size_t ns = (size_t)g.n_slots;
   double y[6] = {0, 0, 0, 0, 0, 0};
+  double acc4[4] = {0.0, 0.0, 0.0, 0.0};   // candidate cost, model change, |step|^2, |x|^2
+  // everything the tail reads, requested together: x of the column (written by other work-groups: past the L1), the static records of
+  // the slot's two poses, the slot's measurement and information, the row lane's damping entry
+  const bool is_begin = col >= 0 && side == SIDE_BEGIN, is_diag = col >= 0 && side == SIDE_DIAG;
+  PoseRec Pc{}, Pr{};
+  double sc_c[6] = {0, 0, 0, 0, 0, 0}, sc_r[6] = {0, 0, 0, 0, 0, 0};
+  uint8_t cm_c = 0, cm_r = 0;
+  double ms[7] = {0, 0, 0, 0, 0, 0, 1};
+  WBlocks Wt{};
   if (col >= 0) {
-    {
-      const __amdgpu_buffer_rsrc_t xb = res_buf(g.cg_x);
-      const double2 a = res_ld2(xb, col_off), b = res_ld2(xb, col_off + 16), c = res_ld2(xb, col_off + 32);
-      x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y; x[4] = c.x; x[5] = c.y;
-    }
-    if (side == SIDE_DIAG) {
-      const PoseRec P = load_pose(g.pose_x, row);
-      const uint8_t cm = g.cmask[row];
-      double d[6];
+    const __amdgpu_buffer_rsrc_t xb = res_buf(g.cg_x);
+    const double2 a = res_ld2(xb, col_off), b = res_ld2(xb, col_off + 16), c = res_ld2(xb, col_off + 32);
+    x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y; x[4] = c.x; x[5] = c.y;
+  }
+  if (is_begin || is_diag) {
+    Pc = load_pose(g.pose_x, col);
+    cm_c = g.cmask[col];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const bool c = (i < 3) ? (cm & 1) : (cm & 2);
-        d[i] = c ? 0.0 : -g.scale[6 * (size_t)row + i] * x[i];
-        g.delta[6 * (size_t)row + i] = d[i];
-      }
-      V3 pc = P.p;
-      Q4 qc = P.q;
-      if (!(cm & 1)) pc = V3{P.p.x + d[0], P.p.y + d[1], P.p.z + d[2]};
-      if (!(cm & 2)) qc = quat_plus(P.q, V3{d[3], d[4], d[5]});
+    for (int i = 0; i < 6; ++i) sc_c[i] = g.scale[6 * (size_t)col + i];
+  }
+  if (is_begin) {
+    Pr = load_pose(g.pose_x, row);
+    cm_r = g.cmask[row];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sc_r[i] = g.scale[6 * (size_t)row + i];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) ms[i] = g.smeas[(size_t)i * ns + t];
+    if constexpr (INFO == 3) Wt = load_W_diag(g.sW, ns, (size_t)t);
+    else if constexpr (INFO == 2) Wt = load_W_blockdiag(g.sW, ns, (size_t)t);
+    else if constexpr (INFO == 1) Wt = load_W(g.sW, ns, (size_t)t);
+  }
+  double d2v = 0.0;
+  uint8_t cm_own = 0;
+  if (own) { d2v = g.d2[gi]; cm_own = g.cmask[r0 + tid / 6]; lds_w[tid] = vx; }      // (x of the work-group's rows for its BEGIN lanes)
+  __syncthreads();
+  // Plus(pose, -S x) of a pose: the candidate (the DIAG lane's statements)
+  auto candidate = [](const PoseRec& P, uint8_t cm, const double (&sc)[6], const double (&xv)[6], double (&d)[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const bool c = (i < 3) ? (cm & 1) : (cm & 2);
+      d[i] = c ? 0.0 : -sc[i] * xv[i];
+    }
+    PoseRec C = P;
+    if (!(cm & 1)) C.p = V3{P.p.x + d[0], P.p.y + d[1], P.p.z + d[2]};
+    if (!(cm & 2)) C.q = quat_plus(P.q, V3{d[3], d[4], d[5]});
+    return C;
+  };
+  if (col >= 0) {
+    if (is_diag) {
+      double d[6];
+      const PoseRec C = candidate(Pc, cm_c, sc_c, x, d);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) g.delta[6 * (size_t)row + i] = d[i];
       double2* o = reinterpret_cast<double2*>(g.pose_c + (size_t)POSE_STRIDE * row);
-      o[0] = double2{pc.x, pc.y};
-      o[1] = double2{pc.z, qc.x};
-      o[2] = double2{qc.y, qc.z};
-      o[3] = double2{qc.w, 0.0};
+      o[0] = double2{C.p.x, C.p.y};
+      o[1] = double2{C.p.z, C.q.x};
+      o[2] = double2{C.q.y, C.q.z};
+      o[3] = double2{C.q.w, 0.0};
+      if (!(cm_c & 1)) {
+        const double dx = Pc.p.x - C.p.x, dy = Pc.p.y - C.p.y, dz = Pc.p.z - C.p.z;
+        acc4[2] += dx * dx + dy * dy + dz * dz;
+        acc4[3] += Pc.p.x * Pc.p.x + Pc.p.y * Pc.p.y + Pc.p.z * Pc.p.z;
+      }
+      if (!(cm_c & 2)) {
+        const double dx = Pc.q.x - C.q.x, dy = Pc.q.y - C.q.y, dz = Pc.q.z - C.q.z, dw = Pc.q.w - C.q.w;
+        acc4[2] += dx * dx + dy * dy + dz * dz + dw * dw;
+        acc4[3] += Pc.q.x * Pc.q.x + Pc.q.y * Pc.q.y + Pc.q.z * Pc.q.z + Pc.q.w * Pc.q.w;
+      }
+    } else if (is_begin) {
+      double xr[6], dr[6], dc[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xr[i] = lds_w[6 * (row - r0) + i];
+      const PoseRec CA = candidate(Pr, cm_r, sc_r, xr, dr), CB = candidate(Pc, cm_c, sc_c, x, dc);
+      double er[6];
+      edge_error(CA.p, CA.q, CB.p, CB.q, V3{ms[0], ms[1], ms[2]}, Q4{ms[3], ms[4], ms[5], ms[6]}, er);
+      double sq;
+      if constexpr (INFO != 0) {       // (edge_cost's statements)
+        const V3 ep{er[0], er[1], er[2]}, eq{er[3], er[4], er[5]};
+        const V3 a1 = mulv(Wt.pp, ep), a2 = mulv(Wt.pr, eq), b1 = mulTv(Wt.pr, ep), b2 = mulv(Wt.rr, eq);
+        sq = dot(ep, V3{a1.x + a2.x, a1.y + a2.y, a1.z + a2.z}) + dot(eq, V3{b1.x + b2.x, b1.y + b2.y, b1.z + b2.z});
+      } else {
+        sq = er[0] * er[0] + er[1] * er[1] + er[2] * er[2] + er[3] * er[3] + er[4] * er[4] + er[5] * er[5];
+      }
+      double rho0, rho1;
+      loss_eval(g.loss_kind, g.loss_a, sq, &rho0, &rho1);
+      acc4[0] = 0.5 * rho0;
     }
     slot_block_times<PACKED, NPAIR>(blk, side, x, y);
   }
@@ -456,7 +571,52 @@ __global__ __launch_bounds__(256, 2) void k_res_cg(DeviceGraph g, CgParams prm, 
     int j = sb;
     for (; j + 1 < sE; j += 2) { s0 += lds[j * SPMV_LDS_STRIDE + kc]; s1 += lds[(j + 1) * SPMV_LDS_STRIDE + kc]; }
     if (j < sE) s0 += lds[j * SPMV_LDS_STRIDE + kc];
-    g.cg_q[gi] = s0 + s1;
+    const double qv = s0 + s1;
+    g.cg_q[gi] = qv;
+    const double hx = qv - d2v * vx;
+    const bool c = (kc < 3) ? (cm_own & 1) : (cm_own & 2);
+    acc4[1] = c ? 0.0 : (vx * vb - 0.5 * vx * hx);
+  }
+  block_sum<4>(acc4, scratch);
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __hip_atomic_store(&g.part_misc[(size_t)k * g.n_part + wg], acc4[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_ok = uni_f_last_arrival(g, wg, g.n_wg) ? 1 : 0;
+  }
+  __syncthreads();
+  if (sh_ok) {
+    // the last work-group to arrive: fold (the other work-groups' partials were stored write-through before their tickets and are read
+    // with device-scope loads) and decide — the TAIL operation's statements
+    const int nT = g.n_wg;
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk * B < nT; ++kk) {
+      const int i = min(tid + kk * B, nT - 1);
+      const double wgt = tid + kk * B < nT ? 1.0 : 0.0;
+      double v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = __hip_atomic_load(&g.part_misc[(size_t)k * g.n_part + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s4[k] += wgt * v[k];
+    }
+    block_sum<4>(s4, scratch);
+    if (tid == 0) {
+      g.scal->cand_cost = s4[0];
+      g.scal->model_change = s4[1];
+      g.scal->step_norm_sq = s4[2];
+      g.scal->x_norm_sq = s4[3];
+      const int bad = g.flags[1] | (g.flags[2] << 1);
+      g.scal->linearize_bad = bad;
+      g.flags[1] = 0;
+      g.flags[2] = 0;
+      g.cg->iters = cnt; g.cg->status = status; g.cg->done = 1;
+      lm_device_decide(g, s4[0], s4[1], s4[2], s4[3], bad, 2 | 8, cnt, status);    // accept / reject / stop, on the spot (pgo_lm_rules.h); 8: no mirror here
+      LmDev& D = *g.lm;
+      CgState::Fused* d = &g.cg->f[wp];
+      d->op = D.halt ? F_EXIT : D.accepted ? F_LIN : F_HEAD;
+      d->cnt = 0; d->pad = 0;
+      d->mirror = 1;         // the next launch publishes the decision to the host
+      d->gamma_prev = 0.0; d->alpha_prev = 0.0; d->q_prev = 0.0;
+    }
   }
   uni_f_trace_end(g, launch);
 }

@@ -116,7 +116,11 @@ def test_one_resident_session_per_device_the_next_one_takes_the_fused_stream(gpu
     assert gpu.solve(opt, c).cg_form == 4
 
 
-def test_resident_launch_trace_is_the_four_kernel_cycle(gpu, ds, monkeypatch):
+def test_resident_launch_trace_is_the_two_kernel_cycle(gpu, ds, monkeypatch):
+    """r06: an LM iteration is TWO launches — [linearise (behind an accepted step) + head, every work-group on its own rows] and
+    [the whole CG + the step tail + the decision] — where r05 ran four (HEAD | CG | TAIL | LIN).  The launch trace names what each
+    launch did: an even launch records 5 (linearise + head) behind an accepted step and 1 (head alone) behind a rejected one or at the
+    start, an odd launch 3 (CG, with the iteration count in its phase word)."""
     monkeypatch.setenv("PGO_BLOCK", "256")
     g = ds.manhattan_se3(1500, 6000, seed=21)
     prob, poses = gpu.problem_from_graph(g)
@@ -127,11 +131,13 @@ def test_resident_launch_trace_is_the_four_kernel_cycle(gpu, ds, monkeypatch):
     s = prob.solver_end()
     assert ran == 10 and s.cg_form == 4
     ops = [int(o) for o in rec[:, 0]]
-    HEAD, CG, TAIL, LIN = 1, 3, 4, 5
+    HEAD, CG, LINHEAD = 1, 3, 5
     for i, o in enumerate(ops):
-        assert o in (0, (HEAD, CG, TAIL, LIN)[i % 4]), (i, o)           # launch L plays role L % 4, or idles
-    assert ops.count(CG) == 10 and ops.count(TAIL) == 10 and ops.count(HEAD) == 11     # (the 11th head only finishes the last accepted step)
-    assert ops.count(LIN) == int(s.iterations["step_is_successful"][1:11].sum())
+        assert o in ((0, HEAD, LINHEAD) if i % 2 == 0 else (0, CG)), (i, o)           # launch L plays role L % 2, or idles
+    accepted = int(s.iterations["step_is_successful"][1:11].sum())
+    assert ops.count(CG) == 10 and ops.count(LINHEAD) == accepted and ops.count(HEAD) == 11 - accepted     # (the 11th even launch only finishes the last step, then the stream pauses)
+    live = [o for o in ops if o]
+    assert len(live) == 21                                           # two launches per LM iteration, none wasted
     # phase word of a CG launch: the iteration count it ran is the record's
     cg = rec[rec[:, 0] == CG]
     assert [int((int(w) >> 48) & 0xffff) for w in cg[:, 3]] == [int(x) for x in s.iterations["linear_solver_iterations"][1:11]]
