@@ -385,10 +385,15 @@ PGO_API int pgo_reproj_solve_batch(int n_problems, const long long* point_ptr, c
 /* ---- one process per GPU: edge/row sharding over RCCL ---- */
 /* contiguous share [begin,end) of n units for `rank` of `world` (host-only helper, no GPU needed) */
 PGO_API int pgo_shard_range(long long n, int rank, int world, long long* begin, long long* end);
-/* Row ownership of the sharded solve — the rule pgo_comm_init itself applies: rank r owns the poses [r * rows_per,
- * (r + 1) * rows_per) cut at n_poses, rows_per = ceil(n_poses / world) rounded up to a multiple of 4 (preconditioner
- * clusters never straddle ranks; equal segments for the all-gather).  rows_per optional. */
+/* Equal shares of the rows (the ownership rule until r05; kept as a helper): rank r owns the poses [r * rows_per, (r + 1) * rows_per)
+ * cut at n_poses, rows_per = ceil(n_poses / world) rounded up to a multiple of 4.  rows_per optional. */
 PGO_API int pgo_row_shard_range(long long n_poses, int rank, int world, long long* begin, long long* end, int* rows_per);
+/* Row ownership of the sharded solve — the rule pgo_comm_init itself applies (r06): contiguous shares of the poses cut where the
+ * incidence slots balance (pose v weighs 1 + its degree), at multiples of 4 (preconditioner clusters never straddle ranks).
+ * cut[0 .. world]: rank r owns the poses [cut[r], cut[r + 1]); rows_per (optional) = the longest share rounded up to a multiple of
+ * 4 = the equal segment every rank's rows occupy in the exchanged arrays.  Host only, no GPU needed.
+ * (BASELINE configs[3] over 8 ranks: heaviest rank 1.18x the mean by row count, <= 1.01x by this rule.) */
+PGO_API int pgo_row_shard_cuts(long long n_poses, long long n_edges, const int* id_begin, const int* id_end, int world, long long* cut, int* rows_per);
 /* 128-byte RCCL unique id created on rank 0 and handed to every rank by the launcher */
 PGO_API int pgo_comm_get_unique_id(unsigned char id[128]);
 /* Attaches rank `rank` of `world` to the problem BEFORE the first solve/evaluate.  Every rank must hold the same problem

@@ -43,7 +43,7 @@ C_ABI_SYMBOLS = [
     "pgo_solver_step", "pgo_solver_reset", "pgo_solver_end", "pgo_time_kernel", "pgo_solver_trace_start", "pgo_solver_trace_read", "pgo_solver_cg_form", "pgo_shard_range",
     "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_init_ipc", "pgo_debug_comm_stress", "pgo_debug_lm_decide", "pgo_loopback_create", "pgo_loopback_destroy", "pgo_comm_init_loopback",
     "pgo_generate_candidates", "pgo_reproj_options_init", "pgo_reproj_solve_batch",
-    "pgo_row_shard_range", "pgo_read_trajectory", "pgo_build_odometry_edges", "pgo_edge_rules_init", "pgo_build_edges",
+    "pgo_row_shard_range", "pgo_row_shard_cuts", "pgo_read_trajectory", "pgo_build_odometry_edges", "pgo_edge_rules_init", "pgo_build_edges",
     "pgo_solve_batch", "pgo_release_device_memory",
 ]
 
@@ -172,6 +172,19 @@ def shard_range(n, rank, world):
     b, e = C.c_longlong(0), C.c_longlong(0)
     _check(lib().pgo_shard_range(C.c_longlong(n), C.c_int(rank), C.c_int(world), C.byref(b), C.byref(e)))
     return b.value, e.value
+
+
+def row_shard_cuts(n_poses, ia, ib, world):
+    """pgo_row_shard_cuts: THE row ownership rule of the sharded solve (r06: shares cut where the incidence slots balance).
+    Returns (cut, rows_per): rank r owns the poses [cut[r], cut[r + 1])."""
+    import numpy as np
+    a = np.ascontiguousarray(ia, dtype=np.int32)
+    b = np.ascontiguousarray(ib, dtype=np.int32)
+    cut = (C.c_longlong * (world + 1))()
+    rp = C.c_int(0)
+    _check(lib().pgo_row_shard_cuts(C.c_longlong(n_poses), C.c_longlong(len(a)), a.ctypes.data_as(C.POINTER(C.c_int)),
+                                    b.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(world), cut, C.byref(rp)))
+    return [int(c) for c in cut], rp.value
 
 
 def row_shard_range(n_poses, rank, world):

@@ -19,7 +19,7 @@ int pgo_evaluate(pgo_problem* P, double* cost, double* residuals, double* jac_be
   P->g.pose_x = P->d_pose_x.p; P->g.pose_c = P->d_pose_c.p;
   rc = upload_poses(P, P->g.pose_x);
   if (rc) return rc;
-  const int E = P->g.E, N = P->g.N;
+  const int E = P->g.E;
   if (residuals || jac_begin || jac_end) {
     if (residuals) HIP_TRY(P->d_tmp_a.alloc((size_t)6 * E));
     if (jac_begin) HIP_TRY(P->d_tmp_b.alloc((size_t)36 * E));
@@ -39,7 +39,8 @@ int pgo_evaluate(pgo_problem* P, double* cost, double* residuals, double* jac_be
     if (rc) return rc;
     rc = linearize_all(P);
     if (rc) return rc;
-    HIP_TRY(staged_d2h(gradient, P->g.grad, sizeof(double) * 6 * N, s));
+    rc = pose_rows_to_host(P, gradient, P->g.grad, 6);
+    if (rc) return rc;
   }
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
@@ -61,9 +62,9 @@ int pgo_normal_equations(pgo_problem* P, double* diag, double* offdiag, double* 
   if (rc) return rc;
   rc = linearize_all(P);
   if (rc) return rc;
-  const int N = P->g.N, E = P->g.E;
-  if (diag) HIP_TRY(staged_d2h(diag, P->g.Hdiag, sizeof(double) * 36 * N, s));
-  if (gradient) HIP_TRY(staged_d2h(gradient, P->g.grad, sizeof(double) * 6 * N, s));
+  const int E = P->g.E;
+  if (diag) { rc = pose_rows_to_host(P, diag, P->g.Hdiag, 36); if (rc) return rc; }
+  if (gradient) { rc = pose_rows_to_host(P, gradient, P->g.grad, 6); if (rc) return rc; }
   std::vector<double> bsr;
   if (offdiag) {
     bsr.resize((size_t)P->g.n_slots * 36);
@@ -95,13 +96,14 @@ int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const do
   if (rc) return rc;
   rc = fill_scale_one(P);
   if (rc) return rc;
-  const size_t m = (size_t)6 * P->g.N;
   rc = prepare_clusters(P, options->pcg_cluster_poses);
   if (rc) return rc;
   rc = linearize_all(P);
   if (rc) return rc;
-  HIP_TRY(staged_h2d(P->g.d2, d2, m * sizeof(double), s));
-  HIP_TRY(staged_h2d(P->g.grad, b, m * sizeof(double), s));  // rhs = scale(=1) * grad
+  rc = pose_rows_to_device(P, P->g.d2, d2, 6, 1.0);      // (padding poses of a sharded problem: an identity row, right-hand side 0)
+  if (rc) return rc;
+  rc = pose_rows_to_device(P, P->g.grad, b, 6);  // rhs = scale(=1) * grad
+  if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(s));
   rc = damping_all(P, 1.0, 0.0, 0.0, 2);
   if (rc) return rc;
@@ -135,7 +137,8 @@ int pgo_linear_solve(pgo_problem* P, const pgo_solver_options* options, const do
     P->sym_active = false;
   }
   if (rc) return rc;
-  HIP_TRY(staged_d2h(x, P->g.cg_x, m * sizeof(double), s));
+  rc = pose_rows_to_host(P, x, P->g.cg_x, 6);
+  if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(s));
   if (iterations) *iterations = it;
   if (status == 2) return set_error(PGO_ERR_NUMERICAL, "PCG broke down with non-finite values");
@@ -153,7 +156,8 @@ int pgo_plus(pgo_problem* P, const double* delta) {
   if (rc) return rc;
   const size_t m = (size_t)6 * P->g.N;
   HIP_TRY(P->d_tmp_a.alloc(m));
-  HIP_TRY(staged_h2d(P->d_tmp_a.p, delta, m * sizeof(double), s));
+  rc = pose_rows_to_device(P, P->d_tmp_a.p, delta, 6);
+  if (rc) return rc;
   pgo::launch_apply_step(P->g, P->d_tmp_a.p, s);
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
@@ -499,6 +503,34 @@ int pgo_row_shard_range(long long n_poses, int rank, int world, long long* begin
   *begin = std::min(n_poses, (long long)rank * rows_per);
   *end = std::min(n_poses, (long long)(rank + 1) * rows_per);
   if (rows_per_out) *rows_per_out = (int)rows_per;
+  return PGO_OK;
+}
+
+// THE row ownership of the sharded solve since r06 (prepare() calls this very function): contiguous shares of the poses cut where the
+// INCIDENCE SLOTS balance — pose v weighs 1 + degree(v), the slots of its block row — at multiples of 4 (2- and 4-pose preconditioner
+// clusters never straddle two ranks).  cut[r] .. cut[r + 1] is rank r's share; rows_per = the longest share rounded up to a multiple of
+// 4 = the segment every rank's rows occupy in the exchanged arrays (the device numbers the poses of rank r from r * rows_per).
+int pgo_row_shard_cuts(long long n_poses, long long n_edges, const int* id_begin, const int* id_end, int world, long long* cut, int* rows_per_out) {
+  if (n_poses < 0 || n_edges < 0 || world <= 0 || !cut || (n_edges > 0 && (!id_begin || !id_end)))
+    return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_row_shard_cuts");
+  std::vector<long long> pre((size_t)n_poses + 1, 0);
+  for (long long e = 0; e < n_edges; ++e) {
+    if (id_begin[e] < 0 || id_begin[e] >= n_poses || id_end[e] < 0 || id_end[e] >= n_poses) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_row_shard_cuts: edge %lld names a pose that does not exist", e);
+    ++pre[(size_t)id_begin[e] + 1]; ++pre[(size_t)id_end[e] + 1];
+  }
+  for (long long v = 0; v < n_poses; ++v) pre[(size_t)v + 1] += pre[(size_t)v] + 1;      // pre[v] = slots of the poses before v
+  const long long total = pre[(size_t)n_poses];
+  cut[0] = 0;
+  for (int r = 1; r < world; ++r) {
+    const long long want = total * r / world;
+    long long c = std::lower_bound(pre.begin(), pre.end(), want) - pre.begin();       // first pose count whose slots reach the target
+    c = (c + 2) / 4 * 4;                                                               // the nearest multiple of 4
+    cut[r] = std::min(n_poses, std::max(cut[r - 1], c));
+  }
+  cut[world] = n_poses;
+  long long longest = 0;
+  for (int r = 0; r < world; ++r) longest = std::max(longest, cut[r + 1] - cut[r]);
+  if (rows_per_out) *rows_per_out = (int)std::max<long long>(4, (longest + 3) / 4 * 4);
   return PGO_OK;
 }
 

@@ -340,6 +340,20 @@ struct pgo_problem {
   int loss_kind = PGO_LOSS_TRIVIAL;
   double loss_a = 1.0;
   bool topo_dirty = true;
+  // Several ranks (r06): the rows are cut where the INCIDENCE SLOTS balance, not the row counts, and the exchanges still want equal
+  // segments — so prepare() renumbers the poses for the device: rank r's share [cut[r], cut[r + 1]) of the caller's poses becomes the
+  // internal poses [r * rows_per, r * rows_per + cut[r + 1] - cut[r]), the rest of the segment is padding (constant poses without
+  // edges).  pose_int[v] = internal index of the caller's pose v (empty: one rank, the identity); ia_int / ib_int / cmask_int /
+  // is_point_int are the topology in internal numbering; everything on the device, and every host array derived from the slot
+  // topology, is internal.  Only the C-ABI entry points that hand per-pose arrays over translate (pose_rows_to_host / _to_device).
+  std::vector<int> pose_int, ia_int, ib_int, shard_cut;
+  std::vector<uint8_t> cmask_int, is_point_int;
+  int n_int = 0;                                      // internal pose count (world * rows_per when renumbered)
+  bool renumbered() const { return !pose_int.empty(); }
+  const std::vector<int>& t_ia() const { return renumbered() ? ia_int : ia; }
+  const std::vector<int>& t_ib() const { return renumbered() ? ib_int : ib; }
+  const std::vector<uint8_t>& t_cmask() const { return renumbered() ? cmask_int : cmask; }
+  const std::vector<uint8_t>& t_is_point() const { return renumbered() ? is_point_int : is_point; }
 
   // ---- device ----
   int device = 0;
@@ -508,6 +522,9 @@ int sym_enter_storage(pgo_problem* P);
 int sym_prepare(pgo_problem* P);
 int upload_poses(pgo_problem* P, double* dst);
 int download_poses(pgo_problem* P, const double* src);
+// per-pose arrays of `width` doubles per pose between the caller's numbering (host) and the device's (pgo_problem::pose_int)
+int pose_rows_to_host(pgo_problem* P, double* host, const double* dev, int width);
+int pose_rows_to_device(pgo_problem* P, double* dev, const double* host, int width, double pad_value = 0.0);   // pad_value: what the padding poses of a renumbered problem get
 int fill_scale_one(pgo_problem* P);
 
 // ---- pgo_linear.cpp: the linear solvers behind an LM iteration — CG batches and their hand-off, preconditioner clusters, the

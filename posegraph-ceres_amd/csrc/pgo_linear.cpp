@@ -271,7 +271,7 @@ long long front_memory_budget() {
 void analyze_front(pgo_problem* P, int N, int n_slots, long long budget, bool* ok, int small_max) {
   pgo::FrontSymbolic& S = P->fsym;
   const auto t_an = Clock::now();
-  *ok = pgo::front_analyze(N, P->ia, P->ib, n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side, budget, &S, small_max, &P->is_point);
+  *ok = pgo::front_analyze(N, P->t_ia(), P->t_ib(), n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side, budget, &S, small_max, &P->t_is_point());
   if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] front: symbolic analysis %.2f ms (%s)\n", 1e3 * seconds_since(t_an), *ok ? "usable" : "declined");
 }
 
@@ -434,7 +434,7 @@ int decide_direct_host(pgo_problem* P, int N, int E, int n_slots, long long fron
   }
   auto pairs = [&]() {
     const auto t_an = Clock::now();
-    usable = pgo::direct_analyze(N, P->ia, P->ib, n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side, P->h_row_slot_begin, &S, &P->is_point);
+    usable = pgo::direct_analyze(N, P->t_ia(), P->t_ib(), n_slots, P->h_slot_row, P->h_slot_col, P->h_slot_side, P->h_row_slot_begin, &S, &P->t_is_point());
     if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] direct: symbolic analysis %.2f ms\n", 1e3 * seconds_since(t_an));
   };
   if (front_mode < 0 && (double)E < 1.5 * (double)N) { pairs(); pair_first_done = true; }

@@ -832,7 +832,7 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
     summary->num_unsuccessful_steps = L.num_unsuccessful;
     summary->num_iterations = (int)L.records.size();
     summary->num_linear_solver_iterations = L.num_linear_iterations;
-    summary->num_poses = P->g.N;
+    summary->num_poses = (int)P->pp.size();
     summary->num_edges = P->g.E;
     const bool want_exact = P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY;
     summary->linear_solver_used = want_exact ? (P->direct_usable ? (P->dsym.hybrid ? 3 : 0) : 2) : 1;
@@ -842,9 +842,10 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
     {
       int const_p = 0, const_q = 0;
       for (uint8_t m : P->cmask) { const_p += m & 1; const_q += (m >> 1) & 1; }
-      summary->num_parameter_blocks_reduced = 2 * P->g.N - const_p - const_q;
-      summary->num_parameters_reduced = 7 * P->g.N - 3 * const_p - 4 * const_q;
-      summary->num_effective_parameters_reduced = 6 * P->g.N - 3 * const_p - 3 * const_q;
+      const int n_caller = (int)P->pp.size();
+      summary->num_parameter_blocks_reduced = 2 * n_caller - const_p - const_q;
+      summary->num_parameters_reduced = 7 * n_caller - 3 * const_p - 4 * const_q;
+      summary->num_effective_parameters_reduced = 6 * n_caller - 3 * const_p - 3 * const_q;
     }
     summary->factor_kind = (want_exact && P->direct_usable) ? (P->sfront_usable ? 3 : P->front_usable ? 2 : 1) : 0;
     summary->factor_max_front = (want_exact && fronts) ? P->fsym.max_front : 0;

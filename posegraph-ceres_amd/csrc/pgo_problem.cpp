@@ -144,8 +144,8 @@ int prepare(pgo_problem* P) {
   if (!P->topo_dirty) return PGO_OK;
   if (P->analysis_thread.joinable()) P->analysis_thread.join();     // (of a topology that is being replaced)
   const auto t0 = Clock::now();
-  const int N = (int)P->pp.size(), E = (int)P->ia.size();
-  if (N == 0) return set_error(PGO_ERR_INVALID_ARGUMENT, "problem has no poses");
+  const int N_caller = (int)P->pp.size(), E = (int)P->ia.size();
+  if (N_caller == 0) return set_error(PGO_ERR_INVALID_ARGUMENT, "problem has no poses");
   hipStream_t s = P->stream;
   P->drop_graph();
 
@@ -154,18 +154,39 @@ int prepare(pgo_problem* P) {
     if (verbose) std::fprintf(stderr, "[pgo] prepare: %-28s %.2f ms\n", what, 1e3 * seconds_since(tl));
     tl = Clock::now();
   };
+  // ---- row ownership: rank r owns a contiguous share of the poses, cut where the incidence slots (1 + degree per pose)
+  // balance (r06; by row count until r05: 1.18x the mean on the heaviest of 8 ranks at BASELINE configs[3]); cut edges are evaluated by
+  // the owners of both endpoints.  The cuts are multiples of 4 so that preconditioner clusters never straddle ranks; the exchanges want
+  // equal segments, so the poses are renumbered for the device (pgo_internal.h pose_int): rank r's share starts at r * rows_per.
+  const int world = P->comm ? P->comm->world : 1, rank = P->comm ? P->comm->rank : 0;
+  int rows_per = 0;
+  P->pose_int.clear(); P->ia_int.clear(); P->ib_int.clear(); P->cmask_int.clear(); P->is_point_int.clear(); P->shard_cut.clear();
+  if (world > 1) {
+    std::vector<long long> cut((size_t)world + 1, 0);
+    if (pgo_row_shard_cuts(N_caller, E, P->ia.data(), P->ib.data(), world, cut.data(), &rows_per) != PGO_OK) return PGO_ERR_INVALID_ARGUMENT;   // THE ownership rule
+    P->shard_cut.assign(cut.begin(), cut.end());
+    P->n_int = world * rows_per;
+    P->pose_int.resize(N_caller);
+    for (int r = 0; r < world; ++r)
+      for (long long v = cut[r]; v < cut[r + 1]; ++v) P->pose_int[(size_t)v] = r * rows_per + (int)(v - cut[r]);
+    P->ia_int.resize(E); P->ib_int.resize(E);
+    for (int e = 0; e < E; ++e) { P->ia_int[e] = P->pose_int[P->ia[e]]; P->ib_int[e] = P->pose_int[P->ib[e]]; }
+    P->cmask_int.assign(P->n_int, 3);                 // padding poses: both blocks constant, no edges
+    for (int v = 0; v < N_caller; ++v) P->cmask_int[P->pose_int[v]] = P->cmask[v];
+    if (!P->is_point.empty()) { P->is_point_int.assign(P->n_int, 0); for (int v = 0; v < N_caller; ++v) P->is_point_int[P->pose_int[v]] = P->is_point[v]; }
+  } else {
+    long long rl = 0, rh = 0;
+    if (pgo_row_shard_range(N_caller, 0, 1, &rl, &rh, &rows_per) != PGO_OK) return PGO_ERR_INVALID_ARGUMENT;
+    P->n_int = N_caller;
+  }
+  const int N = P->n_int;                             // poses as the device counts them
+  const std::vector<int>&t_ia = P->t_ia(), &t_ib = P->t_ib();
+  const int row_lo = world > 1 ? rank * rows_per : 0;
+  const int row_hi = world > 1 ? row_lo + (int)(P->shard_cut[rank + 1] - P->shard_cut[rank]) : N;
   std::vector<int> deg(N, 0);
-  for (int e = 0; e < E; ++e) { ++deg[P->ia[e]]; ++deg[P->ib[e]]; }
+  for (int e = 0; e < E; ++e) { ++deg[t_ia[e]]; ++deg[t_ib[e]]; }
   long long total = 0;
   for (int v = 0; v < N; ++v) total += 1 + deg[v];
-
-  // ---- row ownership: rank r owns the poses [r*rows_per, (r+1)*rows_per); cut edges are evaluated by
-  // the owners of both endpoints.  rows_per is a multiple of 4 so that preconditioner clusters never straddle ranks.
-  const int world = P->comm ? P->comm->world : 1, rank = P->comm ? P->comm->rank : 0;
-  long long rl = 0, rh = 0;
-  int rows_per = 0;
-  if (pgo_row_shard_range(N, rank, world, &rl, &rh, &rows_per) != PGO_OK) return PGO_ERR_INVALID_ARGUMENT;   // THE ownership rule
-  const int row_lo = (int)rl, row_hi = (int)rh;
   const int NP = world * rows_per;   // padded pose count of every replicated / exchanged array
   const int B = choose_block(total / world);
 
@@ -225,7 +246,10 @@ int prepare(pgo_problem* P) {
     pairs_whole = pw;
   }
   int pq_cap = 1;
-  for (int r = 0; r < world; ++r) pq_cap = std::max(pq_cap, pack(std::min(N, r * rows_per), std::min(N, (r + 1) * rows_per), false));
+  for (int r = 0; r < world; ++r) {
+    const int lo_r = world > 1 ? r * rows_per : 0, hi_r = world > 1 ? lo_r + (int)(P->shard_cut[r + 1] - P->shard_cut[r]) : N;
+    pq_cap = std::max(pq_cap, pack(lo_r, hi_r, false));
+  }
   // (one rank: room for one p'q partial per tile of the symmetric form as well — tiles of >= 32 rows, filled to ~0.8 by the row and
   // weight caps of pgo_sym.cpp: N / 26 of them; several ranks: the same room in the partial-sum rows, below)
   if (world == 1) pq_cap = std::max(pq_cap, N / 16 + 8);
@@ -244,7 +268,7 @@ int prepare(pgo_problem* P) {
   }
   P->edge_begin_slot.assign(E, -1);
   for (int e = 0; e < E; ++e) {
-    const int a = P->ia[e], b = P->ib[e];
+    const int a = t_ia[e], b = t_ib[e];
     if (a >= row_lo && a < row_hi) {
       const int t = fill[a]++;
       slot_col[t] = b; slot_row[t] = a; slot_side[t] = pgo::SIDE_BEGIN; slot_edge[t] = e;
@@ -333,9 +357,9 @@ int prepare(pgo_problem* P) {
   HIP_TRY(P->d_wg_row_begin.upload(wg_row_begin, s));
   HIP_TRY(P->d_row_slot_begin.upload(row_slot_begin, s));
   HIP_TRY(P->d_row_slot_cnt.upload(row_slot_cnt, s));
-  HIP_TRY(P->d_cmask.upload(P->cmask, s));
-  HIP_TRY(P->d_edge_a.upload(P->ia, s));
-  HIP_TRY(P->d_edge_b.upload(P->ib, s));
+  HIP_TRY(P->d_cmask.upload(P->t_cmask(), s));
+  HIP_TRY(P->d_edge_a.upload(t_ia, s));
+  HIP_TRY(P->d_edge_b.upload(t_ib, s));
   HIP_TRY(P->d_smeas.upload(smeas.data(), smeas.n, s));
   HIP_TRY(P->d_emeas.upload(emeas.data(), emeas.n, s));
   HIP_TRY(P->d_sW.upload(sW.data(), sW.n, s));
@@ -496,9 +520,11 @@ int peer_direct_setup(pgo_problem* P) {
 
 int upload_poses(pgo_problem* P, double* dst) {
   const int N = (int)P->pp.size();
-  std::vector<double> h((size_t)pgo::POSE_STRIDE * N, 0.0);
+  const bool ren = P->renumbered();
+  std::vector<double> h((size_t)pgo::POSE_STRIDE * (ren ? P->n_int : N), 0.0);
+  if (ren) for (int v = 0; v < P->n_int; ++v) h[(size_t)pgo::POSE_STRIDE * v + 6] = 1.0;      // padding poses: the identity
   for (int v = 0; v < N; ++v) {
-    double* o = &h[(size_t)pgo::POSE_STRIDE * v];
+    double* o = &h[(size_t)pgo::POSE_STRIDE * (ren ? P->pose_int[v] : v)];
     o[0] = P->pp[v][0]; o[1] = P->pp[v][1]; o[2] = P->pp[v][2];
     o[3] = P->qq[v][0]; o[4] = P->qq[v][1]; o[5] = P->qq[v][2]; o[6] = P->qq[v][3];
   }
@@ -508,14 +534,32 @@ int upload_poses(pgo_problem* P, double* dst) {
 
 int download_poses(pgo_problem* P, const double* src) {
   const int N = (int)P->pp.size();
-  std::vector<double> h((size_t)pgo::POSE_STRIDE * N);
+  const bool ren = P->renumbered();
+  std::vector<double> h((size_t)pgo::POSE_STRIDE * (ren ? P->n_int : N));
   HIP_TRY(staged_d2h(h.data(), src, h.size() * sizeof(double), P->stream));
   for (int v = 0; v < N; ++v) {
-    const double* o = &h[(size_t)pgo::POSE_STRIDE * v];
+    const double* o = &h[(size_t)pgo::POSE_STRIDE * (ren ? P->pose_int[v] : v)];
     // constant blocks are never written (row 0 of the reference's before/after files is identical)
     if (!(P->cmask[v] & 1)) { P->pp[v][0] = o[0]; P->pp[v][1] = o[1]; P->pp[v][2] = o[2]; }
     if (!(P->cmask[v] & 2)) { P->qq[v][0] = o[3]; P->qq[v][1] = o[4]; P->qq[v][2] = o[5]; P->qq[v][3] = o[6]; }
   }
+  return PGO_OK;
+}
+
+int pose_rows_to_host(pgo_problem* P, double* host, const double* dev, int width) {
+  const size_t N = P->pp.size();
+  if (!P->renumbered()) { HIP_TRY(staged_d2h(host, dev, sizeof(double) * width * N, P->stream)); return PGO_OK; }
+  std::vector<double> h((size_t)width * P->n_int);
+  HIP_TRY(staged_d2h(h.data(), dev, h.size() * sizeof(double), P->stream));
+  for (size_t v = 0; v < N; ++v) memcpy(host + v * width, &h[(size_t)P->pose_int[v] * width], sizeof(double) * width);
+  return PGO_OK;
+}
+int pose_rows_to_device(pgo_problem* P, double* dev, const double* host, int width, double pad_value) {
+  const size_t N = P->pp.size();
+  if (!P->renumbered()) { HIP_TRY(staged_h2d(dev, host, sizeof(double) * width * N, P->stream)); return PGO_OK; }
+  std::vector<double> h((size_t)width * P->n_int, pad_value);
+  for (size_t v = 0; v < N; ++v) memcpy(&h[(size_t)P->pose_int[v] * width], host + v * width, sizeof(double) * width);
+  HIP_TRY(staged_h2d(dev, h.data(), h.size() * sizeof(double), P->stream));
   return PGO_OK;
 }
 

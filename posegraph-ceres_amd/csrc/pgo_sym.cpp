@@ -35,7 +35,8 @@ int sym_prepare(pgo_problem* P) {
     if (verbose) std::fprintf(stderr, "[pgo] sym_prepare: %-24s %.2f ms\n", what, 1e3 * seconds_since(tl));
     tl = Clock::now();
   };
-  const int N = (int)P->pp.size(), E = (int)P->ia.size();
+  const int N = P->n_int, E = (int)P->ia.size();      // (the device's numbering: pgo_internal.h pose_int)
+  const std::vector<int>&t_ia = P->t_ia(), &t_ib = P->t_ib();
   hipStream_t s = P->stream;
   // tile caps: up to 256 rows; enough tiles to fill the chip on small graphs; the weight cap keeps the tiles' stored slots alike
   pgo::SymHostParams hp;
@@ -45,7 +46,7 @@ int sym_prepare(pgo_problem* P) {
   hp.row_cap = std::max(8, std::min(hp.row_cap, (int)pgo::SYM_LANES));
   // (several ranks: this rank's rows and their incidences)
   long long own_slots = P->g.row_hi - P->g.row_lo;
-  if (P->g.world > 1) { for (int e = 0; e < E; ++e) own_slots += (P->ia[e] >= P->g.row_lo && P->ia[e] < P->g.row_hi) + (P->ib[e] >= P->g.row_lo && P->ib[e] < P->g.row_hi); }
+  if (P->g.world > 1) { for (int e = 0; e < E; ++e) own_slots += (t_ia[e] >= P->g.row_lo && t_ia[e] < P->g.row_hi) + (t_ib[e] >= P->g.row_lo && t_ib[e] < P->g.row_hi); }
   const double avg_w = P->g.world > 1 ? std::max(1.0, (double)own_slots / N_own) : (double)(N + 2LL * E) / std::max(1, N);
   const double w_mult = 0.95;
   hp.w_cap = std::max<long long>(64, (long long)(w_mult * hp.row_cap * avg_w));
@@ -54,7 +55,7 @@ int sym_prepare(pgo_problem* P) {
   // for 6 x 6 ones, and the form is built once per topology whatever preconditioner later sessions ask for
   hp.row_lo = P->g.row_lo; hp.row_hi = P->g.row_hi; hp.unit = 2;
   pgo::SymHostLayout H;
-  pgo::sym_build_host(N, E, P->ia.data(), P->ib.data(), P->h_row_slot_begin.data(), hp, &H);
+  pgo::sym_build_host(N, E, t_ia.data(), t_ib.data(), P->h_row_slot_begin.data(), hp, &H);
   if (verbose) std::fprintf(stderr, "[pgo] sym_prepare: partition %.2f ms, tile layout %.2f ms\n", H.ms_partition, H.ms_layout);
   if (H.unfit) {
     if (verbose) std::fprintf(stderr, "[pgo] sym: tile %d %s: the incidence-slot kernels stay\n", H.unfit_tile, H.unfit);

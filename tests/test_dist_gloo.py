@@ -1,5 +1,5 @@
 """CPU, world_size 2 over gloo: the multi-process decomposition of the path.
-Each rank owns a contiguous share of the pose rows (pgo_row_shard_range: the rule pgo_comm_init itself applies) and every edge incident to them;
+Each rank owns a contiguous share of the pose rows (pgo_row_shard_cuts: the rule pgo_comm_init itself applies — shares cut where the incidence slots balance) and every edge incident to them;
 the per-rank pieces of J'r, of the diagonal J'J blocks and of one block SpMV, all-gathered over gloo,
 must equal the single-process result.  The arithmetic here is the CPU oracle's (no GPU in this
 container); the partition logic is the product's."""
@@ -27,7 +27,8 @@ def _worker(rank, world, port, out):
     g = ds.manhattan_se3(300, 1000, seed=21)
     og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
     _, r, ja, jb = O.evaluate(og)
-    lo, hi, seg = pkg.row_shard_range(g.N, rank, world)
+    cut, seg = pkg.row_shard_cuts(g.N, g.ia, g.ib, world)        # THE ownership rule (r06: shares cut where the incidence slots balance)
+    lo, hi = cut[rank], cut[rank + 1]
     # rows owned by this rank: gradient and diagonal blocks from every incident edge (cut edges are
     # evaluated by both owners, never exchanged)
     grad = np.zeros((hi - lo, 6))
@@ -52,7 +53,7 @@ def _worker(rank, world, port, out):
         dist.all_gather(outs, buf)
         parts = []
         for k in range(world):
-            b0, b1, _ = pkg.row_shard_range(g.N, k, world)
+            b0, b1 = cut[k], cut[k + 1]
             parts.append(outs[k][: (b1 - b0) * width].numpy().reshape(b1 - b0, width))
         return np.concatenate(parts)
     full_grad, full_y = gather(grad, 6), gather(y, 6)
@@ -95,7 +96,7 @@ def _pipe_worker(rank, world, port, out):
     """The sharded path's owner-only pipelined CG (pgo_kernels.hip k_pipe_cg) restated in numpy over gloo:
     every rank multiplies ITS rows of A = J'J + D, updates the eight vectors of its rows only, applies its own 6 x 6 Jacobi blocks, and
     ONE all-gather per iteration carries [m of the owned rows | (r,u), (w,u), x'(b + r)] — the product's exchange layout
-    (pgo_row_shard_range segments).  Every rank derives alpha, beta and the Q-tolerance stop from the same gathered numbers; the
+    (pgo_row_shard_cuts segments).  Every rank derives alpha, beta and the Q-tolerance stop from the same gathered numbers; the
     iterates must be those of standard preconditioned CG on the whole system."""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -118,7 +119,8 @@ def _pipe_worker(rank, world, port, out):
     d = np.diag(A).copy()
     d[d == 0.0] = 1e4                      # (the constant first pose: its columns are zero, the block becomes the identity)
     A += 1e-4 * np.diag(d)
-    lo, hi, seg = pkg.row_shard_range(g.N, rank, world)
+    cut, seg = pkg.row_shard_cuts(g.N, g.ia, g.ib, world)
+    lo, hi = cut[rank], cut[rank + 1]
     rows = slice(6 * lo, 6 * hi)
     Aown = A[rows]                                                     # the owned block rows
     Minv = [np.linalg.inv(A[6 * v:6 * v + 6, 6 * v:6 * v + 6]) for v in range(lo, hi)]
@@ -132,7 +134,7 @@ def _pipe_worker(rank, world, port, out):
         dist.all_gather(outs, buf)
         full, tot = [], np.zeros(3)
         for k in range(world):
-            b0, b1, _ = pkg.row_shard_range(g.N, k, world)
+            b0, b1 = cut[k], cut[k + 1]
             full.append(outs[k][: 6 * (b1 - b0)].numpy())
             tot += outs[k][seg * 6: seg * 6 + 3].numpy()               # rank order: the same bits on every rank
         return np.concatenate(full), tot
