@@ -5,7 +5,7 @@
 #   2. FETCH_SIZE / WRITE_SIZE passes of the same command -> HBM bytes per launch (tools/rocprof_pmc.py)
 #   3. kernel trace of the multifrontal factorisation on C2 and C5
 #   4. FP64 MFMA counters of the multifrontal factorisation on C5
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -39,6 +39,8 @@ python tools/exchange_latency.py 2>/dev/null | grep "^{" > $OUT/exchange_world1_
 [ -x tools/bench/mfma_clock ] && tools/bench/mfma_clock > $OUT/${TAG}_mfma_clock.txt 2>&1
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/front_c2 $OUT/front_c5 $OUT/front_mfma
 bash tools/profile_c4.sh $TAG > $OUT/profile_c4.log 2>&1
+# 6. (r06) the eight-way sharded run once more with FETCH_SIZE / WRITE_SIZE passes: what one rank's kernels move per launch
+bash tools/profile_8way.sh $TAG > $OUT/profile_8way.log 2>&1
 python tools/config_table.py > $OUT/${TAG}_config_table.md 2> $OUT/config_table.err
 cp $OUT/${TAG}_pmc.json $OUT/${TAG}_bench_kernel_stats.csv $OUT/${TAG}_bench_under_rocprof.json profiles/ 2>/dev/null   # on this box only: the final bench run quotes the traffic measured above, on these very sources
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
