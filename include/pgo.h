@@ -231,7 +231,7 @@ PGO_API int pgo_solve(pgo_problem* problem, const pgo_solver_options* options, p
 /* Summary::IsSolutionUsable (finial.cpp:543) */
 /* Device memory of destroyed problems is kept in a process-wide pool and reused by later problems (hipFree synchronises the
  * device: tearing a problem down the blocking way costs as much as a KITTI-scale solve).  This call returns the pooled blocks
- * to the driver; PGO_POOL_MAX_GB bounds the pool (default 16 GB, 0 = no pooling). */
+ * to the driver; the pool holds at most 16 GB. */
 PGO_API int pgo_release_device_memory(void);
 
 /* Several INDEPENDENT problems solved together on one GPU (KITTI-scale graphs leave the machine idle: an LM iteration is a

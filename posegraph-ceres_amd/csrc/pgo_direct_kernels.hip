@@ -984,10 +984,10 @@ void launch_direct_factor(const DeviceGraph& g, const DirectPlan& p, const Direc
       hipLaunchKernelGGL(k_chol_assemble4, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin);
       hipLaunchKernelGGL(k_chol_panel, dim3(st.sub_end), dim3(64 * FUSED_WAVES), 0, s, g, p, st.sub_begin, st.level_end - st.level_begin);
     } else if (epoch > 0 && st.blk_end - st.blk_begin <= fuse_split_max) {
-      // bounded wait (PGO_DIRECT_SPLIT_SPINS, default 2^22 polls ~ 1 s): when it runs out — the workgroups of the step were
+      // bounded wait (PGO_WAIT_SPINS, default 2^22 polls ~ 1 s): when it runs out — the workgroups of the step were
       // not all resident, e.g. on a partitioned or shared GPU — the solve is flagged and the LM driver repeats the
       // factorisation in the two-launch form (epoch 0) and keeps to it for this problem
-      const char* spins_env = getenv("PGO_DIRECT_SPLIT_SPINS");     // (read per call: the tests change it within one process)
+      const char* spins_env = getenv("PGO_WAIT_SPINS");     // (read per call: the tests change it within one process)
       const int max_spins = spins_env ? atoi(spins_env) : (1 << 22);
       hipLaunchKernelGGL(k_chol_split, dim3(st.blk_end - st.blk_begin), dim3(64 * ASM_WAVES), 0, s, g, p, st.blk_begin, epoch, max_spins);
     } else {

@@ -130,14 +130,13 @@ inline hipError_t staged_d2h(void* dst, const void* src, size_t bytes, hipStream
 // fit: hipFree synchronises the whole device and costs ~0.1 ms per block — releasing the ~70 buffers of a problem took 2-9 ms,
 // as much as a KITTI-scale solve.  Only whole-problem teardown goes through the pool (the owner synchronises its stream
 // first); a buffer that is re-allocated in mid-life is freed the blocking way, since work in flight may still read it.
-// PGO_POOL_MAX_GB bounds the cached bytes (default 16; 0 switches the pool off); pgo_release_device_memory() empties it.
+// At most 16 GB are cached; pgo_release_device_memory() empties the pool.
 struct DevicePool {
   std::mutex mu;
   std::multimap<std::pair<int, size_t>, void*> blocks;   // (device, capacity in bytes) -> block
   size_t cached = 0;
   static size_t limit() {
-    static const size_t lim = (size_t)((getenv("PGO_POOL_MAX_GB") ? atof(getenv("PGO_POOL_MAX_GB")) : 16.0) * 1e9);
-    return lim;
+    return (size_t)16e9;
   }
   hipError_t get(size_t bytes, void** out, size_t* cap, int* dev) {
     int d = 0;
@@ -417,7 +416,7 @@ struct pgo_problem {
   DevBuf<int> dd_split_blk, dd_split_sub, dd_split_sub_diag, dd_upd_split, dd_panel_cols, dd_blk_lpos, dd_split_dblk, dd_col_flag;
   int direct_epoch = 0;
   bool split_two_launch = false;   // a single-launch SPLIT step timed out once: this problem keeps to the two-launch form
-  bool sfront_levels = false;      // small-front plan: one launch per level (a wait of the single-launch form ran out, or PGO_SFRONT_FUSED=0)
+  bool sfront_levels = false;      // small-front plan: one launch per level (a wait of the single-launch form ran out, or PGO_FACTOR_FUSED=0)
   int sfront_epoch = 0;
   unsigned sfront_tickets = 0;     // tickets handed out by the single-launch factorisations so far
   DevBuf<uint8_t> dd_split_diag;
@@ -444,7 +443,7 @@ struct pgo_problem {
   DevBuf<long long> ds_stamps;     // PGO_SF_STAMPS=1 (development aid)
   DevBuf<int> df_st_table, df_st_pred_ptr, df_st_pred, df_st_need;
   DevBuf<unsigned long long> df_st_count;
-  bool front_launches = false;     // multifrontal plan: one launch per phase of a round (a wait of the single-launch form ran out, or PGO_FRONT_FUSED=0)
+  bool front_launches = false;     // multifrontal plan: one launch per phase of a round (a wait of the single-launch form ran out, or PGO_FACTOR_FUSED=0)
   unsigned long long front_epoch = 0, front_tickets = 0;
   DevBuf<int> df_perm, df_idx, df_child, df_rel, df_cstart, df_col_front, df_ablk_ptr, df_ablk_slot, df_ablk_front, df_ablk_pos, df_wg_job, df_wg_tile,
       df_bwd_front, df_bwd_chunk, df_bwdb_front, df_bwdb_chunk, df_asm_tile, df_asm_contrib;

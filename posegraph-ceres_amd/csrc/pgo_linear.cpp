@@ -264,8 +264,7 @@ int prepare_clusters(pgo_problem* P, int CL) {
 long long front_memory_budget() {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)64 << 30; }
-  const char* cap = getenv("PGO_FRONT_MAX_GB");
-  return cap ? (long long)(atof(cap) * 1e9) : (long long)(0.6 * (double)free_b);
+  return (long long)(0.6 * (double)free_b);
 }
 // host only (runs on the analysis thread)
 void analyze_front(pgo_problem* P, int N, int n_slots, long long budget, bool* ok, int small_max) {
@@ -313,7 +312,7 @@ int upload_front(pgo_problem* P) {
   f.col_front = P->df_col_front.p; f.ablk_ptr = P->df_ablk_ptr.p; f.ablk_slot = P->df_ablk_slot.p;
   f.ablk_front = P->df_ablk_front.p; f.ablk_pos = P->df_ablk_pos.p; f.n_ablk = (int)S.ablk_front.size();
   f.jobs = P->df_jobs.p; f.Fval = P->df_Fval.p; f.Winv = P->df_Winv.p; f.x = P->df_x.p;
-  // the stages of the single-launch form (pgo_front.h FrontStages); PGO_FRONT_FUSED=0: one launch per phase of a round
+  // the stages of the single-launch form (pgo_front.h FrontStages); PGO_FACTOR_FUSED=0: one launch per phase of a round
   f.st_table = nullptr; f.st_pred_ptr = nullptr; f.st_pred = nullptr; f.st_need = nullptr; f.st_count = nullptr;
   P->front_epoch = 0; P->front_tickets = 0;
   {
@@ -321,8 +320,8 @@ int upload_front(pgo_problem* P) {
     // dense (0.9 GFLOP) 28.1 vs 32.0 ms per 14-iteration solve, Manhattan 10 k (4.5 GFLOP) 3.54 vs 3.57 ms, sphere x10 (383
     // GFLOP) 46 vs 28 ms: every work-group pays a cache write-back and an invalidation of its XCD's L2 where a kernel boundary
     // pays them once, which the GEMM-heavy factorisations cannot afford.  Default: single launch up to 3 GFLOP
-    // (PGO_FRONT_FUSED=1 always, =0 never; PGO_FRONT_FUSED_GFLOP moves the limit).
-    const char* fu = getenv("PGO_FRONT_FUSED");
+    // (PGO_FACTOR_FUSED=1 always, =0 never: one switch for the three factorisations).
+    const char* fu = getenv("PGO_FACTOR_FUSED");
     const double limit = 3.0;
     const bool on = fu ? fu[0] == '1' : S.flops <= limit * 1e9;
     P->front_launches = !on || S.st_table.empty();
@@ -390,7 +389,7 @@ int upload_sfront(pgo_problem* P) {
   P->sfront_epoch = 0;
   P->sfront_tickets = 0;
   {
-    const char* fu = getenv("PGO_SFRONT_FUSED");
+    const char* fu = getenv("PGO_FACTOR_FUSED");
     P->sfront_levels = fu && fu[0] == '0';
   }
   P->splan = pgo::SFrontPlan{P->ds_sf.p, nullptr, P->ds_urel.p, P->ds_upos.p, P->ds_osrc.p, P->ds_L.p, P->ds_U.p, P->ds_W.p, P->ds_done.p};
@@ -520,7 +519,7 @@ int prepare_direct(pgo_problem* P) {
 void enqueue_front_factor(pgo_problem* P, const pgo::DeviceGraph& G) {
   hipStream_t s = P->stream;
   if (!P->front_launches) {
-    const char* sp_env = getenv("PGO_FRONT_SPINS");
+    const char* sp_env = getenv("PGO_WAIT_SPINS");
     const int n_tickets = (int)(P->fsym.st_table.size() / 2);
     static const bool want_stamps = false;
     if (want_stamps && P->ds_stamps.n == 0 && P->ds_stamps.alloc(3 * (size_t)n_tickets) != hipSuccess) return;
@@ -567,7 +566,7 @@ int run_direct(pgo_problem* P, const pgo::DeviceGraph& G) {
   if (P->sfront_usable) {
     if (!P->sfront_levels) {
       // all levels in one launch (SFrontSync): a parent waits for its children's flags instead of for the end of their launch
-      const char* sp_env = getenv("PGO_SFRONT_SPINS");
+      const char* sp_env = getenv("PGO_WAIT_SPINS");
       const int max_spins = sp_env ? atoi(sp_env) : (1 << 20);     // ~1 s of polling before the fallback
       if (++P->sfront_epoch == 0x7fffffff) {     // (the ticket counters keep counting: they wrap with the host's copy)
         P->sfront_epoch = 1;

@@ -139,9 +139,13 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   P->sym_active = false; P->sym_storage = false;
   // ... when the solve can run long enough to repay the form's construction (44 ms of host time at 100 k / 1 M against 0.7 ms saved
   // per LM iteration of ~13 CG iterations: 64 iterations, or a tight forcing term whose CG runs are long); PGO_SYM=1 forces it
-  // (r06: unconditionally — the form's construction, 44 ms of host time at 100 k / 1 M on 16 threads, is less than the rest of the
-  // set-up it sits in, and the first session is as likely to be the long one as any)
-  if (P->opt.linear_solver_type == PGO_BLOCK_JACOBI_PCG && !P->universal && !P->pipelined && sym_wanted(P)) {
+  // ... on one rank when the solve can run long enough to repay the form's construction: 44 ms of host time at 100 k / 1 M against
+  // 0.9 ms saved per LM iteration (2.7 -> 1.8), i.e. from ~50 iterations on — max_num_iterations >= 64, a tight forcing term (long CG
+  // runs), or a form that exists already.  (r06 tried "always": BASELINE configs[3] with 25 iterations went from 242 to 282 ms of wall,
+  // profiles/r06_a_config_table_sym_always.md.)  Several ranks: always — a rank builds the form of ITS rows (5 ms at world 8).  PGO_SYM=1 forces it.
+  const char* sym_env = getenv("PGO_SYM");
+  const bool sym_pays = P->g.world > 1 || (sym_env && sym_env[0] == '1') || P->sym_ready || P->opt.max_num_iterations >= 64 || P->opt.eta <= 0.02;
+  if (P->opt.linear_solver_type == PGO_BLOCK_JACOBI_PCG && !P->universal && !P->pipelined && sym_pays && sym_wanted(P)) {
     rc = sym_prepare(P);
     if (rc) return rc;
     P->sym_active = P->sym_ready;

@@ -35,8 +35,7 @@ int ensure_device(pgo_problem* P) {
     // captured hipGraph of the same kernels is no faster (C2: 0.317 vs 0.317 ms per LM iteration without residual refreshes,
     // 0.322 eager vs 0.353 graph with them; KITTI-00 exact 0.79 vs 0.81 ms).  PGO_GRAPH=1 replays captured batches instead.
     const char* gr = getenv("PGO_GRAPH");
-    const char* ng = getenv("PGO_NO_GRAPH");
-    P->use_graph = (gr && gr[0] == '1') && !(ng && ng[0] == '1');
+    P->use_graph = gr && gr[0] == '1';
   }
   if (!P->scal) {
     void* blk = nullptr;

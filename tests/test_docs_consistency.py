@@ -68,4 +68,5 @@ def test_bench_line_carries_the_fraction_the_csv_gives():
            [r for r in all_rows if d["roofline"]["rocprof_kernel_name"] in r[0]]
     avg = float(rows[0][3])
     assert abs(chk["rocprof_avg_us"] - avg) < 1e-9
-    assert abs(chk["frac_from_rocprof_avg"] - d["roofline"]["algorithmic_bytes_per_launch"] / (avg * 1e-6) / 1e9 / d["roofline"]["peak"]) < 1e-3
+    # (r06: the line's own frac / achieved are this run's live figures; what the committed CSV gives sits in rocprof_check with the bytes it was priced with)
+    assert abs(chk["frac_from_rocprof_avg"] - chk.get("algorithmic_bytes_per_launch", d["roofline"]["algorithmic_bytes_per_launch"]) / (avg * 1e-6) / 1e9 / d["roofline"]["peak"]) < 1e-3

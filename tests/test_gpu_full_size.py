@@ -157,7 +157,6 @@ def test_c4_sharded_eight_ways_matches_one_rank(gpu, ds, big):
     assert not errs, errs
     assert all(o is not None for o in out), "a virtual rank did not finish"
     gpu.loopback_destroy(group)
-    assert ref.sym_form == 1 and ref.cg_form == 2
     for s, x in out:
         assert s.sym_form == 1 and s.cg_form == 2           # (r06) every rank keeps the symmetric form of its rows: k_pipe_cg_sym, k_linearize_lean
         assert list(s.iterations["step_is_successful"]) == list(ref.iterations["step_is_successful"])

@@ -467,10 +467,10 @@ def test_evaluation_entry_points_are_refused_during_a_session(gpu, ds):
 
 def test_split_step_timeout_falls_back_to_two_launches(gpu, O, ds, monkeypatch):
     """The single-launch SPLIT steps of the 6x6-block factorisation wait in-kernel for a column's diagonal block.  With the
-    wait budget forced to zero (PGO_DIRECT_SPLIT_SPINS=0: what a GPU that cannot keep the step's work-groups resident looks
+    wait budget forced to zero (PGO_WAIT_SPINS=0: what a GPU that cannot keep the step's work-groups resident looks
     like) the solve must not fail: the driver repeats the factorisation in the two-launch form and the LM trace is the
     oracle's (same accept / reject sequence, costs 1e-7)."""
-    monkeypatch.setenv("PGO_DIRECT_SPLIT_SPINS", "0")
+    monkeypatch.setenv("PGO_WAIT_SPINS", "0")
     monkeypatch.setenv("PGO_FRONT", "0")
     monkeypatch.setenv("PGO_SFRONT", "0")
     k = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti00.npz"))
@@ -488,7 +488,7 @@ def test_split_step_timeout_falls_back_to_two_launches(gpu, O, ds, monkeypatch):
 
 def test_small_front_single_launch_timeout_falls_back_to_levels(gpu, O, ds, monkeypatch):
     """The single-launch form of the small-front factorisation (all tree levels in one launch, a front polls its children's
-    flags) with the wait budget forced to zero (PGO_SFRONT_SPINS=0): the driver repeats the factorisation level by level, keeps
+    flags) with the wait budget forced to zero (PGO_WAIT_SPINS=0): the driver repeats the factorisation level by level, keeps
     to that form, and the LM trace is the oracle's; and both forms give bit-identical traces when nothing times out."""
     k = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti00.npz"))
     g = ds.PoseGraphData(k["origin"], k["ia"], k["ib"], k["meas"], None)
@@ -496,8 +496,8 @@ def test_small_front_single_launch_timeout_falls_back_to_levels(gpu, O, ds, monk
     og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
     _, osum, otr = O.solve(og, O.default_options(max_num_iterations=8, linear_solver=0))
     traces = []
-    for env in ({"PGO_SFRONT_SPINS": "0"}, {"PGO_SFRONT_FUSED": "0"}, {}):
-        for key in ("PGO_SFRONT_SPINS", "PGO_SFRONT_FUSED"):
+    for env in ({"PGO_WAIT_SPINS": "0"}, {"PGO_FACTOR_FUSED": "0"}, {}):
+        for key in ("PGO_WAIT_SPINS", "PGO_FACTOR_FUSED"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
@@ -533,13 +533,13 @@ def test_diagonal_information_is_read_as_six_planes_with_identical_results(gpu, 
 
 def test_multifrontal_single_launch_timeout_falls_back_to_launches(gpu, ds, monkeypatch):
     """The single-launch form of the multifrontal factorisation (every work-group of the round schedule in one grid, stages
-    ordered by counters) with the wait budget forced to zero (PGO_FRONT_SPINS=0): the driver repeats the factorisation with one
+    ordered by counters) with the wait budget forced to zero (PGO_WAIT_SPINS=0): the driver repeats the factorisation with one
     launch per phase, keeps to that form, and the trace is bit-identical to the one of either form when nothing times out."""
     g = ds.manhattan_se3(1500, 5000, seed=21)
     opt = gpu.SolverOptions(max_num_iterations=6, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
     traces = []
-    for env in ({"PGO_FRONT_SPINS": "0"}, {"PGO_FRONT_FUSED": "0"}, {"PGO_FRONT_FUSED": "1"}):
-        for key in ("PGO_FRONT_SPINS", "PGO_FRONT_FUSED"):
+    for env in ({"PGO_WAIT_SPINS": "0"}, {"PGO_FACTOR_FUSED": "0"}, {"PGO_FACTOR_FUSED": "1"}):
+        for key in ("PGO_WAIT_SPINS", "PGO_FACTOR_FUSED"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)

@@ -14,4 +14,3 @@ os.environ["PGO_DEBUG"] = "0"
 for k in ["empty", "touch", "pcg_update", "cost", "linearize"]:
     print(k, round(prob.time_kernel(k, 500) * 1e3, 2))
 print("pcg_graph per-iteration us", round(prob.time_kernel("pcg_graph", 5) * 1e3, 2))
-os.environ["PGO_NO_GRAPH"] = "1"
