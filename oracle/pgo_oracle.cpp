@@ -996,9 +996,17 @@ struct RowEvents {
 // s = w + beta s, p = u + beta p; x += alpha p, r -= alpha s, u -= alpha qq, w -= alpha z — with ONE set of inner products
 // (gamma = (r,u), delta = (w,u), Q = -x'(b + r)) per iteration, the form the product's one-launch CG iteration computes
 // (posegraph-ceres_amd/csrc/pgo_uni_fused.h); same stop rules on the same quantities, no residual refresh.
+// r06 EXPERIMENT (measured here before any kernel is written, as the chain preconditioner was in r05): a TWO-LEVEL additive
+// preconditioner  M^-1 = M_J^-1 + P (P' A P)^-1 P'  — M_J the 2-pose cluster Jacobi, P an aggregation coarse space: aggregates of `agg`
+// consecutive poses of the trajectory, six rigid-body modes each (a translation t and a rotation w about the aggregate's centre:
+// dp_i = t + 2 w x (p_i - c), dtheta_i = w in the tangent coordinates of Plus, which multiplies exp(delta) from the LEFT), expressed in
+// the Jacobi-scaled unknowns the CG works in (P~ = S^-1 P, rows of constant blocks zero).  Galerkin coarse matrix P~' (H~ + D^2) P~,
+// dense 6 A x 6 A, factored once per linear solve.  Selected by pcg_cluster = -agg (agg >= 8; -1 stays the chain).
+struct CoarseSpace { int agg; const double* poses; const double* scale; const uint8_t* cmask; };
+
 int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, double q_tol,
               int max_it, int min_it, int residual_reset_period, bool* ok, double* final_rnorm, int cluster = 1, Pool* pool = nullptr,
-              int form = 0) {
+              int form = 0, const CoarseSpace* cz = nullptr) {
   const int n = H.n;
   const size_t m = (size_t)6 * n;
   if (pool && pool->width() <= 1) pool = nullptr;
@@ -1012,6 +1020,59 @@ int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, d
   // its edge's diagonal contributions behind).  Block LDL^T down the chain: S_i = A_ii - W_i S_{i-1} W_i^T with
   // W_i = A_{i,i-1} S_{i-1}^-1 — the recurrence the product's chain preconditioner factorises by segments.
   const bool chain = cluster == -1;
+  // ---- two-level: the coarse space and its Galerkin matrix ----
+  const bool two_level = cluster <= -8 && cz != nullptr;
+  int nagg = 0, cdim = 0;
+  const int ag = two_level ? -cluster : 1;
+  std::vector<double> Pt;              // P~ per pose: 6 x 6 row-major (row = fine component, column = mode of the pose's aggregate)
+  std::vector<double> Ac;              // Cholesky factor of the coarse matrix
+  if (two_level) {
+    const int agg = -cluster;
+    nagg = (n + agg - 1) / agg; cdim = 6 * nagg;
+    Pt.assign((size_t)36 * n, 0.0);
+    for (int a = 0; a < nagg; ++a) {
+      const int v0 = a * agg, v1 = std::min(n, v0 + agg);
+      double c[3] = {0, 0, 0};
+      for (int v = v0; v < v1; ++v) for (int k = 0; k < 3; ++k) c[k] += cz->poses[7 * (size_t)v + k] / (v1 - v0);
+      for (int v = v0; v < v1; ++v) {
+        const double d[3] = {cz->poses[7 * (size_t)v] - c[0], cz->poses[7 * (size_t)v + 1] - c[1], cz->poses[7 * (size_t)v + 2] - c[2]};
+        double* Pv = &Pt[(size_t)36 * v];
+        for (int k = 0; k < 3; ++k) { Pv[6 * k + k] = 1.0; Pv[6 * (3 + k) + 3 + k] = 1.0; }
+        // dp = 2 w x d: column 3 + j (w = e_j) -> 2 e_j x d
+        Pv[6 * 1 + 3] = -2 * d[2]; Pv[6 * 2 + 3] = 2 * d[1];      // e_x x d = (0, -d_z, d_y)
+        Pv[6 * 0 + 4] = 2 * d[2];  Pv[6 * 2 + 4] = -2 * d[0];     // e_y x d = (d_z, 0, -d_x)
+        Pv[6 * 0 + 5] = -2 * d[1]; Pv[6 * 1 + 5] = 2 * d[0];      // e_z x d = (-d_y, d_x, 0)
+        for (int r = 0; r < 6; ++r) {
+          const bool cst = (r < 3) ? (cz->cmask[v] & 1) : (cz->cmask[v] & 2);
+          for (int q = 0; q < 6; ++q) Pv[6 * r + q] = cst ? 0.0 : Pv[6 * r + q] / cz->scale[6 * (size_t)v + r];
+        }
+      }
+    }
+    Ac.assign((size_t)cdim * cdim, 0.0);
+    auto add = [&](int i, int j, const double* B, bool with_d2) {      // Ac[a(i), a(j)] += P_i' B P_j  (B = block (i, j) of H~ + D^2)
+      const int ai = i / agg, aj = j / agg;
+      const double *Pi = &Pt[(size_t)36 * i], *Pj = &Pt[(size_t)36 * j];
+      double BP[36];
+      for (int r = 0; r < 6; ++r)
+        for (int q = 0; q < 6; ++q) {
+          double acc = 0;
+          for (int k = 0; k < 6; ++k) acc += (B[6 * r + k] + ((with_d2 && r == k) ? d2[6 * (size_t)i + r] : 0.0)) * Pj[6 * k + q];
+          BP[6 * r + q] = acc;
+        }
+      for (int p2 = 0; p2 < 6; ++p2)
+        for (int q = 0; q < 6; ++q) {
+          double acc = 0;
+          for (int r = 0; r < 6; ++r) acc += Pi[6 * r + p2] * BP[6 * r + q];
+          Ac[(size_t)(6 * ai + p2) * cdim + 6 * aj + q] += acc;
+          if (i != j) Ac[(size_t)(6 * aj + q) * cdim + 6 * ai + p2] += acc;
+        }
+    };
+    for (int j = 0; j < n; ++j)
+      for (int p2 = H.colptr[j]; p2 < H.colptr[j + 1]; ++p2) add(H.rowidx[p2], j, H.val[p2].data(), H.rowidx[p2] == j);
+    for (int k = 0; k < cdim; ++k) if (!(Ac[(size_t)k * cdim + k] > 0.0)) Ac[(size_t)k * cdim + k] = 1.0;      // an aggregate of constant blocks only
+    if (!chol_dense(Ac, cdim)) { *ok = false; return 0; }
+    cluster = 2;
+  }
   std::vector<Blk> chS, chW;        // Cholesky factor of S_i (lower, row-major 6x6), W_i (row-major)
   std::vector<uint8_t> chHas;
   if (chain) {
@@ -1097,9 +1158,25 @@ int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, d
       const int v0 = c * cluster, v1 = std::min(n, v0 + cluster);
       chol_dense_solve(Mfac[c], 6 * (v1 - v0), rin + 6 * (size_t)v0, zout + 6 * (size_t)v0);
     };
-    if (!pool) { for (int c = 0; c < ncl; ++c) one(c); return; }
-    const int chunks = pool->width() * 4;
-    pool->run(chunks, [&](int ch) { for (int c = (int)((long long)ncl * ch / chunks); c < (int)((long long)ncl * (ch + 1) / chunks); ++c) one(c); });
+    if (!pool) { for (int c = 0; c < ncl; ++c) one(c); }
+    else {
+      const int chunks = pool->width() * 4;
+      pool->run(chunks, [&](int ch) { for (int c = (int)((long long)ncl * ch / chunks); c < (int)((long long)ncl * (ch + 1) / chunks); ++c) one(c); });
+    }
+    if (two_level) {                   // + P (P' A P)^-1 P' r
+      std::vector<double> rc(cdim, 0.0), xc(cdim, 0.0);
+      for (int v = 0; v < n; ++v) {
+        const int a = v / ag;
+        const double* Pv = &Pt[(size_t)36 * v];
+        for (int q = 0; q < 6; ++q) { double acc = 0; for (int r = 0; r < 6; ++r) acc += Pv[6 * r + q] * rin[6 * (size_t)v + r]; rc[6 * a + q] += acc; }
+      }
+      chol_dense_solve(Ac, cdim, rc.data(), xc.data());
+      for (int v = 0; v < n; ++v) {
+        const int a = v / ag;
+        const double* Pv = &Pt[(size_t)36 * v];
+        for (int r = 0; r < 6; ++r) { double acc = 0; for (int q = 0; q < 6; ++q) acc += Pv[6 * r + q] * xc[6 * a + q]; zout[6 * (size_t)v + r] += acc; }
+      }
+    }
   };
   std::vector<double> r(b, b + m), z(m), p(m, 0.0), q(m), tmp(m);
   std::fill(x, x + m, 0.0);
@@ -1497,8 +1574,10 @@ int oracle_solve(int N, int E, double* poses, const uint8_t* cmask, const int* i
       sum->factor_nnz_blocks = chol.nnz_blocks;
       sum->factor_flops = chol.flops;
     } else {
+      const CoarseSpace cz{-opt->pcg_cluster, x.data(), scale.data(), cmask};
       lin_it = pcg_solve(H, d2.data(), gs.data(), step.data(), opt->eta, opt->max_linear_solver_iterations,
-                         opt->min_linear_solver_iterations, opt->residual_reset_period, &lin_ok, nullptr, opt->pcg_cluster, pool.get(), opt->pcg_form);
+                         opt->min_linear_solver_iterations, opt->residual_reset_period, &lin_ok, nullptr, opt->pcg_cluster, pool.get(), opt->pcg_form,
+                         opt->pcg_cluster <= -8 ? &cz : nullptr);
       sum->num_linear_iterations += lin_it;
     }
     if (lin_ok) for (size_t i = 0; i < m; ++i) { if (!std::isfinite(step[i])) { lin_ok = false; break; } }
