@@ -59,7 +59,7 @@ class _COptions(C.Structure):
         ("max_num_iterations", C.c_int), ("linear_solver_type", C.c_int), ("jacobi_scaling", C.c_int),
         ("max_linear_solver_iterations", C.c_int), ("min_linear_solver_iterations", C.c_int),
         ("max_num_consecutive_invalid_steps", C.c_int), ("cg_batch", C.c_int), ("pcg_cluster_poses", C.c_int),
-        ("cg_residual_reset_period", C.c_int), ("pcg_form", C.c_int),
+        ("cg_residual_reset_period", C.c_int), ("pcg_form", C.c_int), ("pcg_coarse_aggregate", C.c_int), ("reserved_options", C.c_int),
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
         ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
         ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
@@ -80,7 +80,7 @@ class _CSummary(C.Structure):
         ("final_trust_region_radius", C.c_double), ("message", C.c_char * 256),
         ("factor_kind", C.c_int), ("factor_max_front", C.c_int), ("factor_flops", C.c_double),
         ("num_parameter_blocks_reduced", C.c_int), ("num_parameters_reduced", C.c_int), ("num_effective_parameters_reduced", C.c_int),
-        ("cg_form", C.c_int), ("cg_exchange", C.c_int), ("sym_form", C.c_int), ("reserved_summary", C.c_int),
+        ("cg_form", C.c_int), ("cg_exchange", C.c_int), ("sym_form", C.c_int), ("coarse_level", C.c_int),
     ]
 
 

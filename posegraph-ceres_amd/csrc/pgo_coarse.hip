@@ -1,0 +1,252 @@
+// pgo_coarse.hip — kernels of the PCG's coarse level (pgo_coarse.h).  FP64, gfx950.  None of this is bandwidth work: a coarse space of
+// a few hundred aggregates is a few megabytes; what matters is a FIXED summation order everywhere (bit-reproducible run to run, no FP64
+// atomics) and few dependent round trips per launch.
+#include "pgo_coarse.h"
+#include "pgo_wave.h"
+
+namespace pgo {
+
+namespace {
+
+// P~ of the aggregate's poses: the aggregate's centre (mean position, fixed-order sum), then per pose the 6 x 6 block
+//   [ I   2 [e_j x d] ]      d = p - c      (column 3 + j: the rotation e_j about the centre moves the pose by 2 e_j x d)
+//   [ 0       I      ]
+// with row r divided by the Jacobi scale of that component and the rows of constant blocks zero.
+__global__ __launch_bounds__(256) void k_coarse_basis(DeviceGraph g, CoarsePlan c) {
+  __shared__ double scratch[16];
+  const int a = blockIdx.x, tid = threadIdx.x;
+  const int v0 = a * c.agg, v1 = min(g.N, v0 + c.agg);
+  double ctr[3] = {0.0, 0.0, 0.0};
+  for (int v = v0 + tid; v < v1; v += 256) {
+    const double* p = g.pose_x + (size_t)POSE_STRIDE * v;
+    ctr[0] += p[0]; ctr[1] += p[1]; ctr[2] += p[2];
+  }
+  block_sum<3>(ctr, scratch);
+  const double inv = 1.0 / (double)(v1 - v0);
+  for (int v = v0 + tid; v < v1; v += 256) {
+    const double* p = g.pose_x + (size_t)POSE_STRIDE * v;
+    const double d[3] = {p[0] - ctr[0] * inv, p[1] - ctr[1] * inv, p[2] - ctr[2] * inv};
+    double Pv[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) Pv[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Pv[7 * k] = 1.0;
+    Pv[6 * 1 + 3] = -2.0 * d[2]; Pv[6 * 2 + 3] = 2.0 * d[1];
+    Pv[6 * 0 + 4] = 2.0 * d[2];  Pv[6 * 2 + 4] = -2.0 * d[0];
+    Pv[6 * 0 + 5] = -2.0 * d[1]; Pv[6 * 1 + 5] = 2.0 * d[0];
+    const uint8_t cm = g.cmask[v];
+    double* o = c.Pt + (size_t)36 * v;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const bool cst = (r < 3) ? (cm & 1) : (cm & 2);
+      const double sc = g.scale[6 * (size_t)v + r];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) o[6 * r + q] = cst ? 0.0 : Pv[6 * r + q] / sc;
+    }
+  }
+}
+
+// Row panel a of the Galerkin matrix: sum over the incidence slots (i, j) of the aggregate's rows of P~_i' B_ij P~_j into
+// Ac[6 a .., 6 a(j) ..] — the diagonal slot holds H~_ii + D^2 after the damping, every edge has a slot in each of its rows, so the
+// panel is complete without a transpose.  64 slots per pass, one per lane (its 6 x 6 product in registers: one round trip of loads
+// per pass); the 36 entry lanes then add the pass's products into the LDS panel in slot order: a fixed order, no atomics.
+__global__ __launch_bounds__(64) void k_coarse_galerkin(DeviceGraph g, CoarsePlan c) {
+  extern __shared__ double lds[];      // panel[6][npad] | stage[64][37]
+  double* panel = lds;
+  double* stage = lds + (size_t)6 * c.npad;
+  __shared__ int scol[64];
+  const int a = blockIdx.x, lane = threadIdx.x;
+  const int v0 = a * c.agg, v1 = min(g.N, v0 + c.agg);
+  for (int i = lane; i < 6 * c.npad; i += 64) panel[i] = 0.0;
+  const int t_begin = g.row_slot_begin[v0], t_end = g.row_slot_begin[v1 - 1] + g.row_slot_cnt[v1 - 1];
+  __syncthreads();
+  for (int t0 = t_begin; t0 < t_end; t0 += 64) {
+    const int t = t0 + lane;
+    int col = -1;
+    double C[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) C[k] = 0.0;
+    if (t < t_end) {
+      col = g.slot_col[t];
+      const uint8_t side = g.slot_side[t];
+      if (col >= 0 && side != SIDE_PAD) {
+        const int row = g.slot_row[t];
+        double Pj[36];
+        const double* pj = c.Pt + (size_t)36 * col;
+#pragma unroll
+        for (int k = 0; k < 36; ++k) Pj[k] = pj[k];
+        const double* pi = c.Pt + (size_t)36 * row;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          double T[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            const double b = bsr_elem(g, t, side, 6 * r + k);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) T[q] += b * Pj[6 * k + q];
+          }
+#pragma unroll
+          for (int p = 0; p < 6; ++p) {
+            const double pr = pi[6 * r + p];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) C[6 * p + q] += pr * T[q];
+          }
+        }
+      } else {
+        col = -1;
+      }
+    }
+    scol[lane] = col;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) stage[lane * 37 + k] = C[k];
+    __syncthreads();
+    if (lane < 36) {
+      const int p = lane / 6, q = lane - 6 * p;
+      for (int sidx = 0; sidx < 64; ++sidx) {
+        const int cj = scol[sidx];
+        if (cj < 0) continue;
+        panel[(size_t)p * c.npad + 6 * (cj / c.agg) + q] += stage[sidx * 37 + lane];
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = lane; i < 6 * c.npad; i += 64) {
+    const int p = i / c.npad, j = i - p * c.npad;
+    double v = panel[i];
+    if (j == 6 * a + p && !(v > 0.0)) v = 1.0;          // an aggregate of constant blocks only: identity row
+    c.Ac[(size_t)(6 * a + p) * c.npad + j] = v;
+  }
+}
+// identity on the padding rows / columns (cdim .. npad)
+__global__ void k_coarse_pad(CoarsePlan c) {
+  const int i = c.cdim + blockIdx.x, j = threadIdx.x + 256 * blockIdx.y;
+  if (i >= c.npad || j >= c.npad) return;
+  c.Ac[(size_t)i * c.npad + j] = i == j ? 1.0 : 0.0;
+  if (j < c.cdim) c.Ac[(size_t)j * c.npad + i] = 0.0;
+}
+
+// ---- explicit inverse, in place: block Gauss-Jordan without pivoting (the matrix is symmetric positive definite), 16 x 16 blocks.
+// Step k, with K = the k-th block of rows / columns:   W = A_KK^-1;   R = W A_K:   (pivot kernel, one work-group)
+//   rows i not in K:  A_i: -= A_iK R (columns not in K),  A_iK = -A_iK W;      rows K:  A_K: = R (columns not in K),  A_KK = W   (update kernel)
+constexpr int GJ = 16;
+__global__ __launch_bounds__(256) void k_coarse_gj_pivot(CoarsePlan c, int k) {
+  __shared__ double M[GJ][GJ + 1], W[GJ][GJ + 1];
+  const int tid = threadIdx.x, i = tid / GJ, j = tid % GJ, n = c.npad, K0 = GJ * k;
+  M[i][j] = c.Ac[(size_t)(K0 + i) * n + K0 + j];
+  W[i][j] = i == j ? 1.0 : 0.0;
+  __syncthreads();
+  for (int p = 0; p < GJ; ++p) {
+    const double piv = M[p][p];
+    const double f = M[i][p] / piv;
+    const double mp = M[p][j], wp = W[p][j];
+    __syncthreads();
+    if (i == p) { M[i][j] = mp / piv; W[i][j] = wp / piv; }
+    else { M[i][j] -= f * mp; W[i][j] -= f * wp; }
+    __syncthreads();
+  }
+  c.piv[i * GJ + j] = W[i][j];
+  // R = W A_K: for all columns
+  for (int col = tid; col < n; col += 256) {
+    double acc[GJ];
+#pragma unroll
+    for (int ii = 0; ii < GJ; ++ii) acc[ii] = 0.0;
+    for (int m = 0; m < GJ; ++m) {
+      const double av = c.Ac[(size_t)(K0 + m) * n + col];
+#pragma unroll
+      for (int ii = 0; ii < GJ; ++ii) acc[ii] += W[ii][m] * av;
+    }
+#pragma unroll
+    for (int ii = 0; ii < GJ; ++ii) c.row[(size_t)ii * n + col] = acc[ii];
+  }
+}
+__global__ __launch_bounds__(256) void k_coarse_gj_update(CoarsePlan c, int k) {
+  __shared__ double Cb[GJ][GJ + 1], W[GJ][GJ + 1];
+  const int tid = threadIdx.x, ii = tid / GJ, jj = tid % GJ, n = c.npad, K0 = GJ * k, I0 = GJ * blockIdx.x;
+  W[ii][jj] = c.piv[ii * GJ + jj];
+  Cb[ii][jj] = c.Ac[(size_t)(I0 + ii) * n + K0 + jj];      // the OLD A_iK of this strip (nobody else writes this strip)
+  __syncthreads();
+  if ((int)blockIdx.x == k) {
+    for (int j0 = 0; j0 < n; j0 += GJ) c.Ac[(size_t)(I0 + ii) * n + j0 + jj] = (j0 == K0) ? W[ii][jj] : c.row[(size_t)ii * n + j0 + jj];
+    return;
+  }
+  for (int j0 = 0; j0 < n; j0 += GJ) {
+    if (j0 == K0) continue;
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < GJ; ++m) acc += Cb[ii][m] * c.row[(size_t)m * n + j0 + jj];
+    c.Ac[(size_t)(I0 + ii) * n + j0 + jj] -= acc;
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int m = 0; m < GJ; ++m) acc += Cb[ii][m] * W[m][jj];
+  c.Ac[(size_t)(I0 + ii) * n + K0 + jj] = -acc;
+}
+
+// rc = P~' vec over the aggregate's poses (lane = pose, block sum in fixed order)
+__global__ __launch_bounds__(256) void k_coarse_restrict(DeviceGraph g, CoarsePlan c, const double* vec) {
+  __shared__ double scratch[32];
+  const int a = blockIdx.x, tid = threadIdx.x;
+  const int v0 = a * c.agg, v1 = min(g.N, v0 + c.agg);
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int v = v0 + tid; v < v1; v += 256) {
+    const double* pv = c.Pt + (size_t)36 * v;
+    const double* w = vec + 6 * (size_t)v;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const double wr = w[r];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) acc[q] += pv[6 * r + q] * wr;
+    }
+  }
+  block_sum<6>(acc, scratch);
+  if (tid < 6) c.rc[6 * a + tid] = acc[tid];
+}
+// xc = (Ainv rc) for the aggregate's six rows, then out += P~ xc for its poses
+__global__ __launch_bounds__(256) void k_coarse_correct(DeviceGraph g, CoarsePlan c, double* out, double* out2) {
+  __shared__ double scratch[32];
+  __shared__ double xc[6];
+  const int a = blockIdx.x, tid = threadIdx.x;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int j = tid; j < c.cdim; j += 256) {
+    const double r = c.rc[j];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) acc[p] += c.Ac[(size_t)(6 * a + p) * c.npad + j] * r;
+  }
+  block_sum<6>(acc, scratch);
+  if (tid < 6) xc[tid] = acc[tid];
+  __syncthreads();
+  const int v0 = a * c.agg, v1 = min(g.N, v0 + c.agg);
+  for (int v = v0 + tid; v < v1; v += 256) {
+    const double* pv = c.Pt + (size_t)36 * v;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) s += pv[6 * r + q] * xc[q];
+      out[6 * (size_t)v + r] += s;
+      if (out2) out2[6 * (size_t)v + r] += s;
+    }
+  }
+}
+
+}  // namespace
+
+void launch_coarse_setup(const DeviceGraph& g, const CoarsePlan& c, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_coarse_galerkin), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
+  hipLaunchKernelGGL(k_coarse_basis, dim3(c.n_agg), dim3(256), 0, s, g, c);
+  const size_t lds = ((size_t)6 * c.npad + 64 * 37) * sizeof(double);
+  hipLaunchKernelGGL(k_coarse_galerkin, dim3(c.n_agg), dim3(64), lds, s, g, c);
+  if (c.npad > c.cdim) hipLaunchKernelGGL(k_coarse_pad, dim3(c.npad - c.cdim, (c.npad + 255) / 256), dim3(256), 0, s, c);
+  for (int k = 0; k < c.npad / GJ; ++k) {
+    hipLaunchKernelGGL(k_coarse_gj_pivot, dim3(1), dim3(256), 0, s, c, k);
+    hipLaunchKernelGGL(k_coarse_gj_update, dim3(c.npad / GJ), dim3(256), 0, s, c, k);
+  }
+}
+
+void launch_coarse_apply(const DeviceGraph& g, const CoarsePlan& c, const double* vec, double* out, double* out2, hipStream_t s) {
+  hipLaunchKernelGGL(k_coarse_restrict, dim3(c.n_agg), dim3(256), 0, s, g, c, vec);
+  hipLaunchKernelGGL(k_coarse_correct, dim3(c.n_agg), dim3(256), 0, s, g, c, out, out2);
+}
+
+}  // namespace pgo

@@ -12,6 +12,7 @@
 #include "pgo_front.h"
 #include "pgo_comm.h"
 #include "pgo_pool.h"
+#include "pgo_coarse.h"
 
 namespace pgo { int comm_stress(Comm* c, int iters, size_t seg, hipStream_t s, int* mismatches); }
 
@@ -469,6 +470,11 @@ struct pgo_problem {
   DevBuf<int> d_cl_ptr, d_cl_slot;
   DevBuf<uint8_t> d_cl_rc;
   int cluster_built = 0;
+
+  // coarse level of the PCG (pgo_coarse.h; options.pcg_coarse_aggregate >= 8, one rank): plan + buffers of this session
+  pgo::CoarsePlan coarse{};
+  bool coarse_on = false;
+  DevBuf<double> dc_Pt, dc_Ac, dc_piv, dc_row, dc_rc;
 
   // one process per GPU: the communicator of the row-sharded path (null = single rank)
   pgo::Comm* comm = nullptr;

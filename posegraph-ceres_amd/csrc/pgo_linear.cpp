@@ -33,6 +33,8 @@ bool pipe_mode(const pgo_problem* P, const pgo::CgParams& prm) {
   // One rank (r06): a session that keeps the normal equations in the symmetric tile form — the graphs above the universal stream's size
   // limit — runs the same one-launch CG iteration on it (k_pipe_cg_sym) where the library would take the pipelined recurrences anyway
   // (truncated CG with a forcing term >= 0.01, or pcg_form 2); pcg_form 1 and tighter forcing terms keep Ceres' refreshed CG (k_spmv_sym<0> + k_pcg_update)
+  // ... and a session with a coarse level (pgo_coarse.h): incidence-slot storage, k_pipe_cg with the correction between its launches
+  if (P->coarse_on) return (P->g.cluster == 1 || P->g.cluster == 2) && prm.q_tolerance >= 0.0 && prm.r_tolerance < 0.0 && P->g.pipe_buf[0] != nullptr && P->g.pairs_whole;
   const bool asked = P->opt.pcg_form == 2 || (P->opt.pcg_form == 0 && P->opt.eta >= 1e-2);
   return P->sym_storage && asked && !P->universal && !P->pipelined && (P->g.cluster == 1 || P->g.cluster == 2) && prm.q_tolerance >= 0.0 && prm.r_tolerance < 0.0 &&
          P->g.pipe_buf[0] != nullptr;
@@ -41,6 +43,8 @@ bool pipe_mode(const pgo_problem* P, const pgo::CgParams& prm) {
 static void pipe_cg_launch(pgo_problem* P, const pgo::CgParams& prm, int seq, unsigned long long gseq = 0, bool last_of_batch = false) {
   if (P->sym_storage) pgo::launch_pipe_cg_sym(sym_view(P), P->sym, prm, seq, P->stream, gseq, last_of_batch);
   else pgo::launch_pipe_cg(P->g, prm, seq, 0, P->stream, gseq);
+  // coarse level: the launch left m_J = M_J^-1 w of its rows in the buffer the next launch reads; add P (P'AP)^-1 P' w
+  if (P->coarse_on) pgo::launch_coarse_apply(P->g, P->coarse, P->g.cg_w, P->g.pipe_buf[(seq & 1) ^ 1], nullptr, P->stream);
 }
 
 int enqueue_tail(pgo_problem* P, const pgo::CgParams* finish_prm) {
@@ -50,8 +54,9 @@ int enqueue_tail(pgo_problem* P, const pgo::CgParams* finish_prm) {
   if (finish_prm && pipe_mode(P, *finish_prm)) {
     // owner-only CG: the batch's last launch applied the stop test; x of every row is gathered first (cg_x is laid out like an
     // exchange buffer: rank r owns [r * rows_per * 6, ...)), then the tail of the sharded path as below, gated on the CG having stopped
-    if (P->g.world == 1) {        // (one rank, symmetric form: the two-launch tail of the one-rank path, gated on the CG state k_pipe_cg_sym keeps)
-      pgo::launch_spmv_sym(P->g, P->sym, none, 1 | 64 | 4, 1, s);
+    if (P->g.world == 1) {        // (one rank: the two-launch tail of the one-rank path, gated on the CG state the pipelined kernels keep)
+      if (P->sym_storage) pgo::launch_spmv_sym(P->g, P->sym, none, 1 | 64 | 4, 1, s);
+      else pgo::launch_spmv_tail(P->g, none, s, 2, 1);
       pgo::launch_step_tail(P->g, s, 1);
       return PGO_OK;
     }
@@ -188,6 +193,8 @@ int pcg_begin(pgo_problem* P, const pgo::CgParams& prm) {
     return PGO_OK;
   }
   pgo::launch_pipe_init(P->g, s);
+  // coarse level: u0 = M^-1 r0 gets its coarse part too (r0 = b; into the exchange buffer the first product reads and into u)
+  if (P->coarse_on) pgo::launch_coarse_apply(P->g, P->coarse, P->g.cg_r, P->g.pipe_buf[0], P->g.cg_u, s);
   if (P->g.peer_tab) {       // device-initiated exchange: the kernels store into every rank's buffer and signal each other
     pgo::launch_peer_signal(P->g, ++P->peer_gseq, s);
     pipe_cg_launch(P, prm, 0, ++P->peer_gseq);

@@ -86,6 +86,27 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   pgo::launch_apply_step(P->g, P->g.delta, P->stream);
   pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, P->stream);
   int cluster = P->opt.pcg_cluster_poses;
+  // coarse level of the PCG (pgo_coarse.h): one rank, truncated PCG; on top of the 2-pose cluster Jacobi
+  P->coarse_on = P->opt.linear_solver_type == PGO_BLOCK_JACOBI_PCG && P->opt.pcg_coarse_aggregate >= 8 && P->g.world == 1 && !(P->comm && P->comm->world > 1);
+  if (P->opt.pcg_coarse_aggregate != 0 && !P->coarse_on)
+    return set_error(PGO_ERR_UNSUPPORTED, "pcg_coarse_aggregate = %d: the coarse level needs BLOCK_JACOBI_PCG on one rank and aggregates of at least 8 poses", P->opt.pcg_coarse_aggregate);
+  if (P->coarse_on) {
+    cluster = 2;
+    pgo::CoarsePlan& c = P->coarse;
+    c.agg = P->opt.pcg_coarse_aggregate;
+    c.n_agg = (P->g.N + c.agg - 1) / c.agg;
+    c.cdim = 6 * c.n_agg;
+    c.npad = (c.cdim + 15) / 16 * 16;
+    if ((size_t)(6 * c.npad + 64 * 37) * sizeof(double) > 160 * 1024 - 2048)
+      return set_error(PGO_ERR_UNSUPPORTED, "pcg_coarse_aggregate = %d gives %d aggregates: more than the coarse level's row panel holds (use larger aggregates)", c.agg, c.n_agg);
+    HIP_TRY(P->dc_Pt.alloc((size_t)36 * P->g.N));
+    HIP_TRY(P->dc_Ac.alloc((size_t)c.npad * c.npad));
+    HIP_TRY(P->dc_piv.alloc(256));
+    HIP_TRY(P->dc_row.alloc((size_t)16 * c.npad));
+    HIP_TRY(P->dc_rc.alloc((size_t)c.npad));
+    HIP_TRY(P->dc_rc.zero(P->stream));
+    c.Pt = P->dc_Pt.p; c.Ac = P->dc_Ac.p; c.piv = P->dc_piv.p; c.row = P->dc_row.p; c.rc = P->dc_rc.p;
+  }
   if (P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY) {
     const auto t_sym = Clock::now();
     rc = prepare_direct(P);
@@ -319,6 +340,8 @@ int lm_advance(pgo_problem* P) {
   const pgo::CgParams prm = cg_params_for(o);
   int rc = damping_all(P, L.radius, o.min_lm_diagonal, o.max_lm_diagonal, L.reuse_diagonal ? 1 : 0);
   if (rc) return rc;
+  // coarse level: P~ at the current point, the Galerkin matrix of the damped system, its inverse (pgo_coarse.h)
+  if (P->coarse_on) pgo::launch_coarse_setup(P->g, P->coarse, s);
   const bool direct = o.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY && P->direct_usable;
   // Both available (hybrid): PCG gets the budget of ~1.5 factorisations, in CG iterations priced by the same deterministic
   // cost model that admitted the factorisation (0.7 us per schedule step; 10 us + 42 ps per slot per CG iteration), so the
@@ -440,7 +463,7 @@ int lm_advance(pgo_problem* P) {
 // accepted / halt): a wrong guess costs early-exit launches (~2.6 us each), never a wrong result.
 static bool pipeline_wanted(const pgo_problem* P) {
   const bool off = getenv("PGO_NO_PIPELINE") && getenv("PGO_NO_PIPELINE")[0] == '1';   // (read per solve: the tests compare both drivers in one process)
-  if (off || P->g.world != 1 || (P->comm && P->comm->world > 1) || P->use_graph) return false;
+  if (off || P->g.world != 1 || (P->comm && P->comm->world > 1) || P->use_graph || P->coarse_on) return false;
   const bool direct = P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY && P->direct_usable;
   if (direct && P->dsym.hybrid && !P->front_usable && !P->sfront_usable) return false;   // factorisation or PCG chosen per iteration by the host
   // Exact steps: the launch sequence of an iteration is the same every time, so enqueueing ahead costs nothing.  PCG: the host has
@@ -589,7 +612,7 @@ int pipe_drain(pgo_problem* P) {
 static bool universal_wanted(const pgo_problem* P) {
   const bool off = getenv("PGO_NO_PIPELINE") && getenv("PGO_NO_PIPELINE")[0] == '1';
   const char* u = getenv("PGO_UNI");
-  if (off || (u && u[0] == '0') || P->g.world != 1 || (P->comm && P->comm->world > 1) || P->use_graph) return false;
+  if (off || (u && u[0] == '0') || P->g.world != 1 || (P->comm && P->comm->world > 1) || P->use_graph || P->coarse_on) return false;
   const bool direct = P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY && P->direct_usable;
   if (direct || !pgo::uni_supported(P->g)) return false;
   // large graphs (kernels of 100+ us) gain nothing from it and the slot kernel's LDS footprint (the linearisation's) would cost the
@@ -830,6 +853,7 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
     summary->cg_exchange = P->g.world > 1 ? (P->g.peer_tab && pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : 0;
     summary->cg_form = P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : (P->uni_resident ? 4 : P->uni_fused ? 3 : pipe_mode(P, cg_params_for(P->opt)) ? 2 : 0);
     summary->sym_form = P->sym_storage ? 1 : 0;
+    summary->coarse_level = P->coarse_on ? P->coarse.n_agg : 0;
     summary->termination_type = L.termination;
     summary->reason = L.reason;
     summary->num_successful_steps = L.num_successful;

@@ -753,6 +753,8 @@ void pgo_solver_options_init(pgo_solver_options* o) {
   o->pcg_cluster_poses = 1;
   o->cg_residual_reset_period = 10;   // LinearSolver::Options::residual_reset_period of Ceres 1.13
   o->pcg_form = 0;
+  o->pcg_coarse_aggregate = 0;
+  o->reserved_options = 0;
   o->function_tolerance = 1e-6;
   o->gradient_tolerance = 1e-10;
   o->parameter_tolerance = 1e-8;

@@ -10,7 +10,7 @@
 bool sym_wanted(const pgo_problem* P) {
   const char* e = getenv("PGO_SYM");
   if (e && e[0] == '0') return false;
-  if (P->use_graph) return false;
+  if (P->use_graph || P->coarse_on) return false;
   // several ranks (r06): every rank keeps the form of ITS rows; the only CG that multiplies with it there is the owner-only pipelined
   // one (k_pipe_cg_sym), so the request has to be one that form serves
   if (P->g.world > 1 && !pgo::pipe_supported(P->g, cg_params_for(P->opt), P->g.cluster)) return false;

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for n in names:
         assert hasattr(L, n), n
     assert sorted(pkg.C_ABI_SYMBOLS) == names
-    assert L.pgo_version() == 103
+    assert L.pgo_version() == 104
 
 
 def test_options_defaults(pkg):
