@@ -129,57 +129,65 @@ __global__ void k_coarse_pad(CoarsePlan c) {
 // Step k, with K = the k-th block of rows / columns:   W = A_KK^-1;   R = W A_K:   (pivot kernel, one work-group)
 //   rows i not in K:  A_i: -= A_iK R (columns not in K),  A_iK = -A_iK W;      rows K:  A_K: = R (columns not in K),  A_KK = W   (update kernel)
 constexpr int GJ = 16;
+// (every work-group of the launch inverts the pivot block for itself — sixteen elimination steps in LDS — and forms ITS 256 columns of
+// R; work-group 0 also leaves W for the update kernel)
 __global__ __launch_bounds__(256) void k_coarse_gj_pivot(CoarsePlan c, int k) {
   __shared__ double M[GJ][GJ + 1], W[GJ][GJ + 1];
   const int tid = threadIdx.x, i = tid / GJ, j = tid % GJ, n = c.npad, K0 = GJ * k;
+  const int col = 256 * blockIdx.x + tid;
+  double av[GJ];
+#pragma unroll
+  for (int m = 0; m < GJ; ++m) av[m] = c.Ac[(size_t)(K0 + m) * n + min(col, n - 1)];
   M[i][j] = c.Ac[(size_t)(K0 + i) * n + K0 + j];
   W[i][j] = i == j ? 1.0 : 0.0;
   __syncthreads();
   for (int p = 0; p < GJ; ++p) {
-    const double piv = M[p][p];
-    const double f = M[i][p] / piv;
+    const double ip = 1.0 / M[p][p];
+    const double f = M[i][p] * ip;
     const double mp = M[p][j], wp = W[p][j];
     __syncthreads();
-    if (i == p) { M[i][j] = mp / piv; W[i][j] = wp / piv; }
+    if (i == p) { M[i][j] = mp * ip; W[i][j] = wp * ip; }
     else { M[i][j] -= f * mp; W[i][j] -= f * wp; }
     __syncthreads();
   }
-  c.piv[i * GJ + j] = W[i][j];
-  // R = W A_K: for all columns
-  for (int col = tid; col < n; col += 256) {
-    double acc[GJ];
+  if (blockIdx.x == 0) c.piv[i * GJ + j] = W[i][j];
+  if (col < n) {
 #pragma unroll
-    for (int ii = 0; ii < GJ; ++ii) acc[ii] = 0.0;
-    for (int m = 0; m < GJ; ++m) {
-      const double av = c.Ac[(size_t)(K0 + m) * n + col];
+    for (int ii = 0; ii < GJ; ++ii) {
+      double acc = 0.0;
 #pragma unroll
-      for (int ii = 0; ii < GJ; ++ii) acc[ii] += W[ii][m] * av;
+      for (int m = 0; m < GJ; ++m) acc += W[ii][m] * av[m];
+      c.row[(size_t)ii * n + col] = acc;
     }
-#pragma unroll
-    for (int ii = 0; ii < GJ; ++ii) c.row[(size_t)ii * n + col] = acc[ii];
   }
 }
+// grid (strips of 16 rows, chunks of 256 columns): the chunk's piece of the pivot row panel is staged in LDS once per work-group
 __global__ __launch_bounds__(256) void k_coarse_gj_update(CoarsePlan c, int k) {
-  __shared__ double Cb[GJ][GJ + 1], W[GJ][GJ + 1];
-  const int tid = threadIdx.x, ii = tid / GJ, jj = tid % GJ, n = c.npad, K0 = GJ * k, I0 = GJ * blockIdx.x;
+  __shared__ double Cb[GJ][GJ + 1], W[GJ][GJ + 1], Rs[GJ][256 + 1];
+  const int tid = threadIdx.x, ii = tid / GJ, jj = tid % GJ, n = c.npad, K0 = GJ * k, I0 = GJ * blockIdx.x, J0 = 256 * blockIdx.y;
+  const int ncol = min(256, n - J0);
   W[ii][jj] = c.piv[ii * GJ + jj];
-  Cb[ii][jj] = c.Ac[(size_t)(I0 + ii) * n + K0 + jj];      // the OLD A_iK of this strip (nobody else writes this strip)
+  Cb[ii][jj] = c.Ac[(size_t)(I0 + ii) * n + K0 + jj];      // the OLD A_iK of this strip (only the chunk that holds block K rewrites it, at the very end)
+#pragma unroll
+  for (int m = 0; m < GJ; ++m) if (tid < ncol) Rs[m][tid] = c.row[(size_t)m * n + J0 + tid];
   __syncthreads();
-  if ((int)blockIdx.x == k) {
-    for (int j0 = 0; j0 < n; j0 += GJ) c.Ac[(size_t)(I0 + ii) * n + j0 + jj] = (j0 == K0) ? W[ii][jj] : c.row[(size_t)ii * n + j0 + jj];
-    return;
-  }
-  for (int j0 = 0; j0 < n; j0 += GJ) {
-    if (j0 == K0) continue;
+  const bool pivot_strip = (int)blockIdx.x == k;
+  for (int u = 0; u * GJ < ncol; ++u) {
+    const int jl = GJ * u + jj, j = J0 + jl;
+    if (J0 + GJ * u == K0) continue;                        // block K of this strip: below
+    double* dst = c.Ac + (size_t)(I0 + ii) * n + j;
+    if (pivot_strip) { *dst = Rs[ii][jl]; continue; }
     double acc = 0.0;
 #pragma unroll
-    for (int m = 0; m < GJ; ++m) acc += Cb[ii][m] * c.row[(size_t)m * n + j0 + jj];
-    c.Ac[(size_t)(I0 + ii) * n + j0 + jj] -= acc;
+    for (int m = 0; m < GJ; ++m) acc += Cb[ii][m] * Rs[m][jl];
+    *dst -= acc;
   }
-  double acc = 0.0;
+  if (K0 >= J0 && K0 < J0 + 256) {                          // this chunk holds block K: A_KK = W, A_iK = -A_iK W
+    double acc = 0.0;
 #pragma unroll
-  for (int m = 0; m < GJ; ++m) acc += Cb[ii][m] * W[m][jj];
-  c.Ac[(size_t)(I0 + ii) * n + K0 + jj] = -acc;
+    for (int m = 0; m < GJ; ++m) acc += Cb[ii][m] * W[m][jj];
+    c.Ac[(size_t)(I0 + ii) * n + K0 + jj] = pivot_strip ? W[ii][jj] : -acc;
+  }
 }
 
 // rc = P~' vec over the aggregate's poses (lane = pose, block sum in fixed order)
@@ -239,8 +247,8 @@ void launch_coarse_setup(const DeviceGraph& g, const CoarsePlan& c, hipStream_t 
   hipLaunchKernelGGL(k_coarse_galerkin, dim3(c.n_agg), dim3(64), lds, s, g, c);
   if (c.npad > c.cdim) hipLaunchKernelGGL(k_coarse_pad, dim3(c.npad - c.cdim, (c.npad + 255) / 256), dim3(256), 0, s, c);
   for (int k = 0; k < c.npad / GJ; ++k) {
-    hipLaunchKernelGGL(k_coarse_gj_pivot, dim3(1), dim3(256), 0, s, c, k);
-    hipLaunchKernelGGL(k_coarse_gj_update, dim3(c.npad / GJ), dim3(256), 0, s, c, k);
+    hipLaunchKernelGGL(k_coarse_gj_pivot, dim3((c.npad + 255) / 256), dim3(256), 0, s, c, k);
+    hipLaunchKernelGGL(k_coarse_gj_update, dim3(c.npad / GJ, (c.npad + 255) / 256), dim3(256), 0, s, c, k);
   }
 }
 
