@@ -73,7 +73,10 @@ def main():
     # the N > 1 orchestration of this script is executed on a one-GPU box.  PGO_BENCH_TRANSPORT=ipc selects that data path with one
     # GPU per rank as well (default there: RCCL).
     one_gpu = os.environ.get("PGO_BENCH_ONE_GPU", "0") == "1"
-    transport = "ipc" if one_gpu else os.environ.get("PGO_BENCH_TRANSPORT", "rccl")
+    # (PGO_BENCH_SIMULATE_TRANSPORT_FAILURE=1, with PGO_BENCH_ONE_GPU=1: the first attempt "is" the RCCL one and fails on purpose, so that the
+    # retry chain below — every rank re-executing itself over the IPC transport — can be executed on a one-GPU box)
+    simulate_failure = one_gpu and os.environ.get("PGO_BENCH_SIMULATE_TRANSPORT_FAILURE", "0") == "1" and not os.environ.get("PGO_BENCH_JSON_FD")
+    transport = "rccl" if simulate_failure else "ipc" if one_gpu else os.environ.get("PGO_BENCH_TRANSPORT", "rccl")
     # N > 1, one GPU per rank: the row-sharded run goes over RCCL first; if that fails or does not finish within half of the limit, every
     # rank re-executes itself with the IPC transport (one process per rank, exchange by the kernels through hipIpc-mapped buffers — the
     # transport that HAS run between processes, tests/test_gpu_ipc.py) before the run is given up for the replica figures.  The line
@@ -93,8 +96,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")     # (the launcher sets both; the forced one-GPU run of this path has neither)
         # (the retry over the IPC transport keeps RCCL out of the control plane too: gloo, on the port its re-executed ranks agreed on)
-        ctrl_gloo = one_gpu or bool(os.environ.get("PGO_BENCH_JSON_FD"))
-        if ctrl_gloo:
+        retry = bool(os.environ.get("PGO_BENCH_JSON_FD"))
+        ctrl_gloo = one_gpu or retry
+        if retry:
+            # a re-executed rank: a rendezvous of its own, apart from the keys the first attempt left in the store — through the launcher's
+            # store where there is one (torch.distributed.run hosts it in the agent: it outlives the workers' exec), else a store rank 0
+            # hosts on the next port (a rank that re-executes before rank 0 must not register with the old one)
+            from datetime import timedelta
+            agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "False") == "True"
+            port = int(os.environ["MASTER_PORT"]) + (0 if agent_store else 1)
+            store = dist.TCPStore(os.environ["MASTER_ADDR"], port, world, is_master=(not agent_store and rank == 0), timeout=timedelta(seconds=120))
+            dist.init_process_group(backend="gloo", store=dist.PrefixStore("pgo_bench_retry", store), rank=rank, world_size=world)
+        elif ctrl_gloo:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -202,12 +215,11 @@ def main():
             sys.stderr.flush()
             os.set_inheritable(json_fd, True)
             env = dict(os.environ, PGO_BENCH_TRANSPORT="ipc", PGO_BENCH_JSON_FD=str(json_fd), PGO_BENCH_REPLICA_EL=repr(el_r),
-                       PGO_BENCH_ATTEMPTS=";".join(attempts + ["%s: %s" % (transport, reason)]),
-                       MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29531")) + 1))     # (a new store: a rank that re-executes before rank 0 must not register with the old one)
+                       PGO_BENCH_ATTEMPTS=";".join(attempts + ["%s: %s" % (transport, reason)]))
             os.execve(sys.executable, [sys.executable] + sys.argv, env)
 
         def give_up(reason="timed out"):
-            if transport == "rccl" and not one_gpu and os.environ.get("PGO_BENCH_NO_IPC_RETRY", "0") != "1":
+            if transport == "rccl" and (not one_gpu or simulate_failure) and os.environ.get("PGO_BENCH_NO_IPC_RETRY", "0") != "1":
                 retry_over_ipc(reason)
             if rank == 0:
                 out = record(gr.E * world * args.steps / el_r, el_r,
@@ -254,6 +266,8 @@ def main():
         try:
             def sharded_run(graph):
                 pr, _ = pkg.problem_from_graph(graph)
+                if simulate_failure:
+                    raise RuntimeError("simulated failure of the first transport (PGO_BENCH_SIMULATE_TRANSPORT_FAILURE=1)")
                 if transport == "ipc":
                     sharded_run.n = getattr(sharded_run, "n", 0) + 1
                     # (the name carries a token rank 0 draws for THIS group and broadcasts over the control plane: a block left
@@ -595,6 +609,18 @@ def main():
                 "lm_iterations": s_pc.num_iterations, "cg_iterations": s_pc.num_linear_solver_iterations, "wall_seconds": round(w_pc, 4),
                 "seconds_to_target": _time_to(s_pc, target),
                 "max_translation_distance_to_exact_solution_m": round(float(np.linalg.norm(p_pc[:, :3] - p_ex[:, :3], axis=1).max()), 3)}
+        # r06: the same forcing term eta = 0.1 with a COARSE LEVEL under the cluster Jacobi (options.pcg_coarse_aggregate; csrc/pgo_coarse.hip)
+        q["pcg_with_coarse_level"] = {}
+        for agg in (64, 128):
+            s_cz, p_cz, w_cz = _whole(max_num_iterations=3000, linear_solver_type=pkg.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, eta=0.1,
+                                      max_linear_solver_iterations=3000, pcg_coarse_aggregate=agg)
+            q["pcg_with_coarse_level"]["eta_0.1_aggregates_of_%d" % agg] = {
+                "final_cost_at_own_stop": s_cz.final_cost, "relative_to_exact": round(s_cz.final_cost / s_ex.final_cost - 1.0, 6),
+                "lm_iterations": s_cz.num_iterations, "cg_iterations": s_cz.num_linear_solver_iterations, "wall_seconds": round(w_cz, 4),
+                "seconds_to_target": _time_to(s_cz, target), "coarse_unknowns": 6 * s_cz.coarse_level,
+                "max_translation_distance_to_exact_solution_m": round(float(np.linalg.norm(p_cz[:, :3] - p_ex[:, :3], axis=1).max()), 3)}
+        q["pcg_with_coarse_level"]["what"] = ("M^-1 = M_J^-1 + P (P'AP)^-1 P': 2-pose cluster Jacobi + aggregates of consecutive poses with six rigid-body modes each; "
+                                              "a NEGATIVE relative_to_exact is a cost BELOW the one the exact steps end at (another, better basin of this graph)")
         q["note"] = ("eta = 0.1 is Ceres' default and what the headline steps use; the exact path's own final cost moves by 3e-3 between "
                      "the GPU and the oracle on this graph (tests/test_gpu_front.py), so distances between equal-cost solutions are not errors")
         extra["c2_solution_quality"] = q

@@ -470,7 +470,10 @@ inline void Solver::Solve(const Options& options, Problem* problem, Summary* sum
   o.min_lm_diagonal = options.min_lm_diagonal;
   o.max_lm_diagonal = options.max_lm_diagonal;
   o.eta = options.eta;
-  o.pcg_cluster_poses = (options.preconditioner_type == CLUSTER_JACOBI || options.preconditioner_type == CLUSTER_TRIDIAGONAL) ? 4 : 1;
+  o.pcg_cluster_poses = options.preconditioner_type == CLUSTER_JACOBI ? 4 : options.preconditioner_type == CLUSTER_TRIDIAGONAL ? 2 : 1;
+  // CLUSTER_TRIDIAGONAL, the strongest preconditioner a Ceres caller can name: the library's strongest — 2-pose cluster Jacobi plus the
+  // aggregation coarse level (include/pgo.h pcg_coarse_aggregate; one rank)
+  if (o.linear_solver_type == PGO_BLOCK_JACOBI_PCG && options.preconditioner_type == CLUSTER_TRIDIAGONAL) o.pcg_coarse_aggregate = 64;
 
   std::vector<pgo_iteration_record> rec((size_t)options.max_num_iterations + 2 < 100000 ? options.max_num_iterations + 2 : 100000);
   if (pgo_solve(P, &o, &summary->raw, &rec[0], (int)rec.size()) < 0) return internal::Fail(summary, pgo_last_error());
