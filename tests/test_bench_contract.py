@@ -21,7 +21,13 @@ def test_committed_bench_line_has_the_contract_fields():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # (r06, VERDICT r05: at this size the one-launch streams are latency-bound — a CG turn is a chain of fabric round trips — and the line says so;
+    # the roofline the kernel's arithmetic intensity puts it under stays named beside it, and the PHYSICAL fraction of the peak next to the equivalent one)
+    assert r["bound"] in ("hbm", "latency") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    if r["bound"] == "latency":
+        assert r["bound_by_arithmetic_intensity"] == "hbm" and 0 < r["frac_physical"] < r["frac"]
+    assert "us_per_cg_turn" in d and "fixed_us_per_lm_iteration" in d
+    assert abs(d["fixed_us_per_lm_iteration"] + d["us_per_cg_turn"] * d["cg_iterations_per_step"] - 1e3 * d["ms_per_step"]) < 0.2
     if "k_res_cg" in r["kernel"]:       # the resident CG holds the matrix in registers: a launch of ~15 iterations moves LESS than their algorithmic bytes
         assert r["traffic"] is None or 0 < r["traffic"] < r["algorithmic_bytes_per_launch"]
     else:
