@@ -53,6 +53,12 @@ void resident_slot_release(pgo_problem* P) {
 }
 int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   P->want_direct = options->linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY;
+  {   // a session with a coarse level runs the one-launch CG iteration on the incidence slots, which wants whole pose pairs in a work-group:
+      // work-groups of 256 slots (a topology built otherwise is rebuilt)
+    const bool want_coarse = options->linear_solver_type == PGO_BLOCK_JACOBI_PCG && options->pcg_coarse_aggregate >= 8 && !P->comm;
+    const int fb = want_coarse && !getenv("PGO_BLOCK") ? 256 : 0;
+    if (fb != P->force_block) { P->force_block = fb; P->topo_dirty = true; }
+  }
   int rc = prepare(P);
   P->want_direct = false;
   if (rc) return rc;
@@ -106,6 +112,10 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
     HIP_TRY(P->dc_rc.alloc((size_t)c.npad));
     HIP_TRY(P->dc_rc.zero(P->stream));
     c.Pt = P->dc_Pt.p; c.Ac = P->dc_Ac.p; c.piv = P->dc_piv.p; c.row = P->dc_row.p; c.rc = P->dc_rc.p;
+    if (!P->g.pairs_whole) {        // (never silently the block Jacobi alone: the correction is applied between the launches of k_pipe_cg, which needs whole pairs)
+      P->coarse_on = false;
+      return set_error(PGO_ERR_UNSUPPORTED, "pcg_coarse_aggregate: a pose pair of this graph has more than 256 incidence slots — the one-launch CG iteration the coarse level rides on cannot hold it in one work-group");
+    }
   }
   if (P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY) {
     const auto t_sym = Clock::now();

@@ -187,7 +187,7 @@ int prepare(pgo_problem* P) {
   long long total = 0;
   for (int v = 0; v < N; ++v) total += 1 + deg[v];
   const int NP = world * rows_per;   // padded pose count of every replicated / exchanged array
-  const int B = choose_block(total / world);
+  const int B = P->force_block ? P->force_block : choose_block(total / world);
 
   // rows -> workgroups (greedy packing of `block` slots; a row with more incidences gets its own multi-chunk group)
   std::vector<int> wg_row_begin, wg_slot_begin, row_slot_begin(N, 0), row_slot_cnt(N, 0);
