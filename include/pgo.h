@@ -96,8 +96,10 @@ typedef struct pgo_solver_options {
                                              each, Galerkin coarse matrix inverted once per LM iteration, M^-1 = M_J^-1 + P (P'AP)^-1 P'.  It
                                              carries the long-wavelength correction a block Jacobi misses from dead reckoning: BASELINE
                                              configs[1] with eta = 0.1 ends 5.6 % BELOW the exact path's cost instead of 11 % above it, at the
-                                             same number of CG iterations (32 .. 64 is the useful range).  One rank; the session then runs the
-                                             host-driven loop with the one-launch pipelined CG iteration (Summary::cg_form 2, ::coarse_level 1) */
+                                             same number of CG iterations (32 .. 64 is the useful range).  The session runs the host-driven loop
+                                             with the one-launch pipelined CG iteration (Summary::cg_form 2, ::coarse_level = aggregates).  Row
+                                             shards: aggregates never straddle ranks; the Galerkin row panels (per LM iteration) and the
+                                             restricted vector (per CG iteration, 6 doubles per aggregate) are all-gathered */
   int reserved_options;
   double function_tolerance;              /* 1e-6 */
   double gradient_tolerance;              /* 1e-10 */

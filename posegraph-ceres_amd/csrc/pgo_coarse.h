@@ -8,7 +8,9 @@
 //                      summation order) -> explicit inverse by block Gauss-Jordan (16 x 16 pivot blocks, two launches per block)
 //   per application:   k_coarse_restrict (rc = P~' w, one work-group per aggregate) -> k_coarse_correct (xc = Ainv rc for the
 //                      aggregate's six rows, out += P~ xc for its poses)
-// One rank, incidence-slot storage, the one-launch pipelined CG iteration (k_pipe_cg) with the correction between the launches.
+// Incidence-slot storage, the one-launch pipelined CG iteration (k_pipe_cg) with the correction between the launches.  Several ranks (row
+// shards): every rank forms the row panels of ITS aggregates and restricts over ITS rows; the panels (per LM iteration) and the restricted
+// vector (per application: 6 doubles per aggregate) are all-gathered, the inverse is replicated — bit-identical on every rank.
 #pragma once
 #include "pgo_kernels.h"
 
@@ -16,18 +18,27 @@ namespace pgo {
 
 struct CoarsePlan {
   int agg;          // poses per aggregate
-  int n_agg;        // aggregates
+  int n_agg;        // aggregates (several ranks: per_rank aggregates for every rank's segment of rows_per poses — aggregates never straddle ranks;
+                    // the ones behind a rank's last row are empty: identity rows of the coarse matrix)
+  int per_rank;     // aggregates per rank segment (one rank: n_agg)
+  int a_lo, a_hi;   // the aggregates of THIS rank's rows: it forms their row panels of the Galerkin matrix and their entries of a restriction
   int cdim;         // 6 * n_agg
   int npad;         // cdim rounded up to a multiple of 16: order of the stored matrix (identity on the padding)
   double* Pt;       // [N][36] P~ of every pose, row-major (row = fine component, column = mode)
   double* Ac;       // [npad][npad] Galerkin matrix, then its inverse
   double* piv;      // [16][16] inverse of the current pivot block
-  double* row;      // [16][npad] pivot row panel of the current step
+  double* row;      // [16][npad] pivot row panel of the current step | [npad][16] the old pivot column panel
   double* rc;       // [npad] restricted vector
+  const int* rank_end;   // several ranks: [world] one past the last REAL row of every rank's segment (device numbering; the rows behind it pad the segment)
 };
 
-void launch_coarse_setup(const DeviceGraph& g, const CoarsePlan& c, hipStream_t s);
-// out[6 v + r] += (P (P' A P)^-1 P' vec)[6 v + r] for every pose (out2 likewise when not null)
-void launch_coarse_apply(const DeviceGraph& g, const CoarsePlan& c, const double* vec, double* out, double* out2, hipStream_t s);
+// setup in two halves around the all-gather of the Galerkin matrix's row panels (several ranks; one rank calls them back to back)
+void launch_coarse_galerkin(const DeviceGraph& g, const CoarsePlan& c, hipStream_t s);     // P~ of every pose, the row panels of this rank's aggregates
+void launch_coarse_invert(const CoarsePlan& c, hipStream_t s);                            // identity on empty / padding rows, explicit inverse in place
+// application in two halves around the all-gather of the restricted vector:
+void launch_coarse_restrict(const DeviceGraph& g, const CoarsePlan& c, const double* vec, hipStream_t s);     // rc of this rank's aggregates = P~' vec
+// out += P~ (Ainv rc) for the poses of this rank's aggregates; out is an exchange buffer (pose v of rank k at k * out_seg + (v - k rows_per) * 6; one
+// rank: 6 v), out2 (may be null) a flat vector
+void launch_coarse_correct(const DeviceGraph& g, const CoarsePlan& c, double* out, int out_seg, double* out2, hipStream_t s);
 
 }  // namespace pgo

@@ -8,6 +8,22 @@ namespace pgo {
 
 namespace {
 
+// poses of aggregate a: one rank — [a agg, (a + 1) agg); several — the a-th aggregate of the device numbering, in which rank k's rows start
+// at k * rows_per (pgo_internal.h pose_int) and its aggregates at k * per_rank
+__device__ __forceinline__ void agg_range(const DeviceGraph& g, const CoarsePlan& c, int a, int& v0, int& v1) {
+  const int k = a / c.per_rank, l = a - k * c.per_rank;
+  const int base = g.world > 1 ? k * g.rows_per : 0;
+  // (a rank's segment ends at its last real row: the padding rows behind it have no slots and their vector entries are never written)
+  const int lim = g.world > 1 ? c.rank_end[k] : g.N;
+  v0 = min(lim, base + l * c.agg);
+  v1 = min(lim, v0 + c.agg);
+}
+__device__ __forceinline__ int agg_of(const DeviceGraph& g, const CoarsePlan& c, int v) {
+  if (g.world == 1) return v / c.agg;
+  const int k = v / g.rows_per;
+  return k * c.per_rank + (v - k * g.rows_per) / c.agg;
+}
+
 // P~ of the aggregate's poses: the aggregate's centre (mean position, fixed-order sum), then per pose the 6 x 6 block
 //   [ I   2 [e_j x d] ]      d = p - c      (column 3 + j: the rotation e_j about the centre moves the pose by 2 e_j x d)
 //   [ 0       I      ]
@@ -15,7 +31,9 @@ namespace {
 __global__ __launch_bounds__(256) void k_coarse_basis(DeviceGraph g, CoarsePlan c) {
   __shared__ double scratch[16];
   const int a = blockIdx.x, tid = threadIdx.x;
-  const int v0 = a * c.agg, v1 = min(g.N, v0 + c.agg);
+  int v0, v1;
+  agg_range(g, c, a, v0, v1);
+  if (v1 <= v0) return;
   double ctr[3] = {0.0, 0.0, 0.0};
   for (int v = v0 + tid; v < v1; v += 256) {
     const double* p = g.pose_x + (size_t)POSE_STRIDE * v;
@@ -55,10 +73,11 @@ __global__ __launch_bounds__(64) void k_coarse_galerkin(DeviceGraph g, CoarsePla
   double* panel = lds;
   double* stage = lds + (size_t)6 * c.npad;
   __shared__ int scol[64];
-  const int a = blockIdx.x, lane = threadIdx.x;
-  const int v0 = a * c.agg, v1 = min(g.N, v0 + c.agg);
+  const int a = c.a_lo + blockIdx.x, lane = threadIdx.x;
+  int v0, v1;
+  agg_range(g, c, a, v0, v1);
   for (int i = lane; i < 6 * c.npad; i += 64) panel[i] = 0.0;
-  const int t_begin = g.row_slot_begin[v0], t_end = g.row_slot_begin[v1 - 1] + g.row_slot_cnt[v1 - 1];
+  const int t_begin = v1 > v0 ? g.row_slot_begin[v0] : 0, t_end = v1 > v0 ? g.row_slot_begin[v1 - 1] + g.row_slot_cnt[v1 - 1] : 0;
   __syncthreads();
   for (int t0 = t_begin; t0 < t_end; t0 += 64) {
     const int t = t0 + lane;
@@ -105,7 +124,7 @@ __global__ __launch_bounds__(64) void k_coarse_galerkin(DeviceGraph g, CoarsePla
       for (int sidx = 0; sidx < 64; ++sidx) {
         const int cj = scol[sidx];
         if (cj < 0) continue;
-        panel[(size_t)p * c.npad + 6 * (cj / c.agg) + q] += stage[sidx * 37 + lane];
+        panel[(size_t)p * c.npad + 6 * agg_of(g, c, cj) + q] += stage[sidx * 37 + lane];
       }
     }
     __syncthreads();
@@ -113,7 +132,7 @@ __global__ __launch_bounds__(64) void k_coarse_galerkin(DeviceGraph g, CoarsePla
   for (int i = lane; i < 6 * c.npad; i += 64) {
     const int p = i / c.npad, j = i - p * c.npad;
     double v = panel[i];
-    if (j == 6 * a + p && !(v > 0.0)) v = 1.0;          // an aggregate of constant blocks only: identity row
+    if (j == 6 * a + p && !(v > 0.0)) v = 1.0;          // an aggregate of constant blocks only, or an empty one behind a rank's last row: identity row
     c.Ac[(size_t)(6 * a + p) * c.npad + j] = v;
   }
 }
@@ -159,6 +178,12 @@ __global__ __launch_bounds__(256) void k_coarse_gj_pivot(CoarsePlan c, int k) {
       for (int m = 0; m < GJ; ++m) acc += W[ii][m] * av[m];
       c.row[(size_t)ii * n + col] = acc;
     }
+    // the OLD column panel A_:K of this work-group's 256 rows, for the update kernel: there the work-group that holds block K of a strip
+    // rewrites A_iK while the strip's other work-groups still want the old one — they read this copy instead
+    const double2* src = reinterpret_cast<const double2*>(c.Ac + (size_t)col * n + K0);
+    double2* dstp = reinterpret_cast<double2*>(c.row + (size_t)GJ * n + (size_t)col * GJ);
+#pragma unroll
+    for (int m = 0; m < GJ / 2; ++m) dstp[m] = src[m];
   }
 }
 // grid (strips of 16 rows, chunks of 256 columns): the chunk's piece of the pivot row panel is staged in LDS once per work-group
@@ -167,7 +192,7 @@ __global__ __launch_bounds__(256) void k_coarse_gj_update(CoarsePlan c, int k) {
   const int tid = threadIdx.x, ii = tid / GJ, jj = tid % GJ, n = c.npad, K0 = GJ * k, I0 = GJ * blockIdx.x, J0 = 256 * blockIdx.y;
   const int ncol = min(256, n - J0);
   W[ii][jj] = c.piv[ii * GJ + jj];
-  Cb[ii][jj] = c.Ac[(size_t)(I0 + ii) * n + K0 + jj];      // the OLD A_iK of this strip (only the chunk that holds block K rewrites it, at the very end)
+  Cb[ii][jj] = c.row[(size_t)GJ * n + (size_t)(I0 + ii) * GJ + jj];      // the OLD A_iK of this strip (k_coarse_gj_pivot's copy: the chunk that holds block K rewrites the matrix's)
 #pragma unroll
   for (int m = 0; m < GJ; ++m) if (tid < ncol) Rs[m][tid] = c.row[(size_t)m * n + J0 + tid];
   __syncthreads();
@@ -193,8 +218,9 @@ __global__ __launch_bounds__(256) void k_coarse_gj_update(CoarsePlan c, int k) {
 // rc = P~' vec over the aggregate's poses (lane = pose, block sum in fixed order)
 __global__ __launch_bounds__(256) void k_coarse_restrict(DeviceGraph g, CoarsePlan c, const double* vec) {
   __shared__ double scratch[32];
-  const int a = blockIdx.x, tid = threadIdx.x;
-  const int v0 = a * c.agg, v1 = min(g.N, v0 + c.agg);
+  const int a = c.a_lo + blockIdx.x, tid = threadIdx.x;
+  int v0, v1;
+  agg_range(g, c, a, v0, v1);
   double acc[6] = {0, 0, 0, 0, 0, 0};
   for (int v = v0 + tid; v < v1; v += 256) {
     const double* pv = c.Pt + (size_t)36 * v;
@@ -210,10 +236,10 @@ __global__ __launch_bounds__(256) void k_coarse_restrict(DeviceGraph g, CoarsePl
   if (tid < 6) c.rc[6 * a + tid] = acc[tid];
 }
 // xc = (Ainv rc) for the aggregate's six rows, then out += P~ xc for its poses
-__global__ __launch_bounds__(256) void k_coarse_correct(DeviceGraph g, CoarsePlan c, double* out, double* out2) {
+__global__ __launch_bounds__(256) void k_coarse_correct(DeviceGraph g, CoarsePlan c, double* out, int out_seg, double* out2) {
   __shared__ double scratch[32];
   __shared__ double xc[6];
-  const int a = blockIdx.x, tid = threadIdx.x;
+  const int a = c.a_lo + blockIdx.x, tid = threadIdx.x;
   double acc[6] = {0, 0, 0, 0, 0, 0};
   for (int j = tid; j < c.cdim; j += 256) {
     const double r = c.rc[j];
@@ -223,15 +249,18 @@ __global__ __launch_bounds__(256) void k_coarse_correct(DeviceGraph g, CoarsePla
   block_sum<6>(acc, scratch);
   if (tid < 6) xc[tid] = acc[tid];
   __syncthreads();
-  const int v0 = a * c.agg, v1 = min(g.N, v0 + c.agg);
+  int v0, v1;
+  agg_range(g, c, a, v0, v1);
   for (int v = v0 + tid; v < v1; v += 256) {
     const double* pv = c.Pt + (size_t)36 * v;
+    const int k = g.world > 1 ? v / g.rows_per : 0;
+    double* o = out + (g.world > 1 ? (size_t)k * out_seg + (size_t)(v - k * g.rows_per) * 6 : 6 * (size_t)v);
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       double s = 0.0;
 #pragma unroll
       for (int q = 0; q < 6; ++q) s += pv[6 * r + q] * xc[q];
-      out[6 * (size_t)v + r] += s;
+      o[r] += s;
       if (out2) out2[6 * (size_t)v + r] += s;
     }
   }
@@ -239,22 +268,25 @@ __global__ __launch_bounds__(256) void k_coarse_correct(DeviceGraph g, CoarsePla
 
 }  // namespace
 
-void launch_coarse_setup(const DeviceGraph& g, const CoarsePlan& c, hipStream_t s) {
+void launch_coarse_galerkin(const DeviceGraph& g, const CoarsePlan& c, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_coarse_galerkin), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
   hipLaunchKernelGGL(k_coarse_basis, dim3(c.n_agg), dim3(256), 0, s, g, c);
   const size_t lds = ((size_t)6 * c.npad + 64 * 37) * sizeof(double);
-  hipLaunchKernelGGL(k_coarse_galerkin, dim3(c.n_agg), dim3(64), lds, s, g, c);
+  if (c.a_hi > c.a_lo) hipLaunchKernelGGL(k_coarse_galerkin, dim3(c.a_hi - c.a_lo), dim3(64), lds, s, g, c);
+}
+void launch_coarse_invert(const CoarsePlan& c, hipStream_t s) {
   if (c.npad > c.cdim) hipLaunchKernelGGL(k_coarse_pad, dim3(c.npad - c.cdim, (c.npad + 255) / 256), dim3(256), 0, s, c);
   for (int k = 0; k < c.npad / GJ; ++k) {
     hipLaunchKernelGGL(k_coarse_gj_pivot, dim3((c.npad + 255) / 256), dim3(256), 0, s, c, k);
     hipLaunchKernelGGL(k_coarse_gj_update, dim3(c.npad / GJ, (c.npad + 255) / 256), dim3(256), 0, s, c, k);
   }
 }
-
-void launch_coarse_apply(const DeviceGraph& g, const CoarsePlan& c, const double* vec, double* out, double* out2, hipStream_t s) {
-  hipLaunchKernelGGL(k_coarse_restrict, dim3(c.n_agg), dim3(256), 0, s, g, c, vec);
-  hipLaunchKernelGGL(k_coarse_correct, dim3(c.n_agg), dim3(256), 0, s, g, c, out, out2);
+void launch_coarse_restrict(const DeviceGraph& g, const CoarsePlan& c, const double* vec, hipStream_t s) {
+  if (c.a_hi > c.a_lo) hipLaunchKernelGGL(k_coarse_restrict, dim3(c.a_hi - c.a_lo), dim3(256), 0, s, g, c, vec);
+}
+void launch_coarse_correct(const DeviceGraph& g, const CoarsePlan& c, double* out, int out_seg, double* out2, hipStream_t s) {
+  if (c.a_hi > c.a_lo) hipLaunchKernelGGL(k_coarse_correct, dim3(c.a_hi - c.a_lo), dim3(256), 0, s, g, c, out, out_seg, out2);
 }
 
 }  // namespace pgo

@@ -476,6 +476,7 @@ struct pgo_problem {
   bool coarse_on = false;
   int force_block = 0;             // slots per work-group the topology has to be built with (0: choose_block's rule); a session with a coarse level asks for 256: whole pose pairs per work-group
   DevBuf<double> dc_Pt, dc_Ac, dc_piv, dc_row, dc_rc;
+  DevBuf<int> dc_rank_end;
 
   // one process per GPU: the communicator of the row-sharded path (null = single rank)
   pgo::Comm* comm = nullptr;
@@ -544,6 +545,8 @@ bool pipe_mode(const pgo_problem* P, const pgo::CgParams& prm);
 int pcg_begin(pgo_problem* P, const pgo::CgParams& prm);
 int run_pcg(pgo_problem* P, const pgo::CgParams& prm, int batch, int* iterations, int* status);
 int prepare_clusters(pgo_problem* P, int CL);
+int coarse_setup(pgo_problem* P);                 // coarse level of the PCG (pgo_coarse.h): per LM iteration, behind the damping
+int coarse_apply(pgo_problem* P, const double* vec, double* out, double* out2);
 long long front_memory_budget();
 void analyze_front(pgo_problem* P, int N, int n_slots, long long budget, bool* ok, int small_max = 0);
 int upload_front(pgo_problem* P);

@@ -30,21 +30,40 @@ bool pipe_mode(const pgo_problem* P, const pgo::CgParams& prm) {
   const bool off = e && e[0] == '0';
   if (off || P->use_graph || P->force_standard_cg) return false;
   if (P->g.world > 1) return pgo::pipe_supported(P->g, prm, P->g.cluster);
+  // a session with a coarse level (pgo_coarse.h): incidence-slot storage, k_pipe_cg with the correction between its launches
+  if (P->coarse_on) return (P->g.cluster == 1 || P->g.cluster == 2) && prm.q_tolerance >= 0.0 && prm.r_tolerance < 0.0 && P->g.pipe_buf[0] != nullptr && P->g.pairs_whole;
   // One rank (r06): a session that keeps the normal equations in the symmetric tile form — the graphs above the universal stream's size
   // limit — runs the same one-launch CG iteration on it (k_pipe_cg_sym) where the library would take the pipelined recurrences anyway
   // (truncated CG with a forcing term >= 0.01, or pcg_form 2); pcg_form 1 and tighter forcing terms keep Ceres' refreshed CG (k_spmv_sym<0> + k_pcg_update)
   // ... and a session with a coarse level (pgo_coarse.h): incidence-slot storage, k_pipe_cg with the correction between its launches
-  if (P->coarse_on) return (P->g.cluster == 1 || P->g.cluster == 2) && prm.q_tolerance >= 0.0 && prm.r_tolerance < 0.0 && P->g.pipe_buf[0] != nullptr && P->g.pairs_whole;
   const bool asked = P->opt.pcg_form == 2 || (P->opt.pcg_form == 0 && P->opt.eta >= 1e-2);
   return P->sym_storage && asked && !P->universal && !P->pipelined && (P->g.cluster == 1 || P->g.cluster == 2) && prm.q_tolerance >= 0.0 && prm.r_tolerance < 0.0 &&
          P->g.pipe_buf[0] != nullptr;
 }
+// coarse level (pgo_coarse.h): out += P (P'AP)^-1 P' vec on this rank's rows.  Several ranks: every rank restricts over ITS aggregates, the
+// restricted vector (6 doubles per aggregate) is all-gathered, every rank applies the (replicated, bit-identical) inverse to its own rows.
+int coarse_apply(pgo_problem* P, const double* vec, double* out, double* out2) {
+  const pgo::CoarsePlan& c = P->coarse;
+  pgo::launch_coarse_restrict(P->g, c, vec, P->stream);
+  if (P->g.world > 1) { int rc = exchange(P, c.rc, (size_t)6 * c.per_rank); if (rc) return rc; }
+  pgo::launch_coarse_correct(P->g, c, out, P->g.pipe_seg, out2, P->stream);
+  return PGO_OK;
+}
+// ... and its set-up for the damped system of this LM iteration: P~, the Galerkin row panels of this rank's aggregates, (all-gather,) inverse
+int coarse_setup(pgo_problem* P) {
+  const pgo::CoarsePlan& c = P->coarse;
+  pgo::launch_coarse_galerkin(P->g, c, P->stream);
+  if (P->g.world > 1) { int rc = exchange(P, c.Ac, (size_t)6 * c.per_rank * c.npad); if (rc) return rc; }
+  pgo::launch_coarse_invert(c, P->stream);
+  return PGO_OK;
+}
 // one product launch of the owner-only CG (+ its fold): from the symmetric tile form where the session keeps its blocks there
-static void pipe_cg_launch(pgo_problem* P, const pgo::CgParams& prm, int seq, unsigned long long gseq = 0, bool last_of_batch = false) {
+static int pipe_cg_launch(pgo_problem* P, const pgo::CgParams& prm, int seq, unsigned long long gseq = 0, bool last_of_batch = false) {
   if (P->sym_storage) pgo::launch_pipe_cg_sym(sym_view(P), P->sym, prm, seq, P->stream, gseq, last_of_batch);
   else pgo::launch_pipe_cg(P->g, prm, seq, 0, P->stream, gseq);
   // coarse level: the launch left m_J = M_J^-1 w of its rows in the buffer the next launch reads; add P (P'AP)^-1 P' w
-  if (P->coarse_on) pgo::launch_coarse_apply(P->g, P->coarse, P->g.cg_w, P->g.pipe_buf[(seq & 1) ^ 1], nullptr, P->stream);
+  if (P->coarse_on) return coarse_apply(P, P->g.cg_w, P->g.pipe_buf[(seq & 1) ^ 1], nullptr);
+  return PGO_OK;
 }
 
 int enqueue_tail(pgo_problem* P, const pgo::CgParams* finish_prm) {
@@ -104,9 +123,10 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool wi
     // owner-only CG: one launch and one all-gather per iteration (launch seq = iteration index + 1, pipe_begin() ran seq 0)
     for (int i = 0; i < batch; ++i) {
       const int seq = start_it + i;
-      if (P->g.peer_tab) { pipe_cg_launch(P, prm, seq, ++P->peer_gseq); continue; }
-      pipe_cg_launch(P, prm, seq, 0, i == batch - 1);
-      int rc = exchange(P, P->g.pipe_buf[(seq & 1) ^ 1], (size_t)P->g.pipe_seg);
+      if (P->g.peer_tab) { int rcp = pipe_cg_launch(P, prm, seq, ++P->peer_gseq); if (rcp) return rcp; continue; }
+      int rc = pipe_cg_launch(P, prm, seq, 0, i == batch - 1);
+      if (rc) return rc;
+      rc = exchange(P, P->g.pipe_buf[(seq & 1) ^ 1], (size_t)P->g.pipe_seg);
       if (rc) return rc;
     }
     pgo::launch_pipe_cg(P->g, prm, start_it + batch, with_tail ? 2 : 1, s);    // the stop test of the last iteration; without a tail also the hand-over
@@ -194,15 +214,15 @@ int pcg_begin(pgo_problem* P, const pgo::CgParams& prm) {
   }
   pgo::launch_pipe_init(P->g, s);
   // coarse level: u0 = M^-1 r0 gets its coarse part too (r0 = b; into the exchange buffer the first product reads and into u)
-  if (P->coarse_on) pgo::launch_coarse_apply(P->g, P->coarse, P->g.cg_r, P->g.pipe_buf[0], P->g.cg_u, s);
+  if (P->coarse_on) { int rcc = coarse_apply(P, P->g.cg_r, P->g.pipe_buf[0], P->g.cg_u); if (rcc) return rcc; }
   if (P->g.peer_tab) {       // device-initiated exchange: the kernels store into every rank's buffer and signal each other
     pgo::launch_peer_signal(P->g, ++P->peer_gseq, s);
-    pipe_cg_launch(P, prm, 0, ++P->peer_gseq);
-    return PGO_OK;
+    return pipe_cg_launch(P, prm, 0, ++P->peer_gseq);
   }
   int rc = exchange(P, P->g.pipe_buf[0], (size_t)P->g.pipe_seg);
   if (rc) return rc;
-  pipe_cg_launch(P, prm, 0);
+  rc = pipe_cg_launch(P, prm, 0);
+  if (rc) return rc;
   return exchange(P, P->g.pipe_buf[1], (size_t)P->g.pipe_seg);
 }
 

@@ -55,7 +55,7 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   P->want_direct = options->linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY;
   {   // a session with a coarse level runs the one-launch CG iteration on the incidence slots, which wants whole pose pairs in a work-group:
       // work-groups of 256 slots (a topology built otherwise is rebuilt)
-    const bool want_coarse = options->linear_solver_type == PGO_BLOCK_JACOBI_PCG && options->pcg_coarse_aggregate >= 8 && !P->comm;
+    const bool want_coarse = options->linear_solver_type == PGO_BLOCK_JACOBI_PCG && options->pcg_coarse_aggregate >= 8;
     const int fb = want_coarse && !getenv("PGO_BLOCK") ? 256 : 0;
     if (fb != P->force_block) { P->force_block = fb; P->topo_dirty = true; }
   }
@@ -93,14 +93,18 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
   pgo::launch_finalize_scalars(P->g, P->g.n_edge_wg, P->stream);
   int cluster = P->opt.pcg_cluster_poses;
   // coarse level of the PCG (pgo_coarse.h): one rank, truncated PCG; on top of the 2-pose cluster Jacobi
-  P->coarse_on = P->opt.linear_solver_type == PGO_BLOCK_JACOBI_PCG && P->opt.pcg_coarse_aggregate >= 8 && P->g.world == 1 && !(P->comm && P->comm->world > 1);
+  P->coarse_on = P->opt.linear_solver_type == PGO_BLOCK_JACOBI_PCG && P->opt.pcg_coarse_aggregate >= 8;
   if (P->opt.pcg_coarse_aggregate != 0 && !P->coarse_on)
-    return set_error(PGO_ERR_UNSUPPORTED, "pcg_coarse_aggregate = %d: the coarse level needs BLOCK_JACOBI_PCG on one rank and aggregates of at least 8 poses", P->opt.pcg_coarse_aggregate);
+    return set_error(PGO_ERR_UNSUPPORTED, "pcg_coarse_aggregate = %d: the coarse level needs BLOCK_JACOBI_PCG and aggregates of at least 8 poses", P->opt.pcg_coarse_aggregate);
   if (P->coarse_on) {
     cluster = 2;
     pgo::CoarsePlan& c = P->coarse;
     c.agg = P->opt.pcg_coarse_aggregate;
-    c.n_agg = (P->g.N + c.agg - 1) / c.agg;
+    // several ranks: aggregates never straddle ranks — every rank's segment of rows_per poses gets the same number of aggregate slots
+    c.per_rank = ((P->g.world > 1 ? P->g.rows_per : P->g.N) + c.agg - 1) / c.agg;
+    c.n_agg = P->g.world * c.per_rank;
+    c.a_lo = P->g.rank * c.per_rank; c.a_hi = c.a_lo + c.per_rank;
+    if (P->g.peer_tab) { P->g.peer_tab = nullptr; P->g.peer_flags = nullptr; P->peer_dirty = true; }     // (the correction sits between a CG launch and its exchange: host-enqueued exchange)
     c.cdim = 6 * c.n_agg;
     c.npad = (c.cdim + 15) / 16 * 16;
     if ((size_t)(6 * c.npad + 64 * 37) * sizeof(double) > 160 * 1024 - 2048)
@@ -108,10 +112,17 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
     HIP_TRY(P->dc_Pt.alloc((size_t)36 * P->g.N));
     HIP_TRY(P->dc_Ac.alloc((size_t)c.npad * c.npad));
     HIP_TRY(P->dc_piv.alloc(256));
-    HIP_TRY(P->dc_row.alloc((size_t)16 * c.npad));
+    HIP_TRY(P->dc_row.alloc((size_t)32 * c.npad));
     HIP_TRY(P->dc_rc.alloc((size_t)c.npad));
     HIP_TRY(P->dc_rc.zero(P->stream));
     c.Pt = P->dc_Pt.p; c.Ac = P->dc_Ac.p; c.piv = P->dc_piv.p; c.row = P->dc_row.p; c.rc = P->dc_rc.p;
+    c.rank_end = nullptr;
+    if (P->g.world > 1) {
+      std::vector<int> re((size_t)P->g.world);
+      for (int k = 0; k < P->g.world; ++k) re[(size_t)k] = k * P->g.rows_per + (int)(P->shard_cut[(size_t)k + 1] - P->shard_cut[(size_t)k]);
+      HIP_TRY(P->dc_rank_end.upload(re, P->stream));
+      c.rank_end = P->dc_rank_end.p;
+    }
     if (!P->g.pairs_whole) {        // (never silently the block Jacobi alone: the correction is applied between the launches of k_pipe_cg, which needs whole pairs)
       P->coarse_on = false;
       return set_error(PGO_ERR_UNSUPPORTED, "pcg_coarse_aggregate: a pose pair of this graph has more than 256 incidence slots — the one-launch CG iteration the coarse level rides on cannot hold it in one work-group");
@@ -351,7 +362,7 @@ int lm_advance(pgo_problem* P) {
   int rc = damping_all(P, L.radius, o.min_lm_diagonal, o.max_lm_diagonal, L.reuse_diagonal ? 1 : 0);
   if (rc) return rc;
   // coarse level: P~ at the current point, the Galerkin matrix of the damped system, its inverse (pgo_coarse.h)
-  if (P->coarse_on) pgo::launch_coarse_setup(P->g, P->coarse, s);
+  if (P->coarse_on) { rc = coarse_setup(P); if (rc) return rc; }
   const bool direct = o.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY && P->direct_usable;
   // Both available (hybrid): PCG gets the budget of ~1.5 factorisations, in CG iterations priced by the same deterministic
   // cost model that admitted the factorisation (0.7 us per schedule step; 10 us + 42 ps per slot per CG iteration), so the

@@ -61,3 +61,67 @@ def test_coarse_level_is_refused_where_it_cannot_run(gpu, ds):
         gpu.solve(gpu.SolverOptions(max_num_iterations=3, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY, pcg_coarse_aggregate=32), prob)
     with pytest.raises(gpu.PgoError):
         gpu.solve(gpu.SolverOptions(max_num_iterations=3, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_coarse_aggregate=4), prob)
+
+
+def _virtual_ranks(gpu, g, world, opt_kw):
+    import threading
+    group = gpu.loopback_create(world)
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            prob, poses = gpu.problem_from_graph(g)
+            prob.comm_init_loopback(group, rank)
+            out[rank] = (gpu.solve(gpu.SolverOptions(**opt_kw), prob), poses)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(240)
+    assert not errs, errs
+    assert all(o is not None for o in out), "a virtual rank did not finish"
+    gpu.loopback_destroy(group)
+    return out
+
+
+@pytest.mark.parametrize("world,direct", [(2, False), (3, True), (8, False)])
+def test_coarse_level_on_row_sharded_ranks(gpu, ds, world, direct, monkeypatch):
+    """Several ranks: aggregates never straddle ranks; every rank forms the Galerkin row panels of ITS aggregates and restricts
+    over ITS rows, the panels (per LM iteration) and the restricted vector (per CG iteration, 6 doubles per aggregate) are all-gathered,
+    the inverse is replicated.  All ranks bit-identical; the truncated PCG ends at the exact path's cost with the CG work of the one-rank
+    solve (other aggregate boundaries: not the same counts).  direct: a peer table, where one was set up, is set aside for the session."""
+    if direct:
+        monkeypatch.setenv("PGO_PEER_DIRECT", "1")
+    g = ds.manhattan_se3(1200, 4800, seed=5)
+    agg = 32
+    opt = dict(max_num_iterations=400, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_coarse_aggregate=agg, eta=0.1)
+    out = _virtual_ranks(gpu, g, world, opt)
+    prob, _ = gpu.problem_from_graph(g)
+    one = gpu.solve(gpu.SolverOptions(**opt), prob)
+    prob, _ = gpu.problem_from_graph(g)
+    exact = gpu.solve(gpu.SolverOptions(max_num_iterations=400, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY), prob)
+    s0, x0 = out[0]
+    for s, x in out:
+        assert s.cg_form == 2 and s.cg_exchange == 1 and s.coarse_level >= (g.N + agg - 1) // agg
+        assert np.array_equal(x, x0) and np.array_equal(s.iterations["cost"], s0.iterations["cost"])
+    assert s0.final_cost == pytest.approx(exact.final_cost, rel=1e-4)
+    assert s0.num_linear_solver_iterations <= 1.5 * one.num_linear_solver_iterations + 50
+
+
+def test_coarse_level_on_ranks_at_a_size_where_launches_overlap(gpu, ds):
+    """20 000 poses on 4 virtual ranks: a coarse matrix of 2 184 unknowns inverted by every rank while the others' kernels share the device.
+    (r06: the block Gauss-Jordan update read the old pivot column panel from the matrix another work-group of the same strip rewrites — it
+    went unnoticed while a launch had the device to itself; the panel is copied by the pivot kernel now.)"""
+    g = ds.manhattan_se3(20000, 100000, seed=5)
+    opt = dict(max_num_iterations=12, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_coarse_aggregate=64, eta=0.1)
+    out = _virtual_ranks(gpu, g, 4, opt)
+    prob, _ = gpu.problem_from_graph(g)
+    one = gpu.solve(gpu.SolverOptions(**opt), prob)
+    s0, x0 = out[0]
+    for s, x in out:
+        assert np.array_equal(x, x0) and np.array_equal(s.iterations["cost"], s0.iterations["cost"])
+    assert s0.final_cost == pytest.approx(one.final_cost, rel=2e-2)
+    assert abs(s0.num_linear_solver_iterations - one.num_linear_solver_iterations) <= 0.25 * one.num_linear_solver_iterations
