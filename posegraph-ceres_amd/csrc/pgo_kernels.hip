@@ -2581,6 +2581,11 @@ __global__ void k_copy_delta(DeviceGraph g, const double* step) {
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// Two translation units are built from this text (csrc/Makefile): pgo_kernels.o — everything but the resident stream, compiled without
+// MachineLICM — and pgo_res_kernels.o (PGO_TU_RESIDENT) — the resident stream's two kernels and their launcher, with it: k_res_cg spins
+// through its CG turns inside one loop, where the hoisted literals are worth 0.17 us per turn (0.1884 -> 0.1865 ms per LM iteration at
+// BASELINE configs[1]); everywhere else they only cost registers.
+#ifndef PGO_TU_RESIDENT
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 bool lean_bsr_fits(const DeviceGraph& g) {
@@ -2759,34 +2764,6 @@ bool uni_f_supported(const DeviceGraph& g, const CgParams& p, int cluster) {
          (cluster == 1 || cluster == 2) &&
          p.q_tolerance >= 0.0 && p.r_tolerance < 0.0;
 }
-// The resident stream needs what the fused one needs, every row lane in one pass (rows_fit) and a grid that is resident at once at two
-// waves per SIMD (the grid barrier of k_res_cg): 8 waves per CU, 256 CUs.
-bool uni_r_supported(const DeviceGraph& g, const CgParams& p, int cluster) {
-  // (k_res_cg runs two waves per SIMD — __launch_bounds__(256, 2), 214 registers — i.e. eight waves per compute unit, 27 KB of LDS per work-group)
-  return uni_f_supported(g, p, cluster) && g.rows_fit && g.block >= 64 && g.n_cu > 0 && (long long)g.n_wg * (g.block / 64) <= 8LL * g.n_cu;
-}
-int uni_r_abort_word() { return RES_ABORT; }
-void launch_uni_r(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s) {
-  // r06: a cycle of TWO — [LIN (behind an accepted step) + HEAD, every work-group on its own rows] | [the whole CG + the step tail + the
-  // decision] — where r05 ran four launches per LM iteration (HEAD | CG | TAIL | LIN)
-  const int role = launch & 1;
-  const dim3 grid(g.n_wg), blk(g.block);
-  if (role == 0) {
-    const bool lean = g.info_mode != 1;      // (information without position / rotation coupling: packed slots, the lean algebra)
-    const size_t lds = std::max((size_t)g.block, lean ? (size_t)LEAN_NV * (g.block / 2) : (size_t)NV_LIN * g.block) * sizeof(double);
-#define PGO_RES_LH(INF, LN) do { if (g.cluster == 2) hipLaunchKernelGGL((k_res_lh<INF, 2, LN>), grid, blk, lds, s, g, launch, min_diag, max_diag); \
-                                 else hipLaunchKernelGGL((k_res_lh<INF, 1, LN>), grid, blk, lds, s, g, launch, min_diag, max_diag); } while (0)
-    if (g.info_mode == 3) PGO_RES_LH(3, true); else if (g.info_mode == 2) PGO_RES_LH(2, true); else if (g.info_mode == 1) PGO_RES_LH(1, false); else PGO_RES_LH(0, true);
-#undef PGO_RES_LH
-  } else {
-    const size_t lds = ((size_t)(SPMV_LDS_STRIDE + 6) * g.block + 8) * sizeof(double);
-#define PGO_RES_CG(PK, INF) do { if (g.cluster == 2) hipLaunchKernelGGL((k_res_cg<PK, 2, INF>), grid, blk, lds, s, g, p, launch); \
-                                 else hipLaunchKernelGGL((k_res_cg<PK, 1, INF>), grid, blk, lds, s, g, p, launch); } while (0)
-    // (packed 27-entry slots <=> information without position / rotation coupling: INFO 0, 2, 3)
-    if (g.info_mode == 3) PGO_RES_CG(true, 3); else if (g.info_mode == 2) PGO_RES_CG(true, 2); else if (g.info_mode == 1) PGO_RES_CG(false, 1); else PGO_RES_CG(true, 0);
-#undef PGO_RES_CG
-  }
-}
 void launch_uni_f(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s) {
   const size_t lds = (size_t)NV_LIN * g.block * sizeof(double);
 #define PGO_UNI_F2(PK, INF, CLV) hipLaunchKernelGGL((k_uni_f<PK, INF, CLV>), dim3(g.n_wg), dim3(g.block), lds, s, g, p, launch, min_diag, max_diag)
@@ -2828,5 +2805,35 @@ int vec_block() { return VEC_BLOCK; }
 int pose_block() { return POSE_BLOCK; }
 int edge_block() { return EDGE_BLOCK; }
 int max_edge_wg() { return 1024; }
+#else   // PGO_TU_RESIDENT
+// The resident stream needs what the fused one needs, every row lane in one pass (rows_fit) and a grid that is resident at once at two
+// waves per SIMD (the grid barrier of k_res_cg): 8 waves per CU, 256 CUs.
+bool uni_r_supported(const DeviceGraph& g, const CgParams& p, int cluster) {
+  // (k_res_cg runs two waves per SIMD — __launch_bounds__(256, 2), 214 registers — i.e. eight waves per compute unit, 27 KB of LDS per work-group)
+  return uni_f_supported(g, p, cluster) && g.rows_fit && g.block >= 64 && g.n_cu > 0 && (long long)g.n_wg * (g.block / 64) <= 8LL * g.n_cu;
+}
+int uni_r_abort_word() { return RES_ABORT; }
+void launch_uni_r(const DeviceGraph& g, const CgParams& p, int launch, double min_diag, double max_diag, hipStream_t s) {
+  // r06: a cycle of TWO — [LIN (behind an accepted step) + HEAD, every work-group on its own rows] | [the whole CG + the step tail + the
+  // decision] — where r05 ran four launches per LM iteration (HEAD | CG | TAIL | LIN)
+  const int role = launch & 1;
+  const dim3 grid(g.n_wg), blk(g.block);
+  if (role == 0) {
+    const bool lean = g.info_mode != 1;      // (information without position / rotation coupling: packed slots, the lean algebra)
+    const size_t lds = std::max((size_t)g.block, lean ? (size_t)LEAN_NV * (g.block / 2) : (size_t)NV_LIN * g.block) * sizeof(double);
+#define PGO_RES_LH(INF, LN) do { if (g.cluster == 2) hipLaunchKernelGGL((k_res_lh<INF, 2, LN>), grid, blk, lds, s, g, launch, min_diag, max_diag); \
+                                 else hipLaunchKernelGGL((k_res_lh<INF, 1, LN>), grid, blk, lds, s, g, launch, min_diag, max_diag); } while (0)
+    if (g.info_mode == 3) PGO_RES_LH(3, true); else if (g.info_mode == 2) PGO_RES_LH(2, true); else if (g.info_mode == 1) PGO_RES_LH(1, false); else PGO_RES_LH(0, true);
+#undef PGO_RES_LH
+  } else {
+    const size_t lds = ((size_t)(SPMV_LDS_STRIDE + 6) * g.block + 8) * sizeof(double);
+#define PGO_RES_CG(PK, INF) do { if (g.cluster == 2) hipLaunchKernelGGL((k_res_cg<PK, 2, INF>), grid, blk, lds, s, g, p, launch); \
+                                 else hipLaunchKernelGGL((k_res_cg<PK, 1, INF>), grid, blk, lds, s, g, p, launch); } while (0)
+    // (packed 27-entry slots <=> information without position / rotation coupling: INFO 0, 2, 3)
+    if (g.info_mode == 3) PGO_RES_CG(true, 3); else if (g.info_mode == 2) PGO_RES_CG(true, 2); else if (g.info_mode == 1) PGO_RES_CG(false, 1); else PGO_RES_CG(true, 0);
+#undef PGO_RES_CG
+  }
+}
+#endif  // PGO_TU_RESIDENT
 
 }  // namespace pgo
