@@ -649,7 +649,7 @@ def main():
                                           "sym_pipe_cg", (N4 + E4) * 288 + 2 * N4 * 48 + 10 * N4 * 48 + N4 * 36 * args.cluster * 8, 96),
                                          ("k_spmv_sym<0> (CG product, every interior block read once)", "sym_spmv", (N4 + E4) * 288 + 2 * N4 * 48, 100),
                                          ("k_linearize_lean (the row kernel with the hand-reduced algebra writing the symmetric form: what the session's LM loop runs)", "sym_linearize_lean", 640 * E4 + 392 * N4, 50),
-                                         ("k_linearize_symout (the general body writing the symmetric form, PGO_SYM_LIN=rows)", "sym_linearize_rows", 640 * E4 + 392 * N4, 50),
+                                         ("k_linearize_symout (the general body writing the symmetric form, the knob sym_lin_rows)", "sym_linearize_rows", 640 * E4 + 392 * N4, 50),
                                          ("k_linearize_lean_bsr (the same algebra writing the incidence-slot blocks: sessions below 600 k slots and sharded ranks)", "linearize", 640 * E4 + 392 * N4, 50),
                                          ("k_spmv<0>", "pcg_spmv", (N4 + E4) * 288 + 2 * N4 * 48, 100)):
             t4 = p4.time_kernel(kern, reps4)

@@ -28,7 +28,7 @@ extern "C" {
  * *_reduced fields in r02).  pgo_solve / pgo_solver_end / pgo_solve_batch write sizeof(pgo_solver_summary) bytes: a caller must
  * check pgo_version() == PGO_VERSION of the header it was compiled against before handing structs over (the facade's
  * ceres::Solve does, include/ceres/solver.h). */
-#define PGO_VERSION 104
+#define PGO_VERSION 105
 
 /* The library is built with -fvisibility=hidden: these entry points are all it exports. */
 #if defined(__GNUC__)
@@ -404,6 +404,13 @@ PGO_API int pgo_row_shard_range(long long n_poses, int rank, int world, long lon
  * 4 = the equal segment every rank's rows occupy in the exchanged arrays.  Host only, no GPU needed.
  * (BASELINE configs[3] over 8 ranks: heaviest rank 1.18x the mean by row count, <= 1.01x by this rule.) */
 PGO_API int pgo_row_shard_cuts(long long n_poses, long long n_edges, const int* id_begin, const int* id_end, int world, long long* cut, int* rows_per);
+/* Development / test knobs (r06): process-wide values the library's A/B paths and plan heuristics read — what sixteen of its environment
+ * variables were (the fifteen variables that remain are listed in EXPERIMENTS.md).  value = NAN puts a knob back to its default.  Unknown
+ * name: PGO_ERR_INVALID_ARGUMENT.  pgo_tuning_describe(i, &name, &what) returns the number of knobs and, for 0 <= i < that, the i-th
+ * knob's name and one line on what it does.  Not for production callers: every knob's default is the measured choice. */
+PGO_API int pgo_tuning_set(const char* name, double value);
+PGO_API int pgo_tuning_get(const char* name, double* value, int* is_set);
+PGO_API int pgo_tuning_describe(int index, const char** name, const char** what);
 /* 128-byte RCCL unique id created on rank 0 and handed to every rank by the launcher */
 PGO_API int pgo_comm_get_unique_id(unsigned char id[128]);
 /* Attaches rank `rank` of `world` to the problem BEFORE the first solve/evaluate.  Every rank must hold the same problem

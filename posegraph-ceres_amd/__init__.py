@@ -44,7 +44,7 @@ C_ABI_SYMBOLS = [
     "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_init_ipc", "pgo_debug_comm_stress", "pgo_debug_lm_decide", "pgo_loopback_create", "pgo_loopback_destroy", "pgo_comm_init_loopback",
     "pgo_generate_candidates", "pgo_reproj_options_init", "pgo_reproj_solve_batch",
     "pgo_row_shard_range", "pgo_row_shard_cuts", "pgo_read_trajectory", "pgo_build_odometry_edges", "pgo_edge_rules_init", "pgo_build_edges",
-    "pgo_solve_batch", "pgo_release_device_memory",
+    "pgo_solve_batch", "pgo_release_device_memory", "pgo_tuning_set", "pgo_tuning_get", "pgo_tuning_describe",
 ]
 
 
@@ -340,6 +340,49 @@ def comm_unique_id():
     buf = (C.c_ubyte * 128)()
     _check(lib().pgo_comm_get_unique_id(buf))
     return bytes(buf)
+
+
+def tuning_set(name, value=None):
+    """pgo_tuning_set: a development / test knob of the library (csrc/pgo_tuning.h; until r06 these were environment variables).
+    value None puts it back to its default."""
+    _check(lib().pgo_tuning_set(name.encode(), C.c_double(float("nan") if value is None else float(value))))
+
+
+def tuning_get(name):
+    """(value or None when the knob is at its default)"""
+    v, isset = C.c_double(0.0), C.c_int(0)
+    _check(lib().pgo_tuning_get(name.encode(), C.byref(v), C.byref(isset)))
+    return v.value if isset.value else None
+
+
+def tuning_knobs():
+    """{name: one line on what the knob does}"""
+    out, i = {}, 0
+    name, what = C.c_char_p(), C.c_char_p()
+    n = lib().pgo_tuning_describe(C.c_int(0), C.byref(name), C.byref(what))
+    while i < n:
+        lib().pgo_tuning_describe(C.c_int(i), C.byref(name), C.byref(what))
+        out[name.value.decode()] = what.value.decode()
+        i += 1
+    return out
+
+
+class tuning:
+    """with gpu.tuning(sym_repack=1, sym_rows=64): ...   — knobs set for the block, back to what they were behind it"""
+
+    def __init__(self, **knobs):
+        self.new = knobs
+
+    def __enter__(self):
+        self.old = {k: tuning_get(k) for k in self.new}
+        for k, v in self.new.items():
+            tuning_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            tuning_set(k, v)
+        return False
 
 
 def loopback_create(world):

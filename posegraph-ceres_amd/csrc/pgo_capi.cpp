@@ -215,7 +215,7 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
   const std::string k = kernel;
   pgo::CgParams prm = cg_params_for(P->opt);
 #ifdef PGO_ABLATE
-  { const char* d = getenv("PGO_DEBUG"); P->g.debug = d ? atoi(d) : 0; }
+  P->g.debug = (int)pgo::tuning("debug", 0.0);
 #endif
   if (k == "evaluate") {
     HIP_TRY(P->d_tmp_a.alloc((size_t)6 * P->g.E));
@@ -510,6 +510,25 @@ int pgo_row_shard_range(long long n_poses, int rank, int world, long long* begin
 // INCIDENCE SLOTS balance — pose v weighs 1 + degree(v), the slots of its block row — at multiples of 4 (2- and 4-pose preconditioner
 // clusters never straddle two ranks).  cut[r] .. cut[r + 1] is rank r's share; rows_per = the longest share rounded up to a multiple of
 // 4 = the segment every rank's rows occupy in the exchanged arrays (the device numbers the poses of rank r from r * rows_per).
+// development / test knobs (pgo_tuning.h): what sixteen environment variables were until r06
+int pgo_tuning_set(const char* name, double value) {
+  if (!pgo::tuning_set(name, value)) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_tuning_set: no knob named '%s' (pgo_tuning_describe lists them)", name ? name : "(null)");
+  return PGO_OK;
+}
+int pgo_tuning_get(const char* name, double* value, int* is_set) {
+  if (!pgo::tuning_known(name)) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_tuning_get: no knob named '%s'", name ? name : "(null)");
+  if (is_set) *is_set = pgo::tuning_is_set(name) ? 1 : 0;
+  if (value) *value = pgo::tuning(name, std::nan(""));
+  return PGO_OK;
+}
+int pgo_tuning_describe(int index, const char** name, const char** what) {
+  int n = 0;
+  const pgo::TuningKnob* k = pgo::tuning_knobs(&n);
+  if (index < 0 || index >= n) return n;          // (the count, for the caller's loop; no error text: asking is how one learns it)
+  if (name) *name = k[index].name;
+  if (what) *what = k[index].what;
+  return n;
+}
 int pgo_row_shard_cuts(long long n_poses, long long n_edges, const int* id_begin, const int* id_end, int world, long long* cut, int* rows_per_out) {
   if (n_poses < 0 || n_edges < 0 || world <= 0 || !cut || (n_edges > 0 && (!id_begin || !id_end)))
     return set_error(PGO_ERR_INVALID_ARGUMENT, "bad argument to pgo_row_shard_cuts");

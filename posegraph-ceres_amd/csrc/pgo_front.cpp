@@ -17,17 +17,10 @@
 #include <numeric>
 
 #include "pgo_direct.h"
+#include "pgo_tuning.h"
 
 namespace pgo {
 
-namespace {
-
-double env_or(const char* name, double dflt) {
-  const char* v = getenv(name);
-  return v ? atof(v) : dflt;
-}
-
-}  // namespace
 
 bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib, int n_slots,
                    const std::vector<int>& slot_row, const std::vector<int>& slot_col,
@@ -123,9 +116,9 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
   for (int s = 0; s < ns0; ++s) if (sparent[s] >= 0) kids[sparent[s]].push_back(s);
   phase("supernodes");
   // ---- 4. relaxed amalgamation (parents have larger indices than their children) ----
-  const double zfrac = env_or("PGO_FRONT_ZFRAC", 0.25);
-  const long long small = (long long)env_or("PGO_FRONT_SMALL", 8);
-  const long long max_cols = (long long)env_or("PGO_FRONT_MAXCOLS", 1 << 30);
+  const double zfrac = tuning("front_zfrac", 0.25);
+  const long long small = (long long)tuning("front_small", 8);
+  const long long max_cols = (long long)tuning("front_maxcols", 1 << 30);
   std::vector<char> alive(ns0, 1);
   for (int p = 0; p < ns0; ++p) {
     std::vector<int> ch = kids[p], keep;
@@ -379,14 +372,14 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
   }
   phase("slot sources");
   // ---- 9b. small fronts: compact storage, one launch per level, no schedule ----
-  // pure plan: every front is small.  Mixed plan (PGO_FRONT_MIXED=<scalars>, off by default): the fronts whose whole subtree is
+  // pure plan: every front is small.  Mixed plan (knob front_mixed = <scalars>, pgo_tuning.h; off by default): the fronts whose whole subtree is
   // small (chains and leaves at the bottom of a mesh: KITTI-00 dense 447 of 562 fronts, Manhattan 10 k 730 of 1243) take the
   // small-front kernels level by level before the round schedule of the rest starts; the roots of those subtrees hand their
   // update matrices over in the regular layout.  Measured: no gain on those two graphs (Manhattan 10 k 3.48 vs 3.41 ms per
   // factorisation, KITTI-00 dense 12.1 vs 11.7 ms per three iterations) — the rounds already run the small fronts beside
   // the long panel chains of the big ones, which are the critical path; taking them out in front only adds their launches.
   const bool pure_small = small_max > 0 && S.max_front <= small_max;
-  const int mixed_max = pure_small ? small_max : std::min((int)env_or("PGO_FRONT_MIXED", 0), (int)SFRONT_MAX);
+  const int mixed_max = pure_small ? small_max : std::min((int)tuning("front_mixed", 0), (int)SFRONT_MAX);
   std::vector<char> is_small(nf, 0);
   {
     int cnt = 0;
@@ -474,7 +467,7 @@ bool front_analyze(int N, const std::vector<int>& ia, const std::vector<int>& ib
   // the root (Manhattan 10 k: 69 instead of the 133 a level-by-level schedule needs; sphere x10: 248 instead of 508), and
   // the chain, not the flops, is what bounds these factorisations.  The backward substitution is scheduled the same way from
   // the root down.
-  const long long tile32_below = (long long)env_or("PGO_FRONT_TILE32_BELOW", 192);
+  const long long tile32_below = (long long)tuning("front_tile32_below", 192);
   // width of the outer panels of the factorisation (left-looking inside, one right-looking GEMM behind each): a multiple of 48
   const int nbo = FRONT_NBO;     // (288 / 384 / 576 measured slower in r02 behind PGO_FRONT_NBO: the longer left-looking sums cost more than the longer-K updates gain)
   {

@@ -1351,7 +1351,7 @@ static void sfront_attributes() {
   attr_set = true;
 }
 #ifdef PGO_ABLATE
-static const int sf_dbg = getenv("PGO_SF_DBG") ? atoi(getenv("PGO_SF_DBG")) : 0;   // timing ablations of k_sfront_factor (results are wrong with any bit set)
+static const int sf_dbg = PGO_ABLATE;   // timing ablations of k_sfront_factor, a compile-time constant (results are wrong with any bit set)
 #else
 static const int sf_dbg = 0;
 #endif

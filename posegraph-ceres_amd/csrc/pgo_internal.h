@@ -4,6 +4,7 @@
 // cross files.  Internal: nothing here is part of the C ABI (include/pgo.h); the library is built with -fvisibility=hidden, so none
 // of these names leave it.
 #pragma once
+#include "pgo_tuning.h"
 #include "../../include/pgo.h"
 #include "pgo_kernels.h"
 #include "pgo_sym.h"
@@ -417,7 +418,7 @@ struct pgo_problem {
   DevBuf<int> dd_split_blk, dd_split_sub, dd_split_sub_diag, dd_upd_split, dd_panel_cols, dd_blk_lpos, dd_split_dblk, dd_col_flag;
   int direct_epoch = 0;
   bool split_two_launch = false;   // a single-launch SPLIT step timed out once: this problem keeps to the two-launch form
-  bool sfront_levels = false;      // small-front plan: one launch per level (a wait of the single-launch form ran out, or PGO_FACTOR_FUSED=0)
+  bool sfront_levels = false;      // small-front plan: one launch per level (a wait of the single-launch form ran out, or the knob factor_fused = 0)
   int sfront_epoch = 0;
   unsigned sfront_tickets = 0;     // tickets handed out by the single-launch factorisations so far
   DevBuf<uint8_t> dd_split_diag;
@@ -444,7 +445,7 @@ struct pgo_problem {
   DevBuf<long long> ds_stamps;     // PGO_SF_STAMPS=1 (development aid)
   DevBuf<int> df_st_table, df_st_pred_ptr, df_st_pred, df_st_need;
   DevBuf<unsigned long long> df_st_count;
-  bool front_launches = false;     // multifrontal plan: one launch per phase of a round (a wait of the single-launch form ran out, or PGO_FACTOR_FUSED=0)
+  bool front_launches = false;     // multifrontal plan: one launch per phase of a round (a wait of the single-launch form ran out, or the knob factor_fused = 0)
   unsigned long long front_epoch = 0, front_tickets = 0;
   DevBuf<int> df_perm, df_idx, df_child, df_rel, df_cstart, df_col_front, df_ablk_ptr, df_ablk_slot, df_ablk_front, df_ablk_pos, df_wg_job, df_wg_tile,
       df_bwd_front, df_bwd_chunk, df_bwdb_front, df_bwdb_chunk, df_asm_tile, df_asm_contrib;

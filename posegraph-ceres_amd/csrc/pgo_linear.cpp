@@ -339,7 +339,7 @@ int upload_front(pgo_problem* P) {
   f.col_front = P->df_col_front.p; f.ablk_ptr = P->df_ablk_ptr.p; f.ablk_slot = P->df_ablk_slot.p;
   f.ablk_front = P->df_ablk_front.p; f.ablk_pos = P->df_ablk_pos.p; f.n_ablk = (int)S.ablk_front.size();
   f.jobs = P->df_jobs.p; f.Fval = P->df_Fval.p; f.Winv = P->df_Winv.p; f.x = P->df_x.p;
-  // the stages of the single-launch form (pgo_front.h FrontStages); PGO_FACTOR_FUSED=0: one launch per phase of a round
+  // the stages of the single-launch form (pgo_front.h FrontStages); knob factor_fused = 0: one launch per phase of a round
   f.st_table = nullptr; f.st_pred_ptr = nullptr; f.st_pred = nullptr; f.st_need = nullptr; f.st_count = nullptr;
   P->front_epoch = 0; P->front_tickets = 0;
   {
@@ -347,10 +347,10 @@ int upload_front(pgo_problem* P) {
     // dense (0.9 GFLOP) 28.1 vs 32.0 ms per 14-iteration solve, Manhattan 10 k (4.5 GFLOP) 3.54 vs 3.57 ms, sphere x10 (383
     // GFLOP) 46 vs 28 ms: every work-group pays a cache write-back and an invalidation of its XCD's L2 where a kernel boundary
     // pays them once, which the GEMM-heavy factorisations cannot afford.  Default: single launch up to 3 GFLOP
-    // (PGO_FACTOR_FUSED=1 always, =0 never: one switch for the three factorisations).
-    const char* fu = getenv("PGO_FACTOR_FUSED");
+    // (knob factor_fused, pgo_tuning.h: 1 always, 0 never — one switch for the three factorisations).
+    const double fu = pgo::tuning("factor_fused", -1.0);
     const double limit = 3.0;
-    const bool on = fu ? fu[0] == '1' : S.flops <= limit * 1e9;
+    const bool on = fu >= 0.0 ? fu != 0.0 : S.flops <= limit * 1e9;
     P->front_launches = !on || S.st_table.empty();
   }
   if (!S.st_table.empty()) {
@@ -416,8 +416,7 @@ int upload_sfront(pgo_problem* P) {
   P->sfront_epoch = 0;
   P->sfront_tickets = 0;
   {
-    const char* fu = getenv("PGO_FACTOR_FUSED");
-    P->sfront_levels = fu && fu[0] == '0';
+    P->sfront_levels = pgo::tuning("factor_fused", -1.0) == 0.0;
   }
   P->splan = pgo::SFrontPlan{P->ds_sf.p, nullptr, P->ds_urel.p, P->ds_upos.p, P->ds_osrc.p, P->ds_L.p, P->ds_U.p, P->ds_W.p, P->ds_done.p};
   pgo::launch_sfront_prepare(P->fplan, P->splan, S, s);

@@ -191,8 +191,8 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
     rc = sym_prepare(P);
     if (rc) return rc;
     P->sym_active = P->sym_ready;
-    const char* rp = getenv("PGO_SYM_REPACK");        // (A/B: keep the incidence-slot linearisation and copy its blocks per LM iteration)
-    if (P->sym_active && !(rp && rp[0] == '1')) { rc = sym_enter_storage(P); if (rc) return rc; }
+    const bool rp = pgo::tuning("sym_repack", 0.0) != 0.0;        // (A/B knob, pgo_tuning.h: keep the incidence-slot linearisation and copy its blocks per LM iteration)
+    if (P->sym_active && !rp) { rc = sym_enter_storage(P); if (rc) return rc; }
   }
   L.active = true;            // (only a session that got this far is one: an error above leaves the problem as it was)
   L.t_total += seconds_since(t0);
@@ -368,8 +368,8 @@ int lm_advance(pgo_problem* P) {
   // cost model that admitted the factorisation (0.7 us per schedule step; 10 us + 42 ps per slot per CG iteration), so the
   // choice depends on iteration counts only, never on a clock.  Over budget = redo the iteration with the factorisation.
   const bool hybrid = direct && P->dsym.hybrid;
-  const char* budget_env = getenv("PGO_HYBRID_BUDGET");     // experiments / tests: CG iterations a PCG try may take
-  const int cg_budget = !hybrid ? 0 : budget_env ? std::max(1, atoi(budget_env))
+  const double budget_knob = pgo::tuning("hybrid_budget", -1.0);     // experiments / tests: CG iterations a PCG try may take
+  const int cg_budget = !hybrid ? 0 : budget_knob >= 0.0 ? std::max(1, (int)budget_knob)
                                 : std::max(50, (int)(1.5 * 0.7 * P->dsym.est_steps / (10.0 + 4.2e-5 * (double)P->g.n_slots)));
   bool use_direct = direct;
   if (hybrid && (L.hybrid_pcg || L.hybrid_direct_run >= L.hybrid_probe_after ||
@@ -490,9 +490,9 @@ static bool pipeline_wanted(const pgo_problem* P) {
   // Exact steps: the launch sequence of an iteration is the same every time, so enqueueing ahead costs nothing.  PCG: the host has
   // to allot CG iterations to a sequence before it knows how many the CG will take (Manhattan 10 k: 32, 8, 20, 85, 15, 125, 14 ...
   // then 3-6), every unused one is two early-exit launches and every CG that outlives its sequence a gated tail: measured 0.38 ms
-  // per LM iteration against 0.30 with the host in the loop on a host that answers within 13 us.  PGO_PIPELINE_PCG=1 selects the
+  // per LM iteration against 0.30 with the host in the loop on a host that answers within 13 us.  the knob pipeline_pcg = 1 (pgo_tuning.h) selects the
   // sequences for PCG as well (tests do).
-  if (!direct) { const char* e = getenv("PGO_PIPELINE_PCG"); return e && e[0] == '1'; }
+  if (!direct) return pgo::tuning("pipeline_pcg", 0.0) != 0.0;
   return true;
 }
 
@@ -522,7 +522,7 @@ int lm_upload_state(pgo_problem* P) {
     P->scal->resident_abort = 0;
     // (diagnostic, tests/test_gpu_resident.py: the abort word set by hand — the cycle's kernels find the barrier "given up" before the
     // first CG and the session has to carry on with the fused stream, as it would behind a real time-out)
-    if (P->uni_resident && getenv("PGO_RESIDENT_ABORT_TEST"))
+    if (P->uni_resident && pgo::tuning("resident_abort_test", 0.0) != 0.0)
       HIP_TRY(hipMemsetAsync(P->d_flags.p + pgo::uni_r_abort_word(), 1, sizeof(int), P->stream));
   }
   P->scal->lm = D;

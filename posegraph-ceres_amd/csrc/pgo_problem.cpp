@@ -33,9 +33,8 @@ int ensure_device(pgo_problem* P) {
     P->stream_ready = true;
     // Launch sequences are enqueued eagerly by default: on this stack (ROCm 7.2, MI355X) the host runs ahead of the GPU and a
     // captured hipGraph of the same kernels is no faster (C2: 0.317 vs 0.317 ms per LM iteration without residual refreshes,
-    // 0.322 eager vs 0.353 graph with them; KITTI-00 exact 0.79 vs 0.81 ms).  PGO_GRAPH=1 replays captured batches instead.
-    const char* gr = getenv("PGO_GRAPH");
-    P->use_graph = gr && gr[0] == '1';
+    // 0.322 eager vs 0.353 graph with them; KITTI-00 exact 0.79 vs 0.81 ms).  The knob graph = 1 (pgo_tuning.h) replays captured batches instead.
+    P->use_graph = pgo::tuning("graph", 0.0) != 0.0;
   }
   if (!P->scal) {
     void* blk = nullptr;
@@ -62,11 +61,11 @@ int linearize_all(pgo_problem* P, bool diag_only) {
   if (P->sym_storage) {
     // two kernels write the form: the row kernel with the lean per-incidence algebra (k_linearize_lean, the default where it fits:
     // information without position / rotation coupling) and the row kernel with the general body and redirected block stores
-    // (k_linearize_symout: information with the coupling; PGO_SYM_LIN=rows runs it everywhere — tests/test_gpu_sym.py holds one to the other)
-    const char* sl = getenv("PGO_SYM_LIN");
+    // (k_linearize_symout: information with the coupling; the knob sym_lin_rows = 1 runs it everywhere — tests/test_gpu_sym.py holds one to the other)
+    const bool rows_writer = pgo::tuning("sym_lin_rows", 0.0) != 0.0;
     pgo::DeviceGraph gs = P->g;
     gs.sym_dst = P->sy_dst.p; gs.sym_val = P->sym.val;
-    if (sl && sl[0] == 'r') pgo::launch_linearize_symout(gs, P->stream);
+    if (rows_writer) pgo::launch_linearize_symout(gs, P->stream);
     else pgo::launch_linearize_lean(gs, P->stream);
     if (P->g.world == 1) return PGO_OK;        // (one rank: nothing to exchange; several: the diagonal blocks' diagonals and the gradient, as below)
   } else {
@@ -432,7 +431,7 @@ int prepare(pgo_problem* P) {
   // 27-entry slots.
   {
     const bool force_full = false;
-    static const bool no_diag = getenv("PGO_NO_DIAG_INFO") && getenv("PGO_NO_DIAG_INFO")[0] == '1';    // (A/B: the 12-entry reads of mode 2)
+    const bool no_diag = pgo::tuning("no_diag_info", 0.0) != 0.0;    // (A/B knob: the 12-entry reads of mode 2)
     g.info_mode = !P->has_info ? 0 : (w_diag && !force_full && !no_diag) ? 3 : (w_blockdiag && !force_full) ? 2 : 1;
     g.blk_packed = (g.info_mode != 1 && !force_full) ? 1 : 0;
   }

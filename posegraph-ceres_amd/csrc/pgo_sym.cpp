@@ -40,13 +40,13 @@ int sym_prepare(pgo_problem* P) {
   hipStream_t s = P->stream;
   // tile caps: up to 256 rows; enough tiles to fill the chip on small graphs; the weight cap keeps the tiles' stored slots alike
   pgo::SymHostParams hp;
-  const char* re = getenv("PGO_SYM_ROWS");
+  const int re = (int)pgo::tuning("sym_rows", 0.0);
   const int N_own = std::max(1, P->g.row_hi - P->g.row_lo);
   // (r06, tools/sym_rows_probe.py on a shard-sized problem alone on the chip — 12.5 k / 25 k rows: k_pipe_cg_sym 27.0 / 44.5 us per CG
   // iteration with 32-row tiles, 22.0 / 37.5 with 48, 23.9 / 33.4 with 64, 27.6 / 31.2 with 96, 49.5 / 51.4 with 256: the optimum sits at
   // ~320 tiles, i.e. rows / 260 per tile; larger tiles store fewer blocks — 1.14x the algorithmic bytes per product with 256 rows against
   // 1.44x with 32 on an eighth of BASELINE configs[3] — but a shard of this size is latency-bound, not bandwidth-bound)
-  hp.row_cap = re ? atoi(re) : std::min(256, std::max(32, (N_own / 260) & ~1));
+  hp.row_cap = re > 0 ? re : std::min(256, std::max(32, (N_own / 260) & ~1));
   hp.row_cap = std::max(8, std::min(hp.row_cap, (int)pgo::SYM_LANES));
   // (several ranks: this rank's rows and their incidences)
   long long own_slots = P->g.row_hi - P->g.row_lo;

@@ -38,6 +38,22 @@ def O():
     return oracle
 
 
+@pytest.fixture
+def knobs(pkg):
+    """knobs(name=value, ...): development / test knobs of the library (pgo_tuning_set; csrc/pgo_tuning.h) for the rest of the test;
+    value None = the default.  Put back to what they were at teardown."""
+    before = {}
+
+    def set_(**kw):
+        for k, v in kw.items():
+            if k not in before:
+                before[k] = pkg.tuning_get(k)
+            pkg.tuning_set(k, v)
+    yield set_
+    for k, v in before.items():
+        pkg.tuning_set(k, v)
+
+
 @pytest.fixture(scope="session")
 def gpu(pkg):
     if pkg.device_count() < 1:

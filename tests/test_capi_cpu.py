@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for n in names:
         assert hasattr(L, n), n
     assert sorted(pkg.C_ABI_SYMBOLS) == names
-    assert L.pgo_version() == 104
+    assert L.pgo_version() == 105
 
 
 def test_options_defaults(pkg):
@@ -139,3 +139,40 @@ def test_full_report_renders(pkg):
     assert "Solver Summary" in text and "Residual blocks" in text and "CONVERGENCE" in text
     assert "Original" in text and "Reduced" in text and "Given" in text and "Used" in text      # Ceres 1.13's two-column layout
     assert Summary(s, rec).is_solution_usable()
+
+
+def test_tuning_knobs_replace_sixteen_environment_variables(pkg):
+    """r06: the library's development / test switches are knobs behind pgo_tuning_set (csrc/pgo_tuning.h), not
+    environment variables: set / read back / default / unknown name."""
+    knobs = pkg.tuning_knobs()
+    assert len(knobs) == 15 and all(len(w) > 10 for w in knobs.values())
+    for k in knobs:
+        assert pkg.tuning_get(k) is None                  # all at their defaults
+    pkg.tuning_set("sym_rows", 64)
+    assert pkg.tuning_get("sym_rows") == 64.0
+    with pkg.tuning(sym_rows=48, factor_fused=0):
+        assert pkg.tuning_get("sym_rows") == 48.0 and pkg.tuning_get("factor_fused") == 0.0
+    assert pkg.tuning_get("sym_rows") == 64.0 and pkg.tuning_get("factor_fused") is None
+    pkg.tuning_set("sym_rows", None)
+    assert pkg.tuning_get("sym_rows") is None
+    with pytest.raises(pkg.PgoError):
+        pkg.tuning_set("no_such_knob", 1)
+
+
+def test_environment_switches_are_at_most_fifteen_and_each_is_named_in_a_test():
+    """What the library reads from the environment: at most 15 names (31 before r06), each of them used by a test (or it goes)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "posegraph-ceres_amd", "csrc", "*")):
+        if f.endswith((".cpp", ".hip", ".h", ".inc")):
+            names |= set(re.findall(r'"(PGO_[A-Z0-9_]+)"', open(f).read()))
+    assert len(names) <= 15, sorted(names)
+    tests = {f: open(f).read() for f in glob.glob(os.path.join(root, "tests", "*.py")) if not f.endswith("test_capi_cpu.py")}
+    for n in sorted(names):
+        assert any(re.search(r"\b%s\b" % n, t) for t in tests.values()), "%s is read by the library but no test names it" % n
+    # ... and the list the documents give is this list
+    doc = open(os.path.join(root, "EXPERIMENTS.md")).read()
+    for n in sorted(names):
+        assert "`%s" % n in doc, "%s is missing from the table of environment switches in EXPERIMENTS.md" % n

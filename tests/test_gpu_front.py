@@ -237,11 +237,11 @@ def test_small_front_plan_on_chain_like_graphs(gpu, O, ds, monkeypatch):
         assert np.allclose(s.iterations["cost"], otr[:, 1], rtol=1e-9)
 
 
-def test_mixed_plan_small_subtrees_before_the_rounds(gpu, O, ds, monkeypatch):
-    """PGO_FRONT_MIXED=96: the fronts whose whole subtree fits the LDS are factorised by the small-front kernels level by level,
+def test_mixed_plan_small_subtrees_before_the_rounds(gpu, O, ds, monkeypatch, knobs):
+    """Knob front_mixed = 96: the fronts whose whole subtree fits the LDS are factorised by the small-front kernels level by level,
     the rest by the round schedule (their subtree roots hand their update matrices over in the regular front layout).  Same
     answers: linear solve vs the oracle <= 1e-9, bit-identical when repeated, on a mesh and on the dense KITTI-like graph."""
-    monkeypatch.setenv("PGO_FRONT_MIXED", "96")
+    knobs(front_mixed=96)
     monkeypatch.setenv("PGO_FRONT", "1")
     for g in (ds.manhattan_se3(2000, 8000, seed=3), ds.manhattan_se3(1500, 9000, seed=21, loop_radius=4.0), ds.sphere_layers(n_spheres=3, rings=30, per_ring=30)):
         prob, poses, og = _pair(gpu, O, g)
@@ -256,3 +256,20 @@ def test_mixed_plan_small_subtrees_before_the_rounds(gpu, O, ds, monkeypatch):
     _, osum, otr = O.solve(og, O.default_options(max_num_iterations=6, linear_solver=0))
     assert s.c.factor_kind == 2 and list(s.iterations["step_is_successful"]) == [int(v) for v in otr[:, 8]]
     assert np.allclose(s.iterations["cost"], otr[:, 1], rtol=1e-7)
+
+
+def test_plan_heuristics_are_knobs_and_any_setting_gives_the_same_answer(gpu, ds, monkeypatch, knobs):
+    """front_zfrac / front_small / front_maxcols / front_tile32_below (pgo_tuning_set; environment variables until r06) shape the
+    multifrontal plan — amalgamation and tile size — never the answer: the linear solve agrees with the default plan's to 1e-10."""
+    monkeypatch.setenv("PGO_FRONT", "1")
+    g = ds.manhattan_se3(1500, 6000, seed=21)
+    d2, b = _rhs(g, 4)
+    opt = gpu.SolverOptions(linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
+    prob, _ = gpu.problem_from_graph(g)
+    x0, _ = prob.linear_solve(d2, b, opt)
+    for kw in (dict(front_zfrac=0.05, front_small=2), dict(front_zfrac=0.6, front_maxcols=40), dict(front_tile32_below=0), dict(front_tile32_below=10 ** 9)):
+        knobs(front_zfrac=None, front_small=None, front_maxcols=None, front_tile32_below=None)
+        knobs(**kw)
+        prob, _ = gpu.problem_from_graph(g)
+        x, _ = prob.linear_solve(d2, b, opt)
+        assert np.abs(x - x0).max() <= 1e-10 * np.abs(x0).max(), kw

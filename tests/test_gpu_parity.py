@@ -372,7 +372,7 @@ def test_exact_request_served_by_pcg_converges(gpu, O, ds, monkeypatch):
 
 
 @pytest.mark.parametrize("budget", [None, "100000", "40"])
-def test_exact_request_with_per_iteration_choice(gpu, O, ds, monkeypatch, budget):
+def test_exact_request_with_per_iteration_choice(gpu, O, ds, monkeypatch, knobs, budget):
     """Factorisation admitted but above the always-direct budget (forced here): every LM iteration is served either by
     the factorisation or by PCG to 1e-13, an over-budget PCG try is redone with the factorisation.  Whatever the mix
     (default budget: mostly factorisations; huge: PCG after the first; tiny: every try over budget), the LM trace is
@@ -380,7 +380,7 @@ def test_exact_request_with_per_iteration_choice(gpu, O, ds, monkeypatch, budget
     monkeypatch.setenv("PGO_FRONT", "0")                      # the per-iteration choice belongs to the enumerated factorisation
     monkeypatch.setenv("PGO_DIRECT_MAX_STEPS", "10")
     if budget:
-        monkeypatch.setenv("PGO_HYBRID_BUDGET", budget)
+        knobs(hybrid_budget=int(budget))
     g = ds.manhattan_se3(2000, 8000, seed=3)
     prob, poses, og = _pair(gpu, O, g)
     s = gpu.solve(gpu.SolverOptions(max_num_iterations=8, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY), prob)
@@ -486,7 +486,7 @@ def test_split_step_timeout_falls_back_to_two_launches(gpu, O, ds, monkeypatch):
     assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-7)
 
 
-def test_small_front_single_launch_timeout_falls_back_to_levels(gpu, O, ds, monkeypatch):
+def test_small_front_single_launch_timeout_falls_back_to_levels(gpu, O, ds, monkeypatch, knobs):
     """The single-launch form of the small-front factorisation (all tree levels in one launch, a front polls its children's
     flags) with the wait budget forced to zero (PGO_WAIT_SPINS=0): the driver repeats the factorisation level by level, keeps
     to that form, and the LM trace is the oracle's; and both forms give bit-identical traces when nothing times out."""
@@ -496,11 +496,11 @@ def test_small_front_single_launch_timeout_falls_back_to_levels(gpu, O, ds, monk
     og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
     _, osum, otr = O.solve(og, O.default_options(max_num_iterations=8, linear_solver=0))
     traces = []
-    for env in ({"PGO_WAIT_SPINS": "0"}, {"PGO_FACTOR_FUSED": "0"}, {}):
-        for key in ("PGO_WAIT_SPINS", "PGO_FACTOR_FUSED"):
-            monkeypatch.delenv(key, raising=False)
-        for key, val in env.items():
-            monkeypatch.setenv(key, val)
+    for spins, fused in (("0", None), (None, 0), (None, None)):
+        monkeypatch.delenv("PGO_WAIT_SPINS", raising=False)
+        if spins is not None:
+            monkeypatch.setenv("PGO_WAIT_SPINS", spins)
+        knobs(factor_fused=fused)
         prob, poses = gpu.problem_from_graph(g)
         s = gpu.solve(opt, prob)
         assert s.linear_solver_used == 0 and s.c.factor_kind == 3
@@ -511,18 +511,16 @@ def test_small_front_single_launch_timeout_falls_back_to_levels(gpu, O, ds, monk
     assert traces[0] == traces[1] == traces[2]
 
 
-def test_diagonal_information_is_read_as_six_planes_with_identical_results(gpu, ds, monkeypatch):
+def test_diagonal_information_is_read_as_six_planes_with_identical_results(gpu, ds, knobs):
     """W = diag(1/sigma^2) (the synthetic generators): the kernels read six of the 21 information planes (info_mode 3); the entries
-    they skip are exact zeros, so the LM trace and the poses equal those of the 12-plane reads (PGO_NO_DIAG_INFO=1) bit for bit,
+    they skip are exact zeros, so the LM trace and the poses equal those of the 12-plane reads (knob no_diag_info = 1) bit for bit,
     for truncated PCG and for exact steps."""
     g = ds.manhattan_se3(1200, 4200, seed=33)
     out = []
     for ls, kw in ((gpu.BLOCK_JACOBI_PCG, dict(eta=0.1, max_linear_solver_iterations=500)), (gpu.SPARSE_NORMAL_CHOLESKY, {})):
         res = []
-        for off in ("1", None):
-            monkeypatch.delenv("PGO_NO_DIAG_INFO", raising=False)
-            if off:
-                monkeypatch.setenv("PGO_NO_DIAG_INFO", off)
+        for off in (1, None):
+            knobs(no_diag_info=off)
             prob, poses = gpu.problem_from_graph(g)
             s = gpu.solve(gpu.SolverOptions(max_num_iterations=8, linear_solver_type=ls, **kw), prob)
             res.append((tuple(float(c) for c in s.iterations["cost"]), tuple(int(c) for c in s.iterations["linear_solver_iterations"]), poses.tobytes()))
@@ -531,18 +529,18 @@ def test_diagonal_information_is_read_as_six_planes_with_identical_results(gpu, 
     assert len(out) == 2
 
 
-def test_multifrontal_single_launch_timeout_falls_back_to_launches(gpu, ds, monkeypatch):
+def test_multifrontal_single_launch_timeout_falls_back_to_launches(gpu, ds, monkeypatch, knobs):
     """The single-launch form of the multifrontal factorisation (every work-group of the round schedule in one grid, stages
     ordered by counters) with the wait budget forced to zero (PGO_WAIT_SPINS=0): the driver repeats the factorisation with one
     launch per phase, keeps to that form, and the trace is bit-identical to the one of either form when nothing times out."""
     g = ds.manhattan_se3(1500, 5000, seed=21)
     opt = gpu.SolverOptions(max_num_iterations=6, linear_solver_type=gpu.SPARSE_NORMAL_CHOLESKY)
     traces = []
-    for env in ({"PGO_WAIT_SPINS": "0"}, {"PGO_FACTOR_FUSED": "0"}, {"PGO_FACTOR_FUSED": "1"}):
-        for key in ("PGO_WAIT_SPINS", "PGO_FACTOR_FUSED"):
-            monkeypatch.delenv(key, raising=False)
-        for key, val in env.items():
-            monkeypatch.setenv(key, val)
+    for spins, fused in (("0", None), (None, 0), (None, 1)):
+        monkeypatch.delenv("PGO_WAIT_SPINS", raising=False)
+        if spins is not None:
+            monkeypatch.setenv("PGO_WAIT_SPINS", spins)
+        knobs(factor_fused=fused)
         prob, poses = gpu.problem_from_graph(g)
         s = gpu.solve(opt, prob)
         assert s.linear_solver_used == 0 and s.c.factor_kind == 2
@@ -580,3 +578,25 @@ def test_traces_to_convergence_match_oracle(gpu, O, ds, name, exact):
     assert np.abs(poses - oposes).max() <= (1e-7 if exact else 2e-3 if s.cg_form == 3 else 1e-5)
     if not exact:
         assert s.num_linear_solver_iterations == osum.num_linear_iterations
+
+
+def test_verbose_switch_and_graph_knob(gpu, ds, monkeypatch, knobs, capfd):
+    """PGO_VERBOSE=1: the library's diagnostics on stderr (phase timings of the topology build among them) and nothing else changes;
+    the knob graph = 1 (captured hipGraphs of the launch batches instead of eager enqueue): the same LM trace bit for bit."""
+    g = ds.manhattan_se3(600, 2000, seed=8)
+    opt = dict(max_num_iterations=6, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_form=1)
+    monkeypatch.setenv("PGO_NO_PIPELINE", "1")          # (captured batches belong to the host-driven loop)
+    prob, p0 = gpu.problem_from_graph(g)
+    s0 = gpu.solve(gpu.SolverOptions(**opt), prob)
+    capfd.readouterr()
+    monkeypatch.setenv("PGO_VERBOSE", "1")
+    prob, p1 = gpu.problem_from_graph(g)
+    s1 = gpu.solve(gpu.SolverOptions(**opt), prob)
+    err = capfd.readouterr().err
+    assert "[pgo] prepare:" in err
+    monkeypatch.delenv("PGO_VERBOSE")
+    knobs(graph=1)
+    prob, p2 = gpu.problem_from_graph(g)
+    s2 = gpu.solve(gpu.SolverOptions(**opt), prob)
+    for s, p in ((s1, p1), (s2, p2)):
+        assert np.array_equal(s.iterations["cost"], s0.iterations["cost"]) and np.array_equal(p, p0)

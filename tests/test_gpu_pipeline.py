@@ -15,21 +15,26 @@ FIELDS = ["iteration", "step_is_successful", "linear_solver_iterations", "cost",
 
 
 DRIVERS = {"host": {"PGO_NO_PIPELINE": "1"},                                   # r02: the host decides, one hand-off per iteration
-           "seq": {"PGO_NO_PIPELINE": "0", "PGO_PIPELINE_PCG": "1", "PGO_UNI": "0"},   # allotted sequences (default for exact steps)
+           "seq": {"PGO_NO_PIPELINE": "0", "PGO_UNI": "0"},   # allotted sequences (default for exact steps; for PCG: + the knob pipeline_pcg, below)
            "uni": {"PGO_NO_PIPELINE": "0", "PGO_UNI": "1"}}                        # universal stream (default for PCG)
 
 
 class _Env:
     def __init__(self, driver):
         self.new = DRIVERS[driver]
+        self.seq = driver == "seq"
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in ("PGO_NO_PIPELINE", "PGO_PIPELINE_PCG", "PGO_UNI")}
+        import pgo_loader
+        self.old = {k: os.environ.get(k) for k in ("PGO_NO_PIPELINE", "PGO_UNI")}
         for k in self.old:
             os.environ.pop(k, None)
         os.environ.update(self.new)
+        pgo_loader.load().tuning_set("pipeline_pcg", 1 if self.seq else None)
 
     def __exit__(self, *a):
+        import pgo_loader
+        pgo_loader.load().tuning_set("pipeline_pcg", None)
         for k, v in self.old.items():
             os.environ.pop(k, None)
             if v is not None:

@@ -144,15 +144,15 @@ def test_resident_launch_trace_is_the_two_kernel_cycle(gpu, ds, monkeypatch):
     assert (rec[:, 2] >= rec[:, 1]).all() and host_launches >= len(ops)
 
 
-def test_a_barrier_that_gave_up_hands_the_session_to_the_fused_stream(gpu, ds, monkeypatch):
+def test_a_barrier_that_gave_up_hands_the_session_to_the_fused_stream(gpu, ds, monkeypatch, knobs):
     """The abort word of the resident CG's grid barrier (set by a work-group that waited ~2 s: a grid that is not all on the chip) must
     not cost the solve anything but time: the LM iteration that was in its CG goes back to its HEAD and the session carries on in the
-    fused stream.  PGO_RESIDENT_ABORT_TEST sets the word by hand before the first launch; the time-out itself is exercised by
+    fused stream.  The knob resident_abort_test sets the word by hand before the first launch; the time-out itself is exercised by
     test_two_processes_with_resident_sessions_on_one_gpu_both_finish."""
     monkeypatch.setenv("PGO_BLOCK", "256")
     g = ds.manhattan_se3(1500, 6000, seed=21)
     ref, pref = _solve(gpu, g, 2, pcg_cluster_poses=2)
-    monkeypatch.setenv("PGO_RESIDENT_ABORT_TEST", "1")
+    knobs(resident_abort_test=1)
     prob, poses = gpu.problem_from_graph(g)
     prob.solver_begin(gpu.SolverOptions(max_num_iterations=20, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_form=3))
     assert prob.cg_form() == 4                      # it starts as a resident session ...
@@ -164,7 +164,7 @@ def test_a_barrier_that_gave_up_hands_the_session_to_the_fused_stream(gpu, ds, m
     for f in FIELDS:                                # nothing was lost or repeated: the fused stream's records, bit for bit
         assert np.array_equal(s.iterations[f], ref.iterations[f]), f
     assert np.array_equal(poses, pref)
-    monkeypatch.delenv("PGO_RESIDENT_ABORT_TEST")
+    knobs(resident_abort_test=None)
     c, pc = gpu.problem_from_graph(g)               # the device's resident slot was given back
     assert gpu.solve(gpu.SolverOptions(max_num_iterations=5, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_form=3), c).cg_form == 4
 

@@ -12,17 +12,20 @@ pytestmark = pytest.mark.gpu
 class _Sym:
     def __init__(self, on, rows=None):
         self.new = {"PGO_SYM": "1" if on else "0"}
-        if rows:
-            self.new["PGO_SYM_ROWS"] = str(rows)
+        self.rows = rows          # (rows per tile: the knob sym_rows, csrc/pgo_tuning.h)
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in ("PGO_SYM", "PGO_SYM_ROWS", "PGO_NO_PIPELINE")}
+        import pgo_loader
+        self.old = {k: os.environ.get(k) for k in ("PGO_SYM", "PGO_NO_PIPELINE")}
         for k in self.old:
             os.environ.pop(k, None)
         os.environ.update(self.new)
         os.environ["PGO_NO_PIPELINE"] = "1"      # the host-driven CG is the one that reads the symmetric form
+        pgo_loader.load().tuning_set("sym_rows", self.rows if self.rows else None)
 
     def __exit__(self, *a):
+        import pgo_loader
+        pgo_loader.load().tuning_set("sym_rows", None)
         for k, v in self.old.items():
             os.environ.pop(k, None)
             if v is not None:
@@ -100,17 +103,13 @@ def test_lm_solve_same_answer(gpu, ds, O, repack):
     g = ds.manhattan_se3(4000, 16000, seed=21)
     opt = dict(max_num_iterations=12, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_form=1)     # (pcg_form 1: Ceres' refreshed CG, k_spmv_sym<0>; the pipelined CG on the form is tests/test_gpu_sym_pipe.py)
     runs = []
-    # repack: the incidence-slot linearisation stays and its blocks are copied once per LM iteration (PGO_SYM_REPACK=1); otherwise the
+    # repack: the incidence-slot linearisation stays and its blocks are copied once per LM iteration (knob sym_repack = 1); otherwise the
     # symmetric form is the session's only storage: the linearisation writes it, damping / cluster preconditioner / tail and refresh
     # products read and write it
-    os.environ.pop("PGO_SYM_REPACK", None)
     for on in (False, True):
-        if on and repack:
-            os.environ["PGO_SYM_REPACK"] = "1"
-        with _Sym(on):
+        with _Sym(on), gpu.tuning(sym_repack=1 if (on and repack) else None):
             prob, poses = gpu.problem_from_graph(g)
             runs.append((gpu.solve(gpu.SolverOptions(**opt), prob), poses))
-        os.environ.pop("PGO_SYM_REPACK", None)
     (a, pa), (b, pb) = runs
     assert len(a.iterations) == len(b.iterations)
     assert list(a.iterations["step_is_successful"]) == list(b.iterations["step_is_successful"])
@@ -122,13 +121,13 @@ def test_lm_solve_same_answer(gpu, ds, O, repack):
 
 @pytest.mark.parametrize("lin", ["lean", "rows"])
 @pytest.mark.parametrize("name", ["identity", "fat_rows", "sphere"])
-def test_lm_solve_symmetric_storage_other_graphs(gpu, ds, name, lin, monkeypatch):
+def test_lm_solve_symmetric_storage_other_graphs(gpu, ds, name, lin, knobs):
     """Identity information (INFO 0), rows with many incidences (several chunks per tile, runs across wave boundaries), a mesh:
     whole LM solves with the symmetric form as the only storage against the incidence-slot kernels."""
     # lin: which kernel writes the form — the row kernel with the lean per-incidence algebra (k_linearize_lean, the default) or the row
     # kernel with the general body and redirected block stores (k_linearize_symout: information with position / rotation coupling;
-    # PGO_SYM_LIN=rows runs it on every graph)
-    monkeypatch.setenv("PGO_SYM_LIN", lin)
+    # the knob sym_lin_rows = 1 runs it on every graph)
+    knobs(sym_lin_rows=1 if lin == "rows" else None)
     g = _graphs(ds)[name]
     opt = dict(max_num_iterations=10, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=1 if name == "sphere" else 2, pcg_form=1)
     runs = []

@@ -1,5 +1,5 @@
 """Development aid: BASELINE configs[3]'s graph (100 k poses / 1 M edges) solved on ONE GPU by the host-driven PCG path, with the CG
-products read from the incidence-slot BSR (PGO_SYM=0) and from the symmetric tile form (PGO_SYM=1, the default above 600 k slots):
+products read from the incidence-slot BSR (PGO_SYM=0) and from the symmetric tile form (PGO_SYM=1, the default above 600 k slots; knob sym_repack: its A/B):
 ms per LM iteration, CG iterations, final cost.   usage (GPU box): python tools/c4_lm.py [steps [poses per preconditioner cluster]]"""
 import os
 import sys
@@ -16,7 +16,7 @@ cluster = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 g = ds.manhattan_se3(100000, 1000000, seed=20260930, loop_radius=3.0)
 for sym, rp in (("0", "0"), ("1", "1"), ("1", "0"), ("0", "0"), ("1", "1"), ("1", "0")):
     os.environ["PGO_SYM"] = sym
-    os.environ["PGO_SYM_REPACK"] = rp
+    gpu.tuning_set("sym_repack", int(rp))
     prob, poses = gpu.problem_from_graph(g)
     opt = gpu.SolverOptions(max_num_iterations=2 ** 30, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=cluster, eta=0.1,
                             function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0)
@@ -26,5 +26,5 @@ for sym, rp in (("0", "0"), ("1", "1"), ("1", "0"), ("0", "0"), ("1", "1"), ("1"
     ran, _ = prob.solver_step(steps)
     dt = time.perf_counter() - t0
     s = prob.solver_end()
-    print("cluster %d PGO_SYM=%s PGO_SYM_REPACK=%s: %.3f ms per LM iteration (%d iterations), %d CG iterations in the session, final cost %.9e" % (
+    print("cluster %d PGO_SYM=%s sym_repack=%s: %.3f ms per LM iteration (%d iterations), %d CG iterations in the session, final cost %.9e" % (
         cluster, sym, rp, 1e3 * dt / max(1, ran), ran, s.num_linear_solver_iterations, s.final_cost), flush=True)

@@ -16,7 +16,7 @@
 using namespace pgo;
 
 int main(int argc, char** argv) {
-  setenv("PGO_FRONT_MIXED", "0", 0);   // this tool emulates the regular round schedule only (the small-front kernels are checked on the GPU)
+  // (this tool emulates the regular round schedule only: the knob front_mixed stays at its default, 0 — the small-front kernels are checked on the GPU)
   if (argc < 2) { std::fprintf(stderr, "usage: %s edges.txt\n", argv[0]); return 2; }
   FILE* f = std::fopen(argv[1], "r");
   if (!f) return 2;

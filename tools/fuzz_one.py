@@ -7,8 +7,9 @@ pkg = F.pkg
 for seed in (91011, 91067):
     g, cmask, loss, loss_a, exact, cluster = F.random_case(seed)
     res = {}
-    for name, env in (("host", {"PGO_NO_PIPELINE": "1"}), ("seq", {"PGO_PIPELINE_PCG": "1", "PGO_UNI": "0"}), ("uni", {})):
-        for k in ("PGO_NO_PIPELINE", "PGO_PIPELINE_PCG", "PGO_UNI"): os.environ.pop(k, None)
+    for name, env in (("host", {"PGO_NO_PIPELINE": "1"}), ("seq", {"PGO_UNI": "0"}), ("uni", {})):
+        for k in ("PGO_NO_PIPELINE", "PGO_UNI"): os.environ.pop(k, None)
+        pkg.tuning_set("pipeline_pcg", 1 if name == "seq" else None)
         os.environ.update(env)
         prob, poses = pkg.problem_from_graph(g, loss=loss, loss_a=loss_a, constant_first=False)
         for v in np.nonzero(cmask)[0]: prob.set_pose_constant(int(v), int(cmask[v]))

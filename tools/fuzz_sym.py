@@ -65,8 +65,8 @@ def random_case(seed):
 
 def solve(g, cmask, loss, loss_a, cluster, sym, rows, repack, form):
     os.environ["PGO_SYM"] = "1" if sym else "0"
-    os.environ["PGO_SYM_ROWS"] = str(rows)
-    os.environ["PGO_SYM_REPACK"] = "1" if repack else "0"
+    pkg.tuning_set("sym_rows", rows)
+    pkg.tuning_set("sym_repack", 1 if repack else None)
     prob, poses = pkg.problem_from_graph(g, loss=loss, loss_a=loss_a, constant_first=False)
     for v in np.nonzero(cmask)[0]:
         prob.set_pose_constant(int(v), int(cmask[v]))

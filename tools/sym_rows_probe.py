@@ -1,6 +1,6 @@
 """Development aid: what tile size (rows per tile of the symmetric form) suits a SHARD-sized problem on a whole GPU — a one-rank
 problem of (poses, edges) = one eighth of BASELINE configs[3], the one-launch CG iteration on the form (k_pipe_cg_sym) timed in situ
-for PGO_SYM_ROWS = 32 .. 256.   usage (GPU box): python tools/sym_rows_probe.py [poses edges]"""
+for the knob sym_rows = 32 .. 256.   usage (GPU box): python tools/sym_rows_probe.py [poses edges]"""
 import os
 import sys
 
@@ -15,7 +15,7 @@ g = ds.manhattan_se3(n, e, seed=20260930, loop_radius=3.0)
 os.environ["PGO_SYM"] = "1"
 os.environ["PGO_NO_PIPELINE"] = "1"
 for rows in (32, 48, 64, 96, 128, 256):
-    os.environ["PGO_SYM_ROWS"] = str(rows)
+    gpu.tuning_set("sym_rows", rows)
     prob, _ = gpu.problem_from_graph(g)
     prob.solver_begin(gpu.SolverOptions(max_num_iterations=2 ** 30, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2,
                                         function_tolerance=0.0, parameter_tolerance=0.0, gradient_tolerance=0.0))
