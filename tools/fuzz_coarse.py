@@ -1,0 +1,133 @@
+"""Randomised sweep of the PCG's coarse level (csrc/pgo_coarse.hip, options.pcg_coarse_aggregate): random graphs (tools/fuzz_sym.py's
+generator: lattice walks, random chords, hubs, duplicate edges), random information kinds, constant blocks, losses, aggregate sizes —
+(a) one rank against the oracle's two-level PCG in the same recurrences (decisions, CG counts within one per LM iteration, costs),
+(b) 2 .. 5 virtual ranks of one GPU: bit-identical among themselves, run to run, and with the one-rank solve's
+the same start and comparable progress (other aggregate boundaries: another truncated step from the first iteration on), (c) a refusal is a refusal (PgoError), never a
+silent solve without the level.  Prints every mismatch.      usage (GPU box): python tools/fuzz_coarse.py [n_cases] [first_seed]"""
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+import pgo_loader  # noqa: E402
+import fuzz_sym as FS  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+pkg = FS.pkg
+os.environ.pop("PGO_NO_PIPELINE", None)      # (fuzz_sym sets it for its own sweep)
+os.environ.pop("PGO_SYM", None)
+NIT = 6
+
+
+def options(agg):
+    return dict(max_num_iterations=NIT, linear_solver_type=pkg.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_coarse_aggregate=agg, eta=0.1, max_linear_solver_iterations=300)
+
+
+def problem(g, cmask, loss, loss_a):
+    prob, poses = pkg.problem_from_graph(g, loss=loss, loss_a=loss_a, constant_first=False)
+    for v in np.nonzero(cmask)[0]:
+        prob.set_pose_constant(int(v), int(cmask[v]))
+    return prob, poses
+
+
+def ranks(g, cmask, loss, loss_a, agg, world):
+    group = pkg.loopback_create(world)
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            prob, poses = problem(g, cmask, loss, loss_a)
+            prob.comm_init_loopback(group, rank)
+            out[rank] = (pkg.solve(pkg.SolverOptions(**options(agg)), prob), poses)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    pkg.loopback_destroy(group)
+    if errs:
+        raise errs[0]
+    if any(o is None for o in out):
+        raise RuntimeError("a virtual rank did not finish")
+    return out
+
+
+def main(n_cases=60, first=0):
+    bad = refused = 0
+    t0 = time.time()
+    for seed in range(first, first + n_cases):
+        g, cmask, loss, loss_a, _, _, _, _ = FS.random_case(seed)
+        rng = np.random.default_rng(seed + 7)
+        agg = int(rng.choice([8, 12, 16, 24, 32, 50, 64, 100]))
+        world = int(rng.integers(2, 6))
+        if g.N < 5 * agg or g.N < 16 * world:
+            continue
+        try:
+            prob, p1 = problem(g, cmask, loss, loss_a)
+            s1 = pkg.solve(pkg.SolverOptions(**options(agg)), prob)
+        except pkg.PgoError as exc:
+            refused += 1
+            if "incidence slots" not in str(exc) and "row panel" not in str(exc):
+                bad += 1
+                print("seed", seed, "N", g.N, "E", g.E, "agg", agg, "UNEXPECTED REFUSAL", exc, flush=True)
+            continue
+        why = []
+        if s1.coarse_level != (g.N + agg - 1) // agg or s1.cg_form != 2:
+            why.append("coarse_level %d cg_form %d" % (s1.coarse_level, s1.cg_form))
+        og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info, cmask)
+        op, osum, otr = O.solve(og, O.default_options(max_num_iterations=NIT, linear_solver=1, pcg_cluster=-agg, pcg_form=1, eta=0.1, max_linear_solver_iterations=300,
+                                                      loss_kind=loss, loss_a=loss_a))
+        n = min(len(s1.iterations), len(otr))
+        if list(s1.iterations["step_is_successful"][:n]) != [int(x) for x in otr[:n, 8]]:
+            why.append("decisions differ from the oracle's")
+        else:
+            a = np.asarray(s1.iterations["linear_solver_iterations"][:n], dtype=int)
+            b = otr[:n, 7].astype(int)
+            if np.abs(a - b).max() > np.maximum(1, b // 50).max():
+                why.append("CG counts %s vs oracle %s" % (a, b))
+            if not np.allclose(s1.iterations["cost"][:n], otr[:n, 1], rtol=np.where(otr[:n, 8] > 0, 1e-5, 1e-3), atol=1e-12):
+                why.append("costs %s vs oracle %s" % (s1.iterations["cost"][:n], otr[:n, 1]))
+        try:
+            out = ranks(g, cmask, loss, loss_a, agg, world)
+            out2 = ranks(g, cmask, loss, loss_a, agg, world)
+            s0, x0 = out[0]
+            for (s, x), (s2, x2) in zip(out, out2):
+                if not (np.array_equal(x, x0) and np.array_equal(s.iterations["cost"], s0.iterations["cost"])):
+                    why.append("ranks differ")
+                    break
+                if not (np.array_equal(x, x2) and np.array_equal(s.iterations["cost"], s2.iterations["cost"])):
+                    why.append("ranks not reproducible")
+                    break
+            # (other aggregate boundaries -> another truncated step from the first iteration on: only the start and the size of the progress compare)
+            if s0.initial_cost != s1.initial_cost:
+                why.append("%d ranks: initial cost %r vs one rank %r" % (world, s0.initial_cost, s1.initial_cost))
+            if not (s0.final_cost <= 2.0 * s1.final_cost + 1e-9 and s1.final_cost <= 2.0 * s0.final_cost + 1e-9):
+                why.append("%d ranks: final cost %.6e vs one rank %.6e" % (world, s0.final_cost, s1.final_cost))
+            fixed = np.nonzero(cmask == 3)[0]
+            if not (np.isfinite(x0).all() and np.array_equal(x0[fixed], g.poses[fixed])):
+                why.append("constant pose moved / non-finite on ranks")
+            if not (s0.final_cost <= s0.initial_cost * (1 + 1e-12)):
+                why.append("ranks: cost went up")
+        except pkg.PgoError as exc:
+            if "incidence slots" not in str(exc) and "row panel" not in str(exc):
+                why.append("ranks refused: %s" % exc)
+        except Exception as exc:  # noqa: BLE001
+            why.append("ranks EXCEPTION %r" % (exc,))
+        if why:
+            bad += 1
+            print("seed", seed, "N", g.N, "E", g.E, "agg", agg, "world", world, "loss", loss, ":", "; ".join(why), flush=True)
+    print("%d cases, %d refused, %d bad, %.1f s" % (n_cases, refused, bad, time.time() - t0), flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(*(int(a) for a in sys.argv[1:3])) else 0)
