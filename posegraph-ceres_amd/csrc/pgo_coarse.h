@@ -36,7 +36,8 @@ struct CoarsePlan {
 void launch_coarse_galerkin(const DeviceGraph& g, const CoarsePlan& c, hipStream_t s);     // P~ of every pose, the row panels of this rank's aggregates
 void launch_coarse_invert(const CoarsePlan& c, hipStream_t s);                            // identity on empty / padding rows, explicit inverse in place
 // application in two halves around the all-gather of the restricted vector:
-void launch_coarse_restrict(const DeviceGraph& g, const CoarsePlan& c, const double* vec, hipStream_t s);     // rc of this rank's aggregates = P~' vec
+// rc of this rank's aggregates = P~' vec; fold_seq >= 0: the launch also folds the partial sums of the CG launch `fold_seq` (k_pipe_fold's job)
+void launch_coarse_restrict(const DeviceGraph& g, const CoarsePlan& c, const double* vec, hipStream_t s, int fold_seq = -1);
 // out += P~ (Ainv rc) for the poses of this rank's aggregates; out is an exchange buffer (pose v of rank k at k * out_seg + (v - k rows_per) * 6; one
 // rank: 6 v), out2 (may be null) a flat vector
 void launch_coarse_correct(const DeviceGraph& g, const CoarsePlan& c, double* out, int out_seg, double* out2, hipStream_t s);

@@ -215,9 +215,22 @@ __global__ __launch_bounds__(256) void k_coarse_gj_update(CoarsePlan c, int k) {
   }
 }
 
-// rc = P~' vec over the aggregate's poses (lane = pose, block sum in fixed order)
-__global__ __launch_bounds__(256) void k_coarse_restrict(DeviceGraph g, CoarsePlan c, const double* vec) {
+// rc = P~' vec over the aggregate's poses (lane = pose, block sum in fixed order).  fold_seq >= 0: one more work-group does what k_pipe_fold
+// does behind the CG launch `fold_seq` (pgo_kernels.hip: this rank's per-work-group partial triples -> its three sums in the exchange
+// buffer, same order) — a launch of its own per CG iteration otherwise (4.4 of 27 us at BASELINE configs[1])
+__global__ __launch_bounds__(256) void k_coarse_restrict(DeviceGraph g, CoarsePlan c, const double* vec, int fold_seq) {
   __shared__ double scratch[32];
+  if ((int)blockIdx.x == c.a_hi - c.a_lo) {
+    if (g.cg->done) return;
+    double t3[3] = {0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < g.n_wg; i += 256) { t3[0] += g.part_rz[i]; t3[1] += g.part_q[i]; t3[2] += g.part_rr[i]; }
+    block_sum<3>(t3, scratch);
+    if (threadIdx.x == 0) {
+      double* pp = g.pipe_buf[(fold_seq & 1) ^ 1] + (size_t)g.rank * g.pipe_seg + (size_t)g.rows_per * 6;
+      pp[0] = t3[0]; pp[1] = t3[1]; pp[2] = t3[2];
+    }
+    return;
+  }
   const int a = c.a_lo + blockIdx.x, tid = threadIdx.x;
   int v0, v1;
   agg_range(g, c, a, v0, v1);
@@ -282,8 +295,8 @@ void launch_coarse_invert(const CoarsePlan& c, hipStream_t s) {
     hipLaunchKernelGGL(k_coarse_gj_update, dim3(c.npad / GJ, (c.npad + 255) / 256), dim3(256), 0, s, c, k);
   }
 }
-void launch_coarse_restrict(const DeviceGraph& g, const CoarsePlan& c, const double* vec, hipStream_t s) {
-  if (c.a_hi > c.a_lo) hipLaunchKernelGGL(k_coarse_restrict, dim3(c.a_hi - c.a_lo), dim3(256), 0, s, g, c, vec);
+void launch_coarse_restrict(const DeviceGraph& g, const CoarsePlan& c, const double* vec, hipStream_t s, int fold_seq) {
+  hipLaunchKernelGGL(k_coarse_restrict, dim3(c.a_hi - c.a_lo + (fold_seq >= 0 ? 1 : 0)), dim3(256), 0, s, g, c, vec, fold_seq);
 }
 void launch_coarse_correct(const DeviceGraph& g, const CoarsePlan& c, double* out, int out_seg, double* out2, hipStream_t s) {
   if (c.a_hi > c.a_lo) hipLaunchKernelGGL(k_coarse_correct, dim3(c.a_hi - c.a_lo), dim3(256), 0, s, g, c, out, out_seg, out2);

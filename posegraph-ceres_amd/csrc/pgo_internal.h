@@ -547,7 +547,7 @@ int pcg_begin(pgo_problem* P, const pgo::CgParams& prm);
 int run_pcg(pgo_problem* P, const pgo::CgParams& prm, int batch, int* iterations, int* status);
 int prepare_clusters(pgo_problem* P, int CL);
 int coarse_setup(pgo_problem* P);                 // coarse level of the PCG (pgo_coarse.h): per LM iteration, behind the damping
-int coarse_apply(pgo_problem* P, const double* vec, double* out, double* out2);
+int coarse_apply(pgo_problem* P, const double* vec, double* out, double* out2, int fold_seq);
 long long front_memory_budget();
 void analyze_front(pgo_problem* P, int N, int n_slots, long long budget, bool* ok, int small_max = 0);
 int upload_front(pgo_problem* P);

@@ -332,7 +332,7 @@ bool uni_supported(const DeviceGraph& g);
 bool pipe_supported(const DeviceGraph& g, const CgParams& p, int cluster);
 void launch_hdiag6(const DeviceGraph& g, double* buf, int phase, hipStream_t s);   // diagonals of the diagonal blocks: owned rows into buf (0) / other rows out of it (1)
 void launch_pipe_init(const DeviceGraph& g, hipStream_t s);
-void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, hipStream_t s, unsigned long long gseq = 0);   // gseq: device-initiated exchange, global number of this producing launch
+void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, hipStream_t s, unsigned long long gseq = 0, bool fold = true);   // gseq: device-initiated exchange, global number of this producing launch; fold = false: the caller's next launch folds the partial sums (the coarse level's restriction)
 void launch_peer_signal(const DeviceGraph& g, unsigned long long gseq, hipStream_t s);   // ... behind k_pipe_init
 void launch_pipe_fold(const DeviceGraph& g, int seq, unsigned long long gseq, hipStream_t s);   // one work-group: the g.n_wg partial triples of the producing launch -> this rank's three sums in the exchange buffer(s) (+ signal / wait)
 void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s);

@@ -2742,14 +2742,14 @@ void launch_pipe_init(const DeviceGraph& g, hipStream_t s) {
   else hipLaunchKernelGGL(k_pipe_init<1>, dim3(g.n_vec_wg), dim3(VEC_BLOCK), 0, s, g);
 }
 void launch_peer_signal(const DeviceGraph& g, unsigned long long gseq, hipStream_t s) { hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(1), 0, s, g, gseq); }
-void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, hipStream_t s, unsigned long long gseq) {
+void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, hipStream_t s, unsigned long long gseq, bool fold) {
   const size_t lds = ((size_t)(SPMV_LDS_STRIDE + 6) * g.block + 8) * sizeof(double);
   const dim3 grid(mode ? 1 : g.n_wg);
 #define PGO_PIPE(PK) do { if (g.cluster == 2) hipLaunchKernelGGL((k_pipe_cg<PK, 2>), grid, dim3(g.block), lds, s, g, p, seq, mode); \
                           else hipLaunchKernelGGL((k_pipe_cg<PK, 1>), grid, dim3(g.block), lds, s, g, p, seq, mode); } while (0)
   if (g.blk_packed) PGO_PIPE(true); else PGO_PIPE(false);
 #undef PGO_PIPE
-  if (mode == 0) launch_pipe_fold(g, seq, gseq, s);
+  if (mode == 0 && fold) launch_pipe_fold(g, seq, gseq, s);
 }
 void launch_pipe_fold(const DeviceGraph& g, int seq, unsigned long long gseq, hipStream_t s) {
   hipLaunchKernelGGL(k_pipe_fold, dim3(1), dim3(256), 0, s, g, seq, gseq);

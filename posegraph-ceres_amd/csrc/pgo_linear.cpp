@@ -42,9 +42,9 @@ bool pipe_mode(const pgo_problem* P, const pgo::CgParams& prm) {
 }
 // coarse level (pgo_coarse.h): out += P (P'AP)^-1 P' vec on this rank's rows.  Several ranks: every rank restricts over ITS aggregates, the
 // restricted vector (6 doubles per aggregate) is all-gathered, every rank applies the (replicated, bit-identical) inverse to its own rows.
-int coarse_apply(pgo_problem* P, const double* vec, double* out, double* out2) {
+int coarse_apply(pgo_problem* P, const double* vec, double* out, double* out2, int fold_seq) {
   const pgo::CoarsePlan& c = P->coarse;
-  pgo::launch_coarse_restrict(P->g, c, vec, P->stream);
+  pgo::launch_coarse_restrict(P->g, c, vec, P->stream, fold_seq);
   if (P->g.world > 1) { int rc = exchange(P, c.rc, (size_t)6 * c.per_rank); if (rc) return rc; }
   pgo::launch_coarse_correct(P->g, c, out, P->g.pipe_seg, out2, P->stream);
   return PGO_OK;
@@ -60,9 +60,10 @@ int coarse_setup(pgo_problem* P) {
 // one product launch of the owner-only CG (+ its fold): from the symmetric tile form where the session keeps its blocks there
 static int pipe_cg_launch(pgo_problem* P, const pgo::CgParams& prm, int seq, unsigned long long gseq = 0, bool last_of_batch = false) {
   if (P->sym_storage) pgo::launch_pipe_cg_sym(sym_view(P), P->sym, prm, seq, P->stream, gseq, last_of_batch);
-  else pgo::launch_pipe_cg(P->g, prm, seq, 0, P->stream, gseq);
-  // coarse level: the launch left m_J = M_J^-1 w of its rows in the buffer the next launch reads; add P (P'AP)^-1 P' w
-  if (P->coarse_on) return coarse_apply(P, P->g.cg_w, P->g.pipe_buf[(seq & 1) ^ 1], nullptr);
+  else pgo::launch_pipe_cg(P->g, prm, seq, 0, P->stream, gseq, !P->coarse_on);
+  // coarse level: the launch left m_J = M_J^-1 w of its rows in the buffer the next launch reads; add P (P'AP)^-1 P' w (the restriction's
+  // launch folds the CG launch's partial sums too)
+  if (P->coarse_on) return coarse_apply(P, P->g.cg_w, P->g.pipe_buf[(seq & 1) ^ 1], nullptr, seq);
   return PGO_OK;
 }
 
@@ -214,7 +215,7 @@ int pcg_begin(pgo_problem* P, const pgo::CgParams& prm) {
   }
   pgo::launch_pipe_init(P->g, s);
   // coarse level: u0 = M^-1 r0 gets its coarse part too (r0 = b; into the exchange buffer the first product reads and into u)
-  if (P->coarse_on) { int rcc = coarse_apply(P, P->g.cg_r, P->g.pipe_buf[0], P->g.cg_u); if (rcc) return rcc; }
+  if (P->coarse_on) { int rcc = coarse_apply(P, P->g.cg_r, P->g.pipe_buf[0], P->g.cg_u, -1); if (rcc) return rcc; }
   if (P->g.peer_tab) {       // device-initiated exchange: the kernels store into every rank's buffer and signal each other
     pgo::launch_peer_signal(P->g, ++P->peer_gseq, s);
     return pipe_cg_launch(P, prm, 0, ++P->peer_gseq);
