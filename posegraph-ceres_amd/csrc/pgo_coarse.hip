@@ -68,18 +68,23 @@ __global__ __launch_bounds__(256) void k_coarse_basis(DeviceGraph g, CoarsePlan 
 // Ac[6 a .., 6 a(j) ..] — the diagonal slot holds H~_ii + D^2 after the damping, every edge has a slot in each of its rows, so the
 // panel is complete without a transpose.  64 slots per pass, one per lane (its 6 x 6 product in registers: one round trip of loads
 // per pass); the 36 entry lanes then add the pass's products into the LDS panel in slot order: a fixed order, no atomics.
-__global__ __launch_bounds__(64) void k_coarse_galerkin(DeviceGraph g, CoarsePlan c) {
-  extern __shared__ double lds[];      // panel[6][npad] | stage[64][37]
+// NT lanes (64 or 256: as many as the LDS left by the panel allows) = NT slots per pass: the products are latency (slot words -> blocks and the
+// two P~ -> 6 x 6 x 6 x 2 multiply-adds), so four waves of them at once are four times the rate; the adding-up stays with 36 lanes of wave 0.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_coarse_galerkin(DeviceGraph g, CoarsePlan c) {
+  extern __shared__ double lds[];      // panel[6][npad] | stage[NT][37]
   double* panel = lds;
   double* stage = lds + (size_t)6 * c.npad;
-  __shared__ int scol[64];
+  __shared__ int scol[NT];
   const int a = c.a_lo + blockIdx.x, lane = threadIdx.x;
   int v0, v1;
   agg_range(g, c, a, v0, v1);
-  for (int i = lane; i < 6 * c.npad; i += 64) panel[i] = 0.0;
+  for (int i = lane; i < 6 * c.npad; i += NT) panel[i] = 0.0;
+  const int p_ent = lane / 6, q_ent = lane - 6 * p_ent;      // the entry (of a 6 x 6 product) lanes 0 .. 35 add up
+  double own = 0.0;
   const int t_begin = v1 > v0 ? g.row_slot_begin[v0] : 0, t_end = v1 > v0 ? g.row_slot_begin[v1 - 1] + g.row_slot_cnt[v1 - 1] : 0;
   __syncthreads();
-  for (int t0 = t_begin; t0 < t_end; t0 += 64) {
+  for (int t0 = t_begin; t0 < t_end; t0 += NT) {
     const int t = t0 + lane;
     int col = -1;
     double C[36];
@@ -95,12 +100,14 @@ __global__ __launch_bounds__(64) void k_coarse_galerkin(DeviceGraph g, CoarsePla
 #pragma unroll
         for (int k = 0; k < 36; ++k) Pj[k] = pj[k];
         const double* pi = c.Pt + (size_t)36 * row;
+        double Bf[36];
+        bsr_block_full(g, t, side, Bf);
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
           double T[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
           for (int k = 0; k < 6; ++k) {
-            const double b = bsr_elem(g, t, side, 6 * r + k);
+            const double b = Bf[6 * r + k];
 #pragma unroll
             for (int q = 0; q < 6; ++q) T[q] += b * Pj[6 * k + q];
           }
@@ -115,21 +122,32 @@ __global__ __launch_bounds__(64) void k_coarse_galerkin(DeviceGraph g, CoarsePla
         col = -1;
       }
     }
-    scol[lane] = col;
+    // (the slot's lane works out where its product goes — the division by the aggregate size does not belong in the serial loop below)
+    scol[lane] = col < 0 ? -1 : 6 * agg_of(g, c, col);
 #pragma unroll
     for (int k = 0; k < 36; ++k) stage[lane * 37 + k] = C[k];
     __syncthreads();
     if (lane < 36) {
-      const int p = lane / 6, q = lane - 6 * p;
-      for (int sidx = 0; sidx < 64; ++sidx) {
-        const int cj = scol[sidx];
-        if (cj < 0) continue;
-        panel[(size_t)p * c.npad + 6 * agg_of(g, c, cj) + q] += stage[sidx * 37 + lane];
+      // the pass's products in slot order; the ones for the aggregate's OWN diagonal block (most of them: the diagonal slots, the odometry
+      // edges) are added up in a register, the others go to their columns of the LDS panel: a third of the dependent LDS round trips
+      const int own_t = 6 * a;
+      for (int s4 = 0; s4 < NT; s4 += 4) {
+        int tj[4];
+        double sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { tj[u] = scol[s4 + u]; sv[u] = stage[(s4 + u) * 37 + lane]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (tj[u] == own_t) own += sv[u];
+          else if (tj[u] >= 0) panel[(size_t)p_ent * c.npad + tj[u] + q_ent] += sv[u];
+        }
       }
     }
     __syncthreads();
   }
-  for (int i = lane; i < 6 * c.npad; i += 64) {
+  if (lane < 36) panel[(size_t)p_ent * c.npad + 6 * a + q_ent] += own;      // (nothing else was added there)
+  __syncthreads();
+  for (int i = lane; i < 6 * c.npad; i += NT) {
     const int p = i / c.npad, j = i - p * c.npad;
     double v = panel[i];
     if (j == 6 * a + p && !(v > 0.0)) v = 1.0;          // an aggregate of constant blocks only, or an empty one behind a rank's last row: identity row
@@ -283,10 +301,17 @@ __global__ __launch_bounds__(256) void k_coarse_correct(DeviceGraph g, CoarsePla
 
 void launch_coarse_galerkin(const DeviceGraph& g, const CoarsePlan& c, hipStream_t s) {
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_coarse_galerkin), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
+  const size_t lds_max = 160 * 1024 - 2048;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_coarse_galerkin<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_coarse_galerkin<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    attr_set = true;
+  }
   hipLaunchKernelGGL(k_coarse_basis, dim3(c.n_agg), dim3(256), 0, s, g, c);
-  const size_t lds = ((size_t)6 * c.npad + 64 * 37) * sizeof(double);
-  if (c.a_hi > c.a_lo) hipLaunchKernelGGL(k_coarse_galerkin, dim3(c.a_hi - c.a_lo), dim3(64), lds, s, g, c);
+  if (c.a_hi <= c.a_lo) return;
+  const size_t lds256 = ((size_t)6 * c.npad + 256 * 37) * sizeof(double) + 256 * sizeof(int), lds64 = ((size_t)6 * c.npad + 64 * 37) * sizeof(double);
+  if (lds256 <= lds_max) hipLaunchKernelGGL(k_coarse_galerkin<256>, dim3(c.a_hi - c.a_lo), dim3(256), lds256 - 256 * sizeof(int), s, g, c);
+  else hipLaunchKernelGGL(k_coarse_galerkin<64>, dim3(c.a_hi - c.a_lo), dim3(64), lds64, s, g, c);
 }
 void launch_coarse_invert(const CoarsePlan& c, hipStream_t s) {
   if (c.npad > c.cdim) hipLaunchKernelGGL(k_coarse_pad, dim3(c.npad - c.cdim, (c.npad + 255) / 256), dim3(256), 0, s, c);

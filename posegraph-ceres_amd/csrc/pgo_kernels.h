@@ -260,6 +260,30 @@ __device__ __forceinline__ double bsr_elem(const DeviceGraph& g, int slot, int s
   return p < 0 ? 0.0 : g.bsr_val[bsr_index(slot, p)];
 }
 
+// the whole 6 x 6 block of a slot, row-major, with ALL loads issued before the side is looked at (bsr_elem's loads sit behind its
+// branches: 36 dependent round trips where this is one — k_coarse_galerkin spent most of its time there)
+__device__ __forceinline__ void bsr_block_full(const DeviceGraph& g, int slot, int side, double (&B)[36]) {
+  const double2* bp = reinterpret_cast<const double2*>(g.bsr_val + (size_t)(slot >> 6) * TILE_DOUBLES + (size_t)(slot & 63) * 2);
+  if (!g.blk_packed) {
+#pragma unroll
+    for (int k = 0; k < BLK_PAIRS_FULL; ++k) { const double2 v = bp[(size_t)k * 64]; B[2 * k] = v.x; B[2 * k + 1] = v.y; }
+    return;
+  }
+  double el[2 * BLK_PAIRS_PACKED];
+#pragma unroll
+  for (int k = 0; k < BLK_PAIRS_PACKED; ++k) { const double2 v = bp[(size_t)k * 64]; el[2 * k] = v.x; el[2 * k + 1] = v.y; }
+  const bool is_end = side == SIDE_END, is_diag = side == SIDE_DIAG;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      B[6 * r + cc] = el[3 * r + cc];                                            // top-left
+      B[6 * (r + 3) + cc + 3] = el[9 + 3 * r + cc];                              // bottom-right
+      B[6 * (r + 3) + cc] = is_end ? 0.0 : el[18 + 3 * r + cc];                  // bottom-left (BEGIN, DIAG)
+      B[6 * r + cc + 3] = is_end ? el[18 + 3 * r + cc] : is_diag ? el[18 + 3 * cc + r] : 0.0;      // top-right (END; DIAG: the mirror)
+    }
+}
+
 // ---- batched solve of independent graphs (pgo_solve_batch): the graphs are the components of one block-diagonal problem;
 // poses and edges of component c are the contiguous ranges [pose_begin[c], pose_begin[c+1]) / [edge_begin[c], edge_begin[c+1]).
 // Every LM scalar exists once per component. ----
