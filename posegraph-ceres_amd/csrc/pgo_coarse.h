@@ -5,7 +5,7 @@
 // block Jacobi alone misses the long-wavelength correction a pose graph needs from dead reckoning (BASELINE configs[1]: truncated PCG
 // ends 11 % above the exact path's cost); with the coarse level the same forcing term ends 5.6 % BELOW it, at the same CG work.
 //   per LM iteration:  k_coarse_basis (P~ per pose) -> k_coarse_galerkin (P~' A P~, one work-group per aggregate row panel, fixed
-//                      summation order) -> explicit inverse by block Gauss-Jordan (16 x 16 pivot blocks, two launches per block)
+//                      summation order) -> explicit inverse by block Gauss-Jordan (32 x 32 pivot blocks, one launch per block, between two copies of the matrix)
 //   per application:   k_coarse_restrict (rc = P~' w, one work-group per aggregate) -> k_coarse_correct (xc = Ainv rc for the
 //                      aggregate's six rows, out += P~ xc for its poses)
 // Incidence-slot storage, the one-launch pipelined CG iteration (k_pipe_cg) with the correction between the launches.  Several ranks (row
@@ -23,18 +23,19 @@ struct CoarsePlan {
   int per_rank;     // aggregates per rank segment (one rank: n_agg)
   int a_lo, a_hi;   // the aggregates of THIS rank's rows: it forms their row panels of the Galerkin matrix and their entries of a restriction
   int cdim;         // 6 * n_agg
-  int npad;         // cdim rounded up to a multiple of 16: order of the stored matrix (identity on the padding)
+  int npad;         // cdim rounded up to a multiple of the pivot block (32): order of the stored matrix (identity on the padding)
   double* Pt;       // [N][36] P~ of every pose, row-major (row = fine component, column = mode)
-  double* Ac;       // [npad][npad] Galerkin matrix, then its inverse
-  double* piv;      // [16][16] inverse of the current pivot block
-  double* row;      // [16][npad] pivot row panel of the current step | [npad][16] the old pivot column panel
+  double* Ac;       // [npad][npad] Galerkin matrix (several ranks: all-gathered row panels)
+  double* Ac2;      // [npad][npad] the other copy: a step of the inversion reads one and writes the other
+  double* Ainv;     // = Ac or Ac2: where the last step leaves the inverse
   double* rc;       // [npad] restricted vector
   const int* rank_end;   // several ranks: [world] one past the last REAL row of every rank's segment (device numbering; the rows behind it pad the segment)
 };
 
 // setup in two halves around the all-gather of the Galerkin matrix's row panels (several ranks; one rank calls them back to back)
 void launch_coarse_galerkin(const DeviceGraph& g, const CoarsePlan& c, hipStream_t s);     // P~ of every pose, the row panels of this rank's aggregates
-void launch_coarse_invert(const CoarsePlan& c, hipStream_t s);                            // identity on empty / padding rows, explicit inverse in place
+void launch_coarse_invert(const CoarsePlan& c, hipStream_t s);                            // identity on empty / padding rows, explicit inverse into c.Ainv
+int coarse_pivot_block();                                                                 // 32: npad is a multiple of it
 // application in two halves around the all-gather of the restricted vector:
 // rc of this rank's aggregates = P~' vec; fold_seq >= 0: the launch also folds the partial sums of the CG launch `fold_seq` (k_pipe_fold's job)
 void launch_coarse_restrict(const DeviceGraph& g, const CoarsePlan& c, const double* vec, hipStream_t s, int fold_seq = -1);

@@ -162,74 +162,132 @@ __global__ void k_coarse_pad(CoarsePlan c) {
   if (j < c.cdim) c.Ac[(size_t)j * c.npad + i] = 0.0;
 }
 
-// ---- explicit inverse, in place: block Gauss-Jordan without pivoting (the matrix is symmetric positive definite), 16 x 16 blocks.
-// Step k, with K = the k-th block of rows / columns:   W = A_KK^-1;   R = W A_K:   (pivot kernel, one work-group)
-//   rows i not in K:  A_i: -= A_iK R (columns not in K),  A_iK = -A_iK W;      rows K:  A_K: = R (columns not in K),  A_KK = W   (update kernel)
-constexpr int GJ = 16;
-// (every work-group of the launch inverts the pivot block for itself — sixteen elimination steps in LDS — and forms ITS 256 columns of
-// R; work-group 0 also leaves W for the update kernel)
-__global__ __launch_bounds__(256) void k_coarse_gj_pivot(CoarsePlan c, int k) {
-  __shared__ double M[GJ][GJ + 1], W[GJ][GJ + 1];
-  const int tid = threadIdx.x, i = tid / GJ, j = tid % GJ, n = c.npad, K0 = GJ * k;
-  const int col = 256 * blockIdx.x + tid;
-  double av[GJ];
-#pragma unroll
-  for (int m = 0; m < GJ; ++m) av[m] = c.Ac[(size_t)(K0 + m) * n + min(col, n - 1)];
-  M[i][j] = c.Ac[(size_t)(K0 + i) * n + K0 + j];
-  W[i][j] = i == j ? 1.0 : 0.0;
-  __syncthreads();
-  for (int p = 0; p < GJ; ++p) {
-    const double ip = 1.0 / M[p][p];
-    const double f = M[i][p] * ip;
-    const double mp = M[p][j], wp = W[p][j];
-    __syncthreads();
-    if (i == p) { M[i][j] = mp * ip; W[i][j] = wp * ip; }
-    else { M[i][j] -= f * mp; W[i][j] -= f * wp; }
-    __syncthreads();
-  }
-  if (blockIdx.x == 0) c.piv[i * GJ + j] = W[i][j];
-  if (col < n) {
-#pragma unroll
-    for (int ii = 0; ii < GJ; ++ii) {
-      double acc = 0.0;
-#pragma unroll
-      for (int m = 0; m < GJ; ++m) acc += W[ii][m] * av[m];
-      c.row[(size_t)ii * n + col] = acc;
-    }
-    // the OLD column panel A_:K of this work-group's 256 rows, for the update kernel: there the work-group that holds block K of a strip
-    // rewrites A_iK while the strip's other work-groups still want the old one — they read this copy instead
-    const double2* src = reinterpret_cast<const double2*>(c.Ac + (size_t)col * n + K0);
-    double2* dstp = reinterpret_cast<double2*>(c.row + (size_t)GJ * n + (size_t)col * GJ);
-#pragma unroll
-    for (int m = 0; m < GJ / 2; ++m) dstp[m] = src[m];
-  }
+// ---- explicit inverse: block Gauss-Jordan without pivoting (the matrix is symmetric positive definite), 32 x 32 pivot blocks, ONE launch
+// per step, from one copy of the matrix into the other (src -> dst: nothing a work-group reads is written by the launch).  Step k, with K
+// the k-th block of rows / columns, W = A_KK^-1 and R = W A_K: (the pivot rows times W):
+//   rows i not in K:  A_i: -= A_iK R (columns not in K),  A_iK = -A_iK W;      rows K:  A_K: = R (columns not in K),  A_KK = W
+// A work-group owns a 32-row strip x 64 GJ_NT columns (a wave GJ_NT 16-column tiles).  Every work-group inverts the pivot block for
+// itself — its 1024 entries in registers, four per lane; per elimination step the pivot row and column go through LDS buffers (by step
+// parity) behind ONE barrier — and forms R for its columns on the matrix cores from the pivot rows (v_mfma_f64_16x16x4: A operand = W from
+// LDS, B operand = the pivot rows' entries in the layout the instruction wants); R's accumulators ARE the B operand of the update
+// (D layout row (l >> 4) + 4 r = k index 4 s + (l >> 4) of step s = r: pgo_front_kernels.hip uses the same identity), A operand = the
+// strip's negated column panel from LDS, accumulator preloaded with the strip's old entries.  Redundant arithmetic instead of a
+// hand-over between launches: until r06's last day a step was two launches of 16 x 16 blocks (pivot + row panel | update: 59 steps x
+// (10.3 + 8.1) us = 1.08 ms per LM iteration at BASELINE configs[1] with aggregates of 64) that handed the inverse and two panels over
+// through memory.
+typedef double cg_double4 __attribute__((ext_vector_type(4)));
+constexpr int PB = 32, PBL = PB + 2;
+// GJ_NT = 16-column tiles per wave: a work-group owns 32 rows x 64 GJ_NT columns.  FP64 MFMA is ~61 ns per instruction per SIMD: with four
+// tiles a wave spends 7.8 us on its 128 products (19.9 us per step at BASELINE configs[1], aggregates of 64), with two 3.9 (17.2 us) — as
+// long as the work-groups of a step still fit the chip at once, one per compute unit (450 work-groups of one tile per wave: 2.76 ms per LM iteration against 2.66 with 240 of two): the launcher picks the smallest that does.
+__device__ __forceinline__ double fast_rcp(double d) {       // v_rcp_f64 + two Newton steps: full precision without the division sequence
+  double x = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, x, 1.0);
+  x = fma(x, e, x);
+  e = fma(-d, x, 1.0);
+  return fma(x, e, x);
 }
-// grid (strips of 16 rows, chunks of 256 columns): the chunk's piece of the pivot row panel is staged in LDS once per work-group
-__global__ __launch_bounds__(256) void k_coarse_gj_update(CoarsePlan c, int k) {
-  __shared__ double Cb[GJ][GJ + 1], W[GJ][GJ + 1], Rs[GJ][256 + 1];
-  const int tid = threadIdx.x, ii = tid / GJ, jj = tid % GJ, n = c.npad, K0 = GJ * k, I0 = GJ * blockIdx.x, J0 = 256 * blockIdx.y;
-  const int ncol = min(256, n - J0);
-  W[ii][jj] = c.piv[ii * GJ + jj];
-  Cb[ii][jj] = c.row[(size_t)GJ * n + (size_t)(I0 + ii) * GJ + jj];      // the OLD A_iK of this strip (k_coarse_gj_pivot's copy: the chunk that holds block K rewrites the matrix's)
+template <int GJ_NT>
+__global__ __launch_bounds__(256) void k_coarse_gj_step(CoarsePlan c, int k, const double* __restrict__ src, double* __restrict__ dst) {
+  __shared__ __attribute__((aligned(16))) double Wl[PB][PBL], Cb[PB][PBL];
+  __shared__ double rowb[2][2 * PB], colb[2][PB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g4 = lane >> 4;
+  const int n = c.npad, K0 = PB * k, I0 = PB * blockIdx.x, J0 = 64 * GJ_NT * blockIdx.y + 16 * GJ_NT * wave;
+  const bool pivot_strip = I0 == K0;
+  // ---- everything the step reads, requested at once ----
+  double av[8][GJ_NT];          // av[s][t] = A[K0 + 4 s + g4][column li of tile t]: the pivot rows, B-operand layout
+  cg_double4 cv[2][GJ_NT];      // cv[h][t][r] = A[I0 + 16 h + g4 + 4 r][column li of tile t]: the strip's old entries, accumulator layout
+  bool on[GJ_NT], piv[GJ_NT];
 #pragma unroll
-  for (int m = 0; m < GJ; ++m) if (tid < ncol) Rs[m][tid] = c.row[(size_t)m * n + J0 + tid];
-  __syncthreads();
-  const bool pivot_strip = (int)blockIdx.x == k;
-  for (int u = 0; u * GJ < ncol; ++u) {
-    const int jl = GJ * u + jj, j = J0 + jl;
-    if (J0 + GJ * u == K0) continue;                        // block K of this strip: below
-    double* dst = c.Ac + (size_t)(I0 + ii) * n + j;
-    if (pivot_strip) { *dst = Rs[ii][jl]; continue; }
-    double acc = 0.0;
+  for (int t = 0; t < GJ_NT; ++t) {
+    const int col0 = J0 + 16 * t;
+    on[t] = col0 < n;
+    piv[t] = col0 >= K0 && col0 < K0 + PB;
+    const bool ld = on[t] && !piv[t];
+    const int cc = ld ? col0 + li : 0;
 #pragma unroll
-    for (int m = 0; m < GJ; ++m) acc += Cb[ii][m] * Rs[m][jl];
-    *dst -= acc;
+    for (int s = 0; s < 8; ++s) av[s][t] = ld ? src[(size_t)(K0 + 4 * s + g4) * n + cc] : 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cv[h][t][r] = (ld && !pivot_strip) ? src[(size_t)(I0 + 16 * h + g4 + 4 * r) * n + cc] : 0.0;
   }
-  if (K0 >= J0 && K0 < J0 + 256) {                          // this chunk holds block K: A_KK = W, A_iK = -A_iK W
-    double acc = 0.0;
+  const int gi = tid >> 3, gj0 = tid & 7;       // pivot block: this lane holds the entries (gi, gj0 + 8 t), t = 0 .. 3, of M and of W
+  double m[4], w[4];
 #pragma unroll
-    for (int m = 0; m < GJ; ++m) acc += Cb[ii][m] * W[m][jj];
-    c.Ac[(size_t)(I0 + ii) * n + K0 + jj] = pivot_strip ? W[ii][jj] : -acc;
+  for (int t = 0; t < 4; ++t) { m[t] = src[(size_t)(K0 + gi) * n + K0 + gj0 + 8 * t]; w[t] = gi == gj0 + 8 * t ? 1.0 : 0.0; }
+  for (int e = tid; e < PB * PB; e += 256) {
+    const int r = e / PB, q = e - PB * r;
+    Cb[r][q] = -src[(size_t)(I0 + r) * n + K0 + q];
+  }
+  // ---- W = M^-1 ----
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    const int par = p & 1;
+    if (gi == p) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { rowb[par][gj0 + 8 * t] = m[t]; rowb[par][PB + gj0 + 8 * t] = w[t]; }
+    }
+    if (gj0 == (p & 7)) colb[par][gi] = m[p >> 3];
+    __syncthreads();
+    const double ip = fast_rcp(rowb[par][p]);
+    const double f = colb[par][gi] * ip;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double mp = rowb[par][gj0 + 8 * t], wp = rowb[par][PB + gj0 + 8 * t];
+      if (gi == p) { m[t] = mp * ip; w[t] = wp * ip; }
+      else { m[t] = fma(-f, mp, m[t]); w[t] = fma(-f, wp, w[t]); }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) Wl[gi][gj0 + 8 * t] = w[t];
+  __syncthreads();
+  // ---- R = W A_K: for this wave's columns (pivot columns: R := W, the strip's old entries := 0 — the same update then gives -A_iK W) ----
+  double wa[2][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) wa[h][s] = Wl[16 * h + li][4 * s + g4];
+  cg_double4 R[2][GJ_NT];
+#pragma unroll
+  for (int t = 0; t < GJ_NT; ++t) {
+    if (piv[t]) {
+      const int q0 = J0 + 16 * t - K0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) R[h][t][r] = Wl[16 * h + g4 + 4 * r][q0 + li];
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        cg_double4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[h][s], av[s][t], acc, 0, 0, 0);
+        R[h][t] = acc;
+      }
+    }
+  }
+  // ---- the strip: A_i: - A_iK R (pivot strip: R itself) ----
+  if (!pivot_strip) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) wa[h][s] = Cb[16 * h + li][4 * s + g4];
+  }
+#pragma unroll
+  for (int t = 0; t < GJ_NT; ++t) {
+    if (!on[t]) continue;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      cg_double4 acc = cv[h][t];
+      if (pivot_strip) acc = R[h][t];
+      else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[h][s], R[s >> 2][t][s & 3], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(size_t)(I0 + 16 * h + g4 + 4 * r) * n + J0 + 16 * t + li] = acc[r];
+    }
   }
 }
 
@@ -275,7 +333,7 @@ __global__ __launch_bounds__(256) void k_coarse_correct(DeviceGraph g, CoarsePla
   for (int j = tid; j < c.cdim; j += 256) {
     const double r = c.rc[j];
 #pragma unroll
-    for (int p = 0; p < 6; ++p) acc[p] += c.Ac[(size_t)(6 * a + p) * c.npad + j] * r;
+    for (int p = 0; p < 6; ++p) acc[p] += c.Ainv[(size_t)(6 * a + p) * c.npad + j] * r;
   }
   block_sum<6>(acc, scratch);
   if (tid < 6) xc[tid] = acc[tid];
@@ -315,11 +373,18 @@ void launch_coarse_galerkin(const DeviceGraph& g, const CoarsePlan& c, hipStream
 }
 void launch_coarse_invert(const CoarsePlan& c, hipStream_t s) {
   if (c.npad > c.cdim) hipLaunchKernelGGL(k_coarse_pad, dim3(c.npad - c.cdim, (c.npad + 255) / 256), dim3(256), 0, s, c);
-  for (int k = 0; k < c.npad / GJ; ++k) {
-    hipLaunchKernelGGL(k_coarse_gj_pivot, dim3((c.npad + 255) / 256), dim3(256), 0, s, c, k);
-    hipLaunchKernelGGL(k_coarse_gj_update, dim3(c.npad / GJ, (c.npad + 255) / 256), dim3(256), 0, s, c, k);
+  // Ac -> Ac2 -> Ac ...: the inverse ends up in c.Ainv (lm_begin: whichever copy the last step writes)
+  const int steps = c.npad / PB;
+  for (int k = 0; k < steps; ++k) {
+    const double* src = (k & 1) ? c.Ac2 : c.Ac;
+    double* dst = (k & 1) ? c.Ac : c.Ac2;
+    auto wgs = [&](int nt) { return steps * ((c.npad + 64 * nt - 1) / (64 * nt)); };
+    if (wgs(1) <= 256) hipLaunchKernelGGL(k_coarse_gj_step<1>, dim3(steps, (c.npad + 63) / 64), dim3(256), 0, s, c, k, src, dst);
+    else if (wgs(2) <= 256) hipLaunchKernelGGL(k_coarse_gj_step<2>, dim3(steps, (c.npad + 127) / 128), dim3(256), 0, s, c, k, src, dst);
+    else hipLaunchKernelGGL(k_coarse_gj_step<4>, dim3(steps, (c.npad + 255) / 256), dim3(256), 0, s, c, k, src, dst);
   }
 }
+int coarse_pivot_block() { return PB; }
 void launch_coarse_restrict(const DeviceGraph& g, const CoarsePlan& c, const double* vec, hipStream_t s, int fold_seq) {
   hipLaunchKernelGGL(k_coarse_restrict, dim3(c.a_hi - c.a_lo + (fold_seq >= 0 ? 1 : 0)), dim3(256), 0, s, g, c, vec, fold_seq);
 }

@@ -476,7 +476,7 @@ struct pgo_problem {
   pgo::CoarsePlan coarse{};
   bool coarse_on = false;
   int force_block = 0;             // slots per work-group the topology has to be built with (0: choose_block's rule); a session with a coarse level asks for 256: whole pose pairs per work-group
-  DevBuf<double> dc_Pt, dc_Ac, dc_piv, dc_row, dc_rc;
+  DevBuf<double> dc_Pt, dc_Ac, dc_Ac2, dc_rc;
   DevBuf<int> dc_rank_end;
 
   // one process per GPU: the communicator of the row-sharded path (null = single rank)

@@ -106,16 +106,16 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
     c.a_lo = P->g.rank * c.per_rank; c.a_hi = c.a_lo + c.per_rank;
     if (P->g.peer_tab) { P->g.peer_tab = nullptr; P->g.peer_flags = nullptr; P->peer_dirty = true; }     // (the correction sits between a CG launch and its exchange: host-enqueued exchange)
     c.cdim = 6 * c.n_agg;
-    c.npad = (c.cdim + 15) / 16 * 16;
+    { const int pb = pgo::coarse_pivot_block(); c.npad = (c.cdim + pb - 1) / pb * pb; }
     if ((size_t)(6 * c.npad + 64 * 37) * sizeof(double) > 160 * 1024 - 2048)
       return set_error(PGO_ERR_UNSUPPORTED, "pcg_coarse_aggregate = %d gives %d aggregates: more than the coarse level's row panel holds (use larger aggregates)", c.agg, c.n_agg);
     HIP_TRY(P->dc_Pt.alloc((size_t)36 * P->g.N));
     HIP_TRY(P->dc_Ac.alloc((size_t)c.npad * c.npad));
-    HIP_TRY(P->dc_piv.alloc(256));
-    HIP_TRY(P->dc_row.alloc((size_t)32 * c.npad));
+    HIP_TRY(P->dc_Ac2.alloc((size_t)c.npad * c.npad));
     HIP_TRY(P->dc_rc.alloc((size_t)c.npad));
     HIP_TRY(P->dc_rc.zero(P->stream));
-    c.Pt = P->dc_Pt.p; c.Ac = P->dc_Ac.p; c.piv = P->dc_piv.p; c.row = P->dc_row.p; c.rc = P->dc_rc.p;
+    c.Pt = P->dc_Pt.p; c.Ac = P->dc_Ac.p; c.Ac2 = P->dc_Ac2.p; c.rc = P->dc_rc.p;
+    c.Ainv = ((c.npad / pgo::coarse_pivot_block()) & 1) ? c.Ac2 : c.Ac;
     c.rank_end = nullptr;
     if (P->g.world > 1) {
       std::vector<int> re((size_t)P->g.world);
