@@ -69,6 +69,16 @@ def _f64(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
 
 
+def set_coarse_cuts(cuts=None):
+    """Row shards for the two-level PCG (pcg_cluster <= -8): aggregates are formed inside every segment [cuts[r], cuts[r + 1]) — what the
+    product's sharded solve does (pgo_row_shard_cuts gives the cuts).  None: one segment.  Process-wide: reset it when done."""
+    if cuts is None:
+        lib().oracle_set_coarse_cuts(None, C.c_int(0))
+    else:
+        arr = (C.c_longlong * len(cuts))(*[int(c) for c in cuts])
+        lib().oracle_set_coarse_cuts(arr, C.c_int(len(cuts) - 1))
+
+
 def default_options(**kw):
     o = Options()
     lib().oracle_default_options(C.byref(o))

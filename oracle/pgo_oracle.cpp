@@ -1003,6 +1003,9 @@ struct RowEvents {
 // the Jacobi-scaled unknowns the CG works in (P~ = S^-1 P, rows of constant blocks zero).  Galerkin coarse matrix P~' (H~ + D^2) P~,
 // dense 6 A x 6 A, factored once per linear solve.  Selected by pcg_cluster = -agg (agg >= 8; -1 stays the chain).
 struct CoarseSpace { int agg; const double* poses; const double* scale; const uint8_t* cmask; };
+// Row shards (the product's sharded solve: aggregates never straddle ranks, csrc/pgo_coarse.h): the segments' first poses + the end, set by
+// pgo_oracle_set_coarse_cuts; empty = one segment.  Aggregate of pose v = (aggregates of the segments in front) + (v - segment start) / agg.
+static std::vector<long long> g_coarse_cuts;
 
 int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, double q_tol,
               int max_it, int min_it, int residual_reset_period, bool* ok, double* final_rnorm, int cluster = 1, Pool* pool = nullptr,
@@ -1023,15 +1026,25 @@ int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, d
   // ---- two-level: the coarse space and its Galerkin matrix ----
   const bool two_level = cluster <= -8 && cz != nullptr;
   int nagg = 0, cdim = 0;
-  const int ag = two_level ? -cluster : 1;
+  std::vector<int> aggof, agg_begin;   // aggregate of every pose; first pose of every aggregate (+ n)
   std::vector<double> Pt;              // P~ per pose: 6 x 6 row-major (row = fine component, column = mode of the pose's aggregate)
   std::vector<double> Ac;              // Cholesky factor of the coarse matrix
   if (two_level) {
     const int agg = -cluster;
-    nagg = (n + agg - 1) / agg; cdim = 6 * nagg;
+    std::vector<long long> cuts = g_coarse_cuts;
+    if (cuts.size() < 2 || cuts.front() != 0 || cuts.back() != n) cuts = {0, (long long)n};
+    agg_begin.clear(); aggof.assign((size_t)n, 0);
+    for (size_t sgm = 0; sgm + 1 < cuts.size(); ++sgm)
+      for (long long v0 = cuts[sgm]; v0 < cuts[sgm + 1]; v0 += agg) {
+        const long long v1 = std::min(cuts[sgm + 1], v0 + agg);
+        for (long long v = v0; v < v1; ++v) aggof[(size_t)v] = (int)agg_begin.size();
+        agg_begin.push_back((int)v0);
+      }
+    agg_begin.push_back(n);
+    nagg = (int)agg_begin.size() - 1; cdim = 6 * nagg;
     Pt.assign((size_t)36 * n, 0.0);
     for (int a = 0; a < nagg; ++a) {
-      const int v0 = a * agg, v1 = std::min(n, v0 + agg);
+      const int v0 = agg_begin[(size_t)a], v1 = std::min((int)n, std::min(agg_begin[(size_t)a + 1], v0 + agg));
       double c[3] = {0, 0, 0};
       for (int v = v0; v < v1; ++v) for (int k = 0; k < 3; ++k) c[k] += cz->poses[7 * (size_t)v + k] / (v1 - v0);
       for (int v = v0; v < v1; ++v) {
@@ -1050,7 +1063,7 @@ int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, d
     }
     Ac.assign((size_t)cdim * cdim, 0.0);
     auto add = [&](int i, int j, const double* B, bool with_d2) {      // Ac[a(i), a(j)] += P_i' B P_j  (B = block (i, j) of H~ + D^2)
-      const int ai = i / agg, aj = j / agg;
+      const int ai = aggof[(size_t)i], aj = aggof[(size_t)j];
       const double *Pi = &Pt[(size_t)36 * i], *Pj = &Pt[(size_t)36 * j];
       double BP[36];
       for (int r = 0; r < 6; ++r)
@@ -1166,13 +1179,13 @@ int pcg_solve(const BlockSym& H, const double* d2, const double* b, double* x, d
     if (two_level) {                   // + P (P' A P)^-1 P' r
       std::vector<double> rc(cdim, 0.0), xc(cdim, 0.0);
       for (int v = 0; v < n; ++v) {
-        const int a = v / ag;
+        const int a = aggof[(size_t)v];
         const double* Pv = &Pt[(size_t)36 * v];
         for (int q = 0; q < 6; ++q) { double acc = 0; for (int r = 0; r < 6; ++r) acc += Pv[6 * r + q] * rin[6 * (size_t)v + r]; rc[6 * a + q] += acc; }
       }
       chol_dense_solve(Ac, cdim, rc.data(), xc.data());
       for (int v = 0; v < n; ++v) {
-        const int a = v / ag;
+        const int a = aggof[(size_t)v];
         const double* Pv = &Pt[(size_t)36 * v];
         for (int r = 0; r < 6; ++r) { double acc = 0; for (int q = 0; q < 6; ++q) acc += Pv[6 * r + q] * xc[6 * a + q]; zout[6 * (size_t)v + r] += acc; }
       }
@@ -1315,6 +1328,13 @@ struct oracle_summary {
 //             trust_region_radius, linear_iterations, step_is_successful]
 enum { ORACLE_TRACE_COLS = 9 };
 
+// Row shards for the two-level PCG (pcg_cluster <= -8): cuts[0 .. world], cuts[0] = 0, cuts[world] = number of poses — aggregates are then
+// formed inside every segment [cuts[r], cuts[r + 1]) as the product's sharded solve forms them (csrc/pgo_coarse.h: they never straddle
+// ranks).  world <= 0 (or a mismatch with the problem's size): one segment.  Process-wide, like the checker it serves.
+void oracle_set_coarse_cuts(const long long* cuts, int world) {
+  g_coarse_cuts.clear();
+  if (cuts && world > 0) g_coarse_cuts.assign(cuts, cuts + world + 1);
+}
 void oracle_default_options(oracle_options* o) {
   o->max_num_iterations = 50;
   o->linear_solver = 0;

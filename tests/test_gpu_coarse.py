@@ -125,3 +125,29 @@ def test_coarse_level_on_ranks_at_a_size_where_launches_overlap(gpu, ds):
         assert np.array_equal(x, x0) and np.array_equal(s.iterations["cost"], s0.iterations["cost"])
     assert s0.final_cost == pytest.approx(one.final_cost, rel=2e-2)
     assert abs(s0.num_linear_solver_iterations - one.num_linear_solver_iterations) <= 0.25 * one.num_linear_solver_iterations
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_coarse_level_on_ranks_matches_the_oracle_with_the_same_segments(gpu, ds, O, world):
+    """The sharded solve against the oracle's two-level PCG with aggregates formed inside the same row shares (pgo_row_shard_cuts ->
+    oracle.set_coarse_cuts): the same preconditioner in the same recurrences — same accept / reject decisions, CG counts within one
+    iteration, costs to 1e-5, as on one rank."""
+    g = ds.manhattan_se3(1200, 4800, seed=5)
+    agg, its = 32, 30
+    cuts, rows_per = gpu.row_shard_cuts(g.N, g.ia, g.ib, world)
+    out = _virtual_ranks(gpu, g, world, dict(max_num_iterations=its, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2, pcg_coarse_aggregate=agg,
+                                             eta=0.1, max_linear_solver_iterations=500))
+    s = out[0][0]
+    og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
+    O.set_coarse_cuts(cuts)
+    try:
+        op, osum, otr = O.solve(og, O.default_options(max_num_iterations=its, linear_solver=1, pcg_cluster=-agg, pcg_form=1, eta=0.1, max_linear_solver_iterations=500))
+    finally:
+        O.set_coarse_cuts(None)
+    n = min(len(s.iterations), len(otr))
+    assert n >= 20
+    assert list(s.iterations["step_is_successful"][:n]) == [int(x) for x in otr[:n, 8]]
+    dcg = np.abs(np.asarray(s.iterations["linear_solver_iterations"][:n], dtype=int) - otr[:n, 7].astype(int))
+    assert dcg.max() <= 1 and (dcg == 0).mean() >= 0.8, dcg
+    assert np.allclose(s.iterations["cost"][:n], otr[:n, 1], rtol=1e-5)
+    assert np.abs(out[0][1] - op).max() < 1e-3

@@ -154,3 +154,28 @@ def test_two_level_preconditioner_reaches_the_exact_paths_cost(O, ds):
     _, jac, _ = O.solve(og, O.default_options(max_num_iterations=two.num_iterations - 1, pcg_cluster=2, **kw))
     assert jac.num_linear_iterations >= 3 * two.num_linear_iterations
     assert jac.final_cost > exact.final_cost * (1.0 + 1e-4)
+
+
+def test_two_level_pcg_with_row_shards_as_segments():
+    """oracle.set_coarse_cuts: aggregates formed inside row shares (what the product's sharded solve does).  One segment = the default; cut
+    anywhere the preconditioner stays a two-level one — same final cost, CG work within a quarter."""
+    from oracle import oracle as O
+    import pgo_loader
+    ds = pgo_loader.datasets()
+    g = ds.manhattan_se3(600, 2200, seed=11)
+    og = O.Graph(g.poses, g.ia, g.ib, g.meas, g.sqrt_info)
+    opt = dict(max_num_iterations=25, linear_solver=1, pcg_cluster=-24, pcg_form=1, eta=0.1, max_linear_solver_iterations=400)
+    _, s0, t0 = O.solve(og, O.default_options(**opt))
+    try:
+        O.set_coarse_cuts([0, g.N])
+        _, s1, t1 = O.solve(og, O.default_options(**opt))
+        assert np.array_equal(t0[:, 1], t1[:, 1]) and np.array_equal(t0[:, 7], t1[:, 7])
+        O.set_coarse_cuts([0, 200, 404, g.N])
+        _, s2, t2 = O.solve(og, O.default_options(**opt))
+        O.set_coarse_cuts([0, 7, g.N])                 # (a share smaller than an aggregate)
+        _, s3, t3 = O.solve(og, O.default_options(**opt))
+    finally:
+        O.set_coarse_cuts(None)
+    for s in (s2, s3):
+        assert s.final_cost == pytest.approx(s0.final_cost, rel=2e-3)
+    assert abs(t2[:, 7].sum() - t0[:, 7].sum()) <= 0.25 * t0[:, 7].sum()

@@ -1,7 +1,8 @@
 """Randomised sweep of the PCG's coarse level (csrc/pgo_coarse.hip, options.pcg_coarse_aggregate): random graphs (tools/fuzz_sym.py's
 generator: lattice walks, random chords, hubs, duplicate edges), random information kinds, constant blocks, losses, aggregate sizes —
 (a) one rank against the oracle's two-level PCG in the same recurrences (decisions, CG counts within one per LM iteration, costs),
-(b) 2 .. 5 virtual ranks of one GPU: bit-identical among themselves, run to run, and with the one-rank solve's
+(b) 2 .. 5 virtual ranks of one GPU: bit-identical among themselves, run to run, held to the oracle with aggregates inside the same row shares
+(oracle.set_coarse_cuts) like (a), and with the one-rank solve's
 the same start and comparable progress (other aggregate boundaries: another truncated step from the first iteration on), (c) a refusal is a refusal (PgoError), never a
 silent solve without the level.  Prints every mismatch.      usage (GPU box): python tools/fuzz_coarse.py [n_cases] [first_seed]"""
 import os
@@ -113,6 +114,24 @@ def main(n_cases=60, first=0):
             # (six LM iterations in: a rejected step on one side is a factor of ten — seeds 1079, 1189 agree once converged; this catches a solve gone wrong)
             if not (s0.final_cost <= 20.0 * s1.final_cost + 1e-9 and s1.final_cost <= 20.0 * s0.final_cost + 1e-9):
                 why.append("%d ranks: final cost %.6e vs one rank %.6e" % (world, s0.final_cost, s1.final_cost))
+            # ... and against the oracle with aggregates formed inside the same row shares
+            cuts, _ = pkg.row_shard_cuts(g.N, g.ia, g.ib, world)
+            O.set_coarse_cuts(cuts)
+            try:
+                _, _, otr2 = O.solve(og, O.default_options(max_num_iterations=NIT, linear_solver=1, pcg_cluster=-agg, pcg_form=1, eta=0.1, max_linear_solver_iterations=300,
+                                                           loss_kind=loss, loss_a=loss_a))
+            finally:
+                O.set_coarse_cuts(None)
+            n2 = min(len(s0.iterations), len(otr2))
+            if list(s0.iterations["step_is_successful"][:n2]) != [int(x) for x in otr2[:n2, 8]]:
+                why.append("%d ranks: decisions differ from the oracle's (same segments)" % world)
+            else:
+                a2 = np.asarray(s0.iterations["linear_solver_iterations"][:n2], dtype=int)
+                b2 = otr2[:n2, 7].astype(int)
+                if np.abs(a2 - b2).max() > np.maximum(1, b2 // 50).max():
+                    why.append("%d ranks: CG counts %s vs oracle %s" % (world, a2, b2))
+                if not np.allclose(s0.iterations["cost"][:n2], otr2[:n2, 1], rtol=np.where(otr2[:n2, 8] > 0, 1e-5, 1e-3), atol=1e-12):
+                    why.append("%d ranks: costs %s vs oracle %s" % (world, s0.iterations["cost"][:n2], otr2[:n2, 1]))
             fixed = np.nonzero(cmask == 3)[0]
             if not (np.isfinite(x0).all() and np.array_equal(x0[fixed], g.poses[fixed])):
                 why.append("constant pose moved / non-finite on ranks")
