@@ -837,6 +837,8 @@ def main():
                       ("one graph, pose rows sharded over %d ranks (one process per GPU), " % world + (
                           ("pipelined CG: every rank updates its own rows, the kernels exchange their segments themselves (stores into every rank's "
                            "IPC-mapped buffer + flags, no host-enqueued collective per CG iteration)" if summary.cg_exchange == 2 else
+                           "pipelined CG: every rank updates its own rows, 1 RCCL all-gather over xGMI per CG iteration, of the ranks' boundary rows only "
+                           "(rows with an edge to another rank: ~5 % of the rows at 8 ranks) + three sums each" if summary.cg_exchange == 3 else
                            "pipelined CG: every rank updates its own rows, 1 RCCL all-gather over xGMI per CG iteration") if summary.cg_form == 2 else
                           "replicated standard CG: every rank updates every row, q all-gathered over xGMI per CG iteration (the owner-only form was not usable: PGO_SHARD_PIPE=0, captured graphs or 4-pose clusters)")) if sharded else
                       "replicas: 1 independent graph per GPU, no data-path collective"),

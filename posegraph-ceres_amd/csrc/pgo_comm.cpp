@@ -43,6 +43,7 @@ struct LoopbackComm : Comm {
   LoopbackGroup* g;
   explicit LoopbackComm(LoopbackGroup* group, int r) : g(group) { world = group->world; rank = r; }
   bool capturable() const override { return false; }
+  void give_up() override { g->abort(); }
   int fail(const char** what, const char* where, hipError_t e) {
     static thread_local char msg[256];
     snprintf(msg, sizeof msg, "%s: %s", where, hipGetErrorString(e));

@@ -35,6 +35,9 @@ struct Comm {
   // whether the peers of peer_table() may be OTHER devices (processes, one GPU each): their exchange buffers and flag words must then be
   // fine-grained allocations (pgo_internal.h DevBuf::alloc_fine); virtual ranks share one device and its L2
   virtual bool peers_may_be_remote() const { return false; }
+  // this rank gives up (its solve failed outside a collective): peers waiting for it in one must not wait for ever.  The in-process
+  // transport releases its barriers; RCCL / IPC ranks are processes — their launcher's watchdog is what ends them (bench.py).
+  virtual void give_up() {}
 };
 
 struct LoopbackGroup {

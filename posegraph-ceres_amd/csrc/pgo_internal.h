@@ -459,7 +459,9 @@ struct pgo_problem {
   double sym_interior_fraction = 0.0;
   long long sym_stored_slots = 0;
   DevBuf<pgo::SymTile> sy_tile;
-  DevBuf<int> sy_xlist, sy_chunk_base, sy_chunk_n, sy_src, sy_diag;
+  DevBuf<int> sy_xlist, sy_chunk_base, sy_chunk_n, sy_src, sy_diag, sy_xoff, sy_brow;
+  bool sym_boundary_ready = false;     // the lists of the boundary exchange exist for this topology
+  DevBuf<double> sy_xb0, sy_xb1;       // boundary exchange of the sharded symmetric-form CG (pgo_sym.h SymGraph::xb)
   bool sym_stale = true;            // the off-diagonal blocks were rewritten since the last repack (else only the damped diagonal slots are copied)
   DevBuf<uint32_t> sy_meta, sy_rinfo;
   bool sym_storage = false;         // this LM session keeps the normal equations in the symmetric tile form ONLY: linearisation, damping, the cluster

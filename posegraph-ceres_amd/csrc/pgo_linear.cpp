@@ -57,6 +57,13 @@ int coarse_setup(pgo_problem* P) {
   pgo::launch_coarse_invert(c, P->stream);
   return PGO_OK;
 }
+// several ranks on the symmetric form, host-enqueued exchange: only the ranks' boundary rows (+ three sums each) travel per CG iteration
+// (pgo_sym.h SymGraph::xb; 5 % of the rows of BASELINE configs[3] on 8 ranks), the full-layout buffer stays the rank's own
+static bool boundary_exchange(const pgo_problem* P) { return P->sym_storage && P->g.world > 1 && P->sym.xb[0] != nullptr; }
+static int pipe_exchange(pgo_problem* P, int buf) {
+  if (boundary_exchange(P)) return exchange(P, P->sym.xb[buf], (size_t)P->sym.cseg);
+  return exchange(P, P->g.pipe_buf[buf], (size_t)P->g.pipe_seg);
+}
 // one product launch of the owner-only CG (+ its fold): from the symmetric tile form where the session keeps its blocks there
 static int pipe_cg_launch(pgo_problem* P, const pgo::CgParams& prm, int seq, unsigned long long gseq = 0, bool last_of_batch = false) {
   if (P->sym_storage) pgo::launch_pipe_cg_sym(sym_view(P), P->sym, prm, seq, P->stream, gseq, last_of_batch);
@@ -127,9 +134,14 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool wi
       if (P->g.peer_tab) { int rcp = pipe_cg_launch(P, prm, seq, ++P->peer_gseq); if (rcp) return rcp; continue; }
       int rc = pipe_cg_launch(P, prm, seq, 0, i == batch - 1);
       if (rc) return rc;
-      rc = exchange(P, P->g.pipe_buf[(seq & 1) ^ 1], (size_t)P->g.pipe_seg);
+      rc = pipe_exchange(P, (seq & 1) ^ 1);
       if (rc) return rc;
     }
+    if (boundary_exchange(P)) {      // (the stop-test launch reads nothing but every rank's three sums: at the end of the boundary segments)
+      pgo::DeviceGraph ga = P->g;
+      ga.pipe_buf[0] = P->sym.xb[0]; ga.pipe_buf[1] = P->sym.xb[1]; ga.pipe_seg = P->sym.cseg; ga.rows_per = (P->sym.cseg - 4) / 6;
+      pgo::launch_pipe_cg(ga, prm, start_it + batch, with_tail ? 2 : 1, s);
+    } else
     pgo::launch_pipe_cg(P->g, prm, start_it + batch, with_tail ? 2 : 1, s);    // the stop test of the last iteration; without a tail also the hand-over
     return with_tail ? enqueue_tail(P, &prm) : PGO_OK;
   }
@@ -220,11 +232,12 @@ int pcg_begin(pgo_problem* P, const pgo::CgParams& prm) {
     pgo::launch_peer_signal(P->g, ++P->peer_gseq, s);
     return pipe_cg_launch(P, prm, 0, ++P->peer_gseq);
   }
-  int rc = exchange(P, P->g.pipe_buf[0], (size_t)P->g.pipe_seg);
+  if (boundary_exchange(P)) pgo::launch_pipe_pack(sym_view(P), P->sym, 0, -1, s);      // u0 of the rank's boundary rows into its segment
+  int rc = pipe_exchange(P, 0);
   if (rc) return rc;
   rc = pipe_cg_launch(P, prm, 0);
   if (rc) return rc;
-  return exchange(P, P->g.pipe_buf[1], (size_t)P->g.pipe_seg);
+  return pipe_exchange(P, 1);
 }
 
 int run_pcg(pgo_problem* P, const pgo::CgParams& prm, int batch, int* iterations, int* status) {

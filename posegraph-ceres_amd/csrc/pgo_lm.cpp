@@ -871,7 +871,7 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
   }
   if (summary) {
     memset(summary, 0, sizeof *summary);
-    summary->cg_exchange = P->g.world > 1 ? (P->g.peer_tab && pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : 0;
+    summary->cg_exchange = P->g.world > 1 ? (P->g.peer_tab && pipe_mode(P, cg_params_for(P->opt)) ? 2 : (P->sym_storage && P->sym.xb[0] && pipe_mode(P, cg_params_for(P->opt))) ? 3 : 1) : 0;
     summary->cg_form = P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : (P->uni_resident ? 4 : P->uni_fused ? 3 : pipe_mode(P, cg_params_for(P->opt)) ? 2 : 0);
     summary->sym_form = P->sym_storage ? 1 : 0;
     summary->coarse_level = P->coarse_on ? P->coarse.n_agg : 0;
@@ -996,10 +996,10 @@ int pgo_solve(pgo_problem* P, const pgo_solver_options* options, pgo_solver_summ
               pgo_iteration_record* records, int capacity) {
   if (!P || !options) return set_error(PGO_ERR_INVALID_ARGUMENT, "null argument to pgo_solve");
   int rc = lm_begin(P, options);
-  if (rc) return rc;
+  if (rc) { if (P->comm) P->comm->give_up(); return rc; }       // (peers of an in-process group must not wait for this rank in a collective)
   while (!P->lm.terminated) {
     rc = P->universal ? lm_run_universal(P, -1, nullptr) : P->pipelined ? lm_run_pipelined(P, -1, nullptr) : lm_advance(P);
-    if (rc) { P->lm.active = false; return rc; }   // caller memory keeps the poses it came with; the session is closed
+    if (rc) { P->lm.active = false; if (P->comm) P->comm->give_up(); return rc; }   // caller memory keeps the poses it came with; the session is closed
   }
   return lm_end(P, summary, records, capacity);
 }

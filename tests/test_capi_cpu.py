@@ -145,7 +145,7 @@ def test_tuning_knobs_replace_sixteen_environment_variables(pkg):
     """r06: the library's development / test switches are knobs behind pgo_tuning_set (csrc/pgo_tuning.h), not
     environment variables: set / read back / default / unknown name."""
     knobs = pkg.tuning_knobs()
-    assert len(knobs) == 15 and all(len(w) > 10 for w in knobs.values())
+    assert len(knobs) == 16 and all(len(w) > 10 for w in knobs.values())
     for k in knobs:
         assert pkg.tuning_get(k) is None                  # all at their defaults
     pkg.tuning_set("sym_rows", 64)

@@ -102,7 +102,7 @@ def test_sharded_ranks_keep_the_form_of_their_rows(gpu, ds, O, world, direct, in
     out = _virtual_ranks(gpu, g, world, opt)
     op, osum, otr = _oracle(O, g, 8, 2)
     for s, x in out:
-        assert s.cg_form == 2 and s.sym_form == 1 and s.cg_exchange == (2 if direct else 1)
+        assert s.cg_form == 2 and s.sym_form == 1 and s.cg_exchange == (2 if direct else 3)      # (3: the host-enqueued exchange carries boundary rows only)
         _same_path(s, otr)
         assert np.array_equal(x, out[0][1])                     # all ranks bit-identical
         assert np.array_equal(s.iterations["cost"], out[0][0].iterations["cost"])
@@ -116,3 +116,38 @@ def test_sharded_ranks_keep_the_form_of_their_rows(gpu, ds, O, world, direct, in
     assert list(one.iterations["linear_solver_iterations"]) == list(out[0][0].iterations["linear_solver_iterations"])
     assert np.allclose(one.iterations["cost"], out[0][0].iterations["cost"], rtol=1e-8)
     assert np.abs(poses1 - out[0][1]).max() < 1e-6
+
+
+def test_boundary_exchange_carries_the_same_bits_as_whole_segments(gpu, ds, monkeypatch, knobs):
+    """Sharded symmetric-form sessions, host-enqueued exchange: per CG iteration only the ranks' boundary rows (rows with an edge to another
+    rank) + three sums each are all-gathered (Summary::cg_exchange 3); with the knob shard_boundary = 0 the whole segments (1).  The
+    kernels read the same numbers either way: every rank's poses and cost trace are bit-identical between the two."""
+    monkeypatch.setenv("PGO_SYM", "1")
+    monkeypatch.setenv("PGO_BLOCK", "256")
+    g = ds.manhattan_se3(3000, 15000, seed=9, loop_radius=6.0)      # (closures that reach across the shares: a few hundred boundary rows per rank)
+    opt = dict(max_num_iterations=8, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2)
+    cuts, _ = gpu.row_shard_cuts(g.N, g.ia, g.ib, 4)
+    owner = np.searchsorted(np.asarray(cuts[1:]), np.arange(g.N), side="right")
+    assert (owner[g.ia] != owner[g.ib]).sum() > 50
+    a = _virtual_ranks(gpu, g, 4, opt)
+    knobs(shard_boundary=0)
+    b = _virtual_ranks(gpu, g, 4, opt)
+    for (sa, xa), (sb, xb) in zip(a, b):
+        assert sa.cg_exchange == 3 and sb.cg_exchange == 1 and sa.sym_form == 1 and sb.sym_form == 1
+        assert np.array_equal(xa, xb) and np.array_equal(sa.iterations["cost"], sb.iterations["cost"])
+        assert list(sa.iterations["linear_solver_iterations"]) == list(sb.iterations["linear_solver_iterations"])
+
+
+def test_a_share_without_rows_keeps_the_ranks_off_the_symmetric_form(gpu, ds, monkeypatch):
+    """Five poses on four ranks with the form forced (PGO_SYM=1): a rank without rows would launch an empty grid of tiles (r06,
+    tools/fuzz_sharded.py seed 8078: "invalid configuration argument" on two ranks, the others waiting in a collective for ever) —
+    every rank decides alike, from the shares, to stay on the incidence slots; and a rank whose solve fails releases an in-process group."""
+    monkeypatch.setenv("PGO_SYM", "1")
+    g = ds.manhattan_se3(5, 4, seed=3)          # (a chain: five poses, four odometry edges)
+    opt = dict(max_num_iterations=6, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2)
+    out = _virtual_ranks(gpu, g, 4, opt)
+    prob, x1 = gpu.problem_from_graph(g)
+    one = gpu.solve(gpu.SolverOptions(**opt), prob)
+    for s, x in out:
+        assert s.sym_form == 0 and np.array_equal(x, out[0][1])
+        assert np.allclose(s.iterations["cost"], one.iterations["cost"], rtol=1e-9, atol=1e-18)
