@@ -343,6 +343,7 @@ def main():
         try:
             t_ex = prob.time_kernel("exchange", 200)
             extra["exchange_us_per_cg_iteration"] = round(1e3 * t_ex, 2)
+            extra["exchange_bytes_per_cg_iteration_all_ranks"] = 8 * world * prob.exchange_doubles()
         except Exception as exc:   # noqa: BLE001
             extra["exchange_us_per_cg_iteration"] = "unavailable: %s" % (str(exc)[:120],)
     if one_gpu_extra is not None:

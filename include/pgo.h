@@ -303,6 +303,9 @@ PGO_API int pgo_solver_end(pgo_problem* problem, pgo_solver_summary* summary, pg
  * seconds it spent inside the launch calls since the trace started.  Returns the number of records or a negative status. */
 /* which CG form the stepping session runs (the value Summary::cg_form will carry), or a negative status without a session */
 PGO_API int pgo_solver_cg_form(pgo_problem* problem);
+/* doubles one rank contributes to the collective a CG iteration of the stepping session enqueues (0 with one rank; the exchange is `world`
+ * times that: the ranks' boundary rows + three sums where Summary::cg_exchange is 3, whole row segments otherwise), or a negative status */
+PGO_API int pgo_solver_exchange_doubles(pgo_problem* problem);
 PGO_API int pgo_solver_trace_start(pgo_problem* problem, int max_launches);
 PGO_API int pgo_solver_trace_read(pgo_problem* problem, long long* records, int capacity, double host[2]);
 /* repeats one kernel of the path `repeats` times on the solver stream between two HIP events and

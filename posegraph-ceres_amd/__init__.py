@@ -40,7 +40,7 @@ C_ABI_SYMBOLS = [
     "pgo_problem_set_parameter_block_constant", "pgo_problem_num_poses", "pgo_problem_num_edges",
     "pgo_solver_options_init", "pgo_solve", "pgo_summary_is_solution_usable", "pgo_summary_full_report",
     "pgo_evaluate", "pgo_normal_equations", "pgo_linear_solve", "pgo_plus", "pgo_solver_begin",
-    "pgo_solver_step", "pgo_solver_reset", "pgo_solver_end", "pgo_time_kernel", "pgo_solver_trace_start", "pgo_solver_trace_read", "pgo_solver_cg_form", "pgo_shard_range",
+    "pgo_solver_step", "pgo_solver_reset", "pgo_solver_end", "pgo_time_kernel", "pgo_solver_trace_start", "pgo_solver_trace_read", "pgo_solver_cg_form", "pgo_solver_exchange_doubles", "pgo_shard_range",
     "pgo_comm_get_unique_id", "pgo_comm_init", "pgo_comm_init_ipc", "pgo_debug_comm_stress", "pgo_debug_lm_decide", "pgo_loopback_create", "pgo_loopback_destroy", "pgo_comm_init_loopback",
     "pgo_generate_candidates", "pgo_reproj_options_init", "pgo_reproj_solve_batch",
     "pgo_row_shard_range", "pgo_row_shard_cuts", "pgo_read_trajectory", "pgo_build_odometry_edges", "pgo_edge_rules_init", "pgo_build_edges",
@@ -587,6 +587,10 @@ class Problem:
     def cg_form(self):
         """Summary::cg_form of the running session (0 standard CG, 3 fused stream, 4 resident stream; 1 / 2 several ranks)."""
         return _check(lib().pgo_solver_cg_form(self._h))
+
+    def exchange_doubles(self):
+        """Doubles one rank contributes to the per-CG-iteration collective of the running session (pgo_solver_exchange_doubles)."""
+        return _check(lib().pgo_solver_exchange_doubles(self._h))
 
     def trace_start(self, max_launches=20000):
         """Launch trace of the fused universal stream (include/pgo.h pgo_solver_trace_start); 0 stops recording."""

@@ -130,6 +130,10 @@ def test_boundary_exchange_carries_the_same_bits_as_whole_segments(gpu, ds, monk
     owner = np.searchsorted(np.asarray(cuts[1:]), np.arange(g.N), side="right")
     assert (owner[g.ia] != owner[g.ib]).sum() > 50
     a = _virtual_ranks(gpu, g, 4, opt)
+    prob, _ = gpu.problem_from_graph(g)              # (one rank: nothing to exchange)
+    prob.solver_begin(gpu.SolverOptions(**opt))
+    assert prob.exchange_doubles() == 0
+    prob.solver_end()
     knobs(shard_boundary=0)
     b = _virtual_ranks(gpu, g, 4, opt)
     for (sa, xa), (sb, xb) in zip(a, b):
