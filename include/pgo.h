@@ -158,7 +158,7 @@ typedef struct pgo_solver_summary {
   int cg_exchange;              /* how the ranks' CG exchanged their segments: 0 nothing to exchange (one rank), 1 a host-enqueued collective
                                    per CG iteration (RCCL all-gather, loopback copies), 2 by the kernels themselves (peer table: stores
                                    into every rank's buffer + flags; the IPC transport's normal mode), 3 a host-enqueued collective of the ranks'
-                                   BOUNDARY rows only (symmetric-form sessions: rows with an edge to another rank + three sums per rank) */
+                                   BOUNDARY rows only (rows with an edge to another rank + three sums per rank) */
   int sym_form;                 /* 1: the session kept the normal equations in the symmetric tile form (every interior off-diagonal block stored
                                    and read once; graphs above 600 k incidence slots, on one rank or row-sharded over several), 0: incidence-slot blocks */
   int coarse_level;             /* aggregates of the PCG's coarse level (0: none ran) */

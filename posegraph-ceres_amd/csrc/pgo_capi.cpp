@@ -173,7 +173,7 @@ int pgo_solver_exchange_doubles(pgo_problem* P) {
   if (!P || !P->lm.active) return set_error(PGO_ERR_INVALID_ARGUMENT, "pgo_solver_exchange_doubles needs a stepping session (call pgo_solver_begin first)");
   if (P->g.world <= 1) return 0;
   if (!pipe_mode(P, cg_params_for(P->opt))) return P->g.seg;
-  return (P->sym_storage && P->sym.xb[0]) ? P->sym.cseg : P->g.pipe_seg;
+  return P->g.bx[0] ? P->g.bx_cseg : P->g.pipe_seg;
 }
 
 static const int TRACE_WORDS = pgo::UNI_F_TRACE_WORDS;
@@ -258,7 +258,7 @@ int pgo_time_kernel(pgo_problem* P, const char* kernel, int repeats, double* avg
     if (k == "exchange") {       // the collective of the sharded path as enqueued between two CG launches: the boundary segments where the session
       if (!P->comm) return -2;   // exchanges those (in place, between launches: every rank re-sends what its segment holds), else the q segment
       const char* what = "";
-      if (P->sym_storage && P->sym.xb[0]) return P->comm->all_gather(P->sym.xb[0], (size_t)P->sym.cseg, s, &what) != 0 ? -3 : 0;
+      if (P->g.bx[0] && pipe_mode(P, cg_params_for(P->opt))) return P->comm->all_gather(P->g.bx[0], (size_t)P->g.bx_cseg, s, &what) != 0 ? -3 : 0;
       return P->comm->all_gather(P->g.cg_q, (size_t)P->g.seg, s, &what) != 0 ? -3 : 0;
     }
     if (k == "direct") return run_direct(P);

@@ -459,9 +459,13 @@ struct pgo_problem {
   double sym_interior_fraction = 0.0;
   long long sym_stored_slots = 0;
   DevBuf<pgo::SymTile> sy_tile;
-  DevBuf<int> sy_xlist, sy_chunk_base, sy_chunk_n, sy_src, sy_diag, sy_xoff, sy_brow;
-  bool sym_boundary_ready = false;     // the lists of the boundary exchange exist for this topology
-  DevBuf<double> sy_xb0, sy_xb1;       // boundary exchange of the sharded symmetric-form CG (pgo_sym.h SymGraph::xb)
+  DevBuf<int> sy_xlist, sy_chunk_base, sy_chunk_n, sy_src, sy_diag, sy_xoff;
+  // boundary exchange of the sharded owner-only CG (pgo_kernels.h DeviceGraph::bx): lists and buffers of this topology (prepare())
+  bool bx_ready = false;
+  int bx_cseg = 0, bx_nb = 0;
+  std::vector<int> h_bpos;             // [n_int] index of every boundary row inside its rank's segment (-1: not a boundary row)
+  DevBuf<int> d_bx_brow, d_bx_slot_off;
+  DevBuf<double> d_bx0, d_bx1;
   bool sym_stale = true;            // the off-diagonal blocks were rewritten since the last repack (else only the damped diagonal slots are copied)
   DevBuf<uint32_t> sy_meta, sy_rinfo;
   bool sym_storage = false;         // this LM session keeps the normal equations in the symmetric tile form ONLY: linearisation, damping, the cluster

@@ -244,6 +244,15 @@ struct DeviceGraph {
   const int* cl_ptr;  // [n_clusters+1] BSR slots whose row AND column lie inside the cluster (off-diagonal ones)
   const int* cl_slot;
   const uint8_t* cl_rc;  // per entry: (row - cluster base) << 4 | (col - cluster base)
+  // several ranks, host-enqueued exchange of the owner-only CG (r06): only the rank's BOUNDARY rows — rows with an edge to another rank:
+  // 5 % of the rows of BASELINE configs[3] on 8 ranks — travel per CG iteration.  bx[0 / 1]: exchange buffers [world][bx_cseg] (a rank's
+  // boundary rows in ascending order, 6 doubles each, then its three sums); bx_brow: this rank's boundary rows; bx_slot_off[t]: where
+  // k_pipe_cg finds m of slot t's column — >= 0: a double offset into pipe_buf (a row of this rank: the full-layout buffer stays the rank's
+  // own), < 0: -1 - (double offset into bx) (another rank's boundary row).  bx[0] == nullptr: whole segments travel in pipe_buf.
+  double* bx[2];
+  const int* bx_brow;
+  const int* bx_slot_off;
+  int bx_nb, bx_cseg;
 };
 
 // Timing ablations (a kernel with a phase switched off: its results are wrong) exist in builds made with -DPGO_ABLATE only; a
@@ -358,6 +367,9 @@ void launch_hdiag6(const DeviceGraph& g, double* buf, int phase, hipStream_t s);
 void launch_pipe_init(const DeviceGraph& g, hipStream_t s);
 void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, hipStream_t s, unsigned long long gseq = 0, bool fold = true);   // gseq: device-initiated exchange, global number of this producing launch; fold = false: the caller's next launch folds the partial sums (the coarse level's restriction)
 void launch_peer_signal(const DeviceGraph& g, unsigned long long gseq, hipStream_t s);   // ... behind k_pipe_init
+// boundary exchange (DeviceGraph::bx): this rank's boundary rows of pipe_buf[buf] -> its segment of bx[buf]; fold_seq >= 0: and k_pipe_fold's
+// job behind the CG launch fold_seq (n_entries partial triples, row 0 of the partial-sum arrays) with the sums at the end of the segment
+void launch_pipe_pack(const DeviceGraph& g, int buf, int fold_seq, int n_entries, hipStream_t s);
 void launch_pipe_fold(const DeviceGraph& g, int seq, unsigned long long gseq, hipStream_t s);   // one work-group: the g.n_wg partial triples of the producing launch -> this rank's three sums in the exchange buffer(s) (+ signal / wait)
 void launch_pcg_spmv_only(const DeviceGraph& g, const CgParams& p, int odd, hipStream_t s);
 void launch_pcg_update_only(const DeviceGraph& g, int odd, hipStream_t s, int mode = 0);   // mode: see k_pcg_update

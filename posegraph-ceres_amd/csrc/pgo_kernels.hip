@@ -2224,9 +2224,10 @@ __global__ __launch_bounds__(256) void k_pipe_cg(DeviceGraph g, CgParams prm, in
   const CgState::Pipe st = g.cg->pipe[rs];
   double f_gamma = 0, f_delta = 0, f_q = 0;     // every rank's three sums, added in rank order by every lane alike: same bits everywhere
   for (int rk = 0; rk < g.world; ++rk) {
-    const double* pp = rd + (size_t)rk * g.pipe_seg + (size_t)g.rows_per * 6;
+    const double* pp = g.bx[0] ? g.bx[rs] + (size_t)(rk + 1) * g.bx_cseg - 4 : rd + (size_t)rk * g.pipe_seg + (size_t)g.rows_per * 6;
     f_gamma += pp[0]; f_delta += pp[1]; f_q += pp[2];
   }
+  const int moff = g.bx[0] ? g.bx_slot_off[t] : 0;        // (boundary exchange: where this slot's column lives)
   // the first pass of the owned rows' operands, requested with the blocks
   const bool own0 = mode == 0 && tid < nown;
   const size_t gi = 6 * (size_t)r0 + tid;
@@ -2294,7 +2295,7 @@ __global__ __launch_bounds__(256) void k_pipe_cg(DeviceGraph g, CgParams prm, in
   // ---- n = A m over this work-group's slots ----
   double y[6] = {0, 0, 0, 0, 0, 0};
   if (col >= 0) {
-    const double2* ms = reinterpret_cast<const double2*>(rd + pipe_index(g, col, 0));
+    const double2* ms = reinterpret_cast<const double2*>(!g.bx[0] ? rd + pipe_index(g, col, 0) : moff >= 0 ? rd + moff : g.bx[rs] + (-1 - moff));
     const double2 g0 = ms[0], g1 = ms[1], g2 = ms[2];
     const double x[6] = {g0.x, g0.y, g1.x, g1.y, g2.x, g2.y};
     if (PACKED) {
@@ -2419,6 +2420,26 @@ __global__ __launch_bounds__(256) void k_pipe_fold(DeviceGraph g, int seq, unsig
   }
 }
 __global__ void k_peer_signal(DeviceGraph g, unsigned long long gseq) { peer_signal_and_wait(g, gseq); }
+// boundary exchange: work-group 0 (fold_seq >= 0) does k_pipe_fold's job — the producing launch's partial triples -> this rank's three sums,
+// here at the end of its segment of bx — the others copy the rank's boundary rows out of the full-layout buffer into the segment
+__global__ __launch_bounds__(256) void k_pipe_pack(DeviceGraph g, int buf, int fold_seq, int n_entries) {
+  __shared__ double scratch[16];
+  if (fold_seq >= 0 && g.cg->done) return;
+  double* seg = g.bx[buf] + (size_t)g.rank * g.bx_cseg;
+  if (blockIdx.x == 0) {
+    if (fold_seq < 0) return;
+    double t3[3] = {0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < n_entries; i += 256) { t3[0] += g.part_rz[i]; t3[1] += g.part_q[i]; t3[2] += g.part_rr[i]; }
+    block_sum<3>(t3, scratch);
+    if (threadIdx.x == 0) { double* pp = seg + g.bx_cseg - 4; pp[0] = t3[0]; pp[1] = t3[1]; pp[2] = t3[2]; }
+    return;
+  }
+  const int i = ((int)blockIdx.x - 1) * 256 + (int)threadIdx.x;
+  if (i >= 3 * g.bx_nb) return;
+  const int e = i / 3, k = i - 3 * e;
+  const double2* src = reinterpret_cast<const double2*>(g.pipe_buf[buf] + pipe_index(g, g.bx_brow[e], 0));
+  reinterpret_cast<double2*>(seg + 6 * (size_t)e)[k] = src[k];
+}
 
 // Several ranks, owner-only CG: of the other ranks' diagonal blocks only the six diagonal entries are needed anywhere (column
 // scaling, LM damping, the model change of the step tail), so those travel — 6 doubles per pose instead of 36.  phase 0: the
@@ -2749,7 +2770,10 @@ void launch_pipe_cg(const DeviceGraph& g, const CgParams& p, int seq, int mode, 
                           else hipLaunchKernelGGL((k_pipe_cg<PK, 1>), grid, dim3(g.block), lds, s, g, p, seq, mode); } while (0)
   if (g.blk_packed) PGO_PIPE(true); else PGO_PIPE(false);
 #undef PGO_PIPE
-  if (mode == 0 && fold) launch_pipe_fold(g, seq, gseq, s);
+  if (mode == 0 && fold) { if (g.bx[0]) launch_pipe_pack(g, (seq & 1) ^ 1, seq, g.n_wg, s); else launch_pipe_fold(g, seq, gseq, s); }
+}
+void launch_pipe_pack(const DeviceGraph& g, int buf, int fold_seq, int n_entries, hipStream_t s) {
+  hipLaunchKernelGGL(k_pipe_pack, dim3(1 + (3 * g.bx_nb + 255) / 256), dim3(256), 0, s, g, buf, fold_seq, n_entries);
 }
 void launch_pipe_fold(const DeviceGraph& g, int seq, unsigned long long gseq, hipStream_t s) {
   hipLaunchKernelGGL(k_pipe_fold, dim3(1), dim3(256), 0, s, g, seq, gseq);

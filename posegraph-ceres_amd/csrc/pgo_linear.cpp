@@ -57,11 +57,11 @@ int coarse_setup(pgo_problem* P) {
   pgo::launch_coarse_invert(c, P->stream);
   return PGO_OK;
 }
-// several ranks on the symmetric form, host-enqueued exchange: only the ranks' boundary rows (+ three sums each) travel per CG iteration
-// (pgo_sym.h SymGraph::xb; 5 % of the rows of BASELINE configs[3] on 8 ranks), the full-layout buffer stays the rank's own
-static bool boundary_exchange(const pgo_problem* P) { return P->sym_storage && P->g.world > 1 && P->sym.xb[0] != nullptr; }
+// several ranks, host-enqueued exchange: only the ranks' boundary rows (+ three sums each) travel per CG iteration
+// (pgo_kernels.h DeviceGraph::bx; 5 % of the rows of BASELINE configs[3] on 8 ranks), the full-layout buffer stays the rank's own
+static bool boundary_exchange(const pgo_problem* P) { return P->g.world > 1 && P->g.bx[0] != nullptr; }
 static int pipe_exchange(pgo_problem* P, int buf) {
-  if (boundary_exchange(P)) return exchange(P, P->sym.xb[buf], (size_t)P->sym.cseg);
+  if (boundary_exchange(P)) return exchange(P, P->g.bx[buf], (size_t)P->g.bx_cseg);
   return exchange(P, P->g.pipe_buf[buf], (size_t)P->g.pipe_seg);
 }
 // one product launch of the owner-only CG (+ its fold): from the symmetric tile form where the session keeps its blocks there
@@ -137,11 +137,6 @@ int launch_cg_batch(pgo_problem* P, const pgo::CgParams& prm, int batch, bool wi
       rc = pipe_exchange(P, (seq & 1) ^ 1);
       if (rc) return rc;
     }
-    if (boundary_exchange(P)) {      // (the stop-test launch reads nothing but every rank's three sums: at the end of the boundary segments)
-      pgo::DeviceGraph ga = P->g;
-      ga.pipe_buf[0] = P->sym.xb[0]; ga.pipe_buf[1] = P->sym.xb[1]; ga.pipe_seg = P->sym.cseg; ga.rows_per = (P->sym.cseg - 4) / 6;
-      pgo::launch_pipe_cg(ga, prm, start_it + batch, with_tail ? 2 : 1, s);
-    } else
     pgo::launch_pipe_cg(P->g, prm, start_it + batch, with_tail ? 2 : 1, s);    // the stop test of the last iteration; without a tail also the hand-over
     return with_tail ? enqueue_tail(P, &prm) : PGO_OK;
   }
@@ -232,7 +227,7 @@ int pcg_begin(pgo_problem* P, const pgo::CgParams& prm) {
     pgo::launch_peer_signal(P->g, ++P->peer_gseq, s);
     return pipe_cg_launch(P, prm, 0, ++P->peer_gseq);
   }
-  if (boundary_exchange(P)) pgo::launch_pipe_pack(sym_view(P), P->sym, 0, -1, s);      // u0 of the rank's boundary rows into its segment
+  if (boundary_exchange(P)) pgo::launch_pipe_pack(P->g, 0, -1, 0, s);      // u0 of the rank's boundary rows into its segment
   int rc = pipe_exchange(P, 0);
   if (rc) return rc;
   rc = pipe_cg_launch(P, prm, 0);

@@ -128,6 +128,13 @@ int lm_begin(pgo_problem* P, const pgo_solver_options* options) {
       return set_error(PGO_ERR_UNSUPPORTED, "pcg_coarse_aggregate: a pose pair of this graph has more than 256 incidence slots — the one-launch CG iteration the coarse level rides on cannot hold it in one work-group");
     }
   }
+  // the boundary exchange serves the host-enqueued transports; where the kernels store into every rank's buffers themselves (peer table)
+  // and where a coarse correction is applied to the full-layout buffer between launch and exchange the whole segments travel as before
+  {
+    const bool bx = P->g.world > 1 && P->bx_ready && !P->g.peer_tab && !P->coarse_on && pgo::tuning("shard_boundary", 1.0) != 0.0;
+    P->g.bx[0] = bx ? P->d_bx0.p : nullptr; P->g.bx[1] = bx ? P->d_bx1.p : nullptr;
+    P->g.bx_brow = P->d_bx_brow.p; P->g.bx_slot_off = P->d_bx_slot_off.p; P->g.bx_nb = P->bx_nb; P->g.bx_cseg = P->bx_cseg;
+  }
   if (P->opt.linear_solver_type == PGO_SPARSE_NORMAL_CHOLESKY) {
     const auto t_sym = Clock::now();
     rc = prepare_direct(P);
@@ -871,7 +878,7 @@ int lm_end(pgo_problem* P, pgo_solver_summary* summary, pgo_iteration_record* re
   }
   if (summary) {
     memset(summary, 0, sizeof *summary);
-    summary->cg_exchange = P->g.world > 1 ? (P->g.peer_tab && pipe_mode(P, cg_params_for(P->opt)) ? 2 : (P->sym_storage && P->sym.xb[0] && pipe_mode(P, cg_params_for(P->opt))) ? 3 : 1) : 0;
+    summary->cg_exchange = P->g.world > 1 ? (P->g.peer_tab && pipe_mode(P, cg_params_for(P->opt)) ? 2 : (P->g.bx[0] && pipe_mode(P, cg_params_for(P->opt))) ? 3 : 1) : 0;
     summary->cg_form = P->g.world > 1 ? (pipe_mode(P, cg_params_for(P->opt)) ? 2 : 1) : (P->uni_resident ? 4 : P->uni_fused ? 3 : pipe_mode(P, cg_params_for(P->opt)) ? 2 : 0);
     summary->sym_form = P->sym_storage ? 1 : 0;
     summary->coarse_level = P->coarse_on ? P->coarse.n_agg : 0;

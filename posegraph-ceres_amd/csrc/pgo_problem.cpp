@@ -449,6 +449,49 @@ int prepare(pgo_problem* P) {
   g.part_rr = P->d_part_rr.p; g.part_bb = P->d_part_bb.p; g.part_misc = P->d_part_misc.p; g.part_f = P->d_part_f.p;
   g.cg_u = P->d_cg_u.p; g.cg_w = P->d_cg_w.p; g.cg_s = P->d_cg_s.p; g.cg_qq = P->d_cg_qq.p;
   g.pipe_buf[0] = P->d_pipe_a.p; g.pipe_buf[1] = P->d_pipe_b.p; g.pipe_seg = pipe_seg;
+  g.bx[0] = g.bx[1] = nullptr; g.bx_brow = nullptr; g.bx_slot_off = nullptr; g.bx_nb = 0; g.bx_cseg = 0;     // (a session engages the boundary exchange: lm_begin)
+  P->bx_ready = false;
+  if (world > 1) {
+    // boundary exchange of the owner-only CG (pgo_kernels.h DeviceGraph::bx): a row travels per CG iteration only if an edge leaves its
+    // rank.  Every rank derives every rank's list from the (replicated) edge list: the segments' layout is the same everywhere without a
+    // word exchanged.
+    std::vector<uint8_t> bnd((size_t)N, 0);
+    for (int e = 0; e < E; ++e)
+      if (t_ia[e] / rows_per != t_ib[e] / rows_per) { bnd[(size_t)t_ia[e]] = 1; bnd[(size_t)t_ib[e]] = 1; }
+    std::vector<int> count((size_t)world, 0), brow;
+    P->h_bpos.assign((size_t)N, -1);
+    for (int v = 0; v < N; ++v)
+      if (bnd[(size_t)v]) {
+        const int k = v / rows_per;
+        P->h_bpos[(size_t)v] = count[(size_t)k]++;
+        if (k == rank) brow.push_back(v);
+      }
+    int bmax = 2;
+    for (int k = 0; k < world; ++k) bmax = std::max(bmax, count[(size_t)k]);
+    bmax = (bmax + 1) & ~1;
+    const int cseg = 6 * bmax + 4;
+    bool fits = (long long)world * pipe_seg < (1LL << 31) && (long long)world * cseg < (1LL << 31);
+    std::vector<int> soff((size_t)n_slots, 0);
+    for (int t = 0; t < n_slots && fits; ++t) {
+      const int c = slot_col[(size_t)t];
+      if (c < 0) continue;
+      const int k = c / rows_per;
+      if (k == rank) soff[(size_t)t] = k * pipe_seg + (c - k * rows_per) * 6;
+      else if (P->h_bpos[(size_t)c] >= 0) soff[(size_t)t] = -1 - (k * cseg + 6 * P->h_bpos[(size_t)c]);
+      else fits = false;          // (cannot happen: the far end of a cut edge is a boundary row of its rank)
+    }
+    if (fits) {
+      P->bx_nb = (int)brow.size();
+      if (brow.empty()) brow.push_back(row_lo);       // (an upload of nothing is not one)
+      HIP_TRY(P->d_bx_brow.upload(brow, s));
+      HIP_TRY(P->d_bx_slot_off.upload(soff, s));
+      HIP_TRY(P->d_bx0.alloc((size_t)world * cseg)); HIP_TRY(P->d_bx0.zero(s));
+      HIP_TRY(P->d_bx1.alloc((size_t)world * cseg)); HIP_TRY(P->d_bx1.zero(s));
+      P->bx_cseg = cseg;
+      P->bx_ready = true;
+      if (verbose) std::fprintf(stderr, "[pgo] rank %d: %d of %d rows are boundary rows; a CG iteration exchanges %d doubles per rank instead of %d\n", rank, P->bx_nb, row_hi - row_lo, cseg, pipe_seg);
+    }
+  }
   g.peer_tab = nullptr; g.peer_flags = nullptr;
   P->peer_dirty = true;       // (the table is exchanged by peer_direct_setup(), outside this function's upload scope: it is a collective call)
   g.pairs_whole = pairs_whole ? 1 : 0;

@@ -32,7 +32,6 @@ int sym_prepare(pgo_problem* P) {
   if (P->sym_built) return PGO_OK;
   P->sym_built = true;
   P->sym_ready = false;
-  P->sym_boundary_ready = false;
   const auto t0 = Clock::now();
   const bool verbose = getenv("PGO_VERBOSE") != nullptr;
   auto lap = [&, tl = Clock::now()](const char* what) mutable {
@@ -100,45 +99,18 @@ int sym_prepare(pgo_problem* P) {
   sg.tile = P->sy_tile.p; sg.xlist = P->sy_xlist.p; sg.chunk_base = P->sy_chunk_base.p; sg.chunk_n = P->sy_chunk_n.p;
   sg.meta = P->sy_meta.p; sg.rinfo = P->sy_rinfo.p; sg.src_slot = P->sy_src.p; sg.diag_slot = P->sy_diag.p;
   sg.val = P->sy_val.p;
-  sg.xoff = nullptr; sg.brow = nullptr; sg.nb_own = 0; sg.cseg = 0; sg.xb[0] = sg.xb[1] = nullptr;
-  if (P->g.world > 1) {
-    // boundary exchange (pgo_sym.h): a row travels only if an edge leaves its rank.  Every rank derives every rank's list from the
-    // (replicated) edge list: the segments' layout is the same everywhere without a word exchanged.
-    const int world = P->g.world, rows_per = P->g.rows_per, rank = P->g.rank;
-    std::vector<uint8_t> bnd((size_t)N, 0);
-    for (int e = 0; e < E; ++e)
-      if (t_ia[e] / rows_per != t_ib[e] / rows_per) { bnd[(size_t)t_ia[e]] = 1; bnd[(size_t)t_ib[e]] = 1; }
-    std::vector<int> bpos((size_t)N, -1), count((size_t)world, 0), brow;
-    for (int v = 0; v < N; ++v)
-      if (bnd[(size_t)v]) {
-        const int k = v / rows_per;
-        bpos[(size_t)v] = count[(size_t)k]++;
-        if (k == rank) brow.push_back(v);
-      }
-    int bmax = 2;
-    for (int k = 0; k < world; ++k) bmax = std::max(bmax, count[(size_t)k]);
-    bmax = (bmax + 1) & ~1;
-    const int cseg = 6 * bmax + 4;
+  sg.xoff = nullptr;
+  if (P->g.world > 1 && P->bx_ready) {      // boundary exchange (prepare() made the lists): where every staged column of every tile lives
+    const int rows_per = P->g.rows_per, rank = P->g.rank;
     std::vector<int> xoff(xlist.size());
-    bool fits = (long long)world * P->g.pipe_seg < (1LL << 31) && (long long)world * cseg < (1LL << 31);
+    bool fits = true;
     for (size_t i = 0; i < xlist.size() && fits; ++i) {
       const int v = xlist[i], k = v / rows_per;
       if (k == rank) xoff[i] = k * P->g.pipe_seg + (v - k * rows_per) * 6;
-      else if (bpos[(size_t)v] >= 0) xoff[i] = -1 - (k * cseg + 6 * bpos[(size_t)v]);
+      else if (P->h_bpos[(size_t)v] >= 0) xoff[i] = -1 - (k * P->bx_cseg + 6 * P->h_bpos[(size_t)v]);
       else fits = false;          // (cannot happen: the far end of a cut edge is a boundary row of its rank)
     }
-    if (fits) {
-      if (brow.empty()) brow.push_back(P->g.row_lo);       // (an upload of nothing is not one)
-      HIP_TRY(P->sy_xoff.upload(xoff, s));
-      HIP_TRY(P->sy_brow.upload(brow, s));
-      HIP_TRY(P->sy_xb0.alloc((size_t)world * cseg));
-      HIP_TRY(P->sy_xb1.alloc((size_t)world * cseg));
-      HIP_TRY(P->sy_xb0.zero(s));
-      HIP_TRY(P->sy_xb1.zero(s));
-      sg.xoff = P->sy_xoff.p; sg.brow = P->sy_brow.p; sg.nb_own = count[(size_t)rank]; sg.cseg = cseg;
-      P->sym_boundary_ready = true;
-      if (getenv("PGO_VERBOSE")) std::fprintf(stderr, "[pgo] sym rank %d: %d of %d rows are boundary rows; exchange segment %d doubles instead of %d\n", rank, sg.nb_own, P->g.row_hi - P->g.row_lo, cseg, P->g.pipe_seg);
-    }
+    if (fits) { HIP_TRY(P->sy_xoff.upload(xoff, s)); sg.xoff = P->sy_xoff.p; }
   }
   HIP_TRY(hipStreamSynchronize(s));
   lap("index uploads + sync");
@@ -182,10 +154,6 @@ int sym_enter_storage(pgo_problem* P) {
   pgo::launch_sym_repack(P->g, P->sym, P->stream, 0);
   P->sym_stale = false;
   P->sym_storage = true;
-  // the boundary exchange serves the host-enqueued transports; where the kernels store into every rank's buffers themselves (peer table)
-  // the whole segments travel as before
-  const bool bx = P->g.world > 1 && P->sym_boundary_ready && !P->g.peer_tab && pgo::tuning("shard_boundary", 1.0) != 0.0;
-  P->sym.xb[0] = bx ? P->sy_xb0.p : nullptr;
-  P->sym.xb[1] = bx ? P->sy_xb1.p : nullptr;
+  if (P->g.bx[0] && !P->sym.xoff) P->g.bx[0] = P->g.bx[1] = nullptr;      // (the form has no offsets for the boundary exchange: whole segments)
   return PGO_OK;
 }

@@ -53,15 +53,9 @@ struct SymGraph {
   const int* src_slot;                // [n_slots] slot of the incidence-slot BSR that holds the same block (-1: padding)
   const int* diag_slot;               // [N] stored slot of every row's diagonal block
   double* val;                        // [n_slots * 36] blocks, bsr_index() layout
-  // several ranks, host-enqueued exchange (r06): only the rank's BOUNDARY rows — rows with an edge to another rank: 5 % of the rows of
-  // BASELINE configs[3] on 8 ranks — travel per CG iteration.  xb[0 / 1]: exchange buffers [world][cseg] (the rank's boundary rows in
-  // ascending order, 6 doubles each, then its three sums); brow: the rank's boundary rows (device numbering); xoff[i], parallel to xlist:
-  // where k_pipe_cg_sym finds m of that staged column — >= 0: a double offset into pipe_buf (a row of this rank: the full-layout buffer stays
-  // the rank's own), < 0: -1 - (double offset into xb) (another rank's boundary row).  xb[0] == nullptr: the whole segments travel (pipe_buf).
+  // several ranks, boundary exchange (DeviceGraph::bx): xoff[i], parallel to xlist — where k_pipe_cg_sym finds m of that staged column:
+  // >= 0 a double offset into pipe_buf (a row of this rank), < 0: -1 - (double offset into bx) (another rank's boundary row)
   const int* xoff;
-  const int* brow;
-  int nb_own, cseg;
-  double* xb[2];
 };
 
 // q = A p of a CG iteration (MODE 0: prologue, x = z + beta p, p_new, p'q partials — exactly k_spmv<0>'s contract) or plain
@@ -75,8 +69,6 @@ size_t sym_lds_bytes(const SymGraph& sg);
 // the product from the symmetric tile form, followed by k_pipe_fold; the tiles must be made of whole preconditioner clusters
 // fold (one rank only; several ranks always fold): also run k_pipe_fold behind the launch — wanted in front of a "stop test only" launch
 void launch_pipe_cg_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p, int seq, hipStream_t s, unsigned long long gseq = 0, bool fold = false);
-// boundary exchange (SymGraph::xb): the rank's boundary rows of pipe_buf[buf] -> its segment of xb[buf] (fold: and k_pipe_fold's job behind launch seq)
-void launch_pipe_pack(const DeviceGraph& g, const SymGraph& sg, int buf, int fold_seq, hipStream_t s);
 // pgo_lean_kernels.hip: the row kernel writing the form (g.sym_dst / g.sym_val set) with the lean per-incidence algebra of pgo_lin_lean.h
 void launch_linearize_lean(const DeviceGraph& g, hipStream_t s, int gate = 0);      // (falls back to launch_linearize_symout when it does not fit)
 bool linearize_lean_fits(const DeviceGraph& g);

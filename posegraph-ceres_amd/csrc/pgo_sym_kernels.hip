@@ -436,7 +436,7 @@ __global__ __launch_bounds__(SYM_LANES) void k_pipe_cg_sym(DeviceGraph g, SymGra
   } else {
     // every rank's three sums, added in rank order by every lane alike: same bits everywhere
     for (int rk = 0; rk < g.world; ++rk) {
-      const double* pp = sg.xb[0] ? sg.xb[rs] + (size_t)(rk + 1) * sg.cseg - 4 : rd + (size_t)rk * g.pipe_seg + (size_t)g.rows_per * 6;
+      const double* pp = g.bx[0] ? g.bx[rs] + (size_t)(rk + 1) * g.bx_cseg - 4 : rd + (size_t)rk * g.pipe_seg + (size_t)g.rows_per * 6;
       f3[0] += pp[0]; f3[1] += pp[1]; f3[2] += pp[2];
     }
   }
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(SYM_LANES) void k_pipe_cg_sym(DeviceGraph g, SymGra
   for (int i = tid; i < T.nx * 3; i += SYM_LANES) {
     const int e = i / 3, k = i - 3 * e;
     const double* src;
-    if (sg.xb[0]) { const int off = sg.xoff[T.x0 + e]; src = off >= 0 ? rd + off : sg.xb[rs] + (-1 - off); }
+    if (g.bx[0]) { const int off = sg.xoff[T.x0 + e]; src = off >= 0 ? rd + off : g.bx[rs] + (-1 - off); }
     else src = rd + sym_pipe_index(g, sg.xlist[T.x0 + e]);
     const double2 z = reinterpret_cast<const double2*>(src)[k];
     xs[6 * e + 2 * k] = z.x;
@@ -680,27 +680,6 @@ __global__ __launch_bounds__(SYM_LANES) void k_pipe_cg_sym(DeviceGraph g, SymGra
   }
 }
 
-// boundary exchange: work-group 0 (fold_seq >= 0) does k_pipe_fold's job — the tiles' partial triples of launch fold_seq -> this rank's three
-// sums, here at the end of its segment of xb — the others copy the rank's boundary rows out of the full-layout buffer into the segment
-__global__ __launch_bounds__(256) void k_pipe_pack(DeviceGraph g, SymGraph sg, int buf, int fold_seq) {
-  __shared__ double scratch[16];
-  if (fold_seq >= 0 && g.cg->done) return;
-  double* seg = sg.xb[buf] + (size_t)g.rank * sg.cseg;
-  if (blockIdx.x == 0) {
-    if (fold_seq < 0) return;
-    double t3[3] = {0.0, 0.0, 0.0};
-    for (int i = threadIdx.x; i < sg.n_tiles; i += 256) { t3[0] += g.part_rz[i]; t3[1] += g.part_q[i]; t3[2] += g.part_rr[i]; }
-    block_sum<3>(t3, scratch);
-    if (threadIdx.x == 0) { double* pp = seg + sg.cseg - 4; pp[0] = t3[0]; pp[1] = t3[1]; pp[2] = t3[2]; }
-    return;
-  }
-  const int i = ((int)blockIdx.x - 1) * 256 + (int)threadIdx.x;
-  if (i >= 3 * sg.nb_own) return;
-  const int e = i / 3, k = i - 3 * e;
-  const double2* src = reinterpret_cast<const double2*>(g.pipe_buf[buf] + sym_pipe_index(g, sg.brow[e]));
-  reinterpret_cast<double2*>(seg + 6 * (size_t)e)[k] = src[k];
-}
-
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_sym_repack(DeviceGraph g, SymGraph sg) {
   constexpr int NPAIR = PACKED ? BLK_PAIRS_PACKED : BLK_PAIRS_FULL;
@@ -756,9 +735,6 @@ void launch_spmv_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p
   }
 }
 
-void launch_pipe_pack(const DeviceGraph& g, const SymGraph& sg, int buf, int fold_seq, hipStream_t s) {
-  hipLaunchKernelGGL(k_pipe_pack, dim3(1 + (3 * sg.nb_own + 255) / 256), dim3(256), 0, s, g, sg, buf, fold_seq);
-}
 void launch_pipe_cg_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams& p, int seq, hipStream_t s, unsigned long long gseq, bool fold) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -778,7 +754,7 @@ void launch_pipe_cg_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams
   // several ranks: the rank's three sums go into the exchange buffer(s) behind every launch.  One rank: the next launch folds the
   // partial triples itself; only the "stop test only" launch at the end of a batch (k_pipe_cg's, one work-group) wants them folded
   if (g.world == 1 && !fold) return;
-  if (g.world > 1 && sg.xb[0]) { launch_pipe_pack(g, sg, (seq & 1) ^ 1, seq, s); return; }
+  if (g.world > 1 && g.bx[0]) { launch_pipe_pack(g, (seq & 1) ^ 1, seq, sg.n_tiles, s); return; }
   DeviceGraph gf = g;
   gf.n_wg = sg.n_tiles;         // the fold adds one entry per work-group of the producing launch
   if (g.world == 1) { const size_t off = (size_t)((seq & 1) ^ 1) * g.n_part; gf.part_rz += off; gf.part_q += off; gf.part_rr += off; }

@@ -15,7 +15,7 @@ namespace pgo {
 struct TuningKnob { const char* name; const char* what; };
 inline const TuningKnob* tuning_knobs(int* n) {
   static const TuningKnob knobs[] = {
-      {"shard_boundary", "0: sharded symmetric-form sessions all-gather whole segments per CG iteration instead of the ranks' boundary rows (1; A/B)"},
+      {"shard_boundary", "0: sharded sessions all-gather whole segments per CG iteration instead of the ranks' boundary rows (1; A/B)"},
       {"debug", "DeviceGraph::debug: timing ablations of the CG kernels, tools/ablate.py (0; results are wrong with a bit set)"},
       {"graph", "1: replay captured hipGraphs of the launch batches instead of enqueueing eagerly (0)"},
       {"front_zfrac", "multifrontal plan, relaxed amalgamation: admissible fraction of explicit zeros (0.25)"},

@@ -118,11 +118,13 @@ def test_sharded_ranks_keep_the_form_of_their_rows(gpu, ds, O, world, direct, in
     assert np.abs(poses1 - out[0][1]).max() < 1e-6
 
 
-def test_boundary_exchange_carries_the_same_bits_as_whole_segments(gpu, ds, monkeypatch, knobs):
-    """Sharded symmetric-form sessions, host-enqueued exchange: per CG iteration only the ranks' boundary rows (rows with an edge to another
-    rank) + three sums each are all-gathered (Summary::cg_exchange 3); with the knob shard_boundary = 0 the whole segments (1).  The
-    kernels read the same numbers either way: every rank's poses and cost trace are bit-identical between the two."""
-    monkeypatch.setenv("PGO_SYM", "1")
+@pytest.mark.parametrize("sym", [True, False])
+def test_boundary_exchange_carries_the_same_bits_as_whole_segments(gpu, ds, monkeypatch, knobs, sym):
+    """Sharded sessions (on the symmetric form, k_pipe_cg_sym, and on the incidence slots, k_pipe_cg), host-enqueued exchange: per CG
+    iteration only the ranks' boundary rows (rows with an edge to another rank) + three sums each are all-gathered (Summary::cg_exchange
+    3); with the knob shard_boundary = 0 the whole segments (1).  The kernels read the same numbers either way: every rank's poses and
+    cost trace are bit-identical between the two."""
+    monkeypatch.setenv("PGO_SYM", "1" if sym else "0")
     monkeypatch.setenv("PGO_BLOCK", "256")
     g = ds.manhattan_se3(3000, 15000, seed=9, loop_radius=6.0)      # (closures that reach across the shares: a few hundred boundary rows per rank)
     opt = dict(max_num_iterations=8, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2)
@@ -131,13 +133,15 @@ def test_boundary_exchange_carries_the_same_bits_as_whole_segments(gpu, ds, monk
     assert (owner[g.ia] != owner[g.ib]).sum() > 50
     a = _virtual_ranks(gpu, g, 4, opt)
     prob, _ = gpu.problem_from_graph(g)              # (one rank: nothing to exchange)
+    monkeypatch.delenv("PGO_SYM")
     prob.solver_begin(gpu.SolverOptions(**opt))
     assert prob.exchange_doubles() == 0
     prob.solver_end()
+    monkeypatch.setenv("PGO_SYM", "1" if sym else "0")
     knobs(shard_boundary=0)
     b = _virtual_ranks(gpu, g, 4, opt)
     for (sa, xa), (sb, xb) in zip(a, b):
-        assert sa.cg_exchange == 3 and sb.cg_exchange == 1 and sa.sym_form == 1 and sb.sym_form == 1
+        assert sa.cg_exchange == 3 and sb.cg_exchange == 1 and sa.sym_form == (1 if sym else 0) and sb.sym_form == sa.sym_form
         assert np.array_equal(xa, xb) and np.array_equal(sa.iterations["cost"], sb.iterations["cost"])
         assert list(sa.iterations["linear_solver_iterations"]) == list(sb.iterations["linear_solver_iterations"])
 
