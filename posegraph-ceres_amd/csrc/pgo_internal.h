@@ -459,7 +459,7 @@ struct pgo_problem {
   double sym_interior_fraction = 0.0;
   long long sym_stored_slots = 0;
   DevBuf<pgo::SymTile> sy_tile;
-  DevBuf<int> sy_xlist, sy_chunk_base, sy_chunk_n, sy_src, sy_diag, sy_xoff;
+  DevBuf<int> sy_xlist, sy_chunk_base, sy_chunk_n, sy_src, sy_diag, sy_xoff, sy_xbidx;
   // boundary exchange of the sharded owner-only CG (pgo_kernels.h DeviceGraph::bx): lists and buffers of this topology (prepare())
   bool bx_ready = false;
   int bx_cseg = 0, bx_nb = 0;

@@ -99,7 +99,7 @@ int sym_prepare(pgo_problem* P) {
   sg.tile = P->sy_tile.p; sg.xlist = P->sy_xlist.p; sg.chunk_base = P->sy_chunk_base.p; sg.chunk_n = P->sy_chunk_n.p;
   sg.meta = P->sy_meta.p; sg.rinfo = P->sy_rinfo.p; sg.src_slot = P->sy_src.p; sg.diag_slot = P->sy_diag.p;
   sg.val = P->sy_val.p;
-  sg.xoff = nullptr;
+  sg.xoff = nullptr; sg.xbidx = nullptr;
   if (P->g.world > 1 && P->bx_ready) {      // boundary exchange (prepare() made the lists): where every staged column of every tile lives
     const int rows_per = P->g.rows_per, rank = P->g.rank;
     std::vector<int> xoff(xlist.size());
@@ -110,7 +110,12 @@ int sym_prepare(pgo_problem* P) {
       else if (P->h_bpos[(size_t)v] >= 0) xoff[i] = -1 - (k * P->bx_cseg + 6 * P->h_bpos[(size_t)v]);
       else fits = false;          // (cannot happen: the far end of a cut edge is a boundary row of its rank)
     }
-    if (fits) { HIP_TRY(P->sy_xoff.upload(xoff, s)); sg.xoff = P->sy_xoff.p; }
+    if (fits) {
+      std::vector<int> xbidx(xlist.size(), -1);
+      for (size_t i = 0; i < xlist.size(); ++i) if (xlist[i] / rows_per == rank) xbidx[i] = P->h_bpos[(size_t)xlist[i]];
+      HIP_TRY(P->sy_xoff.upload(xoff, s)); sg.xoff = P->sy_xoff.p;
+      HIP_TRY(P->sy_xbidx.upload(xbidx, s)); sg.xbidx = P->sy_xbidx.p;
+    }
   }
   HIP_TRY(hipStreamSynchronize(s));
   lap("index uploads + sync");

@@ -56,6 +56,7 @@ struct SymGraph {
   // several ranks, boundary exchange (DeviceGraph::bx): xoff[i], parallel to xlist — where k_pipe_cg_sym finds m of that staged column:
   // >= 0 a double offset into pipe_buf (a row of this rank), < 0: -1 - (double offset into bx) (another rank's boundary row)
   const int* xoff;
+  const int* xbidx;      // parallel to xlist, for a tile's own rows: the row's index inside this rank's boundary segment (-1: not a boundary row)
 };
 
 // q = A p of a CG iteration (MODE 0: prologue, x = z + beta p, p_new, p'q partials — exactly k_spmv<0>'s contract) or plain

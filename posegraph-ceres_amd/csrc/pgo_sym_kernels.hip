@@ -405,6 +405,21 @@ __device__ __forceinline__ size_t sym_pipe_index(const DeviceGraph& g, int row) 
   return (size_t)rk * g.pipe_seg + (size_t)(row - rk * g.rows_per) * 6;
 }
 
+// "am I the last tile of this launch to get here?" — the fused stream's two-level ticket (pgo_uni_fused.h uni_f_last_arrival) on the same words
+// of g.flags: tile t bumps the counter of its class t % 8, the last of a class the top counter, the last of those resets the nine words.  One
+// lane calls it, behind its write-through stores.
+__device__ __forceinline__ bool sym_last_arrival(const DeviceGraph& g, int t, int n) {
+  const int cls = t & 7;
+  const int in_class = (n - cls + 7) >> 3;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (atomicAdd(&g.flags[4 + cls], 1) != in_class - 1) return false;
+  const int classes = min(n, 8);
+  if (atomicAdd(&g.flags[12], 1) != classes - 1) return false;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) g.flags[4 + k] = 0;
+  return true;
+}
+
 template <bool PACKED, int CL>
 __global__ __launch_bounds__(SYM_LANES) void k_pipe_cg_sym(DeviceGraph g, SymGraph sg, CgParams prm, int seq) {
   constexpr int NPAIR = PACKED ? BLK_PAIRS_PACKED : BLK_PAIRS_FULL;
@@ -558,6 +573,7 @@ __global__ __launch_bounds__(SYM_LANES) void k_pipe_cg_sym(DeviceGraph g, SymGra
   // the row lane's vectors are requested while the last chunks are multiplied (they depend on nothing the loop produces)
   const bool own = tid < T.nrows;
   const int pose = own ? sg.xlist[T.x0 + tid] : 0;
+  const int bxi = (own && g.world > 1 && g.bx[0]) ? sg.xbidx[T.x0 + tid] : -1;      // (boundary exchange: this row's place in the rank's segment)
   const size_t gj = 6 * (size_t)pose;
   double2 vr[3], vu[3], vw[3], vz[3], vq[3], vs[3], vp[3], vx[3], vb[3];
 #pragma unroll
@@ -671,9 +687,37 @@ __global__ __launch_bounds__(SYM_LANES) void k_pipe_cg_sym(DeviceGraph g, SymGra
     } else {
       double2* o = reinterpret_cast<double2*>(wr + pi);
       o[0] = double2{mn[0], mn[1]}; o[1] = double2{mn[2], mn[3]}; o[2] = double2{mn[4], mn[5]};
+      if (bxi >= 0) {        // boundary exchange: a boundary row goes straight into this rank's segment as well (no copying launch behind this one)
+        double2* ob = reinterpret_cast<double2*>(g.bx[ws] + (size_t)g.rank * g.bx_cseg + 6 * (size_t)bxi);
+        ob[0] = double2{mn[0], mn[1]}; ob[1] = double2{mn[2], mn[3]}; ob[2] = double2{mn[4], mn[5]};
+      }
     }
   }
   block_sum<3>(acc, scratch);
+  if (g.world > 1 && g.bx[0]) {
+    // boundary exchange: the LAST tile to get here folds every tile's three sums (tile order: the same bits whoever is last) into the
+    // end of this rank's segment — k_pipe_fold's job without its launch.  The partials travel as write-through stores in front of the
+    // ticket and are read with device-scope loads (pgo_uni_fused.h uni_f_last_arrival: the fused stream's protocol, its words of g.flags —
+    // a sharded session never runs that stream).
+    __shared__ int last_tile;
+    if (tid == 0) {
+      __hip_atomic_store(&g.part_rz[tile], acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&g.part_q[tile], acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&g.part_rr[tile], acc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_tile = sym_last_arrival(g, tile, sg.n_tiles) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last_tile) return;
+    double t3[3] = {0.0, 0.0, 0.0};
+    for (int i = tid; i < sg.n_tiles; i += SYM_LANES) {
+      t3[0] += __hip_atomic_load(&g.part_rz[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t3[1] += __hip_atomic_load(&g.part_q[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t3[2] += __hip_atomic_load(&g.part_rr[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    block_sum<3>(t3, scratch);
+    if (tid == 0) { double* pp = g.bx[ws] + (size_t)(g.rank + 1) * g.bx_cseg - 4; pp[0] = t3[0]; pp[1] = t3[1]; pp[2] = t3[2]; }
+    return;
+  }
   if (tid == 0) {       // one rank: row `ws` (the next launch folds it itself); several: row 0, folded by k_pipe_fold behind this launch
     const size_t at = (g.world == 1 ? (size_t)ws * g.n_part : 0) + tile;
     g.part_rz[at] = acc[0]; g.part_q[at] = acc[1]; g.part_rr[at] = acc[2];
@@ -754,7 +798,7 @@ void launch_pipe_cg_sym(const DeviceGraph& g, const SymGraph& sg, const CgParams
   // several ranks: the rank's three sums go into the exchange buffer(s) behind every launch.  One rank: the next launch folds the
   // partial triples itself; only the "stop test only" launch at the end of a batch (k_pipe_cg's, one work-group) wants them folded
   if (g.world == 1 && !fold) return;
-  if (g.world > 1 && g.bx[0]) { launch_pipe_pack(g, (seq & 1) ^ 1, seq, sg.n_tiles, s); return; }
+  if (g.world > 1 && g.bx[0]) return;      // (boundary exchange: the tiles stored their boundary rows into the segment themselves, the last one folded the sums)
   DeviceGraph gf = g;
   gf.n_wg = sg.n_tiles;         // the fold adds one entry per work-group of the producing launch
   if (g.world == 1) { const size_t off = (size_t)((seq & 1) ^ 1) * g.n_part; gf.part_rz += off; gf.part_q += off; gf.part_rr += off; }
