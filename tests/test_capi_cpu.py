@@ -111,6 +111,17 @@ def test_row_shard_cuts_balance_the_incidence_slots(pkg, ds):
         assert slots.max() / slots.mean() <= 1.03, (world, slots.max() / slots.mean())
         by_count = np.array([w[min(g.N, r * ((g.N + world - 1) // world)):min(g.N, (r + 1) * ((g.N + world - 1) // world))].sum() for r in range(world)], dtype=float)
         assert slots.max() <= by_count.max()
+        if world == 8:
+            # what the boundary exchange of the sharded CG carries (README): rows with an edge to another rank
+            owner = np.searchsorted(np.asarray(cut[1:]), np.arange(g.N), side="right")
+            crossing = owner[g.ia] != owner[g.ib]
+            bnd = np.zeros(g.N, bool)
+            bnd[g.ia[crossing]] = True
+            bnd[g.ib[crossing]] = True
+            most = max(int(bnd[cut[r]:cut[r + 1]].sum()) for r in range(world))
+            assert 0.02 < crossing.mean() < 0.04 and 0.04 < bnd.mean() < 0.07           # 2.9 % of the edges, 5.3 % of the rows
+            whole, boundary = world * (rp * 6 + 4) * 8, world * (((most + 1) & ~1) * 6 + 4) * 8
+            assert 5.6e6 < whole < 5.8e6 and 3.8e5 < boundary < 4.0e5                   # 5.69 MB against 0.39 MB per all-gather
     # degenerate inputs: more ranks than groups of four poses, no edges, one rank
     for n, world in ((0, 3), (1, 2), (7, 8), (300, 1)):
         cut, rp = pkg.row_shard_cuts(n, np.zeros(0, np.int32), np.zeros(0, np.int32), world)
