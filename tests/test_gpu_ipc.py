@@ -110,3 +110,37 @@ def test_processes_on_one_gpu_exchange_by_themselves(gpu, ds, tmp_path, world, m
         assert np.abs(k["poses"] - poses1).max() < 1e-6
     assert all(np.array_equal(res[0]["poses"], k["poses"]) for k in res)
     assert max(one.iterations["linear_solver_iterations"]) > 20
+
+
+def test_processes_with_the_staged_collective_exchange_boundary_rows(gpu, ds, tmp_path, monkeypatch):
+    """The IPC transport with its device-initiated exchange switched off (PGO_PEER_DIRECT=0): the per-iteration collective is the transport's
+    staged all-gather, and what it carries is the ranks' boundary rows (Summary::cg_exchange 3) — two processes on the box's one GPU
+    reproduce the in-process virtual ranks with the host-enqueued exchange bit for bit."""
+    world = 2
+    monkeypatch.setenv("PGO_BLOCK", "256")
+    g = ds.manhattan_se3(3001, 14000, seed=77, loop_radius=3.0)
+    opt = dict(max_num_iterations=8, linear_solver_type=gpu.BLOCK_JACOBI_PCG, pcg_cluster_poses=2)
+    monkeypatch.delenv("PGO_PEER_DIRECT", raising=False)
+    virt = _virtual_ranks(gpu, g, world, opt)
+    assert virt[0][0].cg_exchange == 3
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    name = "/pgo_ipc_test_staged_%d" % os.getpid()
+    env = dict(os.environ, PGO_ROOT=ROOT, WORLD_SIZE=str(world), PGO_IPC_NAME=name, PGO_OUT=str(tmp_path / "out"),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PGO_BLOCK="256", PGO_PEER_DIRECT="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(world)]
+    t0 = time.time()
+    try:
+        for p in procs:
+            p.wait(timeout=max(1, 300 - (time.time() - t0)))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert [p.returncode for p in procs] == [0] * world
+    for r in range(world):
+        k = np.load(str(tmp_path / "out") + ".%d.npz" % r)
+        assert int(k["cg_form"]) == 2 and int(k["cg_exchange"]) == 3
+        vs, vp = virt[r]
+        assert np.array_equal(k["cost"], vs.iterations["cost"]) and np.array_equal(k["poses"], vp)
+        assert np.array_equal(k["cg"], vs.iterations["linear_solver_iterations"])
